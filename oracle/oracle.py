@@ -1,0 +1,360 @@
+"""ctypes binding of the CPU ORACLE (oracle/_build/libmkhe_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product path (mkhe-kklss_amd/) never imports this module.
+
+The oracle restates the reference Go path (see oracle/ora_mkrlwe.h for file:line citations).
+PARITY UNPINNED vs Go: the reference ships no golden vectors and Go is not available.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libmkhe_oracle.so")
+
+u64p = C.POINTER(C.c_uint64)
+i32p = C.POINTER(C.c_int)
+pp = C.POINTER(C.c_void_p)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.ora_ring_new.restype = C.c_void_p
+        L.ora_ring_new.argtypes = [C.c_int, u64p, C.c_int, u64p]
+        L.ora_ring_free.argtypes = [C.c_void_p]
+        L.ora_ring_psi.restype = C.c_uint64
+        L.ora_ring_psi.argtypes = [C.c_void_p, C.c_int]
+        L.ora_ring_qinv.restype = C.c_uint64
+        L.ora_ring_qinv.argtypes = [C.c_void_p, C.c_int]
+        L.ora_ring_psi_table.restype = u64p
+        L.ora_ring_psi_table.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ora_primitive_root.restype = C.c_uint64
+        L.ora_primitive_root.argtypes = [C.c_uint64]
+        for name in ("ora_ntt", "ora_intt", "ora_intt_lazy", "ora_limb_mform", "ora_limb_invmform",
+                     "ora_limb_neg", "ora_limb_reduce"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int, u64p, u64p]
+        for name in ("ora_limb_mul", "ora_limb_mul_add", "ora_limb_mul_sub", "ora_limb_add", "ora_limb_sub"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]
+        L.ora_limb_mul_scalar.argtypes = [C.c_void_p, C.c_int, u64p, C.c_uint64, u64p]
+        L.ora_permute.argtypes = [C.c_void_p, C.c_int, C.c_uint64, u64p, u64p]
+        L.ora_div_round_last_many.argtypes = [C.c_void_p, C.c_int, C.c_int, u64p, u64p]
+        L.ora_fbe_new.restype = C.c_void_p
+        L.ora_fbe_new.argtypes = [C.c_void_p, C.c_void_p]
+        L.ora_fbe_free.argtypes = [C.c_void_p]
+        L.ora_fbe_modup_a2b.argtypes = [C.c_void_p, C.c_int, C.c_int, u64p, u64p]
+        L.ora_fbe_modup_b2a.argtypes = [C.c_void_p, C.c_int, C.c_int, u64p, u64p]
+        L.ora_fbe_moddown_ab2a.argtypes = [C.c_void_p, C.c_int, C.c_int, u64p, u64p, u64p]
+        L.ora_fbe_moddown_ab2b.argtypes = [C.c_void_p, C.c_int, C.c_int, u64p, u64p, u64p]
+        L.ora_ks_new.restype = C.c_void_p
+        L.ora_ks_new.argtypes = [C.c_int, u64p, C.c_int, u64p, C.c_int, C.c_int, u64p, u64p]
+        L.ora_ks_free.argtypes = [C.c_void_p]
+        L.ora_ks_alpha.argtypes = [C.c_void_p]
+        L.ora_ks_beta.argtypes = [C.c_void_p, C.c_int]
+        L.ora_ks_swk_words.restype = C.c_size_t
+        L.ora_ks_swk_words.argtypes = [C.c_void_p]
+        L.ora_ks_ringq.restype = C.c_void_p
+        L.ora_ks_ringq.argtypes = [C.c_void_p]
+        L.ora_ks_ringp.restype = C.c_void_p
+        L.ora_ks_ringp.argtypes = [C.c_void_p]
+        L.ora_decompose_and_split.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p, u64p, u64p]
+        L.ora_decompose.argtypes = [C.c_void_p, C.c_int, C.c_int, u64p, u64p]
+        L.ora_external_product.argtypes = [C.c_void_p, C.c_int, C.c_int, u64p, u64p, u64p]
+        L.ora_external_product_hoisted.argtypes = [C.c_void_p, C.c_int, u64p, u64p, u64p]
+        L.ora_mul_and_relin.argtypes = [C.c_void_p, C.c_int,
+                                        C.c_int, i32p, u64p, C.c_int,
+                                        C.c_int, i32p, u64p, C.c_int,
+                                        pp, pp, pp, pp, pp, u64p,
+                                        C.c_int, i32p, u64p]
+        L.ora_rotate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, i32p, u64p, C.c_int, pp, pp, u64p, u64p]
+        L.ora_conjugate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, i32p, u64p, C.c_int, pp, u64p, u64p]
+        L.ora_ckks_nb_rescales.restype = C.c_int
+        L.ora_ckks_nb_rescales.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def _u64arr(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+
+
+def _i32(x):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.int32))
+    return a, a.ctypes.data_as(i32p)
+
+
+def _ptrs(arrs, n):
+    """array of n void* from dict/list of numpy arrays (None -> NULL)."""
+    if arrs is None:
+        return None, None
+    T = C.c_void_p * n
+    keep = []
+    vals = []
+    for i in range(n):
+        a = arrs.get(i) if isinstance(arrs, dict) else (arrs[i] if i < len(arrs) else None)
+        if a is None:
+            vals.append(None)
+        else:
+            assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+            keep.append(a)
+            vals.append(a.ctypes.data)
+    return T(*vals), keep
+
+
+class Ring:
+    """lattigo ring.Ring restated (N, moduli, NTT tables)."""
+
+    def __init__(self, logN, moduli, psi=None, _handle=None, _owner=None):
+        self.logN, self.N = logN, 1 << logN
+        self.moduli = [int(q) for q in moduli]
+        self._owner = _owner
+        if _handle is not None:
+            self.h = _handle
+            self._own = False
+        else:
+            m = _u64arr(self.moduli)
+            ps = _u64arr(psi) if psi is not None else None
+            self.h = lib().ora_ring_new(logN, _p(m), len(self.moduli), _p(ps) if ps is not None else None)
+            self._own = True
+            if not self.h:
+                raise ValueError("ora_ring_new failed")
+
+    def __del__(self):
+        if getattr(self, "_own", False) and self.h:
+            lib().ora_ring_free(self.h)
+            self.h = None
+
+    def psi(self, i):
+        return int(lib().ora_ring_psi(self.h, i))
+
+    def psi_table(self, i, inverse=False):
+        ptr = lib().ora_ring_psi_table(self.h, i, 1 if inverse else 0)
+        return np.ctypeslib.as_array(ptr, shape=(self.N,)).copy()
+
+    def _un(self, fn, i, a):
+        a = _u64arr(a)
+        z = np.empty_like(a)
+        getattr(lib(), fn)(self.h, i, _p(a), _p(z))
+        return z
+
+    def _bin(self, fn, i, a, b):
+        a, b = _u64arr(a), _u64arr(b)
+        z = np.empty_like(a)
+        getattr(lib(), fn)(self.h, i, _p(a), _p(b), _p(z))
+        return z
+
+    def ntt(self, i, a): return self._un("ora_ntt", i, a)
+    def intt(self, i, a): return self._un("ora_intt", i, a)
+    def intt_lazy(self, i, a): return self._un("ora_intt_lazy", i, a)
+    def mform(self, i, a): return self._un("ora_limb_mform", i, a)
+    def invmform(self, i, a): return self._un("ora_limb_invmform", i, a)
+    def neg(self, i, a): return self._un("ora_limb_neg", i, a)
+    def reduce(self, i, a): return self._un("ora_limb_reduce", i, a)
+    def mul(self, i, a, b): return self._bin("ora_limb_mul", i, a, b)
+    def add(self, i, a, b): return self._bin("ora_limb_add", i, a, b)
+    def sub(self, i, a, b): return self._bin("ora_limb_sub", i, a, b)
+
+    def mul_add(self, i, a, b, z):
+        a, b = _u64arr(a), _u64arr(b)
+        z = _u64arr(z).copy()
+        lib().ora_limb_mul_add(self.h, i, _p(a), _p(b), _p(z))
+        return z
+
+    def mul_sub(self, i, a, b, z):
+        a, b = _u64arr(a), _u64arr(b)
+        z = _u64arr(z).copy()
+        lib().ora_limb_mul_sub(self.h, i, _p(a), _p(b), _p(z))
+        return z
+
+    def mul_scalar(self, i, a, s):
+        a = _u64arr(a)
+        z = np.empty_like(a)
+        lib().ora_limb_mul_scalar(self.h, i, _p(a), int(s), _p(z))
+        return z
+
+    # poly level ([level+1][N])
+    def ntt_poly(self, p):
+        return np.stack([self.ntt(i, p[i]) for i in range(p.shape[0])])
+
+    def intt_poly(self, p):
+        return np.stack([self.intt(i, p[i]) for i in range(p.shape[0])])
+
+    def permute(self, galEl, p):
+        p = _u64arr(p)
+        out = np.empty_like(p)
+        lib().ora_permute(self.h, p.shape[0] - 1, int(galEl), _p(p), _p(out))
+        return out
+
+    def div_round_last_many(self, p, nb):
+        """returns (out[level+1-nb][N], mutated_in)"""
+        p = _u64arr(p).copy()
+        level = p.shape[0] - 1
+        out = np.zeros_like(p)
+        lib().ora_div_round_last_many(self.h, level, nb, _p(p), _p(out))
+        return out[: level + 1 - nb].copy(), p
+
+
+class BasisExtender:
+    """mkrlwe.FastBasisExtender between ring A and ring B."""
+
+    def __init__(self, ra, rb):
+        self.ra, self.rb = ra, rb
+        self.h = lib().ora_fbe_new(ra.h, rb.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ora_fbe_free(self.h)
+            self.h = None
+
+    def modup_a2b(self, pa, levelB=None):
+        pa = _u64arr(pa)
+        levelB = self.rb_level(levelB)
+        out = np.empty((levelB + 1, self.ra.N), dtype=np.uint64)
+        lib().ora_fbe_modup_a2b(self.h, pa.shape[0] - 1, levelB, _p(pa), _p(out))
+        return out
+
+    def modup_b2a(self, pb, levelA=None):
+        pb = _u64arr(pb)
+        levelA = len(self.ra.moduli) - 1 if levelA is None else levelA
+        out = np.empty((levelA + 1, self.ra.N), dtype=np.uint64)
+        lib().ora_fbe_modup_b2a(self.h, pb.shape[0] - 1, levelA, _p(pb), _p(out))
+        return out
+
+    def rb_level(self, l):
+        return len(self.rb.moduli) - 1 if l is None else l
+
+    def moddown_ab2a(self, pa, pb):
+        pa, pb = _u64arr(pa), _u64arr(pb)
+        out = np.empty_like(pa)
+        lib().ora_fbe_moddown_ab2a(self.h, pa.shape[0] - 1, pb.shape[0] - 1, _p(pa), _p(pb), _p(out))
+        return out
+
+    def moddown_ab2b(self, pa, pb):
+        pa, pb = _u64arr(pa), _u64arr(pb)
+        out = np.empty_like(pb)
+        lib().ora_fbe_moddown_ab2b(self.h, pa.shape[0] - 1, pb.shape[0] - 1, _p(pa), _p(pb), _p(out))
+        return out
+
+
+class KeySwitcher:
+    """mkrlwe.KeySwitcher restated.  Switching keys are uint64[betaMax][nQ+nP][N]."""
+
+    def __init__(self, logN, Q, P, gamma=2, psiQ=None, psiP=None):
+        self.logN, self.N = logN, 1 << logN
+        self.Q, self.P, self.gamma = [int(q) for q in Q], [int(p) for p in P], gamma
+        q, p = _u64arr(self.Q), _u64arr(self.P)
+        pq = _u64arr(psiQ) if psiQ is not None else None
+        ppp = _u64arr(psiP) if psiP is not None else None
+        self.h = lib().ora_ks_new(logN, _p(q), len(self.Q), _p(p), len(self.P), gamma,
+                                  _p(pq) if pq is not None else None, _p(ppp) if ppp is not None else None)
+        if not self.h:
+            raise ValueError("ora_ks_new failed")
+        self.alpha = lib().ora_ks_alpha(self.h)
+        self.beta_max = lib().ora_ks_beta(self.h, len(self.Q) - 1)
+        self.ringQ = Ring(logN, self.Q, _handle=lib().ora_ks_ringq(self.h), _owner=self)
+        self.ringP = Ring(logN, self.P, _handle=lib().ora_ks_ringp(self.h), _owner=self)
+        self.m = len(self.Q) + len(self.P)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ora_ks_free(self.h)
+            self.h = None
+
+    def beta(self, level):
+        return lib().ora_ks_beta(self.h, level)
+
+    def new_swk(self):
+        return np.zeros((self.beta_max, self.m, self.N), dtype=np.uint64)
+
+    def decompose_and_split(self, level, digit, a):
+        a = _u64arr(a)
+        outq = np.zeros((len(self.Q), self.N), dtype=np.uint64)
+        outp = np.zeros((len(self.P), self.N), dtype=np.uint64)
+        lib().ora_decompose_and_split(self.h, level, len(self.P) - 1, self.alpha, digit, self.gamma,
+                                      _p(a), _p(outq), _p(outp))
+        return outq[: level + 1], outp
+
+    def decompose(self, level, a, is_ntt=False):
+        a = _u64arr(a)
+        ad = self.new_swk()
+        lib().ora_decompose(self.h, level, 1 if is_ntt else 0, _p(a), _p(ad))
+        return ad
+
+    def external_product(self, level, a, bg, is_ntt=False):
+        a, bg = _u64arr(a), _u64arr(bg)
+        c = np.empty((level + 1, self.N), dtype=np.uint64)
+        lib().ora_external_product(self.h, level, 1 if is_ntt else 0, _p(a), _p(bg), _p(c))
+        return c
+
+    def external_product_hoisted(self, level, ah, bg):
+        ah, bg = _u64arr(ah), _u64arr(bg)
+        c = np.empty((level + 1, self.N), dtype=np.uint64)
+        lib().ora_external_product_hoisted(self.h, level, _p(ah), _p(bg), _p(c))
+        return c
+
+    def mul_and_relin(self, level, ids0, op0, ids1, op1, rlk, crs_u, hoist0=None, hoist1=None):
+        """op0/op1: uint64[1+n][limbs][N]; rlk: {id: (b, d, v)}; hoist*: {id: swk} or None.
+        Returns (ids_out, out[1+nout][level+1][N])."""
+        op0, op1, crs_u = _u64arr(op0), _u64arr(op1), _u64arr(crs_u)
+        ids_out = sorted(set(ids0) | set(ids1))
+        npar = max(ids_out) + 1
+        out = np.zeros((1 + len(ids_out), level + 1, self.N), dtype=np.uint64)
+        a0, p0 = _i32(ids0)
+        a1, p1 = _i32(ids1)
+        ao, po = _i32(ids_out)
+        rb, k1 = _ptrs({i: rlk[i][0] for i in rlk}, npar)
+        rd, k2 = _ptrs({i: rlk[i][1] for i in rlk}, npar)
+        rv, k3 = _ptrs({i: rlk[i][2] for i in rlk}, npar)
+        h0, k4 = _ptrs(hoist0, npar)
+        h1, k5 = _ptrs(hoist1, npar)
+        lib().ora_mul_and_relin(self.h, level, len(ids0), p0, _p(op0), op0.shape[1],
+                                len(ids1), p1, _p(op1), op1.shape[1],
+                                h0, h1, rb, rd, rv, _p(crs_u), len(ids_out), po, _p(out))
+        return ids_out, out
+
+    def rotate(self, level, galEl, ids, ct, rk, crs, hoist=None):
+        """rk, hoist: lists aligned with ids."""
+        ct, crs = _u64arr(ct), _u64arr(crs)
+        out = np.zeros((1 + len(ids), level + 1, self.N), dtype=np.uint64)
+        a, p = _i32(ids)
+        rkp, k1 = _ptrs(list(rk), len(ids))
+        hp, k2 = _ptrs(list(hoist) if hoist is not None else None, len(ids))
+        lib().ora_rotate(self.h, level, int(galEl), len(ids), p, _p(ct), ct.shape[1], hp, rkp, _p(crs), _p(out))
+        return out
+
+    def conjugate(self, level, galEl, ids, ct, ck, crs):
+        ct, crs = _u64arr(ct), _u64arr(crs)
+        out = np.zeros((1 + len(ids), level + 1, self.N), dtype=np.uint64)
+        a, p = _i32(ids)
+        ckp, k1 = _ptrs(list(ck), len(ids))
+        lib().ora_conjugate(self.h, level, int(galEl), len(ids), p, _p(ct), ct.shape[1], ckp, _p(crs), _p(out))
+        return out
+
+    def ckks_nb_rescales(self, level, scale, min_scale):
+        s = C.c_double(scale)
+        nb = lib().ora_ckks_nb_rescales(self.ringQ.h, level, C.byref(s), float(min_scale))
+        return nb, s.value
