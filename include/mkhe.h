@@ -1,0 +1,120 @@
+/* mkhe.h -- C ABI of the MI355X multi-key RLWE key-switch engine (libmkhe_hip.so).
+ *
+ * Drop-in boundary for the hot path of SNUCP/MKHE-KKLSS (pure Go + lattigo v2.3.0).  The
+ * reference has no FFI; the boundary is the method set of mkrlwe.KeySwitcher plus the lattigo
+ * helpers it calls.  Every entry point cites the reference interface it
+ * replaces as <file>:<line> relative to the reference root.  The cgo stubs a maintainer would
+ * add are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C: opaque handles, pointers and sizes only.  All polynomial data is uint64, limb-major.
+ *  - SwitchingKey / hoisted digit vector : uint64[betaMax][nQ+nP][N]  (Q limbs then P limbs),
+ *    stored exactly as the Go side stores it: NTT domain, Montgomery form for keys and CRS
+ *    (mkrlwe/params.go:56, keygen.go:299-300), NTT domain non-Montgomery for hoisted digits.
+ *  - Ciphertext : uint64[1+n][limbs][N], slot 0 = Value["0"], slot 1+i = Value[ids[i]]
+ *    (mkrlwe/elements.go:17-19); coefficient domain.  level = limbs-1.
+ *  - Party ids are arbitrary ints chosen by the caller (the shim maps Go's string ids).
+ *  - Return value 0 = ok; non-zero = error, text via mkhe_last_error() (the reference panics
+ *    at the same sites: keyswitch.go:126-132, keys.go:151-162,190-198; the shim re-panics).
+ *  - One context per Evaluator, calls on a context serialized by the caller (the reference is
+ *    not reentrant either: shared pools keyswitch.go:12-15).  All work is enqueued on the
+ *    context's HIP stream; *_download and mkhe_ctx_sync synchronize.
+ */
+#ifndef MKHE_H
+#define MKHE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mkhe_ctx mkhe_ctx;
+typedef struct mkhe_swk mkhe_swk;
+typedef struct mkhe_ct  mkhe_ct;
+
+const char* mkhe_last_error(void);
+int mkhe_device_count(void);
+
+/* ---- context: mkrlwe.NewKeySwitcher keyswitch.go:33-47 (+ NewDecomposer basis_extension.go:368,
+ *      lattigo rlwe.NewKeySwitcher / ring.NewRing tables).  psiQ/psiP: optional primitive 2N-th
+ *      roots (plain) per modulus, e.g. InvMForm(ring.NttPsi[i][N/2]); NULL = lattigo's own rule. */
+int  mkhe_ctx_create(mkhe_ctx** out, int logN, const uint64_t* Q, int nQ, const uint64_t* P, int nP,
+                     int gamma, const uint64_t* psiQ, const uint64_t* psiP, int device);
+void mkhe_ctx_destroy(mkhe_ctx* ctx);
+int  mkhe_ctx_sync(mkhe_ctx* ctx);
+int  mkhe_ctx_alpha(const mkhe_ctx* ctx);                 /* Parameters.Alpha  params.go:63-65 */
+int  mkhe_ctx_beta(const mkhe_ctx* ctx, int level);       /* Parameters.Beta   params.go:67-71 */
+int  mkhe_ctx_n(const mkhe_ctx* ctx);
+size_t mkhe_ctx_swk_words(const mkhe_ctx* ctx);           /* betaMax*(nQ+nP)*N */
+uint64_t mkhe_ctx_psi(const mkhe_ctx* ctx, int modulus_index);   /* root in use (Q then P) */
+void* mkhe_ctx_stream(mkhe_ctx* ctx);                     /* hipStream_t, for event timing */
+
+/* ---- SwitchingKey handles: mkrlwe.SwitchingKey keys.go:23-25, NewSwitchingKey keys.go:245-255 */
+int  mkhe_swk_create(mkhe_ctx* ctx, mkhe_swk** out);
+void mkhe_swk_destroy(mkhe_ctx* ctx, mkhe_swk* swk);
+int  mkhe_swk_upload(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* host);
+/* Go's []rlwe.PolyQP: one pointer per limb, order [digit][Q limbs..., P limbs...] */
+int  mkhe_swk_upload_limbs(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* const* limbs, int ndigits);
+int  mkhe_swk_download(mkhe_ctx* ctx, const mkhe_swk* swk, uint64_t* host);
+void* mkhe_swk_devptr(mkhe_swk* swk);
+
+/* ---- Ciphertext handles: mkrlwe.Ciphertext elements.go:17-33 */
+int  mkhe_ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, mkhe_ct** out);
+void mkhe_ct_destroy(mkhe_ctx* ctx, mkhe_ct* ct);
+int  mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host);
+int  mkhe_ct_upload_poly_limbs(mkhe_ctx* ctx, mkhe_ct* ct, int slot, const uint64_t* const* limbs);
+int  mkhe_ct_download(mkhe_ctx* ctx, const mkhe_ct* ct, uint64_t* host);
+int  mkhe_ct_download_poly_limbs(mkhe_ctx* ctx, const mkhe_ct* ct, int slot, uint64_t* const* limbs);
+int  mkhe_ct_limbs(const mkhe_ct* ct);
+int  mkhe_ct_nparties(const mkhe_ct* ct);
+void* mkhe_ct_devptr(mkhe_ct* ct);
+
+/* ---- raw device buffers of uint64 words (callers that keep polynomials resident themselves) */
+int  mkhe_buf_alloc(mkhe_ctx* ctx, size_t words, void** dev_out);
+void mkhe_buf_free(mkhe_ctx* ctx, void* dev);
+int  mkhe_buf_upload(mkhe_ctx* ctx, void* dev, const uint64_t* host, size_t words);
+int  mkhe_buf_download(mkhe_ctx* ctx, const void* dev, uint64_t* host, size_t words);
+
+/* ---- lattigo ring.NTTLvl / InvNTTLvl / InvNTTLazyLvl on a raw device buffer [count][limbs][N];
+ *      limb l uses modulus index mod_base+l (0..nQ-1 = Q, nQ.. = P).  keyswitch.go:29-30,58,114-115 */
+int  mkhe_ntt(mkhe_ctx* ctx, const void* dev_src, void* dev_dst, int count, int limbs, int mod_base, int inverse, int lazy);
+
+/* ---- KeySwitcher.Decompose keyswitch.go:49-73 (DecomposeSingleNTT :21-31, DecomposeAndSplit
+ *      basis_extension.go:428-535).  Input poly = slot `slot` of ct; is_ntt mirrors ring.Poly.IsNTT. */
+int  mkhe_decompose(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* ct, int slot, mkhe_swk* out);
+
+/* ---- KeySwitcher.ExternalProduct keyswitch.go:79-118 / ExternalProductHoisted keyswitch_hoisted.go:10-40.
+ *      Result (coefficient domain, canonical) is written to slot out_slot of out. */
+int  mkhe_external_product(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* a, int slot,
+                           const mkhe_swk* bg, mkhe_ct* out, int out_slot);
+int  mkhe_external_product_hoisted(mkhe_ctx* ctx, int level, const mkhe_swk* a_hoisted,
+                                   const mkhe_swk* bg, mkhe_ct* out, int out_slot);
+
+/* ---- KeySwitcher.MulAndRelin keyswitch.go:122-230 / MulAndRelinHoisted keyswitch_hoisted.go:44-179.
+ *      hoist0/hoist1: per-party hoisted forms aligned with op0/op1 ids, or NULL (engine hoists
+ *      internally = mkckks.Evaluator.MulRelinNew evaluator.go:416-443).
+ *      rlk_d0, rlk_v0 aligned with op0 ids (rlk.Value[1], Value[2]); rlk_b1 aligned with op1 ids
+ *      (rlk.Value[0]) keys.go:34-37;  crs_u = params.CRS[-1] params.go:37.
+ *      level is taken from out (keyswitch_hoisted.go:46); out ids must be the union. */
+int  mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                        const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
+                        const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
+                        const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out);
+
+/* ---- KeySwitcher.Rotate keyswitch.go:234-298 / RotateHoisted keyswitch_hoisted.go:183-247.
+ *      galEl = 5^rotidx mod 2N; rk aligned with ct ids (rkSet[id][rotidx]); crs = params.CRS[rotidx]. */
+int  mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* hoist,
+                 const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* out);
+/* ---- KeySwitcher.Conjugate keyswitch.go:302-332; galEl = 2N-1, crs = params.CRS[-2] */
+int  mkhe_conjugate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* ck,
+                    const mkhe_swk* crs, mkhe_ct* out);
+
+/* ---- body of mkckks.Evaluator.Rescale evaluator.go:385-391 = lattigo
+ *      ring.DivRoundByLastModulusManyLvl on every poly; out has limbs(in)-nb limbs. */
+int  mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

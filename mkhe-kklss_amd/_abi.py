@@ -1,0 +1,88 @@
+"""ctypes binding of include/mkhe.h (libmkhe_hip.so).  Fails loudly when the HIP library is absent."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmkhe_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+i32p = C.POINTER(C.c_int)
+vp = C.c_void_p
+vpp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/mkhe.h declaration by declaration
+SIGNATURES = {
+    "mkhe_last_error": (C.c_char_p, []),
+    "mkhe_device_count": (C.c_int, []),
+    "mkhe_ctx_create": (C.c_int, [vpp, C.c_int, u64p, C.c_int, u64p, C.c_int, C.c_int, u64p, u64p, C.c_int]),
+    "mkhe_ctx_destroy": (None, [vp]),
+    "mkhe_ctx_sync": (C.c_int, [vp]),
+    "mkhe_ctx_alpha": (C.c_int, [vp]),
+    "mkhe_ctx_beta": (C.c_int, [vp, C.c_int]),
+    "mkhe_ctx_n": (C.c_int, [vp]),
+    "mkhe_ctx_swk_words": (C.c_size_t, [vp]),
+    "mkhe_ctx_psi": (C.c_uint64, [vp, C.c_int]),
+    "mkhe_ctx_stream": (vp, [vp]),
+    "mkhe_swk_create": (C.c_int, [vp, vpp]),
+    "mkhe_swk_destroy": (None, [vp, vp]),
+    "mkhe_swk_upload": (C.c_int, [vp, vp, u64p]),
+    "mkhe_swk_upload_limbs": (C.c_int, [vp, vp, vpp, C.c_int]),
+    "mkhe_swk_download": (C.c_int, [vp, vp, u64p]),
+    "mkhe_swk_devptr": (vp, [vp]),
+    "mkhe_ct_create": (C.c_int, [vp, C.c_int, i32p, C.c_int, vpp]),
+    "mkhe_ct_destroy": (None, [vp, vp]),
+    "mkhe_ct_upload": (C.c_int, [vp, vp, u64p]),
+    "mkhe_ct_upload_poly_limbs": (C.c_int, [vp, vp, C.c_int, vpp]),
+    "mkhe_ct_download": (C.c_int, [vp, vp, u64p]),
+    "mkhe_ct_download_poly_limbs": (C.c_int, [vp, vp, C.c_int, vpp]),
+    "mkhe_ct_limbs": (C.c_int, [vp]),
+    "mkhe_ct_nparties": (C.c_int, [vp]),
+    "mkhe_ct_devptr": (vp, [vp]),
+    "mkhe_buf_alloc": (C.c_int, [vp, C.c_size_t, vpp]),
+    "mkhe_buf_free": (None, [vp, vp]),
+    "mkhe_buf_upload": (C.c_int, [vp, vp, u64p, C.c_size_t]),
+    "mkhe_buf_download": (C.c_int, [vp, vp, u64p, C.c_size_t]),
+    "mkhe_ntt": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mkhe_decompose": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "mkhe_external_product": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int]),
+    "mkhe_external_product_hoisted": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int]),
+    "mkhe_mul_and_relin": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),
+    "mkhe_rotate": (C.c_int, [vp, C.c_uint64, vp, vpp, vpp, vp, vp]),
+    "mkhe_conjugate": (C.c_int, [vp, C.c_uint64, vp, vpp, vp, vp]),
+    "mkhe_rescale": (C.c_int, [vp, vp, C.c_int, vp]),
+}
+
+
+class MkheError(RuntimeError):
+    """Raised where the reference panics / returns an error."""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "mkhe_kklss_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)          # AttributeError if the library does not export it
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MkheError(lib().mkhe_last_error().decode())
+
+
+def handle_array(handles):
+    """list of handles (or None) -> (void*)[]; None list -> NULL"""
+    if handles is None:
+        return None
+    return (C.c_void_p * max(len(handles), 1))(*[h for h in handles])

@@ -1,0 +1,241 @@
+// capi.hip -- extern "C" boundary (include/mkhe.h) over mkhe::Context.
+#include "../../include/mkhe.h"
+#include "engine.h"
+#include <string>
+#include <vector>
+
+using namespace mkhe;
+
+struct mkhe_ctx { Context* c; };
+struct mkhe_swk { Swk s; };
+struct mkhe_ct { Ct c; };
+
+static thread_local std::string g_err;
+
+#define MKHE_TRY(body) try { body; return 0; } \
+    catch (const std::exception& e) { g_err = e.what(); return 1; } \
+    catch (...) { g_err = "mkhe: unknown error"; return 1; }
+
+static std::vector<const Swk*> swk_list(const mkhe_swk* const* v, int n) {
+    std::vector<const Swk*> r;
+    if (!v) return r;
+    r.resize(n);
+    for (int i = 0; i < n; ++i) r[i] = v[i] ? &v[i]->s : nullptr;
+    return r;
+}
+
+extern "C" {
+
+const char* mkhe_last_error(void) { return g_err.c_str(); }
+
+int mkhe_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int mkhe_ctx_create(mkhe_ctx** out, int logN, const uint64_t* Q, int nQ, const uint64_t* P, int nP,
+                    int gamma, const uint64_t* psiQ, const uint64_t* psiP, int device) {
+    MKHE_TRY({
+        if (!out || !Q || !P) throw Error("mkhe_ctx_create: null argument");
+        *out = new mkhe_ctx{new Context(logN, Q, nQ, P, nP, gamma, psiQ, psiP, device)};
+    })
+}
+void mkhe_ctx_destroy(mkhe_ctx* ctx) { if (ctx) { delete ctx->c; delete ctx; } }
+int mkhe_ctx_sync(mkhe_ctx* ctx) { MKHE_TRY(ctx->c->sync()) }
+int mkhe_ctx_alpha(const mkhe_ctx* ctx) { return ctx->c->alpha; }
+int mkhe_ctx_beta(const mkhe_ctx* ctx, int level) { return ctx->c->beta(level); }
+int mkhe_ctx_n(const mkhe_ctx* ctx) { return ctx->c->N; }
+size_t mkhe_ctx_swk_words(const mkhe_ctx* ctx) { return ctx->c->swk_words(); }
+uint64_t mkhe_ctx_psi(const mkhe_ctx* ctx, int i) { return (i >= 0 && i < ctx->c->mtot) ? ctx->c->psi_plain[i] : 0; }
+void* mkhe_ctx_stream(mkhe_ctx* ctx) { return (void*)ctx->c->stream; }
+
+// ---- switching keys
+int mkhe_swk_create(mkhe_ctx* ctx, mkhe_swk** out) {
+    MKHE_TRY({
+        Context* c = ctx->c;
+        MKHE_HIP(hipSetDevice(c->device));
+        mkhe_swk* s = new mkhe_swk();
+        hipError_t e = hipMalloc(&s->s.d, c->swk_words() * sizeof(u64));
+        if (e != hipSuccess) { delete s; throw Error(std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        MKHE_HIP(hipMemsetAsync(s->s.d, 0, c->swk_words() * sizeof(u64), c->stream));
+        *out = s;
+    })
+}
+void mkhe_swk_destroy(mkhe_ctx* ctx, mkhe_swk* swk) {
+    if (!swk) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->c->stream);
+    if (swk->s.d && swk->s.owned) (void)hipFree(swk->s.d);
+    delete swk;
+}
+int mkhe_swk_upload(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* host) {
+    MKHE_TRY({
+        Context* c = ctx->c;
+        MKHE_HIP(hipMemcpyAsync(swk->s.d, host, c->swk_words() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        c->sync();
+    })
+}
+int mkhe_swk_upload_limbs(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* const* limbs, int ndigits) {
+    MKHE_TRY({
+        Context* c = ctx->c;
+        if (ndigits < 0 || ndigits > c->beta_max) throw Error("mkhe_swk_upload_limbs: bad digit count");
+        for (int i = 0; i < ndigits * c->mtot; ++i)
+            MKHE_HIP(hipMemcpyAsync(swk->s.d + (size_t)i * c->N, limbs[i], (size_t)c->N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        c->sync();
+    })
+}
+int mkhe_swk_download(mkhe_ctx* ctx, const mkhe_swk* swk, uint64_t* host) {
+    MKHE_TRY({
+        Context* c = ctx->c;
+        MKHE_HIP(hipMemcpyAsync(host, swk->s.d, c->swk_words() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+    })
+}
+void* mkhe_swk_devptr(mkhe_swk* swk) { return swk ? swk->s.d : nullptr; }
+
+// ---- ciphertexts
+int mkhe_ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, mkhe_ct** out) {
+    MKHE_TRY({
+        Context* c = ctx->c;
+        if (n < 0 || n > 32 || limbs < 1 || limbs > c->nq) throw Error("mkhe_ct_create: bad shape");
+        MKHE_HIP(hipSetDevice(c->device));
+        mkhe_ct* t = new mkhe_ct();
+        t->c.n = n; t->c.limbs = limbs; t->c.ids.assign(ids, ids + n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (ids[i] == ids[j]) { delete t; throw Error("mkhe_ct_create: repeated id"); }
+        const size_t w = (size_t)(1 + n) * limbs * c->N;
+        hipError_t e = hipMalloc(&t->c.d, w * sizeof(u64));
+        if (e != hipSuccess) { delete t; throw Error(std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        MKHE_HIP(hipMemsetAsync(t->c.d, 0, w * sizeof(u64), c->stream));
+        *out = t;
+    })
+}
+void mkhe_ct_destroy(mkhe_ctx* ctx, mkhe_ct* ct) {
+    if (!ct) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->c->stream);
+    if (ct->c.d) (void)hipFree(ct->c.d);
+    delete ct;
+}
+int mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host) {
+    MKHE_TRY({
+        Context* c = ctx->c;
+        const size_t w = (size_t)(1 + ct->c.n) * ct->c.limbs * c->N;
+        MKHE_HIP(hipMemcpyAsync(ct->c.d, host, w * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        c->sync();
+    })
+}
+int mkhe_ct_upload_poly_limbs(mkhe_ctx* ctx, mkhe_ct* ct, int slot, const uint64_t* const* limbs) {
+    MKHE_TRY({
+        Context* c = ctx->c;
+        if (slot < 0 || slot > ct->c.n) throw Error("mkhe_ct_upload_poly_limbs: bad slot");
+        for (int l = 0; l < ct->c.limbs; ++l)
+            MKHE_HIP(hipMemcpyAsync(ct->c.d + ((size_t)slot * ct->c.limbs + l) * c->N, limbs[l], (size_t)c->N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        c->sync();
+    })
+}
+int mkhe_ct_download(mkhe_ctx* ctx, const mkhe_ct* ct, uint64_t* host) {
+    MKHE_TRY({
+        Context* c = ctx->c;
+        const size_t w = (size_t)(1 + ct->c.n) * ct->c.limbs * c->N;
+        MKHE_HIP(hipMemcpyAsync(host, ct->c.d, w * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+    })
+}
+int mkhe_ct_download_poly_limbs(mkhe_ctx* ctx, const mkhe_ct* ct, int slot, uint64_t* const* limbs) {
+    MKHE_TRY({
+        Context* c = ctx->c;
+        if (slot < 0 || slot > ct->c.n) throw Error("mkhe_ct_download_poly_limbs: bad slot");
+        for (int l = 0; l < ct->c.limbs; ++l)
+            MKHE_HIP(hipMemcpyAsync(limbs[l], ct->c.d + ((size_t)slot * ct->c.limbs + l) * c->N, (size_t)c->N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+    })
+}
+int mkhe_ct_limbs(const mkhe_ct* ct) { return ct->c.limbs; }
+int mkhe_ct_nparties(const mkhe_ct* ct) { return ct->c.n; }
+void* mkhe_ct_devptr(mkhe_ct* ct) { return ct ? ct->c.d : nullptr; }
+
+// ---- raw buffers
+int mkhe_buf_alloc(mkhe_ctx* ctx, size_t words, void** dev_out) {
+    MKHE_TRY({
+        MKHE_HIP(hipSetDevice(ctx->c->device));
+        void* d = nullptr;
+        MKHE_HIP(hipMalloc(&d, (words ? words : 1) * sizeof(u64)));
+        *dev_out = d;
+    })
+}
+void mkhe_buf_free(mkhe_ctx* ctx, void* dev) {
+    if (!dev) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->c->stream);
+    (void)hipFree(dev);
+}
+int mkhe_buf_upload(mkhe_ctx* ctx, void* dev, const uint64_t* host, size_t words) {
+    MKHE_TRY({
+        MKHE_HIP(hipMemcpyAsync(dev, host, words * sizeof(u64), hipMemcpyHostToDevice, ctx->c->stream));
+        ctx->c->sync();
+    })
+}
+int mkhe_buf_download(mkhe_ctx* ctx, const void* dev, uint64_t* host, size_t words) {
+    MKHE_TRY({
+        MKHE_HIP(hipMemcpyAsync(host, dev, words * sizeof(u64), hipMemcpyDeviceToHost, ctx->c->stream));
+        ctx->c->sync();
+    })
+}
+
+// ---- ring level
+int mkhe_ntt(mkhe_ctx* ctx, const void* src, void* dst, int count, int limbs, int mod_base, int inverse, int lazy) {
+    MKHE_TRY(ctx->c->ntt((const u64*)src, (u64*)dst, count, limbs, mod_base, inverse != 0, lazy != 0))
+}
+
+// ---- KeySwitcher
+static const u64* ct_slot(const Context* c, const mkhe_ct* ct, int slot, int level) {
+    if (slot < 0 || slot > ct->c.n) throw Error("mkhe: bad ciphertext slot");
+    if (ct->c.limbs < level + 1) throw Error("mkhe: ciphertext level below requested level");
+    return ct->c.d + (size_t)slot * ct->c.limbs * c->N;
+}
+int mkhe_decompose(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* ct, int slot, mkhe_swk* out) {
+    MKHE_TRY(ctx->c->decompose(level, is_ntt != 0, ct_slot(ctx->c, ct, slot, level), out->s.d))
+}
+int mkhe_external_product(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* a, int slot,
+                          const mkhe_swk* bg, mkhe_ct* out, int out_slot) {
+    MKHE_TRY({
+        if (out->c.limbs != level + 1) throw Error("mkhe_external_product: out must have level+1 limbs");
+        ctx->c->external_product(level, is_ntt != 0, ct_slot(ctx->c, a, slot, level), bg->s.d,
+                                 const_cast<u64*>(ct_slot(ctx->c, out, out_slot, level)), false);
+    })
+}
+int mkhe_external_product_hoisted(mkhe_ctx* ctx, int level, const mkhe_swk* ah, const mkhe_swk* bg, mkhe_ct* out, int out_slot) {
+    MKHE_TRY({
+        if (out->c.limbs != level + 1) throw Error("mkhe_external_product_hoisted: out must have level+1 limbs");
+        ctx->c->external_product_hoisted(level, ah->s.d, bg->s.d, const_cast<u64*>(ct_slot(ctx->c, out, out_slot, level)), false);
+    })
+}
+int mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                       const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
+                       const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
+                       const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out) {
+    MKHE_TRY({
+        if (!op0 || !op1 || !out || !crs_u || !rlk_b1 || !rlk_d0 || !rlk_v0) throw Error("mkhe_mul_and_relin: null argument");
+        auto h0 = swk_list(hoist0, op0->c.n); auto h1 = swk_list(hoist1, op1->c.n);
+        auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n); auto v0 = swk_list(rlk_v0, op0->c.n);
+        const bool same = (op0 == op1) && (hoist0 == hoist1);
+        ctx->c->mul_and_relin(op0->c, same ? op0->c : op1->c, hoist0 ? h0.data() : nullptr,
+                              hoist1 ? (same ? h0.data() : h1.data()) : nullptr,
+                              b1.data(), d0.data(), v0.data(), crs_u->s, out->c);
+    })
+}
+int mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* hoist,
+                const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* out) {
+    MKHE_TRY({
+        if (!in || !out || !rk || !crs) throw Error("mkhe_rotate: null argument");
+        auto h = swk_list(hoist, in->c.n); auto r = swk_list(rk, in->c.n);
+        ctx->c->rotate(galEl, in->c, hoist ? h.data() : nullptr, r.data(), crs->s, out->c);
+    })
+}
+int mkhe_conjugate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* ck,
+                   const mkhe_swk* crs, mkhe_ct* out) {
+    MKHE_TRY({
+        if (!in || !out || !ck || !crs) throw Error("mkhe_conjugate: null argument");
+        auto k = swk_list(ck, in->c.n);
+        ctx->c->conjugate(galEl, in->c, k.data(), crs->s, out->c);
+    })
+}
+int mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out) {
+    MKHE_TRY(ctx->c->rescale(in->c, nb, out->c))
+}
+
+}  // extern "C"

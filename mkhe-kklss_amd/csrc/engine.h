@@ -1,0 +1,85 @@
+// engine.h -- device-resident multi-key RLWE key-switch engine (host-side C++ over HIP).
+//
+// One Context = one mkrlwe.KeySwitcher (mkrlwe/keyswitch.go:8-47): ring tables for Q and P in
+// HBM, the ModDown / rescale constants, and the scratch pools the reference keeps in
+// ks.Pool / swkPool1-3 / polyQPool (engine-internal here).  One HIP stream per context; calls
+// on a context are serialized by the caller, exactly like the non-reentrant reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "modarith.h"
+#include "ntt_kernels.h"
+#include "poly_kernels.h"
+
+namespace mkhe {
+
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define MKHE_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw ::mkhe::Error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+// device SwitchingKey / hoisted digit vector: uint64[betaMax][nQ+nP][N]
+struct Swk { u64* d = nullptr; bool owned = true; };
+// device ciphertext: uint64[1+n][limbs][N], slot 0 = c_0, slot 1+i = party ids[i]
+struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
+
+class Context {
+  public:
+    Context(int logN, const u64* Q, int nq, const u64* P, int np, int gamma,
+            const u64* psiQ, const u64* psiP, int device);
+    ~Context();
+
+    int logN, N, nq, np, mtot, gamma, alpha, beta_max, device;
+    std::vector<u64> moduli;        // Q then P
+    std::vector<u64> psi_plain;     // 2N-th roots actually used
+    hipStream_t stream = nullptr;
+
+    int beta(int level) const { return (level + 1 + alpha - 1) / alpha; }
+    size_t swk_words() const { return (size_t)beta_max * mtot * N; }
+    size_t poly_words(int limbs) const { return (size_t)limbs * N; }
+
+    // ---- ring-level entry points (tests / bench / callers that hold raw device buffers)
+    // NTT of `count` polys of `limbs` limbs each; modulus of limb l is mod_base + l.
+    void ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, bool inverse, bool lazy);
+
+    // ---- KeySwitcher method set (mkrlwe/keyswitch.go, keyswitch_hoisted.go)
+    void decompose(int level, bool is_ntt, const u64* a /*[level+1.. ][N] device*/, u64* out_swk);
+    void external_product_hoisted(int level, const u64* ah, const u64* bg, u64* c, bool accumulate);
+    void external_product(int level, bool is_ntt, const u64* a, const u64* bg, u64* c, bool accumulate);
+    void mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
+                       const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
+                       const Swk& crs_u, Ct& out);
+    void rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, Ct& out);
+    void conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk& crs, Ct& out);
+    // mkckks Rescale body: nb successive DivRoundByLastModulus on every poly (evaluator.go:385-391)
+    void rescale(const Ct& in, int nb, Ct& out);
+
+    void sync() { MKHE_HIP(hipStreamSynchronize(stream)); }
+
+    // device tables (public for the C ABI accessors / tests)
+    Mod* d_mods = nullptr;
+    u64 *d_psi = nullptr, *d_psiinv = nullptr, *d_inv_aux = nullptr;
+    int *d_map_qp = nullptr, *d_map_id = nullptr;
+    u64 *d_md_qoverqiinvqi = nullptr, *d_md_qoverqimodp = nullptr, *d_md_vtimes = nullptr, *d_md_down = nullptr;
+    u64* d_rescale = nullptr;
+
+  private:
+    // scratch pools
+    u64 *x_ = nullptr, *y_ = nullptr, *swk3_ = nullptr;      // swkPool1..3
+    u64* c1_ = nullptr;                                      // ks.Pool[1]  (PolyQP)
+    u64* polyq_[3] = {nullptr, nullptr, nullptr};            // polyQPool
+    u64* invntt_ = nullptr;                                  // ks.PoolInvNTT
+    u64* nttbuf_ = nullptr; size_t nttbuf_words_ = 0;        // tensor inputs in NTT form
+    u64* ctbuf_ = nullptr;  size_t ctbuf_words_ = 0;         // rotate / rescale staging
+    std::vector<Swk> hoist_pool_[2];                         // rlkSet.HoistPool[0/1]
+
+    u64* scratch(u64*& p, size_t& have, size_t want);
+    Swk& hoist_slot(int which, int idx);
+    const int* map_qp(int level) const { return d_map_qp + (size_t)level * mtot; }
+    void check_level(int level) const;
+    void ext_core(int level, const u64* ah, const u64* bg, u64* c, bool accumulate);
+};
+
+}  // namespace mkhe

@@ -1,0 +1,383 @@
+// engine.hip -- Context: host-side table generation + orchestration of the HIP kernels.
+#include "engine.h"
+#include <algorithm>
+#include <cstring>
+
+namespace mkhe {
+
+typedef unsigned __int128 u128;
+
+// ------------------------------------------------------------------ host number theory
+static u64 mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+static u64 powmod(u64 x, u64 e, u64 q) {
+    u64 r = 1 % q; x %= q;
+    for (; e; e >>= 1) { if (e & 1) r = mulmod(r, x, q); x = mulmod(x, x, q); }
+    return r;
+}
+static u64 inv64(u64 q) { u64 x = q; for (int i = 0; i < 6; ++i) x *= 2 - q * x; return x; }   // q^-1 mod 2^64 (Newton)
+static u64 to_mont(u64 a, u64 q) { return (u64)(((u128)a << 64) % q); }
+static u64 bitrev(u64 x, int bits) { u64 r = 0; for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
+
+static bool is_prime(u64 n) {
+    if (n < 2) return false;
+    for (u64 p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) if (n % p == 0) return n == p;
+    u64 d = n - 1; int s = 0;
+    while ((d & 1) == 0) { d >>= 1; ++s; }
+    for (u64 a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        u64 x = powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool comp = true;
+        for (int i = 1; i < s; ++i) { x = mulmod(x, x, n); if (x == n - 1) { comp = false; break; } }
+        if (comp) return false;
+    }
+    return true;
+}
+
+// Same choice of 2N-th root as lattigo v2.3.0 NewRing (ring/primes.go primitiveRoot: the scan
+// starts at g = 3), so that key material produced by the Go side (NTT domain) lines up when the
+// caller does not pass its own roots.
+static u64 default_psi(u64 q, u64 N) {
+    std::vector<u64> f;
+    u64 n = q - 1;
+    for (u64 p = 2; p * p <= n; p += (p == 2 ? 1 : 2))
+        if (n % p == 0) { f.push_back(p); while (n % p == 0) n /= p; }
+    if (n > 1) f.push_back(n);
+    u64 g = 2;
+    for (;;) {
+        ++g;
+        bool ok = true;
+        for (u64 p : f) if (powmod(g, (q - 1) / p, q) == 1) { ok = false; break; }
+        if (ok) break;
+    }
+    return powmod(g, (q - 1) / (2 * N), q);
+}
+
+template <typename T> static T* dev_upload(const std::vector<T>& v) {
+    T* d = nullptr;
+    MKHE_HIP(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!v.empty()) MKHE_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+static u64* dev_alloc_words(size_t w) { u64* d = nullptr; MKHE_HIP(hipMalloc(&d, std::max<size_t>(w, 1) * sizeof(u64))); return d; }
+
+// ------------------------------------------------------------------ construction
+Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int gamma_,
+                 const u64* psiQ, const u64* psiP, int device_)
+    : logN(logN_), N(1 << logN_), nq(nq_), np(np_), mtot(nq_ + np_), gamma(gamma_), device(device_) {
+    if (logN < 10 || logN > 15) throw Error("mkhe: logN must be in [10,15]");
+    if (nq < 1 || np < 1 || gamma < 1 || np / gamma < 1) throw Error("mkhe: need at least gamma special primes (PCount/gamma >= 1)");
+    if (np > MAXP) throw Error("mkhe: too many special primes");
+    alpha = np / gamma;                                   // mkrlwe/params.go:63-65
+    beta_max = (nq + alpha - 1) / alpha;                  // params.go:67-71
+    if (2 * beta_max > MAX_TERMS) throw Error("mkhe: too many gadget digits");
+    for (int i = 0; i < nq; ++i) moduli.push_back(Q[i]);
+    for (int i = 0; i < np; ++i) moduli.push_back(P[i]);
+    for (int i = 0; i < mtot; ++i) {
+        const u64 q = moduli[i];
+        if (q >= (1ull << 61) || !is_prime(q) || (q - 1) % (2ull * N) != 0) throw Error("mkhe: moduli must be primes < 2^61 with q = 1 mod 2N");
+        for (int j = 0; j < i; ++j) if (moduli[j] == q) throw Error("mkhe: repeated modulus");
+    }
+    MKHE_HIP(hipSetDevice(device));
+    MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+
+    std::vector<Mod> mods(mtot);
+    std::vector<u64> psi((size_t)mtot * N), psiinv((size_t)mtot * N), aux(2 * (size_t)mtot);
+    for (int i = 0; i < mtot; ++i) {
+        const u64 q = moduli[i];
+        Mod& m = mods[i];
+        m.q = q; m.q2 = 2 * q; m.qinv = inv64(q); m.ninv32 = (u32)(0 - m.qinv); m.pad = 0;
+        m.r1 = to_mont(1, q); m.r2 = mulmod(m.r1, m.r1, q);
+        u64 ps = (i < nq) ? (psiQ ? psiQ[i] : 0) : (psiP ? psiP[i - nq] : 0);
+        if (!ps) ps = default_psi(q, N);
+        if (powmod(ps, N, q) != q - 1) throw Error("mkhe: supplied psi is not a primitive 2N-th root");
+        psi_plain.push_back(ps);
+        const u64 psinv = powmod(ps, q - 2, q);
+        u64 a = m.r1, b = m.r1;
+        for (u64 j = 0; j < (u64)N; ++j) {
+            const u64 r = bitrev(j, logN);
+            psi[(size_t)i * N + r] = a; psiinv[(size_t)i * N + r] = b;
+            a = mulmod(a, ps, q); b = mulmod(b, psinv, q);
+        }
+        const u64 ninv = powmod((u64)N, q - 2, q);
+        aux[2 * i] = to_mont(ninv, q);
+        aux[2 * i + 1] = mulmod(psiinv[(size_t)i * N + 1], ninv, q);
+    }
+    d_mods = dev_upload(mods); d_psi = dev_upload(psi); d_psiinv = dev_upload(psiinv); d_inv_aux = dev_upload(aux);
+
+    std::vector<int> map((size_t)nq * mtot, 0), ident(mtot);
+    for (int l = 0; l < nq; ++l) {
+        for (int j = 0; j <= l; ++j) map[(size_t)l * mtot + j] = j;
+        for (int j = 0; j < np; ++j) map[(size_t)l * mtot + l + 1 + j] = nq + j;
+    }
+    for (int j = 0; j < mtot; ++j) ident[j] = j;
+    d_map_qp = dev_upload(map); d_map_id = dev_upload(ident);
+
+    // ModUpPtoQ / ModDown constants, basisextenderparameters(P, Q) at full P
+    // (mkrlwe/basis_extension.go:34-54, 83-153); all are canonical values -> closed forms.
+    std::vector<u64> t1(np), t2((size_t)nq * np), t3((size_t)nq * (np + 1)), t4(nq);
+    for (int i = 0; i < np; ++i) {
+        const u64 pi = P[i]; u64 star = 1;
+        for (int j = 0; j < np; ++j) if (j != i) star = mulmod(star, P[j] % pi, pi);
+        t1[i] = to_mont(powmod(star, pi - 2, pi), pi);
+    }
+    for (int j = 0; j < nq; ++j) {
+        const u64 qj = Q[j]; u64 pm = 1;
+        for (int i = 0; i < np; ++i) {
+            u64 s = 1;
+            for (int u = 0; u < np; ++u) if (u != i) s = mulmod(s, P[u] % qj, qj);
+            t2[(size_t)j * np + i] = to_mont(s, qj);
+            pm = mulmod(pm, P[i] % qj, qj);
+        }
+        const u64 v = qj - pm;
+        t3[(size_t)j * (np + 1)] = 0;
+        for (int i = 1; i <= np; ++i) { u64 s = t3[(size_t)j * (np + 1) + i - 1] + v; t3[(size_t)j * (np + 1) + i] = s >= qj ? s - qj : s; }
+        t4[j] = qj - to_mont(powmod(pm, qj - 2, qj), qj);
+    }
+    d_md_qoverqiinvqi = dev_upload(t1); d_md_qoverqimodp = dev_upload(t2); d_md_vtimes = dev_upload(t3); d_md_down = dev_upload(t4);
+
+    // RescaleParams[L-1][i] = MForm(q_L^-1 mod q_i)  (lattigo ring.go genNTTParams)
+    std::vector<u64> rs((size_t)nq * nq, 0);
+    for (int L = 1; L < nq; ++L)
+        for (int i = 0; i < L; ++i) rs[(size_t)(L - 1) * nq + i] = to_mont(powmod(Q[L] % Q[i], Q[i] - 2, Q[i]), Q[i]);
+    d_rescale = dev_upload(rs);
+
+    x_ = dev_alloc_words(swk_words()); y_ = dev_alloc_words(swk_words()); swk3_ = dev_alloc_words(swk_words());
+    c1_ = dev_alloc_words((size_t)mtot * N);
+    for (auto& p : polyq_) p = dev_alloc_words((size_t)nq * N);
+    invntt_ = dev_alloc_words((size_t)nq * N);
+}
+
+Context::~Context() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
+                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale,
+                    (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
+                    (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_})
+        if (p) (void)hipFree(p);
+    for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+u64* Context::scratch(u64*& p, size_t& have, size_t want) {
+    if (have < want) {
+        if (p) { MKHE_HIP(hipStreamSynchronize(stream)); MKHE_HIP(hipFree(p)); p = nullptr; }
+        p = dev_alloc_words(want); have = want;
+    }
+    return p;
+}
+Swk& Context::hoist_slot(int which, int idx) {
+    auto& v = hoist_pool_[which];
+    while ((int)v.size() <= idx) { Swk s; s.d = dev_alloc_words(swk_words()); v.push_back(s); }
+    return v[idx];
+}
+void Context::check_level(int level) const {
+    if (level < 0 || level >= nq) throw Error("mkhe: level out of range");
+}
+
+// ------------------------------------------------------------------ ring level
+void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, bool inverse, bool lazy) {
+    if (mod_base < 0 || mod_base + limbs > mtot) throw Error("mkhe: ntt modulus range");
+    NttBatch b{};
+    b.src = src; b.dst = dst; b.mods = d_mods; b.psi = inverse ? d_psiinv : d_psi; b.aux = d_inv_aux;
+    b.map = d_map_id + mod_base;
+    b.src_outer = b.dst_outer = (long)limbs * N; b.src_inner = b.dst_inner = N;
+    b.inner_count = limbs; b.njobs = count * limbs; b.lazy_out = lazy ? 1 : 0;
+    if (inverse) launch_ntt_inv(logN, b, stream); else launch_ntt_fwd(logN, b, stream);
+    MKHE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ Decompose (keyswitch.go:49-73)
+void Context::decompose(int level, bool is_ntt, const u64* a, u64* out_swk) {
+    check_level(level);
+    if (alpha != 1) throw Error("mkhe: gadget decomposition with alpha >= 2 (CRT reconstruction) is not implemented on the device yet");
+    const u64* ainv = a;
+    if (is_ntt) { ntt(a, invntt_, 1, level + 1, 0, true, false); ainv = invntt_; }
+    // alpha = 1 (basis_extension.go:443-451): digit i = limb i, re-read under every active modulus,
+    // fused with the forward NTT (DecomposeSingleNTT, keyswitch.go:21-31).
+    NttBatch b{};
+    b.src = ainv; b.dst = out_swk; b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux;
+    b.map = map_qp(level);
+    b.inner_count = level + 1 + np;
+    b.src_outer = N; b.src_inner = 0; b.src_mapped = 0;
+    b.dst_outer = (long)mtot * N; b.dst_inner = N; b.dst_mapped = 1;
+    b.njobs = beta(level) * b.inner_count;
+    b.reduce_in = 1; b.reduce_src_mod_is_outer = 1;
+    launch_ntt_fwd(logN, b, stream);
+    MKHE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ ExternalProduct[Hoisted]
+// (keyswitch_hoisted.go:10-40): sum over digits, InvNTTLazy on Q and P parts, ModDownQPtoQ.
+void Context::ext_core(int level, const u64* ah, const u64* bg, u64* c, bool accumulate) {
+    const int nb = beta(level), nslots = level + 1 + np;
+    InnerProductArgs ip{};
+    for (int i = 0; i < nb; ++i) { ip.a[i] = bg + (size_t)i * mtot * N; ip.b[i] = ah + (size_t)i * mtot * N; }
+    ip.out = c1_; ip.mods = d_mods; ip.map = map_qp(level);
+    ip.term_outer = 0; ip.out_outer = 0; ip.nterms = nb; ip.nslots = nslots; ip.nouter = 1; ip.N = N; ip.mform_out = 0;
+    launch_inner_product(ip, stream);
+
+    NttBatch b{};
+    b.src = c1_; b.dst = c1_; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; b.map = map_qp(level);
+    b.inner_count = nslots; b.njobs = nslots; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
+    b.lazy_out = 1;
+    launch_ntt_inv(logN, b, stream);
+
+    ModDownArgs md{};
+    md.xq = c1_; md.xp = c1_ + (size_t)nq * N; md.dst = c; md.mods_q = d_mods; md.mods_p = d_mods + nq;
+    md.t = ModDownTables{d_md_qoverqiinvqi, d_md_qoverqimodp, d_md_vtimes, d_md_down};
+    md.level = level; md.np = np; md.N = N; md.accumulate = accumulate ? 1 : 0; md.nbatch = 1;
+    launch_moddown(md, stream);
+    MKHE_HIP(hipGetLastError());
+}
+void Context::external_product_hoisted(int level, const u64* ah, const u64* bg, u64* c, bool accumulate) {
+    check_level(level);
+    ext_core(level, ah, bg, c, accumulate);
+}
+void Context::external_product(int level, bool is_ntt, const u64* a, const u64* bg, u64* c, bool accumulate) {
+    check_level(level);
+    decompose(level, is_ntt, a, swk3_);
+    ext_core(level, swk3_, bg, c, accumulate);
+}
+
+// ------------------------------------------------------------------ MulAndRelin[Hoisted]
+// keyswitch_hoisted.go:44-179 (hoist == nullptr: keyswitch.go:122-230, same values).
+void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
+                            const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
+                            const Swk& crs_u, Ct& out) {
+    const int level = out.limbs - 1, L = level + 1;
+    check_level(level);
+    if (op0.limbs < L || op1.limbs < L) throw Error("Cannot MulAndRelin: op0 and op1 have different levels");
+    const int n0 = op0.n, n1 = op1.n;
+    if (n0 > 32 || n1 > 32 || out.n > 32 || n0 > MAX_TERMS || n1 > MAX_TERMS) throw Error("mkhe: too many parties");
+    // out ids must be the union of the operand id sets (newCiphertextBinary, mkckks/evaluator.go:306-313)
+    std::vector<int> slot0(n0), slot1(n1);
+    TensorArgs ta{};
+    auto find = [&](int id) { for (int o = 0; o < out.n; ++o) if (out.ids[o] == id) return o; return -1; };
+    for (int a = 0; a < n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); slot0[a] = o; ta.slot0[1 + o] = 1 + a; }
+    for (int a = 0; a < n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); slot1[a] = o; ta.slot1[1 + o] = 1 + a; }
+    for (int o = 0; o < out.n; ++o) if (!ta.slot0[1 + o] && !ta.slot1[1 + o]) throw Error("mkhe: ctOut has an id that neither operand has");
+
+    const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N, PO = (size_t)L * N;
+    // hoist the operands when the caller did not (MulRelinNew, mkckks/evaluator.go:416-443)
+    std::vector<const u64*> h0(n0), h1(n1);
+    const bool same = (&op0 == &op1) && hoist0 == hoist1;
+    for (int a = 0; a < n0; ++a) {
+        if (hoist0) { if (!hoist0[a]) throw Error("mkhe: missing hoisted form"); h0[a] = hoist0[a]->d; }
+        else { Swk& s = hoist_slot(0, a); decompose(level, false, op0.d + (1 + a) * P0, s.d); h0[a] = s.d; }
+    }
+    for (int a = 0; a < n1; ++a) {
+        if (hoist1) { if (!hoist1[a]) throw Error("mkhe: missing hoisted form"); h1[a] = hoist1[a]->d; }
+        else if (same) h1[a] = h0[a];
+        else { Swk& s = hoist_slot(1, a); decompose(level, false, op1.d + (1 + a) * P1, s.d); h1[a] = s.d; }
+    }
+    const int nb = beta(level), nslots = L + np;
+    // B, C: x = MForm(sum_i d_i (.) h(c0_i)),  y = MForm(sum_j b_j (.) h(c1_j))
+    for (int side = 0; side < 2; ++side) {
+        const int n = side ? n1 : n0;
+        InnerProductArgs ip{};
+        for (int a = 0; a < n; ++a) {
+            const Swk* key = side ? rlk_b1[a] : rlk_d0[a];
+            if (!key) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+            ip.a[a] = key->d; ip.b[a] = side ? h1[a] : h0[a];
+        }
+        ip.out = side ? y_ : x_; ip.mods = d_mods; ip.map = map_qp(level);
+        ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nb; ip.N = N; ip.mform_out = 1;
+        launch_inner_product(ip, stream);
+    }
+    // D: tensor product in the NTT domain, back to coefficients
+    u64* nb_ = scratch(nttbuf_, nttbuf_words_, (size_t)(2 + n0 + n1) * PO);
+    {
+        NttBatch b{};
+        b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; b.map = d_map_id; b.inner_count = L;
+        b.src_inner = b.dst_inner = N; b.dst_outer = (long)PO;
+        b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.njobs = (1 + n0) * L;
+        launch_ntt_fwd(logN, b, stream);
+        b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.njobs = (1 + n1) * L;
+        launch_ntt_fwd(logN, b, stream);
+    }
+    ta.ntt = nb_; ta.out = out.d; ta.mods = d_mods; ta.n0 = n0; ta.n1 = n1; ta.nout = out.n; ta.L = L; ta.N = N;
+    launch_tensor(ta, stream);
+    ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
+    // E: out_j += <h(c1_j), x>_P
+    for (int a = 0; a < n1; ++a) ext_core(level, h1[a], x_, out.d + (size_t)(1 + slot1[a]) * PO, true);
+    // F: t = <h(c0_i), y>_P ; out_0 += <h(t), v_i>_P ; out_i += <h(t), u>_P
+    for (int a = 0; a < n0; ++a) {
+        if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+        ext_core(level, h0[a], y_, polyq_[0], false);
+        decompose(level, false, polyq_[0], swk3_);
+        ext_core(level, swk3_, rlk_v0[a]->d, out.d, true);
+        ext_core(level, swk3_, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PO, true);
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ Rotate[Hoisted] / Conjugate
+// keyswitch.go:234-298, keyswitch_hoisted.go:183-247
+void Context::rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, Ct& out) {
+    const int level = out.limbs - 1, L = level + 1, n = in.n;
+    check_level(level);
+    if (in.limbs < L) throw Error("Cannot Rotate: ctIn and ctOut have different levels");
+    if (out.n != n || out.ids != in.ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
+    const size_t PI = (size_t)in.limbs * N, PO = (size_t)L * N;
+    u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * PO);
+    MKHE_HIP(hipMemcpyAsync(tmp, in.d, PO * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    for (int a = 0; a < n; ++a) {
+        if (!rk[a]) throw Error("cannot GetRotationKeys: there is no rotation key with given id");
+        const u64* h;
+        if (hoist) { if (!hoist[a]) throw Error("mkhe: missing hoisted form"); h = hoist[a]->d; }
+        else { Swk& s = hoist_slot(0, a); decompose(level, false, in.d + (1 + a) * PI, s.d); h = s.d; }
+        ext_core(level, h, rk[a]->d, tmp, true);
+        ext_core(level, h, crs.d, tmp + (size_t)(1 + a) * PO, false);
+    }
+    launch_automorphism(out.d, tmp, d_mods, L, logN, galEl, 1 + n, stream);
+    MKHE_HIP(hipGetLastError());
+}
+
+// keyswitch.go:302-332
+void Context::conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk& crs, Ct& out) {
+    const int level = out.limbs - 1, L = level + 1, n = in.n;
+    check_level(level);
+    if (in.limbs < L) throw Error("Cannot Conjugate: ctIn and ctOut have different levels");
+    if (out.n != n || out.ids != in.ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
+    const size_t PI = (size_t)in.limbs * N, PO = (size_t)L * N;
+    u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * PO);
+    if (in.limbs == L) launch_automorphism(tmp, in.d, d_mods, L, logN, galEl, 1 + n, stream);
+    else for (int a = 0; a <= n; ++a) launch_automorphism(tmp + a * PO, in.d + a * PI, d_mods, L, logN, galEl, 1, stream);
+    MKHE_HIP(hipMemcpyAsync(out.d, tmp, PO * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    for (int a = 0; a < n; ++a) {
+        if (!ck[a]) throw Error("cannot GetConjugationKey: there is no conjugation key with given id");
+        decompose(level, false, tmp + (size_t)(1 + a) * PO, swk3_);
+        ext_core(level, swk3_, ck[a]->d, out.d, true);
+        ext_core(level, swk3_, crs.d, out.d + (size_t)(1 + a) * PO, false);
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ Rescale body
+// mkckks/evaluator.go:385-391 -> lattigo DivRoundByLastModulusManyLvl.  The reference's in-place
+// "+ (q_L-1)/2" on the dropped limb of ctIn is NOT reproduced (ctIn stays untouched).
+void Context::rescale(const Ct& in, int nb, Ct& out) {
+    const int level = in.limbs - 1;
+    check_level(level);
+    if (nb < 0 || nb > level) throw Error("cannot Rescale: input Ciphertext already at level 0");
+    if (out.limbs != in.limbs - nb || out.n != in.n) throw Error("mkhe: ctOut shape does not match the rescaled ciphertext");
+    const int np_ = 1 + in.n;
+    const size_t PI = (size_t)in.limbs * N, PO = (size_t)out.limbs * N;
+    if (nb == 0) { if (out.d != in.d) MKHE_HIP(hipMemcpyAsync(out.d, in.d, np_ * PI * sizeof(u64), hipMemcpyDeviceToDevice, stream)); return; }
+    if (nb == 1) {
+        launch_div_round_last(out.d, in.d, d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, np_, (long)PI, (long)PO, stream);
+    } else {
+        u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)np_ * PI);
+        launch_div_round_last(tmp, in.d, d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, np_, (long)PI, (long)PI, stream);
+        for (int k = 1; k < nb; ++k) {
+            const int lv = level - k;
+            const bool last = (k == nb - 1);
+            launch_div_round_last(last ? out.d : tmp, tmp, d_mods, d_rescale + (size_t)(lv - 1) * nq, lv, N, np_,
+                                  (long)PI, last ? (long)PO : (long)PI, stream);
+        }
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
+}  // namespace mkhe

@@ -1,0 +1,75 @@
+// modarith.h -- 64-bit Montgomery arithmetic for gfx950 (device side).
+//
+// CDNA4 has no 64x64->128 multiply: every product is built from v_mad_u64_u32
+// (32x32+64 -> 64) and v_mul_lo_u32, both measured at half the rate of a simple VALU op
+// (tools/ubench/imul_rate.hip).  The Montgomery product below is word-serial (radix 2^32,
+// two rounds) so that every addition rides on a mad's 64-bit addend: 8 v_mad_u64_u32 +
+// 2 v_mul_lo_u32 + 2 64-bit adds.
+//
+// Semantics mirror lattigo v2.3.0 ring.MRed / MRedConstant / MForm / CRed as used by the
+// reference (mkrlwe/keyswitch_hoisted.go:28-30, basis_extension.go:220,551): radix R = 2^64,
+//   mont_mul(a, b) = a*b*R^-1 mod q.
+// Intermediate (lazy) representatives may differ from lattigo's; every value that leaves a
+// kernel for another modulus or for the caller is canonical or an explicitly restated
+// lazy formula (mult_sum).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mkhe {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+// Per-modulus constants, uniform per workgroup (live in SGPRs).
+struct Mod {
+    u64 q;        // modulus, < 2^61
+    u64 q2;       // 2q
+    u32 ninv32;   // -q^-1 mod 2^32
+    u32 pad;
+    u64 qinv;     // q^-1 mod 2^64   (lattigo MRedParams; used by the literal mult_sum)
+    u64 r1;       // 2^64  mod q     (MForm(1))
+    u64 r2;       // 2^128 mod q     (mont_mul(a, r2) = MForm(a))
+};
+
+__device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+__device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
+__device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
+
+// a*w*R^-1 mod q, result in [0, 2q).  Requires a < 2^62, w < q < 2^61.
+__device__ __forceinline__ u64 mont_mul_lazy(u64 a, u64 w, u64 q, u32 ninv32) {
+    const u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(w), w1 = hi32(w), q0 = lo32(q), q1 = hi32(q);
+    // round 0: T = (a0*w + m*q) >> 32
+    u64 p0 = mad64(a0, w0, 0);
+    u32 m = lo32(p0) * ninv32;
+    u64 r0 = mad64(m, q0, lo32(p0));            // low word is zero by construction
+    u64 p1 = mad64(a0, w1, hi32(p0));
+    u64 T = mad64(m, q1, p1) + hi32(r0);
+    // round 1: result = (T + a1*w + m'*q) >> 32
+    u64 s0 = mad64(a1, w0, T);
+    u32 m2 = lo32(s0) * ninv32;
+    u64 r2 = mad64(m2, q0, lo32(s0));
+    u64 A = mad64(a1, w1, hi32(s0));
+    return mad64(m2, q1, A) + hi32(r2);
+}
+
+__device__ __forceinline__ u64 csub(u64 a, u64 q) { return a >= q ? a - q : a; }
+
+// canonical product (lattigo MRed)
+__device__ __forceinline__ u64 mont_mul(u64 a, u64 w, u64 q, u32 ninv32) {
+    return csub(mont_mul_lazy(a, w, q, ninv32), q);
+}
+
+// full 128-bit product
+__device__ __forceinline__ void mul64x64(u64 a, u64 b, u64& hi, u64& lo) {
+    const u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    u64 p00 = mad64(a0, b0, 0);
+    u64 p01 = mad64(a0, b1, hi32(p00));
+    u64 p10 = mad64(a1, b0, lo32(p01));
+    u64 p11 = mad64(a1, b1, (u64)hi32(p01) + hi32(p10));
+    lo = ((u64)lo32(p10) << 32) | lo32(p00);
+    hi = p11;
+}
+__device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { u64 h, l; mul64x64(a, b, h, l); return h; }
+
+}  // namespace mkhe

@@ -1,0 +1,79 @@
+// poly_kernels.h -- coefficient-wise kernels of the multi-key key-switch path (gfx950).
+//
+// All of these are HBM-streaming kernels (one or a few modular products per 8-byte word):
+// lanes walk consecutive coefficients of one limb (coalesced 8-B accesses, 512 B per wave
+// instruction), blockIdx.y selects the limb so the modulus constants are wave-uniform
+// (SGPRs), and reductions over gadget digits / parties are fused into one pass with the
+// accumulator held in registers (read 2*terms words, write 1) instead of the reference's
+// read-modify-write per term (mkrlwe/keyswitch_hoisted.go:28-30, 84-96).
+#pragma once
+#include "modarith.h"
+
+namespace mkhe {
+
+constexpr int MAX_TERMS = 40;   // >= 2*beta (BFV double gadget) and >= #parties
+constexpr int MAXP = 8;         // special primes handled by the ModDown kernel
+
+// out[o][m][n] = (mform?) sum_t a_t[o][m][n] (*) b_t[o][m][n]      (MulCoeffsMontgomeryAndAdd chain)
+struct InnerProductArgs {
+    const u64* a[MAX_TERMS];
+    const u64* b[MAX_TERMS];
+    u64* out;
+    const Mod* mods;
+    const int* map;          // [nslots] active limb -> limb index in a PolyQP-shaped buffer
+    long term_outer;         // word stride between outer items inside every term buffer
+    long out_outer;
+    int nterms, nslots, nouter, N;
+    int mform_out;           // apply MFormLvl to the sum (keyswitch_hoisted.go:94-96,115-117)
+};
+void launch_inner_product(const InnerProductArgs& a, hipStream_t st);
+
+// ModDownQPtoQ (mkrlwe/basis_extension.go:192-232 = lattigo Baseconverter.ModDownQPtoQ) on
+// coefficient-domain lazy inputs, optionally accumulated into dst (ringQ.AddLvl).
+struct ModDownTables {
+    const u64* qoverqiinvqi;   // [np]            (P/p_i)^-1 * R mod p_i
+    const u64* qoverqimodp;    // [nq][np]        (P/p_i) * R mod q_j
+    const u64* vtimesqmodp;    // [nq][np+1]      v * (q_j - P mod q_j) mod q_j
+    const u64* downparam;      // [nq]            q_j - (P^-1 * R mod q_j)
+};
+struct ModDownArgs {
+    const u64* xq;             // [.. level+1 ..][N] Q part  (lazy, < 2q)
+    const u64* xp;             // [np][N]            P part  (lazy, < 2p)
+    u64* dst;                  // [level+1][N]
+    const Mod* mods_q;         // [nq]
+    const Mod* mods_p;         // [np]
+    ModDownTables t;
+    int level, np, N;
+    int accumulate;            // dst = CRed(dst + result)
+    int nbatch;                // independent (xq, xp, dst) triples
+    long xq_batch, xp_batch, dst_batch;
+};
+void launch_moddown(const ModDownArgs& a, hipStream_t st);
+
+// Tensor step D of MulAndRelin (keyswitch_hoisted.go:120-140) on NTT-domain inputs.
+//   out_0 = a0*b0 ; out_o = b0*a_o (o in ids0) (+)= a0*b_o (o in ids1)
+struct TensorArgs {
+    const u64* ntt;            // [(1+n0) + (1+n1)][L][N]  NTT of op0 slots then op1 slots
+    u64* out;                  // [1+nout][L][N]
+    const Mod* mods;
+    int slot0[33];             // for out slot o>=1: index into op0 slots (1..n0) or 0 if absent
+    int slot1[33];             // likewise for op1
+    int n0, n1, nout, L, N;
+};
+void launch_tensor(const TensorArgs& a, hipStream_t st);
+
+// dst = CRed(a + b) per limb
+void launch_add(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st);
+
+// Coefficient-domain automorphism with sign (keyswitch.go:267-296): out[(i*g) mod N] = +-in[i]
+void launch_automorphism(u64* dst, const u64* src, const Mod* mods, int L, int logN, u64 galEl, int npolys, hipStream_t st);
+
+// DivRoundByLastModulus (lattigo ring_scaling.go; mkckks/evaluator.go:388), one division step:
+// dst[i] (i < level) from src limbs 0..level;  src is not modified.
+void launch_div_round_last(u64* dst, const u64* src, const Mod* mods, const u64* rescale_row /*[level]*/,
+                           int level, int N, int npolys, long src_poly, long dst_poly, hipStream_t st);
+
+// z = MForm(a) / z = mont_mul(a, b) helpers on limb-major buffers
+void launch_mform(u64* dst, const u64* src, const Mod* mods, const int* map, int nslots, int N, hipStream_t st);
+
+}  // namespace mkhe

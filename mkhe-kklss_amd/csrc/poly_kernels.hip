@@ -1,0 +1,193 @@
+// poly_kernels.hip -- see poly_kernels.h.
+#include "poly_kernels.h"
+
+namespace mkhe {
+
+constexpr int PW_THREADS = 256;
+
+// ------------------------------------------------------------------ inner product
+__global__ void __launch_bounds__(PW_THREADS) inner_product_kernel(InnerProductArgs a) {
+    const int s = blockIdx.y;                 // active-limb slot
+    const int o = blockIdx.z;                 // outer item (gadget digit or 0)
+    const int m = a.map[s];
+    const Mod md = a.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const long base = (long)o * a.term_outer + (long)m * a.N;
+    const long obase = (long)o * a.out_outer + (long)m * a.N;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
+        u64 acc = 0;
+#pragma unroll 4
+        for (int t = 0; t < a.nterms; ++t) {
+            u64 p = mont_mul_lazy(a.a[t][base + n], a.b[t][base + n], q, ninv);
+            acc = csub(acc + p, q2);
+        }
+        acc = csub(acc, q);
+        if (a.mform_out) acc = mont_mul(acc, md.r2, q, ninv);
+        a.out[obase + n] = acc;
+    }
+}
+
+void launch_inner_product(const InnerProductArgs& a, hipStream_t st) {
+    int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(inner_product_kernel, dim3(bx, a.nslots, a.nouter), dim3(PW_THREADS), 0, st, a);
+}
+
+// ------------------------------------------------------------------ ModDown
+// reconstructRNS + multSum + the MRed tail, restated literally per coefficient
+// (basis_extension.go:192-232, 337-357, 537-646).  The float64 correction index is evaluated
+// as sequential IEEE divide/add (no contraction: see the -ffp-contract=off build flag).
+__global__ void __launch_bounds__(PW_THREADS) moddown_kernel(ModDownArgs a) {
+    const int bi = blockIdx.z;
+    const u64* xq = a.xq + (long)bi * a.xq_batch;
+    const u64* xp = a.xp + (long)bi * a.xp_batch;
+    u64* dst = a.dst + (long)bi * a.dst_batch;
+    const int n = blockIdx.x * PW_THREADS + threadIdx.x;
+    if (n >= a.N) return;
+    u64 y[MAXP];
+    double vi = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        if (i < a.np) {
+            const Mod mp = a.mods_p[i];
+            y[i] = mont_mul(xp[(long)i * a.N + n], a.t.qoverqiinvqi[i], mp.q, mp.ninv32);
+            vi = vi + (double)y[i] / (double)mp.q;
+        }
+    }
+    const u64 v = (u64)vi;
+    // limbs are split over blockIdx.y to fill the chip
+    for (int j = blockIdx.y; j <= a.level; j += gridDim.y) {
+        const Mod mq = a.mods_q[j];
+        u64 rlo = 0, rhi = 0;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            if (i < a.np) {
+                u64 mhi, mlo;
+                mul64x64(y[i], a.t.qoverqimodp[(long)j * a.np + i], mhi, mlo);
+                u64 sum = rlo + mlo;
+                rhi += mhi + (sum < rlo ? 1 : 0);
+                rlo = sum;
+            }
+        }
+        const u64 hhi = mulhi64(rlo * mq.qinv, mq.q);
+        const u64 lift = rhi - hhi + mq.q + a.t.vtimesqmodp[(long)j * (a.np + 1) + v];
+        const u64 x = xq[(long)j * a.N + n];
+        u64 z = mont_mul(lift + mq.q2 - x, a.t.downparam[j], mq.q, mq.ninv32);
+        if (a.accumulate) z = csub(dst[(long)j * a.N + n] + z, mq.q);
+        dst[(long)j * a.N + n] = z;
+    }
+}
+
+void launch_moddown(const ModDownArgs& a, hipStream_t st) {
+    const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    int by = a.level + 1;
+    if (by > 4) by = 4;
+    hipLaunchKernelGGL(moddown_kernel, dim3(bx, by, a.nbatch), dim3(PW_THREADS), 0, st, a);
+}
+
+// ------------------------------------------------------------------ tensor (step D)
+__global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
+    const int l = blockIdx.y;
+    const Mod md = a.mods[l];
+    const u64 q = md.q;
+    const u32 ninv = md.ninv32;
+    const long P = (long)a.L * a.N;          // words per poly
+    const u64* op0 = a.ntt;
+    const u64* op1 = a.ntt + (long)(1 + a.n0) * P;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
+        const long e = (long)l * a.N + n;
+        const u64 a0m = mont_mul(op0[e], md.r2, q, ninv);     // MForm(NTT(c0_0))
+        const u64 b0 = op1[e];
+        const u64 b0m = mont_mul(b0, md.r2, q, ninv);         // MForm(NTT(c1_0))
+        a.out[e] = mont_mul(a0m, b0, q, ninv);
+        for (int o = 1; o <= a.nout; ++o) {
+            u64 r = 0;
+            const int s0 = a.slot0[o], s1 = a.slot1[o];
+            if (s0) r = mont_mul(b0m, op0[(long)s0 * P + e], q, ninv);
+            if (s1) r = csub(r + mont_mul(a0m, op1[(long)s1 * P + e], q, ninv), q);
+            a.out[(long)o * P + e] = r;
+        }
+    }
+}
+void launch_tensor(const TensorArgs& a, hipStream_t st) {
+    int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(tensor_kernel, dim3(bx, a.L), dim3(PW_THREADS), 0, st, a);
+}
+
+// ------------------------------------------------------------------ add
+__global__ void __launch_bounds__(PW_THREADS) add_kernel(u64* dst, const u64* x, const u64* y, const Mod* mods, int N) {
+    const int l = blockIdx.y;
+    const u64 q = mods[l].q;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < N; n += gridDim.x * PW_THREADS) {
+        const long e = (long)l * N + n;
+        dst[e] = csub(x[e] + y[e], q);
+    }
+}
+void launch_add(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st) {
+    int bx = (N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(add_kernel, dim3(bx, L), dim3(PW_THREADS), 0, st, dst, a, b, mods, N);
+}
+
+// ------------------------------------------------------------------ automorphism
+__global__ void __launch_bounds__(PW_THREADS) automorphism_kernel(u64* dst, const u64* src, const Mod* mods, int L, int logN, u64 galEl) {
+    const int l = blockIdx.y, pidx = blockIdx.z;
+    const int N = 1 << logN;
+    const u64 q = mods[l].q;
+    const long base = ((long)pidx * L + l) * N;
+    for (int i = blockIdx.x * PW_THREADS + threadIdx.x; i < N; i += gridDim.x * PW_THREADS) {
+        const u64 raw = (u64)i * galEl;
+        const int idx = (int)(raw & (u64)(N - 1));
+        const u64 v = src[base + i];
+        dst[base + idx] = ((raw >> logN) & 1) ? q - v : v;     // 0 with a sign flip is written as q, like the reference
+    }
+}
+void launch_automorphism(u64* dst, const u64* src, const Mod* mods, int L, int logN, u64 galEl, int npolys, hipStream_t st) {
+    const int N = 1 << logN;
+    int bx = (N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(automorphism_kernel, dim3(bx, L, npolys), dim3(PW_THREADS), 0, st, dst, src, mods, L, logN, galEl);
+}
+
+// ------------------------------------------------------------------ rescale step
+__global__ void __launch_bounds__(PW_THREADS) div_round_last_kernel(u64* dst, const u64* src, const Mod* mods, const u64* rescale_row,
+                                                                     int level, int N, long src_poly, long dst_poly) {
+    const int i = blockIdx.y, pidx = blockIdx.z;
+    const Mod mi = mods[i];
+    const u64 qL = mods[level].q, h = (qL - 1) >> 1;
+    // BRedAdd(h, q_i): h < 2^60, q_i > 2^20 -> plain remainder (canonical either way)
+    const u64 hneg = mi.q - (h % mi.q);
+    const u64 rp = mi.q - rescale_row[i];
+    const u64* s = src + (long)pidx * src_poly;
+    u64* d = dst + (long)pidx * dst_poly;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < N; n += gridDim.x * PW_THREADS) {
+        const u64 t = csub(s[(long)level * N + n] + h, qL);
+        d[(long)i * N + n] = mont_mul(t + hneg + mi.q2 - s[(long)i * N + n], rp, mi.q, mi.ninv32);
+    }
+}
+void launch_div_round_last(u64* dst, const u64* src, const Mod* mods, const u64* rescale_row, int level, int N, int npolys,
+                           long src_poly, long dst_poly, hipStream_t st) {
+    if (level < 1) return;
+    int bx = (N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(div_round_last_kernel, dim3(bx, level, npolys), dim3(PW_THREADS), 0, st, dst, src, mods, rescale_row, level, N, src_poly, dst_poly);
+}
+
+// ------------------------------------------------------------------ mform
+__global__ void __launch_bounds__(PW_THREADS) mform_kernel(u64* dst, const u64* src, const Mod* mods, const int* map, int N) {
+    const int m = map[blockIdx.y];
+    const Mod md = mods[m];
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < N; n += gridDim.x * PW_THREADS) {
+        const long e = (long)m * N + n;
+        dst[e] = mont_mul(src[e], md.r2, md.q, md.ninv32);
+    }
+}
+void launch_mform(u64* dst, const u64* src, const Mod* mods, const int* map, int nslots, int N, hipStream_t st) {
+    int bx = (N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(mform_kernel, dim3(bx, nslots), dim3(PW_THREADS), 0, st, dst, src, mods, map, N);
+}
+
+}  // namespace mkhe

@@ -1,0 +1,407 @@
+"""Host-side mirror of the reference package `mkrlwe` for the accelerated path.
+
+Same names, argument meaning and error behaviour as the Go types (reference file:line cited per
+item); all polynomial data lives in HBM behind C-ABI handles (include/mkhe.h).  The Go reference
+panics on misuse; here the same conditions raise `MkheError`/`KeyError` with the reference's text.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi
+from ._abi import MkheError, check, handle_array, lib
+
+GALOIS_GEN = 5  # lattigo rlwe.GaloisGen
+
+
+class Parameters:
+    """mkrlwe.Parameters (mkrlwe/params.go:8-12): ring parameters + CRS map + gamma, plus the
+    engine context (= NewKeySwitcher state, keyswitch.go:33-47)."""
+
+    def __init__(self, logN, Q, P, gamma=2, psiQ=None, psiP=None, device=0):
+        self.logN, self._N = int(logN), 1 << int(logN)
+        self.Q, self.P, self.gamma = [int(q) for q in Q], [int(p) for p in P], int(gamma)
+        q = np.asarray(self.Q, dtype=np.uint64)
+        p = np.asarray(self.P, dtype=np.uint64)
+        pq = np.asarray(psiQ, dtype=np.uint64) if psiQ is not None else None
+        pp = np.asarray(psiP, dtype=np.uint64) if psiP is not None else None
+        h = C.c_void_p()
+        check(lib().mkhe_ctx_create(C.byref(h), self.logN, q.ctypes.data_as(_abi.u64p), len(self.Q),
+                                    p.ctypes.data_as(_abi.u64p), len(self.P), self.gamma,
+                                    pq.ctypes.data_as(_abi.u64p) if pq is not None else None,
+                                    pp.ctypes.data_as(_abi.u64p) if pp is not None else None, int(device)))
+        self.ctx = h
+        self.device = int(device)
+        self.CRS = {}                      # idx -> SwitchingKey   (params.go:37-46)
+        self._ids = {}                     # party id string -> dense int for the C ABI
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            lib().mkhe_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # rlwe.Parameters accessors used by the reference
+    def N(self): return self._N
+    def LogN(self): return self.logN
+    def QCount(self): return len(self.Q)
+    def PCount(self): return len(self.P)
+    def MaxLevel(self): return len(self.Q) - 1
+    def Gamma(self): return self.gamma
+    def Alpha(self): return self.PCount() // self.gamma                              # params.go:63-65
+    def Beta(self, levelQ): return int(math.ceil((levelQ + 1) / self.Alpha()))       # params.go:67-71
+    def SwkShape(self): return (self.Beta(self.MaxLevel()), self.QCount() + self.PCount(), self._N)
+
+    def GaloisElementForColumnRotationBy(self, k):
+        return pow(GALOIS_GEN, k % (2 * self._N), 2 * self._N)
+
+    def GaloisElementForRowRotation(self):
+        return 2 * self._N - 1
+
+    def Psi(self, i):
+        return int(lib().mkhe_ctx_psi(self.ctx, i))
+
+    def AddCRS(self, idx, host_swk):
+        """params.AddCRS / NewParameters CRS slots (params.go:37-61,77-99): the uniform polys are
+        sampled by the caller (NTT + Montgomery form) and uploaded once."""
+        self.CRS[idx] = SwitchingKey(self, host_swk)
+        return self.CRS[idx]
+
+    def party_index(self, pid):
+        if pid == "0":
+            raise MkheError("Cannot IDSet Add : 0 cannot be used")              # idset.go:12-16
+        if pid not in self._ids:
+            self._ids[pid] = len(self._ids)
+        return self._ids[pid]
+
+    def sync(self):
+        check(lib().mkhe_ctx_sync(self.ctx))
+
+    def stream(self):
+        return lib().mkhe_ctx_stream(self.ctx)
+
+
+class SwitchingKey:
+    """mkrlwe.SwitchingKey (keys.go:23-25): []rlwe.PolyQP of Beta(maxLevel) digits, resident in HBM.
+    Host layout uint64[beta][nQ+nP][N]."""
+
+    def __init__(self, params, host=None):
+        self.params = params
+        h = C.c_void_p()
+        check(lib().mkhe_swk_create(params.ctx, C.byref(h)))
+        self.h = h
+        if host is not None:
+            self.upload(host)
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        if host.shape != self.params.SwkShape():
+            raise MkheError("SwitchingKey: expected shape %r, got %r" % (self.params.SwkShape(), host.shape))
+        check(lib().mkhe_swk_upload(self.params.ctx, self.h, host.ctypes.data_as(_abi.u64p)))
+
+    def download(self):
+        out = np.empty(self.params.SwkShape(), dtype=np.uint64)
+        check(lib().mkhe_swk_download(self.params.ctx, self.h, out.ctypes.data_as(_abi.u64p)))
+        return out
+
+    def devptr(self):
+        return lib().mkhe_swk_devptr(self.h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.params.ctx:
+                lib().mkhe_swk_destroy(self.params.ctx, self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def NewSwitchingKey(params):
+    """keys.go:245-255"""
+    return SwitchingKey(params)
+
+
+class RelinearizationKey:
+    """keys.go:34-37: Value = (b, d, v)."""
+
+    def __init__(self, params, id, b=None, d=None, v=None):
+        self.ID = id
+        self.Value = [SwitchingKey(params, b), SwitchingKey(params, d), SwitchingKey(params, v)]
+
+
+class RelinearizationKeySet:
+    """keys.go:53-57,165-198"""
+
+    def __init__(self, params):
+        self.params = params
+        self.Value = {}
+
+    def AddRelinearizationKey(self, rlk):
+        self.Value[rlk.ID] = rlk
+
+    def DelRelinearizationKey(self, id):
+        self.Value.pop(id, None)
+
+    def GetRelinearizationKey(self, id):
+        if id not in self.Value:
+            raise MkheError("cannot GetRelinearizationKey: there is no relinearization key with given id")
+        return self.Value[id]
+
+
+class RotationKey:
+    """keys.go:40-44"""
+
+    def __init__(self, params, rotidx, id, value=None):
+        self.ID, self.RotIdx = id, int(rotidx)
+        self.Value = SwitchingKey(params, value)
+
+
+class RotationKeySet:
+    """keys.go:60-62,128-162"""
+
+    def __init__(self):
+        self.Value = {}
+
+    def AddRotationKey(self, rk):
+        self.Value.setdefault(rk.ID, {})[rk.RotIdx] = rk
+
+    def GetRotationKey(self, id, rotidx):
+        if id not in self.Value or rotidx not in self.Value[id]:
+            raise MkheError("cannot GetRotationKeys: there is no rotation key with given id")
+        return self.Value[id][rotidx]
+
+
+class ConjugationKey:
+    """keys.go:47-50"""
+
+    def __init__(self, params, id, value=None):
+        self.ID = id
+        self.Value = SwitchingKey(params, value)
+
+
+class ConjugationKeySet:
+    """keys.go:65-67,200-228"""
+
+    def __init__(self):
+        self.Value = {}
+
+    def AddConjugationKey(self, ck):
+        self.Value[ck.ID] = ck
+
+    def GetConjugationKey(self, id):
+        if id not in self.Value:
+            raise MkheError("cannot GetConjugationKey: there is no conjugation key with given id")
+        return self.Value[id]
+
+
+class HoistedCiphertext:
+    """elements.go:5-15: map id -> SwitchingKey holding h(c_id)."""
+
+    def __init__(self):
+        self.Value = {}
+
+
+def NewHoistedCiphertext():
+    return HoistedCiphertext()
+
+
+class Ciphertext:
+    """mkrlwe.Ciphertext (elements.go:17-33): Value["0"] plus one poly per party id, all at the same
+    level, coefficient domain.  Device layout uint64[1+n][level+1][N]; `ids` fixes the slot order."""
+
+    def __init__(self, params, idset, level):
+        self.params = params
+        self.ids = sorted(idset)
+        for i in self.ids:
+            params.party_index(i)
+        self._level = int(level)
+        arr = np.asarray([params.party_index(i) for i in self.ids], dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().mkhe_ct_create(params.ctx, len(self.ids), arr.ctypes.data_as(_abi.i32p), level + 1, C.byref(h)))
+        self.h = h
+
+    def IDSet(self):
+        return set(self.ids)
+
+    def Level(self):
+        return self._level
+
+    def slot(self, id):
+        return 0 if id == "0" else 1 + self.ids.index(id)
+
+    def shape(self):
+        return (1 + len(self.ids), self._level + 1, self.params.N())
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        if host.shape != self.shape():
+            raise MkheError("Ciphertext: expected shape %r, got %r" % (self.shape(), host.shape))
+        check(lib().mkhe_ct_upload(self.params.ctx, self.h, host.ctypes.data_as(_abi.u64p)))
+        return self
+
+    def download(self):
+        out = np.empty(self.shape(), dtype=np.uint64)
+        check(lib().mkhe_ct_download(self.params.ctx, self.h, out.ctypes.data_as(_abi.u64p)))
+        return out
+
+    def set_values(self, value):
+        """value: {"0": poly, id: poly} with polys uint64[level+1][N] (Go: ct.Value[id].Coeffs)."""
+        host = np.zeros(self.shape(), dtype=np.uint64)
+        for k, v in value.items():
+            host[self.slot(k)] = np.asarray(v, dtype=np.uint64)[: self._level + 1]
+        return self.upload(host)
+
+    def values(self):
+        host = self.download()
+        out = {"0": host[0]}
+        for a, i in enumerate(self.ids):
+            out[i] = host[1 + a]
+        return out
+
+    def devptr(self):
+        return lib().mkhe_ct_devptr(self.h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.params.ctx:
+                lib().mkhe_ct_destroy(self.params.ctx, self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def NewCiphertext(params, idset, level):
+    """elements.go:22-33"""
+    return Ciphertext(params, idset, level)
+
+
+class KeySwitcher:
+    """mkrlwe.KeySwitcher (keyswitch.go:8-47).  The scratch pools of the reference (ks.Pool,
+    swkPool1-3, polyQPool) are engine-internal device buffers owned by the context."""
+
+    def __init__(self, params):
+        self.Parameters = params
+        self.ctx = params.ctx
+
+    # -- Decompose (keyswitch.go:49-73)
+    def Decompose(self, levelQ, ct, id, ad, is_ntt=False):
+        check(lib().mkhe_decompose(self.ctx, levelQ, 1 if is_ntt else 0, ct.h, ct.slot(id), ad.h))
+
+    # -- ExternalProduct (keyswitch.go:79-118): c <- ModDown(<h(a), bg>), a = ct.Value[id]
+    def ExternalProduct(self, levelQ, ct, id, bg, out, out_id, is_ntt=False):
+        check(lib().mkhe_external_product(self.ctx, levelQ, 1 if is_ntt else 0, ct.h, ct.slot(id), bg.h,
+                                          out.h, out.slot(out_id)))
+
+    # -- ExternalProductHoisted (keyswitch_hoisted.go:10-40)
+    def ExternalProductHoisted(self, levelQ, aHoisted, bg, out, out_id):
+        check(lib().mkhe_external_product_hoisted(self.ctx, levelQ, aHoisted.h, bg.h, out.h, out.slot(out_id)))
+
+    # -- MulAndRelin (keyswitch.go:122-230)
+    def MulAndRelin(self, op0, op1, rlkSet, ctOut):
+        self.MulAndRelinHoisted(op0, op1, None, None, rlkSet, ctOut)
+
+    # -- MulAndRelinHoisted (keyswitch_hoisted.go:44-179)
+    def MulAndRelinHoisted(self, op0, op1, op0Hoisted, op1Hoisted, rlkSet, ctOut):
+        level = ctOut.Level()
+        if op0.Level() < level:
+            raise MkheError("Cannot MulAndRelin: op0 and op1 have different levels")        # :48-50
+        if op1.Level() < level:
+            raise MkheError("Cannot MulAndRelin: op0 and op1 have different levels")
+        params = self.Parameters
+        if -1 not in params.CRS:
+            raise MkheError("mkhe: CRS[-1] (u) has not been uploaded")
+        d0 = [rlkSet.GetRelinearizationKey(i).Value[1].h for i in op0.ids]
+        v0 = [rlkSet.GetRelinearizationKey(i).Value[2].h for i in op0.ids]
+        b1 = [rlkSet.GetRelinearizationKey(i).Value[0].h for i in op1.ids]
+        h0 = [op0Hoisted.Value[i].h for i in op0.ids] if op0Hoisted is not None else None
+        if op1Hoisted is op0Hoisted and op1 is op0:
+            h1 = h0
+        else:
+            h1 = [op1Hoisted.Value[i].h for i in op1.ids] if op1Hoisted is not None else None
+        a_h0 = handle_array(h0)
+        a_h1 = a_h0 if h1 is h0 else handle_array(h1)
+        check(lib().mkhe_mul_and_relin(self.ctx, op0.h, op1.h, a_h0, a_h1, handle_array(b1), handle_array(d0),
+                                       handle_array(v0), params.CRS[-1].h, ctOut.h))
+
+    def _rotidx(self, rotidx):
+        n2 = self.Parameters.N() // 2
+        while rotidx < 0:
+            rotidx += n2                                                                     # keyswitch.go:246-249
+        return rotidx
+
+    # -- Rotate (keyswitch.go:234-298)
+    def Rotate(self, ctIn, rotidx, rkSet, ctOut):
+        self.RotateHoisted(ctIn, rotidx, None, rkSet, ctOut)
+
+    # -- RotateHoisted (keyswitch_hoisted.go:183-247)
+    def RotateHoisted(self, ctIn, rotidx, ctInHoisted, rkSet, ctOut):
+        params = self.Parameters
+        if ctIn.Level() < ctOut.Level():
+            raise MkheError("Cannot Rotate: ctIn and ctOut have different levels")
+        rotidx = self._rotidx(rotidx)
+        if rotidx not in params.CRS:
+            raise MkheError("mkhe: no CRS for rotation index %d" % rotidx)
+        rk = [rkSet.GetRotationKey(i, rotidx).Value.h for i in ctIn.ids]
+        hs = [ctInHoisted.Value[i].h for i in ctIn.ids] if ctInHoisted is not None else None
+        galEl = params.GaloisElementForColumnRotationBy(rotidx)
+        check(lib().mkhe_rotate(self.ctx, galEl, ctIn.h, handle_array(hs), handle_array(rk), params.CRS[rotidx].h, ctOut.h))
+
+    # -- Conjugate (keyswitch.go:302-332)
+    def Conjugate(self, ctIn, ckSet, ctOut):
+        params = self.Parameters
+        if ctIn.Level() < ctOut.Level():
+            raise MkheError("Cannot Conjugate: ctIn and ctOut have different levels")
+        ck = [ckSet.GetConjugationKey(i).Value.h for i in ctIn.ids]
+        check(lib().mkhe_conjugate(self.ctx, params.GaloisElementForRowRotation(), ctIn.h, handle_array(ck),
+                                   params.CRS[-2].h, ctOut.h))
+
+
+def NewKeySwitcher(params):
+    return KeySwitcher(params)
+
+
+# ---- raw device buffers for ring-level calls (tests / bench of the NTT kernel)
+class DeviceLimbs:
+    """uint64[count][limbs][N] raw device buffer (mkhe_buf_*)."""
+
+    def __init__(self, params, count, limbs):
+        self.params, self.count, self.limbs = params, count, limbs
+        self.words = count * limbs * params.N()
+        d = C.c_void_p()
+        check(lib().mkhe_buf_alloc(params.ctx, self.words, C.byref(d)))
+        self.d = d
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.uint64)
+        assert host.shape == (self.count, self.limbs, self.params.N())
+        check(lib().mkhe_buf_upload(self.params.ctx, self.d, host.ctypes.data_as(_abi.u64p), self.words))
+        return self
+
+    def download(self):
+        out = np.empty((self.count, self.limbs, self.params.N()), dtype=np.uint64)
+        check(lib().mkhe_buf_download(self.params.ctx, self.d, out.ctypes.data_as(_abi.u64p), self.words))
+        return out
+
+    def devptr(self):
+        return self.d
+
+    def __del__(self):
+        try:
+            if getattr(self, "d", None) and self.params.ctx:
+                lib().mkhe_buf_free(self.params.ctx, self.d)
+                self.d = None
+        except Exception:
+            pass
+
+
+def ntt(params, src, dst, mod_base=0, inverse=False, lazy=False):
+    """ring.NTTLvl / InvNTTLvl / InvNTTLazyLvl on DeviceLimbs buffers (limb l under modulus mod_base+l)."""
+    assert src.count == dst.count and src.limbs == dst.limbs
+    check(lib().mkhe_ntt(params.ctx, src.devptr(), dst.devptr(), src.count, src.limbs, mod_base,
+                         1 if inverse else 0, 1 if lazy else 0))
