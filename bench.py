@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- MK-CKKS MulRelin/sec on MI355X (BASELINE.json metric) + NTT roofline + CPU baseline.
+
+A "step" is one mkckks.Evaluator.MulRelinNew on synthetic k-party ciphertexts:
+hoisting of both operands (Decompose), KeySwitcher.MulAndRelinHoisted and Rescale -- the timed
+region of the reference benchmark (mkckks/mkckks_benchmark_test.go:78-82), all inputs and keys
+resident in HBM when the clock starts.
+
+  python bench.py --gpus 1 --steps K --warmup W          (default workload = configs[1])
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROF_NAMES = ["ntt_fwd_decompose", "ntt_fwd", "ntt_inv", "inner_product", "moddown", "tensor", "other"]
+
+
+def synth_inputs(pset, parties, seed):
+    """uniform residues per limb: ciphertexts, rlk (b,d,v) per party, CRS u."""
+    import harness as H
+    rng = np.random.default_rng(seed)
+    Q, P, N = pset["Q"], pset["P"], 1 << pset["logN"]
+    beta, m = len(Q), len(Q) + len(P)          # alpha = 1
+
+    def swk():
+        out = np.empty((beta, m, N), dtype=np.uint64)
+        for i in range(beta):
+            for j, q in enumerate(Q + P):
+                out[i, j] = rng.integers(0, q, N, dtype=np.uint64)
+        return out
+
+    def ct():
+        return np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q]) for _ in range(1 + parties)])
+
+    return dict(op0=ct(), op1=ct(), rlk=[(swk(), swk(), swk()) for _ in range(parties)], u=swk())
+
+
+def run_single(args):
+    import harness as H
+    from mkhe_kklss_amd import mkrlwe, mkckks
+    from mkhe_kklss_amd._abi import check, lib
+
+    pset = H.PN15QP880 if args.params == "PN15QP880" else H.PN14QP439
+    k = args.parties
+    names = ["user%d" % i for i in range(k)]
+    data = synth_inputs(pset, k, args.seed)
+    params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"], device=0)
+    level = len(pset["Q"]) - 1
+    ct0 = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(data["op0"])
+    ct1 = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(data["op1"])
+    rlk = mkrlwe.RelinearizationKeySet(params)
+    for n, (b, d, v) in zip(names, data["rlk"]):
+        rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, n, b, d, v))
+    params.AddCRS(-1, data["u"])
+    ev = mkckks.NewEvaluator(params)
+
+    def step():
+        return ev.MulRelinNew(ct0, ct1, rlk)
+
+    for _ in range(args.warmup):
+        res = step()
+    params.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    params.sync()
+    dt = time.perf_counter() - t0
+    ms_per_step = dt * 1e3 / args.steps
+    value = args.steps / dt
+
+    # ---- roofline leg: per-kernel HIP-event timing on the context stream, same steps again
+    ncls = lib().mkhe_prof_nclass()
+    check(lib().mkhe_prof_enable(params.ctx, 1))
+    for _ in range(args.steps):
+        res = step()
+    ms = (C.c_double * ncls)()
+    cnt = (C.c_long * ncls)()
+    byt = (C.c_double * ncls)()
+    check(lib().mkhe_prof_collect(params.ctx, ms, cnt, byt))
+    check(lib().mkhe_prof_enable(params.ctx, 0))
+    kernels = {}
+    for i in range(ncls):
+        if cnt[i]:
+            kernels[PROF_NAMES[i]] = dict(launches_per_step=cnt[i] / args.steps, ms_per_step=ms[i] / args.steps,
+                                          avg_launch_us=1e3 * ms[i] / cnt[i],
+                                          achieved_GBs=byt[i] / (ms[i] * 1e-3) / 1e9)
+    dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+    di = PROF_NAMES.index(dom)
+    achieved = byt[di] / (ms[di] * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    alg_bytes_per_launch=byt[di] / cnt[di], avg_launch_us=1e3 * ms[di] / cnt[di],
+                    kernels=kernels)
+
+    # ---- CPU baseline: the oracle (single-thread C restatement of the Go path) on the same inputs
+    cpu = None
+    if not args.no_cpu:
+        from oracle import oracle as O
+        ks = O.KeySwitcher(pset["logN"], pset["Q"], pset["P"], 2)
+        ids = list(range(k))
+        rl = {i: data["rlk"][i] for i in ids}
+        reps = max(1, args.cpu_reps)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            _, ref = ks.mul_and_relin(level, ids, data["op0"], ids, data["op1"], rl, data["u"])
+            ref = np.stack([ks.ringQ.div_round_last_many(ref[s], 1)[0] for s in range(1 + k)])
+        cdt = time.perf_counter() - t0
+        same = bool((res.download() == ref).all())
+        cpu = dict(value=reps / cdt, unit="MulRelin/s", cores=1, kind="port",
+                   sample="%d full %d-party MulRelin (%s) on 1 host thread, %.1f s" % (reps, k, args.params, cdt),
+                   bit_exact_vs_gpu=same)
+    return dict(metric="mkckks_mulrelin_per_sec", value=value, unit="MulRelin/s", n_gpus=1, steps=args.steps,
+                warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
+                vs_baseline=None, dtype="u64", data="synthetic",
+                config=dict(workload="mkckks %d-party MulRelin (hoist + MulAndRelinHoisted + Rescale), %s N=2^%d, %d Q + %d P limbs"
+                            % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["P"])),
+                            parties=k, params=args.params, seed=args.seed),
+                roofline=roofline, cpu_baseline=cpu)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--parties", type=int, default=4)
+    ap.add_argument("--params", default="PN15QP880", choices=["PN15QP880", "PN14QP439"])
+    ap.add_argument("--seed", type=int, default=0x4D4B4845)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=2)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from bench_dist import run_distributed
+        out = run_distributed(args)
+    else:
+        out = run_single(args)
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

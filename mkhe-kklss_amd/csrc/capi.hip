@@ -238,4 +238,10 @@ int mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out) {
     MKHE_TRY(ctx->c->rescale(in->c, nb, out->c))
 }
 
+int mkhe_prof_enable(mkhe_ctx* ctx, int on) { MKHE_TRY(ctx->c->prof_enable(on != 0)) }
+int mkhe_prof_nclass(void) { return Context::PROF_NCLASS; }
+int mkhe_prof_collect(mkhe_ctx* ctx, double* ms, long* launches, double* alg_bytes) {
+    MKHE_TRY(ctx->c->prof_collect(ms, launches, alg_bytes))
+}
+
 }  // extern "C"

@@ -24,6 +24,8 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 struct Swk { u64* d = nullptr; bool owned = true; };
 // device ciphertext: uint64[1+n][limbs][N], slot 0 = c_0, slot 1+i = party ids[i]
 struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
+// one external product of a batch: dst (+)= ModDown_P( sum_i bg[i] (.) ah[i] )
+struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; };
 
 class Context {
   public:
@@ -55,8 +57,16 @@ class Context {
     void conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk& crs, Ct& out);
     // mkckks Rescale body: nb successive DivRoundByLastModulus on every poly (evaluator.go:385-391)
     void rescale(const Ct& in, int nb, Ct& out);
+    // batched building blocks (all parties in one launch)
+    void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst);
+    void ext_batch(int level, const std::vector<ExtItem>& items);
 
     void sync() { MKHE_HIP(hipStreamSynchronize(stream)); }
+
+    // ---- per-kernel-class timing with HIP events on the context stream (bench.py roofline leg)
+    enum { PROF_NTT_DECOMP = 0, PROF_NTT_FWD, PROF_NTT_INV, PROF_INNER, PROF_MODDOWN, PROF_TENSOR, PROF_OTHER, PROF_NCLASS };
+    void prof_enable(bool on);
+    void prof_collect(double* ms, long* launches, double* alg_bytes);   // arrays of PROF_NCLASS; syncs and resets
 
     // device tables (public for the C ABI accessors / tests)
     Mod* d_mods = nullptr;
@@ -73,13 +83,30 @@ class Context {
     u64* invntt_ = nullptr;                                  // ks.PoolInvNTT
     u64* nttbuf_ = nullptr; size_t nttbuf_words_ = 0;        // tensor inputs in NTT form
     u64* ctbuf_ = nullptr;  size_t ctbuf_words_ = 0;         // rotate / rescale staging
-    std::vector<Swk> hoist_pool_[2];                         // rlkSet.HoistPool[0/1]
+    std::vector<Swk> hoist_pool_[3];                         // rlkSet.HoistPool[0/1] + h(t_i) of step F
+    u64* c1b_ = nullptr;   size_t c1b_words_ = 0;           // batched ks.Pool[1]
+    u64* tbuf_ = nullptr;  size_t tbuf_words_ = 0;          // t_i of step F
 
     u64* scratch(u64*& p, size_t& have, size_t want);
     Swk& hoist_slot(int which, int idx);
     const int* map_qp(int level) const { return d_map_qp + (size_t)level * mtot; }
     void check_level(int level) const;
+    void slots_qp(NttBatch& b, int level) const;
+    void slots_range(NttBatch& b, int mod_base, int limbs) const;
+    std::vector<unsigned char> small_q_;                     // per modulus: 34q < 2^63
     void ext_core(int level, const u64* ah, const u64* bg, u64* c, bool accumulate);
+
+    struct ProfRec { hipEvent_t e0, e1; int cls; double bytes; };
+    bool prof_on_ = false;
+    std::vector<ProfRec> prof_recs_;
+    std::vector<hipEvent_t> prof_pool_;
+    hipEvent_t prof_event();
+  public:
+    struct ProfScope {
+        Context* c; size_t idx; bool on;
+        ProfScope(Context* c_, int cls, double bytes);
+        ~ProfScope();
+    };
 };
 
 }  // namespace mkhe

@@ -77,6 +77,8 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
         if (q >= (1ull << 61) || !is_prime(q) || (q - 1) % (2ull * N) != 0) throw Error("mkhe: moduli must be primes < 2^61 with q = 1 mod 2N");
         for (int j = 0; j < i; ++j) if (moduli[j] == q) throw Error("mkhe: repeated modulus");
     }
+    if (mtot > NTT_MAX_SLOTS) throw Error("mkhe: too many moduli");
+    for (int i = 0; i < mtot; ++i) small_q_.push_back(moduli[i] < (1ull << 57) ? 1 : 0);   // 34q < 2^63
     MKHE_HIP(hipSetDevice(device));
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
@@ -153,7 +155,7 @@ Context::~Context() {
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
                     (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
-                    (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_})
+                    (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_})
         if (p) (void)hipFree(p);
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
     if (stream) (void)hipStreamDestroy(stream);
@@ -175,15 +177,54 @@ void Context::check_level(int level) const {
     if (level < 0 || level >= nq) throw Error("mkhe: level out of range");
 }
 
+// ------------------------------------------------------------------ profiling
+hipEvent_t Context::prof_event() {
+    if (!prof_pool_.empty()) { hipEvent_t e = prof_pool_.back(); prof_pool_.pop_back(); return e; }
+    hipEvent_t e; MKHE_HIP(hipEventCreate(&e)); return e;
+}
+Context::ProfScope::ProfScope(Context* c_, int cls, double bytes) : c(c_), idx(0), on(c_->prof_on_) {
+    if (!on) return;
+    ProfRec r{c->prof_event(), c->prof_event(), cls, bytes};
+    (void)hipEventRecord(r.e0, c->stream);
+    idx = c->prof_recs_.size();
+    c->prof_recs_.push_back(r);
+}
+Context::ProfScope::~ProfScope() { if (on) (void)hipEventRecord(c->prof_recs_[idx].e1, c->stream); }
+void Context::prof_enable(bool on) { sync(); prof_on_ = on; }
+void Context::prof_collect(double* ms, long* launches, double* alg_bytes) {
+    sync();
+    for (int i = 0; i < PROF_NCLASS; ++i) { ms[i] = 0; launches[i] = 0; alg_bytes[i] = 0; }
+    for (auto& r : prof_recs_) {
+        float t = 0; MKHE_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+        ms[r.cls] += t; launches[r.cls] += 1; alg_bytes[r.cls] += r.bytes;
+        prof_pool_.push_back(r.e0); prof_pool_.push_back(r.e1);
+    }
+    prof_recs_.clear();
+}
+
+// slot lists of an NttBatch: limbs 0..level of Q then every P limb (PolyQP shaped buffers) ...
+void Context::slots_qp(NttBatch& b, int level) const {
+    b.nslots = level + 1 + np;
+    for (int j = 0; j <= level; ++j) { b.mod[j] = j; b.pos[j] = j; }
+    for (int j = 0; j < np; ++j) { b.mod[level + 1 + j] = nq + j; b.pos[level + 1 + j] = level + 1 + j; }
+}
+// ... or `limbs` consecutive moduli starting at mod_base (plain polynomials)
+void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
+    b.nslots = limbs;
+    for (int j = 0; j < limbs; ++j) { b.mod[j] = mod_base + j; b.pos[j] = j; }
+}
+
 // ------------------------------------------------------------------ ring level
 void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, bool inverse, bool lazy) {
     if (mod_base < 0 || mod_base + limbs > mtot) throw Error("mkhe: ntt modulus range");
     NttBatch b{};
     b.src = src; b.dst = dst; b.mods = d_mods; b.psi = inverse ? d_psiinv : d_psi; b.aux = d_inv_aux;
-    b.map = d_map_id + mod_base;
+    if (limbs > NTT_MAX_SLOTS) throw Error("mkhe: too many limbs per polynomial");
+    slots_range(b, mod_base, limbs);
     b.src_outer = b.dst_outer = (long)limbs * N; b.src_inner = b.dst_inner = N;
-    b.inner_count = limbs; b.njobs = count * limbs; b.lazy_out = lazy ? 1 : 0;
-    if (inverse) launch_ntt_inv(logN, b, stream); else launch_ntt_fwd(logN, b, stream);
+    b.nouter = count; b.lazy_out = lazy ? 1 : 0;
+    ProfScope ps(this, inverse ? PROF_NTT_INV : PROF_NTT_FWD, 16.0 * N * count * limbs);
+    if (inverse) launch_ntt_inv(logN, b, stream); else launch_ntt_fwd(logN, b, small_q_.data(), stream);
     MKHE_HIP(hipGetLastError());
 }
 
@@ -197,13 +238,12 @@ void Context::decompose(int level, bool is_ntt, const u64* a, u64* out_swk) {
     // fused with the forward NTT (DecomposeSingleNTT, keyswitch.go:21-31).
     NttBatch b{};
     b.src = ainv; b.dst = out_swk; b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux;
-    b.map = map_qp(level);
-    b.inner_count = level + 1 + np;
+    slots_qp(b, level);
     b.src_outer = N; b.src_inner = 0; b.src_mapped = 0;
     b.dst_outer = (long)mtot * N; b.dst_inner = N; b.dst_mapped = 1;
-    b.njobs = beta(level) * b.inner_count;
+    b.nouter = beta(level);
     b.reduce_in = 1; b.reduce_src_mod_is_outer = 1;
-    launch_ntt_fwd(logN, b, stream);
+    { ProfScope ps(this, PROF_NTT_DECOMP, 16.0 * N * b.nouter * b.nslots); launch_ntt_fwd(logN, b, small_q_.data(), stream); }
     MKHE_HIP(hipGetLastError());
 }
 
@@ -215,19 +255,19 @@ void Context::ext_core(int level, const u64* ah, const u64* bg, u64* c, bool acc
     for (int i = 0; i < nb; ++i) { ip.a[i] = bg + (size_t)i * mtot * N; ip.b[i] = ah + (size_t)i * mtot * N; }
     ip.out = c1_; ip.mods = d_mods; ip.map = map_qp(level);
     ip.term_outer = 0; ip.out_outer = 0; ip.nterms = nb; ip.nslots = nslots; ip.nouter = 1; ip.N = N; ip.mform_out = 0;
-    launch_inner_product(ip, stream);
+    { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * (2.0 * nb + 1)); launch_inner_product(ip, stream); }
 
     NttBatch b{};
-    b.src = c1_; b.dst = c1_; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; b.map = map_qp(level);
-    b.inner_count = nslots; b.njobs = nslots; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
+    b.src = c1_; b.dst = c1_; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
+    b.nouter = 1; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
     b.lazy_out = 1;
-    launch_ntt_inv(logN, b, stream);
+    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * nslots); launch_ntt_inv(logN, b, stream); }
 
     ModDownArgs md{};
     md.xq = c1_; md.xp = c1_ + (size_t)nq * N; md.dst = c; md.mods_q = d_mods; md.mods_p = d_mods + nq;
     md.t = ModDownTables{d_md_qoverqiinvqi, d_md_qoverqimodp, d_md_vtimes, d_md_down};
     md.level = level; md.np = np; md.N = N; md.accumulate = accumulate ? 1 : 0; md.nbatch = 1;
-    launch_moddown(md, stream);
+    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * ((level + 1) * (accumulate ? 3.0 : 2.0) + np)); launch_moddown(md, stream); }
     MKHE_HIP(hipGetLastError());
 }
 void Context::external_product_hoisted(int level, const u64* ah, const u64* bg, u64* c, bool accumulate) {
@@ -238,6 +278,61 @@ void Context::external_product(int level, bool is_ntt, const u64* a, const u64* 
     check_level(level);
     decompose(level, is_ntt, a, swk3_);
     ext_core(level, swk3_, bg, c, accumulate);
+}
+
+// ------------------------------------------------------------------ batched forms (one launch for all parties)
+void Context::decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst) {
+    check_level(level);
+    if (alpha != 1) throw Error("mkhe: gadget decomposition with alpha >= 2 (CRT reconstruction) is not implemented on the device yet");
+    const int per = level + 1 + np, nb = beta(level);
+    for (size_t base = 0; base < src.size(); base += NTT_MAX_ITEMS) {
+        const int n = (int)std::min<size_t>(NTT_MAX_ITEMS, src.size() - base);
+        NttBatch b{};
+        b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);
+        b.src_outer = N; b.src_inner = 0; b.src_mapped = 0;
+        b.dst_outer = (long)mtot * N; b.dst_inner = N; b.dst_mapped = 1;
+        b.reduce_in = 1; b.reduce_src_mod_is_outer = 1;
+        b.nitems = n; b.outers_per_item = nb;
+        for (int i = 0; i < n; ++i) { b.src_items[i] = src[base + i]; b.dst_items[i] = dst[base + i]; }
+        b.nouter = n * nb;
+        ProfScope ps(this, PROF_NTT_DECOMP, 16.0 * N * n * nb * per);
+        launch_ntt_fwd(logN, b, small_q_.data(), stream);
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
+// items: independent external products  dst (+)= ModDown( sum_i bg[i] (.) ah[i] )
+void Context::ext_batch(int level, const std::vector<ExtItem>& items) {
+    check_level(level);
+    const int nb = beta(level), nslots = level + 1 + np;
+    const size_t item_words = (size_t)mtot * N;
+    for (size_t base = 0; base < items.size(); base += EXT_MAX_ITEMS) {
+        const int n = (int)std::min<size_t>(EXT_MAX_ITEMS, items.size() - base);
+        u64* c1 = scratch(c1b_, c1b_words_, (size_t)n * item_words);
+        ExtInnerArgs ia{};
+        for (int i = 0; i < n; ++i) { ia.ah[i] = items[base + i].ah; ia.bg[i] = items[base + i].bg; }
+        ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
+        ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
+        { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * (2.0 * nb + 1) * n); launch_ext_inner(ia, stream); }
+
+        NttBatch b{};
+        b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
+        b.nouter = n; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
+        b.src_outer = b.dst_outer = (long)item_words; b.lazy_out = 1;
+        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, stream); }
+
+        ModDownBatchArgs md{};
+        md.c1 = c1; md.mods_q = d_mods; md.mods_p = d_mods + nq;
+        md.t = ModDownTables{d_md_qoverqiinvqi, d_md_qoverqimodp, d_md_vtimes, d_md_down};
+        md.c1_item = (long)item_words; md.p_offset = (long)nq * N; md.nitems = n; md.level = level; md.np = np; md.N = N;
+        double bytes = 0;
+        for (int i = 0; i < n; ++i) {
+            md.dst[i] = items[base + i].dst; md.accumulate[i] = items[base + i].accumulate ? 1 : 0;
+            bytes += 8.0 * N * ((level + 1) * (items[base + i].accumulate ? 3.0 : 2.0) + np);
+        }
+        { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_batch(md, stream); }
+    }
+    MKHE_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------ MulAndRelin[Hoisted]
@@ -259,17 +354,21 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
     for (int o = 0; o < out.n; ++o) if (!ta.slot0[1 + o] && !ta.slot1[1 + o]) throw Error("mkhe: ctOut has an id that neither operand has");
 
     const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N, PO = (size_t)L * N;
-    // hoist the operands when the caller did not (MulRelinNew, mkckks/evaluator.go:416-443)
+    // hoist the operands when the caller did not (MulRelinNew, mkckks/evaluator.go:416-443): one launch
     std::vector<const u64*> h0(n0), h1(n1);
     const bool same = (&op0 == &op1) && hoist0 == hoist1;
-    for (int a = 0; a < n0; ++a) {
-        if (hoist0) { if (!hoist0[a]) throw Error("mkhe: missing hoisted form"); h0[a] = hoist0[a]->d; }
-        else { Swk& s = hoist_slot(0, a); decompose(level, false, op0.d + (1 + a) * P0, s.d); h0[a] = s.d; }
-    }
-    for (int a = 0; a < n1; ++a) {
-        if (hoist1) { if (!hoist1[a]) throw Error("mkhe: missing hoisted form"); h1[a] = hoist1[a]->d; }
-        else if (same) h1[a] = h0[a];
-        else { Swk& s = hoist_slot(1, a); decompose(level, false, op1.d + (1 + a) * P1, s.d); h1[a] = s.d; }
+    {
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (int a = 0; a < n0; ++a) {
+            if (hoist0) { if (!hoist0[a]) throw Error("mkhe: missing hoisted form"); h0[a] = hoist0[a]->d; }
+            else { Swk& s = hoist_slot(0, a); dsrc.push_back(op0.d + (1 + a) * P0); ddst.push_back(s.d); h0[a] = s.d; }
+        }
+        for (int a = 0; a < n1; ++a) {
+            if (hoist1) { if (!hoist1[a]) throw Error("mkhe: missing hoisted form"); h1[a] = hoist1[a]->d; }
+            else if (same) h1[a] = h0[a];
+            else { Swk& s = hoist_slot(1, a); dsrc.push_back(op1.d + (1 + a) * P1); ddst.push_back(s.d); h1[a] = s.d; }
+        }
+        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst);
     }
     const int nb = beta(level), nslots = L + np;
     // B, C: x = MForm(sum_i d_i (.) h(c0_i)),  y = MForm(sum_j b_j (.) h(c1_j))
@@ -283,32 +382,41 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
         }
         ip.out = side ? y_ : x_; ip.mods = d_mods; ip.map = map_qp(level);
         ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nb; ip.N = N; ip.mform_out = 1;
-        launch_inner_product(ip, stream);
+        { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nb * (2.0 * n + 1)); launch_inner_product(ip, stream); }
     }
     // D: tensor product in the NTT domain, back to coefficients
     u64* nb_ = scratch(nttbuf_, nttbuf_words_, (size_t)(2 + n0 + n1) * PO);
     {
         NttBatch b{};
-        b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; b.map = d_map_id; b.inner_count = L;
+        b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_range(b, 0, L);
         b.src_inner = b.dst_inner = N; b.dst_outer = (long)PO;
-        b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.njobs = (1 + n0) * L;
-        launch_ntt_fwd(logN, b, stream);
-        b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.njobs = (1 + n1) * L;
-        launch_ntt_fwd(logN, b, stream);
+        b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.nouter = 1 + n0;
+        { ProfScope ps(this, PROF_NTT_FWD, 16.0 * N * b.nouter * L); launch_ntt_fwd(logN, b, small_q_.data(), stream); }
+        b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.nouter = 1 + n1;
+        { ProfScope ps(this, PROF_NTT_FWD, 16.0 * N * b.nouter * L); launch_ntt_fwd(logN, b, small_q_.data(), stream); }
     }
     ta.ntt = nb_; ta.out = out.d; ta.mods = d_mods; ta.n0 = n0; ta.n1 = n1; ta.nout = out.n; ta.L = L; ta.N = N;
-    launch_tensor(ta, stream);
+    { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, stream); }
     ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
-    // E: out_j += <h(c1_j), x>_P
-    for (int a = 0; a < n1; ++a) ext_core(level, h1[a], x_, out.d + (size_t)(1 + slot1[a]) * PO, true);
-    // F: t = <h(c0_i), y>_P ; out_0 += <h(t), v_i>_P ; out_i += <h(t), u>_P
+    // E: out_j += <h(c1_j), x>_P   and   F1: t_i = <h(c0_i), y>_P   (2k independent products, one batch)
+    u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
+    std::vector<ExtItem> items;
+    for (int a = 0; a < n1; ++a) items.push_back(ExtItem{h1[a], x_, out.d + (size_t)(1 + slot1[a]) * PO, true});
+    for (int a = 0; a < n0; ++a) items.push_back(ExtItem{h0[a], y_, tbuf + (size_t)a * PO, false});
+    ext_batch(level, items);
+    // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
+    {
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
+        if (n0) decompose_batch(level, dsrc, ddst);
+    }
+    items.clear();
     for (int a = 0; a < n0; ++a) {
         if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-        ext_core(level, h0[a], y_, polyq_[0], false);
-        decompose(level, false, polyq_[0], swk3_);
-        ext_core(level, swk3_, rlk_v0[a]->d, out.d, true);
-        ext_core(level, swk3_, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PO, true);
+        items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
+        items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PO, true});
     }
+    ext_batch(level, items);
     MKHE_HIP(hipGetLastError());
 }
 
@@ -322,14 +430,22 @@ void Context::rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk
     const size_t PI = (size_t)in.limbs * N, PO = (size_t)L * N;
     u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * PO);
     MKHE_HIP(hipMemcpyAsync(tmp, in.d, PO * sizeof(u64), hipMemcpyDeviceToDevice, stream));
-    for (int a = 0; a < n; ++a) {
-        if (!rk[a]) throw Error("cannot GetRotationKeys: there is no rotation key with given id");
-        const u64* h;
-        if (hoist) { if (!hoist[a]) throw Error("mkhe: missing hoisted form"); h = hoist[a]->d; }
-        else { Swk& s = hoist_slot(0, a); decompose(level, false, in.d + (1 + a) * PI, s.d); h = s.d; }
-        ext_core(level, h, rk[a]->d, tmp, true);
-        ext_core(level, h, crs.d, tmp + (size_t)(1 + a) * PO, false);
+    std::vector<const u64*> h(n);
+    {
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (int a = 0; a < n; ++a) {
+            if (!rk[a]) throw Error("cannot GetRotationKeys: there is no rotation key with given id");
+            if (hoist) { if (!hoist[a]) throw Error("mkhe: missing hoisted form"); h[a] = hoist[a]->d; }
+            else { Swk& s = hoist_slot(0, a); dsrc.push_back(in.d + (1 + a) * PI); ddst.push_back(s.d); h[a] = s.d; }
+        }
+        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst);
     }
+    std::vector<ExtItem> items;
+    for (int a = 0; a < n; ++a) {
+        items.push_back(ExtItem{h[a], rk[a]->d, tmp, true});
+        items.push_back(ExtItem{h[a], crs.d, tmp + (size_t)(1 + a) * PO, false});
+    }
+    ext_batch(level, items);
     launch_automorphism(out.d, tmp, d_mods, L, logN, galEl, 1 + n, stream);
     MKHE_HIP(hipGetLastError());
 }

@@ -26,26 +26,37 @@
 
 namespace mkhe {
 
-// How job j of a batched launch finds its limb.  job = outer * inner_count + s ;
-// m = map[s] is the modulus index (and the limb slot inside a PolyQP-shaped buffer).
+constexpr int NTT_MAX_ITEMS = 64;
+constexpr int NTT_MAX_SLOTS = 48;
+
+// How job j of a batched launch finds its limb.  Jobs are slot-major: s = j / nouter selects the
+// limb slot (modulus mod[s], position pos[s] inside a plain polynomial), outer = j % nouter the
+// polynomial / gadget digit, optionally grouped in items with their own base pointers.
+// The small lists live in the kernel-argument segment and are read with scalar loads.
 struct NttBatch {
     const u64* src;
     u64* dst;
     const Mod* mods;        // [nmod]
     const u64* psi;         // [nmod][N] Montgomery, bit-reversed (forward or inverse table)
     const u64* aux;         // inverse: [nmod][2] = {N^-1 * R, psiinv[1] * N^-1 * R}
-    const int* map;         // [inner_count]
-    long src_outer, src_inner;   // word strides; src limb = src + outer*src_outer + (src_mapped ? m : s)*src_inner
+    long src_outer, src_inner;   // word strides; limb = base + outer*src_outer + (src_mapped ? mod[s] : pos[s])*src_inner
     long dst_outer, dst_inner;
-    int inner_count;
-    int njobs;
+    int nslots;             // limb slots in this launch
+    int nouter;             // polynomials (or items * digits) in this launch
     int src_mapped, dst_mapped;
     int reduce_in;          // forward only: input is a digit spread under a foreign modulus (Decompose)
     int reduce_src_mod_is_outer;   // the digit's own modulus index = outer (alpha = 1)
     int lazy_out;           // inverse only: leave [0,2q) (InvNTTLazy)
+    int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists
+    int mod[NTT_MAX_SLOTS];
+    int pos[NTT_MAX_SLOTS];
+    const u64* src_items[NTT_MAX_ITEMS];
+    u64* dst_items[NTT_MAX_ITEMS];
 };
 
-void launch_ntt_fwd(int logN, const NttBatch& b, hipStream_t st);
+// small_q[m] != 0 marks moduli with 34q < 2^63 (forward NTT without in-loop reductions); the
+// launcher splits the slots of `b` into one launch per class.
+void launch_ntt_fwd(int logN, const NttBatch& b, const unsigned char* small_q, hipStream_t st);
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st);
 
 }  // namespace mkhe

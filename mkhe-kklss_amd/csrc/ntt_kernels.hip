@@ -1,7 +1,20 @@
 // ntt_kernels.hip -- see ntt_kernels.h for the design.
+//
+// v2 structure notes (measured on MI355X, profiles/r1_*):
+//  * one runtime loop over the three radix-32 phases shares the unrolled stage code, so the whole
+//    kernel stays inside the instruction cache (the fully unrolled v1 was ~72 KB of straight-line code);
+//  * only the A<->B re-distribution crosses waves (s_barrier); B<->C is half-wave local and uses
+//    wave-level ordering only, so waves drift apart and LDS traffic overlaps other waves' VALU work;
+//  * forward butterflies skip the conditional subtraction entirely when 34q < 2^63 (all 54-bit
+//    primes of the shipped parameter sets): values then grow by 2q per stage and are normalised
+//    once at the end with a Montgomery product by R mod q;
+//  * all pointers are address_space(1) so loads are global_load (vmcnt only), never flat_load.
 #include "ntt_kernels.h"
 
 namespace mkhe {
+
+typedef const __attribute__((address_space(1))) u64* gcptr;
+typedef __attribute__((address_space(1))) u64* gptr;
 
 // ------------------------------------------------------------------ layouts
 template <int LOGN> struct Geo {
@@ -10,6 +23,7 @@ template <int LOGN> struct Geo {
     static constexpr int BT = T < 64 ? 64 : T;        // block size
     static constexpr int LPB = BT / T;                // limbs per block
     static constexpr int MIDTOP = (LOGN - 6) < 9 ? (LOGN - 6) : 9;   // highest bit handled by the middle phase
+    static constexpr int MIDB = MIDTOP - 5;           // highest register bit with work in the middle phase (-1: none)
     static constexpr bool HAS_MID = MIDTOP >= 5;
 };
 
@@ -25,34 +39,53 @@ template <int LOGN, int L> __device__ __forceinline__ int pos(int t, int r) {
     else return posC(t, r);
 }
 
+// ordering point between LDS phases: workgroup barrier when the exchange crosses waves, otherwise
+// only a compiler/wave-level fence (DS operations of one wave execute in issue order).
+template <bool CROSS> __device__ __forceinline__ void lds_sync() {
+    if constexpr (CROSS) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+}
+
 // Re-distribute the 32 registers of every thread from layout FROM to layout TO through LDS,
-// one 32-bit plane at a time.
-template <int LOGN, int FROM, int TO>
+// one 32-bit plane at a time (N*4 bytes of LDS per limb).
+template <int LOGN, int FROM, int TO, bool CROSS>
 __device__ __forceinline__ void exchange(u64 (&x)[32], u32* lds, int t) {
-    u32 lo[32];
+    // the thread index is made opaque before every pass so that the 64 LDS addresses are recomputed
+    // (2 VALU each) instead of being kept live across the four passes (VGPR budget is 128)
+    asm volatile("" : "+v"(t));
 #pragma unroll
     for (int r = 0; r < 32; ++r) lds[swz(pos<LOGN, FROM>(t, r))] = lo32(x[r]);
-    __syncthreads();
+    lds_sync<CROSS>();
+    asm volatile("" : "+v"(t));
 #pragma unroll
-    for (int r = 0; r < 32; ++r) lo[r] = lds[swz(pos<LOGN, TO>(t, r))];
-    __syncthreads();
+    for (int r = 0; r < 32; ++r) x[r] = (x[r] & 0xffffffff00000000ull) | lds[swz(pos<LOGN, TO>(t, r))];
+    lds_sync<CROSS>();
+    asm volatile("" : "+v"(t));
 #pragma unroll
     for (int r = 0; r < 32; ++r) lds[swz(pos<LOGN, FROM>(t, r))] = hi32(x[r]);
-    __syncthreads();
+    lds_sync<CROSS>();
+    asm volatile("" : "+v"(t));
 #pragma unroll
-    for (int r = 0; r < 32; ++r) x[r] = ((u64)lds[swz(pos<LOGN, TO>(t, r))] << 32) | lo[r];
-    __syncthreads();
+    for (int r = 0; r < 32; ++r) x[r] = ((u64)lds[swz(pos<LOGN, TO>(t, r))] << 32) | lo32(x[r]);
+    lds_sync<CROSS>();
 }
 
 // ------------------------------------------------------------------ butterflies
-// Forward (Harvey lazy): U,V in [0,4q) -> X,Y in [0,4q).
-__device__ __forceinline__ void bfly_fwd(u64& U, u64& V, u64 w, u64 q, u64 q2, u32 ninv) {
+// Forward, reduced every stage (Harvey): U,V in [0,4q) -> [0,4q).
+__device__ __forceinline__ void bfly_fwd_cs(u64& U, u64& V, u64 w, u64 q, u64 q2, u32 ninv) {
     u64 Tm = mont_mul_lazy(V, w, q, ninv);
     u64 u = csub(U, q2);
     U = u + Tm;
     V = u + (q2 - Tm);
 }
-// Inverse (Gentleman-Sande): U,V in [0,2q) -> X,Y in [0,2q).
+// Forward, never reduced: values grow by at most 2q per stage (needs 34q < 2^63).
+__device__ __forceinline__ void bfly_fwd_nr(u64& U, u64& V, u64 w, u64 q, u64 q2, u32 ninv) {
+    u64 Tm = mont_mul_lazy(V, w, q, ninv);
+    u64 u = U;
+    U = u + Tm;
+    V = u + (q2 - Tm);
+}
+// Inverse (Gentleman-Sande): U,V in [0,2q) -> [0,2q).
 __device__ __forceinline__ void bfly_inv(u64& U, u64& V, u64 w, u64 q, u64 q2, u32 ninv) {
     u64 s = csub(U + V, q2);
     u64 d = U + q2 - V;
@@ -61,8 +94,9 @@ __device__ __forceinline__ void bfly_inv(u64& U, u64& V, u64 w, u64 q, u64 q2, u
 }
 
 // One radix-2 stage on register bit B; tw points at the run of (16 >> B) twiddles.
-template <int B, bool INV>
-__device__ __forceinline__ void stage(u64 (&x)[32], const u64* __restrict__ tw, u64 q, u64 q2, u32 ninv) {
+// MODE: 0 forward reduced, 1 forward never-reduced, 2 inverse.
+template <int B, int MODE>
+__device__ __forceinline__ void stage(u64 (&x)[32], gcptr tw, u64 q, u64 q2, u32 ninv) {
     constexpr int NW = 16 >> B;
     u64 w[NW];
 #pragma unroll
@@ -71,36 +105,73 @@ __device__ __forceinline__ void stage(u64 (&x)[32], const u64* __restrict__ tw, 
     for (int g = 0; g < 16; ++g) {
         const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
         const int i1 = i0 | (1 << B);
-        if constexpr (INV) bfly_inv(x[i0], x[i1], w[g >> B], q, q2, ninv);
-        else bfly_fwd(x[i0], x[i1], w[g >> B], q, q2, ninv);
+        if constexpr (MODE == 2) bfly_inv(x[i0], x[i1], w[g >> B], q, q2, ninv);
+        else if constexpr (MODE == 1) bfly_fwd_nr(x[i0], x[i1], w[g >> B], q, q2, ninv);
+        else bfly_fwd_cs(x[i0], x[i1], w[g >> B], q, q2, ninv);
+    }
+    // keep the next stage's twiddle loads from being hoisted above this stage (register pressure)
+    asm volatile("" ::: "memory");
+}
+
+// the (up to) five stages of one phase; stage on register bit B uses
+// psi[(base >> B) + (prefix << (4 - B)) + k].  FWD: most significant bit first; INV: least first.
+template <int MODE>
+__device__ __forceinline__ void phase(u64 (&x)[32], gcptr psi, int base, int prefix, int maxB, u64 q, u64 q2, u32 ninv) {
+    if constexpr (MODE != 2) {
+        if (maxB >= 4) stage<4, MODE>(x, psi + (base >> 4) + prefix, q, q2, ninv);
+        if (maxB >= 3) stage<3, MODE>(x, psi + (base >> 3) + (prefix << 1), q, q2, ninv);
+        if (maxB >= 2) stage<2, MODE>(x, psi + (base >> 2) + (prefix << 2), q, q2, ninv);
+        if (maxB >= 1) stage<1, MODE>(x, psi + (base >> 1) + (prefix << 3), q, q2, ninv);
+        if (maxB >= 0) stage<0, MODE>(x, psi + base + (prefix << 4), q, q2, ninv);
+    } else {
+        if (maxB >= 0) stage<0, MODE>(x, psi + base + (prefix << 4), q, q2, ninv);
+        if (maxB >= 1) stage<1, MODE>(x, psi + (base >> 1) + (prefix << 3), q, q2, ninv);
+        if (maxB >= 2) stage<2, MODE>(x, psi + (base >> 2) + (prefix << 2), q, q2, ninv);
+        if (maxB >= 3) stage<3, MODE>(x, psi + (base >> 3) + (prefix << 1), q, q2, ninv);
+        if (maxB >= 4) stage<4, MODE>(x, psi + (base >> 4) + prefix, q, q2, ninv);
     }
 }
 
-template <int LOGN>
-__device__ __forceinline__ void job_pointers(const NttBatch& b, int job, const u64*& src, u64*& dst, int& m, int& outer) {
-    outer = job / b.inner_count;
-    const int s = job - outer * b.inner_count;
-    m = b.map[s];
-    src = b.src + (long)outer * b.src_outer + (long)(b.src_mapped ? m : s) * b.src_inner;
-    dst = b.dst + (long)outer * b.dst_outer + (long)(b.dst_mapped ? m : s) * b.dst_inner;
+// The small per-launch lists are read straight from the kernarg segment (scalar loads): indexing the
+// by-value struct dynamically would make the compiler copy all of it to scratch.
+typedef const __attribute__((address_space(4))) NttBatch* kargptr;
+__device__ __forceinline__ void job_pointers(const NttBatch& b, int job, gcptr& src, gptr& dst, int& m, int& outer) {
+    kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+    // slot-major job order: consecutive workgroups share a modulus, so at any time the chip works
+    // on 2-3 twiddle tables that stay resident in every XCD's L2
+    const int s = job / b.nouter;
+    outer = job - s * b.nouter;
+    m = kb->mod[s];
+    const int p = kb->pos[s];
+    const u64* sbase = b.src; u64* dbase = b.dst;
+    if (b.nitems > 0) {
+        const int item = outer / b.outers_per_item;
+        outer -= item * b.outers_per_item;
+        sbase = kb->src_items[item]; dbase = kb->dst_items[item];
+    }
+    src = (gcptr)(sbase + (long)outer * b.src_outer + (long)(b.src_mapped ? m : p) * b.src_inner);
+    dst = (gptr)(dbase + (long)outer * b.dst_outer + (long)(b.dst_mapped ? m : p) * b.dst_inner);
 }
 
 // ------------------------------------------------------------------ forward kernel
-template <int LOGN>
+// phases: 0 = index bits n-1..n-5 (layout A), 1 = bits MIDTOP..5 (layout B), 2 = bits 4..0 (layout C)
+// MODE 1: moduli with 34q < 2^63, no reduction inside; MODE 0: reduced every stage.
+template <int LOGN, int MODE>
 __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     using G = Geo<LOGN>;
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
-    const int sub = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    const int sub = G::LPB == 1 ? 0 : threadIdx.x / G::T, t = G::LPB == 1 ? threadIdx.x : threadIdx.x % G::T;
     u32* lds = lds_all + sub * G::N;
     int job = blockIdx.x * G::LPB + sub;
-    const bool active = job < b.njobs;
-    if (!active) job = b.njobs - 1;            // keep every lane in the barriers; results discarded
-    const u64* src; u64* dst; int m, outer;
-    job_pointers<LOGN>(b, job, src, dst, m, outer);
+    const int njobs = b.nslots * b.nouter;
+    const bool active = job < njobs;
+    if (!active) job = njobs - 1;            // keep every lane in the barriers; results discarded
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, job, src, dst, m, outer);
     const Mod md = b.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
-    const u64* psi = b.psi + (long)m * G::N;
+    gcptr psi = (gcptr)(b.psi + (long)m * G::N);
 
     u64 x[32];
 #pragma unroll
@@ -113,34 +184,25 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
             for (int r = 0; r < 32; ++r) x[r] = mont_mul_lazy(x[r], md.r1, q, ninv);
         }
     }
-    // phase 1: index bits n-1 .. n-5 (register bits 4..0); twiddles psi[2^(s-1) + k] are wave-uniform
-    stage<4, false>(x, psi + 1, q, q2, ninv);
-    stage<3, false>(x, psi + 2, q, q2, ninv);
-    stage<2, false>(x, psi + 4, q, q2, ninv);
-    stage<1, false>(x, psi + 8, q, q2, ninv);
-    stage<0, false>(x, psi + 16, q, q2, ninv);
-
-    if constexpr (G::HAS_MID) {
-        exchange<LOGN, LA, LB>(x, lds, t);
-        const int hi = t >> 5;
-        // phase 2: index bits MIDTOP .. 5 (register bit B = beta - 5)
-        if constexpr (G::MIDTOP >= 9) stage<4, false>(x, psi + (G::N >> 10) + (hi << 0), q, q2, ninv);
-        if constexpr (G::MIDTOP >= 8) stage<3, false>(x, psi + (G::N >> 9) + (hi << 1), q, q2, ninv);
-        if constexpr (G::MIDTOP >= 7) stage<2, false>(x, psi + (G::N >> 8) + (hi << 2), q, q2, ninv);
-        if constexpr (G::MIDTOP >= 6) stage<1, false>(x, psi + (G::N >> 7) + (hi << 3), q, q2, ninv);
-        stage<0, false>(x, psi + (G::N >> 6) + (hi << 4), q, q2, ninv);
+#pragma unroll 1
+    for (int ph = 0; ph < 3; ++ph) {
+        int base = 16, prefix = 0, maxB = 4;
+        if (ph == 1) { base = G::N >> 6; prefix = t >> 5; maxB = G::MIDB; }
+        if (ph == 2) { base = G::N >> 1; prefix = t; }
+        phase<MODE>(x, psi, base, prefix, maxB, q, q2, ninv);
+        if (ph == 0) { if constexpr (G::HAS_MID) exchange<LOGN, LA, LB, true>(x, lds, t); }
+        else if (ph == 1) exchange<LOGN, LB, LC, false>(x, lds, t);
     }
-    exchange<LOGN, LB, LC>(x, lds, t);
-    // phase 3: index bits 4..0
-    stage<4, false>(x, psi + (G::N >> 5) + (t << 0), q, q2, ninv);
-    stage<3, false>(x, psi + (G::N >> 4) + (t << 1), q, q2, ninv);
-    stage<2, false>(x, psi + (G::N >> 3) + (t << 2), q, q2, ninv);
-    stage<1, false>(x, psi + (G::N >> 2) + (t << 3), q, q2, ninv);
-    stage<0, false>(x, psi + (G::N >> 1) + (t << 4), q, q2, ninv);
     // canonical output (lattigo: final BRedAdd)
+    if constexpr (MODE == 1) {
 #pragma unroll
-    for (int r = 0; r < 32; ++r) x[r] = csub(csub(x[r], q2), q);
-    exchange<LOGN, LC, LB>(x, lds, t);
+        for (int r = 0; r < 32; ++r) x[r] = mont_mul(x[r], md.r1, q, ninv);      // < 34q -> [0,q)
+    } else {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) x[r] = csub(csub(x[r], q2), q);
+    }
+    // back to layout B for 256-B contiguous stores
+    exchange<LOGN, LC, LB, false>(x, lds, t);
     if (active) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) dst[posB(t, r)] = x[r];
@@ -152,43 +214,34 @@ template <int LOGN>
 __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     using G = Geo<LOGN>;
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
-    const int sub = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    const int sub = G::LPB == 1 ? 0 : threadIdx.x / G::T, t = G::LPB == 1 ? threadIdx.x : threadIdx.x % G::T;
     u32* lds = lds_all + sub * G::N;
     int job = blockIdx.x * G::LPB + sub;
-    const bool active = job < b.njobs;
-    if (!active) job = b.njobs - 1;
-    const u64* src; u64* dst; int m, outer;
-    job_pointers<LOGN>(b, job, src, dst, m, outer);
+    const int njobs = b.nslots * b.nouter;
+    const bool active = job < njobs;
+    if (!active) job = njobs - 1;
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, job, src, dst, m, outer);
     const Mod md = b.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
-    const u64* psi = b.psi + (long)m * G::N;
+    gcptr psi = (gcptr)(b.psi + (long)m * G::N);
 
     u64 x[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = src[posB(t, r)];
-    exchange<LOGN, LB, LC>(x, lds, t);
-    // phase A: index bits 0..4
-    stage<0, true>(x, psi + (G::N >> 1) + (t << 4), q, q2, ninv);
-    stage<1, true>(x, psi + (G::N >> 2) + (t << 3), q, q2, ninv);
-    stage<2, true>(x, psi + (G::N >> 3) + (t << 2), q, q2, ninv);
-    stage<3, true>(x, psi + (G::N >> 4) + (t << 1), q, q2, ninv);
-    stage<4, true>(x, psi + (G::N >> 5) + (t << 0), q, q2, ninv);
-    exchange<LOGN, LC, LB>(x, lds, t);
-    if constexpr (G::HAS_MID) {
-        const int hi = t >> 5;
-        stage<0, true>(x, psi + (G::N >> 6) + (hi << 4), q, q2, ninv);
-        if constexpr (G::MIDTOP >= 6) stage<1, true>(x, psi + (G::N >> 7) + (hi << 3), q, q2, ninv);
-        if constexpr (G::MIDTOP >= 7) stage<2, true>(x, psi + (G::N >> 8) + (hi << 2), q, q2, ninv);
-        if constexpr (G::MIDTOP >= 8) stage<3, true>(x, psi + (G::N >> 9) + (hi << 1), q, q2, ninv);
-        if constexpr (G::MIDTOP >= 9) stage<4, true>(x, psi + (G::N >> 10) + (hi << 0), q, q2, ninv);
-        exchange<LOGN, LB, LA>(x, lds, t);
+    exchange<LOGN, LB, LC, false>(x, lds, t);
+    // phases: 0 = index bits 0..4 (layout C), 1 = bits 5..MIDTOP (layout B); the top phase follows
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        int base = G::N >> 1, prefix = t, maxB = 4;
+        if (ph == 1) { base = G::N >> 6; prefix = t >> 5; maxB = G::MIDB; }
+        phase<2>(x, psi, base, prefix, maxB, q, q2, ninv);
+        if (ph == 0) exchange<LOGN, LC, LB, false>(x, lds, t);
+        else { if constexpr (G::HAS_MID) exchange<LOGN, LB, LA, true>(x, lds, t); }
     }
-    // phase C: index bits n-5 .. n-2, then the last stage with N^-1 folded in
-    stage<0, true>(x, psi + 16, q, q2, ninv);
-    stage<1, true>(x, psi + 8, q, q2, ninv);
-    stage<2, true>(x, psi + 4, q, q2, ninv);
-    stage<3, true>(x, psi + 2, q, q2, ninv);
+    // top phase: index bits n-5 .. n-2, then the last stage with N^-1 folded in
+    phase<2>(x, psi, 16, 0, 3, q, q2, ninv);
     const u64 ninvR = b.aux[2 * m], w1n = b.aux[2 * m + 1];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -205,37 +258,49 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
 }
 
 // ------------------------------------------------------------------ launchers
-template <int LOGN> static void launch_fwd_t(const NttBatch& b, hipStream_t st) {
+template <int LOGN, int MODE> static void launch_fwd_t(const NttBatch& b, hipStream_t st) {
     using G = Geo<LOGN>;
     static bool attr = false;
     const size_t lds = (size_t)G::LPB * G::N * sizeof(u32);
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    const int blocks = (b.njobs + G::LPB - 1) / G::LPB;
-    hipLaunchKernelGGL(ntt_fwd_kernel<LOGN>, dim3(blocks), dim3(G::BT), lds, st, b);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    const int blocks = (b.nslots * b.nouter + G::LPB - 1) / G::LPB;
+    hipLaunchKernelGGL((ntt_fwd_kernel<LOGN, MODE>), dim3(blocks), dim3(G::BT), lds, st, b);
 }
 template <int LOGN> static void launch_inv_t(const NttBatch& b, hipStream_t st) {
     using G = Geo<LOGN>;
     static bool attr = false;
     const size_t lds = (size_t)G::LPB * G::N * sizeof(u32);
     if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    const int blocks = (b.njobs + G::LPB - 1) / G::LPB;
+    const int blocks = (b.nslots * b.nouter + G::LPB - 1) / G::LPB;
     hipLaunchKernelGGL(ntt_inv_kernel<LOGN>, dim3(blocks), dim3(G::BT), lds, st, b);
 }
 
-void launch_ntt_fwd(int logN, const NttBatch& b, hipStream_t st) {
-    if (b.njobs <= 0) return;
+template <int MODE> static void launch_fwd_mode(int logN, const NttBatch& b, hipStream_t st) {
     switch (logN) {
-        case 10: launch_fwd_t<10>(b, st); break;
-        case 11: launch_fwd_t<11>(b, st); break;
-        case 12: launch_fwd_t<12>(b, st); break;
-        case 13: launch_fwd_t<13>(b, st); break;
-        case 14: launch_fwd_t<14>(b, st); break;
-        case 15: launch_fwd_t<15>(b, st); break;
+        case 10: launch_fwd_t<10, MODE>(b, st); break;
+        case 11: launch_fwd_t<11, MODE>(b, st); break;
+        case 12: launch_fwd_t<12, MODE>(b, st); break;
+        case 13: launch_fwd_t<13, MODE>(b, st); break;
+        case 14: launch_fwd_t<14, MODE>(b, st); break;
+        case 15: launch_fwd_t<15, MODE>(b, st); break;
         default: break;
     }
 }
+
+void launch_ntt_fwd(int logN, const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
+    if (b.nslots <= 0 || b.nouter <= 0) return;
+    // one launch per modulus class (different butterfly code)
+    for (int cls = 0; cls < 2; ++cls) {
+        NttBatch c = b;
+        c.nslots = 0;
+        for (int s = 0; s < b.nslots; ++s)
+            if ((small_q[b.mod[s]] != 0) == (cls == 1)) { c.mod[c.nslots] = b.mod[s]; c.pos[c.nslots] = b.pos[s]; ++c.nslots; }
+        if (c.nslots == 0) continue;
+        if (cls == 1) launch_fwd_mode<1>(logN, c, st); else launch_fwd_mode<0>(logN, c, st);
+    }
+}
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
-    if (b.njobs <= 0) return;
+    if (b.nslots <= 0 || b.nouter <= 0) return;
     switch (logN) {
         case 10: launch_inv_t<10>(b, st); break;
         case 11: launch_inv_t<11>(b, st); break;

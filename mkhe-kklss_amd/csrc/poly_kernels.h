@@ -50,6 +50,36 @@ struct ModDownArgs {
 };
 void launch_moddown(const ModDownArgs& a, hipStream_t st);
 
+// Batched ExternalProduct front half over independent items (parties):
+//   c1[item][m][n] = sum_{i<beta} bg_item[i][m][n] (*) ah_item[i][m][n]        (keyswitch_hoisted.go:25-31)
+constexpr int EXT_MAX_ITEMS = 64;
+struct ExtInnerArgs {
+    const u64* ah[EXT_MAX_ITEMS];
+    const u64* bg[EXT_MAX_ITEMS];
+    u64* c1;                 // [nitems][mtot][N]
+    const Mod* mods;
+    const int* map;
+    long digit_stride;       // mtot*N
+    long c1_item;            // mtot*N
+    int nitems, nb, nslots, N;
+};
+void launch_ext_inner(const ExtInnerArgs& a, hipStream_t st);
+
+// Batched ModDown tail: item b reads c1[b] and writes / accumulates into dst[b].  Items that share a
+// destination are applied one after the other by the same thread (out_0 += sum_i ..., step F).
+struct ModDownBatchArgs {
+    const u64* c1;           // [nitems][mtot][N]  (Q part then P part, lazy)
+    u64* dst[EXT_MAX_ITEMS];
+    int accumulate[EXT_MAX_ITEMS];
+    const Mod* mods_q;
+    const Mod* mods_p;
+    ModDownTables t;
+    long c1_item;            // mtot*N
+    long p_offset;           // nq*N
+    int nitems, level, np, N;
+};
+void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st);
+
 // Tensor step D of MulAndRelin (keyswitch_hoisted.go:120-140) on NTT-domain inputs.
 //   out_0 = a0*b0 ; out_o = b0*a_o (o in ids0) (+)= a0*b_o (o in ids1)
 struct TensorArgs {

@@ -86,6 +86,79 @@ void launch_moddown(const ModDownArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(moddown_kernel, dim3(bx, by, a.nbatch), dim3(PW_THREADS), 0, st, a);
 }
 
+// ------------------------------------------------------------------ batched ExternalProduct halves
+__global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
+    const int s = blockIdx.y, item = blockIdx.z;
+    const int m = a.map[s];
+    const Mod md = a.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const u64* ah = a.ah[item] + (long)m * a.N;
+    const u64* bg = a.bg[item] + (long)m * a.N;
+    u64* out = a.c1 + (long)item * a.c1_item + (long)m * a.N;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
+        u64 acc = 0;
+#pragma unroll 2
+        for (int i = 0; i < a.nb; ++i) {
+            u64 p = mont_mul_lazy(bg[(long)i * a.digit_stride + n], ah[(long)i * a.digit_stride + n], q, ninv);
+            acc = csub(acc + p, q2);
+        }
+        out[n] = csub(acc, q);
+    }
+}
+void launch_ext_inner(const ExtInnerArgs& a, hipStream_t st) {
+    int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 32) bx = 32;
+    hipLaunchKernelGGL(ext_inner_kernel, dim3(bx, a.nslots, a.nitems), dim3(PW_THREADS), 0, st, a);
+}
+
+__global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchArgs a) {
+    const int n = blockIdx.x * PW_THREADS + threadIdx.x;
+    if (n >= a.N) return;
+    for (int item = 0; item < a.nitems; ++item) {
+        const u64* xq = a.c1 + (long)item * a.c1_item;
+        const u64* xp = xq + a.p_offset;
+        u64* dst = a.dst[item];
+        u64 y[MAXP];
+        double vi = 0.0;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            if (i < a.np) {
+                const Mod mp = a.mods_p[i];
+                y[i] = mont_mul(xp[(long)i * a.N + n], a.t.qoverqiinvqi[i], mp.q, mp.ninv32);
+                vi = vi + (double)y[i] / (double)mp.q;
+            }
+        }
+        const u64 v = (u64)vi;
+        for (int j = blockIdx.y; j <= a.level; j += gridDim.y) {
+            const Mod mq = a.mods_q[j];
+            u64 rlo = 0, rhi = 0;
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                if (i < a.np) {
+                    u64 mhi, mlo;
+                    mul64x64(y[i], a.t.qoverqimodp[(long)j * a.np + i], mhi, mlo);
+                    u64 sum = rlo + mlo;
+                    rhi += mhi + (sum < rlo ? 1 : 0);
+                    rlo = sum;
+                }
+            }
+            const u64 hhi = mulhi64(rlo * mq.qinv, mq.q);
+            const u64 lift = rhi - hhi + mq.q + a.t.vtimesqmodp[(long)j * (a.np + 1) + v];
+            const u64 x = xq[(long)j * a.N + n];
+            u64 z = mont_mul(lift + mq.q2 - x, a.t.downparam[j], mq.q, mq.ninv32);
+            if (a.accumulate[item]) z = csub(dst[(long)j * a.N + n] + z, mq.q);
+            dst[(long)j * a.N + n] = z;
+        }
+    }
+}
+void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st) {
+    const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    int by = a.level + 1;
+    if (by > 16) by = 16;
+    hipLaunchKernelGGL(moddown_batch_kernel, dim3(bx, by), dim3(PW_THREADS), 0, st, a);
+}
+
 // ------------------------------------------------------------------ tensor (step D)
 __global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
     const int l = blockIdx.y;
