@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz.  Run from the repo root:  python tests/golden/make_golden.py
+
+The reference ships no golden vectors and cannot run here (no Go toolchain, lattigo not
+vendored), so these fixtures are DATA produced by the independent Python big-integer model
+(oracle/pymodel.py: NTT by definition, exact-CRT ModDown, schoolbook products) for small rings, plus
+one size-2^10 single-limb NTT for the GPU kernels (whose minimum ring degree is 2^10).
+Inputs are seeded; outputs are whatever the model computes -- nothing here is copied from the reference.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import harness as H                     # noqa: E402
+from oracle import pymodel as M         # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def rnd_poly(rng, mods, N):
+    return np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in mods])
+
+
+def u64(x):
+    return np.array(x, dtype=np.uint64)
+
+
+def small_case(name, logN, Qs, Ps, seed):
+    N = 1 << logN
+    rng = np.random.default_rng(seed)
+    mdl = M.Model(logN, Qs, Ps, 2)
+    beta, m = mdl.beta(len(Qs) - 1), len(Qs) + len(Ps)
+    d = dict(logN=logN, Q=u64(Qs), P=u64(Ps), psi=u64(mdl.psi))
+    # NTT of one poly per modulus
+    a = rnd_poly(rng, Qs + Ps, N)
+    d["ntt_in"] = a
+    d["ntt_out"] = u64([M.ntt_def([int(v) for v in a[j]], q, mdl.psi[j], logN) for j, q in enumerate(Qs + Ps)])
+    # decompose + external product at two levels
+    poly = rnd_poly(rng, Qs, N)
+    bg = np.stack([rnd_poly(rng, Qs + Ps, N) for _ in range(beta)])
+    d["dec_in"], d["bg"] = poly, bg
+    for level in (len(Qs) - 1, max(0, len(Qs) - 2)):
+        h = mdl.decompose(poly, level)
+        arr = np.zeros((beta, m, N), dtype=np.uint64)
+        for i in range(mdl.beta(level)):
+            for j in mdl.limb_index(level):
+                arr[i, j] = u64(h[i][j])
+        d["dec_out_l%d" % level] = arr
+        d["ext_out_l%d" % level] = u64(mdl.external_product([[int(v) for v in l] for l in poly], bg, level))
+    # MulAndRelin: op0 ids {0,1}, op1 ids {1,2}
+    ids0, ids1 = [0, 1], [1, 2]
+    op0 = np.stack([rnd_poly(rng, Qs, N) for _ in range(3)])
+    op1 = np.stack([rnd_poly(rng, Qs, N) for _ in range(3)])
+    rlk = {i: tuple(np.stack([rnd_poly(rng, Qs + Ps, N) for _ in range(beta)]) for _ in range(3)) for i in range(3)}
+    u = np.stack([rnd_poly(rng, Qs + Ps, N) for _ in range(beta)])
+    d.update(op0=op0, op1=op1, crs_u=u, ids0=np.array(ids0), ids1=np.array(ids1))
+    for i in range(3):
+        d["rlk%d_b" % i], d["rlk%d_d" % i], d["rlk%d_v" % i] = rlk[i]
+    for level in (len(Qs) - 1, 1):
+        ido, out = mdl.mul_and_relin(level, ids0, op0, ids1, op1, rlk, u)
+        d["mr_ids_l%d" % level] = np.array(ido)
+        d["mr_out_l%d" % level] = u64(out)
+    # rescale + automorphism
+    d["rescale_out"] = u64([[M.div_round_last([int(poly[l][k]) for l in range(len(Qs))], Qs)[j] for k in range(N)]
+                            for j in range(len(Qs) - 1)])
+    g = pow(5, 3, 2 * N)
+    d["galEl"] = np.uint64(g)
+    d["perm_out"] = u64([M.automorphism([int(v) for v in poly[l]], g, Qs[l], logN) for l in range(len(Qs))])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print("wrote", name)
+
+
+def ntt_1024():
+    logN, N = 10, 1024
+    rng = np.random.default_rng(77)
+    mods = [H.PN15QP880["Q"][0], H.PN15QP880["Q"][1], H.PN15QP880["P"][0]]
+    psi = [M.find_psi(q, N) for q in mods]
+    a = rnd_poly(rng, mods, N)
+    out = u64([M.ntt_def([int(v) for v in a[j]], q, psi[j], logN) for j, q in enumerate(mods)])
+    np.savez_compressed(os.path.join(OUT, "ntt_n1024.npz"), logN=logN, mods=u64(mods), psi=u64(psi), ntt_in=a, ntt_out=out)
+    print("wrote ntt_n1024")
+
+
+if __name__ == "__main__":
+    small_case("alpha1_n16", 4, H.PN15QP880["Q"][:3], H.PN15QP880["P"], 11)
+    small_case("alpha2_n16", 4, H.PN16_Q[:5], H.PN16_P, 12)
+    ntt_1024()

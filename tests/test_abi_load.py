@@ -1,0 +1,53 @@
+"""CPU: the C-ABI shared library loads and exports every symbol that include/mkhe.h declares, and the
+ctypes binding covers the same set (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mkhe.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mkhe_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_hot_path_entry_points():
+    syms = declared_symbols()
+    for must in ("mkhe_ctx_create", "mkhe_decompose", "mkhe_external_product", "mkhe_external_product_hoisted",
+                 "mkhe_mul_and_relin", "mkhe_rotate", "mkhe_conjugate", "mkhe_rescale", "mkhe_ntt"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from mkhe_kklss_amd import _abi
+    assert os.path.exists(_abi.LIB_PATH), "build the HIP library first (__graft_entry__.build())"
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(lib, s), "libmkhe_hip.so does not export %s" % s
+
+
+def test_binding_matches_header():
+    from mkhe_kklss_amd import _abi
+    assert sorted(_abi.SIGNATURES) == declared_symbols()
+    _abi.lib()          # resolves every symbol with its signature
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mkhe_kklss_amd import _abi
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setattr(_abi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _abi.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mkhe-kklss_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), "%s mentions the oracle" % f

@@ -11,7 +11,8 @@ params = mkrlwe.Parameters(logN, pset["Q"], pset["P"], 2)
 N = 1 << logN
 limbs = 14
 rng = np.random.default_rng(0)
-for count in (16, 18, 36, 73, 146, 292):
+COUNTS = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else (16, 18, 36, 73, 146, 292)
+for count in COUNTS:
     nl = count * limbs
     a = rng.integers(0, 1 << 53, (count, limbs, N), dtype=np.uint64)
     src = mkrlwe.DeviceLimbs(params, count, limbs).upload(a)
