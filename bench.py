@@ -28,24 +28,34 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PROF_NAMES = ["ntt_fwd_decompose", "ntt_fwd", "ntt_inv", "inner_product", "moddown", "tensor", "other"]
 
 
+def synth_swk(pset, rng):
+    """uniform residues per limb, switching-key shaped uint64[beta][nQ+nP][N] (alpha = 1)"""
+    Q, P, N = pset["Q"], pset["P"], 1 << pset["logN"]
+    out = np.empty((len(Q), len(Q) + len(P), N), dtype=np.uint64)
+    for i in range(len(Q)):
+        for j, q in enumerate(Q + P):
+            out[i, j] = rng.integers(0, q, N, dtype=np.uint64)
+    return out
+
+
+def synth_party_keys(pset, party_index, seed):
+    """(b, d, v) of one party; seeded per party so every rank can regenerate just what it needs"""
+    rng = np.random.default_rng(seed + 1000 * (party_index + 1))
+    return tuple(synth_swk(pset, rng) for _ in range(3))
+
+
+def synth_cts(pset, parties, seed):
+    rng = np.random.default_rng(seed)
+    Q, N = pset["Q"], 1 << pset["logN"]
+    ct = lambda: np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q]) for _ in range(1 + parties)])
+    return ct(), ct()
+
+
 def synth_inputs(pset, parties, seed):
     """uniform residues per limb: ciphertexts, rlk (b,d,v) per party, CRS u."""
-    import harness as H
-    rng = np.random.default_rng(seed)
-    Q, P, N = pset["Q"], pset["P"], 1 << pset["logN"]
-    beta, m = len(Q), len(Q) + len(P)          # alpha = 1
-
-    def swk():
-        out = np.empty((beta, m, N), dtype=np.uint64)
-        for i in range(beta):
-            for j, q in enumerate(Q + P):
-                out[i, j] = rng.integers(0, q, N, dtype=np.uint64)
-        return out
-
-    def ct():
-        return np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in Q]) for _ in range(1 + parties)])
-
-    return dict(op0=ct(), op1=ct(), rlk=[(swk(), swk(), swk()) for _ in range(parties)], u=swk())
+    op0, op1 = synth_cts(pset, parties, seed)
+    return dict(op0=op0, op1=op1, rlk=[synth_party_keys(pset, i, seed) for i in range(parties)],
+                u=synth_swk(pset, np.random.default_rng(seed + 7)))
 
 
 def run_single(args):
@@ -123,7 +133,7 @@ def run_single(args):
                    sample="%d full %d-party MulRelin (%s) on 1 host thread, %.1f s" % (reps, k, args.params, cdt),
                    bit_exact_vs_gpu=same)
     return dict(metric="mkckks_mulrelin_per_sec", value=value, unit="MulRelin/s", n_gpus=1, steps=args.steps,
-                warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
+                warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="strong",
                 vs_baseline=None, dtype="u64", data="synthetic",
                 config=dict(workload="mkckks %d-party MulRelin (hoist + MulAndRelinHoisted + Rescale), %s N=2^%d, %d Q + %d P limbs"
                             % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["P"])),
@@ -141,9 +151,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0x4D4B4845)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even at world size 1 (testing)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_dist:
         from bench_dist import run_distributed
         out = run_distributed(args)
     else:

@@ -1,0 +1,68 @@
+"""bench.py, N > 1 leg: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).
+
+The SAME k-party MulRelin as the single-GPU bench is evaluated party-sharded (mkhe_kklss_amd/dist.py):
+strong scaling, value = MulRelin/s of the whole job.  Collectives per step: all-reduce of the x and y
+partial sums (beta*(nQ+nP)*N words each) and of the output ciphertext ((k+1)*(level+1)*N words).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def run_distributed(args):
+    import torch
+    import torch.distributed as dist
+    import harness as H
+    from bench import synth_party_keys, synth_cts, synth_swk
+    from mkhe_kklss_amd import mkckks
+    from mkhe_kklss_amd._abi import check, lib
+    from mkhe_kklss_amd.dist import HipShardBackend, ShardedMulRelin, assign_units
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    pset = H.PN15QP880 if args.params == "PN15QP880" else H.PN14QP439
+    k = args.parties
+    names = ["user%d" % i for i in range(k)]
+    level = len(pset["Q"]) - 1
+    params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"], device=local_rank)
+    op0, op1 = synth_cts(pset, k, args.seed)
+    ids0, ids1 = assign_units(names, world)[rank]
+    rlk = {n: synth_party_keys(pset, names.index(n), args.seed) for n in set(ids0) | set(ids1)}
+    params.AddCRS(-1, synth_swk(pset, np.random.default_rng(args.seed + 7)))
+    backend = HipShardBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank)
+    smr = ShardedMulRelin(backend, dist)
+    res = mkckks.NewCiphertext(params, names, level - 1, pset["scale"])
+
+    def step():
+        smr.run()
+        check(lib().mkhe_rescale(params.ctx, backend.full.h, 1, res.h))
+
+    for _ in range(args.warmup):
+        step()
+    params.sync(); torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    params.sync(); torch.cuda.synchronize(); dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    out = None
+    if rank == 0:
+        nwx = int(lib().mkhe_ctx_swk_words(params.ctx))
+        out = dict(metric="mkckks_mulrelin_per_sec", value=args.steps / dt, unit="MulRelin/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps, higher_is_better=True,
+                   scaling="strong", vs_baseline=None, dtype="u64", data="synthetic",
+                   config=dict(workload="mkckks %d-party MulRelin (hoist + MulAndRelinHoisted + Rescale), %s N=2^%d, %d Q + %d P limbs, "
+                                        "parties sharded over %d GPUs" % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["P"]), world),
+                               parties=k, params=args.params, seed=args.seed, sharding="half-party units, see mkhe_kklss_amd/dist.py",
+                               allreduce_bytes_per_step=8 * (2 * nwx + (k + 1) * (level + 1) * (1 << pset["logN"]))),
+                   roofline=None, cpu_baseline=None)
+    dist.barrier()
+    dist.destroy_process_group()
+    return out

@@ -102,6 +102,24 @@ int  mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                         const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
                         const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out);
 
+/* ---- the same MulAndRelinHoisted split in phases for party-sharded multi-GPU evaluation
+ *      (the reference is single-process).  Each rank passes sub-ciphertexts holding c_0
+ *      and the party components it owns; x_part / y_part receive the rank's canonical partial sums
+ *      sum_i d_i (.) h(c0_i), sum_j b_j (.) h(c1_j) WITHOUT MForm (keyswitch_hoisted.go:79-92,99-113).
+ *      The caller sums them over ranks as uint64 (RCCL all-reduce; exact while ranks*q < 2^63), calls
+ *      mkhe_swk_fold(.., mform=1) (= MFormLvl of the total, :94-96,115-117) and then mkhe_mr_finish
+ *      (steps D-F, :119-178).  with_c0 != 0 on exactly one rank adds c0_0*c1_0 to out_0; out_0 and any
+ *      out_i whose two operand components live on different ranks are partial sums to be reduced and
+ *      folded with mkhe_ct_fold. */
+int  mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                     const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
+                     const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
+                     const mkhe_ct* out_shape, mkhe_swk* x_part, mkhe_swk* y_part);
+int  mkhe_swk_fold(mkhe_ctx* ctx, mkhe_swk* swk, int level, int mform);
+int  mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x, const mkhe_swk* y,
+                    const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, int with_c0, mkhe_ct* out);
+int  mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct);
+
 /* ---- KeySwitcher.Rotate keyswitch.go:234-298 / RotateHoisted keyswitch_hoisted.go:183-247.
  *      galEl = 5^rotidx mod 2N; rk aligned with ct ids (rkSet[id][rotidx]); crs = params.CRS[rotidx]. */
 int  mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* hoist,

@@ -218,6 +218,32 @@ int mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                               b1.data(), d0.data(), v0.data(), crs_u->s, out->c);
     })
 }
+int mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                    const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
+                    const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
+                    const mkhe_ct* out_shape, mkhe_swk* x_part, mkhe_swk* y_part) {
+    MKHE_TRY({
+        if (!op0 || !op1 || !out_shape || !x_part || !y_part || !rlk_b1 || !rlk_d0) throw Error("mkhe_mr_partial: null argument");
+        auto h0 = swk_list(hoist0, op0->c.n); auto h1 = swk_list(hoist1, op1->c.n);
+        auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n);
+        ctx->c->mr_prepare(op0->c, op1->c, hoist0 ? h0.data() : nullptr, hoist1 ? h1.data() : nullptr, out_shape->c);
+        ctx->c->mr_xy(b1.data(), d0.data(), x_part->s.d, y_part->s.d, false);
+    })
+}
+int mkhe_swk_fold(mkhe_ctx* ctx, mkhe_swk* swk, int level, int mform) {
+    MKHE_TRY(ctx->c->fold(swk->s.d, true, level, ctx->c->beta(level), (long)ctx->c->mtot * ctx->c->N, mform != 0))
+}
+int mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x, const mkhe_swk* y,
+                   const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, int with_c0, mkhe_ct* out) {
+    MKHE_TRY({
+        if (!op0 || !op1 || !x || !y || !rlk_v0 || !crs_u || !out) throw Error("mkhe_mr_finish: null argument");
+        auto v0 = swk_list(rlk_v0, op0->c.n);
+        ctx->c->mr_finish(op0->c, op1->c, x->s.d, y->s.d, v0.data(), crs_u->s, with_c0 != 0, out->c);
+    })
+}
+int mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct) {
+    MKHE_TRY(ctx->c->fold(ct->c.d, false, ct->c.limbs - 1, 1 + ct->c.n, (long)ct->c.limbs * ctx->c->N, false))
+}
 int mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* hoist,
                 const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* out) {
     MKHE_TRY({

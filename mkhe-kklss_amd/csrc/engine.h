@@ -57,6 +57,15 @@ class Context {
     void conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk& crs, Ct& out);
     // mkckks Rescale body: nb successive DivRoundByLastModulus on every poly (evaluator.go:385-391)
     void rescale(const Ct& in, int nb, Ct& out);
+    // MulAndRelin split in phases (party-sharded multi-GPU evaluation: the x / y partial sums and out_0
+    // are reduced across devices between the phases)
+    void mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, const Ct& out);
+    void mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform);
+    void mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
+                   const Swk& crs_u, bool with_c0, Ct& out);
+    void fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform);
+    u64* pool_x() { return x_; }
+    u64* pool_y() { return y_; }
     // batched building blocks (all parties in one launch)
     void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst);
     void ext_batch(int level, const std::vector<ExtItem>& items);
@@ -95,6 +104,14 @@ class Context {
     void slots_range(NttBatch& b, int mod_base, int limbs) const;
     std::vector<unsigned char> small_q_;                     // per modulus: 34q < 2^63
     void ext_core(int level, const u64* ah, const u64* bg, u64* c, bool accumulate);
+
+    struct MrPlan {
+        bool valid = false;
+        int level = 0, L = 0, n0 = 0, n1 = 0, nout = 0;
+        std::vector<int> slot0, slot1;
+        std::vector<const u64*> h0, h1;
+        TensorArgs ta{};
+    } plan_;
 
     struct ProfRec { hipEvent_t e0, e1; int cls; double bytes; };
     bool prof_on_ = false;

@@ -340,50 +340,74 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items) {
 void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
                             const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                             const Swk& crs_u, Ct& out) {
-    const int level = out.limbs - 1, L = level + 1;
-    check_level(level);
-    if (op0.limbs < L || op1.limbs < L) throw Error("Cannot MulAndRelin: op0 and op1 have different levels");
-    const int n0 = op0.n, n1 = op1.n;
-    if (n0 > 32 || n1 > 32 || out.n > 32 || n0 > MAX_TERMS || n1 > MAX_TERMS) throw Error("mkhe: too many parties");
-    // out ids must be the union of the operand id sets (newCiphertextBinary, mkckks/evaluator.go:306-313)
-    std::vector<int> slot0(n0), slot1(n1);
-    TensorArgs ta{};
-    auto find = [&](int id) { for (int o = 0; o < out.n; ++o) if (out.ids[o] == id) return o; return -1; };
-    for (int a = 0; a < n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); slot0[a] = o; ta.slot0[1 + o] = 1 + a; }
-    for (int a = 0; a < n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); slot1[a] = o; ta.slot1[1 + o] = 1 + a; }
-    for (int o = 0; o < out.n; ++o) if (!ta.slot0[1 + o] && !ta.slot1[1 + o]) throw Error("mkhe: ctOut has an id that neither operand has");
+    mr_prepare(op0, op1, hoist0, hoist1, out);
+    mr_xy(rlk_b1, rlk_d0, x_, y_, true);
+    mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, true, out);
+}
 
-    const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N, PO = (size_t)L * N;
-    // hoist the operands when the caller did not (MulRelinNew, mkckks/evaluator.go:416-443): one launch
-    std::vector<const u64*> h0(n0), h1(n1);
+// -- step 0: validate, map ids, hoist the operands when the caller did not (MulRelinNew, evaluator.go:416-443)
+void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, const Ct& out) {
+    MrPlan& p = plan_;
+    p = MrPlan{};
+    p.level = out.limbs - 1; p.L = p.level + 1;
+    check_level(p.level);
+    if (op0.limbs < p.L || op1.limbs < p.L) throw Error("Cannot MulAndRelin: op0 and op1 have different levels");
+    p.n0 = op0.n; p.n1 = op1.n; p.nout = out.n;
+    if (p.n0 > 32 || p.n1 > 32 || out.n > 32) throw Error("mkhe: too many parties");
+    // out ids must be the union of the operand id sets (newCiphertextBinary, mkckks/evaluator.go:306-313)
+    p.slot0.assign(p.n0, 0); p.slot1.assign(p.n1, 0);
+    auto find = [&](int id) { for (int o = 0; o < out.n; ++o) if (out.ids[o] == id) return o; return -1; };
+    for (int a = 0; a < p.n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); p.slot0[a] = o; p.ta.slot0[1 + o] = 1 + a; }
+    for (int a = 0; a < p.n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); p.slot1[a] = o; p.ta.slot1[1 + o] = 1 + a; }
+    for (int o = 0; o < out.n; ++o) if (!p.ta.slot0[1 + o] && !p.ta.slot1[1 + o]) throw Error("mkhe: ctOut has an id that neither operand has");
+    const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N;
+    p.h0.assign(p.n0, nullptr); p.h1.assign(p.n1, nullptr);
     const bool same = (&op0 == &op1) && hoist0 == hoist1;
-    {
-        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
-        for (int a = 0; a < n0; ++a) {
-            if (hoist0) { if (!hoist0[a]) throw Error("mkhe: missing hoisted form"); h0[a] = hoist0[a]->d; }
-            else { Swk& s = hoist_slot(0, a); dsrc.push_back(op0.d + (1 + a) * P0); ddst.push_back(s.d); h0[a] = s.d; }
-        }
-        for (int a = 0; a < n1; ++a) {
-            if (hoist1) { if (!hoist1[a]) throw Error("mkhe: missing hoisted form"); h1[a] = hoist1[a]->d; }
-            else if (same) h1[a] = h0[a];
-            else { Swk& s = hoist_slot(1, a); dsrc.push_back(op1.d + (1 + a) * P1); ddst.push_back(s.d); h1[a] = s.d; }
-        }
-        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst);
+    std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+    for (int a = 0; a < p.n0; ++a) {
+        if (hoist0) { if (!hoist0[a]) throw Error("mkhe: missing hoisted form"); p.h0[a] = hoist0[a]->d; }
+        else { Swk& s = hoist_slot(0, a); dsrc.push_back(op0.d + (1 + a) * P0); ddst.push_back(s.d); p.h0[a] = s.d; }
     }
-    const int nb = beta(level), nslots = L + np;
-    // B, C: x = MForm(sum_i d_i (.) h(c0_i)),  y = MForm(sum_j b_j (.) h(c1_j))
+    for (int a = 0; a < p.n1; ++a) {
+        if (hoist1) { if (!hoist1[a]) throw Error("mkhe: missing hoisted form"); p.h1[a] = hoist1[a]->d; }
+        else if (same) p.h1[a] = p.h0[a];
+        else { Swk& s = hoist_slot(1, a); dsrc.push_back(op1.d + (1 + a) * P1); ddst.push_back(s.d); p.h1[a] = s.d; }
+    }
+    if (!dsrc.empty()) decompose_batch(p.level, dsrc, ddst);
+    p.valid = true;
+}
+
+// -- steps B, C: x = [MForm] sum_i d_i (.) h(c0_i),  y = [MForm] sum_j b_j (.) h(c1_j)   (keyswitch_hoisted.go:79-117)
+// mform = false leaves the canonical partial sums for a cross-device reduction (party sharding).
+void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform) {
+    MrPlan& p = plan_;
+    if (!p.valid) throw Error("mkhe: mr_xy without mr_prepare");
+    const int nb = beta(p.level), nslots = p.L + np;
     for (int side = 0; side < 2; ++side) {
-        const int n = side ? n1 : n0;
+        const int n = side ? p.n1 : p.n0;
+        if (n > MAX_TERMS) throw Error("mkhe: too many parties");
         InnerProductArgs ip{};
         for (int a = 0; a < n; ++a) {
             const Swk* key = side ? rlk_b1[a] : rlk_d0[a];
             if (!key) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-            ip.a[a] = key->d; ip.b[a] = side ? h1[a] : h0[a];
+            ip.a[a] = key->d; ip.b[a] = side ? p.h1[a] : p.h0[a];
         }
-        ip.out = side ? y_ : x_; ip.mods = d_mods; ip.map = map_qp(level);
-        ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nb; ip.N = N; ip.mform_out = 1;
+        ip.out = side ? y : x; ip.mods = d_mods; ip.map = map_qp(p.level);
+        ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nb; ip.N = N; ip.mform_out = mform ? 1 : 0;
         { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nb * (2.0 * n + 1)); launch_inner_product(ip, stream); }
     }
+    MKHE_HIP(hipGetLastError());
+}
+
+// -- steps D, E, F (keyswitch_hoisted.go:119-178) with x, y in Montgomery form.
+// with_c0 = false leaves c0_0*c1_0 out of out_0 (another rank of a party-sharded evaluation adds it).
+void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
+                        const Swk& crs_u, bool with_c0, Ct& out) {
+    MrPlan& p = plan_;
+    if (!p.valid) throw Error("mkhe: mr_finish without mr_prepare");
+    if (out.limbs != p.L || out.n != p.nout || op0.n != p.n0 || op1.n != p.n1) throw Error("mkhe: mr_finish arguments do not match mr_prepare");
+    const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
+    const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N, PO = (size_t)L * N;
     // D: tensor product in the NTT domain, back to coefficients
     u64* nb_ = scratch(nttbuf_, nttbuf_words_, (size_t)(2 + n0 + n1) * PO);
     {
@@ -395,14 +419,15 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
         b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.nouter = 1 + n1;
         { ProfScope ps(this, PROF_NTT_FWD, 16.0 * N * b.nouter * L); launch_ntt_fwd(logN, b, small_q_.data(), stream); }
     }
-    ta.ntt = nb_; ta.out = out.d; ta.mods = d_mods; ta.n0 = n0; ta.n1 = n1; ta.nout = out.n; ta.L = L; ta.N = N;
+    TensorArgs& ta = p.ta;
+    ta.ntt = nb_; ta.out = out.d; ta.mods = d_mods; ta.n0 = n0; ta.n1 = n1; ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
     { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, stream); }
     ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
-    // E: out_j += <h(c1_j), x>_P   and   F1: t_i = <h(c0_i), y>_P   (2k independent products, one batch)
+    // E: out_j += <h(c1_j), x>_P   and   F1: t_i = <h(c0_i), y>_P   (independent products, one batch)
     u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
     std::vector<ExtItem> items;
-    for (int a = 0; a < n1; ++a) items.push_back(ExtItem{h1[a], x_, out.d + (size_t)(1 + slot1[a]) * PO, true});
-    for (int a = 0; a < n0; ++a) items.push_back(ExtItem{h0[a], y_, tbuf + (size_t)a * PO, false});
+    for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
+    for (int a = 0; a < n0; ++a) items.push_back(ExtItem{p.h0[a], y, tbuf + (size_t)a * PO, false});
     ext_batch(level, items);
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
     {
@@ -414,9 +439,21 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
     for (int a = 0; a < n0; ++a) {
         if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
         items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
-        items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PO, true});
+        items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
     }
     ext_batch(level, items);
+    p.valid = false;
+    MKHE_HIP(hipGetLastError());
+}
+
+// reduction epilogue of the party-sharded path: words hold sums of canonical residues of several ranks
+// (each < q, total < 2^63); bring them back to [0,q) and optionally to Montgomery form (MFormLvl).
+void Context::fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform) {
+    check_level(level);
+    FoldArgs fa{};
+    fa.buf = buf; fa.mods = d_mods; fa.map = qp_shaped ? map_qp(level) : d_map_id;
+    fa.nslots = qp_shaped ? level + 1 + np : level + 1; fa.npolys = npolys; fa.poly_stride = poly_stride; fa.N = N; fa.mform = mform ? 1 : 0;
+    { ProfScope ps(this, PROF_OTHER, 16.0 * N * fa.nslots * npolys); launch_fold(fa, stream); }
     MKHE_HIP(hipGetLastError());
 }
 

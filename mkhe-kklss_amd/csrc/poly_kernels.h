@@ -89,6 +89,7 @@ struct TensorArgs {
     int slot0[33];             // for out slot o>=1: index into op0 slots (1..n0) or 0 if absent
     int slot1[33];             // likewise for op1
     int n0, n1, nout, L, N;
+    int with_c0;               // 0: leave c0_0*c1_0 out of out_0 (party-sharded evaluation)
 };
 void launch_tensor(const TensorArgs& a, hipStream_t st);
 
@@ -102,6 +103,16 @@ void launch_automorphism(u64* dst, const u64* src, const Mod* mods, int L, int l
 // dst[i] (i < level) from src limbs 0..level;  src is not modified.
 void launch_div_round_last(u64* dst, const u64* src, const Mod* mods, const u64* rescale_row /*[level]*/,
                            int level, int N, int npolys, long src_poly, long dst_poly, hipStream_t st);
+
+// In-place fold of sums of canonical residues (< 2^63) back to [0,q), optionally to Montgomery form.
+struct FoldArgs {
+    u64* buf;
+    const Mod* mods;
+    const int* map;            // [nslots] limb index inside each poly
+    long poly_stride;
+    int nslots, npolys, N, mform;
+};
+void launch_fold(const FoldArgs& a, hipStream_t st);
 
 // z = MForm(a) / z = mont_mul(a, b) helpers on limb-major buffers
 void launch_mform(u64* dst, const u64* src, const Mod* mods, const int* map, int nslots, int N, hipStream_t st);

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
         const u64 a0m = mont_mul(op0[e], md.r2, q, ninv);     // MForm(NTT(c0_0))
         const u64 b0 = op1[e];
         const u64 b0m = mont_mul(b0, md.r2, q, ninv);         // MForm(NTT(c1_0))
-        a.out[e] = mont_mul(a0m, b0, q, ninv);
+        a.out[e] = a.with_c0 ? mont_mul(a0m, b0, q, ninv) : 0;
         for (int o = 1; o <= a.nout; ++o) {
             u64 r = 0;
             const int s0 = a.slot0[o], s1 = a.slot1[o];
@@ -246,6 +246,21 @@ void launch_div_round_last(u64* dst, const u64* src, const Mod* mods, const u64*
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(div_round_last_kernel, dim3(bx, level, npolys), dim3(PW_THREADS), 0, st, dst, src, mods, rescale_row, level, N, src_poly, dst_poly);
+}
+
+// ------------------------------------------------------------------ fold (reduction epilogue)
+__global__ void __launch_bounds__(PW_THREADS) fold_kernel(FoldArgs a) {
+    const int m = a.map[blockIdx.y];
+    const Mod md = a.mods[m];
+    u64* p = a.buf + (long)blockIdx.z * a.poly_stride + (long)m * a.N;
+    const u64 w = a.mform ? md.r2 : md.r1;       // x*R2/R = x*R (MForm) ; x*R1/R = x
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS)
+        p[n] = mont_mul(p[n], w, md.q, md.ninv32);
+}
+void launch_fold(const FoldArgs& a, hipStream_t st) {
+    int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(fold_kernel, dim3(bx, a.nslots, a.npolys), dim3(PW_THREADS), 0, st, a);
 }
 
 // ------------------------------------------------------------------ mform

@@ -1,0 +1,126 @@
+"""Party-sharded MulAndRelin over torch.distributed (one process per GPU; backend "nccl" = RCCL over
+xGMI on MI355X, "gloo" in the CPU tests).
+
+The reference is single-process; the sharding follows the algorithm's own structure
+(keyswitch_hoisted.go:79-117,147-178).  Work is cut into 2k half-party units
+(party i, side 0) = hoist c0_i, d_i-term of x, step F of party i      (needs y)
+(party i, side 1) = hoist c1_i, b_i-term of y, step E of party i      (needs x)
+and every rank evaluates the reference algorithm on the sub-ciphertexts made of c_0 and the
+components of its units.  Exchange steps (the only collectives):
+  1. all-reduce(x_part), all-reduce(y_part)   uint64 sums of canonical residues, then fold + MForm
+  2. all-reduce(out)                          every out slot is a sum of per-rank contributions
+All sums are exact (ranks * q < 2^63) and order independent, so the result is bit-identical to the
+single-device evaluation.
+"""
+import numpy as np
+
+
+def assign_units(names, world):
+    """-> list over ranks of (ids0_local, ids1_local).  Units are chunked evenly in the order
+    (p0,0),(p0,1),(p1,0),... so for world <= k (k % world == 0) a rank owns whole parties."""
+    units = [(n, s) for n in names for s in (0, 1)]
+    out = [([], []) for _ in range(world)]
+    for j, (n, s) in enumerate(units):
+        r = j * world // len(units)
+        out[r][s].append(n)
+    return out
+
+
+class ShardedMulRelin:
+    """Orchestrates one party-sharded MulAndRelinHoisted.  `backend` does the local arithmetic
+    (HipShardBackend below on the GPU); `dist` is torch.distributed (or None for world size 1)."""
+
+    def __init__(self, backend, dist=None, group=None):
+        self.b, self.dist, self.group = backend, dist, group
+
+    def _all_reduce(self, t):
+        if self.dist is not None and self.dist.get_world_size(self.group) > 1:
+            self.b.before_collective()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.b.after_collective()
+
+    def run(self):
+        b = self.b
+        x, y = b.partial_xy()                 # torch int64 views of the rank's partial sums
+        self._all_reduce(x)
+        self._all_reduce(y)
+        b.fold_xy()                           # x, y <- MForm(sum mod q)
+        full = b.finish()                     # torch int64 view [1+k][L][N]: own contributions, zeros elsewhere
+        self._all_reduce(full)
+        b.fold_out()                          # every slot <- sum mod q
+        return full
+
+
+class _DevView:
+    """exposes a raw device pointer to torch through __cuda_array_interface__ (no copy)"""
+
+    def __init__(self, ptr, nwords):
+        self.__cuda_array_interface__ = dict(shape=(int(nwords),), typestr="<i8", data=(int(ptr), False), version=3, strides=None)
+
+
+class HipShardBackend:
+    """Local arithmetic of one rank on its MI355X through the C ABI (include/mkhe.h, mkhe_mr_*)."""
+
+    def __init__(self, params, names, rank, world, op0_host, op1_host, rlk_host, level, torch, device_index):
+        """op*_host: full ciphertexts uint64[1+k][L][N]; rlk_host: {name: (b, d, v)} for (at least) the
+        parties this rank needs.  Only the rank's own components and keys are uploaded."""
+        from . import mkrlwe
+        import ctypes as C
+        from ._abi import check, lib
+        self.params, self.names, self.level, self.torch = params, list(names), level, torch
+        self.C, self.check, self.lib, self.mk = C, check, lib, mkrlwe
+        ids0, ids1 = assign_units(self.names, world)[rank]
+        self.ids0, self.ids1, self.with_c0 = ids0, ids1, rank == 0
+        sl = lambda host, ids: np.ascontiguousarray(np.stack([host[0]] + [host[1 + self.names.index(n)] for n in ids]))
+        self.op0 = mkrlwe.NewCiphertext(params, ids0, level).upload(sl(op0_host, ids0))
+        self.op1 = mkrlwe.NewCiphertext(params, ids1, level).upload(sl(op1_host, ids1))
+        self.keys = {n: [mkrlwe.SwitchingKey(params, rlk_host[n][j]) if need else None
+                         for j, need in enumerate((n in ids1, n in ids0, n in ids0))]
+                     for n in set(ids0) | set(ids1)}
+        self.out_ids = sorted(set(ids0) | set(ids1))
+        self.out = mkrlwe.NewCiphertext(params, self.out_ids, level)
+        self.full = mkrlwe.NewCiphertext(params, self.names, level)
+        self.x, self.y = mkrlwe.NewSwitchingKey(params), mkrlwe.NewSwitchingKey(params)
+        dev = torch.device("cuda", device_index)
+        words = int(lib().mkhe_ctx_swk_words(params.ctx))
+        self.tx = torch.as_tensor(_DevView(self.x.devptr(), words), device=dev)
+        self.ty = torch.as_tensor(_DevView(self.y.devptr(), words), device=dev)
+        N, L = params.N(), level + 1
+        self.tfull = torch.as_tensor(_DevView(self.full.devptr(), (1 + len(self.names)) * L * N), device=dev).view(1 + len(self.names), L, N)
+        self.tout = torch.as_tensor(_DevView(self.out.devptr(), (1 + len(self.out_ids)) * L * N), device=dev).view(1 + len(self.out_ids), L, N)
+
+    def _arr(self, hs):
+        from ._abi import handle_array
+        return handle_array(hs)
+
+    def partial_xy(self):
+        b1 = [self.keys[n][0].h for n in self.op1.ids]
+        d0 = [self.keys[n][1].h for n in self.op0.ids]
+        self.check(self.lib().mkhe_mr_partial(self.params.ctx, self.op0.h, self.op1.h, None, None,
+                                              self._arr(b1), self._arr(d0), self.out.h, self.x.h, self.y.h))
+        return self.tx, self.ty
+
+    def before_collective(self):
+        self.params.sync()                         # engine stream -> host; RCCL runs on torch's stream
+
+    def after_collective(self):
+        self.torch.cuda.current_stream().synchronize()
+
+    def fold_xy(self):
+        self.check(self.lib().mkhe_swk_fold(self.params.ctx, self.x.h, self.level, 1))
+        self.check(self.lib().mkhe_swk_fold(self.params.ctx, self.y.h, self.level, 1))
+
+    def finish(self):
+        v0 = [self.keys[n][2].h for n in self.op0.ids]
+        self.check(self.lib().mkhe_mr_finish(self.params.ctx, self.op0.h, self.op1.h, self.x.h, self.y.h,
+                                             self._arr(v0), self.params.CRS[-1].h, 1 if self.with_c0 else 0, self.out.h))
+        self.params.sync()
+        self.tfull.zero_()
+        self.tfull[0].copy_(self.tout[0])
+        for a, n in enumerate(self.out_ids):
+            self.tfull[1 + self.names.index(n)].copy_(self.tout[1 + a])
+        self.torch.cuda.current_stream().synchronize()
+        return self.tfull
+
+    def fold_out(self):
+        self.check(self.lib().mkhe_ct_fold(self.params.ctx, self.full.h))

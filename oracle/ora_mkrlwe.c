@@ -339,24 +339,21 @@ void ora_external_product_hoisted(ora_ks* ks, int levelQ, const uint64_t* ah, co
 
 static int find_id(int n, const int* ids, int id) { for (int i = 0; i < n; ++i) if (ids[i] == id) return i; return -1; }
 
-/* MulAndRelinHoisted (keyswitch_hoisted.go:44-179); with hoist == NULL it is MulAndRelin
- * (keyswitch.go:122-230), which computes the same values. */
-void ora_mul_and_relin(ora_ks* ks, int level,
+/* Steps A-C of MulAndRelin[Hoisted] (keyswitch_hoisted.go:70-117): x = sum_i d_i (.) h(c0_i),
+ * y = sum_j b_j (.) h(c1_j), followed by MFormLvl when mform != 0.  mform == 0 exposes the canonical
+ * partial sums (used only to check the party-sharded multi-GPU orchestration). */
+void ora_mr_xy(ora_ks* ks, int level,
     int n0, const int* ids0, const uint64_t* op0, int op0_limbs,
     int n1, const int* ids1, const uint64_t* op1, int op1_limbs,
     const uint64_t* const* hoist0, const uint64_t* const* hoist1,
-    const uint64_t* const* rlk_b, const uint64_t* const* rlk_d, const uint64_t* const* rlk_v,
-    const uint64_t* crs_u, int nout, const int* ids_out, uint64_t* out) {
-    const size_t N = (size_t)ks->N, L = (size_t)(level + 1);
+    const uint64_t* const* rlk_b, const uint64_t* const* rlk_d,
+    uint64_t* x, uint64_t* y, int mform) {
+    const size_t N = (size_t)ks->N;
     const int levelP = ks->np - 1, beta = ora_ks_beta(ks, level);
-    const size_t s0 = (size_t)op0_limbs * N, s1 = (size_t)op1_limbs * N, so = L * N;
+    const size_t s0 = (size_t)op0_limbs * N, s1 = (size_t)op1_limbs * N;
     const size_t swkpoly = (size_t)(ks->nq + ks->np) * N;
-    uint64_t *x = ks->swk1, *y = ks->swk2;
-    (void)levelP;
-    /* A: zero x, y */
     memset(x, 0, (size_t)beta * swkpoly * 8);
     memset(y, 0, (size_t)beta * swkpoly * 8);
-    /* B: x = sum_i d_i (.) h(c0_i), then MForm */
     for (int a = 0; a < n0; ++a) {
         int id = ids0[a];
         const uint64_t* h;
@@ -364,8 +361,7 @@ void ora_mul_and_relin(ora_ks* ks, int level,
         else h = hoist0[id];
         for (int i = 0; i < beta; ++i) qp_mul(ks, level, levelP, SWK_Q(ks, rlk_d[id], i), SWK_Q(ks, h, i), SWK_Q(ks, x, i), 1);
     }
-    for (int i = 0; i < beta; ++i) qp_mform(ks, level, levelP, SWK_Q(ks, x, i));
-    /* C: y = sum_j b_j (.) h(c1_j), then MForm */
+    if (mform) for (int i = 0; i < beta; ++i) qp_mform(ks, level, levelP, SWK_Q(ks, x, i));
     for (int a = 0; a < n1; ++a) {
         int id = ids1[a];
         const uint64_t* h;
@@ -373,14 +369,28 @@ void ora_mul_and_relin(ora_ks* ks, int level,
         else h = hoist1[id];
         for (int i = 0; i < beta; ++i) qp_mul(ks, level, levelP, SWK_Q(ks, rlk_b[id], i), SWK_Q(ks, h, i), SWK_Q(ks, y, i), 1);
     }
-    for (int i = 0; i < beta; ++i) qp_mform(ks, level, levelP, SWK_Q(ks, y, i));
+    if (mform) for (int i = 0; i < beta; ++i) qp_mform(ks, level, levelP, SWK_Q(ks, y, i));
+}
+
+/* Steps D-F (keyswitch_hoisted.go:119-178) with x, y given in Montgomery form.  with_c0 == 0 leaves
+ * c0_0*c1_0 out of out_0 (sharded evaluation: exactly one rank adds it). */
+void ora_mr_finish(ora_ks* ks, int level,
+    int n0, const int* ids0, const uint64_t* op0, int op0_limbs,
+    int n1, const int* ids1, const uint64_t* op1, int op1_limbs,
+    const uint64_t* const* hoist0, const uint64_t* const* hoist1,
+    const uint64_t* x, const uint64_t* y,
+    const uint64_t* const* rlk_v, const uint64_t* crs_u, int with_c0,
+    int nout, const int* ids_out, uint64_t* out) {
+    const size_t N = (size_t)ks->N, L = (size_t)(level + 1);
+    const size_t s0 = (size_t)op0_limbs * N, s1 = (size_t)op1_limbs * N, so = L * N;
     /* D: tensor */
     uint64_t *p0 = ks->polyq[0], *p1 = ks->polyq[1], *p2 = ks->polyq[2];
     for (size_t j = 0; j < L; ++j) {
         ora_ntt(ks->rq, (int)j, op0 + j * N, p0 + j * N);
         ora_ntt(ks->rq, (int)j, op1 + j * N, p1 + j * N);
         ora_limb_mform(ks->rq, (int)j, p0 + j * N, p0 + j * N);
-        ora_limb_mul(ks->rq, (int)j, p0 + j * N, p1 + j * N, out + j * N);
+        if (with_c0) ora_limb_mul(ks->rq, (int)j, p0 + j * N, p1 + j * N, out + j * N);
+        else memset(out + j * N, 0, N * 8);
         ora_limb_mform(ks->rq, (int)j, p1 + j * N, p1 + j * N);
     }
     for (int a = 0; a < n0; ++a) {
@@ -419,6 +429,19 @@ void ora_mul_and_relin(ora_ks* ks, int level,
         ora_external_product_hoisted(ks, level, ks->swk3, crs_u, p2);
         for (size_t j = 0; j < L; ++j) ora_limb_add(ks->rq, (int)j, out + (size_t)(1 + o) * so + j * N, p2 + j * N, out + (size_t)(1 + o) * so + j * N);
     }
+}
+
+/* MulAndRelinHoisted (keyswitch_hoisted.go:44-179); with hoist == NULL it is MulAndRelin
+ * (keyswitch.go:122-230), which computes the same values. */
+void ora_mul_and_relin(ora_ks* ks, int level,
+    int n0, const int* ids0, const uint64_t* op0, int op0_limbs,
+    int n1, const int* ids1, const uint64_t* op1, int op1_limbs,
+    const uint64_t* const* hoist0, const uint64_t* const* hoist1,
+    const uint64_t* const* rlk_b, const uint64_t* const* rlk_d, const uint64_t* const* rlk_v,
+    const uint64_t* crs_u, int nout, const int* ids_out, uint64_t* out) {
+    ora_mr_xy(ks, level, n0, ids0, op0, op0_limbs, n1, ids1, op1, op1_limbs, hoist0, hoist1, rlk_b, rlk_d, ks->swk1, ks->swk2, 1);
+    ora_mr_finish(ks, level, n0, ids0, op0, op0_limbs, n1, ids1, op1, op1_limbs, hoist0, hoist1, ks->swk1, ks->swk2,
+                  rlk_v, crs_u, 1, nout, ids_out, out);
 }
 
 /* Rotate / RotateHoisted (keyswitch.go:234-298, keyswitch_hoisted.go:183-247) */

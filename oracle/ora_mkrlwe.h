@@ -85,6 +85,22 @@ void ora_mul_and_relin(ora_ks* ks, int level,
     const uint64_t* crs_u,
     int nout, const int* ids_out, uint64_t* out);
 
+/* the same in two phases (x/y accumulation, then tensor + relinearisation) -- used to check the
+ * party-sharded orchestration; ora_mul_and_relin == ora_mr_xy(mform=1) + ora_mr_finish(with_c0=1). */
+void ora_mr_xy(ora_ks* ks, int level,
+    int n0, const int* ids0, const uint64_t* op0, int op0_limbs,
+    int n1, const int* ids1, const uint64_t* op1, int op1_limbs,
+    const uint64_t* const* hoist0, const uint64_t* const* hoist1,
+    const uint64_t* const* rlk_b, const uint64_t* const* rlk_d,
+    uint64_t* x, uint64_t* y, int mform);
+void ora_mr_finish(ora_ks* ks, int level,
+    int n0, const int* ids0, const uint64_t* op0, int op0_limbs,
+    int n1, const int* ids1, const uint64_t* op1, int op1_limbs,
+    const uint64_t* const* hoist0, const uint64_t* const* hoist1,
+    const uint64_t* x, const uint64_t* y,
+    const uint64_t* const* rlk_v, const uint64_t* crs_u, int with_c0,
+    int nout, const int* ids_out, uint64_t* out);
+
 /* Rotate[Hoisted] (keyswitch.go:234-298, keyswitch_hoisted.go:183-247); hoist may be NULL.
  * rk[i] is the rotation key of party ids[i]; crs = CRS[rotidx]. */
 void ora_rotate(ora_ks* ks, int level, uint64_t galEl, int n, const int* ids,

@@ -85,6 +85,12 @@ def lib():
                                         C.c_int, i32p, u64p, C.c_int,
                                         pp, pp, pp, pp, pp, u64p,
                                         C.c_int, i32p, u64p]
+        L.ora_mr_xy.argtypes = [C.c_void_p, C.c_int,
+                                C.c_int, i32p, u64p, C.c_int, C.c_int, i32p, u64p, C.c_int,
+                                pp, pp, pp, pp, u64p, u64p, C.c_int]
+        L.ora_mr_finish.argtypes = [C.c_void_p, C.c_int,
+                                    C.c_int, i32p, u64p, C.c_int, C.c_int, i32p, u64p, C.c_int,
+                                    pp, pp, u64p, u64p, pp, u64p, C.c_int, C.c_int, i32p, u64p]
         L.ora_rotate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, i32p, u64p, C.c_int, pp, pp, u64p, u64p]
         L.ora_conjugate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, i32p, u64p, C.c_int, pp, u64p, u64p]
         L.ora_ckks_nb_rescales.restype = C.c_int
@@ -334,6 +340,37 @@ class KeySwitcher:
         lib().ora_mul_and_relin(self.h, level, len(ids0), p0, _p(op0), op0.shape[1],
                                 len(ids1), p1, _p(op1), op1.shape[1],
                                 h0, h1, rb, rd, rv, _p(crs_u), len(ids_out), po, _p(out))
+        return ids_out, out
+
+    def mr_xy(self, level, ids0, op0, ids1, op1, rlk, mform, hoist0=None, hoist1=None):
+        """steps A-C: returns (x, y) switching-key shaped arrays; mform=False: canonical partial sums"""
+        op0, op1 = _u64arr(op0), _u64arr(op1)
+        npar = max(list(ids0) + list(ids1) + [0]) + 1
+        x, y = self.new_swk(), self.new_swk()
+        a0, p0 = _i32(ids0)
+        a1, p1 = _i32(ids1)
+        rb, k1 = _ptrs({i: rlk[i][0] for i in rlk}, npar)
+        rd, k2 = _ptrs({i: rlk[i][1] for i in rlk}, npar)
+        h0, k4 = _ptrs(hoist0, npar)
+        h1, k5 = _ptrs(hoist1, npar)
+        lib().ora_mr_xy(self.h, level, len(ids0), p0, _p(op0), op0.shape[1], len(ids1), p1, _p(op1), op1.shape[1],
+                        h0, h1, rb, rd, _p(x), _p(y), 1 if mform else 0)
+        return x, y
+
+    def mr_finish(self, level, ids0, op0, ids1, op1, x, y, rlk, crs_u, with_c0, hoist0=None, hoist1=None):
+        """steps D-F with x, y in Montgomery form -> (ids_out, out)"""
+        op0, op1, crs_u, x, y = _u64arr(op0), _u64arr(op1), _u64arr(crs_u), _u64arr(x), _u64arr(y)
+        ids_out = sorted(set(ids0) | set(ids1))
+        npar = max(ids_out + [0]) + 1
+        out = np.zeros((1 + len(ids_out), level + 1, self.N), dtype=np.uint64)
+        a0, p0 = _i32(ids0)
+        a1, p1 = _i32(ids1)
+        ao, po = _i32(ids_out)
+        rv, k3 = _ptrs({i: rlk[i][2] for i in rlk}, npar)
+        h0, k4 = _ptrs(hoist0, npar)
+        h1, k5 = _ptrs(hoist1, npar)
+        lib().ora_mr_finish(self.h, level, len(ids0), p0, _p(op0), op0.shape[1], len(ids1), p1, _p(op1), op1.shape[1],
+                            h0, h1, _p(x), _p(y), rv, _p(crs_u), 1 if with_c0 else 0, len(ids_out), po, _p(out))
         return ids_out, out
 
     def rotate(self, level, galEl, ids, ct, rk, crs, hoist=None):

@@ -1,0 +1,121 @@
+"""N>1 path: party-sharded MulAndRelin (mkhe_kklss_amd.dist) must reproduce the single-process result
+bit for bit.
+
+CPU (gloo, world_size 2, spawned processes): orchestration + collectives with the oracle doing the local
+arithmetic.  GPU (-m gpu): the HIP backend through the split-phase C ABI (mkhe_mr_partial / mkhe_swk_fold /
+mkhe_mr_finish / mkhe_ct_fold), ranks emulated one after the other on the single available GPU.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import harness as H
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_case(pset, names, seed, level=None):
+    rng = np.random.default_rng(seed)
+    ks = O.KeySwitcher(pset["logN"], pset["Q"], pset["P"], 2)
+    level = len(pset["Q"]) - 1 if level is None else level
+    k = len(names)
+    op0, op1 = H.uniform_ct(rng, ks, k, level + 1), H.uniform_ct(rng, ks, k, level + 1)
+    rlk = {n: tuple(H.uniform_swk(rng, ks) for _ in range(3)) for n in names}
+    u = H.uniform_swk(rng, ks)
+    ids = list(range(k))
+    _, ref = ks.mul_and_relin(level, ids, op0, ids, op1, {i: rlk[n] for i, n in enumerate(names)}, u)
+    return ks, level, op0, op1, rlk, u, ref
+
+
+def test_assign_units():
+    from mkhe_kklss_amd.dist import assign_units
+    names = ["a", "b", "c", "d"]
+    assert assign_units(names, 1) == [(names, names)]
+    assert assign_units(names, 2) == [(["a", "b"], ["a", "b"]), (["c", "d"], ["c", "d"])]
+    assert assign_units(names, 4) == [([n], [n]) for n in names]
+    w8 = assign_units(names, 8)
+    assert w8[0] == (["a"], []) and w8[1] == ([], ["a"]) and w8[7] == ([], ["d"])
+    for world in (1, 2, 3, 4, 8):
+        au = assign_units(names, world)
+        assert sorted(sum((u[0] for u in au), [])) == names and sorted(sum((u[1] for u in au), [])) == names
+
+
+def _worker(rank, world, port, names, seed, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_oracle_backend import OracleShardBackend
+    from mkhe_kklss_amd.dist import ShardedMulRelin
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ks, level, op0, op1, rlk, u, ref = make_case(H.small_ckks(10, 3), names, seed)
+    b = OracleShardBackend(ks, names, rank, world, op0, op1, rlk, u, level, torch)
+    full = ShardedMulRelin(b, dist).run()
+    ok = bool((b.full == ref).all())
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, np.array([ok]))
+    else:
+        assert ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("names", [["u0", "u1"], ["u0", "u1", "u2"]])
+def test_sharded_mulrelin_gloo_world2(tmp_path, names):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(2, port, names, 42, out), nprocs=2, join=True)
+    assert np.load(out)[0]
+
+
+class _FakeDist:
+    """emulates all_reduce(SUM) over backends that live in one process (single GPU available)"""
+
+    def __init__(self, world):
+        self.world, self.pending = world, []
+
+    class ReduceOp:
+        SUM = "sum"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,names", [(1, ["u0", "u1"]), (2, ["u0", "u1"]), (4, ["u0", "u1"]), (2, ["u0", "u1", "u2"])])
+def test_sharded_mulrelin_device_emulated_ranks(world, names):
+    import torch
+    from mkhe_kklss_amd import mkckks
+    from mkhe_kklss_amd.dist import HipShardBackend
+    pset = H.small_ckks(11, 3)
+    ks, level, op0, op1, rlk, u, ref = make_case(pset, names, 7)
+    bs = []
+    for r in range(world):          # one engine context per emulated rank, like one process per GPU
+        params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"])
+        params.AddCRS(-1, u)
+        bs.append(HipShardBackend(params, names, r, world, op0, op1, rlk, level, torch, 0))
+    # phase 1 on every "rank", then the all-reduce by hand, exactly as ShardedMulRelin.run orders it
+    xs, ys = [], []
+    for b in bs:
+        x, y = b.partial_xy()
+        b.before_collective()
+        xs.append(x.clone()); ys.append(y.clone())
+    sx, sy = sum(xs[1:], xs[0]), sum(ys[1:], ys[0])
+    outs = []
+    for b in bs:
+        b.tx.copy_(sx); b.ty.copy_(sy)
+        torch.cuda.synchronize()
+        b.fold_xy()
+        outs.append(b.finish().clone())
+    tot = sum(outs[1:], outs[0])
+    b = bs[0]
+    b.tfull.copy_(tot)
+    torch.cuda.synchronize()
+    b.fold_out()
+    assert (b.full.download() == ref).all()
