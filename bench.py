@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROF_NAMES = ["ntt_fwd_decompose", "ntt_fwd", "ntt_inv", "inner_product", "moddown", "tensor", "other"]
+
 
 
 def synth_swk(pset, rng):
@@ -101,17 +101,29 @@ def run_single(args):
     byt = (C.c_double * ncls)()
     check(lib().mkhe_prof_collect(params.ctx, ms, cnt, byt))
     check(lib().mkhe_prof_enable(params.ctx, 0))
+    names_k = [lib().mkhe_prof_name(i).decode().replace("<N,", "<%d," % pset["logN"]).replace("<N>", "<%d>" % pset["logN"])
+               for i in range(ncls)]
     kernels = {}
     for i in range(ncls):
         if cnt[i]:
-            kernels[PROF_NAMES[i]] = dict(launches_per_step=cnt[i] / args.steps, ms_per_step=ms[i] / args.steps,
-                                          avg_launch_us=1e3 * ms[i] / cnt[i],
-                                          achieved_GBs=byt[i] / (ms[i] * 1e-3) / 1e9)
-    dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
-    di = PROF_NAMES.index(dom)
+            kernels[names_k[i]] = dict(launches_per_step=cnt[i] / args.steps, ms_per_step=ms[i] / args.steps,
+                                       avg_launch_us=1e3 * ms[i] / cnt[i],
+                                       achieved_GBs=byt[i] / (ms[i] * 1e-3) / 1e9)
+    di = max((i for i in range(ncls) if cnt[i]), key=lambda i: ms[i])
+    dom = names_k[di]
     achieved = byt[di] / (ms[di] * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value
+    # comes from the committed rocprofv3 --pmc summary of this same command (profiles/traffic.json, written
+    # by tools/traffic_from_pmc.py: (2*FETCH_SIZE + WRITE_SIZE) KB per launch).
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        key = dom.split()[0]
+        if tj.get("workload") == "%s k=%d" % (args.params, k) and key in tj.get("kernels", {}):
+            traffic = tj["kernels"][key]["hbm_bytes_per_launch"]
     roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                     alg_bytes_per_launch=byt[di] / cnt[di], avg_launch_us=1e3 * ms[di] / cnt[di],
                     kernels=kernels)
 

@@ -133,10 +133,11 @@ int  mkhe_conjugate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe
 int  mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out);
 
 /* ---- measurement support (no reference counterpart): HIP-event timing per kernel class on the
- *      context stream.  Classes: 0 NTT fwd fused with the gadget digit spread (Decompose), 1 NTT fwd,
- *      2 NTT inv, 3 digit/party inner product, 4 ModDown, 5 tensor, 6 other. */
+ *      context stream, one record per kernel launch.  Classes (mkhe_prof_name gives the kernel symbol
+ *      each class corresponds to in a rocprofv3 kernel trace). */
 int  mkhe_prof_enable(mkhe_ctx* ctx, int on);
 int  mkhe_prof_nclass(void);
+const char* mkhe_prof_name(int cls);
 int  mkhe_prof_collect(mkhe_ctx* ctx, double* ms, long* launches, double* alg_bytes);
 
 #ifdef __cplusplus

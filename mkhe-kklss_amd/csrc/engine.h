@@ -73,7 +73,8 @@ class Context {
     void sync() { MKHE_HIP(hipStreamSynchronize(stream)); }
 
     // ---- per-kernel-class timing with HIP events on the context stream (bench.py roofline leg)
-    enum { PROF_NTT_DECOMP = 0, PROF_NTT_FWD, PROF_NTT_INV, PROF_INNER, PROF_MODDOWN, PROF_TENSOR, PROF_OTHER, PROF_NCLASS };
+    enum { PROF_NTT_DECOMP = 0, PROF_NTT_DECOMP_BIGQ, PROF_NTT_FWD, PROF_NTT_FWD_BIGQ, PROF_NTT_INV, PROF_INNER, PROF_EXT_INNER,
+           PROF_MODDOWN, PROF_TENSOR, PROF_OTHER, PROF_NCLASS };
     void prof_enable(bool on);
     void prof_collect(double* ms, long* launches, double* alg_bytes);   // arrays of PROF_NCLASS; syncs and resets
 
@@ -102,6 +103,7 @@ class Context {
     void check_level(int level) const;
     void slots_qp(NttBatch& b, int level) const;
     void slots_range(NttBatch& b, int mod_base, int limbs) const;
+    void ntt_fwd_launch(const NttBatch& b, bool decompose);
     std::vector<unsigned char> small_q_;                     // per modulus: 34q < 2^63
     void ext_core(int level, const u64* ah, const u64* bg, u64* c, bool accumulate);
 

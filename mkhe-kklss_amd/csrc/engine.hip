@@ -214,6 +214,18 @@ void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
     for (int j = 0; j < limbs; ++j) { b.mod[j] = mod_base + j; b.pos[j] = j; }
 }
 
+// forward NTT launch: one kernel per modulus class, each with its own timing record
+void Context::ntt_fwd_launch(const NttBatch& b, bool decompose) {
+    NttBatch part[2];
+    const int n = split_ntt_fwd(b, small_q_.data(), part);
+    for (int i = 0; i < n; ++i) {
+        const bool small = part[i].lazy_out != 0;
+        const int cls = decompose ? (small ? PROF_NTT_DECOMP : PROF_NTT_DECOMP_BIGQ) : (small ? PROF_NTT_FWD : PROF_NTT_FWD_BIGQ);
+        ProfScope ps(this, cls, 16.0 * N * part[i].nouter * part[i].nslots);
+        launch_ntt_fwd_class(logN, part[i], stream);
+    }
+}
+
 // ------------------------------------------------------------------ ring level
 void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, bool inverse, bool lazy) {
     if (mod_base < 0 || mod_base + limbs > mtot) throw Error("mkhe: ntt modulus range");
@@ -223,8 +235,8 @@ void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, 
     slots_range(b, mod_base, limbs);
     b.src_outer = b.dst_outer = (long)limbs * N; b.src_inner = b.dst_inner = N;
     b.nouter = count; b.lazy_out = lazy ? 1 : 0;
-    ProfScope ps(this, inverse ? PROF_NTT_INV : PROF_NTT_FWD, 16.0 * N * count * limbs);
-    if (inverse) launch_ntt_inv(logN, b, stream); else launch_ntt_fwd(logN, b, small_q_.data(), stream);
+    if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * limbs); launch_ntt_inv(logN, b, stream); }
+    else ntt_fwd_launch(b, false);
     MKHE_HIP(hipGetLastError());
 }
 
@@ -243,7 +255,7 @@ void Context::decompose(int level, bool is_ntt, const u64* a, u64* out_swk) {
     b.dst_outer = (long)mtot * N; b.dst_inner = N; b.dst_mapped = 1;
     b.nouter = beta(level);
     b.reduce_in = 1; b.reduce_src_mod_is_outer = 1;
-    { ProfScope ps(this, PROF_NTT_DECOMP, 16.0 * N * b.nouter * b.nslots); launch_ntt_fwd(logN, b, small_q_.data(), stream); }
+    ntt_fwd_launch(b, true);
     MKHE_HIP(hipGetLastError());
 }
 
@@ -284,7 +296,7 @@ void Context::external_product(int level, bool is_ntt, const u64* a, const u64* 
 void Context::decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst) {
     check_level(level);
     if (alpha != 1) throw Error("mkhe: gadget decomposition with alpha >= 2 (CRT reconstruction) is not implemented on the device yet");
-    const int per = level + 1 + np, nb = beta(level);
+    const int nb = beta(level);
     for (size_t base = 0; base < src.size(); base += NTT_MAX_ITEMS) {
         const int n = (int)std::min<size_t>(NTT_MAX_ITEMS, src.size() - base);
         NttBatch b{};
@@ -295,8 +307,7 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
         b.nitems = n; b.outers_per_item = nb;
         for (int i = 0; i < n; ++i) { b.src_items[i] = src[base + i]; b.dst_items[i] = dst[base + i]; }
         b.nouter = n * nb;
-        ProfScope ps(this, PROF_NTT_DECOMP, 16.0 * N * n * nb * per);
-        launch_ntt_fwd(logN, b, small_q_.data(), stream);
+        ntt_fwd_launch(b, true);
     }
     MKHE_HIP(hipGetLastError());
 }
@@ -313,7 +324,7 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items) {
         for (int i = 0; i < n; ++i) { ia.ah[i] = items[base + i].ah; ia.bg[i] = items[base + i].bg; }
         ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
         ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
-        { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * (2.0 * nb + 1) * n); launch_ext_inner(ia, stream); }
+        { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb + 1) * n); launch_ext_inner(ia, stream); }
 
         NttBatch b{};
         b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
@@ -415,9 +426,9 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
         b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_range(b, 0, L);
         b.src_inner = b.dst_inner = N; b.dst_outer = (long)PO;
         b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.nouter = 1 + n0;
-        { ProfScope ps(this, PROF_NTT_FWD, 16.0 * N * b.nouter * L); launch_ntt_fwd(logN, b, small_q_.data(), stream); }
+        ntt_fwd_launch(b, false);
         b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.nouter = 1 + n1;
-        { ProfScope ps(this, PROF_NTT_FWD, 16.0 * N * b.nouter * L); launch_ntt_fwd(logN, b, small_q_.data(), stream); }
+        ntt_fwd_launch(b, false);
     }
     TensorArgs& ta = p.ta;
     ta.ntt = nb_; ta.out = out.d; ta.mods = d_mods; ta.n0 = n0; ta.n1 = n1; ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;

@@ -54,9 +54,11 @@ struct NttBatch {
     u64* dst_items[NTT_MAX_ITEMS];
 };
 
-// small_q[m] != 0 marks moduli with 34q < 2^63 (forward NTT without in-loop reductions); the
-// launcher splits the slots of `b` into one launch per class.
-void launch_ntt_fwd(int logN, const NttBatch& b, const unsigned char* small_q, hipStream_t st);
+// small_q[m] != 0 marks moduli with 34q < 2^63 (forward NTT without in-loop reductions).  The forward
+// kernels are specialised per modulus class: split_ntt_fwd cuts the slots of `b` into one batch per
+// class (returns how many, small-modulus class first), launch_ntt_fwd_class launches one of them.
+int  split_ntt_fwd(const NttBatch& b, const unsigned char* small_q, NttBatch out[2]);
+void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st);
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st);
 
 }  // namespace mkhe

@@ -156,7 +156,8 @@ __device__ __forceinline__ void job_pointers(const NttBatch& b, int job, gcptr& 
 // ------------------------------------------------------------------ forward kernel
 // phases: 0 = index bits n-1..n-5 (layout A), 1 = bits MIDTOP..5 (layout B), 2 = bits 4..0 (layout C)
 // MODE 1: moduli with 34q < 2^63, no reduction inside; MODE 0: reduced every stage.
-template <int LOGN, int MODE>
+// DEC: fused gadget digit spread of Decompose (input limb re-read under a foreign modulus).
+template <int LOGN, int MODE, bool DEC>
 __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     using G = Geo<LOGN>;
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     u64 x[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = src[posA<LOGN>(t, r)];
-    if (b.reduce_in) {
+    if constexpr (DEC) {
         // digit of a foreign modulus (Decompose, alpha = 1): bring it below 4q when needed
         const u64 qs = b.mods[b.reduce_src_mod_is_outer ? outer : m].q;
         if (qs > 4 * q) {
@@ -258,13 +259,13 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
 }
 
 // ------------------------------------------------------------------ launchers
-template <int LOGN, int MODE> static void launch_fwd_t(const NttBatch& b, hipStream_t st) {
+template <int LOGN, int MODE, bool DEC> static void launch_fwd_t(const NttBatch& b, hipStream_t st) {
     using G = Geo<LOGN>;
     static bool attr = false;
     const size_t lds = (size_t)G::LPB * G::N * sizeof(u32);
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN, MODE, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     const int blocks = (b.nslots * b.nouter + G::LPB - 1) / G::LPB;
-    hipLaunchKernelGGL((ntt_fwd_kernel<LOGN, MODE>), dim3(blocks), dim3(G::BT), lds, st, b);
+    hipLaunchKernelGGL((ntt_fwd_kernel<LOGN, MODE, DEC>), dim3(blocks), dim3(G::BT), lds, st, b);
 }
 template <int LOGN> static void launch_inv_t(const NttBatch& b, hipStream_t st) {
     using G = Geo<LOGN>;
@@ -275,29 +276,35 @@ template <int LOGN> static void launch_inv_t(const NttBatch& b, hipStream_t st) 
     hipLaunchKernelGGL(ntt_inv_kernel<LOGN>, dim3(blocks), dim3(G::BT), lds, st, b);
 }
 
-template <int MODE> static void launch_fwd_mode(int logN, const NttBatch& b, hipStream_t st) {
+template <int MODE, bool DEC> static void launch_fwd_mode(int logN, const NttBatch& b, hipStream_t st) {
     switch (logN) {
-        case 10: launch_fwd_t<10, MODE>(b, st); break;
-        case 11: launch_fwd_t<11, MODE>(b, st); break;
-        case 12: launch_fwd_t<12, MODE>(b, st); break;
-        case 13: launch_fwd_t<13, MODE>(b, st); break;
-        case 14: launch_fwd_t<14, MODE>(b, st); break;
-        case 15: launch_fwd_t<15, MODE>(b, st); break;
+        case 10: launch_fwd_t<10, MODE, DEC>(b, st); break;
+        case 11: launch_fwd_t<11, MODE, DEC>(b, st); break;
+        case 12: launch_fwd_t<12, MODE, DEC>(b, st); break;
+        case 13: launch_fwd_t<13, MODE, DEC>(b, st); break;
+        case 14: launch_fwd_t<14, MODE, DEC>(b, st); break;
+        case 15: launch_fwd_t<15, MODE, DEC>(b, st); break;
         default: break;
     }
 }
 
-void launch_ntt_fwd(int logN, const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
-    if (b.nslots <= 0 || b.nouter <= 0) return;
-    // one launch per modulus class (different butterfly code)
-    for (int cls = 0; cls < 2; ++cls) {
+int split_ntt_fwd(const NttBatch& b, const unsigned char* small_q, NttBatch out[2]) {
+    int n = 0;
+    for (int cls = 1; cls >= 0; --cls) {
         NttBatch c = b;
         c.nslots = 0;
         for (int s = 0; s < b.nslots; ++s)
             if ((small_q[b.mod[s]] != 0) == (cls == 1)) { c.mod[c.nslots] = b.mod[s]; c.pos[c.nslots] = b.pos[s]; ++c.nslots; }
-        if (c.nslots == 0) continue;
-        if (cls == 1) launch_fwd_mode<1>(logN, c, st); else launch_fwd_mode<0>(logN, c, st);
+        c.lazy_out = cls;          // carries the class to launch_ntt_fwd_class (field unused by the forward kernels)
+        if (c.nslots) out[n++] = c;
     }
+    return n;
+}
+void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
+    if (b.nslots <= 0 || b.nouter <= 0) return;
+    const bool small = b.lazy_out != 0;
+    if (b.reduce_in) { if (small) launch_fwd_mode<1, true>(logN, b, st); else launch_fwd_mode<0, true>(logN, b, st); }
+    else             { if (small) launch_fwd_mode<1, false>(logN, b, st); else launch_fwd_mode<0, false>(logN, b, st); }
 }
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;

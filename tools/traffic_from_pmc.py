@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from two rocprofv3 --pmc runs of bench.py (FETCH_SIZE pass, WRITE_SIZE pass).
+
+  python tools/traffic_from_pmc.py <fetch_dir> <write_dir> "<PARAMS> k=<parties>" > profiles/traffic.json
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of the
+bytes of a wide coalesced read stream and WRITE_SIZE the exact bytes (MI355X_MICROARCH.md, HBM section;
+calibrated there for 16-B lanes -- these kernels use 8-B lanes, so treat the read side as approximate).
+Counter units are KB.  Kernel names are normalised to the template spelling used by mkhe_prof_name().
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def per_kernel(d, counter):
+    out = collections.defaultdict(list)
+    for cc in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(cc)):
+            if r["Counter_Name"] != counter:
+                continue
+            m = re.search(r"mkhe::(\w+)(<[^>]*>)?", r["Kernel_Name"])
+            if not m:
+                continue
+            key = m.group(1) + (m.group(2) or "").replace(" ", "")
+            out[key].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    fetch, write, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+    f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(f) | set(w)):
+        fm = sum(f[k]) / len(f[k]) if f.get(k) else 0.0
+        wm = sum(w[k]) / len(w[k]) if w.get(k) else 0.0
+        kernels[k] = dict(fetch_size_kb=fm, write_size_kb=wm, launches=len(f.get(k, [])),
+                          hbm_bytes_per_launch=(2 * fm + wm) * 1024)
+    json.dump(dict(workload=workload, formula="(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch", kernels=kernels),
+              sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
