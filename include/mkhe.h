@@ -136,6 +136,9 @@ int  mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out);
  *      context stream, one record per kernel launch.  Classes (mkhe_prof_name gives the kernel symbol
  *      each class corresponds to in a rocprofv3 kernel trace). */
 int  mkhe_prof_enable(mkhe_ctx* ctx, int on);
+/* diagnostic: forward-NTT workgroups write {start, end (100 MHz ticks), HW_ID, XCC_ID} per job into dev_buf
+ * (4 words per job of the NEXT launches; NULL switches it off) */
+int  mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf);
 int  mkhe_prof_nclass(void);
 const char* mkhe_prof_name(int cls);
 int  mkhe_prof_collect(mkhe_ctx* ctx, double* ms, long* launches, double* alg_bytes);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mkhe_conjugate": (C.c_int, [vp, C.c_uint64, vp, vpp, vp, vp]),
     "mkhe_rescale": (C.c_int, [vp, vp, C.c_int, vp]),
     "mkhe_prof_enable": (C.c_int, [vp, C.c_int]),
+    "mkhe_ntt_trace": (C.c_int, [vp, vp]),
     "mkhe_prof_nclass": (C.c_int, []),
     "mkhe_prof_name": (C.c_char_p, [C.c_int]),
     "mkhe_prof_collect": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),

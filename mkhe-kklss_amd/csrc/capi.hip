@@ -264,6 +264,7 @@ int mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out) {
     MKHE_TRY(ctx->c->rescale(in->c, nb, out->c))
 }
 
+int mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf) { ctx->c->ntt_trace = (u64*)dev_buf; return 0; }
 int mkhe_prof_enable(mkhe_ctx* ctx, int on) { MKHE_TRY(ctx->c->prof_enable(on != 0)) }
 int mkhe_prof_nclass(void) { return Context::PROF_NCLASS; }
 const char* mkhe_prof_name(int cls) {

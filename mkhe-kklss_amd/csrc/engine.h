@@ -36,7 +36,8 @@ class Context {
     int logN, N, nq, np, mtot, gamma, alpha, beta_max, device;
     std::vector<u64> moduli;        // Q then P
     std::vector<u64> psi_plain;     // 2N-th roots actually used
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // main stream: everything the caller observes is ordered on it
+    hipStream_t stream2 = nullptr;     // side stream for independent sub-chains (always joined back into `stream`)
 
     int beta(int level) const { return (level + 1 + alpha - 1) / alpha; }
     size_t swk_words() const { return (size_t)beta_max * mtot * N; }
@@ -68,8 +69,9 @@ class Context {
     u64* pool_y() { return y_; }
     // batched building blocks (all parties in one launch)
     void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst);
-    void ext_batch(int level, const std::vector<ExtItem>& items);
+    void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1);
 
+    u64* ntt_trace = nullptr;          // diagnostic buffer handed to the forward NTT kernels (mkhe_ntt_trace)
     void sync() { MKHE_HIP(hipStreamSynchronize(stream)); }
 
     // ---- per-kernel-class timing with HIP events on the context stream (bench.py roofline leg)
@@ -112,7 +114,7 @@ class Context {
         int level = 0, L = 0, n0 = 0, n1 = 0, nout = 0;
         std::vector<int> slot0, slot1;
         std::vector<const u64*> h0, h1;
-        TensorArgs ta{};
+        bool own0 = false, own1 = false;     // hoisted digits computed by the engine itself
     } plan_;
 
     struct ProfRec { hipEvent_t e0, e1; int cls; double bytes; };
@@ -120,9 +122,14 @@ class Context {
     std::vector<ProfRec> prof_recs_;
     std::vector<hipEvent_t> prof_pool_;
     hipEvent_t prof_event();
+    hipStream_t s_ = nullptr;                                // active stream of the launch helpers
+    hipEvent_t ev_[8] = {};                                  // fork/join events of the side stream
+    void fork_side(int k);      // side stream waits for everything enqueued so far on the active stream
+    void side_done(int k);      // marks the end of side chain k
+    void join_side(int k);      // active stream waits for side chain k
   public:
     struct ProfScope {
-        Context* c; size_t idx; bool on;
+        Context* c; size_t idx; bool on; hipStream_t st;
         ProfScope(Context* c_, int cls, double bytes);
         ~ProfScope();
     };

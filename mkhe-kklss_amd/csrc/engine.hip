@@ -81,6 +81,9 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     for (int i = 0; i < mtot; ++i) small_q_.push_back(moduli[i] < (1ull << 57) ? 1 : 0);   // 34q < 2^63
     MKHE_HIP(hipSetDevice(device));
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    for (auto& e : ev_) MKHE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s_ = stream;
 
     std::vector<Mod> mods(mtot);
     std::vector<u64> psi((size_t)mtot * N), psiinv((size_t)mtot * N), aux(2 * (size_t)mtot);
@@ -158,6 +161,8 @@ Context::~Context() {
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_})
         if (p) (void)hipFree(p);
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
+    for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -182,14 +187,17 @@ hipEvent_t Context::prof_event() {
     if (!prof_pool_.empty()) { hipEvent_t e = prof_pool_.back(); prof_pool_.pop_back(); return e; }
     hipEvent_t e; MKHE_HIP(hipEventCreate(&e)); return e;
 }
-Context::ProfScope::ProfScope(Context* c_, int cls, double bytes) : c(c_), idx(0), on(c_->prof_on_) {
+Context::ProfScope::ProfScope(Context* c_, int cls, double bytes) : c(c_), idx(0), on(c_->prof_on_), st(c_->s_) {
     if (!on) return;
     ProfRec r{c->prof_event(), c->prof_event(), cls, bytes};
-    (void)hipEventRecord(r.e0, c->stream);
+    (void)hipEventRecord(r.e0, st);
     idx = c->prof_recs_.size();
     c->prof_recs_.push_back(r);
 }
-Context::ProfScope::~ProfScope() { if (on) (void)hipEventRecord(c->prof_recs_[idx].e1, c->stream); }
+Context::ProfScope::~ProfScope() { if (on) (void)hipEventRecord(c->prof_recs_[idx].e1, st); }
+void Context::fork_side(int k) { MKHE_HIP(hipEventRecord(ev_[2 * k], s_)); MKHE_HIP(hipStreamWaitEvent(stream2, ev_[2 * k], 0)); }
+void Context::side_done(int k) { MKHE_HIP(hipEventRecord(ev_[2 * k + 1], stream2)); }
+void Context::join_side(int k) { MKHE_HIP(hipStreamWaitEvent(s_, ev_[2 * k + 1], 0)); }
 void Context::prof_enable(bool on) { sync(); prof_on_ = on; }
 void Context::prof_collect(double* ms, long* launches, double* alg_bytes) {
     sync();
@@ -218,12 +226,22 @@ void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
 void Context::ntt_fwd_launch(const NttBatch& b, bool decompose) {
     NttBatch part[2];
     const int n = split_ntt_fwd(b, small_q_.data(), part);
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i) part[i].trace = ntt_trace;
+    // two classes = two kernels; the second one runs on the side stream so that their partial last
+    // waves of workgroups (one workgroup per CU) fill each other's idle CUs
+    const bool side = (n == 2) && (s_ == stream);
+    for (int i = n - 1; i >= 0; --i) {
         const bool small = part[i].lazy_out != 0;
         const int cls = decompose ? (small ? PROF_NTT_DECOMP : PROF_NTT_DECOMP_BIGQ) : (small ? PROF_NTT_FWD : PROF_NTT_FWD_BIGQ);
-        ProfScope ps(this, cls, 16.0 * N * part[i].nouter * part[i].nslots);
-        launch_ntt_fwd_class(logN, part[i], stream);
+        const bool on_side = side && i == 1;
+        if (on_side) { fork_side(0); s_ = stream2; }
+        {
+            ProfScope ps(this, cls, 16.0 * N * part[i].nouter * part[i].nslots);
+            launch_ntt_fwd_class(logN, part[i], s_);
+        }
+        if (on_side) { side_done(0); s_ = stream; }
     }
+    if (side) join_side(0);
 }
 
 // ------------------------------------------------------------------ ring level
@@ -235,7 +253,7 @@ void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, 
     slots_range(b, mod_base, limbs);
     b.src_outer = b.dst_outer = (long)limbs * N; b.src_inner = b.dst_inner = N;
     b.nouter = count; b.lazy_out = lazy ? 1 : 0;
-    if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * limbs); launch_ntt_inv(logN, b, stream); }
+    if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * limbs); launch_ntt_inv(logN, b, s_); }
     else ntt_fwd_launch(b, false);
     MKHE_HIP(hipGetLastError());
 }
@@ -267,19 +285,19 @@ void Context::ext_core(int level, const u64* ah, const u64* bg, u64* c, bool acc
     for (int i = 0; i < nb; ++i) { ip.a[i] = bg + (size_t)i * mtot * N; ip.b[i] = ah + (size_t)i * mtot * N; }
     ip.out = c1_; ip.mods = d_mods; ip.map = map_qp(level);
     ip.term_outer = 0; ip.out_outer = 0; ip.nterms = nb; ip.nslots = nslots; ip.nouter = 1; ip.N = N; ip.mform_out = 0;
-    { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * (2.0 * nb + 1)); launch_inner_product(ip, stream); }
+    { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * (2.0 * nb + 1)); launch_inner_product(ip, s_); }
 
     NttBatch b{};
     b.src = c1_; b.dst = c1_; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
     b.nouter = 1; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
     b.lazy_out = 1;
-    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * nslots); launch_ntt_inv(logN, b, stream); }
+    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * nslots); launch_ntt_inv(logN, b, s_); }
 
     ModDownArgs md{};
     md.xq = c1_; md.xp = c1_ + (size_t)nq * N; md.dst = c; md.mods_q = d_mods; md.mods_p = d_mods + nq;
     md.t = ModDownTables{d_md_qoverqiinvqi, d_md_qoverqimodp, d_md_vtimes, d_md_down};
     md.level = level; md.np = np; md.N = N; md.accumulate = accumulate ? 1 : 0; md.nbatch = 1;
-    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * ((level + 1) * (accumulate ? 3.0 : 2.0) + np)); launch_moddown(md, stream); }
+    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * ((level + 1) * (accumulate ? 3.0 : 2.0) + np)); launch_moddown(md, s_); }
     MKHE_HIP(hipGetLastError());
 }
 void Context::external_product_hoisted(int level, const u64* ah, const u64* bg, u64* c, bool accumulate) {
@@ -313,7 +331,7 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
 }
 
 // items: independent external products  dst (+)= ModDown( sum_i bg[i] (.) ah[i] )
-void Context::ext_batch(int level, const std::vector<ExtItem>& items) {
+void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown) {
     check_level(level);
     const int nb = beta(level), nslots = level + 1 + np;
     const size_t item_words = (size_t)mtot * N;
@@ -324,13 +342,13 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items) {
         for (int i = 0; i < n; ++i) { ia.ah[i] = items[base + i].ah; ia.bg[i] = items[base + i].bg; }
         ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
         ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
-        { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb + 1) * n); launch_ext_inner(ia, stream); }
+        { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb + 1) * n); launch_ext_inner(ia, s_); }
 
         NttBatch b{};
         b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
         b.nouter = n; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
         b.src_outer = b.dst_outer = (long)item_words; b.lazy_out = 1;
-        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, stream); }
+        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, s_); }
 
         ModDownBatchArgs md{};
         md.c1 = c1; md.mods_q = d_mods; md.mods_p = d_mods + nq;
@@ -341,8 +359,10 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items) {
             md.dst[i] = items[base + i].dst; md.accumulate[i] = items[base + i].accumulate ? 1 : 0;
             bytes += 8.0 * N * ((level + 1) * (items[base + i].accumulate ? 3.0 : 2.0) + np);
         }
-        { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_batch(md, stream); }
+        if (join_before_moddown >= 0) { join_side(join_before_moddown); join_before_moddown = -1; }
+        { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_batch(md, s_); }
     }
+    if (join_before_moddown >= 0) join_side(join_before_moddown);
     MKHE_HIP(hipGetLastError());
 }
 
@@ -368,12 +388,14 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
     // out ids must be the union of the operand id sets (newCiphertextBinary, mkckks/evaluator.go:306-313)
     p.slot0.assign(p.n0, 0); p.slot1.assign(p.n1, 0);
     auto find = [&](int id) { for (int o = 0; o < out.n; ++o) if (out.ids[o] == id) return o; return -1; };
-    for (int a = 0; a < p.n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); p.slot0[a] = o; p.ta.slot0[1 + o] = 1 + a; }
-    for (int a = 0; a < p.n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); p.slot1[a] = o; p.ta.slot1[1 + o] = 1 + a; }
-    for (int o = 0; o < out.n; ++o) if (!p.ta.slot0[1 + o] && !p.ta.slot1[1 + o]) throw Error("mkhe: ctOut has an id that neither operand has");
+    std::vector<char> seen(out.n, 0);
+    for (int a = 0; a < p.n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); p.slot0[a] = o; seen[o] = 1; }
+    for (int a = 0; a < p.n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); p.slot1[a] = o; seen[o] = 1; }
+    for (int o = 0; o < out.n; ++o) if (!seen[o]) throw Error("mkhe: ctOut has an id that neither operand has");
     const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N;
     p.h0.assign(p.n0, nullptr); p.h1.assign(p.n1, nullptr);
     const bool same = (&op0 == &op1) && hoist0 == hoist1;
+    p.own0 = (hoist0 == nullptr) && alpha == 1; p.own1 = (hoist1 == nullptr) && alpha == 1;
     std::vector<const u64*> dsrc; std::vector<u64*> ddst;
     for (int a = 0; a < p.n0; ++a) {
         if (hoist0) { if (!hoist0[a]) throw Error("mkhe: missing hoisted form"); p.h0[a] = hoist0[a]->d; }
@@ -405,7 +427,7 @@ void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, 
         }
         ip.out = side ? y : x; ip.mods = d_mods; ip.map = map_qp(p.level);
         ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nb; ip.N = N; ip.mform_out = mform ? 1 : 0;
-        { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nb * (2.0 * n + 1)); launch_inner_product(ip, stream); }
+        { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nb * (2.0 * n + 1)); launch_inner_product(ip, s_); }
     }
     MKHE_HIP(hipGetLastError());
 }
@@ -419,27 +441,44 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
     if (out.limbs != p.L || out.n != p.nout || op0.n != p.n0 || op1.n != p.n1) throw Error("mkhe: mr_finish arguments do not match mr_prepare");
     const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
     const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N, PO = (size_t)L * N;
-    // D: tensor product in the NTT domain, back to coefficients
+    // D: tensor product in the NTT domain, back to coefficients -- on the side stream: it only needs the
+    // operands (and the engine's own hoisted digits) and meets the main chain again at the first ModDown.
     u64* nb_ = scratch(nttbuf_, nttbuf_words_, (size_t)(2 + n0 + n1) * PO);
+    u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
+    fork_side(1);
+    s_ = stream2;
     {
+        // NTT(c0_0), NTT(c1_0) always; party components only when the caller supplied the hoisted forms
+        // (the engine's own hoisted digits already contain NTT(c_i) on their diagonal, alpha = 1)
         NttBatch b{};
         b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_range(b, 0, L);
         b.src_inner = b.dst_inner = N; b.dst_outer = (long)PO;
-        b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.nouter = 1 + n0;
+        b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.nouter = p.own0 ? 1 : 1 + n0;
         ntt_fwd_launch(b, false);
-        b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.nouter = 1 + n1;
+        b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.nouter = p.own1 ? 1 : 1 + n1;
         ntt_fwd_launch(b, false);
     }
-    TensorArgs& ta = p.ta;
-    ta.ntt = nb_; ta.out = out.d; ta.mods = d_mods; ta.n0 = n0; ta.n1 = n1; ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
-    { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, stream); }
+    TensorArgs ta{};
+    ta.a0 = nb_; ta.b0 = nb_ + (size_t)(1 + n0) * PO; ta.out = out.d; ta.mods = d_mods;
+    ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
+    const long diag = (long)(mtot + 1) * N;
+    for (int a = 0; a < n0; ++a) {
+        const int o = 1 + p.slot0[a];
+        if (p.own0) { ta.a[o] = p.h0[a]; ta.a_ls[o] = diag; } else { ta.a[o] = nb_ + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
+    }
+    for (int a = 0; a < n1; ++a) {
+        const int o = 1 + p.slot1[a];
+        if (p.own1) { ta.b[o] = p.h1[a]; ta.b_ls[o] = diag; } else { ta.b[o] = nb_ + (size_t)(2 + n0 + a) * PO; ta.b_ls[o] = N; }
+    }
+    { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, s_); }
     ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
+    side_done(1);
+    s_ = stream;
     // E: out_j += <h(c1_j), x>_P   and   F1: t_i = <h(c0_i), y>_P   (independent products, one batch)
-    u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
     std::vector<ExtItem> items;
     for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
     for (int a = 0; a < n0; ++a) items.push_back(ExtItem{p.h0[a], y, tbuf + (size_t)a * PO, false});
-    ext_batch(level, items);
+    ext_batch(level, items, 1);        // joins the tensor chain before its ModDown accumulates into out
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
@@ -464,7 +503,7 @@ void Context::fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_st
     FoldArgs fa{};
     fa.buf = buf; fa.mods = d_mods; fa.map = qp_shaped ? map_qp(level) : d_map_id;
     fa.nslots = qp_shaped ? level + 1 + np : level + 1; fa.npolys = npolys; fa.poly_stride = poly_stride; fa.N = N; fa.mform = mform ? 1 : 0;
-    { ProfScope ps(this, PROF_OTHER, 16.0 * N * fa.nslots * npolys); launch_fold(fa, stream); }
+    { ProfScope ps(this, PROF_OTHER, 16.0 * N * fa.nslots * npolys); launch_fold(fa, s_); }
     MKHE_HIP(hipGetLastError());
 }
 
@@ -477,7 +516,7 @@ void Context::rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk
     if (out.n != n || out.ids != in.ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
     const size_t PI = (size_t)in.limbs * N, PO = (size_t)L * N;
     u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * PO);
-    MKHE_HIP(hipMemcpyAsync(tmp, in.d, PO * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    MKHE_HIP(hipMemcpyAsync(tmp, in.d, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
     std::vector<const u64*> h(n);
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
@@ -494,7 +533,7 @@ void Context::rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk
         items.push_back(ExtItem{h[a], crs.d, tmp + (size_t)(1 + a) * PO, false});
     }
     ext_batch(level, items);
-    launch_automorphism(out.d, tmp, d_mods, L, logN, galEl, 1 + n, stream);
+    launch_automorphism(out.d, tmp, d_mods, L, logN, galEl, 1 + n, s_);
     MKHE_HIP(hipGetLastError());
 }
 
@@ -506,9 +545,9 @@ void Context::conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk
     if (out.n != n || out.ids != in.ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
     const size_t PI = (size_t)in.limbs * N, PO = (size_t)L * N;
     u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * PO);
-    if (in.limbs == L) launch_automorphism(tmp, in.d, d_mods, L, logN, galEl, 1 + n, stream);
-    else for (int a = 0; a <= n; ++a) launch_automorphism(tmp + a * PO, in.d + a * PI, d_mods, L, logN, galEl, 1, stream);
-    MKHE_HIP(hipMemcpyAsync(out.d, tmp, PO * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    if (in.limbs == L) launch_automorphism(tmp, in.d, d_mods, L, logN, galEl, 1 + n, s_);
+    else for (int a = 0; a <= n; ++a) launch_automorphism(tmp + a * PO, in.d + a * PI, d_mods, L, logN, galEl, 1, s_);
+    MKHE_HIP(hipMemcpyAsync(out.d, tmp, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
     for (int a = 0; a < n; ++a) {
         if (!ck[a]) throw Error("cannot GetConjugationKey: there is no conjugation key with given id");
         decompose(level, false, tmp + (size_t)(1 + a) * PO, swk3_);
@@ -528,17 +567,17 @@ void Context::rescale(const Ct& in, int nb, Ct& out) {
     if (out.limbs != in.limbs - nb || out.n != in.n) throw Error("mkhe: ctOut shape does not match the rescaled ciphertext");
     const int np_ = 1 + in.n;
     const size_t PI = (size_t)in.limbs * N, PO = (size_t)out.limbs * N;
-    if (nb == 0) { if (out.d != in.d) MKHE_HIP(hipMemcpyAsync(out.d, in.d, np_ * PI * sizeof(u64), hipMemcpyDeviceToDevice, stream)); return; }
+    if (nb == 0) { if (out.d != in.d) MKHE_HIP(hipMemcpyAsync(out.d, in.d, np_ * PI * sizeof(u64), hipMemcpyDeviceToDevice, s_)); return; }
     if (nb == 1) {
-        launch_div_round_last(out.d, in.d, d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, np_, (long)PI, (long)PO, stream);
+        launch_div_round_last(out.d, in.d, d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, np_, (long)PI, (long)PO, s_);
     } else {
         u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)np_ * PI);
-        launch_div_round_last(tmp, in.d, d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, np_, (long)PI, (long)PI, stream);
+        launch_div_round_last(tmp, in.d, d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, np_, (long)PI, (long)PI, s_);
         for (int k = 1; k < nb; ++k) {
             const int lv = level - k;
             const bool last = (k == nb - 1);
             launch_div_round_last(last ? out.d : tmp, tmp, d_mods, d_rescale + (size_t)(lv - 1) * nq, lv, N, np_,
-                                  (long)PI, last ? (long)PO : (long)PI, stream);
+                                  (long)PI, last ? (long)PO : (long)PI, s_);
         }
     }
     MKHE_HIP(hipGetLastError());

@@ -47,6 +47,7 @@ struct NttBatch {
     int reduce_in;          // forward only: input is a digit spread under a foreign modulus (Decompose)
     int reduce_src_mod_is_outer;   // the digit's own modulus index = outer (alpha = 1)
     int lazy_out;           // inverse only: leave [0,2q) (InvNTTLazy)
+    u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
     int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists
     int mod[NTT_MAX_SLOTS];
     int pos[NTT_MAX_SLOTS];

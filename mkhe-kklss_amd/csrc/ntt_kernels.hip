@@ -10,6 +10,10 @@
 //    once at the end with a Montgomery product by R mod q;
 //  * all pointers are address_space(1) so loads are global_load (vmcnt only), never flat_load.
 #include "ntt_kernels.h"
+#include <cstdlib>
+#ifndef MKHE_SB_MASK
+#define MKHE_SB_MASK 1
+#endif
 
 namespace mkhe {
 
@@ -30,14 +34,26 @@ template <int LOGN> struct Geo {
 template <int LOGN> __device__ __forceinline__ int posA(int t, int r) { return (r << (LOGN - 5)) | t; }
 __device__ __forceinline__ int posB(int t, int r) { return ((t >> 5) << 10) | (r << 5) | (t & 31); }
 __device__ __forceinline__ int posC(int t, int r) { return (t << 5) | r; }
-__device__ __forceinline__ int swz(int p) { return p ^ ((p >> 5) & 31); }
 
 enum Layout { LA = 0, LB = 1, LC = 2 };
-template <int LOGN, int L> __device__ __forceinline__ int pos(int t, int r) {
-    if constexpr (L == LA) return posA<LOGN>(t, r);
-    else if constexpr (L == LB) return posB(t, r);
-    else return posC(t, r);
+
+// LDS image of a limb plane: word address of coefficient p is p + (p >> 5) (one pad word per 32), so
+// that every layout addresses its 32 registers as base(thread) + r * stride with a compile-time stride:
+//   A: p = r*2^(n-5) + t        -> base t + (t>>5),          stride 2^(n-5) + 2^(n-10)
+//   B: p = hi*1024 + r*32 + lo  -> base hi*1056 + lo,        stride 33
+//   C: p = t*32 + r             -> base 33*t,                stride 1
+// i.e. the LDS instructions carry immediate offsets and no per-access address arithmetic is issued.
+// Conflict-free for all three under the 32-bank rule of ds_read_b32 / ds_write_b32 (lanes of a 32-lane
+// group differ in t (A), lo (B: consecutive words) or t (C: stride 33 = 1 mod 32)).
+template <int LOGN, int L> __device__ __forceinline__ int lds_base(int t) {
+    if constexpr (L == LA) return t + (t >> 5);
+    else if constexpr (L == LB) return (t >> 5) * 1056 + (t & 31);
+    else return 33 * t;
 }
+template <int LOGN, int L> constexpr int lds_stride() {
+    return L == LA ? ((1 << (LOGN - 5)) + (1 << (LOGN - 10))) : (L == LB ? 33 : 1);
+}
+template <int LOGN> constexpr int lds_words() { return (1 << LOGN) + (1 << (LOGN - 5)); }
 
 // ordering point between LDS phases: workgroup barrier when the exchange crosses waves, otherwise
 // only a compiler/wave-level fence (DS operations of one wave execute in issue order).
@@ -47,11 +63,42 @@ template <bool CROSS> __device__ __forceinline__ void lds_sync() {
 }
 
 // Re-distribute the 32 registers of every thread from layout FROM to layout TO through LDS,
-// one 32-bit plane at a time (N*4 bytes of LDS per limb).
+// one 32-bit plane at a time (about N*4 bytes of LDS per limb).
 template <int LOGN, int FROM, int TO, bool CROSS>
 __device__ __forceinline__ void exchange(u64 (&x)[32], u32* lds, int t) {
-    // the thread index is made opaque before every pass so that the 64 LDS addresses are recomputed
-    // (2 VALU each) instead of being kept live across the four passes (VGPR budget is 128)
+    // the thread index is made opaque here so that the (loop-invariant) LDS base addresses are recomputed
+    // next to their use instead of being hoisted out of the persistent loop and spilled (VGPR budget 128)
+    asm volatile("" : "+v"(t));
+    u32* wr = lds + lds_base<LOGN, FROM>(t);
+    u32* rd = lds + lds_base<LOGN, TO>(t);
+    constexpr int SW = lds_stride<LOGN, FROM>(), SR = lds_stride<LOGN, TO>();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) wr[r * SW] = lo32(x[r]);
+    lds_sync<CROSS>();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = (x[r] & 0xffffffff00000000ull) | rd[r * SR];
+    lds_sync<CROSS>();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) wr[r * SW] = hi32(x[r]);
+    lds_sync<CROSS>();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = ((u64)rd[r * SR] << 32) | lo32(x[r]);
+    // no trailing workgroup barrier: the next LDS writer of any region is either its own half wave
+    // (wave-local exchanges, ordered by issue order) or sits behind the explicit barrier of the next limb
+    if constexpr (!CROSS) lds_sync<false>();
+}
+
+// XOR-swizzled variant (word address p ^ ((p >> 5) & 31), N words per plane, two VALU per access): used by the
+// inverse kernel, whose register allocation is tighter with per-access addresses than with the base +
+// immediate form above (scratch 60 B vs 288 B per lane, 68 vs 90 us per limb on MI355X).
+template <int LOGN, int L> __device__ __forceinline__ int pos(int t, int r) {
+    if constexpr (L == LA) return posA<LOGN>(t, r);
+    else if constexpr (L == LB) return posB(t, r);
+    else return posC(t, r);
+}
+__device__ __forceinline__ int swz(int p) { return p ^ ((p >> 5) & 31); }
+template <int LOGN, int FROM, int TO, bool CROSS>
+__device__ __forceinline__ void exchange_xor(u64 (&x)[32], u32* lds, int t) {
     asm volatile("" : "+v"(t));
 #pragma unroll
     for (int r = 0; r < 32; ++r) lds[swz(pos<LOGN, FROM>(t, r))] = lo32(x[r]);
@@ -67,7 +114,7 @@ __device__ __forceinline__ void exchange(u64 (&x)[32], u32* lds, int t) {
     asm volatile("" : "+v"(t));
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = ((u64)lds[swz(pos<LOGN, TO>(t, r))] << 32) | lo32(x[r]);
-    lds_sync<CROSS>();
+    if constexpr (!CROSS) lds_sync<false>();
 }
 
 // ------------------------------------------------------------------ butterflies
@@ -97,17 +144,42 @@ __device__ __forceinline__ void bfly_inv(u64& U, u64& V, u64 w, u64 q, u64 q2, u
 // MODE: 0 forward reduced, 1 forward never-reduced, 2 inverse.
 template <int B, int MODE>
 __device__ __forceinline__ void stage(u64 (&x)[32], gcptr tw, u64 q, u64 q2, u32 ninv) {
-    constexpr int NW = 16 >> B;
-    u64 w[NW];
+    constexpr int NW = 16 >> B;                 // twiddles of this stage
+#ifdef MKHE_NO_CHUNK
+    constexpr int CH = NW;
+#else
+    constexpr int CH = NW < 4 ? NW : 4;         // twiddles held at a time (one chunk in use + one in flight:
+#endif
+    constexpr int NCH = NW / CH;                //  <= 16 VGPRs instead of 32 at B = 0; the budget is 128)
+    constexpr int BPC = 16 / NCH;               // butterflies per chunk
+    u64 wc[CH], wn[CH];
 #pragma unroll
-    for (int k = 0; k < NW; ++k) w[k] = tw[k];
+    for (int k = 0; k < CH; ++k) wc[k] = tw[k];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
-        const int i1 = i0 | (1 << B);
-        if constexpr (MODE == 2) bfly_inv(x[i0], x[i1], w[g >> B], q, q2, ninv);
-        else if constexpr (MODE == 1) bfly_fwd_nr(x[i0], x[i1], w[g >> B], q, q2, ninv);
-        else bfly_fwd_cs(x[i0], x[i1], w[g >> B], q, q2, ninv);
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) wn[k] = tw[(c + 1) * CH + k];
+        }
+#pragma unroll
+        for (int gg = 0; gg < BPC; ++gg) {
+            const int g = c * BPC + gg;
+            const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+            const int i1 = i0 | (1 << B);
+            const u64 w = wc[(g >> B) - c * CH];
+            if constexpr (MODE == 2) bfly_inv(x[i0], x[i1], w, q, q2, ninv);
+            else if constexpr (MODE == 1) bfly_fwd_nr(x[i0], x[i1], w, q, q2, ninv);
+            else bfly_fwd_cs(x[i0], x[i1], w, q, q2, ninv);
+            // at 4 waves/SIMD the other waves hide the latency of one wave's dependency chain;
+            // interleaving more than two butterflies only adds live temporaries
+#ifndef MKHE_NO_SCHEDBAR
+            if ((gg & MKHE_SB_MASK) == MKHE_SB_MASK) __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) wc[k] = wn[k];
+        }
     }
     // keep the next stage's twiddle loads from being hoisted above this stage (register pressure)
     asm volatile("" ::: "memory");
@@ -162,11 +234,22 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     using G = Geo<LOGN>;
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
     const int sub = G::LPB == 1 ? 0 : threadIdx.x / G::T, t = G::LPB == 1 ? threadIdx.x : threadIdx.x % G::T;
-    u32* lds = lds_all + sub * G::N;
-    int job = blockIdx.x * G::LPB + sub;
+    u32* lds = lds_all + sub * lds_words<LOGN>();
     const int njobs = b.nslots * b.nouter;
+    // persistent workgroups: each one walks the job list with stride gridDim.x.  A wave that finishes its
+    // part of a limb starts loading the next limb at once; the only workgroup-wide rendezvous are the
+    // barriers around the cross-wave exchange.
+#pragma unroll 1
+    for (int jb = blockIdx.x * G::LPB; jb < njobs; jb += gridDim.x * G::LPB) {
+    int job = jb + sub;
     const bool active = job < njobs;
     if (!active) job = njobs - 1;            // keep every lane in the barriers; results discarded
+    if constexpr (G::LPB == 1) job = __builtin_amdgcn_readfirstlane(job);    // provably wave-uniform: modulus constants and pointers stay in SGPRs
+    if (b.trace && t == 0 && active) {
+        b.trace[4 * job + 0] = __builtin_amdgcn_s_memrealtime();
+        b.trace[4 * job + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+        b.trace[4 * job + 3] = __builtin_amdgcn_s_memtime();                                     // shader clock ticks
+    }
     gcptr src; gptr dst; int m, outer;
     job_pointers(b, job, src, dst, m, outer);
     const Mod md = b.mods[m];
@@ -191,8 +274,12 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
         if (ph == 1) { base = G::N >> 6; prefix = t >> 5; maxB = G::MIDB; }
         if (ph == 2) { base = G::N >> 1; prefix = t; }
         phase<MODE>(x, psi, base, prefix, maxB, q, q2, ninv);
-        if (ph == 0) { if constexpr (G::HAS_MID) exchange<LOGN, LA, LB, true>(x, lds, t); }
-        else if (ph == 1) exchange<LOGN, LB, LC, false>(x, lds, t);
+        if (ph == 0) {
+            if constexpr (G::HAS_MID) {
+                __syncthreads();     // every wave is done with the LDS of the previous limb
+                exchange<LOGN, LA, LB, true>(x, lds, t);
+            }
+        } else if (ph == 1) exchange<LOGN, LB, LC, false>(x, lds, t);
     }
     // canonical output (lattigo: final BRedAdd)
     if constexpr (MODE == 1) {
@@ -208,6 +295,8 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) dst[posB(t, r)] = x[r];
     }
+    if (b.trace && t == 0 && active) { b.trace[4 * job + 1] = __builtin_amdgcn_s_memrealtime(); b.trace[4 * job + 3] = __builtin_amdgcn_s_memtime() - b.trace[4 * job + 3]; }
+    }
 }
 
 // ------------------------------------------------------------------ inverse kernel
@@ -216,11 +305,14 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     using G = Geo<LOGN>;
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
     const int sub = G::LPB == 1 ? 0 : threadIdx.x / G::T, t = G::LPB == 1 ? threadIdx.x : threadIdx.x % G::T;
-    u32* lds = lds_all + sub * G::N;
-    int job = blockIdx.x * G::LPB + sub;
+    u32* lds = lds_all + sub * lds_words<LOGN>();
     const int njobs = b.nslots * b.nouter;
+#pragma unroll 1
+    for (int jb = blockIdx.x * G::LPB; jb < njobs; jb += gridDim.x * G::LPB) {
+    int job = jb + sub;
     const bool active = job < njobs;
     if (!active) job = njobs - 1;
+    if constexpr (G::LPB == 1) job = __builtin_amdgcn_readfirstlane(job);    // provably wave-uniform: modulus constants and pointers stay in SGPRs
     gcptr src; gptr dst; int m, outer;
     job_pointers(b, job, src, dst, m, outer);
     const Mod md = b.mods[m];
@@ -231,15 +323,16 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     u64 x[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = src[posB(t, r)];
-    exchange<LOGN, LB, LC, false>(x, lds, t);
+    if constexpr (G::HAS_MID) __syncthreads();   // other waves may still read this half-wave's LDS region (previous limb)
+    exchange_xor<LOGN, LB, LC, false>(x, lds, t);
     // phases: 0 = index bits 0..4 (layout C), 1 = bits 5..MIDTOP (layout B); the top phase follows
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
         int base = G::N >> 1, prefix = t, maxB = 4;
         if (ph == 1) { base = G::N >> 6; prefix = t >> 5; maxB = G::MIDB; }
         phase<2>(x, psi, base, prefix, maxB, q, q2, ninv);
-        if (ph == 0) exchange<LOGN, LC, LB, false>(x, lds, t);
-        else { if constexpr (G::HAS_MID) exchange<LOGN, LB, LA, true>(x, lds, t); }
+        if (ph == 0) exchange_xor<LOGN, LC, LB, false>(x, lds, t);
+        else { if constexpr (G::HAS_MID) exchange_xor<LOGN, LB, LA, true>(x, lds, t); }
     }
     // top phase: index bits n-5 .. n-2, then the last stage with N^-1 folded in
     phase<2>(x, psi, 16, 0, 3, q, q2, ninv);
@@ -256,23 +349,39 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) dst[posA<LOGN>(t, r)] = x[r];
     }
+    }
 }
 
 // ------------------------------------------------------------------ launchers
+// workgroups that are co-resident on the whole chip for this kernel (persistent grid size)
+static int resident_blocks(const void* fn, int threads, size_t lds) {
+    if (const char* e = getenv("MKHE_NTT_GRID")) { if (e[0] == 'f') return 1 << 30; }     // "full": one workgroup per limb (A/B testing)
+    int dev = 0, cus = 256, per = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, lds) != hipSuccess || per < 1) per = 1;
+    return cus * per;
+}
 template <int LOGN, int MODE, bool DEC> static void launch_fwd_t(const NttBatch& b, hipStream_t st) {
     using G = Geo<LOGN>;
     static bool attr = false;
-    const size_t lds = (size_t)G::LPB * G::N * sizeof(u32);
+    const size_t lds = (size_t)G::LPB * lds_words<LOGN>() * sizeof(u32);
     if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN, MODE, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    const int blocks = (b.nslots * b.nouter + G::LPB - 1) / G::LPB;
+    static int resident = 0;
+    if (!resident) resident = resident_blocks((const void*)ntt_fwd_kernel<LOGN, MODE, DEC>, G::BT, lds);
+    const int need = (b.nslots * b.nouter + G::LPB - 1) / G::LPB;
+    const int blocks = need < resident ? need : resident;
     hipLaunchKernelGGL((ntt_fwd_kernel<LOGN, MODE, DEC>), dim3(blocks), dim3(G::BT), lds, st, b);
 }
 template <int LOGN> static void launch_inv_t(const NttBatch& b, hipStream_t st) {
     using G = Geo<LOGN>;
     static bool attr = false;
-    const size_t lds = (size_t)G::LPB * G::N * sizeof(u32);
+    const size_t lds = (size_t)G::LPB * lds_words<LOGN>() * sizeof(u32);
     if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    const int blocks = (b.nslots * b.nouter + G::LPB - 1) / G::LPB;
+    static int resident = 0;
+    if (!resident) resident = resident_blocks((const void*)ntt_inv_kernel<LOGN>, G::BT, lds);
+    const int need = (b.nslots * b.nouter + G::LPB - 1) / G::LPB;
+    const int blocks = need < resident ? need : resident;
     hipLaunchKernelGGL(ntt_inv_kernel<LOGN>, dim3(blocks), dim3(G::BT), lds, st, b);
 }
 

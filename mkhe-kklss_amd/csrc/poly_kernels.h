@@ -82,13 +82,18 @@ void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st);
 
 // Tensor step D of MulAndRelin (keyswitch_hoisted.go:120-140) on NTT-domain inputs.
 //   out_0 = a0*b0 ; out_o = b0*a_o (o in ids0) (+)= a0*b_o (o in ids1)
+// NTT(c0_i) / NTT(c1_j) of the party components are read either from a plain NTT buffer (limb stride N)
+// or straight from the hoisted digits: for alpha = 1 digit l under its own modulus l IS NTT_l(c limb l),
+// i.e. the diagonal h[l][l] (limb stride (nQ+nP+1)*N) -- those NTTs need not be recomputed.
 struct TensorArgs {
-    const u64* ntt;            // [(1+n0) + (1+n1)][L][N]  NTT of op0 slots then op1 slots
+    const u64* a0;             // [L][N]  NTT(c0_0)
+    const u64* b0;             // [L][N]  NTT(c1_0)
     u64* out;                  // [1+nout][L][N]
     const Mod* mods;
-    int slot0[33];             // for out slot o>=1: index into op0 slots (1..n0) or 0 if absent
-    int slot1[33];             // likewise for op1
-    int n0, n1, nout, L, N;
+    const u64* a[33];          // per out slot o>=1: NTT(c0_o) base or NULL
+    const u64* b[33];          // per out slot o>=1: NTT(c1_o) base or NULL
+    long a_ls[33], b_ls[33];   // limb strides of the above
+    int nout, L, N;
     int with_c0;               // 0: leave c0_0*c1_0 out of out_0 (party-sharded evaluation)
 };
 void launch_tensor(const TensorArgs& a, hipStream_t st);

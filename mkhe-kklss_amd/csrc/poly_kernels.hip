@@ -160,25 +160,26 @@ void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ tensor (step D)
+typedef const __attribute__((address_space(4))) TensorArgs* tensor_kargs;
 __global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
+    tensor_kargs ka = (tensor_kargs)__builtin_amdgcn_kernarg_segment_ptr();    // per-slot lists: scalar loads
     const int l = blockIdx.y;
     const Mod md = a.mods[l];
     const u64 q = md.q;
     const u32 ninv = md.ninv32;
-    const long P = (long)a.L * a.N;          // words per poly
-    const u64* op0 = a.ntt;
-    const u64* op1 = a.ntt + (long)(1 + a.n0) * P;
+    const long P = (long)a.L * a.N;          // words per output poly
     for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
         const long e = (long)l * a.N + n;
-        const u64 a0m = mont_mul(op0[e], md.r2, q, ninv);     // MForm(NTT(c0_0))
-        const u64 b0 = op1[e];
+        const u64 a0m = mont_mul(a.a0[e], md.r2, q, ninv);    // MForm(NTT(c0_0))
+        const u64 b0 = a.b0[e];
         const u64 b0m = mont_mul(b0, md.r2, q, ninv);         // MForm(NTT(c1_0))
         a.out[e] = a.with_c0 ? mont_mul(a0m, b0, q, ninv) : 0;
         for (int o = 1; o <= a.nout; ++o) {
             u64 r = 0;
-            const int s0 = a.slot0[o], s1 = a.slot1[o];
-            if (s0) r = mont_mul(b0m, op0[(long)s0 * P + e], q, ninv);
-            if (s1) r = csub(r + mont_mul(a0m, op1[(long)s1 * P + e], q, ninv), q);
+            const u64* pa = ka->a[o];
+            const u64* pb = ka->b[o];
+            if (pa) r = mont_mul(b0m, pa[(long)l * ka->a_ls[o] + n], q, ninv);
+            if (pb) r = csub(r + mont_mul(a0m, pb[(long)l * ka->b_ls[o] + n], q, ninv), q);
             a.out[(long)o * P + e] = r;
         }
     }
