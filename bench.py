@@ -76,6 +76,8 @@ def run_single(args):
         rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, n, b, d, v))
     params.AddCRS(-1, data["u"])
     ev = mkckks.NewEvaluator(params)
+    if os.environ.get("MKHE_NO_OVERLAP"):
+        check(lib().mkhe_set_overlap(params.ctx, 0))
 
     def step():
         return ev.MulRelinNew(ct0, ct1, rlk)
@@ -92,7 +94,10 @@ def run_single(args):
     value = args.steps / dt
 
     # ---- roofline leg: per-kernel HIP-event timing on the context stream, same steps again
+    # (side-stream overlap off: each kernel then runs alone, so its duration is the kernel's own and
+    #  comparable with the rocprofv3 kernel trace taken with MKHE_NO_OVERLAP=1; `value` above is measured with overlap on)
     ncls = lib().mkhe_prof_nclass()
+    check(lib().mkhe_set_overlap(params.ctx, 0))
     check(lib().mkhe_prof_enable(params.ctx, 1))
     for _ in range(args.steps):
         res = step()
@@ -101,6 +106,7 @@ def run_single(args):
     byt = (C.c_double * ncls)()
     check(lib().mkhe_prof_collect(params.ctx, ms, cnt, byt))
     check(lib().mkhe_prof_enable(params.ctx, 0))
+    check(lib().mkhe_set_overlap(params.ctx, 0 if os.environ.get("MKHE_NO_OVERLAP") else 1))
     names_k = [lib().mkhe_prof_name(i).decode().replace("<N,", "<%d," % pset["logN"]).replace("<N>", "<%d>" % pset["logN"])
                for i in range(ncls)]
     kernels = {}

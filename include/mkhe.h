@@ -108,16 +108,17 @@ int  mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
  *      sum_i d_i (.) h(c0_i), sum_j b_j (.) h(c1_j) WITHOUT MForm (keyswitch_hoisted.go:79-92,99-113).
  *      The caller sums them over ranks as uint64 (RCCL all-reduce; exact while ranks*q < 2^63), calls
  *      mkhe_swk_fold(.., mform=1) (= MFormLvl of the total, :94-96,115-117) and then mkhe_mr_finish
- *      (steps D-F, :119-178).  with_c0 != 0 on exactly one rank adds c0_0*c1_0 to out_0; out_0 and any
+ *      (steps E-F, :146-178; the tensor step D, :119-144, is started by mkhe_mr_partial and written into
+ *      `out`).  with_c0 != 0 on exactly one rank adds c0_0*c1_0 to out_0; out_0 and any
  *      out_i whose two operand components live on different ranks are partial sums to be reduced and
  *      folded with mkhe_ct_fold. */
 int  mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                      const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
                      const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
-                     const mkhe_ct* out_shape, mkhe_swk* x_part, mkhe_swk* y_part);
+                     int with_c0, mkhe_ct* out, mkhe_swk* x_part, mkhe_swk* y_part);
 int  mkhe_swk_fold(mkhe_ctx* ctx, mkhe_swk* swk, int level, int mform);
 int  mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x, const mkhe_swk* y,
-                    const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, int with_c0, mkhe_ct* out);
+                    const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out);
 int  mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct);
 
 /* ---- KeySwitcher.Rotate keyswitch.go:234-298 / RotateHoisted keyswitch_hoisted.go:183-247.
@@ -136,6 +137,9 @@ int  mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out);
  *      context stream, one record per kernel launch.  Classes (mkhe_prof_name gives the kernel symbol
  *      each class corresponds to in a rocprofv3 kernel trace). */
 int  mkhe_prof_enable(mkhe_ctx* ctx, int on);
+/* on = 0: no side-stream overlap, every kernel runs alone on the main stream (per-kernel timings that can be
+ * compared with a rocprofv3 kernel trace); default on = 1 */
+int  mkhe_set_overlap(mkhe_ctx* ctx, int on);
 /* diagnostic: forward-NTT workgroups write {start, end (100 MHz ticks), HW_ID, XCC_ID} per job into dev_buf
  * (4 words per job of the NEXT launches; NULL switches it off) */
 int  mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf);

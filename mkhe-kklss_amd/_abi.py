@@ -47,15 +47,16 @@ SIGNATURES = {
     "mkhe_external_product": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int]),
     "mkhe_external_product_hoisted": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int]),
     "mkhe_mul_and_relin": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),
-    "mkhe_mr_partial": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vp, vp, vp]),
+    "mkhe_mr_partial": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, C.c_int, vp, vp, vp]),
     "mkhe_swk_fold": (C.c_int, [vp, vp, C.c_int, C.c_int]),
-    "mkhe_mr_finish": (C.c_int, [vp, vp, vp, vp, vp, vpp, vp, C.c_int, vp]),
+    "mkhe_mr_finish": (C.c_int, [vp, vp, vp, vp, vp, vpp, vp, vp]),
     "mkhe_ct_fold": (C.c_int, [vp, vp]),
     "mkhe_rotate":(C.c_int, [vp, C.c_uint64, vp, vpp, vpp, vp, vp]),
     "mkhe_conjugate": (C.c_int, [vp, C.c_uint64, vp, vpp, vp, vp]),
     "mkhe_rescale": (C.c_int, [vp, vp, C.c_int, vp]),
     "mkhe_prof_enable": (C.c_int, [vp, C.c_int]),
     "mkhe_ntt_trace": (C.c_int, [vp, vp]),
+    "mkhe_set_overlap": (C.c_int, [vp, C.c_int]),
     "mkhe_prof_nclass": (C.c_int, []),
     "mkhe_prof_name": (C.c_char_p, [C.c_int]),
     "mkhe_prof_collect": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),

@@ -52,16 +52,14 @@ int mkhe_swk_create(mkhe_ctx* ctx, mkhe_swk** out) {
         Context* c = ctx->c;
         MKHE_HIP(hipSetDevice(c->device));
         mkhe_swk* s = new mkhe_swk();
-        hipError_t e = hipMalloc(&s->s.d, c->swk_words() * sizeof(u64));
-        if (e != hipSuccess) { delete s; throw Error(std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        try { s->s.d = c->pool_alloc(c->swk_words()); } catch (...) { delete s; throw; }
         MKHE_HIP(hipMemsetAsync(s->s.d, 0, c->swk_words() * sizeof(u64), c->stream));
         *out = s;
     })
 }
 void mkhe_swk_destroy(mkhe_ctx* ctx, mkhe_swk* swk) {
     if (!swk) return;
-    if (ctx) (void)hipStreamSynchronize(ctx->c->stream);
-    if (swk->s.d && swk->s.owned) (void)hipFree(swk->s.d);
+    if (swk->s.d && swk->s.owned) { if (ctx) ctx->c->pool_free(swk->s.d, ctx->c->swk_words()); else (void)hipFree(swk->s.d); }
     delete swk;
 }
 int mkhe_swk_upload(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* host) {
@@ -99,16 +97,14 @@ int mkhe_ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, mkhe_ct** ou
         t->c.n = n; t->c.limbs = limbs; t->c.ids.assign(ids, ids + n);
         for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (ids[i] == ids[j]) { delete t; throw Error("mkhe_ct_create: repeated id"); }
         const size_t w = (size_t)(1 + n) * limbs * c->N;
-        hipError_t e = hipMalloc(&t->c.d, w * sizeof(u64));
-        if (e != hipSuccess) { delete t; throw Error(std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        try { t->c.d = c->pool_alloc(w); } catch (...) { delete t; throw; }
         MKHE_HIP(hipMemsetAsync(t->c.d, 0, w * sizeof(u64), c->stream));
         *out = t;
     })
 }
 void mkhe_ct_destroy(mkhe_ctx* ctx, mkhe_ct* ct) {
     if (!ct) return;
-    if (ctx) (void)hipStreamSynchronize(ctx->c->stream);
-    if (ct->c.d) (void)hipFree(ct->c.d);
+    if (ct->c.d) { if (ctx) ctx->c->pool_free(ct->c.d, (size_t)(1 + ct->c.n) * ct->c.limbs * ctx->c->N); else (void)hipFree(ct->c.d); }
     delete ct;
 }
 int mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host) {
@@ -221,12 +217,12 @@ int mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
 int mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                     const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
                     const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
-                    const mkhe_ct* out_shape, mkhe_swk* x_part, mkhe_swk* y_part) {
+                    int with_c0, mkhe_ct* out, mkhe_swk* x_part, mkhe_swk* y_part) {
     MKHE_TRY({
-        if (!op0 || !op1 || !out_shape || !x_part || !y_part || !rlk_b1 || !rlk_d0) throw Error("mkhe_mr_partial: null argument");
+        if (!op0 || !op1 || !out || !x_part || !y_part || !rlk_b1 || !rlk_d0) throw Error("mkhe_mr_partial: null argument");
         auto h0 = swk_list(hoist0, op0->c.n); auto h1 = swk_list(hoist1, op1->c.n);
         auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n);
-        ctx->c->mr_prepare(op0->c, op1->c, hoist0 ? h0.data() : nullptr, hoist1 ? h1.data() : nullptr, out_shape->c);
+        ctx->c->mr_prepare(op0->c, op1->c, hoist0 ? h0.data() : nullptr, hoist1 ? h1.data() : nullptr, with_c0 != 0, out->c);
         ctx->c->mr_xy(b1.data(), d0.data(), x_part->s.d, y_part->s.d, false);
     })
 }
@@ -234,11 +230,11 @@ int mkhe_swk_fold(mkhe_ctx* ctx, mkhe_swk* swk, int level, int mform) {
     MKHE_TRY(ctx->c->fold(swk->s.d, true, level, ctx->c->beta(level), (long)ctx->c->mtot * ctx->c->N, mform != 0))
 }
 int mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x, const mkhe_swk* y,
-                   const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, int with_c0, mkhe_ct* out) {
+                   const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out) {
     MKHE_TRY({
         if (!op0 || !op1 || !x || !y || !rlk_v0 || !crs_u || !out) throw Error("mkhe_mr_finish: null argument");
         auto v0 = swk_list(rlk_v0, op0->c.n);
-        ctx->c->mr_finish(op0->c, op1->c, x->s.d, y->s.d, v0.data(), crs_u->s, with_c0 != 0, out->c);
+        ctx->c->mr_finish(op0->c, op1->c, x->s.d, y->s.d, v0.data(), crs_u->s, out->c);
     })
 }
 int mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct) {
@@ -264,6 +260,7 @@ int mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out) {
     MKHE_TRY(ctx->c->rescale(in->c, nb, out->c))
 }
 
+int mkhe_set_overlap(mkhe_ctx* ctx, int on) { MKHE_TRY({ ctx->c->sync(); ctx->c->overlap = on != 0; }) }
 int mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf) { ctx->c->ntt_trace = (u64*)dev_buf; return 0; }
 int mkhe_prof_enable(mkhe_ctx* ctx, int on) { MKHE_TRY(ctx->c->prof_enable(on != 0)) }
 int mkhe_prof_nclass(void) { return Context::PROF_NCLASS; }

@@ -60,10 +60,10 @@ class Context {
     void rescale(const Ct& in, int nb, Ct& out);
     // MulAndRelin split in phases (party-sharded multi-GPU evaluation: the x / y partial sums and out_0
     // are reduced across devices between the phases)
-    void mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, const Ct& out);
+    void mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, bool with_c0, Ct& out);
     void mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform);
     void mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
-                   const Swk& crs_u, bool with_c0, Ct& out);
+                   const Swk& crs_u, Ct& out);
     void fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform);
     u64* pool_x() { return x_; }
     u64* pool_y() { return y_; }
@@ -71,7 +71,13 @@ class Context {
     void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst);
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1);
 
+    bool overlap = true;               // false: everything on the main stream (clean per-kernel timings)
     u64* ntt_trace = nullptr;          // diagnostic buffer handed to the forward NTT kernels (mkhe_ntt_trace)
+    // stream-ordered buffer cache for ciphertext / switching-key handles: freeing a handle does not
+    // synchronise or hipFree, the words go back to a size-keyed free list and are reused by the next
+    // create (all work of a context is ordered on its main stream, so reuse is safe).
+    u64* pool_alloc(size_t words);
+    void pool_free(u64* p, size_t words);
     void sync() { MKHE_HIP(hipStreamSynchronize(stream)); }
 
     // ---- per-kernel-class timing with HIP events on the context stream (bench.py roofline leg)
@@ -116,6 +122,8 @@ class Context {
         std::vector<const u64*> h0, h1;
         bool own0 = false, own1 = false;     // hoisted digits computed by the engine itself
     } plan_;
+
+    std::vector<std::pair<size_t, u64*>> free_list_;
 
     struct ProfRec { hipEvent_t e0, e1; int cls; double bytes; };
     bool prof_on_ = false;

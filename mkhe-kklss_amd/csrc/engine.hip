@@ -161,11 +161,23 @@ Context::~Context() {
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_})
         if (p) (void)hipFree(p);
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
+    for (auto& f : free_list_) (void)hipFree(f.second);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
+u64* Context::pool_alloc(size_t words) {
+    for (size_t i = 0; i < free_list_.size(); ++i)
+        if (free_list_[i].first == words) { u64* p = free_list_[i].second; free_list_.erase(free_list_.begin() + i); return p; }
+    MKHE_HIP(hipSetDevice(device));
+    return dev_alloc_words(words);
+}
+void Context::pool_free(u64* p, size_t words) {
+    if (!p) return;
+    if (free_list_.size() >= 64) { (void)hipStreamSynchronize(stream); (void)hipFree(p); return; }
+    free_list_.push_back({words, p});
+}
 u64* Context::scratch(u64*& p, size_t& have, size_t want) {
     if (have < want) {
         if (p) { MKHE_HIP(hipStreamSynchronize(stream)); MKHE_HIP(hipFree(p)); p = nullptr; }
@@ -195,9 +207,9 @@ Context::ProfScope::ProfScope(Context* c_, int cls, double bytes) : c(c_), idx(0
     c->prof_recs_.push_back(r);
 }
 Context::ProfScope::~ProfScope() { if (on) (void)hipEventRecord(c->prof_recs_[idx].e1, st); }
-void Context::fork_side(int k) { MKHE_HIP(hipEventRecord(ev_[2 * k], s_)); MKHE_HIP(hipStreamWaitEvent(stream2, ev_[2 * k], 0)); }
-void Context::side_done(int k) { MKHE_HIP(hipEventRecord(ev_[2 * k + 1], stream2)); }
-void Context::join_side(int k) { MKHE_HIP(hipStreamWaitEvent(s_, ev_[2 * k + 1], 0)); }
+void Context::fork_side(int k) { if (!overlap) return; MKHE_HIP(hipEventRecord(ev_[2 * k], s_)); MKHE_HIP(hipStreamWaitEvent(stream2, ev_[2 * k], 0)); }
+void Context::side_done(int k) { if (!overlap) return; MKHE_HIP(hipEventRecord(ev_[2 * k + 1], stream2)); }
+void Context::join_side(int k) { if (!overlap) return; MKHE_HIP(hipStreamWaitEvent(s_, ev_[2 * k + 1], 0)); }
 void Context::prof_enable(bool on) { sync(); prof_on_ = on; }
 void Context::prof_collect(double* ms, long* launches, double* alg_bytes) {
     sync();
@@ -234,7 +246,7 @@ void Context::ntt_fwd_launch(const NttBatch& b, bool decompose) {
         const bool small = part[i].lazy_out != 0;
         const int cls = decompose ? (small ? PROF_NTT_DECOMP : PROF_NTT_DECOMP_BIGQ) : (small ? PROF_NTT_FWD : PROF_NTT_FWD_BIGQ);
         const bool on_side = side && i == 1;
-        if (on_side) { fork_side(0); s_ = stream2; }
+        if (on_side) { fork_side(0); s_ = overlap ? stream2 : stream; }
         {
             ProfScope ps(this, cls, 16.0 * N * part[i].nouter * part[i].nslots);
             launch_ntt_fwd_class(logN, part[i], s_);
@@ -371,13 +383,15 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
 void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
                             const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                             const Swk& crs_u, Ct& out) {
-    mr_prepare(op0, op1, hoist0, hoist1, out);
+    mr_prepare(op0, op1, hoist0, hoist1, true, out);
     mr_xy(rlk_b1, rlk_d0, x_, y_, true);
-    mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, true, out);
+    mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
 }
 
 // -- step 0: validate, map ids, hoist the operands when the caller did not (MulRelinNew, evaluator.go:416-443)
-void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, const Ct& out) {
+// and start step D (tensor).  with_c0 = false leaves c0_0*c1_0 out of out_0 (another rank of a party-sharded
+// evaluation adds it).
+void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, bool with_c0, Ct& out) {
     MrPlan& p = plan_;
     p = MrPlan{};
     p.level = out.limbs - 1; p.L = p.level + 1;
@@ -407,6 +421,51 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
         else { Swk& s = hoist_slot(1, a); dsrc.push_back(op1.d + (1 + a) * P1); ddst.push_back(s.d); p.h1[a] = s.d; }
     }
     if (!dsrc.empty()) decompose_batch(p.level, dsrc, ddst);
+    // D: tensor product in the NTT domain, back to coefficients -- started here on the side stream: it only
+    // needs the operands and the engine's own hoisted digits, runs beside the x / y accumulation and meets
+    // the main chain again at the first ModDown of mr_finish.
+    {
+        const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
+        const size_t PO = (size_t)L * N;
+        u64* nb_ = scratch(nttbuf_, nttbuf_words_, (size_t)(2 + n0 + n1) * PO);
+        (void)level;
+        fork_side(1);
+        s_ = overlap ? stream2 : stream;
+        {
+            // NTT(c0_0), NTT(c1_0) always; party components only when the caller supplied the hoisted forms
+            // (the engine's own hoisted digits already contain NTT(c_i) on their diagonal, alpha = 1)
+            NttBatch b{};
+            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_range(b, 0, L);
+            b.src_inner = b.dst_inner = N; b.dst_outer = (long)PO;
+            if (p.own0 && p.own1) {
+                b.nitems = 2; b.outers_per_item = 1; b.nouter = 2;
+                b.src_items[0] = op0.d; b.src_items[1] = op1.d;
+                b.dst_items[0] = nb_; b.dst_items[1] = nb_ + (size_t)(1 + n0) * PO;
+                ntt_fwd_launch(b, false);
+            } else {
+                b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.nouter = p.own0 ? 1 : 1 + n0;
+                ntt_fwd_launch(b, false);
+                b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.nouter = p.own1 ? 1 : 1 + n1;
+                ntt_fwd_launch(b, false);
+            }
+        }
+        TensorArgs ta{};
+        ta.a0 = nb_; ta.b0 = nb_ + (size_t)(1 + n0) * PO; ta.out = out.d; ta.mods = d_mods;
+        ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
+        const long diag = (long)(mtot + 1) * N;
+        for (int a = 0; a < n0; ++a) {
+            const int o = 1 + p.slot0[a];
+            if (p.own0) { ta.a[o] = p.h0[a]; ta.a_ls[o] = diag; } else { ta.a[o] = nb_ + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
+        }
+        for (int a = 0; a < n1; ++a) {
+            const int o = 1 + p.slot1[a];
+            if (p.own1) { ta.b[o] = p.h1[a]; ta.b_ls[o] = diag; } else { ta.b[o] = nb_ + (size_t)(2 + n0 + a) * PO; ta.b_ls[o] = N; }
+        }
+        { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, s_); }
+        ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
+        side_done(1);
+        s_ = stream;
+    }
     p.valid = true;
 }
 
@@ -433,47 +492,14 @@ void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, 
 }
 
 // -- steps D, E, F (keyswitch_hoisted.go:119-178) with x, y in Montgomery form.
-// with_c0 = false leaves c0_0*c1_0 out of out_0 (another rank of a party-sharded evaluation adds it).
 void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
-                        const Swk& crs_u, bool with_c0, Ct& out) {
+                        const Swk& crs_u, Ct& out) {
     MrPlan& p = plan_;
     if (!p.valid) throw Error("mkhe: mr_finish without mr_prepare");
     if (out.limbs != p.L || out.n != p.nout || op0.n != p.n0 || op1.n != p.n1) throw Error("mkhe: mr_finish arguments do not match mr_prepare");
     const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
-    const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N, PO = (size_t)L * N;
-    // D: tensor product in the NTT domain, back to coefficients -- on the side stream: it only needs the
-    // operands (and the engine's own hoisted digits) and meets the main chain again at the first ModDown.
-    u64* nb_ = scratch(nttbuf_, nttbuf_words_, (size_t)(2 + n0 + n1) * PO);
+    const size_t PO = (size_t)L * N;
     u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
-    fork_side(1);
-    s_ = stream2;
-    {
-        // NTT(c0_0), NTT(c1_0) always; party components only when the caller supplied the hoisted forms
-        // (the engine's own hoisted digits already contain NTT(c_i) on their diagonal, alpha = 1)
-        NttBatch b{};
-        b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_range(b, 0, L);
-        b.src_inner = b.dst_inner = N; b.dst_outer = (long)PO;
-        b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.nouter = p.own0 ? 1 : 1 + n0;
-        ntt_fwd_launch(b, false);
-        b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.nouter = p.own1 ? 1 : 1 + n1;
-        ntt_fwd_launch(b, false);
-    }
-    TensorArgs ta{};
-    ta.a0 = nb_; ta.b0 = nb_ + (size_t)(1 + n0) * PO; ta.out = out.d; ta.mods = d_mods;
-    ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
-    const long diag = (long)(mtot + 1) * N;
-    for (int a = 0; a < n0; ++a) {
-        const int o = 1 + p.slot0[a];
-        if (p.own0) { ta.a[o] = p.h0[a]; ta.a_ls[o] = diag; } else { ta.a[o] = nb_ + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
-    }
-    for (int a = 0; a < n1; ++a) {
-        const int o = 1 + p.slot1[a];
-        if (p.own1) { ta.b[o] = p.h1[a]; ta.b_ls[o] = diag; } else { ta.b[o] = nb_ + (size_t)(2 + n0 + a) * PO; ta.b_ls[o] = N; }
-    }
-    { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, s_); }
-    ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
-    side_done(1);
-    s_ = stream;
     // E: out_j += <h(c1_j), x>_P   and   F1: t_i = <h(c0_i), y>_P   (independent products, one batch)
     std::vector<ExtItem> items;
     for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});

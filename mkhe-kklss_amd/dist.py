@@ -97,7 +97,7 @@ class HipShardBackend:
         b1 = [self.keys[n][0].h for n in self.op1.ids]
         d0 = [self.keys[n][1].h for n in self.op0.ids]
         self.check(self.lib().mkhe_mr_partial(self.params.ctx, self.op0.h, self.op1.h, None, None,
-                                              self._arr(b1), self._arr(d0), self.out.h, self.x.h, self.y.h))
+                                              self._arr(b1), self._arr(d0), 1 if self.with_c0 else 0, self.out.h, self.x.h, self.y.h))
         return self.tx, self.ty
 
     def before_collective(self):
@@ -113,7 +113,7 @@ class HipShardBackend:
     def finish(self):
         v0 = [self.keys[n][2].h for n in self.op0.ids]
         self.check(self.lib().mkhe_mr_finish(self.params.ctx, self.op0.h, self.op1.h, self.x.h, self.y.h,
-                                             self._arr(v0), self.params.CRS[-1].h, 1 if self.with_c0 else 0, self.out.h))
+                                             self._arr(v0), self.params.CRS[-1].h, self.out.h))
         self.params.sync()
         self.tfull.zero_()
         self.tfull[0].copy_(self.tout[0])
