@@ -95,6 +95,22 @@ def lib():
         L.ora_conjugate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, i32p, u64p, C.c_int, pp, u64p, u64p]
         L.ora_ckks_nb_rescales.restype = C.c_int
         L.ora_ckks_nb_rescales.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double]
+        L.ora_bfv_new.restype = C.c_void_p
+        L.ora_bfv_new.argtypes = [C.c_int, u64p, u64p, C.c_int, u64p, C.c_int, C.c_int, C.c_uint64]
+        L.ora_bfv_free.argtypes = [C.c_void_p]
+        L.ora_bfv_ks.restype = C.c_void_p
+        L.ora_bfv_ks.argtypes = [C.c_void_p]
+        L.ora_bfv_ringqmul.restype = C.c_void_p
+        L.ora_bfv_ringqmul.argtypes = [C.c_void_p]
+        for name in ("ora_bfv_modup_q_to_r", "ora_bfv_rescale", "ora_bfv_quantize"):
+            getattr(L, name).argtypes = [C.c_void_p, u64p, u64p]
+        L.ora_bfv_decompose.argtypes = [C.c_void_p, u64p, u64p, u64p]
+        L.ora_bfv_external_product.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p]
+        L.ora_bfv_external_product_hoisted.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p, u64p]
+        L.ora_bfv_mul_and_relin.argtypes = [C.c_void_p, C.c_int, i32p, u64p, C.c_int, i32p, u64p,
+                                            pp, pp, pp, pp, pp, pp, pp, pp, pp, u64p, C.c_int, i32p, u64p]
+        L.ora_bfv_mul_relin_new.argtypes = [C.c_void_p, C.c_int, i32p, u64p, C.c_int, i32p, u64p,
+                                            pp, pp, pp, pp, pp, u64p, C.c_int, C.c_int, i32p, u64p]
         _lib = L
     return _lib
 
@@ -269,14 +285,18 @@ class BasisExtender:
 class KeySwitcher:
     """mkrlwe.KeySwitcher restated.  Switching keys are uint64[betaMax][nQ+nP][N]."""
 
-    def __init__(self, logN, Q, P, gamma=2, psiQ=None, psiP=None):
+    def __init__(self, logN, Q, P, gamma=2, psiQ=None, psiP=None, _handle=None, _owner=None):
         self.logN, self.N = logN, 1 << logN
         self.Q, self.P, self.gamma = [int(q) for q in Q], [int(p) for p in P], gamma
         q, p = _u64arr(self.Q), _u64arr(self.P)
         pq = _u64arr(psiQ) if psiQ is not None else None
         ppp = _u64arr(psiP) if psiP is not None else None
-        self.h = lib().ora_ks_new(logN, _p(q), len(self.Q), _p(p), len(self.P), gamma,
-                                  _p(pq) if pq is not None else None, _p(ppp) if ppp is not None else None)
+        self._owner = _owner            # a BFV object that owns the handle
+        if _handle is not None:
+            self.h = _handle
+        else:
+            self.h = lib().ora_ks_new(logN, _p(q), len(self.Q), _p(p), len(self.P), gamma,
+                                      _p(pq) if pq is not None else None, _p(ppp) if ppp is not None else None)
         if not self.h:
             raise ValueError("ora_ks_new failed")
         self.alpha = lib().ora_ks_alpha(self.h)
@@ -286,9 +306,9 @@ class KeySwitcher:
         self.m = len(self.Q) + len(self.P)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(self, "_owner", None) is None:
             lib().ora_ks_free(self.h)
-            self.h = None
+        self.h = None
 
     def beta(self, level):
         return lib().ora_ks_beta(self.h, level)
@@ -395,3 +415,103 @@ class KeySwitcher:
         s = C.c_double(scale)
         nb = lib().ora_ckks_nb_rescales(self.ringQ.h, level, C.byref(s), float(min_scale))
         return nb, s.value
+
+
+class BFV:
+    """mkbfv Evaluator / KeySwitcher / FastBasisExtender restated (alpha = 1, maximum level).
+    rlk of a party = (b1, b2, d1, d2, v): Value[0].Value[0], Value[1].Value[0], Value[0].Value[1],
+    Value[1].Value[1], Value[0].Value[2] of mkbfv.RelinearizationKey (keys.go:6-9, keygen.go:41-83)."""
+
+    def __init__(self, logN, Q, QMul, P, T, gamma=2):
+        self.logN, self.N = logN, 1 << logN
+        self.Q, self.QMul, self.P, self.T = [int(q) for q in Q], [int(q) for q in QMul], [int(p) for p in P], int(T)
+        assert len(self.Q) == len(self.QMul)
+        q, qm, p = _u64arr(self.Q), _u64arr(self.QMul), _u64arr(self.P)
+        self.h = lib().ora_bfv_new(logN, _p(q), _p(qm), len(self.Q), _p(p), len(self.P), gamma, self.T)
+        if not self.h:
+            raise ValueError("ora_bfv_new failed (alpha must be 1)")
+        self.ks = KeySwitcher(logN, self.Q, self.P, gamma, _handle=lib().ora_bfv_ks(self.h), _owner=self)
+        self.ringQ, self.ringP = self.ks.ringQ, self.ks.ringP
+        self.ringQMul = Ring(logN, self.QMul, _handle=lib().ora_bfv_ringqmul(self.h), _owner=self)
+        self.nq = len(self.Q)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ora_bfv_free(self.h)
+            self.h = None
+
+    def _conv(self, fn, a, out_limbs):
+        a = _u64arr(a)
+        out = np.empty((out_limbs, self.N), dtype=np.uint64)
+        getattr(lib(), fn)(self.h, _p(a), _p(out))
+        return out
+
+    def modup_q_to_r(self, polyq): return self._conv("ora_bfv_modup_q_to_r", polyq, 2 * self.nq)
+    def rescale(self, polyq): return self._conv("ora_bfv_rescale", polyq, 2 * self.nq)
+    def quantize(self, polyr_ntt): return self._conv("ora_bfv_quantize", polyr_ntt, self.nq)
+
+    def ntt_r(self, polyr):
+        return np.stack([self.ringQ.ntt(j, polyr[j]) if j < self.nq else self.ringQMul.ntt(j - self.nq, polyr[j])
+                         for j in range(2 * self.nq)])
+
+    def decompose(self, ar):
+        ar = _u64arr(ar)
+        ad1, ad2 = self.ks.new_swk(), self.ks.new_swk()
+        lib().ora_bfv_decompose(self.h, _p(ar), _p(ad1), _p(ad2))
+        return ad1, ad2
+
+    def external_product(self, ar, bg1, bg2):
+        ar, bg1, bg2 = _u64arr(ar), _u64arr(bg1), _u64arr(bg2)
+        c = np.empty((self.nq, self.N), dtype=np.uint64)
+        lib().ora_bfv_external_product(self.h, _p(ar), _p(bg1), _p(bg2), _p(c))
+        return c
+
+    def external_product_hoisted(self, ah1, ah2, bg1, bg2):
+        ah1, ah2, bg1, bg2 = _u64arr(ah1), _u64arr(ah2), _u64arr(bg1), _u64arr(bg2)
+        c = np.empty((self.nq, self.N), dtype=np.uint64)
+        lib().ora_bfv_external_product_hoisted(self.h, _p(ah1), _p(ah2), _p(bg1), _p(bg2), _p(c))
+        return c
+
+    def _rlk_ptrs(self, rlk, npar):
+        out, keep = [], []
+        for k in range(5):
+            p, kp = _ptrs({i: rlk[i][k] for i in rlk}, npar)
+            out.append(p)
+            keep.append(kp)
+        return out, keep
+
+    def mul_and_relin(self, ids0, op0r, ids1, op1r, rlk, crs_u, hoist0=None, hoist1=None):
+        """MulAndRelinBFV[Hoisted] on R-basis operands uint64[1+n][2nQ][N]; hoist*: {id: (ad1, ad2)} or None."""
+        op0r, op1r, crs_u = _u64arr(op0r), _u64arr(op1r), _u64arr(crs_u)
+        ids_out = sorted(set(ids0) | set(ids1))
+        npar = max(ids_out + [0]) + 1
+        out = np.zeros((1 + len(ids_out), self.nq, self.N), dtype=np.uint64)
+        a0, p0 = _i32(ids0)
+        a1, p1 = _i32(ids1)
+        ao, po = _i32(ids_out)
+        rl, keep = self._rlk_ptrs(rlk, npar)
+        hp, hk = [None] * 4, []
+        if hoist0 is not None or hoist1 is not None:
+            assert hoist0 is not None and hoist1 is not None
+            for k, (h, j) in enumerate(((hoist0, 0), (hoist0, 1), (hoist1, 0), (hoist1, 1))):
+                hp[k], kk = _ptrs({i: h[i][j] for i in h}, npar)
+                hk.append(kk)
+        lib().ora_bfv_mul_and_relin(self.h, len(ids0), p0, _p(op0r), len(ids1), p1, _p(op1r),
+                                    hp[0], hp[1], hp[2], hp[3], rl[0], rl[1], rl[2], rl[3], rl[4],
+                                    _p(crs_u), len(ids_out), po, _p(out))
+        return ids_out, out
+
+    def mul_relin_new(self, ids0, op0, ids1, op1, rlk, crs_u, hoisted=True):
+        """Evaluator.MulRelinNew on Q-basis ciphertexts uint64[1+n][nQ][N] -> (ids_out, out)."""
+        op0, op1, crs_u = _u64arr(op0), _u64arr(op1), _u64arr(crs_u)
+        ids_out = sorted(set(ids0) | set(ids1))
+        npar = max(ids_out + [0]) + 1
+        out = np.zeros((1 + len(ids_out), self.nq, self.N), dtype=np.uint64)
+        a0, p0 = _i32(ids0)
+        a1, p1 = _i32(ids1)
+        ao, po = _i32(ids_out)
+        rl, keep = self._rlk_ptrs(rlk, npar)
+        lib().ora_bfv_mul_relin_new(self.h, len(ids0), p0, _p(op0), len(ids1), p1, _p(op1),
+                                    rl[0], rl[1], rl[2], rl[3], rl[4], _p(crs_u), 1 if hoisted else 0,
+                                    len(ids_out), po, _p(out))
+        return ids_out, out
