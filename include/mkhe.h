@@ -133,6 +133,42 @@ int  mkhe_conjugate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe
  *      ring.DivRoundByLastModulusManyLvl on every poly; out has limbs(in)-nb limbs. */
 int  mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out);
 
+/* ---- elementwise evaluator ops on resident ciphertexts ("next" row of SURVEY.md 8f):
+ *      mkckks/evaluator.go:41-104 (evaluateInPlace, add, sub) and mkbfv/evaluator.go:27-76.  out carries the
+ *      union of the id sets; components only one operand has are copied (Sub: negated when they come from op1). */
+int  mkhe_ct_add(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out);
+int  mkhe_ct_sub(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out);
+
+/* ==== mkbfv ========================================================================================
+ * Context for mkbfv.NewParametersFromLiteral (mkbfv/params.go:28-76): rings Q, QMul (same length), R = Q||QMul,
+ * P and the plaintext modulus T; replaces mkbfv.NewKeySwitcher (keyswitch.go:31-65) + NewFastBasisExtender
+ * (basis_extension.go:20-47).  PCount/gamma must be 1 (one prime per gadget digit), as in both reference
+ * parameter sets.  Every mkrlwe-level call above works on such a context too (BFV Rotate / Conjugate use
+ * mkhe_rotate / mkhe_conjugate directly: mkbfv/evaluator.go:142-207).
+ * PolyR device layout: uint64[2*nQ][N], limbs 0..nQ-1 under Q, nQ..2nQ-1 under QMul. */
+int  mkhe_ctx_create_bfv(mkhe_ctx** out, int logN, const uint64_t* Q, const uint64_t* QMul, int nQ,
+                         const uint64_t* P, int nP, int gamma, uint64_t T, int device);
+/* FastBasisExtender.ModUpQtoR / Rescale / Quantize (mkbfv/basis_extension.go:49-96) on raw device buffers:
+ * npolys polynomials, polyq = [npolys][nQ][N], polyr = [npolys][2nQ][N] (Quantize: polyr in the NTT domain). */
+int  mkhe_bfv_modup_q_to_r(mkhe_ctx* ctx, const void* dev_polyq, void* dev_polyr, int npolys);
+int  mkhe_bfv_rescale(mkhe_ctx* ctx, const void* dev_polyq, void* dev_polyr, int npolys);
+int  mkhe_bfv_quantize(mkhe_ctx* ctx, const void* dev_polyr_ntt, void* dev_polyq, int npolys);
+/* ringR.NTT / InvNTT (keyswitch_hoisted.go:128-129) on [count][2nQ][N] */
+int  mkhe_bfv_ntt_r(mkhe_ctx* ctx, const void* dev_src, void* dev_dst, int count, int inverse);
+/* KeySwitcher.DecomposeBFV (mkbfv/keyswitch.go:67-90): one PolyR (coefficient domain) -> ad1 (Q digits), ad2 (QMul digits) */
+int  mkhe_bfv_decompose(mkhe_ctx* ctx, const void* dev_polyr, mkhe_swk* ad1, mkhe_swk* ad2);
+/* KeySwitcher.ExternalProductBFVHoisted (keyswitch_hoisted.go:6-34): c = ModDown_P(sum bg1.ah1 + bg2.ah2), [nQ][N] */
+int  mkhe_bfv_external_product_hoisted(mkhe_ctx* ctx, const mkhe_swk* ah1, const mkhe_swk* ah2,
+                                       const mkhe_swk* bg1, const mkhe_swk* bg2, void* dev_c);
+/* Evaluator.MulRelinNew (mkbfv/evaluator.go:78-82) = mulRelinHoisted (:118-140) + MulAndRelinBFVHoisted
+ * (keyswitch_hoisted.go:36-206).  Ciphertexts at the maximum level, coefficient domain.  Key lists aligned with
+ * the operand ids: rlk_b1/b2[j] = rlkSet[ids1[j]].Value[0/1].Value[0], rlk_d1/d2[i] = rlkSet[ids0[i]].Value[0/1].Value[1],
+ * rlk_v[i] = rlkSet[ids0[i]].Value[0].Value[2]; crs_u = params.CRS[-1]. */
+int  mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                        const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
+                        const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2,
+                        const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out);
+
 /* ---- measurement support (no reference counterpart): HIP-event timing per kernel class on the
  *      context stream, one record per kernel launch.  Classes (mkhe_prof_name gives the kernel symbol
  *      each class corresponds to in a rocprofv3 kernel trace). */

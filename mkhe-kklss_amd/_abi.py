@@ -54,6 +54,16 @@ SIGNATURES = {
     "mkhe_rotate":(C.c_int, [vp, C.c_uint64, vp, vpp, vpp, vp, vp]),
     "mkhe_conjugate": (C.c_int, [vp, C.c_uint64, vp, vpp, vp, vp]),
     "mkhe_rescale": (C.c_int, [vp, vp, C.c_int, vp]),
+    "mkhe_ct_add": (C.c_int, [vp, vp, vp, vp]),
+    "mkhe_ct_sub": (C.c_int, [vp, vp, vp, vp]),
+    "mkhe_ctx_create_bfv": (C.c_int, [vpp, C.c_int, u64p, u64p, C.c_int, u64p, C.c_int, C.c_int, C.c_uint64, C.c_int]),
+    "mkhe_bfv_modup_q_to_r": (C.c_int, [vp, vp, vp, C.c_int]),
+    "mkhe_bfv_rescale": (C.c_int, [vp, vp, vp, C.c_int]),
+    "mkhe_bfv_quantize": (C.c_int, [vp, vp, vp, C.c_int]),
+    "mkhe_bfv_ntt_r": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+    "mkhe_bfv_decompose": (C.c_int, [vp, vp, vp, vp]),
+    "mkhe_bfv_external_product_hoisted": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+    "mkhe_bfv_mul_relin": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),
     "mkhe_prof_enable": (C.c_int, [vp, C.c_int]),
     "mkhe_ntt_trace": (C.c_int, [vp, vp]),
     "mkhe_set_overlap": (C.c_int, [vp, C.c_int]),

@@ -43,7 +43,7 @@ int mkhe_ctx_alpha(const mkhe_ctx* ctx) { return ctx->c->alpha; }
 int mkhe_ctx_beta(const mkhe_ctx* ctx, int level) { return ctx->c->beta(level); }
 int mkhe_ctx_n(const mkhe_ctx* ctx) { return ctx->c->N; }
 size_t mkhe_ctx_swk_words(const mkhe_ctx* ctx) { return ctx->c->swk_words(); }
-uint64_t mkhe_ctx_psi(const mkhe_ctx* ctx, int i) { return (i >= 0 && i < ctx->c->mtot) ? ctx->c->psi_plain[i] : 0; }
+uint64_t mkhe_ctx_psi(const mkhe_ctx* ctx, int i) { return (i >= 0 && i < ctx->c->mall) ? ctx->c->psi_plain[i] : 0; }
 void* mkhe_ctx_stream(mkhe_ctx* ctx) { return (void*)ctx->c->stream; }
 
 // ---- switching keys
@@ -258,6 +258,58 @@ int mkhe_conjugate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_
 }
 int mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out) {
     MKHE_TRY(ctx->c->rescale(in->c, nb, out->c))
+}
+
+int mkhe_ct_add(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out) {
+    MKHE_TRY({ if (!op0 || !op1 || !out) throw Error("mkhe_ct_add: null argument"); ctx->c->ct_binary(0, op0->c, op1->c, out->c); })
+}
+int mkhe_ct_sub(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out) {
+    MKHE_TRY({ if (!op0 || !op1 || !out) throw Error("mkhe_ct_sub: null argument"); ctx->c->ct_binary(1, op0->c, op1->c, out->c); })
+}
+
+// ---- mkbfv
+int mkhe_ctx_create_bfv(mkhe_ctx** out, int logN, const uint64_t* Q, const uint64_t* QMul, int nQ,
+                        const uint64_t* P, int nP, int gamma, uint64_t T, int device) {
+    MKHE_TRY({
+        if (!out || !Q || !QMul || !P) throw Error("mkhe_ctx_create_bfv: null argument");
+        *out = new mkhe_ctx{new Context(logN, Q, nQ, P, nP, gamma, nullptr, nullptr, device, QMul, nQ, T)};
+    })
+}
+int mkhe_bfv_modup_q_to_r(mkhe_ctx* ctx, const void* q, void* r, int npolys) {
+    MKHE_TRY({ if (!q || !r || npolys < 1) throw Error("mkhe_bfv_modup_q_to_r: bad argument"); ctx->c->bfv_modup_q_to_r((const u64*)q, (u64*)r, npolys); })
+}
+int mkhe_bfv_rescale(mkhe_ctx* ctx, const void* q, void* r, int npolys) {
+    MKHE_TRY({ if (!q || !r || npolys < 1) throw Error("mkhe_bfv_rescale: bad argument"); ctx->c->bfv_rescale((const u64*)q, (u64*)r, npolys); })
+}
+int mkhe_bfv_quantize(mkhe_ctx* ctx, const void* r, void* q, int npolys) {
+    MKHE_TRY({ if (!q || !r || npolys < 1) throw Error("mkhe_bfv_quantize: bad argument"); ctx->c->bfv_quantize((const u64*)r, (u64*)q, npolys); })
+}
+int mkhe_bfv_ntt_r(mkhe_ctx* ctx, const void* src, void* dst, int count, int inverse) {
+    MKHE_TRY({ if (!src || !dst || count < 1) throw Error("mkhe_bfv_ntt_r: bad argument"); ctx->c->ntt_r((const u64*)src, (u64*)dst, count, inverse != 0); })
+}
+int mkhe_bfv_decompose(mkhe_ctx* ctx, const void* polyr, mkhe_swk* ad1, mkhe_swk* ad2) {
+    MKHE_TRY({
+        if (!polyr || !ad1 || !ad2) throw Error("mkhe_bfv_decompose: null argument");
+        ctx->c->bfv_decompose_batch({(const u64*)polyr}, {ad1->s.d}, {ad2->s.d});
+    })
+}
+int mkhe_bfv_external_product_hoisted(mkhe_ctx* ctx, const mkhe_swk* ah1, const mkhe_swk* ah2,
+                                      const mkhe_swk* bg1, const mkhe_swk* bg2, void* dev_c) {
+    MKHE_TRY({
+        if (!ah1 || !ah2 || !bg1 || !bg2 || !dev_c) throw Error("mkhe_bfv_external_product_hoisted: null argument");
+        ctx->c->bfv_external_product_hoisted(ah1->s.d, ah2->s.d, bg1->s.d, bg2->s.d, (u64*)dev_c);
+    })
+}
+int mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                       const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
+                       const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2,
+                       const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out) {
+    MKHE_TRY({
+        if (!op0 || !op1 || !out || !crs_u || !rlk_b1 || !rlk_b2 || !rlk_d1 || !rlk_d2 || !rlk_v) throw Error("mkhe_bfv_mul_relin: null argument");
+        auto b1 = swk_list(rlk_b1, op1->c.n); auto b2 = swk_list(rlk_b2, op1->c.n);
+        auto d1 = swk_list(rlk_d1, op0->c.n); auto d2 = swk_list(rlk_d2, op0->c.n); auto v = swk_list(rlk_v, op0->c.n);
+        ctx->c->bfv_mul_relin(op0->c, op1->c, b1.data(), b2.data(), d1.data(), d2.data(), v.data(), crs_u->s, out->c);
+    })
 }
 
 int mkhe_set_overlap(mkhe_ctx* ctx, int on) { MKHE_TRY({ ctx->c->sync(); ctx->c->overlap = on != 0; }) }

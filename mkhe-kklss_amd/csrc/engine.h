@@ -25,16 +25,19 @@ struct Swk { u64* d = nullptr; bool owned = true; };
 // device ciphertext: uint64[1+n][limbs][N], slot 0 = c_0, slot 1+i = party ids[i]
 struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
 // one external product of a batch: dst (+)= ModDown_P( sum_i bg[i] (.) ah[i] )
-struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; };
+struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const u64* ah2 = nullptr; const u64* bg2 = nullptr; };
 
 class Context {
   public:
+    // QMul / T: optional mkbfv extension (mkbfv/params.go:30-76): nqm = nq extra primes and the plaintext modulus
     Context(int logN, const u64* Q, int nq, const u64* P, int np, int gamma,
-            const u64* psiQ, const u64* psiP, int device);
+            const u64* psiQ, const u64* psiP, int device, const u64* QMul = nullptr, int nqm = 0, u64 T = 0);
     ~Context();
 
     int logN, N, nq, np, mtot, gamma, alpha, beta_max, device;
-    std::vector<u64> moduli;        // Q then P
+    int nqm = 0, mall = 0;          // QMul primes (BFV) and the total number of moduli with tables
+    u64 bfv_t = 0;
+    std::vector<u64> moduli;        // Q then P (then QMul)
     std::vector<u64> psi_plain;     // 2N-th roots actually used
     hipStream_t stream = nullptr;      // main stream: everything the caller observes is ordered on it
     hipStream_t stream2 = nullptr;     // side stream for independent sub-chains (always joined back into `stream`)
@@ -56,6 +59,19 @@ class Context {
                        const Swk& crs_u, Ct& out);
     void rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, Ct& out);
     void conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk& crs, Ct& out);
+    // ---- mkbfv (mkbfv/basis_extension.go, keyswitch.go, keyswitch_hoisted.go, evaluator.go); PolyR = [2nq][N]
+    bool is_bfv() const { return nqm > 0; }
+    void bfv_modup_q_to_r(const u64* polyq, u64* polyr, int npolys);          // conv.ModUpQtoR
+    void bfv_rescale(const u64* polyq, u64* polyr, int npolys);               // conv.Rescale
+    void bfv_quantize(const u64* polyr_ntt, u64* polyq, int npolys);          // conv.Quantize (polyr_ntt is consumed)
+    void bfv_decompose_batch(const std::vector<const u64*>& srcr, const std::vector<u64*>& ad1, const std::vector<u64*>& ad2);
+    void bfv_external_product_hoisted(const u64* ah1, const u64* ah2, const u64* bg1, const u64* bg2, u64* c);
+    void bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
+                       const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
+                       const Swk& crs_u, Ct& out);                            // Evaluator.MulRelinNew
+    // elementwise evaluator ops (mkckks/evaluator.go:41-300, mkbfv/evaluator.go:27-76): op 0 add, 1 sub
+    void ct_binary(int op, const Ct& a, const Ct& b, Ct& out);
+    void ntt_r(const u64* src, u64* dst, int count, bool inverse);            // ringR.NTT / InvNTT
     // mkckks Rescale body: nb successive DivRoundByLastModulus on every poly (evaluator.go:385-391)
     void rescale(const Ct& in, int nb, Ct& out);
     // MulAndRelin split in phases (party-sharded multi-GPU evaluation: the x / y partial sums and out_0
@@ -92,6 +108,11 @@ class Context {
     int *d_map_qp = nullptr, *d_map_id = nullptr;
     u64 *d_md_qoverqiinvqi = nullptr, *d_md_qoverqimodp = nullptr, *d_md_vtimes = nullptr, *d_md_down = nullptr;
     u64* d_rescale = nullptr;
+    // mkbfv tables: convQQMul in both directions, ModDown constants, mFormQMul, MForm(t) per limb of R
+    int* d_map_r = nullptr;
+    u64 *d_bq_qoverqiinvqi = nullptr, *d_bq_qoverqimodp = nullptr, *d_bq_vtimes = nullptr;     // Q -> QMul
+    u64 *d_bm_qoverqiinvqi = nullptr, *d_bm_qoverqimodp = nullptr, *d_bm_vtimes = nullptr;     // QMul -> Q
+    u64 *d_down_q_in_m = nullptr, *d_down_m_in_q = nullptr, *d_mform_qmul = nullptr, *d_t_mont = nullptr;
 
   private:
     // scratch pools
@@ -101,7 +122,9 @@ class Context {
     u64* invntt_ = nullptr;                                  // ks.PoolInvNTT
     u64* nttbuf_ = nullptr; size_t nttbuf_words_ = 0;        // tensor inputs in NTT form
     u64* ctbuf_ = nullptr;  size_t ctbuf_words_ = 0;         // rotate / rescale staging
-    std::vector<Swk> hoist_pool_[3];                         // rlkSet.HoistPool[0/1] + h(t_i) of step F
+    std::vector<Swk> hoist_pool_[5];                         // rlkSet.HoistPool[0/1] + h(t_i) of step F; [3],[4]: BFV HoistPool2[0/1]
+    u64 *x2_ = nullptr, *y2_ = nullptr;                      // BFV swkPool4 / swkPool6
+    u64* rbuf_ = nullptr;  size_t rbuf_words_ = 0;          // BFV: operands over R, their NTTs, tensor output
     u64* c1b_ = nullptr;   size_t c1b_words_ = 0;           // batched ks.Pool[1]
     u64* tbuf_ = nullptr;  size_t tbuf_words_ = 0;          // t_i of step F
 

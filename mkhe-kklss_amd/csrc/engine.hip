@@ -62,8 +62,9 @@ static u64* dev_alloc_words(size_t w) { u64* d = nullptr; MKHE_HIP(hipMalloc(&d,
 
 // ------------------------------------------------------------------ construction
 Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int gamma_,
-                 const u64* psiQ, const u64* psiP, int device_)
+                 const u64* psiQ, const u64* psiP, int device_, const u64* QMul, int nqm_, u64 T)
     : logN(logN_), N(1 << logN_), nq(nq_), np(np_), mtot(nq_ + np_), gamma(gamma_), device(device_) {
+    nqm = QMul ? nqm_ : 0; mall = mtot + nqm; bfv_t = T;
     if (logN < 10 || logN > 15) throw Error("mkhe: logN must be in [10,15]");
     if (nq < 1 || np < 1 || gamma < 1 || np / gamma < 1) throw Error("mkhe: need at least gamma special primes (PCount/gamma >= 1)");
     if (np > MAXP) throw Error("mkhe: too many special primes");
@@ -72,27 +73,36 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     if (2 * beta_max > MAX_TERMS) throw Error("mkhe: too many gadget digits");
     for (int i = 0; i < nq; ++i) moduli.push_back(Q[i]);
     for (int i = 0; i < np; ++i) moduli.push_back(P[i]);
-    for (int i = 0; i < mtot; ++i) {
+    for (int i = 0; i < nqm; ++i) moduli.push_back(QMul[i]);
+    if (nqm) {
+        // mkbfv/params.go:30-34 (len(Q) == len(QMul)); alpha = 1 only: DecomposeBFV asks the R-ring decomposer
+        // for one-prime digits (keyswitch.go:73-76), and both reference parameter sets have alpha = 1
+        if (nqm != nq) throw Error("cannot NewParametersFromLiteral: length of Q & QMul is not equal");
+        if (alpha != 1) throw Error("mkhe: mkbfv needs PCount/gamma = 1");
+        if (nq > BC_MAXS) throw Error("mkhe: too many primes in Q for the BFV basis conversion");
+        if (T < 2) throw Error("mkhe: bad plaintext modulus");
+    }
+    for (int i = 0; i < mall; ++i) {
         const u64 q = moduli[i];
         if (q >= (1ull << 61) || !is_prime(q) || (q - 1) % (2ull * N) != 0) throw Error("mkhe: moduli must be primes < 2^61 with q = 1 mod 2N");
         for (int j = 0; j < i; ++j) if (moduli[j] == q) throw Error("mkhe: repeated modulus");
     }
-    if (mtot > NTT_MAX_SLOTS) throw Error("mkhe: too many moduli");
-    for (int i = 0; i < mtot; ++i) small_q_.push_back(moduli[i] < (1ull << 57) ? 1 : 0);   // 34q < 2^63
+    if (mall > NTT_MAX_SLOTS) throw Error("mkhe: too many moduli");
+    for (int i = 0; i < mall; ++i) small_q_.push_back(moduli[i] < (1ull << 57) ? 1 : 0);   // 34q < 2^63
     MKHE_HIP(hipSetDevice(device));
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     for (auto& e : ev_) MKHE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     s_ = stream;
 
-    std::vector<Mod> mods(mtot);
-    std::vector<u64> psi((size_t)mtot * N), psiinv((size_t)mtot * N), aux(2 * (size_t)mtot);
-    for (int i = 0; i < mtot; ++i) {
+    std::vector<Mod> mods(mall);
+    std::vector<u64> psi((size_t)mall * N), psiinv((size_t)mall * N), aux(2 * (size_t)mall);
+    for (int i = 0; i < mall; ++i) {
         const u64 q = moduli[i];
         Mod& m = mods[i];
         m.q = q; m.q2 = 2 * q; m.qinv = inv64(q); m.ninv32 = (u32)(0 - m.qinv); m.pad = 0;
         m.r1 = to_mont(1, q); m.r2 = mulmod(m.r1, m.r1, q);
-        u64 ps = (i < nq) ? (psiQ ? psiQ[i] : 0) : (psiP ? psiP[i - nq] : 0);
+        u64 ps = (i < nq) ? (psiQ ? psiQ[i] : 0) : (i < mtot ? (psiP ? psiP[i - nq] : 0) : 0);
         if (!ps) ps = default_psi(q, N);
         if (powmod(ps, N, q) != q - 1) throw Error("mkhe: supplied psi is not a primitive 2N-th root");
         psi_plain.push_back(ps);
@@ -146,6 +156,47 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
         for (int i = 0; i < L; ++i) rs[(size_t)(L - 1) * nq + i] = to_mont(powmod(Q[L] % Q[i], Q[i] - 2, Q[i]), Q[i]);
     d_rescale = dev_upload(rs);
 
+    if (nqm) {
+        // convQQMul = mkrlwe.NewFastBasisExtender(ringQ, ringQMul) at full levels (mkbfv/basis_extension.go:36),
+        // basisextenderparameters (mkrlwe/basis_extension.go:83-153) in closed form, both directions
+        auto conv = [&](const u64* S, const u64* Tm, int n, u64*& d1, u64*& d2, u64*& d3) {
+            std::vector<u64> a(n), b((size_t)n * n), c((size_t)n * (n + 1));
+            for (int i = 0; i < n; ++i) {
+                const u64 si = S[i]; u64 star = 1;
+                for (int j = 0; j < n; ++j) if (j != i) star = mulmod(star, S[j] % si, si);
+                a[i] = to_mont(powmod(star, si - 2, si), si);
+            }
+            for (int j = 0; j < n; ++j) {
+                const u64 tj = Tm[j]; u64 pm = 1;
+                for (int i = 0; i < n; ++i) {
+                    u64 sprod = 1;
+                    for (int u = 0; u < n; ++u) if (u != i) sprod = mulmod(sprod, S[u] % tj, tj);
+                    b[(size_t)j * n + i] = to_mont(sprod, tj);
+                    pm = mulmod(pm, S[i] % tj, tj);
+                }
+                const u64 v = tj - pm;
+                c[(size_t)j * (n + 1)] = 0;
+                for (int i = 1; i <= n; ++i) { u64 sum = c[(size_t)j * (n + 1) + i - 1] + v; c[(size_t)j * (n + 1) + i] = sum >= tj ? sum - tj : sum; }
+            }
+            d1 = dev_upload(a); d2 = dev_upload(b); d3 = dev_upload(c);
+        };
+        conv(Q, QMul, nq, d_bq_qoverqiinvqi, d_bq_qoverqimodp, d_bq_vtimes);
+        conv(QMul, Q, nq, d_bm_qoverqiinvqi, d_bm_qoverqimodp, d_bm_vtimes);
+        std::vector<u64> dqm(nq), dmq(nq), mf(nq), tm(2 * (size_t)nq);
+        std::vector<int> mr(2 * (size_t)nq);
+        for (int i = 0; i < nq; ++i) {
+            u64 qprod = 1, mprod = 1;                       // Q mod qm_i ; QMul mod q_i
+            for (int j = 0; j < nq; ++j) { qprod = mulmod(qprod, Q[j] % QMul[i], QMul[i]); mprod = mulmod(mprod, QMul[j] % Q[i], Q[i]); }
+            dqm[i] = QMul[i] - to_mont(powmod(qprod, QMul[i] - 2, QMul[i]), QMul[i]);    // genModDownParams, tail of ModDownQPtoP
+            dmq[i] = Q[i] - to_mont(powmod(mprod, Q[i] - 2, Q[i]), Q[i]);                // tail of ModDownQPtoQ
+            mf[i] = to_mont(mprod, Q[i]);                                                // mFormQMul (basis_extension.go:42-44)
+            tm[i] = to_mont(T % Q[i], Q[i]); tm[nq + i] = to_mont(T % QMul[i], QMul[i]); // MulScalar(t) constants
+            mr[i] = i; mr[nq + i] = mtot + i;
+        }
+        d_down_q_in_m = dev_upload(dqm); d_down_m_in_q = dev_upload(dmq); d_mform_qmul = dev_upload(mf); d_t_mont = dev_upload(tm);
+        d_map_r = dev_upload(mr);
+        x2_ = dev_alloc_words(swk_words()); y2_ = dev_alloc_words(swk_words());
+    }
     x_ = dev_alloc_words(swk_words()); y_ = dev_alloc_words(swk_words()); swk3_ = dev_alloc_words(swk_words());
     c1_ = dev_alloc_words((size_t)mtot * N);
     for (auto& p : polyq_) p = dev_alloc_words((size_t)nq * N);
@@ -158,7 +209,10 @@ Context::~Context() {
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
                     (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
-                    (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_})
+                    (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
+                    (void*)d_map_r, (void*)d_bq_qoverqiinvqi, (void*)d_bq_qoverqimodp, (void*)d_bq_vtimes,
+                    (void*)d_bm_qoverqiinvqi, (void*)d_bm_qoverqimodp, (void*)d_bm_vtimes,
+                    (void*)d_down_q_in_m, (void*)d_down_m_in_q, (void*)d_mform_qmul, (void*)d_t_mont})
         if (p) (void)hipFree(p);
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
     for (auto& f : free_list_) (void)hipFree(f.second);
@@ -258,7 +312,7 @@ void Context::ntt_fwd_launch(const NttBatch& b, bool decompose) {
 
 // ------------------------------------------------------------------ ring level
 void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, bool inverse, bool lazy) {
-    if (mod_base < 0 || mod_base + limbs > mtot) throw Error("mkhe: ntt modulus range");
+    if (mod_base < 0 || mod_base + limbs > mall) throw Error("mkhe: ntt modulus range");
     NttBatch b{};
     b.src = src; b.dst = dst; b.mods = d_mods; b.psi = inverse ? d_psiinv : d_psi; b.aux = d_inv_aux;
     if (limbs > NTT_MAX_SLOTS) throw Error("mkhe: too many limbs per polynomial");
@@ -351,10 +405,15 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
         const int n = (int)std::min<size_t>(EXT_MAX_ITEMS, items.size() - base);
         u64* c1 = scratch(c1b_, c1b_words_, (size_t)n * item_words);
         ExtInnerArgs ia{};
-        for (int i = 0; i < n; ++i) { ia.ah[i] = items[base + i].ah; ia.bg[i] = items[base + i].bg; }
+        bool two = false;
+        for (int i = 0; i < n; ++i) {
+            ia.ah[i] = items[base + i].ah; ia.bg[i] = items[base + i].bg;
+            ia.ah2[i] = items[base + i].ah2; ia.bg2[i] = items[base + i].bg2;
+            two = two || ia.ah2[i] != nullptr;
+        }
         ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
         ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
-        { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb + 1) * n); launch_ext_inner(ia, s_); }
+        { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb * (two ? 2 : 1) + 1) * n); launch_ext_inner(ia, s_); }
 
         NttBatch b{};
         b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
@@ -606,6 +665,240 @@ void Context::rescale(const Ct& in, int nb, Ct& out) {
                                   (long)PI, last ? (long)PO : (long)PI, s_);
         }
     }
+    MKHE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ elementwise evaluator ops
+// evaluateInPlace of mkckks/evaluator.go:41-70 and mkbfv/evaluator.go:27-62: c_0 and the components both
+// operands have are combined, the others are copied (Sub: negated when only op1 has them, :59-66).
+void Context::ct_binary(int op, const Ct& a, const Ct& b, Ct& out) {
+    const int L = out.limbs;
+    if (a.limbs < L || b.limbs < L) throw Error("mkhe: operand level below ctOut level");
+    const size_t PA = (size_t)a.limbs * N, PB = (size_t)b.limbs * N, PO = (size_t)L * N;
+    auto find = [](const Ct& c, int id) { for (int i = 0; i < c.n; ++i) if (c.ids[i] == id) return i; return -1; };
+    for (int o = -1; o < out.n; ++o) {
+        const int ia = o < 0 ? 0 : 1 + find(a, out.ids[o]), ib = o < 0 ? 0 : 1 + find(b, out.ids[o]);
+        u64* dst = out.d + (size_t)(1 + o) * PO;
+        const bool ha = o < 0 || ia > 0, hb = o < 0 || ib > 0;
+        if (!ha && !hb) throw Error("mkhe: ctOut has an id that neither operand has");
+        ProfScope ps(this, PROF_OTHER, 8.0 * N * L * ((ha && hb) ? 3 : 2));
+        if (ha && hb) {
+            if (op == 0) launch_add(dst, a.d + ia * PA, b.d + ib * PB, d_mods, L, N, s_);
+            else launch_sub(dst, a.d + ia * PA, b.d + ib * PB, d_mods, L, N, s_);
+        } else if (ha) {
+            MKHE_HIP(hipMemcpyAsync(dst, a.d + ia * PA, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+        } else if (op == 0) {
+            MKHE_HIP(hipMemcpyAsync(dst, b.d + ib * PB, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+        } else {
+            launch_neg(dst, b.d + ib * PB, d_mods, L, N, s_);
+        }
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ mkbfv
+// ring R = Q || QMul (mkbfv/params.go:36-38): limb j of a PolyR uses modulus j (j < nq) or nq+np+(j-nq)
+void Context::ntt_r(const u64* src, u64* dst, int count, bool inverse) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    NttBatch b{};
+    b.src = src; b.dst = dst; b.mods = d_mods; b.psi = inverse ? d_psiinv : d_psi; b.aux = d_inv_aux;
+    b.nslots = 2 * nq;
+    for (int j = 0; j < 2 * nq; ++j) { b.mod[j] = j < nq ? j : mtot + (j - nq); b.pos[j] = j; }
+    b.src_outer = b.dst_outer = 2L * nq * N; b.src_inner = b.dst_inner = N;
+    b.nouter = count;
+    if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * 2 * nq); launch_ntt_inv(logN, b, s_); }
+    else ntt_fwd_launch(b, false);
+    MKHE_HIP(hipGetLastError());
+}
+
+// conv.ModUpQtoR (mkbfv/basis_extension.go:49-64): Q part copied, QMul part = lazy ModUpQtoP
+void Context::bfv_modup_q_to_r(const u64* polyq, u64* polyr, int npolys) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    BasisConvArgs a{};
+    a.src = polyq; a.src_poly = (long)nq * N;
+    a.dst = polyr + (size_t)nq * N; a.dst_poly = 2L * nq * N;
+    a.copy_dst = polyr; a.copy_poly = 2L * nq * N;
+    a.mods_s = d_mods; a.mods_t = d_mods + mtot;
+    a.t = BasisConvTables{d_bq_qoverqiinvqi, d_bq_qoverqimodp, d_bq_vtimes};
+    a.ns = nq; a.nt = nq; a.N = N; a.npolys = npolys;
+    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npolys * 3.0 * nq); launch_basis_conv(a, s_); }
+    MKHE_HIP(hipGetLastError());
+}
+
+// conv.Rescale (basis_extension.go:82-96): QMul part = ModDownQPtoP(x * QMul mod Q, 0), Q part = lazy ModUpPtoQ of it
+void Context::bfv_rescale(const u64* polyq, u64* polyr, int npolys) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    BasisConvArgs a{};
+    a.src = polyq; a.src_poly = (long)nq * N;
+    a.dst = polyr + (size_t)nq * N; a.dst_poly = 2L * nq * N;
+    a.mods_s = d_mods; a.mods_t = d_mods + mtot;
+    a.prescale = d_mform_qmul; a.downparam = d_down_q_in_m;
+    a.t = BasisConvTables{d_bq_qoverqiinvqi, d_bq_qoverqimodp, d_bq_vtimes};
+    a.ns = nq; a.nt = nq; a.N = N; a.npolys = npolys;
+    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npolys * 2.0 * nq); launch_basis_conv(a, s_); }
+    BasisConvArgs c{};
+    c.src = polyr + (size_t)nq * N; c.src_poly = 2L * nq * N;
+    c.dst = polyr; c.dst_poly = 2L * nq * N;
+    c.mods_s = d_mods + mtot; c.mods_t = d_mods;
+    c.t = BasisConvTables{d_bm_qoverqiinvqi, d_bm_qoverqimodp, d_bm_vtimes};
+    c.ns = nq; c.nt = nq; c.N = N; c.npolys = npolys;
+    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npolys * 2.0 * nq); launch_basis_conv(c, s_); }
+    MKHE_HIP(hipGetLastError());
+}
+
+// conv.Quantize (basis_extension.go:66-80) AFTER the MulScalar(t): InvNTT over R (in place), ModDownQPtoQ with QMul as "P".
+// The MulScalar itself is folded into the producer (tensor kernel) or done by the caller (bfv_quantize_full).
+static void quantize_tail_args(BasisConvArgs& a, const Context& c, u64* polyr, u64* polyq, int npolys) {
+    a.src = polyr + (size_t)c.nq * c.N; a.src_poly = 2L * c.nq * c.N;
+    a.xsub = polyr; a.xsub_poly = 2L * c.nq * c.N;
+    a.dst = polyq; a.dst_poly = (long)c.nq * c.N;
+    a.mods_s = c.d_mods + c.mtot; a.mods_t = c.d_mods;
+    a.downparam = c.d_down_m_in_q;
+    a.t = BasisConvTables{c.d_bm_qoverqiinvqi, c.d_bm_qoverqimodp, c.d_bm_vtimes};
+    a.ns = c.nq; a.nt = c.nq; a.N = c.N; a.npolys = npolys;
+}
+void Context::bfv_quantize(const u64* polyr_ntt, u64* polyq, int npolys) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    const size_t PR = 2 * (size_t)nq * N;
+    u64* tmp = scratch(rbuf_, rbuf_words_, (size_t)npolys * PR);
+    // scalar multiplication limb by limb: z = x * t  (MRed(x, MForm(t)))
+    { ProfScope ps(this, PROF_OTHER, 16.0 * N * npolys * 2 * nq); launch_mul_const(tmp, polyr_ntt, d_mods, d_map_r, d_t_mont, 2 * nq, N, npolys, (long)PR, s_); }
+    ntt_r(tmp, tmp, npolys, true);
+    BasisConvArgs a{};
+    quantize_tail_args(a, *this, tmp, polyq, npolys);
+    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npolys * 3.0 * nq); launch_basis_conv(a, s_); }
+    MKHE_HIP(hipGetLastError());
+}
+
+// DecomposeBFV (mkbfv/keyswitch.go:67-90), alpha = 1: digit d = limb d of aR spread under Q and P and NTT'd
+// (DecomposeSingleNTT); Q digits -> ad1, QMul digits -> ad2.  The QMul limbs of ModUpQtoR outputs and the Q limbs
+// of Rescale outputs are lazy (< 3x their modulus): src_lazy.
+void Context::bfv_decompose_batch(const std::vector<const u64*>& srcr, const std::vector<u64*>& ad1, const std::vector<u64*>& ad2) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    const int level = nq - 1;
+    for (int half = 0; half < 2; ++half) {
+        for (size_t base = 0; base < srcr.size(); base += NTT_MAX_ITEMS) {
+            const int n = (int)std::min<size_t>(NTT_MAX_ITEMS, srcr.size() - base);
+            NttBatch b{};
+            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);
+            b.src_outer = N; b.src_inner = 0; b.src_mapped = 0;
+            b.dst_outer = (long)mtot * N; b.dst_inner = N; b.dst_mapped = 1;
+            b.reduce_in = 1; b.reduce_src_mod_is_outer = 2; b.src_lazy = 1;
+            for (int d = 0; d < nq; ++d) b.outer_mod[d] = half ? mtot + d : d;
+            b.nitems = n; b.outers_per_item = nq;
+            for (int i = 0; i < n; ++i) {
+                b.src_items[i] = srcr[base + i] + (half ? (size_t)nq * N : 0);
+                b.dst_items[i] = half ? ad2[base + i] : ad1[base + i];
+            }
+            b.nouter = n * nq;
+            ntt_fwd_launch(b, true);
+        }
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
+// ExternalProductBFVHoisted (keyswitch_hoisted.go:6-34)
+void Context::bfv_external_product_hoisted(const u64* ah1, const u64* ah2, const u64* bg1, const u64* bg2, u64* c) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    std::vector<ExtItem> items;
+    ExtItem it{ah1, bg1, c, false}; it.ah2 = ah2; it.bg2 = bg2;
+    items.push_back(it);
+    ext_batch(nq - 1, items);
+}
+
+// Evaluator.MulRelinNew = mulRelinHoisted (mkbfv/evaluator.go:78-82,118-140) followed by
+// KeySwitcher.MulAndRelinBFVHoisted (keyswitch_hoisted.go:36-206).
+void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
+                            const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
+                            const Swk& crs_u, Ct& out) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    const int level = nq - 1, L = nq, n0 = op0.n, n1 = op1.n;
+    if (op0.limbs != L || op1.limbs != L || out.limbs != L) throw Error("mkhe: BFV ciphertexts live at the maximum level");
+    if (n0 > 32 || n1 > 32 || out.n > 32) throw Error("mkhe: too many parties");
+    std::vector<int> slot0(n0), slot1(n1);
+    auto find = [&](int id) { for (int o = 0; o < out.n; ++o) if (out.ids[o] == id) return o; return -1; };
+    std::vector<char> seen(out.n, 0);
+    for (int a = 0; a < n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); slot0[a] = o; seen[o] = 1; }
+    for (int a = 0; a < n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); slot1[a] = o; seen[o] = 1; }
+    for (int o = 0; o < out.n; ++o) if (!seen[o]) throw Error("mkhe: ctOut has an id that neither operand has");
+    for (int a = 0; a < n0; ++a) if (!rlk_d1[a] || !rlk_d2[a] || !rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+    for (int a = 0; a < n1; ++a) if (!rlk_b1[a] || !rlk_b2[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+
+    const size_t PR = 2 * (size_t)nq * N, PQ = (size_t)nq * N;
+    const int np0 = 1 + n0, np1 = 1 + n1, npo = 1 + out.n;
+    // rbuf: [ct0R | ct1R | NTT(ct0R) | NTT(ct1R) | tensor out]
+    u64* rb = scratch(rbuf_, rbuf_words_, (size_t)(2 * (np0 + np1) + npo) * PR);
+    u64 *r0 = rb, *r1 = rb + (size_t)np0 * PR, *f0 = r1 + (size_t)np1 * PR, *f1 = f0 + (size_t)np0 * PR, *tz = f1 + (size_t)np1 * PR;
+    bfv_modup_q_to_r(op0.d, r0, np0);
+    bfv_rescale(op1.d, r1, np1);
+
+    // tensor over R + Quantize on the side stream (needs only ct0R / ct1R)
+    fork_side(1);
+    s_ = overlap ? stream2 : stream;
+    {
+        ntt_r(r0, f0, np0 + np1, false);        // f0, f1 are contiguous like r0, r1
+        TensorArgs ta{};
+        ta.a0 = f0; ta.b0 = f1; ta.out = tz; ta.mods = d_mods; ta.map = d_map_r; ta.scale = d_t_mont;
+        ta.nout = out.n; ta.L = 2 * nq; ta.N = N; ta.with_c0 = 1;
+        for (int a = 0; a < n0; ++a) { ta.a[1 + slot0[a]] = f0 + (size_t)(1 + a) * PR; ta.a_ls[1 + slot0[a]] = N; }
+        for (int a = 0; a < n1; ++a) { ta.b[1 + slot1[a]] = f1 + (size_t)(1 + a) * PR; ta.b_ls[1 + slot1[a]] = N; }
+        { ProfScope ps(this, PROF_TENSOR, 8.0 * N * 2 * nq * (2.0 + n0 + n1 + npo)); launch_tensor(ta, s_); }
+        ntt_r(tz, tz, npo, true);
+        BasisConvArgs qa{};
+        quantize_tail_args(qa, *this, tz, out.d, npo);
+        { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npo * 3.0 * nq); launch_basis_conv(qa, s_); }
+    }
+    side_done(1);
+    s_ = stream;
+
+    // hoisted forms of the party components (DecomposeBFV of every id of both operands, evaluator.go:126-133)
+    std::vector<const u64*> h0a(n0), h0b(n0), h1a(n1), h1b(n1);
+    {
+        std::vector<const u64*> src; std::vector<u64*> d1, d2;
+        for (int a = 0; a < n0; ++a) {
+            Swk& s1 = hoist_slot(0, a); Swk& s2 = hoist_slot(3, a);
+            src.push_back(r0 + (size_t)(1 + a) * PR); d1.push_back(s1.d); d2.push_back(s2.d); h0a[a] = s1.d; h0b[a] = s2.d;
+        }
+        for (int a = 0; a < n1; ++a) {
+            Swk& s1 = hoist_slot(1, a); Swk& s2 = hoist_slot(4, a);
+            src.push_back(r1 + (size_t)(1 + a) * PR); d1.push_back(s1.d); d2.push_back(s2.d); h1a[a] = s1.d; h1b[a] = s2.d;
+        }
+        if (!src.empty()) bfv_decompose_batch(src, d1, d2);
+    }
+    // x1, x2, y1, y2 (keyswitch_hoisted.go:76-126)
+    const int nslots = L + np;
+    for (int which = 0; which < 4; ++which) {
+        const int side = which >> 1, half = which & 1;
+        const int n = side ? n1 : n0;
+        InnerProductArgs ip{};
+        for (int a = 0; a < n; ++a) {
+            const Swk* key = side ? (half ? rlk_b2[a] : rlk_b1[a]) : (half ? rlk_d2[a] : rlk_d1[a]);
+            ip.a[a] = key->d;
+            ip.b[a] = side ? (half ? h1b[a] : h1a[a]) : (half ? h0b[a] : h0a[a]);
+        }
+        ip.out = side ? (half ? y2_ : y_) : (half ? x2_ : x_);
+        ip.mods = d_mods; ip.map = map_qp(level);
+        ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = beta_max; ip.N = N; ip.mform_out = 1;
+        { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * beta_max * (2.0 * n + 1)); launch_inner_product(ip, s_); }
+    }
+    // E: out_j += <h(c1_j), (x1,x2)> ; F1: t_i = <h(c0_i), (y1,y2)>
+    u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PQ);
+    std::vector<ExtItem> items;
+    for (int a = 0; a < n1; ++a) { ExtItem it{h1a[a], x_, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = h1b[a]; it.bg2 = x2_; items.push_back(it); }
+    for (int a = 0; a < n0; ++a) { ExtItem it{h0a[a], y_, tbuf + (size_t)a * PQ, false}; it.ah2 = h0b[a]; it.bg2 = y2_; items.push_back(it); }
+    ext_batch(level, items, 1);
+    // F2: ks.Decompose(t_i) ; out_0 += <h(t_i), v_i> ; out_i += <h(t_i), u>
+    {
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PQ); ddst.push_back(hoist_slot(2, a).d); }
+        if (n0) decompose_batch(level, dsrc, ddst);
+    }
+    items.clear();
+    for (int a = 0; a < n0; ++a) {
+        items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v[a]->d, out.d, true});
+        items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true});
+    }
+    ext_batch(level, items);
     MKHE_HIP(hipGetLastError());
 }
 

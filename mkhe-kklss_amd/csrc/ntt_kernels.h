@@ -45,12 +45,14 @@ struct NttBatch {
     int nouter;             // polynomials (or items * digits) in this launch
     int src_mapped, dst_mapped;
     int reduce_in;          // forward only: input is a digit spread under a foreign modulus (Decompose)
-    int reduce_src_mod_is_outer;   // the digit's own modulus index = outer (alpha = 1)
+    int reduce_src_mod_is_outer;   // the digit's own modulus index: 1 = outer (alpha = 1), 2 = outer_mod[outer] (BFV digits of R)
+    int src_lazy;           // digit values are lazy base-conversion outputs (< 4 * own modulus) rather than canonical
     int lazy_out;           // inverse only: leave [0,2q) (InvNTTLazy)
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
     int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists
     int mod[NTT_MAX_SLOTS];
     int pos[NTT_MAX_SLOTS];
+    int outer_mod[NTT_MAX_SLOTS];  // reduce_src_mod_is_outer == 2
     const u64* src_items[NTT_MAX_ITEMS];
     u64* dst_items[NTT_MAX_ITEMS];
 };

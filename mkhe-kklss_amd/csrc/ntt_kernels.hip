@@ -262,7 +262,10 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     for (int r = 0; r < 32; ++r) x[r] = src[posA<LOGN>(t, r)];
     if constexpr (DEC) {
         // digit of a foreign modulus (Decompose, alpha = 1): bring it below 4q when needed
-        const u64 qs = b.mods[b.reduce_src_mod_is_outer ? outer : m].q;
+        int sm = m;
+        if (b.reduce_src_mod_is_outer == 1) sm = outer;
+        else if (b.reduce_src_mod_is_outer == 2) sm = ((kargptr)__builtin_amdgcn_kernarg_segment_ptr())->outer_mod[outer];
+        const u64 qs = b.mods[sm].q << (b.src_lazy ? 2 : 0);       // bound of the digit values (< 2^63)
         if (qs > 4 * q) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) x[r] = mont_mul_lazy(x[r], md.r1, q, ninv);

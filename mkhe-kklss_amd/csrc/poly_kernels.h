@@ -56,6 +56,8 @@ constexpr int EXT_MAX_ITEMS = 64;
 struct ExtInnerArgs {
     const u64* ah[EXT_MAX_ITEMS];
     const u64* bg[EXT_MAX_ITEMS];
+    const u64* ah2[EXT_MAX_ITEMS];   // second gadget (BFV: QMul digits, keyswitch_hoisted.go:20-28) or all NULL
+    const u64* bg2[EXT_MAX_ITEMS];
     u64* c1;                 // [nitems][mtot][N]
     const Mod* mods;
     const int* map;
@@ -95,8 +97,47 @@ struct TensorArgs {
     long a_ls[33], b_ls[33];   // limb strides of the above
     int nout, L, N;
     int with_c0;               // 0: leave c0_0*c1_0 out of out_0 (party-sharded evaluation)
+    const int* map;            // [L] modulus index of limb l (NULL: l itself)          -- ring R of mkbfv
+    const u64* scale;          // [L] Montgomery constants multiplied into every output (NULL: none)
+                               //     -- ringR.MulScalar(t) of Quantize, mkbfv/basis_extension.go:71
 };
 void launch_tensor(const TensorArgs& a, hipStream_t st);
+
+// Generic fast basis conversion between two RNS bases S (ns limbs) and T (nt limbs) -- the reference's
+// modUpExact (mkrlwe/basis_extension.go:337-357, reconstructRNS :537-585, multSum :587-646) restated
+// literally per coefficient, with the optional ModDown tail (:192-232 / :292-334):
+//   raw  (downparam == NULL): dst_j = lazy lift of src to modulus t_j          (ModUpQtoP / ModUpPtoQ)
+//   tail (downparam != NULL): dst_j = MRed(lift_j + 2 t_j - xsub_j, downparam_j) (ModDownQPtoQ / QPtoP)
+// prescale: per-source-limb Montgomery constant applied first (mkbfv Rescale, basis_extension.go:87).
+// copy_dst: also store the (unscaled) source limbs there (ModUpQtoR keeps the Q part, :56-58).
+constexpr int BC_MAXS = 16;
+struct BasisConvTables {
+    const u64* qoverqiinvqi;   // [ns]
+    const u64* qoverqimodp;    // [nt][ns]
+    const u64* vtimesqmodp;    // [nt][ns+1]
+};
+struct BasisConvArgs {
+    const u64* src;  long src_poly;      // [npolys][.. ns ..][N]
+    const u64* xsub; long xsub_poly;     // tail minuend [npolys][.. nt ..][N] or NULL (= 0)
+    u64* dst;        long dst_poly;      // [npolys][.. nt ..][N]
+    u64* copy_dst;   long copy_poly;
+    const Mod* mods_s;
+    const Mod* mods_t;
+    const u64* prescale;
+    const u64* downparam;
+    BasisConvTables t;
+    int ns, nt, N, npolys;
+};
+void launch_basis_conv(const BasisConvArgs& a, hipStream_t st);
+
+// elementwise ring ops on ciphertext polynomials: dst = a + b / a - b / -a per limb (canonical inputs)
+// (ring.Add / Sub / Neg as used by mkckks/evaluator.go:41-300 and mkbfv/evaluator.go:40-76)
+void launch_sub(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st);
+void launch_neg(u64* dst, const u64* a, const Mod* mods, int L, int N, hipStream_t st);
+
+// dst[p][l][n] = src[p][l][n] * c_l  (ring.MulScalar with c = MForm(scalar), canonical)
+void launch_mul_const(u64* dst, const u64* src, const Mod* mods, const int* map, const u64* consts, int L, int N, int npolys,
+                      long poly_stride, hipStream_t st);
 
 // dst = CRed(a + b) per limb
 void launch_add(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st);

@@ -95,6 +95,8 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
     const u32 ninv = md.ninv32;
     const u64* ah = a.ah[item] + (long)m * a.N;
     const u64* bg = a.bg[item] + (long)m * a.N;
+    const u64* ah2 = a.ah2[item] ? a.ah2[item] + (long)m * a.N : nullptr;
+    const u64* bg2 = a.ah2[item] ? a.bg2[item] + (long)m * a.N : nullptr;
     u64* out = a.c1 + (long)item * a.c1_item + (long)m * a.N;
     for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
         u64 acc = 0;
@@ -102,6 +104,13 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
         for (int i = 0; i < a.nb; ++i) {
             u64 p = mont_mul_lazy(bg[(long)i * a.digit_stride + n], ah[(long)i * a.digit_stride + n], q, ninv);
             acc = csub(acc + p, q2);
+        }
+        if (ah2) {
+#pragma unroll 2
+            for (int i = 0; i < a.nb; ++i) {
+                u64 p = mont_mul_lazy(bg2[(long)i * a.digit_stride + n], ah2[(long)i * a.digit_stride + n], q, ninv);
+                acc = csub(acc + p, q2);
+            }
         }
         out[n] = csub(acc, q);
     }
@@ -164,22 +173,27 @@ typedef const __attribute__((address_space(4))) TensorArgs* tensor_kargs;
 __global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
     tensor_kargs ka = (tensor_kargs)__builtin_amdgcn_kernarg_segment_ptr();    // per-slot lists: scalar loads
     const int l = blockIdx.y;
-    const Mod md = a.mods[l];
+    const Mod md = a.mods[a.map ? a.map[l] : l];
     const u64 q = md.q;
     const u32 ninv = md.ninv32;
+    const bool scaled = a.scale != nullptr;
+    const u64 sc = scaled ? a.scale[l] : 0;
     const long P = (long)a.L * a.N;          // words per output poly
     for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
         const long e = (long)l * a.N + n;
         const u64 a0m = mont_mul(a.a0[e], md.r2, q, ninv);    // MForm(NTT(c0_0))
         const u64 b0 = a.b0[e];
         const u64 b0m = mont_mul(b0, md.r2, q, ninv);         // MForm(NTT(c1_0))
-        a.out[e] = a.with_c0 ? mont_mul(a0m, b0, q, ninv) : 0;
+        u64 r0 = a.with_c0 ? mont_mul(a0m, b0, q, ninv) : 0;
+        if (scaled) r0 = mont_mul(r0, sc, q, ninv);
+        a.out[e] = r0;
         for (int o = 1; o <= a.nout; ++o) {
             u64 r = 0;
             const u64* pa = ka->a[o];
             const u64* pb = ka->b[o];
             if (pa) r = mont_mul(b0m, pa[(long)l * ka->a_ls[o] + n], q, ninv);
             if (pb) r = csub(r + mont_mul(a0m, pb[(long)l * ka->b_ls[o] + n], q, ninv), q);
+            if (scaled) r = mont_mul(r, sc, q, ninv);
             a.out[(long)o * P + e] = r;
         }
     }
@@ -203,6 +217,100 @@ void launch_add(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, in
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(add_kernel, dim3(bx, L), dim3(PW_THREADS), 0, st, dst, a, b, mods, N);
+}
+
+__global__ void __launch_bounds__(PW_THREADS) sub_kernel(u64* dst, const u64* x, const u64* y, const Mod* mods, int N) {
+    const int l = blockIdx.y;
+    const u64 q = mods[l].q;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < N; n += gridDim.x * PW_THREADS) {
+        const long e = (long)l * N + n;
+        dst[e] = csub(x[e] + q - y[e], q);
+    }
+}
+void launch_sub(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st) {
+    int bx = (N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(sub_kernel, dim3(bx, L), dim3(PW_THREADS), 0, st, dst, a, b, mods, N);
+}
+// ring.Neg writes q - a, i.e. q for a = 0 (lattigo ring_operations.go Neg), kept literally
+__global__ void __launch_bounds__(PW_THREADS) neg_kernel(u64* dst, const u64* x, const Mod* mods, int N) {
+    const int l = blockIdx.y;
+    const u64 q = mods[l].q;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < N; n += gridDim.x * PW_THREADS) {
+        const long e = (long)l * N + n;
+        dst[e] = q - x[e];
+    }
+}
+void launch_neg(u64* dst, const u64* a, const Mod* mods, int L, int N, hipStream_t st) {
+    int bx = (N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(neg_kernel, dim3(bx, L), dim3(PW_THREADS), 0, st, dst, a, mods, N);
+}
+
+__global__ void __launch_bounds__(PW_THREADS) mul_const_kernel(u64* dst, const u64* src, const Mod* mods, const int* map, const u64* consts,
+                                                                int N, long poly_stride) {
+    const int l = blockIdx.y;
+    const Mod md = mods[map ? map[l] : l];
+    const u64 c = consts[l];
+    const long base = (long)blockIdx.z * poly_stride + (long)l * N;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < N; n += gridDim.x * PW_THREADS)
+        dst[base + n] = mont_mul(src[base + n], c, md.q, md.ninv32);
+}
+void launch_mul_const(u64* dst, const u64* src, const Mod* mods, const int* map, const u64* consts, int L, int N, int npolys,
+                      long poly_stride, hipStream_t st) {
+    int bx = (N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(mul_const_kernel, dim3(bx, L, npolys), dim3(PW_THREADS), 0, st, dst, src, mods, map, consts, N, poly_stride);
+}
+
+// ------------------------------------------------------------------ generic basis conversion (mkbfv)
+__global__ void __launch_bounds__(PW_THREADS) basis_conv_kernel(BasisConvArgs a) {
+    const int n = blockIdx.x * PW_THREADS + threadIdx.x;
+    if (n >= a.N) return;
+    const int pi = blockIdx.z;
+    const u64* src = a.src + (long)pi * a.src_poly;
+    u64 y[BC_MAXS];
+    double vi = 0.0;
+    const bool copy = a.copy_dst != nullptr && blockIdx.y == 0;
+#pragma unroll
+    for (int i = 0; i < BC_MAXS; ++i) {
+        if (i < a.ns) {
+            const Mod ms = a.mods_s[i];
+            u64 x = src[(long)i * a.N + n];
+            if (copy) a.copy_dst[(long)pi * a.copy_poly + (long)i * a.N + n] = x;
+            if (a.prescale) x = mont_mul(x, a.prescale[i], ms.q, ms.ninv32);
+            y[i] = mont_mul(x, a.t.qoverqiinvqi[i], ms.q, ms.ninv32);
+            vi = vi + (double)y[i] / (double)ms.q;
+        }
+    }
+    const u64 v = (u64)vi;
+    for (int j = blockIdx.y; j < a.nt; j += gridDim.y) {
+        const Mod mt = a.mods_t[j];
+        u64 rlo = 0, rhi = 0;
+#pragma unroll
+        for (int i = 0; i < BC_MAXS; ++i) {
+            if (i < a.ns) {
+                u64 mhi, mlo;
+                mul64x64(y[i], a.t.qoverqimodp[(long)j * a.ns + i], mhi, mlo);
+                u64 sum = rlo + mlo;
+                rhi += mhi + (sum < rlo ? 1 : 0);
+                rlo = sum;
+            }
+        }
+        const u64 hhi = mulhi64(rlo * mt.qinv, mt.q);
+        u64 z = rhi - hhi + mt.q + a.t.vtimesqmodp[(long)j * (a.ns + 1) + v];
+        if (a.downparam) {
+            const u64 x = a.xsub ? a.xsub[(long)pi * a.xsub_poly + (long)j * a.N + n] : 0;
+            z = mont_mul(z + mt.q2 - x, a.downparam[j], mt.q, mt.ninv32);
+        }
+        a.dst[(long)pi * a.dst_poly + (long)j * a.N + n] = z;
+    }
+}
+void launch_basis_conv(const BasisConvArgs& a, hipStream_t st) {
+    const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    int by = (a.nt + 3) / 4;                 // ~4 target limbs per thread: the y[] set-up is amortised
+    if (by < 1) by = 1;
+    hipLaunchKernelGGL(basis_conv_kernel, dim3(bx, by, a.npolys), dim3(PW_THREADS), 0, st, a);
 }
 
 // ------------------------------------------------------------------ automorphism

@@ -22,6 +22,12 @@ class Parameters:
     def __init__(self, logN, Q, P, gamma=2, psiQ=None, psiP=None, device=0):
         self.logN, self._N = int(logN), 1 << int(logN)
         self.Q, self.P, self.gamma = [int(q) for q in Q], [int(p) for p in P], int(gamma)
+        self.device = int(device)
+        self.ctx = self._create_context(psiQ, psiP)
+        self.CRS = {}                      # idx -> SwitchingKey   (params.go:37-46)
+        self._ids = {}                     # party id string -> dense int for the C ABI
+
+    def _create_context(self, psiQ, psiP):
         q = np.asarray(self.Q, dtype=np.uint64)
         p = np.asarray(self.P, dtype=np.uint64)
         pq = np.asarray(psiQ, dtype=np.uint64) if psiQ is not None else None
@@ -30,11 +36,8 @@ class Parameters:
         check(lib().mkhe_ctx_create(C.byref(h), self.logN, q.ctypes.data_as(_abi.u64p), len(self.Q),
                                     p.ctypes.data_as(_abi.u64p), len(self.P), self.gamma,
                                     pq.ctypes.data_as(_abi.u64p) if pq is not None else None,
-                                    pp.ctypes.data_as(_abi.u64p) if pp is not None else None, int(device)))
-        self.ctx = h
-        self.device = int(device)
-        self.CRS = {}                      # idx -> SwitchingKey   (params.go:37-46)
-        self._ids = {}                     # party id string -> dense int for the C ABI
+                                    pp.ctypes.data_as(_abi.u64p) if pp is not None else None, self.device))
+        return h
 
     def close(self):
         if getattr(self, "ctx", None):
