@@ -58,6 +58,101 @@ def synth_inputs(pset, parties, seed):
                 u=synth_swk(pset, np.random.default_rng(seed + 7)))
 
 
+def run_bfv(args):
+    """--scheme bfv: one mkbfv.Evaluator.MulRelinNew (BASELINE.json configs[3] shape: k-party, PN15QP880 BFV chain,
+    ModUpQtoR / Rescale / DecomposeBFV / MulAndRelinBFVHoisted) per step.  Secondary line, same JSON contract."""
+    import harness_bfv as HB
+    from mkhe_kklss_amd import mkbfv
+    from mkhe_kklss_amd._abi import check, lib
+
+    pset = HB.BFV_PN15QP880 if args.params == "PN15QP880" else HB.BFV_PN14QP439
+    k = args.parties
+    names = ["user%d" % i for i in range(k)]
+    data = HB.uniform_bfv_inputs(pset, k, args.seed)
+    params = mkbfv.Parameters(pset["logN"], pset["Q"], pset["QMul"], pset["P"], pset["T"], device=0)
+    ct0 = mkbfv.NewCiphertext(params, names).upload(data["op0"])
+    ct1 = mkbfv.NewCiphertext(params, names).upload(data["op1"])
+    rlk = mkbfv.NewRelinearizationKeyKeySet(params)
+    for i, n in enumerate(names):
+        rlk.AddRelinearizationKey(mkbfv.RelinearizationKey(params, n, *data["rlk"][i]))
+    params.AddCRS(-1, data["u"])
+    ev = mkbfv.NewEvaluator(params)
+    if os.environ.get("MKHE_NO_OVERLAP"):
+        check(lib().mkhe_set_overlap(params.ctx, 0))
+    step = lambda: ev.MulRelinNew(ct0, ct1, rlk)
+    for _ in range(args.warmup):
+        res = step()
+    params.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    params.sync()
+    dt = time.perf_counter() - t0
+    roofline = roofline_leg(args, params, step, pset["logN"], "%s-bfv k=%d" % (args.params, k))
+    cpu = None
+    if not args.no_cpu:
+        bfv = HB.make_bfv(pset)
+        ids = list(range(k))
+        reps = max(1, args.cpu_reps)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            _, ref = bfv.mul_relin_new(ids, data["op0"], ids, data["op1"], data["rlk"], data["u"])
+        cdt = time.perf_counter() - t0
+        cpu = dict(value=reps / cdt, unit="MulRelin/s", cores=1, kind="port",
+                   sample="%d full %d-party BFV MulRelin (%s) on 1 host thread, %.1f s" % (reps, k, args.params, cdt),
+                   bit_exact_vs_gpu=bool((res.download() == ref).all()))
+    return dict(metric="mkbfv_mulrelin_per_sec", value=args.steps / dt, unit="MulRelin/s", n_gpus=1, steps=args.steps,
+                warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps, higher_is_better=True, scaling="strong",
+                vs_baseline=None, dtype="u64", data="synthetic",
+                config=dict(workload="mkbfv %d-party MulRelinNew (ModUpQtoR + Rescale + DecomposeBFV + MulAndRelinBFVHoisted), %s N=2^%d, %d Q + %d QMul + %d P limbs"
+                            % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["QMul"]), len(pset["P"])),
+                            parties=k, params=args.params, seed=args.seed),
+                roofline=roofline, cpu_baseline=cpu)
+
+
+def roofline_leg(args, params, step, logN, workload):
+    """per-kernel HIP-event timing on the context stream, same steps again (side-stream overlap off: each kernel
+    then runs alone, so its duration is the kernel's own and comparable with the rocprofv3 kernel trace taken with
+    MKHE_NO_OVERLAP=1; `value` is measured with overlap on)"""
+    from mkhe_kklss_amd._abi import check, lib
+    ncls = lib().mkhe_prof_nclass()
+    check(lib().mkhe_set_overlap(params.ctx, 0))
+    check(lib().mkhe_prof_enable(params.ctx, 1))
+    for _ in range(args.steps):
+        step()
+    ms = (C.c_double * ncls)()
+    cnt = (C.c_long * ncls)()
+    byt = (C.c_double * ncls)()
+    check(lib().mkhe_prof_collect(params.ctx, ms, cnt, byt))
+    check(lib().mkhe_prof_enable(params.ctx, 0))
+    check(lib().mkhe_set_overlap(params.ctx, 0 if os.environ.get("MKHE_NO_OVERLAP") else 1))
+    names_k = [lib().mkhe_prof_name(i).decode().replace("<N,", "<%d," % logN).replace("<N>", "<%d>" % logN)
+               for i in range(ncls)]
+    kernels = {}
+    for i in range(ncls):
+        if cnt[i]:
+            kernels[names_k[i]] = dict(launches_per_step=cnt[i] / args.steps, ms_per_step=ms[i] / args.steps,
+                                       avg_launch_us=1e3 * ms[i] / cnt[i],
+                                       achieved_GBs=byt[i] / (ms[i] * 1e-3) / 1e9)
+    di = max((i for i in range(ncls) if cnt[i]), key=lambda i: ms[i])
+    dom = names_k[di]
+    achieved = byt[di] / (ms[di] * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value
+    # comes from the committed rocprofv3 --pmc summary of this same command (profiles/traffic.json, written
+    # by tools/traffic_from_pmc.py: (2*FETCH_SIZE + WRITE_SIZE) KB per launch, see DESIGN.md section 6).
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        key = dom.split()[0]
+        if tj.get("workload") == workload and key in tj.get("kernels", {}):
+            traffic = tj["kernels"][key]["hbm_bytes_per_launch"]
+    return dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                alg_bytes_per_launch=byt[di] / cnt[di], avg_launch_us=1e3 * ms[di] / cnt[di],
+                kernels=kernels)
+
+
 def run_single(args):
     import harness as H
     from mkhe_kklss_amd import mkrlwe, mkckks
@@ -93,45 +188,7 @@ def run_single(args):
     ms_per_step = dt * 1e3 / args.steps
     value = args.steps / dt
 
-    # ---- roofline leg: per-kernel HIP-event timing on the context stream, same steps again
-    # (side-stream overlap off: each kernel then runs alone, so its duration is the kernel's own and
-    #  comparable with the rocprofv3 kernel trace taken with MKHE_NO_OVERLAP=1; `value` above is measured with overlap on)
-    ncls = lib().mkhe_prof_nclass()
-    check(lib().mkhe_set_overlap(params.ctx, 0))
-    check(lib().mkhe_prof_enable(params.ctx, 1))
-    for _ in range(args.steps):
-        res = step()
-    ms = (C.c_double * ncls)()
-    cnt = (C.c_long * ncls)()
-    byt = (C.c_double * ncls)()
-    check(lib().mkhe_prof_collect(params.ctx, ms, cnt, byt))
-    check(lib().mkhe_prof_enable(params.ctx, 0))
-    check(lib().mkhe_set_overlap(params.ctx, 0 if os.environ.get("MKHE_NO_OVERLAP") else 1))
-    names_k = [lib().mkhe_prof_name(i).decode().replace("<N,", "<%d," % pset["logN"]).replace("<N>", "<%d>" % pset["logN"])
-               for i in range(ncls)]
-    kernels = {}
-    for i in range(ncls):
-        if cnt[i]:
-            kernels[names_k[i]] = dict(launches_per_step=cnt[i] / args.steps, ms_per_step=ms[i] / args.steps,
-                                       avg_launch_us=1e3 * ms[i] / cnt[i],
-                                       achieved_GBs=byt[i] / (ms[i] * 1e-3) / 1e9)
-    di = max((i for i in range(ncls) if cnt[i]), key=lambda i: ms[i])
-    dom = names_k[di]
-    achieved = byt[di] / (ms[di] * 1e-3) / 1e9
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value
-    # comes from the committed rocprofv3 --pmc summary of this same command (profiles/traffic.json, written
-    # by tools/traffic_from_pmc.py: (2*FETCH_SIZE + WRITE_SIZE) KB per launch).
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        key = dom.split()[0]
-        if tj.get("workload") == "%s k=%d" % (args.params, k) and key in tj.get("kernels", {}):
-            traffic = tj["kernels"][key]["hbm_bytes_per_launch"]
-    roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                    alg_bytes_per_launch=byt[di] / cnt[di], avg_launch_us=1e3 * ms[di] / cnt[di],
-                    kernels=kernels)
+    roofline = roofline_leg(args, params, step, pset["logN"], "%s k=%d" % (args.params, k))
 
     # ---- CPU baseline: the oracle (single-thread C restatement of the Go path) on the same inputs
     cpu = None
@@ -170,11 +227,15 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even at world size 1 (testing)")
+    ap.add_argument("--scheme", default="ckks", choices=["ckks", "bfv"],
+                    help="ckks = BASELINE.json headline metric (default); bfv = the mkbfv MulRelin line (single GPU)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or args.force_dist:
         from bench_dist import run_distributed
         out = run_distributed(args)
+    elif args.scheme == "bfv":
+        out = run_bfv(args)
     else:
         out = run_single(args)
     if out is not None:

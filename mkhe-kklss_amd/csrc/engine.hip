@@ -721,7 +721,7 @@ void Context::bfv_modup_q_to_r(const u64* polyq, u64* polyr, int npolys) {
     a.mods_s = d_mods; a.mods_t = d_mods + mtot;
     a.t = BasisConvTables{d_bq_qoverqiinvqi, d_bq_qoverqimodp, d_bq_vtimes};
     a.ns = nq; a.nt = nq; a.N = N; a.npolys = npolys;
-    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npolys * 3.0 * nq); launch_basis_conv(a, s_); }
+    { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npolys * 3.0 * nq); launch_basis_conv(a, s_); }
     MKHE_HIP(hipGetLastError());
 }
 
@@ -735,14 +735,14 @@ void Context::bfv_rescale(const u64* polyq, u64* polyr, int npolys) {
     a.prescale = d_mform_qmul; a.downparam = d_down_q_in_m;
     a.t = BasisConvTables{d_bq_qoverqiinvqi, d_bq_qoverqimodp, d_bq_vtimes};
     a.ns = nq; a.nt = nq; a.N = N; a.npolys = npolys;
-    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npolys * 2.0 * nq); launch_basis_conv(a, s_); }
+    { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npolys * 2.0 * nq); launch_basis_conv(a, s_); }
     BasisConvArgs c{};
     c.src = polyr + (size_t)nq * N; c.src_poly = 2L * nq * N;
     c.dst = polyr; c.dst_poly = 2L * nq * N;
     c.mods_s = d_mods + mtot; c.mods_t = d_mods;
     c.t = BasisConvTables{d_bm_qoverqiinvqi, d_bm_qoverqimodp, d_bm_vtimes};
     c.ns = nq; c.nt = nq; c.N = N; c.npolys = npolys;
-    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npolys * 2.0 * nq); launch_basis_conv(c, s_); }
+    { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npolys * 2.0 * nq); launch_basis_conv(c, s_); }
     MKHE_HIP(hipGetLastError());
 }
 
@@ -766,7 +766,7 @@ void Context::bfv_quantize(const u64* polyr_ntt, u64* polyq, int npolys) {
     ntt_r(tmp, tmp, npolys, true);
     BasisConvArgs a{};
     quantize_tail_args(a, *this, tmp, polyq, npolys);
-    { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npolys * 3.0 * nq); launch_basis_conv(a, s_); }
+    { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npolys * 3.0 * nq); launch_basis_conv(a, s_); }
     MKHE_HIP(hipGetLastError());
 }
 
@@ -846,7 +846,7 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
         ntt_r(tz, tz, npo, true);
         BasisConvArgs qa{};
         quantize_tail_args(qa, *this, tz, out.d, npo);
-        { ProfScope ps(this, PROF_MODDOWN, 8.0 * N * npo * 3.0 * nq); launch_basis_conv(qa, s_); }
+        { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npo * 3.0 * nq); launch_basis_conv(qa, s_); }
     }
     side_done(1);
     s_ = stream;
