@@ -108,6 +108,7 @@ class Context {
     int *d_map_qp = nullptr, *d_map_id = nullptr;
     u64 *d_md_qoverqiinvqi = nullptr, *d_md_qoverqimodp = nullptr, *d_md_vtimes = nullptr, *d_md_down = nullptr;
     u64* d_rescale = nullptr;
+    u64 *d_dec_a = nullptr, *d_dec_b = nullptr, *d_dec_c = nullptr;     // Decomposer tables (alpha >= 2)
     // mkbfv tables: convQQMul in both directions, ModDown constants, mFormQMul, MForm(t) per limb of R
     int* d_map_r = nullptr;
     u64 *d_bq_qoverqiinvqi = nullptr, *d_bq_qoverqimodp = nullptr, *d_bq_vtimes = nullptr;     // Q -> QMul

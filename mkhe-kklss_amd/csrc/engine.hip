@@ -65,7 +65,7 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
                  const u64* psiQ, const u64* psiP, int device_, const u64* QMul, int nqm_, u64 T)
     : logN(logN_), N(1 << logN_), nq(nq_), np(np_), mtot(nq_ + np_), gamma(gamma_), device(device_) {
     nqm = QMul ? nqm_ : 0; mall = mtot + nqm; bfv_t = T;
-    if (logN < 10 || logN > 15) throw Error("mkhe: logN must be in [10,15]");
+    if (logN < 10 || logN > 16) throw Error("mkhe: logN must be in [10,16]");
     if (nq < 1 || np < 1 || gamma < 1 || np / gamma < 1) throw Error("mkhe: need at least gamma special primes (PCount/gamma >= 1)");
     if (np > MAXP) throw Error("mkhe: too many special primes");
     alpha = np / gamma;                                   // mkrlwe/params.go:63-65
@@ -96,7 +96,8 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     s_ = stream;
 
     std::vector<Mod> mods(mall);
-    std::vector<u64> psi((size_t)mall * N), psiinv((size_t)mall * N), aux(2 * (size_t)mall);
+    const bool split = logN == 16;        // inverse NTT constants per (modulus, half) -- see ntt_kernels.h NttBatch::split
+    std::vector<u64> psi((size_t)mall * N), psiinv((size_t)mall * N), aux((split ? 4 : 2) * (size_t)mall);
     for (int i = 0; i < mall; ++i) {
         const u64 q = moduli[i];
         Mod& m = mods[i];
@@ -114,8 +115,15 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
             a = mulmod(a, ps, q); b = mulmod(b, psinv, q);
         }
         const u64 ninv = powmod((u64)N, q - 2, q);
-        aux[2 * i] = to_mont(ninv, q);
-        aux[2 * i + 1] = mulmod(psiinv[(size_t)i * N + 1], ninv, q);
+        if (!split) {
+            aux[2 * i] = to_mont(ninv, q);
+            aux[2 * i + 1] = mulmod(psiinv[(size_t)i * N + 1], ninv, q);
+        } else {
+            for (int h = 0; h < 2; ++h) {
+                aux[2 * (2 * i + h)] = to_mont(ninv, q);
+                aux[2 * (2 * i + h) + 1] = mulmod(psiinv[(size_t)i * N + 2 + h], ninv, q);
+            }
+        }
     }
     d_mods = dev_upload(mods); d_psi = dev_upload(psi); d_psiinv = dev_upload(psiinv); d_inv_aux = dev_upload(aux);
 
@@ -155,6 +163,42 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     for (int L = 1; L < nq; ++L)
         for (int i = 0; i < L; ++i) rs[(size_t)(L - 1) * nq + i] = to_mont(powmod(Q[L] % Q[i], Q[i] - 2, Q[i]), Q[i]);
     d_rescale = dev_upload(rs);
+
+    if (alpha > 1) {
+        // NewDecomposer (mkrlwe/basis_extension.go:368-424) at full P: for digit d and nd = 2..alpha limbs,
+        // basisextenderparameters(Q[alpha*d : alpha*d+nd], Q || P) in closed form
+        if (alpha > DEC_MAXA) throw Error("mkhe: PCount/gamma > 4 is not supported");
+        if (beta_max > 64) throw Error("mkhe: too many gadget digits");
+        const int na = alpha - 1;
+        std::vector<u64> ta((size_t)beta_max * na * DEC_MAXA, 0), tb((size_t)beta_max * na * mtot * DEC_MAXA, 0),
+                         tc((size_t)beta_max * na * mtot * (DEC_MAXA + 1), 0);
+        for (int d = 0; d < beta_max; ++d) {
+            for (int nd = 2; nd <= alpha; ++nd) {
+                if (d * alpha + nd > nq) break;
+                const u64* S = Q + d * alpha;
+                const size_t sel = (size_t)d * na + (nd - 2);
+                for (int i = 0; i < nd; ++i) {
+                    const u64 si = S[i]; u64 star = 1;
+                    for (int j = 0; j < nd; ++j) if (j != i) star = mulmod(star, S[j] % si, si);
+                    ta[sel * DEC_MAXA + i] = to_mont(powmod(star, si - 2, si), si);
+                }
+                for (int m = 0; m < mtot; ++m) {
+                    const u64 tj = moduli[m]; u64 pm = 1;
+                    for (int i = 0; i < nd; ++i) {
+                        u64 sprod = 1;
+                        for (int u = 0; u < nd; ++u) if (u != i) sprod = mulmod(sprod, S[u] % tj, tj);
+                        tb[(sel * mtot + m) * DEC_MAXA + i] = to_mont(sprod, tj);
+                        pm = mulmod(pm, S[i] % tj, tj);
+                    }
+                    const u64 v = tj - pm;            // tj - (Q_d mod tj); equals tj (not 0) when tj divides Q_d, as in the reference
+                    u64* c = &tc[(sel * mtot + m) * (DEC_MAXA + 1)];
+                    c[0] = 0;
+                    for (int i = 1; i <= nd; ++i) { u64 sum = c[i - 1] + v; c[i] = sum >= tj ? sum - tj : sum; }
+                }
+            }
+        }
+        d_dec_a = dev_upload(ta); d_dec_b = dev_upload(tb); d_dec_c = dev_upload(tc);
+    }
 
     if (nqm) {
         // convQQMul = mkrlwe.NewFastBasisExtender(ringQ, ringQMul) at full levels (mkbfv/basis_extension.go:36),
@@ -208,6 +252,7 @@ Context::~Context() {
     if (stream) (void)hipStreamSynchronize(stream);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
                     (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale,
+                    (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
                     (void*)d_map_r, (void*)d_bq_qoverqiinvqi, (void*)d_bq_qoverqimodp, (void*)d_bq_vtimes,
@@ -327,9 +372,9 @@ void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, 
 // ------------------------------------------------------------------ Decompose (keyswitch.go:49-73)
 void Context::decompose(int level, bool is_ntt, const u64* a, u64* out_swk) {
     check_level(level);
-    if (alpha != 1) throw Error("mkhe: gadget decomposition with alpha >= 2 (CRT reconstruction) is not implemented on the device yet");
     const u64* ainv = a;
     if (is_ntt) { ntt(a, invntt_, 1, level + 1, 0, true, false); ainv = invntt_; }
+    if (alpha != 1) { decompose_batch(level, {ainv}, {out_swk}); return; }
     // alpha = 1 (basis_extension.go:443-451): digit i = limb i, re-read under every active modulus,
     // fused with the forward NTT (DecomposeSingleNTT, keyswitch.go:21-31).
     NttBatch b{};
@@ -379,8 +424,33 @@ void Context::external_product(int level, bool is_ntt, const u64* a, const u64* 
 // ------------------------------------------------------------------ batched forms (one launch for all parties)
 void Context::decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst) {
     check_level(level);
-    if (alpha != 1) throw Error("mkhe: gadget decomposition with alpha >= 2 (CRT reconstruction) is not implemented on the device yet");
     const int nb = beta(level);
+    if (alpha != 1) {
+        // alpha >= 2: CRT-reconstructed digits are spread in the coefficient domain first (DecomposeAndSplit,
+        // basis_extension.go:428-535), then NTT'd in place (DecomposeSingleNTT, keyswitch.go:29-30)
+        for (size_t base = 0; base < src.size(); base += DEC_MAX_ITEMS) {
+            const int n = (int)std::min<size_t>(DEC_MAX_ITEMS, src.size() - base);
+            DecompSpreadArgs da{};
+            for (int i = 0; i < n; ++i) { da.src[i] = src[base + i]; da.dst[i] = dst[base + i]; }
+            da.mods = d_mods; da.map = map_qp(level); da.ta = d_dec_a; da.tb = d_dec_b; da.tc = d_dec_c;
+            for (int d = 0; d < nb; ++d) {
+                // decompLvl rule of DecomposeAndSplit (:437-441), digit index d
+                const int dl = (level > alpha * (d + 1) - 1) ? alpha - 2 : (level % alpha) - 1;
+                da.nd[d] = dl + 2;
+            }
+            da.alpha = alpha; da.ndigits = nb; da.nslots = level + 1 + np; da.mtot = mtot; da.N = N; da.nitems = n;
+            { ProfScope ps(this, PROF_OTHER, 8.0 * N * n * ((level + 1) + (double)nb * da.nslots)); launch_decomp_spread(da, s_); }
+            NttBatch b{};
+            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);
+            b.src_outer = b.dst_outer = (long)mtot * N; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
+            b.nitems = n; b.outers_per_item = nb;
+            for (int i = 0; i < n; ++i) { b.src_items[i] = dst[base + i]; b.dst_items[i] = dst[base + i]; }
+            b.nouter = n * nb;
+            ntt_fwd_launch(b, false);
+        }
+        MKHE_HIP(hipGetLastError());
+        return;
+    }
     for (size_t base = 0; base < src.size(); base += NTT_MAX_ITEMS) {
         const int n = (int)std::min<size_t>(NTT_MAX_ITEMS, src.size() - base);
         NttBatch b{};

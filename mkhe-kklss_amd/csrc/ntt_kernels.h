@@ -48,6 +48,9 @@ struct NttBatch {
     int reduce_src_mod_is_outer;   // the digit's own modulus index: 1 = outer (alpha = 1), 2 = outer_mod[outer] (BFV digits of R)
     int src_lazy;           // digit values are lazy base-conversion outputs (< 4 * own modulus) rather than canonical
     int lazy_out;           // inverse only: leave [0,2q) (InvNTTLazy)
+    int split;              // N = 2^16: the register-resident kernels transform the two halves of a limb as 2^15-point
+                            // sub-transforms (twiddle rows of 2^16 words, root index 2 + half); the cross-half radix-2 stage
+                            // runs as a separate streaming pass (launch_ntt_* do both)
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
     int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists
     int mod[NTT_MAX_SLOTS];

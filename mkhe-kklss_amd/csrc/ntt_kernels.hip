@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
     const int sub = G::LPB == 1 ? 0 : threadIdx.x / G::T, t = G::LPB == 1 ? threadIdx.x : threadIdx.x % G::T;
     u32* lds = lds_all + sub * lds_words<LOGN>();
-    const int njobs = b.nslots * b.nouter;
+    const int njobs = (b.nslots * b.nouter) << b.split;
     // persistent workgroups: each one walks the job list with stride gridDim.x.  A wave that finishes its
     // part of a limb starts loading the next limb at once; the only workgroup-wide rendezvous are the
     // barriers around the cross-wave exchange.
@@ -251,11 +251,14 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
         b.trace[4 * job + 3] = __builtin_amdgcn_s_memtime();                                     // shader clock ticks
     }
     gcptr src; gptr dst; int m, outer;
-    job_pointers(b, job, src, dst, m, outer);
+    const int half = b.split ? (job & 1) : 0;
+    job_pointers(b, b.split ? (job >> 1) : job, src, dst, m, outer);
+    src += half * G::N; dst += half * G::N;
+    const int root = b.split ? 2 + half : 1;          // twiddle index of a sub-transform group: root * m' + i'
     const Mod md = b.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
-    gcptr psi = (gcptr)(b.psi + (long)m * G::N);
+    gcptr psi = (gcptr)(b.psi + ((long)m * G::N << b.split));
 
     u64 x[32];
 #pragma unroll
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
         int base = 16, prefix = 0, maxB = 4;
         if (ph == 1) { base = G::N >> 6; prefix = t >> 5; maxB = G::MIDB; }
         if (ph == 2) { base = G::N >> 1; prefix = t; }
-        phase<MODE>(x, psi, base, prefix, maxB, q, q2, ninv);
+        phase<MODE>(x, psi, base * root, prefix, maxB, q, q2, ninv);
         if (ph == 0) {
             if constexpr (G::HAS_MID) {
                 __syncthreads();     // every wave is done with the LDS of the previous limb
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
     const int sub = G::LPB == 1 ? 0 : threadIdx.x / G::T, t = G::LPB == 1 ? threadIdx.x : threadIdx.x % G::T;
     u32* lds = lds_all + sub * lds_words<LOGN>();
-    const int njobs = b.nslots * b.nouter;
+    const int njobs = (b.nslots * b.nouter) << b.split;
 #pragma unroll 1
     for (int jb = blockIdx.x * G::LPB; jb < njobs; jb += gridDim.x * G::LPB) {
     int job = jb + sub;
@@ -317,11 +320,14 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     if (!active) job = njobs - 1;
     if constexpr (G::LPB == 1) job = __builtin_amdgcn_readfirstlane(job);    // provably wave-uniform: modulus constants and pointers stay in SGPRs
     gcptr src; gptr dst; int m, outer;
-    job_pointers(b, job, src, dst, m, outer);
+    const int half = b.split ? (job & 1) : 0;
+    job_pointers(b, b.split ? (job >> 1) : job, src, dst, m, outer);
+    src += half * G::N; dst += half * G::N;
+    const int root = b.split ? 2 + half : 1;
     const Mod md = b.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
-    gcptr psi = (gcptr)(b.psi + (long)m * G::N);
+    gcptr psi = (gcptr)(b.psi + ((long)m * G::N << b.split));
 
     u64 x[32];
 #pragma unroll
@@ -333,26 +339,85 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     for (int ph = 0; ph < 2; ++ph) {
         int base = G::N >> 1, prefix = t, maxB = 4;
         if (ph == 1) { base = G::N >> 6; prefix = t >> 5; maxB = G::MIDB; }
-        phase<2>(x, psi, base, prefix, maxB, q, q2, ninv);
+        phase<2>(x, psi, base * root, prefix, maxB, q, q2, ninv);
         if (ph == 0) exchange_xor<LOGN, LC, LB, false>(x, lds, t);
         else { if constexpr (G::HAS_MID) exchange_xor<LOGN, LB, LA, true>(x, lds, t); }
     }
     // top phase: index bits n-5 .. n-2, then the last stage with N^-1 folded in
-    phase<2>(x, psi, 16, 0, 3, q, q2, ninv);
-    const u64 ninvR = b.aux[2 * m], w1n = b.aux[2 * m + 1];
+    phase<2>(x, psi, 16 * root, 0, 3, q, q2, ninv);
+    // {N^-1 * R, psiinv[root] * N^-1 * R}; split: the table has one pair per (modulus, half), N = 2^16
+    const int ax = b.split ? 2 * (2 * m + half) : 2 * m;
+    const u64 ninvR = b.aux[ax], w1n = b.aux[ax + 1];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         u64 U = x[g], V = x[g + 16];
         u64 s = mont_mul_lazy(U + V, ninvR, q, ninv);
         u64 d = mont_mul_lazy(U + q2 - V, w1n, q, ninv);
-        x[g] = b.lazy_out ? s : csub(s, q);
-        x[g + 16] = b.lazy_out ? d : csub(d, q);
+        x[g] = (b.lazy_out | b.split) ? s : csub(s, q);
+        x[g + 16] = (b.lazy_out | b.split) ? d : csub(d, q);
     }
     if (active) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) dst[posA<LOGN>(t, r)] = x[r];
     }
     }
+}
+
+// ------------------------------------------------------------------ N = 2^16: cross-half radix-2 passes
+// The limb does not fit one workgroup's registers (64 coefficients per thread).  The first Cooley-Tukey stage
+// (pairs (j, j + N/2), twiddle psi[1]) is a streaming pass src -> dst; the remaining 15 stages are two independent
+// 2^15-point sub-transforms run in place by the register-resident kernel (NttBatch::split).  Mirror image for the
+// inverse: sub-transforms first, then the last Gentleman-Sande stage (N^-1 already folded into the sub-transforms).
+constexpr int SPLIT_THREADS = 256;
+template <bool DEC>
+__global__ void __launch_bounds__(SPLIT_THREADS) ntt_split_fwd_kernel(NttBatch b, int logN) {
+    const int N = 1 << logN, H = N >> 1;
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    const Mod md = b.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const u64 w = b.psi[(long)m * N + 1];
+    bool red = false;
+    if constexpr (DEC) {
+        int sm = m;
+        if (b.reduce_src_mod_is_outer == 1) sm = outer;
+        else if (b.reduce_src_mod_is_outer == 2) sm = ((kargptr)__builtin_amdgcn_kernarg_segment_ptr())->outer_mod[outer];
+        const u64 qs = b.mods[sm].q << (b.src_lazy ? 2 : 0);
+        red = qs > 4 * q;
+    }
+    for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < H; j += gridDim.x * SPLIT_THREADS) {
+        u64 U = src[j], V = src[j + H];
+        if (red) { U = mont_mul_lazy(U, md.r1, q, ninv); V = mont_mul_lazy(V, md.r1, q, ninv); }
+        else U = csub(U, q2);                                 // inputs < 4q
+        const u64 Tm = mont_mul_lazy(V, w, q, ninv);
+        dst[j] = U + Tm;                                      // < 4q: what the sub-transforms accept
+        dst[j + H] = U + (q2 - Tm);
+    }
+}
+__global__ void __launch_bounds__(SPLIT_THREADS) ntt_split_inv_kernel(NttBatch b, int logN) {
+    const int N = 1 << logN, H = N >> 1;
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    const Mod md = b.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const u64 w = b.psi[(long)m * N + 1];
+    for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < H; j += gridDim.x * SPLIT_THREADS) {
+        const u64 U = dst[j], V = dst[j + H];                 // [0,2q)
+        u64 s = csub(U + V, q2);
+        u64 d = mont_mul_lazy(U + q2 - V, w, q, ninv);
+        if (!b.lazy_out) { s = csub(s, q); d = csub(d, q); }
+        dst[j] = s;
+        dst[j + H] = d;
+    }
+}
+static NttBatch in_place_of_dst(const NttBatch& b) {
+    NttBatch c = b;
+    c.src = b.dst; c.src_outer = b.dst_outer; c.src_inner = b.dst_inner; c.src_mapped = b.dst_mapped;
+    for (int i = 0; i < NTT_MAX_ITEMS; ++i) c.src_items[i] = b.dst_items[i];
+    c.reduce_in = 0; c.split = 1;
+    return c;
 }
 
 // ------------------------------------------------------------------ launchers
@@ -372,7 +437,7 @@ template <int LOGN, int MODE, bool DEC> static void launch_fwd_t(const NttBatch&
     if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN, MODE, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     static int resident = 0;
     if (!resident) resident = resident_blocks((const void*)ntt_fwd_kernel<LOGN, MODE, DEC>, G::BT, lds);
-    const int need = (b.nslots * b.nouter + G::LPB - 1) / G::LPB;
+    const int need = (((b.nslots * b.nouter) << b.split) + G::LPB - 1) / G::LPB;
     const int blocks = need < resident ? need : resident;
     hipLaunchKernelGGL((ntt_fwd_kernel<LOGN, MODE, DEC>), dim3(blocks), dim3(G::BT), lds, st, b);
 }
@@ -383,7 +448,7 @@ template <int LOGN> static void launch_inv_t(const NttBatch& b, hipStream_t st) 
     if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     static int resident = 0;
     if (!resident) resident = resident_blocks((const void*)ntt_inv_kernel<LOGN>, G::BT, lds);
-    const int need = (b.nslots * b.nouter + G::LPB - 1) / G::LPB;
+    const int need = (((b.nslots * b.nouter) << b.split) + G::LPB - 1) / G::LPB;
     const int blocks = need < resident ? need : resident;
     hipLaunchKernelGGL(ntt_inv_kernel<LOGN>, dim3(blocks), dim3(G::BT), lds, st, b);
 }
@@ -415,11 +480,28 @@ int split_ntt_fwd(const NttBatch& b, const unsigned char* small_q, NttBatch out[
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
     const bool small = b.lazy_out != 0;
+    if (logN == 16) {
+        const dim3 grid(32, b.nslots * b.nouter);
+        if (b.reduce_in) hipLaunchKernelGGL(ntt_split_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+        else hipLaunchKernelGGL(ntt_split_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+        const NttBatch c = in_place_of_dst(b);
+        if (small) launch_fwd_mode<1, false>(15, c, st); else launch_fwd_mode<0, false>(15, c, st);
+        return;
+    }
     if (b.reduce_in) { if (small) launch_fwd_mode<1, true>(logN, b, st); else launch_fwd_mode<0, true>(logN, b, st); }
     else             { if (small) launch_fwd_mode<1, false>(logN, b, st); else launch_fwd_mode<0, false>(logN, b, st); }
 }
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
+    if (logN == 16) {
+        NttBatch c = b;
+        c.split = 1;
+        launch_inv_t<15>(c, st);                              // src halves -> dst halves, lazy, N^-1 folded in
+        const NttBatch d = in_place_of_dst(b);                // only the dst addressing is used
+        NttBatch e = d; e.lazy_out = b.lazy_out; e.psi = b.psi;
+        hipLaunchKernelGGL(ntt_split_inv_kernel, dim3(32, b.nslots * b.nouter), dim3(SPLIT_THREADS), 0, st, e, logN);
+        return;
+    }
     switch (logN) {
         case 10: launch_inv_t<10>(b, st); break;
         case 11: launch_inv_t<11>(b, st); break;

@@ -130,6 +130,25 @@ struct BasisConvArgs {
 };
 void launch_basis_conv(const BasisConvArgs& a, hipStream_t st);
 
+// Gadget digit spread for alpha >= 2 (Decomposer.DecomposeAndSplit, mkrlwe/basis_extension.go:428-535): digit d of a
+// polynomial = its limbs [alpha*d, alpha*d + nd), CRT-reconstructed (float64 correction index, literal) and written as a
+// lazy residue under every active modulus of Q and P into a SwitchingKey-shaped buffer [digit][nQ+nP][N] (coefficient
+// domain; the forward NTT follows in place).  nd = 1 is the copy path (:443-451).
+constexpr int DEC_MAXA = 4;
+constexpr int DEC_MAX_ITEMS = 64;
+struct DecompSpreadArgs {
+    const u64* src[DEC_MAX_ITEMS];     // polynomials [.. level+1 ..][N]
+    u64* dst[DEC_MAX_ITEMS];           // [beta][mtot][N]
+    const Mod* mods;                   // Q then P
+    const int* map;                    // [nslots] active slot -> modulus index (= limb position in dst)
+    const u64* ta;                     // [ndig][alpha-1][DEC_MAXA]            qoverqiinvqi
+    const u64* tb;                     // [ndig][alpha-1][mtot][DEC_MAXA]      qoverqimodp
+    const u64* tc;                     // [ndig][alpha-1][mtot][DEC_MAXA+1]    vtimesqmodp
+    int nd[64];                        // limbs of digit d at this level (1 = copy)
+    int alpha, ndigits, nslots, mtot, N, nitems;
+};
+void launch_decomp_spread(const DecompSpreadArgs& a, hipStream_t st);
+
 // elementwise ring ops on ciphertext polynomials: dst = a + b / a - b / -a per limb (canonical inputs)
 // (ring.Add / Sub / Neg as used by mkckks/evaluator.go:41-300 and mkbfv/evaluator.go:40-76)
 void launch_sub(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st);

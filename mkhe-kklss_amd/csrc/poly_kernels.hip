@@ -313,6 +313,64 @@ void launch_basis_conv(const BasisConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(basis_conv_kernel, dim3(bx, by, a.npolys), dim3(PW_THREADS), 0, st, a);
 }
 
+// ------------------------------------------------------------------ gadget digit spread, alpha >= 2
+typedef const __attribute__((address_space(4))) DecompSpreadArgs* dspread_kargs;
+__global__ void __launch_bounds__(PW_THREADS) decomp_spread_kernel(DecompSpreadArgs a) {
+    dspread_kargs ka = (dspread_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int n = blockIdx.x * PW_THREADS + threadIdx.x;
+    if (n >= a.N) return;
+    const int d = blockIdx.y, item = blockIdx.z;
+    const int start = d * a.alpha, nd = ka->nd[d];
+    const u64* src = ka->src[item] + (long)start * a.N;
+    u64* dst = ka->dst[item] + (long)d * a.mtot * a.N;
+    if (nd == 1) {
+        const u64 x = src[n];
+        const u64 qs = a.mods[start].q;
+        for (int s = 0; s < a.nslots; ++s) {
+            const int m = a.map[s];
+            const Mod mt = a.mods[m];
+            dst[(long)m * a.N + n] = qs > 4 * mt.q ? mont_mul_lazy(x, mt.r1, mt.q, mt.ninv32) : x;
+        }
+        return;
+    }
+    const long tsel = (long)d * (a.alpha - 1) + (nd - 2);
+    const u64* ta = a.ta + tsel * DEC_MAXA;
+    const u64* tb = a.tb + tsel * a.mtot * DEC_MAXA;
+    const u64* tc = a.tc + tsel * a.mtot * (DEC_MAXA + 1);
+    u64 y[DEC_MAXA];
+    double vi = 0.0;
+#pragma unroll
+    for (int i = 0; i < DEC_MAXA; ++i) {
+        if (i < nd) {
+            const Mod ms = a.mods[start + i];
+            y[i] = mont_mul(src[(long)i * a.N + n], ta[i], ms.q, ms.ninv32);
+            vi = vi + (double)y[i] / (double)ms.q;
+        }
+    }
+    const u64 v = (u64)vi;
+    for (int s = 0; s < a.nslots; ++s) {
+        const int m = a.map[s];
+        const Mod mt = a.mods[m];
+        u64 rlo = 0, rhi = 0;
+#pragma unroll
+        for (int i = 0; i < DEC_MAXA; ++i) {
+            if (i < nd) {
+                u64 mhi, mlo;
+                mul64x64(y[i], tb[(long)m * DEC_MAXA + i], mhi, mlo);
+                u64 sum = rlo + mlo;
+                rhi += mhi + (sum < rlo ? 1 : 0);
+                rlo = sum;
+            }
+        }
+        const u64 hhi = mulhi64(rlo * mt.qinv, mt.q);
+        dst[(long)m * a.N + n] = rhi - hhi + mt.q + tc[(long)m * (DEC_MAXA + 1) + v];
+    }
+}
+void launch_decomp_spread(const DecompSpreadArgs& a, hipStream_t st) {
+    const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    hipLaunchKernelGGL(decomp_spread_kernel, dim3(bx, a.ndigits, a.nitems), dim3(PW_THREADS), 0, st, a);
+}
+
 // ------------------------------------------------------------------ automorphism
 __global__ void __launch_bounds__(PW_THREADS) automorphism_kernel(u64* dst, const u64* src, const Mod* mods, int L, int logN, u64 galEl) {
     const int l = blockIdx.y, pidx = blockIdx.z;

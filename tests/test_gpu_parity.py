@@ -19,6 +19,12 @@ SETS = {
     "N12_q4": H.small_ckks(12, 4),
     "N13_q3": H.small_ckks(13, 3),
     "N14_pn14": H.PN14QP439,
+    # alpha = 2 (4 special primes, gamma = 2): CRT-reconstructed gadget digits (basis_extension.go:471-533);
+    # odd limb counts end in a one-limb digit (copy path) at the maximum level
+    "N11_a2_q5": H.small_alpha2(11, 5),
+    "N12_a2_q4": H.small_alpha2(12, 4),
+    # N = 2^16 (BASELINE.json configs[3] shape, head of the reference's PN16 chain): split NTT
+    "N16_a2_q3": H.small_alpha2(16, 3),
 }
 
 
