@@ -38,6 +38,13 @@ PN14QP439 = dict(  # mkckks/mkckks_test.go:73-90
 PN16_Q = [0x80000000080001, 0x2000000a0001, 0x2000000e0001, 0x1fffffc20001, 0x200000440001, 0x200000500001,
           0x200000620001, 0x1fffff980001, 0x2000006a0001, 0x1fffff7e0001]   # head of mkrlwe_test.go:22-35
 PN16_P = [0x80000000440001, 0x7fffffffba0001, 0x80000000500001, 0x7fffffffaa0001]
+PN16QP1761 = dict(  # mkrlwe/mkrlwe_test.go:22-35 (55 + 33 x 45 bit Q, 4 x 55 bit P): BASELINE.json configs[3]
+    logN=16,
+    Q=PN16_Q + [0x200000860001, 0x200000a60001, 0x200000aa0001, 0x200000b20001, 0x200000c80001, 0x1fffff360001,
+                0x200000e20001, 0x1fffff060001, 0x200000fe0001, 0x1ffffede0001, 0x1ffffeca0001, 0x1ffffeb40001,
+                0x200001520001, 0x1ffffe760001, 0x2000019a0001, 0x1ffffe640001, 0x200001a00001, 0x1ffffe520001,
+                0x200001e80001, 0x1ffffe0c0001, 0x1ffffdee0001, 0x200002480001, 0x1ffffdb60001, 0x200002560001],
+    P=PN16_P, scale=float(1 << 45))
 
 
 def small_ckks(logN, nq=4, scale_bits=54):
