@@ -3,8 +3,7 @@
 // CDNA4 has no 64x64->128 multiply: every product is built from v_mad_u64_u32
 // (32x32+64 -> 64) and v_mul_lo_u32, both measured at half the rate of a simple VALU op
 // (tools/ubench/imul_rate.hip).  The Montgomery product below is word-serial (radix 2^32,
-// two rounds) so that every addition rides on a mad's 64-bit addend: 8 v_mad_u64_u32 +
-// 2 v_mul_lo_u32 + 2 64-bit adds.
+// two rounds) so that every addition rides on a mad's 64-bit addend (see mont_mul_lazy).
 //
 // Semantics mirror lattigo v2.3.0 ring.MRed / MRedConstant / MForm / CRed as used by the
 // reference (mkrlwe/keyswitch_hoisted.go:28-30, basis_extension.go:220,551): radix R = 2^64,
@@ -36,21 +35,30 @@ __device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) { return (u64)a * b + 
 __device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
 __device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
 
+// A wave-uniform 1 the compiler cannot see through: mad64(x, one, acc) then stays ONE v_mad_u64_u32 that adds
+// a 32-bit VGPR to a 64-bit accumulator.  Written as acc + x it is lowered to a 64-bit add whose 32-bit operand
+// must first be widened into an even-aligned register pair (two v_mov_b32 per addend: about a third of all
+// VALU instructions of the NTT kernels before this form; every VALU instruction costs one issue slot here).
+// K only tells the instances apart: with ONE shared value the compiler factors x*one + y*one into (x + y)*one
+// and is back to widening adds.
+template <int K> __device__ __forceinline__ u32 opaque_one() { u32 o; asm("s_mov_b32 %0, 1 ; %1" : "=s"(o) : "i"(K)); return o; }
+
 // a*w*R^-1 mod q, result in [0, 2q).  Requires a < 2^62, w < q < 2^61.
+// Word-serial Montgomery (radix 2^32, two rounds), 14 v_mad_u64_u32 + 2 v_mul_lo_u32 and nothing else:
+// every addition rides on a mad's 64-bit addend.
 __device__ __forceinline__ u64 mont_mul_lazy(u64 a, u64 w, u64 q, u32 ninv32) {
     const u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(w), w1 = hi32(w), q0 = lo32(q), q1 = hi32(q);
-    // round 0: T = (a0*w + m*q) >> 32
-    u64 p0 = mad64(a0, w0, 0);
-    u32 m = lo32(p0) * ninv32;
-    u64 r0 = mad64(m, q0, lo32(p0));            // low word is zero by construction
-    u64 p1 = mad64(a0, w1, hi32(p0));
-    u64 T = mad64(m, q1, p1) + hi32(r0);
-    // round 1: result = (T + a1*w + m'*q) >> 32
-    u64 s0 = mad64(a1, w0, T);
-    u32 m2 = lo32(s0) * ninv32;
-    u64 r2 = mad64(m2, q0, lo32(s0));
-    u64 A = mad64(a1, w1, hi32(s0));
-    return mad64(m2, q1, A) + hi32(r2);
+    const u32 one_a = opaque_one<0>(), one_b = opaque_one<1>(), one_c = opaque_one<2>();
+    // round 0: T = (a0*w + m*q) >> 32 with m = -a0*w0/q mod 2^32
+    const u64 p0 = mad64(a0, w0, 0);
+    const u32 m = lo32(p0) * ninv32;
+    const u64 r0 = mad64(lo32(p0), one_a, mad64(m, q0, 0));             // low word is zero by construction
+    const u64 T = mad64(hi32(r0), one_b, mad64(hi32(p0), one_c, mad64(m, q1, mad64(a0, w1, 0))));
+    // round 1: result = (T + a1*w + m2*q) >> 32
+    const u64 s0 = mad64(a1, w0, T);
+    const u32 m2 = lo32(s0) * ninv32;
+    const u64 r2 = mad64(lo32(s0), one_a, mad64(m2, q0, 0));
+    return mad64(hi32(r2), one_b, mad64(hi32(s0), one_c, mad64(m2, q1, mad64(a1, w1, 0))));
 }
 
 __device__ __forceinline__ u64 csub(u64 a, u64 q) { return a >= q ? a - q : a; }
