@@ -46,6 +46,23 @@ class Evaluator:
         return NewCiphertext(self.params, op0.IDSet() | op1.IDSet(), min(op0.Level(), op1.Level()),
                              max(op0.ScalingFactor(), op1.ScalingFactor()))
 
+    # ---- AddNew / SubNew (evaluator.go:316-357 -> evaluateInPlace :200-304)
+    def _binary(self, op0, op1, fn):
+        s0, s1 = op0.ScalingFactor(), op1.ScalingFactor()
+        # the reference first multiplies the operand with the smaller scale by floor(ratio) when that is > 1
+        # (MultByConst, :214-281); that branch is not on the accelerated path
+        if (s0 > s1 and s0 // s1 > 1) or (s1 > s0 and s1 // s0 > 1):
+            raise MkheError("mkhe: Add/Sub of ciphertexts whose scales differ by a factor > 1 is not on the device path")
+        ctOut = self.newCiphertextBinary(op0, op1)
+        check(fn(self.params.ctx, op0.h, op1.h, ctOut.h))
+        return ctOut
+
+    def AddNew(self, op0, op1):
+        return self._binary(op0, op1, lib().mkhe_ct_add)
+
+    def SubNew(self, op0, op1):
+        return self._binary(op0, op1, lib().mkhe_ct_sub)
+
     # ---- Rescale (evaluator.go:359-398)
     def nbRescales(self, ctIn, minScale):
         Q = self.params.Q

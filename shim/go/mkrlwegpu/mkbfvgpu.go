@@ -1,0 +1,76 @@
+// mkbfvgpu.go -- cgo binding of the mkhe_bfv_* entry points (include/mkhe.h) for the reference package mkbfv.
+//
+// NOT BUILT OR TESTED IN THIS REPOSITORY (no Go toolchain; see mkrlwegpu.go).  It shows the binding a maintainer
+// adds so that mkbfv.Evaluator.MulRelinNew (mkbfv/evaluator.go:78-82) runs on an MI355X.
+//
+//go:build mkhe_gpu
+
+package mkrlwegpu
+
+/*
+#include <stdlib.h>
+#include "mkhe.h"
+*/
+import "C"
+
+import (
+	"runtime"
+	"unsafe"
+
+	"mk-lattigo/mkbfv"
+	"mk-lattigo/mkrlwe"
+)
+
+// NewBFVContext replaces mkbfv.NewKeySwitcher + NewFastBasisExtender (mkbfv/keyswitch.go:31-65,
+// basis_extension.go:20-47).  The engine generates lattigo's default roots itself (ring.NewRing rule).
+func NewBFVContext(params mkbfv.Parameters, device int) *Context {
+	q, qm, p := params.RingQ().Modulus, params.RingQMul().Modulus, params.RingP().Modulus
+	ctx := &Context{params: params.Parameters, ids: map[string]C.int{}}
+	must(C.mkhe_ctx_create_bfv(&ctx.c, C.int(params.LogN()),
+		(*C.uint64_t)(unsafe.Pointer(&q[0])), (*C.uint64_t)(unsafe.Pointer(&qm[0])), C.int(len(q)),
+		(*C.uint64_t)(unsafe.Pointer(&p[0])), C.int(len(p)), C.int(params.Gamma()), C.uint64_t(params.T()), C.int(device)))
+	runtime.SetFinalizer(ctx, func(c *Context) { C.mkhe_ctx_destroy(c.c) })
+	return ctx
+}
+
+// BFVRelinKeys holds the device copies of rlkSet.Value[id].Value[0/1] (mkbfv/keys.go:6-9).
+type BFVRelinKeys struct {
+	B1, B2, D1, D2, V map[string]*SwitchingKey
+}
+
+func (ctx *Context) UploadBFVRelinKey(rk *BFVRelinKeys, rlk *mkbfv.RelinearizationKey) {
+	id := rlk.ID
+	rk.B1[id] = ctx.UploadSwitchingKey(rlk.Value[0].Value[0])
+	rk.B2[id] = ctx.UploadSwitchingKey(rlk.Value[1].Value[0])
+	rk.D1[id] = ctx.UploadSwitchingKey(rlk.Value[0].Value[1])
+	rk.D2[id] = ctx.UploadSwitchingKey(rlk.Value[1].Value[1])
+	rk.V[id] = ctx.UploadSwitchingKey(rlk.Value[0].Value[2])
+}
+
+func swkList(ids []string, m map[string]*SwitchingKey) **C.mkhe_swk {
+	arr := (**C.mkhe_swk)(C.malloc(C.size_t(len(ids)) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	s := unsafe.Slice(arr, len(ids))
+	for i, id := range ids {
+		s[i] = m[id].h
+	}
+	return arr
+}
+
+// MulRelinBFV is the body of mkbfv.Evaluator.mulRelinHoisted (evaluator.go:118-140): op0, op1 and out are device
+// ciphertexts whose id order is ids0 / ids1 / their union.
+func (ctx *Context) MulRelinBFV(op0, op1 *Ciphertext, ids0, ids1 []string, rk *BFVRelinKeys, crsU *SwitchingKey, out *Ciphertext) {
+	b1, b2 := swkList(ids1, rk.B1), swkList(ids1, rk.B2)
+	d1, d2, v := swkList(ids0, rk.D1), swkList(ids0, rk.D2), swkList(ids0, rk.V)
+	defer func() {
+		for _, p := range []**C.mkhe_swk{b1, b2, d1, d2, v} {
+			C.free(unsafe.Pointer(p))
+		}
+	}()
+	must(C.mkhe_bfv_mul_relin(ctx.c, op0.h, op1.h, b1, b2, d1, d2, v, crsU.h, out.h))
+}
+
+// AddBFV / SubBFV: mkbfv.Evaluator.AddNew / SubNew (evaluator.go:44-76)
+func (ctx *Context) AddBFV(op0, op1, out *Ciphertext) { must(C.mkhe_ct_add(ctx.c, op0.h, op1.h, out.h)) }
+func (ctx *Context) SubBFV(op0, op1, out *Ciphertext) { must(C.mkhe_ct_sub(ctx.c, op0.h, op1.h, out.h)) }
+
+var _ = mkrlwe.NewIDSet

@@ -253,3 +253,31 @@ def test_rescale(pair, nb):
         ref, _ = pair.ks.ringQ.div_round_last_many(h[s], nb)
         assert (got[s] == ref).all()
     assert (d.download() == h).all()      # input untouched (documented deviation from lattigo's in-place +h)
+
+
+def test_ckks_add_sub(pair):
+    """mkckks.Evaluator.AddNew / SubNew (evaluator.go:316-357): union id set, operands at different levels"""
+    from mkhe_kklss_amd import mkckks
+    if pair.maxlevel < 1:
+        pytest.skip("single limb")
+    params = pair.params
+    ev = mkckks.Evaluator.__new__(mkckks.Evaluator)
+    ev.params, ev.ksw = params, pair.ksw
+    params._scale = 2.0 ** 40
+    h0 = H.uniform_ct(pair.rng, pair.ks, 2, pair.maxlevel + 1)
+    h1 = H.uniform_ct(pair.rng, pair.ks, 2, pair.maxlevel)
+    c0 = mkckks.NewCiphertext(params, ["a", "b"], pair.maxlevel, 2.0 ** 40).upload(h0)
+    c1 = mkckks.NewCiphertext(params, ["b", "c"], pair.maxlevel - 1, 2.0 ** 40).upload(h1)
+    add, sub = ev.AddNew(c0, c1), ev.SubNew(c0, c1)
+    L = pair.maxlevel
+    assert add.Level() == L - 1 and add.ids == ["a", "b", "c"]
+    rq = pair.ks.ringQ
+    f = lambda fn, x, y: np.stack([getattr(rq, fn)(j, x[j], y[j]) for j in range(L)])
+    ga, gs = add.download(), sub.download()
+    assert (ga[0] == f("add", h0[0], h1[0])).all() and (gs[0] == f("sub", h0[0], h1[0])).all()
+    assert (ga[1] == h0[1][:L]).all() and (gs[1] == h0[1][:L]).all()
+    assert (ga[2] == f("add", h0[2], h1[1])).all() and (gs[2] == f("sub", h0[2], h1[1])).all()
+    assert (ga[3] == h1[2]).all() and (gs[3] == np.stack([rq.neg(j, h1[2][j]) for j in range(L)])).all()
+    c2 = mkckks.NewCiphertext(params, ["a"], pair.maxlevel, 2.0 ** 45)
+    with pytest.raises(pair.mk.MkheError, match="scales differ"):
+        ev.AddNew(c0, c2)
