@@ -125,6 +125,12 @@ int  mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct);
  *      galEl = 5^rotidx mod 2N; rk aligned with ct ids (rkSet[id][rotidx]); crs = params.CRS[rotidx]. */
 int  mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* hoist,
                  const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* out);
+/* ---- Rotate in two phases for a party-sharded evaluation: the key-switch part of keyswitch.go:251-265
+ *      without the permutation (with_c0 = 0 leaves c_0 out of out_0: exactly one rank adds it), and the signed
+ *      permutation :267-296 on its own.  mkhe_rotate == mkhe_rotate_partial(with_c0 = 1) + mkhe_ct_automorphism. */
+int  mkhe_rotate_partial(mkhe_ctx* ctx, const mkhe_ct* in, const mkhe_swk* const* hoist,
+                         const mkhe_swk* const* rk, const mkhe_swk* crs, int with_c0, mkhe_ct* out);
+int  mkhe_ct_automorphism(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, mkhe_ct* out);
 /* ---- KeySwitcher.Conjugate keyswitch.go:302-332; galEl = 2N-1, crs = params.CRS[-2] */
 int  mkhe_conjugate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* ck,
                     const mkhe_swk* crs, mkhe_ct* out);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "mkhe_mr_finish": (C.c_int, [vp, vp, vp, vp, vp, vpp, vp, vp]),
     "mkhe_ct_fold": (C.c_int, [vp, vp]),
     "mkhe_rotate":(C.c_int, [vp, C.c_uint64, vp, vpp, vpp, vp, vp]),
+    "mkhe_rotate_partial": (C.c_int, [vp, vp, vpp, vpp, vp, C.c_int, vp]),
+    "mkhe_ct_automorphism": (C.c_int, [vp, C.c_uint64, vp, vp]),
     "mkhe_conjugate": (C.c_int, [vp, C.c_uint64, vp, vpp, vp, vp]),
     "mkhe_rescale": (C.c_int, [vp, vp, C.c_int, vp]),
     "mkhe_ct_add": (C.c_int, [vp, vp, vp, vp]),

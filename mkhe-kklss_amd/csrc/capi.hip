@@ -248,6 +248,17 @@ int mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk
         ctx->c->rotate(galEl, in->c, hoist ? h.data() : nullptr, r.data(), crs->s, out->c);
     })
 }
+int mkhe_rotate_partial(mkhe_ctx* ctx, const mkhe_ct* in, const mkhe_swk* const* hoist,
+                        const mkhe_swk* const* rk, const mkhe_swk* crs, int with_c0, mkhe_ct* out) {
+    MKHE_TRY({
+        if (!in || !out || !rk || !crs) throw Error("mkhe_rotate_partial: null argument");
+        auto h = swk_list(hoist, in->c.n); auto r = swk_list(rk, in->c.n);
+        ctx->c->rotate_partial(in->c, hoist ? h.data() : nullptr, r.data(), crs->s, with_c0 != 0, out->c);
+    })
+}
+int mkhe_ct_automorphism(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, mkhe_ct* out) {
+    MKHE_TRY({ if (!in || !out) throw Error("mkhe_ct_automorphism: null argument"); ctx->c->automorphism(galEl, in->c, out->c); })
+}
 int mkhe_conjugate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* ck,
                    const mkhe_swk* crs, mkhe_ct* out) {
     MKHE_TRY({

@@ -59,6 +59,8 @@ class Context {
                        const Swk& crs_u, Ct& out);
     void rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, Ct& out);
     void conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk& crs, Ct& out);
+    void rotate_partial(const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, bool with_c0, Ct& out);
+    void automorphism(u64 galEl, const Ct& in, Ct& out);
     // ---- mkbfv (mkbfv/basis_extension.go, keyswitch.go, keyswitch_hoisted.go, evaluator.go); PolyR = [2nq][N]
     bool is_bfv() const { return nqm > 0; }
     void bfv_modup_q_to_r(const u64* polyq, u64* polyr, int npolys);          // conv.ModUpQtoR

@@ -665,13 +665,24 @@ void Context::fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_st
 // ------------------------------------------------------------------ Rotate[Hoisted] / Conjugate
 // keyswitch.go:234-298, keyswitch_hoisted.go:183-247
 void Context::rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, Ct& out) {
+    const int L = out.limbs, n = in.n;
+    Ct tmp; tmp.n = n; tmp.limbs = L; tmp.ids = in.ids;
+    tmp.d = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * L * N);
+    rotate_partial(in, hoist, rk, crs, true, tmp);
+    automorphism(galEl, tmp, out);
+}
+
+// Rotate without the final permutation: out_0 = [c_0 +] sum_i <h(c_i), rk_i>_P, out_i = <h(c_i), crs>_P
+// (keyswitch.go:251-265).  with_c0 = false leaves c_0 out (party-sharded evaluation: one rank adds it).
+void Context::rotate_partial(const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, bool with_c0, Ct& out) {
     const int level = out.limbs - 1, L = level + 1, n = in.n;
     check_level(level);
     if (in.limbs < L) throw Error("Cannot Rotate: ctIn and ctOut have different levels");
     if (out.n != n || out.ids != in.ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
     const size_t PI = (size_t)in.limbs * N, PO = (size_t)L * N;
-    u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * PO);
-    MKHE_HIP(hipMemcpyAsync(tmp, in.d, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+    u64* tmp = out.d;
+    if (with_c0) MKHE_HIP(hipMemcpyAsync(tmp, in.d, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+    else MKHE_HIP(hipMemsetAsync(tmp, 0, PO * sizeof(u64), s_));
     std::vector<const u64*> h(n);
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
@@ -688,7 +699,15 @@ void Context::rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk
         items.push_back(ExtItem{h[a], crs.d, tmp + (size_t)(1 + a) * PO, false});
     }
     ext_batch(level, items);
-    launch_automorphism(out.d, tmp, d_mods, L, logN, galEl, 1 + n, s_);
+    MKHE_HIP(hipGetLastError());
+}
+
+// signed coefficient permutation X -> X^galEl of every component (keyswitch.go:267-296)
+void Context::automorphism(u64 galEl, const Ct& in, Ct& out) {
+    const int L = out.limbs;
+    if (in.limbs != L || in.n != out.n) throw Error("mkhe: automorphism operands differ in shape");
+    if (in.d == out.d) throw Error("mkhe: automorphism cannot run in place");
+    launch_automorphism(out.d, in.d, d_mods, L, logN, galEl, 1 + in.n, s_);
     MKHE_HIP(hipGetLastError());
 }
 

@@ -51,6 +51,34 @@ class ShardedMulRelin:
         return full
 
 
+def assign_parties(names, world):
+    """whole parties per rank for the rotation: -> list over ranks of id lists (contiguous chunks)"""
+    out = [[] for _ in range(world)]
+    for j, n in enumerate(names):
+        out[j * world // len(names)].append(n)
+    return out
+
+
+class ShardedRotate:
+    """Party-sharded Rotate[Hoisted] (keyswitch.go:234-298, keyswitch_hoisted.go:183-247): the 2k external products
+    are independent per party.  Rank r evaluates them for its parties (rank 0 also carries c_0); one all-reduce of the
+    un-permuted ciphertext (slot 0 is a sum over ranks, slot i comes from its owner, zeros elsewhere), then the signed
+    permutation on the folded result -- after the reduction, so that the reference's "q - 0 = q" representative of
+    keyswitch.go:290 comes out exactly as on one device."""
+
+    def __init__(self, backend, dist=None, group=None):
+        self.b, self.dist, self.group = backend, dist, group
+
+    def run(self):
+        b = self.b
+        full = b.partial()                    # torch int64 view [1+k][L][N]
+        if self.dist is not None and self.dist.get_world_size(self.group) > 1:
+            b.before_collective()
+            self.dist.all_reduce(full, op=self.dist.ReduceOp.SUM, group=self.group)
+            b.after_collective()
+        return b.finish()                     # fold + permutation -> the rotated ciphertext
+
+
 class _DevView:
     """exposes a raw device pointer to torch through __cuda_array_interface__ (no copy)"""
 
@@ -124,3 +152,52 @@ class HipShardBackend:
 
     def fold_out(self):
         self.check(self.lib().mkhe_ct_fold(self.params.ctx, self.full.h))
+
+
+class HipRotateBackend:
+    """Local arithmetic of one rank for ShardedRotate through the C ABI (mkhe_rotate_partial, mkhe_ct_fold,
+    mkhe_ct_automorphism)."""
+
+    def __init__(self, params, names, rank, world, ct_host, rk_host, crs, rotidx, level, torch, device_index):
+        """ct_host: uint64[1+k][L][N]; rk_host: {name: rotation key array} for (at least) this rank's parties;
+        crs: the device SwitchingKey params.CRS[rotidx]."""
+        from . import mkrlwe
+        from ._abi import check, handle_array, lib
+        self.params, self.names, self.level, self.torch = params, list(names), level, torch
+        self.check, self.lib, self.harr = check, lib, handle_array
+        self.ids = assign_parties(self.names, world)[rank]
+        self.with_c0 = rank == 0
+        sub = np.ascontiguousarray(np.stack([ct_host[0]] + [ct_host[1 + self.names.index(n)] for n in self.ids]))
+        self.sub = mkrlwe.NewCiphertext(params, self.ids, level).upload(sub)
+        self.part = mkrlwe.NewCiphertext(params, self.ids, level)
+        self.keys = [mkrlwe.SwitchingKey(params, rk_host[n]) for n in self.ids]
+        self.crs = crs
+        self.galEl = params.GaloisElementForColumnRotationBy(rotidx)
+        self.full = mkrlwe.NewCiphertext(params, self.names, level)
+        self.out = mkrlwe.NewCiphertext(params, self.names, level)
+        dev = torch.device("cuda", device_index)
+        N, L = params.N(), level + 1
+        self.tfull = torch.as_tensor(_DevView(self.full.devptr(), (1 + len(self.names)) * L * N), device=dev).view(1 + len(self.names), L, N)
+        self.tpart = torch.as_tensor(_DevView(self.part.devptr(), (1 + len(self.ids)) * L * N), device=dev).view(1 + len(self.ids), L, N)
+
+    def partial(self):
+        self.check(self.lib().mkhe_rotate_partial(self.params.ctx, self.sub.h, None, self.harr([k.h for k in self.keys]),
+                                                  self.crs.h, 1 if self.with_c0 else 0, self.part.h))
+        self.params.sync()
+        self.tfull.zero_()
+        self.tfull[0].copy_(self.tpart[0])
+        for a, n in enumerate(self.ids):
+            self.tfull[1 + self.names.index(n)].copy_(self.tpart[1 + a])
+        self.torch.cuda.current_stream().synchronize()
+        return self.tfull
+
+    def before_collective(self):
+        self.params.sync()
+
+    def after_collective(self):
+        self.torch.cuda.current_stream().synchronize()
+
+    def finish(self):
+        self.check(self.lib().mkhe_ct_fold(self.params.ctx, self.full.h))
+        self.check(self.lib().mkhe_ct_automorphism(self.params.ctx, self.galEl, self.full.h, self.out.h))
+        return self.out

@@ -2,7 +2,7 @@
 so the sharding + collective pattern can be exercised with gloo on CPU (no GPU in this container)."""
 import numpy as np
 
-from mkhe_kklss_amd.dist import assign_units
+from mkhe_kklss_amd.dist import assign_parties, assign_units
 
 
 class OracleShardBackend:
@@ -52,3 +52,39 @@ class OracleShardBackend:
         for s in range(self.full.shape[0]):
             for j in range(self.level + 1):
                 self.full[s][j] = self.ks.ringQ.reduce(j, self.full[s][j])
+
+
+class OracleRotateBackend:
+    """TEST-ONLY backend of mkhe_kklss_amd.dist.ShardedRotate on the CPU oracle."""
+
+    def __init__(self, ks, names, rank, world, ct_host, rk_host, crs, galEl, level, torch):
+        self.ks, self.names, self.level, self.torch, self.galEl = ks, list(names), level, torch, galEl
+        self.ids = [self.names.index(n) for n in assign_parties(self.names, world)[rank]]
+        self.with_c0 = rank == 0
+        self.ct, self.rk, self.crs = ct_host, rk_host, crs
+
+    def partial(self):
+        ks, L = self.ks, self.level + 1
+        full = np.zeros((1 + len(self.names), L, ks.N), dtype=np.uint64)
+        if self.with_c0:
+            full[0] = self.ct[0]
+        for i in self.ids:
+            a = self.ct[1 + i]
+            e = ks.external_product(self.level, a, self.rk[self.names[i]])
+            for j in range(L):
+                full[0][j] = ks.ringQ.add(j, full[0][j], e[j])
+            full[1 + i] = ks.external_product(self.level, a, self.crs)
+        self.full = full
+        return self.torch.from_numpy(full.view(np.int64))
+
+    def before_collective(self): pass
+    def after_collective(self): pass
+
+    def finish(self):
+        ks = self.ks
+        out = np.empty_like(self.full)
+        for s in range(self.full.shape[0]):
+            red = np.stack([ks.ringQ.reduce(j, self.full[s][j]) for j in range(self.level + 1)])
+            out[s] = ks.ringQ.permute(self.galEl, red)
+        self.out = out
+        return out

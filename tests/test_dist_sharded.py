@@ -119,3 +119,70 @@ def test_sharded_mulrelin_device_emulated_ranks(world, names):
     torch.cuda.synchronize()
     b.fold_out()
     assert (b.full.download() == ref).all()
+
+
+# ---------------------------------------------------------------- party-sharded Rotate
+def make_rot_case(pset, names, seed, rot=3):
+    rng = np.random.default_rng(seed)
+    ks = O.KeySwitcher(pset["logN"], pset["Q"], pset["P"], 2)
+    level = len(pset["Q"]) - 1
+    ct = H.uniform_ct(rng, ks, len(names), level + 1)
+    rk = {n: H.uniform_swk(rng, ks) for n in names}
+    crs = H.uniform_swk(rng, ks)
+    galEl = pow(5, rot, 2 * ks.N)
+    ref = ks.rotate(level, galEl, list(range(len(names))), ct, [rk[n] for n in names], crs)
+    return ks, level, ct, rk, crs, galEl, ref
+
+
+def _rot_worker(rank, world, port, names, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_oracle_backend import OracleRotateBackend
+    from mkhe_kklss_amd.dist import ShardedRotate
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ks, level, ct, rk, crs, galEl, ref = make_rot_case(H.small_ckks(10, 3), names, 9)
+    b = OracleRotateBackend(ks, names, rank, world, ct, rk, crs, galEl, level, torch)
+    out = ShardedRotate(b, dist).run()
+    ok = bool((out == ref).all())
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, np.array([ok]))
+    else:
+        assert ok
+    dist.destroy_process_group()
+
+
+def test_sharded_rotate_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_rot_worker, args=(2, port, ["u0", "u1", "u2"], out), nprocs=2, join=True)
+    assert np.load(out)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_rotate_device_emulated_ranks(world):
+    import torch
+    from mkhe_kklss_amd import mkrlwe
+    from mkhe_kklss_amd.dist import HipRotateBackend
+    pset = H.small_ckks(11, 3)
+    names = ["u0", "u1", "u2"]
+    ks, level, ct, rk, crs, galEl, ref = make_rot_case(pset, names, 11)
+    bs = []
+    for r in range(world):
+        params = mkrlwe.Parameters(pset["logN"], pset["Q"], pset["P"], 2)
+        bs.append(HipRotateBackend(params, names, r, world, ct, rk, params.AddCRS(3, crs), 3, level, torch, 0))
+    parts = [b.partial().clone() for b in bs]
+    tot = sum(parts[1:], parts[0])
+    b = bs[0]
+    b.tfull.copy_(tot)
+    torch.cuda.synchronize()
+    out = b.finish().download()
+    assert (out == ref).all()
