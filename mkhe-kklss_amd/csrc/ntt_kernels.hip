@@ -245,11 +245,15 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     const bool active = job < njobs;
     if (!active) job = njobs - 1;            // keep every lane in the barriers; results discarded
     if constexpr (G::LPB == 1) job = __builtin_amdgcn_readfirstlane(job);    // provably wave-uniform: modulus constants and pointers stay in SGPRs
-    if (b.trace && t == 0 && active) {
-        b.trace[4 * job + 0] = __builtin_amdgcn_s_memrealtime();
-        b.trace[4 * job + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
-        b.trace[4 * job + 3] = __builtin_amdgcn_s_memtime();                                     // shader clock ticks
+    // diagnostic timeline (mkhe_ntt_trace): 16 words per (job, wave): shader-clock stamps 0..9 at the phase
+    // boundaries, [12] / [13] = 100 MHz real time at start / end, [14] = HW_ID
+#define MKHE_STAMP(k) do { if (b.trace && (threadIdx.x & 63) == 0 && active) b.trace[((long)job * 16 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (b.trace && (threadIdx.x & 63) == 0 && active) {
+        u64* tw = b.trace + ((long)job * 16 + (threadIdx.x >> 6)) * 16;
+        tw[12] = __builtin_amdgcn_s_memrealtime();
+        tw[14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
     }
+    MKHE_STAMP(0);
     gcptr src; gptr dst; int m, outer;
     const int half = b.split ? (job & 1) : 0;
     job_pointers(b, b.split ? (job >> 1) : job, src, dst, m, outer);
@@ -263,6 +267,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     u64 x[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = src[posA<LOGN>(t, r)];
+    if (b.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MKHE_STAMP(1); }      // loads landed
     if constexpr (DEC) {
         // digit of a foreign modulus (Decompose, alpha = 1): bring it below 4q when needed
         int sm = m;
@@ -280,12 +285,14 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
         if (ph == 1) { base = G::N >> 6; prefix = t >> 5; maxB = G::MIDB; }
         if (ph == 2) { base = G::N >> 1; prefix = t; }
         phase<MODE>(x, psi, base * root, prefix, maxB, q, q2, ninv);
+        MKHE_STAMP(2 + 2 * ph);                  // 2, 4, 6: end of the butterflies of phase ph
         if (ph == 0) {
             if constexpr (G::HAS_MID) {
                 __syncthreads();     // every wave is done with the LDS of the previous limb
                 exchange<LOGN, LA, LB, true>(x, lds, t);
             }
         } else if (ph == 1) exchange<LOGN, LB, LC, false>(x, lds, t);
+        MKHE_STAMP(3 + 2 * ph);                  // 3, 5: end of the re-distribution after phase ph
     }
     // canonical output (lattigo: final BRedAdd)
     if constexpr (MODE == 1) {
@@ -295,13 +302,16 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) x[r] = csub(csub(x[r], q2), q);
     }
+    MKHE_STAMP(7);                               // normalisation done
     // back to layout B for 256-B contiguous stores
     exchange<LOGN, LC, LB, false>(x, lds, t);
+    MKHE_STAMP(8);
     if (active) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) dst[posB(t, r)] = x[r];
     }
-    if (b.trace && t == 0 && active) { b.trace[4 * job + 1] = __builtin_amdgcn_s_memrealtime(); b.trace[4 * job + 3] = __builtin_amdgcn_s_memtime() - b.trace[4 * job + 3]; }
+    MKHE_STAMP(9);                               // stores issued
+    if (b.trace && (threadIdx.x & 63) == 0 && active) b.trace[((long)job * 16 + (threadIdx.x >> 6)) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

@@ -352,3 +352,125 @@ class Model:
                 out["0"][l] = [(u + w) % q for u, w in zip(out["0"][l], e0[l])]
                 out[i][l] = [(u + w) % q for u, w in zip(out[i][l], e1[l])]
         return ids_out, [out["0"]] + [out[i] for i in ids_out]
+
+
+# --------------------------------------------------------------------------- multi-key BFV model
+class BfvModel(Model):
+    """Mathematical model of mkbfv's multiplication path (mkbfv/basis_extension.go, keyswitch_hoisted.go,
+    evaluator.go:118-140) for small N, alpha = 1.  Base conversions use the literal modUpExact of modup_literal
+    (float64 correction index included) where the reference's result depends on it; products are schoolbook
+    negacyclic products; nothing is shared with the C oracle."""
+
+    def __init__(self, logN, Q, QMul, P, T):
+        super().__init__(logN, Q, P, 2)
+        assert self.alpha == 1 and len(Q) == len(QMul)
+        self.QMul, self.T = list(QMul), T
+        self.R = self.Q + self.QMul
+        self.psiR = self.psi[: len(Q)] + [find_psi(q, self.N) for q in self.QMul]
+        self.Qprod = 1
+        for q in self.Q:
+            self.Qprod *= q
+        self.QMulprod = 1
+        for q in self.QMul:
+            self.QMulprod *= q
+
+    # ---- FastBasisExtender (coefficient domain, one polynomial = [limb][coeff])
+    def _cols(self, poly, n):
+        return [[int(poly[l][k]) for l in range(n)] for k in range(self.N)]
+
+    def modup_q_to_r(self, polyq):
+        nq = len(self.Q)
+        out = [[int(v) for v in polyq[l]] for l in range(nq)] + [[0] * self.N for _ in range(nq)]
+        for k, col in enumerate(self._cols(polyq, nq)):
+            lift, _ = modup_literal(col, self.Q, self.QMul)
+            for j in range(nq):
+                out[nq + j][k] = lift[j]
+        return out
+
+    def rescale(self, polyq):
+        nq = len(self.Q)
+        out = [[0] * self.N for _ in range(2 * nq)]
+        for k, col in enumerate(self._cols(polyq, nq)):
+            pq = [(col[i] * (self.QMulprod % q)) % q for i, q in enumerate(self.Q)]
+            lift, _ = modup_literal(pq, self.Q, self.QMul)
+            qm = [((0 - lift[j]) * pow(self.Qprod, -1, p)) % p for j, p in enumerate(self.QMul)]      # ModDownQPtoP
+            back, _ = modup_literal(qm, self.QMul, self.Q)                                              # ModUpPtoQ (lazy)
+            for j in range(nq):
+                out[j][k], out[nq + j][k] = back[j], qm[j]
+        return out
+
+    def quantize_coeff(self, polyr):
+        """Quantize of a COEFFICIENT-domain polynomial over R (the reference passes the NTT form and inverts it)."""
+        nq = len(self.Q)
+        out = [[0] * self.N for _ in range(nq)]
+        for k in range(self.N):
+            tq = [(int(polyr[l][k]) * self.T) % self.Q[l] for l in range(nq)]
+            tm = [(int(polyr[nq + l][k]) * self.T) % self.QMul[l] for l in range(nq)]
+            lift, _ = modup_literal(tm, self.QMul, self.Q)
+            for i, q in enumerate(self.Q):
+                out[i][k] = ((tq[i] - lift[i]) * pow(self.QMulprod, -1, q)) % q                         # ModDownQPtoQ
+        return out
+
+    # ---- gadget pieces
+    def _acc_digits(self, terms):
+        """sum_t key_t (.) NTT(digits_t): terms = [(digit value lists [nd][N], key [nd][m][N])] -> [nd]{j: coeffs}"""
+        nd = len(terms[0][0])
+        idx = self.limb_index(len(self.Q) - 1)
+        x = [{j: [0] * self.N for j in idx} for _ in range(nd)]
+        for digs, key in terms:
+            for i in range(nd):
+                for j in idx:
+                    q = self.QP[j]
+                    prod = negacyclic_mul([v % q for v in digs[i]], self.key_coeff(key[i], j), q)
+                    x[i][j] = [(u + w) % q for u, w in zip(x[i][j], prod)]
+        return x
+
+    def _ext_digits(self, pairs):
+        """ModDown_P( sum over (digits, xvec) pairs, sum_i xvec[i] * digit_i )"""
+        level = len(self.Q) - 1
+        acc = {j: [0] * self.N for j in self.limb_index(level)}
+        for digs, xvec in pairs:
+            for i in range(len(digs)):
+                for j in self.limb_index(level):
+                    q = self.QP[j]
+                    prod = negacyclic_mul([v % q for v in digs[i]], xvec[i][j], q)
+                    acc[j] = [(u + w) % q for u, w in zip(acc[j], prod)]
+        return self._moddown(acc, level)
+
+    def mul_relin_new(self, ids0, op0, ids1, op1, rlk, crs_u):
+        """Evaluator.MulRelinNew; rlk {id: (b1, b2, d1, d2, v)} in storage form -> (ids_out, [1+n][nQ][N])"""
+        nq, level = len(self.Q), len(self.Q) - 1
+        c0R = [self.modup_q_to_r(op0[s]) for s in range(1 + len(ids0))]
+        c1R = [self.rescale(op1[s]) for s in range(1 + len(ids1))]
+        dq = lambda pr: ([pr[l] for l in range(nq)], [pr[nq + l] for l in range(nq)])     # (Q digits, QMul digits)
+        x1 = self._acc_digits([(dq(c0R[1 + a])[0], rlk[i][2]) for a, i in enumerate(ids0)])
+        x2 = self._acc_digits([(dq(c0R[1 + a])[1], rlk[i][3]) for a, i in enumerate(ids0)])
+        y1 = self._acc_digits([(dq(c1R[1 + a])[0], rlk[i][0]) for a, i in enumerate(ids1)])
+        y2 = self._acc_digits([(dq(c1R[1 + a])[1], rlk[i][1]) for a, i in enumerate(ids1)])
+        ids_out = sorted(set(ids0) | set(ids1))
+        mulR = lambda a, b: [negacyclic_mul([v % m for v in a[l]], [v % m for v in b[l]], m) for l, m in enumerate(self.R)]
+        addR = lambda a, b: [[(u + w) % m for u, w in zip(a[l], b[l])] for l, m in enumerate(self.R)]
+        out = {"0": self.quantize_coeff(mulR(c0R[0], c1R[0]))}
+        for i in ids_out:
+            acc = None
+            if i in ids0:
+                acc = mulR(c1R[0], c0R[1 + ids0.index(i)])
+            if i in ids1:
+                t = mulR(c0R[0], c1R[1 + ids1.index(i)])
+                acc = t if acc is None else addR(acc, t)
+            out[i] = self.quantize_coeff(acc)
+        Q = self.Q
+        for a, j in enumerate(ids1):
+            d1, d2 = dq(c1R[1 + a])
+            e = self._ext_digits([(d1, x1), (d2, x2)])
+            for l, q in enumerate(Q):
+                out[j][l] = [(u + w) % q for u, w in zip(out[j][l], e[l])]
+        for a, i in enumerate(ids0):
+            d1, d2 = dq(c0R[1 + a])
+            t = self._ext_digits([(d1, y1), (d2, y2)])
+            e0 = self.external_product(t, rlk[i][4], level)
+            e1 = self.external_product(t, crs_u, level)
+            for l, q in enumerate(Q):
+                out["0"][l] = [(u + w) % q for u, w in zip(out["0"][l], e0[l])]
+                out[i][l] = [(u + w) % q for u, w in zip(out[i][l], e1[l])]
+        return ids_out, [out["0"]] + [out[i] for i in ids_out]

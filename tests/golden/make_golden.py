@@ -85,7 +85,53 @@ def ntt_1024():
     print("wrote ntt_n1024")
 
 
+def bfv_case():
+    """mkbfv: full MulRelinNew at N = 16 by the independent model (oracle/pymodel.py BfvModel)"""
+    import harness_bfv as HB
+    logN, N = 4, 16
+    Qs, QMs, Ps, T = HB.BFV_PN15QP880["Q"][:2], HB.BFV_PN15QP880["QMul"][:2], HB.BFV_PN15QP880["P"], 65537
+    rng = np.random.default_rng(21)
+    mdl = M.BfvModel(logN, Qs, QMs, Ps, T)
+    swk = lambda: np.stack([rnd_poly(rng, Qs + Ps, N) for _ in range(len(Qs))])
+    ids0, ids1 = [0, 1], [1, 2]
+    op0 = np.stack([rnd_poly(rng, Qs, N) for _ in range(3)])
+    op1 = np.stack([rnd_poly(rng, Qs, N) for _ in range(3)])
+    rlk = {i: tuple(swk() for _ in range(5)) for i in range(3)}
+    u = swk()
+    d = dict(logN=logN, Q=u64(Qs), QMul=u64(QMs), P=u64(Ps), T=np.uint64(T), op0=op0, op1=op1, crs_u=u,
+             ids0=np.array(ids0), ids1=np.array(ids1))
+    for i in range(3):
+        for k, nm in enumerate(("b1", "b2", "d1", "d2", "v")):
+            d["rlk%d_%s" % (i, nm)] = rlk[i][k]
+    ido, out = mdl.mul_relin_new(ids0, op0, ids1, op1, rlk, u)
+    d["mr_ids"], d["mr_out"] = np.array(ido), u64(out)
+    x = rnd_poly(rng, Qs, N)
+    d["conv_in"], d["modup_out"], d["rescale_out"] = x, u64(mdl.modup_q_to_r(x)), u64(mdl.rescale(x))
+    np.savez_compressed(os.path.join(OUT, "bfv_n16.npz"), **d)
+    print("wrote bfv_n16")
+
+
+def bfv_conv_1024():
+    """mkbfv base conversions at the device's minimum ring degree: ModUpQtoR, Rescale, ringR NTT + Quantize"""
+    import harness_bfv as HB
+    logN, N = 10, 1024
+    Qs, QMs, Ps, T = HB.BFV_PN15QP880["Q"][:2], HB.BFV_PN15QP880["QMul"][:2], HB.BFV_PN15QP880["P"], 65537
+    rng = np.random.default_rng(22)
+    mdl = M.BfvModel(logN, Qs, QMs, Ps, T)
+    x = rnd_poly(rng, Qs, N)
+    x[:, 0] = 0
+    x[:, 1] = u64([q - 1 for q in Qs])
+    y = rnd_poly(rng, Qs + QMs, N)
+    yn = u64([M.ntt_def([int(v) for v in y[l]], m, mdl.psiR[l], logN) for l, m in enumerate(Qs + QMs)])
+    np.savez_compressed(os.path.join(OUT, "bfv_conv_n1024.npz"), logN=logN, Q=u64(Qs), QMul=u64(QMs), P=u64(Ps), T=np.uint64(T),
+                        conv_in=x, modup_out=u64(mdl.modup_q_to_r(x)), rescale_out=u64(mdl.rescale(x)),
+                        r_in=y, r_ntt=yn, quantize_out=u64(mdl.quantize_coeff(y)))
+    print("wrote bfv_conv_n1024")
+
+
 if __name__ == "__main__":
+    bfv_case()
+    bfv_conv_1024()
     small_case("alpha1_n16", 4, H.PN15QP880["Q"][:3], H.PN15QP880["P"], 11)
     small_case("alpha2_n16", 4, H.PN16_Q[:5], H.PN16_P, 12)
     ntt_1024()

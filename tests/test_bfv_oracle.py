@@ -133,3 +133,38 @@ def test_hoisted_equals_plain_on_uniform_inputs():
     assert (a == b).all()
     for l, q in enumerate(bfv.Q):
         assert (a[:, l] < q).all()
+
+
+# ---------------------------------------------------------------- C oracle vs the independent Python model
+MODEL_SET = dict(logN=4, Q=HB.BFV_PN15QP880["Q"][:2], QMul=HB.BFV_PN15QP880["QMul"][:2], P=HB.BFV_PN15QP880["P"], T=65537)
+
+
+def _model_pair():
+    # the reference's primes are = 1 mod 2^16 >= 2N for every N <= 2^15, so they serve N = 16 as well
+    return HB.make_bfv(MODEL_SET), M.BfvModel(4, MODEL_SET["Q"], MODEL_SET["QMul"], MODEL_SET["P"], MODEL_SET["T"])
+
+
+def test_conversions_vs_model():
+    bfv, mdl = _model_pair()
+    rng = np.random.default_rng(31)
+    for _ in range(4):
+        x = H.uniform_poly(rng, bfv.Q, bfv.N)
+        assert bfv.modup_q_to_r(x).tolist() == mdl.modup_q_to_r(x)
+        assert bfv.rescale(x).tolist() == mdl.rescale(x)
+        y = np.stack([H.uniform_poly(rng, [m], bfv.N)[0] for m in bfv.Q + bfv.QMul])
+        assert bfv.quantize(bfv.ntt_r(y)).tolist() == mdl.quantize_coeff(y)
+
+
+@pytest.mark.parametrize("ids0,ids1", [([0, 1], [0, 1]), ([0], [1]), ([0, 1], [1, 2])])
+def test_mul_relin_new_vs_model(ids0, ids1):
+    bfv, mdl = _model_pair()
+    rng = np.random.default_rng(hash((tuple(ids0), tuple(ids1))) & 0xffff)
+    swk = lambda: np.stack([H.uniform_poly(rng, bfv.Q + bfv.P, bfv.N) for _ in range(bfv.nq)])
+    ct = lambda n: np.stack([H.uniform_poly(rng, bfv.Q, bfv.N) for _ in range(1 + n)])
+    op0, op1 = ct(len(ids0)), ct(len(ids1))
+    rlk = {i: tuple(swk() for _ in range(5)) for i in sorted(set(ids0) | set(ids1))}
+    u = swk()
+    ido, out = bfv.mul_relin_new(ids0, op0, ids1, op1, rlk, u)
+    idm, outm = mdl.mul_relin_new(ids0, op0, ids1, op1, rlk, u)
+    assert ido == idm
+    assert out.tolist() == outm

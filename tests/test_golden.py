@@ -64,3 +64,42 @@ def test_gpu_ntt_n1024_golden():
     assert (dst.download()[0] == g["ntt_out"]).all()
     mkrlwe.ntt(params, dst, src, inverse=True)
     assert (src.download()[0] == g["ntt_in"]).all()
+
+
+def _bfv(g):
+    return O.BFV(int(g["logN"]), [int(q) for q in g["Q"]], [int(q) for q in g["QMul"]], [int(p) for p in g["P"]], int(g["T"]))
+
+
+def test_oracle_reproduces_bfv_golden():
+    g = load("bfv_n16")
+    bfv = _bfv(g)
+    rlk = {i: tuple(g["rlk%d_%s" % (i, nm)] for nm in ("b1", "b2", "d1", "d2", "v")) for i in range(3)}
+    ido, out = bfv.mul_relin_new(list(g["ids0"]), g["op0"], list(g["ids1"]), g["op1"], rlk, g["crs_u"])
+    assert ido == list(g["mr_ids"]) and (out == g["mr_out"]).all()
+    assert (bfv.modup_q_to_r(g["conv_in"]) == g["modup_out"]).all()
+    assert (bfv.rescale(g["conv_in"]) == g["rescale_out"]).all()
+    c = load("bfv_conv_n1024")
+    bfv = _bfv(c)
+    assert (bfv.modup_q_to_r(c["conv_in"]) == c["modup_out"]).all()
+    assert (bfv.rescale(c["conv_in"]) == c["rescale_out"]).all()
+    assert (bfv.ntt_r(c["r_in"]) == c["r_ntt"]).all()
+    assert (bfv.quantize(c["r_ntt"]) == c["quantize_out"]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_bfv_conversions_golden():
+    from mkhe_kklss_amd import mkbfv, mkrlwe
+    c = load("bfv_conv_n1024")
+    params = mkbfv.Parameters(int(c["logN"]), [int(q) for q in c["Q"]], [int(q) for q in c["QMul"]], [int(p) for p in c["P"]], int(c["T"]))
+    conv = mkbfv.FastBasisExtender(params)
+    nq = len(c["Q"])
+    src = mkrlwe.DeviceLimbs(params, 1, nq).upload(c["conv_in"][None])
+    r = mkbfv.PolyR(params, 1)
+    conv.ModUpQtoR(src, r)
+    assert (r.download()[0] == c["modup_out"]).all()
+    conv.Rescale(src, r)
+    assert (r.download()[0] == c["rescale_out"]).all()
+    rn = mkbfv.PolyR(params, 1).upload(c["r_ntt"][None])
+    out = mkrlwe.DeviceLimbs(params, 1, nq)
+    conv.Quantize(rn, out, params.T())
+    assert (out.download()[0] == c["quantize_out"]).all()

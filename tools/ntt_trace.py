@@ -1,4 +1,7 @@
-"""Diagnostic: timeline of forward-NTT workgroups (start/end per limb, CU placement)."""
+"""Diagnostic: per-wave phase timeline of the forward NTT kernel (mkhe_ntt_trace): where do a limb's cycles go?
+
+    python tools/ntt_trace.py [polys]          (13 small primes of PN15QP880 -> one kernel class, polys*13 limbs)
+"""
 import sys, os
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +10,7 @@ import harness as H
 from mkhe_kklss_amd import mkrlwe
 from mkhe_kklss_amd._abi import lib, check
 pset = H.PN15QP880
-params = mkrlwe.Parameters(15, pset["Q"][1:14], pset["P"], 2)     # 13 small primes only -> one kernel class
+params = mkrlwe.Parameters(15, pset["Q"][1:14], pset["P"], 2)
 N = 1 << 15
 count, limbs = int(sys.argv[1]) if len(sys.argv) > 1 else 80, 13
 rng = np.random.default_rng(0)
@@ -15,35 +18,29 @@ a = rng.integers(0, 1 << 53, (count, limbs, N), dtype=np.uint64)
 src = mkrlwe.DeviceLimbs(params, count, limbs).upload(a)
 dst = mkrlwe.DeviceLimbs(params, count, limbs)
 njobs = count * limbs
-tr = mkrlwe.DeviceLimbs(params, 1, 1)     # N words >= 4*njobs
-assert 4 * njobs <= N
+words = njobs * 16 * 16
+tr = mkrlwe.DeviceLimbs(params, (words + N - 1) // N, 1)
 for _ in range(3): mkrlwe.ntt(params, src, dst)
 check(lib().mkhe_ntt_trace(params.ctx, tr.devptr()))
 mkrlwe.ntt(params, src, dst)
 params.sync()
 check(lib().mkhe_ntt_trace(params.ctx, None))
-t = tr.download().reshape(-1)[: 4 * njobs].reshape(njobs, 4).astype(np.int64)
-t0 = t[:, 0].min()
-start, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0     # us
-dur = end - start
-hw = t[:, 2]; xcc = (hw >> 20) & 0xf   # not the XCC id, only used to count placements
-clk = t[:, 3] / np.maximum(dur, 1e-9) / 1e3
-print('shader clock during a limb (s_memtime ticks / us): mean %.2f GHz  min %.2f  max %.2f' % (clk.mean(), clk.min(), clk.max()))
-cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
-place = hw & 0xfffff00
-print("jobs", njobs, "kernel span %.1f us" % end.max(), "mean limb %.1f us  min %.1f  max %.1f" % (dur.mean(), dur.min(), dur.max()))
-print("distinct placements (xcc,se,sh,cu):", len(set(place.tolist())), " distinct xcc:", sorted(set(xcc.tolist())))
-# concurrency over time
-ts = np.linspace(0, end.max(), 40)
-print("concurrent limbs over time:", [int(((start <= x) & (end > x)).sum()) for x in ts])
-# per placement: jobs and gaps
-order = np.argsort(start)
-gaps = []
-byp = {}
-for j in order:
-    byp.setdefault(int(place[j]), []).append(j)
-for p, js in byp.items():
-    for a_, b_ in zip(js[:-1], js[1:]):
-        gaps.append(start[b_] - end[a_])
-gaps = np.array(gaps)
-print("per-CU gap between consecutive limbs: mean %.2f us, median %.2f, max %.2f (n=%d)" % (gaps.mean(), np.median(gaps), gaps.max(), len(gaps)))
+t = tr.download().reshape(-1)[:words].reshape(njobs, 16, 16).astype(np.int64)
+st = t[:, :, :10]                         # shader-clock stamps
+names = ["load wait", "reduce+phase0", "xchg A->B (barriers)", "phase1", "xchg B->C", "phase2", "normalise", "xchg C->B", "store issue"]
+d = np.diff(st, axis=2)                   # [job][wave][9]
+tot = st[:, :, 9] - st[:, :, 0]
+print("limbs %d; per-wave total cycles: mean %.0f  min %.0f  max %.0f" % (njobs, tot.mean(), tot.min(), tot.max()))
+for k, n in enumerate(names):
+    print("  %-24s mean %8.0f cycles (%5.1f%%)   min %8.0f  max %8.0f" % (n, d[:, :, k].mean(), 100 * d[:, :, k].mean() / tot.mean(), d[:, :, k].min(), d[:, :, k].max()))
+rt = (t[:, :, 13] - t[:, :, 12]) / 100.0
+print("real time per wave per limb: mean %.1f us -> shader clock %.2f GHz" % (rt.mean(), tot.mean() / rt.mean() / 1e3))
+# skew between the waves of one workgroup at the end of each phase
+for k in (2, 3, 4, 6, 9):
+    sk = st[:, :, k].max(axis=1) - st[:, :, k].min(axis=1)
+    print("  wave skew at stamp %d: mean %.0f cycles" % (k, sk.mean()))
+# gap between consecutive limbs of one workgroup (persistent loop): next start - previous end on the same HW slot
+hw = t[:, 0, 14]
+start, end = t[:, 0, 12], t[:, :, 13].max(axis=1)
+span = (end.max() - start.min()) / 100.0
+print("kernel span %.1f us for %d limbs -> %.2f us per limb chip-wide" % (span, njobs, span / njobs))
