@@ -145,6 +145,14 @@ int  mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out);
 int  mkhe_ct_add(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out);
 int  mkhe_ct_sub(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out);
 
+/* mkckks.Evaluator.MultByConst body (mkckks/evaluator.go:150-196): per limb l < min(limbs(in), limbs(out)) the coefficients
+ * [0, N/2) are multiplied by c_first[l], [N/2, N) by c_second[l] (host arrays, Montgomery form = the reference's
+ * ring.MForm(scaledConst); the float64 getConstAndScale / scaleUpExact logic :40-94 stays on the host). */
+int  mkhe_ct_mul_const(mkhe_ctx* ctx, const mkhe_ct* in, const uint64_t* c_first, const uint64_t* c_second, mkhe_ct* out);
+/* mkckks.Evaluator.MulPtxtNew body (evaluator.go:465-478) without its Rescale: every component times the plaintext
+ * polynomial dev_pt = uint64[limbs][N] (coefficient domain, device), via NTT / MForm / InvNTT. */
+int  mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe_ct* out);
+
 /* ==== mkbfv ========================================================================================
  * Context for mkbfv.NewParametersFromLiteral (mkbfv/params.go:28-76): rings Q, QMul (same length), R = Q||QMul,
  * P and the plaintext modulus T; replaces mkbfv.NewKeySwitcher (keyswitch.go:31-65) + NewFastBasisExtender

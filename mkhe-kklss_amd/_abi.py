@@ -58,6 +58,8 @@ SIGNATURES = {
     "mkhe_rescale": (C.c_int, [vp, vp, C.c_int, vp]),
     "mkhe_ct_add": (C.c_int, [vp, vp, vp, vp]),
     "mkhe_ct_sub": (C.c_int, [vp, vp, vp, vp]),
+    "mkhe_ct_mul_const": (C.c_int, [vp, vp, u64p, u64p, vp]),
+    "mkhe_ct_mul_ptxt": (C.c_int, [vp, vp, vp, vp]),
     "mkhe_ctx_create_bfv": (C.c_int, [vpp, C.c_int, u64p, u64p, C.c_int, u64p, C.c_int, C.c_int, C.c_uint64, C.c_int]),
     "mkhe_bfv_modup_q_to_r": (C.c_int, [vp, vp, vp, C.c_int]),
     "mkhe_bfv_rescale": (C.c_int, [vp, vp, vp, C.c_int]),

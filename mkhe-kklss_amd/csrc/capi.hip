@@ -277,6 +277,12 @@ int mkhe_ct_add(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* 
 int mkhe_ct_sub(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out) {
     MKHE_TRY({ if (!op0 || !op1 || !out) throw Error("mkhe_ct_sub: null argument"); ctx->c->ct_binary(1, op0->c, op1->c, out->c); })
 }
+int mkhe_ct_mul_const(mkhe_ctx* ctx, const mkhe_ct* in, const uint64_t* c_first, const uint64_t* c_second, mkhe_ct* out) {
+    MKHE_TRY({ if (!in || !out || !c_first || !c_second) throw Error("mkhe_ct_mul_const: null argument"); ctx->c->ct_mul_const(in->c, c_first, c_second, out->c); })
+}
+int mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe_ct* out) {
+    MKHE_TRY({ if (!in || !out || !dev_pt) throw Error("mkhe_ct_mul_ptxt: null argument"); ctx->c->ct_mul_ptxt(in->c, (const u64*)dev_pt, out->c); })
+}
 
 // ---- mkbfv
 int mkhe_ctx_create_bfv(mkhe_ctx** out, int logN, const uint64_t* Q, const uint64_t* QMul, int nQ,

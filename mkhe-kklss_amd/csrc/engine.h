@@ -73,6 +73,9 @@ class Context {
                        const Swk& crs_u, Ct& out);                            // Evaluator.MulRelinNew
     // elementwise evaluator ops (mkckks/evaluator.go:41-300, mkbfv/evaluator.go:27-76): op 0 add, 1 sub
     void ct_binary(int op, const Ct& a, const Ct& b, Ct& out);
+    // mkckks MultByConst body (evaluator.go:150-196) and MulPtxtNew body without its Rescale (:471-478)
+    void ct_mul_const(const Ct& in, const u64* c_first, const u64* c_second, Ct& out);
+    void ct_mul_ptxt(const Ct& in, const u64* dev_pt, Ct& out);
     void ntt_r(const u64* src, u64* dst, int count, bool inverse);            // ringR.NTT / InvNTT
     // mkckks Rescale body: nb successive DivRoundByLastModulus on every poly (evaluator.go:385-391)
     void rescale(const Ct& in, int nb, Ct& out);

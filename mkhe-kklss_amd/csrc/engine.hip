@@ -785,6 +785,33 @@ void Context::ct_binary(int op, const Ct& a, const Ct& b, Ct& out) {
     MKHE_HIP(hipGetLastError());
 }
 
+void Context::ct_mul_const(const Ct& in, const u64* c_first, const u64* c_second, Ct& out) {
+    const int L = std::min(in.limbs, out.limbs);                   // level := min(ct0.Level(), ctOut.Level()), :119
+    if (in.n != out.n || in.ids != out.ids) throw Error("mkhe: ctOut must carry the ids of ct0");
+    if (L > 48) throw Error("mkhe: too many limbs");
+    MulConstArgs a{};
+    a.src = in.d; a.dst = out.d; a.mods = d_mods; a.src_poly = (long)in.limbs * N; a.dst_poly = (long)out.limbs * N;
+    a.L = L; a.N = N; a.npolys = 1 + in.n;
+    for (int l = 0; l < L; ++l) {
+        if (c_first[l] >= moduli[l] || c_second[l] >= moduli[l]) throw Error("mkhe: MultByConst constants must be reduced");
+        a.c[0][l] = c_first[l]; a.c[1][l] = c_second[l];
+    }
+    { ProfScope ps(this, PROF_OTHER, 16.0 * N * L * (1 + in.n)); launch_mul_const_halves(a, s_); }
+    MKHE_HIP(hipGetLastError());
+}
+
+void Context::ct_mul_ptxt(const Ct& in, const u64* dev_pt, Ct& out) {
+    const int L = in.limbs, np_ = 1 + in.n;
+    if (out.limbs != L || out.n != in.n || out.ids != in.ids) throw Error("mkhe: ctOut shape does not match ct");
+    const size_t PO = (size_t)L * N;
+    u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + np_) * PO);
+    ntt(dev_pt, tmp, 1, L, 0, false, false);
+    ntt(in.d, tmp + PO, np_, L, 0, false, false);
+    { ProfScope ps(this, PROF_OTHER, 8.0 * N * L * (2.0 * np_ + 1)); launch_mul_by_poly(tmp + PO, tmp + PO, tmp, d_mods, L, N, np_, s_); }
+    ntt(tmp + PO, out.d, np_, L, 0, true, false);
+    MKHE_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------ mkbfv
 // ring R = Q || QMul (mkbfv/params.go:36-38): limb j of a PolyR uses modulus j (j < nq) or nq+np+(j-nq)
 void Context::ntt_r(const u64* src, u64* dst, int count, bool inverse) {

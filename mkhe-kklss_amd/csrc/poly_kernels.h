@@ -158,6 +158,19 @@ void launch_neg(u64* dst, const u64* a, const Mod* mods, int L, int N, hipStream
 void launch_mul_const(u64* dst, const u64* src, const Mod* mods, const int* map, const u64* consts, int L, int N, int npolys,
                       long poly_stride, hipStream_t st);
 
+// mkckks MultByConst body (mkckks/evaluator.go:150-196): coefficients [0, N/2) of limb l times c[0][l], [N/2, N) times
+// c[1][l] (Montgomery constants, canonical results); npolys polynomials, possibly different limb counts in / out.
+struct MulConstArgs {
+    const u64* src; u64* dst;
+    const Mod* mods;
+    long src_poly, dst_poly;
+    int L, N, npolys;
+    u64 c[2][48];
+};
+void launch_mul_const_halves(const MulConstArgs& a, hipStream_t st);
+// dst[p][l][n] = a[p][l][n] * MForm(b[l][n])  (one polynomial b against npolys polynomials: MulPtxtNew, evaluator.go:471-478)
+void launch_mul_by_poly(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, int npolys, hipStream_t st);
+
 // dst = CRed(a + b) per limb
 void launch_add(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st);
 

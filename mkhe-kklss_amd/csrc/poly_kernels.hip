@@ -263,6 +263,37 @@ void launch_mul_const(u64* dst, const u64* src, const Mod* mods, const int* map,
     hipLaunchKernelGGL(mul_const_kernel, dim3(bx, L, npolys), dim3(PW_THREADS), 0, st, dst, src, mods, map, consts, N, poly_stride);
 }
 
+typedef const __attribute__((address_space(4))) MulConstArgs* mulconst_kargs;
+__global__ void __launch_bounds__(PW_THREADS) mul_const_halves_kernel(MulConstArgs a) {
+    mulconst_kargs ka = (mulconst_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int l = blockIdx.y;
+    const Mod md = a.mods[l];
+    const u64 c0 = ka->c[0][l], c1 = ka->c[1][l];
+    const u64* s = a.src + (long)blockIdx.z * a.src_poly + (long)l * a.N;
+    u64* d = a.dst + (long)blockIdx.z * a.dst_poly + (long)l * a.N;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS)
+        d[n] = mont_mul(s[n], n < (a.N >> 1) ? c0 : c1, md.q, md.ninv32);
+}
+void launch_mul_const_halves(const MulConstArgs& a, hipStream_t st) {
+    int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(mul_const_halves_kernel, dim3(bx, a.L, a.npolys), dim3(PW_THREADS), 0, st, a);
+}
+__global__ void __launch_bounds__(PW_THREADS) mul_by_poly_kernel(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N) {
+    const int l = blockIdx.y;
+    const Mod md = mods[l];
+    const long base = ((long)blockIdx.z * L + l) * N;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < N; n += gridDim.x * PW_THREADS) {
+        const u64 bm = mont_mul(b[(long)l * N + n], md.r2, md.q, md.ninv32);       // MFormLvl(pt)
+        dst[base + n] = mont_mul(a[base + n], bm, md.q, md.ninv32);
+    }
+}
+void launch_mul_by_poly(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, int npolys, hipStream_t st) {
+    int bx = (N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(mul_by_poly_kernel, dim3(bx, L, npolys), dim3(PW_THREADS), 0, st, dst, a, b, mods, L, N);
+}
+
 // ------------------------------------------------------------------ generic basis conversion (mkbfv)
 __global__ void __launch_bounds__(PW_THREADS) basis_conv_kernel(BasisConvArgs a) {
     const int n = blockIdx.x * PW_THREADS + threadIdx.x;

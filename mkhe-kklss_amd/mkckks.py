@@ -3,8 +3,20 @@
 Orchestration and float64 scale bookkeeping stay on the host exactly as in
 mkckks/evaluator.go:359-443,543-617; all polynomial work runs on the device via mkrlwe.KeySwitcher.
 """
-from . import mkrlwe
+import ctypes as C
+
+import numpy as np
+
+from . import _abi, mkrlwe
 from ._abi import MkheError, check, lib
+
+
+def scaleUpExact(value, n, q):
+    """mkckks/utils.go:59-86: round(|value| * n) mod q through a 53-bit big.Float (= float64 arithmetic), negated
+    for value < 0 (q - 0 = q is kept, like the reference)."""
+    x = float(-n * value) if value < 0 else float(n * value)
+    res = int(x + 0.5) % q
+    return q - res if value < 0 else res
 
 
 class Parameters(mkrlwe.Parameters):
@@ -62,6 +74,70 @@ class Evaluator:
 
     def SubNew(self, op0, op1):
         return self._binary(op0, op1, lib().mkhe_ct_sub)
+
+    # ---- getConstAndScale (evaluator.go:40-94)
+    def getConstAndScale(self, level, constant):
+        scale = 1.0
+        if isinstance(constant, complex):
+            cReal, cImag = constant.real, constant.imag
+            for c in (cReal, cImag):
+                if c != 0 and c - float(int(c)) != 0:
+                    scale = float(self.params.Q[level])
+        elif isinstance(constant, float):
+            cReal, cImag = constant, 0.0
+            if cReal != 0 and cReal - float(int(cReal)) != 0:
+                scale = float(self.params.Q[level])
+        else:
+            cReal, cImag = float(int(constant)), 0.0
+        return cReal, cImag, scale
+
+    # ---- MultByConst (evaluator.go:117-199): constants per limb on the host, the products on the device
+    def MultByConst(self, ct0, constant, ctOut):
+        params = self.params
+        level = min(ct0.Level(), ctOut.Level())
+        cReal, cImag, scale = self.getConstAndScale(level, constant)
+        first = np.zeros(ctOut.Level() + 1, dtype=np.uint64)
+        second = np.zeros(ctOut.Level() + 1, dtype=np.uint64)
+        R = 1 << 64
+        for i in range(level + 1):
+            qi = params.Q[i]
+            sReal = scaleUpExact(cReal, scale, qi) if cReal != 0 else 0
+            sConst, sImag = sReal, 0
+            if cImag != 0:
+                # MRed(scaleUpExact(cImag), NttPsi[i][1]): NttPsi[i][1] = psi^(N/2) * R, so the product is plain
+                sImag = (scaleUpExact(cImag, scale, qi) * pow(params.Psi(i), params.N() // 2, qi)) % qi
+                sConst = (sConst + sImag) % qi if sConst + sImag >= qi else sConst + sImag            # CRed
+            first[i] = (sConst % qi) * R % qi                                                       # MForm
+            c2 = sConst
+            if cImag != 0:
+                c2 = sReal + (qi - sImag)
+                c2 = c2 - qi if c2 >= qi else c2                                                     # CRed
+            second[i] = (c2 % qi) * R % qi
+        check(lib().mkhe_ct_mul_const(params.ctx, ct0.h, first.ctypes.data_as(_abi.u64p), second.ctypes.data_as(_abi.u64p), ctOut.h))
+        ctOut.Scale = ct0.Scale * scale
+
+    # ---- DropLevelNew (evaluator.go:96-114): keep the first level+1-levels limbs of every component
+    def DropLevelNew(self, ct0, levels):
+        out = NewCiphertext(self.params, ct0.IDSet(), ct0.Level() - levels, ct0.Scale)
+        one = np.array([(1 << 64) % q for q in self.params.Q[: out.Level() + 1]], dtype=np.uint64)      # MForm(1): x * 1
+        check(lib().mkhe_ct_mul_const(self.params.ctx, ct0.h, one.ctypes.data_as(_abi.u64p), one.ctypes.data_as(_abi.u64p), out.h))
+        return out
+
+    # ---- MulPtxtNew (evaluator.go:465-481); pt: host polynomial uint64[level+1][N] (coefficient domain) + its scale
+    def MulPtxtNew(self, ct, pt_value, pt_scale):
+        params = self.params
+        level = ct.Level()
+        ctOut = NewCiphertext(params, ct.IDSet(), level, ct.Scale * float(pt_scale))
+        pt = mkrlwe.DeviceLimbs(params, 1, level + 1).upload(np.ascontiguousarray(pt_value, dtype=np.uint64)[None, : level + 1])
+        check(lib().mkhe_ct_mul_ptxt(params.ctx, ct.h, pt.devptr(), ctOut.h))
+        if ctOut.Level() == 0:                 # eval.Rescale returns an error there; MulPtxtNew ignores it (:480)
+            return ctOut
+        nb, scale = self.nbRescales(ctOut, params.Scale())
+        if nb == 0:
+            return ctOut
+        res = NewCiphertext(params, ctOut.IDSet(), level - nb, scale)
+        check(lib().mkhe_rescale(params.ctx, ctOut.h, nb, res.h))
+        return res
 
     # ---- Rescale (evaluator.go:359-398)
     def nbRescales(self, ctIn, minScale):

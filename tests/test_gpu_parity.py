@@ -281,3 +281,56 @@ def test_ckks_add_sub(pair):
     c2 = mkckks.NewCiphertext(params, ["a"], pair.maxlevel, 2.0 ** 45)
     with pytest.raises(pair.mk.MkheError, match="scales differ"):
         ev.AddNew(c0, c2)
+
+
+@pytest.mark.parametrize("constant", [3, -2.5, 0.75 + 1.25j, -4 + 0j])
+def test_ckks_mult_by_const(pair, constant):
+    """mkckks.Evaluator.MultByConst (evaluator.go:117-199): integer, fractional, complex constants"""
+    from mkhe_kklss_amd import mkckks
+    params = pair.params
+    ev = mkckks.Evaluator.__new__(mkckks.Evaluator)
+    ev.params, ev.ksw = params, pair.ksw
+    L = pair.maxlevel + 1
+    h = H.uniform_ct(pair.rng, pair.ks, 2, L)
+    c0 = mkckks.NewCiphertext(params, ["a", "b"], pair.maxlevel, 2.0 ** 40).upload(h)
+    out = mkckks.NewCiphertext(params, ["a", "b"], pair.maxlevel, 1.0)
+    ev.MultByConst(c0, constant, out)
+    got = out.download()
+    cre, cim = (constant.real, constant.imag) if isinstance(constant, complex) else (float(constant), 0.0)
+    frac = any(c != 0 and c != int(c) for c in (cre, cim))
+    scale = float(pair.Q[pair.maxlevel]) if frac else 1.0
+    assert out.Scale == 2.0 ** 40 * scale
+    N = pair.N
+    for l, q in enumerate(pair.Q):
+        sre = mkckks.scaleUpExact(cre, scale, q) if cre != 0 else 0
+        sim = (mkckks.scaleUpExact(cim, scale, q) * pow(pair.ks.ringQ.psi(l), N // 2, q)) % q if cim != 0 else 0
+        c1, c2 = (sre + sim) % q, (sre - sim) % q
+        for s in range(3):
+            x = [int(v) for v in h[s][l]]
+            assert [int(v) for v in got[s][l][: N // 2]] == [(v * c1) % q for v in x[: N // 2]]
+            assert [int(v) for v in got[s][l][N // 2:]] == [(v * c2) % q for v in x[N // 2:]]
+
+
+def test_ckks_mul_ptxt_and_drop_level(pair):
+    """MulPtxtNew (evaluator.go:465-481, product in the NTT domain + Rescale) and DropLevelNew (:96-114)"""
+    from mkhe_kklss_amd import mkckks
+    if pair.maxlevel < 1:
+        pytest.skip("single limb")
+    params, ks = pair.params, pair.ks
+    ev = mkckks.Evaluator.__new__(mkckks.Evaluator)
+    ev.params, ev.ksw = params, pair.ksw
+    scale = float(pair.Q[pair.maxlevel])
+    params.Scale = lambda: scale          # Pair holds mkrlwe.Parameters; mkckks.Parameters adds the default scale
+    L = pair.maxlevel + 1
+    h = H.uniform_ct(pair.rng, ks, 1, L)
+    pt = H.uniform_poly(pair.rng, pair.Q, pair.N)
+    ct = mkckks.NewCiphertext(params, ["a"], pair.maxlevel, scale).upload(h)
+    res = ev.MulPtxtNew(ct, pt, scale)
+    rq = ks.ringQ
+    prod = np.stack([np.stack([rq.intt(l, rq.mul(l, rq.ntt(l, h[s][l]), rq.mform(l, rq.ntt(l, pt[l])))) for l in range(L)]) for s in range(2)])
+    nb, sc = ks.ckks_nb_rescales(pair.maxlevel, scale * scale, scale)
+    assert nb >= 1 and res.Level() == pair.maxlevel - nb and res.Scale == sc
+    ref = np.stack([rq.div_round_last_many(prod[s], nb)[0] for s in range(2)])
+    assert (res.download() == ref).all()
+    d = ev.DropLevelNew(ct, 1)
+    assert d.Level() == pair.maxlevel - 1 and (d.download() == h[:, : L - 1]).all()

@@ -27,6 +27,11 @@ __global__ void __launch_bounds__(256) k(uint64_t* out, unsigned long long* clk)
         if (OP == 9) { REP8(asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(d0));) }
         if (OP == 10) { REP8(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_add_u32 %6, %6, %4\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_add_u32 %7, %7, %5\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_add_u32 %6, %6, %5\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n v_add_u32 %7, %7, %4" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b), "v"(e0), "v"(e1) : "vcc");) }
         if (OP == 11) { REP8(asm volatile("v_sub_co_u32 %0, vcc, %0, %4\n v_subb_co_u32 %1, vcc, %1, %5, vcc\n v_cndmask_b32 %2, %2, %0, vcc\n v_cndmask_b32 %3, %3, %1, vcc" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(a), "v"(b) : "vcc");) }
+        if (OP == 13) { REP8(asm volatile("v_mad_i64_i32 %0, vcc, %4, %5, %0\n v_mad_i64_i32 %1, vcc, %4, %5, %1\n v_mad_i64_i32 %2, vcc, %4, %5, %2\n v_mad_i64_i32 %3, vcc, %4, %5, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b) : "vcc");) }
+        if (OP == 14) { REP8(asm volatile("v_ashrrev_i64 %0, 32, %0\n v_ashrrev_i64 %1, 32, %1\n v_ashrrev_i64 %2, 32, %2\n v_ashrrev_i64 %3, 32, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));) }
+        if (OP == 15) { REP8(asm volatile("v_ashrrev_i32 %0, 31, %0\n v_ashrrev_i32 %1, 31, %1\n v_ashrrev_i32 %2, 31, %2\n v_ashrrev_i32 %3, 31, %3" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));) }
+        if (OP == 16) { REP8(asm volatile("v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %5\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %5" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(a), "v"(b));) }
+        if (OP == 17) { REP8(asm volatile("v_add3_u32 %0, %0, %4, %5\n v_add3_u32 %1, %1, %5, %4\n v_add3_u32 %2, %2, %4, %5\n v_add3_u32 %3, %3, %5, %4" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(a), "v"(b));) }
         if (OP == 12) { REP8(asm volatile("v_lshrrev_b64 %0, 32, %0\n v_lshrrev_b64 %1, 32, %1\n v_lshrrev_b64 %2, 32, %2\n v_lshrrev_b64 %3, 32, %3" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));) }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -54,6 +59,7 @@ template <int OP> int run(const char* name) {
 int main() {
     run<6>("v_add_u32"); run<8>("v_fma_f32"); run<9>("v_pk_fma_f32"); run<2>("v_mov_b32"); run<3>("v_add_co/v_addc_co pair");
     run<11>("v_sub_co,v_subb,2x cndmask"); run<4>("v_cmp_ge_u64 + v_cndmask"); run<1>("v_lshl_add_u64"); run<12>("v_lshrrev_b64");
+    run<13>("v_mad_i64_i32"); run<14>("v_ashrrev_i64 (by 32)"); run<15>("v_ashrrev_i32"); run<16>("v_xor_b32"); run<17>("v_add3_u32");
     run<0>("v_mad_u64_u32"); run<5>("v_mul_lo_u32"); run<7>("v_mul_hi_u32"); run<10>("v_mad_u64_u32 + v_add_u32 interleaved");
     return 0;
 }
