@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmkhe_hip.so")
+LIB_PATH = os.environ.get("MKHE_LIB") or os.path.join(_HERE, "lib", "libmkhe_hip.so")      # MKHE_LIB: diagnostic builds
 
 u64p = C.POINTER(C.c_uint64)
 i32p = C.POINTER(C.c_int)

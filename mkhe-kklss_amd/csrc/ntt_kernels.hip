@@ -247,12 +247,18 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     if constexpr (G::LPB == 1) job = __builtin_amdgcn_readfirstlane(job);    // provably wave-uniform: modulus constants and pointers stay in SGPRs
     // diagnostic timeline (mkhe_ntt_trace): 16 words per (job, wave): shader-clock stamps 0..9 at the phase
     // boundaries, [12] / [13] = 100 MHz real time at start / end, [14] = HW_ID
+    // Only in the diagnostic build (make trace -> lib/libmkhe_hip_trace.so, -DMKHE_PHASE_TRACE): the stamps keep the
+    // job index and the trace pointer live across the whole body and double the spills of the 128-VGPR kernels.
+#ifdef MKHE_PHASE_TRACE
 #define MKHE_STAMP(k) do { if (b.trace && (threadIdx.x & 63) == 0 && active) b.trace[((long)job * 16 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     if (b.trace && (threadIdx.x & 63) == 0 && active) {
         u64* tw = b.trace + ((long)job * 16 + (threadIdx.x >> 6)) * 16;
         tw[12] = __builtin_amdgcn_s_memrealtime();
         tw[14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
     }
+#else
+#define MKHE_STAMP(k) do { } while (0)
+#endif
     MKHE_STAMP(0);
     gcptr src; gptr dst; int m, outer;
     const int half = b.split ? (job & 1) : 0;
@@ -267,7 +273,9 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     u64 x[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = src[posA<LOGN>(t, r)];
+#ifdef MKHE_PHASE_TRACE
     if (b.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MKHE_STAMP(1); }      // loads landed
+#endif
     if constexpr (DEC) {
         // digit of a foreign modulus (Decompose, alpha = 1): bring it below 4q when needed
         int sm = m;
@@ -311,7 +319,9 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
         for (int r = 0; r < 32; ++r) dst[posB(t, r)] = x[r];
     }
     MKHE_STAMP(9);                               // stores issued
+#ifdef MKHE_PHASE_TRACE
     if (b.trace && (threadIdx.x & 63) == 0 && active) b.trace[((long)job * 16 + (threadIdx.x >> 6)) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 }
 

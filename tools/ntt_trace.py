@@ -1,6 +1,8 @@
 """Diagnostic: per-wave phase timeline of the forward NTT kernel (mkhe_ntt_trace): where do a limb's cycles go?
 
-    python tools/ntt_trace.py [polys]          (13 small primes of PN15QP880 -> one kernel class, polys*13 limbs)
+    make -C mkhe-kklss_amd/csrc trace
+    MKHE_LIB=$PWD/mkhe-kklss_amd/lib/libmkhe_hip_trace.so python tools/ntt_trace.py [polys]
+(13 small primes of PN15QP880 -> one kernel class, polys*13 limbs; the stamps are compiled in only in the trace build)
 """
 import sys, os
 import numpy as np
