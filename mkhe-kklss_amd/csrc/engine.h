@@ -66,7 +66,7 @@ class Context {
     void bfv_modup_q_to_r(const u64* polyq, u64* polyr, int npolys);          // conv.ModUpQtoR
     void bfv_rescale(const u64* polyq, u64* polyr, int npolys);               // conv.Rescale
     void bfv_quantize(const u64* polyr_ntt, u64* polyq, int npolys);          // conv.Quantize (polyr_ntt is consumed)
-    void bfv_decompose_batch(const std::vector<const u64*>& srcr, const std::vector<u64*>& ad1, const std::vector<u64*>& ad2);
+    void bfv_decompose_batch(const std::vector<const u64*>& srcr, const std::vector<u64*>& ad1, const std::vector<u64*>& ad2, bool internal = false);
     void bfv_external_product_hoisted(const u64* ah1, const u64* ah2, const u64* bg1, const u64* bg2, u64* c);
     void bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
                        const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
@@ -89,7 +89,9 @@ class Context {
     u64* pool_x() { return x_; }
     u64* pool_y() { return y_; }
     // batched building blocks (all parties in one launch)
-    void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst);
+    // internal = true: the digits stay inside the engine (hoist pools): their forward NTT skips the final
+    // normalisation (values < 34q with the same residues; every consumer is a Montgomery product)
+    void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst, bool internal = false);
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1);
 
     bool overlap = true;               // false: everything on the main stream (clean per-kernel timings)

@@ -422,7 +422,7 @@ void Context::external_product(int level, bool is_ntt, const u64* a, const u64* 
 }
 
 // ------------------------------------------------------------------ batched forms (one launch for all parties)
-void Context::decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst) {
+void Context::decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst, bool internal) {
     check_level(level);
     const int nb = beta(level);
     if (alpha != 1) {
@@ -457,7 +457,7 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
         b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);
         b.src_outer = N; b.src_inner = 0; b.src_mapped = 0;
         b.dst_outer = (long)mtot * N; b.dst_inner = N; b.dst_mapped = 1;
-        b.reduce_in = 1; b.reduce_src_mod_is_outer = 1;
+        b.reduce_in = 1; b.reduce_src_mod_is_outer = 1; b.skip_norm = internal ? 1 : 0;
         b.nitems = n; b.outers_per_item = nb;
         for (int i = 0; i < n; ++i) { b.src_items[i] = src[base + i]; b.dst_items[i] = dst[base + i]; }
         b.nouter = n * nb;
@@ -549,7 +549,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
         else if (same) p.h1[a] = p.h0[a];
         else { Swk& s = hoist_slot(1, a); dsrc.push_back(op1.d + (1 + a) * P1); ddst.push_back(s.d); p.h1[a] = s.d; }
     }
-    if (!dsrc.empty()) decompose_batch(p.level, dsrc, ddst);
+    if (!dsrc.empty()) decompose_batch(p.level, dsrc, ddst, true);
     // D: tensor product in the NTT domain, back to coefficients -- started here on the side stream: it only
     // needs the operands and the engine's own hoisted digits, runs beside the x / y accumulation and meets
     // the main chain again at the first ModDown of mr_finish.
@@ -638,7 +638,7 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
-        if (n0) decompose_batch(level, dsrc, ddst);
+        if (n0) decompose_batch(level, dsrc, ddst, true);
     }
     items.clear();
     for (int a = 0; a < n0; ++a) {
@@ -691,7 +691,7 @@ void Context::rotate_partial(const Ct& in, const Swk* const* hoist, const Swk* c
             if (hoist) { if (!hoist[a]) throw Error("mkhe: missing hoisted form"); h[a] = hoist[a]->d; }
             else { Swk& s = hoist_slot(0, a); dsrc.push_back(in.d + (1 + a) * PI); ddst.push_back(s.d); h[a] = s.d; }
         }
-        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst);
+        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst, true);
     }
     std::vector<ExtItem> items;
     for (int a = 0; a < n; ++a) {
@@ -889,7 +889,7 @@ void Context::bfv_quantize(const u64* polyr_ntt, u64* polyq, int npolys) {
 // DecomposeBFV (mkbfv/keyswitch.go:67-90), alpha = 1: digit d = limb d of aR spread under Q and P and NTT'd
 // (DecomposeSingleNTT); Q digits -> ad1, QMul digits -> ad2.  The QMul limbs of ModUpQtoR outputs and the Q limbs
 // of Rescale outputs are lazy (< 3x their modulus): src_lazy.
-void Context::bfv_decompose_batch(const std::vector<const u64*>& srcr, const std::vector<u64*>& ad1, const std::vector<u64*>& ad2) {
+void Context::bfv_decompose_batch(const std::vector<const u64*>& srcr, const std::vector<u64*>& ad1, const std::vector<u64*>& ad2, bool internal) {
     if (!is_bfv()) throw Error("mkhe: not a BFV context");
     const int level = nq - 1;
     for (int half = 0; half < 2; ++half) {
@@ -899,7 +899,7 @@ void Context::bfv_decompose_batch(const std::vector<const u64*>& srcr, const std
             b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);
             b.src_outer = N; b.src_inner = 0; b.src_mapped = 0;
             b.dst_outer = (long)mtot * N; b.dst_inner = N; b.dst_mapped = 1;
-            b.reduce_in = 1; b.reduce_src_mod_is_outer = 2; b.src_lazy = 1;
+            b.reduce_in = 1; b.reduce_src_mod_is_outer = 2; b.src_lazy = 1; b.skip_norm = internal ? 1 : 0;
             for (int d = 0; d < nq; ++d) b.outer_mod[d] = half ? mtot + d : d;
             b.nitems = n; b.outers_per_item = nq;
             for (int i = 0; i < n; ++i) {
@@ -979,7 +979,7 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
             Swk& s1 = hoist_slot(1, a); Swk& s2 = hoist_slot(4, a);
             src.push_back(r1 + (size_t)(1 + a) * PR); d1.push_back(s1.d); d2.push_back(s2.d); h1a[a] = s1.d; h1b[a] = s2.d;
         }
-        if (!src.empty()) bfv_decompose_batch(src, d1, d2);
+        if (!src.empty()) bfv_decompose_batch(src, d1, d2, true);
     }
     // x1, x2, y1, y2 (keyswitch_hoisted.go:76-126)
     const int nslots = L + np;
@@ -1007,7 +1007,7 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PQ); ddst.push_back(hoist_slot(2, a).d); }
-        if (n0) decompose_batch(level, dsrc, ddst);
+        if (n0) decompose_batch(level, dsrc, ddst, true);
     }
     items.clear();
     for (int a = 0; a < n0; ++a) {

@@ -48,6 +48,8 @@ struct NttBatch {
     int reduce_src_mod_is_outer;   // the digit's own modulus index: 1 = outer (alpha = 1), 2 = outer_mod[outer] (BFV digits of R)
     int src_lazy;           // digit values are lazy base-conversion outputs (< 4 * own modulus) rather than canonical
     int lazy_out;           // inverse only: leave [0,2q) (InvNTTLazy)
+    int skip_norm;          // forward, moduli with 34q < 2^63 only: leave the un-normalised values (< 34q, same residues) --
+                            // for engine-internal outputs whose only consumers are Montgomery products (hoisted digits)
     int split;              // N = 2^16: the register-resident kernels transform the two halves of a limb as 2^15-point
                             // sub-transforms (twiddle rows of 2^16 words, root index 2 + half); the cross-half radix-2 stage
                             // runs as a separate streaming pass (launch_ntt_* do both)

@@ -14,6 +14,9 @@
 #ifndef MKHE_SB_MASK
 #define MKHE_SB_MASK 1
 #endif
+#ifndef MKHE_TW_CHUNK
+#define MKHE_TW_CHUNK 4
+#endif
 
 namespace mkhe {
 
@@ -66,6 +69,9 @@ template <bool CROSS> __device__ __forceinline__ void lds_sync() {
 // one 32-bit plane at a time (about N*4 bytes of LDS per limb).
 template <int LOGN, int FROM, int TO, bool CROSS>
 __device__ __forceinline__ void exchange(u64 (&x)[32], u32* lds, int t) {
+#ifdef MKHE_X_NOXCHG
+    return;      // timing experiment only (wrong results): cost of the LDS re-distribution
+#endif
     // the thread index is made opaque here so that the (loop-invariant) LDS base addresses are recomputed
     // next to their use instead of being hoisted out of the persistent loop and spilled (VGPR budget 128)
     asm volatile("" : "+v"(t));
@@ -148,7 +154,7 @@ __device__ __forceinline__ void stage(u64 (&x)[32], gcptr tw, u64 q, u64 q2, u32
 #ifdef MKHE_NO_CHUNK
     constexpr int CH = NW;
 #else
-    constexpr int CH = NW < 4 ? NW : 4;         // twiddles held at a time (one chunk in use + one in flight:
+    constexpr int CH = NW < MKHE_TW_CHUNK ? NW : MKHE_TW_CHUNK;         // twiddles held at a time (one chunk in use + one in flight:
 #endif
     constexpr int NCH = NW / CH;                //  <= 16 VGPRs instead of 32 at B = 0; the budget is 128)
     constexpr int BPC = 16 / NCH;               // butterflies per chunk
@@ -304,8 +310,10 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     }
     // canonical output (lattigo: final BRedAdd)
     if constexpr (MODE == 1) {
+        if (!b.skip_norm) {
 #pragma unroll
-        for (int r = 0; r < 32; ++r) x[r] = mont_mul(x[r], md.r1, q, ninv);      // < 34q -> [0,q)
+            for (int r = 0; r < 32; ++r) x[r] = mont_mul(x[r], md.r1, q, ninv);      // < 34q -> [0,q)
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < 32; ++r) x[r] = csub(csub(x[r], q2), q);
