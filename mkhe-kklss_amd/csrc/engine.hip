@@ -103,6 +103,7 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
         Mod& m = mods[i];
         m.q = q; m.q2 = 2 * q; m.qinv = inv64(q); m.ninv32 = (u32)(0 - m.qinv); m.pad = 0;
         m.r1 = to_mont(1, q); m.r2 = mulmod(m.r1, m.r1, q);
+        m.qs = sd_split(q); m.r1s = sd_split(m.r1);
         u64 ps = (i < nq) ? (psiQ ? psiQ[i] : 0) : (i < mtot ? (psiP ? psiP[i - nq] : 0) : 0);
         if (!ps) ps = default_psi(q, N);
         if (powmod(ps, N, q) != q - 1) throw Error("mkhe: supplied psi is not a primitive 2N-th root");
@@ -125,6 +126,10 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
             }
         }
     }
+    // the NTT kernels take twiddles and the inverse-NTT constants in signed-split form (mont_mul_sd)
+    for (auto& v : psi) v = sd_split(v);
+    for (auto& v : psiinv) v = sd_split(v);
+    for (auto& v : aux) v = sd_split(v);
     d_mods = dev_upload(mods); d_psi = dev_upload(psi); d_psiinv = dev_upload(psiinv); d_inv_aux = dev_upload(aux);
 
     std::vector<int> map((size_t)nq * mtot, 0), ident(mtot);

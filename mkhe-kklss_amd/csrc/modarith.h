@@ -19,6 +19,8 @@ namespace mkhe {
 
 typedef uint64_t u64;
 typedef uint32_t u32;
+typedef int64_t i64;
+typedef int32_t i32;
 
 // Per-modulus constants, uniform per workgroup (live in SGPRs).
 struct Mod {
@@ -29,7 +31,14 @@ struct Mod {
     u64 qinv;     // q^-1 mod 2^64   (lattigo MRedParams; used by the literal mult_sum)
     u64 r1;       // 2^64  mod q     (MForm(1))
     u64 r2;       // 2^128 mod q     (mont_mul(a, r2) = MForm(a))
+    u64 qs;       // q  in signed-split form (sd_split), for mont_mul_sd
+    u64 r1s;      // r1 in signed-split form
 };
+
+// Signed-split form of a 64-bit constant v: the pair (hi, lo) with v = (i32)hi * 2^32 + (i32)lo, i.e. the high word
+// absorbs the carry of reading the low word as signed.  Twiddle tables and per-modulus constants of the NTT kernels
+// are stored like this (host side: Context constructor).
+__host__ __device__ inline u64 sd_split(u64 v) { return v + ((u64)((u32)v >> 31) << 32); }
 
 __device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
 __device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
@@ -59,6 +68,36 @@ __device__ __forceinline__ u64 mont_mul_lazy(u64 a, u64 w, u64 q, u32 ninv32) {
     const u32 m2 = lo32(s0) * ninv32;
     const u64 r2 = mad64(lo32(s0), one_a, mad64(m2, q0, 0));
     return mad64(hi32(r2), one_b, mad64(hi32(s0), one_c, mad64(m2, q1, mad64(a1, w1, 0))));
+}
+
+// Signed word-serial Montgomery product for the NTT kernels: a*w*R^-1 mod q as a SIGNED representative r with
+// |r| <= q/2 + |a|*w/2^64 + 1.  a: any signed 64-bit value with |a| < 2^62; ws, qs: signed-split forms of w < q < 2^61.
+// With balanced 32-bit digits every partial sum fits a signed 64-bit accumulator, so each round is
+//   P = a_i*w0 [+ carry-in]; m = lo(P)*(-q^-1); S = m*q0 + P (low word 0); next = m*q1 + a_i*w1 + (S >> 32)
+// = 4 v_mad_i64_i32 + 1 v_mul_lo_u32 + 1 v_ashrrev_i64 and nothing else (no widening moves, no carry chains): 12
+// multiplier-class instructions + 2 plain ones for the digit split of a, against 16 for mont_mul_lazy.
+__device__ __forceinline__ i64 mont_mul_sd(i64 a, u64 ws, u64 qs, u32 ninv32) {
+    const i32 a0 = (i32)lo32((u64)a);
+    const i32 a1 = (i32)(hi32((u64)a) + (lo32((u64)a) >> 31));
+    i32 w0 = (i32)lo32(ws), q0 = (i32)lo32(qs), w1 = (i32)hi32(ws), q1 = (i32)hi32(qs);
+    // opaque 32-bit values: seen as the sign-extended halves of a wave-uniform 64-bit constant, the compiler
+    // multiplies by them as 64-bit values (4 instructions instead of one v_mad_i64_i32)
+    asm("" : "+v"(w0), "+v"(w1), "+v"(q0), "+v"(q1));
+    // the shift amount is opaque: knowing that S >> 32 is a sign-extended 32-bit value, the compiler splits the
+    // 64-bit multiply-adds that consume it into 32-bit pieces (3x the instructions)
+    u32 sh; asm("s_mov_b32 %0, 32" : "=s"(sh));
+    const i64 P0 = (i64)a0 * w0;
+    const i32 m = (i32)(lo32((u64)P0) * ninv32);
+    const i64 S = (i64)m * q0 + P0;                      // |S| < 2^63 (q0 is odd, so |q0| < 2^31); low word is zero
+    const i64 Y = (i64)m * q1 + ((i64)a0 * w1 + (S >> sh));
+    const i64 U = (i64)a1 * w0 + Y;
+    const i32 m2 = (i32)(lo32((u64)U) * ninv32);
+    const i64 S2 = (i64)m2 * q0 + U;
+    return (i64)m2 * q1 + ((i64)a1 * w1 + (S2 >> sh));
+}
+// the same as an unsigned lazy representative in [0, 2q) (needs |a|*w < q*2^63, e.g. 0 <= a < 4q, q < 2^60)
+__device__ __forceinline__ u64 mont_mul_sdu(u64 a, u64 ws, u64 qs, u64 q, u32 ninv32) {
+    return (u64)(mont_mul_sd((i64)a, ws, qs, ninv32) + (i64)q);
 }
 
 __device__ __forceinline__ u64 csub(u64 a, u64 q) { return a >= q ? a - q : a; }

@@ -124,32 +124,33 @@ __device__ __forceinline__ void exchange_xor(u64 (&x)[32], u32* lds, int t) {
 }
 
 // ------------------------------------------------------------------ butterflies
+// Twiddles (ws) and the modulus (qs) are in signed-split form, see mont_mul_sd.
 // Forward, reduced every stage (Harvey): U,V in [0,4q) -> [0,4q).
-__device__ __forceinline__ void bfly_fwd_cs(u64& U, u64& V, u64 w, u64 q, u64 q2, u32 ninv) {
-    u64 Tm = mont_mul_lazy(V, w, q, ninv);
+__device__ __forceinline__ void bfly_fwd_cs(u64& U, u64& V, u64 ws, u64 q, u64 q2, u64 qs, u32 ninv) {
+    u64 Tm = mont_mul_sdu(V, ws, qs, q, ninv);
     u64 u = csub(U, q2);
     U = u + Tm;
     V = u + (q2 - Tm);
 }
-// Forward, never reduced: values grow by at most 2q per stage (needs 34q < 2^63).
-__device__ __forceinline__ void bfly_fwd_nr(u64& U, u64& V, u64 w, u64 q, u64 q2, u32 ninv) {
-    u64 Tm = mont_mul_lazy(V, w, q, ninv);
-    u64 u = U;
-    U = u + Tm;
-    V = u + (q2 - Tm);
+// Forward, never reduced, SIGNED values: |x| grows by less than q per stage (34q < 2^63 class): one add, one sub.
+__device__ __forceinline__ void bfly_fwd_nr(u64& U, u64& V, u64 ws, u64 qs, u32 ninv) {
+    const i64 Tm = mont_mul_sd((i64)V, ws, qs, ninv);
+    const i64 u = (i64)U;
+    U = (u64)(u + Tm);
+    V = (u64)(u - Tm);
 }
 // Inverse (Gentleman-Sande): U,V in [0,2q) -> [0,2q).
-__device__ __forceinline__ void bfly_inv(u64& U, u64& V, u64 w, u64 q, u64 q2, u32 ninv) {
+__device__ __forceinline__ void bfly_inv(u64& U, u64& V, u64 ws, u64 q, u64 q2, u64 qs, u32 ninv) {
     u64 s = csub(U + V, q2);
     u64 d = U + q2 - V;
     U = s;
-    V = mont_mul_lazy(d, w, q, ninv);
+    V = mont_mul_sdu(d, ws, qs, q, ninv);
 }
 
 // One radix-2 stage on register bit B; tw points at the run of (16 >> B) twiddles.
 // MODE: 0 forward reduced, 1 forward never-reduced, 2 inverse.
 template <int B, int MODE>
-__device__ __forceinline__ void stage(u64 (&x)[32], gcptr tw, u64 q, u64 q2, u32 ninv) {
+__device__ __forceinline__ void stage(u64 (&x)[32], gcptr tw, u64 q, u64 q2, u64 qs, u32 ninv) {
     constexpr int NW = 16 >> B;                 // twiddles of this stage
 #ifdef MKHE_NO_CHUNK
     constexpr int CH = NW;
@@ -173,9 +174,9 @@ __device__ __forceinline__ void stage(u64 (&x)[32], gcptr tw, u64 q, u64 q2, u32
             const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
             const int i1 = i0 | (1 << B);
             const u64 w = wc[(g >> B) - c * CH];
-            if constexpr (MODE == 2) bfly_inv(x[i0], x[i1], w, q, q2, ninv);
-            else if constexpr (MODE == 1) bfly_fwd_nr(x[i0], x[i1], w, q, q2, ninv);
-            else bfly_fwd_cs(x[i0], x[i1], w, q, q2, ninv);
+            if constexpr (MODE == 2) bfly_inv(x[i0], x[i1], w, q, q2, qs, ninv);
+            else if constexpr (MODE == 1) bfly_fwd_nr(x[i0], x[i1], w, qs, ninv);
+            else bfly_fwd_cs(x[i0], x[i1], w, q, q2, qs, ninv);
             // at 4 waves/SIMD the other waves hide the latency of one wave's dependency chain;
             // interleaving more than two butterflies only adds live temporaries
 #ifndef MKHE_NO_SCHEDBAR
@@ -194,19 +195,19 @@ __device__ __forceinline__ void stage(u64 (&x)[32], gcptr tw, u64 q, u64 q2, u32
 // the (up to) five stages of one phase; stage on register bit B uses
 // psi[(base >> B) + (prefix << (4 - B)) + k].  FWD: most significant bit first; INV: least first.
 template <int MODE>
-__device__ __forceinline__ void phase(u64 (&x)[32], gcptr psi, int base, int prefix, int maxB, u64 q, u64 q2, u32 ninv) {
+__device__ __forceinline__ void phase(u64 (&x)[32], gcptr psi, int base, int prefix, int maxB, u64 q, u64 q2, u64 qs, u32 ninv) {
     if constexpr (MODE != 2) {
-        if (maxB >= 4) stage<4, MODE>(x, psi + (base >> 4) + prefix, q, q2, ninv);
-        if (maxB >= 3) stage<3, MODE>(x, psi + (base >> 3) + (prefix << 1), q, q2, ninv);
-        if (maxB >= 2) stage<2, MODE>(x, psi + (base >> 2) + (prefix << 2), q, q2, ninv);
-        if (maxB >= 1) stage<1, MODE>(x, psi + (base >> 1) + (prefix << 3), q, q2, ninv);
-        if (maxB >= 0) stage<0, MODE>(x, psi + base + (prefix << 4), q, q2, ninv);
+        if (maxB >= 4) stage<4, MODE>(x, psi + (base >> 4) + prefix, q, q2, qs, ninv);
+        if (maxB >= 3) stage<3, MODE>(x, psi + (base >> 3) + (prefix << 1), q, q2, qs, ninv);
+        if (maxB >= 2) stage<2, MODE>(x, psi + (base >> 2) + (prefix << 2), q, q2, qs, ninv);
+        if (maxB >= 1) stage<1, MODE>(x, psi + (base >> 1) + (prefix << 3), q, q2, qs, ninv);
+        if (maxB >= 0) stage<0, MODE>(x, psi + base + (prefix << 4), q, q2, qs, ninv);
     } else {
-        if (maxB >= 0) stage<0, MODE>(x, psi + base + (prefix << 4), q, q2, ninv);
-        if (maxB >= 1) stage<1, MODE>(x, psi + (base >> 1) + (prefix << 3), q, q2, ninv);
-        if (maxB >= 2) stage<2, MODE>(x, psi + (base >> 2) + (prefix << 2), q, q2, ninv);
-        if (maxB >= 3) stage<3, MODE>(x, psi + (base >> 3) + (prefix << 1), q, q2, ninv);
-        if (maxB >= 4) stage<4, MODE>(x, psi + (base >> 4) + prefix, q, q2, ninv);
+        if (maxB >= 0) stage<0, MODE>(x, psi + base + (prefix << 4), q, q2, qs, ninv);
+        if (maxB >= 1) stage<1, MODE>(x, psi + (base >> 1) + (prefix << 3), q, q2, qs, ninv);
+        if (maxB >= 2) stage<2, MODE>(x, psi + (base >> 2) + (prefix << 2), q, q2, qs, ninv);
+        if (maxB >= 3) stage<3, MODE>(x, psi + (base >> 3) + (prefix << 1), q, q2, qs, ninv);
+        if (maxB >= 4) stage<4, MODE>(x, psi + (base >> 4) + prefix, q, q2, qs, ninv);
     }
 }
 
@@ -290,7 +291,10 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
         const u64 qs = b.mods[sm].q << (b.src_lazy ? 2 : 0);       // bound of the digit values (< 2^63)
         if (qs > 4 * q) {
 #pragma unroll
-            for (int r = 0; r < 32; ++r) x[r] = mont_mul_lazy(x[r], md.r1, q, ninv);
+            for (int r = 0; r < 32; ++r) {
+                if constexpr (MODE == 1) x[r] = (u64)mont_mul_sd((i64)x[r], md.r1s, md.qs, ninv);     // signed, |.| < q
+                else x[r] = mont_mul_sdu(x[r], md.r1s, md.qs, q, ninv);                                // [0,2q)
+            }
         }
     }
 #pragma unroll 1
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
         int base = 16, prefix = 0, maxB = 4;
         if (ph == 1) { base = G::N >> 6; prefix = t >> 5; maxB = G::MIDB; }
         if (ph == 2) { base = G::N >> 1; prefix = t; }
-        phase<MODE>(x, psi, base * root, prefix, maxB, q, q2, ninv);
+        phase<MODE>(x, psi, base * root, prefix, maxB, q, q2, md.qs, ninv);
         MKHE_STAMP(2 + 2 * ph);                  // 2, 4, 6: end of the butterflies of phase ph
         if (ph == 0) {
             if constexpr (G::HAS_MID) {
@@ -310,9 +314,17 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     }
     // canonical output (lattigo: final BRedAdd)
     if constexpr (MODE == 1) {
+        // MODE 1 values are signed with |x| < 4q + 15 * 0.65q < 14q
         if (!b.skip_norm) {
 #pragma unroll
-            for (int r = 0; r < 32; ++r) x[r] = mont_mul(x[r], md.r1, q, ninv);      // < 34q -> [0,q)
+            for (int r = 0; r < 32; ++r) {
+                const i64 y = mont_mul_sd((i64)x[r], md.r1s, md.qs, ninv);             // (-0.6q, 0.6q)
+                x[r] = (u64)(y + ((y >> 63) & (i64)q));                               // canonical
+            }
+        } else {
+            const i64 bias = (i64)(q << 4);                                            // same residue, positive: (2q, 30q)
+#pragma unroll
+            for (int r = 0; r < 32; ++r) x[r] = (u64)((i64)x[r] + bias);
         }
     } else {
 #pragma unroll
@@ -367,20 +379,20 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     for (int ph = 0; ph < 2; ++ph) {
         int base = G::N >> 1, prefix = t, maxB = 4;
         if (ph == 1) { base = G::N >> 6; prefix = t >> 5; maxB = G::MIDB; }
-        phase<2>(x, psi, base * root, prefix, maxB, q, q2, ninv);
+        phase<2>(x, psi, base * root, prefix, maxB, q, q2, md.qs, ninv);
         if (ph == 0) exchange_xor<LOGN, LC, LB, false>(x, lds, t);
         else { if constexpr (G::HAS_MID) exchange_xor<LOGN, LB, LA, true>(x, lds, t); }
     }
     // top phase: index bits n-5 .. n-2, then the last stage with N^-1 folded in
-    phase<2>(x, psi, 16 * root, 0, 3, q, q2, ninv);
+    phase<2>(x, psi, 16 * root, 0, 3, q, q2, md.qs, ninv);
     // {N^-1 * R, psiinv[root] * N^-1 * R}; split: the table has one pair per (modulus, half), N = 2^16
     const int ax = b.split ? 2 * (2 * m + half) : 2 * m;
     const u64 ninvR = b.aux[ax], w1n = b.aux[ax + 1];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         u64 U = x[g], V = x[g + 16];
-        u64 s = mont_mul_lazy(U + V, ninvR, q, ninv);
-        u64 d = mont_mul_lazy(U + q2 - V, w1n, q, ninv);
+        u64 s = mont_mul_sdu(U + V, ninvR, md.qs, q, ninv);          // aux constants are in signed-split form
+        u64 d = mont_mul_sdu(U + q2 - V, w1n, md.qs, q, ninv);
         x[g] = (b.lazy_out | b.split) ? s : csub(s, q);
         x[g + 16] = (b.lazy_out | b.split) ? d : csub(d, q);
     }
@@ -416,9 +428,9 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_split_fwd_kernel(NttBatch b
     }
     for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < H; j += gridDim.x * SPLIT_THREADS) {
         u64 U = src[j], V = src[j + H];
-        if (red) { U = mont_mul_lazy(U, md.r1, q, ninv); V = mont_mul_lazy(V, md.r1, q, ninv); }
+        if (red) { U = mont_mul_sdu(U, md.r1s, md.qs, q, ninv); V = mont_mul_sdu(V, md.r1s, md.qs, q, ninv); }
         else U = csub(U, q2);                                 // inputs < 4q
-        const u64 Tm = mont_mul_lazy(V, w, q, ninv);
+        const u64 Tm = mont_mul_sdu(V, w, md.qs, q, ninv);
         dst[j] = U + Tm;                                      // < 4q: what the sub-transforms accept
         dst[j + H] = U + (q2 - Tm);
     }
@@ -434,7 +446,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_split_inv_kernel(NttBatch b
     for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < H; j += gridDim.x * SPLIT_THREADS) {
         const u64 U = dst[j], V = dst[j + H];                 // [0,2q)
         u64 s = csub(U + V, q2);
-        u64 d = mont_mul_lazy(U + q2 - V, w, q, ninv);
+        u64 d = mont_mul_sdu(U + q2 - V, w, md.qs, q, ninv);
         if (!b.lazy_out) { s = csub(s, q); d = csub(d, q); }
         dst[j] = s;
         dst[j + H] = d;
