@@ -96,8 +96,8 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     s_ = stream;
 
     std::vector<Mod> mods(mall);
-    const bool split = logN == 16;        // inverse NTT constants per (modulus, half) -- see ntt_kernels.h NttBatch::split
-    std::vector<u64> psi((size_t)mall * N), psiinv((size_t)mall * N), aux((split ? 4 : 2) * (size_t)mall);
+    // inverse NTT constants, 6 words per modulus: whole transform, then the two sub-transforms of a split limb
+    std::vector<u64> psi((size_t)mall * N), psiinv((size_t)mall * N), aux(6 * (size_t)mall);
     for (int i = 0; i < mall; ++i) {
         const u64 q = moduli[i];
         Mod& m = mods[i];
@@ -116,14 +116,9 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
             a = mulmod(a, ps, q); b = mulmod(b, psinv, q);
         }
         const u64 ninv = powmod((u64)N, q - 2, q);
-        if (!split) {
-            aux[2 * i] = to_mont(ninv, q);
-            aux[2 * i + 1] = mulmod(psiinv[(size_t)i * N + 1], ninv, q);
-        } else {
-            for (int h = 0; h < 2; ++h) {
-                aux[2 * (2 * i + h)] = to_mont(ninv, q);
-                aux[2 * (2 * i + h) + 1] = mulmod(psiinv[(size_t)i * N + 2 + h], ninv, q);
-            }
+        for (int h = 0; h < 3; ++h) {
+            aux[6 * i + 2 * h] = to_mont(ninv, q);
+            aux[6 * i + 2 * h + 1] = mulmod(psiinv[(size_t)i * N + (h == 0 ? 1 : 1 + h)], ninv, q);
         }
     }
     // the NTT kernels take twiddles and the inverse-NTT constants in signed-split form (mont_mul_sd)

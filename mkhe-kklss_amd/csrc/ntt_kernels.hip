@@ -385,8 +385,9 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     }
     // top phase: index bits n-5 .. n-2, then the last stage with N^-1 folded in
     phase<2>(x, psi, 16 * root, 0, 3, q, q2, md.qs, ninv);
-    // {N^-1 * R, psiinv[root] * N^-1 * R}; split: the table has one pair per (modulus, half), N = 2^16
-    const int ax = b.split ? 2 * (2 * m + half) : 2 * m;
+    // aux: 6 words per modulus = {N^-1 * R, psiinv[1] * N^-1 * R} for the whole transform, then the same pair with
+    // psiinv[2 + half] for the two sub-transforms of a split limb (N = size of the whole limb in both cases)
+    const int ax = 6 * m + (b.split ? 2 + 2 * half : 0);
     const u64 ninvR = b.aux[ax], w1n = b.aux[ax + 1];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -517,15 +518,27 @@ int split_ntt_fwd(const NttBatch& b, const unsigned char* small_q, NttBatch out[
     }
     return n;
 }
+// A limb is one workgroup's work for 60-70 us whatever the batch size, so a launch with fewer limbs than CUs is latency
+// bound at half the chip idle.  Such launches (and every N = 2^16 launch) run split: cross-half radix-2 pass + two
+// half-size sub-transforms per limb (2 workgroups per CU fit), which nearly halves the latency of the small launches
+// on the critical path (tensor / ExternalProduct inverse NTTs).  MKHE_NTT_SPLIT=0 / 1 forces the choice (A/B tests).
+static bool use_split(int logN, const NttBatch& b) {
+    if (logN == 16) return true;
+    if (logN < 13) return false;
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("MKHE_NTT_SPLIT"); forced = (e && *e) ? atoi(e) : -1; }
+    if (forced >= 0) return forced != 0;
+    return b.nslots * b.nouter <= 160;
+}
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
     const bool small = b.lazy_out != 0;
-    if (logN == 16) {
+    if (use_split(logN, b)) {
         const dim3 grid(32, b.nslots * b.nouter);
         if (b.reduce_in) hipLaunchKernelGGL(ntt_split_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
         else hipLaunchKernelGGL(ntt_split_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
         const NttBatch c = in_place_of_dst(b);
-        if (small) launch_fwd_mode<1, false>(15, c, st); else launch_fwd_mode<0, false>(15, c, st);
+        if (small) launch_fwd_mode<1, false>(logN - 1, c, st); else launch_fwd_mode<0, false>(logN - 1, c, st);
         return;
     }
     if (b.reduce_in) { if (small) launch_fwd_mode<1, true>(logN, b, st); else launch_fwd_mode<0, true>(logN, b, st); }
@@ -533,10 +546,10 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
 }
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
-    if (logN == 16) {
+    if (!b.split && use_split(logN, b)) {
         NttBatch c = b;
         c.split = 1;
-        launch_inv_t<15>(c, st);                              // src halves -> dst halves, lazy, N^-1 folded in
+        launch_ntt_inv(logN - 1, c, st);                      // src halves -> dst halves, lazy, N^-1 folded in
         const NttBatch d = in_place_of_dst(b);                // only the dst addressing is used
         NttBatch e = d; e.lazy_out = b.lazy_out; e.psi = b.psi;
         hipLaunchKernelGGL(ntt_split_inv_kernel, dim3(32, b.nslots * b.nouter), dim3(SPLIT_THREADS), 0, st, e, logN);
