@@ -1,5 +1,6 @@
 // poly_kernels.hip -- see poly_kernels.h.
 #include "poly_kernels.h"
+#include <cstdlib>
 
 namespace mkhe {
 
@@ -30,7 +31,9 @@ __global__ void __launch_bounds__(PW_THREADS) inner_product_kernel(InnerProductA
 
 void launch_inner_product(const InnerProductArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("MKHE_IP_BX"); cap = (e && *e) ? atoi(e) : 128; }
+    if (bx > cap) bx = cap;
     hipLaunchKernelGGL(inner_product_kernel, dim3(bx, a.nslots, a.nouter), dim3(PW_THREADS), 0, st, a);
 }
 
@@ -117,7 +120,9 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
 }
 void launch_ext_inner(const ExtInnerArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 32) bx = 32;
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("MKHE_EXT_BX"); cap = (e && *e) ? atoi(e) : 64; }
+    if (bx > cap) bx = cap;
     hipLaunchKernelGGL(ext_inner_kernel, dim3(bx, a.nslots, a.nitems), dim3(PW_THREADS), 0, st, a);
 }
 

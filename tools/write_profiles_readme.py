@@ -71,15 +71,14 @@ the algorithmic figure because the fused digit spread re-reads each source limb 
 (A diagnostic build whose time stamps doubled the scratch size to ≈ 200 B tripled WRITE_SIZE and ran 20 % slower —
 the stamps are therefore compiled only into `make trace`.)
 
-Why the NTT sits at a quarter of the HBM roofline: `{tag}_sq_counters.txt` — `SQ_WAIT_INST_ANY` (0.32–0.38 of the wave
-cycles) is waves waiting for the vector ALU that another wave of the SIMD holds, `SQ_WAIT_ANY` (0.37–0.43) waves parked
-at barriers / waitcnt while the others compute; LDS (`SQ_ACTIVE_INST_LDS` 0.012–0.016, bank conflicts 0) and VMEM issue
+Why the NTT sits at a third of the HBM roofline and not higher: `{tag}_sq_counters.txt` — `SQ_WAIT_INST_ANY` (≈ 0.3–0.4 of
+the wave cycles) is waves waiting for the vector ALU that another wave of the SIMD holds, `SQ_WAIT_ANY` (≈ 0.4) waves
+parked at barriers / waitcnt while the others compute; LDS (`SQ_ACTIVE_INST_LDS` ≈ 0.015, bank conflicts 0) and VMEM issue
 are negligible.  `tools/ubench/valu_rate.hip` on the same chip: every 64-bit, carry or multiply instruction
-(`v_mad_u64_u32`, `v_mul_lo_u32`, `v_lshl_add_u64`, `v_add_co/v_addc`, `v_ashrrev_i64`, even `v_add3_u32`) issues at
-≈ 1.8 ns per wave and SIMD, only plain 32-bit VOP1/VOP2 ops at ≈ 1.05 ns; a 64-bit modular product needs ≥ 10 multiplier
-instructions, a butterfly ≈ 20 slow-class instructions ⇒ ≈ 38 ns per wave-butterfly ⇒ ≈ 44 µs per 2^15-point limb and CU
-if the ALUs never idled; measured 60–73 µs.  Rewriting the Montgomery product as a pure `v_mad_u64_u32` chain removed
-15–30 % of the VALU instructions at unchanged run time.
+(`v_mad_u64_u32`, `v_mad_i64_i32`, `v_mul_lo_u32`, `v_lshl_add_u64`, `v_add_co/v_addc`, `v_ashrrev_i64`, even
+`v_add3_u32`) issues at ≈ 1.8 ns per wave and SIMD, only plain 32-bit VOP1/VOP2 ops at ≈ 1.05 ns.  The butterfly went
+from ≈ 26 such instructions + 12 moves (first kernels, 306 µs per launch) to 15 + 2 with the signed-digit Montgomery
+product (233 µs): DESIGN.md §3 has the steps and what each bought.
 
 The memory-streaming kernels are where HBM is the bound: `ext_inner_kernel` {R["kernels"]["ext_inner_kernel"]["achieved_GBs"]:.0f} GB/s and
 `inner_product_kernel` {R["kernels"]["inner_product_kernel"]["achieved_GBs"]:.0f} GB/s of algorithmic bytes (PMC traffic {tr["kernels"]["ext_inner_kernel"]["hbm_bytes_per_launch"] / 1e6:.0f} MB and {tr["kernels"]["inner_product_kernel"]["hbm_bytes_per_launch"] / 1e6:.0f} MB per launch;
