@@ -347,7 +347,7 @@ class KeySwitcher:
         Returns (ids_out, out[1+nout][level+1][N])."""
         op0, op1, crs_u = _u64arr(op0), _u64arr(op1), _u64arr(crs_u)
         ids_out = sorted(set(ids0) | set(ids1))
-        npar = max(ids_out) + 1
+        npar = max(ids_out + [0]) + 1
         out = np.zeros((1 + len(ids_out), level + 1, self.N), dtype=np.uint64)
         a0, p0 = _i32(ids0)
         a1, p1 = _i32(ids1)

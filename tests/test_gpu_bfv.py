@@ -127,6 +127,8 @@ CASES = [
     (["a"], ["b"]),
     (["a", "b"], ["b", "c"]),
     (["a", "b", "c"], ["a", "b", "c"]),
+    ([], []),
+    ([], ["a"]),
 ]
 
 

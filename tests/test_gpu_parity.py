@@ -121,6 +121,11 @@ CASES = [
     (["a"], ["b"], 0, 0, True),
     (["a", "b", "c"], ["b"], 1, 1, False),
     (["a", "b"], ["a", "b"], 1, 0, True),
+    # degenerate id sets (a ciphertext may consist of c_0 only) and a larger party count
+    ([], [], 0, 0, False),
+    ([], ["a"], 0, 0, False),
+    (["a"], [], 0, 0, True),
+    (["p%d" % i for i in range(7)], ["p%d" % i for i in range(3, 9)], 0, 0, False),
 ]
 
 
