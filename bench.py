@@ -225,7 +225,7 @@ def main():
     ap.add_argument("--params", default="PN15QP880", choices=["PN15QP880", "PN14QP439"])
     ap.add_argument("--seed", type=int, default=0x4D4B4845)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--cpu-reps", type=int, default=4)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even at world size 1 (testing)")
     ap.add_argument("--scheme", default="ckks", choices=["ckks", "bfv"],
                     help="ckks = BASELINE.json headline metric (default); bfv = the mkbfv MulRelin line (single GPU)")
