@@ -82,7 +82,9 @@ class Context {
     // MulAndRelin split in phases (party-sharded multi-GPU evaluation: the x / y partial sums and out_0
     // are reduced across devices between the phases)
     void mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, bool with_c0, Ct& out);
-    void mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform);
+    // defer_x: x is accumulated on the side stream and joined by mr_finish just before its first use (step E), so that it
+    // overlaps the latency-bound part of step F; false (split-phase ABI): x and y are both complete on the main stream
+    void mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x = false);
     void mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
                    const Swk& crs_u, Ct& out);
     void fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform);
@@ -152,6 +154,7 @@ class Context {
         std::vector<int> slot0, slot1;
         std::vector<const u64*> h0, h1;
         bool own0 = false, own1 = false;     // hoisted digits computed by the engine itself
+        bool x_pending = false;              // x still running on the side stream (chain 2)
     } plan_;
 
     std::vector<std::pair<size_t, u64*>> free_list_;

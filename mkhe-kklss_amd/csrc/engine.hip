@@ -513,7 +513,7 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
                             const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                             const Swk& crs_u, Ct& out) {
     mr_prepare(op0, op1, hoist0, hoist1, true, out);
-    mr_xy(rlk_b1, rlk_d0, x_, y_, true);
+    mr_xy(rlk_b1, rlk_d0, x_, y_, true, true);
     mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
 }
 
@@ -600,11 +600,12 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
 
 // -- steps B, C: x = [MForm] sum_i d_i (.) h(c0_i),  y = [MForm] sum_j b_j (.) h(c1_j)   (keyswitch_hoisted.go:79-117)
 // mform = false leaves the canonical partial sums for a cross-device reduction (party sharding).
-void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform) {
+void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x) {
     MrPlan& p = plan_;
     if (!p.valid) throw Error("mkhe: mr_xy without mr_prepare");
     const int nb = beta(p.level), nslots = p.L + np;
-    for (int side = 0; side < 2; ++side) {
+    // y first: it feeds step F, the long chain (F1 -> Decompose -> F2); x only feeds step E
+    for (int side = 1; side >= 0; --side) {
         const int n = side ? p.n1 : p.n0;
         if (n > MAX_TERMS) throw Error("mkhe: too many parties");
         InnerProductArgs ip{};
@@ -615,7 +616,10 @@ void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, 
         }
         ip.out = side ? y : x; ip.mods = d_mods; ip.map = map_qp(p.level);
         ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nb; ip.N = N; ip.mform_out = mform ? 1 : 0;
+        const bool on_side = side == 0 && defer_x && overlap;
+        if (on_side) { fork_side(2); s_ = stream2; }
         { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nb * (2.0 * n + 1)); launch_inner_product(ip, s_); }
+        if (on_side) { side_done(2); s_ = stream; p.x_pending = true; }
     }
     MKHE_HIP(hipGetLastError());
 }
@@ -629,24 +633,28 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
     const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
     const size_t PO = (size_t)L * N;
     u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
-    // E: out_j += <h(c1_j), x>_P   and   F1: t_i = <h(c0_i), y>_P   (independent products, one batch)
+    // F1: t_i = <h(c0_i), y>_P -- the head of the long chain; E (needs x, which may still be accumulating on the side
+    // stream) joins the last batch below
     std::vector<ExtItem> items;
-    for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
     for (int a = 0; a < n0; ++a) items.push_back(ExtItem{p.h0[a], y, tbuf + (size_t)a * PO, false});
-    ext_batch(level, items, 1);        // joins the tensor chain before its ModDown accumulates into out
+    ext_batch(level, items);
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
         if (n0) decompose_batch(level, dsrc, ddst, true);
     }
+    // E: out_j += <h(c1_j), x>_P ; F2: out_0 += <h(t_i), v_i>_P, out_i += <h(t_i), u>_P   (one batch; items that share a
+    // destination are accumulated one after the other by the same thread of the ModDown kernel)
     items.clear();
+    for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
     for (int a = 0; a < n0; ++a) {
         if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
         items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
         items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
     }
-    ext_batch(level, items);
+    if (p.x_pending) { join_side(2); p.x_pending = false; }
+    ext_batch(level, items, 1);        // joins the tensor chain before the ModDown accumulates into out
     p.valid = false;
     MKHE_HIP(hipGetLastError());
 }
@@ -981,9 +989,10 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
         }
         if (!src.empty()) bfv_decompose_batch(src, d1, d2, true);
     }
-    // x1, x2, y1, y2 (keyswitch_hoisted.go:76-126)
+    // y1, y2 on the main stream (they feed step F, the long chain), x1, x2 on the side stream (step E joins the last
+    // batch)   (keyswitch_hoisted.go:76-126)
     const int nslots = L + np;
-    for (int which = 0; which < 4; ++which) {
+    for (int which = 3; which >= 0; --which) {
         const int side = which >> 1, half = which & 1;
         const int n = side ? n1 : n0;
         InnerProductArgs ip{};
@@ -995,26 +1004,33 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
         ip.out = side ? (half ? y2_ : y_) : (half ? x2_ : x_);
         ip.mods = d_mods; ip.map = map_qp(level);
         ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = beta_max; ip.N = N; ip.mform_out = 1;
+        const bool on_side = side == 0 && overlap;
+        if (which == 1 && on_side) fork_side(2);
+        if (on_side) s_ = stream2;
         { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * beta_max * (2.0 * n + 1)); launch_inner_product(ip, s_); }
+        if (on_side) s_ = stream;
+        if (which == 0 && on_side) side_done(2);
     }
-    // E: out_j += <h(c1_j), (x1,x2)> ; F1: t_i = <h(c0_i), (y1,y2)>
+    // F1: t_i = <h(c0_i), (y1,y2)>
     u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PQ);
     std::vector<ExtItem> items;
-    for (int a = 0; a < n1; ++a) { ExtItem it{h1a[a], x_, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = h1b[a]; it.bg2 = x2_; items.push_back(it); }
     for (int a = 0; a < n0; ++a) { ExtItem it{h0a[a], y_, tbuf + (size_t)a * PQ, false}; it.ah2 = h0b[a]; it.bg2 = y2_; items.push_back(it); }
-    ext_batch(level, items, 1);
+    ext_batch(level, items);
     // F2: ks.Decompose(t_i) ; out_0 += <h(t_i), v_i> ; out_i += <h(t_i), u>
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PQ); ddst.push_back(hoist_slot(2, a).d); }
         if (n0) decompose_batch(level, dsrc, ddst, true);
     }
+    // E: out_j += <h(c1_j), (x1,x2)> together with F2
     items.clear();
+    for (int a = 0; a < n1; ++a) { ExtItem it{h1a[a], x_, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = h1b[a]; it.bg2 = x2_; items.push_back(it); }
     for (int a = 0; a < n0; ++a) {
         items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v[a]->d, out.d, true});
         items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true});
     }
-    ext_batch(level, items);
+    join_side(2);
+    ext_batch(level, items, 1);        // joins the tensor / Quantize chain before the ModDown accumulates into out
     MKHE_HIP(hipGetLastError());
 }
 

@@ -528,7 +528,7 @@ static bool use_split(int logN, const NttBatch& b) {
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("MKHE_NTT_SPLIT"); forced = (e && *e) ? atoi(e) : -1; }
     if (forced >= 0) return forced != 0;
-    return b.nslots * b.nouter <= 160;
+    return b.nslots * b.nouter <= 128;        // at most one sub-transform workgroup per CU (256 CUs)
 }
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
