@@ -481,6 +481,9 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
             ia.ah2[i] = items[base + i].ah2; ia.bg2[i] = items[base + i].bg2;
             two = two || ia.ah2[i] != nullptr;
         }
+        // neighbours that share their digits (step F: <h(t_i), v_i> and <h(t_i), u>) are computed together
+        for (int i = 0; i + 1 < n; ++i)
+            if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }
         ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
         ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
         { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb * (two ? 2 : 1) + 1) * n); launch_ext_inner(ia, s_); }

@@ -92,15 +92,33 @@ void launch_moddown(const ModDownArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------ batched ExternalProduct halves
 __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
     const int s = blockIdx.y, item = blockIdx.z;
+    const int role = a.pair[item];
+    if (role == 2) return;                    // computed by its leader
     const int m = a.map[s];
     const Mod md = a.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
     const u64* ah = a.ah[item] + (long)m * a.N;
     const u64* bg = a.bg[item] + (long)m * a.N;
+    u64* out = a.c1 + (long)item * a.c1_item + (long)m * a.N;
+    if (role == 1) {
+        const u64* bgn = a.bg[item + 1] + (long)m * a.N;
+        u64* outn = out + a.c1_item;
+        for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
+            u64 acc = 0, accn = 0;
+#pragma unroll 2
+            for (int i = 0; i < a.nb; ++i) {
+                const u64 h = ah[(long)i * a.digit_stride + n];
+                acc = csub(acc + mont_mul_lazy(bg[(long)i * a.digit_stride + n], h, q, ninv), q2);
+                accn = csub(accn + mont_mul_lazy(bgn[(long)i * a.digit_stride + n], h, q, ninv), q2);
+            }
+            out[n] = csub(acc, q);
+            outn[n] = csub(accn, q);
+        }
+        return;
+    }
     const u64* ah2 = a.ah2[item] ? a.ah2[item] + (long)m * a.N : nullptr;
     const u64* bg2 = a.ah2[item] ? a.bg2[item] + (long)m * a.N : nullptr;
-    u64* out = a.c1 + (long)item * a.c1_item + (long)m * a.N;
     for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
         u64 acc = 0;
 #pragma unroll 2
