@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=4)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even at world size 1 (testing)")
+    ap.add_argument("--shard", default="limb", choices=["limb", "party"],
+                    help="N > 1: shard the RNS limbs (default: x, y stay local, ~40 MB exchanged per step) or the parties "
+                         "(the paper's structure, ~135 MB all-reduced per step)")
     ap.add_argument("--scheme", default="ckks", choices=["ckks", "bfv"],
                     help="ckks = BASELINE.json headline metric (default); bfv = the mkbfv MulRelin line (single GPU)")
     args = ap.parse_args()

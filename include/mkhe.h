@@ -121,6 +121,21 @@ int  mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const
                     const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out);
 int  mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct);
 
+/* ---- limb-sharded multi-GPU MulAndRelin (no reference counterpart; mkhe_kklss_amd/dist.py LimbShardedMulRelin).
+ *      A context may own a subset of the RNS moduli (indices over Q then P; n = 0: all).  With an ownership set the
+ *      four phases below evaluate KeySwitcher.MulAndRelin (keyswitch.go:122-230) on full operands (all parties, every
+ *      rank) for the owned moduli only: the per-party sums x, y are local; after each phase *words_out words of the
+ *      caller's device buffer dev_stage (phase 4: of `out` itself) are all-reduced (sums of disjoint slices):
+ *        1: tensor, hoisting, x, y, <h(c0_i), y> + InvNTT        -> P limbs of those products
+ *        2: their ModDown = t_i on the owned limbs               -> t_i
+ *        3: Decompose(t_i), <h(c1_j), x>, <h(t_i), v_i>, <h(t_i), u> + InvNTT  -> P limbs
+ *        4: ModDown accumulated into out (owned limbs, zeros elsewhere)        -> out
+ *      Keys: rlk_b1 / rlk_d0 for phase 1, rlk_v0 / crs_u for phase 3 (NULL otherwise). */
+int  mkhe_ctx_set_owned(mkhe_ctx* ctx, const int* mod_idx, int n);
+int  mkhe_lsh_phase(mkhe_ctx* ctx, int phase, const mkhe_ct* op0, const mkhe_ct* op1,
+                    const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0, const mkhe_swk* const* rlk_v0,
+                    const mkhe_swk* crs_u, mkhe_ct* out, void* dev_stage, size_t* words_out);
+
 /* ---- KeySwitcher.Rotate keyswitch.go:234-298 / RotateHoisted keyswitch_hoisted.go:183-247.
  *      galEl = 5^rotidx mod 2N; rk aligned with ct ids (rkSet[id][rotidx]); crs = params.CRS[rotidx]. */
 int  mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* hoist,

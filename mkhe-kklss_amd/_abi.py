@@ -52,6 +52,8 @@ SIGNATURES = {
     "mkhe_mr_finish": (C.c_int, [vp, vp, vp, vp, vp, vpp, vp, vp]),
     "mkhe_ct_fold": (C.c_int, [vp, vp]),
     "mkhe_rotate":(C.c_int, [vp, C.c_uint64, vp, vpp, vpp, vp, vp]),
+    "mkhe_ctx_set_owned": (C.c_int, [vp, i32p, C.c_int]),
+    "mkhe_lsh_phase": (C.c_int, [vp, C.c_int, vp, vp, vpp, vpp, vpp, vp, vp, vp, C.POINTER(C.c_size_t)]),
     "mkhe_rotate_partial": (C.c_int, [vp, vp, vpp, vpp, vp, C.c_int, vp]),
     "mkhe_ct_automorphism": (C.c_int, [vp, C.c_uint64, vp, vp]),
     "mkhe_conjugate": (C.c_int, [vp, C.c_uint64, vp, vpp, vp, vp]),

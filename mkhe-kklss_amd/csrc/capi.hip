@@ -248,6 +248,19 @@ int mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk
         ctx->c->rotate(galEl, in->c, hoist ? h.data() : nullptr, r.data(), crs->s, out->c);
     })
 }
+int mkhe_ctx_set_owned(mkhe_ctx* ctx, const int* mod_idx, int n) {
+    MKHE_TRY({ if (n < 0 || (n > 0 && !mod_idx)) throw Error("mkhe_ctx_set_owned: bad argument"); ctx->c->set_owned(mod_idx, n); })
+}
+int mkhe_lsh_phase(mkhe_ctx* ctx, int phase, const mkhe_ct* op0, const mkhe_ct* op1,
+                   const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0, const mkhe_swk* const* rlk_v0,
+                   const mkhe_swk* crs_u, mkhe_ct* out, void* dev_stage, size_t* words_out) {
+    MKHE_TRY({
+        if (!op0 || !op1 || !out || !words_out) throw Error("mkhe_lsh_phase: null argument");
+        auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n); auto v0 = swk_list(rlk_v0, op0->c.n);
+        *words_out = ctx->c->lsh_phase(phase, op0->c, op1->c, rlk_b1 ? b1.data() : nullptr, rlk_d0 ? d0.data() : nullptr,
+                                       rlk_v0 ? v0.data() : nullptr, crs_u ? &crs_u->s : nullptr, out->c, (u64*)dev_stage);
+    })
+}
 int mkhe_rotate_partial(mkhe_ctx* ctx, const mkhe_ct* in, const mkhe_swk* const* hoist,
                         const mkhe_swk* const* rk, const mkhe_swk* crs, int with_c0, mkhe_ct* out) {
     MKHE_TRY({

@@ -94,7 +94,21 @@ class Context {
     // internal = true: the digits stay inside the engine (hoist pools): their forward NTT skips the final
     // normalisation (values < 34q with the same residues; every consumer is a Montgomery product)
     void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst, bool internal = false);
-    void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1);
+    // stage 0: whole external products; 1: front half only (inner products + inverse NTT into the c1 pool);
+    // 2: back half only (ModDown of the c1 pool filled by the preceding stage-1 call with the same items)
+    void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0);
+
+    // ---- limb-sharded multi-GPU evaluation (mkhe_kklss_amd/dist.py LimbShardedMulRelin): this context owns a subset of
+    // the RNS moduli ("slots"); NTTs, inner products and ModDown outputs are computed for the owned slots only, all
+    // parties.  The per-party sums x, y are then LOCAL; what crosses the links are the P limbs of the external
+    // products, t_i and the output ciphertext (about 40 MB per step instead of 130 MB for party sharding).
+    void set_owned(const int* mod_idx, int n);          // n == 0: everything (single-device behaviour)
+    bool masked() const { return masked_; }
+    // MulAndRelin in four phases around three exchanges through `stage` (device, caller-owned); each returns the number
+    // of words of `stage` to all-reduce (sum of disjoint slices) before the next phase.  After phase 4 `out` holds the
+    // owned limbs (zeros elsewhere) and is all-reduced itself.
+    size_t lsh_phase(int phase, const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_d0,
+                     const Swk* const* rlk_v0, const Swk* crs_u, Ct& out, u64* stage);
 
     bool overlap = true;               // false: everything on the main stream (clean per-kernel timings)
     u64* ntt_trace = nullptr;          // diagnostic buffer handed to the forward NTT kernels (mkhe_ntt_trace)
@@ -140,7 +154,18 @@ class Context {
 
     u64* scratch(u64*& p, size_t& have, size_t want);
     Swk& hoist_slot(int which, int idx);
-    const int* map_qp(int level) const { return d_map_qp + (size_t)level * mtot; }
+    const int* map_qp(int level) const { return (masked_ ? d_map_own : d_map_qp) + (size_t)level * mtot; }
+    int nslots_qp(int level) const { return masked_ ? own_cnt_[level] : level + 1 + np; }
+    // slot ownership (limb sharding)
+    bool masked_ = false;
+    std::vector<char> own_;                                  // per modulus index < mtot
+    std::vector<std::vector<int>> own_list_;                 // per level: owned active modulus indices (Q limbs first)
+    std::vector<int> own_cnt_, ownq_;                        // per level: size of own_list_; owned Q limbs, ascending
+    int *d_map_own = nullptr, *d_ownq = nullptr;
+    int nq_owned(int level) const { int c = 0; for (int l : ownq_) if (l <= level) ++c; return c; }
+    void slots_q_owned(NttBatch& b, int L) const;            // plain polynomials: owned Q limbs < L
+    void zero_unowned(u64* base, int npolys, long poly_stride, int first_mod, int nlimbs);
+    std::vector<ExtItem> lsh_items_;
     void check_level(int level) const;
     void slots_qp(NttBatch& b, int level) const;
     void slots_range(NttBatch& b, int mod_base, int limbs) const;

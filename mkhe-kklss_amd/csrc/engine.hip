@@ -252,7 +252,7 @@ Context::~Context() {
     if (stream) (void)hipStreamSynchronize(stream);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
                     (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale,
-                    (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c,
+                    (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
                     (void*)d_map_r, (void*)d_bq_qoverqiinvqi, (void*)d_bq_qoverqimodp, (void*)d_bq_vtimes,
@@ -323,9 +323,41 @@ void Context::prof_collect(double* ms, long* launches, double* alg_bytes) {
 
 // slot lists of an NttBatch: limbs 0..level of Q then every P limb (PolyQP shaped buffers) ...
 void Context::slots_qp(NttBatch& b, int level) const {
+    if (masked_) {                       // limb sharding: only the owned slots (buffers are always addressed "mapped" here)
+        const std::vector<int>& l = own_list_[level];
+        b.nslots = (int)l.size();
+        for (int k = 0; k < b.nslots; ++k) { b.mod[k] = l[k]; b.pos[k] = l[k] < nq ? l[k] : level + 1 + (l[k] - nq); }
+        return;
+    }
     b.nslots = level + 1 + np;
     for (int j = 0; j <= level; ++j) { b.mod[j] = j; b.pos[j] = j; }
     for (int j = 0; j < np; ++j) { b.mod[level + 1 + j] = nq + j; b.pos[level + 1 + j] = level + 1 + j; }
+}
+void Context::slots_q_owned(NttBatch& b, int L) const {
+    if (!masked_) { slots_range(b, 0, L); return; }
+    b.nslots = 0;
+    for (int l : ownq_) if (l < L) { b.mod[b.nslots] = l; b.pos[b.nslots] = l; ++b.nslots; }
+}
+
+// limb sharding: which moduli this context computes (mod_idx over Q then P); n == 0 restores "everything"
+void Context::set_owned(const int* mod_idx, int n) {
+    sync();
+    if (is_bfv() || alpha != 1) { if (n) throw Error("mkhe: limb sharding is wired for the mkckks path with one prime per digit only"); }
+    own_.assign(mtot, n == 0 ? 1 : 0);
+    for (int i = 0; i < n; ++i) { if (mod_idx[i] < 0 || mod_idx[i] >= mtot) throw Error("mkhe: owned modulus index out of range"); own_[mod_idx[i]] = 1; }
+    masked_ = n != 0;
+    own_list_.assign(nq, {}); own_cnt_.assign(nq, 0); ownq_.clear();
+    std::vector<int> map((size_t)nq * mtot, 0);
+    for (int l = 0; l < nq; ++l) {
+        for (int j = 0; j <= l; ++j) if (own_[j]) own_list_[l].push_back(j);
+        for (int j = 0; j < np; ++j) if (own_[nq + j]) own_list_[l].push_back(nq + j);
+        own_cnt_[l] = (int)own_list_[l].size();
+        for (int k = 0; k < own_cnt_[l]; ++k) map[(size_t)l * mtot + k] = own_list_[l][k];
+    }
+    for (int j = 0; j < nq; ++j) if (own_[j]) ownq_.push_back(j);
+    if (d_map_own) MKHE_HIP(hipFree(d_map_own));
+    if (d_ownq) MKHE_HIP(hipFree(d_ownq));
+    d_map_own = dev_upload(map); d_ownq = dev_upload(ownq_);
 }
 // ... or `limbs` consecutive moduli starting at mod_base (plain polynomials)
 void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
@@ -391,7 +423,7 @@ void Context::decompose(int level, bool is_ntt, const u64* a, u64* out_swk) {
 // ------------------------------------------------------------------ ExternalProduct[Hoisted]
 // (keyswitch_hoisted.go:10-40): sum over digits, InvNTTLazy on Q and P parts, ModDownQPtoQ.
 void Context::ext_core(int level, const u64* ah, const u64* bg, u64* c, bool accumulate) {
-    const int nb = beta(level), nslots = level + 1 + np;
+    const int nb = beta(level), nslots = nslots_qp(level);
     InnerProductArgs ip{};
     for (int i = 0; i < nb; ++i) { ip.a[i] = bg + (size_t)i * mtot * N; ip.b[i] = ah + (size_t)i * mtot * N; }
     ip.out = c1_; ip.mods = d_mods; ip.map = map_qp(level);
@@ -467,9 +499,10 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
 }
 
 // items: independent external products  dst (+)= ModDown( sum_i bg[i] (.) ah[i] )
-void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown) {
+void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown, int stage) {
+    if (stage != 0 && items.size() > (size_t)EXT_MAX_ITEMS) throw Error("mkhe: too many external products for a staged batch");
     check_level(level);
-    const int nb = beta(level), nslots = level + 1 + np;
+    const int nb = beta(level), nslots = nslots_qp(level);
     const size_t item_words = (size_t)mtot * N;
     for (size_t base = 0; base < items.size(); base += EXT_MAX_ITEMS) {
         const int n = (int)std::min<size_t>(EXT_MAX_ITEMS, items.size() - base);
@@ -486,18 +519,21 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
             if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }
         ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
         ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
-        { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb * (two ? 2 : 1) + 1) * n); launch_ext_inner(ia, s_); }
-
-        NttBatch b{};
-        b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
-        b.nouter = n; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
-        b.src_outer = b.dst_outer = (long)item_words; b.lazy_out = 1;
-        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, s_); }
+        if (stage != 2 && nslots > 0) {
+            { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb * (two ? 2 : 1) + 1) * n); launch_ext_inner(ia, s_); }
+            NttBatch b{};
+            b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
+            b.nouter = n; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
+            b.src_outer = b.dst_outer = (long)item_words; b.lazy_out = 1;
+            { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, s_); }
+        }
+        if (stage == 1) continue;
 
         ModDownBatchArgs md{};
         md.c1 = c1; md.mods_q = d_mods; md.mods_p = d_mods + nq;
         md.t = ModDownTables{d_md_qoverqiinvqi, d_md_qoverqimodp, d_md_vtimes, d_md_down};
         md.c1_item = (long)item_words; md.p_offset = (long)nq * N; md.nitems = n; md.level = level; md.np = np; md.N = N;
+        if (masked_) { md.qlist = d_ownq; md.nqlist = nq_owned(level); }
         double bytes = 0;
         for (int i = 0; i < n; ++i) {
             md.dst[i] = items[base + i].dst; md.accumulate[i] = items[base + i].accumulate ? 1 : 0;
@@ -542,6 +578,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
     p.h0.assign(p.n0, nullptr); p.h1.assign(p.n1, nullptr);
     const bool same = (&op0 == &op1) && hoist0 == hoist1;
     p.own0 = (hoist0 == nullptr) && alpha == 1; p.own1 = (hoist1 == nullptr) && alpha == 1;
+    if (masked_ && !(p.own0 && p.own1)) throw Error("mkhe: a limb-sharded evaluation hoists its operands itself");
     std::vector<const u64*> dsrc; std::vector<u64*> ddst;
     for (int a = 0; a < p.n0; ++a) {
         if (hoist0) { if (!hoist0[a]) throw Error("mkhe: missing hoisted form"); p.h0[a] = hoist0[a]->d; }
@@ -567,7 +604,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
             // NTT(c0_0), NTT(c1_0) always; party components only when the caller supplied the hoisted forms
             // (the engine's own hoisted digits already contain NTT(c_i) on their diagonal, alpha = 1)
             NttBatch b{};
-            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_range(b, 0, L);
+            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_q_owned(b, L);
             b.src_inner = b.dst_inner = N; b.dst_outer = (long)PO;
             if (p.own0 && p.own1) {
                 b.nitems = 2; b.outers_per_item = 1; b.nouter = 2;
@@ -584,6 +621,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
         TensorArgs ta{};
         ta.a0 = nb_; ta.b0 = nb_ + (size_t)(1 + n0) * PO; ta.out = out.d; ta.mods = d_mods;
         ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
+        if (masked_) { ta.limbs = d_ownq; ta.nlimbs = nq_owned(level); }
         const long diag = (long)(mtot + 1) * N;
         for (int a = 0; a < n0; ++a) {
             const int o = 1 + p.slot0[a];
@@ -594,7 +632,13 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
             if (p.own1) { ta.b[o] = p.h1[a]; ta.b_ls[o] = diag; } else { ta.b[o] = nb_ + (size_t)(2 + n0 + a) * PO; ta.b_ls[o] = N; }
         }
         { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, s_); }
-        ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
+        if (!masked_) ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
+        else {
+            NttBatch ib{};
+            ib.src = out.d; ib.dst = out.d; ib.mods = d_mods; ib.psi = d_psiinv; ib.aux = d_inv_aux; slots_q_owned(ib, L);
+            ib.src_outer = ib.dst_outer = (long)PO; ib.src_inner = ib.dst_inner = N; ib.nouter = 1 + out.n;
+            if (ib.nslots > 0) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * ib.nouter * ib.nslots); launch_ntt_inv(logN, ib, s_); }
+        }
         side_done(1);
         s_ = stream;
     }
@@ -606,7 +650,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
 void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x) {
     MrPlan& p = plan_;
     if (!p.valid) throw Error("mkhe: mr_xy without mr_prepare");
-    const int nb = beta(p.level), nslots = p.L + np;
+    const int nb = beta(p.level), nslots = nslots_qp(p.level);
     // y first: it feeds step F, the long chain (F1 -> Decompose -> F2); x only feeds step E
     for (int side = 1; side >= 0; --side) {
         const int n = side ? p.n1 : p.n0;
@@ -662,13 +706,86 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
     MKHE_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------ limb-sharded MulAndRelin (see engine.h)
+void Context::zero_unowned(u64* base, int npolys, long poly_stride, int first_mod, int nlimbs) {
+    for (int l = 0; l < nlimbs; ++l)
+        if (!own_[first_mod + l])
+            MKHE_HIP(hipMemset2DAsync(base + (size_t)l * N, (size_t)poly_stride * sizeof(u64), 0, (size_t)N * sizeof(u64), npolys, s_));
+}
+
+size_t Context::lsh_phase(int phase, const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_d0,
+                          const Swk* const* rlk_v0, const Swk* crs_u, Ct& out, u64* stage) {
+    if (!masked_) throw Error("mkhe: lsh_phase needs mkhe_ctx_set_owned first");
+    if (!stage) throw Error("mkhe: lsh_phase needs a staging buffer");
+    MrPlan& p = plan_;
+    const size_t item_words = (size_t)mtot * N, prow = (size_t)np * N * sizeof(u64);
+    // P limbs of the c1 pool <-> contiguous staging [item][np][N]; limbs this rank does not own travel as zeros
+    auto pack = [&](int n) -> size_t {
+        zero_unowned(c1b_ + (size_t)nq * N, n, (long)item_words, nq, np);
+        if (n) MKHE_HIP(hipMemcpy2DAsync(stage, prow, c1b_ + (size_t)nq * N, item_words * sizeof(u64), prow, n, hipMemcpyDeviceToDevice, s_));
+        return (size_t)n * np * N;
+    };
+    auto unpack = [&](int n) {
+        if (n) MKHE_HIP(hipMemcpy2DAsync(c1b_ + (size_t)nq * N, item_words * sizeof(u64), stage, prow, prow, n, hipMemcpyDeviceToDevice, s_));
+    };
+    if (phase == 1) {
+        // every rank computes its limbs of the tensor product (c0_0*c1_0 included: the limbs are disjoint), hoists all
+        // parties under its moduli and accumulates x, y there: complete sums, no exchange
+        mr_prepare(op0, op1, nullptr, nullptr, true, out);
+        mr_xy(rlk_b1, rlk_d0, x_, y_, true, false);
+        const size_t PO = (size_t)p.L * N;
+        u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)std::max(p.n0, 1) * PO);
+        lsh_items_.clear();
+        for (int a = 0; a < p.n0; ++a) lsh_items_.push_back(ExtItem{p.h0[a], y_, tbuf + (size_t)a * PO, false});
+        scratch(c1b_, c1b_words_, (size_t)std::max<size_t>(lsh_items_.size(), 1) * item_words);
+        ext_batch(p.level, lsh_items_, -1, 1);
+        return pack((int)lsh_items_.size());
+    }
+    if (!p.valid) throw Error("mkhe: lsh_phase out of order");
+    const int level = p.level, L = p.L;
+    const size_t PO = (size_t)L * N;
+    if (phase == 2) {
+        unpack((int)lsh_items_.size());
+        ext_batch(level, lsh_items_, -1, 2);                       // t_i, owned limbs
+        zero_unowned(tbuf_, p.n0, (long)PO, 0, L);
+        if (p.n0) MKHE_HIP(hipMemcpyAsync(stage, tbuf_, (size_t)p.n0 * PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+        return (size_t)p.n0 * PO;
+    }
+    if (phase == 3) {
+        if (!crs_u || !rlk_v0) throw Error("mkhe: lsh_phase 3 needs the v keys and the CRS");
+        if (p.n0) MKHE_HIP(hipMemcpyAsync(tbuf_, stage, (size_t)p.n0 * PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (int a = 0; a < p.n0; ++a) { dsrc.push_back(tbuf_ + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
+        if (p.n0) decompose_batch(level, dsrc, ddst, true);
+        lsh_items_.clear();
+        for (int a = 0; a < p.n1; ++a) lsh_items_.push_back(ExtItem{p.h1[a], x_, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
+        for (int a = 0; a < p.n0; ++a) {
+            if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+            lsh_items_.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
+            lsh_items_.push_back(ExtItem{hoist_slot(2, a).d, crs_u->d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
+        }
+        scratch(c1b_, c1b_words_, (size_t)std::max<size_t>(lsh_items_.size(), 1) * item_words);
+        ext_batch(level, lsh_items_, -1, 1);
+        return pack((int)lsh_items_.size());
+    }
+    if (phase == 4) {
+        unpack((int)lsh_items_.size());
+        ext_batch(level, lsh_items_, 1, 2);                        // joins the tensor chain, then accumulates into out
+        zero_unowned(out.d, 1 + out.n, (long)PO, 0, L);
+        p.valid = false;
+        MKHE_HIP(hipGetLastError());
+        return (size_t)(1 + out.n) * PO;
+    }
+    throw Error("mkhe: lsh_phase 1..4");
+}
+
 // reduction epilogue of the party-sharded path: words hold sums of canonical residues of several ranks
 // (each < q, total < 2^63); bring them back to [0,q) and optionally to Montgomery form (MFormLvl).
 void Context::fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform) {
     check_level(level);
     FoldArgs fa{};
     fa.buf = buf; fa.mods = d_mods; fa.map = qp_shaped ? map_qp(level) : d_map_id;
-    fa.nslots = qp_shaped ? level + 1 + np : level + 1; fa.npolys = npolys; fa.poly_stride = poly_stride; fa.N = N; fa.mform = mform ? 1 : 0;
+    fa.nslots = qp_shaped ? nslots_qp(level) : level + 1; fa.npolys = npolys; fa.poly_stride = poly_stride; fa.N = N; fa.mform = mform ? 1 : 0;
     { ProfScope ps(this, PROF_OTHER, 16.0 * N * fa.nslots * npolys); launch_fold(fa, s_); }
     MKHE_HIP(hipGetLastError());
 }

@@ -81,6 +81,8 @@ struct ModDownBatchArgs {
     long c1_item;            // mtot*N
     long p_offset;           // nq*N
     int nitems, level, np, N;
+    const int* qlist;        // limb-sharded evaluation: the Q limbs to produce (device list) or NULL = 0..level
+    int nqlist;
 };
 void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st);
 
@@ -99,6 +101,8 @@ struct TensorArgs {
     long a_ls[33], b_ls[33];   // limb strides of the above
     int nout, L, N;
     int with_c0;               // 0: leave c0_0*c1_0 out of out_0 (party-sharded evaluation)
+    const int* limbs;          // limb-sharded evaluation: the limbs to produce (device list of nlimbs entries) or NULL = all L
+    int nlimbs;
     const int* map;            // [L] modulus index of limb l (NULL: l itself)          -- ring R of mkbfv
     const u64* scale;          // [L] Montgomery constants multiplied into every output (NULL: none)
                                //     -- ringR.MulScalar(t) of Quantize, mkbfv/basis_extension.go:71

@@ -162,7 +162,9 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
             }
         }
         const u64 v = (u64)vi;
-        for (int j = blockIdx.y; j <= a.level; j += gridDim.y) {
+        const int nj = a.qlist ? a.nqlist : a.level + 1;
+        for (int jj = blockIdx.y; jj < nj; jj += gridDim.y) {
+            const int j = a.qlist ? a.qlist[jj] : jj;
             const Mod mq = a.mods_q[j];
             u64 rlo = 0, rhi = 0;
 #pragma unroll
@@ -186,8 +188,9 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
 }
 void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st) {
     const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    int by = a.level + 1;
+    int by = a.qlist ? a.nqlist : a.level + 1;
     if (by > 16) by = 16;
+    if (by < 1) return;
     hipLaunchKernelGGL(moddown_batch_kernel, dim3(bx, by), dim3(PW_THREADS), 0, st, a);
 }
 
@@ -195,7 +198,7 @@ void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st) {
 typedef const __attribute__((address_space(4))) TensorArgs* tensor_kargs;
 __global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
     tensor_kargs ka = (tensor_kargs)__builtin_amdgcn_kernarg_segment_ptr();    // per-slot lists: scalar loads
-    const int l = blockIdx.y;
+    const int l = a.limbs ? a.limbs[blockIdx.y] : blockIdx.y;
     const Mod md = a.mods[a.map ? a.map[l] : l];
     const u64 q = md.q;
     const u32 ninv = md.ninv32;
@@ -224,7 +227,9 @@ __global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
 void launch_tensor(const TensorArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(tensor_kernel, dim3(bx, a.L), dim3(PW_THREADS), 0, st, a);
+    const int by = a.limbs ? a.nlimbs : a.L;
+    if (by < 1) return;
+    hipLaunchKernelGGL(tensor_kernel, dim3(bx, by), dim3(PW_THREADS), 0, st, a);
 }
 
 // ------------------------------------------------------------------ add

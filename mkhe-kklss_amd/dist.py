@@ -201,3 +201,87 @@ class HipRotateBackend:
         self.check(self.lib().mkhe_ct_fold(self.params.ctx, self.full.h))
         self.check(self.lib().mkhe_ct_automorphism(self.params.ctx, self.galEl, self.full.h, self.out.h))
         return self.out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Limb sharding: every rank holds the full operands (ciphertext polynomials are small) and owns a subset of the RNS
+# moduli.  NTTs, inner products and ModDown outputs are computed for the owned moduli only, for ALL parties, so the
+# per-party sums x, y -- the 2 x 56 MiB that party sharding has to all-reduce -- never leave the rank.  What crosses
+# the links per step (PN15QP880, k = 4): the P limbs of the external products (2 + 6 MiB), t_i (14 MiB) and the
+# output ciphertext (17.5 MiB).  All exchanges are all-reduces of disjoint slices (zeros elsewhere): exact and order
+# independent, so the result is bit-identical to the single-device evaluation.
+def assign_moduli(nq, np_, world):
+    """-> list over ranks of modulus-index lists (Q then P), round-robin so every rank gets Q limbs and the two
+    modulus classes (small / big primes) are spread evenly"""
+    out = [[] for _ in range(world)]
+    for j in range(nq + np_):
+        out[j % world].append(j)
+    return out
+
+
+class LimbShardedMulRelin:
+    """Orchestrates one limb-sharded MulAndRelin: four engine phases around three exchanges + the output exchange."""
+
+    def __init__(self, backend, dist=None, group=None):
+        self.b, self.dist, self.group = backend, dist, group
+
+    def _all_reduce(self, t):
+        if self.dist is not None and self.dist.get_world_size(self.group) > 1:
+            self.b.before_collective()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.b.after_collective()
+
+    def run(self):
+        b = self.b
+        for phase in (1, 2, 3, 4):
+            t = b.phase(phase)                 # torch int64 view of what has to be summed over the ranks
+            if t.numel():
+                self._all_reduce(t)
+        return b.result()
+
+
+class HipLimbBackend:
+    """One rank of LimbShardedMulRelin on its MI355X through the C ABI (mkhe_ctx_set_owned, mkhe_lsh_phase)."""
+
+    def __init__(self, params, names, rank, world, op0_host, op1_host, rlk_host, level, torch, device_index):
+        """full operands uint64[1+k][L][N] and the keys {name: (b, d, v)} of ALL parties (only the owned limbs of the
+        keys are ever read)."""
+        import ctypes as C
+        from . import mkrlwe, _abi
+        from ._abi import check, handle_array, lib
+        self.params, self.names, self.level, self.torch = params, list(names), level, torch
+        self.C, self.check, self.lib, self.harr = C, check, lib, handle_array
+        self.owned = assign_moduli(len(params.Q), len(params.P), world)[rank]
+        arr = np.asarray(self.owned, dtype=np.int32)
+        check(lib().mkhe_ctx_set_owned(params.ctx, arr.ctypes.data_as(_abi.i32p), len(arr)))
+        self.op0 = mkrlwe.NewCiphertext(params, self.names, level).upload(op0_host)
+        self.op1 = mkrlwe.NewCiphertext(params, self.names, level).upload(op1_host)
+        self.keys = {n: [mkrlwe.SwitchingKey(params, rlk_host[n][j]) for j in range(3)] for n in self.names}
+        self.out = mkrlwe.NewCiphertext(params, self.names, level)
+        k, N, L = len(self.names), params.N(), level + 1
+        self.stage_words = max((3 * k) * len(params.P) * N, k * L * N, 1)
+        self.stage = mkrlwe.DeviceLimbs(params, 1, -(-self.stage_words // N))
+        dev = torch.device("cuda", device_index)
+        self.tstage = torch.as_tensor(_DevView(self.stage.devptr().value, self.stage.words), device=dev)
+        self.tout = torch.as_tensor(_DevView(self.out.devptr(), (1 + k) * L * N), device=dev)
+        self.b1 = self.harr([self.keys[n][0].h for n in self.names])
+        self.d0 = self.harr([self.keys[n][1].h for n in self.names])
+        self.v0 = self.harr([self.keys[n][2].h for n in self.names])
+
+    def phase(self, ph):
+        w = self.C.c_size_t(0)
+        first, third = ph == 1, ph == 3
+        self.check(self.lib().mkhe_lsh_phase(self.params.ctx, ph, self.op0.h, self.op1.h,
+                                             self.b1 if first else None, self.d0 if first else None,
+                                             self.v0 if third else None, self.params.CRS[-1].h if third else None,
+                                             self.out.h, self.stage.devptr(), self.C.byref(w)))
+        return self.tout[: w.value] if ph == 4 else self.tstage[: w.value]
+
+    def before_collective(self):
+        self.params.sync()                         # engine stream -> host; RCCL runs on torch's stream
+
+    def after_collective(self):
+        self.torch.cuda.current_stream().synchronize()
+
+    def result(self):
+        return self.out

@@ -2,7 +2,7 @@
 so the sharding + collective pattern can be exercised with gloo on CPU (no GPU in this container)."""
 import numpy as np
 
-from mkhe_kklss_amd.dist import assign_parties, assign_units
+from mkhe_kklss_amd.dist import assign_moduli, assign_parties, assign_units
 
 
 class OracleShardBackend:
@@ -88,3 +88,45 @@ class OracleRotateBackend:
             out[s] = ks.ringQ.permute(self.galEl, red)
         self.out = out
         return out
+
+
+class OracleLimbBackend:
+    """TEST-ONLY backend of mkhe_kklss_amd.dist.LimbShardedMulRelin for the gloo tests: the CPU oracle evaluates the whole
+    MulAndRelin on every rank and the backend hands LimbShardedMulRelin exactly the slices a rank would own (zeros
+    elsewhere), so that the exchange pattern -- all-reduces of disjoint slices, four rounds -- is exercised end to end:
+    rounds 1-3 carry a known pattern cut by modulus ownership, round 4 the real output limbs."""
+
+    def __init__(self, ks, names, rank, world, op0, op1, rlk, crs_u, level, torch):
+        self.ks, self.names, self.level, self.torch = ks, list(names), level, torch
+        nq, np_ = len(ks.Q), len(ks.P)
+        self.owned = set(assign_moduli(nq, np_, world)[rank])
+        ids = list(range(len(names)))
+        _, self.ref = ks.mul_and_relin(level, ids, op0, ids, op1, {i: rlk[n] for i, n in enumerate(names)}, crs_u)
+        self.nq, self.np_ = nq, np_
+        self.pattern = {}
+
+    def _mask(self, arr, first_mod):
+        """arr [..., limbs, N]: keep the limbs whose modulus index first_mod + l is owned"""
+        out = np.zeros_like(arr)
+        for l in range(arr.shape[-2]):
+            if first_mod + l in self.owned:
+                out[..., l, :] = arr[..., l, :]
+        return out
+
+    def phase(self, ph):
+        k, N, L = len(self.names), self.ks.N, self.level + 1
+        if ph == 4:
+            self.out = self._mask(self.ref, 0)
+            return self.torch.from_numpy(self.out.view(np.int64).reshape(-1))
+        shape = {1: (k, self.np_, N), 2: (k, L, N), 3: (3 * k, self.np_, N)}[ph]
+        full = (np.arange(int(np.prod(shape)), dtype=np.uint64) * np.uint64(2654435761 + ph)).reshape(shape)
+        self.pattern[ph] = full
+        self.sent = self._mask(full, self.nq if ph in (1, 3) else 0)
+        return self.torch.from_numpy(self.sent.view(np.int64).reshape(-1))
+
+    def before_collective(self): pass
+    def after_collective(self): pass
+
+    def result(self):
+        assert (self.sent.reshape(-1) == self.pattern[3].reshape(-1)).all()      # round 3 arrived complete
+        return self.out
