@@ -190,6 +190,27 @@ def run_single(args):
 
     roofline = roofline_leg(args, params, step, pset["logN"], "%s k=%d" % (args.params, k))
 
+    # ---- secondary figure: hoisted rotation of the same k-party ciphertext, hoisting included / excluded
+    extras = {}
+    if not args.no_extras:
+        rot = 1
+        rng = np.random.default_rng(args.seed + 99)
+        params.AddCRS(rot, synth_swk(pset, rng))
+        rks = mkrlwe.RotationKeySet()
+        for n in names:
+            rks.AddRotationKey(mkrlwe.RotationKey(params, rot, n, synth_swk(pset, rng)))
+        hh = ev.HoistedForm(ct0)
+        for fn, key in ((lambda: ev.RotateNew(ct0, rot, rks), "rotate_per_sec"),
+                        (lambda: ev.RotateHoistedNew(ct0, rot, hh, rks), "rotate_hoisted_per_sec")):
+            for _ in range(3):
+                fn()
+            params.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            params.sync()
+            extras[key] = args.steps / (time.perf_counter() - t0)
+
     # ---- CPU baseline: the oracle (single-thread C restatement of the Go path) on the same inputs
     cpu = None
     if not args.no_cpu:
@@ -212,7 +233,7 @@ def run_single(args):
                 vs_baseline=None, dtype="u64", data="synthetic",
                 config=dict(workload="mkckks %d-party MulRelin (hoist + MulAndRelinHoisted + Rescale), %s N=2^%d, %d Q + %d P limbs"
                             % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["P"])),
-                            parties=k, params=args.params, seed=args.seed),
+                            parties=k, params=args.params, seed=args.seed, **extras),
                 roofline=roofline, cpu_baseline=cpu)
 
 
@@ -227,6 +248,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=4)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even at world size 1 (testing)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary Rotate / RotateHoisted figures")
     ap.add_argument("--shard", default="limb", choices=["limb", "party"],
                     help="N > 1: shard the RNS limbs (default: x, y stay local, ~40 MB exchanged per step) or the parties "
                          "(the paper's structure, ~135 MB all-reduced per step)")
