@@ -339,3 +339,25 @@ def test_ckks_mul_ptxt_and_drop_level(pair):
     assert (res.download() == ref).all()
     d = ev.DropLevelNew(ct, 1)
     assert d.Level() == pair.maxlevel - 1 and (d.download() == h[:, : L - 1]).all()
+
+
+def test_overlap_switch_does_not_change_results(pair):
+    """mkhe_set_overlap(0): every kernel on the main stream (the configuration of the per-kernel timings)"""
+    from mkhe_kklss_amd._abi import check, lib
+    mk = pair.mk
+    level = pair.maxlevel
+    names = ["a", "b", "c"]
+    h0, d0 = pair.ct(names, level)
+    h1, d1 = pair.ct(names, level)
+    rlk_h, rlk_d = pair.rlk_set(names)
+    u_h = H.uniform_swk(pair.rng, pair.ks)
+    pair.params.AddCRS(-1, u_h)
+    _, ref = oracle_mul_and_relin(pair, level, names, h0, names, h1, rlk_h, u_h, names)
+    try:
+        for on in (0, 1, 0):
+            check(lib().mkhe_set_overlap(pair.params.ctx, on))
+            out = mk.NewCiphertext(pair.params, names, level)
+            pair.ksw.MulAndRelin(d0, d1, rlk_d, out)
+            assert (out.download() == ref).all()
+    finally:
+        check(lib().mkhe_set_overlap(pair.params.ctx, 1))
