@@ -161,3 +161,41 @@ def test_rotation_and_conjugation_device(sc, dev):
     assert _max_log2_err(got, np.conj(tot)) <= sc.precision_bound(8)
     with pytest.raises(Exception, match="precomputed rotation keys"):
         ev.RotateHoistedNew(d, 5, hoisted, dev["rks"])
+
+
+@pytest.mark.gpu
+def test_caller_chain_device():
+    """A caller on top of the path (what cnn/ does with the evaluator): encrypted inner product of a
+    2-party vector with plaintext weights -- MulPtxtNew (incl. Rescale), rotate-and-sum over RotateNew / AddNew, a
+    MultByConst and a SubNew -- entirely on resident ciphertexts; the decrypted result must match numpy within the
+    CKKS precision bound the reference uses for one multiplication."""
+    from mkhe_kklss_amd import mkrlwe, mkckks
+    pset = H.small_ckks(11, 4)
+    rots = (1, 2, 4, 8)
+    sc = Scenario(pset, parties=2, seed=23, rotations=rots)
+    params = mkckks.Parameters(sc.logN, sc.Q, sc.P, sc.scale)
+    for idx, host in sc.kg.CRS.items():
+        params.AddCRS(idx, host)
+    rks = mkrlwe.RotationKeySet()
+    for n in sc.names:
+        for rot, k in sc.rk[n].items():
+            rks.AddRotationKey(mkrlwe.RotationKey(params, rot, n, k))
+    ev = mkckks.NewEvaluator(params)
+    n = sc.N // 2
+    zs = {nm: sc.rng.uniform(-1, 1, n) + 0j for nm in sc.names}
+    x = sum(zs.values())
+    w = sc.rng.uniform(-1, 1, n) + 0j
+    ct = mkckks.NewCiphertext(params, sc.names, sc.level, sc.scale).upload(sc.sum_ciphertext(zs))
+    pt = sc.enc.encode(w, sc.scale, sc.Q)
+    prod = ev.MulPtxtNew(ct, pt, sc.scale)                       # slot-wise x * w, rescaled
+    assert prod.Level() == sc.level - 1
+    acc = prod
+    for rot in rots:                                              # 16-slot partial sums by rotate-and-sum
+        acc = ev.AddNew(acc, ev.RotateNew(acc, rot, rks))
+    tripled = mkckks.NewCiphertext(params, sc.names, acc.Level(), acc.Scale)
+    ev.MultByConst(acc, 3, tripled)
+    res = ev.SubNew(tripled, acc)                                 # 3*acc - acc = 2*acc
+    got = sc.decrypt_decode(res.ids, res.download(), res.Scale)
+    xw = x * w
+    want = 2 * sum(np.roll(xw, -s) for s in range(16))
+    assert _max_log2_err(got, want) <= sc.precision_bound(12) + 5      # 32 summed terms: 5 more bits
