@@ -361,3 +361,32 @@ def test_overlap_switch_does_not_change_results(pair):
             assert (out.download() == ref).all()
     finally:
         check(lib().mkhe_set_overlap(pair.params.ctx, 1))
+
+
+def test_ntt_word_boundary_patterns(pair):
+    """inputs whose 32-bit words sit on the boundaries of the signed-digit split used by the NTT kernels
+    (low word 0x80000000 / 0x7fffffff / 0xffffffff / 0, values up to 4q - 1), forward and inverse"""
+    mk, ks = pair.mk, pair.ks
+    nq = len(pair.Q)
+    N = pair.N
+    pats = np.array([0x80000000, 0x7fffffff, 0xffffffff, 0, 1, 0x100000000, 0x17fffffff, 0x180000000], dtype=np.uint64)
+    a = np.empty((1, nq, N), dtype=np.uint64)
+    for j, q in enumerate(pair.Q):
+        hi = pair.rng.integers(0, (4 * q) >> 32, N, dtype=np.uint64) << np.uint64(32)
+        v = hi | pats[pair.rng.integers(0, len(pats), N)]
+        v = np.where(v >= np.uint64(4 * q), v % np.uint64(q), v)
+        v[:4] = [4 * q - 1, q - 1, q, 2 * q + 0x80000000]
+        a[0, j] = v
+    src = mk.DeviceLimbs(pair.params, 1, nq).upload(a)
+    dst = mk.DeviceLimbs(pair.params, 1, nq)
+    mk.ntt(pair.params, src, dst)
+    got = dst.download()
+    for j in range(nq):
+        assert (got[0][j] == ks.ringQ.ntt(j, a[0][j])).all()
+    # inverse on canonical inputs with the same word patterns
+    b = np.stack([a[0, j] % np.uint64(q) for j, q in enumerate(pair.Q)])[None]
+    src.upload(b)
+    mk.ntt(pair.params, src, dst, inverse=True)
+    got = dst.download()
+    for j in range(nq):
+        assert (got[0][j] == ks.ringQ.intt(j, b[0][j])).all()
