@@ -38,7 +38,9 @@ int mkhe_device_count(void);
 
 /* ---- context: mkrlwe.NewKeySwitcher keyswitch.go:33-47 (+ NewDecomposer basis_extension.go:368,
  *      lattigo rlwe.NewKeySwitcher / ring.NewRing tables).  psiQ/psiP: optional primitive 2N-th
- *      roots (plain) per modulus, e.g. InvMForm(ring.NttPsi[i][N/2]); NULL = lattigo's own rule. */
+ *      roots (plain) per modulus, e.g. InvMForm(ring.NttPsi[i][N/2]); NULL = lattigo's own rule.
+ *      Moduli: distinct primes < 2^60 with q = 1 mod 2N (every prime of the reference's parameter sets is <= 60 bits
+ *      and < 2^60; the lazy butterflies need 4q < 2^62); logN in [10, 16]. */
 int  mkhe_ctx_create(mkhe_ctx** out, int logN, const uint64_t* Q, int nQ, const uint64_t* P, int nP,
                      int gamma, const uint64_t* psiQ, const uint64_t* psiP, int device);
 void mkhe_ctx_destroy(mkhe_ctx* ctx);

@@ -84,7 +84,7 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     }
     for (int i = 0; i < mall; ++i) {
         const u64 q = moduli[i];
-        if (q >= (1ull << 61) || !is_prime(q) || (q - 1) % (2ull * N) != 0) throw Error("mkhe: moduli must be primes < 2^61 with q = 1 mod 2N");
+        if (q >= (1ull << 60) || !is_prime(q) || (q - 1) % (2ull * N) != 0) throw Error("mkhe: moduli must be primes < 2^60 with q = 1 mod 2N");   // 4q < 2^62: range of the lazy butterflies
         for (int j = 0; j < i; ++j) if (moduli[j] == q) throw Error("mkhe: repeated modulus");
     }
     if (mall > NTT_MAX_SLOTS) throw Error("mkhe: too many moduli");

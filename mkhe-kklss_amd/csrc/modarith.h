@@ -24,7 +24,7 @@ typedef int32_t i32;
 
 // Per-modulus constants, uniform per workgroup (live in SGPRs).
 struct Mod {
-    u64 q;        // modulus, < 2^61
+    u64 q;        // modulus, < 2^60 (enforced by the Context constructor)
     u64 q2;       // 2q
     u32 ninv32;   // -q^-1 mod 2^32
     u32 pad;
