@@ -40,8 +40,8 @@ def run_distributed(args):
     if args.shard == "limb":
         # every rank: full operands and (the owned limbs of) every party's keys; x, y stay local
         rlk = {n: synth_party_keys(pset, names.index(n), args.seed) for n in names}
-        backend = HipLimbBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank)
-        smr = LimbShardedMulRelin(backend, dist)
+        backend = HipLimbBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank, sync=args.dist_sync)
+        smr = LimbShardedMulRelin(backend, dist, force_collectives=bool(os.environ.get("MKHE_FORCE_COLLECTIVES")))
         full = backend.out
         exchanged = 8 * Nn * (k * npp + k * L + 3 * k * npp + (k + 1) * L)
         sharding = "RNS limbs (every rank: all parties, its moduli), see mkhe_kklss_amd/dist.py LimbShardedMulRelin"

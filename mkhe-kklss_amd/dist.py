@@ -220,13 +220,17 @@ def assign_moduli(nq, np_, world):
 
 
 class LimbShardedMulRelin:
-    """Orchestrates one limb-sharded MulAndRelin: four engine phases around three exchanges + the output exchange."""
+    """Orchestrates one limb-sharded MulAndRelin: four engine phases around three exchanges + the output exchange.
+    force_collectives: issue the all-reduces even at world size 1 (exercises the stream plumbing on one GPU)."""
 
-    def __init__(self, backend, dist=None, group=None):
-        self.b, self.dist, self.group = backend, dist, group
+    def __init__(self, backend, dist=None, group=None, force_collectives=False):
+        self.b, self.dist, self.group, self.force = backend, dist, group, force_collectives
 
     def _all_reduce(self, t):
-        if self.dist is not None and self.dist.get_world_size(self.group) > 1:
+        if self.dist is not None and (self.force or self.dist.get_world_size(self.group) > 1):
+            if hasattr(self.b, "all_reduce"):
+                self.b.all_reduce(self.dist, t, self.group)          # stream-ordered, no host synchronisation
+                return
             self.b.before_collective()
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
             self.b.after_collective()
@@ -243,9 +247,11 @@ class LimbShardedMulRelin:
 class HipLimbBackend:
     """One rank of LimbShardedMulRelin on its MI355X through the C ABI (mkhe_ctx_set_owned, mkhe_lsh_phase)."""
 
-    def __init__(self, params, names, rank, world, op0_host, op1_host, rlk_host, level, torch, device_index):
+    def __init__(self, params, names, rank, world, op0_host, op1_host, rlk_host, level, torch, device_index, sync="stream"):
         """full operands uint64[1+k][L][N] and the keys {name: (b, d, v)} of ALL parties (only the owned limbs of the
-        keys are ever read)."""
+        keys are ever read).  sync = "stream": the collectives are enqueued with the engine's stream as torch's current
+        stream (torch.cuda.ExternalStream), so RCCL orders itself against the engine's kernels with events and the host
+        never waits inside a step; "host": drain the engine stream, all-reduce on torch's stream, wait for it."""
         import ctypes as C
         from . import mkrlwe, _abi
         from ._abi import check, handle_array, lib
@@ -267,6 +273,13 @@ class HipLimbBackend:
         self.b1 = self.harr([self.keys[n][0].h for n in self.names])
         self.d0 = self.harr([self.keys[n][1].h for n in self.names])
         self.v0 = self.harr([self.keys[n][2].h for n in self.names])
+        if sync == "stream":
+            self.ext = torch.cuda.ExternalStream(int(params.stream()), device=dev)
+            self.all_reduce = self._all_reduce_on_engine_stream
+
+    def _all_reduce_on_engine_stream(self, dist, t, group):
+        with self.torch.cuda.stream(self.ext):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
     def phase(self, ph):
         w = self.C.c_size_t(0)

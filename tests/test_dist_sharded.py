@@ -256,3 +256,36 @@ def test_limb_sharded_exchange_pattern_gloo_world2(tmp_path):
     out = str(tmp_path / "ok.npy")
     mp.spawn(_limb_worker, args=(2, port, ["u0", "u1"], out), nprocs=2, join=True)
     assert np.load(out)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sync", ["stream", "host"])
+def test_limb_sharded_with_rccl_world1(sync):
+    """the real collective path on one GPU: a one-rank RCCL process group, the all-reduces forced, ordered on the
+    engine's stream (torch.cuda.ExternalStream) or through the host; the result must still equal the oracle's"""
+    import torch
+    import torch.distributed as dist
+    from mkhe_kklss_amd import mkckks
+    from mkhe_kklss_amd.dist import HipLimbBackend, LimbShardedMulRelin
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        pset = H.small_ckks(12, 3)
+        names = ["u0", "u1"]
+        ks, level, op0, op1, rlk, u, ref = make_case(pset, names, 29)
+        params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"])
+        params.AddCRS(-1, u)
+        b = HipLimbBackend(params, names, 0, 1, op0, op1, rlk, level, torch, 0, sync=sync)
+        smr = LimbShardedMulRelin(b, dist, force_collectives=True)
+        for _ in range(3):                     # back-to-back steps: nothing may overtake the collectives
+            out = smr.run()
+        params.sync()
+        torch.cuda.synchronize()
+        assert (out.download() == ref).all()
+    finally:
+        dist.destroy_process_group()
