@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(PW_THREADS) inner_product_kernel(InnerProductA
     const long obase = (long)o * a.out_outer + (long)m * a.N;
     for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
         u64 acc = 0;
-#pragma unroll 4
+// (runtime trip count: the optimizer keeps this loop rolled)
         for (int t = 0; t < a.nterms; ++t) {
             u64 p = mont_mul_lazy(a.a[t][base + n], a.b[t][base + n], q, ninv);
             acc = csub(acc + p, q2);
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
         u64* outn = out + a.c1_item;
         for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
             u64 acc = 0, accn = 0;
-#pragma unroll 2
+// (runtime trip count: the optimizer keeps this loop rolled)
             for (int i = 0; i < a.nb; ++i) {
                 const u64 h = ah[(long)i * a.digit_stride + n];
                 acc = csub(acc + mont_mul_lazy(bg[(long)i * a.digit_stride + n], h, q, ninv), q2);
@@ -121,13 +121,13 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
     const u64* bg2 = a.ah2[item] ? a.bg2[item] + (long)m * a.N : nullptr;
     for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
         u64 acc = 0;
-#pragma unroll 2
+// (runtime trip count: the optimizer keeps this loop rolled)
         for (int i = 0; i < a.nb; ++i) {
             u64 p = mont_mul_lazy(bg[(long)i * a.digit_stride + n], ah[(long)i * a.digit_stride + n], q, ninv);
             acc = csub(acc + p, q2);
         }
         if (ah2) {
-#pragma unroll 2
+// (runtime trip count: the optimizer keeps this loop rolled)
             for (int i = 0; i < a.nb; ++i) {
                 u64 p = mont_mul_lazy(bg2[(long)i * a.digit_stride + n], ah2[(long)i * a.digit_stride + n], q, ninv);
                 acc = csub(acc + p, q2);
