@@ -83,6 +83,11 @@ struct ModDownBatchArgs {
     int nitems, level, np, N;
     const int* qlist;        // limb-sharded evaluation: the Q limbs to produce (device list) or NULL = 0..level
     int nqlist;
+    // items are processed group by group in parallel (blockIdx.z = group); the items of one group (same destination)
+    // one after the other by the same thread.  group g = items order[gstart[g] .. gstart[g+1])
+    unsigned char order[EXT_MAX_ITEMS];
+    unsigned char gstart[EXT_MAX_ITEMS + 1];
+    int ngroups;
 };
 void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st);
 

@@ -144,13 +144,18 @@ void launch_ext_inner(const ExtInnerArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(ext_inner_kernel, dim3(bx, a.nslots, a.nitems), dim3(PW_THREADS), 0, st, a);
 }
 
+typedef const __attribute__((address_space(4))) ModDownBatchArgs* mdb_kargs;
 __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchArgs a) {
+    mdb_kargs ka = (mdb_kargs)__builtin_amdgcn_kernarg_segment_ptr();
     const int n = blockIdx.x * PW_THREADS + threadIdx.x;
     if (n >= a.N) return;
-    for (int item = 0; item < a.nitems; ++item) {
+    const int g = blockIdx.z;
+    for (int k = ka->gstart[g]; k < ka->gstart[g + 1]; ++k) {
+        const int item = ka->order[k];
         const u64* xq = a.c1 + (long)item * a.c1_item;
         const u64* xp = xq + a.p_offset;
-        u64* dst = a.dst[item];
+        u64* dst = ka->dst[item];
+        const int acc = ka->accumulate[item];
         u64 y[MAXP];
         double vi = 0.0;
 #pragma unroll
@@ -181,17 +186,33 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
             const u64 lift = rhi - hhi + mq.q + a.t.vtimesqmodp[(long)j * (a.np + 1) + v];
             const u64 x = xq[(long)j * a.N + n];
             u64 z = mont_mul(lift + mq.q2 - x, a.t.downparam[j], mq.q, mq.ninv32);
-            if (a.accumulate[item]) z = csub(dst[(long)j * a.N + n] + z, mq.q);
+            if (acc) z = csub(dst[(long)j * a.N + n] + z, mq.q);
             dst[(long)j * a.N + n] = z;
         }
     }
 }
-void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st) {
+void launch_moddown_batch(const ModDownBatchArgs& a_in, hipStream_t st) {
+    // group the items by destination: different destinations are independent, equal ones are applied in order
+    ModDownBatchArgs a = a_in;
+    int pos = 0; a.ngroups = 0;
+    bool used[EXT_MAX_ITEMS] = {};
+    for (int i = 0; i < a.nitems; ++i) {
+        if (used[i]) continue;
+        a.gstart[a.ngroups++] = (unsigned char)pos;
+        for (int k = i; k < a.nitems; ++k) if (!used[k] && a.dst[k] == a.dst[i]) { a.order[pos++] = (unsigned char)k; used[k] = true; }
+    }
+    a.gstart[a.ngroups] = (unsigned char)pos;
+    if (a.ngroups < 1) return;
     const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    int by = a.qlist ? a.nqlist : a.level + 1;
-    if (by > 16) by = 16;
+    // the P-limb part (two Montgomery products and two float64 divisions per coefficient) is shared by all Q limbs a
+    // thread produces: few limb slices per coefficient, the parallelism comes from the destination groups
+    const int nj = a.qlist ? a.nqlist : a.level + 1;
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("MKHE_MD_BY"); cap = (e && *e) ? atoi(e) : 4; }
+    int by = nj < cap ? nj : cap;
+    if (a.ngroups * by < 8) by = nj < 8 ? nj : 8;          // a single external product: spread over the limbs instead
     if (by < 1) return;
-    hipLaunchKernelGGL(moddown_batch_kernel, dim3(bx, by), dim3(PW_THREADS), 0, st, a);
+    hipLaunchKernelGGL(moddown_batch_kernel, dim3(bx, by, a.ngroups), dim3(PW_THREADS), 0, st, a);
 }
 
 // ------------------------------------------------------------------ tensor (step D)
