@@ -63,6 +63,9 @@ void* mkhe_swk_devptr(mkhe_swk* swk);
 
 /* ---- Ciphertext handles: mkrlwe.Ciphertext elements.go:17-33 */
 int  mkhe_ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, mkhe_ct** out);
+/* same without the zero fill: for ciphertexts that are the output of the next engine call (every entry point writes all
+ * limbs of its ctOut), e.g. the result of Evaluator.MulRelinNew */
+int  mkhe_ct_create_uninit(mkhe_ctx* ctx, int n, const int* ids, int limbs, mkhe_ct** out);
 void mkhe_ct_destroy(mkhe_ctx* ctx, mkhe_ct* ct);
 int  mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host);
 int  mkhe_ct_upload_poly_limbs(mkhe_ctx* ctx, mkhe_ct* ct, int slot, const uint64_t* const* limbs);

@@ -30,6 +30,7 @@ SIGNATURES = {
     "mkhe_swk_download": (C.c_int, [vp, vp, u64p]),
     "mkhe_swk_devptr": (vp, [vp]),
     "mkhe_ct_create": (C.c_int, [vp, C.c_int, i32p, C.c_int, vpp]),
+    "mkhe_ct_create_uninit": (C.c_int, [vp, C.c_int, i32p, C.c_int, vpp]),
     "mkhe_ct_destroy": (None, [vp, vp]),
     "mkhe_ct_upload": (C.c_int, [vp, vp, u64p]),
     "mkhe_ct_upload_poly_limbs": (C.c_int, [vp, vp, C.c_int, vpp]),

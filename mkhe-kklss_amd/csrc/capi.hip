@@ -88,8 +88,16 @@ int mkhe_swk_download(mkhe_ctx* ctx, const mkhe_swk* swk, uint64_t* host) {
 void* mkhe_swk_devptr(mkhe_swk* swk) { return swk ? swk->s.d : nullptr; }
 
 // ---- ciphertexts
+static void ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, bool zero, mkhe_ct** out);
 int mkhe_ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, mkhe_ct** out) {
-    MKHE_TRY({
+    MKHE_TRY(ct_create(ctx, n, ids, limbs, true, out))
+}
+int mkhe_ct_create_uninit(mkhe_ctx* ctx, int n, const int* ids, int limbs, mkhe_ct** out) {
+    MKHE_TRY(ct_create(ctx, n, ids, limbs, false, out))
+}
+} // extern "C"
+static void ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, bool zero, mkhe_ct** out) {
+    {
         Context* c = ctx->c;
         if (n < 0 || n > 32 || limbs < 1 || limbs > c->nq) throw Error("mkhe_ct_create: bad shape");
         MKHE_HIP(hipSetDevice(c->device));
@@ -98,10 +106,11 @@ int mkhe_ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, mkhe_ct** ou
         for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (ids[i] == ids[j]) { delete t; throw Error("mkhe_ct_create: repeated id"); }
         const size_t w = (size_t)(1 + n) * limbs * c->N;
         try { t->c.d = c->pool_alloc(w); } catch (...) { delete t; throw; }
-        MKHE_HIP(hipMemsetAsync(t->c.d, 0, w * sizeof(u64), c->stream));
+        if (zero) MKHE_HIP(hipMemsetAsync(t->c.d, 0, w * sizeof(u64), c->stream));
         *out = t;
-    })
+    }
 }
+extern "C" {
 void mkhe_ct_destroy(mkhe_ctx* ctx, mkhe_ct* ct) {
     if (!ct) return;
     if (ct->c.d) { if (ctx) ctx->c->pool_free(ct->c.d, (size_t)(1 + ct->c.n) * ct->c.limbs * ctx->c->N); else (void)hipFree(ct->c.d); }

@@ -40,12 +40,12 @@ class Parameters(mkrlwe.Parameters):
 class Ciphertext(mkrlwe.Ciphertext):
     """mkbfv.Ciphertext (elements.go:5-11): always at params.MaxLevel()."""
 
-    def __init__(self, params, idset):
-        super().__init__(params, idset, params.MaxLevel())
+    def __init__(self, params, idset, zero=True):
+        super().__init__(params, idset, params.MaxLevel(), zero)
 
 
-def NewCiphertext(params, idset):
-    return Ciphertext(params, idset)
+def NewCiphertext(params, idset, zero=True):
+    return Ciphertext(params, idset, zero)
 
 
 class RelinearizationKey:
@@ -154,7 +154,7 @@ class Evaluator:
         params = self.params
         if -1 not in params.CRS:
             raise MkheError("mkhe: CRS[-1] (u) has not been uploaded")
-        ctOut = self.newCiphertextBinary(op0, op1)
+        ctOut = NewCiphertext(params, op0.IDSet() | op1.IDSet(), zero=False)        # every limb is written by the engine
         k0 = [rlkSet.GetRelinearizationKey(i) for i in op0.ids]
         k1 = [rlkSet.GetRelinearizationKey(i) for i in op1.ids]
         b1 = [k.Value[0].Value[0].h for k in k1]

@@ -34,16 +34,16 @@ class Parameters(mkrlwe.Parameters):
 class Ciphertext(mkrlwe.Ciphertext):
     """mkckks.Ciphertext (mkckks/elements.go:5-17): mkrlwe.Ciphertext + Scale."""
 
-    def __init__(self, params, idset, level, scale):
-        super().__init__(params, idset, level)
+    def __init__(self, params, idset, level, scale, zero=True):
+        super().__init__(params, idset, level, zero)
         self.Scale = float(scale)
 
     def ScalingFactor(self):
         return self.Scale
 
 
-def NewCiphertext(params, idset, level, scale):
-    return Ciphertext(params, idset, level, scale)
+def NewCiphertext(params, idset, level, scale, zero=True):
+    return Ciphertext(params, idset, level, scale, zero)
 
 
 class Evaluator:
@@ -174,13 +174,13 @@ class Evaluator:
 
     # ---- MulRelinHoistedNew / mulRelinHoisted (evaluator.go:558-581)
     def MulRelinHoistedNew(self, op0, op1, op0Hoisted, op1Hoisted, rlkSet):
-        ctOut = self.newCiphertextBinary(op0, op1)
-        ctOut.Scale = op0.ScalingFactor() * op1.ScalingFactor()
+        ctOut = NewCiphertext(self.params, op0.IDSet() | op1.IDSet(), min(op0.Level(), op1.Level()),
+                              op0.ScalingFactor() * op1.ScalingFactor(), zero=False)      # newCiphertextBinary, :306-313
         self.ksw.MulAndRelinHoisted(op0, op1, op0Hoisted, op1Hoisted, rlkSet, ctOut)
         nb, scale = self.nbRescales(ctOut, self.params.Scale())
         if nb == 0 or ctOut.Level() == 0:
             return ctOut
-        res = NewCiphertext(self.params, ctOut.IDSet(), ctOut.Level() - nb, scale)
+        res = NewCiphertext(self.params, ctOut.IDSet(), ctOut.Level() - nb, scale, zero=False)
         check(lib().mkhe_rescale(self.params.ctx, ctOut.h, nb, res.h))
         return res
 

@@ -218,7 +218,8 @@ class Ciphertext:
     """mkrlwe.Ciphertext (elements.go:17-33): Value["0"] plus one poly per party id, all at the same
     level, coefficient domain.  Device layout uint64[1+n][level+1][N]; `ids` fixes the slot order."""
 
-    def __init__(self, params, idset, level):
+    def __init__(self, params, idset, level, zero=True):
+        """zero=False: no zero fill (the ciphertext is about to be the ctOut of an engine call, which writes all of it)"""
         self.params = params
         self.ids = sorted(idset)
         for i in self.ids:
@@ -226,7 +227,8 @@ class Ciphertext:
         self._level = int(level)
         arr = np.asarray([params.party_index(i) for i in self.ids], dtype=np.int32)
         h = C.c_void_p()
-        check(lib().mkhe_ct_create(params.ctx, len(self.ids), arr.ctypes.data_as(_abi.i32p), level + 1, C.byref(h)))
+        create = lib().mkhe_ct_create if zero else lib().mkhe_ct_create_uninit
+        check(create(params.ctx, len(self.ids), arr.ctypes.data_as(_abi.i32p), level + 1, C.byref(h)))
         self.h = h
 
     def IDSet(self):
