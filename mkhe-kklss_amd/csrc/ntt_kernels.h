@@ -16,8 +16,15 @@
 //     X(C->B)  half-wave local, store in layout B (256-B contiguous per half wave)
 //   inverse (Gentleman-Sande, lattigo ring.InvNTT / InvNTTLazy) is the mirror image.
 //
-// LDS word address = p ^ ((p >> 5) & 31) (p = coefficient index): conflict-free for every
-// layout above under the 32-bank rule of ds_read_b32 / ds_write_b32.
+// LDS image of a plane: forward kernels p + (p >> 5) (padded: every layout is base + r*stride with compile-time
+// strides, the DS instructions carry immediate offsets), inverse kernel p ^ ((p >> 5) & 31) (swizzled: fewer live
+// registers there); both conflict-free for every layout above under the 32-bank rule of ds_read_b32 / ds_write_b32.
+//
+// Arithmetic: signed-digit Montgomery products (modarith.h mont_mul_sd; twiddles and constants pre-split); moduli
+// with 34q < 2^63 run the forward butterflies on signed lazy values without any reduction (MODE 1), larger ones as
+// Harvey butterflies reduced every stage (MODE 0).  Persistent workgroups walk a slot-major job list.  Launches with
+// fewer limbs than CUs and every N = 2^16 launch run split (NttBatch::split): a streaming cross-half radix-2 pass +
+// two half-size register-resident sub-transforms per limb.
 //
 // Replaces: lattigo ring.NTTLvl / InvNTTLvl / InvNTTLazyLvl as called from
 // mkrlwe/keyswitch.go:29-30,58,88,114-115,206 and keyswitch_hoisted.go:36-37,120-143.
