@@ -252,8 +252,9 @@ def main():
     ap.add_argument("--shard", default="limb", choices=["limb", "party"],
                     help="N > 1: shard the RNS limbs (default: x, y stay local, ~40 MB exchanged per step) or the parties "
                          "(the paper's structure, ~135 MB all-reduced per step)")
-    ap.add_argument("--dist-sync", default="stream", choices=["stream", "host"],
-                    help="N > 1, limb sharding: order the collectives on the engine's stream (default) or through the host")
+    ap.add_argument("--dist-sync", default="auto", choices=["auto", "stream", "host"],
+                    help="N > 1, limb sharding: order the collectives on the engine's stream or through the host "
+                         "(auto: an untimed probe of both after the warm-up picks the faster one)")
     ap.add_argument("--scheme", default="ckks", choices=["ckks", "bfv"],
                     help="ckks = BASELINE.json headline metric (default); bfv = the mkbfv MulRelin line (single GPU)")
     args = ap.parse_args()

@@ -26,8 +26,14 @@ def run_distributed(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    backend_name = os.environ.get("MKHE_DIST_BACKEND", "nccl")          # "gloo" + MKHE_DIST_ONE_DEVICE=1: functional test of
+    if os.environ.get("MKHE_DIST_ONE_DEVICE"):                          # the N > 1 path on a single-GPU box (timings meaningless)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if backend_name == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend_name, rank=rank, world_size=world)
     pset = H.PN15QP880 if args.params == "PN15QP880" else H.PN14QP439
     k = args.parties
     names = ["user%d" % i for i in range(k)]
@@ -40,7 +46,8 @@ def run_distributed(args):
     if args.shard == "limb":
         # every rank: full operands and (the owned limbs of) every party's keys; x, y stay local
         rlk = {n: synth_party_keys(pset, names.index(n), args.seed) for n in names}
-        backend = HipLimbBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank, sync=args.dist_sync)
+        backend = HipLimbBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank,
+                                 sync="stream" if args.dist_sync == "auto" else args.dist_sync)
         smr = LimbShardedMulRelin(backend, dist, force_collectives=bool(os.environ.get("MKHE_FORCE_COLLECTIVES")))
         full = backend.out
         exchanged = 8 * Nn * (k * npp + k * L + 3 * k * npp + (k + 1) * L)
@@ -63,6 +70,25 @@ def run_distributed(args):
     for _ in range(args.warmup):
         step()
     params.sync(); torch.cuda.synchronize(); dist.barrier()
+    sync_mode = getattr(backend, "sync", "host")
+    if args.shard == "limb" and args.dist_sync == "auto":
+        # untimed probe: three steps with each way of ordering the collectives, every rank adopts the faster one
+        probe = {}
+        for mode in ("stream", "host"):
+            backend.set_sync(mode)
+            step()
+            params.sync(); torch.cuda.synchronize(); dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            params.sync(); torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            probe[mode] = float(tt.item())
+        sync_mode = min(probe, key=probe.get)
+        backend.set_sync(sync_mode)
+        step()
+        params.sync(); torch.cuda.synchronize(); dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -77,7 +103,7 @@ def run_distributed(args):
                    scaling="strong", vs_baseline=None, dtype="u64", data="synthetic",
                    config=dict(workload="mkckks %d-party MulRelin (hoist + MulAndRelinHoisted + Rescale), %s N=2^%d, %d Q + %d P limbs, "
                                         "sharded over %d GPUs" % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["P"]), world),
-                               parties=k, params=args.params, seed=args.seed, sharding=sharding,
+                               parties=k, params=args.params, seed=args.seed, sharding=sharding, collective_ordering=sync_mode,
                                allreduce_bytes_per_step=exchanged),
                    roofline=None, cpu_baseline=None)
     dist.barrier()

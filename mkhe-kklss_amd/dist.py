@@ -273,9 +273,16 @@ class HipLimbBackend:
         self.b1 = self.harr([self.keys[n][0].h for n in self.names])
         self.d0 = self.harr([self.keys[n][1].h for n in self.names])
         self.v0 = self.harr([self.keys[n][2].h for n in self.names])
+        self.ext = torch.cuda.ExternalStream(int(params.stream()), device=dev)
+        self.set_sync(sync)
+
+    def set_sync(self, sync):
+        """"stream": collectives ordered on the engine stream; "host": through the host (see __init__)"""
+        self.sync = sync
         if sync == "stream":
-            self.ext = torch.cuda.ExternalStream(int(params.stream()), device=dev)
             self.all_reduce = self._all_reduce_on_engine_stream
+        elif "all_reduce" in self.__dict__:
+            del self.all_reduce
 
     def _all_reduce_on_engine_stream(self, dist, t, group):
         with self.torch.cuda.stream(self.ext):

@@ -289,3 +289,50 @@ def test_limb_sharded_with_rccl_world1(sync):
         assert (out.download() == ref).all()
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_gpu_worker(rank, world, port, mode, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mkhe_kklss_amd import mkckks
+    from mkhe_kklss_amd.dist import HipLimbBackend, HipShardBackend, LimbShardedMulRelin, ShardedMulRelin
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # gloo moves CUDA tensors through the host
+    pset = H.small_ckks(11, 3)
+    names = ["u0", "u1", "u2"]
+    ks, level, op0, op1, rlk, u, ref = make_case(pset, names, 31)
+    params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"])
+    params.AddCRS(-1, u)
+    if mode == "party":
+        b = HipShardBackend(params, names, rank, world, op0, op1, rlk, level, torch, 0)
+        ShardedMulRelin(b, dist).run()
+        got = b.full.download()
+    else:
+        b = HipLimbBackend(params, names, rank, world, op0, op1, rlk, level, torch, 0, sync=mode)
+        got = LimbShardedMulRelin(b, dist).run().download()
+    ok = bool((got == ref).all())
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, np.array([ok]))
+    else:
+        assert ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["host", "stream", "party"])
+def test_two_real_ranks_on_one_gpu(tmp_path, mode):
+    """two PROCESSES, each with its own engine context on GPU 0, exchanging through torch.distributed (gloo carries the
+    device tensors through the host: the only single-GPU way to run world size 2 for real): limb sharding with both
+    synchronisation modes, and party sharding"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_two_rank_gpu_worker, args=(2, port, mode, out), nprocs=2, join=True)
+    assert np.load(out)[0]
