@@ -8,18 +8,19 @@
 using namespace mkhe;
 #define CHECK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1;}}while(0)
 
+// the butterflies of csrc/ntt_kernels.hip (signed-digit products; twiddles / q in signed-split form)
 __device__ __forceinline__ void bf_nr(u64& U, u64& V, u64 w, u64 q, u64 q2, u32 ninv) {
-    u64 Tm = mont_mul_lazy(V, w, q, ninv); u64 u = U; U = u + Tm; V = u + (q2 - Tm);
+    const i64 Tm = mont_mul_sd((i64)V, w, sd_split(q), ninv); const i64 u = (i64)U; U = (u64)(u + Tm); V = (u64)(u - Tm);
 }
 __device__ __forceinline__ void bf_cs(u64& U, u64& V, u64 w, u64 q, u64 q2, u32 ninv) {
-    u64 Tm = mont_mul_lazy(V, w, q, ninv); u64 u = csub(U, q2); U = u + Tm; V = u + (q2 - Tm);
+    u64 Tm = mont_mul_sdu(V, w, sd_split(q), q, ninv); u64 u = csub(U, q2); U = u + Tm; V = u + (q2 - Tm);
 }
 template <int MODE, int THREADS>
 __global__ void __launch_bounds__(THREADS) k(u64* out, const u64* tw, u64 q, u32 ninv, int reps, unsigned long long* clk) {
     u64 x[32], w[16];
     const u64 q2 = 2 * q;
     for (int r = 0; r < 32; ++r) x[r] = (threadIdx.x * 977 + r * 131 + 7) % q;
-    for (int k2 = 0; k2 < 16; ++k2) w[k2] = tw[(threadIdx.x * 16 + k2) & 1023];
+    for (int k2 = 0; k2 < 16; ++k2) w[k2] = sd_split(tw[(threadIdx.x * 16 + k2) & 1023]);
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll 1
@@ -32,7 +33,7 @@ __global__ void __launch_bounds__(THREADS) k(u64* out, const u64* tw, u64 q, u32
                 if (MODE == 1) bf_nr(x[i0], x[i1], w[g >> B], q, q2, ninv); else bf_cs(x[i0], x[i1], w[g >> B], q, q2, ninv);
             }
         }
-        if (MODE == 1) { for (int r = 0; r < 32; ++r) x[r] &= 0x00ffffffffffffffull; }   // keep values bounded (cheap, not counted)
+        if (MODE == 1) { for (int r = 0; r < 32; ++r) x[r] = (u64)((i64)(x[r] << 8) >> 8); }   // keep |x| < 2^55 (cheap, not counted)
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
