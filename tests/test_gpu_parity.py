@@ -390,3 +390,56 @@ def test_ntt_word_boundary_patterns(pair):
     got = dst.download()
     for j in range(nq):
         assert (got[0][j] == ks.ringQ.intt(j, b[0][j])).all()
+
+
+def test_limb_pointer_entry_points(pair):
+    """the upload / download entry points the cgo shim uses (ring.Poly.Coeffs is [][]uint64: one pointer per limb):
+    mkhe_swk_upload_limbs, mkhe_ct_upload_poly_limbs, mkhe_ct_download_poly_limbs"""
+    import ctypes as C
+    from mkhe_kklss_amd._abi import check, lib
+    mk = pair.mk
+    N, nq, m = pair.N, len(pair.Q), len(pair.Q) + len(pair.P)
+    host = H.uniform_swk(pair.rng, pair.ks)
+    limbs = [np.ascontiguousarray(host[i, j]) for i in range(host.shape[0]) for j in range(m)]       # separate heap objects
+    ptrs = (C.c_void_p * len(limbs))(*[l.ctypes.data for l in limbs])
+    swk = mk.NewSwitchingKey(pair.params)
+    check(lib().mkhe_swk_upload_limbs(pair.params.ctx, swk.h, ptrs, host.shape[0]))
+    assert (swk.download() == host).all()
+    ct = mk.NewCiphertext(pair.params, ["a", "b"], pair.maxlevel)
+    polys = H.uniform_ct(pair.rng, pair.ks, 2, nq)
+    for slot in range(3):
+        pl = [np.ascontiguousarray(polys[slot, l]) for l in range(nq)]
+        pp = (C.c_void_p * nq)(*[l.ctypes.data for l in pl])
+        check(lib().mkhe_ct_upload_poly_limbs(pair.params.ctx, ct.h, slot, pp))
+    assert (ct.download() == polys).all()
+    out = [np.zeros(N, dtype=np.uint64) for _ in range(nq)]
+    po = (C.c_void_p * nq)(*[l.ctypes.data for l in out])
+    check(lib().mkhe_ct_download_poly_limbs(pair.params.ctx, ct.h, 2, po))
+    assert (np.stack(out) == polys[2]).all()
+
+
+def test_ckks_rescale_new_and_errors(pair):
+    """mkckks.Evaluator.RescaleNew (evaluator.go:359-414): scale loop on the host, division on the device, the error cases"""
+    from mkhe_kklss_amd import mkckks
+    if pair.maxlevel < 2:
+        pytest.skip("needs three limbs")
+    params = pair.params
+    ev = mkckks.Evaluator.__new__(mkckks.Evaluator)
+    ev.params, ev.ksw = params, pair.ksw
+    L = pair.maxlevel + 1
+    h = H.uniform_ct(pair.rng, pair.ks, 1, L)
+    scale = float(pair.Q[pair.maxlevel]) * float(pair.Q[pair.maxlevel - 1]) * 2.0 ** 30
+    ct = mkckks.NewCiphertext(params, ["a"], pair.maxlevel, scale).upload(h)
+    res = ev.RescaleNew(ct, 2.0 ** 30)
+    nb, sc = pair.ks.ckks_nb_rescales(pair.maxlevel, scale, 2.0 ** 30)
+    assert nb == 2 and res.Level() == pair.maxlevel - 2 and res.Scale == sc
+    ref = np.stack([pair.ks.ringQ.div_round_last_many(h[s], nb)[0] for s in range(2)])
+    assert (res.download() == ref).all()
+    with pytest.raises(pair.mk.MkheError, match="minScale is 0"):
+        ev.RescaleNew(ct, 0)
+    low = mkckks.NewCiphertext(params, ["a"], 0, scale)
+    with pytest.raises(pair.mk.MkheError, match="already at level 0"):
+        ev.RescaleNew(low, 2.0 ** 30)
+    ct.Scale = 0.0
+    with pytest.raises(pair.mk.MkheError, match="scale is 0"):
+        ev.RescaleNew(ct, 2.0 ** 30)
