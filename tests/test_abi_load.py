@@ -51,3 +51,22 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), "%s mentions the oracle" % f
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """cgo needs a C header: include/mkhe.h must compile as C99, and a C translation unit that references every
+    declared entry point must link against libmkhe_hip.so (nothing is called: there is no GPU here)."""
+    import subprocess
+    from mkhe_kklss_amd import _abi
+    hdr = os.path.join(ROOT, "include", "mkhe.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    src = tmp_path / "use.c"
+    body = "\n".join("    p[%d] = (void*)%s;" % (i, s) for i, s in enumerate(declared_symbols()))
+    src.write_text('#include "mkhe.h"\n#include <stdio.h>\nint main(void) {\n    void* p[%d];\n%s\n'
+                   '    printf("%%d entry points\\n", (int)(sizeof p / sizeof p[0]));\n    return p[0] == 0;\n}\n'
+                   % (len(declared_symbols()), body))
+    exe = tmp_path / "use"
+    libdir = os.path.dirname(_abi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lmkhe_hip", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
+    assert os.path.exists(exe)
