@@ -1,0 +1,423 @@
+// mkhe.hpp -- C++ host-side mirror of the reference packages mkrlwe / mkckks / mkbfv over the C ABI (mkhe.h).
+//
+// The reference is Go; this image has no Go toolchain, so the compiled-language host layer a user of the reference
+// would program against is given here in C++ (header-only, C++17): the same type and method names, argument meaning
+// and error behaviour as the Go API (a Go `panic` becomes a thrown mkhe::Error carrying the same text), all polynomial
+// data resident in HBM behind RAII handles.  Reference file:line per item; the un-built cgo equivalent is shim/go/.
+// (mkhe-kklss_amd/*.py is the same mirror for the Python tests and the bench.)
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "mkhe.h"
+
+namespace mkhe {
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+inline void check(int rc) { if (rc) throw Error(mkhe_last_error()); }
+}  // namespace mkhe
+
+namespace mkrlwe {
+using mkhe::check;
+using mkhe::Error;
+typedef std::set<std::string> IDSet;                                   // mkrlwe/idset.go
+
+class SwitchingKey;
+
+// mkrlwe.Parameters (params.go:8-12): ring parameters + CRS map + gamma, plus the engine context
+// (= NewKeySwitcher state, keyswitch.go:33-47).
+class Parameters {
+  public:
+    Parameters(int logN, std::vector<uint64_t> Q, std::vector<uint64_t> P, int gamma = 2, int device = 0)
+        : logN_(logN), Q_(std::move(Q)), P_(std::move(P)), gamma_(gamma) {
+        check(mkhe_ctx_create(&ctx, logN, Q_.data(), (int)Q_.size(), P_.data(), (int)P_.size(), gamma, nullptr, nullptr, device));
+    }
+    virtual ~Parameters() { CRS.clear(); if (ctx) mkhe_ctx_destroy(ctx); }
+    Parameters(const Parameters&) = delete;
+    Parameters& operator=(const Parameters&) = delete;
+
+    int N() const { return 1 << logN_; }
+    int LogN() const { return logN_; }
+    int QCount() const { return (int)Q_.size(); }
+    int PCount() const { return (int)P_.size(); }
+    int MaxLevel() const { return QCount() - 1; }
+    int Gamma() const { return gamma_; }
+    int Alpha() const { return PCount() / gamma_; }                                     // params.go:63-65
+    int Beta(int levelQ) const { return (levelQ + 1 + Alpha() - 1) / Alpha(); }          // params.go:67-71
+    size_t SwkWords() const { return mkhe_ctx_swk_words(ctx); }
+    const std::vector<uint64_t>& Q() const { return Q_; }
+    const std::vector<uint64_t>& P() const { return P_; }
+    uint64_t GaloisElementForColumnRotationBy(int k) const {
+        const uint64_t m = 2ull * N();
+        uint64_t r = 1, b = 5, e = (uint64_t)(((k % (int)m) + (int)m) % (int)m);
+        for (; e; e >>= 1) { if (e & 1) r = r * b % m; b = b * b % m; }
+        return r;
+    }
+    uint64_t GaloisElementForRowRotation() const { return 2ull * N() - 1; }
+    // params.AddCRS / NewParameters CRS slots (params.go:37-61): uniform polys (NTT + Montgomery form), uploaded once
+    std::shared_ptr<SwitchingKey> AddCRS(int idx, const uint64_t* host_swk);
+    int party_index(const std::string& id) {
+        if (id == "0") throw Error("Cannot IDSet Add : 0 cannot be used");                // idset.go:12-16
+        auto it = ids_.find(id);
+        if (it != ids_.end()) return it->second;
+        const int v = (int)ids_.size();
+        ids_[id] = v;
+        return v;
+    }
+    void sync() { check(mkhe_ctx_sync(ctx)); }
+
+    mkhe_ctx* ctx = nullptr;
+    std::map<int, std::shared_ptr<SwitchingKey>> CRS;                                    // params.go:37-46
+
+  protected:
+    Parameters(int logN, std::vector<uint64_t> Q, std::vector<uint64_t> P, int gamma, bool /*no context yet*/)
+        : logN_(logN), Q_(std::move(Q)), P_(std::move(P)), gamma_(gamma) {}
+    int logN_;
+    std::vector<uint64_t> Q_, P_;
+    int gamma_;
+    std::map<std::string, int> ids_;
+};
+
+// mkrlwe.SwitchingKey (keys.go:23-25): host layout uint64[beta][nQ+nP][N]
+class SwitchingKey {
+  public:
+    explicit SwitchingKey(Parameters& p, const uint64_t* host = nullptr) : params(p) {
+        check(mkhe_swk_create(p.ctx, &h));
+        if (host) upload(host);
+    }
+    ~SwitchingKey() { if (h) mkhe_swk_destroy(params.ctx, h); }
+    SwitchingKey(const SwitchingKey&) = delete;
+    SwitchingKey& operator=(const SwitchingKey&) = delete;
+    void upload(const uint64_t* host) { check(mkhe_swk_upload(params.ctx, h, host)); }
+    void download(uint64_t* host) const { check(mkhe_swk_download(params.ctx, h, host)); }
+    Parameters& params;
+    mkhe_swk* h = nullptr;
+};
+inline std::shared_ptr<SwitchingKey> NewSwitchingKey(Parameters& p) { return std::make_shared<SwitchingKey>(p); }   // keys.go:245-255
+inline std::shared_ptr<SwitchingKey> Parameters::AddCRS(int idx, const uint64_t* host_swk) {
+    return CRS[idx] = std::make_shared<SwitchingKey>(*this, host_swk);
+}
+
+// keys.go:34-37: Value = (b, d, v)
+struct RelinearizationKey {
+    RelinearizationKey(Parameters& p, std::string id, const uint64_t* b, const uint64_t* d, const uint64_t* v) : ID(std::move(id)) {
+        Value[0] = std::make_shared<SwitchingKey>(p, b); Value[1] = std::make_shared<SwitchingKey>(p, d); Value[2] = std::make_shared<SwitchingKey>(p, v);
+    }
+    std::string ID;
+    std::shared_ptr<SwitchingKey> Value[3];
+};
+// keys.go:53-57,165-198
+struct RelinearizationKeySet {
+    void AddRelinearizationKey(std::shared_ptr<RelinearizationKey> k) { Value[k->ID] = std::move(k); }
+    void DelRelinearizationKey(const std::string& id) { Value.erase(id); }
+    RelinearizationKey& GetRelinearizationKey(const std::string& id) {
+        auto it = Value.find(id);
+        if (it == Value.end()) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+        return *it->second;
+    }
+    std::map<std::string, std::shared_ptr<RelinearizationKey>> Value;
+};
+// keys.go:40-44,60-62,128-162
+struct RotationKey {
+    RotationKey(Parameters& p, int rotidx, std::string id, const uint64_t* v) : ID(std::move(id)), RotIdx(rotidx), Value(std::make_shared<SwitchingKey>(p, v)) {}
+    std::string ID; int RotIdx; std::shared_ptr<SwitchingKey> Value;
+};
+struct RotationKeySet {
+    void AddRotationKey(std::shared_ptr<RotationKey> k) { Value[k->ID][k->RotIdx] = std::move(k); }
+    RotationKey& GetRotationKey(const std::string& id, int rotidx) {
+        auto it = Value.find(id);
+        if (it == Value.end() || !it->second.count(rotidx)) throw Error("cannot GetRotationKeys: there is no rotation key with given id");
+        return *it->second[rotidx];
+    }
+    std::map<std::string, std::map<int, std::shared_ptr<RotationKey>>> Value;
+};
+// keys.go:47-50,65-67,200-228
+struct ConjugationKey {
+    ConjugationKey(Parameters& p, std::string id, const uint64_t* v) : ID(std::move(id)), Value(std::make_shared<SwitchingKey>(p, v)) {}
+    std::string ID; std::shared_ptr<SwitchingKey> Value;
+};
+struct ConjugationKeySet {
+    void AddConjugationKey(std::shared_ptr<ConjugationKey> k) { Value[k->ID] = std::move(k); }
+    ConjugationKey& GetConjugationKey(const std::string& id) {
+        auto it = Value.find(id);
+        if (it == Value.end()) throw Error("cannot GetConjugationKey: there is no conjugation key with given id");
+        return *it->second;
+    }
+    std::map<std::string, std::shared_ptr<ConjugationKey>> Value;
+};
+// elements.go:5-15
+struct HoistedCiphertext { std::map<std::string, std::shared_ptr<SwitchingKey>> Value; };
+
+// mkrlwe.Ciphertext (elements.go:17-33): Value["0"] + one poly per id; device layout uint64[1+n][level+1][N], ids sorted
+class Ciphertext {
+  public:
+    Ciphertext(Parameters& p, const IDSet& idset, int level, bool zero = true) : params(p), ids(idset.begin(), idset.end()), level_(level) {
+        std::vector<int> dense;
+        for (auto& s : ids) dense.push_back(p.party_index(s));
+        check((zero ? mkhe_ct_create : mkhe_ct_create_uninit)(p.ctx, (int)ids.size(), dense.data(), level + 1, &h));
+    }
+    virtual ~Ciphertext() { if (h) mkhe_ct_destroy(params.ctx, h); }
+    Ciphertext(const Ciphertext&) = delete;
+    Ciphertext& operator=(const Ciphertext&) = delete;
+    IDSet IDSet_() const { return IDSet(ids.begin(), ids.end()); }
+    int Level() const { return level_; }
+    int slot(const std::string& id) const {
+        if (id == "0") return 0;
+        auto it = std::find(ids.begin(), ids.end(), id);
+        if (it == ids.end()) throw Error("mkhe: ciphertext has no component of that id");
+        return 1 + (int)(it - ids.begin());
+    }
+    size_t words() const { return (size_t)(1 + ids.size()) * (level_ + 1) * params.N(); }
+    void upload(const uint64_t* host) { check(mkhe_ct_upload(params.ctx, h, host)); }
+    void download(uint64_t* host) const { check(mkhe_ct_download(params.ctx, h, host)); }
+    Parameters& params;
+    std::vector<std::string> ids;
+    mkhe_ct* h = nullptr;
+  protected:
+    int level_;
+};
+
+// mkrlwe.KeySwitcher (keyswitch.go:8-47); the reference's pools are engine-internal device buffers
+class KeySwitcher {
+  public:
+    explicit KeySwitcher(Parameters& p) : params(p) {}
+    void Decompose(int levelQ, const Ciphertext& ct, const std::string& id, SwitchingKey& ad, bool isNTT = false) {     // keyswitch.go:49-73
+        check(mkhe_decompose(params.ctx, levelQ, isNTT ? 1 : 0, ct.h, ct.slot(id), ad.h));
+    }
+    void ExternalProduct(int levelQ, const Ciphertext& ct, const std::string& id, const SwitchingKey& bg, Ciphertext& out, const std::string& out_id, bool isNTT = false) {
+        check(mkhe_external_product(params.ctx, levelQ, isNTT ? 1 : 0, ct.h, ct.slot(id), bg.h, out.h, out.slot(out_id)));      // keyswitch.go:79-118
+    }
+    void ExternalProductHoisted(int levelQ, const SwitchingKey& aHoisted, const SwitchingKey& bg, Ciphertext& out, const std::string& out_id) {
+        check(mkhe_external_product_hoisted(params.ctx, levelQ, aHoisted.h, bg.h, out.h, out.slot(out_id)));                    // keyswitch_hoisted.go:10-40
+    }
+    void MulAndRelin(const Ciphertext& op0, const Ciphertext& op1, RelinearizationKeySet& rlkSet, Ciphertext& ctOut) {          // keyswitch.go:122-230
+        MulAndRelinHoisted(op0, op1, nullptr, nullptr, rlkSet, ctOut);
+    }
+    void MulAndRelinHoisted(const Ciphertext& op0, const Ciphertext& op1, const HoistedCiphertext* op0Hoisted, const HoistedCiphertext* op1Hoisted,
+                            RelinearizationKeySet& rlkSet, Ciphertext& ctOut) {                                                 // keyswitch_hoisted.go:44-179
+        if (op0.Level() < ctOut.Level() || op1.Level() < ctOut.Level()) throw Error("Cannot MulAndRelin: op0 and op1 have different levels");
+        if (!params.CRS.count(-1)) throw Error("mkhe: CRS[-1] (u) has not been uploaded");
+        std::vector<const mkhe_swk*> d0, v0, b1, h0, h1;
+        for (auto& i : op0.ids) { auto& k = rlkSet.GetRelinearizationKey(i); d0.push_back(k.Value[1]->h); v0.push_back(k.Value[2]->h); }
+        for (auto& i : op1.ids) b1.push_back(rlkSet.GetRelinearizationKey(i).Value[0]->h);
+        if (op0Hoisted) for (auto& i : op0.ids) h0.push_back(op0Hoisted->Value.at(i)->h);
+        if (op1Hoisted) for (auto& i : op1.ids) h1.push_back(op1Hoisted->Value.at(i)->h);
+        check(mkhe_mul_and_relin(params.ctx, op0.h, op1.h, op0Hoisted ? h0.data() : nullptr, op1Hoisted ? h1.data() : nullptr,
+                                 b1.data(), d0.data(), v0.data(), params.CRS[-1]->h, ctOut.h));
+    }
+    void Rotate(const Ciphertext& ctIn, int rotidx, RotationKeySet& rkSet, Ciphertext& ctOut) { RotateHoisted(ctIn, rotidx, nullptr, rkSet, ctOut); }   // keyswitch.go:234-298
+    void RotateHoisted(const Ciphertext& ctIn, int rotidx, const HoistedCiphertext* ctInHoisted, RotationKeySet& rkSet, Ciphertext& ctOut) {        // keyswitch_hoisted.go:183-247
+        if (ctIn.Level() < ctOut.Level()) throw Error("Cannot Rotate: ctIn and ctOut have different levels");
+        const int n2 = params.N() / 2;
+        while (rotidx < 0) rotidx += n2;                                                                                                             // keyswitch.go:246-249
+        if (!params.CRS.count(rotidx)) throw Error("mkhe: no CRS for this rotation index");
+        std::vector<const mkhe_swk*> rk, hs;
+        for (auto& i : ctIn.ids) rk.push_back(rkSet.GetRotationKey(i, rotidx).Value->h);
+        if (ctInHoisted) for (auto& i : ctIn.ids) hs.push_back(ctInHoisted->Value.at(i)->h);
+        check(mkhe_rotate(params.ctx, params.GaloisElementForColumnRotationBy(rotidx), ctIn.h, ctInHoisted ? hs.data() : nullptr, rk.data(),
+                          params.CRS[rotidx]->h, ctOut.h));
+    }
+    void Conjugate(const Ciphertext& ctIn, ConjugationKeySet& ckSet, Ciphertext& ctOut) {                                                           // keyswitch.go:302-332
+        if (ctIn.Level() < ctOut.Level()) throw Error("Cannot Conjugate: ctIn and ctOut have different levels");
+        std::vector<const mkhe_swk*> ck;
+        for (auto& i : ctIn.ids) ck.push_back(ckSet.GetConjugationKey(i).Value->h);
+        check(mkhe_conjugate(params.ctx, params.GaloisElementForRowRotation(), ctIn.h, ck.data(), params.CRS.at(-2)->h, ctOut.h));
+    }
+    Parameters& params;
+};
+inline IDSet Union(const IDSet& a, const IDSet& b) { IDSet r = a; r.insert(b.begin(), b.end()); return r; }
+}  // namespace mkrlwe
+
+namespace mkckks {
+using mkhe::check;
+using mkhe::Error;
+
+// mkckks.Parameters (params.go:11-24): mkrlwe parameters with gamma = 2 + default scale
+class Parameters : public mkrlwe::Parameters {
+  public:
+    Parameters(int logN, std::vector<uint64_t> Q, std::vector<uint64_t> P, double scale, int device = 0)
+        : mkrlwe::Parameters(logN, std::move(Q), std::move(P), 2, device), scale_(scale) {}
+    double Scale() const { return scale_; }
+  private:
+    double scale_;
+};
+// mkckks.Ciphertext (elements.go:5-17)
+class Ciphertext : public mkrlwe::Ciphertext {
+  public:
+    Ciphertext(Parameters& p, const mkrlwe::IDSet& idset, int level, double scale, bool zero = true) : mkrlwe::Ciphertext(p, idset, level, zero), Scale(scale) {}
+    double ScalingFactor() const { return Scale; }
+    double Scale;
+};
+typedef std::unique_ptr<Ciphertext> CiphertextPtr;
+
+// mkckks.Evaluator (evaluator.go:13-39)
+class Evaluator {
+  public:
+    explicit Evaluator(Parameters& p) : params(p), ksw(p) {}
+    CiphertextPtr AddNew(const Ciphertext& op0, const Ciphertext& op1) { return binary(op0, op1, mkhe_ct_add); }      // evaluator.go:316-327
+    CiphertextPtr SubNew(const Ciphertext& op0, const Ciphertext& op1) { return binary(op0, op1, mkhe_ct_sub); }      // evaluator.go:329-357
+    // evaluator.go:376-384
+    int nbRescales(const Ciphertext& ctIn, double minScale, double* scaleOut) const {
+        double scale = ctIn.Scale; int nb = 0;
+        while (ctIn.Level() - nb >= 0 && scale / (double)params.Q()[ctIn.Level() - nb] >= minScale / 2) { scale /= (double)params.Q()[ctIn.Level() - nb]; ++nb; }
+        *scaleOut = scale;
+        return nb;
+    }
+    CiphertextPtr RescaleNew(const Ciphertext& ct0, double threshold) {                                                 // evaluator.go:359-414
+        if (threshold <= 0) throw Error("cannot Rescale: minScale is 0");
+        if (ct0.Scale == 0) throw Error("cannot Rescale: ciphertext scale is 0");
+        if (ct0.Level() == 0) throw Error("cannot Rescale: input Ciphertext already at level 0");
+        double scale; const int nb = nbRescales(ct0, threshold, &scale);
+        auto out = std::make_unique<Ciphertext>(params, ct0.IDSet_(), ct0.Level() - nb, scale, false);
+        check(mkhe_rescale(params.ctx, ct0.h, nb, out->h));
+        return out;
+    }
+    std::unique_ptr<mkrlwe::HoistedCiphertext> HoistedForm(const Ciphertext& ct) {                                      // evaluator.go:543-553
+        auto h = std::make_unique<mkrlwe::HoistedCiphertext>();
+        for (auto& id : ct.ids) { h->Value[id] = mkrlwe::NewSwitchingKey(params); ksw.Decompose(ct.Level(), ct, id, *h->Value[id]); }
+        return h;
+    }
+    CiphertextPtr MulRelinNew(const Ciphertext& op0, const Ciphertext& op1, mkrlwe::RelinearizationKeySet& rlkSet) {      // evaluator.go:416-443
+        return MulRelinHoistedNew(op0, op1, nullptr, nullptr, rlkSet);
+    }
+    CiphertextPtr MulRelinHoistedNew(const Ciphertext& op0, const Ciphertext& op1, const mkrlwe::HoistedCiphertext* h0, const mkrlwe::HoistedCiphertext* h1,
+                                     mkrlwe::RelinearizationKeySet& rlkSet) {                                            // evaluator.go:558-581
+        auto ctOut = std::make_unique<Ciphertext>(params, mkrlwe::Union(op0.IDSet_(), op1.IDSet_()), std::min(op0.Level(), op1.Level()),
+                                                  op0.ScalingFactor() * op1.ScalingFactor(), false);
+        ksw.MulAndRelinHoisted(op0, op1, h0, h1, rlkSet, *ctOut);
+        double scale; const int nb = nbRescales(*ctOut, params.Scale(), &scale);
+        if (nb == 0 || ctOut->Level() == 0) return ctOut;
+        auto res = std::make_unique<Ciphertext>(params, ctOut->IDSet_(), ctOut->Level() - nb, scale, false);
+        check(mkhe_rescale(params.ctx, ctOut->h, nb, res->h));
+        return res;
+    }
+    CiphertextPtr RotateNew(const Ciphertext& ct0, int rotidx, mkrlwe::RotationKeySet& rkSet) {                          // evaluator.go:485-525
+        const int n2 = params.N() / 2;
+        rotidx = ((rotidx % n2) + n2) % n2;
+        if (rotidx == 0) return copy(ct0);
+        if (params.CRS.count(rotidx)) { auto out = like(ct0); ksw.Rotate(ct0, rotidx, rkSet, *out); return out; }
+        CiphertextPtr cur; const Ciphertext* src = &ct0;
+        for (int k = 1; rotidx > 0; k *= 2, rotidx /= 2) {                                                                // power-of-two decomposition, :516-523
+            if (rotidx % 2 == 0) continue;
+            auto nxt = like(ct0);
+            ksw.Rotate(*src, k, rkSet, *nxt);
+            cur = std::move(nxt); src = cur.get();
+        }
+        return cur;
+    }
+    CiphertextPtr RotateHoistedNew(const Ciphertext& ct0, int rotidx, const mkrlwe::HoistedCiphertext& hoisted, mkrlwe::RotationKeySet& rkSet) {   // evaluator.go:585-617
+        const int n2 = params.N() / 2;
+        rotidx = ((rotidx % n2) + n2) % n2;
+        if (rotidx == 0) return copy(ct0);
+        if (!params.CRS.count(rotidx)) throw Error("Hoisted rotation only works for precomputed rotation keys");
+        auto out = like(ct0);
+        ksw.RotateHoisted(ct0, rotidx, &hoisted, rkSet, *out);
+        return out;
+    }
+    CiphertextPtr ConjugateNew(const Ciphertext& ct0, mkrlwe::ConjugationKeySet& ckSet) {                                // evaluator.go:527-541
+        auto out = like(ct0);
+        ksw.Conjugate(ct0, ckSet, *out);
+        return out;
+    }
+    Parameters& params;
+    mkrlwe::KeySwitcher ksw;
+
+  private:
+    CiphertextPtr like(const Ciphertext& c) { return std::make_unique<Ciphertext>(params, c.IDSet_(), c.Level(), c.Scale, false); }
+    CiphertextPtr copy(const Ciphertext& c) {
+        auto out = like(c);
+        std::vector<uint64_t> tmp(c.words());
+        c.download(tmp.data()); out->upload(tmp.data());
+        return out;
+    }
+    template <typename F> CiphertextPtr binary(const Ciphertext& op0, const Ciphertext& op1, F fn) {
+        const double s0 = op0.Scale, s1 = op1.Scale;
+        if ((s0 > s1 && std::floor(s0 / s1) > 1) || (s1 > s0 && std::floor(s1 / s0) > 1))
+            throw Error("mkhe: Add/Sub of ciphertexts whose scales differ by a factor > 1 is not on the device path");
+        auto out = std::make_unique<Ciphertext>(params, mkrlwe::Union(op0.IDSet_(), op1.IDSet_()), std::min(op0.Level(), op1.Level()), std::max(s0, s1), false);
+        check(fn(params.ctx, op0.h, op1.h, out->h));
+        return out;
+    }
+};
+}  // namespace mkckks
+
+namespace mkbfv {
+using mkhe::check;
+using mkhe::Error;
+
+// mkbfv.Parameters (params.go:21-76): rings Q, QMul, R = Q || QMul, P, plaintext modulus T; gamma = 2
+class Parameters : public mkrlwe::Parameters {
+  public:
+    Parameters(int logN, std::vector<uint64_t> Q, std::vector<uint64_t> QMul, std::vector<uint64_t> P, uint64_t T, int device = 0)
+        : mkrlwe::Parameters(logN, std::move(Q), std::move(P), 2, true), QMul_(std::move(QMul)), T_(T) {
+        if (Q_.size() != QMul_.size()) throw Error("cannot NewParametersFromLiteral: length of Q & QMul is not equal");            // params.go:30-32
+        check(mkhe_ctx_create_bfv(&ctx, logN, Q_.data(), QMul_.data(), (int)Q_.size(), P_.data(), (int)P_.size(), 2, T, device));
+    }
+    uint64_t T() const { return T_; }
+  private:
+    std::vector<uint64_t> QMul_;
+    uint64_t T_;
+};
+// mkbfv.Ciphertext (elements.go:5-11): always at MaxLevel, coefficient domain
+class Ciphertext : public mkrlwe::Ciphertext {
+  public:
+    Ciphertext(Parameters& p, const mkrlwe::IDSet& idset, bool zero = true) : mkrlwe::Ciphertext(p, idset, p.MaxLevel(), zero) {}
+};
+typedef std::unique_ptr<Ciphertext> CiphertextPtr;
+// mkbfv.RelinearizationKey (keys.go:6-9): Value[0] = (b1, d1, v), Value[1] = (b2, d2, -)
+struct RelinearizationKey {
+    RelinearizationKey(Parameters& p, std::string id, const uint64_t* b1, const uint64_t* b2, const uint64_t* d1, const uint64_t* d2, const uint64_t* v) : ID(id) {
+        Value[0] = std::make_shared<mkrlwe::RelinearizationKey>(p, id, b1, d1, v);
+        Value[1] = std::make_shared<mkrlwe::RelinearizationKey>(p, id, b2, d2, nullptr);
+    }
+    std::string ID;
+    std::shared_ptr<mkrlwe::RelinearizationKey> Value[2];
+};
+struct RelinearizationKeySet {                                                                                                     // keys.go:11-21,33-82
+    void AddRelinearizationKey(std::shared_ptr<RelinearizationKey> k) { Value[k->ID] = std::move(k); }
+    RelinearizationKey& GetRelinearizationKey(const std::string& id) {
+        auto it = Value.find(id);
+        if (it == Value.end()) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+        return *it->second;
+    }
+    std::map<std::string, std::shared_ptr<RelinearizationKey>> Value;
+};
+// mkbfv.Evaluator (evaluator.go:7-20)
+class Evaluator {
+  public:
+    explicit Evaluator(Parameters& p) : params(p), ksw(p) {}
+    CiphertextPtr AddNew(const Ciphertext& op0, const Ciphertext& op1) { auto o = bin(op0, op1); check(mkhe_ct_add(params.ctx, op0.h, op1.h, o->h)); return o; }   // :44-52
+    CiphertextPtr SubNew(const Ciphertext& op0, const Ciphertext& op1) { auto o = bin(op0, op1); check(mkhe_ct_sub(params.ctx, op0.h, op1.h, o->h)); return o; }   // :54-76
+    CiphertextPtr MulRelinNew(const Ciphertext& op0, const Ciphertext& op1, RelinearizationKeySet& rlkSet) {                       // evaluator.go:78-82,118-140
+        if (!params.CRS.count(-1)) throw Error("mkhe: CRS[-1] (u) has not been uploaded");
+        auto out = bin(op0, op1);
+        std::vector<const mkhe_swk*> b1, b2, d1, d2, v;
+        for (auto& i : op1.ids) { auto& k = rlkSet.GetRelinearizationKey(i); b1.push_back(k.Value[0]->Value[0]->h); b2.push_back(k.Value[1]->Value[0]->h); }
+        for (auto& i : op0.ids) {
+            auto& k = rlkSet.GetRelinearizationKey(i);
+            d1.push_back(k.Value[0]->Value[1]->h); d2.push_back(k.Value[1]->Value[1]->h); v.push_back(k.Value[0]->Value[2]->h);
+        }
+        check(mkhe_bfv_mul_relin(params.ctx, op0.h, op1.h, b1.data(), b2.data(), d1.data(), d2.data(), v.data(), params.CRS[-1]->h, out->h));
+        return out;
+    }
+    CiphertextPtr RotateNew(const Ciphertext& ct0, int rotidx, mkrlwe::RotationKeySet& rkSet) {                                    // evaluator.go:142-180 (precomputed indices)
+        auto out = std::make_unique<Ciphertext>(params, ct0.IDSet_(), false);
+        ksw.Rotate(ct0, rotidx, rkSet, *out);
+        return out;
+    }
+    CiphertextPtr ConjugateNew(const Ciphertext& ct0, mkrlwe::ConjugationKeySet& ckSet) {                                          // evaluator.go:182-192
+        auto out = std::make_unique<Ciphertext>(params, ct0.IDSet_(), false);
+        ksw.Conjugate(ct0, ckSet, *out);
+        return out;
+    }
+    Parameters& params;
+    mkrlwe::KeySwitcher ksw;
+  private:
+    CiphertextPtr bin(const Ciphertext& a, const Ciphertext& b) { return std::make_unique<Ciphertext>(params, mkrlwe::Union(a.IDSet_(), b.IDSet_()), false); }
+};
+}  // namespace mkbfv
