@@ -111,6 +111,22 @@ def lib():
                                             pp, pp, pp, pp, pp, pp, pp, pp, pp, u64p, C.c_int, i32p, u64p]
         L.ora_bfv_mul_relin_new.argtypes = [C.c_void_p, C.c_int, i32p, u64p, C.c_int, i32p, u64p,
                                             pp, pp, pp, pp, pp, u64p, C.c_int, C.c_int, i32p, u64p]
+        s32p = C.POINTER(C.c_int32)
+        L.ora_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.ora_crs_sample.restype = C.c_uint64
+        L.ora_crs_sample.argtypes = [C.c_uint64, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.ora_crs_expand.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, u64p]
+        for name in ("ora_small_to_qp", "ora_gen_secret_key", "ora_gen_gaussian_error"):
+            getattr(L, name).argtypes = [C.c_void_p, s32p, u64p]
+        L.ora_gen_switching_key.argtypes = [C.c_void_p, u64p, s32p, u64p]
+        L.ora_gen_public_key.argtypes = [C.c_void_p, u64p, s32p, u64p, u64p]
+        L.ora_gen_relin_key.argtypes = [C.c_void_p, u64p, u64p, s32p, u64p, u64p, u64p, u64p, u64p]
+        L.ora_permute_ntt_qp.argtypes = [C.c_void_p, C.c_uint64, u64p, u64p]
+        L.ora_gen_rotation_key.argtypes = [C.c_void_p, C.c_uint64, u64p, s32p, u64p, u64p]
+        L.ora_gen_conjugation_key.argtypes = [C.c_void_p, u64p, s32p, u64p, u64p]
+        L.ora_bfv_gen_switching_key.argtypes = [C.c_void_p, u64p, u64p, s32p, u64p]
+        L.ora_bfv_gen_relin_key.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p, s32p, u64p, u64p, u64p,
+                                            u64p, u64p, u64p, u64p, u64p]
         _lib = L
     return _lib
 
@@ -515,3 +531,91 @@ class BFV:
                                     rl[0], rl[1], rl[2], rl[3], rl[4], _p(crs_u), 1 if hoisted else 0,
                                     len(ids_out), po, _p(out))
         return ids_out, out
+
+
+def _s32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().ora_philox4x32_10(c, k, o)
+    return list(o)
+
+
+class KeyGen:
+    """mkrlwe.KeyGenerator / mkbfv.KeyGenerator and CRS generation restated with the random samples as inputs
+    (oracle/ora_keygen.h).  ks: KeySwitcher (for BFV: BFV(...).ks).  Secret keys are PolyQP uint64[nQ+nP][N]."""
+
+    def __init__(self, ks):
+        self.ks = ks
+
+    def _qp(self):
+        return np.zeros((self.ks.m, self.ks.N), dtype=np.uint64)
+
+    def crs_sample(self, seed, idx, row, coeff, q):
+        return int(lib().ora_crs_sample(seed, idx, row, coeff, q))
+
+    def crs_expand(self, seed, idx):
+        out = self.ks.new_swk()
+        lib().ora_crs_expand(self.ks.h, seed, idx, _p(out))
+        return out
+
+    def small_to_qp(self, s):
+        a, p = _s32(s); out = self._qp()
+        lib().ora_small_to_qp(self.ks.h, p, _p(out))
+        return out
+
+    def gen_secret_key(self, s):
+        a, p = _s32(s); out = self._qp()
+        lib().ora_gen_secret_key(self.ks.h, p, _p(out))
+        return out
+
+    def gen_gaussian_error(self, e):
+        a, p = _s32(e); out = self._qp()
+        lib().ora_gen_gaussian_error(self.ks.h, p, _p(out))
+        return out
+
+    def gen_switching_key(self, sk, e):
+        a, p = _s32(e); out = self.ks.new_swk()
+        lib().ora_gen_switching_key(self.ks.h, _p(_u64arr(sk)), p, _p(out))
+        return out
+
+    def gen_public_key(self, sk, e, crs_a):
+        a, p = _s32(e); out = np.zeros((2, self.ks.m, self.ks.N), dtype=np.uint64)
+        lib().ora_gen_public_key(self.ks.h, _p(_u64arr(sk)), p, _p(_u64arr(crs_a)), _p(out))
+        return out
+
+    def gen_relin_key(self, sk, r, e, crs_a, crs_u):
+        a, p = _s32(e); b, d, v = self.ks.new_swk(), self.ks.new_swk(), self.ks.new_swk()
+        lib().ora_gen_relin_key(self.ks.h, _p(_u64arr(sk)), _p(_u64arr(r)), p, _p(_u64arr(crs_a)), _p(_u64arr(crs_u)), _p(b), _p(d), _p(v))
+        return b, d, v
+
+    def permute_ntt_qp(self, galEl, poly):
+        out = self._qp()
+        lib().ora_permute_ntt_qp(self.ks.h, galEl, _p(_u64arr(poly)), _p(out))
+        return out
+
+    def gen_rotation_key(self, galEl, sk, e, crs):
+        a, p = _s32(e); out = self.ks.new_swk()
+        lib().ora_gen_rotation_key(self.ks.h, galEl, _p(_u64arr(sk)), p, _p(_u64arr(crs)), _p(out))
+        return out
+
+    def gen_conjugation_key(self, sk, e, crs):
+        a, p = _s32(e); out = self.ks.new_swk()
+        lib().ora_gen_conjugation_key(self.ks.h, _p(_u64arr(sk)), p, _p(_u64arr(crs)), _p(out))
+        return out
+
+    def bfv_gen_switching_key(self, sk, g, e):
+        a, p = _s32(e); out = self.ks.new_swk()
+        lib().ora_bfv_gen_switching_key(self.ks.h, _p(_u64arr(sk)), _p(_u64arr(g)), p, _p(out))
+        return out
+
+    def bfv_gen_relin_key(self, sk, r, g1, g2, e, crs_a1, crs_a2, crs_u):
+        a, p = _s32(e); o = [self.ks.new_swk() for _ in range(5)]
+        lib().ora_bfv_gen_relin_key(self.ks.h, _p(_u64arr(sk)), _p(_u64arr(r)), _p(_u64arr(g1)), _p(_u64arr(g2)), p,
+                                    _p(_u64arr(crs_a1)), _p(_u64arr(crs_a2)), _p(_u64arr(crs_u)), *[_p(x) for x in o])
+        return tuple(o)
