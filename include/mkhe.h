@@ -203,6 +203,46 @@ int  mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                         const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2,
                         const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out);
 
+/* ==== key generation and CRS expansion =========================================
+ * mkrlwe/keygen.go, mkbfv/keygen.go, mkrlwe/params.go:16-61,77-99.  The reference draws secrets, errors and CRS from
+ * lattigo's crypto PRNG (utils.NewPRNG: keygen.go:26, params.go:28,79), so no output of it can be reproduced bit for
+ * bit; what is reproduced is the ring arithmetic applied to the samples:
+ *  - secrets / errors are SAMPLES supplied by the caller as host int32 arrays, N small signed coefficients per
+ *    polynomial (what ring.TernarySampler / ring.GaussianSampler draw; the Go shim copies them out of its own samplers,
+ *    so the secret randomness never comes from the GPU),
+ *  - a SecretKey is a device PolyQP buffer uint64[nQ+nP][N] (mkhe_buf_alloc), NTT domain, Montgomery form
+ *    (SecretKey.Value, keygen.go:44-55),
+ *  - keys are written into SwitchingKey handles in the layout every other entry point expects. */
+/* genSecretKeyFromSampler keygen.go:44-55 */
+int  mkhe_keygen_secret(mkhe_ctx* ctx, const int32_t* s, void* dev_sk);
+/* GenSwitchingKey keygen.go:270-327: g*sk + e; e = int32[betaMax][N] */
+int  mkhe_keygen_switching_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, mkhe_swk* out);
+/* GenPublicKey keygen.go:88-109: dev_pk = uint64[2][nQ+nP][N], pk[0] = NTT(e) - sk*a, pk[1] = a = CRS[0].Value[0]; e = int32[N] */
+int  mkhe_keygen_public_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, const mkhe_swk* crs_a, void* dev_pk);
+/* GenRelinearizationKey keygen.go:137-187: (b, d, v) from sk, the auxiliary secret r, a = CRS[0], u = CRS[-1];
+ * e = int32[3][betaMax][N], the errors of b, d, v in this order */
+int  mkhe_keygen_relin_key(mkhe_ctx* ctx, const void* dev_sk, const void* dev_r, const int32_t* e,
+                           const mkhe_swk* crs_a, const mkhe_swk* crs_u, mkhe_swk* b, mkhe_swk* d, mkhe_swk* v);
+/* GenRotationKey keygen.go:190-229: galEl = 5^rotidx mod 2N, crs = CRS[rotidx]; e = int32[betaMax][N] */
+int  mkhe_keygen_rotation_key(mkhe_ctx* ctx, uint64_t galEl, const void* dev_sk, const int32_t* e,
+                              const mkhe_swk* crs, mkhe_swk* out);
+/* GenConjugationKey keygen.go:240-268: crs = CRS[-2] */
+int  mkhe_keygen_conjugation_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, const mkhe_swk* crs, mkhe_swk* out);
+/* mkbfv GenBFVSwitchingKey (mkbfv/keygen.go:91-162), one of its two loops: g = uint64[betaMax][nQ+nP], the residues
+ * (plain, < modulus) of the big-integer gadget scalars Gi (:104-116 resp. :137-149), computed by the caller */
+int  mkhe_bfv_keygen_switching_key(mkhe_ctx* ctx, const void* dev_sk, const uint64_t* g, const int32_t* e, mkhe_swk* out);
+/* mkbfv GenRelinearizationKey (mkbfv/keygen.go:24-88): a1 = CRS[0], a2 = CRS[-3], u = CRS[-1];
+ * e = int32[5][betaMax][N] for b1, b2, d1, d2, v */
+int  mkhe_bfv_keygen_relin_key(mkhe_ctx* ctx, const void* dev_sk, const void* dev_r, const uint64_t* g1, const uint64_t* g2,
+                               const int32_t* e, const mkhe_swk* crs_a1, const mkhe_swk* crs_a2, const mkhe_swk* crs_u,
+                               mkhe_swk* b1, mkhe_swk* b2, mkhe_swk* d1, mkhe_swk* d2, mkhe_swk* v);
+/* CRS[idx] (params.go:47-59, AddCRS :77-99) expanded on the device from a public seed instead of uploaded (56 MiB each
+ * at PN15QP880): limb (digit i, modulus j) coefficient w = MForm(first of the 64-bit words of
+ * Philox4x32-10(key = seed, counter = {w, i*(nQ+nP)+j, idx, block}), block = 0, 1, ..., two words per block, masked to
+ * bitlen(q_j) bits, that is < q_j) -- the mask-and-reject shape of lattigo's ring.UniformSampler.  Parties that share
+ * the seed derive the same CRS. */
+int  mkhe_crs_expand(mkhe_ctx* ctx, uint64_t seed, int32_t idx, mkhe_swk* out);
+
 /* ---- measurement support (no reference counterpart): HIP-event timing per kernel class on the
  *      context stream, one record per kernel launch.  Classes (mkhe_prof_name gives the kernel symbol
  *      each class corresponds to in a rocprofv3 kernel trace). */

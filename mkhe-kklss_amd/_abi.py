@@ -7,6 +7,7 @@ LIB_PATH = os.environ.get("MKHE_LIB") or os.path.join(_HERE, "lib", "libmkhe_hip
 
 u64p = C.POINTER(C.c_uint64)
 i32p = C.POINTER(C.c_int)
+s32p = C.POINTER(C.c_int32)
 vp = C.c_void_p
 vpp = C.POINTER(C.c_void_p)
 
@@ -71,6 +72,15 @@ SIGNATURES = {
     "mkhe_bfv_decompose": (C.c_int, [vp, vp, vp, vp]),
     "mkhe_bfv_external_product_hoisted": (C.c_int, [vp, vp, vp, vp, vp, vp]),
     "mkhe_bfv_mul_relin": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),
+    "mkhe_keygen_secret": (C.c_int, [vp, s32p, vp]),
+    "mkhe_keygen_switching_key": (C.c_int, [vp, vp, s32p, vp]),
+    "mkhe_keygen_public_key": (C.c_int, [vp, vp, s32p, vp, vp]),
+    "mkhe_keygen_relin_key": (C.c_int, [vp, vp, vp, s32p, vp, vp, vp, vp, vp]),
+    "mkhe_keygen_rotation_key": (C.c_int, [vp, C.c_uint64, vp, s32p, vp, vp]),
+    "mkhe_keygen_conjugation_key": (C.c_int, [vp, vp, s32p, vp, vp]),
+    "mkhe_bfv_keygen_switching_key": (C.c_int, [vp, vp, u64p, s32p, vp]),
+    "mkhe_bfv_keygen_relin_key": (C.c_int, [vp, vp, vp, u64p, u64p, s32p, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mkhe_crs_expand": (C.c_int, [vp, C.c_uint64, C.c_int32, vp]),
     "mkhe_prof_enable": (C.c_int, [vp, C.c_int]),
     "mkhe_ntt_trace": (C.c_int, [vp, vp]),
     "mkhe_set_overlap": (C.c_int, [vp, C.c_int]),

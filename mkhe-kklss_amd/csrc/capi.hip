@@ -306,6 +306,45 @@ int mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe_
     MKHE_TRY({ if (!in || !out || !dev_pt) throw Error("mkhe_ct_mul_ptxt: null argument"); ctx->c->ct_mul_ptxt(in->c, (const u64*)dev_pt, out->c); })
 }
 
+// ---- key generation / CRS expansion
+int mkhe_keygen_secret(mkhe_ctx* ctx, const int32_t* s, void* dev_sk) {
+    MKHE_TRY({ if (!s || !dev_sk) throw Error("mkhe_keygen_secret: null argument"); ctx->c->keygen_secret(s, (u64*)dev_sk); })
+}
+int mkhe_keygen_switching_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, mkhe_swk* out) {
+    MKHE_TRY({ if (!dev_sk || !e || !out) throw Error("mkhe_keygen_switching_key: null argument"); ctx->c->keygen_switching_key((const u64*)dev_sk, e, out->s.d); })
+}
+int mkhe_keygen_public_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, const mkhe_swk* crs_a, void* dev_pk) {
+    MKHE_TRY({ if (!dev_sk || !e || !crs_a || !dev_pk) throw Error("mkhe_keygen_public_key: null argument"); ctx->c->keygen_public_key((const u64*)dev_sk, e, crs_a->s.d, (u64*)dev_pk); })
+}
+int mkhe_keygen_relin_key(mkhe_ctx* ctx, const void* dev_sk, const void* dev_r, const int32_t* e,
+                          const mkhe_swk* crs_a, const mkhe_swk* crs_u, mkhe_swk* b, mkhe_swk* d, mkhe_swk* v) {
+    MKHE_TRY({
+        if (!dev_sk || !dev_r || !e || !crs_a || !crs_u || !b || !d || !v) throw Error("mkhe_keygen_relin_key: null argument");
+        ctx->c->keygen_relin_key((const u64*)dev_sk, (const u64*)dev_r, e, crs_a->s.d, crs_u->s.d, b->s.d, d->s.d, v->s.d);
+    })
+}
+int mkhe_keygen_rotation_key(mkhe_ctx* ctx, uint64_t galEl, const void* dev_sk, const int32_t* e, const mkhe_swk* crs, mkhe_swk* out) {
+    MKHE_TRY({ if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_rotation_key: null argument"); ctx->c->keygen_rotation_key(galEl, (const u64*)dev_sk, e, crs->s.d, out->s.d); })
+}
+int mkhe_keygen_conjugation_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, const mkhe_swk* crs, mkhe_swk* out) {
+    MKHE_TRY({ if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_conjugation_key: null argument"); ctx->c->keygen_conjugation_key((const u64*)dev_sk, e, crs->s.d, out->s.d); })
+}
+int mkhe_bfv_keygen_switching_key(mkhe_ctx* ctx, const void* dev_sk, const uint64_t* g, const int32_t* e, mkhe_swk* out) {
+    MKHE_TRY({ if (!dev_sk || !g || !e || !out) throw Error("mkhe_bfv_keygen_switching_key: null argument"); ctx->c->bfv_keygen_switching_key((const u64*)dev_sk, g, e, out->s.d); })
+}
+int mkhe_bfv_keygen_relin_key(mkhe_ctx* ctx, const void* dev_sk, const void* dev_r, const uint64_t* g1, const uint64_t* g2,
+                              const int32_t* e, const mkhe_swk* a1, const mkhe_swk* a2, const mkhe_swk* u,
+                              mkhe_swk* b1, mkhe_swk* b2, mkhe_swk* d1, mkhe_swk* d2, mkhe_swk* v) {
+    MKHE_TRY({
+        if (!dev_sk || !dev_r || !g1 || !g2 || !e || !a1 || !a2 || !u || !b1 || !b2 || !d1 || !d2 || !v) throw Error("mkhe_bfv_keygen_relin_key: null argument");
+        ctx->c->bfv_keygen_relin_key((const u64*)dev_sk, (const u64*)dev_r, g1, g2, e, a1->s.d, a2->s.d, u->s.d,
+                                     b1->s.d, b2->s.d, d1->s.d, d2->s.d, v->s.d);
+    })
+}
+int mkhe_crs_expand(mkhe_ctx* ctx, uint64_t seed, int32_t idx, mkhe_swk* out) {
+    MKHE_TRY({ if (!out) throw Error("mkhe_crs_expand: null argument"); ctx->c->crs_expand(seed, idx, out->s.d); })
+}
+
 // ---- mkbfv
 int mkhe_ctx_create_bfv(mkhe_ctx** out, int logN, const uint64_t* Q, const uint64_t* QMul, int nQ,
                         const uint64_t* P, int nP, int gamma, uint64_t T, int device) {

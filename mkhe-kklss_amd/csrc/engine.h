@@ -13,6 +13,7 @@
 #include "modarith.h"
 #include "ntt_kernels.h"
 #include "poly_kernels.h"
+#include "keygen_kernels.h"
 
 namespace mkhe {
 
@@ -110,6 +111,22 @@ class Context {
     size_t lsh_phase(int phase, const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_d0,
                      const Swk* const* rlk_v0, const Swk* crs_u, Ct& out, u64* stage);
 
+    // ---- key generation and CRS expansion (mkrlwe/keygen.go, mkbfv/keygen.go, params.go:16-99).
+    // Secrets and errors are SAMPLES supplied by the caller (host int32, N per polynomial: what lattigo's ternary /
+    // Gaussian samplers draw); secret keys are device PolyQP buffers [nq+np][N] (NTT, Montgomery form).
+    void keygen_secret(const int32_t* s, u64* dev_sk);                                         // keygen.go:44-55
+    void keygen_switching_key(const u64* sk, const int32_t* e, u64* out);                      // keygen.go:270-327
+    void keygen_public_key(const u64* sk, const int32_t* e, const u64* crs_a, u64* dev_pk);    // keygen.go:88-109
+    void keygen_relin_key(const u64* sk, const u64* r, const int32_t* e, const u64* crs_a, const u64* crs_u,
+                          u64* b, u64* d, u64* v);                                             // keygen.go:137-187
+    void keygen_rotation_key(u64 galEl, const u64* sk, const int32_t* e, const u64* crs, u64* out);   // keygen.go:190-229
+    void keygen_conjugation_key(const u64* sk, const int32_t* e, const u64* crs, u64* out);    // keygen.go:240-268
+    // mkbfv/keygen.go:91-162 (one gadget) and :24-88; g1 / g2: host residues [beta][nq+np] of the big-integer scalars Gi
+    void bfv_keygen_switching_key(const u64* sk, const u64* g, const int32_t* e, u64* out);
+    void bfv_keygen_relin_key(const u64* sk, const u64* r, const u64* g1, const u64* g2, const int32_t* e,
+                              const u64* crs_a1, const u64* crs_a2, const u64* crs_u, u64* b1, u64* b2, u64* d1, u64* d2, u64* v);
+    void crs_expand(u64 seed, int32_t idx, u64* out);                                          // params.go:47-59,91-98
+
     bool overlap = true;               // false: everything on the main stream (clean per-kernel timings)
     u64* ntt_trace = nullptr;          // diagnostic buffer handed to the forward NTT kernels (mkhe_ntt_trace)
     // stream-ordered buffer cache for ciphertext / switching-key handles: freeing a handle does not
@@ -151,6 +168,14 @@ class Context {
     u64* rbuf_ = nullptr;  size_t rbuf_words_ = 0;          // BFV: operands over R, their NTTs, tensor output
     u64* c1b_ = nullptr;   size_t c1b_words_ = 0;           // batched ks.Pool[1]
     u64* tbuf_ = nullptr;  size_t tbuf_words_ = 0;          // t_i of step F
+    // key generation scratch: uploaded samples, gadget constants (slot 0: mkrlwe gadget, 1: caller's), permuted secret
+    int32_t* kg_small_ = nullptr; u64 *kg_g_ = nullptr, *kg_sk_ = nullptr;
+    bool kg_ready_ = false;
+    void kg_init();
+    // out <- NTT(e_i) for beta_max error polynomials, then the combine pass (keygen_kernels.h); gadget: 0 none, 1 mkrlwe
+    // (P on the limbs of digit i, keygen.go:288-323), 2 the constants last uploaded with kg_upload_g
+    void kg_key(const int32_t* e, int gadget, const u64* skA, const u64* crs, const u64* skB, int sign, bool neg, u64* out);
+    void kg_upload_g(const u64* g_plain);
 
     u64* scratch(u64*& p, size_t& have, size_t want);
     Swk& hoist_slot(int which, int idx);

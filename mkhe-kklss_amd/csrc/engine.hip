@@ -257,7 +257,8 @@ Context::~Context() {
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
                     (void*)d_map_r, (void*)d_bq_qoverqiinvqi, (void*)d_bq_qoverqimodp, (void*)d_bq_vtimes,
                     (void*)d_bm_qoverqiinvqi, (void*)d_bm_qoverqimodp, (void*)d_bm_vtimes,
-                    (void*)d_down_q_in_m, (void*)d_down_m_in_q, (void*)d_mform_qmul, (void*)d_t_mont})
+                    (void*)d_down_q_in_m, (void*)d_down_m_in_q, (void*)d_mform_qmul, (void*)d_t_mont,
+                    (void*)kg_small_, (void*)kg_g_, (void*)kg_sk_})
         if (p) (void)hipFree(p);
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
     for (auto& f : free_list_) (void)hipFree(f.second);

@@ -5,6 +5,7 @@ polynomial work runs on the device through the C ABI (include/mkhe.h, mkhe_bfv_*
 BFV ciphertexts live at the maximum level in the coefficient domain (elements.go:9-11).
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -78,6 +79,50 @@ class RelinearizationKeySet:
 
 def NewRelinearizationKeyKeySet(params):
     return RelinearizationKeySet(params)
+
+
+class KeyGenerator(mkrlwe.KeyGenerator):
+    """mkbfv.KeyGenerator (mkbfv/keygen.go:9-21): the mkrlwe generator plus the BFV relinearization key."""
+
+    def gadget(self, which):
+        """residues [beta][nQ+nP] of the big-integer gadget scalars Gi of GenBFVSwitchingKey (keygen.go:104-116 for the
+        Q digits, which = 0; :137-149 for the QMul digits, which = 1)"""
+        params = self.params
+        Q, QMul, P = math.prod(params.Q), math.prod(params.QMul), math.prod(params.P)
+        moduli = params.Q if which == 0 else params.QMul
+        alpha, beta = params.Alpha(), params.Beta(params.MaxLevel())
+        g = np.zeros((beta, params.QCount() + params.PCount()), dtype=np.uint64)
+        for i in range(beta):
+            Qi = math.prod(moduli[i * alpha:(i + 1) * alpha])
+            Gi = (Q * QMul) // Qi
+            Ti = pow(Gi % Qi, -1, Qi)
+            Gi = (Gi * params.T() * Ti * P) // QMul
+            g[i] = [Gi % m for m in params.Q + params.P]
+        return g
+
+    def GenBFVSwitchingKey(self, sk, swk1, swk2, e=None):
+        """keygen.go:91-162; e: [2][beta][N]"""
+        a, ptr = self._errors(e, (2, self._beta()))
+        for which, swk in enumerate((swk1, swk2)):
+            g = self.gadget(which)
+            check(lib().mkhe_bfv_keygen_switching_key(self.params.ctx, sk.Value.devptr(), g.ctypes.data_as(_abi.u64p),
+                                                      a[which].ctypes.data_as(_abi.s32p), swk.h))
+
+    def GenRelinearizationKey(self, sk, r, e=None):
+        """mkbfv/keygen.go:24-88; e: [5][beta][N] for b1, b2, d1, d2, v"""
+        params = self.params
+        a, ptr = self._errors(e, (5, self._beta()))
+        rlk = RelinearizationKey(params, sk.ID)
+        g1, g2 = self.gadget(0), self.gadget(1)
+        V = rlk.Value
+        check(lib().mkhe_bfv_keygen_relin_key(params.ctx, sk.Value.devptr(), r.Value.devptr(), g1.ctypes.data_as(_abi.u64p),
+                                              g2.ctypes.data_as(_abi.u64p), ptr, params.CRS[0].h, params.CRS[-3].h, params.CRS[-1].h,
+                                              V[0].Value[0].h, V[1].Value[0].h, V[0].Value[1].h, V[1].Value[1].h, V[0].Value[2].h))
+        return rlk
+
+
+def NewKeyGenerator(params, sampler=None):
+    return KeyGenerator(params, sampler)
 
 
 class PolyR(mkrlwe.DeviceLimbs):

@@ -70,11 +70,25 @@ class Parameters:
     def Psi(self, i):
         return int(lib().mkhe_ctx_psi(self.ctx, i))
 
-    def AddCRS(self, idx, host_swk):
-        """params.AddCRS / NewParameters CRS slots (params.go:37-61,77-99): the uniform polys are
-        sampled by the caller (NTT + Montgomery form) and uploaded once."""
-        self.CRS[idx] = SwitchingKey(self, host_swk)
+    CRS_SEED = 0x4D4B4845          # default public seed of the device-side CRS expansion
+
+    def AddCRS(self, idx, host_swk=None, seed=None):
+        """params.AddCRS / NewParameters CRS slots (params.go:37-61,77-99).  With host_swk the uniform polys are
+        sampled by the caller (NTT + Montgomery form) and uploaded once; without, CRS[idx] is expanded on the
+        device from the public `seed` (mkhe_crs_expand: Philox4x32-10 + mask-and-reject, then MForm) -- every party
+        that uses the same seed holds the same CRS and nothing is transferred."""
+        if host_swk is not None:
+            self.CRS[idx] = SwitchingKey(self, host_swk)
+        else:
+            self.CRS[idx] = SwitchingKey(self)
+            check(lib().mkhe_crs_expand(self.ctx, self.CRS_SEED if seed is None else int(seed), int(idx), self.CRS[idx].h))
         return self.CRS[idx]
+
+    def GenDefaultCRS(self, seed=None):
+        """the CRS list NewParameters creates (params.go:37-46): 0, -1 (relin), -2 (conj), -3, -4 (BFV relin) and the
+        power-of-two rotations"""
+        for idx in [0, -1, -2, -3, -4] + [1 << i for i in range(self.logN - 1)]:
+            self.AddCRS(idx, seed=seed)
 
     def party_index(self, pid):
         if pid == "0":
@@ -369,6 +383,157 @@ class KeySwitcher:
 
 def NewKeySwitcher(params):
     return KeySwitcher(params)
+
+
+# ---- key generation
+class SecretKey:
+    """mkrlwe.SecretKey (keys.go:9-12): Value = PolyQP (NTT, Montgomery form) resident on the device."""
+
+    def __init__(self, params, id):
+        self.ID = id
+        self.Value = DeviceLimbs(params, 1, params.QCount() + params.PCount())
+
+
+class PublicKey:
+    """mkrlwe.PublicKey (keys.go:15-18): Value = [2]PolyQP, (-a*s + e, a)."""
+
+    def __init__(self, params, id):
+        self.ID = id
+        self.Value = DeviceLimbs(params, 2, params.QCount() + params.PCount())
+
+
+class HostSampler:
+    """The small-norm samples of lattigo's ring.TernarySampler / ring.GaussianSampler, drawn on the HOST: secret
+    randomness never comes from the GPU.  `rng` is a numpy Generator; the default one is seeded from os.urandom but
+    PCG64 is not a cryptographic generator -- a deployment passes its own sampler object with these two methods
+    (the Go shim copies the samples out of lattigo's samplers)."""
+
+    def __init__(self, rng=None, sigma=3.2):
+        import os
+        self.rng = rng if rng is not None else np.random.Generator(np.random.PCG64(int.from_bytes(os.urandom(16), "little")))
+        self.sigma, self.bound = float(sigma), int(6 * float(sigma))        # rlwe.DefaultSigma, keygen.go:36
+
+    def ternary(self, N, p=0.5):
+        """0 with probability p, +-1 with (1-p)/2 each (GenSecretKeyWithDistrib keygen.go:69-76)"""
+        u = self.rng.random(N)
+        return np.where(u < p, 0, np.where(u < p + (1 - p) / 2, 1, -1)).astype(np.int32)
+
+    def gaussian(self, count, N):
+        """round(N(0, sigma)), resampled while |.| > bound"""
+        e = np.rint(self.rng.normal(0.0, self.sigma, (count, N)))
+        bad = np.abs(e) > self.bound
+        while bad.any():
+            e[bad] = np.rint(self.rng.normal(0.0, self.sigma, int(bad.sum())))
+            bad = np.abs(e) > self.bound
+        return e.astype(np.int32)
+
+
+def _s32(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if a.shape != tuple(shape):
+        raise MkheError("keygen: expected samples of shape %r, got %r" % (tuple(shape), a.shape))
+    return a, a.ctypes.data_as(_abi.s32p)
+
+
+class KeyGenerator:
+    """mkrlwe.KeyGenerator (keygen.go:13-40) on the device.  Every Gen* method takes the samples it would draw as an
+    optional argument (`s` / `e`, int32) -- given, the result is a deterministic function of them (parity tests);
+    omitted, they come from `sampler`."""
+
+    def __init__(self, params, sampler=None):
+        self.params = params
+        self.sampler = sampler if sampler is not None else HostSampler()
+
+    def _beta(self):
+        return self.params.Beta(self.params.MaxLevel())
+
+    def _errors(self, e, count):
+        N = self.params.N()
+        if e is None:
+            e = self.sampler.gaussian(int(np.prod(count)), N)
+        return _s32(np.asarray(e).reshape(tuple(np.atleast_1d(count)) + (N,)), tuple(np.atleast_1d(count)) + (N,))
+
+    def GenSecretKey(self, id, s=None):
+        """keygen.go:58-60 (ternary, P(0) = 1/2) -> genSecretKeyFromSampler :44-55"""
+        return self.GenSecretKeyWithDistrib(0.5, id, s)
+
+    def GenSecretKeyWithDistrib(self, p, id, s=None):
+        """keygen.go:69-76"""
+        if s is None:
+            s = self.sampler.ternary(self.params.N(), p)
+        a, ptr = _s32(s, (self.params.N(),))
+        sk = SecretKey(self.params, id)
+        check(lib().mkhe_keygen_secret(self.params.ctx, ptr, sk.Value.devptr()))
+        return sk
+
+    def GenSecretKeyGaussian(self, id, s=None):
+        """keygen.go:63-65"""
+        if s is None:
+            s = self.sampler.gaussian(1, self.params.N())[0]
+        return self.GenSecretKeyWithDistrib(0.0, id, s)
+
+    def GenPublicKey(self, sk, e=None):
+        """keygen.go:88-109"""
+        if 0 not in self.params.CRS:
+            raise MkheError("cannot GenPublicKey: CRS[0] is not generated")
+        a, ptr = self._errors(e, 1)
+        pk = PublicKey(self.params, sk.ID)
+        check(lib().mkhe_keygen_public_key(self.params.ctx, sk.Value.devptr(), ptr, self.params.CRS[0].h, pk.Value.devptr()))
+        return pk
+
+    def GenKeyPair(self, id):
+        """keygen.go:112-115"""
+        sk = self.GenSecretKey(id)
+        return sk, self.GenPublicKey(sk)
+
+    def GenSwitchingKey(self, skIn, swk, e=None):
+        """keygen.go:270-327: swk <- g*skIn + e in MForm"""
+        a, ptr = self._errors(e, self._beta())
+        check(lib().mkhe_keygen_switching_key(self.params.ctx, skIn.Value.devptr(), ptr, swk.h))
+
+    def GenRelinearizationKey(self, sk, r, e=None):
+        """keygen.go:137-187; e: [3][beta][N] for b, d, v"""
+        params = self.params
+        if params.PCount() == 0:
+            raise MkheError("modulus P is empty")
+        a, ptr = self._errors(e, (3, self._beta()))
+        rlk = RelinearizationKey(params, sk.ID)
+        check(lib().mkhe_keygen_relin_key(params.ctx, sk.Value.devptr(), r.Value.devptr(), ptr, params.CRS[0].h, params.CRS[-1].h,
+                                          rlk.Value[0].h, rlk.Value[1].h, rlk.Value[2].h))
+        return rlk
+
+    def GenRotationKey(self, rotidx, sk, e=None):
+        """keygen.go:190-229"""
+        params = self.params
+        if rotidx not in params.CRS:
+            raise MkheError("Cannot GenRotationKey: CRS for given rot idx is not generated")
+        crs = params.CRS[rotidx]
+        while rotidx < 0:
+            rotidx += params.N() // 2
+        a, ptr = self._errors(e, self._beta())
+        rk = RotationKey(params, rotidx, sk.ID)
+        check(lib().mkhe_keygen_rotation_key(params.ctx, params.GaloisElementForColumnRotationBy(rotidx), sk.Value.devptr(), ptr,
+                                             crs.h, rk.Value.h))
+        return rk
+
+    def GenDefaultRotationKeys(self, sk, rtkSet):
+        """keygen.go:232-237"""
+        rotidx = 1
+        while rotidx < self.params.N() // 2:
+            rtkSet.AddRotationKey(self.GenRotationKey(rotidx, sk))
+            rotidx *= 2
+
+    def GenConjugationKey(self, sk, e=None):
+        """keygen.go:240-268"""
+        params = self.params
+        a, ptr = self._errors(e, self._beta())
+        ck = ConjugationKey(params, sk.ID)
+        check(lib().mkhe_keygen_conjugation_key(params.ctx, sk.Value.devptr(), ptr, params.CRS[-2].h, ck.Value.h))
+        return ck
+
+
+def NewKeyGenerator(params, sampler=None):
+    return KeyGenerator(params, sampler)
 
 
 # ---- raw device buffers for ring-level calls (tests / bench of the NTT kernel)
