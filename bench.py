@@ -211,6 +211,23 @@ def run_single(args):
             params.sync()
             extras[key] = args.steps / (time.perf_counter() - t0)
 
+        # ---- one party's relinearization key generated on the device (samples drawn on the host beforehand,
+        # their upload included) and one CRS expanded from the public seed instead of uploaded
+        kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(args.seed + 5)))
+        params.AddCRS(0)
+        sk, r = kgen.GenSecretKey("user0"), kgen.GenSecretKey("user0")
+        e = kgen.sampler.gaussian(3 * params.Beta(level), params.N())
+        for name, fn in (("relin_keygen_per_sec", lambda: kgen.GenRelinearizationKey(sk, r, e)),
+                         ("crs_expand_per_sec", lambda: params.AddCRS(7))):
+            for _ in range(3):
+                fn()
+            params.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            params.sync()
+            extras[name] = args.steps / (time.perf_counter() - t0)
+
     # ---- CPU baseline: the oracle (single-thread C restatement of the Go path) on the same inputs
     cpu = None
     if not args.no_cpu:

@@ -61,6 +61,8 @@ class Parameters {
     uint64_t GaloisElementForRowRotation() const { return 2ull * N() - 1; }
     // params.AddCRS / NewParameters CRS slots (params.go:37-61): uniform polys (NTT + Montgomery form), uploaded once
     std::shared_ptr<SwitchingKey> AddCRS(int idx, const uint64_t* host_swk);
+    // the same slot expanded on the device from a public seed (mkhe_crs_expand): nothing is uploaded
+    std::shared_ptr<SwitchingKey> AddCRS(int idx, uint64_t seed);
     int party_index(const std::string& id) {
         if (id == "0") throw Error("Cannot IDSet Add : 0 cannot be used");                // idset.go:12-16
         auto it = ids_.find(id);
@@ -102,6 +104,36 @@ inline std::shared_ptr<SwitchingKey> NewSwitchingKey(Parameters& p) { return std
 inline std::shared_ptr<SwitchingKey> Parameters::AddCRS(int idx, const uint64_t* host_swk) {
     return CRS[idx] = std::make_shared<SwitchingKey>(*this, host_swk);
 }
+
+inline std::shared_ptr<SwitchingKey> Parameters::AddCRS(int idx, uint64_t seed) {
+    auto k = std::make_shared<SwitchingKey>(*this);
+    check(mkhe_crs_expand(ctx, seed, idx, k->h));
+    return CRS[idx] = k;
+}
+
+// raw device words behind mkhe_buf_* (secret / public keys: PolyQP buffers)
+class DeviceWords {
+  public:
+    DeviceWords(Parameters& p, size_t words_) : params(p), words(words_) { check(mkhe_buf_alloc(p.ctx, words, &d)); }
+    ~DeviceWords() { if (d) mkhe_buf_free(params.ctx, d); }
+    DeviceWords(const DeviceWords&) = delete;
+    DeviceWords& operator=(const DeviceWords&) = delete;
+    void download(uint64_t* host) const { check(mkhe_buf_download(params.ctx, d, host, words)); }
+    Parameters& params;
+    size_t words;
+    void* d = nullptr;
+};
+// mkrlwe.SecretKey keys.go:9-12 / PublicKey :15-18: PolyQP (NTT, Montgomery form) resp. two of them, on the device
+struct SecretKey {
+    SecretKey(Parameters& p, std::string id) : ID(std::move(id)), Value(p, (size_t)(p.QCount() + p.PCount()) * p.N()) {}
+    std::string ID;
+    DeviceWords Value;
+};
+struct PublicKey {
+    PublicKey(Parameters& p, std::string id) : ID(std::move(id)), Value(p, 2 * (size_t)(p.QCount() + p.PCount()) * p.N()) {}
+    std::string ID;
+    DeviceWords Value;
+};
 
 // keys.go:34-37: Value = (b, d, v)
 struct RelinearizationKey {
@@ -231,6 +263,53 @@ class KeySwitcher {
     Parameters& params;
 };
 inline IDSet Union(const IDSet& a, const IDSet& b) { IDSet r = a; r.insert(b.begin(), b.end()); return r; }
+
+// mkrlwe.KeyGenerator (keygen.go:13-40) on the device.  The small-norm SAMPLES (what lattigo's ternary / Gaussian samplers
+// draw) are arguments: int32, N per polynomial, from the caller's CSPRNG -- secret randomness never comes from the GPU.
+class KeyGenerator {
+  public:
+    explicit KeyGenerator(Parameters& p) : params(p) {}
+    std::unique_ptr<SecretKey> GenSecretKey(const std::string& id, const int32_t* s) {                                   // keygen.go:44-76
+        auto sk = std::make_unique<SecretKey>(params, id);
+        check(mkhe_keygen_secret(params.ctx, s, sk->Value.d));
+        return sk;
+    }
+    std::unique_ptr<PublicKey> GenPublicKey(const SecretKey& sk, const int32_t* e) {                                     // keygen.go:88-109
+        auto pk = std::make_unique<PublicKey>(params, sk.ID);
+        check(mkhe_keygen_public_key(params.ctx, sk.Value.d, e, crs(0)->h, pk->Value.d));
+        return pk;
+    }
+    void GenSwitchingKey(const SecretKey& skIn, SwitchingKey& swk, const int32_t* e) {                                   // keygen.go:270-327
+        check(mkhe_keygen_switching_key(params.ctx, skIn.Value.d, e, swk.h));
+    }
+    std::shared_ptr<RelinearizationKey> GenRelinearizationKey(const SecretKey& sk, const SecretKey& r, const int32_t* e) {   // keygen.go:137-187
+        if (params.PCount() == 0) throw Error("modulus P is empty");
+        auto rlk = std::make_shared<RelinearizationKey>(params, sk.ID, nullptr, nullptr, nullptr);
+        check(mkhe_keygen_relin_key(params.ctx, sk.Value.d, r.Value.d, e, crs(0)->h, crs(-1)->h, rlk->Value[0]->h, rlk->Value[1]->h, rlk->Value[2]->h));
+        return rlk;
+    }
+    std::shared_ptr<RotationKey> GenRotationKey(int rotidx, const SecretKey& sk, const int32_t* e) {                     // keygen.go:190-229
+        if (!params.CRS.count(rotidx)) throw Error("Cannot GenRotationKey: CRS for given rot idx is not generated");
+        auto a = params.CRS.at(rotidx);
+        while (rotidx < 0) rotidx += params.N() / 2;
+        auto rk = std::make_shared<RotationKey>(params, rotidx, sk.ID, nullptr);
+        check(mkhe_keygen_rotation_key(params.ctx, params.GaloisElementForColumnRotationBy(rotidx), sk.Value.d, e, a->h, rk->Value->h));
+        return rk;
+    }
+    std::shared_ptr<ConjugationKey> GenConjugationKey(const SecretKey& sk, const int32_t* e) {                           // keygen.go:240-268
+        auto ck = std::make_shared<ConjugationKey>(params, sk.ID, nullptr);
+        check(mkhe_keygen_conjugation_key(params.ctx, sk.Value.d, e, crs(-2)->h, ck->Value->h));
+        return ck;
+    }
+    Parameters& params;
+
+  protected:
+    std::shared_ptr<SwitchingKey> crs(int idx) {
+        auto it = params.CRS.find(idx);
+        if (it == params.CRS.end()) throw Error("mkhe: CRS[" + std::to_string(idx) + "] is not generated");
+        return it->second;
+    }
+};
 }  // namespace mkrlwe
 
 namespace mkckks {

@@ -7,7 +7,7 @@
 #include <cstring>
 #include "mkhe.hpp"
 extern "C" {
-#include "ora_mkbfv.h"
+#include "ora_keygen.h"
 }
 
 typedef std::vector<uint64_t> vec;
@@ -84,6 +84,29 @@ int main() {
         bool threw = false;
         try { mkrlwe::RelinearizationKeySet empty; eval.MulRelinNew(ct0, ct1, empty); } catch (const mkhe::Error& e) { threw = std::strstr(e.what(), "cannot GetRelinearizationKey") != nullptr; }
         expect(threw, "missing relinearization key raises the reference's panic text");
+        // ---- mkrlwe.KeyGenerator on the device with a CRS expanded from a public seed, against the oracle on the same samples
+        auto a = params.AddCRS(0, (uint64_t)0x5EED), uu = params.AddCRS(-1, (uint64_t)0x5EED), a3 = params.AddCRS(3, (uint64_t)0x5EED);
+        const size_t beta = Q.size();
+        vec ah(u.size()), uh(u.size()), a3h(u.size()), oexp(u.size());
+        a->download(ah.data()); uu->download(uh.data()); a3->download(a3h.data());
+        ora_crs_expand(ks, 0x5EED, 0, oexp.data());
+        expect(ah == oexp, "Parameters.AddCRS(idx, seed): CRS expanded on the device");
+        std::vector<int32_t> s(N), r(N), e(3 * beta * N);
+        for (auto& x : s) x = (int32_t)(next64() % 3) - 1;
+        for (auto& x : r) x = (int32_t)(next64() % 3) - 1;
+        for (auto& x : e) x = (int32_t)(next64() % 39) - 19;
+        mkrlwe::KeyGenerator kgen(params);
+        auto sk = kgen.GenSecretKey("alice", s.data()), rr = kgen.GenSecretKey("alice", r.data());
+        auto gen = kgen.GenRelinearizationKey(*sk, *rr, e.data());
+        vec skh((Q.size() + P.size()) * N), rh(skh.size()), ob(u.size()), od(u.size()), ov(u.size()), gb(u.size()), gd(u.size()), gv(u.size());
+        ora_gen_secret_key(ks, s.data(), skh.data()); ora_gen_secret_key(ks, r.data(), rh.data());
+        ora_gen_relin_key(ks, skh.data(), rh.data(), e.data(), ah.data(), uh.data(), ob.data(), od.data(), ov.data());
+        gen->Value[0]->download(gb.data()); gen->Value[1]->download(gd.data()); gen->Value[2]->download(gv.data());
+        expect(gb == ob && gd == od && gv == ov, "mkrlwe.KeyGenerator.GenRelinearizationKey");
+        auto grk = kgen.GenRotationKey(rot, *sk, e.data());
+        ora_gen_rotation_key(ks, params.GaloisElementForColumnRotationBy(rot), skh.data(), e.data(), a3h.data(), ob.data());
+        grk->Value->download(gb.data());
+        expect(gb == ob, "mkrlwe.KeyGenerator.GenRotationKey");
         ora_ks_free(ks);
     }
     {   // ---------------- mkbfv: MulRelinNew
