@@ -158,18 +158,32 @@ def run_single(args):
     from mkhe_kklss_amd import mkrlwe, mkckks
     from mkhe_kklss_amd._abi import check, lib
 
-    pset = H.PN15QP880 if args.params == "PN15QP880" else H.PN14QP439
+    pset = {"PN15QP880": H.PN15QP880, "PN14QP439": H.PN14QP439, "PN16QP1761": H.PN16QP1761}[args.params]
     k = args.parties
     names = ["user%d" % i for i in range(k)]
-    data = synth_inputs(pset, k, args.seed)
     params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"], device=0)
     level = len(pset["Q"]) - 1
+    device_keys = args.device_keys or args.params == "PN16QP1761"
+    rlk = mkrlwe.RelinearizationKeySet(params)
+    if device_keys:
+        # uniform key material written by the engine's own CRS expander (mkhe_crs_expand) instead of 1 GB per party
+        # of host random numbers: same distribution, nothing to upload; no host copy, hence no CPU-oracle comparison
+        op0, op1 = synth_cts(pset, k, args.seed)
+        data = dict(op0=op0, op1=op1)
+        for i, n in enumerate(names):
+            key = mkrlwe.RelinearizationKey(params, n)
+            for j in range(3):
+                check(lib().mkhe_crs_expand(params.ctx, args.seed, 1000 + 3 * i + j, key.Value[j].h))
+            rlk.AddRelinearizationKey(key)
+        params.AddCRS(-1, seed=args.seed)
+        args.no_cpu = True
+    else:
+        data = synth_inputs(pset, k, args.seed)
+        for n, (b, d, v) in zip(names, data["rlk"]):
+            rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, n, b, d, v))
+        params.AddCRS(-1, data["u"])
     ct0 = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(data["op0"])
     ct1 = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(data["op1"])
-    rlk = mkrlwe.RelinearizationKeySet(params)
-    for n, (b, d, v) in zip(names, data["rlk"]):
-        rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, n, b, d, v))
-    params.AddCRS(-1, data["u"])
     ev = mkckks.NewEvaluator(params)
     if os.environ.get("MKHE_NO_OVERLAP"):
         check(lib().mkhe_set_overlap(params.ctx, 0))
@@ -195,10 +209,17 @@ def run_single(args):
     if not args.no_extras:
         rot = 1
         rng = np.random.default_rng(args.seed + 99)
-        params.AddCRS(rot, synth_swk(pset, rng))
         rks = mkrlwe.RotationKeySet()
-        for n in names:
-            rks.AddRotationKey(mkrlwe.RotationKey(params, rot, n, synth_swk(pset, rng)))
+        if device_keys:
+            params.AddCRS(rot, seed=args.seed)
+            for i, n in enumerate(names):
+                rk = mkrlwe.RotationKey(params, rot, n)
+                check(lib().mkhe_crs_expand(params.ctx, args.seed, 2000 + i, rk.Value.h))
+                rks.AddRotationKey(rk)
+        else:
+            params.AddCRS(rot, synth_swk(pset, rng))
+            for n in names:
+                rks.AddRotationKey(mkrlwe.RotationKey(params, rot, n, synth_swk(pset, rng)))
         hh = ev.HoistedForm(ct0)
         for fn, key in ((lambda: ev.RotateNew(ct0, rot, rks), "rotate_per_sec"),
                         (lambda: ev.RotateHoistedNew(ct0, rot, hh, rks), "rotate_hoisted_per_sec")):
@@ -250,7 +271,7 @@ def run_single(args):
                 vs_baseline=None, dtype="u64", data="synthetic",
                 config=dict(workload="mkckks %d-party MulRelin (hoist + MulAndRelinHoisted + Rescale), %s N=2^%d, %d Q + %d P limbs"
                             % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["P"])),
-                            parties=k, params=args.params, seed=args.seed, **extras),
+                            parties=k, params=args.params, seed=args.seed, key_material="device" if device_keys else "host", **extras),
                 roofline=roofline, cpu_baseline=cpu)
 
 
@@ -260,7 +281,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--parties", type=int, default=4)
-    ap.add_argument("--params", default="PN15QP880", choices=["PN15QP880", "PN14QP439"])
+    ap.add_argument("--params", default="PN15QP880", choices=["PN15QP880", "PN14QP439", "PN16QP1761"],
+                    help="PN15QP880 = BASELINE.json configs[1] (default); PN16QP1761 = the configs[3] ring (N = 2^16, 34 + 4 primes, "
+                         "alpha = 2) on ONE GPU, keys written on the device (implies --device-keys, single GPU only)")
+    ap.add_argument("--device-keys", action="store_true",
+                    help="fill keys / CRS with the engine's CRS expander instead of host random numbers (no CPU-oracle check)")
     ap.add_argument("--seed", type=int, default=0x4D4B4845)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=4)

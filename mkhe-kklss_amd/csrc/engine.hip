@@ -472,13 +472,15 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
                 da.nd[d] = dl + 2;
             }
             da.alpha = alpha; da.ndigits = nb; da.nslots = level + 1 + np; da.mtot = mtot; da.N = N; da.nitems = n;
+            // N = 2^16: the forward NTT always runs split; its cross-half stage is applied by the spread kernel itself
+            da.psi = d_psi; da.first_stage = (logN == 16 && !masked_) ? 1 : 0;
             { ProfScope ps(this, PROF_OTHER, 8.0 * N * n * ((level + 1) + (double)nb * da.nslots)); launch_decomp_spread(da, s_); }
             NttBatch b{};
             b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);
             b.src_outer = b.dst_outer = (long)mtot * N; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
             b.nitems = n; b.outers_per_item = nb;
             for (int i = 0; i < n; ++i) { b.src_items[i] = dst[base + i]; b.dst_items[i] = dst[base + i]; }
-            b.nouter = n * nb;
+            b.nouter = n * nb; b.prestaged = da.first_stage; b.skip_norm = internal ? 1 : 0;
             ntt_fwd_launch(b, false);
         }
         MKHE_HIP(hipGetLastError());

@@ -60,6 +60,8 @@ struct NttBatch {
     int split;              // N = 2^16: the register-resident kernels transform the two halves of a limb as 2^15-point
                             // sub-transforms (twiddle rows of 2^16 words, root index 2 + half); the cross-half radix-2 stage
                             // runs as a separate streaming pass (launch_ntt_* do both)
+    int prestaged;          // forward, split launches only: the cross-half stage was already applied by the producer of src
+                            // (decomp_spread_kernel with first_stage): only the sub-transforms run, in place on dst
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
     int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists
     int mod[NTT_MAX_SLOTS];

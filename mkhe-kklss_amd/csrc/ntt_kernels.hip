@@ -535,7 +535,8 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     const bool small = b.lazy_out != 0;
     if (use_split(logN, b)) {
         const dim3 grid(32, b.nslots * b.nouter);
-        if (b.reduce_in) hipLaunchKernelGGL(ntt_split_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+        if (b.prestaged) { /* first stage done by the producer */ }
+        else if (b.reduce_in) hipLaunchKernelGGL(ntt_split_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
         else hipLaunchKernelGGL(ntt_split_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
         const NttBatch c = in_place_of_dst(b);
         if (small) launch_fwd_mode<1, false>(logN - 1, c, st); else launch_fwd_mode<0, false>(logN - 1, c, st);

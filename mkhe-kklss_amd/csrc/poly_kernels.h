@@ -157,6 +157,11 @@ struct DecompSpreadArgs {
     const u64* tc;                     // [ndig][alpha-1][mtot][DEC_MAXA+1]    vtimesqmodp
     int nd[64];                        // limbs of digit d at this level (1 = copy)
     int alpha, ndigits, nslots, mtot, N, nitems;
+    // first_stage (N = 2^16, whose forward NTT always runs split): each thread produces the coefficients n and n + N/2 and
+    // applies the first Cooley-Tukey stage (twiddle psi[m][1]) before storing, exactly as ntt_split_fwd_kernel would -- the
+    // NTT that follows (NttBatch::prestaged) then skips its streaming pass (one read + one write of every digit limb)
+    const u64* psi;                    // forward twiddle tables [mtot][N], signed-split form
+    int first_stage;
 };
 void launch_decomp_spread(const DecompSpreadArgs& a, hipStream_t st);
 

@@ -395,21 +395,67 @@ void launch_basis_conv(const BasisConvArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------ gadget digit spread, alpha >= 2
 typedef const __attribute__((address_space(4))) DecompSpreadArgs* dspread_kargs;
+// value of coefficient n of digit d under target modulus m (lazy, < 4q): the literal reconstructRNS / multSum sequence
+struct SpreadCoeff {
+    u64 y[DEC_MAXA];
+    u64 v;
+};
+__device__ __forceinline__ void spread_prepare(const DecompSpreadArgs& a, const u64* src, const u64* ta, int start, int nd, int n, SpreadCoeff& c) {
+    double vi = 0.0;
+#pragma unroll
+    for (int i = 0; i < DEC_MAXA; ++i) {
+        if (i < nd) {
+            const Mod ms = a.mods[start + i];
+            c.y[i] = mont_mul(src[(long)i * a.N + n], ta[i], ms.q, ms.ninv32);
+            vi = vi + (double)c.y[i] / (double)ms.q;
+        }
+    }
+    c.v = (u64)vi;
+}
+__device__ __forceinline__ u64 spread_value(const SpreadCoeff& c, const u64* tb, const u64* tc, int m, int nd, const Mod& mt) {
+    u64 rlo = 0, rhi = 0;
+#pragma unroll
+    for (int i = 0; i < DEC_MAXA; ++i) {
+        if (i < nd) {
+            u64 mhi, mlo;
+            mul64x64(c.y[i], tb[(long)m * DEC_MAXA + i], mhi, mlo);
+            u64 sum = rlo + mlo;
+            rhi += mhi + (sum < rlo ? 1 : 0);
+            rlo = sum;
+        }
+    }
+    const u64 hhi = mulhi64(rlo * mt.qinv, mt.q);
+    return rhi - hhi + mt.q + tc[(long)m * (DEC_MAXA + 1) + c.v];
+}
+// first Cooley-Tukey stage on the pair (lo, hi) = coefficients (n, n + N/2), both < 4q: same arithmetic as ntt_split_fwd_kernel
+__device__ __forceinline__ void spread_first_stage(u64& lo, u64& hi, u64 w, const Mod& mt) {
+    const u64 U = csub(lo, mt.q2);
+    const u64 Tm = mont_mul_sdu(hi, w, mt.qs, mt.q, mt.ninv32);
+    lo = U + Tm;
+    hi = U + (mt.q2 - Tm);
+}
 __global__ void __launch_bounds__(PW_THREADS) decomp_spread_kernel(DecompSpreadArgs a) {
     dspread_kargs ka = (dspread_kargs)__builtin_amdgcn_kernarg_segment_ptr();
     const int n = blockIdx.x * PW_THREADS + threadIdx.x;
-    if (n >= a.N) return;
+    const int H = a.N >> 1;
+    if (n >= (a.first_stage ? H : a.N)) return;
     const int d = blockIdx.y, item = blockIdx.z;
     const int start = d * a.alpha, nd = ka->nd[d];
     const u64* src = ka->src[item] + (long)start * a.N;
     u64* dst = ka->dst[item] + (long)d * a.mtot * a.N;
     if (nd == 1) {
-        const u64 x = src[n];
+        const u64 x = src[n], x2 = a.first_stage ? src[n + H] : 0;
         const u64 qs = a.mods[start].q;
         for (int s = 0; s < a.nslots; ++s) {
             const int m = a.map[s];
             const Mod mt = a.mods[m];
-            dst[(long)m * a.N + n] = qs > 4 * mt.q ? mont_mul_lazy(x, mt.r1, mt.q, mt.ninv32) : x;
+            u64 lo = qs > 4 * mt.q ? mont_mul_lazy(x, mt.r1, mt.q, mt.ninv32) : x;
+            if (a.first_stage) {
+                u64 hi = qs > 4 * mt.q ? mont_mul_lazy(x2, mt.r1, mt.q, mt.ninv32) : x2;
+                spread_first_stage(lo, hi, a.psi[(long)m * a.N + 1], mt);
+                dst[(long)m * a.N + n + H] = hi;
+            }
+            dst[(long)m * a.N + n] = lo;
         }
         return;
     }
@@ -417,37 +463,24 @@ __global__ void __launch_bounds__(PW_THREADS) decomp_spread_kernel(DecompSpreadA
     const u64* ta = a.ta + tsel * DEC_MAXA;
     const u64* tb = a.tb + tsel * a.mtot * DEC_MAXA;
     const u64* tc = a.tc + tsel * a.mtot * (DEC_MAXA + 1);
-    u64 y[DEC_MAXA];
-    double vi = 0.0;
-#pragma unroll
-    for (int i = 0; i < DEC_MAXA; ++i) {
-        if (i < nd) {
-            const Mod ms = a.mods[start + i];
-            y[i] = mont_mul(src[(long)i * a.N + n], ta[i], ms.q, ms.ninv32);
-            vi = vi + (double)y[i] / (double)ms.q;
-        }
-    }
-    const u64 v = (u64)vi;
+    SpreadCoeff c0, c1;
+    spread_prepare(a, src, ta, start, nd, n, c0);
+    if (a.first_stage) spread_prepare(a, src, ta, start, nd, n + H, c1);
     for (int s = 0; s < a.nslots; ++s) {
         const int m = a.map[s];
         const Mod mt = a.mods[m];
-        u64 rlo = 0, rhi = 0;
-#pragma unroll
-        for (int i = 0; i < DEC_MAXA; ++i) {
-            if (i < nd) {
-                u64 mhi, mlo;
-                mul64x64(y[i], tb[(long)m * DEC_MAXA + i], mhi, mlo);
-                u64 sum = rlo + mlo;
-                rhi += mhi + (sum < rlo ? 1 : 0);
-                rlo = sum;
-            }
+        u64 lo = spread_value(c0, tb, tc, m, nd, mt);
+        if (a.first_stage) {
+            u64 hi = spread_value(c1, tb, tc, m, nd, mt);
+            spread_first_stage(lo, hi, a.psi[(long)m * a.N + 1], mt);
+            dst[(long)m * a.N + n + H] = hi;
         }
-        const u64 hhi = mulhi64(rlo * mt.qinv, mt.q);
-        dst[(long)m * a.N + n] = rhi - hhi + mt.q + tc[(long)m * (DEC_MAXA + 1) + v];
+        dst[(long)m * a.N + n] = lo;
     }
 }
 void launch_decomp_spread(const DecompSpreadArgs& a, hipStream_t st) {
-    const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    const int cnt = a.first_stage ? a.N / 2 : a.N;
+    const int bx = (cnt + PW_THREADS - 1) / PW_THREADS;
     hipLaunchKernelGGL(decomp_spread_kernel, dim3(bx, a.ndigits, a.nitems), dim3(PW_THREADS), 0, st, a);
 }
 
