@@ -1,0 +1,61 @@
+"""The reference's encrypted CNN (cnn/cnn.go, TestCNN cnn_test.go:100-182) on the device (-m gpu): keys and CRS generated
+on the GPU, fresh encryptions from the host harness, the whole circuit (12 MulRelin, 29 rotations, additions, MulPtxt)
+on resident ciphertexts, decrypted logits against the plaintext network.  The reference asserts argmax only (:181)."""
+import numpy as np
+import pytest
+
+import harness_cnn as HC
+
+pytestmark = pytest.mark.gpu
+
+TWO = dict(image="dataOwner", kernels="modelOwner", fc1="modelOwner", fc2="modelOwner")          # cnn_test.go:34-35
+FOUR = dict(image="dataOwner", kernels="convOwner", fc1="fc1Owner", fc2="fc2Owner")              # BASELINE.json configs[4]: 4 parties
+
+
+@pytest.mark.parametrize("owners", [TWO, FOUR], ids=["2party", "4party"])
+def test_encrypted_cnn_matches_plaintext(owners):
+    from mkhe_kklss_amd import cnn
+    sc = HC.CnnScenario(owners, seed=3)
+    model = HC.synthetic_model(7)
+    cts = sc.encrypt_model(model)
+    # the mask is multiplied into square2Out, which sits 4 levels below the fresh ciphertexts
+    pt, pt_scale = sc.mask_plaintext(sc.level - 4)
+    out = cnn.Inference(sc.eval, sc.rlkSet, sc.rtkSet, cts["ctImage"], cts["ctKernels"], cts["ctFC1"], cts["ctFC2"],
+                        cts["ctB1"], cts["ctB2"], pt, pt_scale)
+    assert sorted(out.ids) == sorted(set(owners.values())) and out.Level() == 0
+    got = sc.decrypt(out)[:HC.NCLS]
+    ref = HC.plain_forward(model)
+    err = np.abs(got.real - ref).max()
+    print("logits", np.round(ref, 4), "max abs error", err, "imag", np.abs(got.imag).max())
+    assert int(np.argmax(got.real)) == int(np.argmax(ref))
+    assert err < 1e-3 * max(1.0, np.abs(ref).max())
+
+
+def test_layers_one_by_one():
+    """each layer function against the slot-level circuit on its own inputs (2 parties)"""
+    from mkhe_kklss_amd import cnn
+    sc = HC.CnnScenario(TWO, seed=4)
+    m = HC.synthetic_model(8)
+    ev = sc.eval
+    ctImage = sc.encrypt(HC.pack_image(m), "dataOwner")
+    ctK = [sc.encrypt(v, "modelOwner") for v in HC.pack_kernels(m)]
+    conv = cnn.Convolution(ev, sc.rlkSet, sc.rtkSet, ctImage, ev.HoistedForm(ctImage), ctK, [ev.HoistedForm(c) for c in ctK])
+    img, ker = HC.pack_image(m), HC.pack_kernels(m)
+    exp = img * ker[0] + HC.rot(img, 1) * ker[1] + HC.rot(img, 14) * ker[2] + HC.rot(img, 15) * ker[3]
+    exp = exp + HC.rot(exp, 2048)
+    exp = exp + HC.rot(exp, 1024)
+    assert conv.Level() == sc.level - 1
+    assert np.abs(sc.decrypt(conv) - exp).max() < 1e-6
+    # FC2 on a fresh vector: mask, 4 negative rotations, MulRelin, 6 rotations, bias
+    vec = np.random.default_rng(1).normal(size=HC.SLOTS)
+    ctVec = sc.encrypt(vec, "dataOwner")
+    pt, pts = sc.mask_plaintext(sc.level)
+    out = cnn.FC2Layer(ev, sc.rlkSet, sc.rtkSet, ctVec, sc.encrypt(HC.pack_fc2(m), "modelOwner"), sc.encrypt(HC.pack_b2(m), "modelOwner"), pt, pts)
+    f = vec * HC.mask()
+    for i in range(4):
+        f = f + HC.rot(f, -(1 << i))
+    f = f * HC.pack_fc2(m)
+    for i in range(6):
+        f = f + HC.rot(f, 128 * (1 << i))
+    f = f + HC.pack_b2(m)
+    assert np.abs(sc.decrypt(out)[:HC.NCLS] - f[:HC.NCLS]).max() < 1e-5
