@@ -110,6 +110,75 @@ def run_bfv(args):
                 roofline=roofline, cpu_baseline=cpu)
 
 
+def run_cnn(args):
+    """--scheme cnn: the reference's BenchmarkCNN (cnn/cnn_bench_test.go:11-78): one encrypted inference = Convolution,
+    square, FC1, square, FC2 on PN14QP433; --parties 2 = the reference's dataOwner / modelOwner, 4 = one owner per layer
+    (BASELINE.json configs[4]).  Keys and CRS are generated on the device; ciphertext limbs are uniform (timing does
+    not depend on the values; encrypted == plaintext is tests/test_gpu_cnn.py).  Secondary line, same JSON contract."""
+    import harness_cnn as HC
+    from mkhe_kklss_amd import cnn, mkckks, mkrlwe
+    p = HC.PN14QP433
+    owners = (dict(image="dataOwner", kernels="modelOwner", fc1="modelOwner", fc2="modelOwner") if args.parties <= 2 else
+              dict(image="dataOwner", kernels="convOwner", fc1="fc1Owner", fc2="fc2Owner"))
+    params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"], device=0)
+    params.GenDefaultCRS(seed=args.seed)
+    for r in HC.ROTS:
+        params.AddCRS(r, seed=args.seed)
+    kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(args.seed)))
+    rlkSet, rtkSet = mkrlwe.RelinearizationKeySet(params), mkrlwe.RotationKeySet()
+    t0 = time.perf_counter()
+    for id in sorted(set(owners.values())):
+        sk = kgen.GenSecretKey(id)
+        rlkSet.AddRelinearizationKey(kgen.GenRelinearizationKey(sk, kgen.GenSecretKey(id)))
+        for r in HC.ROTS + [1 << i for i in range(p["logN"] - 1)]:
+            rtkSet.AddRotationKey(kgen.GenRotationKey(r, sk))
+    params.sync()
+    keygen_s = time.perf_counter() - t0
+    rng = np.random.default_rng(args.seed)
+    level, N = len(p["Q"]) - 1, 1 << p["logN"]
+    def ct(id):
+        host = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in p["Q"]]) for _ in range(2)])
+        return mkckks.NewCiphertext(params, [id], level, p["scale"]).upload(host)
+    ctImage, ctKernels = ct(owners["image"]), [ct(owners["kernels"]) for _ in range(4)]
+    ctFC1, ctFC2, ctB1, ctB2 = [ct(owners["fc1"]) for _ in range(8)], ct(owners["fc2"]), ct(owners["fc1"]), ct(owners["fc2"])
+    ptMask = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in p["Q"][: level - 3]])
+    ev = mkckks.NewEvaluator(params)
+    hoisted = (ev.HoistedForm(ctImage), [ev.HoistedForm(c) for c in ctKernels], [ev.HoistedForm(c) for c in ctFC1])     # precomputation, as in the reference
+    layer_ms = {}
+    def timed(name, fn):
+        params.sync(); t = time.perf_counter(); out = fn(); params.sync()
+        layer_ms[name] = layer_ms.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+        return out
+    def inference(record):
+        T = timed if record else (lambda name, fn: fn())
+        convOut = T("Convolution", lambda: cnn.Convolution(ev, rlkSet, rtkSet, ctImage, hoisted[0], ctKernels, hoisted[1]))
+        sq1 = T("Square1", lambda: (lambda h: (ev.MulRelinHoistedNew(convOut, convOut, h, h, rlkSet)))(ev.HoistedForm(convOut)))
+        sq1h = T("Square1", lambda: ev.HoistedForm(sq1))
+        fc1 = T("FC1", lambda: cnn.FC1Layer(ev, rlkSet, rtkSet, sq1, sq1h, ctFC1, hoisted[2], ctB1))
+        sq2 = T("Square2", lambda: (lambda h: ev.MulRelinHoistedNew(fc1, fc1, h, h, rlkSet))(ev.HoistedForm(fc1)))
+        return T("FC2", lambda: cnn.FC2Layer(ev, rlkSet, rtkSet, sq2, ctFC2, ctB2, ptMask, p["scale"]))
+    for _ in range(args.warmup):
+        inference(False)
+    params.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = inference(False)
+    params.sync()
+    dt = time.perf_counter() - t0
+    for _ in range(args.steps):                      # per-layer figures: a second, untimed-for-`value` pass with a sync per layer
+        inference(True)
+    roofline = roofline_leg(args, params, lambda: inference(False), p["logN"], "cnn PN14QP433 k=%d" % len(set(owners.values())))
+    return dict(metric="cnn_inference_per_sec", value=args.steps / dt, unit="inference/s", n_gpus=1, steps=args.steps,
+                warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps, higher_is_better=True, scaling="strong",
+                vs_baseline=None, dtype="u64", data="synthetic",
+                config=dict(workload="cnn encrypted inference (Convolution + square + FC1 + square + FC2, cnn/cnn.go), PN14QP433 N=2^14, "
+                                     "7 Q + 2 P limbs, %d parties" % len(set(owners.values())),
+                            parties=len(set(owners.values())), params="PN14QP433", seed=args.seed,
+                            layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
+                            keygen_s=keygen_s, keys_generated=len(set(owners.values())) * (3 + len(HC.ROTS) + p["logN"] - 1)),
+                roofline=roofline, cpu_baseline=None)
+
+
 def roofline_leg(args, params, step, logN, workload):
     """per-kernel HIP-event timing on the context stream, same steps again (side-stream overlap off: each kernel
     then runs alone, so its duration is the kernel's own and comparable with the rocprofv3 kernel trace taken with
@@ -297,8 +366,9 @@ def main():
     ap.add_argument("--dist-sync", default="auto", choices=["auto", "stream", "host"],
                     help="N > 1, limb sharding: order the collectives on the engine's stream or through the host "
                          "(auto: an untimed probe of both after the warm-up picks the faster one)")
-    ap.add_argument("--scheme", default="ckks", choices=["ckks", "bfv"],
-                    help="ckks = BASELINE.json headline metric (default); bfv = the mkbfv MulRelin line (single GPU)")
+    ap.add_argument("--scheme", default="ckks", choices=["ckks", "bfv", "cnn"],
+                    help="ckks = BASELINE.json headline metric (default); bfv = the mkbfv MulRelin line; cnn = one encrypted "
+                         "CNN inference per step (cnn/cnn.go on PN14QP433; --parties 2 or 4) -- both single GPU")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or args.force_dist:
@@ -306,6 +376,8 @@ def main():
         out = run_distributed(args)
     elif args.scheme == "bfv":
         out = run_bfv(args)
+    elif args.scheme == "cnn":
+        out = run_cnn(args)
     else:
         out = run_single(args)
     if out is not None:

@@ -88,7 +88,11 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
         for (int j = 0; j < i; ++j) if (moduli[j] == q) throw Error("mkhe: repeated modulus");
     }
     if (mall > NTT_MAX_SLOTS) throw Error("mkhe: too many moduli");
-    for (int i = 0; i < mall; ++i) small_q_.push_back(moduli[i] < (1ull << 57) ? 1 : 0);   // 34q < 2^63
+    // moduli whose forward NTT runs without reductions (MODE 1): the signed lazy values stay below 14.65q (4q input + 16
+    // stages of 0.65q, N = 2^16 included), internal digits leave the kernel as x + 16q < 31q and every consumer
+    // (mont_mul_lazy / mont_mul_sd) takes operands below 2^62.  2^62 / 31 = 2^57.05: the 57-bit head prime of the
+    // reference's PN14QP433 chain (2^57 + 0x2b0001) is still in; the 59/60-bit primes of PN15QP880 are not.
+    for (int i = 0; i < mall; ++i) small_q_.push_back(moduli[i] < (1ull << 62) / 31 ? 1 : 0);
     MKHE_HIP(hipSetDevice(device));
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
