@@ -900,23 +900,22 @@ void Context::ct_binary(int op, const Ct& a, const Ct& b, Ct& out) {
     if (a.limbs < L || b.limbs < L) throw Error("mkhe: operand level below ctOut level");
     const size_t PA = (size_t)a.limbs * N, PB = (size_t)b.limbs * N, PO = (size_t)L * N;
     auto find = [](const Ct& c, int id) { for (int i = 0; i < c.n; ++i) if (c.ids[i] == id) return i; return -1; };
+    if (1 + out.n > CTBIN_MAX) throw Error("mkhe: too many parties in one ciphertext");
+    CtBinArgs ba{};
+    ba.mods = d_mods; ba.L = L; ba.N = N; ba.ncomp = 1 + out.n;
+    double bytes = 0;
     for (int o = -1; o < out.n; ++o) {
         const int ia = o < 0 ? 0 : 1 + find(a, out.ids[o]), ib = o < 0 ? 0 : 1 + find(b, out.ids[o]);
-        u64* dst = out.d + (size_t)(1 + o) * PO;
         const bool ha = o < 0 || ia > 0, hb = o < 0 || ib > 0;
         if (!ha && !hb) throw Error("mkhe: ctOut has an id that neither operand has");
-        ProfScope ps(this, PROF_OTHER, 8.0 * N * L * ((ha && hb) ? 3 : 2));
-        if (ha && hb) {
-            if (op == 0) launch_add(dst, a.d + ia * PA, b.d + ib * PB, d_mods, L, N, s_);
-            else launch_sub(dst, a.d + ia * PA, b.d + ib * PB, d_mods, L, N, s_);
-        } else if (ha) {
-            MKHE_HIP(hipMemcpyAsync(dst, a.d + ia * PA, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
-        } else if (op == 0) {
-            MKHE_HIP(hipMemcpyAsync(dst, b.d + ib * PB, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
-        } else {
-            launch_neg(dst, b.d + ib * PB, d_mods, L, N, s_);
-        }
+        const int c = 1 + o;
+        ba.dst[c] = out.d + (size_t)c * PO;
+        ba.a[c] = ha ? a.d + ia * PA : nullptr;
+        ba.b[c] = hb ? b.d + ib * PB : nullptr;
+        ba.mode[c] = (ha && hb) ? (op == 0 ? 0 : 1) : ha ? 2 : (op == 0 ? 3 : 4);
+        bytes += 8.0 * N * L * ((ha && hb) ? 3 : 2);
     }
+    { ProfScope ps(this, PROF_OTHER, bytes); launch_ct_binary(ba, s_); }
     MKHE_HIP(hipGetLastError());
 }
 

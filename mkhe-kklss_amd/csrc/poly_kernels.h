@@ -187,6 +187,17 @@ void launch_mul_const_halves(const MulConstArgs& a, hipStream_t st);
 // dst[p][l][n] = a[p][l][n] * MForm(b[l][n])  (one polynomial b against npolys polynomials: MulPtxtNew, evaluator.go:471-478)
 void launch_mul_by_poly(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, int npolys, hipStream_t st);
 
+// all components of a ciphertext Add / Sub in ONE launch (mkckks/evaluator.go:200-304 evaluateInPlace, mkbfv/evaluator.go:27-76):
+// per component mode 0: a + b, 1: a - b, 2: copy a, 3: copy b, 4: -b (q - b, 0 -> q like ring.Neg)
+constexpr int CTBIN_MAX = 65;
+struct CtBinArgs {
+    const u64* a[CTBIN_MAX]; const u64* b[CTBIN_MAX]; u64* dst[CTBIN_MAX];
+    unsigned char mode[CTBIN_MAX];
+    const Mod* mods;
+    int L, N, ncomp;
+};
+void launch_ct_binary(const CtBinArgs& a, hipStream_t st);
+
 // dst = CRed(a + b) per limb
 void launch_add(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st);
 

@@ -281,6 +281,29 @@ void launch_sub(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, in
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(sub_kernel, dim3(bx, L), dim3(PW_THREADS), 0, st, dst, a, b, mods, N);
 }
+typedef const __attribute__((address_space(4))) CtBinArgs* ctbin_kargs;
+__global__ void __launch_bounds__(PW_THREADS) ct_binary_kernel(CtBinArgs a) {
+    ctbin_kargs ka = (ctbin_kargs)__builtin_amdgcn_kernarg_segment_ptr();      // per-component lists: scalar loads, no scratch copy
+    const int l = blockIdx.y, c = blockIdx.z;
+    const u64 q = a.mods[l].q;
+    const u64* x = ka->a[c]; const u64* y = ka->b[c]; u64* dst = ka->dst[c];
+    const int mode = ka->mode[c];
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
+        const long e = (long)l * a.N + n;
+        u64 v;
+        if (mode == 0) v = csub(x[e] + y[e], q);
+        else if (mode == 1) v = csub(x[e] + q - y[e], q);
+        else if (mode == 2) v = x[e];
+        else if (mode == 3) v = y[e];
+        else v = q - y[e];
+        dst[e] = v;
+    }
+}
+void launch_ct_binary(const CtBinArgs& a, hipStream_t st) {
+    int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(ct_binary_kernel, dim3(bx, a.L, a.ncomp), dim3(PW_THREADS), 0, st, a);
+}
 // ring.Neg writes q - a, i.e. q for a = 0 (lattigo ring_operations.go Neg), kept literally
 __global__ void __launch_bounds__(PW_THREADS) neg_kernel(u64* dst, const u64* x, const Mod* mods, int N) {
     const int l = blockIdx.y;

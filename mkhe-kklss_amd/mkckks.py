@@ -56,7 +56,7 @@ class Evaluator:
     def newCiphertextBinary(self, op0, op1):
         """evaluator.go:306-313"""
         return NewCiphertext(self.params, op0.IDSet() | op1.IDSet(), min(op0.Level(), op1.Level()),
-                             max(op0.ScalingFactor(), op1.ScalingFactor()))
+                             max(op0.ScalingFactor(), op1.ScalingFactor()), zero=False)      # every limb is written by the engine call that follows
 
     # ---- AddNew / SubNew (evaluator.go:316-357 -> evaluateInPlace :200-304)
     def _binary(self, op0, op1, fn):
@@ -118,7 +118,7 @@ class Evaluator:
 
     # ---- DropLevelNew (evaluator.go:96-114): keep the first level+1-levels limbs of every component
     def DropLevelNew(self, ct0, levels):
-        out = NewCiphertext(self.params, ct0.IDSet(), ct0.Level() - levels, ct0.Scale)
+        out = NewCiphertext(self.params, ct0.IDSet(), ct0.Level() - levels, ct0.Scale, zero=False)
         one = np.array([(1 << 64) % q for q in self.params.Q[: out.Level() + 1]], dtype=np.uint64)      # MForm(1): x * 1
         check(lib().mkhe_ct_mul_const(self.params.ctx, ct0.h, one.ctypes.data_as(_abi.u64p), one.ctypes.data_as(_abi.u64p), out.h))
         return out
@@ -127,7 +127,7 @@ class Evaluator:
     def MulPtxtNew(self, ct, pt_value, pt_scale):
         params = self.params
         level = ct.Level()
-        ctOut = NewCiphertext(params, ct.IDSet(), level, ct.Scale * float(pt_scale))
+        ctOut = NewCiphertext(params, ct.IDSet(), level, ct.Scale * float(pt_scale), zero=False)
         pt = mkrlwe.DeviceLimbs(params, 1, level + 1).upload(np.ascontiguousarray(pt_value, dtype=np.uint64)[None, : level + 1])
         check(lib().mkhe_ct_mul_ptxt(params.ctx, ct.h, pt.devptr(), ctOut.h))
         if ctOut.Level() == 0:                 # eval.Rescale returns an error there; MulPtxtNew ignores it (:480)
@@ -135,7 +135,7 @@ class Evaluator:
         nb, scale = self.nbRescales(ctOut, params.Scale())
         if nb == 0:
             return ctOut
-        res = NewCiphertext(params, ctOut.IDSet(), level - nb, scale)
+        res = NewCiphertext(params, ctOut.IDSet(), level - nb, scale, zero=False)
         check(lib().mkhe_rescale(params.ctx, ctOut.h, nb, res.h))
         return res
 
@@ -156,7 +156,7 @@ class Evaluator:
         if ct0.Level() == 0:
             raise MkheError("cannot Rescale: input Ciphertext already at level 0")
         nb, scale = self.nbRescales(ct0, threshold)
-        out = NewCiphertext(self.params, ct0.IDSet(), ct0.Level() - nb, scale)
+        out = NewCiphertext(self.params, ct0.IDSet(), ct0.Level() - nb, scale, zero=False)
         check(lib().mkhe_rescale(self.params.ctx, ct0.h, nb, out.h))
         return out
 
@@ -191,7 +191,7 @@ class Evaluator:
     # ---- RotateNew (evaluator.go:485-525)
     def RotateNew(self, ct0, rotidx, rkSet):
         rotidx = self._norm_rot(rotidx)
-        ctOut = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale)
+        ctOut = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale, zero=False)
         if rotidx == 0:
             ctOut.upload(ct0.download())
             return ctOut
@@ -201,7 +201,7 @@ class Evaluator:
         ctTmp, k = ct0, 1
         while rotidx > 0:                                   # power-of-two decomposition, :516-523
             if rotidx % 2:
-                nxt = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale)
+                nxt = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale, zero=False)
                 self.ksw.Rotate(ctTmp, k, rkSet, nxt)
                 ctTmp = nxt
             rotidx //= 2
@@ -211,7 +211,7 @@ class Evaluator:
     # ---- RotateHoistedNew (evaluator.go:585-617)
     def RotateHoistedNew(self, ct0, rotidx, ct0Hoisted, rkSet):
         rotidx = self._norm_rot(rotidx)
-        ctOut = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale)
+        ctOut = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale, zero=False)
         if rotidx == 0:
             ctOut.upload(ct0.download())
             return ctOut
@@ -222,7 +222,7 @@ class Evaluator:
 
     # ---- ConjugateNew (evaluator.go:527-541)
     def ConjugateNew(self, ct0, ckSet):
-        ctOut = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale)
+        ctOut = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale, zero=False)
         self.ksw.Conjugate(ct0, ckSet, ctOut)
         return ctOut
 
