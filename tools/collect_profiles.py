@@ -29,6 +29,12 @@ for d, name in (("stats_noovl", "kernel_stats_noovl"), ("stats_ovl", "kernel_sta
     shutil.copy(os.path.join(G, d, "p_kernel_stats.csv"), os.path.join(P, "%s_%s.csv" % (tag, name)))
 for f in ("bench_noovl", "bench_ovl", "bench_plain", "bench_bfv"):
     shutil.copy(os.path.join(G, f + ".json"), os.path.join(P, "%s_%s.json" % (tag, f)))
+for d, name in (("stats_pn16", "kernel_stats_pn16"), ("stats_cnn", "kernel_stats_cnn")):
+    if os.path.exists(os.path.join(G, d, "p_kernel_stats.csv")):
+        shutil.copy(os.path.join(G, d, "p_kernel_stats.csv"), os.path.join(P, "%s_%s.csv" % (tag, name)))
+for f in ("bench_pn16", "bench_pn16_noovl", "bench_cnn2", "bench_cnn4", "bench_cnn_noovl", "bench_bfv_plain"):
+    if os.path.exists(os.path.join(G, f + ".json")):
+        shutil.copy(os.path.join(G, f + ".json"), os.path.join(P, "%s_%s.json" % (tag, f)))
 out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "traffic_from_pmc.py"),
                                os.path.join(G, "pmc_fetch"), os.path.join(G, "pmc_write"), workload])
 open(os.path.join(P, "traffic.json"), "wb").write(out)
