@@ -143,6 +143,7 @@ def run_cnn(args):
     ctFC1, ctFC2, ctB1, ctB2 = [ct(owners["fc1"]) for _ in range(8)], ct(owners["fc2"]), ct(owners["fc1"]), ct(owners["fc2"])
     ptMask = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in p["Q"][: level - 3]])
     ev = mkckks.NewEvaluator(params)
+    forks = [ev.Fork() for _ in range(max(0, args.forks))]       # extra engine contexts: the independent chains of a layer overlap
     hoisted = (ev.HoistedForm(ctImage), [ev.HoistedForm(c) for c in ctKernels], [ev.HoistedForm(c) for c in ctFC1])     # precomputation, as in the reference
     layer_ms = {}
     def timed(name, fn):
@@ -151,10 +152,10 @@ def run_cnn(args):
         return out
     def inference(record):
         T = timed if record else (lambda name, fn: fn())
-        convOut = T("Convolution", lambda: cnn.Convolution(ev, rlkSet, rtkSet, ctImage, hoisted[0], ctKernels, hoisted[1]))
+        convOut = T("Convolution", lambda: cnn.Convolution(ev, rlkSet, rtkSet, ctImage, hoisted[0], ctKernels, hoisted[1], forks))
         sq1 = T("Square1", lambda: (lambda h: (ev.MulRelinHoistedNew(convOut, convOut, h, h, rlkSet)))(ev.HoistedForm(convOut)))
         sq1h = T("Square1", lambda: ev.HoistedForm(sq1))
-        fc1 = T("FC1", lambda: cnn.FC1Layer(ev, rlkSet, rtkSet, sq1, sq1h, ctFC1, hoisted[2], ctB1))
+        fc1 = T("FC1", lambda: cnn.FC1Layer(ev, rlkSet, rtkSet, sq1, sq1h, ctFC1, hoisted[2], ctB1, forks))
         sq2 = T("Square2", lambda: (lambda h: ev.MulRelinHoistedNew(fc1, fc1, h, h, rlkSet))(ev.HoistedForm(fc1)))
         return T("FC2", lambda: cnn.FC2Layer(ev, rlkSet, rtkSet, sq2, ctFC2, ctB2, ptMask, p["scale"]))
     for _ in range(args.warmup):
@@ -174,7 +175,7 @@ def run_cnn(args):
                 config=dict(workload="cnn encrypted inference (Convolution + square + FC1 + square + FC2, cnn/cnn.go), PN14QP433 N=2^14, "
                                      "7 Q + 2 P limbs, %d parties" % len(set(owners.values())),
                             parties=len(set(owners.values())), params="PN14QP433", seed=args.seed,
-                            layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
+                            forks=len(forks), layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
                             keygen_s=keygen_s, keys_generated=len(set(owners.values())) * (3 + len(HC.ROTS) + p["logN"] - 1)),
                 roofline=roofline, cpu_baseline=None)
 
@@ -353,6 +354,8 @@ def main():
     ap.add_argument("--params", default="PN15QP880", choices=["PN15QP880", "PN14QP439", "PN16QP1761"],
                     help="PN15QP880 = BASELINE.json configs[1] (default); PN16QP1761 = the configs[3] ring (N = 2^16, 34 + 4 primes, "
                          "alpha = 2) on ONE GPU, keys written on the device (implies --device-keys, single GPU only)")
+    ap.add_argument("--forks", type=int, default=7,
+                    help="--scheme cnn: extra engine contexts through which the independent chains of a layer are issued (0 = one stream)")
     ap.add_argument("--device-keys", action="store_true",
                     help="fill keys / CRS with the engine's CRS expander instead of host random numbers (no CPU-oracle check)")
     ap.add_argument("--seed", type=int, default=0x4D4B4845)

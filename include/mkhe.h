@@ -45,6 +45,13 @@ int  mkhe_ctx_create(mkhe_ctx** out, int logN, const uint64_t* Q, int nQ, const 
                      int gamma, const uint64_t* psiQ, const uint64_t* psiP, int device);
 void mkhe_ctx_destroy(mkhe_ctx* ctx);
 int  mkhe_ctx_sync(mkhe_ctx* ctx);
+/* Several contexts over the same ring on one device (no reference counterpart: the Go evaluator is single-threaded): each
+ * has its own stream and scratch pools; keys, CRS, hoisted forms and ciphertexts are plain device memory behind their
+ * handles and may be used through any of them.  Independent operations issued through different contexts overlap on the
+ * GPU.  mkhe_ctx_wait_for orders them without a host synchronisation: work enqueued on ctx after the call starts only
+ * after everything enqueued on other before the call has finished.  A handle must be destroyed through the context that
+ * created it, after every other context that used it has been waited for. */
+int  mkhe_ctx_wait_for(mkhe_ctx* ctx, mkhe_ctx* other);
 int  mkhe_ctx_alpha(const mkhe_ctx* ctx);                 /* Parameters.Alpha  params.go:63-65 */
 int  mkhe_ctx_beta(const mkhe_ctx* ctx, int level);       /* Parameters.Beta   params.go:67-71 */
 int  mkhe_ctx_n(const mkhe_ctx* ctx);

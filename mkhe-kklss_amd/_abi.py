@@ -18,6 +18,7 @@ SIGNATURES = {
     "mkhe_ctx_create": (C.c_int, [vpp, C.c_int, u64p, C.c_int, u64p, C.c_int, C.c_int, u64p, u64p, C.c_int]),
     "mkhe_ctx_destroy": (None, [vp]),
     "mkhe_ctx_sync": (C.c_int, [vp]),
+    "mkhe_ctx_wait_for": (C.c_int, [vp, vp]),
     "mkhe_ctx_alpha": (C.c_int, [vp]),
     "mkhe_ctx_beta": (C.c_int, [vp, C.c_int]),
     "mkhe_ctx_n": (C.c_int, [vp]),

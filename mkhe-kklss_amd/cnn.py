@@ -1,29 +1,55 @@
 """The reference's encrypted-CNN caller (package `cnn`, cnn/cnn.go) on the device-resident evaluator: the three layer
 functions with the reference's names and argument order.  Every ciphertext, hoisted form and key stays in HBM between
-the calls; the only host work is the float64 scale bookkeeping inside the mkckks mirror."""
+the calls; the only host work is the float64 scale bookkeeping inside the mkckks mirror.
+
+`forks` (optional, a list of mkckks.Evaluator.Fork() evaluators): the independent rotate -> hoist -> MulRelin chains of
+Convolution (3) and FC1Layer (8) are issued through different engine contexts and overlap on the GPU -- every launch of
+this workload covers a few dozen 2^14-point limbs, a fraction of the 256 CUs.  Results are the same bit for bit."""
 
 
-def Convolution(eval, rlkSet, rtkSet, ctImage, ctImageHoisted, ctKernels, ctKernelsHoisted):
+def _fan_out(eval, used):
+    for f in used:
+        f.params.wait_for(eval.params)
+
+
+def _fan_in(eval, used):
+    for f in used:
+        eval.params.wait_for(f.params)
+
+
+def Convolution(eval, rlkSet, rtkSet, ctImage, ctImageHoisted, ctKernels, ctKernelsHoisted, forks=None):
     """cnn.go:10-39: kernels pre-rotated by 0, 1, 14, 15; the image is hoisted once and reused by the three rotations"""
+    def chain(ev, i, rot):
+        temp = ev.RotateHoistedNew(ctImage, rot, ctImageHoisted, rtkSet)
+        tempHoisted = ev.HoistedForm(temp)
+        return ev.MulRelinHoistedNew(temp, ctKernels[i], tempHoisted, ctKernelsHoisted[i], rlkSet)
+    work = ((1, 1), (2, 14), (3, 15))
+    used = [forks[j % len(forks)] for j in range(len(work))] if forks else []
+    _fan_out(eval, set(used))
     convOut = eval.MulRelinHoistedNew(ctImage, ctKernels[0], ctImageHoisted, ctKernelsHoisted[0], rlkSet)
-    for i, rot in ((1, 1), (2, 14), (3, 15)):
-        temp = eval.RotateHoistedNew(ctImage, rot, ctImageHoisted, rtkSet)
-        tempHoisted = eval.HoistedForm(temp)
-        temp = eval.MulRelinHoistedNew(temp, ctKernels[i], tempHoisted, ctKernelsHoisted[i], rlkSet)
+    temps = [chain(used[j] if forks else eval, i, rot) for j, (i, rot) in enumerate(work)]
+    _fan_in(eval, set(used))
+    for temp in temps:
         convOut = eval.AddNew(convOut, temp)
     for rot in (2048, 1024):
         convOut = eval.AddNew(convOut, eval.RotateNew(convOut, rot, rtkSet))
     return convOut
 
 
-def FC1Layer(eval, rlkSet, rtkSet, ctVec, ctVecHoisted, ctMat, ctMatHoisted, ctBias):
+def FC1Layer(eval, rlkSet, rtkSet, ctVec, ctVecHoisted, ctMat, ctMatHoisted, ctBias, forks=None):
     """cnn.go:41-71: diagonal-packed 64 x 1024 matrix in 8 ciphertexts, then a log-sum over each 128-slot block"""
-    fc1Out = None
-    for i in range(len(ctMat)):
-        temp = eval.RotateHoistedNew(ctVec, i * 128, ctVecHoisted, rtkSet)
-        tempHoisted = eval.HoistedForm(temp)
-        temp = eval.MulRelinHoistedNew(temp, ctMat[i], tempHoisted, ctMatHoisted[i], rlkSet)
-        fc1Out = temp if i == 0 else eval.AddNew(fc1Out, temp)
+    def chain(ev, i):
+        temp = ev.RotateHoistedNew(ctVec, i * 128, ctVecHoisted, rtkSet)
+        tempHoisted = ev.HoistedForm(temp)
+        return ev.MulRelinHoistedNew(temp, ctMat[i], tempHoisted, ctMatHoisted[i], rlkSet)
+    evs = [eval] + list(forks or [])
+    used = set(evs[i % len(evs)] for i in range(len(ctMat))) - {eval}
+    _fan_out(eval, used)
+    temps = [chain(evs[i % len(evs)], i) for i in range(len(ctMat))]
+    _fan_in(eval, used)
+    fc1Out = temps[0]
+    for temp in temps[1:]:
+        fc1Out = eval.AddNew(fc1Out, temp)
     for i in range(7):                                        # log2(128)
         fc1Out = eval.AddNew(fc1Out, eval.RotateNew(fc1Out, 1 << i, rtkSet))
     return eval.AddNew(fc1Out, ctBias)
@@ -40,17 +66,17 @@ def FC2Layer(eval, rlkSet, rtkSet, ctVec, ctMat, ctBias, ptMask, ptMaskScale):
     return eval.AddNew(fc2Out, ctBias)
 
 
-def Inference(eval, rlkSet, rtkSet, ctImage, ctKernels, ctFC1, ctFC2, ctB1, ctB2, ptMask, ptMaskScale, hoisted=None):
+def Inference(eval, rlkSet, rtkSet, ctImage, ctKernels, ctFC1, ctFC2, ctB1, ctB2, ptMask, ptMaskScale, hoisted=None, forks=None):
     """the evaluation part of TestCNN / BenchmarkCNN (cnn_test.go:153-165): convolution, square, FC1, square, FC2.
     hoisted: optional (ctImageHoisted, ctKernelsHoisted, ctFC1Hoisted) precomputed by the caller, as the reference does."""
     if hoisted is None:
         hoisted = (eval.HoistedForm(ctImage), [eval.HoistedForm(c) for c in ctKernels], [eval.HoistedForm(c) for c in ctFC1])
     ctImageHoisted, ctKernelsHoisted, ctFC1Hoisted = hoisted
-    convOut = Convolution(eval, rlkSet, rtkSet, ctImage, ctImageHoisted, ctKernels, ctKernelsHoisted)
+    convOut = Convolution(eval, rlkSet, rtkSet, ctImage, ctImageHoisted, ctKernels, ctKernelsHoisted, forks)
     convOutHoisted = eval.HoistedForm(convOut)
     square1Out = eval.MulRelinHoistedNew(convOut, convOut, convOutHoisted, convOutHoisted, rlkSet)
     square1OutHoisted = eval.HoistedForm(square1Out)
-    fc1Out = FC1Layer(eval, rlkSet, rtkSet, square1Out, square1OutHoisted, ctFC1, ctFC1Hoisted, ctB1)
+    fc1Out = FC1Layer(eval, rlkSet, rtkSet, square1Out, square1OutHoisted, ctFC1, ctFC1Hoisted, ctB1, forks)
     fc1OutHoisted = eval.HoistedForm(fc1Out)
     square2Out = eval.MulRelinHoistedNew(fc1Out, fc1Out, fc1OutHoisted, fc1OutHoisted, rlkSet)
     return FC2Layer(eval, rlkSet, rtkSet, square2Out, ctFC2, ctB2, ptMask, ptMaskScale)

@@ -39,6 +39,9 @@ int mkhe_ctx_create(mkhe_ctx** out, int logN, const uint64_t* Q, int nQ, const u
 }
 void mkhe_ctx_destroy(mkhe_ctx* ctx) { if (ctx) { delete ctx->c; delete ctx; } }
 int mkhe_ctx_sync(mkhe_ctx* ctx) { MKHE_TRY(ctx->c->sync()) }
+int mkhe_ctx_wait_for(mkhe_ctx* ctx, mkhe_ctx* other) {
+    MKHE_TRY({ if (!ctx || !other) throw Error("mkhe_ctx_wait_for: null argument"); ctx->c->wait_for(*other->c); })
+}
 int mkhe_ctx_alpha(const mkhe_ctx* ctx) { return ctx->c->alpha; }
 int mkhe_ctx_beta(const mkhe_ctx* ctx, int level) { return ctx->c->beta(level); }
 int mkhe_ctx_n(const mkhe_ctx* ctx) { return ctx->c->N; }

@@ -135,6 +135,11 @@ class Context {
     u64* pool_alloc(size_t words);
     void pool_free(u64* p, size_t words);
     void sync() { MKHE_HIP(hipStreamSynchronize(stream)); }
+    // cross-context ordering on one device: everything enqueued on this context from now on starts after everything
+    // enqueued on `other` so far has finished (event on other's stream; no host synchronisation).  Contexts over the same
+    // ring share keys / CRS / ciphertext handles freely (handles are plain device memory): independent operations issued
+    // through different contexts overlap on the GPU.
+    void wait_for(Context& other);
 
     // ---- per-kernel-class timing with HIP events on the context stream (bench.py roofline leg)
     enum { PROF_NTT_DECOMP = 0, PROF_NTT_DECOMP_BIGQ, PROF_NTT_FWD, PROF_NTT_FWD_BIGQ, PROF_NTT_INV, PROF_INNER, PROF_EXT_INNER,
@@ -216,6 +221,7 @@ class Context {
     hipEvent_t prof_event();
     hipStream_t s_ = nullptr;                                // active stream of the launch helpers
     hipEvent_t ev_[8] = {};                                  // fork/join events of the side stream
+    hipEvent_t xev_ = nullptr;                               // wait_for
     void fork_side(int k);      // side stream waits for everything enqueued so far on the active stream
     void side_done(int k);      // marks the end of side chain k
     void join_side(int k);      // active stream waits for side chain k

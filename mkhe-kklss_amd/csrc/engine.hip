@@ -267,6 +267,7 @@ Context::~Context() {
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
     for (auto& f : free_list_) (void)hipFree(f.second);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    if (xev_) (void)hipEventDestroy(xev_);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -314,6 +315,13 @@ Context::ProfScope::~ProfScope() { if (on) (void)hipEventRecord(c->prof_recs_[id
 void Context::fork_side(int k) { if (!overlap) return; MKHE_HIP(hipEventRecord(ev_[2 * k], s_)); MKHE_HIP(hipStreamWaitEvent(stream2, ev_[2 * k], 0)); }
 void Context::side_done(int k) { if (!overlap) return; MKHE_HIP(hipEventRecord(ev_[2 * k + 1], stream2)); }
 void Context::join_side(int k) { if (!overlap) return; MKHE_HIP(hipStreamWaitEvent(s_, ev_[2 * k + 1], 0)); }
+void Context::wait_for(Context& other) {
+    if (&other == this) return;
+    if (other.device != device) throw Error("mkhe: wait_for needs two contexts on the same device");
+    if (!xev_) MKHE_HIP(hipEventCreateWithFlags(&xev_, hipEventDisableTiming));
+    MKHE_HIP(hipEventRecord(xev_, other.stream));
+    MKHE_HIP(hipStreamWaitEvent(stream, xev_, 0));
+}
 void Context::prof_enable(bool on) { sync(); prof_on_ = on; }
 void Context::prof_collect(double* ms, long* launches, double* alg_bytes) {
     sync();

@@ -53,6 +53,10 @@ class Evaluator:
         self.params = params
         self.ksw = mkrlwe.NewKeySwitcher(params)
 
+    def Fork(self):
+        """an evaluator on a forked context (mkrlwe.Parameters.Fork): same keys and ciphertexts, its own stream"""
+        return Evaluator(self.params.Fork())
+
     def newCiphertextBinary(self, op0, op1):
         """evaluator.go:306-313"""
         return NewCiphertext(self.params, op0.IDSet() | op1.IDSet(), min(op0.Level(), op1.Level()),

@@ -23,6 +23,7 @@ class Parameters:
         self.logN, self._N = int(logN), 1 << int(logN)
         self.Q, self.P, self.gamma = [int(q) for q in Q], [int(p) for p in P], int(gamma)
         self.device = int(device)
+        self._psi = (psiQ, psiP)
         self.ctx = self._create_context(psiQ, psiP)
         self.CRS = {}                      # idx -> SwitchingKey   (params.go:37-46)
         self._ids = {}                     # party id string -> dense int for the C ABI
@@ -99,6 +100,20 @@ class Parameters:
 
     def sync(self):
         check(lib().mkhe_ctx_sync(self.ctx))
+
+    def Fork(self):
+        """A second engine context over the same ring (own stream and scratch pools) that shares this object's CRS map,
+        party ids and every key / ciphertext handle.  Operations issued through different forks run concurrently on
+        the GPU; order them with wait_for.  (No reference counterpart: the Go evaluator is single-threaded.)"""
+        import copy
+        f = copy.copy(self)                 # same Q / P lists, same CRS and id dictionaries (shared objects)
+        f.ctx = self._create_context(*self._psi)
+        f._parent = self                    # the CRS handles belong to the parent's context: keep it alive
+        return f
+
+    def wait_for(self, other):
+        """work issued through this context from now on starts after everything issued through `other` so far"""
+        check(lib().mkhe_ctx_wait_for(self.ctx, other.ctx))
 
     def stream(self):
         return lib().mkhe_ctx_stream(self.ctx)

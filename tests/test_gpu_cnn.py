@@ -59,3 +59,23 @@ def test_layers_one_by_one():
         f = f + HC.rot(f, 128 * (1 << i))
     f = f + HC.pack_b2(m)
     assert np.abs(sc.decrypt(out)[:HC.NCLS] - f[:HC.NCLS]).max() < 1e-5
+
+
+def test_forked_contexts_give_identical_results():
+    """the independent chains of Convolution / FC1Layer issued through forked engine contexts (own streams, shared keys and
+    ciphertexts): bit-identical to the single-stream evaluation, repeated to exercise buffer reuse across contexts"""
+    from mkhe_kklss_amd import cnn
+    sc = HC.CnnScenario(TWO, seed=5)
+    model = HC.synthetic_model(9)
+    cts = sc.encrypt_model(model)
+    pt, pt_scale = sc.mask_plaintext(sc.level - 4)
+    args = (sc.rlkSet, sc.rtkSet, cts["ctImage"], cts["ctKernels"], cts["ctFC1"], cts["ctFC2"], cts["ctB1"], cts["ctB2"], pt, pt_scale)
+    ref = cnn.Inference(sc.eval, *args).download()
+    for nf in (3, 7):
+        forks = [sc.eval.Fork() for _ in range(nf)]
+        for _ in range(3):
+            out = cnn.Inference(sc.eval, *args, forks=forks)
+            assert (out.download() == ref).all()
+        sc.params.sync()
+        for f in forks:
+            f.params.sync()
