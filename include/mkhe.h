@@ -52,6 +52,18 @@ int  mkhe_ctx_sync(mkhe_ctx* ctx);
  * after everything enqueued on other before the call has finished.  A handle must be destroyed through the context that
  * created it, after every other context that used it has been waited for. */
 int  mkhe_ctx_wait_for(mkhe_ctx* ctx, mkhe_ctx* other);
+/* Capture of a fixed sequence of engine calls into a HIP graph (no reference counterpart).  Between mkhe_capture_begin and
+ * mkhe_capture_end every call on ctx -- and on contexts ordered with mkhe_ctx_wait_for after the begin and joined back
+ * with mkhe_ctx_wait_for(ctx, other) before the end -- is recorded instead of executed; mkhe_graph_launch replays the
+ * whole sequence with one submission (launch-bound circuits of many small kernels: the cnn caller).  Rules: no upload /
+ * download / sync / key generation inside a capture; the replay reads and writes exactly the device buffers the captured
+ * calls used, so the handles created inside the capture must stay alive (their buffers are the graph's temporaries and
+ * outputs) and new inputs are uploaded into the SAME input handles. */
+typedef struct mkhe_graph mkhe_graph;
+int  mkhe_capture_begin(mkhe_ctx* ctx);
+int  mkhe_capture_end(mkhe_ctx* ctx, mkhe_graph** out);
+int  mkhe_graph_launch(mkhe_ctx* ctx, mkhe_graph* graph);
+void mkhe_graph_destroy(mkhe_graph* graph);
 int  mkhe_ctx_alpha(const mkhe_ctx* ctx);                 /* Parameters.Alpha  params.go:63-65 */
 int  mkhe_ctx_beta(const mkhe_ctx* ctx, int level);       /* Parameters.Beta   params.go:67-71 */
 int  mkhe_ctx_n(const mkhe_ctx* ctx);
@@ -78,6 +90,8 @@ int  mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host);
 int  mkhe_ct_upload_poly_limbs(mkhe_ctx* ctx, mkhe_ct* ct, int slot, const uint64_t* const* limbs);
 int  mkhe_ct_download(mkhe_ctx* ctx, const mkhe_ct* ct, uint64_t* host);
 int  mkhe_ct_download_poly_limbs(mkhe_ctx* ctx, const mkhe_ct* ct, int slot, uint64_t* const* limbs);
+/* device-to-device copy of a ciphertext with the same ids and number of limbs (rlwe Ciphertext.CopyNew; rotation by 0) */
+int  mkhe_ct_copy(mkhe_ctx* ctx, const mkhe_ct* in, mkhe_ct* out);
 int  mkhe_ct_limbs(const mkhe_ct* ct);
 int  mkhe_ct_nparties(const mkhe_ct* ct);
 void* mkhe_ct_devptr(mkhe_ct* ct);

@@ -410,8 +410,7 @@ class Evaluator {
     CiphertextPtr like(const Ciphertext& c) { return std::make_unique<Ciphertext>(params, c.IDSet_(), c.Level(), c.Scale, false); }
     CiphertextPtr copy(const Ciphertext& c) {
         auto out = like(c);
-        std::vector<uint64_t> tmp(c.words());
-        c.download(tmp.data()); out->upload(tmp.data());
+        check(mkhe_ct_copy(params.ctx, c.h, out->h));
         return out;
     }
     template <typename F> CiphertextPtr binary(const Ciphertext& op0, const Ciphertext& op1, F fn) {

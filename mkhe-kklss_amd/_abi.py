@@ -19,6 +19,11 @@ SIGNATURES = {
     "mkhe_ctx_destroy": (None, [vp]),
     "mkhe_ctx_sync": (C.c_int, [vp]),
     "mkhe_ctx_wait_for": (C.c_int, [vp, vp]),
+    "mkhe_capture_begin": (C.c_int, [vp]),
+    "mkhe_capture_end": (C.c_int, [vp, vpp]),
+    "mkhe_graph_launch": (C.c_int, [vp, vp]),
+    "mkhe_graph_destroy": (None, [vp]),
+    "mkhe_ct_copy": (C.c_int, [vp, vp, vp]),
     "mkhe_ctx_alpha": (C.c_int, [vp]),
     "mkhe_ctx_beta": (C.c_int, [vp, C.c_int]),
     "mkhe_ctx_n": (C.c_int, [vp]),

@@ -9,6 +9,7 @@ using namespace mkhe;
 struct mkhe_ctx { Context* c; };
 struct mkhe_swk { Swk s; };
 struct mkhe_ct { Ct c; };
+struct mkhe_graph { hipGraphExec_t exec; };
 
 static thread_local std::string g_err;
 
@@ -39,6 +40,28 @@ int mkhe_ctx_create(mkhe_ctx** out, int logN, const uint64_t* Q, int nQ, const u
 }
 void mkhe_ctx_destroy(mkhe_ctx* ctx) { if (ctx) { delete ctx->c; delete ctx; } }
 int mkhe_ctx_sync(mkhe_ctx* ctx) { MKHE_TRY(ctx->c->sync()) }
+int mkhe_capture_begin(mkhe_ctx* ctx) {
+    MKHE_TRY({
+        MKHE_HIP(hipSetDevice(ctx->c->device));
+        MKHE_HIP(hipStreamBeginCapture(ctx->c->stream, hipStreamCaptureModeRelaxed));
+    })
+}
+int mkhe_capture_end(mkhe_ctx* ctx, mkhe_graph** out) {
+    MKHE_TRY({
+        if (!out) throw Error("mkhe_capture_end: null argument");
+        hipGraph_t g = nullptr;
+        MKHE_HIP(hipStreamEndCapture(ctx->c->stream, &g));
+        hipGraphExec_t ex = nullptr;
+        const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) throw Error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        *out = new mkhe_graph{ex};
+    })
+}
+int mkhe_graph_launch(mkhe_ctx* ctx, mkhe_graph* graph) {
+    MKHE_TRY({ if (!graph) throw Error("mkhe_graph_launch: null argument"); MKHE_HIP(hipGraphLaunch(graph->exec, ctx->c->stream)); })
+}
+void mkhe_graph_destroy(mkhe_graph* graph) { if (graph) { (void)hipGraphExecDestroy(graph->exec); delete graph; } }
 int mkhe_ctx_wait_for(mkhe_ctx* ctx, mkhe_ctx* other) {
     MKHE_TRY({ if (!ctx || !other) throw Error("mkhe_ctx_wait_for: null argument"); ctx->c->wait_for(*other->c); })
 }
@@ -125,6 +148,14 @@ int mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host) {
         const size_t w = (size_t)(1 + ct->c.n) * ct->c.limbs * c->N;
         MKHE_HIP(hipMemcpyAsync(ct->c.d, host, w * sizeof(u64), hipMemcpyHostToDevice, c->stream));
         c->sync();
+    })
+}
+int mkhe_ct_copy(mkhe_ctx* ctx, const mkhe_ct* in, mkhe_ct* out) {
+    MKHE_TRY({
+        if (!in || !out) throw Error("mkhe_ct_copy: null argument");
+        if (in->c.n != out->c.n || in->c.limbs != out->c.limbs || in->c.ids != out->c.ids) throw Error("mkhe_ct_copy: shapes differ");
+        const size_t w = (size_t)(1 + in->c.n) * in->c.limbs * ctx->c->N;
+        MKHE_HIP(hipMemcpyAsync(out->c.d, in->c.d, w * sizeof(u64), hipMemcpyDeviceToDevice, ctx->c->stream));
     })
 }
 int mkhe_ct_upload_poly_limbs(mkhe_ctx* ctx, mkhe_ct* ct, int slot, const uint64_t* const* limbs) {

@@ -217,7 +217,7 @@ class Evaluator:
         rotidx %= n2
         ctOut = NewCiphertext(self.params, ct0.IDSet())
         if rotidx == 0:
-            ctOut.upload(ct0.download())
+            check(lib().mkhe_ct_copy(self.params.ctx, ct0.h, ctOut.h))
             return ctOut
         if rotidx in self.params.CRS:
             self.ksw.Rotate(ct0, rotidx, rkSet, ctOut)

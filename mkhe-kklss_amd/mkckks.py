@@ -132,7 +132,12 @@ class Evaluator:
         params = self.params
         level = ct.Level()
         ctOut = NewCiphertext(params, ct.IDSet(), level, ct.Scale * float(pt_scale), zero=False)
-        pt = mkrlwe.DeviceLimbs(params, 1, level + 1).upload(np.ascontiguousarray(pt_value, dtype=np.uint64)[None, : level + 1])
+        if isinstance(pt_value, mkrlwe.DeviceLimbs):          # already resident (uploaded once by the caller; required inside a graph capture)
+            pt = pt_value
+            if pt.limbs != level + 1:
+                raise MkheError("MulPtxtNew: the resident plaintext must have level + 1 limbs")
+        else:
+            pt = mkrlwe.DeviceLimbs(params, 1, level + 1).upload(np.ascontiguousarray(pt_value, dtype=np.uint64)[None, : level + 1])
         check(lib().mkhe_ct_mul_ptxt(params.ctx, ct.h, pt.devptr(), ctOut.h))
         if ctOut.Level() == 0:                 # eval.Rescale returns an error there; MulPtxtNew ignores it (:480)
             return ctOut
@@ -197,7 +202,7 @@ class Evaluator:
         rotidx = self._norm_rot(rotidx)
         ctOut = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale, zero=False)
         if rotidx == 0:
-            ctOut.upload(ct0.download())
+            check(lib().mkhe_ct_copy(self.params.ctx, ct0.h, ctOut.h))
             return ctOut
         if rotidx in self.params.CRS:
             self.ksw.Rotate(ct0, rotidx, rkSet, ctOut)
@@ -217,7 +222,7 @@ class Evaluator:
         rotidx = self._norm_rot(rotidx)
         ctOut = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale, zero=False)
         if rotidx == 0:
-            ctOut.upload(ct0.download())
+            check(lib().mkhe_ct_copy(self.params.ctx, ct0.h, ctOut.h))
             return ctOut
         if rotidx not in self.params.CRS:
             raise MkheError("Hoisted rotation only works for precomputed rotation keys")

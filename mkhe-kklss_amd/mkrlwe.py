@@ -111,12 +111,59 @@ class Parameters:
         f._parent = self                    # the CRS handles belong to the parent's context: keep it alive
         return f
 
+    def Capture(self):
+        """context manager recording every engine call issued through this context (and through forks ordered after it and
+        joined back) into a HIP graph: `with params.Capture() as g: ...calls...`, then g.launch() replays them with one
+        submission.  Objects created inside the block are kept alive by the graph (their buffers are its temporaries)."""
+        return Graph(self)
+
     def wait_for(self, other):
         """work issued through this context from now on starts after everything issued through `other` so far"""
         check(lib().mkhe_ctx_wait_for(self.ctx, other.ctx))
 
     def stream(self):
         return lib().mkhe_ctx_stream(self.ctx)
+
+
+class Graph:
+    """mkhe_capture_* / mkhe_graph_launch (include/mkhe.h): a captured sequence of engine calls."""
+
+    def __init__(self, params):
+        self.params, self.h, self.keep = params, None, []
+
+    def __enter__(self):
+        check(lib().mkhe_capture_begin(self.params.ctx))
+        _live_graphs.append(self)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _live_graphs.remove(self)
+        h = C.c_void_p()
+        rc = lib().mkhe_capture_end(self.params.ctx, C.byref(h))
+        if et is None:
+            check(rc)
+            self.h = h
+        return False
+
+    def launch(self):
+        check(lib().mkhe_graph_launch(self.params.ctx, self.h))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.params.sync()
+                lib().mkhe_graph_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+_live_graphs = []      # captures in progress: device objects created meanwhile are pinned to them (never freed before the graph)
+
+
+def _pin(obj):
+    for g in _live_graphs:
+        g.keep.append(obj)
 
 
 class SwitchingKey:
@@ -128,6 +175,7 @@ class SwitchingKey:
         h = C.c_void_p()
         check(lib().mkhe_swk_create(params.ctx, C.byref(h)))
         self.h = h
+        _pin(self)
         if host is not None:
             self.upload(host)
 
@@ -259,6 +307,7 @@ class Ciphertext:
         create = lib().mkhe_ct_create if zero else lib().mkhe_ct_create_uninit
         check(create(params.ctx, len(self.ids), arr.ctypes.data_as(_abi.i32p), level + 1, C.byref(h)))
         self.h = h
+        _pin(self)
 
     def IDSet(self):
         return set(self.ids)
@@ -561,6 +610,7 @@ class DeviceLimbs:
         d = C.c_void_p()
         check(lib().mkhe_buf_alloc(params.ctx, self.words, C.byref(d)))
         self.d = d
+        _pin(self)
 
     def upload(self, host):
         host = np.ascontiguousarray(host, dtype=np.uint64)
