@@ -137,7 +137,9 @@ Encrypted == plaintext logits to 4e-6: `tests/test_gpu_cnn.py`.
 | 2 (dataOwner, modelOwner: the reference's setting) | **{c2["value"]:.0f}** | {c2["ms_per_step"]:.2f} | {c2["config"]["layer_ms"]["Convolution"]:.2f} | {c2["config"]["layer_ms"]["Square1"]:.2f} | {c2["config"]["layer_ms"]["FC1"]:.2f} | {c2["config"]["layer_ms"]["Square2"]:.2f} | {c2["config"]["layer_ms"]["FC2"]:.2f} |
 | 4 (one owner per layer) | **{c4["value"]:.0f}** | {c4["ms_per_step"]:.2f} | {c4["config"]["layer_ms"]["Convolution"]:.2f} | {c4["config"]["layer_ms"]["Square1"]:.2f} | {c4["config"]["layer_ms"]["FC1"]:.2f} | {c4["config"]["layer_ms"]["Square2"]:.2f} | {c4["config"]["layer_ms"]["FC2"]:.2f} |
 
-This workload is latency-bound, not bandwidth-bound: ≈ 360 dependent launches per inference, each over a few dozen limbs of
+`value` is measured with 7 forked engine contexts (independent chains of a layer overlap; `--forks 0`: one stream) and eager
+submission (`--graph 1` replays a captured HIP graph: same result, not faster).  The per-layer columns add a sync per layer.
+This workload is latency-bound, not bandwidth-bound: ≈ 360 launches per inference, each over a few dozen limbs of
 2^14 coefficients (a fraction of the 256 CUs), so the figure of merit is the per-launch latency (≈ 25–30 µs for an NTT launch):
 
 | kernel (2 parties) | launches/step | avg µs/launch | ms/step | algorithmic GB/s |
