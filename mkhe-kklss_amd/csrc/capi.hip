@@ -43,6 +43,13 @@ int mkhe_ctx_sync(mkhe_ctx* ctx) { MKHE_TRY(ctx->c->sync()) }
 int mkhe_capture_begin(mkhe_ctx* ctx) {
     MKHE_TRY({
         MKHE_HIP(hipSetDevice(ctx->c->device));
+        // the engine captures several streams (side stream, forked contexts) that join each other in both directions; the
+        // HIP runtime of ROCm 7.0 (e.g. the one bundled with PyTorch 2.10, which a process that imported torch first
+        // binds to) recurses without end in hipStreamEndCapture on such a capture.  Refuse instead of crashing.
+        int rv = 0;
+        MKHE_HIP(hipRuntimeGetVersion(&rv));
+        if (rv < 70200000) throw Error("mkhe_capture_begin: the HIP runtime loaded in this process (version " + std::to_string(rv) +
+                                       ") cannot end a multi-stream capture; graph capture needs the ROCm >= 7.2 runtime");
         MKHE_HIP(hipStreamBeginCapture(ctx->c->stream, hipStreamCaptureModeRelaxed));
     })
 }

@@ -453,6 +453,136 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_split_inv_kernel(NttBatch b
         dst[j + H] = d;
     }
 }
+// ------------------------------------------------------------------ low-latency sub-transforms (small launches)
+// A launch with far fewer limbs than the chip has CUs is bound by the latency of ONE register-resident sub-transform:
+// 32 coefficients per thread = 200+ dependent butterflies on one or two waves per SIMD.  For those launches the
+// sub-transforms run on 2^13 coefficients with 8 per thread instead (1024 threads, 4 waves per SIMD, 52 butterflies
+// each): radix-8 phases in registers, the data re-distributed through LDS (64-bit words, skewed) between phases, first
+// phase straight from global memory, last phase straight to it.  N = 2^14: one streaming pass + 2 sub-transforms per
+// limb; N = 2^15: two streaming passes + 4.  Same values in and out as the register-resident path.
+constexpr int SM_LOGM = 13, SM_M = 1 << SM_LOGM, SM_T = 1024, SM_E = SM_M / SM_T;
+constexpr int SM_LDS_WORDS = SM_M + (SM_M >> 3);
+__device__ __forceinline__ int sm_pad(int p) { return p + ((p >> 4) << 1); }     // 16 consecutive words, then 2 words of skew
+
+// One phase: NB stages S0 .. S0+NB-1 of the 2^13-point sub-transform on units of 2^NB coefficients p + a * gl.
+// MODE 0 / 1: forward (Harvey / signed never-reduced), 2: inverse (stages in descending order).
+// FIN 1: forward normalisation on the way out (canonical, or +16q when skip_norm); FIN 2: inverse, times N^-1.
+template <int S0, int NB, bool FROM_G, bool TO_G, int MODE, int FIN>
+__device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr psi, int root, int t, const Mod& md, u64 fin_c, int skip_norm) {
+    constexpr int LGL = SM_LOGM - S0 - NB, GL = 1 << LGL, UPT = SM_E >> NB, NE = 1 << NB;
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) {
+        const int u = k * SM_T + t;
+        const int low = u & (GL - 1), high = u >> LGL;
+        const int p = (high << (LGL + NB)) | low;
+        u64 x[NE];
+#pragma unroll
+        for (int a = 0; a < NE; ++a) x[a] = FROM_G ? gsrc[p + a * GL] : lds[sm_pad(p + a * GL)];
+#pragma unroll
+        for (int ii = 0; ii < NB; ++ii) {
+            const int i = MODE == 2 ? NB - 1 - ii : ii;
+            const int half = 1 << (NB - 1 - i);
+#pragma unroll
+            for (int a = 0; a < NE; ++a) {
+                if (a & half) continue;
+                const u64 w = psi[(root << (S0 + i)) + (high << i) + (a >> (NB - i))];
+                if constexpr (MODE == 2) bfly_inv(x[a], x[a + half], w, q, q2, md.qs, ninv);
+                else if constexpr (MODE == 1) bfly_fwd_nr(x[a], x[a + half], w, md.qs, ninv);
+                else bfly_fwd_cs(x[a], x[a + half], w, q, q2, md.qs, ninv);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NE; ++a) {
+            u64 v = x[a];
+            if constexpr (FIN == 1) {
+                if constexpr (MODE == 1) {
+                    if (!skip_norm) { const i64 y = mont_mul_sd((i64)v, md.r1s, md.qs, ninv); v = (u64)(y + ((y >> 63) & (i64)q)); }
+                    else v = (u64)((i64)v + (i64)(q << 4));
+                } else v = csub(csub(v, q2), q);
+            } else if constexpr (FIN == 2) v = mont_mul_sdu(v, fin_c, md.qs, q, ninv);          // [0,2q), N^-1 folded in
+            if constexpr (TO_G) gdst[p + a * GL] = v; else lds[sm_pad(p + a * GL)] = v;
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(SM_T) ntt_fwd_lds_kernel(NttBatch b, int d) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
+    const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, job >> d, src, dst, m, outer);
+    src += part * SM_M; dst += part * SM_M;
+    const int root = (1 << d) + part;
+    const Mod md = b.mods[m];
+    gcptr psi = (gcptr)(b.psi + ((long)m * SM_M << d));
+    sm_phase<0, 3, true, false, MODE, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<3, 3, false, false, MODE, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<6, 3, false, false, MODE, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<9, 3, false, false, MODE, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<12, 1, false, true, MODE, 1>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
+}
+
+__global__ void __launch_bounds__(SM_T) ntt_inv_lds_kernel(NttBatch b, int d) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
+    const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, job >> d, src, dst, m, outer);
+    src += part * SM_M; dst += part * SM_M;
+    const int root = (1 << d) + part;
+    const Mod md = b.mods[m];
+    gcptr psi = (gcptr)(b.psi + ((long)m * SM_M << d));
+    const u64 ninvR = b.aux[6 * m];                            // N^-1 * R of the WHOLE limb size, signed-split form
+    sm_phase<12, 1, true, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<9, 3, false, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<6, 3, false, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<3, 3, false, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<0, 3, false, true, 2, 2>(src, dst, sm_lds, psi, root, t, md, ninvR, 0);
+}
+
+// cross-block radix-2 passes below the first one (level L >= 1: blocks of N >> L coefficients, twiddle index 2^L + block),
+// in place on dst; forward: values < 4q in and out; inverse: [0,2q) in and out (N^-1 already folded in)
+__global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass_fwd_kernel(NttBatch b, int logN, int L) {
+    const int N = 1 << logN, G = N >> (L + 1);
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    const Mod md = b.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < (N >> 1); j += gridDim.x * SPLIT_THREADS) {
+        const int blk = j / G, off = j - blk * G, i0 = blk * 2 * G + off;
+        const u64 w = b.psi[(long)m * N + (1 << L) + blk];
+        const u64 U = csub(dst[i0], q2), V = dst[i0 + G];
+        const u64 Tm = mont_mul_sdu(V, w, md.qs, q, ninv);
+        dst[i0] = U + Tm;
+        dst[i0 + G] = U + (q2 - Tm);
+    }
+}
+__global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass_inv_kernel(NttBatch b, int logN, int L) {
+    const int N = 1 << logN, G = N >> (L + 1);
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    const Mod md = b.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < (N >> 1); j += gridDim.x * SPLIT_THREADS) {
+        const int blk = j / G, off = j - blk * G, i0 = blk * 2 * G + off;
+        const u64 w = b.psi[(long)m * N + (1 << L) + blk];
+        const u64 U = dst[i0], V = dst[i0 + G];
+        dst[i0] = csub(U + V, q2);
+        dst[i0 + G] = mont_mul_sdu(U + q2 - V, w, md.qs, q, ninv);
+    }
+}
+
 static NttBatch in_place_of_dst(const NttBatch& b) {
     NttBatch c = b;
     c.src = b.dst; c.src_outer = b.dst_outer; c.src_inner = b.dst_inner; c.src_mapped = b.dst_mapped;
@@ -530,6 +660,23 @@ static bool use_split(int logN, const NttBatch& b) {
     if (forced >= 0) return forced != 0;
     return b.nslots * b.nouter <= 128;        // at most one sub-transform workgroup per CU (256 CUs)
 }
+// depth of the low-latency path for this launch: 0 = register-resident sub-transforms, d >= 1 = 2^d LDS sub-transforms of
+// 2^13 coefficients per limb after d streaming passes.  MKHE_NTT_LDS=0 switches it off (A/B tests).
+static int lds_depth(int logN, const NttBatch& b) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MKHE_NTT_LDS"); on = (e && *e) ? atoi(e) : 1; }
+    if (!on || b.prestaged) return 0;
+    if (logN != 14 && logN != 15) return 0;
+    static bool attr = false;
+    if (!attr) {
+        const int lds = SM_LDS_WORDS * (int)sizeof(u64);
+        (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)ntt_inv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    return logN - SM_LOGM;
+}
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
     const bool small = b.lazy_out != 0;
@@ -539,6 +686,14 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
         else if (b.reduce_in) hipLaunchKernelGGL(ntt_split_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
         else hipLaunchKernelGGL(ntt_split_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
         const NttBatch c = in_place_of_dst(b);
+        if (const int d = lds_depth(logN, b)) {
+            for (int L = 1; L < d; ++L) hipLaunchKernelGGL(ntt_pass_fwd_kernel, grid, dim3(SPLIT_THREADS), 0, st, c, logN, L);
+            const int jobs = (b.nslots * b.nouter) << d;
+            const size_t lds = SM_LDS_WORDS * sizeof(u64);
+            if (small) hipLaunchKernelGGL(ntt_fwd_lds_kernel<1>, dim3(jobs), dim3(SM_T), lds, st, c, d);
+            else hipLaunchKernelGGL(ntt_fwd_lds_kernel<0>, dim3(jobs), dim3(SM_T), lds, st, c, d);
+            return;
+        }
         if (small) launch_fwd_mode<1, false>(logN - 1, c, st); else launch_fwd_mode<0, false>(logN - 1, c, st);
         return;
     }
@@ -548,6 +703,16 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
     if (!b.split && use_split(logN, b)) {
+        if (const int d = lds_depth(logN, b)) {
+            const int jobs = (b.nslots * b.nouter) << d;
+            hipLaunchKernelGGL(ntt_inv_lds_kernel, dim3(jobs), dim3(SM_T), SM_LDS_WORDS * sizeof(u64), st, b, d);     // src -> dst, [0,2q), N^-1 folded in
+            const NttBatch ip = in_place_of_dst(b);
+            const dim3 grid(32, b.nslots * b.nouter);
+            for (int L = d - 1; L >= 1; --L) hipLaunchKernelGGL(ntt_pass_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, ip, logN, L);
+            NttBatch e = ip; e.lazy_out = b.lazy_out; e.psi = b.psi;
+            hipLaunchKernelGGL(ntt_split_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, e, logN);
+            return;
+        }
         NttBatch c = b;
         c.split = 1;
         launch_ntt_inv(logN - 1, c, st);                      // src halves -> dst halves, lazy, N^-1 folded in

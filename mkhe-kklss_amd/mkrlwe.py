@@ -132,14 +132,23 @@ class Graph:
         self.params, self.h, self.keep = params, None, []
 
     def __enter__(self):
+        import gc
+        # no destructor of an unrelated device object may run inside the capture window (hipFree / stream destruction are
+        # device-wide operations): collect pending cyclic garbage now and keep the collector off until the capture ends
+        gc.collect()
+        self._gc = gc.isenabled()
+        gc.disable()
         check(lib().mkhe_capture_begin(self.params.ctx))
         _live_graphs.append(self)
         return self
 
     def __exit__(self, et, ev, tb):
+        import gc
         _live_graphs.remove(self)
         h = C.c_void_p()
         rc = lib().mkhe_capture_end(self.params.ctx, C.byref(h))
+        if self._gc:
+            gc.enable()
         if et is None:
             check(rc)
             self.h = h

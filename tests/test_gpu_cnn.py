@@ -83,28 +83,26 @@ def test_forked_contexts_give_identical_results():
 
 def test_captured_graph_replays_identically():
     """the whole inference captured into a HIP graph (mkhe_capture_*; forks become parallel branches); replays give the
-    eager result bit for bit, also after a new image has been uploaded into the same input handle"""
-    from mkhe_kklss_amd import cnn, mkrlwe
-    sc = HC.CnnScenario(TWO, seed=6)
-    model = HC.synthetic_model(10)
-    cts = sc.encrypt_model(model)
-    pt, pt_scale = sc.mask_plaintext(sc.level - 4)
-    pt = mkrlwe.DeviceLimbs(sc.params, 1, sc.level - 3).upload(pt[None])
-    args = (sc.rlkSet, sc.rtkSet, cts["ctImage"], cts["ctKernels"], cts["ctFC1"], cts["ctFC2"], cts["ctB1"], cts["ctB2"], pt, pt_scale)
-    forks = [sc.eval.Fork() for _ in range(7)]
-    hoisted = (sc.eval.HoistedForm(cts["ctImage"]), [sc.eval.HoistedForm(c) for c in cts["ctKernels"]], [sc.eval.HoistedForm(c) for c in cts["ctFC1"]])
-    ref = cnn.Inference(sc.eval, *args, hoisted=hoisted, forks=forks).download()          # eager (also warms every pool)
-    with sc.params.Capture() as graph:
-        out = cnn.Inference(sc.eval, *args, hoisted=hoisted, forks=forks)
-    for _ in range(3):
-        graph.launch()
-        assert (out.download() == ref).all()
-    # a second image through the same handles: the image's hoisted form is an input too (Decompose outside the graph)
-    model2 = dict(model, image=HC.synthetic_model(11)["image"])
-    fresh = sc.encrypt(HC.pack_image(model2), "dataOwner")
-    cts["ctImage"].upload(fresh.download())
-    for id in cts["ctImage"].ids:
-        sc.eval.ksw.Decompose(cts["ctImage"].Level(), cts["ctImage"], id, hoisted[0].Value[id])
-    graph.launch()
-    got = sc.decrypt(out)[:HC.NCLS]
-    assert np.abs(got.real - HC.plain_forward(model2)).max() < 1e-3
+    eager result bit for bit, also after a new image has been uploaded into the same input handle.  Runs in a fresh
+    interpreter: a process that has imported torch is bound to torch's bundled ROCm 7.0 HIP runtime, whose
+    hipStreamEndCapture cannot end the engine's multi-stream captures (mkhe_capture_begin refuses there, checked below)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "cnn_graph_check.py")], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0 and "graph replay ok" in out.stdout
+
+
+def test_capture_refused_on_old_runtime_or_works():
+    """in THIS process: either the runtime supports the capture (no torch imported before) or mkhe_capture_begin raises"""
+    from mkhe_kklss_amd import mkckks
+    from mkhe_kklss_amd._abi import MkheError
+    p = HC.PN14QP433
+    params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"])
+    try:
+        with params.Capture() as g:
+            pass
+    except MkheError as e:
+        assert "cannot end a multi-stream capture" in str(e)
