@@ -508,7 +508,7 @@ __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr 
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(SM_T) ntt_fwd_lds_kernel(NttBatch b, int d) {
+__global__ void __launch_bounds__(SM_T, 2) ntt_fwd_lds_kernel(NttBatch b, int d) {
     extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
     const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
     gcptr src; gptr dst; int m, outer;
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(SM_T) ntt_fwd_lds_kernel(NttBatch b, int d) {
     sm_phase<12, 1, false, true, MODE, 1>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
 }
 
-__global__ void __launch_bounds__(SM_T) ntt_inv_lds_kernel(NttBatch b, int d) {
+__global__ void __launch_bounds__(SM_T, 2) ntt_inv_lds_kernel(NttBatch b, int d) {
     extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
     const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
     gcptr src; gptr dst; int m, outer;
@@ -580,6 +580,64 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass_inv_kernel(NttBatch b,
         const u64 U = dst[i0], V = dst[i0 + G];
         dst[i0] = csub(U + V, q2);
         dst[i0 + G] = mont_mul_sdu(U + q2 - V, w, md.qs, q, ninv);
+    }
+}
+
+// The two outermost stages in ONE streaming pass (low-latency path at N = 2^15: four 2^13-point sub-transforms per limb):
+// every thread owns the coefficients j, j + N/4, j + N/2, j + 3N/4.  Forward: src -> dst (optionally with the Decompose
+// reduction), values < 4q out; inverse: in place on dst, [0,2q) in (N^-1 folded in by the sub-transforms), canonical or
+// lazy out.
+template <bool DEC>
+__global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass4_fwd_kernel(NttBatch b, int logN) {
+    const int N = 1 << logN, Q = N >> 2;
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    const Mod md = b.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const u64 w1 = b.psi[(long)m * N + 1], w2 = b.psi[(long)m * N + 2], w3 = b.psi[(long)m * N + 3];
+    bool red = false;
+    if constexpr (DEC) {
+        int sm = m;
+        if (b.reduce_src_mod_is_outer == 1) sm = outer;
+        else if (b.reduce_src_mod_is_outer == 2) sm = ((kargptr)__builtin_amdgcn_kernarg_segment_ptr())->outer_mod[outer];
+        const u64 qs = b.mods[sm].q << (b.src_lazy ? 2 : 0);
+        red = qs > 4 * q;
+    }
+    for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < Q; j += gridDim.x * SPLIT_THREADS) {
+        u64 a0 = src[j], a1 = src[j + Q], a2 = src[j + 2 * Q], a3 = src[j + 3 * Q];
+        if (red) {
+            a0 = mont_mul_sdu(a0, md.r1s, md.qs, q, ninv); a1 = mont_mul_sdu(a1, md.r1s, md.qs, q, ninv);
+            a2 = mont_mul_sdu(a2, md.r1s, md.qs, q, ninv); a3 = mont_mul_sdu(a3, md.r1s, md.qs, q, ninv);
+        } else { a0 = csub(a0, q2); a1 = csub(a1, q2); }
+        u64 T = mont_mul_sdu(a2, w1, md.qs, q, ninv);
+        const u64 b0 = a0 + T, b2 = a0 + (q2 - T);
+        T = mont_mul_sdu(a3, w1, md.qs, q, ninv);
+        const u64 b1 = a1 + T, b3 = a1 + (q2 - T);
+        u64 u = csub(b0, q2);
+        T = mont_mul_sdu(b1, w2, md.qs, q, ninv);
+        dst[j] = u + T; dst[j + Q] = u + (q2 - T);
+        u = csub(b2, q2);
+        T = mont_mul_sdu(b3, w3, md.qs, q, ninv);
+        dst[j + 2 * Q] = u + T; dst[j + 3 * Q] = u + (q2 - T);
+    }
+}
+__global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass4_inv_kernel(NttBatch b, int logN) {
+    const int N = 1 << logN, Q = N >> 2;
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    const Mod md = b.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const u64 w1 = b.psi[(long)m * N + 1], w2 = b.psi[(long)m * N + 2], w3 = b.psi[(long)m * N + 3];
+    for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < Q; j += gridDim.x * SPLIT_THREADS) {
+        const u64 a0 = dst[j], a1 = dst[j + Q], a2 = dst[j + 2 * Q], a3 = dst[j + 3 * Q];
+        const u64 s0 = csub(a0 + a1, q2), d0 = mont_mul_sdu(a0 + q2 - a1, w2, md.qs, q, ninv);
+        const u64 s1 = csub(a2 + a3, q2), d1 = mont_mul_sdu(a2 + q2 - a3, w3, md.qs, q, ninv);
+        u64 r0 = csub(s0 + s1, q2), r2 = mont_mul_sdu(s0 + q2 - s1, w1, md.qs, q, ninv);
+        u64 r1 = csub(d0 + d1, q2), r3 = mont_mul_sdu(d0 + q2 - d1, w1, md.qs, q, ninv);
+        if (!b.lazy_out) { r0 = csub(r0, q); r1 = csub(r1, q); r2 = csub(r2, q); r3 = csub(r3, q); }
+        dst[j] = r0; dst[j + Q] = r1; dst[j + 2 * Q] = r2; dst[j + 3 * Q] = r3;
     }
 }
 
@@ -658,6 +716,9 @@ static bool use_split(int logN, const NttBatch& b) {
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("MKHE_NTT_SPLIT"); forced = (e && *e) ? atoi(e) : -1; }
     if (forced >= 0) return forced != 0;
+    static int lim = 0;
+    if (!lim) { const char* e = getenv("MKHE_NTT_SPLIT_MAX"); lim = (e && *e) ? atoi(e) : 128; }     // A/B: limb count up to which a launch runs split
+    if ((logN == 14 || logN == 15) && b.nslots * b.nouter <= lim) return true;
     return b.nslots * b.nouter <= 128;        // at most one sub-transform workgroup per CU (256 CUs)
 }
 // depth of the low-latency path for this launch: 0 = register-resident sub-transforms, d >= 1 = 2^d LDS sub-transforms of
@@ -682,12 +743,17 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     const bool small = b.lazy_out != 0;
     if (use_split(logN, b)) {
         const dim3 grid(32, b.nslots * b.nouter);
+        const int d = lds_depth(logN, b);
         if (b.prestaged) { /* first stage done by the producer */ }
+        else if (d == 2) {
+            if (b.reduce_in) hipLaunchKernelGGL(ntt_pass4_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+            else hipLaunchKernelGGL(ntt_pass4_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+        }
         else if (b.reduce_in) hipLaunchKernelGGL(ntt_split_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
         else hipLaunchKernelGGL(ntt_split_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
         const NttBatch c = in_place_of_dst(b);
-        if (const int d = lds_depth(logN, b)) {
-            for (int L = 1; L < d; ++L) hipLaunchKernelGGL(ntt_pass_fwd_kernel, grid, dim3(SPLIT_THREADS), 0, st, c, logN, L);
+        if (d) {
+            for (int L = 1; L < d && d != 2; ++L) hipLaunchKernelGGL(ntt_pass_fwd_kernel, grid, dim3(SPLIT_THREADS), 0, st, c, logN, L);
             const int jobs = (b.nslots * b.nouter) << d;
             const size_t lds = SM_LDS_WORDS * sizeof(u64);
             if (small) hipLaunchKernelGGL(ntt_fwd_lds_kernel<1>, dim3(jobs), dim3(SM_T), lds, st, c, d);
@@ -708,8 +774,9 @@ void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
             hipLaunchKernelGGL(ntt_inv_lds_kernel, dim3(jobs), dim3(SM_T), SM_LDS_WORDS * sizeof(u64), st, b, d);     // src -> dst, [0,2q), N^-1 folded in
             const NttBatch ip = in_place_of_dst(b);
             const dim3 grid(32, b.nslots * b.nouter);
-            for (int L = d - 1; L >= 1; --L) hipLaunchKernelGGL(ntt_pass_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, ip, logN, L);
             NttBatch e = ip; e.lazy_out = b.lazy_out; e.psi = b.psi;
+            if (d == 2) { hipLaunchKernelGGL(ntt_pass4_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, e, logN); return; }
+            for (int L = d - 1; L >= 1; --L) hipLaunchKernelGGL(ntt_pass_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, ip, logN, L);
             hipLaunchKernelGGL(ntt_split_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, e, logN);
             return;
         }
