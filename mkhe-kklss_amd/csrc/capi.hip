@@ -17,11 +17,17 @@ static thread_local std::string g_err;
     catch (const std::exception& e) { g_err = e.what(); return 1; } \
     catch (...) { g_err = "mkhe: unknown error"; return 1; }
 
+// every entry point goes through this: a null context is an error of the caller, reported like any other
+static Context* need(const mkhe_ctx* ctx) {
+    if (!ctx || !ctx->c) throw Error("mkhe: null context");
+    return ctx->c;
+}
+
 static std::vector<const Swk*> swk_list(const mkhe_swk* const* v, int n) {
     std::vector<const Swk*> r;
     if (!v) return r;
     r.resize(n);
-    for (int i = 0; i < n; ++i) r[i] = v[i] ? &v[i]->s : nullptr;
+    for (int i = 0; i < n; ++i) { if (!v[i]) throw Error("mkhe: null key handle in a per-party key list"); r[i] = &v[i]->s; }
     return r;
 }
 
@@ -39,10 +45,10 @@ int mkhe_ctx_create(mkhe_ctx** out, int logN, const uint64_t* Q, int nQ, const u
     })
 }
 void mkhe_ctx_destroy(mkhe_ctx* ctx) { if (ctx) { delete ctx->c; delete ctx; } }
-int mkhe_ctx_sync(mkhe_ctx* ctx) { MKHE_TRY(ctx->c->sync()) }
+int mkhe_ctx_sync(mkhe_ctx* ctx) { MKHE_TRY(need(ctx)->sync()) }
 int mkhe_capture_begin(mkhe_ctx* ctx) {
     MKHE_TRY({
-        MKHE_HIP(hipSetDevice(ctx->c->device));
+        MKHE_HIP(hipSetDevice(need(ctx)->device));
         // the engine captures several streams (side stream, forked contexts) that join each other in both directions; the
         // HIP runtime of ROCm 7.0 (e.g. the one bundled with PyTorch 2.10, which a process that imported torch first
         // binds to) recurses without end in hipStreamEndCapture on such a capture.  Refuse instead of crashing.
@@ -50,14 +56,14 @@ int mkhe_capture_begin(mkhe_ctx* ctx) {
         MKHE_HIP(hipRuntimeGetVersion(&rv));
         if (rv < 70200000) throw Error("mkhe_capture_begin: the HIP runtime loaded in this process (version " + std::to_string(rv) +
                                        ") cannot end a multi-stream capture; graph capture needs the ROCm >= 7.2 runtime");
-        MKHE_HIP(hipStreamBeginCapture(ctx->c->stream, hipStreamCaptureModeRelaxed));
+        MKHE_HIP(hipStreamBeginCapture(need(ctx)->stream, hipStreamCaptureModeRelaxed));
     })
 }
 int mkhe_capture_end(mkhe_ctx* ctx, mkhe_graph** out) {
     MKHE_TRY({
         if (!out) throw Error("mkhe_capture_end: null argument");
         hipGraph_t g = nullptr;
-        MKHE_HIP(hipStreamEndCapture(ctx->c->stream, &g));
+        MKHE_HIP(hipStreamEndCapture(need(ctx)->stream, &g));
         hipGraphExec_t ex = nullptr;
         const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
@@ -66,24 +72,25 @@ int mkhe_capture_end(mkhe_ctx* ctx, mkhe_graph** out) {
     })
 }
 int mkhe_graph_launch(mkhe_ctx* ctx, mkhe_graph* graph) {
-    MKHE_TRY({ if (!graph) throw Error("mkhe_graph_launch: null argument"); MKHE_HIP(hipGraphLaunch(graph->exec, ctx->c->stream)); })
+    MKHE_TRY({ if (!graph) throw Error("mkhe_graph_launch: null argument"); MKHE_HIP(hipGraphLaunch(graph->exec, need(ctx)->stream)); })
 }
 void mkhe_graph_destroy(mkhe_graph* graph) { if (graph) { (void)hipGraphExecDestroy(graph->exec); delete graph; } }
 int mkhe_ctx_wait_for(mkhe_ctx* ctx, mkhe_ctx* other) {
-    MKHE_TRY({ if (!ctx || !other) throw Error("mkhe_ctx_wait_for: null argument"); ctx->c->wait_for(*other->c); })
+    MKHE_TRY({ if (!ctx || !other) throw Error("mkhe_ctx_wait_for: null argument"); need(ctx)->wait_for(*need(other)); })
 }
-int mkhe_ctx_alpha(const mkhe_ctx* ctx) { return ctx->c->alpha; }
-int mkhe_ctx_beta(const mkhe_ctx* ctx, int level) { return ctx->c->beta(level); }
-int mkhe_ctx_n(const mkhe_ctx* ctx) { return ctx->c->N; }
-size_t mkhe_ctx_swk_words(const mkhe_ctx* ctx) { return ctx->c->swk_words(); }
-uint64_t mkhe_ctx_psi(const mkhe_ctx* ctx, int i) { return (i >= 0 && i < ctx->c->mall) ? ctx->c->psi_plain[i] : 0; }
-void* mkhe_ctx_stream(mkhe_ctx* ctx) { return (void*)ctx->c->stream; }
+int mkhe_ctx_alpha(const mkhe_ctx* ctx) { if (!ctx) return 0; return ctx->c->alpha; }
+int mkhe_ctx_beta(const mkhe_ctx* ctx, int level) { if (!ctx) return 0; return ctx->c->beta(level); }
+int mkhe_ctx_n(const mkhe_ctx* ctx) { if (!ctx) return 0; return ctx->c->N; }
+size_t mkhe_ctx_swk_words(const mkhe_ctx* ctx) { if (!ctx) return 0; return ctx->c->swk_words(); }
+uint64_t mkhe_ctx_psi(const mkhe_ctx* ctx, int i) { if (!ctx) return 0; return (i >= 0 && i < ctx->c->mall) ? ctx->c->psi_plain[i] : 0; }
+void* mkhe_ctx_stream(mkhe_ctx* ctx) { if (!ctx) return 0; return (void*)ctx->c->stream; }
 
 // ---- switching keys
 int mkhe_swk_create(mkhe_ctx* ctx, mkhe_swk** out) {
     MKHE_TRY({
-        Context* c = ctx->c;
+        Context* c = need(ctx);
         MKHE_HIP(hipSetDevice(c->device));
+        if (!out) throw Error("mkhe_swk_create: null argument");
         mkhe_swk* s = new mkhe_swk();
         try { s->s.d = c->pool_alloc(c->swk_words()); } catch (...) { delete s; throw; }
         MKHE_HIP(hipMemsetAsync(s->s.d, 0, c->swk_words() * sizeof(u64), c->stream));
@@ -97,14 +104,16 @@ void mkhe_swk_destroy(mkhe_ctx* ctx, mkhe_swk* swk) {
 }
 int mkhe_swk_upload(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* host) {
     MKHE_TRY({
-        Context* c = ctx->c;
+        Context* c = need(ctx);
+        if (!swk || !host) throw Error("mkhe_swk_upload: null argument");
         MKHE_HIP(hipMemcpyAsync(swk->s.d, host, c->swk_words() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
         c->sync();
     })
 }
 int mkhe_swk_upload_limbs(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* const* limbs, int ndigits) {
     MKHE_TRY({
-        Context* c = ctx->c;
+        Context* c = need(ctx);
+        if (!swk || !limbs) throw Error("mkhe_swk_upload_limbs: null argument");
         if (ndigits < 0 || ndigits > c->beta_max) throw Error("mkhe_swk_upload_limbs: bad digit count");
         for (int i = 0; i < ndigits * c->mtot; ++i)
             MKHE_HIP(hipMemcpyAsync(swk->s.d + (size_t)i * c->N, limbs[i], (size_t)c->N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
@@ -113,7 +122,8 @@ int mkhe_swk_upload_limbs(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* const* l
 }
 int mkhe_swk_download(mkhe_ctx* ctx, const mkhe_swk* swk, uint64_t* host) {
     MKHE_TRY({
-        Context* c = ctx->c;
+        Context* c = need(ctx);
+        if (!swk || !host) throw Error("mkhe_swk_download: null argument");
         MKHE_HIP(hipMemcpyAsync(host, swk->s.d, c->swk_words() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         c->sync();
     })
@@ -131,7 +141,8 @@ int mkhe_ct_create_uninit(mkhe_ctx* ctx, int n, const int* ids, int limbs, mkhe_
 } // extern "C"
 static void ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, bool zero, mkhe_ct** out) {
     {
-        Context* c = ctx->c;
+        Context* c = need(ctx);
+        if (!out || (n > 0 && !ids)) throw Error("mkhe_ct_create: null argument");
         if (n < 0 || n > 32 || limbs < 1 || limbs > c->nq) throw Error("mkhe_ct_create: bad shape");
         MKHE_HIP(hipSetDevice(c->device));
         mkhe_ct* t = new mkhe_ct();
@@ -151,7 +162,8 @@ void mkhe_ct_destroy(mkhe_ctx* ctx, mkhe_ct* ct) {
 }
 int mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host) {
     MKHE_TRY({
-        Context* c = ctx->c;
+        Context* c = need(ctx);
+        if (!ct || !host) throw Error("mkhe_ct_upload: null argument");
         const size_t w = (size_t)(1 + ct->c.n) * ct->c.limbs * c->N;
         MKHE_HIP(hipMemcpyAsync(ct->c.d, host, w * sizeof(u64), hipMemcpyHostToDevice, c->stream));
         c->sync();
@@ -161,13 +173,14 @@ int mkhe_ct_copy(mkhe_ctx* ctx, const mkhe_ct* in, mkhe_ct* out) {
     MKHE_TRY({
         if (!in || !out) throw Error("mkhe_ct_copy: null argument");
         if (in->c.n != out->c.n || in->c.limbs != out->c.limbs || in->c.ids != out->c.ids) throw Error("mkhe_ct_copy: shapes differ");
-        const size_t w = (size_t)(1 + in->c.n) * in->c.limbs * ctx->c->N;
-        MKHE_HIP(hipMemcpyAsync(out->c.d, in->c.d, w * sizeof(u64), hipMemcpyDeviceToDevice, ctx->c->stream));
+        const size_t w = (size_t)(1 + in->c.n) * in->c.limbs * need(ctx)->N;
+        MKHE_HIP(hipMemcpyAsync(out->c.d, in->c.d, w * sizeof(u64), hipMemcpyDeviceToDevice, need(ctx)->stream));
     })
 }
 int mkhe_ct_upload_poly_limbs(mkhe_ctx* ctx, mkhe_ct* ct, int slot, const uint64_t* const* limbs) {
     MKHE_TRY({
-        Context* c = ctx->c;
+        Context* c = need(ctx);
+        if (!ct || !limbs) throw Error("mkhe_ct_upload_poly_limbs: null argument");
         if (slot < 0 || slot > ct->c.n) throw Error("mkhe_ct_upload_poly_limbs: bad slot");
         for (int l = 0; l < ct->c.limbs; ++l)
             MKHE_HIP(hipMemcpyAsync(ct->c.d + ((size_t)slot * ct->c.limbs + l) * c->N, limbs[l], (size_t)c->N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
@@ -176,7 +189,8 @@ int mkhe_ct_upload_poly_limbs(mkhe_ctx* ctx, mkhe_ct* ct, int slot, const uint64
 }
 int mkhe_ct_download(mkhe_ctx* ctx, const mkhe_ct* ct, uint64_t* host) {
     MKHE_TRY({
-        Context* c = ctx->c;
+        Context* c = need(ctx);
+        if (!ct || !host) throw Error("mkhe_ct_download: null argument");
         const size_t w = (size_t)(1 + ct->c.n) * ct->c.limbs * c->N;
         MKHE_HIP(hipMemcpyAsync(host, ct->c.d, w * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         c->sync();
@@ -184,21 +198,22 @@ int mkhe_ct_download(mkhe_ctx* ctx, const mkhe_ct* ct, uint64_t* host) {
 }
 int mkhe_ct_download_poly_limbs(mkhe_ctx* ctx, const mkhe_ct* ct, int slot, uint64_t* const* limbs) {
     MKHE_TRY({
-        Context* c = ctx->c;
+        Context* c = need(ctx);
+        if (!ct || !limbs) throw Error("mkhe_ct_download_poly_limbs: null argument");
         if (slot < 0 || slot > ct->c.n) throw Error("mkhe_ct_download_poly_limbs: bad slot");
         for (int l = 0; l < ct->c.limbs; ++l)
             MKHE_HIP(hipMemcpyAsync(limbs[l], ct->c.d + ((size_t)slot * ct->c.limbs + l) * c->N, (size_t)c->N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         c->sync();
     })
 }
-int mkhe_ct_limbs(const mkhe_ct* ct) { return ct->c.limbs; }
-int mkhe_ct_nparties(const mkhe_ct* ct) { return ct->c.n; }
+int mkhe_ct_limbs(const mkhe_ct* ct) { return ct ? ct->c.limbs : 0; }
+int mkhe_ct_nparties(const mkhe_ct* ct) { return ct ? ct->c.n : 0; }
 void* mkhe_ct_devptr(mkhe_ct* ct) { return ct ? ct->c.d : nullptr; }
 
 // ---- raw buffers
 int mkhe_buf_alloc(mkhe_ctx* ctx, size_t words, void** dev_out) {
     MKHE_TRY({
-        MKHE_HIP(hipSetDevice(ctx->c->device));
+        MKHE_HIP(hipSetDevice(need(ctx)->device));
         void* d = nullptr;
         MKHE_HIP(hipMalloc(&d, (words ? words : 1) * sizeof(u64)));
         *dev_out = d;
@@ -211,43 +226,46 @@ void mkhe_buf_free(mkhe_ctx* ctx, void* dev) {
 }
 int mkhe_buf_upload(mkhe_ctx* ctx, void* dev, const uint64_t* host, size_t words) {
     MKHE_TRY({
-        MKHE_HIP(hipMemcpyAsync(dev, host, words * sizeof(u64), hipMemcpyHostToDevice, ctx->c->stream));
-        ctx->c->sync();
+        MKHE_HIP(hipMemcpyAsync(dev, host, words * sizeof(u64), hipMemcpyHostToDevice, need(ctx)->stream));
+        need(ctx)->sync();
     })
 }
 int mkhe_buf_download(mkhe_ctx* ctx, const void* dev, uint64_t* host, size_t words) {
     MKHE_TRY({
-        MKHE_HIP(hipMemcpyAsync(host, dev, words * sizeof(u64), hipMemcpyDeviceToHost, ctx->c->stream));
-        ctx->c->sync();
+        MKHE_HIP(hipMemcpyAsync(host, dev, words * sizeof(u64), hipMemcpyDeviceToHost, need(ctx)->stream));
+        need(ctx)->sync();
     })
 }
 
 // ---- ring level
 int mkhe_ntt(mkhe_ctx* ctx, const void* src, void* dst, int count, int limbs, int mod_base, int inverse, int lazy) {
-    MKHE_TRY(ctx->c->ntt((const u64*)src, (u64*)dst, count, limbs, mod_base, inverse != 0, lazy != 0))
+    MKHE_TRY({ if (!src || !dst || count < 1 || limbs < 1) throw Error("mkhe_ntt: bad argument"); need(ctx)->ntt((const u64*)src, (u64*)dst, count, limbs, mod_base, inverse != 0, lazy != 0); })
 }
 
 // ---- KeySwitcher
 static const u64* ct_slot(const Context* c, const mkhe_ct* ct, int slot, int level) {
+    if (!ct) throw Error("mkhe: null ciphertext");
     if (slot < 0 || slot > ct->c.n) throw Error("mkhe: bad ciphertext slot");
     if (ct->c.limbs < level + 1) throw Error("mkhe: ciphertext level below requested level");
     return ct->c.d + (size_t)slot * ct->c.limbs * c->N;
 }
 int mkhe_decompose(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* ct, int slot, mkhe_swk* out) {
-    MKHE_TRY(ctx->c->decompose(level, is_ntt != 0, ct_slot(ctx->c, ct, slot, level), out->s.d))
+    MKHE_TRY({ if (!out) throw Error("mkhe_decompose: null argument"); need(ctx)->decompose(level, is_ntt != 0, ct_slot(need(ctx), ct, slot, level), out->s.d); })
 }
 int mkhe_external_product(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* a, int slot,
                           const mkhe_swk* bg, mkhe_ct* out, int out_slot) {
     MKHE_TRY({
+        if (!out || !bg) throw Error("mkhe_external_product: null argument");
         if (out->c.limbs != level + 1) throw Error("mkhe_external_product: out must have level+1 limbs");
-        ctx->c->external_product(level, is_ntt != 0, ct_slot(ctx->c, a, slot, level), bg->s.d,
-                                 const_cast<u64*>(ct_slot(ctx->c, out, out_slot, level)), false);
+        need(ctx)->external_product(level, is_ntt != 0, ct_slot(need(ctx), a, slot, level), bg->s.d,
+                                 const_cast<u64*>(ct_slot(need(ctx), out, out_slot, level)), false);
     })
 }
 int mkhe_external_product_hoisted(mkhe_ctx* ctx, int level, const mkhe_swk* ah, const mkhe_swk* bg, mkhe_ct* out, int out_slot) {
     MKHE_TRY({
+        if (!out || !ah || !bg) throw Error("mkhe_external_product_hoisted: null argument");
         if (out->c.limbs != level + 1) throw Error("mkhe_external_product_hoisted: out must have level+1 limbs");
-        ctx->c->external_product_hoisted(level, ah->s.d, bg->s.d, const_cast<u64*>(ct_slot(ctx->c, out, out_slot, level)), false);
+        need(ctx)->external_product_hoisted(level, ah->s.d, bg->s.d, const_cast<u64*>(ct_slot(need(ctx), out, out_slot, level)), false);
     })
 }
 int mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
@@ -259,7 +277,7 @@ int mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
         auto h0 = swk_list(hoist0, op0->c.n); auto h1 = swk_list(hoist1, op1->c.n);
         auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n); auto v0 = swk_list(rlk_v0, op0->c.n);
         const bool same = (op0 == op1) && (hoist0 == hoist1);
-        ctx->c->mul_and_relin(op0->c, same ? op0->c : op1->c, hoist0 ? h0.data() : nullptr,
+        need(ctx)->mul_and_relin(op0->c, same ? op0->c : op1->c, hoist0 ? h0.data() : nullptr,
                               hoist1 ? (same ? h0.data() : h1.data()) : nullptr,
                               b1.data(), d0.data(), v0.data(), crs_u->s, out->c);
     })
@@ -272,34 +290,34 @@ int mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
         if (!op0 || !op1 || !out || !x_part || !y_part || !rlk_b1 || !rlk_d0) throw Error("mkhe_mr_partial: null argument");
         auto h0 = swk_list(hoist0, op0->c.n); auto h1 = swk_list(hoist1, op1->c.n);
         auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n);
-        ctx->c->mr_prepare(op0->c, op1->c, hoist0 ? h0.data() : nullptr, hoist1 ? h1.data() : nullptr, with_c0 != 0, out->c);
-        ctx->c->mr_xy(b1.data(), d0.data(), x_part->s.d, y_part->s.d, false);
+        need(ctx)->mr_prepare(op0->c, op1->c, hoist0 ? h0.data() : nullptr, hoist1 ? h1.data() : nullptr, with_c0 != 0, out->c);
+        need(ctx)->mr_xy(b1.data(), d0.data(), x_part->s.d, y_part->s.d, false);
     })
 }
 int mkhe_swk_fold(mkhe_ctx* ctx, mkhe_swk* swk, int level, int mform) {
-    MKHE_TRY(ctx->c->fold(swk->s.d, true, level, ctx->c->beta(level), (long)ctx->c->mtot * ctx->c->N, mform != 0))
+    MKHE_TRY({ if (!swk) throw Error("mkhe_swk_fold: null argument"); need(ctx)->fold(swk->s.d, true, level, need(ctx)->beta(level), (long)need(ctx)->mtot * need(ctx)->N, mform != 0); })
 }
 int mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x, const mkhe_swk* y,
                    const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out) {
     MKHE_TRY({
         if (!op0 || !op1 || !x || !y || !rlk_v0 || !crs_u || !out) throw Error("mkhe_mr_finish: null argument");
         auto v0 = swk_list(rlk_v0, op0->c.n);
-        ctx->c->mr_finish(op0->c, op1->c, x->s.d, y->s.d, v0.data(), crs_u->s, out->c);
+        need(ctx)->mr_finish(op0->c, op1->c, x->s.d, y->s.d, v0.data(), crs_u->s, out->c);
     })
 }
 int mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct) {
-    MKHE_TRY(ctx->c->fold(ct->c.d, false, ct->c.limbs - 1, 1 + ct->c.n, (long)ct->c.limbs * ctx->c->N, false))
+    MKHE_TRY({ if (!ct) throw Error("mkhe_ct_fold: null argument"); need(ctx)->fold(ct->c.d, false, ct->c.limbs - 1, 1 + ct->c.n, (long)ct->c.limbs * need(ctx)->N, false); })
 }
 int mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* hoist,
                 const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* out) {
     MKHE_TRY({
         if (!in || !out || !rk || !crs) throw Error("mkhe_rotate: null argument");
         auto h = swk_list(hoist, in->c.n); auto r = swk_list(rk, in->c.n);
-        ctx->c->rotate(galEl, in->c, hoist ? h.data() : nullptr, r.data(), crs->s, out->c);
+        need(ctx)->rotate(galEl, in->c, hoist ? h.data() : nullptr, r.data(), crs->s, out->c);
     })
 }
 int mkhe_ctx_set_owned(mkhe_ctx* ctx, const int* mod_idx, int n) {
-    MKHE_TRY({ if (n < 0 || (n > 0 && !mod_idx)) throw Error("mkhe_ctx_set_owned: bad argument"); ctx->c->set_owned(mod_idx, n); })
+    MKHE_TRY({ if (n < 0 || (n > 0 && !mod_idx)) throw Error("mkhe_ctx_set_owned: bad argument"); need(ctx)->set_owned(mod_idx, n); })
 }
 int mkhe_lsh_phase(mkhe_ctx* ctx, int phase, const mkhe_ct* op0, const mkhe_ct* op1,
                    const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0, const mkhe_swk* const* rlk_v0,
@@ -307,7 +325,7 @@ int mkhe_lsh_phase(mkhe_ctx* ctx, int phase, const mkhe_ct* op0, const mkhe_ct* 
     MKHE_TRY({
         if (!op0 || !op1 || !out || !words_out) throw Error("mkhe_lsh_phase: null argument");
         auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n); auto v0 = swk_list(rlk_v0, op0->c.n);
-        *words_out = ctx->c->lsh_phase(phase, op0->c, op1->c, rlk_b1 ? b1.data() : nullptr, rlk_d0 ? d0.data() : nullptr,
+        *words_out = need(ctx)->lsh_phase(phase, op0->c, op1->c, rlk_b1 ? b1.data() : nullptr, rlk_d0 ? d0.data() : nullptr,
                                        rlk_v0 ? v0.data() : nullptr, crs_u ? &crs_u->s : nullptr, out->c, (u64*)dev_stage);
     })
 }
@@ -316,74 +334,74 @@ int mkhe_rotate_partial(mkhe_ctx* ctx, const mkhe_ct* in, const mkhe_swk* const*
     MKHE_TRY({
         if (!in || !out || !rk || !crs) throw Error("mkhe_rotate_partial: null argument");
         auto h = swk_list(hoist, in->c.n); auto r = swk_list(rk, in->c.n);
-        ctx->c->rotate_partial(in->c, hoist ? h.data() : nullptr, r.data(), crs->s, with_c0 != 0, out->c);
+        need(ctx)->rotate_partial(in->c, hoist ? h.data() : nullptr, r.data(), crs->s, with_c0 != 0, out->c);
     })
 }
 int mkhe_ct_automorphism(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, mkhe_ct* out) {
-    MKHE_TRY({ if (!in || !out) throw Error("mkhe_ct_automorphism: null argument"); ctx->c->automorphism(galEl, in->c, out->c); })
+    MKHE_TRY({ if (!in || !out) throw Error("mkhe_ct_automorphism: null argument"); need(ctx)->automorphism(galEl, in->c, out->c); })
 }
 int mkhe_conjugate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* ck,
                    const mkhe_swk* crs, mkhe_ct* out) {
     MKHE_TRY({
         if (!in || !out || !ck || !crs) throw Error("mkhe_conjugate: null argument");
         auto k = swk_list(ck, in->c.n);
-        ctx->c->conjugate(galEl, in->c, k.data(), crs->s, out->c);
+        need(ctx)->conjugate(galEl, in->c, k.data(), crs->s, out->c);
     })
 }
 int mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out) {
-    MKHE_TRY(ctx->c->rescale(in->c, nb, out->c))
+    MKHE_TRY({ if (!in || !out) throw Error("mkhe_rescale: null argument"); need(ctx)->rescale(in->c, nb, out->c); })
 }
 
 int mkhe_ct_add(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out) {
-    MKHE_TRY({ if (!op0 || !op1 || !out) throw Error("mkhe_ct_add: null argument"); ctx->c->ct_binary(0, op0->c, op1->c, out->c); })
+    MKHE_TRY({ if (!op0 || !op1 || !out) throw Error("mkhe_ct_add: null argument"); need(ctx)->ct_binary(0, op0->c, op1->c, out->c); })
 }
 int mkhe_ct_sub(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out) {
-    MKHE_TRY({ if (!op0 || !op1 || !out) throw Error("mkhe_ct_sub: null argument"); ctx->c->ct_binary(1, op0->c, op1->c, out->c); })
+    MKHE_TRY({ if (!op0 || !op1 || !out) throw Error("mkhe_ct_sub: null argument"); need(ctx)->ct_binary(1, op0->c, op1->c, out->c); })
 }
 int mkhe_ct_mul_const(mkhe_ctx* ctx, const mkhe_ct* in, const uint64_t* c_first, const uint64_t* c_second, mkhe_ct* out) {
-    MKHE_TRY({ if (!in || !out || !c_first || !c_second) throw Error("mkhe_ct_mul_const: null argument"); ctx->c->ct_mul_const(in->c, c_first, c_second, out->c); })
+    MKHE_TRY({ if (!in || !out || !c_first || !c_second) throw Error("mkhe_ct_mul_const: null argument"); need(ctx)->ct_mul_const(in->c, c_first, c_second, out->c); })
 }
 int mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe_ct* out) {
-    MKHE_TRY({ if (!in || !out || !dev_pt) throw Error("mkhe_ct_mul_ptxt: null argument"); ctx->c->ct_mul_ptxt(in->c, (const u64*)dev_pt, out->c); })
+    MKHE_TRY({ if (!in || !out || !dev_pt) throw Error("mkhe_ct_mul_ptxt: null argument"); need(ctx)->ct_mul_ptxt(in->c, (const u64*)dev_pt, out->c); })
 }
 
 // ---- key generation / CRS expansion
 int mkhe_keygen_secret(mkhe_ctx* ctx, const int32_t* s, void* dev_sk) {
-    MKHE_TRY({ if (!s || !dev_sk) throw Error("mkhe_keygen_secret: null argument"); ctx->c->keygen_secret(s, (u64*)dev_sk); })
+    MKHE_TRY({ if (!s || !dev_sk) throw Error("mkhe_keygen_secret: null argument"); need(ctx)->keygen_secret(s, (u64*)dev_sk); })
 }
 int mkhe_keygen_switching_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, mkhe_swk* out) {
-    MKHE_TRY({ if (!dev_sk || !e || !out) throw Error("mkhe_keygen_switching_key: null argument"); ctx->c->keygen_switching_key((const u64*)dev_sk, e, out->s.d); })
+    MKHE_TRY({ if (!dev_sk || !e || !out) throw Error("mkhe_keygen_switching_key: null argument"); need(ctx)->keygen_switching_key((const u64*)dev_sk, e, out->s.d); })
 }
 int mkhe_keygen_public_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, const mkhe_swk* crs_a, void* dev_pk) {
-    MKHE_TRY({ if (!dev_sk || !e || !crs_a || !dev_pk) throw Error("mkhe_keygen_public_key: null argument"); ctx->c->keygen_public_key((const u64*)dev_sk, e, crs_a->s.d, (u64*)dev_pk); })
+    MKHE_TRY({ if (!dev_sk || !e || !crs_a || !dev_pk) throw Error("mkhe_keygen_public_key: null argument"); need(ctx)->keygen_public_key((const u64*)dev_sk, e, crs_a->s.d, (u64*)dev_pk); })
 }
 int mkhe_keygen_relin_key(mkhe_ctx* ctx, const void* dev_sk, const void* dev_r, const int32_t* e,
                           const mkhe_swk* crs_a, const mkhe_swk* crs_u, mkhe_swk* b, mkhe_swk* d, mkhe_swk* v) {
     MKHE_TRY({
         if (!dev_sk || !dev_r || !e || !crs_a || !crs_u || !b || !d || !v) throw Error("mkhe_keygen_relin_key: null argument");
-        ctx->c->keygen_relin_key((const u64*)dev_sk, (const u64*)dev_r, e, crs_a->s.d, crs_u->s.d, b->s.d, d->s.d, v->s.d);
+        need(ctx)->keygen_relin_key((const u64*)dev_sk, (const u64*)dev_r, e, crs_a->s.d, crs_u->s.d, b->s.d, d->s.d, v->s.d);
     })
 }
 int mkhe_keygen_rotation_key(mkhe_ctx* ctx, uint64_t galEl, const void* dev_sk, const int32_t* e, const mkhe_swk* crs, mkhe_swk* out) {
-    MKHE_TRY({ if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_rotation_key: null argument"); ctx->c->keygen_rotation_key(galEl, (const u64*)dev_sk, e, crs->s.d, out->s.d); })
+    MKHE_TRY({ if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_rotation_key: null argument"); need(ctx)->keygen_rotation_key(galEl, (const u64*)dev_sk, e, crs->s.d, out->s.d); })
 }
 int mkhe_keygen_conjugation_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, const mkhe_swk* crs, mkhe_swk* out) {
-    MKHE_TRY({ if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_conjugation_key: null argument"); ctx->c->keygen_conjugation_key((const u64*)dev_sk, e, crs->s.d, out->s.d); })
+    MKHE_TRY({ if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_conjugation_key: null argument"); need(ctx)->keygen_conjugation_key((const u64*)dev_sk, e, crs->s.d, out->s.d); })
 }
 int mkhe_bfv_keygen_switching_key(mkhe_ctx* ctx, const void* dev_sk, const uint64_t* g, const int32_t* e, mkhe_swk* out) {
-    MKHE_TRY({ if (!dev_sk || !g || !e || !out) throw Error("mkhe_bfv_keygen_switching_key: null argument"); ctx->c->bfv_keygen_switching_key((const u64*)dev_sk, g, e, out->s.d); })
+    MKHE_TRY({ if (!dev_sk || !g || !e || !out) throw Error("mkhe_bfv_keygen_switching_key: null argument"); need(ctx)->bfv_keygen_switching_key((const u64*)dev_sk, g, e, out->s.d); })
 }
 int mkhe_bfv_keygen_relin_key(mkhe_ctx* ctx, const void* dev_sk, const void* dev_r, const uint64_t* g1, const uint64_t* g2,
                               const int32_t* e, const mkhe_swk* a1, const mkhe_swk* a2, const mkhe_swk* u,
                               mkhe_swk* b1, mkhe_swk* b2, mkhe_swk* d1, mkhe_swk* d2, mkhe_swk* v) {
     MKHE_TRY({
         if (!dev_sk || !dev_r || !g1 || !g2 || !e || !a1 || !a2 || !u || !b1 || !b2 || !d1 || !d2 || !v) throw Error("mkhe_bfv_keygen_relin_key: null argument");
-        ctx->c->bfv_keygen_relin_key((const u64*)dev_sk, (const u64*)dev_r, g1, g2, e, a1->s.d, a2->s.d, u->s.d,
+        need(ctx)->bfv_keygen_relin_key((const u64*)dev_sk, (const u64*)dev_r, g1, g2, e, a1->s.d, a2->s.d, u->s.d,
                                      b1->s.d, b2->s.d, d1->s.d, d2->s.d, v->s.d);
     })
 }
 int mkhe_crs_expand(mkhe_ctx* ctx, uint64_t seed, int32_t idx, mkhe_swk* out) {
-    MKHE_TRY({ if (!out) throw Error("mkhe_crs_expand: null argument"); ctx->c->crs_expand(seed, idx, out->s.d); })
+    MKHE_TRY({ if (!out) throw Error("mkhe_crs_expand: null argument"); need(ctx)->crs_expand(seed, idx, out->s.d); })
 }
 
 // ---- mkbfv
@@ -395,28 +413,28 @@ int mkhe_ctx_create_bfv(mkhe_ctx** out, int logN, const uint64_t* Q, const uint6
     })
 }
 int mkhe_bfv_modup_q_to_r(mkhe_ctx* ctx, const void* q, void* r, int npolys) {
-    MKHE_TRY({ if (!q || !r || npolys < 1) throw Error("mkhe_bfv_modup_q_to_r: bad argument"); ctx->c->bfv_modup_q_to_r((const u64*)q, (u64*)r, npolys); })
+    MKHE_TRY({ if (!q || !r || npolys < 1) throw Error("mkhe_bfv_modup_q_to_r: bad argument"); need(ctx)->bfv_modup_q_to_r((const u64*)q, (u64*)r, npolys); })
 }
 int mkhe_bfv_rescale(mkhe_ctx* ctx, const void* q, void* r, int npolys) {
-    MKHE_TRY({ if (!q || !r || npolys < 1) throw Error("mkhe_bfv_rescale: bad argument"); ctx->c->bfv_rescale((const u64*)q, (u64*)r, npolys); })
+    MKHE_TRY({ if (!q || !r || npolys < 1) throw Error("mkhe_bfv_rescale: bad argument"); need(ctx)->bfv_rescale((const u64*)q, (u64*)r, npolys); })
 }
 int mkhe_bfv_quantize(mkhe_ctx* ctx, const void* r, void* q, int npolys) {
-    MKHE_TRY({ if (!q || !r || npolys < 1) throw Error("mkhe_bfv_quantize: bad argument"); ctx->c->bfv_quantize((const u64*)r, (u64*)q, npolys); })
+    MKHE_TRY({ if (!q || !r || npolys < 1) throw Error("mkhe_bfv_quantize: bad argument"); need(ctx)->bfv_quantize((const u64*)r, (u64*)q, npolys); })
 }
 int mkhe_bfv_ntt_r(mkhe_ctx* ctx, const void* src, void* dst, int count, int inverse) {
-    MKHE_TRY({ if (!src || !dst || count < 1) throw Error("mkhe_bfv_ntt_r: bad argument"); ctx->c->ntt_r((const u64*)src, (u64*)dst, count, inverse != 0); })
+    MKHE_TRY({ if (!src || !dst || count < 1) throw Error("mkhe_bfv_ntt_r: bad argument"); need(ctx)->ntt_r((const u64*)src, (u64*)dst, count, inverse != 0); })
 }
 int mkhe_bfv_decompose(mkhe_ctx* ctx, const void* polyr, mkhe_swk* ad1, mkhe_swk* ad2) {
     MKHE_TRY({
         if (!polyr || !ad1 || !ad2) throw Error("mkhe_bfv_decompose: null argument");
-        ctx->c->bfv_decompose_batch({(const u64*)polyr}, {ad1->s.d}, {ad2->s.d});
+        need(ctx)->bfv_decompose_batch({(const u64*)polyr}, {ad1->s.d}, {ad2->s.d});
     })
 }
 int mkhe_bfv_external_product_hoisted(mkhe_ctx* ctx, const mkhe_swk* ah1, const mkhe_swk* ah2,
                                       const mkhe_swk* bg1, const mkhe_swk* bg2, void* dev_c) {
     MKHE_TRY({
         if (!ah1 || !ah2 || !bg1 || !bg2 || !dev_c) throw Error("mkhe_bfv_external_product_hoisted: null argument");
-        ctx->c->bfv_external_product_hoisted(ah1->s.d, ah2->s.d, bg1->s.d, bg2->s.d, (u64*)dev_c);
+        need(ctx)->bfv_external_product_hoisted(ah1->s.d, ah2->s.d, bg1->s.d, bg2->s.d, (u64*)dev_c);
     })
 }
 int mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
@@ -427,13 +445,13 @@ int mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
         if (!op0 || !op1 || !out || !crs_u || !rlk_b1 || !rlk_b2 || !rlk_d1 || !rlk_d2 || !rlk_v) throw Error("mkhe_bfv_mul_relin: null argument");
         auto b1 = swk_list(rlk_b1, op1->c.n); auto b2 = swk_list(rlk_b2, op1->c.n);
         auto d1 = swk_list(rlk_d1, op0->c.n); auto d2 = swk_list(rlk_d2, op0->c.n); auto v = swk_list(rlk_v, op0->c.n);
-        ctx->c->bfv_mul_relin(op0->c, op1->c, b1.data(), b2.data(), d1.data(), d2.data(), v.data(), crs_u->s, out->c);
+        need(ctx)->bfv_mul_relin(op0->c, op1->c, b1.data(), b2.data(), d1.data(), d2.data(), v.data(), crs_u->s, out->c);
     })
 }
 
-int mkhe_set_overlap(mkhe_ctx* ctx, int on) { MKHE_TRY({ ctx->c->sync(); ctx->c->overlap = on != 0; }) }
-int mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf) { ctx->c->ntt_trace = (u64*)dev_buf; return 0; }
-int mkhe_prof_enable(mkhe_ctx* ctx, int on) { MKHE_TRY(ctx->c->prof_enable(on != 0)) }
+int mkhe_set_overlap(mkhe_ctx* ctx, int on) { MKHE_TRY({ need(ctx)->sync(); need(ctx)->overlap = on != 0; }) }
+int mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf) { need(ctx)->ntt_trace = (u64*)dev_buf; return 0; }
+int mkhe_prof_enable(mkhe_ctx* ctx, int on) { MKHE_TRY(need(ctx)->prof_enable(on != 0)) }
 int mkhe_prof_nclass(void) { return Context::PROF_NCLASS; }
 const char* mkhe_prof_name(int cls) {
     static const char* names[] = {"ntt_fwd_kernel<N,1,true>  (Decompose, q<2^57)", "ntt_fwd_kernel<N,0,true>  (Decompose, q>=2^57)",
@@ -442,7 +460,7 @@ const char* mkhe_prof_name(int cls) {
     return (cls >= 0 && cls < Context::PROF_NCLASS) ? names[cls] : "";
 }
 int mkhe_prof_collect(mkhe_ctx* ctx, double* ms, long* launches, double* alg_bytes) {
-    MKHE_TRY(ctx->c->prof_collect(ms, launches, alg_bytes))
+    MKHE_TRY(need(ctx)->prof_collect(ms, launches, alg_bytes))
 }
 
 }  // extern "C"

@@ -443,3 +443,21 @@ def test_ckks_rescale_new_and_errors(pair):
     ct.Scale = 0.0
     with pytest.raises(pair.mk.MkheError, match="scale is 0"):
         ev.RescaleNew(ct, 2.0 ** 30)
+
+
+def test_null_arguments_are_errors_not_crashes():
+    """the C ABI reports null contexts / handles through its error channel (the reference panics; it never segfaults)"""
+    import ctypes as C
+    from mkhe_kklss_amd._abi import lib
+    L = lib()
+    assert L.mkhe_ctx_sync(None) != 0 and b"null context" in L.mkhe_last_error()
+    assert L.mkhe_ctx_n(None) == 0 and L.mkhe_ct_limbs(None) == 0
+    h = C.c_void_p()
+    assert L.mkhe_swk_create(None, C.byref(h)) != 0
+    pset = H.small_ckks(10, 2)
+    from mkhe_kklss_amd import mkrlwe
+    params = mkrlwe.Parameters(pset["logN"], pset["Q"], pset["P"])
+    assert L.mkhe_swk_upload(params.ctx, None, None) != 0 and b"null argument" in L.mkhe_last_error()
+    assert L.mkhe_ct_download(params.ctx, None, None) != 0
+    assert L.mkhe_rescale(params.ctx, None, 1, None) != 0
+    assert L.mkhe_crs_expand(params.ctx, 1, 0, None) != 0
