@@ -508,7 +508,7 @@ __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr 
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(SM_T, 2) ntt_fwd_lds_kernel(NttBatch b, int d) {
+__global__ void __launch_bounds__(SM_T) ntt_fwd_lds_kernel(NttBatch b, int d) {
     extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
     const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
     gcptr src; gptr dst; int m, outer;
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(SM_T, 2) ntt_fwd_lds_kernel(NttBatch b, int d)
     sm_phase<12, 1, false, true, MODE, 1>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
 }
 
-__global__ void __launch_bounds__(SM_T, 2) ntt_inv_lds_kernel(NttBatch b, int d) {
+__global__ void __launch_bounds__(SM_T) ntt_inv_lds_kernel(NttBatch b, int d) {
     extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
     const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
     gcptr src; gptr dst; int m, outer;
