@@ -145,6 +145,12 @@ def run_cnn(args):
     ptMask = mkrlwe.DeviceLimbs(params, 1, level - 3).upload(ptMask[None])            # resident plaintext (uploaded once)
     ev = mkckks.NewEvaluator(params)
     forks = [ev.Fork() for _ in range(max(0, args.forks))]       # extra engine contexts: the independent chains of a layer overlap
+    if os.environ.get("MKHE_CNN_INTRA_OVERLAP", "0") == "0":
+        # the side streams inside one operation (x / y / tensor overlap) pay off for the large launches of the headline workload;
+        # here every launch is tiny, the forks provide the concurrency, and the extra event record / wait calls only cost host time
+        from mkhe_kklss_amd._abi import check, lib
+        for e in [ev] + forks:
+            check(lib().mkhe_set_overlap(e.params.ctx, 0))
     hoisted = (ev.HoistedForm(ctImage), [ev.HoistedForm(c) for c in ctKernels], [ev.HoistedForm(c) for c in ctFC1])     # precomputation, as in the reference
     layer_ms = {}
     def timed(name, fn):
@@ -166,17 +172,25 @@ def run_cnn(args):
     if args.graph:
         # the whole inference recorded once into a HIP graph (the fork streams become parallel branches) and replayed with
         # one submission per step: the inputs are the resident ciphertext handles, a new image is uploaded into ctImage
-        with params.Capture() as graph:
-            out = inference(False)
-        for _ in range(max(1, args.warmup)):
-            graph.launch()
-        params.sync()
+        from mkhe_kklss_amd._abi import MkheError
+        try:
+            with params.Capture() as graph:
+                out = inference(False)
+            for _ in range(max(1, args.warmup)):
+                graph.launch()
+            params.sync()
+        except MkheError as e:
+            print("graph capture unavailable, issuing eagerly: %s" % e, file=sys.stderr)
+            graph = None
     t0 = time.perf_counter()
+    issue = 0.0
     for _ in range(args.steps):
+        ti = time.perf_counter()
         if graph is not None:
             graph.launch()
         else:
             out = inference(False)
+        issue += time.perf_counter() - ti
     params.sync()
     dt = time.perf_counter() - t0
     for _ in range(args.steps):                      # per-layer figures: a second, untimed-for-`value` pass with a sync per layer
@@ -188,7 +202,7 @@ def run_cnn(args):
                 config=dict(workload="cnn encrypted inference (Convolution + square + FC1 + square + FC2, cnn/cnn.go), PN14QP433 N=2^14, "
                                      "7 Q + 2 P limbs, %d parties" % len(set(owners.values())),
                             parties=len(set(owners.values())), params="PN14QP433", seed=args.seed,
-                            forks=len(forks), hip_graph=bool(args.graph), layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
+                            forks=len(forks), hip_graph=graph is not None, host_issue_ms=issue * 1e3 / args.steps, layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
                             keygen_s=keygen_s, keys_generated=len(set(owners.values())) * (3 + len(HC.ROTS) + p["logN"] - 1)),
                 roofline=roofline, cpu_baseline=None)
 
@@ -382,10 +396,9 @@ def main():
                          "alpha = 2) on ONE GPU, keys written on the device (implies --device-keys, single GPU only)")
     ap.add_argument("--forks", type=int, default=7,
                     help="--scheme cnn: extra engine contexts through which the independent chains of a layer are issued (0 = one stream)")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="--scheme cnn: 1 = replay the inference from a captured HIP graph, 0 = issue every call eagerly (default: "
-                         "measured 4.4 ms eager vs 4.6 ms replayed -- with the forks the step is bound by its chain of dependent "
-                         "small kernels on the GPU, not by the host's launch rate)")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="--scheme cnn: 1 = replay the inference from a captured HIP graph (default; falls back to eager issue when the "
+                         "loaded HIP runtime cannot capture), 0 = issue every call eagerly")
     ap.add_argument("--device-keys", action="store_true",
                     help="fill keys / CRS with the engine's CRS expander instead of host random numbers (no CPU-oracle check)")
     ap.add_argument("--seed", type=int, default=0x4D4B4845)
