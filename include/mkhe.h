@@ -110,6 +110,10 @@ int  mkhe_ntt(mkhe_ctx* ctx, const void* dev_src, void* dev_dst, int count, int 
  *      basis_extension.go:428-535).  Input poly = slot `slot` of ct; is_ntt mirrors ring.Poly.IsNTT. */
 int  mkhe_decompose(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* ct, int slot, mkhe_swk* out);
 
+/* ---- mkckks.Evaluator.HoistedForm evaluator.go:543-553: Decompose of every party component ct.Value[id] (slots 1..n, not
+ *      slot 0) in one batched launch; out[i] receives h(ct.Value[ids[i]]). */
+int  mkhe_hoisted_form(mkhe_ctx* ctx, int level, const mkhe_ct* ct, mkhe_swk* const* out);
+
 /* ---- KeySwitcher.ExternalProduct keyswitch.go:79-118 / ExternalProductHoisted keyswitch_hoisted.go:10-40.
  *      Result (coefficient domain, canonical) is written to slot out_slot of out. */
 int  mkhe_external_product(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* a, int slot,

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mkhe_buf_download": (C.c_int, [vp, vp, u64p, C.c_size_t]),
     "mkhe_ntt": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mkhe_decompose": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "mkhe_hoisted_form": (C.c_int, [vp, C.c_int, vp, vpp]),
     "mkhe_external_product": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int]),
     "mkhe_external_product_hoisted": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int]),
     "mkhe_mul_and_relin": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),

@@ -252,6 +252,17 @@ static const u64* ct_slot(const Context* c, const mkhe_ct* ct, int slot, int lev
 int mkhe_decompose(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* ct, int slot, mkhe_swk* out) {
     MKHE_TRY({ if (!out) throw Error("mkhe_decompose: null argument"); need(ctx)->decompose(level, is_ntt != 0, ct_slot(need(ctx), ct, slot, level), out->s.d); })
 }
+int mkhe_hoisted_form(mkhe_ctx* ctx, int level, const mkhe_ct* ct, mkhe_swk* const* out) {
+    MKHE_TRY({
+        if (!ct || (ct->c.n > 0 && !out)) throw Error("mkhe_hoisted_form: null argument");
+        std::vector<const u64*> src; std::vector<u64*> dst;
+        for (int i = 0; i < ct->c.n; ++i) {
+            if (!out[i]) throw Error("mkhe_hoisted_form: null output handle");
+            src.push_back(ct_slot(need(ctx), ct, 1 + i, level)); dst.push_back(out[i]->s.d);
+        }
+        if (!src.empty()) need(ctx)->decompose_batch(level, src, dst, false);
+    })
+}
 int mkhe_external_product(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* a, int slot,
                           const mkhe_swk* bg, mkhe_ct* out, int out_slot) {
     MKHE_TRY({

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi, mkrlwe
-from ._abi import MkheError, check, lib
+from ._abi import MkheError, check, handle_array, lib
 
 
 def scaleUpExact(value, n, q):
@@ -174,7 +174,7 @@ class Evaluator:
         h = mkrlwe.NewHoistedCiphertext()
         for id in ct.ids:
             h.Value[id] = mkrlwe.NewSwitchingKey(self.params)
-            self.ksw.Decompose(ct.Level(), ct, id, h.Value[id])
+        check(lib().mkhe_hoisted_form(self.params.ctx, ct.Level(), ct.h, handle_array([h.Value[id].h for id in ct.ids])))   # one batched launch
         return h
 
     # ---- MulRelinNew (evaluator.go:416-443): hoisting of both operands happens inside the engine
