@@ -73,6 +73,8 @@ void* mkhe_ctx_stream(mkhe_ctx* ctx);                     /* hipStream_t, for ev
 
 /* ---- SwitchingKey handles: mkrlwe.SwitchingKey keys.go:23-25, NewSwitchingKey keys.go:245-255 */
 int  mkhe_swk_create(mkhe_ctx* ctx, mkhe_swk** out);
+/* same without the zero fill: for keys / hoisted forms that the next engine call writes (mkhe_hoisted_form, mkhe_decompose, key generation) */
+int  mkhe_swk_create_uninit(mkhe_ctx* ctx, mkhe_swk** out);
 void mkhe_swk_destroy(mkhe_ctx* ctx, mkhe_swk* swk);
 int  mkhe_swk_upload(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* host);
 /* Go's []rlwe.PolyQP: one pointer per limb, order [digit][Q limbs..., P limbs...] */

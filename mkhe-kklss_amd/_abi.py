@@ -31,6 +31,7 @@ SIGNATURES = {
     "mkhe_ctx_psi": (C.c_uint64, [vp, C.c_int]),
     "mkhe_ctx_stream": (vp, [vp]),
     "mkhe_swk_create": (C.c_int, [vp, vpp]),
+    "mkhe_swk_create_uninit": (C.c_int, [vp, vpp]),
     "mkhe_swk_destroy": (None, [vp, vp]),
     "mkhe_swk_upload": (C.c_int, [vp, vp, u64p]),
     "mkhe_swk_upload_limbs": (C.c_int, [vp, vp, vpp, C.c_int]),

@@ -86,17 +86,17 @@ uint64_t mkhe_ctx_psi(const mkhe_ctx* ctx, int i) { if (!ctx) return 0; return (
 void* mkhe_ctx_stream(mkhe_ctx* ctx) { if (!ctx) return 0; return (void*)ctx->c->stream; }
 
 // ---- switching keys
-int mkhe_swk_create(mkhe_ctx* ctx, mkhe_swk** out) {
-    MKHE_TRY({
-        Context* c = need(ctx);
-        MKHE_HIP(hipSetDevice(c->device));
-        if (!out) throw Error("mkhe_swk_create: null argument");
-        mkhe_swk* s = new mkhe_swk();
-        try { s->s.d = c->pool_alloc(c->swk_words()); } catch (...) { delete s; throw; }
-        MKHE_HIP(hipMemsetAsync(s->s.d, 0, c->swk_words() * sizeof(u64), c->stream));
-        *out = s;
-    })
+static void swk_create(mkhe_ctx* ctx, mkhe_swk** out, bool zero) {
+    Context* c = need(ctx);
+    MKHE_HIP(hipSetDevice(c->device));
+    if (!out) throw Error("mkhe_swk_create: null argument");
+    mkhe_swk* s = new mkhe_swk();
+    try { s->s.d = c->pool_alloc(c->swk_words()); } catch (...) { delete s; throw; }
+    if (zero) MKHE_HIP(hipMemsetAsync(s->s.d, 0, c->swk_words() * sizeof(u64), c->stream));
+    *out = s;
 }
+int mkhe_swk_create(mkhe_ctx* ctx, mkhe_swk** out) { MKHE_TRY(swk_create(ctx, out, true)) }
+int mkhe_swk_create_uninit(mkhe_ctx* ctx, mkhe_swk** out) { MKHE_TRY(swk_create(ctx, out, false)) }
 void mkhe_swk_destroy(mkhe_ctx* ctx, mkhe_swk* swk) {
     if (!swk) return;
     if (swk->s.d && swk->s.owned) { if (ctx) ctx->c->pool_free(swk->s.d, ctx->c->swk_words()); else (void)hipFree(swk->s.d); }

@@ -173,7 +173,7 @@ class Evaluator:
     def HoistedForm(self, ct):
         h = mkrlwe.NewHoistedCiphertext()
         for id in ct.ids:
-            h.Value[id] = mkrlwe.NewSwitchingKey(self.params)
+            h.Value[id] = mkrlwe.SwitchingKey(self.params, zero=False)          # every digit the level uses is written below
         check(lib().mkhe_hoisted_form(self.params.ctx, ct.Level(), ct.h, handle_array([h.Value[id].h for id in ct.ids])))   # one batched launch
         return h
 

@@ -179,10 +179,12 @@ class SwitchingKey:
     """mkrlwe.SwitchingKey (keys.go:23-25): []rlwe.PolyQP of Beta(maxLevel) digits, resident in HBM.
     Host layout uint64[beta][nQ+nP][N]."""
 
-    def __init__(self, params, host=None):
+    def __init__(self, params, host=None, zero=True):
+        """zero=False: no zero fill (the key is about to be written by an engine call or an upload)"""
         self.params = params
         h = C.c_void_p()
-        check(lib().mkhe_swk_create(params.ctx, C.byref(h)))
+        create = lib().mkhe_swk_create if (zero and host is None) else lib().mkhe_swk_create_uninit
+        check(create(params.ctx, C.byref(h)))
         self.h = h
         _pin(self)
         if host is not None:
