@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerates profiles/README.md from the distilled files of tools/collect_profiles.py:  python tools/write_profiles_readme.py r1c"""
+"""Regenerates profiles/README.md from the distilled files of tools/collect_profiles.py:  python tools/write_profiles_readme.py r1d"""
 import csv
 import json
 import os
@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles") + "/"
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1c"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1d"
 pl = json.load(open(P + tag + "_bench_plain.json"))
 no = json.load(open(P + tag + "_bench_noovl.json"))
 bf = json.load(open(P + tag + "_bench_bfv.json"))
@@ -59,6 +59,10 @@ Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per 
 | kernel | launches/step | avg µs/launch | ms/step | algorithmic GB/s |
 |---|---|---|---|---|
 {table(pl)}
+
+(The classes are the engine's timing classes: launches of ≤ 128 limbs in the `ntt_fwd_kernel<15,·,false>` and `ntt_inv_kernel<15>`
+classes run as `ntt_pass4_fwd/inv_kernel` + `ntt_fwd/inv_lds_kernel` — the low-latency path of DESIGN.md §4 — which is what the
+rocprofv3 kernel statistics list under those names.)
 
 Dominant kernel `ntt_fwd_kernel<15,1,true>` (Decompose-fused forward NTT, 54-bit primes):
 HIP-event average {R["avg_launch_us"]:.1f} µs per launch, rocprofv3 kernel-trace average {st("ntt_fwd_kernel<15, 1, true>")[0]:.1f} µs
