@@ -98,6 +98,8 @@ class Context {
     // stage 0: whole external products; 1: front half only (inner products + inverse NTT into the c1 pool);
     // 2: back half only (ModDown of the c1 pool filled by the preceding stage-1 call with the same items)
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0);
+    void ext_front(int level, const ExtItem* items, int n, u64* c1);          // inner products + lazy inverse NTT into c1 [n][mtot][N]
+    void ext_back(int level, const ExtItem* items, int n, const u64* c1);     // ModDown of c1 into / onto the destinations
 
     // ---- limb-sharded multi-GPU evaluation (mkhe_kklss_amd/dist.py LimbShardedMulRelin): this context owns a subset of
     // the RNS moduli ("slots"); NTTs, inner products and ModDown outputs are computed for the owned slots only, all

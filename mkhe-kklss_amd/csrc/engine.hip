@@ -514,48 +514,57 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
 }
 
 // items: independent external products  dst (+)= ModDown( sum_i bg[i] (.) ah[i] )
+// front half: inner products over the gadget digits + lazy inverse NTT of up to EXT_MAX_ITEMS items into c1 ([item][mtot][N])
+void Context::ext_front(int level, const ExtItem* it, int n, u64* c1) {
+    const int nb = beta(level), nslots = nslots_qp(level);
+    const size_t item_words = (size_t)mtot * N;
+    if (n < 1 || nslots < 1) return;
+    ExtInnerArgs ia{};
+    bool two = false;
+    for (int i = 0; i < n; ++i) {
+        ia.ah[i] = it[i].ah; ia.bg[i] = it[i].bg;
+        ia.ah2[i] = it[i].ah2; ia.bg2[i] = it[i].bg2;
+        two = two || ia.ah2[i] != nullptr;
+    }
+    // neighbours that share their digits (step F: <h(t_i), v_i> and <h(t_i), u>) are computed together
+    for (int i = 0; i + 1 < n; ++i)
+        if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }
+    ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
+    ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
+    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb * (two ? 2 : 1) + 1) * n); launch_ext_inner(ia, s_); }
+    NttBatch b{};
+    b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
+    b.nouter = n; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
+    b.src_outer = b.dst_outer = (long)item_words; b.lazy_out = 1;
+    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, s_); }
+}
+// back half: ModDown of the items in c1 into (or onto) their destinations
+void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1) {
+    if (n < 1) return;
+    const size_t item_words = (size_t)mtot * N;
+    ModDownBatchArgs md{};
+    md.c1 = c1; md.mods_q = d_mods; md.mods_p = d_mods + nq;
+    md.t = ModDownTables{d_md_qoverqiinvqi, d_md_qoverqimodp, d_md_vtimes, d_md_down};
+    md.c1_item = (long)item_words; md.p_offset = (long)nq * N; md.nitems = n; md.level = level; md.np = np; md.N = N;
+    if (masked_) { md.qlist = d_ownq; md.nqlist = nq_owned(level); }
+    double bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        md.dst[i] = it[i].dst; md.accumulate[i] = it[i].accumulate ? 1 : 0;
+        bytes += 8.0 * N * ((level + 1) * (it[i].accumulate ? 3.0 : 2.0) + np);
+    }
+    { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_batch(md, s_); }
+}
 void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown, int stage) {
     if (stage != 0 && items.size() > (size_t)EXT_MAX_ITEMS) throw Error("mkhe: too many external products for a staged batch");
     check_level(level);
-    const int nb = beta(level), nslots = nslots_qp(level);
     const size_t item_words = (size_t)mtot * N;
     for (size_t base = 0; base < items.size(); base += EXT_MAX_ITEMS) {
         const int n = (int)std::min<size_t>(EXT_MAX_ITEMS, items.size() - base);
         u64* c1 = scratch(c1b_, c1b_words_, (size_t)n * item_words);
-        ExtInnerArgs ia{};
-        bool two = false;
-        for (int i = 0; i < n; ++i) {
-            ia.ah[i] = items[base + i].ah; ia.bg[i] = items[base + i].bg;
-            ia.ah2[i] = items[base + i].ah2; ia.bg2[i] = items[base + i].bg2;
-            two = two || ia.ah2[i] != nullptr;
-        }
-        // neighbours that share their digits (step F: <h(t_i), v_i> and <h(t_i), u>) are computed together
-        for (int i = 0; i + 1 < n; ++i)
-            if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }
-        ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
-        ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
-        if (stage != 2 && nslots > 0) {
-            { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb * (two ? 2 : 1) + 1) * n); launch_ext_inner(ia, s_); }
-            NttBatch b{};
-            b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
-            b.nouter = n; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
-            b.src_outer = b.dst_outer = (long)item_words; b.lazy_out = 1;
-            { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, s_); }
-        }
+        if (stage != 2) ext_front(level, items.data() + base, n, c1);
         if (stage == 1) continue;
-
-        ModDownBatchArgs md{};
-        md.c1 = c1; md.mods_q = d_mods; md.mods_p = d_mods + nq;
-        md.t = ModDownTables{d_md_qoverqiinvqi, d_md_qoverqimodp, d_md_vtimes, d_md_down};
-        md.c1_item = (long)item_words; md.p_offset = (long)nq * N; md.nitems = n; md.level = level; md.np = np; md.N = N;
-        if (masked_) { md.qlist = d_ownq; md.nqlist = nq_owned(level); }
-        double bytes = 0;
-        for (int i = 0; i < n; ++i) {
-            md.dst[i] = items[base + i].dst; md.accumulate[i] = items[base + i].accumulate ? 1 : 0;
-            bytes += 8.0 * N * ((level + 1) * (items[base + i].accumulate ? 3.0 : 2.0) + np);
-        }
         if (join_before_moddown >= 0) { join_side(join_before_moddown); join_before_moddown = -1; }
-        { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_batch(md, s_); }
+        ext_back(level, items.data() + base, n, c1);
     }
     if (join_before_moddown >= 0) join_side(join_before_moddown);
     MKHE_HIP(hipGetLastError());
@@ -695,9 +704,9 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
     const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
     const size_t PO = (size_t)L * N;
     u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
+    std::vector<ExtItem> items;
     // F1: t_i = <h(c0_i), y>_P -- the head of the long chain; E (needs x, which may still be accumulating on the side
     // stream) joins the last batch below
-    std::vector<ExtItem> items;
     for (int a = 0; a < n0; ++a) items.push_back(ExtItem{p.h0[a], y, tbuf + (size_t)a * PO, false});
     ext_batch(level, items);
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
