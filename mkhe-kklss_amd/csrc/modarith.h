@@ -70,6 +70,13 @@ __device__ __forceinline__ u64 mont_mul_lazy(u64 a, u64 w, u64 q, u32 ninv32) {
     return mad64(hi32(r2), one_b, mad64(hi32(s0), one_c, mad64(m2, q1, mad64(a1, w1, 0))));
 }
 
+// d = a * b + c as ONE v_mad_i64_i32 (the carry-out SGPR pair is unused)
+__device__ __forceinline__ i64 mad_i64(i32 a, i32 b, i64 c) {
+    i64 d;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+}
+
 // Signed word-serial Montgomery product for the NTT kernels: a*w*R^-1 mod q as a SIGNED representative r with
 // |r| <= q/2 + |a|*w/2^64 + 1.  a: any signed 64-bit value with |a| < 2^62; ws, qs: signed-split forms of w < q < 2^61.
 // With balanced 32-bit digits every partial sum fits a signed 64-bit accumulator, so each round is
@@ -86,6 +93,21 @@ __device__ __forceinline__ i64 mont_mul_sd(i64 a, u64 ws, u64 qs, u32 ninv32) {
     // the shift amount is opaque: knowing that S >> 32 is a sign-extended 32-bit value, the compiler splits the
     // 64-bit multiply-adds that consume it into 32-bit pieces (3x the instructions)
     u32 sh; asm("s_mov_b32 %0, 32" : "=s"(sh));
+#ifdef MKHE_ASM_MAD
+    // Experiment (tools/ubench/bfly_rate.hip -DMKHE_ASM_MAD): written in C the compiler starts the products that do not
+    // depend on S early with a zero addend and adds S >> 32 with a separate v_lshl_add_u64 afterwards (two extra
+    // multiplier-class instructions per product).  Spelling the chain out with inline asm takes the bare butterfly from 85 to
+    // 77 cycles, but in the 128-VGPR NTT kernels the asm operands raise the scratch from 76 to 132 B per lane and the kernel
+    // gets SLOWER (231 -> 243 us per launch): not enabled.
+    const i64 P0 = mad_i64(a0, w0, 0);
+    const i32 m = (i32)(lo32((u64)P0) * ninv32);
+    const i64 S = mad_i64(m, q0, P0);                    // |S| < 2^63 (q0 is odd, so |q0| < 2^31); low word is zero
+    const i64 Y = mad_i64(m, q1, mad_i64(a0, w1, S >> sh));
+    const i64 U = mad_i64(a1, w0, Y);
+    const i32 m2 = (i32)(lo32((u64)U) * ninv32);
+    const i64 S2 = mad_i64(m2, q0, U);
+    return mad_i64(m2, q1, mad_i64(a1, w1, S2 >> sh));
+#else
     const i64 P0 = (i64)a0 * w0;
     const i32 m = (i32)(lo32((u64)P0) * ninv32);
     const i64 S = (i64)m * q0 + P0;                      // |S| < 2^63 (q0 is odd, so |q0| < 2^31); low word is zero
@@ -94,6 +116,7 @@ __device__ __forceinline__ i64 mont_mul_sd(i64 a, u64 ws, u64 qs, u32 ninv32) {
     const i32 m2 = (i32)(lo32((u64)U) * ninv32);
     const i64 S2 = (i64)m2 * q0 + U;
     return (i64)m2 * q1 + ((i64)a1 * w1 + (S2 >> sh));
+#endif
 }
 // the same as an unsigned lazy representative in [0, 2q) (needs |a|*w < q*2^63, e.g. 0 <= a < 4q, q < 2^60)
 __device__ __forceinline__ u64 mont_mul_sdu(u64 a, u64 ws, u64 qs, u64 q, u32 ninv32) {
