@@ -106,7 +106,11 @@ __device__ __forceinline__ i64 mont_mul_sd(i64 a, u64 ws, u64 qs, u32 ninv32) {
     const i64 U = mad_i64(a1, w0, Y);
     const i32 m2 = (i32)(lo32((u64)U) * ninv32);
     const i64 S2 = mad_i64(m2, q0, U);
+#if MKHE_ASM_MAD >= 2
     return mad_i64(m2, q1, mad_i64(a1, w1, S2 >> sh));
+#else
+    return (i64)m2 * q1 + ((i64)a1 * w1 + (S2 >> sh));      // second round left to the compiler (fusing it too costs 48 B more scratch)
+#endif
 #else
     const i64 P0 = (i64)a0 * w0;
     const i32 m = (i32)(lo32((u64)P0) * ninv32);
