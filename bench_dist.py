@@ -23,6 +23,9 @@ def run_distributed(args):
     from mkhe_kklss_amd._abi import check, lib
     from mkhe_kklss_amd.dist import HipLimbBackend, HipShardBackend, LimbShardedMulRelin, ShardedMulRelin, assign_units
 
+    # a plain `python bench.py --force-dist` (no launcher): single-rank rendezvous on the loopback interface
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
