@@ -411,7 +411,9 @@ __global__ void __launch_bounds__(PW_THREADS) basis_conv_kernel(BasisConvArgs a)
 }
 void launch_basis_conv(const BasisConvArgs& a, hipStream_t st) {
     const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    int by = (a.nt + 3) / 4;                 // ~4 target limbs per thread: the y[] set-up is amortised
+    static int per = 0;                      // target limbs per thread: the y[] set-up (ns products + ns float64 divisions) is amortised over them
+    if (!per) { const char* e = getenv("MKHE_BC_PER"); per = (e && *e) ? atoi(e) : 7; }     // measured at PN15 (nt = 14): 7 -> 44.6 us per launch, 4 -> 54.8, 14 -> 54.2, 2 -> 68.7
+    int by = (a.nt + per - 1) / per;
     if (by < 1) by = 1;
     hipLaunchKernelGGL(basis_conv_kernel, dim3(bx, by, a.npolys), dim3(PW_THREADS), 0, st, a);
 }
