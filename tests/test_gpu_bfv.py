@@ -224,3 +224,22 @@ def test_rotate_on_bfv_context(bp):
     galEl = pow(5, 3, 2 * bp.N)
     ref = bp.bfv.ks.rotate(bp.nq - 1, galEl, [0, 1], h, rk_h, crs_h)
     assert (out.download() == ref).all()
+
+
+def test_forked_context_same_results(bp):
+    """a forked engine context (own stream and pools, shared keys / ciphertexts) evaluates MulRelinNew to the same bits"""
+    if bp.nq >= 14:
+        pytest.skip("covered on the small chains")
+    names = ["a", "b"]
+    h0, c0 = bp.ct(names)
+    h1, c1 = bp.ct(names)
+    rlk_h, rlk_d = bp.rlk_set(names)
+    u_h, u_d = bp.swk()
+    bp.params.CRS[-1] = u_d
+    ref = bp.ev.MulRelinNew(c0, c1, rlk_d).download()
+    fork = bp.mkb.NewEvaluator(bp.params.Fork())
+    fork.params.wait_for(bp.params)
+    got = fork.MulRelinNew(c0, c1, rlk_d)
+    bp.params.wait_for(fork.params)
+    assert (got.download() == ref).all()
+    fork.params.sync()
