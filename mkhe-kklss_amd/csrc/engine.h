@@ -26,7 +26,8 @@ struct Swk { u64* d = nullptr; bool owned = true; };
 // device ciphertext: uint64[1+n][limbs][N], slot 0 = c_0, slot 1+i = party ids[i]
 struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
 // one external product of a batch: dst (+)= ModDown_P( sum_i bg[i] (.) ah[i] )
-struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const u64* ah2 = nullptr; const u64* bg2 = nullptr; };
+struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const u64* ah2 = nullptr; const u64* bg2 = nullptr;
+                 const u64* addend = nullptr; /* accumulate onto this polynomial instead of onto dst (Rotate: c_0 of the input) */ };
 
 class Context {
   public:
@@ -61,6 +62,7 @@ class Context {
     void rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, Ct& out);
     void conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk& crs, Ct& out);
     void rotate_partial(const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, bool with_c0, Ct& out);
+    void rotate_core(const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, bool with_c0, Ct& out, u64 galEl);
     void automorphism(u64 galEl, const Ct& in, Ct& out);
     // ---- mkbfv (mkbfv/basis_extension.go, keyswitch.go, keyswitch_hoisted.go, evaluator.go); PolyR = [2nq][N]
     bool is_bfv() const { return nqm > 0; }
@@ -97,9 +99,9 @@ class Context {
     void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst, bool internal = false);
     // stage 0: whole external products; 1: front half only (inner products + inverse NTT into the c1 pool);
     // 2: back half only (ModDown of the c1 pool filled by the preceding stage-1 call with the same items)
-    void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0);
+    void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
     void ext_front(int level, const ExtItem* items, int n, u64* c1);          // inner products + lazy inverse NTT into c1 [n][mtot][N]
-    void ext_back(int level, const ExtItem* items, int n, const u64* c1);     // ModDown of c1 into / onto the destinations
+    void ext_back(int level, const ExtItem* items, int n, const u64* c1, u64 galEl = 0);     // ModDown of c1 into / onto the destinations [signed-permuted]
 
     // ---- limb-sharded multi-GPU evaluation (mkhe_kklss_amd/dist.py LimbShardedMulRelin): this context owns a subset of
     // the RNS moduli ("slots"); NTTs, inner products and ModDown outputs are computed for the owned slots only, all

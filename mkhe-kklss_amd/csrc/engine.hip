@@ -539,7 +539,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1) {
     { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, s_); }
 }
 // back half: ModDown of the items in c1 into (or onto) their destinations
-void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1) {
+void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 galEl) {
     if (n < 1) return;
     const size_t item_words = (size_t)mtot * N;
     ModDownBatchArgs md{};
@@ -549,12 +549,14 @@ void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1) {
     if (masked_) { md.qlist = d_ownq; md.nqlist = nq_owned(level); }
     double bytes = 0;
     for (int i = 0; i < n; ++i) {
-        md.dst[i] = it[i].dst; md.accumulate[i] = it[i].accumulate ? 1 : 0;
+        md.dst[i] = it[i].dst; md.accumulate[i] = it[i].accumulate ? 1 : 0; md.addend[i] = it[i].addend;
         bytes += 8.0 * N * ((level + 1) * (it[i].accumulate ? 3.0 : 2.0) + np);
     }
+    md.galEl = galEl; md.logN = logN;
     { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_batch(md, s_); }
 }
-void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown, int stage) {
+void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown, int stage, u64 galEl) {
+    if (galEl && items.size() > (size_t)EXT_MAX_ITEMS) throw Error("mkhe: too many external products for a fused rotation");
     if (stage != 0 && items.size() > (size_t)EXT_MAX_ITEMS) throw Error("mkhe: too many external products for a staged batch");
     check_level(level);
     const size_t item_words = (size_t)mtot * N;
@@ -564,7 +566,7 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
         if (stage != 2) ext_front(level, items.data() + base, n, c1);
         if (stage == 1) continue;
         if (join_before_moddown >= 0) { join_side(join_before_moddown); join_before_moddown = -1; }
-        ext_back(level, items.data() + base, n, c1);
+        ext_back(level, items.data() + base, n, c1, galEl);
     }
     if (join_before_moddown >= 0) join_side(join_before_moddown);
     MKHE_HIP(hipGetLastError());
@@ -818,6 +820,12 @@ void Context::fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_st
 // keyswitch.go:234-298, keyswitch_hoisted.go:183-247
 void Context::rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, Ct& out) {
     const int L = out.limbs, n = in.n;
+    if (n > 0 && 2 * n <= EXT_MAX_ITEMS && in.d != out.d) {
+        // the signed permutation and the + c_0 ride on the ModDown of the external products: no staging copy of the
+        // ciphertext, no separate permutation kernel
+        rotate_core(in, hoist, rk, crs, true, out, galEl);
+        return;
+    }
     Ct tmp; tmp.n = n; tmp.limbs = L; tmp.ids = in.ids;
     tmp.d = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * L * N);
     rotate_partial(in, hoist, rk, crs, true, tmp);
@@ -827,14 +835,21 @@ void Context::rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk
 // Rotate without the final permutation: out_0 = [c_0 +] sum_i <h(c_i), rk_i>_P, out_i = <h(c_i), crs>_P
 // (keyswitch.go:251-265).  with_c0 = false leaves c_0 out (party-sharded evaluation: one rank adds it).
 void Context::rotate_partial(const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, bool with_c0, Ct& out) {
+    rotate_core(in, hoist, rk, crs, with_c0, out, 0);
+}
+void Context::rotate_core(const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, bool with_c0, Ct& out, u64 galEl) {
     const int level = out.limbs - 1, L = level + 1, n = in.n;
     check_level(level);
     if (in.limbs < L) throw Error("Cannot Rotate: ctIn and ctOut have different levels");
     if (out.n != n || out.ids != in.ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
     const size_t PI = (size_t)in.limbs * N, PO = (size_t)L * N;
     u64* tmp = out.d;
-    if (with_c0) MKHE_HIP(hipMemcpyAsync(tmp, in.d, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
-    else MKHE_HIP(hipMemsetAsync(tmp, 0, PO * sizeof(u64), s_));
+    const bool fused = galEl != 0;          // c_0 enters as the addend of the first accumulating item, stores are permuted
+    if (fused && !with_c0) throw Error("mkhe: a fused rotation includes c_0");
+    if (!fused) {
+        if (with_c0) MKHE_HIP(hipMemcpyAsync(tmp, in.d, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+        else MKHE_HIP(hipMemsetAsync(tmp, 0, PO * sizeof(u64), s_));
+    }
     std::vector<const u64*> h(n);
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
@@ -848,9 +863,10 @@ void Context::rotate_partial(const Ct& in, const Swk* const* hoist, const Swk* c
     std::vector<ExtItem> items;
     for (int a = 0; a < n; ++a) {
         items.push_back(ExtItem{h[a], rk[a]->d, tmp, true});
+        if (fused && a == 0) items.back().addend = in.d;
         items.push_back(ExtItem{h[a], crs.d, tmp + (size_t)(1 + a) * PO, false});
     }
-    ext_batch(level, items);
+    ext_batch(level, items, -1, 0, galEl);
     MKHE_HIP(hipGetLastError());
 }
 

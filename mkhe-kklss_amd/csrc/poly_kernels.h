@@ -88,6 +88,13 @@ struct ModDownBatchArgs {
     unsigned char order[EXT_MAX_ITEMS];
     unsigned char gstart[EXT_MAX_ITEMS + 1];
     int ngroups;
+    // Rotate tail fused in (keyswitch.go:251-296): addend[b] != NULL: an accumulating item adds onto addend[b] (read at the
+    // un-permuted position, limb stride N) instead of onto its destination -- the c_0 of the input, no copy needed;
+    // galEl != 0: every store goes to the signed-permuted position X -> X^galEl (0 with a sign flip is written as q, like
+    // the reference's permutation loop), and later items of the group accumulate in that permuted image.
+    const u64* addend[EXT_MAX_ITEMS];
+    u64 galEl;
+    int logN;
 };
 void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st);
 

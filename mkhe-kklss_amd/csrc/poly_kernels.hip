@@ -186,8 +186,20 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
             const u64 lift = rhi - hhi + mq.q + a.t.vtimesqmodp[(long)j * (a.np + 1) + v];
             const u64 x = xq[(long)j * a.N + n];
             u64 z = mont_mul(lift + mq.q2 - x, a.t.downparam[j], mq.q, mq.ninv32);
-            if (acc) z = csub(dst[(long)j * a.N + n] + z, mq.q);
-            dst[(long)j * a.N + n] = z;
+            long pos = (long)j * a.N + n;
+            bool flip = false;
+            if (a.galEl) {
+                const u64 raw = (u64)n * a.galEl;
+                pos = (long)j * a.N + (long)(raw & (u64)(a.N - 1));
+                flip = ((raw >> a.logN) & 1) != 0;
+            }
+            if (acc) {
+                const u64* add = ka->addend[item];
+                if (add) z = csub(add[(long)j * a.N + n] + z, mq.q);
+                else if (flip) z = csub((mq.q - dst[pos]) + z, mq.q);       // the stored value is q - (sum so far), in (0, q]
+                else z = csub(dst[pos] + z, mq.q);
+            }
+            dst[pos] = flip ? mq.q - z : z;
         }
     }
 }
