@@ -318,8 +318,15 @@ def run_single(args):
             for n in names:
                 rks.AddRotationKey(mkrlwe.RotationKey(params, rot, n, synth_swk(pset, rng)))
         hh = ev.HoistedForm(ct0)
+        cks = mkrlwe.ConjugationKeySet()
+        for i, n in enumerate(names):
+            ck = mkrlwe.ConjugationKey(params, n)
+            check(lib().mkhe_crs_expand(params.ctx, args.seed, 3000 + i, ck.Value.h))      # uniform key material written on the device
+            cks.AddConjugationKey(ck)
+        params.AddCRS(-2, seed=args.seed)
         for fn, key in ((lambda: ev.RotateNew(ct0, rot, rks), "rotate_per_sec"),
-                        (lambda: ev.RotateHoistedNew(ct0, rot, hh, rks), "rotate_hoisted_per_sec")):
+                        (lambda: ev.RotateHoistedNew(ct0, rot, hh, rks), "rotate_hoisted_per_sec"),
+                        (lambda: ev.ConjugateNew(ct0, cks), "conjugate_per_sec")):
             for _ in range(3):
                 fn()
             params.sync()

@@ -889,13 +889,23 @@ void Context::conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk
     u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * PO);
     if (in.limbs == L) launch_automorphism(tmp, in.d, d_mods, L, logN, galEl, 1 + n, s_);
     else for (int a = 0; a <= n; ++a) launch_automorphism(tmp + a * PO, in.d + a * PI, d_mods, L, logN, galEl, 1, s_);
-    MKHE_HIP(hipMemcpyAsync(out.d, tmp, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+    if (n == 0) { MKHE_HIP(hipMemcpyAsync(out.d, tmp, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_)); return; }
+    // all parties in one Decompose launch and one batch of external products, like Rotate; sigma(c_0) enters as the addend
+    // of the first accumulating item (the permuted polynomials keep q for a sign-flipped 0, exactly what the reference
+    // decomposes)
+    std::vector<const u64*> dsrc; std::vector<u64*> ddst;
     for (int a = 0; a < n; ++a) {
         if (!ck[a]) throw Error("cannot GetConjugationKey: there is no conjugation key with given id");
-        decompose(level, false, tmp + (size_t)(1 + a) * PO, swk3_);
-        ext_core(level, swk3_, ck[a]->d, out.d, true);
-        ext_core(level, swk3_, crs.d, out.d + (size_t)(1 + a) * PO, false);
+        dsrc.push_back(tmp + (size_t)(1 + a) * PO); ddst.push_back(hoist_slot(0, a).d);
     }
+    decompose_batch(level, dsrc, ddst, true);
+    std::vector<ExtItem> items;
+    for (int a = 0; a < n; ++a) {
+        items.push_back(ExtItem{ddst[a], ck[a]->d, out.d, true});
+        if (a == 0) items.back().addend = tmp;
+        items.push_back(ExtItem{ddst[a], crs.d, out.d + (size_t)(1 + a) * PO, false});
+    }
+    ext_batch(level, items);
     MKHE_HIP(hipGetLastError());
 }
 
