@@ -72,6 +72,9 @@ class Parameters {
         return v;
     }
     void sync() { check(mkhe_ctx_sync(ctx)); }
+    // work issued through this context from now on starts after everything issued through `other` so far (another context
+    // over the same ring on the same device: own stream and scratch pools, all handles shared) -- mkhe_ctx_wait_for
+    void wait_for(const Parameters& other) { check(mkhe_ctx_wait_for(ctx, other.ctx)); }
 
     mkhe_ctx* ctx = nullptr;
     std::map<int, std::shared_ptr<SwitchingKey>> CRS;                                    // params.go:37-46
@@ -347,6 +350,25 @@ class Evaluator {
         *scaleOut = scale;
         return nb;
     }
+    // evaluator.go:96-114: keep the first Level()+1-levels limbs of every component
+    CiphertextPtr DropLevelNew(const Ciphertext& ct0, int levels) {
+        auto out = std::make_unique<Ciphertext>(params, ct0.IDSet_(), ct0.Level() - levels, ct0.Scale, false);
+        std::vector<uint64_t> one;
+        for (int i = 0; i <= out->Level(); ++i) one.push_back((uint64_t)((((unsigned __int128)1) << 64) % params.Q()[i]));     // MForm(1)
+        check(mkhe_ct_mul_const(params.ctx, ct0.h, one.data(), one.data(), out->h));
+        return out;
+    }
+    // evaluator.go:465-481: dev_pt = the plaintext polynomial uint64[Level()+1][N] resident on the device (mkhe_buf_*), pt_scale its scale
+    CiphertextPtr MulPtxtNew(const Ciphertext& ct, const void* dev_pt, double pt_scale) {
+        auto out = std::make_unique<Ciphertext>(params, ct.IDSet_(), ct.Level(), ct.Scale * pt_scale, false);
+        check(mkhe_ct_mul_ptxt(params.ctx, ct.h, dev_pt, out->h));
+        if (out->Level() == 0) return out;
+        double scale; const int nb = nbRescales(*out, params.Scale(), &scale);
+        if (nb == 0) return out;
+        auto res = std::make_unique<Ciphertext>(params, out->IDSet_(), out->Level() - nb, scale, false);
+        check(mkhe_rescale(params.ctx, out->h, nb, res->h));
+        return res;
+    }
     CiphertextPtr RescaleNew(const Ciphertext& ct0, double threshold) {                                                 // evaluator.go:359-414
         if (threshold <= 0) throw Error("cannot Rescale: minScale is 0");
         if (ct0.Scale == 0) throw Error("cannot Rescale: ciphertext scale is 0");
@@ -358,7 +380,9 @@ class Evaluator {
     }
     std::unique_ptr<mkrlwe::HoistedCiphertext> HoistedForm(const Ciphertext& ct) {                                      // evaluator.go:543-553
         auto h = std::make_unique<mkrlwe::HoistedCiphertext>();
-        for (auto& id : ct.ids) { h->Value[id] = mkrlwe::NewSwitchingKey(params); ksw.Decompose(ct.Level(), ct, id, *h->Value[id]); }
+        std::vector<mkhe_swk*> outs;
+        for (auto& id : ct.ids) { h->Value[id] = mkrlwe::NewSwitchingKey(params); outs.push_back(h->Value[id]->h); }
+        check(mkhe_hoisted_form(params.ctx, ct.Level(), ct.h, outs.data()));          // all party components in one batched launch
         return h;
     }
     CiphertextPtr MulRelinNew(const Ciphertext& op0, const Ciphertext& op1, mkrlwe::RelinearizationKeySet& rlkSet) {      // evaluator.go:416-443
