@@ -466,6 +466,7 @@ int mkhe_prof_enable(mkhe_ctx* ctx, int on) { MKHE_TRY(need(ctx)->prof_enable(on
 int mkhe_prof_nclass(void) { return Context::PROF_NCLASS; }
 const char* mkhe_prof_name(int cls) {
     static const char* names[] = {"ntt_fwd_kernel<N,1,true>  (Decompose, q<2^57)", "ntt_fwd_kernel<N,0,true>  (Decompose, q>=2^57)",
+                                  "ntt_fwd_kernel<N,2,true>  (Decompose, both modulus classes in one persistent launch)",
                                   "ntt_fwd_kernel<N,1,false>", "ntt_fwd_kernel<N,0,false>", "ntt_inv_kernel<N>",
                                   "inner_product_kernel", "ext_inner_kernel", "moddown[_batch]_kernel", "tensor_kernel", "basis_conv_kernel", "other"};
     return (cls >= 0 && cls < Context::PROF_NCLASS) ? names[cls] : "";

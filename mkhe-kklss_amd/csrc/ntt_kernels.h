@@ -60,6 +60,7 @@ struct NttBatch {
     int split;              // N = 2^16: the register-resident kernels transform the two halves of a limb as 2^15-point
                             // sub-transforms (twiddle rows of 2^16 words, root index 2 + half); the cross-half radix-2 stage
                             // runs as a separate streaming pass (launch_ntt_* do both)
+    unsigned long long small_slots;   // mixed forward launch (launch_ntt_fwd_mixed): bit s set = slot s is a small-modulus (MODE 1) limb
     int prestaged;          // forward, split launches only: the cross-half stage was already applied by the producer of src
                             // (decomp_spread_kernel with first_stage): only the sub-transforms run, in place on dst
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
@@ -76,6 +77,10 @@ struct NttBatch {
 // class (returns how many, small-modulus class first), launch_ntt_fwd_class launches one of them.
 int  split_ntt_fwd(const NttBatch& b, const unsigned char* small_q, NttBatch out[2]);
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st);
+// both modulus classes of `b` in ONE persistent launch (N = 2^15 Decompose launches that fill the chip several times over);
+// ntt_fwd_mixed_ok: false when the launch does not qualify (the caller then issues one launch per class)
+bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q);
+void launch_ntt_fwd_mixed(int logN, const NttBatch& b, const unsigned char* small_q, hipStream_t st);
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st);
 
 }  // namespace mkhe

@@ -236,35 +236,21 @@ __device__ __forceinline__ void job_pointers(const NttBatch& b, int job, gcptr& 
 // phases: 0 = index bits n-1..n-5 (layout A), 1 = bits MIDTOP..5 (layout B), 2 = bits 4..0 (layout C)
 // MODE 1: moduli with 34q < 2^63, no reduction inside; MODE 0: reduced every stage.
 // DEC: fused gadget digit spread of Decompose (input limb re-read under a foreign modulus).
-template <int LOGN, int MODE, bool DEC>
-__global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
-    using G = Geo<LOGN>;
-    extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
-    const int sub = G::LPB == 1 ? 0 : threadIdx.x / G::T, t = G::LPB == 1 ? threadIdx.x : threadIdx.x % G::T;
-    u32* lds = lds_all + sub * lds_words<LOGN>();
-    const int njobs = (b.nslots * b.nouter) << b.split;
-    // persistent workgroups: each one walks the job list with stride gridDim.x.  A wave that finishes its
-    // part of a limb starts loading the next limb at once; the only workgroup-wide rendezvous are the
-    // barriers around the cross-wave exchange.
-#pragma unroll 1
-    for (int jb = blockIdx.x * G::LPB; jb < njobs; jb += gridDim.x * G::LPB) {
-    int job = jb + sub;
-    const bool active = job < njobs;
-    if (!active) job = njobs - 1;            // keep every lane in the barriers; results discarded
-    if constexpr (G::LPB == 1) job = __builtin_amdgcn_readfirstlane(job);    // provably wave-uniform: modulus constants and pointers stay in SGPRs
-    // diagnostic timeline (mkhe_ntt_trace): 16 words per (job, wave): shader-clock stamps 0..9 at the phase
-    // boundaries, [12] / [13] = 100 MHz real time at start / end, [14] = HW_ID
-    // Only in the diagnostic build (make trace -> lib/libmkhe_hip_trace.so, -DMKHE_PHASE_TRACE): the stamps keep the
-    // job index and the trace pointer live across the whole body and double the spills of the 128-VGPR kernels.
 #ifdef MKHE_PHASE_TRACE
 #define MKHE_STAMP(k) do { if (b.trace && (threadIdx.x & 63) == 0 && active) b.trace[((long)job * 16 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MKHE_STAMP(k) do { } while (0)
+#endif
+// one limb (or half limb of a split launch): load, [digit reduction], three radix-32 phases, normalisation, store
+template <int LOGN, int MODE, bool DEC>
+__device__ __forceinline__ void ntt_fwd_job(const NttBatch& b, int job, bool active, u32* lds, int t) {
+    using G = Geo<LOGN>;
+#ifdef MKHE_PHASE_TRACE
     if (b.trace && (threadIdx.x & 63) == 0 && active) {
         u64* tw = b.trace + ((long)job * 16 + (threadIdx.x >> 6)) * 16;
         tw[12] = __builtin_amdgcn_s_memrealtime();
         tw[14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
     }
-#else
-#define MKHE_STAMP(k) do { } while (0)
 #endif
     MKHE_STAMP(0);
     gcptr src; gptr dst; int m, outer;
@@ -342,6 +328,32 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
 #ifdef MKHE_PHASE_TRACE
     if (b.trace && (threadIdx.x & 63) == 0 && active) b.trace[((long)job * 16 + (threadIdx.x >> 6)) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// MODE 2 (mixed launch): the modulus class is looked up per job (NttBatch::small_slots), so that the limbs of both classes
+// share ONE persistent grid -- launched as two kernels the big-modulus class only gets the CUs when the other class's
+// persistent workgroups exit, and then runs a ragged second round on a quarter of the chip.
+template <int LOGN, int MODE, bool DEC>
+__global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
+    using G = Geo<LOGN>;
+    extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
+    const int sub = G::LPB == 1 ? 0 : threadIdx.x / G::T, t = G::LPB == 1 ? threadIdx.x : threadIdx.x % G::T;
+    u32* lds = lds_all + sub * lds_words<LOGN>();
+    const int njobs = (b.nslots * b.nouter) << b.split;
+    // persistent workgroups: each one walks the job list with stride gridDim.x.  A wave that finishes its
+    // part of a limb starts loading the next limb at once; the only workgroup-wide rendezvous are the
+    // barriers around the cross-wave exchange.
+#pragma unroll 1
+    for (int jb = blockIdx.x * G::LPB; jb < njobs; jb += gridDim.x * G::LPB) {
+        int job = jb + sub;
+        const bool active = job < njobs;
+        if (!active) job = njobs - 1;            // keep every lane in the barriers; results discarded
+        if constexpr (G::LPB == 1) job = __builtin_amdgcn_readfirstlane(job);    // provably wave-uniform: modulus constants and pointers stay in SGPRs
+        if constexpr (MODE == 2) {
+            const int slot = (b.split ? (job >> 1) : job) / b.nouter;
+            if ((b.small_slots >> slot) & 1) ntt_fwd_job<LOGN, 1, DEC>(b, job, active, lds, t);
+            else ntt_fwd_job<LOGN, 0, DEC>(b, job, active, lds, t);
+        } else ntt_fwd_job<LOGN, MODE, DEC>(b, job, active, lds, t);
     }
 }
 
@@ -737,6 +749,21 @@ static int lds_depth(int logN, const NttBatch& b) {
         attr = true;
     }
     return logN - SM_LOGM;
+}
+bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MKHE_NTT_MIXED"); on = (e && *e) ? atoi(e) : 1; }
+    if (!on || logN != 15 || !b.reduce_in || b.split || b.nslots > 64 || b.nslots * b.nouter <= 512) return false;
+    int nsmall = 0;
+    for (int s = 0; s < b.nslots; ++s) if (small_q[b.mod[s]]) ++nsmall;
+    return nsmall != 0 && nsmall != b.nslots;               // a single class: the specialised kernel
+}
+void launch_ntt_fwd_mixed(int logN, const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
+    (void)logN;
+    NttBatch c = b;
+    c.small_slots = 0;
+    for (int s = 0; s < b.nslots; ++s) if (small_q[b.mod[s]]) c.small_slots |= 1ull << s;
+    launch_fwd_t<15, 2, true>(c, st);
 }
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;

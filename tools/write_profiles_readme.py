@@ -31,8 +31,10 @@ def st(name):
     return (0, 0)
 
 
-dom = tr["kernels"]["ntt_fwd_kernel<15,1,true>"]
 R = pl["roofline"]
+dom_key = R["kernel"].split()[0]                       # e.g. ntt_fwd_kernel<15,2,true>
+dom_prof = dom_key.replace(",", ", ")                   # spelling of the rocprofv3 kernel statistics
+dom = tr["kernels"][dom_key]
 txt = f'''# profiles/ — measured on MI355X (gfx950), round 1
 
 All files are distilled by `tools/collect_profiles.py` from `gpurun` runs of `tools/profile_round.sh` /
@@ -65,9 +67,12 @@ Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per 
 classes run as `ntt_pass4_fwd/inv_kernel` + `ntt_fwd/inv_lds_kernel` — the low-latency path of DESIGN.md §4 — which is what the
 rocprofv3 kernel statistics list under those names.)
 
-Dominant kernel `ntt_fwd_kernel<15,1,true>` (Decompose-fused forward NTT, 54-bit primes):
-HIP-event average {R["avg_launch_us"]:.1f} µs per launch, rocprofv3 kernel-trace average {st("ntt_fwd_kernel<15, 1, true>")[0]:.1f} µs
-({st("ntt_fwd_kernel<15, 1, true>")[1]} calls; the two launches per step have 1456 and 728 limbs);
+Dominant kernel `{dom_key}` (Decompose-fused forward NTT; template argument 2 = the 54-bit primes (reduction-free signed
+butterflies) and the 59/60-bit primes (Harvey butterflies) of a batch share ONE persistent launch, the class is looked up per limb;
+launched separately the big-prime class only got the CUs when the other class's workgroups exited and then ran a ragged
+second round: 0.664 → 0.600 ms per step for the two Decompose launches):
+HIP-event average {R["avg_launch_us"]:.1f} µs per launch, rocprofv3 kernel-trace average {st(dom_prof)[0]:.1f} µs
+({st(dom_prof)[1]} calls; the two launches per step have 1792 and 896 limbs);
 algorithmic bytes per launch {R["alg_bytes_per_launch"] / 1e6:.1f} MB (16·N B per limb-NTT) ⇒ **{R["achieved"]:.0f} GB/s = {R["frac"]:.3f} of the 8 TB/s HBM peak**;
 HBM traffic from the PMC passes {dom["hbm_bytes_per_launch"] / 1e6:.1f} MB per launch (FETCH_SIZE {dom["fetch_size_kb"] / 1e3:.1f} MB ×2 + WRITE_SIZE {dom["write_size_kb"] / 1e3:.1f} MB):
 {dom["hbm_bytes_per_launch"] / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  The excess is on the write side (WRITE_SIZE is ≈ 1.5× the limb bytes written): register
