@@ -761,8 +761,15 @@ bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q)
 void launch_ntt_fwd_mixed(int logN, const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
     (void)logN;
     NttBatch c = b;
-    c.small_slots = 0;
-    for (int s = 0; s < b.nslots; ++s) if (small_q[b.mod[s]]) c.small_slots |= 1ull << s;
+    // slots reordered: the big-modulus limbs (the longer jobs) first, so that a ragged last round holds the cheap kind
+    c.small_slots = 0; c.nslots = 0;
+    for (int cls = 0; cls < 2; ++cls)
+        for (int s = 0; s < b.nslots; ++s)
+            if ((small_q[b.mod[s]] != 0) == (cls == 1)) {
+                c.mod[c.nslots] = b.mod[s]; c.pos[c.nslots] = b.pos[s];
+                if (cls) c.small_slots |= 1ull << c.nslots;
+                ++c.nslots;
+            }
     launch_fwd_t<15, 2, true>(c, st);
 }
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
