@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of one MulRelin step from a rocprofv3 kernel trace (overlap on): start, duration, kernel, and the idle gaps.
   rocprofv3 --output-format csv --kernel-trace -d gpurun_out/tl -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-extras
-  python3 tools/step_timeline.py gpurun_out/tl"""
+  python3 tools/step_timeline.py gpurun_out/tl [marker-kernel (default tensor_kernel)]"""
 import csv
 import glob
 import sys
@@ -9,8 +9,9 @@ import sys
 f = glob.glob(sys.argv[1] + "/**/p_kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "mkhe" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "tensor_kernel" in r["Kernel_Name"]]
-print("tensor launches", len(idx))
+marker = sys.argv[2] if len(sys.argv) > 2 else "tensor_kernel"
+idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+print(marker, "launches", len(idx))
 a, b = idx[4], idx[5]
 seg = rows[a:b]
 t0 = int(seg[0]["Start_Timestamp"])
