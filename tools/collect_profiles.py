@@ -9,7 +9,7 @@ into the tracked profiles/ directory:
   profiles/<tag>_sq_counters.txt          SQ counter means per kernel (VALU/LDS/VMEM instructions, wait buckets)
   profiles/traffic.json                   HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes
 
-  python tools/collect_profiles.py r1e "PN15QP880 k=4"
+  python tools/collect_profiles.py r1f "PN15QP880 k=4"
 """
 import collections
 import csv

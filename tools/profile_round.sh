@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile set (run on the GPU box through gpurun): kernel-trace stats of bench.py with and without the
 # side-stream overlap, and the two HBM-traffic PMC passes (separate runs, kernel-trace only, as the guide prescribes).
-#   gpurun -- 'bash tools/profile_round.sh r1e'
+#   gpurun -- 'bash tools/profile_round.sh r1f'
 TAG=${1:-r1x}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG

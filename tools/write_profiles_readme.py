@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerates profiles/README.md from the distilled files of tools/collect_profiles.py:  python tools/write_profiles_readme.py r1e"""
+"""Regenerates profiles/README.md from the distilled files of tools/collect_profiles.py:  python tools/write_profiles_readme.py r1f"""
 import csv
 import json
 import os
@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles") + "/"
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1e"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1f"
 pl = json.load(open(P + tag + "_bench_plain.json"))
 no = json.load(open(P + tag + "_bench_noovl.json"))
 bf = json.load(open(P + tag + "_bench_bfv.json"))
