@@ -112,6 +112,25 @@ def load(name):
 
 
 pn, c2, c4, bp = load("bench_pn16"), load("bench_cnn2"), load("bench_cnn4"), load("bench_bfv_plain")
+sweep = P + tag + "_party_sweep.jsonl"
+if os.path.exists(sweep):
+    rows = [json.loads(l) for l in open(sweep) if l.strip()]
+    p14 = load("bench_pn14")
+    txt += f"""
+## Party count (the metric is "MulRelin/sec at n parties"): PN15QP880, one GPU
+
+`python3 bench.py --parties k --no-cpu --device-keys --steps 20 --warmup 3` for k = 1 ... 16 (`{tag}_party_sweep.jsonl`; key material written
+on the device, 2.7 GB of relinearization keys at k = 16).  The cost per MulRelin is linear in the number of parties, as the
+reference's construction promises (≈ 0.28 ms per party + 0.2 ms):
+
+| parties | MulRelin/s | ms per MulRelin | Rotate/s | RotateHoisted/s | Conjugate/s |
+|---|---|---|---|---|---|
+""" + "\n".join("| %d | %.0f | %.3f | %.0f | %.0f | %.0f |" % (r["config"]["parties"], r["value"], r["ms_per_step"], r["config"]["rotate_per_sec"],
+                                                              r["config"]["rotate_hoisted_per_sec"], r["config"]["conjugate_per_sec"]) for r in rows) + "\n"
+    if p14:
+        txt += f"""
+The reference's second parameter set, PN14QP439 (N = 2^14, 7 + 2 limbs), 4 parties: {p14["value"]:.0f} MulRelin/s ({p14["ms_per_step"]:.3f} ms), `{tag}_bench_pn14.json`.
+"""
 if bp:
     txt += f"""
 Without the profiler and with the side-stream overlap on: **{bp["value"]:.0f} MulRelin/s** ({bp["ms_per_step"]:.3f} ms), `{tag}_bench_bfv_plain.json`.
