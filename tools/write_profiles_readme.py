@@ -112,6 +112,10 @@ def load(name):
 
 
 pn, c2, c4, bp = load("bench_pn16"), load("bench_cnn2"), load("bench_cnn4"), load("bench_bfv_plain")
+if bp:
+    txt += f"""
+Without the profiler and with the side-stream overlap on: **{bp["value"]:.0f} MulRelin/s** ({bp["ms_per_step"]:.3f} ms), `{tag}_bench_bfv_plain.json`.
+"""
 sweep = P + tag + "_party_sweep.jsonl"
 if os.path.exists(sweep):
     rows = [json.loads(l) for l in open(sweep) if l.strip()]
@@ -130,10 +134,6 @@ reference's construction promises (≈ 0.28 ms per party + 0.2 ms):
     if p14:
         txt += f"""
 The reference's second parameter set, PN14QP439 (N = 2^14, 7 + 2 limbs), 4 parties: {p14["value"]:.0f} MulRelin/s ({p14["ms_per_step"]:.3f} ms), `{tag}_bench_pn14.json`.
-"""
-if bp:
-    txt += f"""
-Without the profiler and with the side-stream overlap on: **{bp["value"]:.0f} MulRelin/s** ({bp["ms_per_step"]:.3f} ms), `{tag}_bench_bfv_plain.json`.
 """
 if pn:
     e = pn["config"]
