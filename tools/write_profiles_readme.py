@@ -49,6 +49,7 @@ All files are distilled by `tools/collect_profiles.py` from `gpurun` runs of `to
 | `{tag}_kernel_stats_bfv.csv`, `{tag}_bench_bfv.json` | `MKHE_NO_OVERLAP=1 rocprofv3 ... -- python3 bench.py --scheme bfv --steps 10 --warmup 2 --no-cpu` |
 | `traffic.json` | two passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (+ `--kernel-trace`) of `bench.py --steps 6 --warmup 2 --no-cpu`, `tools/traffic_from_pmc.py` |
 | `{tag}_sq_counters.txt` | three passes of 8 SQ counters each (`tools/profile_sq.sh`) |
+| `{tag}_step_timeline.txt` | `tools/step_timeline.py` over a `rocprofv3 --kernel-trace` of `bench.py --steps 6 --warmup 2 --no-cpu --no-extras` (overlap on): start, duration and stream interleaving of every kernel of one MulRelin; the GPU is busy 99 % of the step, i.e. the step is the sum of its dependent kernels |
 | `{tag}_ubench.txt` | output of `tools/ubench/valu_rate`, `imul_rate`, `bfly_rate` on the same chip: instruction issue rates per class and the register-resident butterfly floor (85 cycles per wave-butterfly ⇒ 38–45 µs per 2^15-point limb and CU before any load, store, exchange or twiddle traffic) |
 
 ## Headline (BASELINE.json configs[1]): mkckks 4-party MulRelin, PN15QP880, N = 2^15, 14 Q + 2 P limbs
