@@ -262,6 +262,11 @@ void ora_decompose_and_split(const ora_ks* ks, int levelQ, int levelP, int alpha
     }
 }
 
+/* limb-level parallelism for the multi-thread CPU baseline figure of bench.py (the reference is a single goroutine: the
+ * default is 1 thread; every limb loop is independent, results are identical for any thread count) */
+int ora_threads = 1;
+void ora_set_threads(int n) { ora_threads = n < 1 ? 1 : n; }
+
 #define SWK_Q(ks, swk, i) ((swk) + (size_t)(i) * (size_t)((ks)->nq + (ks)->np) * (size_t)(ks)->N)
 #define SWK_P(ks, swk, i) (SWK_Q(ks, swk, i) + (size_t)(ks)->nq * (size_t)(ks)->N)
 
@@ -270,7 +275,9 @@ static void decompose_single_ntt(const ora_ks* ks, int levelQ, int levelP, int d
                                  const uint64_t* a_invntt, uint64_t* cq, uint64_t* cp) {
     const size_t N = (size_t)ks->N;
     ora_decompose_and_split(ks, levelQ, levelP, ks->alpha, digit, ks->gamma, a_invntt, cq, cp);
+#pragma omp parallel for schedule(static) if (ora_threads > 1) num_threads(ora_threads)
     for (int j = 0; j <= levelQ; ++j) ora_ntt(ks->rq, j, cq + (size_t)j * N, cq + (size_t)j * N);
+#pragma omp parallel for schedule(static) if (ora_threads > 1) num_threads(ora_threads)
     for (int j = 0; j <= levelP; ++j) ora_ntt(ks->rp, j, cp + (size_t)j * N, cp + (size_t)j * N);
 }
 
@@ -289,6 +296,7 @@ void ora_decompose(ora_ks* ks, int levelQ, int is_ntt, const uint64_t* a, uint64
 
 static void qp_mul(const ora_ks* ks, int levelQ, int levelP, const uint64_t* a, const uint64_t* b, uint64_t* z, int add) {
     const size_t N = (size_t)ks->N, po = (size_t)ks->nq * N;
+#pragma omp parallel for schedule(static) if (ora_threads > 1) num_threads(ora_threads)
     for (int j = 0; j <= levelQ; ++j) {
         if (add) ora_limb_mul_add(ks->rq, j, a + j * N, b + j * N, z + j * N);
         else     ora_limb_mul(ks->rq, j, a + j * N, b + j * N, z + j * N);
@@ -300,12 +308,14 @@ static void qp_mul(const ora_ks* ks, int levelQ, int levelP, const uint64_t* a, 
 }
 static void qp_mform(const ora_ks* ks, int levelQ, int levelP, uint64_t* a) {
     const size_t N = (size_t)ks->N, po = (size_t)ks->nq * N;
+#pragma omp parallel for schedule(static) if (ora_threads > 1) num_threads(ora_threads)
     for (int j = 0; j <= levelQ; ++j) ora_limb_mform(ks->rq, j, a + j * N, a + j * N);
     for (int j = 0; j <= levelP; ++j) ora_limb_mform(ks->rp, j, a + po + j * N, a + po + j * N);
 }
 /* InvNTTLazy on Q and P halves, then ks.Baseconverter.ModDownQPtoQ (keyswitch.go:114-117) */
 static void invntt_moddown(ora_ks* ks, int levelQ, int levelP, uint64_t* c1qp, uint64_t* c) {
     const size_t N = (size_t)ks->N, po = (size_t)ks->nq * N;
+#pragma omp parallel for schedule(static) if (ora_threads > 1) num_threads(ora_threads)
     for (int j = 0; j <= levelQ; ++j) ora_intt_lazy(ks->rq, j, c1qp + j * N, c1qp + j * N);
     for (int j = 0; j <= levelP; ++j) ora_intt_lazy(ks->rp, j, c1qp + po + j * N, c1qp + po + j * N);
     ora_fbe_moddown_ab2a(ks->conv, levelQ, levelP, c1qp, c1qp + po, c);

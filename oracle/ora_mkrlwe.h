@@ -59,6 +59,7 @@ typedef struct ora_ks {
     uint64_t *swk1, *swk2, *swk3;      /* ks.swkPool1..3                       */
 } ora_ks;
 
+void ora_set_threads(int n);          /* limb-level OpenMP threads of the hot loops (default 1, like the single-goroutine reference) */
 ora_ks* ora_ks_new(int logN, const uint64_t* Q, int nq, const uint64_t* P, int np, int gamma,
                    const uint64_t* psiQ_or_null, const uint64_t* psiP_or_null);
 void ora_ks_free(ora_ks* ks);

@@ -127,8 +127,14 @@ def lib():
         L.ora_bfv_gen_switching_key.argtypes = [C.c_void_p, u64p, u64p, s32p, u64p]
         L.ora_bfv_gen_relin_key.argtypes = [C.c_void_p, u64p, u64p, u64p, u64p, s32p, u64p, u64p, u64p,
                                             u64p, u64p, u64p, u64p, u64p]
+        L.ora_set_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """limb-level OpenMP threads of the oracle's hot loops (1 = the single-goroutine reference)"""
+    lib().ora_set_threads(int(n))
 
 
 def _p(a):
