@@ -382,7 +382,7 @@ def run_single(args):
         same = bool((res.download() == ref).all())
         # the same oracle with its limb loops (NTTs, products, MForm) spread over the host cores with OpenMP: a fairer ceiling than
         # the single goroutine of the reference; identical results
-        nth = os.cpu_count() or 1
+        nth = min(os.cpu_count() or 1, len(pset["Q"]) + len(pset["P"]))      # one thread per limb at most (the loops have 14..16 iterations)
         O.set_threads(nth)
         ks.mul_and_relin(level, ids, data["op0"], ids, data["op1"], rl, data["u"])          # thread pool warm-up
         t0 = time.perf_counter()
