@@ -1,0 +1,60 @@
+"""Determinism under load (-m gpu): the same little circuit -- MulRelinNew, RotateNew, AddNew, ConjugateNew on resident
+ciphertexts, side-stream overlap on, a forked context doing the same concurrently -- evaluated a few hundred times must give
+the first iteration's bits every time.  Guards the stream-ordered buffer pools, the side-stream fork / join logic and the
+cross-context ordering against races (every kernel is deterministic, so any difference is an ordering bug)."""
+import numpy as np
+import pytest
+
+import harness as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("pname", ["N13_q6", "N15_q4"])
+def test_repeated_circuit_is_deterministic(pname):
+    from mkhe_kklss_amd import mkckks, mkrlwe
+    from mkhe_kklss_amd._abi import check, lib
+    pset = {"N13_q6": H.small_ckks(13, 6), "N15_q4": H.small_ckks(15, 4)}[pname]
+    params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"])
+    names = ["a", "b", "c"]
+    level = len(pset["Q"]) - 1
+    rng = np.random.default_rng(3)
+    N = 1 << pset["logN"]
+    host = lambda: np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in pset["Q"]]) for _ in range(1 + len(names))])
+    ct0 = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(host())
+    ct1 = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(host())
+    rlk, rks, cks = mkrlwe.RelinearizationKeySet(params), mkrlwe.RotationKeySet(), mkrlwe.ConjugationKeySet()
+    seed = 99
+    for i, n in enumerate(names):                      # uniform key material written on the device
+        key = mkrlwe.RelinearizationKey(params, n)
+        for j in range(3):
+            check(lib().mkhe_crs_expand(params.ctx, seed, 100 + 3 * i + j, key.Value[j].h))
+        rlk.AddRelinearizationKey(key)
+        rk = mkrlwe.RotationKey(params, 1, n)
+        check(lib().mkhe_crs_expand(params.ctx, seed, 200 + i, rk.Value.h))
+        rks.AddRotationKey(rk)
+        ck = mkrlwe.ConjugationKey(params, n)
+        check(lib().mkhe_crs_expand(params.ctx, seed, 300 + i, ck.Value.h))
+        cks.AddConjugationKey(ck)
+    for idx in (-1, 1, -2):
+        params.AddCRS(idx, seed=seed)
+    ev = mkckks.NewEvaluator(params)
+    fork = ev.Fork()
+
+    def circuit(e):
+        r = e.MulRelinNew(ct0, ct1, rlk)
+        s = e.AddNew(e.RotateNew(r, 1, rks), r)
+        return e.AddNew(e.ConjugateNew(s, cks), s)
+
+    ref = circuit(ev).download()
+    iters = 150 if pset["logN"] <= 13 else 40
+    for it in range(iters):
+        fork.params.wait_for(params)
+        a = circuit(ev)
+        b = circuit(fork)
+        params.wait_for(fork.params)
+        if it % 10 == 9 or it == iters - 1:
+            assert (a.download() == ref).all(), "main context, iteration %d" % it
+            assert (b.download() == ref).all(), "forked context, iteration %d" % it
+    params.sync()
+    fork.params.sync()
