@@ -129,7 +129,41 @@ def bfv_conv_1024():
     print("wrote bfv_conv_n1024")
 
 
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al., SC'11) in plain Python integers, independent of the C oracle"""
+    c, k = list(ctr), list(key)
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+        k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+    return c
+
+
+def crs_case():
+    """CRS expansion (include/mkhe.h mkhe_crs_expand): uniform sample by mask-and-reject over the Philox words, then MForm"""
+    logN, Qs, Ps, seed, idx = 4, H.PN15QP880["Q"][:3], H.PN15QP880["P"][:1], 0x4D4B4845, -1
+    N, mods = 1 << logN, Qs + Ps
+    beta, m = len(Qs), len(mods)
+    out = np.zeros((beta, m, N), dtype=np.uint64)
+    for d in range(beta):
+        for j, q in enumerate(mods):
+            mask = (1 << q.bit_length()) - 1
+            for w in range(N):
+                block = 0
+                while True:
+                    o = philox4x32_10([w, d * m + j, idx & 0xffffffff, block], [seed & 0xffffffff, seed >> 32])
+                    c = [((o[1] << 32) | o[0]) & mask, ((o[3] << 32) | o[2]) & mask]
+                    hit = [x for x in c if x < q]
+                    if hit:
+                        out[d, j, w] = (hit[0] << 64) % q          # MForm
+                        break
+                    block += 1
+    np.savez_compressed(os.path.join(OUT, "crs_n16.npz"), logN=logN, Q=u64(Qs), P=u64(Ps), seed=np.uint64(seed), idx=np.int64(idx), crs=out)
+    print("wrote crs_n16")
+
+
 if __name__ == "__main__":
+    crs_case()
     bfv_case()
     bfv_conv_1024()
     small_case("alpha1_n16", 4, H.PN15QP880["Q"][:3], H.PN15QP880["P"], 11)

@@ -103,3 +103,10 @@ def test_gpu_bfv_conversions_golden():
     out = mkrlwe.DeviceLimbs(params, 1, nq)
     conv.Quantize(rn, out, params.T())
     assert (out.download()[0] == c["quantize_out"]).all()
+
+
+def test_crs_expansion_golden():
+    """the CRS stream definition (Philox4x32-10 words, mask-and-reject, MForm) pinned by a fixture computed in plain Python integers"""
+    g = load("crs_n16")
+    ks = O.KeySwitcher(int(g["logN"]), [int(q) for q in g["Q"]], [int(p) for p in g["P"]], 1)
+    assert (O.KeyGen(ks).crs_expand(int(g["seed"]), int(g["idx"])) == g["crs"]).all()
