@@ -1,0 +1,167 @@
+"""Headline configurations under -m gpu: BASELINE.json configs[1] and configs[2] at FULL size, device vs oracle bit for bit.
+
+* configs[1]: mkckks PN15QP880 (N = 2^15, 14 Q + 2 P primes), 4 parties: MulRelinNew = hoisting of both operands +
+  MulAndRelinHoisted + Rescale -- the timed region of mkckks/mkckks_benchmark_test.go:57-84;
+* the Decompose-fused forward NTT of that ring at every launch size class of csrc/ntt_kernels.hip (1792, 896, 672, 448
+  and 224 limbs, and a lower level), so that the mixed-class persistent launch, the per-class kernels and the
+  split / low-latency paths are each compared with the oracle (mkrlwe/keyswitch.go:49-73);
+* RotateHoisted with 4 parties at PN15QP880 (mkrlwe/keyswitch_hoisted.go:183-247);
+* configs[2]: mkbfv PN15QP880 (14 Q + 14 QMul + 2 P primes), MulRelinNew with 2 and 4 parties
+  (mkbfv/mkbfv_bench_test.go:10-64);
+* configs[3] ring: PN16QP1761 with 8 parties, one hoisted Rotate (mkrlwe/mkrlwe_test.go:22-35).
+"""
+import numpy as np
+import pytest
+
+import harness as H
+from gpu_common import Pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _swk(pset, rng, beta=None):
+    """uniform residues, switching-key shaped uint64[beta][nQ+nP][N]"""
+    Q, P, N = pset["Q"], pset["P"], 1 << pset["logN"]
+    beta = len(Q) if beta is None else beta
+    out = np.empty((beta, len(Q) + len(P), N), dtype=np.uint64)
+    for j, q in enumerate(Q + P):
+        out[:, j] = rng.integers(0, q, (beta, N), dtype=np.uint64)
+    return out
+
+
+def _ct(pset, rng, n, limbs):
+    N = 1 << pset["logN"]
+    out = np.empty((1 + n, limbs, N), dtype=np.uint64)
+    for l in range(limbs):
+        out[:, l] = rng.integers(0, pset["Q"][l], (1 + n, N), dtype=np.uint64)
+    return out
+
+
+@pytest.fixture(scope="module")
+def pn15():
+    from oracle import oracle as O
+    from mkhe_kklss_amd import mkckks
+    p = H.PN15QP880
+    ks = O.KeySwitcher(p["logN"], p["Q"], p["P"], 2)
+    params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"], device=0)
+    return dict(pset=p, ks=ks, params=params, mk=mkckks, rng=np.random.default_rng(0x15880))
+
+
+def test_pn15_four_party_mulrelin_new(pn15):
+    """BASELINE.json configs[1]: the benchmark's timed region (hoist + MulAndRelinHoisted + Rescale), k = 4."""
+    from mkhe_kklss_amd import mkrlwe
+    p, ks, params, mk, rng = (pn15[k] for k in ("pset", "ks", "params", "mk", "rng"))
+    k = 4
+    names = ["user%d" % i for i in range(k)]
+    level = len(p["Q"]) - 1
+    h0, h1 = _ct(p, rng, k, level + 1), _ct(p, rng, k, level + 1)
+    rlk_h, rlk = {}, mkrlwe.RelinearizationKeySet(params)
+    for i, n in enumerate(names):
+        rlk_h[i] = tuple(_swk(p, rng) for _ in range(3))
+        rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, n, *rlk_h[i]))
+    u = _swk(p, rng)
+    params.AddCRS(-1, u)
+    ct0 = mk.NewCiphertext(params, names, level, p["scale"]).upload(h0)
+    ct1 = mk.NewCiphertext(params, names, level, p["scale"]).upload(h1)
+    ev = mk.NewEvaluator(params)
+    res = ev.MulRelinNew(ct0, ct1, rlk)
+    ids = list(range(k))
+    _, ref = ks.mul_and_relin(level, ids, h0, ids, h1, rlk_h, u)
+    nb, _ = ks.ckks_nb_rescales(level, p["scale"] * p["scale"], p["scale"])
+    assert nb == 1 and res.Level() == level - 1
+    ref = np.stack([ks.ringQ.div_round_last_many(ref[s], nb)[0] for s in range(1 + k)])
+    got = res.download()
+    assert got.shape == ref.shape and (got == ref).all()
+    # the hoisted entry point on precomputed hoisted forms gives the same ciphertext
+    res2 = ev.MulRelinHoistedNew(ct0, ct1, ev.HoistedForm(ct0), ev.HoistedForm(ct1), rlk)
+    assert (res2.download() == ref).all()
+    # and a second evaluation through the same (now warm) pools is identical: no stale scratch
+    assert (ev.MulRelinNew(ct0, ct1, rlk).download() == ref).all()
+
+
+@pytest.mark.parametrize("parties,drop", [(8, 0), (4, 0), (3, 0), (2, 0), (1, 0), (3, 2), (5, 1)])
+def test_pn15_hoisted_form_launch_classes(pn15, parties, drop):
+    """HoistedForm of n components = ONE Decompose launch of n * beta * (level + 1 + nP) limbs:
+    1792 / 896 / 672 (mixed-class persistent kernel), 448 / 224 (one kernel per modulus class), and lower levels
+    (3 * 12 * 14 = 504 limbs just under, 5 * 13 * 15 = 975 over the threshold)."""
+    p, ks, params, mk, rng = (pn15[k] for k in ("pset", "ks", "params", "mk", "rng"))
+    level = len(p["Q"]) - 1 - drop
+    names = ["p%d" % i for i in range(parties)]
+    h = _ct(p, rng, parties, level + 1)
+    ct = mk.NewCiphertext(params, names, level, p["scale"]).upload(h)
+    hoisted = mk.NewEvaluator(params).HoistedForm(ct)
+    beta = ks.beta(level)
+    act = list(range(level + 1)) + [len(p["Q"]) + j for j in range(len(p["P"]))]
+    for i, n in enumerate(names):
+        ref = ks.decompose(level, h[1 + i])
+        got = hoisted.Value[n].download()
+        assert (got[:beta][:, act] == ref[:beta][:, act]).all(), "party %d" % i
+
+
+def test_pn15_rotate_hoisted_four_parties(pn15):
+    from mkhe_kklss_amd import mkrlwe
+    p, ks, params, mk, rng = (pn15[k] for k in ("pset", "ks", "params", "mk", "rng"))
+    k, rot = 4, 3
+    names = ["r%d" % i for i in range(k)]
+    level = len(p["Q"]) - 1
+    h = _ct(p, rng, k, level + 1)
+    ct = mk.NewCiphertext(params, names, level, p["scale"]).upload(h)
+    crs = _swk(p, rng)
+    params.AddCRS(rot, crs)
+    keys = [_swk(p, rng) for _ in range(k)]
+    rks = mkrlwe.RotationKeySet()
+    for n, key in zip(names, keys):
+        rks.AddRotationKey(mkrlwe.RotationKey(params, rot, n, key))
+    ev = mk.NewEvaluator(params)
+    ref = ks.rotate(level, pow(5, rot, 2 << p["logN"]), list(range(k)), h, keys, crs)
+    assert (ev.RotateHoistedNew(ct, rot, ev.HoistedForm(ct), rks).download() == ref).all()
+    assert (ev.RotateNew(ct, rot, rks).download() == ref).all()
+
+
+@pytest.mark.parametrize("parties", [2, 4])
+def test_bfv_pn15_mulrelin_new(parties):
+    """BASELINE.json configs[2]: mkbfv MulRelinNew (ModUpQtoR + Rescale + DecomposeBFV + MulAndRelinBFVHoisted + Quantize)."""
+    import harness_bfv as HB
+    from mkhe_kklss_amd import mkbfv
+    pset = HB.BFV_PN15QP880
+    names = ["user%d" % i for i in range(parties)]
+    data = HB.uniform_bfv_inputs(pset, parties, 0xBF15 + parties)
+    params = mkbfv.Parameters(pset["logN"], pset["Q"], pset["QMul"], pset["P"], pset["T"], device=0)
+    ct0 = mkbfv.NewCiphertext(params, names).upload(data["op0"])
+    ct1 = mkbfv.NewCiphertext(params, names).upload(data["op1"])
+    rlk = mkbfv.NewRelinearizationKeyKeySet(params)
+    for i, n in enumerate(names):
+        rlk.AddRelinearizationKey(mkbfv.RelinearizationKey(params, n, *data["rlk"][i]))
+    params.AddCRS(-1, data["u"])
+    res = mkbfv.NewEvaluator(params).MulRelinNew(ct0, ct1, rlk)
+    ids = list(range(parties))
+    _, ref = HB.make_bfv(pset).mul_relin_new(ids, data["op0"], ids, data["op1"], data["rlk"], data["u"])
+    got = res.download()
+    assert got.shape == ref.shape and (got == ref).all()
+    params.close()
+
+
+def test_pn16_rotate_hoisted_eight_parties():
+    """BASELINE.json configs[3] ring at its party count: PN16QP1761 (N = 2^16, alpha = 2, beta = 17), 8 parties."""
+    pair = Pair(H.PN16QP1761, seed=168)
+    mk, p, rng = pair.mk, H.PN16QP1761, pair.rng
+    k, rot = 8, 5
+    names = ["u%d" % i for i in range(k)]
+    level = pair.maxlevel
+    h = _ct(p, rng, k, level + 1)
+    ct = mk.NewCiphertext(pair.params, names, level).upload(h)
+    beta = pair.ks.beta_max
+    crs = _swk(p, rng, beta)
+    pair.params.AddCRS(rot, crs)
+    keys = [_swk(p, rng, beta) for _ in range(k)]
+    rks = mk.RotationKeySet()
+    for n, key in zip(names, keys):
+        rks.AddRotationKey(mk.RotationKey(pair.params, rot, n, key))
+    hh = mk.NewHoistedCiphertext()
+    for n in names:
+        hh.Value[n] = mk.NewSwitchingKey(pair.params)
+        pair.ksw.Decompose(level, ct, n, hh.Value[n])
+    out = mk.NewCiphertext(pair.params, names, level)
+    pair.ksw.RotateHoisted(ct, rot, hh, rks, out)
+    ref = pair.ks.rotate(level, pow(5, rot, 2 * pair.N), list(range(k)), h, keys, crs)
+    assert (out.download() == ref).all()
