@@ -467,6 +467,7 @@ int mkhe_prof_nclass(void) { return Context::PROF_NCLASS; }
 const char* mkhe_prof_name(int cls) {
     static const char* names[] = {"ntt_fwd_kernel<N,1,true>  (Decompose, q<2^57)", "ntt_fwd_kernel<N,0,true>  (Decompose, q>=2^57)",
                                   "ntt_fwd_kernel<N,2,true>  (Decompose, both modulus classes in one persistent launch)",
+                                  "ntt16_fwd_kernel<true>  (Decompose, 16 coefficients per thread, two workgroups per CU)", "ntt16_fwd_kernel<false>",
                                   "ntt_fwd_kernel<N,1,false>", "ntt_fwd_kernel<N,0,false>", "ntt_inv_kernel<N>",
                                   "inner_product_kernel", "ext_inner_kernel", "moddown[_batch]_kernel", "tensor_kernel", "basis_conv_kernel", "other"};
     return (cls >= 0 && cls < Context::PROF_NCLASS) ? names[cls] : "";

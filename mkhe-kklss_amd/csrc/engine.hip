@@ -380,6 +380,12 @@ void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
 
 // forward NTT launch: one kernel per modulus class, each with its own timing record
 void Context::ntt_fwd_launch(const NttBatch& b, bool decompose) {
+    if (ntt16_ok(logN, b)) {
+        ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
+        NttBatch bt = b; bt.trace = ntt_trace;
+        launch_ntt16_fwd(bt, small_q_.data(), s_);
+        return;
+    }
     if (decompose && ntt_fwd_mixed_ok(logN, b, small_q_.data())) {
         // large Decompose launches: both modulus classes in one persistent grid (no ragged tail of the big-modulus class)
         ProfScope ps(this, PROF_NTT_DECOMP_MIXED, 16.0 * N * b.nouter * b.nslots);

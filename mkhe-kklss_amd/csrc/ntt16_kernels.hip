@@ -1,0 +1,506 @@
+// ntt16_kernels.hip -- forward negacyclic NTT, N = 2^15, for the large Decompose launches of a MulRelin ("H16" form).
+//
+// Why a second forward kernel: the register-resident kernel of ntt_kernels.hip
+// holds a whole limb in ONE workgroup per CU (1024 threads x 32 coefficients x 128 VGPRs).  Its three resources --
+// VALU (butterflies), LDS (re-distribution) and the memory pipe (loads / stores) -- are then used one after the
+// other, because the 16 waves of the only resident workgroup move through the same phases together: 36 us + 9 us +
+// 10 us per limb and CU = the 55 us that kernel measures.  Here a thread holds 16 coefficients (64 VGPRs), so TWO
+// workgroups are resident per CU (8 waves per SIMD) and one workgroup's LDS / memory phases run under the other
+// one's butterflies.
+//
+// A limb is transformed in two passes by the same workgroup (1024 threads):
+//   pass 0: load x[j], x[j + N/2]; stage 0 (the cross-half butterflies, twiddle psi[1]); the lower outputs stay in
+//           registers, the upper outputs are parked in the upper half of the destination limb (same thread reloads
+//           them in pass 1); then the 14 remaining stages of the lower half;
+//   pass 1: reload the parked half, the same 14 stages.
+// The 14 stages of a half (2^14 points, index bits 13..0) run as four register phases with LDS re-distributions:
+//   A: bits 13..10 in registers, thread = bits 9..0          twiddles uniform per workgroup  (scalar loads)
+//   B: bits  9..6,  wave = bits 13..10, lane = bits 5..0      twiddles uniform per wave       (scalar loads)
+//   C: bits  5..2,  lane = (bits 9..6, bits 1..0)             twiddles per lane (vector loads, 16-B)
+//   D: bits  1..0 (registers hold bits 3..0), lane = (bits 9..6, bits 5..4)
+//   E: store layout: registers = bits 9..6, lane = bits 5..0 (512 B contiguous per store instruction)
+// Only A -> B crosses waves (4 workgroup barriers per pass); B -> C, C -> D, D -> E stay inside a wave's own 1024
+// coefficients and need no barrier at all.  LDS image: one 32-bit plane of the half at a time (68 KiB per workgroup,
+// 136 KiB per CU), every layout addressed as base(thread) + immediate(register), conflict-free under the 32-bank rule
+// of ds_read_b32 / ds_write_b32 (padding constants below).
+//
+// Arithmetic and values are those of ntt_kernels.hip (mont_mul_sd: signed-digit Montgomery product; MODE 1 signed
+// never-reduced butterflies for moduli with 31q < 2^62, MODE 0 Harvey butterflies; same DEC digit reduction, same
+// skip_norm / canonical outputs), so the two kernels are interchangeable bit for bit on canonical outputs.
+//
+// Replaces: lattigo ring.NTTLvl as called from DecomposeSingleNTT (mkrlwe/keyswitch.go:21-31,49-73).
+#include "ntt_kernels.h"
+#include <cstdlib>
+
+namespace mkhe {
+namespace h16 {
+
+typedef const __attribute__((address_space(1))) u64* gcptr;
+typedef __attribute__((address_space(1))) u64* gptr;
+typedef const __attribute__((address_space(4))) u64* scptr;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) u64x2* gcptr2;
+typedef const __attribute__((address_space(4))) NttBatch* kargptr;
+typedef const __attribute__((address_space(4))) Mod* smodptr;
+
+constexpr int NN = 1 << 15, HH = 1 << 14, NT = 1024;
+constexpr int WSTR = 1088;                 // LDS words per wave region (1024 + padding of the wave-local layouts)
+constexpr int LDS_WORDS = 16 * WSTR;
+
+// Uniform (SGPR) base + 32-bit per-lane index: the `saddr` form of global_load / global_store.  The base is made opaque per access so
+// that the compiler neither folds it into 64-bit per-lane addresses nor hoists 16 of those out of the pass loop (spills).
+template <class P> __device__ __forceinline__ P sbase(P p) { asm volatile("" : "+s"(p)); return p; }
+
+// two consecutive twiddles in one 16-byte load
+__device__ __forceinline__ void ld2(u64* out, gcptr2 base, unsigned idx) {
+    // the byte offset is formed in 32 bits, so that base + zext(offset) selects the SGPR-base addressing form
+    const u64x2 v = *(gcptr2)((const __attribute__((address_space(1))) char*)base + (unsigned)(idx * 16u));
+    out[0] = v.x; out[1] = v.y;
+}
+
+// per-job constants, wave-uniform (SGPRs)
+struct MC { i32 q0, q1; u32 ninv; u64 q, q2; };
+
+// ------------------------------------------------------------------ signed-digit Montgomery product (modarith.h mont_mul_sd)
+// a * w * 2^-64 mod q as a signed representative, |r| <= q/2 + |a| w / 2^64 + 1: 12 multiplier-class + 2 plain instructions.
+// The two reduction rounds are spelled out as two asm blocks of v_mad_i64_i32 chains: written in C the compiler starts the
+// products that do not depend on the carry word early and adds it with separate 64-bit additions (2 extra instructions per
+// product), and written as one asm statement per instruction it pads every statement with an s_nop (it has to assume a
+// transcendental result).  A block only names whole operands: the low word of the running sum that the next round multiplies by
+// -q^-1 is passed in as its own 32-bit operand, which is why the chain is cut there.
+// SW: the twiddle halves are SGPRs (phases A, B, stage 0, normalisation) or VGPRs (phases C, D); q0, q1, -q^-1 are always SGPRs.
+template <bool SW> __device__ __forceinline__ i64 mm(i64 a, u64 ws, const MC& c) {
+    const u32 al = lo32((u64)a);
+    const i32 a0 = (i32)al;
+    const i32 a1 = (i32)(hi32((u64)a) + (al >> 31));
+    i32 w0 = (i32)lo32(ws), w1 = (i32)hi32(ws);
+    // opaque 32-bit values: seen as the halves of a 64-bit constant the compiler multiplies by them as 64-bit values
+    if constexpr (SW) asm("" : "+s"(w0), "+s"(w1)); else asm("" : "+v"(w0), "+v"(w1));
+    i64 acc = (i64)a0 * w0;                                  // v_mad_i64_i32 acc, a0, w0, 0
+    i32 m, m2; u64 k;
+    if constexpr (SW) {
+        asm("v_mul_lo_u32 %1, %3, %7\n\t"                   // m = lo(acc) * -q^-1
+            "v_mad_i64_i32 %0, %2, %1, %8, %0\n\t"          // S = m*q0 + acc (low word zero)
+            "v_ashrrev_i64 %0, 32, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %6, %0\n\t"          // + a0*w1
+            "v_mad_i64_i32 %0, %2, %1, %9, %0\n\t"          // + m*q1
+            "v_mad_i64_i32 %0, %2, %5, %10, %0"              // + a1*w0
+            : "+v"(acc), "=&v"(m), "=&s"(k)
+            : "v"(lo32((u64)acc)), "v"(a0), "v"(a1), "s"(w1), "s"(c.ninv), "s"(c.q0), "s"(c.q1), "s"(w0));
+        asm("v_mul_lo_u32 %1, %3, %6\n\t"
+            "v_mad_i64_i32 %0, %2, %1, %7, %0\n\t"
+            "v_ashrrev_i64 %0, 32, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %5, %0\n\t"          // + a1*w1
+            "v_mad_i64_i32 %0, %2, %1, %8, %0"               // + m2*q1
+            : "+v"(acc), "=&v"(m2), "=&s"(k)
+            : "v"(lo32((u64)acc)), "v"(a1), "s"(w1), "s"(c.ninv), "s"(c.q0), "s"(c.q1));
+    } else {
+        asm("v_mul_lo_u32 %1, %3, %7\n\t"
+            "v_mad_i64_i32 %0, %2, %1, %8, %0\n\t"
+            "v_ashrrev_i64 %0, 32, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %6, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %1, %9, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %5, %10, %0"
+            : "+v"(acc), "=&v"(m), "=&s"(k)
+            : "v"(lo32((u64)acc)), "v"(a0), "v"(a1), "v"(w1), "s"(c.ninv), "s"(c.q0), "s"(c.q1), "v"(w0));
+        asm("v_mul_lo_u32 %1, %3, %6\n\t"
+            "v_mad_i64_i32 %0, %2, %1, %7, %0\n\t"
+            "v_ashrrev_i64 %0, 32, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %5, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %1, %8, %0"
+            : "+v"(acc), "=&v"(m2), "=&s"(k)
+            : "v"(lo32((u64)acc)), "v"(a1), "v"(w1), "s"(c.ninv), "s"(c.q0), "s"(c.q1));
+    }
+    return acc;
+}
+
+// MODE 1: signed, never reduced (31q < 2^62).  MODE 0: Harvey, U, V in [0,4q) -> [0,4q).
+template <int MODE, bool SW> __device__ __forceinline__ void bfly(u64& U, u64& V, u64 ws, const MC& c) {
+#ifdef MKHE_H16_X_NOBFLY
+    if ((MKHE_H16_X_NOBFLY >> (SW ? 0 : 1)) & 1) { U += ws; return; }      // timing experiment only: butterflies with scalar / per-lane twiddles removed
+#endif
+    if constexpr (MODE == 1) {
+        const i64 T = mm<SW>((i64)V, ws, c);
+        const i64 u = (i64)U;
+        U = (u64)(u + T);
+        V = (u64)(u - T);
+    } else {
+        const u64 T = (u64)(mm<SW>((i64)V, ws, c) + (i64)c.q);       // [0,2q)
+        const u64 u = csub(U, c.q2);
+        U = u + T;
+        V = u + (c.q2 - T);
+    }
+}
+
+// one radix-2 stage on register bit B of the 16 registers; tw: the 8 >> B twiddles of this thread for the stage
+template <int MODE, bool SW, int B> __device__ __forceinline__ void stage(u64 (&x)[16], const u64* tw, const MC& c) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+        bfly<MODE, SW>(x[i0], x[i0 | (1 << B)], tw[g >> B], c);
+#ifndef MKHE_H16_NO_SCHEDBAR
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
+// butterfly number g (0..7) of the stage on register bit B, per-lane twiddle
+template <int MODE, int B> __device__ __forceinline__ void bfly1(u64 (&x)[16], int g, u64 w, const MC& c) {
+    const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+    bfly<MODE, false>(x[i0], x[i0 | (1 << B)], w, c);
+#ifndef MKHE_H16_NO_SCHEDBAR
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// ------------------------------------------------------------------ LDS re-distributions
+// word offsets of register r in the four exchanges (write side, read side); bases are per thread (below)
+enum { X_AB = 0, X_BC = 1, X_CD = 2, X_DE = 3 };
+template <int X> constexpr int woff(int r) {
+    return X == X_AB ? r * WSTR : X == X_BC ? 68 * r : X == X_CD ? 65 * (r >> 2) + 260 * (r & 3) : r;
+}
+template <int X> constexpr int roff(int r) {
+    return X == X_AB ? 64 * r : X == X_BC ? 4 * r : X == X_CD ? 260 * (r >> 2) + (r & 3) : 66 * r;
+}
+__device__ __forceinline__ int de_w(int c) { return 16 * c + (c >> 1); }     // {0, 16, 33, 49}
+template <int X> __device__ __forceinline__ int wbase(int wv, int l) {
+    if constexpr (X == X_AB) return wv * 64 + l;
+    else if constexpr (X == X_DE) return wv * WSTR + 66 * (l >> 2) + de_w(l & 3);
+    else return wv * WSTR + l;
+}
+template <int X> __device__ __forceinline__ int rbase(int wv, int l) {
+    if constexpr (X == X_AB) return wv * WSTR + l;
+    else if constexpr (X == X_BC) return wv * WSTR + 68 * (l >> 2) + (l & 3);
+    else if constexpr (X == X_CD) return wv * WSTR + 4 * (l >> 2) + 65 * (l & 3);
+    else return wv * WSTR + de_w(l >> 4) + (l & 15);
+}
+template <bool CROSS> __device__ __forceinline__ void xsync() {
+    if constexpr (CROSS) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+}
+template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds, int wv, int l) {
+    constexpr bool CROSS = X == X_AB;
+#ifdef MKHE_H16_X_NOXCHG
+    if ((MKHE_H16_X_NOXCHG >> X) & 1) return;      // timing experiment only (wrong results): cost of this re-distribution
+#endif
+    // opaque copies: the (loop-invariant) LDS bases are recomputed next to their use instead of living in VGPRs across the whole job
+    asm volatile("" : "+v"(l));
+    typedef __attribute__((address_space(3))) u32* lptr;
+    typedef volatile __attribute__((address_space(3))) u32* vlptr;
+    lptr wr = (lptr)lds + wbase<X>(wv, l);
+    // The reads are volatile so that they stay single ds_read_b32: merged into ds_read2_b32 the two words of one instruction
+    // (same plane, two different coefficients) land in a consecutive register pair and every coefficient then needs two v_mov to
+    // get its own (low, high) pair back -- 32 VALU instructions per re-distribution, in a kernel that is VALU-issue bound.
+    vlptr rd = (vlptr)((lptr)lds + rbase<X>(wv, l));
+    if constexpr (CROSS) __syncthreads();          // every wave is done reading its region (previous pass)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[woff<X>(r)] = lo32(x[r]);
+    xsync<CROSS>();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = (x[r] & 0xffffffff00000000ull) | rd[roff<X>(r)];
+    xsync<CROSS>();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[woff<X>(r)] = hi32(x[r]);
+    xsync<CROSS>();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = ((u64)rd[roff<X>(r)] << 32) | lo32(x[r]);
+    if constexpr (!CROSS) xsync<false>();
+}
+
+// ------------------------------------------------------------------ one limb
+// what one limb needs, all wave-uniform
+struct Job { gcptr src; gptr dst; const u64* psi; smodptr mp; bool red; bool skip_norm; u64* trace; };
+// diagnostic build (make trace): shader-clock stamps per wave and pass, 32 words per (job, wave): [16 * pass + k], see tools/ntt16_trace.py
+// (every lane stores the same word: a lane-0 branch here makes the compiler lose the uniformity of the scalar twiddle loads)
+#ifdef MKHE_PHASE_TRACE
+#define H16_STAMP(k) do { if (jb.trace) jb.trace[(long)wv * 32 + 16 * h + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define H16_STAMP(k) do { } while (0)
+#endif
+
+template <int MODE, bool DEC>
+__device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
+    smodptr mp = jb.mp;                                 // scalar loads: the constants live in SGPRs
+    struct { u64 qs, r1s; } md;
+    md.qs = mp->qs; md.r1s = mp->r1s;
+    MC c;
+    c.q = mp->q; c.q2 = mp->q2; c.ninv = mp->ninv32;
+    c.q0 = (i32)lo32(md.qs); c.q1 = (i32)hi32(md.qs);
+    asm("" : "+s"(c.q0), "+s"(c.q1), "+s"(c.ninv));        // opaque wave-uniform 32-bit values (see modarith.h mont_mul_sd)
+    scptr psi_s = (scptr)jb.psi;
+    gcptr psi_v = (gcptr)jb.psi;
+    const gcptr src = jb.src; const gptr dst = jb.dst;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
+    const bool red = DEC && jb.red;
+    u64 x[16];
+    const unsigned tu = (unsigned)t;
+#pragma unroll 1
+    for (int hh = 0; hh < 2; ++hh) {
+        const int h = __builtin_amdgcn_readfirstlane(hh);
+        H16_STAMP(0);
+        if (h == 0) {
+            // ---- stage 0: cross-half butterflies; upper outputs parked in dst[N/2 + j]
+            const u64 w1 = psi_s[1];
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                u64 U[8], V[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { U[r] = sbase(src + (r0 + r) * NT)[tu]; V[r] = sbase(src + HH + (r0 + r) * NT)[tu]; }
+                if constexpr (DEC) {
+                    if (red) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            if constexpr (MODE == 1) { U[r] = (u64)mm<true>((i64)U[r], md.r1s, c); V[r] = (u64)mm<true>((i64)V[r], md.r1s, c); }
+                            else { U[r] = (u64)(mm<true>((i64)U[r], md.r1s, c) + (i64)c.q); V[r] = (u64)(mm<true>((i64)V[r], md.r1s, c) + (i64)c.q); }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    bfly<MODE, true>(U[r], V[r], w1, c);
+                    x[r0 + r] = U[r];
+                    sbase(dst + HH + (r0 + r) * NT)[tu] = V[r];
+                }
+                asm volatile("" ::: "memory");
+            }
+        } else {
+            // the parked half: written by this same thread in pass 0; all but the 16 youngest memory operations (the final
+            // stores of pass 0) are complete before the reload is issued
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                x[r] = __hip_atomic_load(sbase(dst + HH + r * NT) + tu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        H16_STAMP(1);                            // loads landed, stage 0 done
+        // ---- phase A: bits 13..10, twiddles psi[2^k + (h << (k-1)) + i], k = 1..4
+        {
+            u64 tw[15];
+            tw[0] = psi_s[2 + h];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[4 + 2 * h + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[8 + 4 * h + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tw[7 + i] = psi_s[16 + 8 * h + i];
+            stage<MODE, true, 3>(x, tw, c);
+            stage<MODE, true, 2>(x, tw + 1, c);
+            stage<MODE, true, 1>(x, tw + 3, c);
+            stage<MODE, true, 0>(x, tw + 7, c);
+        }
+        H16_STAMP(2);
+        exchange<X_AB>(x, lds, wv, l);
+        H16_STAMP(3);
+        // ---- phase B: bits 9..6, twiddles psi[2^k + ((16h + wave) << (k-5)) + i], k = 5..8
+        {
+            const int cb = 16 * h + wv;
+            u64 tw[15];
+            tw[0] = psi_s[32 + cb];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[64 + 2 * cb + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[128 + 4 * cb + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tw[7 + i] = psi_s[256 + 8 * cb + i];
+            stage<MODE, true, 3>(x, tw, c);
+            stage<MODE, true, 2>(x, tw + 1, c);
+            stage<MODE, true, 1>(x, tw + 3, c);
+            stage<MODE, true, 0>(x, tw + 7, c);
+        }
+        // Phases C and D: per-lane twiddles, fetched in 16-byte groups a few butterflies ahead of their use (at most three groups =
+        // 12 VGPRs live; issuing all 15 + 12 at once would not fit beside the 32 data registers).  The first groups of a phase are
+        // requested before the re-distribution that precedes it.
+        // ---- phase C: bits 5..2, twiddles psi[2^k + (cc << (k-9)) + i], k = 9..12, cc = (16h + wave) * 16 + bits 9..6 (lane >> 2)
+        {
+            int lc = l; asm volatile("" : "+v"(lc));
+            const unsigned cu = (unsigned)((16 * h + wv) * 16 + (lc >> 2));
+            __builtin_assume(cu < 512);
+            u64 g[8][2];
+            auto loadg = [&](int k) {
+                if (k == 0) g[0][0] = *(gcptr)((const __attribute__((address_space(1))) char*)sbase(psi_v + 512) + (unsigned)(cu * 8u));
+                else if (k == 1) ld2(g[1], (gcptr2)sbase(psi_v + 1024), cu);
+                else if (k < 4) ld2(g[k], (gcptr2)sbase(psi_v + 2048) + (k - 2), 2 * cu);
+                else ld2(g[k], (gcptr2)sbase(psi_v + 4096) + (k - 4), 4 * cu);
+            };
+            loadg(0); loadg(1); loadg(2);
+            H16_STAMP(4);
+            exchange<X_BC>(x, lds, wv, l);
+            H16_STAMP(5);
+#pragma unroll
+            for (int n = 0; n < 32; ++n) {
+                if (n == 8) loadg(3);
+                if (n == 16) loadg(4);
+                if (n == 20) loadg(5);
+                if (n == 24) loadg(6);
+                if (n == 26) loadg(7);
+                const int gi = n & 7;
+                if (n < 8) bfly1<MODE, 3>(x, gi, g[0][0], c);
+                else if (n < 16) bfly1<MODE, 2>(x, gi, g[1][gi >> 2], c);
+                else if (n < 24) bfly1<MODE, 1>(x, gi, g[2 + (gi >> 2)][(gi >> 1) & 1], c);
+                else bfly1<MODE, 0>(x, gi, g[4 + (gi >> 1)][gi & 1], c);
+            }
+        }
+        // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane
+        {
+            int ld = l; asm volatile("" : "+v"(ld));
+            const unsigned du = (unsigned)((16 * h + wv) * 64 + ld);
+            __builtin_assume(du < 2048);
+            u64 g[6][2];
+            auto loadg = [&](int k) {
+                if (k < 2) ld2(g[k], (gcptr2)sbase(psi_v + 8192) + k, 2 * du);
+                else ld2(g[k], (gcptr2)sbase(psi_v + 16384) + (k - 2), 4 * du);
+            };
+            loadg(0); loadg(1); loadg(2);
+            H16_STAMP(6);
+            exchange<X_CD>(x, lds, wv, l);
+            H16_STAMP(7);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                if (n == 4) loadg(3);
+                if (n == 8) loadg(4);
+                if (n == 10) loadg(5);
+                const int gi = n & 7;
+                if (n < 8) bfly1<MODE, 1>(x, gi, g[gi >> 2][(gi >> 1) & 1], c);
+                else bfly1<MODE, 0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
+            }
+        }
+        H16_STAMP(8);
+        // ---- output representative
+        if constexpr (MODE == 1) {
+            if (!jb.skip_norm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const i64 y = mm<true>((i64)x[r], md.r1s, c);                     // (-0.6q, 0.6q)
+                    x[r] = (u64)(y + ((y >> 63) & (i64)c.q));                       // canonical
+                }
+            } else {
+                const i64 bias = (i64)(c.q << 4);                                    // same residue, positive: (2q, 30q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = (u64)((i64)x[r] + bias);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = csub(csub(x[r], c.q2), c.q);
+        }
+        H16_STAMP(9);
+        exchange<X_DE>(x, lds, wv, l);
+        H16_STAMP(10);
+        {
+            gptr o = dst + h * HH + wv * 1024;
+            const unsigned lu = (unsigned)l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#ifdef MKHE_H16_X_NOSTORE
+                if (x[r] != 0x123456789abcdefull) continue;      // timing experiment only: (almost) no result stores
+#endif
+                sbase(o + r * 64)[lu] = x[r];
+            }
+        }
+        H16_STAMP(11);
+    }
+}
+
+template <bool DEC>
+__global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int t = threadIdx.x;
+    const int njobs = b.nslots * b.nouter;
+    // optional start delay of the second half of the persistent grid (the co-resident workgroup of every CU, as far as the
+    // dispatcher deals workgroups b and b + gridDim/2 to the same CU): the two workgroups of a CU then sit in different phases
+    if (b.lazy_out > 0 && blockIdx.x >= (gridDim.x >> 1)) { for (int i = 0; i < b.lazy_out; ++i) __builtin_amdgcn_s_sleep(127); }
+#pragma unroll 1
+    for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+        // The launch description is re-read from the kernel-argument segment for every limb (a handful of scalar loads) instead
+        // of being kept in SGPRs across the limb: kept live it overflows the SGPR file into VGPR lanes, and those VGPRs are
+        // what the 64-register budget of this kernel does not have.
+        kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kb));
+        // slot-major job order (ntt_kernels.hip job_pointers): consecutive workgroups share a modulus
+        const int nouter = kb->nouter;
+        const int s = __builtin_amdgcn_readfirstlane(job / nouter);      // integer division runs on the VALU: make the result an SGPR again
+        int outer = __builtin_amdgcn_readfirstlane(job - s * nouter);
+        const int m = kb->mod[s], p = kb->pos[s];
+        const u64* sbase_ = kb->src; u64* dbase_ = kb->dst;
+        if (kb->nitems > 0) {
+            const int opi = kb->outers_per_item;
+            const int item = __builtin_amdgcn_readfirstlane(outer / opi);
+            outer -= item * opi;
+            sbase_ = kb->src_items[item]; dbase_ = kb->dst_items[item];
+        }
+        Job jb;
+        jb.src = (gcptr)(sbase_ + (long)outer * kb->src_outer + (long)(kb->src_mapped ? m : p) * kb->src_inner);
+        jb.dst = (gptr)(dbase_ + (long)outer * kb->dst_outer + (long)(kb->dst_mapped ? m : p) * kb->dst_inner);
+        jb.psi = kb->psi + (long)m * NN;
+        jb.mp = (smodptr)kb->mods + m;
+        jb.skip_norm = kb->skip_norm != 0;
+        jb.trace = kb->trace ? kb->trace + (long)job * 16 * 32 : nullptr;
+        jb.red = false;
+        if constexpr (DEC) {
+            int sm = m;
+            const int rs = kb->reduce_src_mod_is_outer;
+            if (rs == 1) sm = outer; else if (rs == 2) sm = kb->outer_mod[outer];
+            const u64 qsb = ((smodptr)kb->mods)[sm].q << (kb->src_lazy ? 2 : 0);     // bound of the digit values (< 2^63)
+            jb.red = qsb > 4 * jb.mp->q;
+        }
+#ifdef MKHE_PHASE_TRACE
+        if (jb.trace && (t & 63) == 0) {
+            u64* tw = jb.trace + (long)(t >> 6) * 32;
+            tw[12] = __builtin_amdgcn_s_memrealtime();
+            tw[13] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+            tw[14] = blockIdx.x;
+        }
+#endif
+        if ((kb->small_slots >> s) & 1) limb<1, DEC>(jb, lds, t);
+        else limb<0, DEC>(jb, lds, t);
+#ifdef MKHE_PHASE_TRACE
+        if (jb.trace && (t & 63) == 0) jb.trace[(long)(t >> 6) * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+}
+
+}  // namespace h16
+
+// ------------------------------------------------------------------ launcher
+bool ntt16_ok(int logN, const NttBatch& b) {
+    static int on = -1, minl = 0;
+    if (on < 0) {
+        const char* e = getenv("MKHE_NTT16"); on = (e && *e) ? atoi(e) : 1;
+        const char* f = getenv("MKHE_NTT16_MIN"); minl = (f && *f) ? atoi(f) : 256;
+    }
+    return on && logN == 15 && !b.split && !b.prestaged && b.nslots <= 64 && b.nslots * b.nouter >= minl;
+}
+void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
+    using namespace h16;
+    NttBatch c = b;
+    // big-modulus limbs (the longer jobs) first, as in launch_ntt_fwd_mixed
+    c.small_slots = 0; c.nslots = 0;
+    for (int cls = 0; cls < 2; ++cls)
+        for (int s = 0; s < b.nslots; ++s)
+            if ((small_q[b.mod[s]] != 0) == (cls == 1)) {
+                c.mod[c.nslots] = b.mod[s]; c.pos[c.nslots] = b.pos[s];
+                if (cls) c.small_slots |= 1ull << c.nslots;
+                ++c.nslots;
+            }
+    const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("MKHE_NTT16_STAGGER"); stagger = (e && *e) ? atoi(e) : 0; }
+    c.lazy_out = stagger;
+    static bool attr = false;
+    static int resident = 0;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, cus = 256, per = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)ntt16_fwd_kernel<true>, NT, lds) != hipSuccess || per < 1) per = 1;
+        if (const char* e = getenv("MKHE_NTT16_PER_CU")) { if (*e) per = atoi(e); }
+        resident = cus * per;
+        attr = true;
+    }
+    const int need = c.nslots * c.nouter;
+    const int blocks = need < resident ? need : resident;
+    if (c.reduce_in) hipLaunchKernelGGL(ntt16_fwd_kernel<true>, dim3(blocks), dim3(NT), lds, st, c);
+    else hipLaunchKernelGGL(ntt16_fwd_kernel<false>, dim3(blocks), dim3(NT), lds, st, c);
+}
+
+}  // namespace mkhe

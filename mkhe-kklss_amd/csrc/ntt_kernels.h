@@ -82,5 +82,9 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st);
 bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q);
 void launch_ntt_fwd_mixed(int logN, const NttBatch& b, const unsigned char* small_q, hipStream_t st);
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st);
+// N = 2^15 launches that fill the chip (ntt16_kernels.hip): 16 coefficients per thread, two workgroups per CU, both modulus
+// classes in one persistent launch.  ntt16_ok: false when the launch does not qualify (MKHE_NTT16=0 switches the path off).
+bool ntt16_ok(int logN, const NttBatch& b);
+void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st);
 
 }  // namespace mkhe
