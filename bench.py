@@ -7,7 +7,8 @@ region of the reference benchmark (mkckks/mkckks_benchmark_test.go:78-82), all i
 resident in HBM when the clock starts.
 
   python bench.py --gpus 1 --steps K --warmup W          (default workload = configs[1])
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N ...                           (spawns N ranks itself: torch.distributed.run on 127.0.0.1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the same, launched from outside)
 
 Prints ONE JSON line on rank 0.
 """
@@ -425,9 +426,8 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=4)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even at world size 1 (testing)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary Rotate / RotateHoisted figures")
-    ap.add_argument("--shard", default="limb", choices=["limb", "party"],
-                    help="N > 1: shard the RNS limbs (default: x, y stay local, ~40 MB exchanged per step) or the parties "
-                         "(the paper's structure, ~135 MB all-reduced per step)")
+    ap.add_argument("--no-limb-leg", action="store_true",
+                    help="N > 1: skip the secondary limb-sharded MulRelin figure (the headline value is always the party-sharded one)")
     ap.add_argument("--dist-sync", default="auto", choices=["auto", "stream", "host"],
                     help="N > 1, limb sharding: order the collectives on the engine's stream or through the host "
                          "(auto: an untimed probe of both after the warm-up picks the faster one)")
@@ -436,6 +436,17 @@ def main():
                          "CNN inference per step (cnn/cnn.go on PN14QP433; --parties 2 or 4) -- both single GPU")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- N rank processes, one per GPU, started BEFORE anything in this
+        # process has touched the GPU; rank 0 of the children prints the JSON line on the inherited stdout
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     if args.gpus > 1 or world > 1 or args.force_dist:
         from bench_dist import run_distributed
         out = run_distributed(args)

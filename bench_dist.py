@@ -1,11 +1,14 @@
 """bench.py, N > 1 leg: one process per GPU (torch.distributed, backend nccl = RCCL over xGMI).
 
-The SAME k-party MulRelin as the single-GPU bench is evaluated sharded over the ranks (mkhe_kklss_amd/dist.py):
-strong scaling, value = MulRelin/s of the whole job.
-  --shard limb  (default) every rank owns a subset of the RNS moduli and evaluates all parties there; x, y stay local;
-                exchanged per step: P limbs of the external products, t_i, the output ciphertext (~40 MB at k = 4)
-  --shard party the paper's structure: half-party units; all-reduce of the x and y partial sums (beta*(nQ+nP)*N words
-                each) and of the output ciphertext (~135 MB at k = 4)
+The SAME k-party MulRelin as the single-GPU bench is evaluated sharded over the ranks (mkhe_kklss_amd/dist.py): strong
+scaling, value = MulRelin/s of the whole job.  Legs (all timed with the barrier / synchronise / max-over-ranks contract):
+  party  (the headline `value`; SURVEY.md 8e, BASELINE.json north_star): GPU g owns whole parties (half-party units when
+         there are more GPUs than parties) with their keys; all-reduce of the x and y partial sums, all-reduce of out_0 and
+         all-gather of the out_i
+  limb   (secondary, alpha = 1 rings only): every rank owns a subset of the RNS moduli and evaluates all parties there;
+         x, y stay local; exchanged: P limbs of the external products, t_i, the output ciphertext
+  rotate (secondary): hoisted Rotate of the k-party ciphertext, parties sharded, one all-reduce
+--params PN16QP1761 --parties 8 is BASELINE.json configs[3] (keys written on the device by the CRS expander).
 """
 import os
 import sys
@@ -14,14 +17,29 @@ import time
 import numpy as np
 
 
+def _timed(dist, torch, params, fn, steps, warmup):
+    """W untimed + K timed calls of fn between barrier + synchronise on both sides; MAX over ranks; -> seconds"""
+    for _ in range(warmup):
+        fn()
+    params.sync(); torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    params.sync(); torch.cuda.synchronize(); dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    return float(dt.item())
+
+
 def run_distributed(args):
     import torch
     import torch.distributed as dist
     import harness as H
     from bench import synth_party_keys, synth_cts, synth_swk
-    from mkhe_kklss_amd import mkckks
+    from mkhe_kklss_amd import mkckks, mkrlwe
     from mkhe_kklss_amd._abi import check, lib
-    from mkhe_kklss_amd.dist import HipLimbBackend, HipShardBackend, LimbShardedMulRelin, ShardedMulRelin, assign_units
+    from mkhe_kklss_amd.dist import (HipLimbBackend, HipRotateBackend, HipShardBackend, LimbShardedMulRelin, ShardedMulRelin,
+                                     ShardedRotate, assign_parties, assign_units)
 
     # a plain `python bench.py --force-dist` (no launcher): single-rank rendezvous on the loopback interface
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -37,77 +55,101 @@ def run_distributed(args):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend_name, rank=rank, world_size=world)
-    pset = H.PN15QP880 if args.params == "PN15QP880" else H.PN14QP439
+    pset = {"PN15QP880": H.PN15QP880, "PN14QP439": H.PN14QP439, "PN16QP1761": H.PN16QP1761}[args.params]
     k = args.parties
     names = ["user%d" % i for i in range(k)]
     level = len(pset["Q"]) - 1
+    device_keys = args.device_keys or args.params == "PN16QP1761"
     params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"], device=local_rank)
     op0, op1 = synth_cts(pset, k, args.seed)
-    params.AddCRS(-1, synth_swk(pset, np.random.default_rng(args.seed + 7)))
+    if device_keys:
+        params.AddCRS(-1, seed=args.seed)
+    else:
+        params.AddCRS(-1, synth_swk(pset, np.random.default_rng(args.seed + 7)))
     nwx = int(lib().mkhe_ctx_swk_words(params.ctx))
     Nn, L, npp = 1 << pset["logN"], level + 1, len(pset["P"])
-    if args.shard == "limb":
-        # every rank: full operands and (the owned limbs of) every party's keys; x, y stay local
-        rlk = {n: synth_party_keys(pset, names.index(n), args.seed) for n in names}
-        backend = HipLimbBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank,
-                                 sync="stream" if args.dist_sync == "auto" else args.dist_sync)
-        smr = LimbShardedMulRelin(backend, dist, force_collectives=bool(os.environ.get("MKHE_FORCE_COLLECTIVES")))
-        full = backend.out
-        exchanged = 8 * Nn * (k * npp + k * L + 3 * k * npp + (k + 1) * L)
-        sharding = "RNS limbs (every rank: all parties, its moduli), see mkhe_kklss_amd/dist.py LimbShardedMulRelin"
-    else:
-        ids0, ids1 = assign_units(names, world)[rank]
-        rlk = {n: synth_party_keys(pset, names.index(n), args.seed) for n in set(ids0) | set(ids1)}
-        backend = HipShardBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank)
-        smr = ShardedMulRelin(backend, dist)
-        full = backend.full
-        exchanged = 8 * (2 * nwx + (k + 1) * L * Nn)
-        sharding = "half-party units, see mkhe_kklss_amd/dist.py ShardedMulRelin"
-    del rlk
+
+    def party_keys(n):
+        """(b, d, v) of one party: host arrays, or device handles filled by the CRS expander (same on every rank: the seed and
+        the index are public)"""
+        i = names.index(n)
+        if not device_keys:
+            return synth_party_keys(pset, i, args.seed)
+        keys = []
+        for j in range(3):
+            key = mkrlwe.SwitchingKey(params, zero=False)
+            check(lib().mkhe_crs_expand(params.ctx, args.seed, 1000 + 3 * i + j, key.h))
+            keys.append(key)
+        return tuple(keys)
+
+    legs = {}
     res = mkckks.NewCiphertext(params, names, level - 1, pset["scale"])
-
-    def step():
+    # ---- party sharding (headline)
+    ids0, ids1 = assign_units(names, world)[rank]
+    rlk = {n: party_keys(n) for n in sorted(set(ids0) | set(ids1))}
+    backend = HipShardBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank)
+    smr = ShardedMulRelin(backend, dist)
+    def step_party():
         smr.run()
-        check(lib().mkhe_rescale(params.ctx, full.h, 1, res.h))
-
-    for _ in range(args.warmup):
-        step()
-    params.sync(); torch.cuda.synchronize(); dist.barrier()
-    sync_mode = getattr(backend, "sync", "host")
-    if args.shard == "limb" and args.dist_sync == "auto":
-        # untimed probe: three steps with each way of ordering the collectives, every rank adopts the faster one
-        probe = {}
-        for mode in ("stream", "host"):
-            backend.set_sync(mode)
-            step()
-            params.sync(); torch.cuda.synchronize(); dist.barrier()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                step()
-            params.sync(); torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            probe[mode] = float(tt.item())
-        sync_mode = min(probe, key=probe.get)
-        backend.set_sync(sync_mode)
-        step()
-        params.sync(); torch.cuda.synchronize(); dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    params.sync(); torch.cuda.synchronize(); dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
+        check(lib().mkhe_rescale(params.ctx, backend.full.h, 1, res.h))
+    dt = _timed(dist, torch, params, step_party, args.steps, args.warmup)
+    legs["party"] = dict(mulrelin_per_sec=args.steps / dt, ms_per_step=dt * 1e3 / args.steps,
+                         exchanged_bytes_per_step=8 * (2 * nwx + (1 + (k // world if k % world == 0 else k)) * L * Nn))
+    del smr, backend, rlk
+    # ---- hoisted Rotate, parties sharded (BASELINE.json configs[3]: "MulRelin + hoisted Rotate")
+    rot = 1
+    mine = assign_parties(names, world)[rank]
+    if device_keys:
+        params.AddCRS(rot, seed=args.seed)
+        rk = {}
+        for n in mine:
+            key = mkrlwe.SwitchingKey(params, zero=False)
+            check(lib().mkhe_crs_expand(params.ctx, args.seed, 2000 + names.index(n), key.h))
+            rk[n] = key
+    else:
+        params.AddCRS(rot, synth_swk(pset, np.random.default_rng(args.seed + 99)))
+        rk = {n: synth_swk(pset, np.random.default_rng(args.seed + 100 + names.index(n))) for n in mine}
+    rb = HipRotateBackend(params, names, rank, world, op0, rk, params.CRS[rot], rot, level, torch, local_rank, hoisted=True)
+    srot = ShardedRotate(rb, dist)
+    dt = _timed(dist, torch, params, srot.run, args.steps, args.warmup)
+    legs["rotate_hoisted"] = dict(rotate_per_sec=args.steps / dt, ms_per_step=dt * 1e3 / args.steps,
+                                  exchanged_bytes_per_step=8 * (k + 1) * L * Nn)
+    del srot, rb, rk
+    # ---- limb sharding (secondary; alpha = 1 only: with alpha >= 2 a gadget digit spans several moduli)
+    sync_mode = None
+    if params.Alpha() == 1 and not device_keys and not args.no_limb_leg:
+        rlk = {n: synth_party_keys(pset, names.index(n), args.seed) for n in names}
+        lb = HipLimbBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank,
+                            sync="stream" if args.dist_sync == "auto" else args.dist_sync)
+        del rlk
+        lsm = LimbShardedMulRelin(lb, dist, force_collectives=bool(os.environ.get("MKHE_FORCE_COLLECTIVES")))
+        def step_limb():
+            lsm.run()
+            check(lib().mkhe_rescale(params.ctx, lb.out.h, 1, res.h))
+        sync_mode = lb.sync
+        if args.dist_sync == "auto":
+            # untimed probe: three steps with each way of ordering the collectives, every rank adopts the faster one
+            probe = {}
+            for mode in ("stream", "host"):
+                lb.set_sync(mode)
+                probe[mode] = _timed(dist, torch, params, step_limb, 3, 1)
+            sync_mode = min(probe, key=probe.get)
+            lb.set_sync(sync_mode)
+        dt = _timed(dist, torch, params, step_limb, args.steps, args.warmup)
+        legs["limb"] = dict(mulrelin_per_sec=args.steps / dt, ms_per_step=dt * 1e3 / args.steps, collective_ordering=sync_mode,
+                            exchanged_bytes_per_step=8 * Nn * (k * npp + k * L + 3 * k * npp + (k + 1) * L))
     out = None
     if rank == 0:
-        out = dict(metric="mkckks_mulrelin_per_sec", value=args.steps / dt, unit="MulRelin/s", n_gpus=world,
-                   steps=args.steps, warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps, higher_is_better=True,
+        v = legs["party"]
+        out = dict(metric="mkckks_mulrelin_per_sec", value=v["mulrelin_per_sec"], unit="MulRelin/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=v["ms_per_step"], higher_is_better=True,
                    scaling="strong", vs_baseline=None, dtype="u64", data="synthetic",
                    config=dict(workload="mkckks %d-party MulRelin (hoist + MulAndRelinHoisted + Rescale), %s N=2^%d, %d Q + %d P limbs, "
-                                        "sharded over %d GPUs" % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["P"]), world),
-                               parties=k, params=args.params, seed=args.seed, sharding=sharding, collective_ordering=sync_mode,
-                               allreduce_bytes_per_step=exchanged),
+                                        "parties sharded over %d GPUs (RCCL all-reduce of x, y, out_0; all-gather of out_i)"
+                                        % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["P"]), world),
+                               parties=k, params=args.params, seed=args.seed, rccl_ranks=dist.get_world_size(),
+                               key_material="device" if device_keys else "host",
+                               sharding="parties (mkhe_kklss_amd/dist.py ShardedMulRelin); secondary legs below", legs=legs),
                    roofline=None, cpu_baseline=None)
     dist.barrier()
     dist.destroy_process_group()

@@ -8,7 +8,8 @@ The reference is single-process; the sharding follows the algori
 and every rank evaluates the reference algorithm on the sub-ciphertexts made of c_0 and the
 components of its units.  Exchange steps (the only collectives):
   1. all-reduce(x_part), all-reduce(y_part)   uint64 sums of canonical residues, then fold + MForm
-  2. all-reduce(out)                          every out slot is a sum of per-rank contributions
+  2. all-reduce(out_0) + all-gather(out_i)    out_0 is a sum over ranks; out_i comes from party i's owner (ranks that own whole
+                                              parties in equal numbers; otherwise one all-reduce of the whole ciphertext)
 All sums are exact (ranks * q < 2^63) and order independent, so the result is bit-identical to the
 single-device evaluation.
 """
@@ -46,9 +47,28 @@ class ShardedMulRelin:
         self._all_reduce(y)
         b.fold_xy()                           # x, y <- MForm(sum mod q)
         full = b.finish()                     # torch int64 view [1+k][L][N]: own contributions, zeros elsewhere
-        self._all_reduce(full)
+        self._exchange_out(full)
         b.fold_out()                          # every slot <- sum mod q
         return full
+
+    def _exchange_out(self, full):
+        """out_0 is a sum over the ranks (keyswitch_hoisted.go:147-178: every party adds <h(t_i), v_i> to it): all-reduce of
+        that one slot.  out_i comes from the rank that owns party i when the ranks own whole parties in equal numbers: then
+        the slots are all-gathered (each rank sends only its own), otherwise (half-party units: two ranks add into the same
+        slot) the whole ciphertext is all-reduced."""
+        dist = self.dist
+        if dist is None or dist.get_world_size(self.group) == 1:
+            return
+        world, k = dist.get_world_size(self.group), full.shape[0] - 1
+        if k == 0 or k % world != 0:
+            self._all_reduce(full)
+            return
+        c, rank = k // world, dist.get_rank(self.group)
+        self.b.before_collective()
+        dist.all_reduce(full[0], op=dist.ReduceOp.SUM, group=self.group)
+        chunks = [full[1 + r * c: 1 + (r + 1) * c] for r in range(world)]
+        dist.all_gather(chunks, chunks[rank].clone(), group=self.group)       # the input is copied: it is also one of the output views
+        self.b.after_collective()
 
 
 def assign_parties(names, world):
@@ -102,7 +122,9 @@ class HipShardBackend:
         sl = lambda host, ids: np.ascontiguousarray(np.stack([host[0]] + [host[1 + self.names.index(n)] for n in ids]))
         self.op0 = mkrlwe.NewCiphertext(params, ids0, level).upload(sl(op0_host, ids0))
         self.op1 = mkrlwe.NewCiphertext(params, ids1, level).upload(sl(op1_host, ids1))
-        self.keys = {n: [mkrlwe.SwitchingKey(params, rlk_host[n][j]) if need else None
+        # key material: host arrays (uploaded here) or resident SwitchingKey handles (e.g. written by mkhe_crs_expand)
+        as_key = lambda k_: k_ if isinstance(k_, mkrlwe.SwitchingKey) else mkrlwe.SwitchingKey(params, k_)
+        self.keys = {n: [as_key(rlk_host[n][j]) if need else None
                          for j, need in enumerate((n in ids1, n in ids0, n in ids0))]
                      for n in set(ids0) | set(ids1)}
         self.out_ids = sorted(set(ids0) | set(ids1))
@@ -158,9 +180,10 @@ class HipRotateBackend:
     """Local arithmetic of one rank for ShardedRotate through the C ABI (mkhe_rotate_partial, mkhe_ct_fold,
     mkhe_ct_automorphism)."""
 
-    def __init__(self, params, names, rank, world, ct_host, rk_host, crs, rotidx, level, torch, device_index):
-        """ct_host: uint64[1+k][L][N]; rk_host: {name: rotation key array} for (at least) this rank's parties;
-        crs: the device SwitchingKey params.CRS[rotidx]."""
+    def __init__(self, params, names, rank, world, ct_host, rk_host, crs, rotidx, level, torch, device_index, hoisted=False):
+        """ct_host: uint64[1+k][L][N]; rk_host: {name: rotation key array or resident SwitchingKey} for (at least) this
+        rank's parties; crs: the device SwitchingKey params.CRS[rotidx]; hoisted: RotateHoisted (keyswitch_hoisted.go:183-247)
+        on hoisted forms of the rank's components computed once here, instead of Rotate (keyswitch.go:234-298)."""
         from . import mkrlwe
         from ._abi import check, handle_array, lib
         self.params, self.names, self.level, self.torch = params, list(names), level, torch
@@ -170,8 +193,12 @@ class HipRotateBackend:
         sub = np.ascontiguousarray(np.stack([ct_host[0]] + [ct_host[1 + self.names.index(n)] for n in self.ids]))
         self.sub = mkrlwe.NewCiphertext(params, self.ids, level).upload(sub)
         self.part = mkrlwe.NewCiphertext(params, self.ids, level)
-        self.keys = [mkrlwe.SwitchingKey(params, rk_host[n]) for n in self.ids]
+        self.keys = [rk_host[n] if isinstance(rk_host[n], mkrlwe.SwitchingKey) else mkrlwe.SwitchingKey(params, rk_host[n]) for n in self.ids]
         self.crs = crs
+        self.hoist = None
+        if hoisted and self.ids:
+            self.hoist = [mkrlwe.SwitchingKey(params, zero=False) for _ in self.ids]
+            check(lib().mkhe_hoisted_form(params.ctx, level, self.sub.h, handle_array([h.h for h in self.hoist])))
         self.galEl = params.GaloisElementForColumnRotationBy(rotidx)
         self.full = mkrlwe.NewCiphertext(params, self.names, level)
         self.out = mkrlwe.NewCiphertext(params, self.names, level)
@@ -181,7 +208,8 @@ class HipRotateBackend:
         self.tpart = torch.as_tensor(_DevView(self.part.devptr(), (1 + len(self.ids)) * L * N), device=dev).view(1 + len(self.ids), L, N)
 
     def partial(self):
-        self.check(self.lib().mkhe_rotate_partial(self.params.ctx, self.sub.h, None, self.harr([k.h for k in self.keys]),
+        self.check(self.lib().mkhe_rotate_partial(self.params.ctx, self.sub.h, self.harr([h.h for h in self.hoist]) if self.hoist else None,
+                                                  self.harr([k.h for k in self.keys]),
                                                   self.crs.h, 1 if self.with_c0 else 0, self.part.h))
         self.params.sync()
         self.tfull.zero_()

@@ -167,8 +167,9 @@ def test_sharded_rotate_gloo_world2(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hoisted", [False, True])
 @pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_rotate_device_emulated_ranks(world):
+def test_sharded_rotate_device_emulated_ranks(world, hoisted):
     import torch
     from mkhe_kklss_amd import mkrlwe
     from mkhe_kklss_amd.dist import HipRotateBackend
@@ -178,7 +179,7 @@ def test_sharded_rotate_device_emulated_ranks(world):
     bs = []
     for r in range(world):
         params = mkrlwe.Parameters(pset["logN"], pset["Q"], pset["P"], 2)
-        bs.append(HipRotateBackend(params, names, r, world, ct, rk, params.AddCRS(3, crs), 3, level, torch, 0))
+        bs.append(HipRotateBackend(params, names, r, world, ct, rk, params.AddCRS(3, crs), 3, level, torch, 0, hoisted=hoisted))
     parts = [b.partial().clone() for b in bs]
     tot = sum(parts[1:], parts[0])
     b = bs[0]
@@ -336,3 +337,25 @@ def test_two_real_ranks_on_one_gpu(tmp_path, mode):
     out = str(tmp_path / "ok.npy")
     mp.spawn(_two_rank_gpu_worker, args=(2, port, mode, out), nprocs=2, join=True)
     assert np.load(out)[0]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_self_launch_on_one_gpu():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must spawn its two ranks itself and print ONE JSON line with
+    n_gpus == 2.  On a single-GPU box both ranks share GPU 0 and gloo carries the tensors through the host
+    (MKHE_DIST_ONE_DEVICE / MKHE_DIST_BACKEND): the figures are meaningless, the path is the real one."""
+    import json
+    import subprocess
+    env = dict(os.environ, MKHE_DIST_ONE_DEVICE="1", MKHE_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--params", "PN14QP439", "--parties", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["scaling"] == "strong"
+    assert out["value"] > 0 and out["steps"] == 2 and out["warmup"] == 1
+    legs = out["config"]["legs"]
+    assert {"party", "rotate_hoisted", "limb"} <= set(legs) and all(v["ms_per_step"] > 0 for v in legs.values())
