@@ -125,7 +125,7 @@ def run_cnn(args):
     params.GenDefaultCRS(seed=args.seed)
     for r in HC.ROTS:
         params.AddCRS(r, seed=args.seed)
-    kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(args.seed)))
+    kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(args.seed), insecure_test_only=True))
     rlkSet, rtkSet = mkrlwe.RelinearizationKeySet(params), mkrlwe.RotationKeySet()
     t0 = time.perf_counter()
     for id in sorted(set(owners.values())):
@@ -352,7 +352,7 @@ def run_single(args):
 
         # ---- one party's relinearization key generated on the device (samples drawn on the host beforehand,
         # their upload included) and one CRS expanded from the public seed instead of uploaded
-        kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(args.seed + 5)))
+        kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(args.seed + 5), insecure_test_only=True))
         params.AddCRS(0)
         sk, r = kgen.GenSecretKey("user0"), kgen.GenSecretKey("user0")
         e = kgen.sampler.gaussian(3 * params.Beta(level), params.N())

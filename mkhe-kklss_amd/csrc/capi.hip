@@ -13,13 +13,18 @@ struct mkhe_graph { hipGraphExec_t exec; };
 
 static thread_local std::string g_err;
 
+// An exception may leave the context in the middle of a forked chain (active stream still the side stream, a side chain that
+// writes into the caller's output never joined, a MulAndRelin plan half executed): recover() puts the context back into its
+// idle state and drains both streams before the error is reported, so that the caller may free its handles safely.
+static thread_local Context* g_last_ctx = nullptr;
 #define MKHE_TRY(body) try { body; return 0; } \
-    catch (const std::exception& e) { g_err = e.what(); return 1; } \
-    catch (...) { g_err = "mkhe: unknown error"; return 1; }
+    catch (const std::exception& e) { g_err = e.what(); if (g_last_ctx) g_last_ctx->recover(); return 1; } \
+    catch (...) { g_err = "mkhe: unknown error"; if (g_last_ctx) g_last_ctx->recover(); return 1; }
 
 // every entry point goes through this: a null context is an error of the caller, reported like any other
 static Context* need(const mkhe_ctx* ctx) {
-    if (!ctx || !ctx->c) throw Error("mkhe: null context");
+    if (!ctx || !ctx->c) { g_last_ctx = nullptr; throw Error("mkhe: null context"); }
+    g_last_ctx = ctx->c;
     return ctx->c;
 }
 
@@ -44,7 +49,7 @@ int mkhe_ctx_create(mkhe_ctx** out, int logN, const uint64_t* Q, int nQ, const u
         *out = new mkhe_ctx{new Context(logN, Q, nQ, P, nP, gamma, psiQ, psiP, device)};
     })
 }
-void mkhe_ctx_destroy(mkhe_ctx* ctx) { if (ctx) { delete ctx->c; delete ctx; } }
+void mkhe_ctx_destroy(mkhe_ctx* ctx) { if (ctx) { if (g_last_ctx == ctx->c) g_last_ctx = nullptr; delete ctx->c; delete ctx; } }
 int mkhe_ctx_sync(mkhe_ctx* ctx) { MKHE_TRY(need(ctx)->sync()) }
 int mkhe_capture_begin(mkhe_ctx* ctx) {
     MKHE_TRY({

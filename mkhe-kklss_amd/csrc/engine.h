@@ -149,7 +149,8 @@ class Context {
     enum { PROF_NTT_DECOMP = 0, PROF_NTT_DECOMP_BIGQ, PROF_NTT_DECOMP_MIXED, PROF_NTT16_DECOMP, PROF_NTT16_FWD, PROF_NTT_FWD, PROF_NTT_FWD_BIGQ, PROF_NTT_INV, PROF_INNER, PROF_EXT_INNER,
            PROF_MODDOWN, PROF_TENSOR, PROF_BASISCONV, PROF_OTHER, PROF_NCLASS };
     void prof_enable(bool on);
-    void prof_collect(double* ms, long* launches, double* alg_bytes);   // arrays of PROF_NCLASS; syncs and resets
+    void prof_collect(double* ms, long* launches, double* alg_bytes);
+    void recover();             // after an exception: active stream back to the main stream, plans dropped, both streams drained   // arrays of PROF_NCLASS; syncs and resets
 
     // device tables (public for the C ABI accessors / tests)
     Mod* d_mods = nullptr;
@@ -179,6 +180,7 @@ class Context {
     u64* tbuf_ = nullptr;  size_t tbuf_words_ = 0;          // t_i of step F
     // key generation scratch: uploaded samples, gadget constants (slot 0: mkrlwe gadget, 1: caller's), permuted secret
     int32_t* kg_small_ = nullptr; u64 *kg_g_ = nullptr, *kg_sk_ = nullptr;
+    void wipe_samples(size_t count);
     bool kg_ready_ = false;
     void kg_init();
     // out <- NTT(e_i) for beta_max error polynomials, then the combine pass (keygen_kernels.h); gadget: 0 none, 1 mkrlwe
@@ -216,7 +218,16 @@ class Context {
         bool x_pending = false;              // x still running on the side stream (chain 2)
     } plan_;
 
-    std::vector<std::pair<size_t, u64*>> free_list_;
+    // Stream-ordered buffer pool.  A buffer freed through this context may still be read by kernels that ANOTHER context of the
+    // same device enqueued (handles are shared freely between forked contexts): every free is stamped with the registry's epoch,
+    // and before a buffer freed after the last fence is reused, a fence (one event per live context of the device, recorded on its
+    // main stream) is taken and this context's stream waits for it (pool_alloc).  Single-context processes never fence.
+    struct FreeEntry { size_t words; u64* p; unsigned long long epoch; };
+    std::vector<FreeEntry> free_list_;
+    hipEvent_t fence_ev_ = nullptr;
+    void registry_add();
+    void registry_remove();
+    unsigned long long waited_epoch_ = 0;
 
     struct ProfRec { hipEvent_t e0, e1; int cls; double bytes; };
     bool prof_on_ = false;

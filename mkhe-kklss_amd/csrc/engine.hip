@@ -1,5 +1,6 @@
 // engine.hip -- Context: host-side table generation + orchestration of the HIP kernels.
 #include "engine.h"
+#include <mutex>
 #include <algorithm>
 #include <cstring>
 
@@ -96,6 +97,7 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     MKHE_HIP(hipSetDevice(device));
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    registry_add();
     for (auto& e : ev_) MKHE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     s_ = stream;
 
@@ -265,23 +267,58 @@ Context::~Context() {
                     (void*)kg_small_, (void*)kg_g_, (void*)kg_sk_})
         if (p) (void)hipFree(p);
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
-    for (auto& f : free_list_) (void)hipFree(f.second);
+    for (auto& f : free_list_) (void)hipFree(f.p);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    registry_remove();
+    if (fence_ev_) (void)hipEventDestroy(fence_ev_);
     if (xev_) (void)hipEventDestroy(xev_);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
+// live contexts per device: who may still be using a buffer that some context returns to its pool
+namespace {
+struct DeviceRegistry { std::mutex mu; std::vector<Context*> live; unsigned long long epoch = 1, fence_epoch = 0; };
+DeviceRegistry& registry(int device) { static DeviceRegistry r[64]; return r[device & 63]; }
+}
+void Context::registry_add() { auto& r = registry(device); std::lock_guard<std::mutex> g(r.mu); r.live.push_back(this); }
+void Context::registry_remove() {
+    auto& r = registry(device); std::lock_guard<std::mutex> g(r.mu);
+    for (size_t i = 0; i < r.live.size(); ++i) if (r.live[i] == this) { r.live.erase(r.live.begin() + i); break; }
+}
 u64* Context::pool_alloc(size_t words) {
     for (size_t i = 0; i < free_list_.size(); ++i)
-        if (free_list_[i].first == words) { u64* p = free_list_[i].second; free_list_.erase(free_list_.begin() + i); return p; }
+        if (free_list_[i].words == words) {
+            const FreeEntry e = free_list_[i];
+            free_list_.erase(free_list_.begin() + i);          // the oldest matching entry: most likely already behind a fence
+            auto& r = registry(device);
+            std::lock_guard<std::mutex> g(r.mu);
+            if (r.live.size() > 1 && waited_epoch_ < e.epoch) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(stream, &cs);
+                if (cs == hipStreamCaptureStatusNone) {           // (a capture keeps its temporaries alive itself)
+                    if (r.fence_epoch < e.epoch) {
+                        for (Context* m : r.live) {
+                            if (!m->fence_ev_) MKHE_HIP(hipEventCreateWithFlags(&m->fence_ev_, hipEventDisableTiming));
+                            MKHE_HIP(hipEventRecord(m->fence_ev_, m->stream));
+                        }
+                        r.fence_epoch = r.epoch++;
+                    }
+                    for (Context* m : r.live) if (m != this && m->fence_ev_) MKHE_HIP(hipStreamWaitEvent(stream, m->fence_ev_, 0));
+                    waited_epoch_ = r.fence_epoch;
+                }
+            }
+            return e.p;
+        }
     MKHE_HIP(hipSetDevice(device));
     return dev_alloc_words(words);
 }
 void Context::pool_free(u64* p, size_t words) {
     if (!p) return;
-    if (free_list_.size() >= 64) { (void)hipStreamSynchronize(stream); (void)hipFree(p); return; }
-    free_list_.push_back({words, p});
+    if (free_list_.size() >= 64) { (void)hipDeviceSynchronize(); (void)hipFree(p); return; }
+    auto& r = registry(device);
+    std::lock_guard<std::mutex> g(r.mu);
+    free_list_.push_back({words, p, r.epoch});
 }
 u64* Context::scratch(u64*& p, size_t& have, size_t want) {
     if (have < want) {
@@ -315,6 +352,14 @@ Context::ProfScope::~ProfScope() { if (on) (void)hipEventRecord(c->prof_recs_[id
 void Context::fork_side(int k) { if (!overlap) return; MKHE_HIP(hipEventRecord(ev_[2 * k], s_)); MKHE_HIP(hipStreamWaitEvent(stream2, ev_[2 * k], 0)); }
 void Context::side_done(int k) { if (!overlap) return; MKHE_HIP(hipEventRecord(ev_[2 * k + 1], stream2)); }
 void Context::join_side(int k) { if (!overlap) return; MKHE_HIP(hipStreamWaitEvent(s_, ev_[2 * k + 1], 0)); }
+void Context::recover() {
+    s_ = stream;
+    plan_.valid = false; plan_.x_pending = false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cs);
+    if (cs == hipStreamCaptureStatusNone) { (void)hipStreamSynchronize(stream2); (void)hipStreamSynchronize(stream); }
+    (void)hipGetLastError();
+}
 void Context::wait_for(Context& other) {
     if (&other == this) return;
     if (other.device != device) throw Error("mkhe: wait_for needs two contexts on the same device");
@@ -932,6 +977,9 @@ void Context::rescale(const Ct& in, int nb, Ct& out) {
     const int np_ = 1 + in.n;
     const size_t PI = (size_t)in.limbs * N, PO = (size_t)out.limbs * N;
     if (nb == 0) { if (out.d != in.d) MKHE_HIP(hipMemcpyAsync(out.d, in.d, np_ * PI * sizeof(u64), hipMemcpyDeviceToDevice, s_)); return; }
+    // source and destination polynomials have different strides (in.limbs vs out.limbs): in place the threads of one polynomial
+    // would overwrite limbs of the next one that other threads still read
+    if (out.d == in.d) throw Error("cannot Rescale in place: ctOut must not alias ctIn when levels are dropped");
     if (nb == 1) {
         launch_div_round_last(out.d, in.d, d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, np_, (long)PI, (long)PO, s_);
     } else {

@@ -35,6 +35,12 @@ void Context::kg_init() {
     kg_ready_ = true;
 }
 
+// the uploaded small-norm samples (secret / error coefficients) are consumed by small_expand_kernel on the same stream: zero the
+// scratch right behind it, so that secret material does not linger in a reusable device buffer
+void Context::wipe_samples(size_t count) {
+    MKHE_HIP(hipMemsetAsync(kg_small_, 0, count * sizeof(int32_t), s_));
+}
+
 void Context::kg_upload_g(const u64* g_plain) {
     kg_init();
     std::vector<u64> g((size_t)beta_max * mtot);
@@ -52,6 +58,7 @@ void Context::kg_key(const int32_t* e, int gadget, const u64* skA, const u64* cr
         ProfScope ps(this, PROF_OTHER, (double)beta_max * N * (4.0 + 8.0 * mtot));
         launch_small_expand(out, kg_small_, d_mods, beta_max, mtot, N, s_);
     }
+    wipe_samples((size_t)beta_max * N);
     ntt(out, out, beta_max, mtot, 0, false, false);
     KeygenArgs a{};
     a.out = out; a.skA = skA; a.g = gadget ? kg_g_ + (gadget == 2 ? (size_t)beta_max * mtot : 0) : nullptr;
@@ -69,6 +76,7 @@ void Context::keygen_secret(const int32_t* s, u64* dev_sk) {
     MKHE_HIP(hipMemcpyAsync(kg_small_, s, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     sync();
     launch_small_expand(dev_sk, kg_small_, d_mods, 1, mtot, N, s_);
+    wipe_samples((size_t)N);
     ntt(dev_sk, dev_sk, 1, mtot, 0, false, false);
     launch_mform(dev_sk, dev_sk, d_mods, d_map_id, mtot, N, s_);
     MKHE_HIP(hipGetLastError());
@@ -82,6 +90,7 @@ void Context::keygen_public_key(const u64* sk, const int32_t* e, const u64* crs_
     MKHE_HIP(hipMemcpyAsync(kg_small_, e, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     sync();
     launch_small_expand(pk, kg_small_, d_mods, 1, mtot, N, s_);
+    wipe_samples((size_t)N);
     ntt(pk, pk, 1, mtot, 0, false, false);
     MKHE_HIP(hipMemcpyAsync(pk + pw, crs_a, pw * sizeof(u64), hipMemcpyDeviceToDevice, s_));      // pk[1] = CRS[0].Value[0]
     KeygenArgs a{};
@@ -106,12 +115,14 @@ void Context::keygen_rotation_key(u64 galEl, const u64* sk, const int32_t* e, co
     for (u64 ex = n2 - 1; ex; ex >>= 1) { if (ex & 1) inv = inv * bs % n2; bs = bs * bs % n2; }
     launch_permute_ntt(kg_sk_, sk, mtot, logN, inv, s_);
     kg_key(e, 1, sk, crs, kg_sk_, -1, false, out);
+    MKHE_HIP(hipMemsetAsync(kg_sk_, 0, (size_t)mtot * N * sizeof(u64), s_));       // the permuted secret does not outlive the call
 }
 
 void Context::keygen_conjugation_key(const u64* sk, const int32_t* e, const u64* crs, u64* out) {
     kg_init();
     launch_permute_ntt(kg_sk_, sk, mtot, logN, 2 * (u64)N - 1, s_);
     kg_key(e, 1, kg_sk_, crs, sk, -1, false, out);
+    MKHE_HIP(hipMemsetAsync(kg_sk_, 0, (size_t)mtot * N * sizeof(u64), s_));
 }
 
 void Context::bfv_keygen_switching_key(const u64* sk, const u64* g, const int32_t* e, u64* out) {

@@ -4,6 +4,7 @@ Orchestration and float64 scale bookkeeping stay on the host exactly as in
 mkckks/evaluator.go:359-443,543-617; all polynomial work runs on the device via mkrlwe.KeySwitcher.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -65,11 +66,19 @@ class Evaluator:
     # ---- AddNew / SubNew (evaluator.go:316-357 -> evaluateInPlace :200-304)
     def _binary(self, op0, op1, fn):
         s0, s1 = op0.ScalingFactor(), op1.ScalingFactor()
-        # the reference first multiplies the operand with the smaller scale by floor(ratio) when that is > 1
-        # (MultByConst, :214-281); that branch is not on the accelerated path
-        if (s0 > s1 and s0 // s1 > 1) or (s1 > s0 and s1 // s0 > 1):
-            raise MkheError("mkhe: Add/Sub of ciphertexts whose scales differ by a factor > 1 is not on the device path")
+        # scale matching (evaluateInPlace :270-292, the branch for a fresh ctOut): the operand with the smaller scale is
+        # first multiplied by floor(ratio) when that is > 1 -- MultByConst with an integer-valued float64, i.e. constant scale 1
+        # -- into a pool element; the result carries max(s0, s1) like the reference's (the residual factor is not tracked)
+        if s1 > s0 and math.floor(s1 / s0) > 1:
+            tmp = NewCiphertext(self.params, op0.ids, op0.Level(), s0, zero=False)
+            self.MultByConst(op0, float(math.floor(s1 / s0)), tmp)
+            op0 = tmp
+        elif s0 > s1 and math.floor(s0 / s1) > 1:
+            tmp = NewCiphertext(self.params, op1.ids, op1.Level(), s1, zero=False)
+            self.MultByConst(op1, float(math.floor(s0 / s1)), tmp)
+            op1 = tmp
         ctOut = self.newCiphertextBinary(op0, op1)
+        ctOut.Scale = max(s0, s1)
         check(fn(self.params.ctx, op0.h, op1.h, ctOut.h))
         return ctOut
 

@@ -41,7 +41,14 @@ class Parameters:
         return h
 
     def close(self):
+        """destroys the engine context.  The CRS handles point back at this object (a reference cycle whose finalizers run in
+        arbitrary order), so they are released here first; handles that outlive the context are freed by their own
+        finalizer through the context-less path of mkhe_*_destroy (plain hipFree)."""
         if getattr(self, "ctx", None):
+            if getattr(self, "_parent", None) is None:          # a fork shares its parent's CRS dictionary
+                for key in list(getattr(self, "CRS", {}).values()):
+                    key.__del__()
+                self.CRS.clear()
             lib().mkhe_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -206,8 +213,8 @@ class SwitchingKey:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None) and self.params.ctx:
-                lib().mkhe_swk_destroy(self.params.ctx, self.h)
+            if getattr(self, "h", None):
+                lib().mkhe_swk_destroy(self.params.ctx, self.h)          # ctx None (context already closed): plain hipFree
                 self.h = None
         except Exception:
             pass
@@ -363,8 +370,8 @@ class Ciphertext:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None) and self.params.ctx:
-                lib().mkhe_ct_destroy(self.params.ctx, self.h)
+            if getattr(self, "h", None):
+                lib().mkhe_ct_destroy(self.params.ctx, self.h)           # ctx None (context already closed): plain hipFree
                 self.h = None
         except Exception:
             pass
@@ -479,26 +486,49 @@ class PublicKey:
 
 class HostSampler:
     """The small-norm samples of lattigo's ring.TernarySampler / ring.GaussianSampler, drawn on the HOST: secret
-    randomness never comes from the GPU.  `rng` is a numpy Generator; the default one is seeded from os.urandom but
-    PCG64 is not a cryptographic generator -- a deployment passes its own sampler object with these two methods
-    (the Go shim copies the samples out of lattigo's samplers)."""
+    randomness never comes from the GPU.
 
-    def __init__(self, rng=None, sigma=3.2):
-        import os
-        self.rng = rng if rng is not None else np.random.Generator(np.random.PCG64(int.from_bytes(os.urandom(16), "little")))
+    Default (no argument): every draw is fed by os.urandom -- the kernel CSPRNG, the counterpart of lattigo's keyed
+    blake2b XOF (utils.NewPRNG, keygen.go:26).  Uniform 64-bit words become 53-bit uniforms; ternary values come from
+    one uniform each, Gaussians from Box-Muller pairs, rounded, and redrawn while |.| > 6 sigma like lattigo's sampler.
+
+    `rng` (a numpy Generator) replaces the entropy source for REPRODUCIBLE TESTS AND BENCHMARKS ONLY and must be
+    acknowledged with insecure_test_only=True: numpy's generators are not cryptographic."""
+
+    def __init__(self, rng=None, sigma=3.2, insecure_test_only=False):
+        if rng is not None and not insecure_test_only:
+            raise MkheError("HostSampler: a numpy Generator is not a cryptographic source -- pass insecure_test_only=True "
+                            "(tests / benchmarks), or no rng at all for os.urandom")
+        self.rng = rng
         self.sigma, self.bound = float(sigma), int(6 * float(sigma))        # rlwe.DefaultSigma, keygen.go:36
+
+    def _uniform(self, n):
+        """n uniforms in [0, 1) with 53 random bits each"""
+        if self.rng is not None:
+            return self.rng.random(n)
+        import os
+        w = np.frombuffer(os.urandom(8 * n), dtype=np.uint64)
+        return (w >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+    def _normal(self, n):
+        if self.rng is not None:
+            return self.rng.normal(0.0, self.sigma, n)
+        m = (n + 1) // 2
+        u1, u2 = 1.0 - self._uniform(m), self._uniform(m)                   # u1 in (0, 1]
+        r = np.sqrt(-2.0 * np.log(u1)) * self.sigma
+        return np.concatenate([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)])[:n]
 
     def ternary(self, N, p=0.5):
         """0 with probability p, +-1 with (1-p)/2 each (GenSecretKeyWithDistrib keygen.go:69-76)"""
-        u = self.rng.random(N)
+        u = self._uniform(N)
         return np.where(u < p, 0, np.where(u < p + (1 - p) / 2, 1, -1)).astype(np.int32)
 
     def gaussian(self, count, N):
         """round(N(0, sigma)), resampled while |.| > bound"""
-        e = np.rint(self.rng.normal(0.0, self.sigma, (count, N)))
+        e = np.rint(self._normal(count * N)).reshape(count, N)
         bad = np.abs(e) > self.bound
         while bad.any():
-            e[bad] = np.rint(self.rng.normal(0.0, self.sigma, int(bad.sum())))
+            e[bad] = np.rint(self._normal(int(bad.sum())))
             bad = np.abs(e) > self.bound
         return e.astype(np.int32)
 

@@ -1,7 +1,8 @@
 """Test-side pieces of the reference's encrypted-CNN caller (cnn/cnn_test.go): parameter set, slot packing of the
 image / kernels / FC matrices / biases, a plaintext model of the network and of the slot-level circuit, and an
 O(N log N) CKKS encoder.  The reference's MNIST file is absent and nothing under /root/reference may be
-read at run time, so the model weights and the image are synthetic (seeded); what is checked is encrypted == plaintext.
+read at run time, so the image is synthetic (seeded); the model is either synthetic or the reference's trained weights (reference_model, a
+committed fixture); what is checked is encrypted == plaintext.
 
 Network (cnn_test.go:21-36): 28x28 image -> 5 kernels 4x4, stride 2 -> 13x13x5 -> square -> FC 845 -> 64 (+B1)
 -> square -> FC 64 -> 10 (+B2).
@@ -23,6 +24,18 @@ def synthetic_model(seed):
     rng = np.random.default_rng(seed)
     return dict(image=rng.random((IMG, IMG)), kernels=rng.normal(0, 0.3, (NK, KS, KS)), FC1=rng.normal(0, 0.05, (CO * CO * NK, NFC)),
                 FC2=rng.normal(0, 0.1, (NFC, NCLS)), B1=rng.normal(0, 0.1, NFC), B2=rng.normal(0, 0.1, NCLS))
+
+
+def reference_model(seed):
+    """the trained model of the reference's own test (cnn/data/{k1,FC1,FC2,B1,B2}.txt, loaded as cnn_test.go:234-349 does; stored
+    as tests/golden/cnn_weights.npz by tests/golden/make_cnn_weights.py) with a seeded synthetic image: the reference's MNIST
+    csv (cnn_test.go:65) is not part of its repository."""
+    import os
+    w = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cnn_weights.npz"))
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:IMG, 0:IMG]
+    img = np.clip(np.exp(-((xx - 14 + 3 * np.sin(yy / 4.0)) ** 2) / 8.0) + 0.05 * rng.random((IMG, IMG)), 0, 1)      # a stroke, values in [0, 1]
+    return dict(image=img, kernels=w["kernels"], FC1=w["FC1"], FC2=w["FC2"], B1=w["B1"], B2=w["B2"])
 
 
 def plain_forward(m):
@@ -171,7 +184,7 @@ class CnnScenario:
             params.AddCRS(r, seed=seed)
         self.hkg = H.KeyGen(O.KeySwitcher(p["logN"], p["Q"], p["P"], 2), seed)          # host encryptor / decryptor
         self.enc = FastEncoder(p["logN"])
-        kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(seed)))
+        kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(seed), insecure_test_only=True))
         self.rlkSet, self.rtkSet = mkrlwe.RelinearizationKeySet(params), mkrlwe.RotationKeySet()
         self.sk, self.pk = {}, {}
         rots = ROTS + [1 << i for i in range(p["logN"] - 1)]

@@ -12,11 +12,13 @@ TWO = dict(image="dataOwner", kernels="modelOwner", fc1="modelOwner", fc2="model
 FOUR = dict(image="dataOwner", kernels="convOwner", fc1="fc1Owner", fc2="fc2Owner")              # BASELINE.json configs[4]: 4 parties
 
 
+@pytest.mark.parametrize("weights", ["synthetic", "reference"])
 @pytest.mark.parametrize("owners", [TWO, FOUR], ids=["2party", "4party"])
-def test_encrypted_cnn_matches_plaintext(owners):
+def test_encrypted_cnn_matches_plaintext(owners, weights):
+    """weights = reference: the trained model the reference's TestCNN loads (cnn/data/*.txt as a committed fixture)"""
     from mkhe_kklss_amd import cnn
     sc = HC.CnnScenario(owners, seed=3)
-    model = HC.synthetic_model(7)
+    model = HC.synthetic_model(7) if weights == "synthetic" else HC.reference_model(7)
     cts = sc.encrypt_model(model)
     # the mask is multiplied into square2Out, which sits 4 levels below the fresh ciphertexts
     pt, pt_scale = sc.mask_plaintext(sc.level - 4)

@@ -29,7 +29,7 @@ class Pair:
         self.okg = O.KeyGen(self.ks)
         self.rng = np.random.default_rng(seed)
         self.N, self.beta = self.ks.N, self.ks.beta_max
-        self.kgen = mkrlwe.NewKeyGenerator(self.params, mkrlwe.HostSampler(np.random.default_rng(seed + 1)))
+        self.kgen = mkrlwe.NewKeyGenerator(self.params, mkrlwe.HostSampler(np.random.default_rng(seed + 1), insecure_test_only=True))
 
     def ternary(self):
         return self.rng.choice(np.array([-1, 0, 0, 1], dtype=np.int32), self.N)
@@ -111,7 +111,7 @@ def test_missing_crs_raises(pr):
 
 def test_sampler_statistics(pr):
     """the host sampler draws what lattigo's samplers draw: ternary with P(0) = 1/2, rounded Gaussian sigma 3.2, |e| <= 19"""
-    smp = pr.mk.HostSampler(np.random.default_rng(3))
+    smp = pr.mk.HostSampler(np.random.default_rng(3), insecure_test_only=True)
     t = smp.ternary(1 << 16)
     assert set(np.unique(t)) == {-1, 0, 1} and abs((t == 0).mean() - 0.5) < 0.02 and abs((t == 1).mean() - 0.25) < 0.02
     g = smp.gaussian(4, 1 << 14)

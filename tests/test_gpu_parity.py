@@ -283,9 +283,22 @@ def test_ckks_add_sub(pair):
     assert (ga[1] == h0[1][:L]).all() and (gs[1] == h0[1][:L]).all()
     assert (ga[2] == f("add", h0[2], h1[1])).all() and (gs[2] == f("sub", h0[2], h1[1])).all()
     assert (ga[3] == h1[2]).all() and (gs[3] == np.stack([rq.neg(j, h1[2][j]) for j in range(L)])).all()
-    c2 = mkckks.NewCiphertext(params, ["a"], pair.maxlevel, 2.0 ** 45)
-    with pytest.raises(pair.mk.MkheError, match="scales differ"):
-        ev.AddNew(c0, c2)
+    # scale matching (evaluator.go:270-292): the operand with the smaller scale is multiplied by floor(ratio) first
+    h2 = H.uniform_ct(pair.rng, pair.ks, 1, pair.maxlevel + 1)
+    c2 = mkckks.NewCiphertext(params, ["a"], pair.maxlevel, 2.0 ** 45 * 1.5).upload(h2)
+    ratio = int((2.0 ** 45 * 1.5) // 2.0 ** 40)                       # 48
+    for (x, y), fn in (((c0, c2), "add"), ((c2, c0), "sub")):
+        r = (ev.AddNew if fn == "add" else ev.SubNew)(x, y)
+        assert r.Scale == 2.0 ** 45 * 1.5 and r.Level() == pair.maxlevel and r.ids == ["a", "b"]
+        g = r.download()
+        Lf = pair.maxlevel + 1
+        sc = lambda p: np.stack([rq.mul_scalar(j, p[j], ratio) for j in range(Lf)])        # the scaled c0
+        ff = lambda a_, b_: np.stack([getattr(rq, fn)(j, a_[j], b_[j]) for j in range(Lf)])
+        if fn == "add":
+            assert (g[0] == ff(sc(h0[0]), h2[0])).all() and (g[1] == ff(sc(h0[1]), h2[1])).all() and (g[2] == sc(h0[2])).all()
+        else:
+            assert (g[0] == ff(h2[0], sc(h0[0]))).all() and (g[1] == ff(h2[1], sc(h0[1]))).all()
+            assert (g[2] == np.stack([rq.neg(j, sc(h0[2])[j]) for j in range(Lf)])).all()
 
 
 @pytest.mark.parametrize("constant", [3, -2.5, 0.75 + 1.25j, -4 + 0j])
