@@ -121,7 +121,7 @@ def run_cnn(args):
     p = HC.PN14QP433
     owners = (dict(image="dataOwner", kernels="modelOwner", fc1="modelOwner", fc2="modelOwner") if args.parties <= 2 else
               dict(image="dataOwner", kernels="convOwner", fc1="fc1Owner", fc2="fc2Owner"))
-    params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"], device=0)
+    params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"], device=getattr(args, "device", 0))
     params.GenDefaultCRS(seed=args.seed)
     for r in HC.ROTS:
         params.AddCRS(r, seed=args.seed)
@@ -448,8 +448,9 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     if args.gpus > 1 or world > 1 or args.force_dist:
-        from bench_dist import run_distributed
-        out = run_distributed(args)
+        import bench_dist
+        out = (bench_dist.run_distributed_bfv if args.scheme == "bfv" else bench_dist.run_replicas_cnn if args.scheme == "cnn"
+               else bench_dist.run_distributed)(args)
     elif args.scheme == "bfv":
         out = run_bfv(args)
     elif args.scheme == "cnn":

@@ -31,16 +31,7 @@ def _timed(dist, torch, params, fn, steps, warmup):
     return float(dt.item())
 
 
-def run_distributed(args):
-    import torch
-    import torch.distributed as dist
-    import harness as H
-    from bench import synth_party_keys, synth_cts, synth_swk
-    from mkhe_kklss_amd import mkckks, mkrlwe
-    from mkhe_kklss_amd._abi import check, lib
-    from mkhe_kklss_amd.dist import (HipLimbBackend, HipRotateBackend, HipShardBackend, LimbShardedMulRelin, ShardedMulRelin,
-                                     ShardedRotate, assign_parties, assign_units)
-
+def _init(torch, dist):
     # a plain `python bench.py --force-dist` (no launcher): single-rank rendezvous on the loopback interface
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
@@ -55,6 +46,77 @@ def run_distributed(args):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend_name, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def run_distributed_bfv(args):
+    """--scheme bfv at N > 1 (BASELINE.json configs[2] sharded): mkbfv MulRelinNew with whole parties per rank
+    (mkhe_kklss_amd/dist.py ShardedBfvMulRelin); needs N <= parties"""
+    import torch
+    import torch.distributed as dist
+    import harness_bfv as HB
+    from mkhe_kklss_amd import mkbfv
+    from mkhe_kklss_amd.dist import HipBfvShardBackend, ShardedBfvMulRelin, assign_parties
+    rank, world, local_rank = _init(torch, dist)
+    pset = HB.BFV_PN15QP880 if args.params == "PN15QP880" else HB.BFV_PN14QP439
+    k = args.parties
+    names = ["user%d" % i for i in range(k)]
+    data = HB.uniform_bfv_inputs(pset, k, args.seed)
+    params = mkbfv.Parameters(pset["logN"], pset["Q"], pset["QMul"], pset["P"], pset["T"], device=local_rank)
+    params.AddCRS(-1, data["u"])
+    mine = assign_parties(names, world)[rank]
+    rlk = {n: data["rlk"][names.index(n)] for n in mine}
+    b = HipBfvShardBackend(params, names, rank, world, data["op0"], data["op1"], rlk, torch, local_rank)
+    del data, rlk
+    smr = ShardedBfvMulRelin(b, dist)
+    dt = _timed(dist, torch, params, smr.run, args.steps, args.warmup)
+    out = None
+    if rank == 0:
+        out = dict(metric="mkbfv_mulrelin_per_sec", value=args.steps / dt, unit="MulRelin/s", n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps, higher_is_better=True, scaling="strong", vs_baseline=None,
+                   dtype="u64", data="synthetic",
+                   config=dict(workload="mkbfv %d-party MulRelinNew, %s, whole parties sharded over %d GPUs (RCCL all-reduce of x1, x2, "
+                                        "y1, y2, out_0; all-gather of out_i)" % (k, args.params, world), parties=k, params=args.params,
+                               seed=args.seed, rccl_ranks=dist.get_world_size()),
+                   roofline=None, cpu_baseline=None)
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def run_replicas_cnn(args):
+    """--scheme cnn at N > 1 (BASELINE.json configs[4]): the encrypted inference is one latency-bound circuit that does not shard;
+    every GPU runs its own inference (independent replicas, no data-path collective): weak scaling, value = inferences/s of the node"""
+    import torch
+    import torch.distributed as dist
+    from bench import run_cnn
+    rank, world, local_rank = _init(torch, dist)
+    args.device = local_rank
+    dist.barrier()
+    one = run_cnn(args)
+    t = torch.tensor([one["ms_per_step"]], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out = None
+    if rank == 0:
+        ms = float(t.item())
+        out = dict(one, value=world * 1e3 / ms, ms_per_step=ms, n_gpus=world, scaling="weak", roofline=None)
+        out["config"] = dict(one["config"], replicas=world, sharding="independent replicas: one inference per GPU, no collective")
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def run_distributed(args):
+    import torch
+    import torch.distributed as dist
+    import harness as H
+    from bench import synth_party_keys, synth_cts, synth_swk
+    from mkhe_kklss_amd import mkckks, mkrlwe
+    from mkhe_kklss_amd._abi import check, lib
+    from mkhe_kklss_amd.dist import (HipLimbBackend, HipRotateBackend, HipShardBackend, LimbShardedMulRelin, ShardedMulRelin,
+                                     ShardedRotate, assign_parties, assign_units)
+
+    rank, world, local_rank = _init(torch, dist)
     pset = {"PN15QP880": H.PN15QP880, "PN14QP439": H.PN14QP439, "PN16QP1761": H.PN16QP1761}[args.params]
     k = args.parties
     names = ["user%d" % i for i in range(k)]

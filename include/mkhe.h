@@ -218,17 +218,35 @@ int  mkhe_bfv_quantize(mkhe_ctx* ctx, const void* dev_polyr_ntt, void* dev_polyq
 int  mkhe_bfv_ntt_r(mkhe_ctx* ctx, const void* dev_src, void* dev_dst, int count, int inverse);
 /* KeySwitcher.DecomposeBFV (mkbfv/keyswitch.go:67-90): one PolyR (coefficient domain) -> ad1 (Q digits), ad2 (QMul digits) */
 int  mkhe_bfv_decompose(mkhe_ctx* ctx, const void* dev_polyr, mkhe_swk* ad1, mkhe_swk* ad2);
+/* KeySwitcher.ExternalProductBFV (mkbfv/keyswitch.go:83-113): the non-hoisted form -- DecomposeBFV of one PolyR (coefficient
+ * domain) into the engine's own pool, then the product below; c = [nQ][N], coefficient domain, canonical */
+int  mkhe_bfv_external_product(mkhe_ctx* ctx, const void* dev_polyr, const mkhe_swk* bg1, const mkhe_swk* bg2, void* dev_c);
 /* KeySwitcher.ExternalProductBFVHoisted (keyswitch_hoisted.go:6-34): c = ModDown_P(sum bg1.ah1 + bg2.ah2), [nQ][N] */
 int  mkhe_bfv_external_product_hoisted(mkhe_ctx* ctx, const mkhe_swk* ah1, const mkhe_swk* ah2,
                                        const mkhe_swk* bg1, const mkhe_swk* bg2, void* dev_c);
 /* Evaluator.MulRelinNew (mkbfv/evaluator.go:78-82) = mulRelinHoisted (:118-140) + MulAndRelinBFVHoisted
- * (keyswitch_hoisted.go:36-206).  Ciphertexts at the maximum level, coefficient domain.  Key lists aligned with
+ * (keyswitch_hoisted.go:36-206).  The reference's non-hoisted twin (Evaluator.mulRelin evaluator.go:95-113 ->
+ * KeySwitcher.MulAndRelinBFV keyswitch.go:115-251) decomposes the same polynomials inside its loops and yields the same
+ * ciphertext bit for bit (tests/test_bfv_oracle.py); on the device the decompositions are always batched, so both map here.
+ * Ciphertexts at the maximum level, coefficient domain.  Key lists aligned with
  * the operand ids: rlk_b1/b2[j] = rlkSet[ids1[j]].Value[0/1].Value[0], rlk_d1/d2[i] = rlkSet[ids0[i]].Value[0/1].Value[1],
  * rlk_v[i] = rlkSet[ids0[i]].Value[0].Value[2]; crs_u = params.CRS[-1]. */
 int  mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                         const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
                         const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2,
                         const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out);
+/* Party-sharded BFV MulRelinNew (no reference counterpart; mkhe_kklss_amd/dist.py ShardedBfvMulRelin; keyswitch_hoisted.go:76-206
+ * is the structure being cut): every rank holds c_0 and BOTH components of the parties it owns (Quantize rounds, so the two tensor
+ * terms of an output slot must meet on one rank).  mkhe_bfv_mr_partial: conversions, tensor + Quantize into `out` (out_0 only where
+ * with_c0), DecomposeBFV, and the rank's canonical partial sums of x1, x2, y1, y2 -- to be summed over the ranks and folded with
+ * mkhe_swk_fold(mform = 1); mkhe_bfv_mr_finish: steps E and F with the complete sums; out_0 and out_i are then partial
+ * sums / owner slots to be exchanged and folded with mkhe_ct_fold.  mkhe_bfv_mul_relin == partial(with_c0 = 1) + finish on one rank. */
+int  mkhe_bfv_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                         const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
+                         const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2, int with_c0, mkhe_ct* out,
+                         mkhe_swk* x1, mkhe_swk* x2, mkhe_swk* y1, mkhe_swk* y2);
+int  mkhe_bfv_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x1, const mkhe_swk* x2,
+                        const mkhe_swk* y1, const mkhe_swk* y2, const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out);
 
 /* ==== key generation and CRS expansion =========================================
  * mkrlwe/keygen.go, mkbfv/keygen.go, mkrlwe/params.go:16-61,77-99.  The reference draws secrets, errors and CRS from

@@ -446,6 +446,12 @@ int mkhe_bfv_decompose(mkhe_ctx* ctx, const void* polyr, mkhe_swk* ad1, mkhe_swk
         need(ctx)->bfv_decompose_batch({(const u64*)polyr}, {ad1->s.d}, {ad2->s.d});
     })
 }
+int mkhe_bfv_external_product(mkhe_ctx* ctx, const void* dev_polyr, const mkhe_swk* bg1, const mkhe_swk* bg2, void* dev_c) {
+    MKHE_TRY({
+        if (!dev_polyr || !bg1 || !bg2 || !dev_c) throw Error("mkhe_bfv_external_product: null argument");
+        need(ctx)->bfv_external_product((const u64*)dev_polyr, bg1->s.d, bg2->s.d, (u64*)dev_c);
+    })
+}
 int mkhe_bfv_external_product_hoisted(mkhe_ctx* ctx, const mkhe_swk* ah1, const mkhe_swk* ah2,
                                       const mkhe_swk* bg1, const mkhe_swk* bg2, void* dev_c) {
     MKHE_TRY({
@@ -462,6 +468,27 @@ int mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
         auto b1 = swk_list(rlk_b1, op1->c.n); auto b2 = swk_list(rlk_b2, op1->c.n);
         auto d1 = swk_list(rlk_d1, op0->c.n); auto d2 = swk_list(rlk_d2, op0->c.n); auto v = swk_list(rlk_v, op0->c.n);
         need(ctx)->bfv_mul_relin(op0->c, op1->c, b1.data(), b2.data(), d1.data(), d2.data(), v.data(), crs_u->s, out->c);
+    })
+}
+
+int mkhe_bfv_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                        const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
+                        const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2, int with_c0, mkhe_ct* out,
+                        mkhe_swk* x1, mkhe_swk* x2, mkhe_swk* y1, mkhe_swk* y2) {
+    MKHE_TRY({
+        if (!op0 || !op1 || !out || !rlk_b1 || !rlk_b2 || !rlk_d1 || !rlk_d2 || !x1 || !x2 || !y1 || !y2) throw Error("mkhe_bfv_mr_partial: null argument");
+        auto b1 = swk_list(rlk_b1, op1->c.n); auto b2 = swk_list(rlk_b2, op1->c.n);
+        auto d1 = swk_list(rlk_d1, op0->c.n); auto d2 = swk_list(rlk_d2, op0->c.n);
+        need(ctx)->bfv_mr_partial(op0->c, op1->c, b1.data(), b2.data(), d1.data(), d2.data(), with_c0 != 0, false, out->c,
+                                  x1->s.d, x2->s.d, y1->s.d, y2->s.d);
+    })
+}
+int mkhe_bfv_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x1, const mkhe_swk* x2,
+                       const mkhe_swk* y1, const mkhe_swk* y2, const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out) {
+    MKHE_TRY({
+        if (!op0 || !op1 || !out || !x1 || !x2 || !y1 || !y2 || !rlk_v || !crs_u) throw Error("mkhe_bfv_mr_finish: null argument");
+        auto v = swk_list(rlk_v, op0->c.n);
+        need(ctx)->bfv_mr_finish(op0->c, op1->c, x1->s.d, x2->s.d, y1->s.d, y2->s.d, v.data(), crs_u->s, out->c);
     })
 }
 

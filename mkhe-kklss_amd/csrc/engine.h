@@ -71,6 +71,14 @@ class Context {
     void bfv_quantize(const u64* polyr_ntt, u64* polyq, int npolys);          // conv.Quantize (polyr_ntt is consumed)
     void bfv_decompose_batch(const std::vector<const u64*>& srcr, const std::vector<u64*>& ad1, const std::vector<u64*>& ad2, bool internal = false);
     void bfv_external_product_hoisted(const u64* ah1, const u64* ah2, const u64* bg1, const u64* bg2, u64* c);
+    void bfv_external_product(const u64* polyr, const u64* bg1, const u64* bg2, u64* c);
+    void bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
+                        const Swk* const* rlk_d1, const Swk* const* rlk_d2, bool with_c0, bool mform, Ct& out,
+                        u64* x1, u64* x2, u64* y1, u64* y2);
+    void bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u64* x2, const u64* y1, const u64* y2,
+                       const Swk* const* rlk_v, const Swk& crs_u, Ct& out);
+    void bfv_slots(const Ct& op0, const Ct& op1, const Ct& out, std::vector<int>& slot0, std::vector<int>& slot1) const;
+    bool bfv_plan_valid_ = false;
     void bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
                        const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
                        const Swk& crs_u, Ct& out);                            // Evaluator.MulRelinNew

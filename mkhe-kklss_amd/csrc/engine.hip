@@ -1150,6 +1150,15 @@ void Context::bfv_decompose_batch(const std::vector<const u64*>& srcr, const std
     MKHE_HIP(hipGetLastError());
 }
 
+// ExternalProductBFV (mkbfv/keyswitch.go:83-113): DecomposeBFV into the engine's own pool (ks.swkPool1 / swkPool2 there), then the
+// same sum over digits, InvNTTLazy and ModDownQPtoQ as the hoisted form
+void Context::bfv_external_product(const u64* polyr, const u64* bg1, const u64* bg2, u64* c) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    u64* a1 = hoist_slot(3, 0).d; u64* a2 = hoist_slot(3, 1).d;
+    bfv_decompose_batch({polyr}, {a1}, {a2}, true);
+    bfv_external_product_hoisted(a1, a2, bg1, bg2, c);
+}
+
 // ExternalProductBFVHoisted (keyswitch_hoisted.go:6-34)
 void Context::bfv_external_product_hoisted(const u64* ah1, const u64* ah2, const u64* bg1, const u64* bg2, u64* c) {
     if (!is_bfv()) throw Error("mkhe: not a BFV context");
@@ -1160,24 +1169,36 @@ void Context::bfv_external_product_hoisted(const u64* ah1, const u64* ah2, const
 }
 
 // Evaluator.MulRelinNew = mulRelinHoisted (mkbfv/evaluator.go:78-82,118-140) followed by
-// KeySwitcher.MulAndRelinBFVHoisted (keyswitch_hoisted.go:36-206).
-void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
-                            const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
-                            const Swk& crs_u, Ct& out) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    const int level = nq - 1, L = nq, n0 = op0.n, n1 = op1.n;
-    if (op0.limbs != L || op1.limbs != L || out.limbs != L) throw Error("mkhe: BFV ciphertexts live at the maximum level");
+// KeySwitcher.MulAndRelinBFVHoisted (keyswitch_hoisted.go:36-206), in two phases so that the parties can be sharded over GPUs
+// (mkhe_kklss_amd/dist.py ShardedBfvMulRelin):
+//   bfv_mr_partial: ModUpQtoR / Rescale, tensor over R + Quantize (out_0 only where with_c0), DecomposeBFV of the party
+//                   components, the partial sums x1, x2, y1, y2 (MForm'ed when mform, canonical partial sums otherwise);
+//   bfv_mr_finish:  steps E and F with the complete x, y.
+// Quantize rounds, so both tensor terms of an output slot (op0_0 * op1_j + op0_j * op1_0) have to be added before it: a rank
+// must own whole parties (both components of every id it holds).
+void Context::bfv_slots(const Ct& op0, const Ct& op1, const Ct& out, std::vector<int>& slot0, std::vector<int>& slot1) const {
+    const int n0 = op0.n, n1 = op1.n;
+    if (op0.limbs != nq || op1.limbs != nq || out.limbs != nq) throw Error("mkhe: BFV ciphertexts live at the maximum level");
     if (n0 > 32 || n1 > 32 || out.n > 32) throw Error("mkhe: too many parties");
-    std::vector<int> slot0(n0), slot1(n1);
+    slot0.assign(n0, 0); slot1.assign(n1, 0);
     auto find = [&](int id) { for (int o = 0; o < out.n; ++o) if (out.ids[o] == id) return o; return -1; };
     std::vector<char> seen(out.n, 0);
     for (int a = 0; a < n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); slot0[a] = o; seen[o] = 1; }
     for (int a = 0; a < n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); slot1[a] = o; seen[o] = 1; }
     for (int o = 0; o < out.n; ++o) if (!seen[o]) throw Error("mkhe: ctOut has an id that neither operand has");
-    for (int a = 0; a < n0; ++a) if (!rlk_d1[a] || !rlk_d2[a] || !rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+}
+
+void Context::bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
+                             const Swk* const* rlk_d1, const Swk* const* rlk_d2, bool with_c0, bool mform, Ct& out,
+                             u64* x1, u64* x2, u64* y1, u64* y2) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    const int level = nq - 1, L = nq, n0 = op0.n, n1 = op1.n;
+    std::vector<int> slot0, slot1;
+    bfv_slots(op0, op1, out, slot0, slot1);
+    for (int a = 0; a < n0; ++a) if (!rlk_d1[a] || !rlk_d2[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
     for (int a = 0; a < n1; ++a) if (!rlk_b1[a] || !rlk_b2[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
 
-    const size_t PR = 2 * (size_t)nq * N, PQ = (size_t)nq * N;
+    const size_t PR = 2 * (size_t)nq * N;
     const int np0 = 1 + n0, np1 = 1 + n1, npo = 1 + out.n;
     // rbuf: [ct0R | ct1R | NTT(ct0R) | NTT(ct1R) | tensor out]
     u64* rb = scratch(rbuf_, rbuf_words_, (size_t)(2 * (np0 + np1) + npo) * PR);
@@ -1192,7 +1213,7 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
         ntt_r(r0, f0, np0 + np1, false);        // f0, f1 are contiguous like r0, r1
         TensorArgs ta{};
         ta.a0 = f0; ta.b0 = f1; ta.out = tz; ta.mods = d_mods; ta.map = d_map_r; ta.scale = d_t_mont;
-        ta.nout = out.n; ta.L = 2 * nq; ta.N = N; ta.with_c0 = 1;
+        ta.nout = out.n; ta.L = 2 * nq; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
         for (int a = 0; a < n0; ++a) { ta.a[1 + slot0[a]] = f0 + (size_t)(1 + a) * PR; ta.a_ls[1 + slot0[a]] = N; }
         for (int a = 0; a < n1; ++a) { ta.b[1 + slot1[a]] = f1 + (size_t)(1 + a) * PR; ta.b_ls[1 + slot1[a]] = N; }
         { ProfScope ps(this, PROF_TENSOR, 8.0 * N * 2 * nq * (2.0 + n0 + n1 + npo)); launch_tensor(ta, s_); }
@@ -1230,9 +1251,9 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
             ip.a[a] = key->d;
             ip.b[a] = side ? (half ? h1b[a] : h1a[a]) : (half ? h0b[a] : h0a[a]);
         }
-        ip.out = side ? (half ? y2_ : y_) : (half ? x2_ : x_);
+        ip.out = side ? (half ? y2 : y1) : (half ? x2 : x1);
         ip.mods = d_mods; ip.map = map_qp(level);
-        ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = beta_max; ip.N = N; ip.mform_out = 1;
+        ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = beta_max; ip.N = N; ip.mform_out = mform ? 1 : 0;
         const bool on_side = side == 0 && overlap;
         if (which == 1 && on_side) fork_side(2);
         if (on_side) s_ = stream2;
@@ -1240,10 +1261,27 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
         if (on_side) s_ = stream;
         if (which == 0 && on_side) side_done(2);
     }
+    // split-phase callers read x1, x2 between the phases (cross-device reduction): the side chain joins the main stream here
+    if (!mform) join_side(2);
+    bfv_plan_valid_ = true;
+    MKHE_HIP(hipGetLastError());
+}
+
+void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u64* x2, const u64* y1, const u64* y2,
+                            const Swk* const* rlk_v, const Swk& crs_u, Ct& out) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    if (!bfv_plan_valid_) throw Error("mkhe: bfv_mr_finish without bfv_mr_partial");
+    const int level = nq - 1, n0 = op0.n, n1 = op1.n;
+    std::vector<int> slot0, slot1;
+    bfv_slots(op0, op1, out, slot0, slot1);
+    for (int a = 0; a < n0; ++a) if (!rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+    const size_t PQ = (size_t)nq * N;
     // F1: t_i = <h(c0_i), (y1,y2)>
     u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PQ);
     std::vector<ExtItem> items;
-    for (int a = 0; a < n0; ++a) { ExtItem it{h0a[a], y_, tbuf + (size_t)a * PQ, false}; it.ah2 = h0b[a]; it.bg2 = y2_; items.push_back(it); }
+    for (int a = 0; a < n0; ++a) {
+        ExtItem it{hoist_slot(0, a).d, y1, tbuf + (size_t)a * PQ, false}; it.ah2 = hoist_slot(3, a).d; it.bg2 = y2; items.push_back(it);
+    }
     ext_batch(level, items);
     // F2: ks.Decompose(t_i) ; out_0 += <h(t_i), v_i> ; out_i += <h(t_i), u>
     {
@@ -1253,14 +1291,25 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
     }
     // E: out_j += <h(c1_j), (x1,x2)> together with F2
     items.clear();
-    for (int a = 0; a < n1; ++a) { ExtItem it{h1a[a], x_, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = h1b[a]; it.bg2 = x2_; items.push_back(it); }
+    for (int a = 0; a < n1; ++a) {
+        ExtItem it{hoist_slot(1, a).d, x1, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = hoist_slot(4, a).d; it.bg2 = x2; items.push_back(it);
+    }
     for (int a = 0; a < n0; ++a) {
         items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v[a]->d, out.d, true});
         items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true});
     }
     join_side(2);
     ext_batch(level, items, 1);        // joins the tensor / Quantize chain before the ModDown accumulates into out
+    bfv_plan_valid_ = false;
     MKHE_HIP(hipGetLastError());
+}
+
+void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
+                            const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
+                            const Swk& crs_u, Ct& out) {
+    for (int a = 0; a < op0.n; ++a) if (!rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+    bfv_mr_partial(op0, op1, rlk_b1, rlk_b2, rlk_d1, rlk_d2, true, true, out, x_, x2_, y_, y2_);
+    bfv_mr_finish(op0, op1, x_, x2_, y_, y2_, rlk_v, crs_u, out);
 }
 
 }  // namespace mkhe

@@ -333,3 +333,86 @@ class HipLimbBackend:
 
     def result(self):
         return self.out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mkbfv: MulRelinNew sharded by WHOLE parties (mkbfv/keyswitch_hoisted.go:36-206).  Quantize rounds, so the two tensor terms
+# of an output slot (op0_0 * op1_j + op0_j * op1_0) must be added on one rank before it: the half-party units of the CKKS
+# sharding do not work here, a rank holds both components of every party it owns (world <= k).  The linear parts are
+# exchanged exactly as in ShardedMulRelin: all-reduce of the four partial sums x1, x2, y1, y2 (Q and QMul gadgets), then
+# all-reduce(out_0) + all-gather(out_i).
+class ShardedBfvMulRelin(ShardedMulRelin):
+    def run(self):
+        b = self.b
+        parts = b.partial_xy()                # four torch int64 views: x1, x2, y1, y2
+        for t in parts:
+            self._all_reduce(t)
+        b.fold_xy()
+        full = b.finish()
+        self._exchange_out(full)
+        b.fold_out()
+        return full
+
+
+class HipBfvShardBackend:
+    """Local arithmetic of one rank of ShardedBfvMulRelin through the C ABI (mkhe_bfv_mr_partial / mkhe_swk_fold /
+    mkhe_bfv_mr_finish / mkhe_ct_fold).  rlk_host: {name: (b1, b2, d1, d2, v)} for (at least) the rank's parties."""
+
+    def __init__(self, params, names, rank, world, op0_host, op1_host, rlk_host, torch, device_index):
+        from . import mkbfv, mkrlwe
+        from ._abi import check, handle_array, lib
+        self.params, self.names, self.torch = params, list(names), torch
+        self.check, self.lib, self.harr = check, lib, handle_array
+        if world > len(self.names):
+            raise ValueError("BFV sharding needs whole parties: world <= number of parties")
+        self.ids = assign_parties(self.names, world)[rank]
+        self.with_c0 = rank == 0
+        sl = lambda host: np.ascontiguousarray(np.stack([host[0]] + [host[1 + self.names.index(n)] for n in self.ids]))
+        self.op0 = mkbfv.NewCiphertext(params, self.ids).upload(sl(op0_host))
+        self.op1 = mkbfv.NewCiphertext(params, self.ids).upload(sl(op1_host))
+        as_key = lambda k_: k_ if isinstance(k_, mkrlwe.SwitchingKey) else mkrlwe.SwitchingKey(params, k_)
+        self.keys = {n: [as_key(k_) for k_ in rlk_host[n]] for n in self.ids}
+        self.out = mkbfv.NewCiphertext(params, self.ids)
+        self.full = mkbfv.NewCiphertext(params, self.names)
+        self.xy = [mkrlwe.NewSwitchingKey(params) for _ in range(4)]
+        dev = torch.device("cuda", device_index)
+        words = int(lib().mkhe_ctx_swk_words(params.ctx))
+        self.txy = [torch.as_tensor(_DevView(s.devptr(), words), device=dev) for s in self.xy]
+        N, L = params.N(), params.MaxLevel() + 1
+        self.level = params.MaxLevel()
+        self.tfull = torch.as_tensor(_DevView(self.full.devptr(), (1 + len(self.names)) * L * N), device=dev).view(1 + len(self.names), L, N)
+        self.tout = torch.as_tensor(_DevView(self.out.devptr(), (1 + len(self.ids)) * L * N), device=dev).view(1 + len(self.ids), L, N)
+
+    def _k(self, j):
+        return self.harr([self.keys[n][j].h for n in self.ids])
+
+    def partial_xy(self):
+        x1, x2, y1, y2 = self.xy
+        self.check(self.lib().mkhe_bfv_mr_partial(self.params.ctx, self.op0.h, self.op1.h, self._k(0), self._k(1), self._k(2), self._k(3),
+                                                  1 if self.with_c0 else 0, self.out.h, x1.h, x2.h, y1.h, y2.h))
+        return self.txy
+
+    def before_collective(self):
+        self.params.sync()
+
+    def after_collective(self):
+        self.torch.cuda.current_stream().synchronize()
+
+    def fold_xy(self):
+        for s in self.xy:
+            self.check(self.lib().mkhe_swk_fold(self.params.ctx, s.h, self.level, 1))
+
+    def finish(self):
+        x1, x2, y1, y2 = self.xy
+        self.check(self.lib().mkhe_bfv_mr_finish(self.params.ctx, self.op0.h, self.op1.h, x1.h, x2.h, y1.h, y2.h, self._k(4),
+                                                 self.params.CRS[-1].h, self.out.h))
+        self.params.sync()
+        self.tfull.zero_()
+        self.tfull[0].copy_(self.tout[0])
+        for a, n in enumerate(self.ids):
+            self.tfull[1 + self.names.index(n)].copy_(self.tout[1 + a])
+        self.torch.cuda.current_stream().synchronize()
+        return self.tfull
+
+    def fold_out(self):
+        self.check(self.lib().mkhe_ct_fold(self.params.ctx, self.full.h))

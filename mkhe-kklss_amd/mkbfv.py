@@ -161,6 +161,12 @@ class KeySwitcher(mkrlwe.KeySwitcher):
         off = index * polyR.limbs * self.Parameters.N() * 8
         check(lib().mkhe_bfv_decompose(self.ctx, C.c_void_p(polyR.devptr().value + off), ad1.h, ad2.h))
 
+    def ExternalProductBFV(self, polyR, bg1, bg2, c, index=0):
+        """keyswitch.go:83-113 (non-hoisted: the decomposition happens inside); polynomial `index` of a PolyR buffer;
+        c: DeviceLimbs [1][nQ][N]"""
+        off = index * polyR.limbs * self.Parameters.N() * 8
+        check(lib().mkhe_bfv_external_product(self.ctx, C.c_void_p(polyR.devptr().value + off), bg1.h, bg2.h, c.devptr()))
+
     def ExternalProductBFVHoisted(self, aHoisted1, aHoisted2, bg1, bg2, c):
         """keyswitch_hoisted.go:6-34; c: DeviceLimbs [1][nQ][N]"""
         check(lib().mkhe_bfv_external_product_hoisted(self.ctx, aHoisted1.h, aHoisted2.h, bg1.h, bg2.h, c.devptr()))
@@ -193,6 +199,13 @@ class Evaluator:
         ctOut = self.newCiphertextBinary(op0, op1)
         check(lib().mkhe_ct_sub(self.params.ctx, op0.h, op1.h, ctOut.h))
         return ctOut
+
+    def mulRelin(self, op0, op1, rlkSet):
+        """evaluator.go:95-113 -> KeySwitcher.MulAndRelinBFV (keyswitch.go:115-251): the non-hoisted twin of mulRelinHoisted.
+        It decomposes the same polynomials inside its loops and returns the same ciphertext bit for bit
+        (checked on the CPU restatement: hoisted == non-hoisted); the engine always batches the decompositions, so both map to
+        the one device entry point."""
+        return self.MulRelinNew(op0, op1, rlkSet)
 
     def MulRelinNew(self, op0, op1, rlkSet):
         """evaluator.go:78-82 -> mulRelinHoisted (:118-140)"""

@@ -130,3 +130,91 @@ class OracleLimbBackend:
     def result(self):
         assert (self.sent.reshape(-1) == self.pattern[3].reshape(-1)).all()      # round 3 arrived complete
         return self.out
+
+
+class OracleBfvShardBackend:
+    """TEST-ONLY backend of mkhe_kklss_amd.dist.ShardedBfvMulRelin: the sharded algorithm restated with the oracle's mkbfv
+    building blocks (ModUpQtoR / Rescale / Quantize / DecomposeBFV / ExternalProductBFVHoisted / Decompose /
+    ExternalProductHoisted, mkbfv/keyswitch_hoisted.go:36-206) and its ring operations for the linear parts."""
+
+    def __init__(self, bfv, names, rank, world, op0_host, op1_host, rlk_host, crs_u, torch):
+        self.bfv, self.names, self.torch = bfv, list(names), torch
+        self.idx = {n: i for i, n in enumerate(self.names)}
+        self.ids = [self.idx[n] for n in assign_parties(self.names, world)[rank]]
+        self.with_c0 = rank == 0
+        self.op0 = [op0_host[0]] + [op0_host[1 + i] for i in self.ids]
+        self.op1 = [op1_host[0]] + [op1_host[1 + i] for i in self.ids]
+        self.rlk = {self.idx[n]: rlk_host[n] for n in rlk_host}
+        self.u = crs_u
+        self.level = bfv.nq - 1
+
+    def _rings(self, m):                       # limbs of a switching key: Q then P
+        nq = self.bfv.nq
+        return [(self.bfv.ringQ, j) for j in range(nq)] + [(self.bfv.ringP, j) for j in range(m - nq)]
+
+    def _ringr(self, j):
+        return (self.bfv.ringQ, j) if j < self.bfv.nq else (self.bfv.ringQMul, j - self.bfv.nq)
+
+    def _mac(self, acc, key, h):               # acc += key (.) h over all digits and limbs (canonical partial sums)
+        for i in range(acc.shape[0]):
+            for jj, (r, j) in enumerate(self._rings(acc.shape[1])):
+                acc[i][jj] = r.mul_add(j, key[i][jj], h[i][jj], acc[i][jj])
+
+    def partial_xy(self):
+        bfv = self.bfv
+        self.r0 = [bfv.modup_q_to_r(p) for p in self.op0]
+        self.r1 = [bfv.rescale(p) for p in self.op1]
+        self.h0 = [bfv.decompose(p) for p in self.r0[1:]]
+        self.h1 = [bfv.decompose(p) for p in self.r1[1:]]
+        z = lambda: np.zeros_like(bfv.ks.new_swk())
+        self.x1, self.x2, self.y1, self.y2 = z(), z(), z(), z()
+        for a, i in enumerate(self.ids):
+            b1, b2, d1, d2, _ = self.rlk[i]
+            self._mac(self.x1, d1, self.h0[a][0]); self._mac(self.x2, d2, self.h0[a][1])
+            self._mac(self.y1, b1, self.h1[a][0]); self._mac(self.y2, b2, self.h1[a][1])
+        self.t = [self.torch.from_numpy(v.view(np.int64)) for v in (self.x1, self.x2, self.y1, self.y2)]
+        return self.t
+
+    def before_collective(self): pass
+    def after_collective(self): pass
+
+    def fold_xy(self):
+        for buf in (self.x1, self.x2, self.y1, self.y2):
+            for i in range(buf.shape[0]):
+                for jj, (r, j) in enumerate(self._rings(buf.shape[1])):
+                    buf[i][jj] = r.mform(j, r.reduce(j, buf[i][jj]))
+
+    def finish(self):
+        bfv, nq, N = self.bfv, self.bfv.nq, self.bfv.N
+        mulr = lambda a, b: np.stack([self._ringr(j)[0].mul(self._ringr(j)[1], a[j], b[j]) for j in range(2 * nq)])
+        addr = lambda a, b: np.stack([self._ringr(j)[0].add(self._ringr(j)[1], a[j], b[j]) for j in range(2 * nq)])
+        mformr = lambda a: np.stack([self._ringr(j)[0].mform(self._ringr(j)[1], a[j]) for j in range(2 * nq)])
+        f0 = [bfv.ntt_r(p) for p in self.r0]
+        f1 = [bfv.ntt_r(p) for p in self.r1]
+        p1 = mformr(f0[0])                                         # MForm(NTT(op0_0))
+        p2m = mformr(f1[0])                                        # MForm(NTT(op1_0))
+        out = np.zeros((1 + len(self.ids), nq, N), dtype=np.uint64)
+        if self.with_c0:
+            out[0] = bfv.quantize(mulr(p1, f1[0]))
+        for a in range(len(self.ids)):
+            out[1 + a] = bfv.quantize(addr(mulr(p1, f1[1 + a]), mulr(p2m, f0[1 + a])))
+        addq = lambda a, b: np.stack([bfv.ringQ.add(j, a[j], b[j]) for j in range(nq)])
+        for a, i in enumerate(self.ids):
+            out[1 + a] = addq(out[1 + a], bfv.external_product_hoisted(self.h1[a][0], self.h1[a][1], self.x1, self.x2))
+        for a, i in enumerate(self.ids):
+            t = bfv.external_product_hoisted(self.h0[a][0], self.h0[a][1], self.y1, self.y2)
+            ht = bfv.ks.decompose(self.level, t)
+            out[0] = addq(out[0], bfv.ks.external_product_hoisted(self.level, ht, self.rlk[i][4]))
+            out[1 + a] = addq(out[1 + a], bfv.ks.external_product_hoisted(self.level, ht, self.u))
+        full = np.zeros((1 + len(self.names), nq, N), dtype=np.uint64)
+        full[0] = out[0]
+        for a, i in enumerate(self.ids):
+            full[1 + i] = out[1 + a]
+        self.full = full
+        self.tfull = self.torch.from_numpy(full.view(np.int64))
+        return self.tfull
+
+    def fold_out(self):
+        for s in range(self.full.shape[0]):
+            for j in range(self.bfv.nq):
+                self.full[s][j] = self.bfv.ringQ.reduce(j, self.full[s][j])

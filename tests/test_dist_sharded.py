@@ -359,3 +359,83 @@ def test_bench_gpus_2_self_launch_on_one_gpu():
     assert out["value"] > 0 and out["steps"] == 2 and out["warmup"] == 1
     legs = out["config"]["legs"]
     assert {"party", "rotate_hoisted", "limb"} <= set(legs) and all(v["ms_per_step"] > 0 for v in legs.values())
+
+
+# ---------------------------------------------------------------- mkbfv, parties sharded (whole parties per rank)
+def make_bfv_case(pset, names, seed):
+    import harness_bfv as HB
+    bfv = HB.make_bfv(pset)
+    data = HB.uniform_bfv_inputs(pset, len(names), seed)
+    ids = list(range(len(names)))
+    _, ref = bfv.mul_relin_new(ids, data["op0"], ids, data["op1"], data["rlk"], data["u"])
+    rlk = {n: data["rlk"][i] for i, n in enumerate(names)}
+    return bfv, data["op0"], data["op1"], rlk, data["u"], ref
+
+
+def _bfv_worker(rank, world, port, names, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness_bfv as HB
+    from dist_oracle_backend import OracleBfvShardBackend
+    from mkhe_kklss_amd.dist import ShardedBfvMulRelin
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bfv, op0, op1, rlk, u, ref = make_bfv_case(HB.small_bfv(10, 3), names, 41)
+    b = OracleBfvShardBackend(bfv, names, rank, world, op0, op1, rlk, u, torch)
+    ShardedBfvMulRelin(b, dist).run()
+    ok = bool((b.full == ref).all())
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, np.array([ok]))
+    else:
+        assert ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("names", [["u0", "u1"], ["u0", "u1", "u2"]])
+def test_sharded_bfv_mulrelin_gloo_world2(tmp_path, names):
+    """mkbfv MulRelinNew with whole parties per rank: gloo, world size 2, the oracle's mkbfv blocks doing the local arithmetic"""
+    import torch.multiprocessing as mp
+    import socket as _s
+    s = _s.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_bfv_worker, args=(2, port, names, out), nprocs=2, join=True)
+    assert np.load(out)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,names", [(1, ["u0", "u1"]), (2, ["u0", "u1"]), (2, ["u0", "u1", "u2"]), (3, ["u0", "u1", "u2"])])
+def test_sharded_bfv_mulrelin_device_emulated_ranks(world, names):
+    """the HIP backend through mkhe_bfv_mr_partial / mkhe_swk_fold / mkhe_bfv_mr_finish / mkhe_ct_fold, ranks emulated one after
+    the other on the one GPU, the collectives done by hand"""
+    import torch
+    import harness_bfv as HB
+    from mkhe_kklss_amd import mkbfv
+    from mkhe_kklss_amd.dist import HipBfvShardBackend
+    pset = HB.small_bfv(11, 3)
+    bfv, op0, op1, rlk, u, ref = make_bfv_case(pset, names, 43)
+    bs = []
+    for r in range(world):
+        params = mkbfv.Parameters(pset["logN"], pset["Q"], pset["QMul"], pset["P"], pset["T"])
+        params.AddCRS(-1, u)
+        bs.append(HipBfvShardBackend(params, names, r, world, op0, op1, rlk, torch, 0))
+    parts = []
+    for b in bs:
+        ts = b.partial_xy()
+        b.before_collective()                  # engine stream -> host, as ShardedBfvMulRelin does before touching the sums
+        parts.append([t.clone() for t in ts])
+    torch.cuda.synchronize()
+    sums = [sum((p[j] for p in parts[1:]), parts[0][j]) for j in range(4)]
+    for b in bs:
+        for j in range(4):
+            b.txy[j].copy_(sums[j])
+        torch.cuda.synchronize()
+        b.fold_xy()
+    fulls = [b.finish().clone() for b in bs]
+    tot = sum(fulls[1:], fulls[0])
+    bs[0].tfull.copy_(tot)
+    torch.cuda.synchronize()
+    bs[0].fold_out()
+    assert (bs[0].full.download() == ref).all()

@@ -121,6 +121,18 @@ def test_external_product_bfv_hoisted(bp):
     assert (c.download()[0] == bp.bfv.external_product_hoisted(h1, h2, g1, g2)).all()
 
 
+@pytest.mark.parametrize("kind", ["modup", "rescale"])
+def test_external_product_bfv_non_hoisted(bp, kind):
+    """ExternalProductBFV (keyswitch.go:83-113): decomposition inside; equals DecomposeBFV + ExternalProductBFVHoisted"""
+    x = _polys_q(bp, 1)[0]
+    ar = bp.bfv.modup_q_to_r(x) if kind == "modup" else bp.bfv.rescale(x)
+    src = bp.mkb.PolyR(bp.params, 1).upload(ar[None])
+    (g1, k1), (g2, k2) = bp.swk(), bp.swk()
+    c = bp.mk.DeviceLimbs(bp.params, 1, bp.nq)
+    bp.ev.ksw.ExternalProductBFV(src, k1, k2, c)
+    assert (c.download()[0] == bp.bfv.external_product(ar, g1, g2)).all()
+
+
 CASES = [
     (["a"], ["a"]),
     (["a", "b"], ["a", "b"]),
