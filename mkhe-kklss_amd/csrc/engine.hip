@@ -107,7 +107,8 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     for (int i = 0; i < mall; ++i) {
         const u64 q = moduli[i];
         Mod& m = mods[i];
-        m.q = q; m.q2 = 2 * q; m.qinv = inv64(q); m.ninv32 = (u32)(0 - m.qinv); m.pad = 0;
+        m.q = q; m.q2 = 2 * q; m.qinv = inv64(q); m.ninv32 = (u32)(0 - m.qinv);
+        { const float f = (float)(4294967296.0 / (double)q); std::memcpy(&m.finv, &f, 4); }
         m.r1 = to_mont(1, q); m.r2 = mulmod(m.r1, m.r1, q);
         m.qs = sd_split(q); m.r1s = sd_split(m.r1);
         u64 ps = (i < nq) ? (psiQ ? psiQ[i] : 0) : (i < mtot ? (psiP ? psiP[i - nq] : 0) : 0);

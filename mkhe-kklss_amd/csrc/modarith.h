@@ -27,7 +27,7 @@ struct Mod {
     u64 q;        // modulus, < 2^60 (enforced by the Context constructor)
     u64 q2;       // 2q
     u32 ninv32;   // -q^-1 mod 2^32
-    u32 pad;
+    u32 finv;     // float32 bits of 2^32 / q: quotient estimate of the cheap partial reduction of ntt16_kernels.hip
     u64 qinv;     // q^-1 mod 2^64   (lattigo MRedParams; used by the literal mult_sum)
     u64 r1;       // 2^64  mod q     (MForm(1))
     u64 r2;       // 2^128 mod q     (mont_mul(a, r2) = MForm(a))

@@ -31,6 +31,7 @@
 // Replaces: lattigo ring.NTTLvl as called from DecomposeSingleNTT (mkrlwe/keyswitch.go:21-31,49-73).
 #include "ntt_kernels.h"
 #include <cstdlib>
+#include <mutex>
 
 namespace mkhe {
 namespace h16 {
@@ -59,7 +60,7 @@ __device__ __forceinline__ void ld2(u64* out, gcptr2 base, unsigned idx) {
 }
 
 // per-job constants, wave-uniform (SGPRs)
-struct MC { i32 q0, q1; u32 ninv; u64 q, q2; };
+struct MC { i32 q0, q1; u32 ninv; u64 q, q2; float finv; };
 
 // ------------------------------------------------------------------ signed-digit Montgomery product (modarith.h mont_mul_sd)
 // a * w * 2^-64 mod q as a signed representative, |r| <= q/2 + |a| w / 2^64 + 1: 12 multiplier-class + 2 plain instructions.
@@ -114,21 +115,34 @@ template <bool SW> __device__ __forceinline__ i64 mm(i64 a, u64 ws, const MC& c)
     return acc;
 }
 
-// MODE 1: signed, never reduced (31q < 2^62).  MODE 0: Harvey, U, V in [0,4q) -> [0,4q).
+// Cheap partial reduction: x -> x - round(x / q) * q, |result| <= q/2 + q * 2^-19, for any |x| < 2^62.9.  The quotient is estimated
+// from the high word in float32 (3 plain VALU instructions: convert, fma with the 1.5 * 2^23 rounding constant, subtract) and is at
+// most a few dozen, so the product is one v_mad_i64_i32 for the low digit of q plus a 32-bit multiply-add for the high digit:
+// 7 instructions, 3 of them multiplier-class, against 14 / 12 for a Montgomery product by R mod q.
+__device__ __forceinline__ i64 pred(i64 x, const MC& c) {
+    const float f = __builtin_fmaf((float)(i32)hi32((u64)x), c.finv, 12582912.0f);
+    const i32 nt = (i32)(0x4B400000u - __builtin_bit_cast(u32, f));              // -round(x / q)
+    i64 y = (i64)nt * c.q0 + x;                                                   // v_mad_i64_i32
+    return (i64)((u64)y + ((u64)(u32)(nt * c.q1) << 32));                         // high word += nt * q1 (v_mul_lo_u32 + v_add_u32)
+}
+
+// Signed butterfly, never reduced: X = U + w V, Y = U - w V with the product as a signed representative; |x| grows by less than
+// q/2 + |x|/16 per stage.  Both modulus classes use it: MODE 1 (31q < 2^62: the 54-bit primes) runs all 15 stages without any
+// reduction, MODE 0 (q < 2^60) interposes the partial reduction above after at most 8 stages (limb() below) instead of the
+// conditional subtractions of a Harvey butterfly (+50 % instructions per butterfly in the first version of this kernel).
 template <int MODE, bool SW> __device__ __forceinline__ void bfly(u64& U, u64& V, u64 ws, const MC& c) {
 #ifdef MKHE_H16_X_NOBFLY
     if ((MKHE_H16_X_NOBFLY >> (SW ? 0 : 1)) & 1) { U += ws; return; }      // timing experiment only: butterflies with scalar / per-lane twiddles removed
 #endif
-    if constexpr (MODE == 1) {
-        const i64 T = mm<SW>((i64)V, ws, c);
-        const i64 u = (i64)U;
-        U = (u64)(u + T);
-        V = (u64)(u - T);
-    } else {
-        const u64 T = (u64)(mm<SW>((i64)V, ws, c) + (i64)c.q);       // [0,2q)
-        const u64 u = csub(U, c.q2);
-        U = u + T;
-        V = u + (c.q2 - T);
+    const i64 T = mm<SW>((i64)V, ws, c);
+    const i64 u = (i64)U;
+    U = (u64)(u + T);
+    V = (u64)(u - T);
+}
+template <int MODE> __device__ __forceinline__ void reduce_all(u64 (&x)[16], const MC& c) {
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = (u64)pred((i64)x[r], c);
     }
 }
 
@@ -226,6 +240,7 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
     MC c;
     c.q = mp->q; c.q2 = mp->q2; c.ninv = mp->ninv32;
     c.q0 = (i32)lo32(md.qs); c.q1 = (i32)hi32(md.qs);
+    c.finv = __builtin_bit_cast(float, mp->finv);
     asm("" : "+s"(c.q0), "+s"(c.q1), "+s"(c.ninv));        // opaque wave-uniform 32-bit values (see modarith.h mont_mul_sd)
     scptr psi_s = (scptr)jb.psi;
     gcptr psi_v = (gcptr)jb.psi;
@@ -246,14 +261,11 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
                 u64 U[8], V[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) { U[r] = sbase(src + (r0 + r) * NT)[tu]; V[r] = sbase(src + HH + (r0 + r) * NT)[tu]; }
-                if constexpr (DEC) {
-                    if (red) {
+                // digits of a foreign modulus (Decompose) may be far above q: bring them to (-q, q) first.  MODE 0 (q up to 2^60)
+                // has no headroom for five stages on raw inputs and always starts from reduced values.
+                if (MODE == 0 || red) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            if constexpr (MODE == 1) { U[r] = (u64)mm<true>((i64)U[r], md.r1s, c); V[r] = (u64)mm<true>((i64)V[r], md.r1s, c); }
-                            else { U[r] = (u64)(mm<true>((i64)U[r], md.r1s, c) + (i64)c.q); V[r] = (u64)(mm<true>((i64)V[r], md.r1s, c) + (i64)c.q); }
-                        }
-                    }
+                    for (int r = 0; r < 8; ++r) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); }
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -287,6 +299,7 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
             stage<MODE, true, 1>(x, tw + 3, c);
             stage<MODE, true, 0>(x, tw + 7, c);
         }
+        reduce_all<MODE>(x, c);                  // MODE 0: |x| < 3.6q after stage 0 + phase A -> (-q, q)
         H16_STAMP(2);
         exchange<X_AB>(x, lds, wv, l);
         H16_STAMP(3);
@@ -339,6 +352,7 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
                 else bfly1<MODE, 0>(x, gi, g[4 + (gi >> 1)][gi & 1], c);
             }
         }
+        reduce_all<MODE>(x, c);                  // MODE 0: |x| < 5.9q < 2^62.6 after phases B and C (8 stages) -> (-q, q)
         // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane
         {
             int ld = l; asm volatile("" : "+v"(ld));
@@ -365,21 +379,16 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
         }
         H16_STAMP(8);
         // ---- output representative
-        if constexpr (MODE == 1) {
-            if (!jb.skip_norm) {
+        if (MODE == 0 || !jb.skip_norm) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const i64 y = mm<true>((i64)x[r], md.r1s, c);                     // (-0.6q, 0.6q)
-                    x[r] = (u64)(y + ((y >> 63) & (i64)c.q));                       // canonical
-                }
-            } else {
-                const i64 bias = (i64)(c.q << 4);                                    // same residue, positive: (2q, 30q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = (u64)((i64)x[r] + bias);
+            for (int r = 0; r < 16; ++r) {
+                const i64 y = pred((i64)x[r], c);                                    // (-q, q)
+                x[r] = (u64)(y + ((y >> 63) & (i64)c.q));                           // canonical (lattigo: final BRedAdd)
             }
         } else {
+            const i64 bias = (i64)(c.q << 4);                                        // MODE 1, engine-internal digits: same residue, positive: (2q, 30q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = csub(csub(x[r], c.q2), c.q);
+            for (int r = 0; r < 16; ++r) x[r] = (u64)((i64)x[r] + bias);
         }
         H16_STAMP(9);
         exchange<X_DE>(x, lds, wv, l);
@@ -460,12 +469,12 @@ __global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
 }  // namespace h16
 
 // ------------------------------------------------------------------ launcher
+namespace {
+int env_int16(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+struct LaunchState16 { std::mutex mu; int resident[64] = {}; };      // per device, see ntt_kernels.hip
+}
 bool ntt16_ok(int logN, const NttBatch& b) {
-    static int on = -1, minl = 0;
-    if (on < 0) {
-        const char* e = getenv("MKHE_NTT16"); on = (e && *e) ? atoi(e) : 1;
-        const char* f = getenv("MKHE_NTT16_MIN"); minl = (f && *f) ? atoi(f) : 256;
-    }
+    static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128);
     return on && logN == 15 && !b.split && !b.prestaged && b.nslots <= 64 && b.nslots * b.nouter >= minl;
 }
 void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
@@ -481,21 +490,24 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
                 ++c.nslots;
             }
     const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
-    static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("MKHE_NTT16_STAGGER"); stagger = (e && *e) ? atoi(e) : 0; }
+    static const int stagger = env_int16("MKHE_NTT16_STAGGER", 0), per_cu = env_int16("MKHE_NTT16_PER_CU", 0);
     c.lazy_out = stagger;
-    static bool attr = false;
-    static int resident = 0;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        int dev = 0, cus = 256, per = 1;
+    static LaunchState16 ls;
+    int resident;
+    {
+        int dev = 0;
         (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)ntt16_fwd_kernel<true>, NT, lds) != hipSuccess || per < 1) per = 1;
-        if (const char* e = getenv("MKHE_NTT16_PER_CU")) { if (*e) per = atoi(e); }
-        resident = cus * per;
-        attr = true;
+        std::lock_guard<std::mutex> g(ls.mu);
+        if (!ls.resident[dev & 63]) {
+            (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            int cus = 256, per = 1;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)ntt16_fwd_kernel<true>, NT, lds) != hipSuccess || per < 1) per = 1;
+            if (per_cu > 0) per = per_cu;
+            ls.resident[dev & 63] = cus * per;
+        }
+        resident = ls.resident[dev & 63];
     }
     const int need = c.nslots * c.nouter;
     const int blocks = need < resident ? need : resident;

@@ -11,6 +11,7 @@
 //  * all pointers are address_space(1) so loads are global_load (vmcnt only), never flat_load.
 #include "ntt_kernels.h"
 #include <cstdlib>
+#include <mutex>
 #ifndef MKHE_SB_MASK
 #define MKHE_SB_MASK 1
 #endif
@@ -662,6 +663,13 @@ static NttBatch in_place_of_dst(const NttBatch& b) {
 }
 
 // ------------------------------------------------------------------ launchers
+// Launch state is kept PER DEVICE (a process may hold contexts on several GPUs: the function attribute has to be set and the
+// persistent grid sized on each of them) and behind a mutex (contexts may be driven from different host threads).
+namespace {
+struct LaunchState { std::mutex mu; int resident[64] = {}; bool attr[64] = {}; };
+int current_device() { int dev = 0; (void)hipGetDevice(&dev); return dev & 63; }
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+}
 // workgroups that are co-resident on the whole chip for this kernel (persistent grid size)
 static int resident_blocks(const void* fn, int threads, size_t lds) {
     if (const char* e = getenv("MKHE_NTT_GRID")) { if (e[0] == 'f') return 1 << 30; }     // "full": one workgroup per limb (A/B testing)
@@ -673,22 +681,32 @@ static int resident_blocks(const void* fn, int threads, size_t lds) {
 }
 template <int LOGN, int MODE, bool DEC> static void launch_fwd_t(const NttBatch& b, hipStream_t st) {
     using G = Geo<LOGN>;
-    static bool attr = false;
+    static LaunchState ls;
     const size_t lds = (size_t)G::LPB * lds_words<LOGN>() * sizeof(u32);
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN, MODE, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    static int resident = 0;
-    if (!resident) resident = resident_blocks((const void*)ntt_fwd_kernel<LOGN, MODE, DEC>, G::BT, lds);
+    int resident;
+    {
+        const int dev = current_device();
+        std::lock_guard<std::mutex> g(ls.mu);
+        if (!ls.attr[dev]) { (void)hipFuncSetAttribute((const void*)ntt_fwd_kernel<LOGN, MODE, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); ls.attr[dev] = true; }
+        if (!ls.resident[dev]) ls.resident[dev] = resident_blocks((const void*)ntt_fwd_kernel<LOGN, MODE, DEC>, G::BT, lds);
+        resident = ls.resident[dev];
+    }
     const int need = (((b.nslots * b.nouter) << b.split) + G::LPB - 1) / G::LPB;
     const int blocks = need < resident ? need : resident;
     hipLaunchKernelGGL((ntt_fwd_kernel<LOGN, MODE, DEC>), dim3(blocks), dim3(G::BT), lds, st, b);
 }
 template <int LOGN> static void launch_inv_t(const NttBatch& b, hipStream_t st) {
     using G = Geo<LOGN>;
-    static bool attr = false;
+    static LaunchState ls;
     const size_t lds = (size_t)G::LPB * lds_words<LOGN>() * sizeof(u32);
-    if (!attr) { (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    static int resident = 0;
-    if (!resident) resident = resident_blocks((const void*)ntt_inv_kernel<LOGN>, G::BT, lds);
+    int resident;
+    {
+        const int dev = current_device();
+        std::lock_guard<std::mutex> g(ls.mu);
+        if (!ls.attr[dev]) { (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); ls.attr[dev] = true; }
+        if (!ls.resident[dev]) ls.resident[dev] = resident_blocks((const void*)ntt_inv_kernel<LOGN>, G::BT, lds);
+        resident = ls.resident[dev];
+    }
     const int need = (((b.nslots * b.nouter) << b.split) + G::LPB - 1) / G::LPB;
     const int blocks = need < resident ? need : resident;
     hipLaunchKernelGGL(ntt_inv_kernel<LOGN>, dim3(blocks), dim3(G::BT), lds, st, b);
@@ -725,34 +743,34 @@ int split_ntt_fwd(const NttBatch& b, const unsigned char* small_q, NttBatch out[
 static bool use_split(int logN, const NttBatch& b) {
     if (logN == 16) return true;
     if (logN < 13) return false;
-    static int forced = -2;
-    if (forced == -2) { const char* e = getenv("MKHE_NTT_SPLIT"); forced = (e && *e) ? atoi(e) : -1; }
+    static const int forced = env_int("MKHE_NTT_SPLIT", -1);                 // (function-local statics: initialised once, thread-safe)
     if (forced >= 0) return forced != 0;
-    static int lim = 0;
-    if (!lim) { const char* e = getenv("MKHE_NTT_SPLIT_MAX"); lim = (e && *e) ? atoi(e) : 128; }     // A/B: limb count up to which a launch runs split
+    static const int lim = env_int("MKHE_NTT_SPLIT_MAX", 128);               // A/B: limb count up to which a launch runs split
     if ((logN == 14 || logN == 15) && b.nslots * b.nouter <= lim) return true;
     return b.nslots * b.nouter <= 128;        // at most one sub-transform workgroup per CU (256 CUs)
 }
 // depth of the low-latency path for this launch: 0 = register-resident sub-transforms, d >= 1 = 2^d LDS sub-transforms of
 // 2^13 coefficients per limb after d streaming passes.  MKHE_NTT_LDS=0 switches it off (A/B tests).
 static int lds_depth(int logN, const NttBatch& b) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MKHE_NTT_LDS"); on = (e && *e) ? atoi(e) : 1; }
+    static const int on = env_int("MKHE_NTT_LDS", 1);
     if (!on || b.prestaged) return 0;
     if (logN != 14 && logN != 15) return 0;
-    static bool attr = false;
-    if (!attr) {
-        const int lds = SM_LDS_WORDS * (int)sizeof(u64);
-        (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)ntt_inv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
+    static LaunchState ls;
+    {
+        const int dev = current_device();
+        std::lock_guard<std::mutex> g(ls.mu);
+        if (!ls.attr[dev]) {
+            const int lds = SM_LDS_WORDS * (int)sizeof(u64);
+            (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)ntt_inv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            ls.attr[dev] = true;
+        }
     }
     return logN - SM_LOGM;
 }
 bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MKHE_NTT_MIXED"); on = (e && *e) ? atoi(e) : 1; }
+    static const int on = env_int("MKHE_NTT_MIXED", 1);
     if (!on || logN != 15 || !b.reduce_in || b.split || b.nslots > 64 || b.nslots * b.nouter <= 512) return false;
     int nsmall = 0;
     for (int s = 0; s < b.nslots; ++s) if (small_q[b.mod[s]]) ++nsmall;

@@ -7,6 +7,11 @@ namespace mkhe {
 constexpr int PW_THREADS = 256;
 
 // ------------------------------------------------------------------ inner product
+// HBM-bound (2 * nterms + 1 words moved per output word): every lane moves 16 bytes per load (two coefficients), all the loads of
+// a thread are issued before the first product (the term loop is unrolled: NT is a template argument), and the grid covers the
+// limb exactly (no grid-stride loop, no block cap).
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+template <int NT>
 __global__ void __launch_bounds__(PW_THREADS) inner_product_kernel(InnerProductArgs a) {
     const int s = blockIdx.y;                 // active-limb slot
     const int o = blockIdx.z;                 // outer item (gadget digit or 0)
@@ -16,25 +21,42 @@ __global__ void __launch_bounds__(PW_THREADS) inner_product_kernel(InnerProductA
     const u32 ninv = md.ninv32;
     const long base = (long)o * a.term_outer + (long)m * a.N;
     const long obase = (long)o * a.out_outer + (long)m * a.N;
-    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
-        u64 acc = 0;
-// (runtime trip count: the optimizer keeps this loop rolled)
-        for (int t = 0; t < a.nterms; ++t) {
-            u64 p = mont_mul_lazy(a.a[t][base + n], a.b[t][base + n], q, ninv);
-            acc = csub(acc + p, q2);
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
+    if (n >= a.N) return;
+    const int nt = NT ? NT : a.nterms;
+    u64 acc0 = 0, acc1 = 0;
+    if constexpr (NT != 0) {
+        u64x2 x[NT], y[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { x[t] = *(const u64x2*)(a.a[t] + base + n); y[t] = *(const u64x2*)(a.b[t] + base + n); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc0 = csub(acc0 + mont_mul_lazy(x[t].x, y[t].x, q, ninv), q2);
+            acc1 = csub(acc1 + mont_mul_lazy(x[t].y, y[t].y, q, ninv), q2);
         }
-        acc = csub(acc, q);
-        if (a.mform_out) acc = mont_mul(acc, md.r2, q, ninv);
-        a.out[obase + n] = acc;
+    } else {
+        for (int t = 0; t < nt; ++t) {
+            const u64x2 x = *(const u64x2*)(a.a[t] + base + n), y = *(const u64x2*)(a.b[t] + base + n);
+            acc0 = csub(acc0 + mont_mul_lazy(x.x, y.x, q, ninv), q2);
+            acc1 = csub(acc1 + mont_mul_lazy(x.y, y.y, q, ninv), q2);
+        }
     }
+    acc0 = csub(acc0, q); acc1 = csub(acc1, q);
+    if (a.mform_out) { acc0 = mont_mul(acc0, md.r2, q, ninv); acc1 = mont_mul(acc1, md.r2, q, ninv); }
+    u64x2 r; r.x = acc0; r.y = acc1;
+    *(u64x2*)(a.out + obase + n) = r;
 }
 
 void launch_inner_product(const InnerProductArgs& a, hipStream_t st) {
-    int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    static int cap = 0;
-    if (!cap) { const char* e = getenv("MKHE_IP_BX"); cap = (e && *e) ? atoi(e) : 128; }
-    if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(inner_product_kernel, dim3(bx, a.nslots, a.nouter), dim3(PW_THREADS), 0, st, a);
+    const dim3 grid((a.N / 2 + PW_THREADS - 1) / PW_THREADS, a.nslots, a.nouter), blk(PW_THREADS);
+    switch (a.nterms) {
+        case 1: hipLaunchKernelGGL(inner_product_kernel<1>, grid, blk, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(inner_product_kernel<2>, grid, blk, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(inner_product_kernel<3>, grid, blk, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(inner_product_kernel<4>, grid, blk, 0, st, a); break;
+        case 8: hipLaunchKernelGGL(inner_product_kernel<8>, grid, blk, 0, st, a); break;
+        default: hipLaunchKernelGGL(inner_product_kernel<0>, grid, blk, 0, st, a); break;
+    }
 }
 
 // ------------------------------------------------------------------ ModDown
@@ -90,57 +112,58 @@ void launch_moddown(const ModDownArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ batched ExternalProduct halves
+// HBM-bound like the inner product: 16-byte lanes (two coefficients per thread), the digit loop unrolled by four so that
+// 8 (12 for a pair) loads are in flight per thread, the grid covers the limb exactly.
 __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
     const int s = blockIdx.y, item = blockIdx.z;
     const int role = a.pair[item];
     if (role == 2) return;                    // computed by its leader
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
+    if (n >= a.N) return;
     const int m = a.map[s];
     const Mod md = a.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
-    const u64* ah = a.ah[item] + (long)m * a.N;
-    const u64* bg = a.bg[item] + (long)m * a.N;
-    u64* out = a.c1 + (long)item * a.c1_item + (long)m * a.N;
+    const u64* ah = a.ah[item] + (long)m * a.N + n;
+    const u64* bg = a.bg[item] + (long)m * a.N + n;
+    u64* out = a.c1 + (long)item * a.c1_item + (long)m * a.N + n;
+    const long ds = a.digit_stride;
+    u64x2 r;
     if (role == 1) {
-        const u64* bgn = a.bg[item + 1] + (long)m * a.N;
-        u64* outn = out + a.c1_item;
-        for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
-            u64 acc = 0, accn = 0;
-// (runtime trip count: the optimizer keeps this loop rolled)
-            for (int i = 0; i < a.nb; ++i) {
-                const u64 h = ah[(long)i * a.digit_stride + n];
-                acc = csub(acc + mont_mul_lazy(bg[(long)i * a.digit_stride + n], h, q, ninv), q2);
-                accn = csub(accn + mont_mul_lazy(bgn[(long)i * a.digit_stride + n], h, q, ninv), q2);
-            }
-            out[n] = csub(acc, q);
-            outn[n] = csub(accn, q);
+        const u64* bgn = a.bg[item + 1] + (long)m * a.N + n;
+        u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll 4
+        for (int i = 0; i < a.nb; ++i) {
+            const u64x2 h = *(const u64x2*)(ah + i * ds), g = *(const u64x2*)(bg + i * ds), gn = *(const u64x2*)(bgn + i * ds);
+            a0 = csub(a0 + mont_mul_lazy(g.x, h.x, q, ninv), q2); a1 = csub(a1 + mont_mul_lazy(g.y, h.y, q, ninv), q2);
+            b0 = csub(b0 + mont_mul_lazy(gn.x, h.x, q, ninv), q2); b1 = csub(b1 + mont_mul_lazy(gn.y, h.y, q, ninv), q2);
         }
+        r.x = csub(a0, q); r.y = csub(a1, q);
+        *(u64x2*)out = r;
+        r.x = csub(b0, q); r.y = csub(b1, q);
+        *(u64x2*)(out + a.c1_item) = r;
         return;
     }
-    const u64* ah2 = a.ah2[item] ? a.ah2[item] + (long)m * a.N : nullptr;
-    const u64* bg2 = a.ah2[item] ? a.bg2[item] + (long)m * a.N : nullptr;
-    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
-        u64 acc = 0;
-// (runtime trip count: the optimizer keeps this loop rolled)
-        for (int i = 0; i < a.nb; ++i) {
-            u64 p = mont_mul_lazy(bg[(long)i * a.digit_stride + n], ah[(long)i * a.digit_stride + n], q, ninv);
-            acc = csub(acc + p, q2);
-        }
-        if (ah2) {
-// (runtime trip count: the optimizer keeps this loop rolled)
-            for (int i = 0; i < a.nb; ++i) {
-                u64 p = mont_mul_lazy(bg2[(long)i * a.digit_stride + n], ah2[(long)i * a.digit_stride + n], q, ninv);
-                acc = csub(acc + p, q2);
-            }
-        }
-        out[n] = csub(acc, q);
+    u64 a0 = 0, a1 = 0;
+#pragma unroll 4
+    for (int i = 0; i < a.nb; ++i) {
+        const u64x2 h = *(const u64x2*)(ah + i * ds), g = *(const u64x2*)(bg + i * ds);
+        a0 = csub(a0 + mont_mul_lazy(g.x, h.x, q, ninv), q2); a1 = csub(a1 + mont_mul_lazy(g.y, h.y, q, ninv), q2);
     }
+    if (a.ah2[item]) {
+        const u64* ah2 = a.ah2[item] + (long)m * a.N + n;
+        const u64* bg2 = a.bg2[item] + (long)m * a.N + n;
+#pragma unroll 4
+        for (int i = 0; i < a.nb; ++i) {
+            const u64x2 h = *(const u64x2*)(ah2 + i * ds), g = *(const u64x2*)(bg2 + i * ds);
+            a0 = csub(a0 + mont_mul_lazy(g.x, h.x, q, ninv), q2); a1 = csub(a1 + mont_mul_lazy(g.y, h.y, q, ninv), q2);
+        }
+    }
+    r.x = csub(a0, q); r.y = csub(a1, q);
+    *(u64x2*)out = r;
 }
 void launch_ext_inner(const ExtInnerArgs& a, hipStream_t st) {
-    int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    static int cap = 0;
-    if (!cap) { const char* e = getenv("MKHE_EXT_BX"); cap = (e && *e) ? atoi(e) : 64; }
-    if (bx > cap) bx = cap;
+    const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
     hipLaunchKernelGGL(ext_inner_kernel, dim3(bx, a.nslots, a.nitems), dim3(PW_THREADS), 0, st, a);
 }
 

@@ -18,7 +18,7 @@ N, level = 1 << p["logN"], len(p["Q"]) - 1
 ev = mkckks.NewEvaluator(params)
 ncls = lib().mkhe_prof_nclass()
 names = [lib().mkhe_prof_name(i).decode() for i in range(ncls)]
-for k in (8, 4, 2):
+for k in (8, 4, 2, 1):
     ids = ["u%d" % i for i in range(k)]
     host = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in p["Q"]]) for _ in range(1 + k)])
     ct = mkckks.NewCiphertext(params, ids, level, p["scale"]).upload(host)
