@@ -584,6 +584,12 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1) {
         ia.ah2[i] = it[i].ah2; ia.bg2[i] = it[i].bg2;
         two = two || ia.ah2[i] != nullptr;
     }
+    // keys that a single item reads (v_i, rotation keys) are streamed; x, y, u are shared by several items and stay cached
+    for (int i = 0; i < n; ++i) {
+        int uses = 0;
+        for (int k = 0; k < n; ++k) uses += (it[k].bg == it[i].bg);
+        ia.bg_once[i] = uses == 1 ? 1 : 0;
+    }
     // neighbours that share their digits (step F: <h(t_i), v_i> and <h(t_i), u>) are computed together
     for (int i = 0; i + 1 < n; ++i)
         if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }

@@ -58,6 +58,7 @@ struct ExtInnerArgs {
     const u64* bg[EXT_MAX_ITEMS];
     const u64* ah2[EXT_MAX_ITEMS];   // second gadget (BFV: QMul digits, keyswitch_hoisted.go:20-28) or all NULL
     const u64* bg2[EXT_MAX_ITEMS];
+    unsigned char bg_once[EXT_MAX_ITEMS];  // this item's key is read by no other item of the launch: stream it past the caches
     unsigned char pair[EXT_MAX_ITEMS];   // 1: this item and the next one share `ah` (step F: <h(t_i), v_i> and <h(t_i), u>):
                                          // computed together, the digits are read once; 2: the follower (skipped); 0: single
     u64* c1;                 // [nitems][mtot][N]
