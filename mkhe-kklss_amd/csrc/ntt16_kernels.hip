@@ -401,7 +401,11 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
 #ifdef MKHE_H16_X_NOSTORE
                 if (x[r] != 0x123456789abcdefull) continue;      // timing experiment only: (almost) no result stores
 #endif
+#ifndef MKHE_X_NO_NTSTORE      // results are written once and read by later kernels: stream them past the caches (twiddles, sources and the CRS stay resident)
+                __builtin_nontemporal_store(x[r], (u64 __attribute__((address_space(1)))*)(sbase(o + r * 64) + lu));
+#else
                 sbase(o + r * 64)[lu] = x[r];
+#endif
             }
         }
         H16_STAMP(11);
