@@ -208,7 +208,7 @@ def run_cnn(args):
                 roofline=roofline, cpu_baseline=None)
 
 
-def roofline_leg(args, params, step, logN, workload):
+def roofline_leg(args, params, step, logN, workload, extra=None):
     """per-kernel HIP-event timing on the context stream, same steps again (side-stream overlap off: each kernel
     then runs alone, so its duration is the kernel's own and comparable with the rocprofv3 kernel trace taken with
     MKHE_NO_OVERLAP=1; `value` is measured with overlap on)"""
@@ -235,20 +235,48 @@ def roofline_leg(args, params, step, logN, workload):
     di = max((i for i in range(ncls) if cnt[i]), key=lambda i: ms[i])
     dom = names_k[di]
     achieved = byt[di] / (ms[di] * 1e-3) / 1e9
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the value
-    # comes from the committed rocprofv3 --pmc summary of this same command (profiles/traffic.json, written
-    # by tools/traffic_from_pmc.py: (2*FETCH_SIZE + WRITE_SIZE) KB per launch).
-    traffic = None
+    # HBM traffic: PMC counters cannot be read from inside this process; the figures come from the committed rocprofv3 --pmc
+    # summary of the clean profile command (profiles/traffic.json, tools/profile_r2.sh + tools/traffic_from_pmc.py:
+    # (2*FETCH_SIZE + WRITE_SIZE) KB per launch).  They are attached only when the profiled run had the launch
+    # pattern measured here: same workload, and per kernel the recorded call count equals launches_per_step * (warmup + 2 * steps)
+    # of the recorded command (warm-up + timed loop + HIP-event leg) -- otherwise `traffic` stays null.
+    traffic, tnote = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        key = dom.split()[0]
-        if tj.get("workload") == workload and key in tj.get("kernels", {}):
-            traffic = tj["kernels"][key]["hbm_bytes_per_launch"]
-    return dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                alg_bytes_per_launch=byt[di] / cnt[di], avg_launch_us=1e3 * ms[di] / cnt[di],
-                kernels=kernels)
+        tk = tj.get("kernels", {})
+        def pmc_bytes(name):
+            key = name.split()[0]
+            rec = tk.get(key) or tk.get(key.replace("[_batch]", "_batch"))
+            if tj.get("workload") != workload or rec is None or tj.get("steps") is None:
+                return None
+            expect = kernels[name]["launches_per_step"] * (tj["warmup"] + 2 * tj["steps"])
+            return rec["hbm_bytes_per_launch"] if abs(rec["launches"] - expect) < 0.5 else None
+        traffic = pmc_bytes(dom)
+        for name, k in kernels.items():
+            hb = pmc_bytes(name)
+            if hb is not None:
+                k["hbm_bytes_per_launch_pmc"] = hb
+                k["hbm_GBs_pmc"] = hb / (k["avg_launch_us"] * 1e-6) / 1e9          # what the kernel really moves: never above the peak
+        if traffic is None:
+            tnote = "profiles/traffic.json was recorded for another workload or launch pattern"
+    out = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+               alg_bytes_per_launch=byt[di] / cnt[di], avg_launch_us=1e3 * ms[di] / cnt[di],
+               kernels=kernels)
+    if tnote:
+        out["traffic_note"] = tnote
+    if "true>" in dom.split()[0] and "fwd" in dom and extra and extra.get("decompose"):
+        # the Decompose-fused NTT reads each source limb once (compulsorily; the re-reads by the nQ+nP workgroups that spread it
+        # are cache hits) and writes beta * (level + 1 + nP) limbs per component: SURVEY.md 8(d) "Decompose" row, beside the
+        # 16*N-per-limb NTT figure that `achieved` is computed from
+        N = 1 << logN
+        limbs = byt[di] / cnt[di] / (16.0 * N)
+        comps = limbs / extra["decompose"]["limbs_per_component"]
+        comp_bytes = 8.0 * N * (comps * extra["decompose"]["source_limbs_per_component"] + limbs)
+        out["compulsory_bytes_per_launch"] = comp_bytes
+        out["frac_compulsory"] = comp_bytes / (out["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    return out
 
 
 def run_single(args):
@@ -300,7 +328,10 @@ def run_single(args):
     ms_per_step = dt * 1e3 / args.steps
     value = args.steps / dt
 
-    roofline = roofline_leg(args, params, step, pset["logN"], "%s k=%d" % (args.params, k))
+    beta = params.Beta(level)
+    roofline = roofline_leg(args, params, step, pset["logN"], "%s k=%d" % (args.params, k),
+                            extra=dict(decompose=dict(limbs_per_component=beta * (level + 1 + len(pset["P"])), source_limbs_per_component=level + 1))
+                            if params.Alpha() == 1 else None)
 
     # ---- secondary figure: hoisted rotation of the same k-party ciphertext, hoisting included / excluded
     extras = {}

@@ -67,7 +67,7 @@ func (ctx *Context) GenSecretKey(sampler ring.Sampler, id string) *SecretKey {
 
 // ExpandCRS replaces the upload of params.CRS[idx] (56 MiB at PN15QP880) by its expansion from a public seed.
 func (ctx *Context) ExpandCRS(seed uint64, idx int) *SwitchingKey {
-	out := &SwitchingKey{}
+	out := &SwitchingKey{ctx: ctx}
 	must(C.mkhe_swk_create(ctx.c, &out.h))
 	must(C.mkhe_crs_expand(ctx.c, C.uint64_t(seed), C.int32_t(idx), out.h))
 	return out
@@ -77,7 +77,7 @@ func (ctx *Context) ExpandCRS(seed uint64, idx int) *SwitchingKey {
 func (ctx *Context) GenRelinearizationKey(g *ring.GaussianSampler, sk, r *SecretKey, a, u *SwitchingKey) (b, d, v *SwitchingKey) {
 	beta := ctx.params.Beta(ctx.params.MaxLevel())
 	e := ctx.sampleErrors(g, 3*beta)
-	b, d, v = &SwitchingKey{}, &SwitchingKey{}, &SwitchingKey{}
+	b, d, v = &SwitchingKey{ctx: ctx}, &SwitchingKey{ctx: ctx}, &SwitchingKey{ctx: ctx}
 	for _, k := range []*SwitchingKey{b, d, v} {
 		must(C.mkhe_swk_create(ctx.c, &k.h))
 	}
@@ -91,7 +91,7 @@ func (ctx *Context) GenRotationKey(g *ring.GaussianSampler, rotidx int, sk *Secr
 		rotidx += ctx.params.N() / 2
 	}
 	e := ctx.sampleErrors(g, ctx.params.Beta(ctx.params.MaxLevel()))
-	out := &SwitchingKey{}
+	out := &SwitchingKey{ctx: ctx}
 	must(C.mkhe_swk_create(ctx.c, &out.h))
 	must(C.mkhe_keygen_rotation_key(ctx.c, C.uint64_t(ctx.params.GaloisElementForColumnRotationBy(rotidx)), sk.d, &e[0], crs.h, out.h))
 	return out

@@ -74,31 +74,43 @@ func (ctx *Context) id(s string) C.int {
 	return v
 }
 
-// SwitchingKey mirrors mkrlwe.SwitchingKey (keys.go:23-25) on the device.
-type SwitchingKey struct{ h *C.mkhe_swk }
+// SwitchingKey mirrors mkrlwe.SwitchingKey (keys.go:23-25) on the device.  Device memory is released by Close or, failing
+// that, by the finalizer; the handle keeps its Context reachable, so the context's own finalizer cannot run first.
+type SwitchingKey struct {
+	h   *C.mkhe_swk
+	ctx *Context
+}
 
-// UploadSwitchingKey copies []rlwe.PolyQP limb by limb (cgo cannot pass [][]uint64 directly: the limb
-// pointers are collected in C memory first).
+func (k *SwitchingKey) Close() {
+	if k.h != nil {
+		C.mkhe_swk_destroy(k.ctx.c, k.h)
+		k.h = nil
+	}
+	runtime.SetFinalizer(k, nil)
+}
+
+// UploadSwitchingKey copies []rlwe.PolyQP into ONE contiguous Go buffer [digit][Q limbs..., P limbs...][N] and hands that to
+// mkhe_swk_upload.  (Storing the Go limb pointers in a C array -- mkhe_swk_upload_limbs -- is not allowed by the cgo pointer
+// rules unless every slice is pinned with runtime.Pinner; one staging copy of 56 MiB at key-upload time is the simpler contract.)
 func (ctx *Context) UploadSwitchingKey(swk *mkrlwe.SwitchingKey) *SwitchingKey {
-	out := &SwitchingKey{}
+	out := &SwitchingKey{ctx: ctx}
 	must(C.mkhe_swk_create(ctx.c, &out.h))
-	nq, np := ctx.params.QCount(), ctx.params.PCount()
-	n := len(swk.Value) * (nq + np)
-	ptrs := (*[1 << 20]*C.uint64_t)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-	defer C.free(unsafe.Pointer(ptrs))
+	runtime.SetFinalizer(out, func(k *SwitchingKey) { k.Close() })
+	nq, np, n := ctx.params.QCount(), ctx.params.PCount(), ctx.params.N()
+	buf := make([]uint64, len(swk.Value)*(nq+np)*n)
 	k := 0
 	for _, p := range swk.Value {
 		for j := 0; j < nq; j++ {
-			ptrs[k] = (*C.uint64_t)(unsafe.Pointer(&p.Q.Coeffs[j][0]))
-			k++
+			copy(buf[k:k+n], p.Q.Coeffs[j])
+			k += n
 		}
 		for j := 0; j < np; j++ {
-			ptrs[k] = (*C.uint64_t)(unsafe.Pointer(&p.P.Coeffs[j][0]))
-			k++
+			copy(buf[k:k+n], p.P.Coeffs[j])
+			k += n
 		}
 	}
-	must(C.mkhe_swk_upload_limbs(ctx.c, out.h, (**C.uint64_t)(unsafe.Pointer(ptrs)), C.int(len(swk.Value))))
-	runtime.KeepAlive(swk)
+	must(C.mkhe_swk_upload(ctx.c, out.h, (*C.uint64_t)(unsafe.Pointer(&buf[0]))))
+	runtime.KeepAlive(buf)
 	return out
 }
 
@@ -106,6 +118,15 @@ func (ctx *Context) UploadSwitchingKey(swk *mkrlwe.SwitchingKey) *SwitchingKey {
 type Ciphertext struct {
 	h   *C.mkhe_ct
 	ids []string
+	ctx *Context
+}
+
+func (c *Ciphertext) Close() {
+	if c.h != nil {
+		C.mkhe_ct_destroy(c.ctx.c, c.h)
+		c.h = nil
+	}
+	runtime.SetFinalizer(c, nil)
 }
 
 func (ctx *Context) newCt(ids []string, level int) *Ciphertext {
@@ -113,17 +134,10 @@ func (ctx *Context) newCt(ids []string, level int) *Ciphertext {
 	for i, s := range ids {
 		cids[i] = ctx.id(s)
 	}
-	out := &Ciphertext{ids: ids}
+	out := &Ciphertext{ids: ids, ctx: ctx}
 	must(C.mkhe_ct_create(ctx.c, C.int(len(ids)), &cids[0], C.int(level+1), &out.h))
+	runtime.SetFinalizer(out, func(c *Ciphertext) { c.Close() })
 	return out
-}
-
-func limbPtrs(p *ring.Poly, limbs int) unsafe.Pointer {
-	ptrs := (*[1 << 16]*C.uint64_t)(C.malloc(C.size_t(limbs) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-	for j := 0; j < limbs; j++ {
-		ptrs[j] = (*C.uint64_t)(unsafe.Pointer(&p.Coeffs[j][0]))
-	}
-	return unsafe.Pointer(ptrs)
 }
 
 func sortedIDs(ct *mkrlwe.Ciphertext) []string {
@@ -142,26 +156,34 @@ func sortedIDs(ct *mkrlwe.Ciphertext) []string {
 	return ids
 }
 
-// Upload copies ct.Value[...] (coefficient domain) to the device.
+// Upload copies ct.Value[...] (coefficient domain) to the device through one contiguous staging buffer [slot][limb][N].
 func (ctx *Context) Upload(ct *mkrlwe.Ciphertext) *Ciphertext {
 	ids := sortedIDs(ct)
 	out := ctx.newCt(ids, ct.Level())
+	limbs, n := ct.Level()+1, ctx.params.N()
+	buf := make([]uint64, (len(ids)+1)*limbs*n)
 	for slot, id := range append([]string{"0"}, ids...) {
-		p := limbPtrs(ct.Value[id], ct.Level()+1)
-		must(C.mkhe_ct_upload_poly_limbs(ctx.c, out.h, C.int(slot), (**C.uint64_t)(p)))
-		C.free(p)
+		for j := 0; j < limbs; j++ {
+			copy(buf[(slot*limbs+j)*n:(slot*limbs+j+1)*n], ct.Value[id].Coeffs[j])
+		}
 	}
-	runtime.KeepAlive(ct)
+	must(C.mkhe_ct_upload(ctx.c, out.h, (*C.uint64_t)(unsafe.Pointer(&buf[0]))))
+	runtime.KeepAlive(buf)
 	return out
 }
 
 // Download writes the device ciphertext back into ct (which must have the same ids and level).
 func (ctx *Context) Download(d *Ciphertext, ct *mkrlwe.Ciphertext) {
+	limbs, n := ct.Level()+1, ctx.params.N()
+	buf := make([]uint64, (len(d.ids)+1)*limbs*n)
+	must(C.mkhe_ct_download(ctx.c, d.h, (*C.uint64_t)(unsafe.Pointer(&buf[0]))))
 	for slot, id := range append([]string{"0"}, d.ids...) {
-		p := limbPtrs(ct.Value[id], ct.Level()+1)
-		must(C.mkhe_ct_download_poly_limbs(ctx.c, d.h, C.int(slot), (**C.uint64_t)(p)))
-		C.free(p)
+		for j := 0; j < limbs; j++ {
+			copy(ct.Value[id].Coeffs[j], buf[(slot*limbs+j)*n:(slot*limbs+j+1)*n])
+		}
 	}
+	runtime.KeepAlive(d)
+	runtime.KeepAlive(ct)
 }
 
 // RelinKeys holds the device copies of rlkSet.Value[id].Value[0..2] = (b, d, v) (keys.go:34-37).

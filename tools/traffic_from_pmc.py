@@ -23,7 +23,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(cc)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"mkhe::(\w+)(<[^>]*>)?", r["Kernel_Name"])
+            m = re.search(r"mkhe::(?:h16::)?(\w+)(<[^>]*>)?", r["Kernel_Name"])
             if not m:
                 continue
             key = m.group(1) + (m.group(2) or "").replace(" ", "")
@@ -32,7 +32,10 @@ def per_kernel(d, counter):
 
 
 def main():
+    """argv: <fetch_dir> <write_dir> "<workload>" [steps warmup]  -- steps / warmup of the profiled bench.py command are recorded so
+    that bench.py can refuse the figures when the launch pattern it measures is not the profiled one"""
     fetch, write, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+    steps, warmup = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (None, None)
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(f) | set(w)):
@@ -40,8 +43,18 @@ def main():
         wm = sum(w[k]) / len(w[k]) if w.get(k) else 0.0
         kernels[k] = dict(fetch_size_kb=fm, write_size_kb=wm, launches=len(f.get(k, [])),
                           hbm_bytes_per_launch=(2 * fm + wm) * 1024)
-    json.dump(dict(workload=workload, formula="(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch", kernels=kernels),
-              sys.stdout, indent=1)
+    # a kernel with a single template instance in the run is also listed under its bare name (bench.py's timing classes
+    # do not spell the template arguments of inner_product_kernel<NT>)
+    bare = collections.defaultdict(list)
+    for k in kernels:
+        if "<" in k:
+            bare[k.split("<")[0]].append(k)
+    for b, ks in bare.items():
+        if len(ks) == 1 and b not in kernels:
+            kernels[b] = dict(kernels[ks[0]], instance=ks[0])
+    json.dump(dict(workload=workload, formula="(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch",
+                   command="MKHE_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps %s --warmup %s --no-cpu --no-extras" % (steps, warmup),
+                   steps=steps, warmup=warmup, kernels=kernels), sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
