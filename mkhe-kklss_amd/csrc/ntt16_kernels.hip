@@ -130,7 +130,7 @@ __device__ __forceinline__ i64 pred(i64 x, const MC& c) {
 // q/2 + |x|/16 per stage.  Both modulus classes use it: MODE 1 (31q < 2^62: the 54-bit primes) runs all 15 stages without any
 // reduction, MODE 0 (q < 2^60) interposes the partial reduction above after at most 8 stages (limb() below) instead of the
 // conditional subtractions of a Harvey butterfly (+50 % instructions per butterfly in the first version of this kernel).
-template <int MODE, bool SW> __device__ __forceinline__ void bfly(u64& U, u64& V, u64 ws, const MC& c) {
+template <bool SW> __device__ __forceinline__ void bfly(u64& U, u64& V, u64 ws, const MC& c) {
 #ifdef MKHE_H16_X_NOBFLY
     if ((MKHE_H16_X_NOBFLY >> (SW ? 0 : 1)) & 1) { U += ws; return; }      // timing experiment only: butterflies with scalar / per-lane twiddles removed
 #endif
@@ -139,19 +139,19 @@ template <int MODE, bool SW> __device__ __forceinline__ void bfly(u64& U, u64& V
     U = (u64)(u + T);
     V = (u64)(u - T);
 }
-template <int MODE> __device__ __forceinline__ void reduce_all(u64 (&x)[16], const MC& c) {
-    if constexpr (MODE == 0) {
+__device__ __forceinline__ void reduce_all(u64 (&x)[16], const MC& c, bool big) {
+    if (big) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = (u64)pred((i64)x[r], c);
     }
 }
 
 // one radix-2 stage on register bit B of the 16 registers; tw: the 8 >> B twiddles of this thread for the stage
-template <int MODE, bool SW, int B> __device__ __forceinline__ void stage(u64 (&x)[16], const u64* tw, const MC& c) {
+template <bool SW, int B> __device__ __forceinline__ void stage(u64 (&x)[16], const u64* tw, const MC& c) {
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
-        bfly<MODE, SW>(x[i0], x[i0 | (1 << B)], tw[g >> B], c);
+        bfly<SW>(x[i0], x[i0 | (1 << B)], tw[g >> B], c);
 #ifndef MKHE_H16_NO_SCHEDBAR
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -159,9 +159,9 @@ template <int MODE, bool SW, int B> __device__ __forceinline__ void stage(u64 (&
 }
 
 // butterfly number g (0..7) of the stage on register bit B, per-lane twiddle
-template <int MODE, int B> __device__ __forceinline__ void bfly1(u64 (&x)[16], int g, u64 w, const MC& c) {
+template <int B> __device__ __forceinline__ void bfly1(u64 (&x)[16], int g, u64 w, const MC& c) {
     const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
-    bfly<MODE, false>(x[i0], x[i0 | (1 << B)], w, c);
+    bfly<false>(x[i0], x[i0 | (1 << B)], w, c);
 #ifndef MKHE_H16_NO_SCHEDBAR
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -232,8 +232,11 @@ struct Job { gcptr src; gptr dst; const u64* psi; smodptr mp; bool red; bool ski
 #define H16_STAMP(k) do { } while (0)
 #endif
 
-template <int MODE, bool DEC>
-__device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
+// big: modulus class 0 (q up to 2^60, partial reductions interposed); one instantiation serves both classes (wave-uniform
+// branches around the reductions), which halves the code the two workgroups of a CU -- and the neighbouring CU that shares the
+// instruction cache -- stream through
+template <bool DEC>
+__device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, int t) {
     smodptr mp = jb.mp;                                 // scalar loads: the constants live in SGPRs
     struct { u64 qs, r1s; } md;
     md.qs = mp->qs; md.r1s = mp->r1s;
@@ -263,13 +266,13 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
                 for (int r = 0; r < 8; ++r) { U[r] = sbase(src + (r0 + r) * NT)[tu]; V[r] = sbase(src + HH + (r0 + r) * NT)[tu]; }
                 // digits of a foreign modulus (Decompose) may be far above q: bring them to (-q, q) first.  MODE 0 (q up to 2^60)
                 // has no headroom for five stages on raw inputs and always starts from reduced values.
-                if (MODE == 0 || red) {
+                if (big || red) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); }
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    bfly<MODE, true>(U[r], V[r], w1, c);
+                    bfly<true>(U[r], V[r], w1, c);
                     x[r0 + r] = U[r];
                     sbase(dst + HH + (r0 + r) * NT)[tu] = V[r];
                 }
@@ -294,12 +297,12 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
             for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[8 + 4 * h + i];
 #pragma unroll
             for (int i = 0; i < 8; ++i) tw[7 + i] = psi_s[16 + 8 * h + i];
-            stage<MODE, true, 3>(x, tw, c);
-            stage<MODE, true, 2>(x, tw + 1, c);
-            stage<MODE, true, 1>(x, tw + 3, c);
-            stage<MODE, true, 0>(x, tw + 7, c);
+            stage<true, 3>(x, tw, c);
+            stage<true, 2>(x, tw + 1, c);
+            stage<true, 1>(x, tw + 3, c);
+            stage<true, 0>(x, tw + 7, c);
         }
-        reduce_all<MODE>(x, c);                  // MODE 0: |x| < 3.6q after stage 0 + phase A -> (-q, q)
+        reduce_all(x, c, big);                  // MODE 0: |x| < 3.6q after stage 0 + phase A -> (-q, q)
         H16_STAMP(2);
         exchange<X_AB>(x, lds, wv, l);
         H16_STAMP(3);
@@ -314,10 +317,10 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
             for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[128 + 4 * cb + i];
 #pragma unroll
             for (int i = 0; i < 8; ++i) tw[7 + i] = psi_s[256 + 8 * cb + i];
-            stage<MODE, true, 3>(x, tw, c);
-            stage<MODE, true, 2>(x, tw + 1, c);
-            stage<MODE, true, 1>(x, tw + 3, c);
-            stage<MODE, true, 0>(x, tw + 7, c);
+            stage<true, 3>(x, tw, c);
+            stage<true, 2>(x, tw + 1, c);
+            stage<true, 1>(x, tw + 3, c);
+            stage<true, 0>(x, tw + 7, c);
         }
         // Phases C and D: per-lane twiddles, fetched in 16-byte groups a few butterflies ahead of their use (at most three groups =
         // 12 VGPRs live; issuing all 15 + 12 at once would not fit beside the 32 data registers).  The first groups of a phase are
@@ -346,13 +349,13 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
                 if (n == 24) loadg(6);
                 if (n == 26) loadg(7);
                 const int gi = n & 7;
-                if (n < 8) bfly1<MODE, 3>(x, gi, g[0][0], c);
-                else if (n < 16) bfly1<MODE, 2>(x, gi, g[1][gi >> 2], c);
-                else if (n < 24) bfly1<MODE, 1>(x, gi, g[2 + (gi >> 2)][(gi >> 1) & 1], c);
-                else bfly1<MODE, 0>(x, gi, g[4 + (gi >> 1)][gi & 1], c);
+                if (n < 8) bfly1<3>(x, gi, g[0][0], c);
+                else if (n < 16) bfly1<2>(x, gi, g[1][gi >> 2], c);
+                else if (n < 24) bfly1<1>(x, gi, g[2 + (gi >> 2)][(gi >> 1) & 1], c);
+                else bfly1<0>(x, gi, g[4 + (gi >> 1)][gi & 1], c);
             }
         }
-        reduce_all<MODE>(x, c);                  // MODE 0: |x| < 5.9q < 2^62.6 after phases B and C (8 stages) -> (-q, q)
+        reduce_all(x, c, big);                  // MODE 0: |x| < 5.9q < 2^62.6 after phases B and C (8 stages) -> (-q, q)
         // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane
         {
             int ld = l; asm volatile("" : "+v"(ld));
@@ -373,13 +376,13 @@ __device__ __forceinline__ void limb(const Job& jb, u32* lds, int t) {
                 if (n == 8) loadg(4);
                 if (n == 10) loadg(5);
                 const int gi = n & 7;
-                if (n < 8) bfly1<MODE, 1>(x, gi, g[gi >> 2][(gi >> 1) & 1], c);
-                else bfly1<MODE, 0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
+                if (n < 8) bfly1<1>(x, gi, g[gi >> 2][(gi >> 1) & 1], c);
+                else bfly1<0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
             }
         }
         H16_STAMP(8);
         // ---- output representative
-        if (MODE == 0 || !jb.skip_norm) {
+        if (big || !jb.skip_norm) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const i64 y = pred((i64)x[r], c);                                    // (-q, q)
@@ -462,8 +465,7 @@ __global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
             tw[14] = blockIdx.x;
         }
 #endif
-        if ((kb->small_slots >> s) & 1) limb<1, DEC>(jb, lds, t);
-        else limb<0, DEC>(jb, lds, t);
+        limb<DEC>(jb, ((kb->small_slots >> s) & 1) == 0, lds, t);
 #ifdef MKHE_PHASE_TRACE
         if (jb.trace && (t & 63) == 0) jb.trace[(long)(t >> 6) * 32 + 28] = __builtin_amdgcn_s_memrealtime();
 #endif
