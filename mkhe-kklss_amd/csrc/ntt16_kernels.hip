@@ -49,8 +49,12 @@ constexpr int WSTR = 1088;                 // LDS words per wave region (1024 + 
 constexpr int LDS_WORDS = 16 * WSTR;
 
 // Uniform (SGPR) base + 32-bit per-lane index: the `saddr` form of global_load / global_store.  The base is made opaque per access so
-// that the compiler neither folds it into 64-bit per-lane addresses nor hoists 16 of those out of the pass loop (spills).
+// that the compiler neither folds it into 64-bit per-lane addresses nor hoists 16 of those out of the pass loop (spills); the
+// constant part of an address is added AFTER the opaque copy for the same reason (base + constant is loop invariant too).
 template <class P> __device__ __forceinline__ P sbase(P p) { asm volatile("" : "+s"(p)); return p; }
+// base + constant as ONE scalar value: opaque before the addition (so that it is not hoisted out of the pass loop and spilled) and
+// after it (so that it is not re-associated into a 64-bit per-lane address)
+template <class P> __device__ __forceinline__ P sbk(P p, long k) { return sbase(sbase(p) + k); }
 
 // two consecutive twiddles in one 16-byte load
 __device__ __forceinline__ void ld2(u64* out, gcptr2 base, unsigned idx) {
@@ -60,7 +64,7 @@ __device__ __forceinline__ void ld2(u64* out, gcptr2 base, unsigned idx) {
 }
 
 // per-job constants, wave-uniform (SGPRs)
-struct MC { i32 q0, q1; u32 ninv; u64 q, q2; float finv; };
+struct MC { i32 q0, q1; u32 ninv; u64 q; float finv; };
 
 // ------------------------------------------------------------------ signed-digit Montgomery product (modarith.h mont_mul_sd)
 // a * w * 2^-64 mod q as a signed representative, |r| <= q/2 + |a| w / 2^64 + 1: 12 multiplier-class + 2 plain instructions.
@@ -238,11 +242,10 @@ struct Job { gcptr src; gptr dst; const u64* psi; smodptr mp; bool red; bool ski
 template <bool DEC>
 __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, int t) {
     smodptr mp = jb.mp;                                 // scalar loads: the constants live in SGPRs
-    struct { u64 qs, r1s; } md;
-    md.qs = mp->qs; md.r1s = mp->r1s;
+    const u64 qs = mp->qs;
     MC c;
-    c.q = mp->q; c.q2 = mp->q2; c.ninv = mp->ninv32;
-    c.q0 = (i32)lo32(md.qs); c.q1 = (i32)hi32(md.qs);
+    c.q = mp->q; c.ninv = mp->ninv32;
+    c.q0 = (i32)lo32(qs); c.q1 = (i32)hi32(qs);
     c.finv = __builtin_bit_cast(float, mp->finv);
     asm("" : "+s"(c.q0), "+s"(c.q1), "+s"(c.ninv));        // opaque wave-uniform 32-bit values (see modarith.h mont_mul_sd)
     scptr psi_s = (scptr)jb.psi;
@@ -263,18 +266,19 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
             for (int r0 = 0; r0 < 16; r0 += 8) {
                 u64 U[8], V[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { U[r] = sbase(src + (r0 + r) * NT)[tu]; V[r] = sbase(src + HH + (r0 + r) * NT)[tu]; }
+                for (int r = 0; r < 8; ++r) { U[r] = sbk(src, (r0 + r) * NT)[tu]; V[r] = sbk(src, HH + (r0 + r) * NT)[tu]; }
                 // digits of a foreign modulus (Decompose) may be far above q: bring them to (-q, q) first.  MODE 0 (q up to 2^60)
                 // has no headroom for five stages on raw inputs and always starts from reduced values.
                 if (big || red) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); }
+                    for (int r = 0; r < 8; ++r) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); __builtin_amdgcn_sched_barrier(0); }
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     bfly<true>(U[r], V[r], w1, c);
                     x[r0 + r] = U[r];
-                    sbase(dst + HH + (r0 + r) * NT)[tu] = V[r];
+                    sbk(dst, HH + (r0 + r) * NT)[tu] = V[r];
+                    __builtin_amdgcn_sched_barrier(0);       // one butterfly at a time: interleaved, their temporaries do not fit beside 16 loads in flight
                 }
                 asm volatile("" ::: "memory");
             }
@@ -284,23 +288,25 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                x[r] = __hip_atomic_load(sbase(dst + HH + r * NT) + tu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x[r] = __hip_atomic_load(sbk(dst, HH + r * NT) + tu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         H16_STAMP(1);                            // loads landed, stage 0 done
         // ---- phase A: bits 13..10, twiddles psi[2^k + (h << (k-1)) + i], k = 1..4
         {
-            u64 tw[15];
+            // (the 8 twiddles of the last stage are fetched after the first two stages: 30 twiddle SGPRs at once do not fit the
+            // 80-SGPR budget of 8 waves per SIMD beside the job state, and every spilled SGPR costs VALU lane moves)
+            u64 tw[7], tl[8];
             tw[0] = psi_s[2 + h];
 #pragma unroll
             for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[4 + 2 * h + i];
 #pragma unroll
             for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[8 + 4 * h + i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tw[7 + i] = psi_s[16 + 8 * h + i];
             stage<true, 3>(x, tw, c);
             stage<true, 2>(x, tw + 1, c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tl[i] = psi_s[16 + 8 * h + i];
             stage<true, 1>(x, tw + 3, c);
-            stage<true, 0>(x, tw + 7, c);
+            stage<true, 0>(x, tl, c);
         }
         reduce_all(x, c, big);                  // MODE 0: |x| < 3.6q after stage 0 + phase A -> (-q, q)
         H16_STAMP(2);
@@ -309,18 +315,18 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
         // ---- phase B: bits 9..6, twiddles psi[2^k + ((16h + wave) << (k-5)) + i], k = 5..8
         {
             const int cb = 16 * h + wv;
-            u64 tw[15];
+            u64 tw[7], tl[8];
             tw[0] = psi_s[32 + cb];
 #pragma unroll
             for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[64 + 2 * cb + i];
 #pragma unroll
             for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[128 + 4 * cb + i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tw[7 + i] = psi_s[256 + 8 * cb + i];
             stage<true, 3>(x, tw, c);
             stage<true, 2>(x, tw + 1, c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tl[i] = psi_s[256 + 8 * cb + i];
             stage<true, 1>(x, tw + 3, c);
-            stage<true, 0>(x, tw + 7, c);
+            stage<true, 0>(x, tl, c);
         }
         // Phases C and D: per-lane twiddles, fetched in 16-byte groups a few butterflies ahead of their use (at most three groups =
         // 12 VGPRs live; issuing all 15 + 12 at once would not fit beside the 32 data registers).  The first groups of a phase are
@@ -332,10 +338,10 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
             __builtin_assume(cu < 512);
             u64 g[8][2];
             auto loadg = [&](int k) {
-                if (k == 0) g[0][0] = *(gcptr)((const __attribute__((address_space(1))) char*)sbase(psi_v + 512) + (unsigned)(cu * 8u));
-                else if (k == 1) ld2(g[1], (gcptr2)sbase(psi_v + 1024), cu);
-                else if (k < 4) ld2(g[k], (gcptr2)sbase(psi_v + 2048) + (k - 2), 2 * cu);
-                else ld2(g[k], (gcptr2)sbase(psi_v + 4096) + (k - 4), 4 * cu);
+                if (k == 0) g[0][0] = *(gcptr)((const __attribute__((address_space(1))) char*)sbk(psi_v, 512) + (unsigned)(cu * 8u));
+                else if (k == 1) ld2(g[1], (gcptr2)sbk(psi_v, 1024), cu);
+                else if (k < 4) ld2(g[k], (gcptr2)sbk(psi_v, 2048) + (k - 2), 2 * cu);
+                else ld2(g[k], (gcptr2)sbk(psi_v, 4096) + (k - 4), 4 * cu);
             };
             loadg(0); loadg(1); loadg(2);
             H16_STAMP(4);
@@ -363,8 +369,8 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
             __builtin_assume(du < 2048);
             u64 g[6][2];
             auto loadg = [&](int k) {
-                if (k < 2) ld2(g[k], (gcptr2)sbase(psi_v + 8192) + k, 2 * du);
-                else ld2(g[k], (gcptr2)sbase(psi_v + 16384) + (k - 2), 4 * du);
+                if (k < 2) ld2(g[k], (gcptr2)sbk(psi_v, 8192) + k, 2 * du);
+                else ld2(g[k], (gcptr2)sbk(psi_v, 16384) + (k - 2), 4 * du);
             };
             loadg(0); loadg(1); loadg(2);
             H16_STAMP(6);
@@ -397,7 +403,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
         exchange<X_DE>(x, lds, wv, l);
         H16_STAMP(10);
         {
-            gptr o = dst + h * HH + wv * 1024;
+            const int obase = h * HH + wv * 1024;
             const unsigned lu = (unsigned)l;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -405,9 +411,9 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
                 if (x[r] != 0x123456789abcdefull) continue;      // timing experiment only: (almost) no result stores
 #endif
 #ifndef MKHE_X_NO_NTSTORE      // results are written once and read by later kernels: stream them past the caches (twiddles, sources and the CRS stay resident)
-                __builtin_nontemporal_store(x[r], (u64 __attribute__((address_space(1)))*)(sbase(o + r * 64) + lu));
+                __builtin_nontemporal_store(x[r], (u64 __attribute__((address_space(1)))*)(sbk(dst, obase + r * 64) + lu));
 #else
-                sbase(o + r * 64)[lu] = x[r];
+                sbk(dst, obase + r * 64)[lu] = x[r];
 #endif
             }
         }
