@@ -55,6 +55,24 @@ template <class P> __device__ __forceinline__ P sbase(P p) { asm volatile("" : "
 // base + constant as ONE scalar value: opaque before the addition (so that it is not hoisted out of the pass loop and spilled) and
 // after it (so that it is not re-associated into a 64-bit per-lane address)
 template <class P> __device__ __forceinline__ P sbk(P p, long k) { return sbase(sbase(p) + k); }
+// element `byte_off / 8` of a scalar base: the per-lane part of the address is a 32-bit BYTE offset, so that base + zext(offset) selects
+// the SGPR-base (saddr) form of the global instructions whatever the compiler knows about the index range
+// The pass-0 source loads and the parking stores are spelled out: left to the compiler, the second group of 16 loads is addressed with
+// 64-bit per-lane additions (one multiplier-class VALU instruction per load) and some loaded values are spilled the moment they land
+// (s_waitcnt vmcnt(0) + scratch_store between two loads).  ld_issue only issues; ld_wait16 is the one wait, and it takes the sixteen
+// destinations as read-write operands so that no use can be scheduled above it.
+__device__ __forceinline__ u64 ld_issue(gcptr base, unsigned byte_off) {
+    u64 v; asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base)); return v;
+}
+__device__ __forceinline__ void ld_wait16(u64 (&a)[8], u64 (&b)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                                         "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+}
+__device__ __forceinline__ void st_issue(gptr base, unsigned byte_off, u64 v) {
+    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ gcptr at(gcptr p, unsigned byte_off) { return (gcptr)((const __attribute__((address_space(1))) char*)p + byte_off); }
+__device__ __forceinline__ gptr at(gptr p, unsigned byte_off) { return (gptr)((__attribute__((address_space(1))) char*)p + byte_off); }
 
 // two consecutive twiddles in one 16-byte load
 __device__ __forceinline__ void ld2(u64* out, gcptr2 base, unsigned idx) {
@@ -196,13 +214,20 @@ template <bool CROSS> __device__ __forceinline__ void xsync() {
     if constexpr (CROSS) __syncthreads();
     else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 }
-template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds, int wv, int l) {
+// lane index, recomputed where it is needed (two plain VALU instructions) instead of a register that lives -- or is spilled and
+// reloaded -- across the whole limb; the wave index is an SGPR
+__device__ __forceinline__ int lane_id() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));            // not hoisted, not common-subexpression'd across phases
+    return l;
+}
+template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds, int wv) {
     constexpr bool CROSS = X == X_AB;
 #ifdef MKHE_H16_X_NOXCHG
     if ((MKHE_H16_X_NOXCHG >> X) & 1) return;      // timing experiment only (wrong results): cost of this re-distribution
 #endif
-    // opaque copies: the (loop-invariant) LDS bases are recomputed next to their use instead of living in VGPRs across the whole job
-    asm volatile("" : "+v"(l));
+    // the (loop-invariant) LDS bases are recomputed next to their use instead of living in VGPRs across the whole job
+    const int l = lane_id();
     typedef __attribute__((address_space(3))) u32* lptr;
     typedef volatile __attribute__((address_space(3))) u32* vlptr;
     lptr wr = (lptr)lds + wbase<X>(wv, l);
@@ -240,7 +265,7 @@ struct Job { gcptr src; gptr dst; const u64* psi; smodptr mp; bool red; bool ski
 // branches around the reductions), which halves the code the two workgroups of a CU -- and the neighbouring CU that shares the
 // instruction cache -- stream through
 template <bool DEC>
-__device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, int t) {
+__device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, const int wv) {
     smodptr mp = jb.mp;                                 // scalar loads: the constants live in SGPRs
     const u64 qs = mp->qs;
     MC c;
@@ -251,10 +276,8 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
     scptr psi_s = (scptr)jb.psi;
     gcptr psi_v = (gcptr)jb.psi;
     const gcptr src = jb.src; const gptr dst = jb.dst;
-    const int wv = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
     const bool red = DEC && jb.red;
     u64 x[16];
-    const unsigned tu = (unsigned)t;
 #pragma unroll 1
     for (int hh = 0; hh < 2; ++hh) {
         const int h = __builtin_amdgcn_readfirstlane(hh);
@@ -262,11 +285,13 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
         if (h == 0) {
             // ---- stage 0: cross-half butterflies; upper outputs parked in dst[N/2 + j]
             const u64 w1 = psi_s[1];
+            const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
                 u64 U[8], V[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { U[r] = sbk(src, (r0 + r) * NT)[tu]; V[r] = sbk(src, HH + (r0 + r) * NT)[tu]; }
+                for (int r = 0; r < 8; ++r) { U[r] = ld_issue(sbk(src, (r0 + r) * NT), tb); V[r] = ld_issue(sbk(src, HH + (r0 + r) * NT), tb); }
+                ld_wait16(U, V);
                 // digits of a foreign modulus (Decompose) may be far above q: bring them to (-q, q) first.  MODE 0 (q up to 2^60)
                 // has no headroom for five stages on raw inputs and always starts from reduced values.
                 if (big || red) {
@@ -277,7 +302,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
                 for (int r = 0; r < 8; ++r) {
                     bfly<true>(U[r], V[r], w1, c);
                     x[r0 + r] = U[r];
-                    sbk(dst, HH + (r0 + r) * NT)[tu] = V[r];
+                    st_issue(sbk(dst, HH + (r0 + r) * NT), tb, V[r]);
                     __builtin_amdgcn_sched_barrier(0);       // one butterfly at a time: interleaved, their temporaries do not fit beside 16 loads in flight
                 }
                 asm volatile("" ::: "memory");
@@ -286,9 +311,10 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
             // the parked half: written by this same thread in pass 0; all but the 16 youngest memory operations (the final
             // stores of pass 0) are complete before the reload is issued
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                x[r] = __hip_atomic_load(sbk(dst, HH + r * NT) + tu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x[r] = __hip_atomic_load(at(sbk(dst, HH + r * NT), tb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         H16_STAMP(1);                            // loads landed, stage 0 done
         // ---- phase A: bits 13..10, twiddles psi[2^k + (h << (k-1)) + i], k = 1..4
@@ -310,7 +336,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
         }
         reduce_all(x, c, big);                  // MODE 0: |x| < 3.6q after stage 0 + phase A -> (-q, q)
         H16_STAMP(2);
-        exchange<X_AB>(x, lds, wv, l);
+        exchange<X_AB>(x, lds, wv);
         H16_STAMP(3);
         // ---- phase B: bits 9..6, twiddles psi[2^k + ((16h + wave) << (k-5)) + i], k = 5..8
         {
@@ -333,7 +359,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
         // requested before the re-distribution that precedes it.
         // ---- phase C: bits 5..2, twiddles psi[2^k + (cc << (k-9)) + i], k = 9..12, cc = (16h + wave) * 16 + bits 9..6 (lane >> 2)
         {
-            int lc = l; asm volatile("" : "+v"(lc));
+            const int lc = lane_id();
             const unsigned cu = (unsigned)((16 * h + wv) * 16 + (lc >> 2));
             __builtin_assume(cu < 512);
             u64 g[8][2];
@@ -345,7 +371,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
             };
             loadg(0); loadg(1); loadg(2);
             H16_STAMP(4);
-            exchange<X_BC>(x, lds, wv, l);
+            exchange<X_BC>(x, lds, wv);
             H16_STAMP(5);
 #pragma unroll
             for (int n = 0; n < 32; ++n) {
@@ -364,7 +390,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
         reduce_all(x, c, big);                  // MODE 0: |x| < 5.9q < 2^62.6 after phases B and C (8 stages) -> (-q, q)
         // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane
         {
-            int ld = l; asm volatile("" : "+v"(ld));
+            const int ld = lane_id();
             const unsigned du = (unsigned)((16 * h + wv) * 64 + ld);
             __builtin_assume(du < 2048);
             u64 g[6][2];
@@ -374,7 +400,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
             };
             loadg(0); loadg(1); loadg(2);
             H16_STAMP(6);
-            exchange<X_CD>(x, lds, wv, l);
+            exchange<X_CD>(x, lds, wv);
             H16_STAMP(7);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
@@ -400,20 +426,20 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
             for (int r = 0; r < 16; ++r) x[r] = (u64)((i64)x[r] + bias);
         }
         H16_STAMP(9);
-        exchange<X_DE>(x, lds, wv, l);
+        exchange<X_DE>(x, lds, wv);
         H16_STAMP(10);
         {
             const int obase = h * HH + wv * 1024;
-            const unsigned lu = (unsigned)l;
+            const unsigned lb = 8u * (unsigned)lane_id();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
 #ifdef MKHE_H16_X_NOSTORE
                 if (x[r] != 0x123456789abcdefull) continue;      // timing experiment only: (almost) no result stores
 #endif
 #ifndef MKHE_X_NO_NTSTORE      // results are written once and read by later kernels: stream them past the caches (twiddles, sources and the CRS stay resident)
-                __builtin_nontemporal_store(x[r], (u64 __attribute__((address_space(1)))*)(sbk(dst, obase + r * 64) + lu));
+                __builtin_nontemporal_store(x[r], (u64 __attribute__((address_space(1)))*)at(sbk(dst, obase + r * 64), lb));
 #else
-                sbk(dst, obase + r * 64)[lu] = x[r];
+                *at(sbk(dst, obase + r * 64), lb) = x[r];
 #endif
             }
         }
@@ -424,7 +450,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, in
 template <bool DEC>
 __global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    const int t = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int njobs = b.nslots * b.nouter;
     // optional start delay of the second half of the persistent grid (the co-resident workgroup of every CU, as far as the
     // dispatcher deals workgroups b and b + gridDim/2 to the same CU): the two workgroups of a CU then sit in different phases
@@ -464,16 +490,16 @@ __global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
             jb.red = qsb > 4 * jb.mp->q;
         }
 #ifdef MKHE_PHASE_TRACE
-        if (jb.trace && (t & 63) == 0) {
-            u64* tw = jb.trace + (long)(t >> 6) * 32;
+        if (jb.trace && ((int)threadIdx.x & 63) == 0) {
+            u64* tw = jb.trace + (long)wv * 32;
             tw[12] = __builtin_amdgcn_s_memrealtime();
             tw[13] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
             tw[14] = blockIdx.x;
         }
 #endif
-        limb<DEC>(jb, ((kb->small_slots >> s) & 1) == 0, lds, t);
+        limb<DEC>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv);
 #ifdef MKHE_PHASE_TRACE
-        if (jb.trace && (t & 63) == 0) jb.trace[(long)(t >> 6) * 32 + 28] = __builtin_amdgcn_s_memrealtime();
+        if (jb.trace && ((int)threadIdx.x & 63) == 0) jb.trace[(long)wv * 32 + 28] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
 }
