@@ -7,8 +7,8 @@
 using namespace mkhe;
 
 struct mkhe_ctx { Context* c; };
-struct mkhe_swk { Swk s; };
-struct mkhe_ct { Ct c; };
+struct mkhe_swk { Swk s; mutable HandleUsers users; };
+struct mkhe_ct { Ct c; mutable HandleUsers users; };
 struct mkhe_graph { hipGraphExec_t exec; };
 
 static thread_local std::string g_err;
@@ -25,14 +25,21 @@ static thread_local Context* g_last_ctx = nullptr;
 static Context* need(const mkhe_ctx* ctx) {
     if (!ctx || !ctx->c) { g_last_ctx = nullptr; throw Error("mkhe: null context"); }
     g_last_ctx = ctx->c;
+    ctx->c->touch();                 // anything this call enqueues is counted (Context::seq_, the pool's ordering clock)
     return ctx->c;
 }
 
-static std::vector<const Swk*> swk_list(const mkhe_swk* const* v, int n) {
+// Every entry point names the handles it is about to enqueue work on (Context::note_use: the pool of whichever context the buffer
+// is freed into later orders itself behind exactly these uses, csrc/engine.h).
+static void mark1(Context* c, const mkhe_ct* h) { if (h) c->note_use(h->users); }
+static void mark1(Context* c, const mkhe_swk* h) { if (h) c->note_use(h->users); }
+template <class... H> static void mark(const mkhe_ctx* ctx, H... hs) { if (ctx && ctx->c) { (mark1(ctx->c, hs), ...); } }
+
+static std::vector<const Swk*> swk_list(const mkhe_ctx* ctx, const mkhe_swk* const* v, int n) {
     std::vector<const Swk*> r;
     if (!v) return r;
     r.resize(n);
-    for (int i = 0; i < n; ++i) { if (!v[i]) throw Error("mkhe: null key handle in a per-party key list"); r[i] = &v[i]->s; }
+    for (int i = 0; i < n; ++i) { if (!v[i]) throw Error("mkhe: null key handle in a per-party key list"); mark(ctx, v[i]); r[i] = &v[i]->s; }
     return r;
 }
 
@@ -88,7 +95,7 @@ int mkhe_ctx_beta(const mkhe_ctx* ctx, int level) { if (!ctx) return 0; return c
 int mkhe_ctx_n(const mkhe_ctx* ctx) { if (!ctx) return 0; return ctx->c->N; }
 size_t mkhe_ctx_swk_words(const mkhe_ctx* ctx) { if (!ctx) return 0; return ctx->c->swk_words(); }
 uint64_t mkhe_ctx_psi(const mkhe_ctx* ctx, int i) { if (!ctx) return 0; return (i >= 0 && i < ctx->c->mall) ? ctx->c->psi_plain[i] : 0; }
-void* mkhe_ctx_stream(mkhe_ctx* ctx) { if (!ctx) return 0; return (void*)ctx->c->stream; }
+void* mkhe_ctx_stream(mkhe_ctx* ctx) { if (!ctx) return 0; ctx->c->mark_external(); return (void*)ctx->c->stream; }
 
 // ---- switching keys
 static void swk_create(mkhe_ctx* ctx, mkhe_swk** out, bool zero) {
@@ -97,18 +104,18 @@ static void swk_create(mkhe_ctx* ctx, mkhe_swk** out, bool zero) {
     if (!out) throw Error("mkhe_swk_create: null argument");
     mkhe_swk* s = new mkhe_swk();
     try { s->s.d = c->pool_alloc(c->swk_words()); } catch (...) { delete s; throw; }
-    if (zero) MKHE_HIP(hipMemsetAsync(s->s.d, 0, c->swk_words() * sizeof(u64), c->stream));
+    if (zero) { c->note_use(s->users); MKHE_HIP(hipMemsetAsync(s->s.d, 0, c->swk_words() * sizeof(u64), c->stream)); }
     *out = s;
 }
 int mkhe_swk_create(mkhe_ctx* ctx, mkhe_swk** out) { MKHE_TRY(swk_create(ctx, out, true)) }
 int mkhe_swk_create_uninit(mkhe_ctx* ctx, mkhe_swk** out) { MKHE_TRY(swk_create(ctx, out, false)) }
 void mkhe_swk_destroy(mkhe_ctx* ctx, mkhe_swk* swk) {
     if (!swk) return;
-    if (swk->s.d && swk->s.owned) { if (ctx) ctx->c->pool_free(swk->s.d, ctx->c->swk_words()); else (void)hipFree(swk->s.d); }
+    if (swk->s.d && swk->s.owned) { if (ctx) ctx->c->pool_free(swk->s.d, ctx->c->swk_words(), &swk->users); else (void)hipFree(swk->s.d); }
     delete swk;
 }
 int mkhe_swk_upload(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* host) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, swk);
         Context* c = need(ctx);
         if (!swk || !host) throw Error("mkhe_swk_upload: null argument");
         MKHE_HIP(hipMemcpyAsync(swk->s.d, host, c->swk_words() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
@@ -116,7 +123,7 @@ int mkhe_swk_upload(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* host) {
     })
 }
 int mkhe_swk_upload_limbs(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* const* limbs, int ndigits) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, swk);
         Context* c = need(ctx);
         if (!swk || !limbs) throw Error("mkhe_swk_upload_limbs: null argument");
         if (ndigits < 0 || ndigits > c->beta_max) throw Error("mkhe_swk_upload_limbs: bad digit count");
@@ -126,14 +133,14 @@ int mkhe_swk_upload_limbs(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* const* l
     })
 }
 int mkhe_swk_download(mkhe_ctx* ctx, const mkhe_swk* swk, uint64_t* host) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, swk);
         Context* c = need(ctx);
         if (!swk || !host) throw Error("mkhe_swk_download: null argument");
         MKHE_HIP(hipMemcpyAsync(host, swk->s.d, c->swk_words() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         c->sync();
     })
 }
-void* mkhe_swk_devptr(mkhe_swk* swk) { return swk ? swk->s.d : nullptr; }
+void* mkhe_swk_devptr(mkhe_swk* swk) { if (swk) swk->users.exposed = true; return swk ? swk->s.d : nullptr; }
 
 // ---- ciphertexts
 static void ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, bool zero, mkhe_ct** out);
@@ -155,18 +162,18 @@ static void ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, bool zero
         for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (ids[i] == ids[j]) { delete t; throw Error("mkhe_ct_create: repeated id"); }
         const size_t w = (size_t)(1 + n) * limbs * c->N;
         try { t->c.d = c->pool_alloc(w); } catch (...) { delete t; throw; }
-        if (zero) MKHE_HIP(hipMemsetAsync(t->c.d, 0, w * sizeof(u64), c->stream));
+        if (zero) { c->note_use(t->users); MKHE_HIP(hipMemsetAsync(t->c.d, 0, w * sizeof(u64), c->stream)); }
         *out = t;
     }
 }
 extern "C" {
 void mkhe_ct_destroy(mkhe_ctx* ctx, mkhe_ct* ct) {
     if (!ct) return;
-    if (ct->c.d) { if (ctx) ctx->c->pool_free(ct->c.d, (size_t)(1 + ct->c.n) * ct->c.limbs * ctx->c->N); else (void)hipFree(ct->c.d); }
+    if (ct->c.d) { if (ctx) ctx->c->pool_free(ct->c.d, (size_t)(1 + ct->c.n) * ct->c.limbs * ctx->c->N, &ct->users); else (void)hipFree(ct->c.d); }
     delete ct;
 }
 int mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, ct);
         Context* c = need(ctx);
         if (!ct || !host) throw Error("mkhe_ct_upload: null argument");
         const size_t w = (size_t)(1 + ct->c.n) * ct->c.limbs * c->N;
@@ -175,7 +182,7 @@ int mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host) {
     })
 }
 int mkhe_ct_copy(mkhe_ctx* ctx, const mkhe_ct* in, mkhe_ct* out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, in, out);
         if (!in || !out) throw Error("mkhe_ct_copy: null argument");
         if (in->c.n != out->c.n || in->c.limbs != out->c.limbs || in->c.ids != out->c.ids) throw Error("mkhe_ct_copy: shapes differ");
         const size_t w = (size_t)(1 + in->c.n) * in->c.limbs * need(ctx)->N;
@@ -183,7 +190,7 @@ int mkhe_ct_copy(mkhe_ctx* ctx, const mkhe_ct* in, mkhe_ct* out) {
     })
 }
 int mkhe_ct_upload_poly_limbs(mkhe_ctx* ctx, mkhe_ct* ct, int slot, const uint64_t* const* limbs) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, ct);
         Context* c = need(ctx);
         if (!ct || !limbs) throw Error("mkhe_ct_upload_poly_limbs: null argument");
         if (slot < 0 || slot > ct->c.n) throw Error("mkhe_ct_upload_poly_limbs: bad slot");
@@ -193,7 +200,7 @@ int mkhe_ct_upload_poly_limbs(mkhe_ctx* ctx, mkhe_ct* ct, int slot, const uint64
     })
 }
 int mkhe_ct_download(mkhe_ctx* ctx, const mkhe_ct* ct, uint64_t* host) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, ct);
         Context* c = need(ctx);
         if (!ct || !host) throw Error("mkhe_ct_download: null argument");
         const size_t w = (size_t)(1 + ct->c.n) * ct->c.limbs * c->N;
@@ -202,7 +209,7 @@ int mkhe_ct_download(mkhe_ctx* ctx, const mkhe_ct* ct, uint64_t* host) {
     })
 }
 int mkhe_ct_download_poly_limbs(mkhe_ctx* ctx, const mkhe_ct* ct, int slot, uint64_t* const* limbs) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, ct);
         Context* c = need(ctx);
         if (!ct || !limbs) throw Error("mkhe_ct_download_poly_limbs: null argument");
         if (slot < 0 || slot > ct->c.n) throw Error("mkhe_ct_download_poly_limbs: bad slot");
@@ -213,7 +220,7 @@ int mkhe_ct_download_poly_limbs(mkhe_ctx* ctx, const mkhe_ct* ct, int slot, uint
 }
 int mkhe_ct_limbs(const mkhe_ct* ct) { return ct ? ct->c.limbs : 0; }
 int mkhe_ct_nparties(const mkhe_ct* ct) { return ct ? ct->c.n : 0; }
-void* mkhe_ct_devptr(mkhe_ct* ct) { return ct ? ct->c.d : nullptr; }
+void* mkhe_ct_devptr(mkhe_ct* ct) { if (ct) ct->users.exposed = true; return ct ? ct->c.d : nullptr; }
 
 // ---- raw buffers
 int mkhe_buf_alloc(mkhe_ctx* ctx, size_t words, void** dev_out) {
@@ -255,14 +262,15 @@ static const u64* ct_slot(const Context* c, const mkhe_ct* ct, int slot, int lev
     return ct->c.d + (size_t)slot * ct->c.limbs * c->N;
 }
 int mkhe_decompose(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* ct, int slot, mkhe_swk* out) {
-    MKHE_TRY({ if (!out) throw Error("mkhe_decompose: null argument"); need(ctx)->decompose(level, is_ntt != 0, ct_slot(need(ctx), ct, slot, level), out->s.d); })
+    MKHE_TRY({ mark(ctx, ct, out); if (!out) throw Error("mkhe_decompose: null argument"); need(ctx)->decompose(level, is_ntt != 0, ct_slot(need(ctx), ct, slot, level), out->s.d); })
 }
 int mkhe_hoisted_form(mkhe_ctx* ctx, int level, const mkhe_ct* ct, mkhe_swk* const* out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, ct);
         if (!ct || (ct->c.n > 0 && !out)) throw Error("mkhe_hoisted_form: null argument");
         std::vector<const u64*> src; std::vector<u64*> dst;
         for (int i = 0; i < ct->c.n; ++i) {
             if (!out[i]) throw Error("mkhe_hoisted_form: null output handle");
+            mark(ctx, out[i]);
             src.push_back(ct_slot(need(ctx), ct, 1 + i, level)); dst.push_back(out[i]->s.d);
         }
         if (!src.empty()) need(ctx)->decompose_batch(level, src, dst, false);
@@ -270,7 +278,7 @@ int mkhe_hoisted_form(mkhe_ctx* ctx, int level, const mkhe_ct* ct, mkhe_swk* con
 }
 int mkhe_external_product(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* a, int slot,
                           const mkhe_swk* bg, mkhe_ct* out, int out_slot) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, a, bg, out);
         if (!out || !bg) throw Error("mkhe_external_product: null argument");
         if (out->c.limbs != level + 1) throw Error("mkhe_external_product: out must have level+1 limbs");
         need(ctx)->external_product(level, is_ntt != 0, ct_slot(need(ctx), a, slot, level), bg->s.d,
@@ -278,7 +286,7 @@ int mkhe_external_product(mkhe_ctx* ctx, int level, int is_ntt, const mkhe_ct* a
     })
 }
 int mkhe_external_product_hoisted(mkhe_ctx* ctx, int level, const mkhe_swk* ah, const mkhe_swk* bg, mkhe_ct* out, int out_slot) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, ah, bg, out);
         if (!out || !ah || !bg) throw Error("mkhe_external_product_hoisted: null argument");
         if (out->c.limbs != level + 1) throw Error("mkhe_external_product_hoisted: out must have level+1 limbs");
         need(ctx)->external_product_hoisted(level, ah->s.d, bg->s.d, const_cast<u64*>(ct_slot(need(ctx), out, out_slot, level)), false);
@@ -288,10 +296,10 @@ int mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                        const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
                        const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
                        const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, op0, op1, crs_u, out);
         if (!op0 || !op1 || !out || !crs_u || !rlk_b1 || !rlk_d0 || !rlk_v0) throw Error("mkhe_mul_and_relin: null argument");
-        auto h0 = swk_list(hoist0, op0->c.n); auto h1 = swk_list(hoist1, op1->c.n);
-        auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n); auto v0 = swk_list(rlk_v0, op0->c.n);
+        auto h0 = swk_list(ctx, hoist0, op0->c.n); auto h1 = swk_list(ctx, hoist1, op1->c.n);
+        auto b1 = swk_list(ctx, rlk_b1, op1->c.n); auto d0 = swk_list(ctx, rlk_d0, op0->c.n); auto v0 = swk_list(ctx, rlk_v0, op0->c.n);
         const bool same = (op0 == op1) && (hoist0 == hoist1);
         need(ctx)->mul_and_relin(op0->c, same ? op0->c : op1->c, hoist0 ? h0.data() : nullptr,
                               hoist1 ? (same ? h0.data() : h1.data()) : nullptr,
@@ -302,33 +310,33 @@ int mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                     const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
                     const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
                     int with_c0, mkhe_ct* out, mkhe_swk* x_part, mkhe_swk* y_part) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, op0, op1, out, x_part, y_part);
         if (!op0 || !op1 || !out || !x_part || !y_part || !rlk_b1 || !rlk_d0) throw Error("mkhe_mr_partial: null argument");
-        auto h0 = swk_list(hoist0, op0->c.n); auto h1 = swk_list(hoist1, op1->c.n);
-        auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n);
+        auto h0 = swk_list(ctx, hoist0, op0->c.n); auto h1 = swk_list(ctx, hoist1, op1->c.n);
+        auto b1 = swk_list(ctx, rlk_b1, op1->c.n); auto d0 = swk_list(ctx, rlk_d0, op0->c.n);
         need(ctx)->mr_prepare(op0->c, op1->c, hoist0 ? h0.data() : nullptr, hoist1 ? h1.data() : nullptr, with_c0 != 0, out->c);
         need(ctx)->mr_xy(b1.data(), d0.data(), x_part->s.d, y_part->s.d, false);
     })
 }
 int mkhe_swk_fold(mkhe_ctx* ctx, mkhe_swk* swk, int level, int mform) {
-    MKHE_TRY({ if (!swk) throw Error("mkhe_swk_fold: null argument"); need(ctx)->fold(swk->s.d, true, level, need(ctx)->beta(level), (long)need(ctx)->mtot * need(ctx)->N, mform != 0); })
+    MKHE_TRY({ mark(ctx, swk); if (!swk) throw Error("mkhe_swk_fold: null argument"); need(ctx)->fold(swk->s.d, true, level, need(ctx)->beta(level), (long)need(ctx)->mtot * need(ctx)->N, mform != 0); })
 }
 int mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x, const mkhe_swk* y,
                    const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, op0, op1, x, y, crs_u, out);
         if (!op0 || !op1 || !x || !y || !rlk_v0 || !crs_u || !out) throw Error("mkhe_mr_finish: null argument");
-        auto v0 = swk_list(rlk_v0, op0->c.n);
+        auto v0 = swk_list(ctx, rlk_v0, op0->c.n);
         need(ctx)->mr_finish(op0->c, op1->c, x->s.d, y->s.d, v0.data(), crs_u->s, out->c);
     })
 }
 int mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct) {
-    MKHE_TRY({ if (!ct) throw Error("mkhe_ct_fold: null argument"); need(ctx)->fold(ct->c.d, false, ct->c.limbs - 1, 1 + ct->c.n, (long)ct->c.limbs * need(ctx)->N, false); })
+    MKHE_TRY({ mark(ctx, ct); if (!ct) throw Error("mkhe_ct_fold: null argument"); need(ctx)->fold(ct->c.d, false, ct->c.limbs - 1, 1 + ct->c.n, (long)ct->c.limbs * need(ctx)->N, false); })
 }
 int mkhe_rotate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* hoist,
                 const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, in, crs, out);
         if (!in || !out || !rk || !crs) throw Error("mkhe_rotate: null argument");
-        auto h = swk_list(hoist, in->c.n); auto r = swk_list(rk, in->c.n);
+        auto h = swk_list(ctx, hoist, in->c.n); auto r = swk_list(ctx, rk, in->c.n);
         need(ctx)->rotate(galEl, in->c, hoist ? h.data() : nullptr, r.data(), crs->s, out->c);
     })
 }
@@ -338,47 +346,47 @@ int mkhe_ctx_set_owned(mkhe_ctx* ctx, const int* mod_idx, int n) {
 int mkhe_lsh_phase(mkhe_ctx* ctx, int phase, const mkhe_ct* op0, const mkhe_ct* op1,
                    const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0, const mkhe_swk* const* rlk_v0,
                    const mkhe_swk* crs_u, mkhe_ct* out, void* dev_stage, size_t* words_out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, op0, op1, crs_u, out);
         if (!op0 || !op1 || !out || !words_out) throw Error("mkhe_lsh_phase: null argument");
-        auto b1 = swk_list(rlk_b1, op1->c.n); auto d0 = swk_list(rlk_d0, op0->c.n); auto v0 = swk_list(rlk_v0, op0->c.n);
+        auto b1 = swk_list(ctx, rlk_b1, op1->c.n); auto d0 = swk_list(ctx, rlk_d0, op0->c.n); auto v0 = swk_list(ctx, rlk_v0, op0->c.n);
         *words_out = need(ctx)->lsh_phase(phase, op0->c, op1->c, rlk_b1 ? b1.data() : nullptr, rlk_d0 ? d0.data() : nullptr,
                                        rlk_v0 ? v0.data() : nullptr, crs_u ? &crs_u->s : nullptr, out->c, (u64*)dev_stage);
     })
 }
 int mkhe_rotate_partial(mkhe_ctx* ctx, const mkhe_ct* in, const mkhe_swk* const* hoist,
                         const mkhe_swk* const* rk, const mkhe_swk* crs, int with_c0, mkhe_ct* out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, in, crs, out);
         if (!in || !out || !rk || !crs) throw Error("mkhe_rotate_partial: null argument");
-        auto h = swk_list(hoist, in->c.n); auto r = swk_list(rk, in->c.n);
+        auto h = swk_list(ctx, hoist, in->c.n); auto r = swk_list(ctx, rk, in->c.n);
         need(ctx)->rotate_partial(in->c, hoist ? h.data() : nullptr, r.data(), crs->s, with_c0 != 0, out->c);
     })
 }
 int mkhe_ct_automorphism(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, mkhe_ct* out) {
-    MKHE_TRY({ if (!in || !out) throw Error("mkhe_ct_automorphism: null argument"); need(ctx)->automorphism(galEl, in->c, out->c); })
+    MKHE_TRY({ mark(ctx, in, out); if (!in || !out) throw Error("mkhe_ct_automorphism: null argument"); need(ctx)->automorphism(galEl, in->c, out->c); })
 }
 int mkhe_conjugate(mkhe_ctx* ctx, uint64_t galEl, const mkhe_ct* in, const mkhe_swk* const* ck,
                    const mkhe_swk* crs, mkhe_ct* out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, in, crs, out);
         if (!in || !out || !ck || !crs) throw Error("mkhe_conjugate: null argument");
-        auto k = swk_list(ck, in->c.n);
+        auto k = swk_list(ctx, ck, in->c.n);
         need(ctx)->conjugate(galEl, in->c, k.data(), crs->s, out->c);
     })
 }
 int mkhe_rescale(mkhe_ctx* ctx, const mkhe_ct* in, int nb, mkhe_ct* out) {
-    MKHE_TRY({ if (!in || !out) throw Error("mkhe_rescale: null argument"); need(ctx)->rescale(in->c, nb, out->c); })
+    MKHE_TRY({ mark(ctx, in, out); if (!in || !out) throw Error("mkhe_rescale: null argument"); need(ctx)->rescale(in->c, nb, out->c); })
 }
 
 int mkhe_ct_add(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out) {
-    MKHE_TRY({ if (!op0 || !op1 || !out) throw Error("mkhe_ct_add: null argument"); need(ctx)->ct_binary(0, op0->c, op1->c, out->c); })
+    MKHE_TRY({ mark(ctx, op0, op1, out); if (!op0 || !op1 || !out) throw Error("mkhe_ct_add: null argument"); need(ctx)->ct_binary(0, op0->c, op1->c, out->c); })
 }
 int mkhe_ct_sub(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out) {
-    MKHE_TRY({ if (!op0 || !op1 || !out) throw Error("mkhe_ct_sub: null argument"); need(ctx)->ct_binary(1, op0->c, op1->c, out->c); })
+    MKHE_TRY({ mark(ctx, op0, op1, out); if (!op0 || !op1 || !out) throw Error("mkhe_ct_sub: null argument"); need(ctx)->ct_binary(1, op0->c, op1->c, out->c); })
 }
 int mkhe_ct_mul_const(mkhe_ctx* ctx, const mkhe_ct* in, const uint64_t* c_first, const uint64_t* c_second, mkhe_ct* out) {
-    MKHE_TRY({ if (!in || !out || !c_first || !c_second) throw Error("mkhe_ct_mul_const: null argument"); need(ctx)->ct_mul_const(in->c, c_first, c_second, out->c); })
+    MKHE_TRY({ mark(ctx, in, out); if (!in || !out || !c_first || !c_second) throw Error("mkhe_ct_mul_const: null argument"); need(ctx)->ct_mul_const(in->c, c_first, c_second, out->c); })
 }
 int mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe_ct* out) {
-    MKHE_TRY({ if (!in || !out || !dev_pt) throw Error("mkhe_ct_mul_ptxt: null argument"); need(ctx)->ct_mul_ptxt(in->c, (const u64*)dev_pt, out->c); })
+    MKHE_TRY({ mark(ctx, in, out); if (!in || !out || !dev_pt) throw Error("mkhe_ct_mul_ptxt: null argument"); need(ctx)->ct_mul_ptxt(in->c, (const u64*)dev_pt, out->c); })
 }
 
 // ---- key generation / CRS expansion
@@ -386,38 +394,38 @@ int mkhe_keygen_secret(mkhe_ctx* ctx, const int32_t* s, void* dev_sk) {
     MKHE_TRY({ if (!s || !dev_sk) throw Error("mkhe_keygen_secret: null argument"); need(ctx)->keygen_secret(s, (u64*)dev_sk); })
 }
 int mkhe_keygen_switching_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, mkhe_swk* out) {
-    MKHE_TRY({ if (!dev_sk || !e || !out) throw Error("mkhe_keygen_switching_key: null argument"); need(ctx)->keygen_switching_key((const u64*)dev_sk, e, out->s.d); })
+    MKHE_TRY({ mark(ctx, out); if (!dev_sk || !e || !out) throw Error("mkhe_keygen_switching_key: null argument"); need(ctx)->keygen_switching_key((const u64*)dev_sk, e, out->s.d); })
 }
 int mkhe_keygen_public_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, const mkhe_swk* crs_a, void* dev_pk) {
-    MKHE_TRY({ if (!dev_sk || !e || !crs_a || !dev_pk) throw Error("mkhe_keygen_public_key: null argument"); need(ctx)->keygen_public_key((const u64*)dev_sk, e, crs_a->s.d, (u64*)dev_pk); })
+    MKHE_TRY({ mark(ctx, crs_a); if (!dev_sk || !e || !crs_a || !dev_pk) throw Error("mkhe_keygen_public_key: null argument"); need(ctx)->keygen_public_key((const u64*)dev_sk, e, crs_a->s.d, (u64*)dev_pk); })
 }
 int mkhe_keygen_relin_key(mkhe_ctx* ctx, const void* dev_sk, const void* dev_r, const int32_t* e,
                           const mkhe_swk* crs_a, const mkhe_swk* crs_u, mkhe_swk* b, mkhe_swk* d, mkhe_swk* v) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, crs_a, crs_u, b, d, v);
         if (!dev_sk || !dev_r || !e || !crs_a || !crs_u || !b || !d || !v) throw Error("mkhe_keygen_relin_key: null argument");
         need(ctx)->keygen_relin_key((const u64*)dev_sk, (const u64*)dev_r, e, crs_a->s.d, crs_u->s.d, b->s.d, d->s.d, v->s.d);
     })
 }
 int mkhe_keygen_rotation_key(mkhe_ctx* ctx, uint64_t galEl, const void* dev_sk, const int32_t* e, const mkhe_swk* crs, mkhe_swk* out) {
-    MKHE_TRY({ if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_rotation_key: null argument"); need(ctx)->keygen_rotation_key(galEl, (const u64*)dev_sk, e, crs->s.d, out->s.d); })
+    MKHE_TRY({ mark(ctx, crs, out); if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_rotation_key: null argument"); need(ctx)->keygen_rotation_key(galEl, (const u64*)dev_sk, e, crs->s.d, out->s.d); })
 }
 int mkhe_keygen_conjugation_key(mkhe_ctx* ctx, const void* dev_sk, const int32_t* e, const mkhe_swk* crs, mkhe_swk* out) {
-    MKHE_TRY({ if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_conjugation_key: null argument"); need(ctx)->keygen_conjugation_key((const u64*)dev_sk, e, crs->s.d, out->s.d); })
+    MKHE_TRY({ mark(ctx, crs, out); if (!dev_sk || !e || !crs || !out) throw Error("mkhe_keygen_conjugation_key: null argument"); need(ctx)->keygen_conjugation_key((const u64*)dev_sk, e, crs->s.d, out->s.d); })
 }
 int mkhe_bfv_keygen_switching_key(mkhe_ctx* ctx, const void* dev_sk, const uint64_t* g, const int32_t* e, mkhe_swk* out) {
-    MKHE_TRY({ if (!dev_sk || !g || !e || !out) throw Error("mkhe_bfv_keygen_switching_key: null argument"); need(ctx)->bfv_keygen_switching_key((const u64*)dev_sk, g, e, out->s.d); })
+    MKHE_TRY({ mark(ctx, out); if (!dev_sk || !g || !e || !out) throw Error("mkhe_bfv_keygen_switching_key: null argument"); need(ctx)->bfv_keygen_switching_key((const u64*)dev_sk, g, e, out->s.d); })
 }
 int mkhe_bfv_keygen_relin_key(mkhe_ctx* ctx, const void* dev_sk, const void* dev_r, const uint64_t* g1, const uint64_t* g2,
                               const int32_t* e, const mkhe_swk* a1, const mkhe_swk* a2, const mkhe_swk* u,
                               mkhe_swk* b1, mkhe_swk* b2, mkhe_swk* d1, mkhe_swk* d2, mkhe_swk* v) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, a1, a2, u, b1, b2, d1, d2, v);
         if (!dev_sk || !dev_r || !g1 || !g2 || !e || !a1 || !a2 || !u || !b1 || !b2 || !d1 || !d2 || !v) throw Error("mkhe_bfv_keygen_relin_key: null argument");
         need(ctx)->bfv_keygen_relin_key((const u64*)dev_sk, (const u64*)dev_r, g1, g2, e, a1->s.d, a2->s.d, u->s.d,
                                      b1->s.d, b2->s.d, d1->s.d, d2->s.d, v->s.d);
     })
 }
 int mkhe_crs_expand(mkhe_ctx* ctx, uint64_t seed, int32_t idx, mkhe_swk* out) {
-    MKHE_TRY({ if (!out) throw Error("mkhe_crs_expand: null argument"); need(ctx)->crs_expand(seed, idx, out->s.d); })
+    MKHE_TRY({ mark(ctx, out); if (!out) throw Error("mkhe_crs_expand: null argument"); need(ctx)->crs_expand(seed, idx, out->s.d); })
 }
 
 // ---- mkbfv
@@ -441,20 +449,20 @@ int mkhe_bfv_ntt_r(mkhe_ctx* ctx, const void* src, void* dst, int count, int inv
     MKHE_TRY({ if (!src || !dst || count < 1) throw Error("mkhe_bfv_ntt_r: bad argument"); need(ctx)->ntt_r((const u64*)src, (u64*)dst, count, inverse != 0); })
 }
 int mkhe_bfv_decompose(mkhe_ctx* ctx, const void* polyr, mkhe_swk* ad1, mkhe_swk* ad2) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, ad1, ad2);
         if (!polyr || !ad1 || !ad2) throw Error("mkhe_bfv_decompose: null argument");
         need(ctx)->bfv_decompose_batch({(const u64*)polyr}, {ad1->s.d}, {ad2->s.d});
     })
 }
 int mkhe_bfv_external_product(mkhe_ctx* ctx, const void* dev_polyr, const mkhe_swk* bg1, const mkhe_swk* bg2, void* dev_c) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, bg1, bg2);
         if (!dev_polyr || !bg1 || !bg2 || !dev_c) throw Error("mkhe_bfv_external_product: null argument");
         need(ctx)->bfv_external_product((const u64*)dev_polyr, bg1->s.d, bg2->s.d, (u64*)dev_c);
     })
 }
 int mkhe_bfv_external_product_hoisted(mkhe_ctx* ctx, const mkhe_swk* ah1, const mkhe_swk* ah2,
                                       const mkhe_swk* bg1, const mkhe_swk* bg2, void* dev_c) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, ah1, ah2, bg1, bg2);
         if (!ah1 || !ah2 || !bg1 || !bg2 || !dev_c) throw Error("mkhe_bfv_external_product_hoisted: null argument");
         need(ctx)->bfv_external_product_hoisted(ah1->s.d, ah2->s.d, bg1->s.d, bg2->s.d, (u64*)dev_c);
     })
@@ -463,10 +471,10 @@ int mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                        const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
                        const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2,
                        const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, op0, op1, crs_u, out);
         if (!op0 || !op1 || !out || !crs_u || !rlk_b1 || !rlk_b2 || !rlk_d1 || !rlk_d2 || !rlk_v) throw Error("mkhe_bfv_mul_relin: null argument");
-        auto b1 = swk_list(rlk_b1, op1->c.n); auto b2 = swk_list(rlk_b2, op1->c.n);
-        auto d1 = swk_list(rlk_d1, op0->c.n); auto d2 = swk_list(rlk_d2, op0->c.n); auto v = swk_list(rlk_v, op0->c.n);
+        auto b1 = swk_list(ctx, rlk_b1, op1->c.n); auto b2 = swk_list(ctx, rlk_b2, op1->c.n);
+        auto d1 = swk_list(ctx, rlk_d1, op0->c.n); auto d2 = swk_list(ctx, rlk_d2, op0->c.n); auto v = swk_list(ctx, rlk_v, op0->c.n);
         need(ctx)->bfv_mul_relin(op0->c, op1->c, b1.data(), b2.data(), d1.data(), d2.data(), v.data(), crs_u->s, out->c);
     })
 }
@@ -475,19 +483,19 @@ int mkhe_bfv_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                         const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
                         const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2, int with_c0, mkhe_ct* out,
                         mkhe_swk* x1, mkhe_swk* x2, mkhe_swk* y1, mkhe_swk* y2) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, op0, op1, out, x1, x2, y1, y2);
         if (!op0 || !op1 || !out || !rlk_b1 || !rlk_b2 || !rlk_d1 || !rlk_d2 || !x1 || !x2 || !y1 || !y2) throw Error("mkhe_bfv_mr_partial: null argument");
-        auto b1 = swk_list(rlk_b1, op1->c.n); auto b2 = swk_list(rlk_b2, op1->c.n);
-        auto d1 = swk_list(rlk_d1, op0->c.n); auto d2 = swk_list(rlk_d2, op0->c.n);
+        auto b1 = swk_list(ctx, rlk_b1, op1->c.n); auto b2 = swk_list(ctx, rlk_b2, op1->c.n);
+        auto d1 = swk_list(ctx, rlk_d1, op0->c.n); auto d2 = swk_list(ctx, rlk_d2, op0->c.n);
         need(ctx)->bfv_mr_partial(op0->c, op1->c, b1.data(), b2.data(), d1.data(), d2.data(), with_c0 != 0, false, out->c,
                                   x1->s.d, x2->s.d, y1->s.d, y2->s.d);
     })
 }
 int mkhe_bfv_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x1, const mkhe_swk* x2,
                        const mkhe_swk* y1, const mkhe_swk* y2, const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out) {
-    MKHE_TRY({
+    MKHE_TRY({ mark(ctx, op0, op1, x1, x2, y1, y2, crs_u, out);
         if (!op0 || !op1 || !out || !x1 || !x2 || !y1 || !y2 || !rlk_v || !crs_u) throw Error("mkhe_bfv_mr_finish: null argument");
-        auto v = swk_list(rlk_v, op0->c.n);
+        auto v = swk_list(ctx, rlk_v, op0->c.n);
         need(ctx)->bfv_mr_finish(op0->c, op1->c, x1->s.d, x2->s.d, y1->s.d, y2->s.d, v.data(), crs_u->s, out->c);
     })
 }

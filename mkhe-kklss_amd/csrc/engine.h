@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <atomic>
 #include <vector>
 #include <stdexcept>
 #include "modarith.h"
@@ -28,6 +29,11 @@ struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
 // one external product of a batch: dst (+)= ModDown_P( sum_i bg[i] (.) ah[i] )
 struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const u64* ah2 = nullptr; const u64* bg2 = nullptr;
                  const u64* addend = nullptr; /* accumulate onto this polynomial instead of onto dst (Rotate: c_0 of the input) */ };
+
+typedef unsigned long long seq_t;
+// per handle: (uid of a context, that context's call counter at its latest use of the buffer); `exposed` once the raw device
+// pointer was handed out (uses can no longer be seen by the C ABI)
+struct HandleUsers { std::vector<std::pair<seq_t, seq_t>> v; bool exposed = false; };
 
 class Context {
   public:
@@ -145,8 +151,8 @@ class Context {
     // synchronise or hipFree, the words go back to a size-keyed free list and are reused by the next
     // create (all work of a context is ordered on its main stream, so reuse is safe).
     u64* pool_alloc(size_t words);
-    void pool_free(u64* p, size_t words);
-    void sync() { MKHE_HIP(hipStreamSynchronize(stream)); }
+    void pool_free(u64* p, size_t words, const HandleUsers* users = nullptr);   // users == nullptr / exposed: every live context counts
+    void sync() { const unsigned long long s0 = seq_.load(); MKHE_HIP(hipStreamSynchronize(stream)); if (completed_.load() < s0) completed_.store(s0); }
     // cross-context ordering on one device: everything enqueued on this context from now on starts after everything
     // enqueued on `other` so far has finished (event on other's stream; no host synchronisation).  Contexts over the same
     // ring share keys / CRS / ciphertext handles freely (handles are plain device memory): independent operations issued
@@ -226,16 +232,32 @@ class Context {
         bool x_pending = false;              // x still running on the side stream (chain 2)
     } plan_;
 
-    // Stream-ordered buffer pool.  A buffer freed through this context may still be read by kernels that ANOTHER context of the
-    // same device enqueued (handles are shared freely between forked contexts): every free is stamped with the registry's epoch,
-    // and before a buffer freed after the last fence is reused, a fence (one event per live context of the device, recorded on its
-    // main stream) is taken and this context's stream waits for it (pool_alloc).  Single-context processes never fence.
-    struct FreeEntry { size_t words; u64* p; unsigned long long epoch; };
+    // Stream-ordered buffer pool.  A buffer freed through this context may still be in use by kernels that ANOTHER context of the
+    // same device enqueued (handles are shared freely between forked contexts).  Ordering between contexts is tracked with one
+    // counter per context: seq_ counts the C-ABI calls that named the context (anything it may have enqueued), completed_ is seq_ at
+    // its last host-side drain, and synced_ holds, per other context, the seq_ value this context's stream is known to be ordered
+    // after (wait_for, fences).  A free records for which contexts that knowledge is behind at that moment; pool_alloc makes the
+    // stream wait for exactly those (one event each) unless a wait_for / drain has caught up in the meantime.  The joins an
+    // application needs for its own data flow therefore make the pool free of charge; single-context processes never fence.
+    // Which contexts enqueued work on a handle's buffer is recorded in the handle (HandleUsers, filled by the C ABI on every call
+    // that names the handle), so a temporary that never left its context costs nothing and never orders independent forks.
+    struct FreeEntry { size_t words; u64* p; std::vector<std::pair<seq_t, seq_t>> behind; };      // (uid of a context, its seq_ at the free)
     std::vector<FreeEntry> free_list_;
     hipEvent_t fence_ev_ = nullptr;
     void registry_add();
     void registry_remove();
-    unsigned long long waited_epoch_ = 0;
+    seq_t uid_ = 0;
+    std::atomic<seq_t> seq_{1}, completed_{0};
+    std::atomic<bool> external_{false};                      // stream handed out (mkhe_ctx_stream): work may arrive without a C-ABI call
+    std::vector<std::pair<seq_t, seq_t>> synced_;            // (uid, seq_) pairs, guarded by the registry mutex
+    seq_t synced_with(seq_t uid) const { for (auto& e : synced_) if (e.first == uid) return e.second; return 0; }
+    void set_synced(seq_t uid, seq_t v) { for (auto& e : synced_) if (e.first == uid) { if (e.second < v) e.second = v; return; } synced_.push_back({uid, v}); }
+  public:
+    void note_use(HandleUsers& u);                            // this context is about to enqueue work on the handle's buffer
+    void touch() { seq_.fetch_add(1, std::memory_order_relaxed); }
+    void mark_external() { external_.store(true); }
+    seq_t now_seq() { return external_.load() ? seq_.fetch_add(1) + 1 : seq_.load(); }
+  private:
 
     struct ProfRec { hipEvent_t e0, e1; int cls; double bytes; };
     bool prof_on_ = false;

@@ -279,10 +279,10 @@ Context::~Context() {
 
 // live contexts per device: who may still be using a buffer that some context returns to its pool
 namespace {
-struct DeviceRegistry { std::mutex mu; std::vector<Context*> live; unsigned long long epoch = 1, fence_epoch = 0; };
+struct DeviceRegistry { std::mutex mu; std::vector<Context*> live; unsigned long long next_uid = 1; };
 DeviceRegistry& registry(int device) { static DeviceRegistry r[64]; return r[device & 63]; }
 }
-void Context::registry_add() { auto& r = registry(device); std::lock_guard<std::mutex> g(r.mu); r.live.push_back(this); }
+void Context::registry_add() { auto& r = registry(device); std::lock_guard<std::mutex> g(r.mu); uid_ = r.next_uid++; r.live.push_back(this); }
 void Context::registry_remove() {
     auto& r = registry(device); std::lock_guard<std::mutex> g(r.mu);
     for (size_t i = 0; i < r.live.size(); ++i) if (r.live[i] == this) { r.live.erase(r.live.begin() + i); break; }
@@ -290,23 +290,25 @@ void Context::registry_remove() {
 u64* Context::pool_alloc(size_t words) {
     for (size_t i = 0; i < free_list_.size(); ++i)
         if (free_list_[i].words == words) {
-            const FreeEntry e = free_list_[i];
-            free_list_.erase(free_list_.begin() + i);          // the oldest matching entry: most likely already behind a fence
-            auto& r = registry(device);
-            std::lock_guard<std::mutex> g(r.mu);
-            if (r.live.size() > 1 && waited_epoch_ < e.epoch) {
+            const FreeEntry e = std::move(free_list_[i]);
+            free_list_.erase(free_list_.begin() + i);          // the oldest matching entry: most likely already ordered
+            if (!e.behind.empty()) {
                 hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
                 (void)hipStreamIsCapturing(stream, &cs);
                 if (cs == hipStreamCaptureStatusNone) {           // (a capture keeps its temporaries alive itself)
-                    if (r.fence_epoch < e.epoch) {
-                        for (Context* m : r.live) {
-                            if (!m->fence_ev_) MKHE_HIP(hipEventCreateWithFlags(&m->fence_ev_, hipEventDisableTiming));
-                            MKHE_HIP(hipEventRecord(m->fence_ev_, m->stream));
-                        }
-                        r.fence_epoch = r.epoch++;
+                    auto& r = registry(device);
+                    std::lock_guard<std::mutex> g(r.mu);
+                    for (const auto& b : e.behind) {
+                        Context* m = nullptr;
+                        for (Context* x : r.live) if (x->uid_ == b.first) m = x;
+                        if (!m) continue;                         // destroyed since: its destructor drained its streams
+                        if (std::max(synced_with(m->uid_), m->completed_.load()) >= b.second) continue;
+                        const seq_t upto = m->seq_.load();     // read before the record: everything counted so far is covered by it
+                        if (!m->fence_ev_) MKHE_HIP(hipEventCreateWithFlags(&m->fence_ev_, hipEventDisableTiming));
+                        MKHE_HIP(hipEventRecord(m->fence_ev_, m->stream));
+                        MKHE_HIP(hipStreamWaitEvent(stream, m->fence_ev_, 0));
+                        set_synced(m->uid_, upto);
                     }
-                    for (Context* m : r.live) if (m != this && m->fence_ev_) MKHE_HIP(hipStreamWaitEvent(stream, m->fence_ev_, 0));
-                    waited_epoch_ = r.fence_epoch;
                 }
             }
             return e.p;
@@ -314,12 +316,31 @@ u64* Context::pool_alloc(size_t words) {
     MKHE_HIP(hipSetDevice(device));
     return dev_alloc_words(words);
 }
-void Context::pool_free(u64* p, size_t words) {
-    if (!p) return;
-    if (free_list_.size() >= 64) { (void)hipDeviceSynchronize(); (void)hipFree(p); return; }
+void Context::note_use(HandleUsers& u) {
+    touch();
     auto& r = registry(device);
     std::lock_guard<std::mutex> g(r.mu);
-    free_list_.push_back({words, p, r.epoch});
+    const seq_t s = seq_.load();
+    for (auto& e : u.v) if (e.first == uid_) { e.second = s; return; }
+    u.v.push_back({uid_, s});
+}
+void Context::pool_free(u64* p, size_t words, const HandleUsers* users) {
+    if (!p) return;
+    if (free_list_.size() >= 64) { (void)hipDeviceSynchronize(); (void)hipFree(p); return; }
+    FreeEntry e{words, p, {}};
+    {
+        auto& r = registry(device);
+        std::lock_guard<std::mutex> g(r.mu);
+        if (r.live.size() > 1)
+            for (Context* m : r.live) {
+                if (m == this) continue;
+                seq_t s = 0;
+                if (!users || users->exposed || m->external_.load()) s = m->now_seq();          // unknown uses: anything it enqueued so far
+                else { for (const auto& u : users->v) if (u.first == m->uid_) s = u.second; if (!s) continue; }
+                if (std::max(synced_with(m->uid_), m->completed_.load()) < s) e.behind.push_back({m->uid_, s});
+            }
+    }
+    free_list_.push_back(std::move(e));
 }
 u64* Context::scratch(u64*& p, size_t& have, size_t want) {
     if (have < want) {
@@ -365,8 +386,10 @@ void Context::wait_for(Context& other) {
     if (&other == this) return;
     if (other.device != device) throw Error("mkhe: wait_for needs two contexts on the same device");
     if (!xev_) MKHE_HIP(hipEventCreateWithFlags(&xev_, hipEventDisableTiming));
+    const seq_t upto = other.seq_.load();
     MKHE_HIP(hipEventRecord(xev_, other.stream));
     MKHE_HIP(hipStreamWaitEvent(stream, xev_, 0));
+    { auto& r = registry(device); std::lock_guard<std::mutex> g(r.mu); set_synced(other.uid_, upto); }
 }
 void Context::prof_enable(bool on) { sync(); prof_on_ = on; }
 void Context::prof_collect(double* ms, long* launches, double* alg_bytes) {

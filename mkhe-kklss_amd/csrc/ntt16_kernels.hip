@@ -24,9 +24,10 @@
 // 136 KiB per CU), every layout addressed as base(thread) + immediate(register), conflict-free under the 32-bank rule
 // of ds_read_b32 / ds_write_b32 (padding constants below).
 //
-// Arithmetic and values are those of ntt_kernels.hip (mont_mul_sd: signed-digit Montgomery product; MODE 1 signed
-// never-reduced butterflies for moduli with 31q < 2^62, MODE 0 Harvey butterflies; same DEC digit reduction, same
-// skip_norm / canonical outputs), so the two kernels are interchangeable bit for bit on canonical outputs.
+// Arithmetic: mont_mul_sd of modarith.h (signed-digit Montgomery product) and signed never-reduced butterflies for BOTH modulus
+// classes; the 59/60-bit primes (31q >= 2^62) get a 7-instruction float-estimated partial reduction after at most 8 stages
+// (pred() below) where ntt_kernels.hip runs Harvey butterflies.  Same DEC digit reduction, same skip_norm / canonical outputs,
+// so the two kernels are interchangeable bit for bit on canonical outputs (internal lazy representatives differ).
 //
 // Replaces: lattigo ring.NTTLvl as called from DecomposeSingleNTT (mkrlwe/keyswitch.go:21-31,49-73).
 #include "ntt_kernels.h"

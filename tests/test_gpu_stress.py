@@ -58,3 +58,52 @@ def test_repeated_circuit_is_deterministic(pname):
             assert (b.download() == ref).all(), "forked context, iteration %d" % it
     params.sync()
     fork.params.sync()
+
+
+def test_buffer_freed_under_a_foreign_reader_is_not_reused_early():
+    """A ciphertext created on the main context is read by work queued on a forked context and destroyed right away; a new
+    ciphertext of the same shape (the pool hands the same buffer back) is then overwritten on the main stream.  The fork's
+    results must be those of the original operand: pool_alloc has to order the main stream behind the fork's readers
+    (Context::seq_ / synced_ bookkeeping, csrc/engine.hip), although the application itself never joined the two."""
+    from mkhe_kklss_amd import mkckks, mkrlwe
+    from mkhe_kklss_amd._abi import check, lib
+    pset = H.small_ckks(15, 4)
+    params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"])
+    names = ["a", "b"]
+    level = len(pset["Q"]) - 1
+    rng = np.random.default_rng(11)
+    N = 1 << pset["logN"]
+    host = lambda: np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in pset["Q"]]) for _ in range(1 + len(names))])
+    rlk = mkrlwe.RelinearizationKeySet(params)
+    for i, n in enumerate(names):
+        key = mkrlwe.RelinearizationKey(params, n)
+        for j in range(3):
+            check(lib().mkhe_crs_expand(params.ctx, 5, 10 + 3 * i + j, key.Value[j].h))
+        rlk.AddRelinearizationKey(key)
+    params.AddCRS(-1, seed=5)
+    ev = mkckks.NewEvaluator(params)
+    fork = ev.Fork()
+    hx, hy, hz = host(), host(), host()
+    ct1 = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(hy)
+    x = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(hx)
+    ref = ev.MulRelinNew(x, ct1, rlk).download()
+    for rep in range(6):
+        fork.params.wait_for(params)
+        outs = [fork.MulRelinNew(x, ct1, rlk) for _ in range(6)]          # milliseconds of queued readers of x on the fork's stream
+        ptr = x.devptr()
+        x.__del__()                                                          # back into the main context's pool, no join
+        held = []                                                            # the pool hands out its oldest matching entry first
+        for _ in range(16):
+            held.append(mkckks.NewCiphertext(params, names, level, pset["scale"]))
+            if held[-1].devptr() == ptr:
+                break
+        z = held[-1]
+        assert z.devptr() == ptr, "the pool is expected to hand the freed buffer back"
+        z.upload(hz)                                                         # overwrites it on the main stream
+        for o in outs:
+            assert (o.download() == ref).all(), "repetition %d: a reader on the forked context saw the buffer's next contents" % rep
+        for h in held:
+            h.__del__()
+        x = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(hx)
+    params.sync()
+    fork.params.sync()

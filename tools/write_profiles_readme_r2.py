@@ -19,10 +19,18 @@ def st(name):
     return (0, 0, 0, 0)
 
 
-def table(j):
+def table(j, traffic=None):
+    """PMC column: bytes per launch from the traffic file recorded in the SAME profile run (not from what bench.py attached: the plain
+    bench of a run starts before that run's traffic.json exists), over the avg launch time of this table; only for kernels whose
+    recorded call count matches launches_per_step * (W + 2 K) of the PMC command"""
     rows = []
+    tk = (traffic or {}).get("kernels", {})
     for k, v in j["roofline"]["kernels"].items():
-        pmc = "%.0f" % v["hbm_GBs_pmc"] if "hbm_GBs_pmc" in v else "–"
+        key = k.split()[0]
+        rec = tk.get(key) or tk.get(key.replace("[_batch]", "_batch"))
+        pmc = "–"
+        if rec and traffic.get("steps") is not None and abs(rec["launches"] - v["launches_per_step"] * (traffic["warmup"] + 2 * traffic["steps"])) < 0.5:
+            pmc = "%.0f" % (rec["hbm_bytes_per_launch"] / (v["avg_launch_us"] * 1e-6) / 1e9)
         rows.append("| `%s` | %.1f | %.1f | %.3f | %.0f | %s |" % (k.split("  ")[0], v["launches_per_step"], v["avg_launch_us"], v["ms_per_step"], v["achieved_GBs"], pmc))
     return "\n".join(rows)
 
@@ -71,7 +79,7 @@ cache-served re-reads and may exceed the chip's peak); "PMC GB/s" is what the ke
 
 | kernel | launches/step | avg µs/launch | ms/step | algorithmic GB/s | PMC GB/s |
 |---|---|---|---|---|---|
-{table(pl)}
+{table(pl, tr)}
 
 (Launches of ≤ 128 limbs in the `ntt_fwd_kernel<15,·,false>` and `ntt_inv_kernel<15>` classes run as `ntt_pass4_fwd/inv_kernel` + `ntt_fwd/inv_lds_kernel`,
 the low-latency path of DESIGN.md §4; that is what the rocprofv3 statistics list, so those classes have no PMC column.)
@@ -84,7 +92,7 @@ the low-latency path of DESIGN.md §4; that is what the rocprofv3 statistics lis
   By the compulsory bytes of the fused Decompose (read every source limb once, write every digit limb: {R.get("compulsory_bytes_per_launch", 0) / 1e6:.0f} MB per average launch) it is {R.get("frac_compulsory", 0):.3f}.
 * HBM traffic from the PMC passes: {dom.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch (FETCH_SIZE {dom.get("fetch_size_kb", 0) / 1e3:.1f} MB ×2 + WRITE_SIZE {dom.get("write_size_kb", 0) / 1e3:.1f} MB) =
   {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results, the parked upper halves of pass 0 (half of that again; they are
-  re-read by the same thread from L2) and {"%.0f" % (64 * 1024 * 1344 * 2 / 1e6)} MB-scale scratch traffic (64 B per lane).  Read: source limbs (each is spread under 16 moduli: re-reads are cache hits), twiddle tables, the parked halves.
+  re-read by the same thread from L2) and the register spills (40 B of scratch per lane: 13–15 spilled VGPRs, no SGPR spills).  Read: source limbs (each is spread under 16 moduli: re-reads are cache hits), twiddle tables, the parked halves.
 * It is **VALU-issue / power bound, not HBM bound**.  `{tag}_ntt16_isa.txt`: the butterfly is 15 multiplier-class / 64-bit instructions + 2 plain ones (12 + 2 for the
   signed-digit Montgomery product, one 64-bit add, one 64-bit subtract), 17.5 VALU instructions per butterfly over the whole pass body.  `{tag}_ubench.txt`
   (`bfly16_rate`): exactly this butterfly, bare (no LDS, no memory), takes **73–75 cycles per wave at 8, 4 and 2 waves per SIMD alike and with one or two interleaved chains** —
@@ -92,7 +100,7 @@ the low-latency path of DESIGN.md §4; that is what the rocprofv3 statistics lis
   A 2^15-point limb is 240 butterflies × 16 waves / 4 SIMDs = 960 wave-butterflies per SIMD ⇒ **32–35 µs per limb and CU before any load, store, exchange or
   twiddle fetch**; the average launch has 1344 / 256 = 5.25 limbs per CU ⇒ ≥ 168–186 µs = at most 0.48–0.52 of the HBM roofline for a kernel that did nothing but these
   butterflies at 100 % issue.  Measured: {R["avg_launch_us"]:.0f} µs = {R["avg_launch_us"] * 256 / 1344:.1f} µs per limb and CU, i.e. {34.0 * 1344 / 256 / R["avg_launch_us"]:.2f} of that floor; the rest is the non-butterfly
-  instructions (output representative, addresses, 64-B scratch), and the phases in which the two workgroups of a CU both wait (`{tag}_ntt16_phase_trace.txt`: the
+  instructions (output representative, addresses, 40 B of scratch per lane), and the phases in which the two workgroups of a CU both wait (`{tag}_ntt16_phase_trace.txt`: the
   pass-0 source loads and the four barriers of the cross-wave exchange).
 * `{tag}_sq_counters.txt`: `SQ_INSTS_VALU` per wave, `SQ_WAIT_INST_ANY` (waves ready but waiting for the vector ALU that another wave holds) vs `SQ_WAIT_ANY`
   (waves at barriers / waitcnt), `SQ_LDS_BANK_CONFLICT` = 0 for all four LDS layouts, L2 hit rate.
