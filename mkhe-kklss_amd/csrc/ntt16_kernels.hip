@@ -253,7 +253,7 @@ template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds
 
 // ------------------------------------------------------------------ one limb
 // what one limb needs, all wave-uniform
-struct Job { gcptr src; gptr dst; const u64* psi; smodptr mp; bool red; bool skip_norm; u64* trace; };
+struct Job { gcptr src; gptr dst; const u64* psi; smodptr mp; bool red; bool skip_norm; int root; u64* trace; };
 // diagnostic build (make trace): shader-clock stamps per wave and pass, 32 words per (job, wave): [16 * pass + k], see tools/ntt16_trace.py
 // (every lane stores the same word: a lane-0 branch here makes the compiler lose the uniformity of the scalar twiddle loads)
 #ifdef MKHE_PHASE_TRACE
@@ -265,8 +265,11 @@ struct Job { gcptr src; gptr dst; const u64* psi; smodptr mp; bool red; bool ski
 // big: modulus class 0 (q up to 2^60, partial reductions interposed); one instantiation serves both classes (wave-uniform
 // branches around the reductions), which halves the code the two workgroups of a CU -- and the neighbouring CU that shares the
 // instruction cache -- stream through
-template <bool DEC>
+// SPLIT: the 2^15 points are one half of a 2^16-point limb whose cross-half stage has already been applied (NttBatch::split): the
+// group i' of local stage k then uses the twiddle psi16[root * 2^k + i'], root = 2 + half, where a whole limb uses psi[2^k + i'].
+template <bool DEC, bool SPLIT>
 __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, const int wv) {
+    const int tm = SPLIT ? jb.root : 1;
     smodptr mp = jb.mp;                                 // scalar loads: the constants live in SGPRs
     const u64 qs = mp->qs;
     MC c;
@@ -285,7 +288,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
         H16_STAMP(0);
         if (h == 0) {
             // ---- stage 0: cross-half butterflies; upper outputs parked in dst[N/2 + j]
-            const u64 w1 = psi_s[1];
+            const u64 w1 = psi_s[tm];
             const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
@@ -323,15 +326,15 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
             // (the 8 twiddles of the last stage are fetched after the first two stages: 30 twiddle SGPRs at once do not fit the
             // 80-SGPR budget of 8 waves per SIMD beside the job state, and every spilled SGPR costs VALU lane moves)
             u64 tw[7], tl[8];
-            tw[0] = psi_s[2 + h];
+            tw[0] = psi_s[2 * tm + h];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[4 + 2 * h + i];
+            for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[4 * tm + 2 * h + i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[8 + 4 * h + i];
+            for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[8 * tm + 4 * h + i];
             stage<true, 3>(x, tw, c);
             stage<true, 2>(x, tw + 1, c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tl[i] = psi_s[16 + 8 * h + i];
+            for (int i = 0; i < 8; ++i) tl[i] = psi_s[16 * tm + 8 * h + i];
             stage<true, 1>(x, tw + 3, c);
             stage<true, 0>(x, tl, c);
         }
@@ -343,15 +346,15 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
         {
             const int cb = 16 * h + wv;
             u64 tw[7], tl[8];
-            tw[0] = psi_s[32 + cb];
+            tw[0] = psi_s[32 * tm + cb];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[64 + 2 * cb + i];
+            for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[64 * tm + 2 * cb + i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[128 + 4 * cb + i];
+            for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[128 * tm + 4 * cb + i];
             stage<true, 3>(x, tw, c);
             stage<true, 2>(x, tw + 1, c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tl[i] = psi_s[256 + 8 * cb + i];
+            for (int i = 0; i < 8; ++i) tl[i] = psi_s[256 * tm + 8 * cb + i];
             stage<true, 1>(x, tw + 3, c);
             stage<true, 0>(x, tl, c);
         }
@@ -365,10 +368,10 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
             __builtin_assume(cu < 512);
             u64 g[8][2];
             auto loadg = [&](int k) {
-                if (k == 0) g[0][0] = *(gcptr)((const __attribute__((address_space(1))) char*)sbk(psi_v, 512) + (unsigned)(cu * 8u));
-                else if (k == 1) ld2(g[1], (gcptr2)sbk(psi_v, 1024), cu);
-                else if (k < 4) ld2(g[k], (gcptr2)sbk(psi_v, 2048) + (k - 2), 2 * cu);
-                else ld2(g[k], (gcptr2)sbk(psi_v, 4096) + (k - 4), 4 * cu);
+                if (k == 0) g[0][0] = *(gcptr)((const __attribute__((address_space(1))) char*)sbk(psi_v, 512 * tm) + (unsigned)(cu * 8u));
+                else if (k == 1) ld2(g[1], (gcptr2)sbk(psi_v, 1024 * tm), cu);
+                else if (k < 4) ld2(g[k], (gcptr2)sbk(psi_v, 2048 * tm) + (k - 2), 2 * cu);
+                else ld2(g[k], (gcptr2)sbk(psi_v, 4096 * tm) + (k - 4), 4 * cu);
             };
             loadg(0); loadg(1); loadg(2);
             H16_STAMP(4);
@@ -396,8 +399,8 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
             __builtin_assume(du < 2048);
             u64 g[6][2];
             auto loadg = [&](int k) {
-                if (k < 2) ld2(g[k], (gcptr2)sbk(psi_v, 8192) + k, 2 * du);
-                else ld2(g[k], (gcptr2)sbk(psi_v, 16384) + (k - 2), 4 * du);
+                if (k < 2) ld2(g[k], (gcptr2)sbk(psi_v, 8192 * tm) + k, 2 * du);
+                else ld2(g[k], (gcptr2)sbk(psi_v, 16384 * tm) + (k - 2), 4 * du);
             };
             loadg(0); loadg(1); loadg(2);
             H16_STAMP(6);
@@ -448,16 +451,16 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
     }
 }
 
-template <bool DEC>
-__global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
-    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+template <bool DEC, bool SPLIT>
+__device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int njobs = b.nslots * b.nouter;
+    const int njobs = (b.nslots * b.nouter) << (SPLIT ? 1 : 0);
     // optional start delay of the second half of the persistent grid (the co-resident workgroup of every CU, as far as the
     // dispatcher deals workgroups b and b + gridDim/2 to the same CU): the two workgroups of a CU then sit in different phases
     if (b.lazy_out > 0 && blockIdx.x >= (gridDim.x >> 1)) { for (int i = 0; i < b.lazy_out; ++i) __builtin_amdgcn_s_sleep(127); }
 #pragma unroll 1
-    for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+    for (int job2 = blockIdx.x; job2 < njobs; job2 += gridDim.x) {
+        const int job = SPLIT ? job2 >> 1 : job2;           // SPLIT: the two halves of a limb are consecutive jobs
         // The launch description is re-read from the kernel-argument segment for every limb (a handful of scalar loads) instead
         // of being kept in SGPRs across the limb: kept live it overflows the SGPR file into VGPR lanes, and those VGPRs are
         // what the 64-register budget of this kernel does not have.
@@ -478,10 +481,12 @@ __global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
         Job jb;
         jb.src = (gcptr)(sbase_ + (long)outer * kb->src_outer + (long)(kb->src_mapped ? m : p) * kb->src_inner);
         jb.dst = (gptr)(dbase_ + (long)outer * kb->dst_outer + (long)(kb->dst_mapped ? m : p) * kb->dst_inner);
-        jb.psi = kb->psi + (long)m * NN;
+        jb.psi = kb->psi + (long)m * (SPLIT ? 2 * NN : NN);
+        jb.root = 1;
+        if constexpr (SPLIT) { const int half = job2 & 1; jb.src += half * NN; jb.dst += half * NN; jb.root = 2 + half; }
         jb.mp = (smodptr)kb->mods + m;
         jb.skip_norm = kb->skip_norm != 0;
-        jb.trace = kb->trace ? kb->trace + (long)job * 16 * 32 : nullptr;
+        jb.trace = kb->trace ? kb->trace + (long)job2 * 16 * 32 : nullptr;
         jb.red = false;
         if constexpr (DEC) {
             int sm = m;
@@ -498,11 +503,22 @@ __global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
             tw[14] = blockIdx.x;
         }
 #endif
-        limb<DEC>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv);
+        limb<DEC, SPLIT>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv);
 #ifdef MKHE_PHASE_TRACE
         if (jb.trace && ((int)threadIdx.x & 63) == 0) jb.trace[(long)wv * 32 + 28] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
+}
+
+template <bool DEC>
+__global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    fwd_body<DEC, false>(b, lds);
+}
+// the two 2^15-point sub-transforms of every 2^16-point limb, in place, after the cross-half stage (NttBatch::split)
+__global__ void __launch_bounds__(NT, 8) ntt16_fwd_split_kernel(NttBatch b) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    fwd_body<false, true>(b, lds);
 }
 
 }  // namespace h16
@@ -511,6 +527,42 @@ __global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
 namespace {
 int env_int16(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 struct LaunchState16 { std::mutex mu; int resident[64] = {}; };      // per device, see ntt_kernels.hip
+}
+namespace {
+int resident16(size_t lds) {
+    using namespace h16;
+    static const int per_cu = env_int16("MKHE_NTT16_PER_CU", 0);
+    static LaunchState16 ls;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(ls.mu);
+    if (!ls.resident[dev & 63]) {
+        (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)ntt16_fwd_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int cus = 256, per = 1;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)ntt16_fwd_kernel<true>, NT, lds) != hipSuccess || per < 1) per = 1;
+        if (per_cu > 0) per = per_cu;
+        ls.resident[dev & 63] = cus * per;
+    }
+    return ls.resident[dev & 63];
+}
+}
+// sub-transforms of a split N = 2^16 launch (one modulus class per launch: `small` = 31 q < 2^62 for every slot)
+bool ntt16_split_ok(const NttBatch& c) {
+    static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128);
+    return on && c.split && !c.reduce_in && c.nslots <= 64 && 2 * c.nslots * c.nouter >= minl;
+}
+void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
+    using namespace h16;
+    NttBatch c = b;
+    c.small_slots = small ? ~0ull : 0ull;
+    c.lazy_out = 0;
+    const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
+    const int resident = resident16(lds);
+    const int need = 2 * c.nslots * c.nouter;
+    hipLaunchKernelGGL(ntt16_fwd_split_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
 }
 bool ntt16_ok(int logN, const NttBatch& b) {
     static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128);
@@ -529,25 +581,9 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
                 ++c.nslots;
             }
     const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
-    static const int stagger = env_int16("MKHE_NTT16_STAGGER", 0), per_cu = env_int16("MKHE_NTT16_PER_CU", 0);
+    static const int stagger = env_int16("MKHE_NTT16_STAGGER", 0);
     c.lazy_out = stagger;
-    static LaunchState16 ls;
-    int resident;
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> g(ls.mu);
-        if (!ls.resident[dev & 63]) {
-            (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            int cus = 256, per = 1;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)ntt16_fwd_kernel<true>, NT, lds) != hipSuccess || per < 1) per = 1;
-            if (per_cu > 0) per = per_cu;
-            ls.resident[dev & 63] = cus * per;
-        }
-        resident = ls.resident[dev & 63];
-    }
+    const int resident = resident16(lds);
     const int need = c.nslots * c.nouter;
     const int blocks = need < resident ? need : resident;
     if (c.reduce_in) hipLaunchKernelGGL(ntt16_fwd_kernel<true>, dim3(blocks), dim3(NT), lds, st, c);

@@ -86,5 +86,8 @@ void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st);
 // classes in one persistent launch.  ntt16_ok: false when the launch does not qualify (MKHE_NTT16=0 switches the path off).
 bool ntt16_ok(int logN, const NttBatch& b);
 void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st);
+// the same kernel on the 2^15-point sub-transforms of a split N = 2^16 launch (one modulus class per launch)
+bool ntt16_split_ok(const NttBatch& c);
+void launch_ntt16_fwd_split(const NttBatch& c, bool small, hipStream_t st);
 
 }  // namespace mkhe

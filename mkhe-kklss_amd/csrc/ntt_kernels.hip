@@ -812,7 +812,8 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
             else hipLaunchKernelGGL(ntt_fwd_lds_kernel<0>, dim3(jobs), dim3(SM_T), lds, st, c, d);
             return;
         }
-        if (small) launch_fwd_mode<1, false>(logN - 1, c, st); else launch_fwd_mode<0, false>(logN - 1, c, st);
+        if (logN == 16 && ntt16_split_ok(c)) launch_ntt16_fwd_split(c, small, st);
+        else if (small) launch_fwd_mode<1, false>(logN - 1, c, st); else launch_fwd_mode<0, false>(logN - 1, c, st);
         return;
     }
     if (b.reduce_in) { if (small) launch_fwd_mode<1, true>(logN, b, st); else launch_fwd_mode<0, true>(logN, b, st); }
