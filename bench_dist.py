@@ -49,6 +49,12 @@ def _init(torch, dist):
     return rank, world, local_rank
 
 
+def _party_sync(args, dist):
+    """ordering of the collectives of the party-sharded legs (mkhe_kklss_amd/dist.py): on the engine's stream under RCCL,
+    through the host with gloo (which moves device tensors through the host) or when --dist-sync host asks for it"""
+    return "stream" if dist.get_backend() == "nccl" and getattr(args, "dist_sync", "auto") != "host" else "host"
+
+
 def run_distributed_bfv(args):
     """--scheme bfv at N > 1 (BASELINE.json configs[2] sharded): mkbfv MulRelinNew with whole parties per rank
     (mkhe_kklss_amd/dist.py ShardedBfvMulRelin); needs N <= parties"""
@@ -66,7 +72,7 @@ def run_distributed_bfv(args):
     params.AddCRS(-1, data["u"])
     mine = assign_parties(names, world)[rank]
     rlk = {n: data["rlk"][names.index(n)] for n in mine}
-    b = HipBfvShardBackend(params, names, rank, world, data["op0"], data["op1"], rlk, torch, local_rank)
+    b = HipBfvShardBackend(params, names, rank, world, data["op0"], data["op1"], rlk, torch, local_rank, sync=_party_sync(args, dist))
     del data, rlk
     smr = ShardedBfvMulRelin(b, dist)
     dt = _timed(dist, torch, params, smr.run, args.steps, args.warmup)
@@ -149,13 +155,14 @@ def run_distributed(args):
     # ---- party sharding (headline)
     ids0, ids1 = assign_units(names, world)[rank]
     rlk = {n: party_keys(n) for n in sorted(set(ids0) | set(ids1))}
-    backend = HipShardBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank)
+    psync = _party_sync(args, dist)
+    backend = HipShardBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank, sync=psync)
     smr = ShardedMulRelin(backend, dist)
     def step_party():
         smr.run()
         check(lib().mkhe_rescale(params.ctx, backend.full.h, 1, res.h))
     dt = _timed(dist, torch, params, step_party, args.steps, args.warmup)
-    legs["party"] = dict(mulrelin_per_sec=args.steps / dt, ms_per_step=dt * 1e3 / args.steps,
+    legs["party"] = dict(mulrelin_per_sec=args.steps / dt, ms_per_step=dt * 1e3 / args.steps, collective_ordering=psync,
                          exchanged_bytes_per_step=8 * (2 * nwx + (1 + (k // world if k % world == 0 else k)) * L * Nn))
     del smr, backend, rlk
     # ---- hoisted Rotate, parties sharded (BASELINE.json configs[3]: "MulRelin + hoisted Rotate")
@@ -171,7 +178,7 @@ def run_distributed(args):
     else:
         params.AddCRS(rot, synth_swk(pset, np.random.default_rng(args.seed + 99)))
         rk = {n: synth_swk(pset, np.random.default_rng(args.seed + 100 + names.index(n))) for n in mine}
-    rb = HipRotateBackend(params, names, rank, world, op0, rk, params.CRS[rot], rot, level, torch, local_rank, hoisted=True)
+    rb = HipRotateBackend(params, names, rank, world, op0, rk, params.CRS[rot], rot, level, torch, local_rank, hoisted=True, sync=psync)
     srot = ShardedRotate(rb, dist)
     dt = _timed(dist, torch, params, srot.run, args.steps, args.warmup)
     legs["rotate_hoisted"] = dict(rotate_per_sec=args.steps / dt, ms_per_step=dt * 1e3 / args.steps,

@@ -151,6 +151,13 @@ int  mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
 int  mkhe_swk_fold(mkhe_ctx* ctx, mkhe_swk* swk, int level, int mform);
 int  mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x, const mkhe_swk* y,
                     const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out);
+/* mkhe_mr_finish in two halves, so that the all-reduce of x can still be in flight while the part that needs y alone runs:
+ * head = t_i = <h(c0_i), y>_P for every party of op0 (keyswitch_hoisted.go:165-169) and the Decompose of the t_i (:171);
+ * tail = out_j += <h(c1_j), x>_P (:146-154), then out_0 += <h(t_i), v_i>_P and out_i += <h(t_i), u>_P (:173-177).
+ * mkhe_mr_finish == head; tail.  Both take the operands of the preceding mkhe_mr_partial. */
+int  mkhe_mr_finish_head(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* y, mkhe_ct* out);
+int  mkhe_mr_finish_tail(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x,
+                         const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out);
 int  mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct);
 
 /* ---- limb-sharded multi-GPU MulAndRelin (no reference counterpart; mkhe_kklss_amd/dist.py LimbShardedMulRelin).

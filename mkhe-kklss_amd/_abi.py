@@ -60,6 +60,8 @@ SIGNATURES = {
     "mkhe_mr_partial": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, C.c_int, vp, vp, vp]),
     "mkhe_swk_fold": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "mkhe_mr_finish": (C.c_int, [vp, vp, vp, vp, vp, vpp, vp, vp]),
+    "mkhe_mr_finish_head": (C.c_int, [vp, vp, vp, vp, vp]),
+    "mkhe_mr_finish_tail": (C.c_int, [vp, vp, vp, vp, vpp, vp, vp]),
     "mkhe_ct_fold": (C.c_int, [vp, vp]),
     "mkhe_rotate":(C.c_int, [vp, C.c_uint64, vp, vpp, vpp, vp, vp]),
     "mkhe_ctx_set_owned": (C.c_int, [vp, i32p, C.c_int]),

@@ -329,6 +329,20 @@ int mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const 
         need(ctx)->mr_finish(op0->c, op1->c, x->s.d, y->s.d, v0.data(), crs_u->s, out->c);
     })
 }
+int mkhe_mr_finish_head(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* y, mkhe_ct* out) {
+    MKHE_TRY({ mark(ctx, op0, op1, y, out);
+        if (!op0 || !op1 || !y || !out) throw Error("mkhe_mr_finish_head: null argument");
+        need(ctx)->mr_finish_head(op0->c, op1->c, y->s.d, out->c);
+    })
+}
+int mkhe_mr_finish_tail(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x,
+                        const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out) {
+    MKHE_TRY({ mark(ctx, op0, op1, x, crs_u, out);
+        if (!op0 || !op1 || !x || !rlk_v0 || !crs_u || !out) throw Error("mkhe_mr_finish_tail: null argument");
+        auto v0 = swk_list(ctx, rlk_v0, op0->c.n);
+        need(ctx)->mr_finish_tail(op0->c, op1->c, x->s.d, v0.data(), crs_u->s, out->c);
+    })
+}
 int mkhe_ct_fold(mkhe_ctx* ctx, mkhe_ct* ct) {
     MKHE_TRY({ mark(ctx, ct); if (!ct) throw Error("mkhe_ct_fold: null argument"); need(ctx)->fold(ct->c.d, false, ct->c.limbs - 1, 1 + ct->c.n, (long)ct->c.limbs * need(ctx)->N, false); })
 }

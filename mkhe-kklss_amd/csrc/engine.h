@@ -102,6 +102,8 @@ class Context {
     // defer_x: x is accumulated on the side stream and joined by mr_finish just before its first use (step E), so that it
     // overlaps the latency-bound part of step F; false (split-phase ABI): x and y are both complete on the main stream
     void mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x = false);
+    void mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out);          // F1 + Decompose(t_i): needs y only
+    void mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const Swk* const* rlk_v0, const Swk& crs_u, Ct& out);
     void mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
                    const Swk& crs_u, Ct& out);
     void fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform);
@@ -230,6 +232,7 @@ class Context {
         std::vector<const u64*> h0, h1;
         bool own0 = false, own1 = false;     // hoisted digits computed by the engine itself
         bool x_pending = false;              // x still running on the side stream (chain 2)
+        bool head_done = false;              // mr_finish_head ran, mr_finish_tail still to come
     } plan_;
 
     // Stream-ordered buffer pool.  A buffer freed through this context may still be in use by kernels that ANOTHER context of the

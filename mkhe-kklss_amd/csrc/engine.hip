@@ -376,7 +376,7 @@ void Context::side_done(int k) { if (!overlap) return; MKHE_HIP(hipEventRecord(e
 void Context::join_side(int k) { if (!overlap) return; MKHE_HIP(hipStreamWaitEvent(s_, ev_[2 * k + 1], 0)); }
 void Context::recover() {
     s_ = stream;
-    plan_.valid = false; plan_.x_pending = false;
+    plan_.valid = false; plan_.x_pending = false; plan_.head_done = false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cs);
     if (cs == hipStreamCaptureStatusNone) { (void)hipStreamSynchronize(stream2); (void)hipStreamSynchronize(stream); }
@@ -755,7 +755,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
         side_done(1);
         s_ = stream;
     }
-    p.valid = true;
+    p.valid = true; p.head_done = false;
 }
 
 // -- steps B, C: x = [MForm] sum_i d_i (.) h(c0_i),  y = [MForm] sum_j b_j (.) h(c1_j)   (keyswitch_hoisted.go:79-117)
@@ -785,12 +785,13 @@ void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, 
 }
 
 // -- steps D, E, F (keyswitch_hoisted.go:119-178) with x, y in Montgomery form.
-void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
-                        const Swk& crs_u, Ct& out) {
+// mr_finish = head (F1 and the Decompose of its results: needs y only) + tail (E and F2: needs x).  A party-sharded caller
+// runs the head while the all-reduce of x is still in flight (mkhe-kklss_amd/dist.py).
+void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out) {
     MrPlan& p = plan_;
     if (!p.valid) throw Error("mkhe: mr_finish without mr_prepare");
     if (out.limbs != p.L || out.n != p.nout || op0.n != p.n0 || op1.n != p.n1) throw Error("mkhe: mr_finish arguments do not match mr_prepare");
-    const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
+    const int level = p.level, L = p.L, n0 = p.n0;
     const size_t PO = (size_t)L * N;
     u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
     std::vector<ExtItem> items;
@@ -804,9 +805,18 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
         for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
         if (n0) decompose_batch(level, dsrc, ddst, true);
     }
+    p.head_done = true;
+    MKHE_HIP(hipGetLastError());
+}
+void Context::mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const Swk* const* rlk_v0, const Swk& crs_u, Ct& out) {
+    MrPlan& p = plan_;
+    if (!p.valid || !p.head_done) throw Error("mkhe: mr_finish_tail without mr_finish_head");
+    if (out.limbs != p.L || out.n != p.nout || op0.n != p.n0 || op1.n != p.n1) throw Error("mkhe: mr_finish arguments do not match mr_prepare");
+    const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
+    const size_t PO = (size_t)L * N;
     // E: out_j += <h(c1_j), x>_P ; F2: out_0 += <h(t_i), v_i>_P, out_i += <h(t_i), u>_P   (one batch; items that share a
     // destination are accumulated one after the other by the same thread of the ModDown kernel)
-    items.clear();
+    std::vector<ExtItem> items;
     for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
     for (int a = 0; a < n0; ++a) {
         if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
@@ -815,8 +825,13 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
     }
     if (p.x_pending) { join_side(2); p.x_pending = false; }
     ext_batch(level, items, 1);        // joins the tensor chain before the ModDown accumulates into out
-    p.valid = false;
+    p.valid = false; p.head_done = false;
     MKHE_HIP(hipGetLastError());
+}
+void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
+                        const Swk& crs_u, Ct& out) {
+    mr_finish_head(op0, op1, y, out);
+    mr_finish_tail(op0, op1, x, rlk_v0, crs_u, out);
 }
 
 // ------------------------------------------------------------------ limb-sharded MulAndRelin (see engine.h)

@@ -12,7 +12,15 @@ components of its units.  Exchange steps (the only collectives):
                                               parties in equal numbers; otherwise one all-reduce of the whole ciphertext)
 All sums are exact (ranks * q < 2^63) and order independent, so the result is bit-identical to the
 single-device evaluation.
+
+Ordering of the collectives (every Hip*Backend, `sync`): "stream" (default under RCCL) makes the engine's own stream torch's
+current stream (torch.cuda.ExternalStream) for every collective and every torch copy, so RCCL orders itself against the
+engine's kernels with events and the host never waits inside a step; the all-reduces of y and x are issued asynchronously
+back to back, the engine waits for y alone, runs the part of the finish that needs only y (F1 and the Decompose of the t_i:
+mkhe_mr_finish_head) while x is still being reduced, then waits for x (mkhe_mr_finish_tail).  "host" drains the engine stream
+before every collective and waits for it afterwards (gloo, which moves device tensors through the host).
 """
+import contextlib
 import numpy as np
 
 
@@ -27,26 +35,84 @@ def assign_units(names, world):
     return out
 
 
+class _TorchOnEngineStream:
+    """mixin of the Hip*Backends: torch work (collectives, slot copies) ordered against the engine's kernels"""
+
+    def _init_sync(self, params, torch, dev, sync):
+        self.ext = torch.cuda.ExternalStream(int(params.stream()), device=dev)
+        self.sync = sync
+
+    def set_sync(self, sync):
+        self.sync = sync
+
+    @contextlib.contextmanager
+    def torch_section(self):
+        if self.sync == "stream":
+            with self.torch.cuda.stream(self.ext):           # enqueued on the engine stream: no host synchronisation
+                yield
+        else:
+            self.params.sync()                                # engine stream -> host; torch runs on its own stream
+            yield
+            self.torch.cuda.current_stream().synchronize()
+
+    # (the pre-round-2 names, still used by the emulated-rank tests)
+    def before_collective(self):
+        self.params.sync()
+
+    def after_collective(self):
+        self.torch.cuda.current_stream().synchronize()
+
+
+@contextlib.contextmanager
+def _section(backend):
+    sec = getattr(backend, "torch_section", None)
+    if sec is not None:
+        with sec():
+            yield
+    else:
+        backend.before_collective()
+        yield
+        backend.after_collective()
+
+
 class ShardedMulRelin:
     """Orchestrates one party-sharded MulAndRelinHoisted.  `backend` does the local arithmetic
-    (HipShardBackend below on the GPU); `dist` is torch.distributed (or None for world size 1)."""
+    (HipShardBackend below on the GPU); `dist` is torch.distributed (or None for world size 1).
+    force_collectives: issue the collectives even at world size 1 (exercises the stream plumbing on one GPU)."""
 
-    def __init__(self, backend, dist=None, group=None):
-        self.b, self.dist, self.group = backend, dist, group
+    def __init__(self, backend, dist=None, group=None, force_collectives=False):
+        self.b, self.dist, self.group, self.force = backend, dist, group, force_collectives
+
+    def _active(self):
+        return self.dist is not None and (self.force or self.dist.get_world_size(self.group) > 1)
 
     def _all_reduce(self, t):
-        if self.dist is not None and self.dist.get_world_size(self.group) > 1:
-            self.b.before_collective()
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-            self.b.after_collective()
+        if self._active():
+            with _section(self.b):
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def run(self):
         b = self.b
         x, y = b.partial_xy()                 # torch int64 views of the rank's partial sums
-        self._all_reduce(x)
-        self._all_reduce(y)
-        b.fold_xy()                           # x, y <- MForm(sum mod q)
-        full = b.finish()                     # torch int64 view [1+k][L][N]: own contributions, zeros elsewhere
+        if self._active() and getattr(b, "sync", "host") == "stream" and hasattr(b, "finish_head"):
+            # y is needed first (F1 -> Decompose(t_i), the long chain), x only by step E: both reductions are started now, the
+            # engine stream waits for y, and x is reduced under F1 / Decompose
+            dist = self.dist
+            with b.torch_section():
+                wy = dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                wx = dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                wy.wait()                     # blocks the engine stream, not the host
+            b.fold_y()
+            b.finish_head()
+            with b.torch_section():
+                wx.wait()
+            b.fold_x()
+            full = b.finish_tail()
+        else:
+            self._all_reduce(x)
+            self._all_reduce(y)
+            b.fold_xy()                       # x, y <- MForm(sum mod q)
+            full = b.finish()                 # torch int64 view [1+k][L][N]: own contributions, zeros elsewhere
         self._exchange_out(full)
         b.fold_out()                          # every slot <- sum mod q
         return full
@@ -57,18 +123,17 @@ class ShardedMulRelin:
         the slots are all-gathered (each rank sends only its own), otherwise (half-party units: two ranks add into the same
         slot) the whole ciphertext is all-reduced."""
         dist = self.dist
-        if dist is None or dist.get_world_size(self.group) == 1:
+        if not self._active():
             return
         world, k = dist.get_world_size(self.group), full.shape[0] - 1
         if k == 0 or k % world != 0:
             self._all_reduce(full)
             return
         c, rank = k // world, dist.get_rank(self.group)
-        self.b.before_collective()
-        dist.all_reduce(full[0], op=dist.ReduceOp.SUM, group=self.group)
-        chunks = [full[1 + r * c: 1 + (r + 1) * c] for r in range(world)]
-        dist.all_gather(chunks, chunks[rank].clone(), group=self.group)       # the input is copied: it is also one of the output views
-        self.b.after_collective()
+        with _section(self.b):
+            dist.all_reduce(full[0], op=dist.ReduceOp.SUM, group=self.group)
+            chunks = [full[1 + r * c: 1 + (r + 1) * c] for r in range(world)]
+            dist.all_gather(chunks, chunks[rank].clone(), group=self.group)   # the input is copied: it is also one of the output views
 
 
 def assign_parties(names, world):
@@ -86,16 +151,15 @@ class ShardedRotate:
     permutation on the folded result -- after the reduction, so that the reference's "q - 0 = q" representative of
     keyswitch.go:290 comes out exactly as on one device."""
 
-    def __init__(self, backend, dist=None, group=None):
-        self.b, self.dist, self.group = backend, dist, group
+    def __init__(self, backend, dist=None, group=None, force_collectives=False):
+        self.b, self.dist, self.group, self.force = backend, dist, group, force_collectives
 
     def run(self):
         b = self.b
         full = b.partial()                    # torch int64 view [1+k][L][N]
-        if self.dist is not None and self.dist.get_world_size(self.group) > 1:
-            b.before_collective()
-            self.dist.all_reduce(full, op=self.dist.ReduceOp.SUM, group=self.group)
-            b.after_collective()
+        if self.dist is not None and (self.force or self.dist.get_world_size(self.group) > 1):
+            with _section(b):
+                self.dist.all_reduce(full, op=self.dist.ReduceOp.SUM, group=self.group)
         return b.finish()                     # fold + permutation -> the rotated ciphertext
 
 
@@ -106,12 +170,12 @@ class _DevView:
         self.__cuda_array_interface__ = dict(shape=(int(nwords),), typestr="<i8", data=(int(ptr), False), version=3, strides=None)
 
 
-class HipShardBackend:
+class HipShardBackend(_TorchOnEngineStream):
     """Local arithmetic of one rank on its MI355X through the C ABI (include/mkhe.h, mkhe_mr_*)."""
 
-    def __init__(self, params, names, rank, world, op0_host, op1_host, rlk_host, level, torch, device_index):
+    def __init__(self, params, names, rank, world, op0_host, op1_host, rlk_host, level, torch, device_index, sync="host"):
         """op*_host: full ciphertexts uint64[1+k][L][N]; rlk_host: {name: (b, d, v)} for (at least) the
-        parties this rank needs.  Only the rank's own components and keys are uploaded."""
+        parties this rank needs.  Only the rank's own components and keys are uploaded.  sync: see the module docstring."""
         from . import mkrlwe
         import ctypes as C
         from ._abi import check, lib
@@ -138,6 +202,7 @@ class HipShardBackend:
         N, L = params.N(), level + 1
         self.tfull = torch.as_tensor(_DevView(self.full.devptr(), (1 + len(self.names)) * L * N), device=dev).view(1 + len(self.names), L, N)
         self.tout = torch.as_tensor(_DevView(self.out.devptr(), (1 + len(self.out_ids)) * L * N), device=dev).view(1 + len(self.out_ids), L, N)
+        self._init_sync(params, torch, dev, sync)
 
     def _arr(self, hs):
         from ._abi import handle_array
@@ -150,37 +215,49 @@ class HipShardBackend:
                                               self._arr(b1), self._arr(d0), 1 if self.with_c0 else 0, self.out.h, self.x.h, self.y.h))
         return self.tx, self.ty
 
-    def before_collective(self):
-        self.params.sync()                         # engine stream -> host; RCCL runs on torch's stream
+    def fold_x(self):
+        self.check(self.lib().mkhe_swk_fold(self.params.ctx, self.x.h, self.level, 1))
 
-    def after_collective(self):
-        self.torch.cuda.current_stream().synchronize()
+    def fold_y(self):
+        self.check(self.lib().mkhe_swk_fold(self.params.ctx, self.y.h, self.level, 1))
 
     def fold_xy(self):
-        self.check(self.lib().mkhe_swk_fold(self.params.ctx, self.x.h, self.level, 1))
-        self.check(self.lib().mkhe_swk_fold(self.params.ctx, self.y.h, self.level, 1))
+        self.fold_x()
+        self.fold_y()
+
+    def _spread_out(self):
+        """the rank's slots of `out` into the full-width ciphertext (zeros elsewhere)"""
+        with self.torch_section():
+            self.tfull.zero_()
+            self.tfull[0].copy_(self.tout[0])
+            for a, n in enumerate(self.out_ids):
+                self.tfull[1 + self.names.index(n)].copy_(self.tout[1 + a])
+        return self.tfull
 
     def finish(self):
         v0 = [self.keys[n][2].h for n in self.op0.ids]
         self.check(self.lib().mkhe_mr_finish(self.params.ctx, self.op0.h, self.op1.h, self.x.h, self.y.h,
                                              self._arr(v0), self.params.CRS[-1].h, self.out.h))
-        self.params.sync()
-        self.tfull.zero_()
-        self.tfull[0].copy_(self.tout[0])
-        for a, n in enumerate(self.out_ids):
-            self.tfull[1 + self.names.index(n)].copy_(self.tout[1 + a])
-        self.torch.cuda.current_stream().synchronize()
-        return self.tfull
+        return self._spread_out()
+
+    def finish_head(self):
+        self.check(self.lib().mkhe_mr_finish_head(self.params.ctx, self.op0.h, self.op1.h, self.y.h, self.out.h))
+
+    def finish_tail(self):
+        v0 = [self.keys[n][2].h for n in self.op0.ids]
+        self.check(self.lib().mkhe_mr_finish_tail(self.params.ctx, self.op0.h, self.op1.h, self.x.h,
+                                                  self._arr(v0), self.params.CRS[-1].h, self.out.h))
+        return self._spread_out()
 
     def fold_out(self):
         self.check(self.lib().mkhe_ct_fold(self.params.ctx, self.full.h))
 
 
-class HipRotateBackend:
+class HipRotateBackend(_TorchOnEngineStream):
     """Local arithmetic of one rank for ShardedRotate through the C ABI (mkhe_rotate_partial, mkhe_ct_fold,
     mkhe_ct_automorphism)."""
 
-    def __init__(self, params, names, rank, world, ct_host, rk_host, crs, rotidx, level, torch, device_index, hoisted=False):
+    def __init__(self, params, names, rank, world, ct_host, rk_host, crs, rotidx, level, torch, device_index, hoisted=False, sync="host"):
         """ct_host: uint64[1+k][L][N]; rk_host: {name: rotation key array or resident SwitchingKey} for (at least) this
         rank's parties; crs: the device SwitchingKey params.CRS[rotidx]; hoisted: RotateHoisted (keyswitch_hoisted.go:183-247)
         on hoisted forms of the rank's components computed once here, instead of Rotate (keyswitch.go:234-298)."""
@@ -206,24 +283,18 @@ class HipRotateBackend:
         N, L = params.N(), level + 1
         self.tfull = torch.as_tensor(_DevView(self.full.devptr(), (1 + len(self.names)) * L * N), device=dev).view(1 + len(self.names), L, N)
         self.tpart = torch.as_tensor(_DevView(self.part.devptr(), (1 + len(self.ids)) * L * N), device=dev).view(1 + len(self.ids), L, N)
+        self._init_sync(params, torch, dev, sync)
 
     def partial(self):
         self.check(self.lib().mkhe_rotate_partial(self.params.ctx, self.sub.h, self.harr([h.h for h in self.hoist]) if self.hoist else None,
                                                   self.harr([k.h for k in self.keys]),
                                                   self.crs.h, 1 if self.with_c0 else 0, self.part.h))
-        self.params.sync()
-        self.tfull.zero_()
-        self.tfull[0].copy_(self.tpart[0])
-        for a, n in enumerate(self.ids):
-            self.tfull[1 + self.names.index(n)].copy_(self.tpart[1 + a])
-        self.torch.cuda.current_stream().synchronize()
+        with self.torch_section():
+            self.tfull.zero_()
+            self.tfull[0].copy_(self.tpart[0])
+            for a, n in enumerate(self.ids):
+                self.tfull[1 + self.names.index(n)].copy_(self.tpart[1 + a])
         return self.tfull
-
-    def before_collective(self):
-        self.params.sync()
-
-    def after_collective(self):
-        self.torch.cuda.current_stream().synchronize()
 
     def finish(self):
         self.check(self.lib().mkhe_ct_fold(self.params.ctx, self.full.h))
@@ -354,11 +425,11 @@ class ShardedBfvMulRelin(ShardedMulRelin):
         return full
 
 
-class HipBfvShardBackend:
+class HipBfvShardBackend(_TorchOnEngineStream):
     """Local arithmetic of one rank of ShardedBfvMulRelin through the C ABI (mkhe_bfv_mr_partial / mkhe_swk_fold /
     mkhe_bfv_mr_finish / mkhe_ct_fold).  rlk_host: {name: (b1, b2, d1, d2, v)} for (at least) the rank's parties."""
 
-    def __init__(self, params, names, rank, world, op0_host, op1_host, rlk_host, torch, device_index):
+    def __init__(self, params, names, rank, world, op0_host, op1_host, rlk_host, torch, device_index, sync="host"):
         from . import mkbfv, mkrlwe
         from ._abi import check, handle_array, lib
         self.params, self.names, self.torch = params, list(names), torch
@@ -382,6 +453,7 @@ class HipBfvShardBackend:
         self.level = params.MaxLevel()
         self.tfull = torch.as_tensor(_DevView(self.full.devptr(), (1 + len(self.names)) * L * N), device=dev).view(1 + len(self.names), L, N)
         self.tout = torch.as_tensor(_DevView(self.out.devptr(), (1 + len(self.ids)) * L * N), device=dev).view(1 + len(self.ids), L, N)
+        self._init_sync(params, torch, dev, sync)
 
     def _k(self, j):
         return self.harr([self.keys[n][j].h for n in self.ids])
@@ -392,12 +464,6 @@ class HipBfvShardBackend:
                                                   1 if self.with_c0 else 0, self.out.h, x1.h, x2.h, y1.h, y2.h))
         return self.txy
 
-    def before_collective(self):
-        self.params.sync()
-
-    def after_collective(self):
-        self.torch.cuda.current_stream().synchronize()
-
     def fold_xy(self):
         for s in self.xy:
             self.check(self.lib().mkhe_swk_fold(self.params.ctx, s.h, self.level, 1))
@@ -406,12 +472,11 @@ class HipBfvShardBackend:
         x1, x2, y1, y2 = self.xy
         self.check(self.lib().mkhe_bfv_mr_finish(self.params.ctx, self.op0.h, self.op1.h, x1.h, x2.h, y1.h, y2.h, self._k(4),
                                                  self.params.CRS[-1].h, self.out.h))
-        self.params.sync()
-        self.tfull.zero_()
-        self.tfull[0].copy_(self.tout[0])
-        for a, n in enumerate(self.ids):
-            self.tfull[1 + self.names.index(n)].copy_(self.tout[1 + a])
-        self.torch.cuda.current_stream().synchronize()
+        with self.torch_section():
+            self.tfull.zero_()
+            self.tfull[0].copy_(self.tout[0])
+            for a, n in enumerate(self.ids):
+                self.tfull[1 + self.names.index(n)].copy_(self.tout[1 + a])
         return self.tfull
 
     def fold_out(self):

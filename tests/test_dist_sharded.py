@@ -292,6 +292,63 @@ def test_limb_sharded_with_rccl_world1(sync):
         dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("sync", ["stream", "host"])
+def test_party_sharded_with_rccl_world1(sync):
+    """the party-sharded legs through a REAL one-rank RCCL group with the collectives forced: MulRelin (asynchronous all-reduces of
+    y and x, mkhe_mr_finish_head under the reduction of x, mkhe_mr_finish_tail), hoisted Rotate and the mkbfv MulRelinNew, ordered
+    on the engine's stream (torch.cuda.ExternalStream) or through the host; back-to-back steps, results = the oracle's"""
+    import torch
+    import torch.distributed as dist
+    import harness_bfv as HB
+    from mkhe_kklss_amd import mkbfv, mkckks
+    from mkhe_kklss_amd.dist import (HipBfvShardBackend, HipRotateBackend, HipShardBackend, ShardedBfvMulRelin, ShardedMulRelin,
+                                     ShardedRotate)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        pset = H.small_ckks(12, 3)
+        names = ["u0", "u1", "u2"]
+        ks, level, op0, op1, rlk, u, ref = make_case(pset, names, 37)
+        params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"])
+        params.AddCRS(-1, u)
+        b = HipShardBackend(params, names, 0, 1, op0, op1, rlk, level, torch, 0, sync=sync)
+        smr = ShardedMulRelin(b, dist, force_collectives=True)
+        for _ in range(3):                     # back-to-back steps: nothing may overtake the collectives
+            smr.run()
+        params.sync()
+        torch.cuda.synchronize()
+        assert (b.full.download() == ref).all()
+        # hoisted Rotate
+        ks, level, ct, rk, crs, galEl, rref = make_rot_case(pset, names, 39)
+        rb = HipRotateBackend(params, names, 0, 1, ct, rk, params.AddCRS(3, crs), 3, level, torch, 0, hoisted=True, sync=sync)
+        srot = ShardedRotate(rb, dist, force_collectives=True)
+        for _ in range(3):
+            out = srot.run()
+        params.sync()
+        torch.cuda.synchronize()
+        assert (out.download() == rref).all()
+        # mkbfv
+        bset = HB.small_bfv(11, 3)
+        bfv, bop0, bop1, brlk, bu, bref = make_bfv_case(bset, names, 45)
+        bparams = mkbfv.Parameters(bset["logN"], bset["Q"], bset["QMul"], bset["P"], bset["T"])
+        bparams.AddCRS(-1, bu)
+        bb = HipBfvShardBackend(bparams, names, 0, 1, bop0, bop1, brlk, torch, 0, sync=sync)
+        sb = ShardedBfvMulRelin(bb, dist, force_collectives=True)
+        for _ in range(3):
+            sb.run()
+        bparams.sync()
+        torch.cuda.synchronize()
+        assert (bb.full.download() == bref).all()
+    finally:
+        dist.destroy_process_group()
+
+
 def _two_rank_gpu_worker(rank, world, port, mode, out_path):
     import torch
     import torch.distributed as dist
