@@ -113,7 +113,10 @@ butterflies with a 7-instruction float-estimated partial reduction (round 1: Har
 ### Streaming kernels
 
 `inner_product_kernel<4>` {R["kernels"]["inner_product_kernel"]["avg_launch_us"]:.0f} µs per launch (round 1: 104), `ext_inner_kernel` {R["kernels"]["ext_inner_kernel"]["avg_launch_us"]:.0f} µs (132): 16-byte lanes, unrolled term / digit loops, and
-**non-temporal loads for every operand that is read once per launch** (keys, hoisted digits), so that x, y, the CRS and the twiddles stay cache-resident.  PMC GB/s in the table above.
+**non-temporal loads for every operand that is read once per launch** (keys, hoisted digits), so that x, y, the CRS and the twiddles stay cache-resident.  PMC GB/s in the table above:
+0.74 and 0.81 of the 8 TB/s spec — against the 6.29 TB/s that MI355X_MICROARCH.md measures for a float4 copy (6.0–6.1 TB/s for an in-order sweep of a large table) the inner product is at
+0.94–0.98 of what the memory system delivers; a block-size × chunks-per-thread sweep spans 85–90 µs ("Streaming kernels").  `moddown_batch_kernel` and the small inverse NTTs are
+launch-latency-bound (`{tag}_sq_counters.txt`: `SQ_WAIT_ANY` 0.74 of the wave cycles), not bandwidth-bound.
 
 ## BASELINE.json configs[2]: mkbfv 4-party MulRelinNew, PN15QP880 BFV chain (14 Q + 14 QMul + 2 P)
 
