@@ -322,6 +322,15 @@ void Context::note_use(HandleUsers& u) {
     std::lock_guard<std::mutex> g(r.mu);
     const seq_t s = seq_.load();
     for (auto& e : u.v) if (e.first == uid_) { e.second = s; return; }
+    if (u.v.size() >= 8) {            // a long-lived handle (a key) seen by many short-lived contexts: forget the ones that are gone
+        size_t w = 0;
+        for (size_t i = 0; i < u.v.size(); ++i) {
+            bool live = false;
+            for (const Context* m : r.live) if (m->uid_ == u.v[i].first) { live = true; break; }
+            if (live) u.v[w++] = u.v[i];
+        }
+        u.v.resize(w);
+    }
     u.v.push_back({uid_, s});
 }
 void Context::pool_free(u64* p, size_t words, const HandleUsers* users) {
