@@ -5,7 +5,7 @@
 namespace mkhe {
 
 constexpr int KG_THREADS = 256;
-static int kg_bx(int N) { int bx = (N + KG_THREADS - 1) / KG_THREADS; return bx > 64 ? 64 : bx; }
+static int kg_bx(int N) { return (N + KG_THREADS - 1) / KG_THREADS; }
 
 __global__ void __launch_bounds__(KG_THREADS) small_expand_kernel(u64* dst, const i32* small, const Mod* mods, int limbs, int N) {
     const int j = blockIdx.y, c = blockIdx.z;

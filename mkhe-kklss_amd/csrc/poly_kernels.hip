@@ -288,7 +288,6 @@ __global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
 }
 void launch_tensor(const TensorArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     const int by = a.limbs ? a.nlimbs : a.L;
     if (by < 1) return;
     hipLaunchKernelGGL(tensor_kernel, dim3(bx, by), dim3(PW_THREADS), 0, st, a);
@@ -305,7 +304,6 @@ __global__ void __launch_bounds__(PW_THREADS) add_kernel(u64* dst, const u64* x,
 }
 void launch_add(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st) {
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(add_kernel, dim3(bx, L), dim3(PW_THREADS), 0, st, dst, a, b, mods, N);
 }
 
@@ -319,7 +317,6 @@ __global__ void __launch_bounds__(PW_THREADS) sub_kernel(u64* dst, const u64* x,
 }
 void launch_sub(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st) {
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(sub_kernel, dim3(bx, L), dim3(PW_THREADS), 0, st, dst, a, b, mods, N);
 }
 typedef const __attribute__((address_space(4))) CtBinArgs* ctbin_kargs;
@@ -342,7 +339,6 @@ __global__ void __launch_bounds__(PW_THREADS) ct_binary_kernel(CtBinArgs a) {
 }
 void launch_ct_binary(const CtBinArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(ct_binary_kernel, dim3(bx, a.L, a.ncomp), dim3(PW_THREADS), 0, st, a);
 }
 // ring.Neg writes q - a, i.e. q for a = 0 (lattigo ring_operations.go Neg), kept literally
@@ -356,7 +352,6 @@ __global__ void __launch_bounds__(PW_THREADS) neg_kernel(u64* dst, const u64* x,
 }
 void launch_neg(u64* dst, const u64* a, const Mod* mods, int L, int N, hipStream_t st) {
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(neg_kernel, dim3(bx, L), dim3(PW_THREADS), 0, st, dst, a, mods, N);
 }
 
@@ -372,7 +367,6 @@ __global__ void __launch_bounds__(PW_THREADS) mul_const_kernel(u64* dst, const u
 void launch_mul_const(u64* dst, const u64* src, const Mod* mods, const int* map, const u64* consts, int L, int N, int npolys,
                       long poly_stride, hipStream_t st) {
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(mul_const_kernel, dim3(bx, L, npolys), dim3(PW_THREADS), 0, st, dst, src, mods, map, consts, N, poly_stride);
 }
 
@@ -389,7 +383,6 @@ __global__ void __launch_bounds__(PW_THREADS) mul_const_halves_kernel(MulConstAr
 }
 void launch_mul_const_halves(const MulConstArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(mul_const_halves_kernel, dim3(bx, a.L, a.npolys), dim3(PW_THREADS), 0, st, a);
 }
 __global__ void __launch_bounds__(PW_THREADS) mul_by_poly_kernel(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N) {
@@ -403,7 +396,6 @@ __global__ void __launch_bounds__(PW_THREADS) mul_by_poly_kernel(u64* dst, const
 }
 void launch_mul_by_poly(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, int npolys, hipStream_t st) {
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(mul_by_poly_kernel, dim3(bx, L, npolys), dim3(PW_THREADS), 0, st, dst, a, b, mods, L, N);
 }
 
@@ -566,7 +558,6 @@ __global__ void __launch_bounds__(PW_THREADS) automorphism_kernel(u64* dst, cons
 void launch_automorphism(u64* dst, const u64* src, const Mod* mods, int L, int logN, u64 galEl, int npolys, hipStream_t st) {
     const int N = 1 << logN;
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(automorphism_kernel, dim3(bx, L, npolys), dim3(PW_THREADS), 0, st, dst, src, mods, L, logN, galEl);
 }
 
@@ -590,7 +581,6 @@ void launch_div_round_last(u64* dst, const u64* src, const Mod* mods, const u64*
                            long src_poly, long dst_poly, hipStream_t st) {
     if (level < 1) return;
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(div_round_last_kernel, dim3(bx, level, npolys), dim3(PW_THREADS), 0, st, dst, src, mods, rescale_row, level, N, src_poly, dst_poly);
 }
 
@@ -605,7 +595,6 @@ __global__ void __launch_bounds__(PW_THREADS) fold_kernel(FoldArgs a) {
 }
 void launch_fold(const FoldArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(fold_kernel, dim3(bx, a.nslots, a.npolys), dim3(PW_THREADS), 0, st, a);
 }
 
@@ -620,7 +609,6 @@ __global__ void __launch_bounds__(PW_THREADS) mform_kernel(u64* dst, const u64* 
 }
 void launch_mform(u64* dst, const u64* src, const Mod* mods, const int* map, int nslots, int N, hipStream_t st) {
     int bx = (N + PW_THREADS - 1) / PW_THREADS;
-    if (bx > 64) bx = 64;
     hipLaunchKernelGGL(mform_kernel, dim3(bx, nslots), dim3(PW_THREADS), 0, st, dst, src, mods, map, N);
 }
 
