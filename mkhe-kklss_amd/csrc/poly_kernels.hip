@@ -567,8 +567,17 @@ __global__ void __launch_bounds__(PW_THREADS) div_round_last_kernel(u64* dst, co
     const int i = blockIdx.y, pidx = blockIdx.z;
     const Mod mi = mods[i];
     const u64 qL = mods[level].q, h = (qL - 1) >> 1;
-    // BRedAdd(h, q_i): h < 2^60, q_i > 2^20 -> plain remainder (canonical either way)
-    const u64 hneg = mi.q - (h % mi.q);
+    // BRedAdd(h, q_i): h < 2^60, q_i > 2^20 -> plain remainder (canonical either way).  The 64-bit `%` is a long software loop that
+    // every thread would run for one coefficient's worth of work: the quotient (< 2^40) is estimated in float64 (off by at most one)
+    // and the remainder fixed up -- same value.
+    u64 hr;
+    {
+        const u64 k = (u64)((double)h / (double)mi.q);
+        hr = h - k * mi.q;
+        if ((i64)hr < 0) hr += mi.q;
+        if (hr >= mi.q) hr -= mi.q;
+    }
+    const u64 hneg = mi.q - hr;
     const u64 rp = mi.q - rescale_row[i];
     const u64* s = src + (long)pidx * src_poly;
     u64* d = dst + (long)pidx * dst_poly;
