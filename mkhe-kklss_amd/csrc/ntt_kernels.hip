@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass_fwd_kernel(NttBatch b,
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
     for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < (N >> 1); j += gridDim.x * SPLIT_THREADS) {
-        const int blk = j / G, off = j - blk * G, i0 = blk * 2 * G + off;
+        const int blk = j >> (logN - L - 1), off = j - blk * G, i0 = blk * 2 * G + off;         // G = 2^(logN - L - 1)
         const u64 w = b.psi[(long)m * N + (1 << L) + blk];
         const u64 U = csub(dst[i0], q2), V = dst[i0 + G];
         const u64 Tm = mont_mul_sdu(V, w, md.qs, q, ninv);
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass_inv_kernel(NttBatch b,
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
     for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < (N >> 1); j += gridDim.x * SPLIT_THREADS) {
-        const int blk = j / G, off = j - blk * G, i0 = blk * 2 * G + off;
+        const int blk = j >> (logN - L - 1), off = j - blk * G, i0 = blk * 2 * G + off;         // G = 2^(logN - L - 1)
         const u64 w = b.psi[(long)m * N + (1 << L) + blk];
         const u64 U = dst[i0], V = dst[i0 + G];
         dst[i0] = csub(U + V, q2);
