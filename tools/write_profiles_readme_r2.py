@@ -35,7 +35,25 @@ def table(j, traffic=None):
     return "\n".join(rows)
 
 
+def whole_step_text():
+    """bytes one MulRelin moves through HBM by the PMC passes, against SURVEY.md 8(d)'s two models"""
+    tk, tot, cov_ms, all_ms = tr["kernels"], 0.0, 0.0, 0.0
+    for k, v in pl["roofline"]["kernels"].items():
+        key = k.split()[0]
+        rec = tk.get(key) or tk.get(key.replace("[_batch]", "_batch"))
+        all_ms += v["ms_per_step"]
+        if rec and tr.get("steps") is not None and abs(rec["launches"] - v["launches_per_step"] * (tr["warmup"] + 2 * tr["steps"])) < 0.5:
+            tot += rec["hbm_bytes_per_launch"] * v["launches_per_step"]
+            cov_ms += v["ms_per_step"]
+    return ("Whole step (SURVEY.md §8d asks for the bytes moved against its two models): the kernels with a PMC column — %.0f %% of the kernel time — move **%.2f GB per MulRelin** through HBM "
+            "= %.2f TB/s averaged over the %.3f ms step.  Compulsory model (every key read once: 13 × 56 MiB; the 12 hoisted digit vectors written and read: ≈ 0.9 GiB): 1.75 GB ⇒ 0.22 ms at 8 TB/s; staged "
+            "(unfused) model: 7.7 GB ⇒ 0.97 ms.  The step sits between the two: the fused kernels (digit spread in the NTT load, batched inner products, tensor on the hoisted diagonal) remove "
+            "%.0f %% of the staged model's traffic; what remains above the compulsory bytes is mostly the second read of the hoisted digits (inner product, then external product) and the NTT's parked half-limbs.\n"
+            % (100 * cov_ms / all_ms, tot / 1e9, tot / 1e9 / pl["ms_per_step"], pl["ms_per_step"], 100 * (1 - tot / 7.7e9)))
+
+
 R, Rn = pl["roofline"], no["roofline"]
+whole_step = whole_step_text()
 dom_key = R["kernel"].split()[0]
 avg, calls, mn, mx = st("ntt16_fwd_kernel<true>")
 expect = 2 * (no["warmup"] + 2 * no["steps"])
@@ -84,6 +102,7 @@ cache-served re-reads and may exceed the chip's peak); "PMC GB/s" is what the ke
 (Launches of ≤ 128 limbs in the `ntt_fwd_kernel<15,·,false>` and `ntt_inv_kernel<15>` classes run as `ntt_pass4_fwd/inv_kernel` + `ntt_fwd/inv_lds_kernel`,
 the low-latency path of DESIGN.md §4; that is what the rocprofv3 statistics list, so those classes have no PMC column.)
 
+{whole_step}
 ### Dominant kernel `ntt16_fwd_kernel<true>` (DESIGN.md §4, "H16")
 
 * HIP-event average inside `bench.py`: **{R["avg_launch_us"]:.1f} µs per launch** (plain run), {Rn["avg_launch_us"]:.1f} µs in the profiled run; rocprofv3 kernel-trace average of that
