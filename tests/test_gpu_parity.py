@@ -474,3 +474,40 @@ def test_null_arguments_are_errors_not_crashes():
     assert L.mkhe_ct_download(params.ctx, None, None) != 0
     assert L.mkhe_rescale(params.ctx, None, 1, None) != 0
     assert L.mkhe_crs_expand(params.ctx, 1, 0, None) != 0
+
+
+def test_split_finish_matches_finish_and_checks_its_order():
+    """mkhe_mr_finish == mkhe_mr_finish_head; mkhe_mr_finish_tail (the party-sharded path runs the head while x is still being
+    all-reduced): same bits as the one-call form and as the oracle; a tail without its head is an error, not a crash"""
+    from mkhe_kklss_amd import mkrlwe
+    from mkhe_kklss_amd._abi import check, handle_array, lib
+    pset = H.small_ckks(12, 3)
+    pair = Pair(pset, seed=77)
+    names = ["a", "b", "c"]
+    level = pair.maxlevel
+    h0, d0 = pair.ct(names, level, level + 1)
+    h1, d1 = pair.ct(names, level, level + 1)
+    rlk_h, rlk_d = pair.rlk_set(names)
+    u_h = H.uniform_swk(pair.rng, pair.ks)
+    pair.params.AddCRS(-1, u_h)
+    _, ref = oracle_mul_and_relin(pair, level, names, h0, names, h1, rlk_h, u_h, names)
+    L, ctx = lib(), pair.params.ctx
+    keys = [rlk_d.Value[n] for n in names]
+    b1 = handle_array([k.Value[0].h for k in keys]); dd = handle_array([k.Value[1].h for k in keys]); v0 = handle_array([k.Value[2].h for k in keys])
+    outs = []
+    for split in (False, True):
+        out = mkrlwe.NewCiphertext(pair.params, names, level)
+        x, y = mkrlwe.NewSwitchingKey(pair.params), mkrlwe.NewSwitchingKey(pair.params)
+        check(L.mkhe_mr_partial(ctx, d0.h, d1.h, None, None, b1, dd, 1, out.h, x.h, y.h))
+        check(L.mkhe_swk_fold(ctx, x.h, level, 1)); check(L.mkhe_swk_fold(ctx, y.h, level, 1))
+        if split:
+            assert L.mkhe_mr_finish_tail(ctx, d0.h, d1.h, x.h, v0, pair.params.CRS[-1].h, out.h) != 0
+            assert b"without mr_finish_head" in L.mkhe_last_error()
+            check(L.mkhe_mr_partial(ctx, d0.h, d1.h, None, None, b1, dd, 1, out.h, x.h, y.h))      # (the error reset the plan)
+            check(L.mkhe_swk_fold(ctx, x.h, level, 1)); check(L.mkhe_swk_fold(ctx, y.h, level, 1))
+            check(L.mkhe_mr_finish_head(ctx, d0.h, d1.h, y.h, out.h))
+            check(L.mkhe_mr_finish_tail(ctx, d0.h, d1.h, x.h, v0, pair.params.CRS[-1].h, out.h))
+        else:
+            check(L.mkhe_mr_finish(ctx, d0.h, d1.h, x.h, y.h, v0, pair.params.CRS[-1].h, out.h))
+        outs.append(out.download())
+    assert (outs[0] == ref).all() and (outs[1] == ref).all()
