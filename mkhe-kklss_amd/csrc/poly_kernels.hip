@@ -492,9 +492,14 @@ __device__ __forceinline__ void spread_first_stage(u64& lo, u64& hi, u64 w, cons
     lo = U + Tm;
     hi = U + (mt.q2 - Tm);
 }
+// Two adjacent coefficients per thread (16-byte lanes: the kernel writes beta * m limbs per source digit and is bound by its stores).
+__device__ __forceinline__ void st2(u64* p, u64 x0, u64 x1) {
+    u64x2 r; r.x = x0; r.y = x1;
+    __builtin_nontemporal_store(r, (u64x2*)p);          // written once, gigabytes per launch, read by the NTT that follows: past the caches
+}
 __global__ void __launch_bounds__(PW_THREADS) decomp_spread_kernel(DecompSpreadArgs a) {
     dspread_kargs ka = (dspread_kargs)__builtin_amdgcn_kernarg_segment_ptr();
-    const int n = blockIdx.x * PW_THREADS + threadIdx.x;
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
     const int H = a.N >> 1;
     if (n >= (a.first_stage ? H : a.N)) return;
     const int d = blockIdx.y, item = blockIdx.z;
@@ -502,18 +507,25 @@ __global__ void __launch_bounds__(PW_THREADS) decomp_spread_kernel(DecompSpreadA
     const u64* src = ka->src[item] + (long)start * a.N;
     u64* dst = ka->dst[item] + (long)d * a.mtot * a.N;
     if (nd == 1) {
-        const u64 x = src[n], x2 = a.first_stage ? src[n + H] : 0;
+        const u64x2 x = *(const u64x2*)(src + n);
+        u64x2 x2; x2.x = 0; x2.y = 0;
+        if (a.first_stage) x2 = *(const u64x2*)(src + n + H);
         const u64 qs = a.mods[start].q;
         for (int s = 0; s < a.nslots; ++s) {
             const int m = a.map[s];
             const Mod mt = a.mods[m];
-            u64 lo = qs > 4 * mt.q ? mont_mul_lazy(x, mt.r1, mt.q, mt.ninv32) : x;
+            const bool red = qs > 4 * mt.q;
+            u64 lo0 = red ? mont_mul_lazy(x.x, mt.r1, mt.q, mt.ninv32) : x.x;
+            u64 lo1 = red ? mont_mul_lazy(x.y, mt.r1, mt.q, mt.ninv32) : x.y;
             if (a.first_stage) {
-                u64 hi = qs > 4 * mt.q ? mont_mul_lazy(x2, mt.r1, mt.q, mt.ninv32) : x2;
-                spread_first_stage(lo, hi, a.psi[(long)m * a.N + 1], mt);
-                dst[(long)m * a.N + n + H] = hi;
+                u64 hi0 = red ? mont_mul_lazy(x2.x, mt.r1, mt.q, mt.ninv32) : x2.x;
+                u64 hi1 = red ? mont_mul_lazy(x2.y, mt.r1, mt.q, mt.ninv32) : x2.y;
+                const u64 w = a.psi[(long)m * a.N + 1];
+                spread_first_stage(lo0, hi0, w, mt);
+                spread_first_stage(lo1, hi1, w, mt);
+                st2(dst + (long)m * a.N + n + H, hi0, hi1);
             }
-            dst[(long)m * a.N + n] = lo;
+            st2(dst + (long)m * a.N + n, lo0, lo1);
         }
         return;
     }
@@ -521,23 +533,28 @@ __global__ void __launch_bounds__(PW_THREADS) decomp_spread_kernel(DecompSpreadA
     const u64* ta = a.ta + tsel * DEC_MAXA;
     const u64* tb = a.tb + tsel * a.mtot * DEC_MAXA;
     const u64* tc = a.tc + tsel * a.mtot * (DEC_MAXA + 1);
-    SpreadCoeff c0, c1;
-    spread_prepare(a, src, ta, start, nd, n, c0);
-    if (a.first_stage) spread_prepare(a, src, ta, start, nd, n + H, c1);
+    SpreadCoeff c00, c01, c10, c11;
+    spread_prepare(a, src, ta, start, nd, n, c00);
+    spread_prepare(a, src, ta, start, nd, n + 1, c01);
+    if (a.first_stage) { spread_prepare(a, src, ta, start, nd, n + H, c10); spread_prepare(a, src, ta, start, nd, n + H + 1, c11); }
     for (int s = 0; s < a.nslots; ++s) {
         const int m = a.map[s];
         const Mod mt = a.mods[m];
-        u64 lo = spread_value(c0, tb, tc, m, nd, mt);
+        u64 lo0 = spread_value(c00, tb, tc, m, nd, mt);
+        u64 lo1 = spread_value(c01, tb, tc, m, nd, mt);
         if (a.first_stage) {
-            u64 hi = spread_value(c1, tb, tc, m, nd, mt);
-            spread_first_stage(lo, hi, a.psi[(long)m * a.N + 1], mt);
-            dst[(long)m * a.N + n + H] = hi;
+            u64 hi0 = spread_value(c10, tb, tc, m, nd, mt);
+            u64 hi1 = spread_value(c11, tb, tc, m, nd, mt);
+            const u64 w = a.psi[(long)m * a.N + 1];
+            spread_first_stage(lo0, hi0, w, mt);
+            spread_first_stage(lo1, hi1, w, mt);
+            st2(dst + (long)m * a.N + n + H, hi0, hi1);
         }
-        dst[(long)m * a.N + n] = lo;
+        st2(dst + (long)m * a.N + n, lo0, lo1);
     }
 }
 void launch_decomp_spread(const DecompSpreadArgs& a, hipStream_t st) {
-    const int cnt = a.first_stage ? a.N / 2 : a.N;
+    const int cnt = (a.first_stage ? a.N / 2 : a.N) / 2;          // two coefficients per thread
     const int bx = (cnt + PW_THREADS - 1) / PW_THREADS;
     hipLaunchKernelGGL(decomp_spread_kernel, dim3(bx, a.ndigits, a.nitems), dim3(PW_THREADS), 0, st, a);
 }
