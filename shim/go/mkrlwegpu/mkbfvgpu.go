@@ -69,6 +69,17 @@ func (ctx *Context) MulRelinBFV(op0, op1 *Ciphertext, ids0, ids1 []string, rk *B
 	must(C.mkhe_bfv_mul_relin(ctx.c, op0.h, op1.h, b1, b2, d1, d2, v, crsU.h, out.h))
 }
 
+// ExternalProductBFV is mkbfv.KeySwitcher.ExternalProductBFV (mkbfv/keyswitch.go:92-114, the non-hoisted form: DecomposeBFV of the
+// PolyR operand inside): polyR and out are raw device buffers (mkhe_buf_alloc) holding a PolyR (2l limbs) and a PolyQ (l limbs).
+func (ctx *Context) ExternalProductBFV(polyR unsafe.Pointer, bg1, bg2 *SwitchingKey, out unsafe.Pointer) {
+	must(C.mkhe_bfv_external_product(ctx.c, polyR, bg1.h, bg2.h, out))
+}
+
+// ExternalProductBFVHoisted is mkbfv.KeySwitcher.ExternalProductBFVHoisted (mkbfv/keyswitch_hoisted.go:6-34).
+func (ctx *Context) ExternalProductBFVHoisted(ah1, ah2, bg1, bg2 *SwitchingKey, out unsafe.Pointer) {
+	must(C.mkhe_bfv_external_product_hoisted(ctx.c, ah1.h, ah2.h, bg1.h, bg2.h, out))
+}
+
 // AddBFV / SubBFV: mkbfv.Evaluator.AddNew / SubNew (evaluator.go:44-76)
 func (ctx *Context) AddBFV(op0, op1, out *Ciphertext) { must(C.mkhe_ct_add(ctx.c, op0.h, op1.h, out.h)) }
 func (ctx *Context) SubBFV(op0, op1, out *Ciphertext) { must(C.mkhe_ct_sub(ctx.c, op0.h, op1.h, out.h)) }
