@@ -437,12 +437,27 @@ class Evaluator {
         check(mkhe_ct_copy(params.ctx, c.h, out->h));
         return out;
     }
+    // the operand times an integer factor (MultByConst with an integer-valued float64: constant scale 1, evaluator.go:117-199), scale unchanged
+    CiphertextPtr timesInteger(const Ciphertext& op, double f) {
+        if (!(f < 9223372036854775808.0)) throw Error("mkhe: scale ratio beyond 2^63");
+        const uint64_t fi = (uint64_t)f;
+        std::vector<uint64_t> c;
+        for (int i = 0; i <= op.Level(); ++i) { const uint64_t q = params.Q()[i]; c.push_back((uint64_t)((((unsigned __int128)(fi % q)) << 64) % q)); }     // MForm(f mod q_i)
+        auto tmp = like(op);
+        check(mkhe_ct_mul_const(params.ctx, op.h, c.data(), c.data(), tmp->h));
+        return tmp;
+    }
+    // AddNew / SubNew with the scale matching of evaluateInPlace (evaluator.go:214-281, the fresh-ctOut branch): the operand with the
+    // smaller scale is first multiplied by floor(ratio) when that is > 1; the result carries max(s0, s1) like the reference's
     template <typename F> CiphertextPtr binary(const Ciphertext& op0, const Ciphertext& op1, F fn) {
         const double s0 = op0.Scale, s1 = op1.Scale;
-        if ((s0 > s1 && std::floor(s0 / s1) > 1) || (s1 > s0 && std::floor(s1 / s0) > 1))
-            throw Error("mkhe: Add/Sub of ciphertexts whose scales differ by a factor > 1 is not on the device path");
+        CiphertextPtr t0, t1;
+        if (s1 > s0 && std::floor(s1 / s0) > 1) t0 = timesInteger(op0, std::floor(s1 / s0));
+        else if (s0 > s1 && std::floor(s0 / s1) > 1) t1 = timesInteger(op1, std::floor(s0 / s1));
+        const Ciphertext& a = t0 ? *t0 : op0;
+        const Ciphertext& b = t1 ? *t1 : op1;
         auto out = std::make_unique<Ciphertext>(params, mkrlwe::Union(op0.IDSet_(), op1.IDSet_()), std::min(op0.Level(), op1.Level()), std::max(s0, s1), false);
-        check(fn(params.ctx, op0.h, op1.h, out->h));
+        check(fn(params.ctx, a.h, b.h, out->h));
         return out;
     }
 };

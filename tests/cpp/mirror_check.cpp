@@ -81,6 +81,22 @@ int main() {
             if (sgot[e] != v) { okadd = false; break; }
         }
         expect(okadd, "mkckks.Evaluator.AddNew");
+        {   // unequal scales: the operand with the smaller scale is multiplied by floor(ratio) first (evaluator.go:214-281)
+            const double keep = ct0.Scale;
+            ct0.Scale = keep / 5.25;                       // floor(ratio) = 5
+            auto d = eval.SubNew(ct0, ct1);
+            vec dgot(d->words());
+            d->download(dgot.data());
+            bool ok = d->Scale == ct1.Scale;
+            for (size_t s = 0; s < 3 && ok; ++s) for (size_t l = 0; l < Q.size() && ok; ++l) for (size_t i = 0; i < N; ++i) {
+                const size_t e = (s * Q.size() + l) * N + i;
+                const uint64_t a5 = (uint64_t)(((unsigned __int128)h0[e] * 5) % Q[l]);
+                uint64_t v = a5 + Q[l] - h1[e]; if (v >= Q[l]) v -= Q[l];
+                if (dgot[e] != v) { ok = false; break; }
+            }
+            ct0.Scale = keep;
+            expect(ok, "mkckks.Evaluator.SubNew with unequal scales (MultByConst first)");
+        }
         bool threw = false;
         try { mkrlwe::RelinearizationKeySet empty; eval.MulRelinNew(ct0, ct1, empty); } catch (const mkhe::Error& e) { threw = std::strstr(e.what(), "cannot GetRelinearizationKey") != nullptr; }
         expect(threw, "missing relinearization key raises the reference's panic text");
