@@ -76,6 +76,8 @@ def run_distributed_bfv(args):
     del data, rlk
     smr = ShardedBfvMulRelin(b, dist)
     dt = _timed(dist, torch, params, smr.run, args.steps, args.warmup)
+    from bench import roofline_leg
+    roofline = roofline_leg(args, params, smr.run, pset["logN"], "%s-bfv k=%d sharded over %d" % (args.params, k, world))     # every rank: the steps contain collectives
     out = None
     if rank == 0:
         out = dict(metric="mkbfv_mulrelin_per_sec", value=args.steps / dt, unit="MulRelin/s", n_gpus=world, steps=args.steps,
@@ -84,7 +86,7 @@ def run_distributed_bfv(args):
                    config=dict(workload="mkbfv %d-party MulRelinNew, %s, whole parties sharded over %d GPUs (RCCL all-reduce of x1, x2, "
                                         "y1, y2, out_0; all-gather of out_i)" % (k, args.params, world), parties=k, params=args.params,
                                seed=args.seed, rccl_ranks=dist.get_world_size()),
-                   roofline=None, cpu_baseline=None)
+                   roofline=roofline, cpu_baseline=None)
     dist.barrier()
     dist.destroy_process_group()
     return out
@@ -105,7 +107,7 @@ def run_replicas_cnn(args):
     out = None
     if rank == 0:
         ms = float(t.item())
-        out = dict(one, value=world * 1e3 / ms, ms_per_step=ms, n_gpus=world, scaling="weak", roofline=None)
+        out = dict(one, value=world * 1e3 / ms, ms_per_step=ms, n_gpus=world, scaling="weak")            # roofline: rank 0's replica
         out["config"] = dict(one["config"], replicas=world, sharding="independent replicas: one inference per GPU, no collective")
     dist.barrier()
     dist.destroy_process_group()
@@ -164,6 +166,10 @@ def run_distributed(args):
     dt = _timed(dist, torch, params, step_party, args.steps, args.warmup)
     legs["party"] = dict(mulrelin_per_sec=args.steps / dt, ms_per_step=dt * 1e3 / args.steps, collective_ordering=psync,
                          exchanged_bytes_per_step=8 * (2 * nwx + (1 + (k // world if k % world == 0 else k)) * L * Nn))
+    # per-kernel HIP-event leg on every rank (the steps contain collectives), rank 0's figures are reported: the dominant kernel of a
+    # rank's share of the work (its launch sizes shrink with N: a "sharded k=.. N=.." workload tag keeps the single-GPU PMC traffic out)
+    from bench import roofline_leg
+    roofline = roofline_leg(args, params, step_party, pset["logN"], "%s k=%d sharded over %d" % (args.params, k, world))
     del smr, backend, rlk
     # ---- hoisted Rotate, parties sharded (BASELINE.json configs[3]: "MulRelin + hoisted Rotate")
     rot = 1
@@ -219,7 +225,7 @@ def run_distributed(args):
                                parties=k, params=args.params, seed=args.seed, rccl_ranks=dist.get_world_size(),
                                key_material="device" if device_keys else "host",
                                sharding="parties (mkhe_kklss_amd/dist.py ShardedMulRelin); secondary legs below", legs=legs),
-                   roofline=None, cpu_baseline=None)
+                   roofline=roofline, cpu_baseline=None)
     dist.barrier()
     dist.destroy_process_group()
     return out

@@ -88,7 +88,8 @@ class _FakeDist:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,names", [(1, ["u0", "u1"]), (2, ["u0", "u1"]), (4, ["u0", "u1"]), (2, ["u0", "u1", "u2"])])
+@pytest.mark.parametrize("world,names", [(1, ["u0", "u1"]), (2, ["u0", "u1"]), (4, ["u0", "u1"]), (2, ["u0", "u1", "u2"]),
+                                         (8, ["u0", "u1", "u2", "u3"])])        # the last one: `bench.py --gpus 8` at its default 4 parties (half-party units)
 def test_sharded_mulrelin_device_emulated_ranks(world, names):
     import torch
     from mkhe_kklss_amd import mkckks
@@ -168,7 +169,7 @@ def test_sharded_rotate_gloo_world2(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("hoisted", [False, True])
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])          # 8 ranks, 3 parties: ranks without a party (the bench's rotate leg at --gpus 8)
 def test_sharded_rotate_device_emulated_ranks(world, hoisted):
     import torch
     from mkhe_kklss_amd import mkrlwe
