@@ -477,7 +477,20 @@ def main():
             port = s_.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        # the ranks' stdout carries library banners (RCCL / gloo) besides rank 0's result: pass everything but the JSON line on to
+        # stderr, so that stdout is the ONE line the contract asks for
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+        result = None
+        for line in proc.stdout:
+            if line.startswith('{"metric"'):
+                result = line
+            else:
+                sys.stderr.write(line)
+        rc = proc.wait()
+        if result is not None:
+            sys.stdout.write(result)
+            sys.stdout.flush()
+        sys.exit(rc)
     if args.gpus > 1 or world > 1 or args.force_dist:
         import bench_dist
         out = (bench_dist.run_distributed_bfv if args.scheme == "bfv" else bench_dist.run_replicas_cnn if args.scheme == "cnn"
