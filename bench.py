@@ -491,6 +491,13 @@ def main():
             sys.stdout.write(result)
             sys.stdout.flush()
         sys.exit(rc)
+    json_fd = None
+    if world > 1:
+        # a rank of a multi-process run: the collective library prints its banner on stdout from every rank.  Everything written to
+        # fd 1 from here on (C level included) goes to stderr; rank 0's JSON line is written to the real stdout at the end.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     if args.gpus > 1 or world > 1 or args.force_dist:
         import bench_dist
         out = (bench_dist.run_distributed_bfv if args.scheme == "bfv" else bench_dist.run_replicas_cnn if args.scheme == "cnn"
@@ -502,7 +509,10 @@ def main():
     else:
         out = run_single(args)
     if out is not None:
-        print(json.dumps(out))
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out))
 
 
 if __name__ == "__main__":
