@@ -466,6 +466,9 @@ def main():
                     help="ckks = BASELINE.json headline metric (default); bfv = the mkbfv MulRelin line; cnn = one encrypted "
                          "CNN inference per step (cnn/cnn.go on PN14QP433; --parties 2 or 4) -- both single GPU")
     args = ap.parse_args()
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the image exports it, a
+    # stripped environment may not -- set before anything initialises the HIP runtime, inherited by the ranks we launch
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- N rank processes, one per GPU, started BEFORE anything in this
