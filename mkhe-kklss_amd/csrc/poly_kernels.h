@@ -61,6 +61,12 @@ struct ExtInnerArgs {
     unsigned char bg_once[EXT_MAX_ITEMS];  // this item's key is read by no other item of the launch: stream it past the caches
     unsigned char pair[EXT_MAX_ITEMS];   // 1: this item and the next one share `ah` (step F: <h(t_i), v_i> and <h(t_i), u>):
                                          // computed together, the digits are read once; 2: the follower (skipped); 0: single
+    // groups (set by launch_ext_inner): single items that share `bg` (step E: every <h(c1_j), x>; F1: every <h(c0_i), y>) and pairs that
+    // share their second key (step F2: the CRS u) are computed by ONE thread, up to four at a time, so that the shared operand is
+    // loaded once per coefficient instead of once per item.  grp: 0 = on its own, 1 = leader, 2 = member (skipped); gnext: next
+    // member's index, 255 = end of the chain
+    unsigned char grp[EXT_MAX_ITEMS];
+    unsigned char gnext[EXT_MAX_ITEMS];
     u64* c1;                 // [nitems][mtot][N]
     const Mod* mods;
     const int* map;

@@ -119,6 +119,91 @@ void launch_moddown(const ModDownArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------ batched ExternalProduct halves
 // HBM-bound like the inner product: 16-byte lanes (two coefficients per thread), the digit loop unrolled by four so that
 // 8 (12 for a pair) loads are in flight per thread, the grid covers the limb exactly.
+typedef const __attribute__((address_space(4))) ExtInnerArgs* ext_kargs;
+__device__ __forceinline__ void ext_store(u64* out, u64 x0, u64 x1, u64 q) { u64x2 r; r.x = csub(x0, q); r.y = csub(x1, q); *(u64x2*)out = r; }
+// G single items that share bg: out_m = sum_i bg[i] (.) ah_m[i]
+template <int G>
+__device__ __forceinline__ void ext_group_singles(const ExtInnerArgs& a, ext_kargs ka, int leader, long off, const Mod& md) {
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const long ds = a.digit_stride;
+    const u64* ah[G]; int idx[G];
+    int it = leader;
+#pragma unroll
+    for (int m = 0; m < G; ++m) { idx[m] = it; ah[m] = ka->ah[it] + off; it = ka->gnext[it]; }
+    const u64* bg = ka->bg[leader] + off;
+    const bool once = ka->bg_once[leader] != 0;
+    u64 acc[G][2];
+#pragma unroll
+    for (int m = 0; m < G; ++m) { acc[m][0] = 0; acc[m][1] = 0; }
+#pragma unroll 2
+    for (int i = 0; i < a.nb; ++i) {
+        const u64x2 g = once ? ld_stream(bg + i * ds) : ld_cached(bg + i * ds);
+        u64x2 h[G];
+#pragma unroll
+        for (int m = 0; m < G; ++m) h[m] = ld_stream(ah[m] + i * ds);
+#pragma unroll
+        for (int m = 0; m < G; ++m) {
+            acc[m][0] = csub(acc[m][0] + mont_mul_lazy(g.x, h[m].x, q, ninv), q2);
+            acc[m][1] = csub(acc[m][1] + mont_mul_lazy(g.y, h[m].y, q, ninv), q2);
+        }
+    }
+    if (ka->ah2[leader]) {                       // second gadget (mkbfv: the QMul digits), same shape
+        const u64* ah2[G];
+#pragma unroll
+        for (int m = 0; m < G; ++m) ah2[m] = ka->ah2[idx[m]] + off;
+        const u64* bg2 = ka->bg2[leader] + off;
+#pragma unroll 2
+        for (int i = 0; i < a.nb; ++i) {
+            const u64x2 g = once ? ld_stream(bg2 + i * ds) : ld_cached(bg2 + i * ds);
+            u64x2 h[G];
+#pragma unroll
+            for (int m = 0; m < G; ++m) h[m] = ld_stream(ah2[m] + i * ds);
+#pragma unroll
+            for (int m = 0; m < G; ++m) {
+                acc[m][0] = csub(acc[m][0] + mont_mul_lazy(g.x, h[m].x, q, ninv), q2);
+                acc[m][1] = csub(acc[m][1] + mont_mul_lazy(g.y, h[m].y, q, ninv), q2);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < G; ++m) ext_store(a.c1 + (long)idx[m] * a.c1_item + off, acc[m][0], acc[m][1], q);
+}
+// G pairs (item, item + 1) that share ah within the pair and bg[item + 1] (the CRS u) across the pairs
+template <int G>
+__device__ __forceinline__ void ext_group_pairs(const ExtInnerArgs& a, ext_kargs ka, int leader, long off, const Mod& md) {
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const long ds = a.digit_stride;
+    const u64* ah[G]; const u64* bg[G]; int idx[G];
+    int it = leader;
+#pragma unroll
+    for (int m = 0; m < G; ++m) { idx[m] = it; ah[m] = ka->ah[it] + off; bg[m] = ka->bg[it] + off; it = ka->gnext[it]; }
+    const u64* bgn = ka->bg[leader + 1] + off;
+    const bool once_n = ka->bg_once[leader + 1] != 0;
+    u64 av[G][2], bv[G][2];
+#pragma unroll
+    for (int m = 0; m < G; ++m) { av[m][0] = av[m][1] = bv[m][0] = bv[m][1] = 0; }
+#pragma unroll 1
+    for (int i = 0; i < a.nb; ++i) {
+        const u64x2 gn = once_n ? ld_stream(bgn + i * ds) : ld_cached(bgn + i * ds);
+        u64x2 h[G], g[G];
+#pragma unroll
+        for (int m = 0; m < G; ++m) { h[m] = ld_stream(ah[m] + i * ds); g[m] = ld_stream(bg[m] + i * ds); }
+#pragma unroll
+        for (int m = 0; m < G; ++m) {
+            av[m][0] = csub(av[m][0] + mont_mul_lazy(g[m].x, h[m].x, q, ninv), q2); av[m][1] = csub(av[m][1] + mont_mul_lazy(g[m].y, h[m].y, q, ninv), q2);
+            bv[m][0] = csub(bv[m][0] + mont_mul_lazy(gn.x, h[m].x, q, ninv), q2); bv[m][1] = csub(bv[m][1] + mont_mul_lazy(gn.y, h[m].y, q, ninv), q2);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < G; ++m) {
+        u64* out = a.c1 + (long)idx[m] * a.c1_item + off;
+        ext_store(out, av[m][0], av[m][1], q);
+        ext_store(out + a.c1_item, bv[m][0], bv[m][1], q);
+    }
+}
+// an item (or a pair of neighbours that share their digits) per thread: launches without groups (few registers, full occupancy)
 __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
     const int s = blockIdx.y, item = blockIdx.z;
     const int role = a.pair[item];
@@ -168,9 +253,94 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
     r.x = csub(a0, q); r.y = csub(a1, q);
     *(u64x2*)out = r;
 }
-void launch_ext_inner(const ExtInnerArgs& a, hipStream_t st) {
+// launches with groups: the leaders run the grouped forms above, everything else the per-item form
+__global__ void __launch_bounds__(PW_THREADS) ext_inner_group_kernel(ExtInnerArgs a) {
+    ext_kargs ka = (ext_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int s = blockIdx.y, item = blockIdx.z;
+    const int role = ka->pair[item], grp = ka->grp[item];
+    if (role == 2 || grp == 2) return;                    // computed by its (pair / group) leader
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
+    if (n >= a.N) return;
+    const int m = a.map[s];
+    const Mod md = a.mods[m];
+    if (grp == 1) {
+        const long off = (long)m * a.N + n;
+        int G = 1;
+        for (int it = ka->gnext[item]; it != 255; it = ka->gnext[it]) ++G;
+        if (role == 1) { if (G == 2) ext_group_pairs<2>(a, ka, item, off, md); else if (G == 3) ext_group_pairs<3>(a, ka, item, off, md); else ext_group_pairs<4>(a, ka, item, off, md); }
+        else { if (G == 2) ext_group_singles<2>(a, ka, item, off, md); else if (G == 3) ext_group_singles<3>(a, ka, item, off, md); else ext_group_singles<4>(a, ka, item, off, md); }
+        return;
+    }
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const u64* ah = a.ah[item] + (long)m * a.N + n;
+    const u64* bg = a.bg[item] + (long)m * a.N + n;
+    u64* out = a.c1 + (long)item * a.c1_item + (long)m * a.N + n;
+    const long ds = a.digit_stride;
+    const bool once = a.bg_once[item] != 0;
+    u64x2 r;
+    if (role == 1) {
+        const u64* bgn = a.bg[item + 1] + (long)m * a.N + n;
+        u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll 4
+        for (int i = 0; i < a.nb; ++i) {
+            const u64x2 h = ld_stream(ah + i * ds), g = once ? ld_stream(bg + i * ds) : ld_cached(bg + i * ds), gn = ld_cached(bgn + i * ds);
+            a0 = csub(a0 + mont_mul_lazy(g.x, h.x, q, ninv), q2); a1 = csub(a1 + mont_mul_lazy(g.y, h.y, q, ninv), q2);
+            b0 = csub(b0 + mont_mul_lazy(gn.x, h.x, q, ninv), q2); b1 = csub(b1 + mont_mul_lazy(gn.y, h.y, q, ninv), q2);
+        }
+        r.x = csub(a0, q); r.y = csub(a1, q);
+        *(u64x2*)out = r;
+        r.x = csub(b0, q); r.y = csub(b1, q);
+        *(u64x2*)(out + a.c1_item) = r;
+        return;
+    }
+    u64 a0 = 0, a1 = 0;
+#pragma unroll 4
+    for (int i = 0; i < a.nb; ++i) {
+        const u64x2 h = ld_stream(ah + i * ds), g = once ? ld_stream(bg + i * ds) : ld_cached(bg + i * ds);
+        a0 = csub(a0 + mont_mul_lazy(g.x, h.x, q, ninv), q2); a1 = csub(a1 + mont_mul_lazy(g.y, h.y, q, ninv), q2);
+    }
+    if (a.ah2[item]) {
+        const u64* ah2 = a.ah2[item] + (long)m * a.N + n;
+        const u64* bg2 = a.bg2[item] + (long)m * a.N + n;
+#pragma unroll 4
+        for (int i = 0; i < a.nb; ++i) {
+            const u64x2 h = *(const u64x2*)(ah2 + i * ds), g = *(const u64x2*)(bg2 + i * ds);
+            a0 = csub(a0 + mont_mul_lazy(g.x, h.x, q, ninv), q2); a1 = csub(a1 + mont_mul_lazy(g.y, h.y, q, ninv), q2);
+        }
+    }
+    r.x = csub(a0, q); r.y = csub(a1, q);
+    *(u64x2*)out = r;
+}
+void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
+    ExtInnerArgs a = a_in;
+    static const int grouping = getenv("MKHE_EXT_GROUP") ? atoi(getenv("MKHE_EXT_GROUP")) : 1;
+    for (int i = 0; i < a.nitems; ++i) { a.grp[i] = 0; a.gnext[i] = 255; }
+    if (grouping) {
+        for (int i = 0; i < a.nitems; ++i) {
+            if (a.grp[i] || a.pair[i] == 2) continue;
+            const bool pr = a.pair[i] == 1;            // (pairs never carry a second gadget: see Context::ext_front)
+            int last = i, cnt = 1;
+            for (int k = i + 1; k < a.nitems && cnt < 4; ++k) {
+                if (a.grp[k] || a.pair[k] != a.pair[i] || (a.ah2[k] != nullptr) != (a.ah2[i] != nullptr)) continue;
+                if (pr ? (a.bg[k + 1] != a.bg[i + 1]) : (a.bg[k] != a.bg[i] || a.bg2[k] != a.bg2[i])) continue;
+                a.gnext[last] = (unsigned char)k; a.grp[k] = 2; last = k; ++cnt;
+            }
+            if (cnt > 1) {
+                a.grp[i] = 1;
+                // the shared operand is read once per coefficient by this group: stream it past the caches when no other group uses it
+                const u64* sh = pr ? a.bg[i + 1] : a.bg[i];
+                int uses = 0;
+                for (int k = 0; k < a.nitems; ++k) uses += (a.bg[k] == sh);
+                if (uses == cnt) a.bg_once[pr ? i + 1 : i] = 1;
+            }
+        }
+    }
     const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
-    hipLaunchKernelGGL(ext_inner_kernel, dim3(bx, a.nslots, a.nitems), dim3(PW_THREADS), 0, st, a);
+    bool any = false;
+    for (int i = 0; i < a.nitems; ++i) any = any || a.grp[i] == 1;
+    if (any) hipLaunchKernelGGL(ext_inner_group_kernel, dim3(bx, a.nslots, a.nitems), dim3(PW_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(ext_inner_kernel, dim3(bx, a.nslots, a.nitems), dim3(PW_THREADS), 0, st, a);
 }
 
 typedef const __attribute__((address_space(4))) ModDownBatchArgs* mdb_kargs;
