@@ -826,12 +826,13 @@ void Context::mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const S
     // E: out_j += <h(c1_j), x>_P ; F2: out_0 += <h(t_i), v_i>_P, out_i += <h(t_i), u>_P   (one batch; items that share a
     // destination are accumulated one after the other by the same thread of the ModDown kernel)
     std::vector<ExtItem> items;
-    for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
+    // (the F2 pairs first: grouped four at a time they are the longest blocks of the launch, and the sums are order independent)
     for (int a = 0; a < n0; ++a) {
         if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
         items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
         items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
     }
+    for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
     if (p.x_pending) { join_side(2); p.x_pending = false; }
     ext_batch(level, items, 1);        // joins the tensor chain before the ModDown accumulates into out
     p.valid = false; p.head_done = false;

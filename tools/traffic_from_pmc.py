@@ -27,6 +27,8 @@ def per_kernel(d, counter):
             if not m:
                 continue
             key = m.group(1) + (m.group(2) or "").replace(" ", "")
+            if key == "ext_inner_group_kernel":         # same timing class as the per-item form (mkhe_prof_name: "ext_inner_kernel")
+                key = "ext_inner_kernel"
             out[key].append(float(r["Counter_Value"]))
     return out
 
