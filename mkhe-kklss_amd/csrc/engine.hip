@@ -1346,12 +1346,13 @@ void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u
     }
     // E: out_j += <h(c1_j), (x1,x2)> together with F2
     items.clear();
-    for (int a = 0; a < n1; ++a) {
-        ExtItem it{hoist_slot(1, a).d, x1, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = hoist_slot(4, a).d; it.bg2 = x2; items.push_back(it);
-    }
+    // (the F2 pairs first, as in Context::mr_finish_tail: out_0 is the longest ModDown group)
     for (int a = 0; a < n0; ++a) {
         items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v[a]->d, out.d, true});
         items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true});
+    }
+    for (int a = 0; a < n1; ++a) {
+        ExtItem it{hoist_slot(1, a).d, x1, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = hoist_slot(4, a).d; it.bg2 = x2; items.push_back(it);
     }
     join_side(2);
     ext_batch(level, items, 1);        // joins the tensor / Quantize chain before the ModDown accumulates into out
