@@ -28,6 +28,7 @@ struct Swk { u64* d = nullptr; bool owned = true; };
 struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
 // one external product of a batch: dst (+)= ModDown_P( sum_i bg[i] (.) ah[i] )
 struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const u64* ah2 = nullptr; const u64* bg2 = nullptr;
+                 const u64* xkey = nullptr;   /* F1 only: this party's d_i, for the x by-product (ExtInnerArgs::xkey) */
                  const u64* addend = nullptr; /* accumulate onto this polynomial instead of onto dst (Rotate: c_0 of the input) */ };
 
 typedef unsigned long long seq_t;
@@ -101,7 +102,8 @@ class Context {
     void mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, bool with_c0, Ct& out);
     // defer_x: x is accumulated on the side stream and joined by mr_finish just before its first use (step E), so that it
     // overlaps the latency-bound part of step F; false (split-phase ABI): x and y are both complete on the main stream
-    void mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x = false);
+    // fuse_x: x is not computed here but by the F1 kernel of mr_finish_head (one pass over h(c0_i) less); needs 1 <= n0 <= 4
+    void mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x = false, bool fuse_x = false);
     void mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out);          // F1 + Decompose(t_i): needs y only
     void mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const Swk* const* rlk_v0, const Swk& crs_u, Ct& out);
     void mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
@@ -116,6 +118,7 @@ class Context {
     // stage 0: whole external products; 1: front half only (inner products + inverse NTT into the c1 pool);
     // 2: back half only (ModDown of the c1 pool filled by the preceding stage-1 call with the same items)
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
+    u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
     void ext_front(int level, const ExtItem* items, int n, u64* c1);          // inner products + lazy inverse NTT into c1 [n][mtot][N]
     void ext_back(int level, const ExtItem* items, int n, const u64* c1, u64 galEl = 0);     // ModDown of c1 into / onto the destinations [signed-permuted]
 
@@ -233,6 +236,8 @@ class Context {
         bool own0 = false, own1 = false;     // hoisted digits computed by the engine itself
         bool x_pending = false;              // x still running on the side stream (chain 2)
         bool head_done = false;              // mr_finish_head ran, mr_finish_tail still to come
+        std::vector<const u64*> xkeys;       // non-empty: x is produced by the F1 kernel of mr_finish_head (into xfused) instead of by mr_xy
+        u64* xfused = nullptr;
     } plan_;
 
     // Stream-ordered buffer pool.  A buffer freed through this context may still be in use by kernels that ANOTHER context of the

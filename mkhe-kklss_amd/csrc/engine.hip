@@ -385,7 +385,7 @@ void Context::side_done(int k) { if (!overlap) return; MKHE_HIP(hipEventRecord(e
 void Context::join_side(int k) { if (!overlap) return; MKHE_HIP(hipStreamWaitEvent(s_, ev_[2 * k + 1], 0)); }
 void Context::recover() {
     s_ = stream;
-    plan_.valid = false; plan_.x_pending = false; plan_.head_done = false;
+    plan_.valid = false; plan_.x_pending = false; plan_.head_done = false; plan_.xkeys.clear(); ext_xout_ = nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cs);
     if (cs == hipStreamCaptureStatusNone) { (void)hipStreamSynchronize(stream2); (void)hipStreamSynchronize(stream); }
@@ -611,11 +611,16 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1) {
     if (n < 1 || nslots < 1) return;
     ExtInnerArgs ia{};
     bool two = false;
+    bool xby = ext_xout_ != nullptr && n <= 4;
     for (int i = 0; i < n; ++i) {
         ia.ah[i] = it[i].ah; ia.bg[i] = it[i].bg;
         ia.ah2[i] = it[i].ah2; ia.bg2[i] = it[i].bg2;
+        ia.xkey[i] = it[i].xkey;
         two = two || ia.ah2[i] != nullptr;
+        xby = xby && it[i].xkey && !it[i].ah2 && it[i].bg == it[0].bg;
     }
+    if (ext_xout_ && !xby) throw Error("mkhe: internal: x by-product requested for a batch that cannot carry it");
+    ia.xout = xby ? ext_xout_ : nullptr; ia.xmform = 1;
     // keys that a single item reads (v_i, rotation keys) are streamed; x, y, u are shared by several items and stay cached
     for (int i = 0; i < n; ++i) {
         int uses = 0;
@@ -623,11 +628,11 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1) {
         ia.bg_once[i] = uses == 1 ? 1 : 0;
     }
     // neighbours that share their digits (step F: <h(t_i), v_i> and <h(t_i), u>) are computed together
-    for (int i = 0; i + 1 < n; ++i)
+    for (int i = 0; i + 1 < n && !xby; ++i)
         if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }
     ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
     ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
-    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * (2.0 * nb * (two ? 2 : 1) + 1) * n); launch_ext_inner(ia, s_); }
+    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((2.0 * nb * (two ? 2 : 1) + 1) * n + (xby ? nb * (n + 1.0) : 0.0))); launch_ext_inner(ia, s_); }
     NttBatch b{};
     b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
     b.nouter = n; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
@@ -674,7 +679,9 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
                             const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                             const Swk& crs_u, Ct& out) {
     mr_prepare(op0, op1, hoist0, hoist1, true, out);
-    mr_xy(rlk_b1, rlk_d0, x_, y_, true, true);
+    static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
+    const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= 4 && !masked_;
+    mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse);
     mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
 }
 
@@ -769,12 +776,21 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
 
 // -- steps B, C: x = [MForm] sum_i d_i (.) h(c0_i),  y = [MForm] sum_j b_j (.) h(c1_j)   (keyswitch_hoisted.go:79-117)
 // mform = false leaves the canonical partial sums for a cross-device reduction (party sharding).
-void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x) {
+void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x, bool fuse_x) {
     MrPlan& p = plan_;
     if (!p.valid) throw Error("mkhe: mr_xy without mr_prepare");
     const int nb = beta(p.level), nslots = nslots_qp(p.level);
+    p.xkeys.clear(); p.xfused = nullptr;
+    if (fuse_x) {
+        if (!mform) throw Error("mkhe: internal: the fused x is produced in Montgomery form");
+        for (int a = 0; a < p.n0; ++a) {
+            if (!rlk_d0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+            p.xkeys.push_back(rlk_d0[a]->d);
+        }
+        p.xfused = x;
+    }
     // y first: it feeds step F, the long chain (F1 -> Decompose -> F2); x only feeds step E
-    for (int side = 1; side >= 0; --side) {
+    for (int side = 1; side >= (fuse_x ? 1 : 0); --side) {
         const int n = side ? p.n1 : p.n0;
         if (n > MAX_TERMS) throw Error("mkhe: too many parties");
         InnerProductArgs ip{};
@@ -806,8 +822,14 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
     std::vector<ExtItem> items;
     // F1: t_i = <h(c0_i), y>_P -- the head of the long chain; E (needs x, which may still be accumulating on the side
     // stream) joins the last batch below
-    for (int a = 0; a < n0; ++a) items.push_back(ExtItem{p.h0[a], y, tbuf + (size_t)a * PO, false});
-    ext_batch(level, items);
+    for (int a = 0; a < n0; ++a) {
+        ExtItem it{p.h0[a], y, tbuf + (size_t)a * PO, false};
+        if (!p.xkeys.empty()) it.xkey = p.xkeys[a];
+        items.push_back(it);
+    }
+    if (!p.xkeys.empty()) ext_xout_ = p.xfused;          // x = sum_i d_i (.) h(c0_i) comes out of the same pass over h(c0_i)
+    try { ext_batch(level, items); } catch (...) { ext_xout_ = nullptr; throw; }
+    ext_xout_ = nullptr;
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;

@@ -67,6 +67,12 @@ struct ExtInnerArgs {
     // member's index, 255 = end of the chain
     unsigned char grp[EXT_MAX_ITEMS];
     unsigned char gnext[EXT_MAX_ITEMS];
+    // Optional by-product of a group of single items (MulAndRelin step F1, where ah = h(c0_i)): xout[d] = sum_i xkey[i][d] (.) ah_i[d]
+    // for every digit d -- the x of keyswitch_hoisted.go:79-96 (MForm'd when xmform) from the digits the thread holds anyway, instead of a
+    // second pass over h(c0_i) by the inner-product kernel.  Only when ALL items of the launch form one group (nitems <= 4).
+    const u64* xkey[EXT_MAX_ITEMS];
+    u64* xout;
+    int xmform;
     u64* c1;                 // [nitems][mtot][N]
     const Mod* mods;
     const int* map;

@@ -136,6 +136,32 @@ __device__ __forceinline__ void ext_group_singles(const ExtInnerArgs& a, ext_kar
     u64 acc[G][2];
 #pragma unroll
     for (int m = 0; m < G; ++m) { acc[m][0] = 0; acc[m][1] = 0; }
+    if (a.xout) {
+        // with the x by-product: per digit the G keys d_i as well, x[d] stored as soon as it is complete
+        const u64* xk[G];
+#pragma unroll
+        for (int m = 0; m < G; ++m) xk[m] = ka->xkey[idx[m]] + off;
+        u64* xo = a.xout + off;
+#pragma unroll 1
+        for (int i = 0; i < a.nb; ++i) {
+            const u64x2 g = once ? ld_stream(bg + i * ds) : ld_cached(bg + i * ds);
+            u64x2 h[G], k[G];
+#pragma unroll
+            for (int m = 0; m < G; ++m) { h[m] = ld_stream(ah[m] + i * ds); k[m] = ld_stream(xk[m] + i * ds); }
+            u64 x0 = 0, x1 = 0;
+#pragma unroll
+            for (int m = 0; m < G; ++m) {
+                acc[m][0] = csub(acc[m][0] + mont_mul_lazy(g.x, h[m].x, q, ninv), q2);
+                acc[m][1] = csub(acc[m][1] + mont_mul_lazy(g.y, h[m].y, q, ninv), q2);
+                x0 = csub(x0 + mont_mul_lazy(k[m].x, h[m].x, q, ninv), q2);
+                x1 = csub(x1 + mont_mul_lazy(k[m].y, h[m].y, q, ninv), q2);
+            }
+            x0 = csub(x0, q); x1 = csub(x1, q);
+            if (a.xmform) { x0 = mont_mul(x0, md.r2, q, ninv); x1 = mont_mul(x1, md.r2, q, ninv); }
+            u64x2 r; r.x = x0; r.y = x1;
+            *(u64x2*)(xo + i * ds) = r;
+        }
+    } else {
 #pragma unroll 2
     for (int i = 0; i < a.nb; ++i) {
         const u64x2 g = once ? ld_stream(bg + i * ds) : ld_cached(bg + i * ds);
@@ -147,6 +173,7 @@ __device__ __forceinline__ void ext_group_singles(const ExtInnerArgs& a, ext_kar
             acc[m][0] = csub(acc[m][0] + mont_mul_lazy(g.x, h[m].x, q, ninv), q2);
             acc[m][1] = csub(acc[m][1] + mont_mul_lazy(g.y, h[m].y, q, ninv), q2);
         }
+    }
     }
     if (ka->ah2[leader]) {                       // second gadget (mkbfv: the QMul digits), same shape
         const u64* ah2[G];
@@ -268,7 +295,7 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_group_kernel(ExtInnerArg
         int G = 1;
         for (int it = ka->gnext[item]; it != 255; it = ka->gnext[it]) ++G;
         if (role == 1) { if (G == 2) ext_group_pairs<2>(a, ka, item, off, md); else if (G == 3) ext_group_pairs<3>(a, ka, item, off, md); else ext_group_pairs<4>(a, ka, item, off, md); }
-        else { if (G == 2) ext_group_singles<2>(a, ka, item, off, md); else if (G == 3) ext_group_singles<3>(a, ka, item, off, md); else ext_group_singles<4>(a, ka, item, off, md); }
+        else { if (G == 1) ext_group_singles<1>(a, ka, item, off, md); else if (G == 2) ext_group_singles<2>(a, ka, item, off, md); else if (G == 3) ext_group_singles<3>(a, ka, item, off, md); else ext_group_singles<4>(a, ka, item, off, md); }
         return;
     }
     const u64 q = md.q, q2 = md.q2;
@@ -316,7 +343,11 @@ void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
     ExtInnerArgs a = a_in;
     static const int grouping = getenv("MKHE_EXT_GROUP") ? atoi(getenv("MKHE_EXT_GROUP")) : 1;
     for (int i = 0; i < a.nitems; ++i) { a.grp[i] = 0; a.gnext[i] = 255; }
-    if (grouping) {
+    if (a.xout) {
+        // the x by-product needs every item in ONE group (checked by the caller: single items, one shared key, at most four)
+        for (int i = 0; i < a.nitems; ++i) { a.grp[i] = i ? 2 : 1; a.gnext[i] = i + 1 < a.nitems ? (unsigned char)(i + 1) : 255; }
+        a.bg_once[0] = 1;
+    } else if (grouping) {
         for (int i = 0; i < a.nitems; ++i) {
             if (a.grp[i] || a.pair[i] == 2) continue;
             const bool pr = a.pair[i] == 1;            // (pairs never carry a second gadget: see Context::ext_front)
