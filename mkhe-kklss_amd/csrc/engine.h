@@ -119,8 +119,18 @@ class Context {
     // 2: back half only (ModDown of the c1 pool filled by the preceding stage-1 call with the same items)
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
     u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
-    void ext_front(int level, const ExtItem* items, int n, u64* c1);          // inner products + lazy inverse NTT into c1 [n][mtot][N]
-    void ext_back(int level, const ExtItem* items, int n, const u64* c1, u64 galEl = 0);     // ModDown of c1 into / onto the destinations [signed-permuted]
+    // External products that ModDown adds into ONE destination are merged (ModDown is linear in the Q part, see NttBatch::vi and
+    // ModDownMergedArgs): virtual item v = up to VI_MAX items of the batch with the same destination; their Q limbs are summed in the
+    // NTT domain at the load of ONE inverse NTT, their P limbs are transformed and lifted one by one.  MKHE_EXT_MERGE=0 switches it off.
+    struct ExtMerge {
+        int nvi = 0, members_max = 0;
+        unsigned char cnt[64] = {}, mem[64][4] = {}, accumulate[64] = {};
+        u64* dst[64] = {};
+        const u64* addend[64] = {};
+    };
+    bool ext_plan_merge(int level, const ExtItem* items, int n, ExtMerge& mp) const;
+    void ext_front(int level, const ExtItem* items, int n, u64* c1, const ExtMerge* mp = nullptr);   // inner products + lazy inverse NTT into c1 [n][mtot][N]
+    void ext_back(int level, const ExtItem* items, int n, const u64* c1, u64 galEl = 0, const ExtMerge* mp = nullptr);   // ModDown of c1 into / onto the destinations [signed-permuted]
 
     // ---- limb-sharded multi-GPU evaluation (mkhe_kklss_amd/dist.py LimbShardedMulRelin): this context owns a subset of
     // the RNS moduli ("slots"); NTTs, inner products and ModDown outputs are computed for the owned slots only, all

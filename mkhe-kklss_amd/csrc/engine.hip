@@ -605,7 +605,44 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
 
 // items: independent external products  dst (+)= ModDown( sum_i bg[i] (.) ah[i] )
 // front half: inner products over the gadget digits + lazy inverse NTT of up to EXT_MAX_ITEMS items into c1 ([item][mtot][N])
-void Context::ext_front(int level, const ExtItem* it, int n, u64* c1) {
+bool Context::ext_plan_merge(int level, const ExtItem* it, int n, ExtMerge& mp) const {
+    static const int on = getenv("MKHE_EXT_MERGE") ? atoi(getenv("MKHE_EXT_MERGE")) : 1;
+    if (!on || masked_ || n < 2 || n > 64 || np > 4) return false;
+    static_assert(VI_MAX == 4 && MD_VI_MAX == 4 && EXT_MAX_ITEMS == 64 && NTT_MAX_ITEMS == 64, "ExtMerge is sized for these");
+    // members per virtual item: the padded slot list of the inverse launch has to fit, and the merged multSum adds
+    // members * np 128-bit products before its one Montgomery fold
+    int M = VI_MAX;
+    if (M > 16 / np) M = 16 / np;
+    if (M > (NTT_MAX_SLOTS - (level + 1)) / np) M = (NTT_MAX_SLOTS - (level + 1)) / np;
+    if (M < 2) return false;
+    mp = ExtMerge{};
+    bool used[64] = {};
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        if (used[i]) continue;
+        int first = 1;
+        for (int k = i; k < n; ++k) {
+            if (used[k] || it[k].dst != it[i].dst) continue;
+            used[k] = true;
+            // a later product of the group has to ADD onto the destination (anything else is not a sum: leave the batch alone)
+            if (k != i && (!it[k].accumulate || it[k].addend)) return false;
+            if (first || mp.cnt[mp.nvi - 1] == M) {
+                const int v = mp.nvi++;
+                mp.dst[v] = it[i].dst;
+                mp.accumulate[v] = first ? (it[i].accumulate ? 1 : 0) : 1;
+                mp.addend[v] = first ? it[i].addend : nullptr;
+                first = 0;
+            }
+            const int v = mp.nvi - 1;
+            mp.mem[v][mp.cnt[v]++] = (unsigned char)k;
+            if (mp.cnt[v] > 1) any = true;
+            if (mp.cnt[v] > mp.members_max) mp.members_max = mp.cnt[v];
+        }
+    }
+    return any;
+}
+
+void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtMerge* mp) {
     const int nb = beta(level), nslots = nslots_qp(level);
     const size_t item_words = (size_t)mtot * N;
     if (n < 1 || nslots < 1) return;
@@ -634,15 +671,44 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1) {
     ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
     { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((2.0 * nb * (two ? 2 : 1) + 1) * n + (xby ? nb * (n + 1.0) : 0.0))); launch_ext_inner(ia, s_); }
     NttBatch b{};
-    b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
-    b.nouter = n; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
+    b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux;
+    b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
     b.src_outer = b.dst_outer = (long)item_words; b.lazy_out = 1;
+    if (mp) {
+        // merged: one job per (virtual item, Q limb) -- the members' limbs are added up at the load -- and one per (member, P limb)
+        b.vi = 1; b.vi_q = level + 1; b.vi_np = np; b.nouter = mp->nvi;
+        b.nslots = level + 1 + mp->members_max * np;
+        for (int j = 0; j <= level; ++j) { b.mod[j] = j; b.pos[j] = j; }
+        for (int k = 0; k < mp->members_max; ++k)
+            for (int j = 0; j < np; ++j) { b.mod[level + 1 + k * np + j] = nq + j; b.pos[level + 1 + k * np + j] = level + 1 + j; }
+        for (int v = 0; v < mp->nvi; ++v) { b.vi_cnt[v] = mp->cnt[v]; for (int k = 0; k < VI_MAX; ++k) b.vi_mem[v] |= (unsigned)mp->mem[v][k] << (8 * k); }
+        b.vi_jobs = mp->nvi * (level + 1) + n * np;
+        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * b.vi_jobs); launch_ntt_inv(logN, b, s_); }
+        return;
+    }
+    slots_qp(b, level);
+    b.nouter = n;
     { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, s_); }
 }
 // back half: ModDown of the items in c1 into (or onto) their destinations
-void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 galEl) {
+void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 galEl, const ExtMerge* mp) {
     if (n < 1) return;
     const size_t item_words = (size_t)mtot * N;
+    if (mp) {
+        ModDownMergedArgs md{};
+        md.c1 = c1; md.mods_q = d_mods; md.mods_p = d_mods + nq;
+        md.t = ModDownTables{d_md_qoverqiinvqi, d_md_qoverqimodp, d_md_vtimes, d_md_down};
+        md.c1_item = (long)item_words; md.p_offset = (long)nq * N; md.nvi = mp->nvi; md.level = level; md.np = np; md.N = N;
+        double bytes = 0;
+        for (int v = 0; v < mp->nvi; ++v) {
+            md.dst[v] = mp->dst[v]; md.accumulate[v] = mp->accumulate[v]; md.addend[v] = mp->addend[v]; md.cnt[v] = mp->cnt[v];
+            for (int k = 0; k < MD_VI_MAX; ++k) md.mem[v] |= (unsigned)mp->mem[v][k] << (8 * k);
+            bytes += 8.0 * N * ((level + 1) * (mp->accumulate[v] ? 3.0 : 2.0) + np * mp->cnt[v]);
+        }
+        md.galEl = galEl; md.logN = logN;
+        { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_merged(md, s_); }
+        return;
+    }
     ModDownBatchArgs md{};
     md.c1 = c1; md.mods_q = d_mods; md.mods_p = d_mods + nq;
     md.t = ModDownTables{d_md_qoverqiinvqi, d_md_qoverqimodp, d_md_vtimes, d_md_down};
@@ -664,10 +730,12 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
     for (size_t base = 0; base < items.size(); base += EXT_MAX_ITEMS) {
         const int n = (int)std::min<size_t>(EXT_MAX_ITEMS, items.size() - base);
         u64* c1 = scratch(c1b_, c1b_words_, (size_t)n * item_words);
-        if (stage != 2) ext_front(level, items.data() + base, n, c1);
+        ExtMerge mp;
+        const bool merged = stage == 0 && ext_plan_merge(level, items.data() + base, n, mp);
+        if (stage != 2) ext_front(level, items.data() + base, n, c1, merged ? &mp : nullptr);
         if (stage == 1) continue;
         if (join_before_moddown >= 0) { join_side(join_before_moddown); join_before_moddown = -1; }
-        ext_back(level, items.data() + base, n, c1, galEl);
+        ext_back(level, items.data() + base, n, c1, galEl, merged ? &mp : nullptr);
     }
     if (join_before_moddown >= 0) join_side(join_before_moddown);
     MKHE_HIP(hipGetLastError());

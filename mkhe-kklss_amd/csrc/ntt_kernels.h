@@ -35,6 +35,7 @@ namespace mkhe {
 
 constexpr int NTT_MAX_ITEMS = 64;
 constexpr int NTT_MAX_SLOTS = 48;
+constexpr int VI_MAX = 4;       // members of one merged group (NttBatch::vi)
 
 // How job j of a batched launch finds its limb.  Jobs are slot-major: s = j / nouter selects the
 // limb slot (modulus mod[s], position pos[s] inside a plain polynomial), outer = j % nouter the
@@ -70,6 +71,16 @@ struct NttBatch {
     int outer_mod[NTT_MAX_SLOTS];  // reduce_src_mod_is_outer == 2
     const u64* src_items[NTT_MAX_ITEMS];
     u64* dst_items[NTT_MAX_ITEMS];
+    // Merged inverse launch (vi != 0; Context::ext_batch): the external products that ModDown adds into ONE destination are
+    // linear in their Q limbs -- sum_i (x_i - lift_i) * P^-1 = (sum_i x_i - sum_i lift_i) * P^-1 mod q -- so their Q limbs are
+    // summed in the NTT domain and transformed ONCE; only the P limbs (the non-linear lift) are transformed per product.
+    // outer = group g of vi_cnt[g] <= VI_MAX members, member k = item vi_mem[g][k] of the buffer src = dst
+    // ([item][.. mapped limbs ..][N], item stride src_outer).  Slots [0, vi_q): Q limb mod[s], source = the canonical sum of
+    // that limb over the members (formed at the load), written over the first member's limb; slots >= vi_q: P limb mod[s] of
+    // member (s - vi_q) / vi_np, in place -- no job when the group has fewer members.  vi_jobs = jobs that exist.
+    int vi, vi_q, vi_np, vi_jobs;
+    int vi_cnt[NTT_MAX_ITEMS];
+    unsigned int vi_mem[NTT_MAX_ITEMS];          // item index of member k in bits 8k .. 8k+7 (32-bit lists: see ModDownMergedArgs)
 };
 
 // small_q[m] != 0 marks moduli with 34q < 2^63 (forward NTT without in-loop reductions).  The forward

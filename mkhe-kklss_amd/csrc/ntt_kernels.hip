@@ -215,13 +215,25 @@ __device__ __forceinline__ void phase(u64 (&x)[32], gcptr psi, int base, int pre
 // The small per-launch lists are read straight from the kernarg segment (scalar loads): indexing the
 // by-value struct dynamically would make the compiler copy all of it to scratch.
 typedef const __attribute__((address_space(4))) NttBatch* kargptr;
-__device__ __forceinline__ void job_pointers(const NttBatch& b, int job, gcptr& src, gptr& dst, int& m, int& outer) {
+// Returns the number of source limbs to add up (1 everywhere but in the Q slots of a merged inverse launch, NttBatch::vi;
+// 0 = this job does not exist: a P slot of a member the group does not have).
+template <bool VI = false>
+__device__ __forceinline__ int job_pointers(const NttBatch& b, int job, gcptr& src, gptr& dst, int& m, int& outer) {
     kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
     // slot-major job order: consecutive workgroups share a modulus, so at any time the chip works
     // on 2-3 twiddle tables that stay resident in every XCD's L2
     const int s = job / b.nouter;
     outer = job - s * b.nouter;
     m = kb->mod[s];
+    if (VI && b.vi) {
+        const int cnt = kb->vi_cnt[outer];
+        const int k = s < b.vi_q ? 0 : (s - b.vi_q) / b.vi_np;
+        const bool exists = k < cnt;
+        const long off = (long)((kb->vi_mem[outer] >> (exists ? 8 * k : 0)) & 255u) * b.src_outer + (long)m * b.src_inner;
+        src = (gcptr)(b.src + off);
+        dst = (gptr)(b.dst + off);
+        return !exists ? 0 : (s < b.vi_q ? cnt : 1);
+    }
     const int p = kb->pos[s];
     const u64* sbase = b.src; u64* dbase = b.dst;
     if (b.nitems > 0) {
@@ -231,6 +243,13 @@ __device__ __forceinline__ void job_pointers(const NttBatch& b, int job, gcptr& 
     }
     src = (gcptr)(sbase + (long)outer * b.src_outer + (long)(b.src_mapped ? m : p) * b.src_inner);
     dst = (gptr)(dbase + (long)outer * b.dst_outer + (long)(b.dst_mapped ? m : p) * b.dst_inner);
+    return 1;
+}
+// word offset of member k of group g relative to the group's first member (merged inverse launches)
+__device__ __forceinline__ long vi_member_offset(const NttBatch& b, int g, int k) {
+    kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned mem = kb->vi_mem[g];
+    return ((long)((mem >> (8 * k)) & 255u) - (long)(mem & 255u)) * b.src_outer;
 }
 
 // ------------------------------------------------------------------ forward kernel
@@ -359,7 +378,8 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
 }
 
 // ------------------------------------------------------------------ inverse kernel
-template <int LOGN>
+// VI: merged launches (NttBatch::vi) -- a separate instantiation, the member sum at the load costs the plain kernel registers
+template <int LOGN, bool VI>
 __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     using G = Geo<LOGN>;
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
@@ -374,7 +394,12 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     if constexpr (G::LPB == 1) job = __builtin_amdgcn_readfirstlane(job);    // provably wave-uniform: modulus constants and pointers stay in SGPRs
     gcptr src; gptr dst; int m, outer;
     const int half = b.split ? (job & 1) : 0;
-    job_pointers(b, b.split ? (job >> 1) : job, src, dst, m, outer);
+    const int nsum_ = job_pointers<VI>(b, b.split ? (job >> 1) : job, src, dst, m, outer);
+    const int nsum = VI ? nsum_ : 1;
+    if (nsum == 0) {                             // merged launch: a P slot of a member this group does not have
+        if constexpr (G::LPB == 1) continue;     // (the whole workgroup shares the job)
+    }
+    const bool exists = active && nsum != 0;
     src += half * G::N; dst += half * G::N;
     const int root = b.split ? 2 + half : 1;
     const Mod md = b.mods[m];
@@ -385,6 +410,15 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     u64 x[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) x[r] = src[posB(t, r)];
+    if constexpr (VI) {
+        // merged launch, Q slot: the canonical sum of this limb over the group's members
+#pragma unroll 1
+        for (int k = 1; k < nsum; ++k) {
+            gcptr sk = src + vi_member_offset(b, outer, k);
+#pragma unroll
+            for (int r = 0; r < 32; ++r) x[r] = csub(x[r] + sk[posB(t, r)], q);
+        }
+    }
     if constexpr (G::HAS_MID) __syncthreads();   // other waves may still read this half-wave's LDS region (previous limb)
     exchange_xor<LOGN, LB, LC, false>(x, lds, t);
     // phases: 0 = index bits 0..4 (layout C), 1 = bits 5..MIDTOP (layout B); the top phase follows
@@ -410,7 +444,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
         x[g] = (b.lazy_out | b.split) ? s : csub(s, q);
         x[g + 16] = (b.lazy_out | b.split) ? d : csub(d, q);
     }
-    if (active) {
+    if (exists) {
 #pragma unroll
         for (int r = 0; r < 32; ++r) dst[posA<LOGN>(t, r)] = x[r];
     }
@@ -452,7 +486,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_split_fwd_kernel(NttBatch b
 __global__ void __launch_bounds__(SPLIT_THREADS) ntt_split_inv_kernel(NttBatch b, int logN) {
     const int N = 1 << logN, H = N >> 1;
     gcptr src; gptr dst; int m, outer;
-    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    if (!job_pointers<true>(b, blockIdx.y, src, dst, m, outer)) return;
     const Mod md = b.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
@@ -480,8 +514,10 @@ __device__ __forceinline__ int sm_pad(int p) { return p + ((p >> 4) << 1); }    
 // One phase: NB stages S0 .. S0+NB-1 of the 2^13-point sub-transform on units of 2^NB coefficients p + a * gl.
 // MODE 0 / 1: forward (Harvey / signed never-reduced), 2: inverse (stages in descending order).
 // FIN 1: forward normalisation on the way out (canonical, or +16q when skip_norm); FIN 2: inverse, times N^-1.
+// nsum > 1 (first inverse phase of a merged launch, NttBatch::vi): the input is the canonical sum of nsum limbs, gsrc + sum_off[k].
 template <int S0, int NB, bool FROM_G, bool TO_G, int MODE, int FIN>
-__device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr psi, int root, int t, const Mod& md, u64 fin_c, int skip_norm) {
+__device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr psi, int root, int t, const Mod& md, u64 fin_c, int skip_norm,
+                                         int nsum = 1, const long* sum_off = nullptr) {
     constexpr int LGL = SM_LOGM - S0 - NB, GL = 1 << LGL, UPT = SM_E >> NB, NE = 1 << NB;
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
@@ -493,6 +529,14 @@ __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr 
         u64 x[NE];
 #pragma unroll
         for (int a = 0; a < NE; ++a) x[a] = FROM_G ? gsrc[p + a * GL] : lds[sm_pad(p + a * GL)];
+        if constexpr (FROM_G && MODE == 2) {
+#pragma unroll
+            for (int k = 1; k < VI_MAX; ++k)
+                if (k < nsum) {
+#pragma unroll
+                    for (int a = 0; a < NE; ++a) x[a] = csub(x[a] + gsrc[sum_off[k] + p + a * GL], q);
+                }
+        }
 #pragma unroll
         for (int ii = 0; ii < NB; ++ii) {
             const int i = MODE == 2 ? NB - 1 - ii : ii;
@@ -545,13 +589,17 @@ __global__ void __launch_bounds__(SM_T) ntt_inv_lds_kernel(NttBatch b, int d) {
     extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
     const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
     gcptr src; gptr dst; int m, outer;
-    job_pointers(b, job >> d, src, dst, m, outer);
+    const int nsum = job_pointers<true>(b, job >> d, src, dst, m, outer);
+    if (nsum == 0) return;                                     // merged launch: no such member (the whole workgroup returns)
+    long sum_off[VI_MAX] = {};
+#pragma unroll
+    for (int k = 1; k < VI_MAX; ++k) if (k < nsum) sum_off[k] = vi_member_offset(b, outer, k);
     src += part * SM_M; dst += part * SM_M;
     const int root = (1 << d) + part;
     const Mod md = b.mods[m];
     gcptr psi = (gcptr)(b.psi + ((long)m * SM_M << d));
     const u64 ninvR = b.aux[6 * m];                            // N^-1 * R of the WHOLE limb size, signed-split form
-    sm_phase<12, 1, true, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    sm_phase<12, 1, true, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0, nsum, sum_off);
     __syncthreads();
     sm_phase<9, 3, false, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
     __syncthreads();
@@ -583,7 +631,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass_fwd_kernel(NttBatch b,
 __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass_inv_kernel(NttBatch b, int logN, int L) {
     const int N = 1 << logN, G = N >> (L + 1);
     gcptr src; gptr dst; int m, outer;
-    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    if (!job_pointers<true>(b, blockIdx.y, src, dst, m, outer)) return;
     const Mod md = b.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
@@ -638,7 +686,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass4_fwd_kernel(NttBatch b
 __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass4_inv_kernel(NttBatch b, int logN) {
     const int N = 1 << logN, Q = N >> 2;
     gcptr src; gptr dst; int m, outer;
-    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    if (!job_pointers<true>(b, blockIdx.y, src, dst, m, outer)) return;
     const Mod md = b.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
@@ -695,7 +743,7 @@ template <int LOGN, int MODE, bool DEC> static void launch_fwd_t(const NttBatch&
     const int blocks = need < resident ? need : resident;
     hipLaunchKernelGGL((ntt_fwd_kernel<LOGN, MODE, DEC>), dim3(blocks), dim3(G::BT), lds, st, b);
 }
-template <int LOGN> static void launch_inv_t(const NttBatch& b, hipStream_t st) {
+template <int LOGN, bool VI> static void launch_inv_tv(const NttBatch& b, hipStream_t st) {
     using G = Geo<LOGN>;
     static LaunchState ls;
     const size_t lds = (size_t)G::LPB * lds_words<LOGN>() * sizeof(u32);
@@ -703,13 +751,16 @@ template <int LOGN> static void launch_inv_t(const NttBatch& b, hipStream_t st) 
     {
         const int dev = current_device();
         std::lock_guard<std::mutex> g(ls.mu);
-        if (!ls.attr[dev]) { (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); ls.attr[dev] = true; }
-        if (!ls.resident[dev]) ls.resident[dev] = resident_blocks((const void*)ntt_inv_kernel<LOGN>, G::BT, lds);
+        if (!ls.attr[dev]) { (void)hipFuncSetAttribute((const void*)ntt_inv_kernel<LOGN, VI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); ls.attr[dev] = true; }
+        if (!ls.resident[dev]) ls.resident[dev] = resident_blocks((const void*)ntt_inv_kernel<LOGN, VI>, G::BT, lds);
         resident = ls.resident[dev];
     }
     const int need = (((b.nslots * b.nouter) << b.split) + G::LPB - 1) / G::LPB;
     const int blocks = need < resident ? need : resident;
-    hipLaunchKernelGGL(ntt_inv_kernel<LOGN>, dim3(blocks), dim3(G::BT), lds, st, b);
+    hipLaunchKernelGGL((ntt_inv_kernel<LOGN, VI>), dim3(blocks), dim3(G::BT), lds, st, b);
+}
+template <int LOGN> static void launch_inv_t(const NttBatch& b, hipStream_t st) {
+    if (b.vi) launch_inv_tv<LOGN, true>(b, st); else launch_inv_tv<LOGN, false>(b, st);
 }
 
 template <int MODE, bool DEC> static void launch_fwd_mode(int logN, const NttBatch& b, hipStream_t st) {
@@ -746,8 +797,9 @@ static bool use_split(int logN, const NttBatch& b) {
     static const int forced = env_int("MKHE_NTT_SPLIT", -1);                 // (function-local statics: initialised once, thread-safe)
     if (forced >= 0) return forced != 0;
     static const int lim = env_int("MKHE_NTT_SPLIT_MAX", 128);               // A/B: limb count up to which a launch runs split
-    if ((logN == 14 || logN == 15) && b.nslots * b.nouter <= lim) return true;
-    return b.nslots * b.nouter <= 128;        // at most one sub-transform workgroup per CU (256 CUs)
+    const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;                // merged launches: the jobs that exist
+    if ((logN == 14 || logN == 15) && limbs <= lim) return true;
+    return limbs <= 128;        // at most one sub-transform workgroup per CU (256 CUs)
 }
 // depth of the low-latency path for this launch: 0 = register-resident sub-transforms, d >= 1 = 2^d LDS sub-transforms of
 // 2^13 coefficients per limb after d streaming passes.  MKHE_NTT_LDS=0 switches it off (A/B tests).

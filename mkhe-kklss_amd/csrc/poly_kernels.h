@@ -111,6 +111,37 @@ struct ModDownBatchArgs {
 };
 void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st);
 
+// The same tail on MERGED items (Context::ext_batch, NttBatch::vi): ModDown is linear in the Q part and the sum the reference
+// forms, sum_i ModDown(x_i) = sum_i (x_i - lift(xP_i)) * P^-1 mod q (every term canonical: MRed, then ring.Add), equals
+// (sum_i x_i - sum_i lift(xP_i)) * P^-1 mod q.  A virtual item v is a set of <= MD_VI_MAX external products with ONE destination:
+// the Q limbs of member 0 in c1 hold the lazy inverse NTT of the summed Q parts, every member's P limbs its own P part.  Per
+// coefficient: y_k, v_k of every member literally (reconstructRNS, basis_extension.go:537-579), ONE 128-bit multSum over all
+// members' y (the Montgomery fold of :623-645 is linear too) + sum_k vtimesqmodp[v_k], ONE MRed tail, ONE store.
+constexpr int MD_VI_MAX = 4;
+struct ModDownMergedArgs {
+    const u64* c1;           // [nitems][mtot][N]
+    u64* dst[EXT_MAX_ITEMS];                      // per virtual item
+    const u64* addend[EXT_MAX_ITEMS];             // as ModDownBatchArgs::addend
+    // (32-bit fields on purpose: indexed by a value that also indexes the 8-byte lists above, byte-sized lists made hipcc 7.2 fold
+    // the index into the BASE of a scalar load, whose low address bits the hardware ignores -- wrong members were read)
+    unsigned int accumulate[EXT_MAX_ITEMS];
+    unsigned int cnt[EXT_MAX_ITEMS];              // members of virtual item v
+    unsigned int mem[EXT_MAX_ITEMS];              // their item indices in c1, one byte each (member k: bits 8k .. 8k+7)
+    const Mod* mods_q;
+    const Mod* mods_p;
+    ModDownTables t;
+    long c1_item, p_offset;
+    int nvi, level, np, N;
+    // virtual items with the same destination are applied one after the other by the same thread, different destinations in
+    // parallel (blockIdx.z), exactly like ModDownBatchArgs
+    unsigned char order[EXT_MAX_ITEMS];
+    unsigned char gstart[EXT_MAX_ITEMS + 1];
+    int ngroups;
+    u64 galEl;
+    int logN;
+};
+void launch_moddown_merged(const ModDownMergedArgs& a, hipStream_t st);
+
 // Tensor step D of MulAndRelin (keyswitch_hoisted.go:120-140) on NTT-domain inputs.
 //   out_0 = a0*b0 ; out_o = b0*a_o (o in ids0) (+)= a0*b_o (o in ids1)
 // NTT(c0_i) / NTT(c1_j) of the party components are read either from a plain NTT buffer (limb stride N)

@@ -457,6 +457,105 @@ void launch_moddown_batch(const ModDownBatchArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL(moddown_batch_kernel, dim3(bx, by, a.ngroups), dim3(PW_THREADS), 0, st, a);
 }
 
+// merged form: see ModDownMergedArgs.  NPT = number of special primes (compile time: the members' y live in registers)
+typedef const __attribute__((address_space(4))) ModDownMergedArgs* mdm_kargs;
+template <int NPT>
+__global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMergedArgs a) {
+    mdm_kargs ka = (mdm_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int n = blockIdx.x * PW_THREADS + threadIdx.x;
+    if (n >= a.N) return;
+    const int g = blockIdx.z;
+    for (int kk = ka->gstart[g]; kk < ka->gstart[g + 1]; ++kk) {
+        const int vi = ka->order[kk];
+        const int cnt = (int)ka->cnt[vi];
+        const u32 members = ka->mem[vi];
+        const u64* xq = a.c1 + (long)(members & 255u) * a.c1_item;
+        u64* dst = ka->dst[vi];
+        const int acc = (int)ka->accumulate[vi];
+        u64 y[MD_VI_MAX][NPT];
+        u32 v[MD_VI_MAX];
+#pragma unroll
+        for (int k = 0; k < MD_VI_MAX; ++k) {
+            v[k] = 0;
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) y[k][i] = 0;
+            if (k < cnt) {
+                const u64* xp = a.c1 + (long)((members >> (8 * k)) & 255u) * a.c1_item + a.p_offset;
+                double vi_ = 0.0;
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    const Mod mp = a.mods_p[i];
+                    y[k][i] = mont_mul(xp[(long)i * a.N + n], a.t.qoverqiinvqi[i], mp.q, mp.ninv32);
+                    vi_ = vi_ + (double)y[k][i] / (double)mp.q;
+                }
+                v[k] = (u32)(u64)vi_;
+            }
+        }
+        for (int j = blockIdx.y; j <= a.level; j += gridDim.y) {
+            const Mod mq = a.mods_q[j];
+            u64 rlo = 0, rhi = 0, vt = 0;
+#pragma unroll
+            for (int k = 0; k < MD_VI_MAX; ++k) {
+                if (k < cnt) {
+#pragma unroll
+                    for (int i = 0; i < NPT; ++i) {
+                        u64 mhi, mlo;
+                        mul64x64(y[k][i], a.t.qoverqimodp[(long)j * NPT + i], mhi, mlo);
+                        const u64 sum = rlo + mlo;
+                        rhi += mhi + (sum < rlo ? 1 : 0);
+                        rlo = sum;
+                    }
+                    vt = csub(vt + a.t.vtimesqmodp[(long)j * (NPT + 1) + v[k]], mq.q);
+                }
+            }
+            const u64 hhi = mulhi64(rlo * mq.qinv, mq.q);
+            const u64 lift = rhi - hhi + mq.q + vt;                      // = sum_k (the reference's per-product lift) mod q
+            const u64 x = xq[(long)j * a.N + n];                         // lazy, < 2q
+            u64 z = mont_mul(lift + mq.q2 - x, a.t.downparam[j], mq.q, mq.ninv32);
+            long pos = (long)j * a.N + n;
+            bool flip = false;
+            if (a.galEl) {
+                const u64 raw = (u64)n * a.galEl;
+                pos = (long)j * a.N + (long)(raw & (u64)(a.N - 1));
+                flip = ((raw >> a.logN) & 1) != 0;
+            }
+            if (acc) {
+                const u64* add = ka->addend[vi];
+                if (add) z = csub(add[(long)j * a.N + n] + z, mq.q);
+                else if (flip) z = csub((mq.q - dst[pos]) + z, mq.q);       // the stored value is q - (sum so far), in (0, q]
+                else z = csub(dst[pos] + z, mq.q);
+            }
+            dst[pos] = flip ? mq.q - z : z;
+        }
+    }
+}
+void launch_moddown_merged(const ModDownMergedArgs& a_in, hipStream_t st) {
+    ModDownMergedArgs a = a_in;
+    int pos = 0; a.ngroups = 0;
+    bool used[EXT_MAX_ITEMS] = {};
+    for (int i = 0; i < a.nvi; ++i) {
+        if (used[i]) continue;
+        a.gstart[a.ngroups++] = (unsigned char)pos;
+        for (int k = i; k < a.nvi; ++k) if (!used[k] && a.dst[k] == a.dst[i]) { a.order[pos++] = (unsigned char)k; used[k] = true; }
+    }
+    a.gstart[a.ngroups] = (unsigned char)pos;
+    if (a.ngroups < 1) return;
+    const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    const int nj = a.level + 1;
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("MKHE_MDM_BY"); cap = (e && *e) ? atoi(e) : 4; }
+    int by = nj < cap ? nj : cap;
+    if (a.ngroups * by < 8) by = nj < 8 ? nj : 8;
+    const dim3 grid(bx, by, a.ngroups), blk(PW_THREADS);
+    switch (a.np) {
+        case 1: hipLaunchKernelGGL(moddown_merged_kernel<1>, grid, blk, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(moddown_merged_kernel<2>, grid, blk, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(moddown_merged_kernel<3>, grid, blk, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(moddown_merged_kernel<4>, grid, blk, 0, st, a); break;
+        default: break;        // (Context::ext_batch merges only for np <= 4)
+    }
+}
+
 // ------------------------------------------------------------------ tensor (step D)
 typedef const __attribute__((address_space(4))) TensorArgs* tensor_kargs;
 __global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
