@@ -29,7 +29,9 @@ struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
 // one external product of a batch: dst (+)= ModDown_P( sum_i bg[i] (.) ah[i] )
 struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const u64* ah2 = nullptr; const u64* bg2 = nullptr;
                  const u64* xkey = nullptr;   /* F1 only: this party's d_i, for the x by-product (ExtInnerArgs::xkey) */
-                 const u64* addend = nullptr; /* accumulate onto this polynomial instead of onto dst (Rotate: c_0 of the input) */ };
+                 const u64* addend = nullptr; /* accumulate onto this polynomial instead of onto dst (Rotate: c_0 of the input) */
+                 const u64* qadd = nullptr;   /* first product of a destination, not accumulating: an NTT-domain polynomial [L][N] (canonical, already
+                                                 times P) that joins the summed Q parts of the merged batch -- dst = that term + the products */ };
 
 typedef unsigned long long seq_t;
 // per handle: (uid of a context, that context's call counter at its latest use of the buffer); `exposed` once the raw device
@@ -127,7 +129,9 @@ class Context {
         unsigned char cnt[64] = {}, mem[64][4] = {}, accumulate[64] = {};
         u64* dst[64] = {};
         const u64* addend[64] = {};
+        const u64* qadd[64] = {};
     };
+    int ext_merge_members(int level) const;      // members a virtual item may have at this level (< 2: no merging)
     bool ext_plan_merge(int level, const ExtItem* items, int n, ExtMerge& mp) const;
     void ext_front(int level, const ExtItem* items, int n, u64* c1, const ExtMerge* mp = nullptr);   // inner products + lazy inverse NTT into c1 [n][mtot][N]
     void ext_back(int level, const ExtItem* items, int n, const u64* c1, u64 galEl = 0, const ExtMerge* mp = nullptr);   // ModDown of c1 into / onto the destinations [signed-permuted]
@@ -186,6 +190,7 @@ class Context {
     u64 *d_psi = nullptr, *d_psiinv = nullptr, *d_inv_aux = nullptr;
     int *d_map_qp = nullptr, *d_map_id = nullptr;
     u64 *d_md_qoverqiinvqi = nullptr, *d_md_qoverqimodp = nullptr, *d_md_vtimes = nullptr, *d_md_down = nullptr;
+    u64* d_pmodq = nullptr;                      // [nq] MForm(P mod q_j)
     u64* d_rescale = nullptr;
     u64 *d_dec_a = nullptr, *d_dec_b = nullptr, *d_dec_c = nullptr;     // Decomposer tables (alpha >= 2)
     // mkbfv tables: convQQMul in both directions, ModDown constants, mFormQMul, MForm(t) per limb of R
@@ -207,6 +212,7 @@ class Context {
     u64* rbuf_ = nullptr;  size_t rbuf_words_ = 0;          // BFV: operands over R, their NTTs, tensor output
     u64* c1b_ = nullptr;   size_t c1b_words_ = 0;           // batched ks.Pool[1]
     u64* tbuf_ = nullptr;  size_t tbuf_words_ = 0;          // t_i of step F
+    u64* tens_ = nullptr;  size_t tens_words_ = 0;          // tensor term kept in the NTT domain (times P) for the merged E / F2 batch
     // key generation scratch: uploaded samples, gadget constants (slot 0: mkrlwe gadget, 1: caller's), permuted secret
     int32_t* kg_small_ = nullptr; u64 *kg_g_ = nullptr, *kg_sk_ = nullptr;
     void wipe_samples(size_t count);
@@ -245,6 +251,7 @@ class Context {
         std::vector<const u64*> h0, h1;
         bool own0 = false, own1 = false;     // hoisted digits computed by the engine itself
         bool x_pending = false;              // x still running on the side stream (chain 2)
+        const u64* tens = nullptr;           // the tensor term stays in the NTT domain (times P) and joins the E / F2 batch
         bool head_done = false;              // mr_finish_head ran, mr_finish_tail still to come
         std::vector<const u64*> xkeys;       // non-empty: x is produced by the F1 kernel of mr_finish_head (into xfused) instead of by mr_xy
         u64* xfused = nullptr;

@@ -144,7 +144,7 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
 
     // ModUpPtoQ / ModDown constants, basisextenderparameters(P, Q) at full P
     // (mkrlwe/basis_extension.go:34-54, 83-153); all are canonical values -> closed forms.
-    std::vector<u64> t1(np), t2((size_t)nq * np), t3((size_t)nq * (np + 1)), t4(nq);
+    std::vector<u64> t1(np), t2((size_t)nq * np), t3((size_t)nq * (np + 1)), t4(nq), t5(nq);
     for (int i = 0; i < np; ++i) {
         const u64 pi = P[i]; u64 star = 1;
         for (int j = 0; j < np; ++j) if (j != i) star = mulmod(star, P[j] % pi, pi);
@@ -162,7 +162,9 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
         t3[(size_t)j * (np + 1)] = 0;
         for (int i = 1; i <= np; ++i) { u64 s = t3[(size_t)j * (np + 1) + i - 1] + v; t3[(size_t)j * (np + 1) + i] = s >= qj ? s - qj : s; }
         t4[j] = qj - to_mont(powmod(pm, qj - 2, qj), qj);
+        t5[j] = to_mont(pm, qj);
     }
+    d_pmodq = dev_upload(t5);
     d_md_qoverqiinvqi = dev_upload(t1); d_md_qoverqimodp = dev_upload(t2); d_md_vtimes = dev_upload(t3); d_md_down = dev_upload(t4);
 
     // RescaleParams[L-1][i] = MForm(q_L^-1 mod q_i)  (lattigo ring.go genNTTParams)
@@ -258,7 +260,7 @@ Context::~Context() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
-                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale,
+                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_,
                     (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
@@ -605,19 +607,27 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
 
 // items: independent external products  dst (+)= ModDown( sum_i bg[i] (.) ah[i] )
 // front half: inner products over the gadget digits + lazy inverse NTT of up to EXT_MAX_ITEMS items into c1 ([item][mtot][N])
-bool Context::ext_plan_merge(int level, const ExtItem* it, int n, ExtMerge& mp) const {
+int Context::ext_merge_members(int level) const {
     static const int on = getenv("MKHE_EXT_MERGE") ? atoi(getenv("MKHE_EXT_MERGE")) : 1;
-    if (!on || masked_ || n < 2 || n > 64 || np > 4) return false;
+    if (!on || masked_ || np > 4) return 0;
     static_assert(VI_MAX == 4 && MD_VI_MAX == 4 && EXT_MAX_ITEMS == 64 && NTT_MAX_ITEMS == 64, "ExtMerge is sized for these");
     // members per virtual item: the padded slot list of the inverse launch has to fit, and the merged multSum adds
     // members * np 128-bit products before its one Montgomery fold
     int M = VI_MAX;
     if (M > 16 / np) M = 16 / np;
     if (M > (NTT_MAX_SLOTS - (level + 1)) / np) M = (NTT_MAX_SLOTS - (level + 1)) / np;
-    if (M < 2) return false;
+    return M;
+}
+bool Context::ext_plan_merge(int level, const ExtItem* it, int n, ExtMerge& mp) const {
+    const int M = ext_merge_members(level);
+    bool any = false;
+    for (int i = 0; i < n; ++i) any = any || it[i].qadd != nullptr;
+    if (M < 2 || n > 64 || (n < 2 && !any)) {
+        if (any) throw Error("mkhe: internal: a batch with an NTT-domain summand has to be merged");
+        return false;
+    }
     mp = ExtMerge{};
     bool used[64] = {};
-    bool any = false;
     for (int i = 0; i < n; ++i) {
         if (used[i]) continue;
         int first = 1;
@@ -625,12 +635,17 @@ bool Context::ext_plan_merge(int level, const ExtItem* it, int n, ExtMerge& mp) 
             if (used[k] || it[k].dst != it[i].dst) continue;
             used[k] = true;
             // a later product of the group has to ADD onto the destination (anything else is not a sum: leave the batch alone)
-            if (k != i && (!it[k].accumulate || it[k].addend)) return false;
+            if (k != i && (!it[k].accumulate || it[k].addend || it[k].qadd)) {
+                if (any) throw Error("mkhe: internal: a batch with an NTT-domain summand has to be merged");
+                return false;
+            }
+            if (k == i && it[i].qadd && (it[i].accumulate || it[i].addend)) throw Error("mkhe: internal: qadd on an accumulating product");
             if (first || mp.cnt[mp.nvi - 1] == M) {
                 const int v = mp.nvi++;
                 mp.dst[v] = it[i].dst;
                 mp.accumulate[v] = first ? (it[i].accumulate ? 1 : 0) : 1;
                 mp.addend[v] = first ? it[i].addend : nullptr;
+                mp.qadd[v] = first ? it[i].qadd : nullptr;
                 first = 0;
             }
             const int v = mp.nvi - 1;
@@ -681,7 +696,10 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         for (int j = 0; j <= level; ++j) { b.mod[j] = j; b.pos[j] = j; }
         for (int k = 0; k < mp->members_max; ++k)
             for (int j = 0; j < np; ++j) { b.mod[level + 1 + k * np + j] = nq + j; b.pos[level + 1 + k * np + j] = level + 1 + j; }
-        for (int v = 0; v < mp->nvi; ++v) { b.vi_cnt[v] = mp->cnt[v]; for (int k = 0; k < VI_MAX; ++k) b.vi_mem[v] |= (unsigned)mp->mem[v][k] << (8 * k); }
+        for (int v = 0; v < mp->nvi; ++v) {
+            b.vi_cnt[v] = mp->cnt[v]; b.vi_extra[v] = mp->qadd[v];
+            for (int k = 0; k < VI_MAX; ++k) b.vi_mem[v] |= (unsigned)mp->mem[v][k] << (8 * k);
+        }
         b.vi_jobs = mp->nvi * (level + 1) + n * np;
         { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * b.vi_jobs); launch_ntt_inv(logN, b, s_); }
         return;
@@ -815,8 +833,16 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
                 ntt_fwd_launch(b, false);
             }
         }
+        // With at least one party in op0 every output slot receives an external product in steps E / F2.  The tensor term then
+        // stays in the NTT domain, times P, and joins the summed Q parts of that (merged) batch: ModDown's (x - lift) * P^-1
+        // returns it as itself, canonical like everything else -- no inverse NTT for step D.  MKHE_TENSOR_FOLD=0: A/B switch.
+        static const int fold_env = getenv("MKHE_TENSOR_FOLD") ? atoi(getenv("MKHE_TENSOR_FOLD")) : 1;
+        const bool fold = fold_env && n0 >= 1 && !masked_ && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
+        u64* tout = out.d;
+        if (fold) { tout = scratch(tens_, tens_words_, (size_t)(1 + out.n) * PO); p.tens = tout; }
         TensorArgs ta{};
-        ta.a0 = nb_; ta.b0 = nb_ + (size_t)(1 + n0) * PO; ta.out = out.d; ta.mods = d_mods;
+        ta.a0 = nb_; ta.b0 = nb_ + (size_t)(1 + n0) * PO; ta.out = tout; ta.mods = d_mods;
+        if (fold) ta.scale = d_pmodq;
         ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
         if (masked_) { ta.limbs = d_ownq; ta.nlimbs = nq_owned(level); }
         const long diag = (long)(mtot + 1) * N;
@@ -829,7 +855,8 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
             if (p.own1) { ta.b[o] = p.h1[a]; ta.b_ls[o] = diag; } else { ta.b[o] = nb_ + (size_t)(2 + n0 + a) * PO; ta.b_ls[o] = N; }
         }
         { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, s_); }
-        if (!masked_) ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
+        if (fold) { /* no inverse NTT: see above */ }
+        else if (!masked_) ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
         else {
             NttBatch ib{};
             ib.src = out.d; ib.dst = out.d; ib.mods = d_mods; ib.psi = d_psiinv; ib.aux = d_inv_aux; slots_q_owned(ib, L);
@@ -924,6 +951,18 @@ void Context::mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const S
     }
     for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
     if (p.x_pending) { join_side(2); p.x_pending = false; }
+    if (p.tens) {
+        // the tensor term of every output slot rides on the first product that goes there (see mr_prepare)
+        std::vector<const u64*> seen;
+        for (auto& it : items) {
+            if (std::find(seen.begin(), seen.end(), it.dst) != seen.end()) continue;
+            seen.push_back(it.dst);
+            it.accumulate = false; it.qadd = p.tens + (it.dst - out.d);
+        }
+        if ((int)seen.size() != 1 + out.n) throw Error("mkhe: internal: an output slot without an external product");
+        join_side(1);                  // the tensor chain, before the inverse NTT that sums it in
+        ext_batch(level, items);
+    } else
     ext_batch(level, items, 1);        // joins the tensor chain before the ModDown accumulates into out
     p.valid = false; p.head_done = false;
     MKHE_HIP(hipGetLastError());

@@ -79,6 +79,9 @@ struct NttBatch {
     // that limb over the members (formed at the load), written over the first member's limb; slots >= vi_q: P limb mod[s] of
     // member (s - vi_q) / vi_np, in place -- no job when the group has fewer members.  vi_jobs = jobs that exist.
     int vi, vi_q, vi_np, vi_jobs;
+    // vi_extra[g] != NULL: one more Q-only summand of group g, a plain polynomial [.. limbs ..][N] in the NTT domain, canonical
+    // (MulAndRelin's tensor term times P: it leaves ModDown as the tensor term itself, so that it needs no inverse NTT of its own)
+    const u64* vi_extra[NTT_MAX_ITEMS];
     int vi_cnt[NTT_MAX_ITEMS];
     unsigned int vi_mem[NTT_MAX_ITEMS];          // item index of member k in bits 8k .. 8k+7 (32-bit lists: see ModDownMergedArgs)
 };

@@ -215,8 +215,8 @@ __device__ __forceinline__ void phase(u64 (&x)[32], gcptr psi, int base, int pre
 // The small per-launch lists are read straight from the kernarg segment (scalar loads): indexing the
 // by-value struct dynamically would make the compiler copy all of it to scratch.
 typedef const __attribute__((address_space(4))) NttBatch* kargptr;
-// Returns the number of source limbs to add up (1 everywhere but in the Q slots of a merged inverse launch, NttBatch::vi;
-// 0 = this job does not exist: a P slot of a member the group does not have).
+// Returns the number of source limbs to add up (1 everywhere but in the Q slots of a merged inverse launch, NttBatch::vi: the
+// group's members and its Q-only extra summand; 0 = this job does not exist: a P slot of a member the group does not have).
 template <bool VI = false>
 __device__ __forceinline__ int job_pointers(const NttBatch& b, int job, gcptr& src, gptr& dst, int& m, int& outer) {
     kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -232,7 +232,7 @@ __device__ __forceinline__ int job_pointers(const NttBatch& b, int job, gcptr& s
         const long off = (long)((kb->vi_mem[outer] >> (exists ? 8 * k : 0)) & 255u) * b.src_outer + (long)m * b.src_inner;
         src = (gcptr)(b.src + off);
         dst = (gptr)(b.dst + off);
-        return !exists ? 0 : (s < b.vi_q ? cnt : 1);
+        return !exists ? 0 : (s < b.vi_q ? cnt + (kb->vi_extra[outer] != nullptr ? 1 : 0) : 1);
     }
     const int p = kb->pos[s];
     const u64* sbase = b.src; u64* dbase = b.dst;
@@ -245,9 +245,11 @@ __device__ __forceinline__ int job_pointers(const NttBatch& b, int job, gcptr& s
     dst = (gptr)(dbase + (long)outer * b.dst_outer + (long)(b.dst_mapped ? m : p) * b.dst_inner);
     return 1;
 }
-// word offset of member k of group g relative to the group's first member (merged inverse launches)
-__device__ __forceinline__ long vi_member_offset(const NttBatch& b, int g, int k) {
+// word offset of summand k of group g relative to `first`, limb m of the group's first member (merged inverse launches);
+// k = member count: the Q-only extra summand
+__device__ __forceinline__ long vi_member_offset(const NttBatch& b, int g, int k, int m, gcptr first) {
     kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+    if (k >= kb->vi_cnt[g]) return (long)(((u64)kb->vi_extra[g] - (u64)first) >> 3) + (long)m * b.src_inner;
     const unsigned mem = kb->vi_mem[g];
     return ((long)((mem >> (8 * k)) & 255u) - (long)(mem & 255u)) * b.src_outer;
 }
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
         // merged launch, Q slot: the canonical sum of this limb over the group's members
 #pragma unroll 1
         for (int k = 1; k < nsum; ++k) {
-            gcptr sk = src + vi_member_offset(b, outer, k);
+            gcptr sk = src + vi_member_offset(b, outer, k, m, src - half * G::N);
 #pragma unroll
             for (int r = 0; r < 32; ++r) x[r] = csub(x[r] + sk[posB(t, r)], q);
         }
@@ -531,7 +533,7 @@ __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr 
         for (int a = 0; a < NE; ++a) x[a] = FROM_G ? gsrc[p + a * GL] : lds[sm_pad(p + a * GL)];
         if constexpr (FROM_G && MODE == 2) {
 #pragma unroll
-            for (int k = 1; k < VI_MAX; ++k)
+            for (int k = 1; k <= VI_MAX; ++k)
                 if (k < nsum) {
 #pragma unroll
                     for (int a = 0; a < NE; ++a) x[a] = csub(x[a] + gsrc[sum_off[k] + p + a * GL], q);
@@ -591,9 +593,9 @@ __global__ void __launch_bounds__(SM_T) ntt_inv_lds_kernel(NttBatch b, int d) {
     gcptr src; gptr dst; int m, outer;
     const int nsum = job_pointers<true>(b, job >> d, src, dst, m, outer);
     if (nsum == 0) return;                                     // merged launch: no such member (the whole workgroup returns)
-    long sum_off[VI_MAX] = {};
+    long sum_off[VI_MAX + 1] = {};
 #pragma unroll
-    for (int k = 1; k < VI_MAX; ++k) if (k < nsum) sum_off[k] = vi_member_offset(b, outer, k);
+    for (int k = 1; k <= VI_MAX; ++k) if (k < nsum) sum_off[k] = vi_member_offset(b, outer, k, m, src);
     src += part * SM_M; dst += part * SM_M;
     const int root = (1 << d) + part;
     const Mod md = b.mods[m];
