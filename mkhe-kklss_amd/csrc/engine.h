@@ -29,6 +29,7 @@ struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
 // one external product of a batch: dst (+)= ModDown_P( sum_i bg[i] (.) ah[i] )
 struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const u64* ah2 = nullptr; const u64* bg2 = nullptr;
                  const u64* xkey = nullptr;   /* F1 only: this party's d_i, for the x by-product (ExtInnerArgs::xkey) */
+                 const u64* xkey2 = nullptr;  /* mkbfv F1: this party's d2_i (second gadget) */
                  const u64* addend = nullptr; /* accumulate onto this polynomial instead of onto dst (Rotate: c_0 of the input) */
                  const u64* qadd = nullptr;   /* first product of a destination, not accumulating: an NTT-domain polynomial [L][N] (canonical, already
                                                  times P) that joins the summed Q parts of the merged batch -- dst = that term + the products */ };
@@ -83,7 +84,7 @@ class Context {
     void bfv_external_product(const u64* polyr, const u64* bg1, const u64* bg2, u64* c);
     void bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
                         const Swk* const* rlk_d1, const Swk* const* rlk_d2, bool with_c0, bool mform, Ct& out,
-                        u64* x1, u64* x2, u64* y1, u64* y2);
+                        u64* x1, u64* x2, u64* y1, u64* y2, bool fuse_x = false);
     void bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u64* x2, const u64* y1, const u64* y2,
                        const Swk* const* rlk_v, const Swk& crs_u, Ct& out);
     void bfv_slots(const Ct& op0, const Ct& op1, const Ct& out, std::vector<int>& slot0, std::vector<int>& slot1) const;
@@ -121,6 +122,8 @@ class Context {
     // 2: back half only (ModDown of the c1 pool filled by the preceding stage-1 call with the same items)
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
     u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
+    u64* ext_xout2_ = nullptr;            // ... and the second gadget's x (mkbfv)
+    std::vector<const u64*> bfv_xk1_, bfv_xk2_;   // mkbfv single-device MulRelinNew: d1_i, d2_i for the fused x1, x2
     // External products that ModDown adds into ONE destination are merged (ModDown is linear in the Q part, see NttBatch::vi and
     // ModDownMergedArgs): virtual item v = up to VI_MAX items of the batch with the same destination; their Q limbs are summed in the
     // NTT domain at the load of ONE inverse NTT, their P limbs are transformed and lifted one by one.  MKHE_EXT_MERGE=0 switches it off.

@@ -664,15 +664,17 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     ExtInnerArgs ia{};
     bool two = false;
     bool xby = ext_xout_ != nullptr && n <= 4;
+    const bool xby2 = ext_xout2_ != nullptr;               // mkbfv: both gadgets carry their x
     for (int i = 0; i < n; ++i) {
         ia.ah[i] = it[i].ah; ia.bg[i] = it[i].bg;
         ia.ah2[i] = it[i].ah2; ia.bg2[i] = it[i].bg2;
-        ia.xkey[i] = it[i].xkey;
+        ia.xkey[i] = it[i].xkey; ia.xkey2[i] = it[i].xkey2;
         two = two || ia.ah2[i] != nullptr;
-        xby = xby && it[i].xkey && !it[i].ah2 && it[i].bg == it[0].bg;
+        xby = xby && it[i].xkey && it[i].bg == it[0].bg;
+        if (xby2) xby = xby && it[i].ah2 && it[i].xkey2 && it[i].bg2 == it[0].bg2; else xby = xby && !it[i].ah2;
     }
-    if (ext_xout_ && !xby) throw Error("mkhe: internal: x by-product requested for a batch that cannot carry it");
-    ia.xout = xby ? ext_xout_ : nullptr; ia.xmform = 1;
+    if ((ext_xout_ || ext_xout2_) && !xby) throw Error("mkhe: internal: x by-product requested for a batch that cannot carry it");
+    ia.xout = xby ? ext_xout_ : nullptr; ia.xout2 = xby && xby2 ? ext_xout2_ : nullptr; ia.xmform = 1;
     // keys that a single item reads (v_i, rotation keys) are streamed; x, y, u are shared by several items and stay cached
     for (int i = 0; i < n; ++i) {
         int uses = 0;
@@ -684,7 +686,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }
     ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
     ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
-    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((2.0 * nb * (two ? 2 : 1) + 1) * n + (xby ? nb * (n + 1.0) : 0.0))); launch_ext_inner(ia, s_); }
+    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((2.0 * nb * (two ? 2 : 1) + 1) * n + (xby ? nb * (n + 1.0) * (xby2 ? 2 : 1) : 0.0))); launch_ext_inner(ia, s_); }
     NttBatch b{};
     b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux;
     b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
@@ -1374,9 +1376,10 @@ void Context::bfv_slots(const Ct& op0, const Ct& op1, const Ct& out, std::vector
 
 void Context::bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
                              const Swk* const* rlk_d1, const Swk* const* rlk_d2, bool with_c0, bool mform, Ct& out,
-                             u64* x1, u64* x2, u64* y1, u64* y2) {
+                             u64* x1, u64* x2, u64* y1, u64* y2, bool fuse_x) {
     if (!is_bfv()) throw Error("mkhe: not a BFV context");
     const int level = nq - 1, L = nq, n0 = op0.n, n1 = op1.n;
+    bfv_xk1_.clear(); bfv_xk2_.clear();
     std::vector<int> slot0, slot1;
     bfv_slots(op0, op1, out, slot0, slot1);
     for (int a = 0; a < n0; ++a) if (!rlk_d1[a] || !rlk_d2[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
@@ -1426,7 +1429,13 @@ void Context::bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk
     // y1, y2 on the main stream (they feed step F, the long chain), x1, x2 on the side stream (step E joins the last
     // batch)   (keyswitch_hoisted.go:76-126)
     const int nslots = L + np;
-    for (int which = 3; which >= 0; --which) {
+    // single-device evaluation with 1..4 parties in op0: x1, x2 come out of step F1 as by-products of the digits it holds anyway
+    // (Context::mul_and_relin does the same for mkckks) -- two inner-product launches and one pass over h1(c0_i), h2(c0_i) less
+    if (fuse_x) {
+        if (!mform) throw Error("mkhe: internal: the fused x is produced in Montgomery form");
+        for (int a = 0; a < n0; ++a) { bfv_xk1_.push_back(rlk_d1[a]->d); bfv_xk2_.push_back(rlk_d2[a]->d); }
+    }
+    for (int which = 3; which >= (fuse_x ? 2 : 0); --which) {
         const int side = which >> 1, half = which & 1;
         const int n = side ? n1 : n0;
         InnerProductArgs ip{};
@@ -1463,10 +1472,16 @@ void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u
     // F1: t_i = <h(c0_i), (y1,y2)>
     u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PQ);
     std::vector<ExtItem> items;
+    const bool fused = !bfv_xk1_.empty();
     for (int a = 0; a < n0; ++a) {
-        ExtItem it{hoist_slot(0, a).d, y1, tbuf + (size_t)a * PQ, false}; it.ah2 = hoist_slot(3, a).d; it.bg2 = y2; items.push_back(it);
+        ExtItem it{hoist_slot(0, a).d, y1, tbuf + (size_t)a * PQ, false}; it.ah2 = hoist_slot(3, a).d; it.bg2 = y2;
+        if (fused) { it.xkey = bfv_xk1_[a]; it.xkey2 = bfv_xk2_[a]; }
+        items.push_back(it);
     }
-    ext_batch(level, items);
+    if (fused) { ext_xout_ = const_cast<u64*>(x1); ext_xout2_ = const_cast<u64*>(x2); }
+    try { ext_batch(level, items); } catch (...) { ext_xout_ = ext_xout2_ = nullptr; throw; }
+    ext_xout_ = ext_xout2_ = nullptr;
+    bfv_xk1_.clear(); bfv_xk2_.clear();
     // F2: ks.Decompose(t_i) ; out_0 += <h(t_i), v_i> ; out_i += <h(t_i), u>
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
@@ -1493,7 +1508,9 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
                             const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
                             const Swk& crs_u, Ct& out) {
     for (int a = 0; a < op0.n; ++a) if (!rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-    bfv_mr_partial(op0, op1, rlk_b1, rlk_b2, rlk_d1, rlk_d2, true, true, out, x_, x2_, y_, y2_);
+    static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
+    const bool fuse = fuse_env && op0.n >= 1 && op0.n <= 4 && !masked_;
+    bfv_mr_partial(op0, op1, rlk_b1, rlk_b2, rlk_d1, rlk_d2, true, true, out, x_, x2_, y_, y2_, fuse);
     bfv_mr_finish(op0, op1, x_, x2_, y_, y2_, rlk_v, crs_u, out);
 }
 

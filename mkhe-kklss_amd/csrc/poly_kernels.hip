@@ -180,6 +180,31 @@ __device__ __forceinline__ void ext_group_singles(const ExtInnerArgs& a, ext_kar
 #pragma unroll
         for (int m = 0; m < G; ++m) ah2[m] = ka->ah2[idx[m]] + off;
         const u64* bg2 = ka->bg2[leader] + off;
+        if (a.xout2) {
+            const u64* xk[G];
+#pragma unroll
+            for (int m = 0; m < G; ++m) xk[m] = ka->xkey2[idx[m]] + off;
+            u64* xo = a.xout2 + off;
+#pragma unroll 1
+            for (int i = 0; i < a.nb; ++i) {
+                const u64x2 g = once ? ld_stream(bg2 + i * ds) : ld_cached(bg2 + i * ds);
+                u64x2 h[G], k[G];
+#pragma unroll
+                for (int m = 0; m < G; ++m) { h[m] = ld_stream(ah2[m] + i * ds); k[m] = ld_stream(xk[m] + i * ds); }
+                u64 x0 = 0, x1 = 0;
+#pragma unroll
+                for (int m = 0; m < G; ++m) {
+                    acc[m][0] = csub(acc[m][0] + mont_mul_lazy(g.x, h[m].x, q, ninv), q2);
+                    acc[m][1] = csub(acc[m][1] + mont_mul_lazy(g.y, h[m].y, q, ninv), q2);
+                    x0 = csub(x0 + mont_mul_lazy(k[m].x, h[m].x, q, ninv), q2);
+                    x1 = csub(x1 + mont_mul_lazy(k[m].y, h[m].y, q, ninv), q2);
+                }
+                x0 = csub(x0, q); x1 = csub(x1, q);
+                if (a.xmform) { x0 = mont_mul(x0, md.r2, q, ninv); x1 = mont_mul(x1, md.r2, q, ninv); }
+                u64x2 r; r.x = x0; r.y = x1;
+                *(u64x2*)(xo + i * ds) = r;
+            }
+        } else {
 #pragma unroll 2
         for (int i = 0; i < a.nb; ++i) {
             const u64x2 g = once ? ld_stream(bg2 + i * ds) : ld_cached(bg2 + i * ds);
@@ -191,6 +216,7 @@ __device__ __forceinline__ void ext_group_singles(const ExtInnerArgs& a, ext_kar
                 acc[m][0] = csub(acc[m][0] + mont_mul_lazy(g.x, h[m].x, q, ninv), q2);
                 acc[m][1] = csub(acc[m][1] + mont_mul_lazy(g.y, h[m].y, q, ninv), q2);
             }
+        }
         }
     }
 #pragma unroll
