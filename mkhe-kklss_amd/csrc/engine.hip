@@ -94,6 +94,9 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     // (mont_mul_lazy / mont_mul_sd) takes operands below 2^62.  2^62 / 31 = 2^57.05: the 57-bit head prime of the
     // reference's PN14QP433 chain (2^57 + 0x2b0001) is still in; the 59/60-bit primes of PN15QP880 are not.
     for (int i = 0; i < mall; ++i) small_q_.push_back(moduli[i] < (1ull << 62) / 31 ? 1 : 0);
+    // the H16 kernel (ntt16_kernels.hip) grows its never-reduced values by up to 1.03q per stage in the stages with the one-round product:
+    // < 4q + 9 * 1.03q + 6 * 0.53q < 17q, internal digits leave as x + 20q < 37q -- small-class moduli have to satisfy 40q < 2^62 there
+    for (int i = 0; i < mall; ++i) if (small_q_[i] && moduli[i] >= (1ull << 62) / 40) h16_gap_ = true;
     MKHE_HIP(hipSetDevice(device));
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
@@ -133,6 +136,28 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     for (auto& v : psiinv) v = sd_split(v);
     for (auto& v : aux) v = sd_split(v);
     d_mods = dev_upload(mods); d_psi = dev_upload(psi); d_psiinv = dev_upload(psiinv); d_inv_aux = dev_upload(aux);
+    if (logN >= 15 && !h16_gap_) {
+        // one-round product of the H16 kernel: a * w = a0 * u + a1 * u' with u = w 2^31, u' = w 2^63 (mod q, balanced), then ONE Montgomery
+        // round of radix 2^31.  psi holds w * 2^64 in signed-split form at this point: w * 2^31 = psi * 2^-33.
+        std::vector<u64> p31(2 * (size_t)mall * N);
+        for (int i = 0; i < mall; ++i) {
+            const u64 q = moduli[i];
+            const u64 c33 = powmod(powmod(2, 33, q), q - 2, q), c32 = powmod(2, 32, q);
+            for (size_t j = 0; j < (size_t)N; ++j) {
+                const u64 ps = psi[(size_t)i * N + j];
+                const u64 wR = ps - ((u64)((u32)ps >> 31) << 32);                  // undo sd_split
+                const u64 u = mulmod(wR, c33, q), v = mulmod(u, c32, q);
+                auto pack = [q](u64 x) {
+                    const i64 b = x > q / 2 ? (i64)x - (i64)q : (i64)x;           // balanced representative
+                    const i64 d0 = (i64)((u64)b << 33) >> 33;                      // low 31 bits, sign-extended
+                    const i64 d1 = (b - d0) >> 31;
+                    return (u64)(u32)(i32)d0 | ((u64)(u32)(i32)d1 << 32);
+                };
+                p31[2 * ((size_t)i * N + j)] = pack(u); p31[2 * ((size_t)i * N + j) + 1] = pack(v);
+            }
+        }
+        d_psi31 = dev_upload(p31);
+    }
 
     std::vector<int> map((size_t)nq * mtot, 0), ident(mtot);
     for (int l = 0; l < nq; ++l) {
@@ -260,7 +285,7 @@ Context::~Context() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
-                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_,
+                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31,
                     (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
@@ -459,7 +484,9 @@ void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
 }
 
 // forward NTT launch: one kernel per modulus class, each with its own timing record
-void Context::ntt_fwd_launch(const NttBatch& b, bool decompose) {
+void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
+    NttBatch b = b_in;
+    b.psi31 = d_psi31; b.no_h16 = d_psi31 ? 0 : 1;
     if (ntt16_ok(logN, b)) {
         ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;

@@ -69,6 +69,13 @@ __device__ __forceinline__ void ld_wait16(u64 (&a)[8], u64 (&b)[8]) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
                                          "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
 }
+// stage-0 source loads: SG pairs in flight per thread (4 instead of 8 changes neither the spills the compiler places around stage 0
+// nor the time: 224 vs 222 us per average launch)
+constexpr int SG = 8;
+__device__ __forceinline__ void ld_wait(u64 (&a)[4], u64 (&b)[4]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+__device__ __forceinline__ void ld_wait(u64 (&a)[8], u64 (&b)[8]) { ld_wait16(a, b); }
 __device__ __forceinline__ void st_issue(gptr base, unsigned byte_off, u64 v) {
     asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
 }
@@ -83,7 +90,7 @@ __device__ __forceinline__ void ld2(u64* out, gcptr2 base, unsigned idx) {
 }
 
 // per-job constants, wave-uniform (SGPRs)
-struct MC { i32 q0, q1; u32 ninv; u64 q; float finv; };
+struct MC { i32 q0, q1; u32 ninv; u64 q; float finv; i32 p0, p1; /* radix-2^31 digits of q, balanced (mm31) */ };
 
 // ------------------------------------------------------------------ signed-digit Montgomery product (modarith.h mont_mul_sd)
 // a * w * 2^-64 mod q as a signed representative, |r| <= q/2 + |a| w / 2^64 + 1: 12 multiplier-class + 2 plain instructions.
@@ -138,6 +145,49 @@ template <bool SW> __device__ __forceinline__ i64 mm(i64 a, u64 ws, const MC& c)
     return acc;
 }
 
+// ------------------------------------------------------------------ one-round product (round 2)
+// The twiddle enters as TWO pre-reduced constants, u = w 2^31 mod q and v = w 2^63 mod q (balanced, radix-2^31 digits u = u1 2^31 + u0,
+// |u0| <= 2^30: NttBatch::psi31).  With a = a1 2^32 + a0 (balanced digits, as in mm):  a w 2^31 = a0 u + a1 v  (mod q) is a 92-bit
+// number, and ONE Montgomery round of radix 2^31 brings it back to 61 bits where the 128-bit product a * (w 2^64) of mm needs two:
+//   C = a0 u0 + a1 v0 ; m = balanced31(lo(C) * -q^-1) ; T = ((C + m p0) >> 31) + a0 u1 + a1 v1 + m p1  =  (a0 u + a1 v + m q) / 2^31
+// = a w mod q exactly, |T| <= q + |a| q / 2^64 (|a0 u| / 2^31 <= q/2, |m q| / 2^31 <= q/2).  Every column sum stays below 2^63 for
+// |a| < 2^62.9: 2^61 + 2^61 + 2^60 in column 0.  8 multiplier-class + 1 plain instruction against 12: the bare butterfly goes from
+// 73 to 61 cycles per wave and the clock from 1.98 to 2.10 GHz (tools/ubench/bfly31_rate.hip: 36.8 -> 28.8 ns).  The price: twice
+// the twiddle words, and values that grow by q (not q/2) per stage -- see the range notes in limb().
+template <bool SW> __device__ __forceinline__ i64 mm31(i64 a, u64 us, u64 vs, const MC& c) {
+    const u32 al = lo32((u64)a);
+    const i32 a0 = (i32)al;
+    const i32 a1 = (i32)(hi32((u64)a) + (al >> 31));
+    i32 u0 = (i32)lo32(us), u1 = (i32)hi32(us), v0 = (i32)lo32(vs), v1 = (i32)hi32(vs);
+    if constexpr (SW) asm("" : "+s"(u0), "+s"(u1), "+s"(v0), "+s"(v1)); else asm("" : "+v"(u0), "+v"(u1), "+v"(v0), "+v"(v1));
+    i64 acc = (i64)a0 * u0;                                  // v_mad_i64_i32 acc, a0, u0, 0
+    i32 m; u64 k;
+    if constexpr (SW) {
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=&s"(k) : "v"(a1), "s"(v0));          // + a1 * v0
+        asm("v_mul_lo_u32 %1, %3, %7\n\t"                  // lo(C) * -q^-1
+            "v_bfe_i32 %1, %1, 0, 31\n\t"                  // balanced 31-bit digit
+            "v_mad_i64_i32 %0, %2, %1, %8, %0\n\t"         // + m * p0: low 31 bits zero
+            "v_ashrrev_i64 %0, 31, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %6, %0\n\t"         // + a0 * u1
+            "v_mad_i64_i32 %0, %2, %5, %10, %0\n\t"        // + a1 * v1
+            "v_mad_i64_i32 %0, %2, %1, %9, %0"               // + m * p1
+            : "+v"(acc), "=&v"(m), "=&s"(k)
+            : "v"(lo32((u64)acc)), "v"(a0), "v"(a1), "s"(u1), "s"(c.ninv), "s"(c.p0), "s"(c.p1), "s"(v1));
+    } else {
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=&s"(k) : "v"(a1), "v"(v0));
+        asm("v_mul_lo_u32 %1, %3, %7\n\t"
+            "v_bfe_i32 %1, %1, 0, 31\n\t"
+            "v_mad_i64_i32 %0, %2, %1, %8, %0\n\t"
+            "v_ashrrev_i64 %0, 31, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %6, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %5, %10, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %1, %9, %0"
+            : "+v"(acc), "=&v"(m), "=&s"(k)
+            : "v"(lo32((u64)acc)), "v"(a0), "v"(a1), "v"(u1), "s"(c.ninv), "s"(c.p0), "s"(c.p1), "v"(v1));
+    }
+    return acc;
+}
+
 // Cheap partial reduction: x -> x - round(x / q) * q, |result| <= q/2 + q * 2^-19, for any |x| < 2^62.9.  The quotient is estimated
 // from the high word in float32 (3 plain VALU instructions: convert, fma with the 1.5 * 2^23 rounding constant, subtract) and is at
 // most a few dozen, so the product is one v_mad_i64_i32 for the low digit of q plus a 32-bit multiply-add for the high digit:
@@ -162,6 +212,16 @@ template <bool SW> __device__ __forceinline__ void bfly(u64& U, u64& V, u64 ws, 
     U = (u64)(u + T);
     V = (u64)(u - T);
 }
+// the same butterfly on the one-round product; tw[0] = u, tw[1] = v
+template <bool SW> __device__ __forceinline__ void bfly31(u64& U, u64& V, const u64* tw, const MC& c) {
+#ifdef MKHE_H16_X_NOBFLY
+    if ((MKHE_H16_X_NOBFLY >> (SW ? 0 : 1)) & 1) { U += tw[0] + tw[1]; return; }      // timing experiment only
+#endif
+    const i64 T = mm31<SW>((i64)V, tw[0], tw[1], c);
+    const i64 u = (i64)U;
+    U = (u64)(u + T);
+    V = (u64)(u - T);
+}
 __device__ __forceinline__ void reduce_all(u64 (&x)[16], const MC& c, bool big) {
     if (big) {
 #pragma unroll
@@ -175,6 +235,18 @@ template <bool SW, int B> __device__ __forceinline__ void stage(u64 (&x)[16], co
     for (int g = 0; g < 8; ++g) {
         const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
         bfly<SW>(x[i0], x[i0 | (1 << B)], tw[g >> B], c);
+#ifndef MKHE_H16_NO_SCHEDBAR
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
+// the same stage with scalar twiddle PAIRS: butterflies G0 .. G0 + NG - 1, tw[2 i], tw[2 i + 1] = (u, v) of twiddle (G0 >> B) + i
+template <int B, int G0 = 0, int NG = 8> __device__ __forceinline__ void stage31(u64 (&x)[16], const u64* tw, const MC& c) {
+#pragma unroll
+    for (int g = G0; g < G0 + NG; ++g) {
+        const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+        bfly31<true>(x[i0], x[i0 | (1 << B)], tw + 2 * ((g >> B) - (G0 >> B)), c);
 #ifndef MKHE_H16_NO_SCHEDBAR
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -253,7 +325,7 @@ template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds
 
 // ------------------------------------------------------------------ one limb
 // what one limb needs, all wave-uniform
-struct Job { gcptr src; gptr dst; const u64* psi; smodptr mp; bool red; bool skip_norm; int root; u64* trace; };
+struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; smodptr mp; bool red; bool skip_norm; int root; u64* trace; };
 // diagnostic build (make trace): shader-clock stamps per wave and pass, 32 words per (job, wave): [16 * pass + k], see tools/ntt16_trace.py
 // (every lane stores the same word: a lane-0 branch here makes the compiler lose the uniformity of the scalar twiddle loads)
 #ifdef MKHE_PHASE_TRACE
@@ -276,8 +348,11 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
     c.q = mp->q; c.ninv = mp->ninv32;
     c.q0 = (i32)lo32(qs); c.q1 = (i32)hi32(qs);
     c.finv = __builtin_bit_cast(float, mp->finv);
-    asm("" : "+s"(c.q0), "+s"(c.q1), "+s"(c.ninv));        // opaque wave-uniform 32-bit values (see modarith.h mont_mul_sd)
+    c.p0 = (i32)((u32)c.q << 1) >> 1;                       // q = p1 2^31 + p0, |p0| <= 2^30
+    c.p1 = (i32)((c.q - (u64)(i64)c.p0) >> 31);
+    asm("" : "+s"(c.q0), "+s"(c.q1), "+s"(c.ninv), "+s"(c.p0), "+s"(c.p1));        // opaque wave-uniform 32-bit values (see modarith.h mont_mul_sd)
     scptr psi_s = (scptr)jb.psi;
+    scptr p31 = (scptr)jb.psi31;                            // (u, v) of twiddle i at words 2i, 2i + 1
     gcptr psi_v = (gcptr)jb.psi;
     const gcptr src = jb.src; const gptr dst = jb.dst;
     const bool red = DEC && jb.red;
@@ -286,27 +361,42 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
     for (int hh = 0; hh < 2; ++hh) {
         const int h = __builtin_amdgcn_readfirstlane(hh);
         H16_STAMP(0);
-        if (h == 0) {
-            // ---- stage 0: cross-half butterflies; upper outputs parked in dst[N/2 + j]
-            const u64 w1 = psi_s[tm];
+        // ---- stage 0: the cross-half butterflies.  Out of place (every Decompose launch: the source is a ciphertext limb) BOTH passes
+        // load x[j], x[j + N/2] and keep their own output of the butterfly -- the second pass repeats 16 products per thread (1/15 of
+        // the butterfly work) and re-reads the source, which 15 other workgroups read as well (L2 / Infinity Cache), instead of
+        // parking the upper outputs in the destination limb in pass 0 and reloading them: 128 KiB written + 128 KiB read per limb,
+        // a third of what this kernel moved through HBM, and memory is what bounds it once the butterflies are cheap
+        // (tools/ubench + the MKHE_H16_X_* ablations: 245 us of a 367 us launch remain with every butterfly removed).
+        // In place (src == dst) pass 0's results overwrite the source: the upper outputs are parked as before.
+        const bool park = (const void*)src == (const void*)dst;
+        if (h == 0 || !park) {
+            u64 w1[2] = {p31[2 * tm], p31[2 * tm + 1]};
+            if (h != 0) {
+                // second pass: x - w y = x + (-w) y -- both digits of both constants negated (scalar), the butterfly keeps its `+` output
+                w1[0] = ((u64)(u32)(0 - (i32)hi32(w1[0])) << 32) | (u32)(0 - (i32)lo32(w1[0]));
+                w1[1] = ((u64)(u32)(0 - (i32)hi32(w1[1])) << 32) | (u32)(0 - (i32)lo32(w1[1]));
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // (keeps the store queue of pass 0 from growing under the loads)
+            }
             const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
 #pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += 8) {
-                u64 U[8], V[8];
+            for (int r0 = 0; r0 < 16; r0 += SG) {
+                u64 U[SG], V[SG];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { U[r] = ld_issue(sbk(src, (r0 + r) * NT), tb); V[r] = ld_issue(sbk(src, HH + (r0 + r) * NT), tb); }
-                ld_wait16(U, V);
+                for (int r = 0; r < SG; ++r) { U[r] = ld_issue(sbk(src, (r0 + r) * NT), tb); V[r] = ld_issue(sbk(src, HH + (r0 + r) * NT), tb); }
+                ld_wait(U, V);
                 // digits of a foreign modulus (Decompose) may be far above q: bring them to (-q, q) first.  MODE 0 (q up to 2^60)
                 // has no headroom for five stages on raw inputs and always starts from reduced values.
                 if (big || red) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); __builtin_amdgcn_sched_barrier(0); }
+                    for (int r = 0; r < SG; ++r) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); __builtin_amdgcn_sched_barrier(0); }
                 }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    bfly<true>(U[r], V[r], w1, c);
-                    x[r0 + r] = U[r];
-                    st_issue(sbk(dst, HH + (r0 + r) * NT), tb, V[r]);
+                for (int r = 0; r < SG; ++r) {
+                    const i64 T = mm31<true>((i64)V[r], w1[0], w1[1], c);
+                    x[r0 + r] = (u64)((i64)U[r] + T);
+#ifndef MKHE_H16_X_NOPARK      // timing experiment only (wrong results): no parking store / reload of the upper half
+                    if (park) st_issue(sbk(dst, HH + (r0 + r) * NT), tb, (u64)((i64)U[r] - T));
+#endif
                     __builtin_amdgcn_sched_barrier(0);       // one butterfly at a time: interleaved, their temporaries do not fit beside 16 loads in flight
                 }
                 asm volatile("" ::: "memory");
@@ -318,46 +408,61 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
             const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
 #pragma unroll
             for (int r = 0; r < 16; ++r)
+#ifndef MKHE_H16_X_NOPARK
                 x[r] = __hip_atomic_load(at(sbk(dst, HH + r * NT), tb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+                x[r] = x[r] * 3 + tb;
+#endif
         }
         H16_STAMP(1);                            // loads landed, stage 0 done
         // ---- phase A: bits 13..10, twiddles psi[2^k + (h << (k-1)) + i], k = 1..4
         {
             // (the 8 twiddles of the last stage are fetched after the first two stages: 30 twiddle SGPRs at once do not fit the
             // 80-SGPR budget of 8 waves per SIMD beside the job state, and every spilled SGPR costs VALU lane moves)
-            u64 tw[7], tl[8];
-            tw[0] = psi_s[2 * tm + h];
+            // (the twiddle pairs of a stage are fetched one stage ahead, the eight of the last stage in two halves: all 30 pairs at once
+            // = 120 SGPRs do not fit the SGPR budget of 8 waves per SIMD beside the job state, and every spilled SGPR costs VALU lane moves)
+            u64 tw[6], tm4[8], ta[8], tb[8];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[4 * tm + 2 * h + i];
+            for (int i = 0; i < 2; ++i) tw[i] = p31[2 * (2 * tm + h) + i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[8 * tm + 4 * h + i];
-            stage<true, 3>(x, tw, c);
-            stage<true, 2>(x, tw + 1, c);
+            for (int i = 0; i < 4; ++i) tw[2 + i] = p31[2 * (4 * tm + 2 * h) + i];
+            stage31<3>(x, tw, c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tl[i] = psi_s[16 * tm + 8 * h + i];
-            stage<true, 1>(x, tw + 3, c);
-            stage<true, 0>(x, tl, c);
+            for (int i = 0; i < 8; ++i) tm4[i] = p31[2 * (8 * tm + 4 * h) + i];
+            stage31<2>(x, tw + 2, c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ta[i] = p31[2 * (16 * tm + 8 * h) + i];
+            stage31<1>(x, tm4, c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tb[i] = p31[2 * (16 * tm + 8 * h + 4) + i];
+            stage31<0, 0, 4>(x, ta, c);
+            stage31<0, 4, 4>(x, tb, c);
         }
-        reduce_all(x, c, big);                  // MODE 0: |x| < 3.6q after stage 0 + phase A -> (-q, q)
+        reduce_all(x, c, big);                  // MODE 0: |x| < 6.4q < 2^62.7 after stage 0 + phase A (five stages of up to q + |x|/16 each) -> (-q, q)
         H16_STAMP(2);
         exchange<X_AB>(x, lds, wv);
         H16_STAMP(3);
         // ---- phase B: bits 9..6, twiddles psi[2^k + ((16h + wave) << (k-5)) + i], k = 5..8
         {
             const int cb = 16 * h + wv;
-            u64 tw[7], tl[8];
-            tw[0] = psi_s[32 * tm + cb];
+            u64 tw[6], tm4[8], ta[8], tb[8];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) tw[1 + i] = psi_s[64 * tm + 2 * cb + i];
+            for (int i = 0; i < 2; ++i) tw[i] = p31[2 * (32 * tm + cb) + i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tw[3 + i] = psi_s[128 * tm + 4 * cb + i];
-            stage<true, 3>(x, tw, c);
-            stage<true, 2>(x, tw + 1, c);
+            for (int i = 0; i < 4; ++i) tw[2 + i] = p31[2 * (64 * tm + 2 * cb) + i];
+            stage31<3>(x, tw, c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tl[i] = psi_s[256 * tm + 8 * cb + i];
-            stage<true, 1>(x, tw + 3, c);
-            stage<true, 0>(x, tl, c);
+            for (int i = 0; i < 8; ++i) tm4[i] = p31[2 * (128 * tm + 4 * cb) + i];
+            stage31<2>(x, tw + 2, c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ta[i] = p31[2 * (256 * tm + 8 * cb) + i];
+            stage31<1>(x, tm4, c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tb[i] = p31[2 * (256 * tm + 8 * cb + 4) + i];
+            stage31<0, 0, 4>(x, ta, c);
+            stage31<0, 4, 4>(x, tb, c);
         }
+        reduce_all(x, c, big);                  // MODE 0: |x| < 5.1q after the four one-round stages of phase B -> (-q, q): phase C may add 2.7q
         // Phases C and D: per-lane twiddles, fetched in 16-byte groups a few butterflies ahead of their use (at most three groups =
         // 12 VGPRs live; issuing all 15 + 12 at once would not fit beside the 32 data registers).  The first groups of a phase are
         // requested before the re-distribution that precedes it.
@@ -391,7 +496,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                 else bfly1<0>(x, gi, g[4 + (gi >> 1)][gi & 1], c);
             }
         }
-        reduce_all(x, c, big);                  // MODE 0: |x| < 5.9q < 2^62.6 after phases B and C (8 stages) -> (-q, q)
+        reduce_all(x, c, big);                  // MODE 0: |x| < 3.3q after phase C (four two-round stages) -> (-q, q)
         // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane
         {
             const int ld = lane_id();
@@ -425,7 +530,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                 x[r] = (u64)(y + ((y >> 63) & (i64)c.q));                           // canonical (lattigo: final BRedAdd)
             }
         } else {
-            const i64 bias = (i64)(c.q << 4);                                        // MODE 1, engine-internal digits: same residue, positive: (2q, 30q)
+            const i64 bias = (i64)((c.q << 4) + (c.q << 2));                         // MODE 1, engine-internal digits: same residue, positive: |x| < 17q -> (3q, 37q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = (u64)((i64)x[r] + bias);
         }
@@ -482,6 +587,7 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         jb.src = (gcptr)(sbase_ + (long)outer * kb->src_outer + (long)(kb->src_mapped ? m : p) * kb->src_inner);
         jb.dst = (gptr)(dbase_ + (long)outer * kb->dst_outer + (long)(kb->dst_mapped ? m : p) * kb->dst_inner);
         jb.psi = kb->psi + (long)m * (SPLIT ? 2 * NN : NN);
+        jb.psi31 = kb->psi31 + 2 * (long)m * (SPLIT ? 2 * NN : NN);
         jb.root = 1;
         if constexpr (SPLIT) { const int half = job2 & 1; jb.src += half * NN; jb.dst += half * NN; jb.root = 2 + half; }
         jb.mp = (smodptr)kb->mods + m;
@@ -552,7 +658,7 @@ int resident16(size_t lds) {
 // sub-transforms of a split N = 2^16 launch (one modulus class per launch: `small` = 31 q < 2^62 for every slot)
 bool ntt16_split_ok(const NttBatch& c) {
     static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128);
-    return on && c.split && !c.reduce_in && c.nslots <= 64 && 2 * c.nslots * c.nouter >= minl;
+    return on && !c.no_h16 && c.psi31 && c.split && !c.reduce_in && c.nslots <= 64 && 2 * c.nslots * c.nouter >= minl;
 }
 void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
     using namespace h16;
@@ -566,7 +672,7 @@ void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
 }
 bool ntt16_ok(int logN, const NttBatch& b) {
     static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128);
-    return on && logN == 15 && !b.split && !b.prestaged && b.nslots <= 64 && b.nslots * b.nouter >= minl;
+    return on && !b.no_h16 && b.psi31 && logN == 15 && !b.split && !b.prestaged && b.nslots <= 64 && b.nslots * b.nouter >= minl;
 }
 void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
     using namespace h16;
