@@ -192,7 +192,7 @@ class Context {
     Mod* d_mods = nullptr;
     u64 *d_psi = nullptr, *d_psiinv = nullptr, *d_inv_aux = nullptr;
     u64* d_psi31 = nullptr;                      // logN >= 15: twiddle pairs of the H16 kernel's one-round product (NttBatch::psi31)
-    bool h16_gap_ = false;                       // some modulus has 31q < 2^62 <= 40q: H16's signed ranges do not cover it
+    bool h16_gap_ = false;                       // some modulus has 31q < 2^62 <= 48q: H16's signed ranges do not cover it
     int *d_map_qp = nullptr, *d_map_id = nullptr;
     u64 *d_md_qoverqiinvqi = nullptr, *d_md_qoverqimodp = nullptr, *d_md_vtimes = nullptr, *d_md_down = nullptr;
     u64* d_pmodq = nullptr;                      // [nq] MForm(P mod q_j)

@@ -94,9 +94,9 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     // (mont_mul_lazy / mont_mul_sd) takes operands below 2^62.  2^62 / 31 = 2^57.05: the 57-bit head prime of the
     // reference's PN14QP433 chain (2^57 + 0x2b0001) is still in; the 59/60-bit primes of PN15QP880 are not.
     for (int i = 0; i < mall; ++i) small_q_.push_back(moduli[i] < (1ull << 62) / 31 ? 1 : 0);
-    // the H16 kernel (ntt16_kernels.hip) grows its never-reduced values by up to 1.03q per stage in the stages with the one-round product:
-    // < 4q + 9 * 1.03q + 6 * 0.53q < 17q, internal digits leave as x + 20q < 37q -- small-class moduli have to satisfy 40q < 2^62 there
-    for (int i = 0; i < mall; ++i) if (small_q_[i] && moduli[i] >= (1ull << 62) / 40) h16_gap_ = true;
+    // the H16 kernel (ntt16_kernels.hip) grows its never-reduced values by up to 1.03q per stage (one-round product): < 4q + 15 * 1.03q
+    // < 20q, internal digits leave as x + 24q < 44q -- small-class moduli have to satisfy 48q < 2^62 there
+    for (int i = 0; i < mall; ++i) if (small_q_[i] && moduli[i] >= (1ull << 62) / 48) h16_gap_ = true;
     MKHE_HIP(hipSetDevice(device));
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));

@@ -262,6 +262,19 @@ template <int B> __device__ __forceinline__ void bfly1(u64 (&x)[16], int g, u64 
 #endif
 }
 
+// the same on the one-round product: tw = the (u, v) pair of this lane's twiddle; RING pairs (4 VGPRs each) are live in phases C / D
+#ifndef MKHE_H16_RING
+#define MKHE_H16_RING 3
+#endif
+constexpr int RING = MKHE_H16_RING;
+template <int B> __device__ __forceinline__ void bfly1_31(u64 (&x)[16], int g, const u64* tw, const MC& c) {
+    const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+    bfly31<false>(x[i0], x[i0 | (1 << B)], tw, c);
+#ifndef MKHE_H16_NO_SCHEDBAR
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // ------------------------------------------------------------------ LDS re-distributions
 // word offsets of register r in the four exchanges (write side, read side); bases are per thread (below)
 enum { X_AB = 0, X_BC = 1, X_CD = 2, X_DE = 3 };
@@ -400,7 +413,27 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                     __builtin_amdgcn_sched_barrier(0);       // one butterfly at a time: interleaved, their temporaries do not fit beside 16 loads in flight
                 }
                 asm volatile("" ::: "memory");
+#ifndef MKHE_H16_NO_STASH
+                // The first group's results wait in the wave's own LDS region (idle until the A -> B exchange) while the second group's
+                // 16 loads are in flight: left in registers, the allocator sent six of them to scratch and back -- 140 KB of scratch
+                // writes per limb through HBM (the scratch of 512 resident workgroups is 30 MB, more than the L2s hold).
+                if (r0 == 0) {
+                    typedef __attribute__((address_space(3))) u64* lptr64;
+                    lptr64 st = (lptr64)((__attribute__((address_space(3))) u32*)lds + wv * WSTR) + lane_id();
+#pragma unroll
+                    for (int r = 0; r < SG; ++r) { st[r * 64] = x[r]; }
+                    asm volatile("" ::: "memory");
+                }
+#endif
             }
+#ifndef MKHE_H16_NO_STASH
+            {
+                typedef volatile __attribute__((address_space(3))) u64* lptr64;
+                lptr64 st = (lptr64)((__attribute__((address_space(3))) u32*)lds + wv * WSTR) + lane_id();
+#pragma unroll
+                for (int r = 0; r < SG; ++r) x[r] = st[r * 64];
+            }
+#endif
         } else {
             // the parked half: written by this same thread in pass 0; all but the 16 youngest memory operations (the final
             // stores of pass 0) are complete before the reload is issued
@@ -467,36 +500,66 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
         // 12 VGPRs live; issuing all 15 + 12 at once would not fit beside the 32 data registers).  The first groups of a phase are
         // requested before the re-distribution that precedes it.
         // ---- phase C: bits 5..2, twiddles psi[2^k + (cc << (k-9)) + i], k = 9..12, cc = (16h + wave) * 16 + bits 9..6 (lane >> 2)
+        // Twiddle t of the phase (t = 0: k = 9; 1, 2: k = 10; 3..6: k = 11; 7..14: k = 12) is one 16-byte load of its (u, v) pair; the
+        // butterflies use them in that order (8, 4, 4, 2, 2, 2, 2, 1 x 8 times), a ring of four pairs (16 VGPRs) keeps the next three in flight.
         {
             const int lc = lane_id();
             const unsigned cu = (unsigned)((16 * h + wv) * 16 + (lc >> 2));
             __builtin_assume(cu < 512);
-            u64 g[8][2];
-            auto loadg = [&](int k) {
-                if (k == 0) g[0][0] = *(gcptr)((const __attribute__((address_space(1))) char*)sbk(psi_v, 512 * tm) + (unsigned)(cu * 8u));
-                else if (k == 1) ld2(g[1], (gcptr2)sbk(psi_v, 1024 * tm), cu);
-                else if (k < 4) ld2(g[k], (gcptr2)sbk(psi_v, 2048 * tm) + (k - 2), 2 * cu);
-                else ld2(g[k], (gcptr2)sbk(psi_v, 4096 * tm) + (k - 4), 4 * cu);
+            u64 g[RING][2];
+            gcptr p31v = (gcptr)jb.psi31;
+            auto loadt = [&](int t) {
+                if (t == 0) ld2(g[0], (gcptr2)sbk(p31v, 2 * 512 * tm), cu);
+                else if (t < 3) ld2(g[t % RING], (gcptr2)sbk(p31v, 2 * 1024 * tm) + (t - 1), 2 * cu);
+                else if (t < 7) ld2(g[t % RING], (gcptr2)sbk(p31v, 2 * 2048 * tm) + (t - 3), 4 * cu);
+                else if (t < 15) ld2(g[t % RING], (gcptr2)sbk(p31v, 2 * 4096 * tm) + (t - 7), 8 * cu);
             };
-            loadg(0); loadg(1); loadg(2);
+            loadt(0); loadt(1); if (RING > 3) loadt(2);
             H16_STAMP(4);
             exchange<X_BC>(x, lds, wv);
             H16_STAMP(5);
 #pragma unroll
             for (int n = 0; n < 32; ++n) {
-                if (n == 8) loadg(3);
-                if (n == 16) loadg(4);
-                if (n == 20) loadg(5);
-                if (n == 24) loadg(6);
-                if (n == 26) loadg(7);
                 const int gi = n & 7;
-                if (n < 8) bfly1<3>(x, gi, g[0][0], c);
-                else if (n < 16) bfly1<2>(x, gi, g[1][gi >> 2], c);
-                else if (n < 24) bfly1<1>(x, gi, g[2 + (gi >> 2)][(gi >> 1) & 1], c);
-                else bfly1<0>(x, gi, g[4 + (gi >> 1)][gi & 1], c);
+                const int t = n < 8 ? 0 : n < 16 ? 1 + (gi >> 2) : n < 24 ? 3 + (gi >> 1) : 7 + gi;
+                const int tp = n == 0 ? -1 : (n - 1 < 8 ? 0 : n - 1 < 16 ? 1 + (((n - 1) & 7) >> 2) : n - 1 < 24 ? 3 + (((n - 1) & 7) >> 1) : 7 + ((n - 1) & 7));
+                if (t != tp) loadt(t + RING - 1);            // first use of pair t: its predecessor's slot is free
+                if (n < 8) bfly1_31<3>(x, gi, g[t % RING], c);
+                else if (n < 16) bfly1_31<2>(x, gi, g[t % RING], c);
+                else if (n < 24) bfly1_31<1>(x, gi, g[t % RING], c);
+                else bfly1_31<0>(x, gi, g[t % RING], c);
             }
         }
-        reduce_all(x, c, big);                  // MODE 0: |x| < 3.3q after phase C (four two-round stages) -> (-q, q)
+        reduce_all(x, c, big);                  // MODE 0: |x| < 5.8q < 2^62.6 after the four stages of phase C -> (-q, q)
+#ifdef MKHE_H16_D31
+        // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane: pairs 0..3 (k = 13,
+        // two butterflies each) and 4..11 (k = 14)
+        {
+            const int ld = lane_id();
+            const unsigned du = (unsigned)((16 * h + wv) * 64 + ld);
+            __builtin_assume(du < 2048);
+            u64 g[RING][2];
+            gcptr p31v = (gcptr)jb.psi31;
+            auto loadt = [&](int t) {
+                if (t < 4) ld2(g[t % RING], (gcptr2)sbk(p31v, 2 * 8192 * tm) + t, 4 * du);
+                else if (t < 12) ld2(g[t % RING], (gcptr2)sbk(p31v, 2 * 16384 * tm) + (t - 4), 8 * du);
+            };
+            loadt(0); loadt(1); if (RING > 3) loadt(2);
+            H16_STAMP(6);
+            exchange<X_CD>(x, lds, wv);
+            H16_STAMP(7);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int gi = n & 7;
+                const int t = n < 8 ? (gi >> 1) : 4 + gi;
+                const int tp = n == 0 ? -1 : (n - 1 < 8 ? (((n - 1) & 7) >> 1) : 4 + ((n - 1) & 7));
+                if (t != tp) loadt(t + RING - 1);
+                if (n < 8) bfly1_31<1>(x, gi, g[t % RING], c);
+                else bfly1_31<0>(x, gi, g[t % RING], c);
+            }
+        }
+#else
+        // (phase D keeps the two-round product: with pairs of constants per twiddle the register allocator spills around it)
         // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane
         {
             const int ld = lane_id();
@@ -521,6 +584,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                 else bfly1<0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
             }
         }
+#endif
         H16_STAMP(8);
         // ---- output representative
         if (big || !jb.skip_norm) {
@@ -530,7 +594,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                 x[r] = (u64)(y + ((y >> 63) & (i64)c.q));                           // canonical (lattigo: final BRedAdd)
             }
         } else {
-            const i64 bias = (i64)((c.q << 4) + (c.q << 2));                         // MODE 1, engine-internal digits: same residue, positive: |x| < 17q -> (3q, 37q)
+            const i64 bias = (i64)((c.q << 4) + (c.q << 3));                         // MODE 1, engine-internal digits: same residue, positive: |x| < 20q -> (4q, 44q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = (u64)((i64)x[r] + bias);
         }

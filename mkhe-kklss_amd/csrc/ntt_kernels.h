@@ -66,7 +66,7 @@ struct NttBatch {
                             // (decomp_spread_kernel with first_stage): only the sub-transforms run, in place on dst
     const u64* psi31;       // forward, ntt16_kernels.hip only: [nmod][N][2] the twiddle w as the constant pair (w 2^31 mod q, w 2^63 mod q),
                             // balanced, radix-2^31 digits -- operands of the one-round product (mm31)
-    int no_h16;             // this context has a modulus the H16 kernel's ranges do not cover (40q >= 2^62 > 31q): keep to the other kernels
+    int no_h16;             // this context has a modulus the H16 kernel's ranges do not cover (48q >= 2^62 > 31q): keep to the other kernels
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
     int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists
     int mod[NTT_MAX_SLOTS];
