@@ -30,7 +30,7 @@ python3 bench.py --scheme cnn --parties 4 --steps 20 --warmup 3 > $O/bench_cnn4.
 python3 bench.py --params PN14QP439 --steps 20 --warmup 3 --no-cpu > $O/bench_pn14.json 2> $O/bench_pn14.err
 for k in 1 2 4 8 16; do python3 bench.py --parties $k --no-cpu --device-keys --steps 20 --warmup 3 2>/dev/null; done > $O/party_sweep.jsonl
 # issue-rate microbenchmarks and the per-phase timeline of the dominant kernel
-(echo "== tools/ubench/bfly16_rate.hip"; tools/ubench/bfly16_rate; echo "== tools/ubench/valu_rate.hip"; tools/ubench/valu_rate; echo "== tools/ubench/bfly_rate.hip"; tools/ubench/bfly_rate) > $O/ubench.txt 2>&1
+(echo "== tools/ubench/bfly31_rate.hip"; tools/ubench/bfly31_rate; echo "== tools/ubench/bfly16_rate.hip"; tools/ubench/bfly16_rate; echo "== tools/ubench/valu_rate.hip"; tools/ubench/valu_rate; echo "== tools/ubench/bfly_rate.hip"; tools/ubench/bfly_rate) > $O/ubench.txt 2>&1
 MKHE_LIB=$R/mkhe-kklss_amd/lib/libmkhe_hip_trace.so python3 tools/ntt16_trace.py 8 > $O/ntt16_trace.txt 2>&1
 python3 tools/ntt16_bench.py > $O/ntt16_bench.txt 2>&1
 find $O -name '*kernel_trace.csv' -path '*stats_*' -delete
