@@ -54,6 +54,9 @@ def whole_step_text():
 
 R, Rn = pl["roofline"], no["roofline"]
 whole_step = whole_step_text()
+def pmc_frac(k):
+    v = R["kernels"].get(k, {}).get("hbm_GBs_pmc")
+    return "%.2f" % (v / 8000.0) if v else "n/a"
 dom_key = R["kernel"].split()[0]
 avg, calls, mn, mx = st("ntt16_fwd_kernel<true>")
 expect = 2 * (no["warmup"] + 2 * no["steps"])
@@ -110,32 +113,33 @@ the low-latency path of DESIGN.md §4; that is what the rocprofv3 statistics lis
 * algorithmic bytes per launch {R["alg_bytes_per_launch"] / 1e6:.1f} MB (16·N B per limb-NTT × (1792 + 896)/2 limbs) ⇒ **{R["achieved"]:.0f} GB/s = {R["frac"]:.3f} of the 8 TB/s HBM peak** (round 1: 0.296).
   By the compulsory bytes of the fused Decompose (read every source limb once, write every digit limb: {R.get("compulsory_bytes_per_launch", 0) / 1e6:.0f} MB per average launch) it is {R.get("frac_compulsory", 0):.3f}.
 * HBM traffic from the PMC passes: {dom.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch (FETCH_SIZE {dom.get("fetch_size_kb", 0) / 1e3:.1f} MB ×2 + WRITE_SIZE {dom.get("write_size_kb", 0) / 1e3:.1f} MB) =
-  {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results, the parked upper halves of pass 0 (half of that again; they are
-  re-read by the same thread from L2) and the register spills (40 B of scratch per lane: 13–15 spilled VGPRs, no SGPR spills).  Read: source limbs (each is spread under 16 moduli: re-reads are cache hits), twiddle tables, the parked halves.
-* It is **VALU-issue / power bound, not HBM bound**.  `{tag}_ntt16_isa.txt`: the butterfly is 15 multiplier-class / 64-bit instructions + 2 plain ones (12 + 2 for the
-  signed-digit Montgomery product, one 64-bit add, one 64-bit subtract), 17.5 VALU instructions per butterfly over the whole pass body.  `{tag}_ubench.txt`
-  (`bfly16_rate`): exactly this butterfly, bare (no LDS, no memory), takes **73–75 cycles per wave at 8, 4 and 2 waves per SIMD alike and with one or two interleaved chains** —
-  it is throughput-, not latency-limited, ≈ 4.3 cycles per instruction — while the chip lowers its clock to 1.97–2.1 GHz under this load: 33–37 ns per wave-butterfly and SIMD.
-  A 2^15-point limb is 240 butterflies × 16 waves / 4 SIMDs = 960 wave-butterflies per SIMD ⇒ **32–35 µs per limb and CU before any load, store, exchange or
-  twiddle fetch**; the average launch has 1344 / 256 = 5.25 limbs per CU ⇒ ≥ 168–186 µs = at most 0.48–0.52 of the HBM roofline for a kernel that did nothing but these
-  butterflies at 100 % issue.  Measured: {R["avg_launch_us"]:.0f} µs = {R["avg_launch_us"] * 256 / 1344:.1f} µs per limb and CU, i.e. {34.0 * 1344 / 256 / R["avg_launch_us"]:.2f} of that floor; the rest is the non-butterfly
-  instructions (output representative, addresses, 40 B of scratch per lane), and the phases in which the two workgroups of a CU both wait (`{tag}_ntt16_phase_trace.txt`: the
-  pass-0 source loads and the four barriers of the cross-wave exchange).
+  {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and what is left of the register spills (28 B of scratch per
+  lane: 6 spilled VGPRs; the first half of round 2 wrote 40–60 B per lane plus the parked upper halves of pass 0: 1005 MB per launch).  Read: the source limbs in both passes (each is spread
+  under 16 moduli: most re-reads are cache hits), the twiddle pairs.
+* **What bounds it** (DESIGN.md §3): its memory traffic and its butterflies, which overlap only partly.  Ablation builds at 1792 limbs back to back (throttled clock): whole kernel
+  ≈ 360 µs, every butterfly removed 202 µs (245 µs before the parking store / reload and most of the scratch traffic were removed), scalar-twiddle butterflies removed 253 µs, per-lane ones
+  268 µs.  `{tag}_ubench.txt` (`bfly31_rate`): the butterfly on the one-round product takes **60.7 cycles per wave at 2.10 GHz = 28.8 ns**, on the two-round product (`bfly16_rate`,
+  phase D) 73.1 cycles at 1.98 GHz = 36.8 ns.  A limb is 2 × (104 one-round + 16 two-round) wave-butterflies on 16 waves / 4 SIMDs ⇒ **28.7 µs per limb and CU** before any load, store,
+  exchange or twiddle fetch; the average launch has 1344 / 256 = 5.25 limbs per CU ⇒ ≥ 151 µs.  Measured: {R["avg_launch_us"]:.0f} µs = {R["avg_launch_us"] * 256 / 1344:.1f} µs per limb and CU, {28.7 * 1344 / 256 / R["avg_launch_us"]:.2f} of that floor.
+  `{tag}_ntt16_isa.txt` counts the instructions of the shipped code object, `{tag}_ntt16_phase_trace.txt` stamps the phases per wave.
 * `{tag}_sq_counters.txt`: `SQ_INSTS_VALU` per wave, `SQ_WAIT_INST_ANY` (waves ready but waiting for the vector ALU that another wave holds) vs `SQ_WAIT_ANY`
   (waves at barriers / waitcnt), `SQ_LDS_BANK_CONFLICT` = 0 for all four LDS layouts, L2 hit rate.
 
-What changed against round 1 (DESIGN.md §4 has the measurements): 16 coefficients per thread and 64 VGPRs ⇒ two workgroups per CU; scalar (SGPR) twiddles for the
-eight stages whose twiddles are uniform per workgroup / wave; the product as two asm blocks of `v_mad_i64_i32` chains; both modulus classes on signed never-reduced
-butterflies with a 7-instruction float-estimated partial reduction (round 1: Harvey butterflies, +50 % instructions, for the 59/60-bit primes); single-word LDS reads
-(no register re-pairing moves); non-temporal result stores; one instantiation (29 KB of code).
+What changed against round 1 (DESIGN.md §3, §4 have the measurements): 16 coefficients per thread and 64 VGPRs ⇒ two workgroups per CU; scalar (SGPR) twiddles for the
+nine stages whose twiddles are uniform per workgroup / wave; **the one-round product** (twiddle stored as the pair w·2^31, w·2^63 mod q: 8 + 1 instructions instead of 12) in stage 0 and
+phases A, B, C; both modulus classes on signed never-reduced butterflies with a 7-instruction float-estimated partial reduction (round 1: Harvey butterflies, +50 % instructions, for the
+59/60-bit primes); stage 0 recomputed in the second pass instead of parking half a limb in HBM; stage-0 results staged through the wave's own LDS region instead of scratch; single-word
+LDS reads (no register re-pairing moves); non-temporal result stores; one instantiation.
 
 ### Streaming kernels
 
-`inner_product_kernel<4>` {R["kernels"]["inner_product_kernel"]["avg_launch_us"]:.0f} µs per launch (round 1: 104), `ext_inner_kernel` {R["kernels"]["ext_inner_kernel"]["avg_launch_us"]:.0f} µs (132): 16-byte lanes, unrolled term / digit loops, and
-**non-temporal loads for every operand that is read once per launch** (keys, hoisted digits), so that x, y, the CRS and the twiddles stay cache-resident.  PMC GB/s in the table above:
-0.74 and 0.81 of the 8 TB/s spec — against the 6.29 TB/s that MI355X_MICROARCH.md measures for a float4 copy (6.0–6.1 TB/s for an in-order sweep of a large table) the inner product is at
-0.94–0.98 of what the memory system delivers; a block-size × chunks-per-thread sweep spans 85–90 µs (DESIGN.md §4, "Streaming kernels").  `moddown_batch_kernel` and the small inverse NTTs are
-launch-latency-bound (`{tag}_sq_counters.txt`: `SQ_WAIT_ANY` 0.74 of the wave cycles), not bandwidth-bound.
+`inner_product_kernel<4>` {R["kernels"]["inner_product_kernel"]["avg_launch_us"]:.0f} µs per launch (round 1: 104; one launch per step since x comes out of step F1's kernel as a by-product), `ext_inner_kernel` {R["kernels"]["ext_inner_kernel"]["avg_launch_us"]:.0f} µs
+(two launches: F1 + x, and the E / F2 batch): 16-byte lanes, unrolled term / digit loops, items that share a key computed by one thread, and **non-temporal loads for every operand that is
+read once per launch** (keys, hoisted digits), so that x, y, the CRS and the twiddles stay cache-resident.  PMC GB/s in the table above: {pmc_frac("inner_product_kernel")} and {pmc_frac("ext_inner_kernel")} of the 8 TB/s spec —
+MI355X_MICROARCH.md measures 6.29 TB/s for a float4 copy (6.0–6.1 TB/s for an in-order sweep of a large table), i.e. they run at what the memory system delivers; a block-size ×
+chunks-per-thread sweep spans 85–90 µs (DESIGN.md §4, "Streaming kernels").  The ModDown launches and the small inverse NTTs are launch-latency-bound (`{tag}_sq_counters.txt`: `SQ_WAIT_ANY`
+0.74 of the wave cycles), not bandwidth-bound; since the external products of one destination are merged (DESIGN.md §4, "Merged external products": Q limbs summed in the NTT domain at the load
+of one inverse NTT, the tensor term folded in, one ModDown tail per destination) a 4-party MulRelin runs 158 instead of 326 inverse limb-NTTs.
 
 ## BASELINE.json configs[2]: mkbfv 4-party MulRelinNew, PN15QP880 BFV chain (14 Q + 14 QMul + 2 P)
 
