@@ -98,6 +98,28 @@ def test_pn15_hoisted_form_launch_classes(pn15, parties, drop):
         assert (got[:beta][:, act] == ref[:beta][:, act]).all(), "party %d" % i
 
 
+def test_n15_modulus_outside_the_h16_ranges():
+    """A small-class modulus (31q < 2^62) that the one-round product of csrc/ntt16_kernels.hip does not cover (48q >= 2^62: its
+    never-reduced values grow by q per stage): such a context keeps the round-1 forward kernels for its large Decompose
+    launches (Context::h16_gap_), and those still agree with the oracle."""
+    from oracle import oracle as O
+    from mkhe_kklss_amd import mkckks
+    base = H.PN15QP880
+    pset = dict(logN=15, Q=[0x1fffffffffc0001] + base["Q"][1:9], P=base["P"], scale=base["scale"])
+    assert (1 << 62) // 48 <= pset["Q"][0] < (1 << 62) // 31
+    ks = O.KeySwitcher(pset["logN"], pset["Q"], pset["P"], 2)
+    params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"], device=0)
+    rng = np.random.default_rng(57)
+    level = len(pset["Q"]) - 1
+    names = ["a", "b"]
+    h = _ct(pset, rng, 2, level + 1)
+    ct = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(h)
+    hoisted = mkckks.NewEvaluator(params).HoistedForm(ct)          # 2 * 9 * 11 = 198 limbs: an H16 launch in any other context
+    for i, n in enumerate(names):
+        assert (hoisted.Value[n].download() == ks.decompose(level, h[1 + i])).all(), "party %d" % i
+    params.close()
+
+
 def test_pn15_rotate_hoisted_four_parties(pn15):
     from mkhe_kklss_amd import mkrlwe
     p, ks, params, mk, rng = (pn15[k] for k in ("pset", "ks", "params", "mk", "rng"))

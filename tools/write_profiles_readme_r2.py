@@ -48,7 +48,7 @@ def whole_step_text():
     return ("Whole step (SURVEY.md §8d asks for the bytes moved against its two models): the kernels with a PMC column — %.0f %% of the kernel time — move **%.2f GB per MulRelin** through HBM "
             "= %.2f TB/s averaged over the %.3f ms step.  Compulsory model (every key read once: 13 × 56 MiB; the 12 hoisted digit vectors written and read: ≈ 0.9 GiB): 1.75 GB ⇒ 0.22 ms at 8 TB/s; staged "
             "(unfused) model: 7.7 GB ⇒ 0.97 ms.  The step sits between the two: the fused kernels (digit spread in the NTT load, batched inner products, tensor on the hoisted diagonal) remove "
-            "%.0f %% of the staged model's traffic; what remains above the compulsory bytes is mostly the second read of the hoisted digits (inner product, then external product) and the NTT's parked half-limbs.\n"
+            "%.0f %% of the staged model's traffic; what remains above the compulsory bytes is mostly the second read of the hoisted digits (inner product, then external product) and the source re-reads of the Decompose NTT.\n"
             % (100 * cov_ms / all_ms, tot / 1e9, tot / 1e9 / pl["ms_per_step"], pl["ms_per_step"], 100 * (1 - tot / 7.7e9)))
 
 
