@@ -9,10 +9,11 @@
 // one's butterflies.
 //
 // A limb is transformed in two passes by the same workgroup (1024 threads):
-//   pass 0: load x[j], x[j + N/2]; stage 0 (the cross-half butterflies, twiddle psi[1]); the lower outputs stay in
-//           registers, the upper outputs are parked in the upper half of the destination limb (same thread reloads
-//           them in pass 1); then the 14 remaining stages of the lower half;
-//   pass 1: reload the parked half, the same 14 stages.
+//   pass 0: load x[j], x[j + N/2]; stage 0 (the cross-half butterflies, twiddle psi[1]); keep the lower outputs; then the
+//           14 remaining stages of the lower half;
+//   pass 1: out of place (every Decompose launch) the same loads and stage 0 again, keeping the upper outputs (16 products
+//           per thread repeated instead of half a limb written to HBM and read back); in place (src == dst) pass 0 parks the
+//           upper outputs in the upper half of the destination limb and pass 1 reloads them; then the same 14 stages.
 // The 14 stages of a half (2^14 points, index bits 13..0) run as four register phases with LDS re-distributions:
 //   A: bits 13..10 in registers, thread = bits 9..0          twiddles uniform per workgroup  (scalar loads)
 //   B: bits  9..6,  wave = bits 13..10, lane = bits 5..0      twiddles uniform per wave       (scalar loads)
@@ -24,9 +25,10 @@
 // 136 KiB per CU), every layout addressed as base(thread) + immediate(register), conflict-free under the 32-bank rule
 // of ds_read_b32 / ds_write_b32 (padding constants below).
 //
-// Arithmetic: mont_mul_sd of modarith.h (signed-digit Montgomery product) and signed never-reduced butterflies for BOTH modulus
-// classes; the 59/60-bit primes (31q >= 2^62) get a 7-instruction float-estimated partial reduction after at most 8 stages
-// (pred() below) where ntt_kernels.hip runs Harvey butterflies.  Same DEC digit reduction, same skip_norm / canonical outputs,
+// Arithmetic: signed never-reduced butterflies for BOTH modulus classes on the one-round product mm31 (stage 0, phases A, B, C: the
+// twiddle as the pair w 2^31, w 2^63 mod q, one Montgomery round of radix 2^31, 8 + 1 instructions) and on mont_mul_sd of
+// modarith.h (phase D: two rounds, 12 + 2); the 59/60-bit primes get a 7-instruction float-estimated partial reduction after every
+// phase (pred() below) where ntt_kernels.hip runs Harvey butterflies.  Same DEC digit reduction, same skip_norm / canonical outputs,
 // so the two kernels are interchangeable bit for bit on canonical outputs (internal lazy representatives differ).
 //
 // Replaces: lattigo ring.NTTLvl as called from DecomposeSingleNTT (mkrlwe/keyswitch.go:21-31,49-73).
