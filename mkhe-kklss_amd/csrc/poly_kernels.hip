@@ -748,17 +748,33 @@ __global__ void __launch_bounds__(PW_THREADS) basis_conv_kernel(BasisConvArgs a)
     const u64 v = (u64)vi;
     for (int j = blockIdx.y; j < a.nt; j += gridDim.y) {
         const Mod mt = a.mods_t[j];
-        u64 rlo = 0, rhi = 0;
+        // multSum (basis_extension.go:587-646): the exact 128-bit sum of the ns products y_i * t_i, formed column by column -- y_i = y1 2^32 + y0,
+        // t_i = t1 2^32 + t0 (wave-uniform: SGPR operands): c0 = sum y0 t0, c1 = sum (y0 t1 + y1 t0), c2 = sum y1 t1 as 64-bit multiply-adds
+        // whose carry-outs are counted (k0, k1; c2 < ns 2^56 cannot carry), 7 instructions per term where the 128-bit product + 128-bit
+        // addition took 12.  Same integer, hence the same (rlo, rhi) as the reference's sequential accumulation.
+        u64 c0 = 0, c1 = 0, c2 = 0;
+        u32 k0 = 0, k1 = 0;
 #pragma unroll
         for (int i = 0; i < BC_MAXS; ++i) {
             if (i < a.ns) {
-                u64 mhi, mlo;
-                mul64x64(y[i], a.t.qoverqimodp[(long)j * a.ns + i], mhi, mlo);
-                u64 sum = rlo + mlo;
-                rhi += mhi + (sum < rlo ? 1 : 0);
-                rlo = sum;
+                const u64 t = a.t.qoverqimodp[(long)j * a.ns + i];
+                const u32 y0 = lo32(y[i]), y1 = hi32(y[i]);
+                u32 t0 = lo32(t), t1 = hi32(t);
+                asm("v_mad_u64_u32 %0, vcc, %5, %7, %0\n\t"
+                    "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+                    "v_mad_u64_u32 %1, vcc, %5, %8, %1\n\t"
+                    "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+                    "v_mad_u64_u32 %1, vcc, %6, %7, %1\n\t"
+                    "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+                    "v_mad_u64_u32 %2, vcc, %6, %8, %2"
+                    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(k0), "+v"(k1)
+                    : "v"(y0), "v"(y1), "s"(t0), "s"(t1)
+                    : "vcc");
             }
         }
+        // total = c0 + k0 2^64 + (c1 + k1 2^64) 2^32 + c2 2^64
+        const u64 rlo = c0 + (c1 << 32);
+        const u64 rhi = (u64)k0 + (c1 >> 32) + ((u64)k1 << 32) + c2 + (rlo < c0 ? 1 : 0);
         const u64 hhi = mulhi64(rlo * mt.qinv, mt.q);
         u64 z = rhi - hhi + mt.q + a.t.vtimesqmodp[(long)j * (a.ns + 1) + v];
         if (a.downparam) {
