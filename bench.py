@@ -381,6 +381,20 @@ def run_single(args):
         extras["mulrelin_per_sec_two_in_flight"] = 2 * args.steps / (time.perf_counter() - t0)
         del r1, r2, ev2
 
+        # ---- the same single-stream MulRelin in the steady state: after an idle phase (the host-side set-up above is one) this GPU takes
+        # about 150 ms of load to settle its clocks -- a 5-step window runs at 1.10 ms per step right after 0.2 s of idleness and at
+        # 0.92 ms 120 steps later (tools/ramp_probe.py) -- so `value`, timed over `steps` steps after `warmup` steps as the contract
+        # says, is a cold-start figure; this one times 200 steps after 100 untimed ones
+        for _ in range(100):
+            step()
+        params.sync()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            res_s = step()
+        params.sync()
+        extras["mulrelin_per_sec_steady_state"] = 200 / (time.perf_counter() - t0)
+        del res_s
+
         # ---- one party's relinearization key generated on the device (samples drawn on the host beforehand,
         # their upload included) and one CRS expanded from the public seed instead of uploaded
         kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(args.seed + 5), insecure_test_only=True))

@@ -92,6 +92,10 @@ timed loop and the HIP-event leg.
 * **{pl["value"]:.0f} MulRelin/s** ({pl["ms_per_step"]:.3f} ms per step: hoist both operands + MulAndRelinHoisted + Rescale; round 1: 763/s, 1.310 ms), bit-exact against
   the oracle on the same inputs in this very run (`cpu_baseline.bit_exact_vs_gpu = {cb["bit_exact_vs_gpu"]}`); CPU oracle on the GPU box's host: {cb["value"]:.2f} MulRelin/s on 1 thread,
   {cb.get("value_limb_parallel", 0):.2f} with its limb loops on {cb.get("cores_limb_parallel", "?")} threads.
+* steady state: **{pl["config"].get("mulrelin_per_sec_steady_state", 0):.0f} MulRelin/s** (200 steps after 100 untimed ones, same run).  The headline figure above is timed as the
+  bench contract says — {pl["steps"]} steps after {pl["warmup"]} warm-up steps, right after the host-side set-up — and this GPU takes about 150 ms of load to settle its clocks: a 5-step
+  window runs at ≈ 1.10 ms per step after 0.2 s of idleness and at ≈ 0.92 ms 120 steps later (`tools/ramp_probe.py`); two MulRelin in flight through forked contexts:
+  {pl["config"].get("mulrelin_per_sec_two_in_flight", 0):.0f}/s.
 * under `rocprofv3 --kernel-trace`, overlap off: {no["value"]:.0f} MulRelin/s ({no["ms_per_step"]:.3f} ms); overlap on: {ov["value"]:.0f} MulRelin/s ({ov["ms_per_step"]:.3f} ms).
 
 Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per step.  "algorithmic GB/s" is the byte model of DESIGN.md §4 (it counts
