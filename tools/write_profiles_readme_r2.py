@@ -82,6 +82,7 @@ timed loop and the HIP-event leg.
 | `{tag}_ntt16_isa.txt` | `tools/ntt16_isa.py`: instruction counts of the dominant kernel's pass body from the gfx950 ISA, one butterfly verbatim, code-object record |
 | `{tag}_ubench.txt` | `tools/ubench/bfly16_rate` (the kernel's butterfly, bare, at 1 / 2 / 4 / 8 waves per SIMD, one and two interleaved chains), `valu_rate`, `bfly_rate` |
 | `{tag}_ntt16_phase_trace.txt` | `tools/ntt16_trace.py` on the trace build: shader-clock stamps per wave, pass and phase of the dominant kernel |
+| `{tag}_ntt16_ablation.txt` | `tools/ntt16_ablation.sh`: the dominant kernel re-built without its butterflies / LDS exchanges / result stores / LDS stash (timing only), 1792 and 896 limbs back to back |
 | `{tag}_ntt16_launch_sizes.txt` | `tools/ntt16_bench.py`: the Decompose NTT at 1792 / 896 / 448 / 224 limbs (canonical outputs) |
 | `{tag}_kernel_stats_bfv.csv`, `{tag}_bench_bfv*.json` | `bench.py --scheme bfv` under the profiler (overlap off) and plain |
 | `{tag}_bench_pn16*.json`, `{tag}_kernel_stats_pn16.csv` | `bench.py --params PN16QP1761 --parties 8` (configs[3] ring on one GPU) |
