@@ -65,6 +65,9 @@ template <class P> __device__ __forceinline__ P sbk(P p, long k) { return sbase(
 // (s_waitcnt vmcnt(0) + scratch_store between two loads).  ld_issue only issues; ld_wait16 is the one wait, and it takes the sixteen
 // destinations as read-write operands so that no use can be scheduled above it.
 __device__ __forceinline__ u64 ld_issue(gcptr base, unsigned byte_off) {
+#ifdef MKHE_H16_X_NOSRC         // timing experiment only (wrong results): no source loads
+    return (u64)byte_off * 0x9E3779B97F4A7C15ull;
+#endif
     u64 v; asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base)); return v;
 }
 __device__ __forceinline__ void ld_wait16(u64 (&a)[8], u64 (&b)[8]) {
@@ -86,6 +89,9 @@ __device__ __forceinline__ gptr at(gptr p, unsigned byte_off) { return (gptr)((_
 
 // two consecutive twiddles in one 16-byte load
 __device__ __forceinline__ void ld2(u64* out, gcptr2 base, unsigned idx) {
+#ifdef MKHE_H16_X_NOTWLOAD      // timing experiment only (wrong results): no per-lane twiddle loads
+    out[0] = idx; out[1] = idx + 1; return;
+#endif
     // the byte offset is formed in 32 bits, so that base + zext(offset) selects the SGPR-base addressing form
     const u64x2 v = *(gcptr2)((const __attribute__((address_space(1))) char*)base + (unsigned)(idx * 16u));
     out[0] = v.x; out[1] = v.y;

@@ -24,5 +24,8 @@ run no_perlane_butterflies  -DMKHE_H16_X_NOBFLY=2
 run no_butterflies          -DMKHE_H16_X_NOBFLY=3
 run no_butterflies_no_xchg  -DMKHE_H16_X_NOBFLY=3 -DMKHE_H16_X_NOXCHG=14
 run no_butterflies_no_store -DMKHE_H16_X_NOBFLY=3 -DMKHE_H16_X_NOSTORE
+run no_butterflies_no_twiddle_loads -DMKHE_H16_X_NOBFLY=3 -DMKHE_H16_X_NOTWLOAD
+run no_butterflies_no_source_loads  -DMKHE_H16_X_NOBFLY=3 -DMKHE_H16_X_NOSRC
+run skeleton_only           -DMKHE_H16_X_NOBFLY=3 -DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE
 run no_stash                -DMKHE_H16_NO_STASH
 run shipped
