@@ -9,14 +9,14 @@ from oracle import oracle as O
 class Pair:
     """One parameter set instantiated on the oracle (ks) and on the device (params)."""
 
-    def __init__(self, pset, seed=0):
+    def __init__(self, pset, seed=0, gamma=2):
         from mkhe_kklss_amd import mkrlwe
         self.mk = mkrlwe
         self.pset = pset
         self.logN, self.N = pset["logN"], 1 << pset["logN"]
         self.Q, self.P = pset["Q"], pset["P"]
-        self.ks = O.KeySwitcher(self.logN, self.Q, self.P, 2)
-        self.params = mkrlwe.Parameters(self.logN, self.Q, self.P, 2)
+        self.ks = O.KeySwitcher(self.logN, self.Q, self.P, gamma)
+        self.params = mkrlwe.Parameters(self.logN, self.Q, self.P, gamma)
         self.ksw = mkrlwe.NewKeySwitcher(self.params)
         self.rng = np.random.default_rng(seed)
         self.maxlevel = len(self.Q) - 1

@@ -222,6 +222,39 @@ def test_rotate(pair, hoisted):
     assert (out.download() == ref).all()
 
 
+@pytest.mark.parametrize("nP,gamma", [(1, 1), (3, 3), (3, 1)])
+def test_merged_products_other_special_prime_counts(nP, gamma):
+    """The merged external products (one inverse NTT of the summed Q limbs, one ModDown tail per destination: csrc/poly_kernels.hip
+    moddown_merged_kernel<nP>) with one and three special primes -- alpha = 1 and alpha = 3 -- on a 3-party MulAndRelin with equal id sets
+    (destinations with three and two products) and a Rotate (keyswitch_hoisted.go:44-179, keyswitch.go:234-298)."""
+    from gpu_common import Pair, oracle_mul_and_relin
+    pset = dict(logN=11, Q=H.PN16_Q[:4], P=H.PN16_P[:nP], scale=float(1 << 45))
+    pr = Pair(pset, seed=100 * nP + gamma, gamma=gamma)
+    mk, level = pr.mk, pr.maxlevel
+    names = ["a", "b", "c"]
+    h0, d0 = pr.ct(names, level)
+    h1, d1 = pr.ct(names, level)
+    rlk_h, rlk_d = pr.rlk_set(names)
+    u_h = H.uniform_swk(pr.rng, pr.ks)
+    pr.params.AddCRS(-1, u_h)
+    out = mk.NewCiphertext(pr.params, names, level)
+    pr.ksw.MulAndRelin(d0, d1, rlk_d, out)
+    ido, ref = oracle_mul_and_relin(pr, level, names, h0, names, h1, rlk_h, u_h, names)
+    assert ido == names and (out.download() == ref).all()
+    rot = 5
+    crs_h = H.uniform_swk(pr.rng, pr.ks)
+    pr.params.AddCRS(rot, crs_h)
+    rkset, rk_h = mk.RotationKeySet(), []
+    for i in names:
+        k = H.uniform_swk(pr.rng, pr.ks)
+        rk_h.append(k)
+        rkset.AddRotationKey(mk.RotationKey(pr.params, rot, i, k))
+    rout = mk.NewCiphertext(pr.params, names, level)
+    pr.ksw.Rotate(d0, rot, rkset, rout)
+    assert (rout.download() == pr.ks.rotate(level, pow(5, rot, 2 * pr.N), [0, 1, 2], h0, rk_h, crs_h)).all()
+    pr.params.close()
+
+
 def test_conjugate(pair):
     """KeySwitcher.Conjugate (keyswitch.go:302-332)."""
     mk = pair.mk
