@@ -17,7 +17,9 @@ static thread_local std::string g_err;
 // writes into the caller's output never joined, a MulAndRelin plan half executed): recover() puts the context back into its
 // idle state and drains both streams before the error is reported, so that the caller may free its handles safely.
 static thread_local Context* g_last_ctx = nullptr;
-#define MKHE_TRY(body) try { body; return 0; } \
+// g_last_ctx is reset first, so that a call that fails before it reaches need() -- mkhe_ctx_create, a null-argument check -- never drains or
+// invalidates the plan of whichever context this thread happened to use last (which may even be gone).
+#define MKHE_TRY(body) g_last_ctx = nullptr; try { body; if (g_last_ctx) g_last_ctx->mark_enqueued(); return 0; } \
     catch (const std::exception& e) { g_err = e.what(); if (g_last_ctx) g_last_ctx->recover(); return 1; } \
     catch (...) { g_err = "mkhe: unknown error"; if (g_last_ctx) g_last_ctx->recover(); return 1; }
 

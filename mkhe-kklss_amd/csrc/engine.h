@@ -191,6 +191,8 @@ class Context {
     // device tables (public for the C ABI accessors / tests)
     Mod* d_mods = nullptr;
     u64 *d_psi = nullptr, *d_psiinv = nullptr, *d_inv_aux = nullptr;
+    u64* d_psi31n = nullptr;                     // [mall][4][2]: pairs of -psi[1..3] (NttBatch::psi31n)
+    unsigned long long u_mods_ = 0;              // bit m: modulus m is of the H16 kernel's U class (NttBatch::u_mods)
     u64* d_psi31 = nullptr;                      // logN >= 15: twiddle pairs of the H16 kernel's one-round product (NttBatch::psi31)
     bool h16_gap_ = false;                       // some modulus has 31q < 2^62 <= 48q: H16's signed ranges do not cover it
     int *d_map_qp = nullptr, *d_map_id = nullptr;
@@ -275,9 +277,14 @@ class Context {
     std::vector<FreeEntry> free_list_;
     hipEvent_t fence_ev_ = nullptr;
     void registry_add();
+    void init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP, const u64* QMul, int nqm_, u64 T);     // the constructor's body
+    void release_all() noexcept;                              // frees everything the context owns (destructor; constructor that throws)
     void registry_remove();
     seq_t uid_ = 0;
     std::atomic<seq_t> seq_{1}, completed_{0};
+    std::atomic<seq_t> enqueued_{0};                         // seq_ as of the last C-ABI call that has FINISHED enqueuing its work: the clock an event
+                                                             // recorded on this context's stream by ANOTHER thread may claim to cover (seq_ runs ahead of it
+                                                             // while a call is in flight)
     std::atomic<bool> external_{false};                      // stream handed out (mkhe_ctx_stream): work may arrive without a C-ABI call
     std::vector<std::pair<seq_t, seq_t>> synced_;            // (uid, seq_) pairs, guarded by the registry mutex
     seq_t synced_with(seq_t uid) const { for (auto& e : synced_) if (e.first == uid) return e.second; return 0; }
@@ -285,6 +292,7 @@ class Context {
   public:
     void note_use(HandleUsers& u);                            // this context is about to enqueue work on the handle's buffer
     void touch() { seq_.fetch_add(1, std::memory_order_relaxed); }
+    void mark_enqueued() { const seq_t s = seq_.load(); if (enqueued_.load() < s) enqueued_.store(s); }
     void mark_external() { external_.store(true); }
     seq_t now_seq() { return external_.load() ? seq_.fetch_add(1) + 1 : seq_.load(); }
   private:

@@ -3,6 +3,7 @@
 #include <mutex>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 namespace mkhe {
 
@@ -65,6 +66,14 @@ static u64* dev_alloc_words(size_t w) { u64* d = nullptr; MKHE_HIP(hipMalloc(&d,
 Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int gamma_,
                  const u64* psiQ, const u64* psiP, int device_, const u64* QMul, int nqm_, u64 T)
     : logN(logN_), N(1 << logN_), nq(nq_), np(np_), mtot(nq_ + np_), gamma(gamma_), device(device_) {
+    // The context enters the per-device registry (the pools of the other contexts walk it) only once it is complete: a constructor that
+    // throws half way -- a bad root, an unsupported alpha, a failed allocation -- never runs the destructor, so everything built so
+    // far is released here and no dangling pointer is ever visible to pool_free / pool_alloc of another context.
+    try { init(Q, P, psiQ, psiP, QMul, nqm_, T); }
+    catch (...) { release_all(); throw; }
+    registry_add();
+}
+void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP, const u64* QMul, int nqm_, u64 T) {
     nqm = QMul ? nqm_ : 0; mall = mtot + nqm; bfv_t = T;
     if (logN < 10 || logN > 16) throw Error("mkhe: logN must be in [10,16]");
     if (nq < 1 || np < 1 || gamma < 1 || np / gamma < 1) throw Error("mkhe: need at least gamma special primes (PCount/gamma >= 1)");
@@ -100,7 +109,6 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     MKHE_HIP(hipSetDevice(device));
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-    registry_add();
     for (auto& e : ev_) MKHE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     s_ = stream;
 
@@ -139,24 +147,37 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
     if (logN >= 15 && !h16_gap_) {
         // one-round product of the H16 kernel: a * w = a0 * u + a1 * u' with u = w 2^31, u' = w 2^63 (mod q, balanced), then ONE Montgomery
         // round of radix 2^31.  psi holds w * 2^64 in signed-split form at this point: w * 2^31 = psi * 2^-33.
-        std::vector<u64> p31(2 * (size_t)mall * N);
+        // Round 3, "U class" (160 q < 2^62: 4q of input + 75q of growth either way + the 75q bias of internal digits): the data word enters
+        // the product as hi 2^32 + lo with lo UNSIGNED, the pair is u = w 2^30 mod q in [0, q) with non-negative radix-2^30 digits and
+        // v = w 2^62 mod q balanced, one round of radix 2^30 (ntt16_kernels.hip mm30u).  psi31n: the pairs of -psi[1..3] (the second pass of
+        // the cross-half stage multiplies by -w; the unsigned digits cannot be negated in place), in the format of the modulus's class.
+        static const int uclass_on = [] { const char* e = getenv("MKHE_H16_UCLASS"); return (e && *e) ? atoi(e) : 1; }();
+        std::vector<u64> p31(2 * (size_t)mall * N), p31n(8 * (size_t)mall, 0);
         for (int i = 0; i < mall; ++i) {
             const u64 q = moduli[i];
-            const u64 c33 = powmod(powmod(2, 33, q), q - 2, q), c32 = powmod(2, 32, q);
+            const bool uc = uclass_on && small_q_[i] && q < (1ull << 62) / 160;
+            if (uc) u_mods_ |= 1ull << i;
+            const int sh = uc ? 30 : 31;
+            const u64 cinv = powmod(powmod(2, 64 - sh, q), q - 2, q), c32 = powmod(2, 32, q);
+            auto pack = [q, sh](u64 x, bool balanced) {
+                const i64 b = balanced && x > q / 2 ? (i64)x - (i64)q : (i64)x;
+                i64 d0 = (i64)((u64)b & ((1ull << sh) - 1));
+                if (balanced && d0 >= (1ll << (sh - 1))) d0 -= 1ll << sh;             // low digit, sign-extended
+                const i64 d1 = (b - d0) >> sh;
+                return (u64)(u32)(i32)d0 | ((u64)(u32)(i32)d1 << 32);
+            };
+            auto pair_of = [&](u64 wR, u64* out) {                                   // wR = w 2^64 mod q
+                const u64 u = mulmod(wR, cinv, q), v = mulmod(u, c32, q);           // w 2^sh, w 2^(sh + 32)
+                out[0] = pack(u, !uc); out[1] = pack(v, true);
+            };
             for (size_t j = 0; j < (size_t)N; ++j) {
                 const u64 ps = psi[(size_t)i * N + j];
                 const u64 wR = ps - ((u64)((u32)ps >> 31) << 32);                  // undo sd_split
-                const u64 u = mulmod(wR, c33, q), v = mulmod(u, c32, q);
-                auto pack = [q](u64 x) {
-                    const i64 b = x > q / 2 ? (i64)x - (i64)q : (i64)x;           // balanced representative
-                    const i64 d0 = (i64)((u64)b << 33) >> 33;                      // low 31 bits, sign-extended
-                    const i64 d1 = (b - d0) >> 31;
-                    return (u64)(u32)(i32)d0 | ((u64)(u32)(i32)d1 << 32);
-                };
-                p31[2 * ((size_t)i * N + j)] = pack(u); p31[2 * ((size_t)i * N + j) + 1] = pack(v);
+                pair_of(wR, &p31[2 * ((size_t)i * N + j)]);
+                if (j >= 1 && j <= 3) pair_of(wR ? q - wR : 0, &p31n[8 * (size_t)i + 2 * j]);
             }
         }
-        d_psi31 = dev_upload(p31);
+        d_psi31 = dev_upload(p31); d_psi31n = dev_upload(p31n);
     }
 
     std::vector<int> map((size_t)nq * mtot, 0), ident(mtot);
@@ -283,9 +304,16 @@ Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int ga
 
 Context::~Context() {
     (void)hipSetDevice(device);
+    // both streams: a pool of another context skips its fence for a context that is gone ("its destructor drained its streams")
+    if (stream2) (void)hipStreamSynchronize(stream2);
     if (stream) (void)hipStreamSynchronize(stream);
+    registry_remove();
+    release_all();
+}
+void Context::release_all() noexcept {
+    (void)hipSetDevice(device);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
-                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31,
+                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n,
                     (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
@@ -297,11 +325,11 @@ Context::~Context() {
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
     for (auto& f : free_list_) (void)hipFree(f.p);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
-    registry_remove();
     if (fence_ev_) (void)hipEventDestroy(fence_ev_);
     if (xev_) (void)hipEventDestroy(xev_);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
+    stream = stream2 = nullptr;
 }
 
 // live contexts per device: who may still be using a buffer that some context returns to its pool
@@ -330,7 +358,8 @@ u64* Context::pool_alloc(size_t words) {
                         for (Context* x : r.live) if (x->uid_ == b.first) m = x;
                         if (!m) continue;                         // destroyed since: its destructor drained its streams
                         if (std::max(synced_with(m->uid_), m->completed_.load()) >= b.second) continue;
-                        const seq_t upto = m->seq_.load();     // read before the record: everything counted so far is covered by it
+                        const seq_t upto = m->enqueued_.load();     // read before the record: every call that has finished enqueuing is covered by it (a call
+                                                                     // still in flight on another thread is counted in seq_ but its kernels come after the event)
                         if (!m->fence_ev_) MKHE_HIP(hipEventCreateWithFlags(&m->fence_ev_, hipEventDisableTiming));
                         MKHE_HIP(hipEventRecord(m->fence_ev_, m->stream));
                         MKHE_HIP(hipStreamWaitEvent(stream, m->fence_ev_, 0));
@@ -412,7 +441,8 @@ void Context::side_done(int k) { if (!overlap) return; MKHE_HIP(hipEventRecord(e
 void Context::join_side(int k) { if (!overlap) return; MKHE_HIP(hipStreamWaitEvent(s_, ev_[2 * k + 1], 0)); }
 void Context::recover() {
     s_ = stream;
-    plan_.valid = false; plan_.x_pending = false; plan_.head_done = false; plan_.xkeys.clear(); ext_xout_ = nullptr;
+    plan_.valid = false; plan_.x_pending = false; plan_.head_done = false; plan_.xkeys.clear(); ext_xout_ = ext_xout2_ = nullptr;
+    bfv_plan_valid_ = false; bfv_xk1_.clear(); bfv_xk2_.clear();
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cs);
     if (cs == hipStreamCaptureStatusNone) { (void)hipStreamSynchronize(stream2); (void)hipStreamSynchronize(stream); }
@@ -422,7 +452,7 @@ void Context::wait_for(Context& other) {
     if (&other == this) return;
     if (other.device != device) throw Error("mkhe: wait_for needs two contexts on the same device");
     if (!xev_) MKHE_HIP(hipEventCreateWithFlags(&xev_, hipEventDisableTiming));
-    const seq_t upto = other.seq_.load();
+    const seq_t upto = other.enqueued_.load();
     MKHE_HIP(hipEventRecord(xev_, other.stream));
     MKHE_HIP(hipStreamWaitEvent(stream, xev_, 0));
     { auto& r = registry(device); std::lock_guard<std::mutex> g(r.mu); set_synced(other.uid_, upto); }
@@ -486,7 +516,7 @@ void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
 // forward NTT launch: one kernel per modulus class, each with its own timing record
 void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     NttBatch b = b_in;
-    b.psi31 = d_psi31; b.no_h16 = d_psi31 ? 0 : 1;
+    b.psi31 = d_psi31; b.psi31n = d_psi31n; b.u_mods = u_mods_; b.no_h16 = d_psi31 ? 0 : 1;
     if (ntt16_ok(logN, b)) {
         ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;
@@ -713,7 +743,17 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }
     ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
     ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
-    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((2.0 * nb * (two ? 2 : 1) + 1) * n + (xby ? nb * (n + 1.0) * (xby2 ? 2 : 1) : 0.0))); launch_ext_inner(ia, s_); }
+    // algorithmic bytes: every DISTINCT digit / key array once (items that share x, y or the CRS u are computed by one thread that loads the
+    // shared operand once per coefficient, ext_inner_group_kernel), one output limb per item, and the x by-product's keys and result
+    (void)two;
+    int distinct = 0;
+    {
+        const u64* seen[4 * EXT_MAX_ITEMS]; int ns = 0;
+        auto add = [&](const u64* p) { if (!p) return; for (int k = 0; k < ns; ++k) if (seen[k] == p) return; seen[ns++] = p; };
+        for (int i = 0; i < n; ++i) { add(ia.ah[i]); add(ia.bg[i]); add(ia.ah2[i]); add(ia.bg2[i]); }
+        distinct = ns;
+    }
+    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + 1.0) * (xby2 ? 2 : 1) : 0.0))); launch_ext_inner(ia, s_); }
     NttBatch b{};
     b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux;
     b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;

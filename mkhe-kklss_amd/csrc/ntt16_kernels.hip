@@ -196,6 +196,53 @@ template <bool SW> __device__ __forceinline__ i64 mm31(i64 a, u64 us, u64 vs, co
     return acc;
 }
 
+// ------------------------------------------------------------------ one-round product with an UNSIGNED low data digit (round 3)
+// For the moduli with 160 q < 2^62 (the 2^54 - delta primes of PN15QP880, the 45-bit ones of PN16QP1761: "U class") the data word is taken
+// as it stands, a = hi 2^32 + lo with hi signed and lo UNSIGNED: no digit fix-up (v_lshrrev + v_add per product) in front of the chain.
+// The twiddle pair is then  u = w 2^30 mod q in [0, q)  (radix-2^30 digits u0, u1 >= 0: they meet lo in v_mad_u64_u32)  and
+// v = w 2^62 mod q, balanced (radix-2^30 digits, signed: they meet hi in v_mad_i64_i32); one Montgomery round of radix 2^30:
+//   C = lo u0 + hi v0 ; m = balanced30(lo(C) * -q^-1) ; T = ((C + m p0) >> 30) + lo u1 + hi v1 + m p1  =  (lo u + hi v + m q) / 2^30 = a w mod q.
+// Columns: lo u0 < 2^62, |hi v0| < 2^60, |m p0| < 2^58; lo u1 < 2^32 q / 2^30, ... all far below 2^63 for |a| < 2^62.  The price is the range:
+// lo u / 2^30 < 4 q, |hi v| / 2^30 < |a| q / 2^63 < q / 2, |m q| / 2^30 <= q / 2, so T lies in (-q, 5q) and the never-reduced values grow by up to
+// 5q on either side per stage -- 75q over the 15 stages of a pass, which is why only moduli with (4 + 75 + 75) q < 2^62 take this path.
+// 8 multiplier-class + 1 plain instruction like mm31, but 2 plain instructions less in front: tools/ubench/bfly30u_rate.hip.
+template <bool SW> __device__ __forceinline__ i64 mm30u(i64 a, u64 us, u64 vs, const MC& c) {
+    const u32 lo = lo32((u64)a);
+    const i32 hi = (i32)hi32((u64)a);
+    i32 u0 = (i32)lo32(us), u1 = (i32)hi32(us), v0 = (i32)lo32(vs), v1 = (i32)hi32(vs);
+    if constexpr (SW) asm("" : "+s"(u0), "+s"(u1), "+s"(v0), "+s"(v1)); else asm("" : "+v"(u0), "+v"(u1), "+v"(v0), "+v"(v1));
+    i64 acc; i32 m; u64 k;
+    // (the chain is cut after the low column: a block only names whole operands, and the multiply by -q^-1 reads the low word of the sum)
+    if constexpr (SW) {
+        asm("v_mad_u64_u32 %0, %1, %2, %4, 0\n\t"           // lo * u0
+            "v_mad_i64_i32 %0, %1, %3, %5, %0"                // + hi * v0
+            : "=&v"(acc), "=&s"(k) : "v"(lo), "v"(hi), "s"(u0), "s"(v0));
+        asm("v_mul_lo_u32 %1, %3, %8\n\t"                   // lo(C) * -q^-1
+            "v_bfe_i32 %1, %1, 0, 30\n\t"                   // balanced 30-bit digit
+            "v_mad_i64_i32 %0, %2, %1, %9, %0\n\t"          // + m * p0: low 30 bits zero
+            "v_ashrrev_i64 %0, 30, %0\n\t"
+            "v_mad_u64_u32 %0, %2, %4, %6, %0\n\t"          // + lo * u1
+            "v_mad_i64_i32 %0, %2, %5, %7, %0\n\t"          // + hi * v1
+            "v_mad_i64_i32 %0, %2, %1, %10, %0"               // + m * p1
+            : "+v"(acc), "=&v"(m), "=&s"(k)
+            : "v"(lo32((u64)acc)), "v"(lo), "v"(hi), "s"(u1), "s"(v1), "s"(c.ninv), "s"(c.p0), "s"(c.p1));
+    } else {
+        asm("v_mad_u64_u32 %0, %1, %2, %4, 0\n\t"
+            "v_mad_i64_i32 %0, %1, %3, %5, %0"
+            : "=&v"(acc), "=&s"(k) : "v"(lo), "v"(hi), "v"(u0), "v"(v0));
+        asm("v_mul_lo_u32 %1, %3, %8\n\t"
+            "v_bfe_i32 %1, %1, 0, 30\n\t"
+            "v_mad_i64_i32 %0, %2, %1, %9, %0\n\t"
+            "v_ashrrev_i64 %0, 30, %0\n\t"
+            "v_mad_u64_u32 %0, %2, %4, %6, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %5, %7, %0\n\t"
+            "v_mad_i64_i32 %0, %2, %1, %10, %0"
+            : "+v"(acc), "=&v"(m), "=&s"(k)
+            : "v"(lo32((u64)acc)), "v"(lo), "v"(hi), "v"(u1), "v"(v1), "s"(c.ninv), "s"(c.p0), "s"(c.p1));
+    }
+    return acc;
+}
+
 // Cheap partial reduction: x -> x - round(x / q) * q, |result| <= q/2 + q * 2^-19, for any |x| < 2^62.9.  The quotient is estimated
 // from the high word in float32 (3 plain VALU instructions: convert, fma with the 1.5 * 2^23 rounding constant, subtract) and is at
 // most a few dozen, so the product is one v_mad_i64_i32 for the low digit of q plus a 32-bit multiply-add for the high digit:
@@ -221,11 +268,11 @@ template <bool SW> __device__ __forceinline__ void bfly(u64& U, u64& V, u64 ws, 
     V = (u64)(u - T);
 }
 // the same butterfly on the one-round product; tw[0] = u, tw[1] = v
-template <bool SW> __device__ __forceinline__ void bfly31(u64& U, u64& V, const u64* tw, const MC& c) {
+template <bool SW, bool UC> __device__ __forceinline__ void bfly31(u64& U, u64& V, const u64* tw, const MC& c) {
 #ifdef MKHE_H16_X_NOBFLY
     if ((MKHE_H16_X_NOBFLY >> (SW ? 0 : 1)) & 1) { U += tw[0] + tw[1]; return; }      // timing experiment only
 #endif
-    const i64 T = mm31<SW>((i64)V, tw[0], tw[1], c);
+    const i64 T = UC ? mm30u<SW>((i64)V, tw[0], tw[1], c) : mm31<SW>((i64)V, tw[0], tw[1], c);
     const i64 u = (i64)U;
     U = (u64)(u + T);
     V = (u64)(u - T);
@@ -250,11 +297,11 @@ template <bool SW, int B> __device__ __forceinline__ void stage(u64 (&x)[16], co
 }
 
 // the same stage with scalar twiddle PAIRS: butterflies G0 .. G0 + NG - 1, tw[2 i], tw[2 i + 1] = (u, v) of twiddle (G0 >> B) + i
-template <int B, int G0 = 0, int NG = 8> __device__ __forceinline__ void stage31(u64 (&x)[16], const u64* tw, const MC& c) {
+template <bool UC, int B, int G0 = 0, int NG = 8> __device__ __forceinline__ void stage31(u64 (&x)[16], const u64* tw, const MC& c) {
 #pragma unroll
     for (int g = G0; g < G0 + NG; ++g) {
         const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
-        bfly31<true>(x[i0], x[i0 | (1 << B)], tw + 2 * ((g >> B) - (G0 >> B)), c);
+        bfly31<true, UC>(x[i0], x[i0 | (1 << B)], tw + 2 * ((g >> B) - (G0 >> B)), c);
 #ifndef MKHE_H16_NO_SCHEDBAR
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -274,10 +321,15 @@ template <int B> __device__ __forceinline__ void bfly1(u64 (&x)[16], int g, u64 
 #ifndef MKHE_H16_RING
 #define MKHE_H16_RING 3
 #endif
+// U class, phase D on the one-round product too (pairs of constants per lane): measured slower (10 spilled VGPRs around it: 372 against 349 us
+// for the 1792-limb launch), so phase D keeps the two-round product of the balanced path (8-byte twiddles) for both classes
+#ifndef MKHE_H16_UD31
+#define MKHE_H16_UD31 0
+#endif
 constexpr int RING = MKHE_H16_RING;
-template <int B> __device__ __forceinline__ void bfly1_31(u64 (&x)[16], int g, const u64* tw, const MC& c) {
+template <bool UC, int B> __device__ __forceinline__ void bfly1_31(u64 (&x)[16], int g, const u64* tw, const MC& c) {
     const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
-    bfly31<false>(x[i0], x[i0 | (1 << B)], tw, c);
+    bfly31<false, UC>(x[i0], x[i0 | (1 << B)], tw, c);
 #ifndef MKHE_H16_NO_SCHEDBAR
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -346,7 +398,7 @@ template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds
 
 // ------------------------------------------------------------------ one limb
 // what one limb needs, all wave-uniform
-struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; smodptr mp; bool red; bool skip_norm; int root; u64* trace; };
+struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* psi31n; smodptr mp; bool red; bool skip_norm; int root; u64* trace; };
 // diagnostic build (make trace): shader-clock stamps per wave and pass, 32 words per (job, wave): [16 * pass + k], see tools/ntt16_trace.py
 // (every lane stores the same word: a lane-0 branch here makes the compiler lose the uniformity of the scalar twiddle loads)
 #ifdef MKHE_PHASE_TRACE
@@ -360,8 +412,11 @@ struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; smodptr mp; 
 // instruction cache -- stream through
 // SPLIT: the 2^15 points are one half of a 2^16-point limb whose cross-half stage has already been applied (NttBatch::split): the
 // group i' of local stage k then uses the twiddle psi16[root * 2^k + i'], root = 2 + half, where a whole limb uses psi[2^k + i'].
-template <bool DEC, bool SPLIT>
-__device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, const int wv) {
+// UC: the modulus is of the U class (160 q < 2^62): mm30u, twiddle pairs in the unsigned radix-2^30 format, no reductions anywhere, every
+// stage (phase D included) on the one-round product.  The other instantiation serves the 59/60-bit primes (`big`) and the moduli in between.
+template <bool DEC, bool SPLIT, bool UC>
+__device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, const int wv) {
+    const bool big = UC ? false : big_;
     const int tm = SPLIT ? jb.root : 1;
     smodptr mp = jb.mp;                                 // scalar loads: the constants live in SGPRs
     const u64 qs = mp->qs;
@@ -369,8 +424,13 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
     c.q = mp->q; c.ninv = mp->ninv32;
     c.q0 = (i32)lo32(qs); c.q1 = (i32)hi32(qs);
     c.finv = __builtin_bit_cast(float, mp->finv);
-    c.p0 = (i32)((u32)c.q << 1) >> 1;                       // q = p1 2^31 + p0, |p0| <= 2^30
-    c.p1 = (i32)((c.q - (u64)(i64)c.p0) >> 31);
+    if constexpr (UC) {
+        c.p0 = (i32)((u32)c.q << 2) >> 2;                   // q = p1 2^30 + p0, |p0| <= 2^29
+        c.p1 = (i32)((c.q - (u64)(i64)c.p0) >> 30);
+    } else {
+        c.p0 = (i32)((u32)c.q << 1) >> 1;                   // q = p1 2^31 + p0, |p0| <= 2^30
+        c.p1 = (i32)((c.q - (u64)(i64)c.p0) >> 31);
+    }
     asm("" : "+s"(c.q0), "+s"(c.q1), "+s"(c.ninv), "+s"(c.p0), "+s"(c.p1));        // opaque wave-uniform 32-bit values (see modarith.h mont_mul_sd)
     scptr psi_s = (scptr)jb.psi;
     scptr p31 = (scptr)jb.psi31;                            // (u, v) of twiddle i at words 2i, 2i + 1
@@ -393,9 +453,16 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
         if (h == 0 || !park) {
             u64 w1[2] = {p31[2 * tm], p31[2 * tm + 1]};
             if (h != 0) {
-                // second pass: x - w y = x + (-w) y -- both digits of both constants negated (scalar), the butterfly keeps its `+` output
-                w1[0] = ((u64)(u32)(0 - (i32)hi32(w1[0])) << 32) | (u32)(0 - (i32)lo32(w1[0]));
-                w1[1] = ((u64)(u32)(0 - (i32)hi32(w1[1])) << 32) | (u32)(0 - (i32)lo32(w1[1]));
+                // second pass: x - w y = x + (-w) y, the butterfly keeps its `+` output
+                if constexpr (UC) {
+                    // (the unsigned digits of u cannot be negated in place: the pair of -w mod q comes from its own small table, NttBatch::psi31n)
+                    scptr pn = (scptr)jb.psi31n;
+                    w1[0] = pn[2 * tm]; w1[1] = pn[2 * tm + 1];
+                } else {
+                    // both digits of both constants negated (scalar)
+                    w1[0] = ((u64)(u32)(0 - (i32)hi32(w1[0])) << 32) | (u32)(0 - (i32)lo32(w1[0]));
+                    w1[1] = ((u64)(u32)(0 - (i32)hi32(w1[1])) << 32) | (u32)(0 - (i32)lo32(w1[1]));
+                }
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // (keeps the store queue of pass 0 from growing under the loads)
             }
             const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
@@ -413,7 +480,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                 }
 #pragma unroll
                 for (int r = 0; r < SG; ++r) {
-                    const i64 T = mm31<true>((i64)V[r], w1[0], w1[1], c);
+                    const i64 T = UC ? mm30u<true>((i64)V[r], w1[0], w1[1], c) : mm31<true>((i64)V[r], w1[0], w1[1], c);
                     x[r0 + r] = (u64)((i64)U[r] + T);
 #ifndef MKHE_H16_X_NOPARK      // timing experiment only (wrong results): no parking store / reload of the upper half
                     if (park) st_issue(sbk(dst, HH + (r0 + r) * NT), tb, (u64)((i64)U[r] - T));
@@ -467,17 +534,17 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
             for (int i = 0; i < 2; ++i) tw[i] = p31[2 * (2 * tm + h) + i];
 #pragma unroll
             for (int i = 0; i < 4; ++i) tw[2 + i] = p31[2 * (4 * tm + 2 * h) + i];
-            stage31<3>(x, tw, c);
+            stage31<UC, 3>(x, tw, c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) tm4[i] = p31[2 * (8 * tm + 4 * h) + i];
-            stage31<2>(x, tw + 2, c);
+            stage31<UC, 2>(x, tw + 2, c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) ta[i] = p31[2 * (16 * tm + 8 * h) + i];
-            stage31<1>(x, tm4, c);
+            stage31<UC, 1>(x, tm4, c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) tb[i] = p31[2 * (16 * tm + 8 * h + 4) + i];
-            stage31<0, 0, 4>(x, ta, c);
-            stage31<0, 4, 4>(x, tb, c);
+            stage31<UC, 0, 0, 4>(x, ta, c);
+            stage31<UC, 0, 4, 4>(x, tb, c);
         }
         reduce_all(x, c, big);                  // MODE 0: |x| < 6.4q < 2^62.7 after stage 0 + phase A (five stages of up to q + |x|/16 each) -> (-q, q)
         H16_STAMP(2);
@@ -491,17 +558,17 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
             for (int i = 0; i < 2; ++i) tw[i] = p31[2 * (32 * tm + cb) + i];
 #pragma unroll
             for (int i = 0; i < 4; ++i) tw[2 + i] = p31[2 * (64 * tm + 2 * cb) + i];
-            stage31<3>(x, tw, c);
+            stage31<UC, 3>(x, tw, c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) tm4[i] = p31[2 * (128 * tm + 4 * cb) + i];
-            stage31<2>(x, tw + 2, c);
+            stage31<UC, 2>(x, tw + 2, c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) ta[i] = p31[2 * (256 * tm + 8 * cb) + i];
-            stage31<1>(x, tm4, c);
+            stage31<UC, 1>(x, tm4, c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) tb[i] = p31[2 * (256 * tm + 8 * cb + 4) + i];
-            stage31<0, 0, 4>(x, ta, c);
-            stage31<0, 4, 4>(x, tb, c);
+            stage31<UC, 0, 0, 4>(x, ta, c);
+            stage31<UC, 0, 4, 4>(x, tb, c);
         }
         reduce_all(x, c, big);                  // MODE 0: |x| < 5.1q after the four one-round stages of phase B -> (-q, q): phase C may add 2.7q
         // Phases C and D: per-lane twiddles, fetched in 16-byte groups a few butterflies ahead of their use (at most three groups =
@@ -532,17 +599,21 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                 const int t = n < 8 ? 0 : n < 16 ? 1 + (gi >> 2) : n < 24 ? 3 + (gi >> 1) : 7 + gi;
                 const int tp = n == 0 ? -1 : (n - 1 < 8 ? 0 : n - 1 < 16 ? 1 + (((n - 1) & 7) >> 2) : n - 1 < 24 ? 3 + (((n - 1) & 7) >> 1) : 7 + ((n - 1) & 7));
                 if (t != tp) loadt(t + RING - 1);            // first use of pair t: its predecessor's slot is free
-                if (n < 8) bfly1_31<3>(x, gi, g[t % RING], c);
-                else if (n < 16) bfly1_31<2>(x, gi, g[t % RING], c);
-                else if (n < 24) bfly1_31<1>(x, gi, g[t % RING], c);
-                else bfly1_31<0>(x, gi, g[t % RING], c);
+                if (n < 8) bfly1_31<UC, 3>(x, gi, g[t % RING], c);
+                else if (n < 16) bfly1_31<UC, 2>(x, gi, g[t % RING], c);
+                else if (n < 24) bfly1_31<UC, 1>(x, gi, g[t % RING], c);
+                else bfly1_31<UC, 0>(x, gi, g[t % RING], c);
             }
         }
         reduce_all(x, c, big);                  // MODE 0: |x| < 5.8q < 2^62.6 after the four stages of phase C -> (-q, q)
 #ifdef MKHE_H16_D31
+        constexpr bool D31 = true;
+#else
+        constexpr bool D31 = UC && MKHE_H16_UD31;
+#endif
         // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane: pairs 0..3 (k = 13,
         // two butterflies each) and 4..11 (k = 14)
-        {
+        if constexpr (D31) {
             const int ld = lane_id();
             const unsigned du = (unsigned)((16 * h + wv) * 64 + ld);
             __builtin_assume(du < 2048);
@@ -562,14 +633,12 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                 const int t = n < 8 ? (gi >> 1) : 4 + gi;
                 const int tp = n == 0 ? -1 : (n - 1 < 8 ? (((n - 1) & 7) >> 1) : 4 + ((n - 1) & 7));
                 if (t != tp) loadt(t + RING - 1);
-                if (n < 8) bfly1_31<1>(x, gi, g[t % RING], c);
-                else bfly1_31<0>(x, gi, g[t % RING], c);
+                if (n < 8) bfly1_31<UC, 1>(x, gi, g[t % RING], c);
+                else bfly1_31<UC, 0>(x, gi, g[t % RING], c);
             }
-        }
-#else
-        // (phase D keeps the two-round product: with pairs of constants per twiddle the register allocator spills around it)
+        } else {
+        // (phase D keeps the two-round product on the balanced path: with pairs of constants per twiddle the register allocator spills around it)
         // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane
-        {
             const int ld = lane_id();
             const unsigned du = (unsigned)((16 * h + wv) * 64 + ld);
             __builtin_assume(du < 2048);
@@ -592,7 +661,6 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                 else bfly1<0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
             }
         }
-#endif
         H16_STAMP(8);
         // ---- output representative
         if (big || !jb.skip_norm) {
@@ -602,7 +670,8 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big, u32* lds, co
                 x[r] = (u64)(y + ((y >> 63) & (i64)c.q));                           // canonical (lattigo: final BRedAdd)
             }
         } else {
-            const i64 bias = (i64)((c.q << 4) + (c.q << 3));                         // MODE 1, engine-internal digits: same residue, positive: |x| < 20q -> (4q, 44q)
+            // engine-internal digits: same residue, positive.  Balanced path: |x| < 20q -> + 24q -> (4q, 44q); U class: x in (-75q, 79q) -> + 75q -> (0, 154q) < 2^62
+            const i64 bias = UC ? (i64)((c.q << 6) + (c.q << 3) + (c.q << 1) + c.q) : (i64)((c.q << 4) + (c.q << 3));
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = (u64)((i64)x[r] + bias);
         }
@@ -660,6 +729,7 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         jb.dst = (gptr)(dbase_ + (long)outer * kb->dst_outer + (long)(kb->dst_mapped ? m : p) * kb->dst_inner);
         jb.psi = kb->psi + (long)m * (SPLIT ? 2 * NN : NN);
         jb.psi31 = kb->psi31 + 2 * (long)m * (SPLIT ? 2 * NN : NN);
+        jb.psi31n = kb->psi31n + 8 * (long)m;
         jb.root = 1;
         if constexpr (SPLIT) { const int half = job2 & 1; jb.src += half * NN; jb.dst += half * NN; jb.root = 2 + half; }
         jb.mp = (smodptr)kb->mods + m;
@@ -681,7 +751,8 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
             tw[14] = blockIdx.x;
         }
 #endif
-        limb<DEC, SPLIT>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv);
+        if ((kb->u_mods >> m) & 1) limb<DEC, SPLIT, true>(jb, false, lds, wv);
+        else limb<DEC, SPLIT, false>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv);
 #ifdef MKHE_PHASE_TRACE
         if (jb.trace && ((int)threadIdx.x & 63) == 0) jb.trace[(long)wv * 32 + 28] = __builtin_amdgcn_s_memrealtime();
 #endif

@@ -66,6 +66,9 @@ struct NttBatch {
                             // (decomp_spread_kernel with first_stage): only the sub-transforms run, in place on dst
     const u64* psi31;       // forward, ntt16_kernels.hip only: [nmod][N][2] the twiddle w as the constant pair (w 2^31 mod q, w 2^63 mod q),
                             // balanced, radix-2^31 digits -- operands of the one-round product (mm31)
+    const u64* psi31n;      // [nmod][4][2]: the pairs of -psi[1], -psi[2], -psi[3] (entries 1..3), for the second pass of the cross-half stage
+    unsigned long long u_mods;   // bit m set = modulus m is of the U class (160 q < 2^62): its psi31 rows hold the UNSIGNED radix-2^30 format
+                            // (u = w 2^30 mod q in [0, q) as digits u0, u1 >= 0; v = w 2^62 mod q balanced) of ntt16_kernels.hip mm30u
     int no_h16;             // this context has a modulus the H16 kernel's ranges do not cover (48q >= 2^62 > 31q): keep to the other kernels
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
     int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists

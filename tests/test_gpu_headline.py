@@ -8,7 +8,7 @@
 * RotateHoisted with 4 parties at PN15QP880 (mkrlwe/keyswitch_hoisted.go:183-247);
 * configs[2]: mkbfv PN15QP880 (14 Q + 14 QMul + 2 P primes), MulRelinNew with 2 and 4 parties
   (mkbfv/mkbfv_bench_test.go:10-64);
-* configs[3] ring: PN16QP1761 with 8 parties, one hoisted Rotate (mkrlwe/mkrlwe_test.go:22-35).
+* configs[3] ring: PN16QP1761 with 8 parties at the maximum level, one hoisted Rotate and MulAndRelin[Hoisted] (mkrlwe/mkrlwe_test.go:22-35).
 """
 import numpy as np
 import pytest
@@ -187,3 +187,54 @@ def test_pn16_rotate_hoisted_eight_parties():
     pair.ksw.RotateHoisted(ct, rot, hh, rks, out)
     ref = pair.ks.rotate(level, pow(5, rot, 2 * pair.N), list(range(k)), h, keys, crs)
     assert (out.download() == ref).all()
+
+
+def test_pn16_mul_and_relin_eight_parties():
+    """BASELINE.json configs[3], the MulRelin half: PN16QP1761 (N = 2^16, 34 + 4 primes, alpha = 2, beta = 17) at the maximum level with
+    8 parties, MulAndRelin and MulAndRelinHoisted against the oracle (mkrlwe/keyswitch.go:122-230, keyswitch_hoisted.go:44-179).  Eight
+    parties drive what two (tests/test_gpu_fullsize.py) do not: two virtual items per output slot in the merged external products, the
+    x inner product as its own launch (more than four parties) and decomp_spread's fused first stage over 16 operand components.
+    The 24 key polynomials (8.1 GB) are three random arrays rotated by a party-specific offset along the coefficient axis -- distinct
+    data per party and per key at memcpy speed; the oracle runs its limb loops on 8 threads (same integers, tests/test_oracle_vs_model)."""
+    from oracle import oracle as O
+    pair = Pair(H.PN16QP1761, seed=1688)
+    mk, p, rng = pair.mk, H.PN16QP1761, pair.rng
+    k = 8
+    names = ["u%d" % i for i in range(k)]
+    level = pair.maxlevel
+    beta = pair.ks.beta_max
+    assert pair.params.Alpha() == 2 and pair.params.Beta(level) == 17 == beta
+    h0, h1 = _ct(p, rng, k, level + 1), _ct(p, rng, k, level + 1)
+    base = [_swk(p, rng, beta) for _ in range(3)]
+    u = _swk(p, rng, beta)
+    pair.params.AddCRS(-1, u)
+    rlk_h, rlk = {}, mk.RelinearizationKeySet(pair.params)
+    for i, n in enumerate(names):
+        rlk_h[i] = tuple(np.ascontiguousarray(np.roll(base[j], 997 * i + 131 * j + 1, axis=2)) for j in range(3))
+        rlk.AddRelinearizationKey(mk.RelinearizationKey(pair.params, n, *rlk_h[i]))
+    ct0 = mk.NewCiphertext(pair.params, names, level).upload(h0)
+    ct1 = mk.NewCiphertext(pair.params, names, level).upload(h1)
+    out = mk.NewCiphertext(pair.params, names, level)
+    pair.ksw.MulAndRelin(ct0, ct1, rlk, out)
+    got = out.download()
+    O.set_threads(8)
+    try:
+        ids = list(range(k))
+        _, ref = pair.ks.mul_and_relin(level, ids, h0, ids, h1, rlk_h, u)
+    finally:
+        O.set_threads(1)
+    assert got.shape == ref.shape and (got == ref).all()
+    for l, q in enumerate(pair.Q):
+        assert (got[:, l] < q).all()
+    # the hoisted entry point on hoisted forms computed beforehand (keyswitch_hoisted.go:44-179)
+    hh = []
+    for ct in (ct0, ct1):
+        h = mk.NewHoistedCiphertext()
+        for n in names:
+            h.Value[n] = mk.NewSwitchingKey(pair.params)
+            pair.ksw.Decompose(level, ct, n, h.Value[n])
+        hh.append(h)
+    out2 = mk.NewCiphertext(pair.params, names, level)
+    pair.ksw.MulAndRelinHoisted(ct0, ct1, hh[0], hh[1], rlk, out2)
+    assert (out2.download() == ref).all()
+    pair.params.close()

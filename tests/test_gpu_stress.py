@@ -107,3 +107,42 @@ def test_buffer_freed_under_a_foreign_reader_is_not_reused_early():
         x = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(hx)
     params.sync()
     fork.params.sync()
+
+
+def test_failed_context_creation_leaves_no_trace():
+    """mkhe_ctx_create that throws AFTER the streams exist (a supplied psi that is not a primitive 2N-th root; an alpha the
+    decomposer tables do not cover) must not leave a half-built context in the per-device registry that the pools of the other
+    contexts walk (csrc/engine.hip Context::Context / registry_add): afterwards handles of a good context on the same device --
+    and of a fork of it -- are created, used and freed as usual, and the failed call did not disturb a split-phase sequence
+    (MKHE_TRY resets the thread's last-context pointer before anything can throw)."""
+    from mkhe_kklss_amd import mkckks, mkrlwe
+    from mkhe_kklss_amd._abi import MkheError
+    pset = H.small_ckks(12, 4)
+    params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"])
+    names = ["a", "b"]
+    level = len(pset["Q"]) - 1
+    rng = np.random.default_rng(3)
+    N = 1 << pset["logN"]
+    host = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in pset["Q"]]) for _ in range(1 + len(names))])
+    ct = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(host)
+    for _ in range(3):
+        with pytest.raises(MkheError, match="psi"):
+            mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"], psiQ=[2] * len(pset["Q"]))
+        with pytest.raises(MkheError, match="PCount/gamma"):            # alpha = 7: thrown while the decomposer tables are built
+            mkrlwe.Parameters(12, H.PN16_Q[:6], H.PN16_P + H.PN15QP880["P"] + H.PN14QP439["P"][:1], gamma=1)
+    ev = mkckks.NewEvaluator(params)
+    fork = ev.Fork()
+    for it in range(8):                                   # pool_free / pool_alloc walk the registry on every one of these
+        t = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(host)
+        s = ev.AddNew(ct, t)
+        fork.params.wait_for(params)
+        r = fork.AddNew(s, t)
+        params.wait_for(fork.params)
+        exp = host.copy()
+        for l, q in enumerate(pset["Q"]):
+            exp[:, l] = (3 * host[:, l].astype(object) % q).astype(np.uint64)
+        assert (r.download() == exp).all()
+        for h in (t, s, r):
+            h.__del__()
+    fork.params.sync()
+    params.sync()

@@ -17,7 +17,7 @@ params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"])
 params.GenDefaultCRS(seed=1)
 for r in HC.ROTS:
     params.AddCRS(r, seed=1)
-kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(1)))
+kgen = mkrlwe.NewKeyGenerator(params, mkrlwe.HostSampler(np.random.default_rng(1), insecure_test_only=True))
 rlkSet, rtkSet = mkrlwe.RelinearizationKeySet(params), mkrlwe.RotationKeySet()
 for id in ("dataOwner", "modelOwner"):
     sk = kgen.GenSecretKey(id)

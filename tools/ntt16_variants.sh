@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds variants of csrc/ntt16_kernels.hip (compile-time switches) against the objects of the normal build and times the 1792 / 896-limb
+# Decompose launches back to back (tools/ntt16_bench.py; digests show whether a variant still computes the same hoisted digits).
+#   gpurun -- 'bash tools/ntt16_variants.sh "name1:-DFLAG1 -DFLAG2" "name2:..." > gpurun_out/variants.txt 2>&1'
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+C=$R/mkhe-kklss_amd/csrc
+B=$R/mkhe-kklss_amd/build
+make -s -C $C -j8 > /dev/null 2>&1
+run() {
+    name=$1; shift
+    mkdir -p $B/var_$name
+    for f in ntt_kernels poly_kernels keygen_kernels engine keygen capi; do cp $B/$f.o $B/var_$name/$f.o; done
+    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$C $* -c $C/ntt16_kernels.hip -o $B/var_$name/ntt16_kernels.o 2>/dev/null || { echo "$name: build failed"; return; }
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/var_$name/lib.so $B/var_$name/*.o
+    echo "== $name   ($*)"
+    MKHE_LIB=$B/var_$name/lib.so python3 $R/tools/ntt16_bench.py ${REPS:-10} 2>&1 | grep -E "limbs +(1792|896) " | cut -c1-150
+    rm -rf $B/var_$name
+}
+for v in "$@"; do
+    name=${v%%:*}; flags=${v#*:}
+    [ "$flags" = "$v" ] && flags=""
+    run $name $flags
+done

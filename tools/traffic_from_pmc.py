@@ -56,7 +56,12 @@ def main():
     for b, ks in bare.items():
         if len(ks) == 1 and b not in kernels:
             kernels[b] = dict(kernels[ks[0]], instance=ks[0])
-    json.dump(dict(workload=workload, formula="(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch",
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mkhe-kklss_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):      # same digest as bench.py csrc_digest()
+        h.update(os.path.basename(fn).encode()); h.update(open(fn, "rb").read())
+    json.dump(dict(workload=workload, csrc_sha256=h.hexdigest(), formula="(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch",
                    command="MKHE_NO_OVERLAP=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps %s --warmup %s --no-cpu --no-extras" % (steps, warmup),
                    steps=steps, warmup=warmup, kernels=kernels), sys.stdout, indent=1)
 
