@@ -35,6 +35,7 @@
 #include "ntt_kernels.h"
 #include <cstdlib>
 #include <mutex>
+#include <utility>
 
 namespace mkhe {
 namespace h16 {
@@ -81,6 +82,19 @@ __device__ __forceinline__ void ld_wait(u64 (&a)[4], u64 (&b)[4]) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
 }
 __device__ __forceinline__ void ld_wait(u64 (&a)[8], u64 (&b)[8]) { ld_wait16(a, b); }
+// pipelined stage-0 loads (round 3): PIPE_P pairs requested up front, the rest one by one behind every second consumed pair / the stash;
+// pipe_issued(r) = pairs requested by the time pair r is waited for
+#ifndef MKHE_H16_PIPE_P
+#define MKHE_H16_PIPE_P 11
+#endif
+constexpr int PIPE_P = MKHE_H16_PIPE_P;
+constexpr int pipe_issued(int r) {
+    int n = PIPE_P;
+    for (int k = 0; k < r && k < 16; ++k) if (n < 16 && ((k & 1) == 1 || k >= 7)) ++n;      // after pair k has been consumed
+    return n;
+}
+template <int... I, class F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int K> __device__ __forceinline__ void ld_wait_pair(u64& a, u64& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(K)); }
 __device__ __forceinline__ void st_issue(gptr base, unsigned byte_off, u64 v) {
     asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
 }
@@ -466,14 +480,50 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // (keeps the store queue of pass 0 from growing under the loads)
             }
             const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
+#ifdef MKHE_H16_PIPE
+            if (!park) {
+                // EXPERIMENT (make XFLAGS=-DMKHE_H16_PIPE, not the default): one memory round trip per pass instead of two.  Eleven of the sixteen
+                // (x[j], x[j + N/2]) pairs are requested up front, the other five as registers come free (a consumed pair turns four VGPRs into
+                // two; the first eight results wait in the wave's LDS region), and every pair is consumed behind a counted wait -- memory
+                // operations of a wave complete in order, so `vmcnt(loads issued after the pair)` is exact (tools/check_inflight.py verifies on
+                // the ISA that nothing touches a register of a load in flight: with twelve pairs up front the allocator spills one of them).
+                // Measured in the steady state (2000 launches back to back): 276 us against 271 us for the two groups of eight below -- the
+                // kernel runs at the 1400 W package power cap (tools/power_probe.sh: 1360 W, 2.06 GHz), where hiding latency buys nothing
+                // and the 23 additional spilled SGPRs cost instructions.
+                u64 U[16], V[16];
+#pragma unroll
+                for (int r = 0; r < PIPE_P; ++r) { U[r] = ld_issue(sbk(src, r * NT), tb); V[r] = ld_issue(sbk(src, HH + r * NT), tb); }
+                static_for(std::make_integer_sequence<int, 16>{}, [&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    ld_wait_pair<2 * (pipe_issued(r) - r - 1)>(U[r], V[r]);
+                    // digits of a foreign modulus (Decompose) may be far above q: bring them to (-q, q) first.  MODE 0 (q up to 2^60)
+                    // has no headroom for five stages on raw inputs and always starts from reduced values.
+                    if (big || red) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); }
+                    const i64 T = UC ? mm30u<true>((i64)V[r], w1[0], w1[1], c) : mm31<true>((i64)V[r], w1[0], w1[1], c);
+                    x[r] = (u64)((i64)U[r] + T);
+                    __builtin_amdgcn_sched_barrier(0);       // one butterfly at a time
+#ifndef MKHE_H16_NO_STASH
+                    if constexpr (r == 7) {
+                        typedef __attribute__((address_space(3))) u64* lptr64;
+                        lptr64 st = (lptr64)((__attribute__((address_space(3))) u32*)lds + wv * WSTR) + lane_id();
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { st[k * 64] = x[k]; }
+                        asm volatile("" ::: "memory");
+                    }
+#endif
+                    if constexpr (pipe_issued(r + 1) > pipe_issued(r)) {
+                        constexpr int n = pipe_issued(r);    // the next pair, requested now that its registers are free
+                        U[n] = ld_issue(sbk(src, n * NT), tb); V[n] = ld_issue(sbk(src, HH + n * NT), tb);
+                    }
+                });
+            } else
+#endif
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += SG) {
                 u64 U[SG], V[SG];
 #pragma unroll
                 for (int r = 0; r < SG; ++r) { U[r] = ld_issue(sbk(src, (r0 + r) * NT), tb); V[r] = ld_issue(sbk(src, HH + (r0 + r) * NT), tb); }
                 ld_wait(U, V);
-                // digits of a foreign modulus (Decompose) may be far above q: bring them to (-q, q) first.  MODE 0 (q up to 2^60)
-                // has no headroom for five stages on raw inputs and always starts from reduced values.
                 if (big || red) {
 #pragma unroll
                     for (int r = 0; r < SG; ++r) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); __builtin_amdgcn_sched_barrier(0); }
