@@ -192,6 +192,7 @@ class Context {
     Mod* d_mods = nullptr;
     u64 *d_psi = nullptr, *d_psiinv = nullptr, *d_inv_aux = nullptr;
     u64* d_psi31n = nullptr;                     // [mall][4][2]: pairs of -psi[1..3] (NttBatch::psi31n)
+    std::vector<unsigned char> h16_sched_;       // per modulus: NttBatch::sched
     unsigned long long u_mods_ = 0;              // bit m: modulus m is of the H16 kernel's U class (NttBatch::u_mods)
     u64* d_psi31 = nullptr;                      // logN >= 15: twiddle pairs of the H16 kernel's one-round product (NttBatch::psi31)
     bool h16_gap_ = false;                       // some modulus has 31q < 2^62 <= 48q: H16's signed ranges do not cover it

@@ -178,6 +178,25 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
             }
         }
         d_psi31 = dev_upload(p31); d_psi31n = dev_upload(p31n);
+        // Reduction schedule of the balanced path for inputs below 2^60 (canonical digits of any modulus): the never-reduced values must stay
+        // below 2^62.9 (column sums of mm31) and grow by at most 1.03q per one-round stage (q + |x| q / 2^64) and q/2 + |x|/16 per two-round
+        // stage of phase D; a partial reduction leaves |x| <= 0.51q.  Greedy from the load: reduce only where the next phase would overflow.
+        static const int lightsched = [] { const char* e = getenv("MKHE_H16_SCHED"); return (e && *e) ? atoi(e) : 1; }();
+        h16_sched_.assign(mall, 15);
+        for (int i = 0; i < mall && lightsched; ++i) {
+            const double q = (double)moduli[i], H = 0.98 * 8.6e18 / q;          // 2^62.9 = 8.606e18, 2 % of slack on the bound
+            double b = 1152921504606846976.0 / q;                                // 2^60 / q
+            int sc = 0;
+            if (b + 5 * 1.04 > H) { sc |= 1; b = 0.51; }
+            b += 5 * 1.04;                                                       // stage 0 + phase A
+            if (b + 4 * 1.04 > H) { sc |= 2; b = 0.51; }
+            b += 4 * 1.04;                                                       // phase B
+            if (b + 4 * 1.04 > H) { sc |= 4; b = 0.51; }
+            b += 4 * 1.04;                                                       // phase C
+            // phase D runs on the two-round product, whose second round needs |a| < 2^62 (mont_mul_sd: m2 q0 + a1 w0 + ... < 2^63)
+            if (b > 0.98 * 4.611686018427388e18 / q) sc |= 8;
+            h16_sched_[i] = (unsigned char)sc;
+        }
     }
 
     std::vector<int> map((size_t)nq * mtot, 0), ident(mtot);
@@ -517,6 +536,7 @@ void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
 void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     NttBatch b = b_in;
     b.psi31 = d_psi31; b.psi31n = d_psi31n; b.u_mods = u_mods_; b.no_h16 = d_psi31 ? 0 : 1;
+    for (int i = 0; i < mall && i < NTT_MAX_SLOTS; ++i) b.sched[i] = h16_sched_.empty() ? 15 : h16_sched_[i];
     if (ntt16_ok(logN, b)) {
         ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;

@@ -412,7 +412,7 @@ template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds
 
 // ------------------------------------------------------------------ one limb
 // what one limb needs, all wave-uniform
-struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* psi31n; smodptr mp; bool red; bool skip_norm; int root; u64* trace; };
+struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* psi31n; smodptr mp; bool red; bool skip_norm; int root; u64* trace; int sched; };
 // diagnostic build (make trace): shader-clock stamps per wave and pass, 32 words per (job, wave): [16 * pass + k], see tools/ntt16_trace.py
 // (every lane stores the same word: a lane-0 branch here makes the compiler lose the uniformity of the scalar twiddle loads)
 #ifdef MKHE_PHASE_TRACE
@@ -463,7 +463,11 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         // a third of what this kernel moved through HBM, and memory is what bounds it once the butterflies are cheap
         // (tools/ubench + the MKHE_H16_X_* ablations: 245 us of a 367 us launch remain with every butterfly removed).
         // In place (src == dst) pass 0's results overwrite the source: the upper outputs are parked as before.
+#ifdef MKHE_H16_FORCE_PARK      // experiment: park the upper stage-0 outputs in the destination limb also out of place (no recompute, no source re-read)
+        const bool park = true;
+#else
         const bool park = (const void*)src == (const void*)dst;
+#endif
         if (h == 0 || !park) {
             u64 w1[2] = {p31[2 * tm], p31[2 * tm + 1]};
             if (h != 0) {
@@ -498,7 +502,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
                     ld_wait_pair<2 * (pipe_issued(r) - r - 1)>(U[r], V[r]);
                     // digits of a foreign modulus (Decompose) may be far above q: bring them to (-q, q) first.  MODE 0 (q up to 2^60)
                     // has no headroom for five stages on raw inputs and always starts from reduced values.
-                    if (big || red) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); }
+                    if ((big && (jb.sched & 1)) || red) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); }
                     const i64 T = UC ? mm30u<true>((i64)V[r], w1[0], w1[1], c) : mm31<true>((i64)V[r], w1[0], w1[1], c);
                     x[r] = (u64)((i64)U[r] + T);
                     __builtin_amdgcn_sched_barrier(0);       // one butterfly at a time
@@ -524,7 +528,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
 #pragma unroll
                 for (int r = 0; r < SG; ++r) { U[r] = ld_issue(sbk(src, (r0 + r) * NT), tb); V[r] = ld_issue(sbk(src, HH + (r0 + r) * NT), tb); }
                 ld_wait(U, V);
-                if (big || red) {
+                if ((big && (jb.sched & 1)) || red) {
 #pragma unroll
                     for (int r = 0; r < SG; ++r) { U[r] = (u64)pred((i64)U[r], c); V[r] = (u64)pred((i64)V[r], c); __builtin_amdgcn_sched_barrier(0); }
                 }
@@ -596,7 +600,11 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
             stage31<UC, 0, 0, 4>(x, ta, c);
             stage31<UC, 0, 4, 4>(x, tb, c);
         }
-        reduce_all(x, c, big);                  // MODE 0: |x| < 6.4q < 2^62.7 after stage 0 + phase A (five stages of up to q + |x|/16 each) -> (-q, q)
+        // The 59/60-bit primes: partial reductions where the schedule of the modulus asks for them (NttBatch::sched, computed by the Context from
+        // the headroom 2^62.9 / q: bit 0 at the load, bits 1..3 after phases A, B, C).  Round 2 reduced after every phase; the 60-bit head prime
+        // needs it after A and B only (raw digits < 2^60 = q: 1 + 5 stages of 1.03q = 6.2q < 7.46q; then 0.5 + 4.1; C and D add 4.1 + 1.6), the
+        // 59-bit special primes after A only.
+        reduce_all(x, c, big && (jb.sched & 2));
         H16_STAMP(2);
         exchange<X_AB>(x, lds, wv);
         H16_STAMP(3);
@@ -620,7 +628,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
             stage31<UC, 0, 0, 4>(x, ta, c);
             stage31<UC, 0, 4, 4>(x, tb, c);
         }
-        reduce_all(x, c, big);                  // MODE 0: |x| < 5.1q after the four one-round stages of phase B -> (-q, q): phase C may add 2.7q
+        reduce_all(x, c, big && (jb.sched & 4));
         // Phases C and D: per-lane twiddles, fetched in 16-byte groups a few butterflies ahead of their use (at most three groups =
         // 12 VGPRs live; issuing all 15 + 12 at once would not fit beside the 32 data registers).  The first groups of a phase are
         // requested before the re-distribution that precedes it.
@@ -655,7 +663,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
                 else bfly1_31<UC, 0>(x, gi, g[t % RING], c);
             }
         }
-        reduce_all(x, c, big);                  // MODE 0: |x| < 5.8q < 2^62.6 after the four stages of phase C -> (-q, q)
+        reduce_all(x, c, big && (jb.sched & 8));
 #ifdef MKHE_H16_D31
         constexpr bool D31 = true;
 #else
@@ -780,6 +788,7 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         jb.psi = kb->psi + (long)m * (SPLIT ? 2 * NN : NN);
         jb.psi31 = kb->psi31 + 2 * (long)m * (SPLIT ? 2 * NN : NN);
         jb.psi31n = kb->psi31n + 8 * (long)m;
+        jb.sched = kb->src_lazy ? 15 : kb->sched[m];        // lazy (BFV) digits reach 2^62: the schedule of round 2
         jb.root = 1;
         if constexpr (SPLIT) { const int half = job2 & 1; jb.src += half * NN; jb.dst += half * NN; jb.root = 2 + half; }
         jb.mp = (smodptr)kb->mods + m;

@@ -69,6 +69,8 @@ struct NttBatch {
     const u64* psi31n;      // [nmod][4][2]: the pairs of -psi[1], -psi[2], -psi[3] (entries 1..3), for the second pass of the cross-half stage
     unsigned long long u_mods;   // bit m set = modulus m is of the U class (160 q < 2^62): its psi31 rows hold the UNSIGNED radix-2^30 format
                             // (u = w 2^30 mod q in [0, q) as digits u0, u1 >= 0; v = w 2^62 mod q balanced) of ntt16_kernels.hip mm30u
+    unsigned char sched[NTT_MAX_SLOTS];   // ntt16_kernels.hip, indexed by MODULUS: where a limb of a 59/60-bit modulus gets its partial reductions when its
+                            // inputs are below 2^60 (bit 0: at the load, bits 1..3: after phases A, B, C); Context::h16_sched_
     int no_h16;             // this context has a modulus the H16 kernel's ranges do not cover (48q >= 2^62 > 31q): keep to the other kernels
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
     int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists
