@@ -170,7 +170,50 @@ def run_distributed(args):
     # rank's share of the work (its launch sizes shrink with N: a "sharded k=.. N=.." workload tag keeps the single-GPU PMC traffic out)
     from bench import roofline_leg
     roofline = roofline_leg(args, params, step_party, pset["logN"], "%s k=%d sharded over %d" % (args.params, k, world))
-    del smr, backend, rlk
+    # ---- self-validation + replica leg (round 3).  Every rank builds the full key set and evaluates the SAME MulRelin on its own GPU
+    # (the single-GPU path of bench.py): rank 0 compares the sharded result with it byte for byte (config.matches_single_gpu) and, with
+    # host key material, with the CPU oracle (cpu_baseline.bit_exact_vs_gpu); timed under the same contract, the N independent
+    # evaluations are the replica leg (weak scaling: N MulRelins per step, no data-path collective) reported beside the strong-scaling
+    # `value` -- DESIGN.md section 7 says which one the link model expects to win.
+    sharded = res.download() if rank == 0 else None
+    rlk_all = mkrlwe.RelinearizationKeySet(params)
+    host_keys = {}
+    for n in names:
+        kb = party_keys(n)
+        if device_keys:
+            key = mkrlwe.RelinearizationKey.__new__(mkrlwe.RelinearizationKey)      # wraps the expanded handles, nothing allocated
+            key.ID, key.Value = n, list(kb)
+            rlk_all.AddRelinearizationKey(key)
+        else:
+            host_keys[names.index(n)] = kb
+            rlk_all.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, n, *kb))
+    ct0 = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(op0)
+    ct1 = mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(op1)
+    ev1 = mkckks.NewEvaluator(params)
+    single = ev1.MulRelinNew(ct0, ct1, rlk_all)
+    matches = bool(rank != 0 or (sharded.shape == tuple(single.download().shape) and (sharded == single.download()).all()))
+    def step_replica():
+        return ev1.MulRelinNew(ct0, ct1, rlk_all)
+    dt = _timed(dist, torch, params, step_replica, args.steps, args.warmup)
+    legs["replicas"] = dict(mulrelin_per_sec=world * args.steps / dt, ms_per_step=dt * 1e3 / args.steps, scaling="weak",
+                            note="every GPU evaluates its own %d-party MulRelin with all keys resident: N per step, no collective" % k)
+    cpu = None
+    if rank == 0 and not args.no_cpu and not device_keys:
+        from oracle import oracle as O
+        ks = O.KeySwitcher(pset["logN"], pset["Q"], pset["P"], 2)
+        ids = list(range(k))
+        u_h = synth_swk(pset, np.random.default_rng(args.seed + 7))
+        nth = min(os.cpu_count() or 1, len(pset["Q"]) + len(pset["P"]))
+        O.set_threads(nth)
+        t0 = time.perf_counter()
+        _, ref = ks.mul_and_relin(level, ids, op0, ids, op1, host_keys, u_h)
+        ref = np.stack([ks.ringQ.div_round_last_many(ref[s_], 1)[0] for s_ in range(1 + k)])
+        cdt = time.perf_counter() - t0
+        O.set_threads(1)
+        cpu = dict(value=1.0 / cdt, unit="MulRelin/s", cores=nth, kind="port",
+                   sample="1 full %d-party MulRelin (%s), oracle with its limb loops on %d host threads of rank 0, %.1f s" % (k, args.params, nth, cdt),
+                   bit_exact_vs_gpu=bool((sharded == ref).all()))
+    del smr, backend, rlk, rlk_all, host_keys, ev1, single, ct0, ct1
     # ---- hoisted Rotate, parties sharded (BASELINE.json configs[3]: "MulRelin + hoisted Rotate")
     rot = 1
     mine = assign_parties(names, world)[rank]
@@ -224,8 +267,9 @@ def run_distributed(args):
                                         % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["P"]), world),
                                parties=k, params=args.params, seed=args.seed, rccl_ranks=dist.get_world_size(),
                                key_material="device" if device_keys else "host",
-                               sharding="parties (mkhe_kklss_amd/dist.py ShardedMulRelin); secondary legs below", legs=legs),
-                   roofline=roofline, cpu_baseline=None)
+                               sharding="parties (mkhe_kklss_amd/dist.py ShardedMulRelin); secondary legs below", legs=legs,
+                               matches_single_gpu=matches),
+                   roofline=roofline, cpu_baseline=cpu)
     dist.barrier()
     dist.destroy_process_group()
     return out

@@ -416,7 +416,12 @@ def test_bench_gpus_2_self_launch_on_one_gpu():
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["scaling"] == "strong"
     assert out["value"] > 0 and out["steps"] == 2 and out["warmup"] == 1
     legs = out["config"]["legs"]
-    assert {"party", "rotate_hoisted", "limb"} <= set(legs) and all(v["ms_per_step"] > 0 for v in legs.values())
+    assert {"party", "rotate_hoisted", "limb", "replicas"} <= set(legs) and all(v["ms_per_step"] > 0 for v in legs.values())
+    # round 3: the line validates itself -- the sharded result equals rank 0's single-GPU evaluation of the same inputs and the CPU
+    # oracle's (run on rank 0 after the timed legs), and the replica leg (weak scaling) stands beside the strong-scaling value
+    assert out["config"]["matches_single_gpu"] is True
+    assert out["cpu_baseline"] is not None and out["cpu_baseline"]["bit_exact_vs_gpu"] is True and out["cpu_baseline"]["value"] > 0
+    assert legs["replicas"]["scaling"] == "weak" and legs["replicas"]["mulrelin_per_sec"] > 0
 
 
 # ---------------------------------------------------------------- mkbfv, parties sharded (whole parties per rank)
