@@ -234,7 +234,7 @@ int  mkhe_bfv_external_product_hoisted(mkhe_ctx* ctx, const mkhe_swk* ah1, const
 /* Evaluator.MulRelinNew (mkbfv/evaluator.go:78-82) = mulRelinHoisted (:118-140) + MulAndRelinBFVHoisted
  * (keyswitch_hoisted.go:36-206).  The reference's non-hoisted twin (Evaluator.mulRelin evaluator.go:95-113 ->
  * KeySwitcher.MulAndRelinBFV keyswitch.go:115-251) decomposes the same polynomials inside its loops and yields the same
- * ciphertext bit for bit (tests/test_bfv_oracle.py); on the device the decompositions are always batched, so both map here.
+ * ciphertext bit for bit (tests/test_bfv_oracle.py); it has its own device path below (mkhe_bfv_mul_relin_unhoisted).
  * Ciphertexts at the maximum level, coefficient domain.  Key lists aligned with
  * the operand ids: rlk_b1/b2[j] = rlkSet[ids1[j]].Value[0/1].Value[0], rlk_d1/d2[i] = rlkSet[ids0[i]].Value[0/1].Value[1],
  * rlk_v[i] = rlkSet[ids0[i]].Value[0].Value[2]; crs_u = params.CRS[-1]. */
@@ -242,6 +242,15 @@ int  mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                         const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
                         const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2,
                         const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out);
+/* Evaluator.mulRelin (mkbfv/evaluator.go:95-113) -> KeySwitcher.MulAndRelinBFV (mkbfv/keyswitch.go:115-251): the reference's NON-hoisted
+ * twin as its own device path, in the reference's order and with its pool discipline -- one pair of digit vectors that every
+ * DecomposeBFV overwrites (each party component is decomposed twice), x / y accumulated party by party, every ExternalProductBFV /
+ * ExternalProduct on its own.  Same arguments and the same ciphertext, bit for bit, as mkhe_bfv_mul_relin (tests/test_gpu_bfv.py); 2 digit
+ * vectors of scratch instead of 4k, about twice the forward NTTs. */
+int  mkhe_bfv_mul_relin_unhoisted(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                                  const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
+                                  const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2,
+                                  const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out);
 /* Party-sharded BFV MulRelinNew (no reference counterpart; mkhe_kklss_amd/dist.py ShardedBfvMulRelin; keyswitch_hoisted.go:76-206
  * is the structure being cut): every rank holds c_0 and BOTH components of the parties it owns (Quantize rounds, so the two tensor
  * terms of an output slot must meet on one rank).  mkhe_bfv_mr_partial: conversions, tensor + Quantize into `out` (out_0 only where

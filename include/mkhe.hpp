@@ -510,7 +510,9 @@ class Evaluator {
     explicit Evaluator(Parameters& p) : params(p), ksw(p) {}
     CiphertextPtr AddNew(const Ciphertext& op0, const Ciphertext& op1) { auto o = bin(op0, op1); check(mkhe_ct_add(params.ctx, op0.h, op1.h, o->h)); return o; }   // :44-52
     CiphertextPtr SubNew(const Ciphertext& op0, const Ciphertext& op1) { auto o = bin(op0, op1); check(mkhe_ct_sub(params.ctx, op0.h, op1.h, o->h)); return o; }   // :54-76
-    CiphertextPtr MulRelinNew(const Ciphertext& op0, const Ciphertext& op1, RelinearizationKeySet& rlkSet) {                       // evaluator.go:78-82,118-140
+    // evaluator.go:95-113 -> KeySwitcher.MulAndRelinBFV (keyswitch.go:115-251): the non-hoisted twin on its own device path
+    CiphertextPtr mulRelin(const Ciphertext& op0, const Ciphertext& op1, RelinearizationKeySet& rlkSet) { return MulRelinNew(op0, op1, rlkSet, false); }
+    CiphertextPtr MulRelinNew(const Ciphertext& op0, const Ciphertext& op1, RelinearizationKeySet& rlkSet, bool hoisted = true) {  // evaluator.go:78-82,118-140
         if (!params.CRS.count(-1)) throw Error("mkhe: CRS[-1] (u) has not been uploaded");
         auto out = bin(op0, op1);
         std::vector<const mkhe_swk*> b1, b2, d1, d2, v;
@@ -519,7 +521,7 @@ class Evaluator {
             auto& k = rlkSet.GetRelinearizationKey(i);
             d1.push_back(k.Value[0]->Value[1]->h); d2.push_back(k.Value[1]->Value[1]->h); v.push_back(k.Value[0]->Value[2]->h);
         }
-        check(mkhe_bfv_mul_relin(params.ctx, op0.h, op1.h, b1.data(), b2.data(), d1.data(), d2.data(), v.data(), params.CRS[-1]->h, out->h));
+        check((hoisted ? mkhe_bfv_mul_relin : mkhe_bfv_mul_relin_unhoisted)(params.ctx, op0.h, op1.h, b1.data(), b2.data(), d1.data(), d2.data(), v.data(), params.CRS[-1]->h, out->h));
         return out;
     }
     CiphertextPtr RotateNew(const Ciphertext& ct0, int rotidx, mkrlwe::RotationKeySet& rkSet) {                                    // evaluator.go:142-180 (precomputed indices)

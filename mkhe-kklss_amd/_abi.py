@@ -85,6 +85,7 @@ SIGNATURES = {
     "mkhe_bfv_mr_partial": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, C.c_int, vp, vp, vp, vp, vp]),
     "mkhe_bfv_mr_finish": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vpp, vp, vp]),
     "mkhe_bfv_mul_relin": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),
+    "mkhe_bfv_mul_relin_unhoisted": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),
     "mkhe_keygen_secret": (C.c_int, [vp, s32p, vp]),
     "mkhe_keygen_switching_key": (C.c_int, [vp, vp, s32p, vp]),
     "mkhe_keygen_public_key": (C.c_int, [vp, vp, s32p, vp, vp]),

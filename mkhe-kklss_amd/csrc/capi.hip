@@ -495,6 +495,18 @@ int mkhe_bfv_mul_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
     })
 }
 
+int mkhe_bfv_mul_relin_unhoisted(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                                 const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
+                                 const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2,
+                                 const mkhe_swk* const* rlk_v, const mkhe_swk* crs_u, mkhe_ct* out) {
+    MKHE_TRY({ mark(ctx, op0, op1, crs_u, out);
+        if (!op0 || !op1 || !out || !crs_u || !rlk_b1 || !rlk_b2 || !rlk_d1 || !rlk_d2 || !rlk_v) throw Error("mkhe_bfv_mul_relin_unhoisted: null argument");
+        auto b1 = swk_list(ctx, rlk_b1, op1->c.n); auto b2 = swk_list(ctx, rlk_b2, op1->c.n);
+        auto d1 = swk_list(ctx, rlk_d1, op0->c.n); auto d2 = swk_list(ctx, rlk_d2, op0->c.n); auto v = swk_list(ctx, rlk_v, op0->c.n);
+        need(ctx)->bfv_mul_relin_unhoisted(op0->c, op1->c, b1.data(), b2.data(), d1.data(), d2.data(), v.data(), crs_u->s, out->c);
+    })
+}
+
 int mkhe_bfv_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                         const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_b2,
                         const mkhe_swk* const* rlk_d1, const mkhe_swk* const* rlk_d2, int with_c0, mkhe_ct* out,

@@ -89,6 +89,8 @@ class Context {
                        const Swk* const* rlk_v, const Swk& crs_u, Ct& out);
     void bfv_slots(const Ct& op0, const Ct& op1, const Ct& out, std::vector<int>& slot0, std::vector<int>& slot1) const;
     bool bfv_plan_valid_ = false;
+    void bfv_mul_relin_unhoisted(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
+                                 const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v, const Swk& crs_u, Ct& out);
     void bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
                        const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
                        const Swk& crs_u, Ct& out);                            // Evaluator.MulRelinNew

@@ -1601,4 +1601,80 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
     bfv_mr_finish(op0, op1, x_, x2_, y_, y2_, rlk_v, crs_u, out);
 }
 
+// Evaluator.mulRelin (mkbfv/evaluator.go:95-113) -> KeySwitcher.MulAndRelinBFV (mkbfv/keyswitch.go:115-251): the NON-hoisted twin, restated
+// in the reference's own order with its pool discipline -- ONE pair of digit vectors (ks.swkPool1 / swkPool2) that every DecomposeBFV
+// overwrites, so every party component is decomposed twice (once for its term of x or y, once inside ExternalProductBFV) and the digit
+// scratch is 2 vectors instead of 4k; x1, x2, y1, y2 grow party by party through MulCoeffsMontgomeryAndAdd (InnerProductArgs::addend) and
+// are MForm'ed by the call of the last party; every ExternalProductBFV / ExternalProduct is its own Decompose + inner product + InvNTTLazy +
+// ModDown + AddLvl (no batching over parties, no merged ModDown, no x by-product).  Same integers as bfv_mul_relin (the products are exact
+// residues and every sum is canonical), checked bit for bit on the device in tests/test_gpu_bfv.py.
+void Context::bfv_mul_relin_unhoisted(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
+                                      const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
+                                      const Swk& crs_u, Ct& out) {
+    if (!is_bfv()) throw Error("mkhe: not a BFV context");
+    const int level = nq - 1, L = nq, n0 = op0.n, n1 = op1.n;
+    std::vector<int> slot0, slot1;
+    bfv_slots(op0, op1, out, slot0, slot1);
+    for (int a = 0; a < n0; ++a) if (!rlk_d1[a] || !rlk_d2[a] || !rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+    for (int a = 0; a < n1; ++a) if (!rlk_b1[a] || !rlk_b2[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+    const size_t PR = 2 * (size_t)nq * N, PQ = (size_t)nq * N;
+    const int np0 = 1 + n0, np1 = 1 + n1, npo = 1 + out.n;
+    u64* rb = scratch(rbuf_, rbuf_words_, (size_t)(2 * (np0 + np1) + npo) * PR);
+    u64 *r0 = rb, *r1 = rb + (size_t)np0 * PR, *f0 = r1 + (size_t)np1 * PR, *f1 = f0 + (size_t)np0 * PR, *tz = f1 + (size_t)np1 * PR;
+    bfv_modup_q_to_r(op0.d, r0, np0);                  // evaluator.go:102-105
+    bfv_rescale(op1.d, r1, np1);                       // evaluator.go:107-110
+    u64* p1 = hoist_slot(3, 0).d; u64* p2 = hoist_slot(3, 1).d;        // ks.swkPool1, ks.swkPool2
+    const int nslots = L + np;
+    // x1, x2 (keyswitch.go:157-171), then y1, y2 (:173-187)
+    for (int side = 0; side < 2; ++side) {
+        const int n = side ? n1 : n0;
+        u64* s1 = side ? y_ : x_; u64* s2 = side ? y2_ : x2_;
+        if (n == 0) { MKHE_HIP(hipMemsetAsync(s1, 0, swk_words() * sizeof(u64), s_)); MKHE_HIP(hipMemsetAsync(s2, 0, swk_words() * sizeof(u64), s_)); }
+        for (int a = 0; a < n; ++a) {
+            bfv_decompose_batch({(side ? r1 : r0) + (size_t)(1 + a) * PR}, {p1}, {p2}, true);
+            for (int half = 0; half < 2; ++half) {
+                InnerProductArgs ip{};
+                ip.a[0] = (side ? (half ? rlk_b2[a] : rlk_b1[a]) : (half ? rlk_d2[a] : rlk_d1[a]))->d;
+                ip.b[0] = half ? p2 : p1;
+                ip.out = half ? s2 : s1;
+                ip.addend = a ? ip.out : nullptr;          // the pool vector was zeroed at :146-155
+                ip.mods = d_mods; ip.map = map_qp(level);
+                ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = 1; ip.nslots = nslots; ip.nouter = beta_max; ip.N = N;
+                ip.mform_out = a == n - 1 ? 1 : 0;         // MFormLvl after the last party (:168-171, :184-187)
+                { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * beta_max * (a ? 4.0 : 3.0)); launch_inner_product(ip, s_); }
+            }
+        }
+    }
+    // tensor over R + Quantize (:189-233), in the batched form of bfv_mr_partial (same kernels, same integers)
+    {
+        ntt_r(r0, f0, np0 + np1, false);
+        TensorArgs ta{};
+        ta.a0 = f0; ta.b0 = f1; ta.out = tz; ta.mods = d_mods; ta.map = d_map_r; ta.scale = d_t_mont;
+        ta.nout = out.n; ta.L = 2 * nq; ta.N = N; ta.with_c0 = 1;
+        for (int a = 0; a < n0; ++a) { ta.a[1 + slot0[a]] = f0 + (size_t)(1 + a) * PR; ta.a_ls[1 + slot0[a]] = N; }
+        for (int a = 0; a < n1; ++a) { ta.b[1 + slot1[a]] = f1 + (size_t)(1 + a) * PR; ta.b_ls[1 + slot1[a]] = N; }
+        { ProfScope ps(this, PROF_TENSOR, 8.0 * N * 2 * nq * (2.0 + n0 + n1 + npo)); launch_tensor(ta, s_); }
+        ntt_r(tz, tz, npo, true);
+        BasisConvArgs qa{};
+        quantize_tail_args(qa, *this, tz, out.d, npo);
+        { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npo * 3.0 * nq); launch_basis_conv(qa, s_); }
+    }
+    // ctOut_j += ExternalProductBFV(op1_j, x1, x2)   (:235-239)
+    for (int a = 0; a < n1; ++a) {
+        bfv_decompose_batch({r1 + (size_t)(1 + a) * PR}, {p1}, {p2}, true);
+        ExtItem it{p1, x_, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = p2; it.bg2 = x2_;
+        ext_batch(level, {it});
+    }
+    // t = ExternalProductBFV(op0_i, y1, y2); ctOut_0 += ExternalProduct(t, v_i); ctOut_i += ExternalProduct(t, u)   (:241-250)
+    u64* t = scratch(tbuf_, tbuf_words_, PQ);
+    for (int a = 0; a < n0; ++a) {
+        bfv_decompose_batch({r0 + (size_t)(1 + a) * PR}, {p1}, {p2}, true);
+        ExtItem it{p1, y_, t, false}; it.ah2 = p2; it.bg2 = y2_;
+        ext_batch(level, {it});
+        external_product(level, false, t, rlk_v[a]->d, out.d, true);
+        external_product(level, false, t, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true);
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
 }  // namespace mkhe

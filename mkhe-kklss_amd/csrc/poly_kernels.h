@@ -25,6 +25,8 @@ struct InnerProductArgs {
     long out_outer;
     int nterms, nslots, nouter, N;
     int mform_out;           // apply MFormLvl to the sum (keyswitch_hoisted.go:94-96,115-117)
+    const u64* addend;       // optional running sum (canonical, laid out like out; may be out itself): the products are added to it --
+                             // MulCoeffsMontgomeryAndAddLvl onto a pool vector, mkbfv/keyswitch.go:160-189
 };
 void launch_inner_product(const InnerProductArgs& a, hipStream_t st);
 

@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(PW_THREADS) inner_product_kernel(InnerProductA
     if (n >= a.N) return;
     const int nt = NT ? NT : a.nterms;
     u64 acc0 = 0, acc1 = 0;
+    if (a.addend) { const u64x2 p = ld_cached(a.addend + obase + n); acc0 = p.x; acc1 = p.y; }      // canonical: < q < 2q
     if constexpr (NT != 0) {
         u64x2 x[NT], y[NT];
 #pragma unroll

@@ -201,13 +201,12 @@ class Evaluator:
         return ctOut
 
     def mulRelin(self, op0, op1, rlkSet):
-        """evaluator.go:95-113 -> KeySwitcher.MulAndRelinBFV (keyswitch.go:115-251): the non-hoisted twin of mulRelinHoisted.
-        It decomposes the same polynomials inside its loops and returns the same ciphertext bit for bit
-        (checked on the CPU restatement: hoisted == non-hoisted); the engine always batches the decompositions, so both map to
-        the one device entry point."""
-        return self.MulRelinNew(op0, op1, rlkSet)
+        """evaluator.go:95-113 -> KeySwitcher.MulAndRelinBFV (keyswitch.go:115-251): the non-hoisted twin of mulRelinHoisted, on its
+        own device path (mkhe_bfv_mul_relin_unhoisted: the reference's order and pool discipline, every party component decomposed
+        twice into one pair of pool vectors); the same ciphertext bit for bit."""
+        return self.MulRelinNew(op0, op1, rlkSet, hoisted=False)
 
-    def MulRelinNew(self, op0, op1, rlkSet):
+    def MulRelinNew(self, op0, op1, rlkSet, hoisted=True):
         """evaluator.go:78-82 -> mulRelinHoisted (:118-140)"""
         params = self.params
         if -1 not in params.CRS:
@@ -220,8 +219,9 @@ class Evaluator:
         d1 = [k.Value[0].Value[1].h for k in k0]
         d2 = [k.Value[1].Value[1].h for k in k0]
         v = [k.Value[0].Value[2].h for k in k0]
-        check(lib().mkhe_bfv_mul_relin(params.ctx, op0.h, op1.h, handle_array(b1), handle_array(b2), handle_array(d1),
-                                       handle_array(d2), handle_array(v), params.CRS[-1].h, ctOut.h))
+        fn = lib().mkhe_bfv_mul_relin if hoisted else lib().mkhe_bfv_mul_relin_unhoisted
+        check(fn(params.ctx, op0.h, op1.h, handle_array(b1), handle_array(b2), handle_array(d1),
+                 handle_array(d2), handle_array(v), params.CRS[-1].h, ctOut.h))
         return ctOut
 
     def RotateNew(self, ct0, rotidx, rkSet):

@@ -69,6 +69,20 @@ func (ctx *Context) MulRelinBFV(op0, op1 *Ciphertext, ids0, ids1 []string, rk *B
 	must(C.mkhe_bfv_mul_relin(ctx.c, op0.h, op1.h, b1, b2, d1, d2, v, crsU.h, out.h))
 }
 
+// MulRelinBFVUnhoisted is the body of mkbfv.Evaluator.mulRelin (evaluator.go:95-113) -> KeySwitcher.MulAndRelinBFV
+// (keyswitch.go:115-251), the non-hoisted twin: same arguments and the same ciphertext as MulRelinBFV, the reference's own order of
+// operations on one pair of pool digit vectors.
+func (ctx *Context) MulRelinBFVUnhoisted(op0, op1 *Ciphertext, ids0, ids1 []string, rk *BFVRelinKeys, crsU *SwitchingKey, out *Ciphertext) {
+	b1, b2 := swkList(ids1, rk.B1), swkList(ids1, rk.B2)
+	d1, d2, v := swkList(ids0, rk.D1), swkList(ids0, rk.D2), swkList(ids0, rk.V)
+	defer func() {
+		for _, p := range []**C.mkhe_swk{b1, b2, d1, d2, v} {
+			C.free(unsafe.Pointer(p))
+		}
+	}()
+	must(C.mkhe_bfv_mul_relin_unhoisted(ctx.c, op0.h, op1.h, b1, b2, d1, d2, v, crsU.h, out.h))
+}
+
 // ExternalProductBFV is mkbfv.KeySwitcher.ExternalProductBFV (mkbfv/keyswitch.go:92-114, the non-hoisted form: DecomposeBFV of the
 // PolyR operand inside): polyR and out are raw device buffers (mkhe_buf_alloc) holding a PolyR (2l limbs) and a PolyQ (l limbs).
 func (ctx *Context) ExternalProductBFV(polyR unsafe.Pointer, bg1, bg2 *SwitchingKey, out unsafe.Pointer) {

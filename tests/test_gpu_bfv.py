@@ -166,6 +166,13 @@ def test_mul_relin_new(bp, ids0, ids1):
     _, ref2 = bp.bfv.mul_relin_new([idx[i] for i in ids0], h0, [idx[i] for i in ids0], h0,
                                    {idx[n]: rlk_h[n] for n in names}, u_h)
     assert (sq.download() == ref2).all()
+    # the reference's non-hoisted twin (Evaluator.mulRelin -> KeySwitcher.MulAndRelinBFV, mkbfv/keyswitch.go:115-251) on its own
+    # device path (mkhe_bfv_mul_relin_unhoisted): the same ciphertext bit for bit, also for the square and after the hoisted path has
+    # left its cached slots behind
+    un = bp.ev.mulRelin(c0, c1, rlk_d)
+    assert un.ids == out.ids and (un.download() == ref).all()
+    assert (bp.ev.mulRelin(c0, c0, rlk_d).download() == ref2).all()
+    assert (bp.ev.MulRelinNew(c0, c1, rlk_d).download() == ref).all()
 
 
 def test_missing_rlk_raises(bp):
@@ -176,6 +183,8 @@ def test_missing_rlk_raises(bp):
     bp.params.CRS[-1] = u_d
     with pytest.raises(MkheError, match="cannot GetRelinearizationKey"):
         bp.ev.MulRelinNew(c0, c0, rlk_d)
+    with pytest.raises(MkheError, match="cannot GetRelinearizationKey"):
+        bp.ev.mulRelin(c0, c0, rlk_d)
 
 
 def test_add_sub(bp):

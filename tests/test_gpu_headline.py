@@ -160,6 +160,8 @@ def test_bfv_pn15_mulrelin_new(parties):
     _, ref = HB.make_bfv(pset).mul_relin_new(ids, data["op0"], ids, data["op1"], data["rlk"], data["u"])
     got = res.download()
     assert got.shape == ref.shape and (got == ref).all()
+    if parties == 2:      # the non-hoisted twin at full size (mkbfv/keyswitch.go:115-251; its own device path)
+        assert (mkbfv.NewEvaluator(params).mulRelin(ct0, ct1, rlk).download() == ref).all()
     params.close()
 
 
