@@ -144,7 +144,7 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
     for (auto& v : psiinv) v = sd_split(v);
     for (auto& v : aux) v = sd_split(v);
     d_mods = dev_upload(mods); d_psi = dev_upload(psi); d_psiinv = dev_upload(psiinv); d_inv_aux = dev_upload(aux);
-    if (logN >= 15 && !h16_gap_) {
+    if (logN >= 14 && !h16_gap_) {
         // one-round product of the H16 kernel: a * w = a0 * u + a1 * u' with u = w 2^31, u' = w 2^63 (mod q, balanced), then ONE Montgomery
         // round of radix 2^31.  psi holds w * 2^64 in signed-split form at this point: w * 2^31 = psi * 2^-33.
         // Round 3, "U class" (160 q < 2^62: 4q of input + 75q of growth either way + the 75q bias of internal digits): the data word enters
@@ -540,7 +540,7 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     if (ntt16_ok(logN, b)) {
         ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;
-        launch_ntt16_fwd(bt, small_q_.data(), s_);
+        launch_ntt16_fwd(bt, small_q_.data(), s_, logN);
         return;
     }
     if (decompose && ntt_fwd_mixed_ok(logN, b, small_q_.data())) {

@@ -428,10 +428,14 @@ struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* p
 // group i' of local stage k then uses the twiddle psi16[root * 2^k + i'], root = 2 + half, where a whole limb uses psi[2^k + i'].
 // UC: the modulus is of the U class (160 q < 2^62): mm30u, twiddle pairs in the unsigned radix-2^30 format, no reductions anywhere, every
 // stage (phase D included) on the one-round product.  The other instantiation serves the 59/60-bit primes (`big`) and the moduli in between.
-template <bool DEC, bool SPLIT, bool UC>
+// LOGN = 14 (round 3): a 2^14-point limb IS one pass of this kernel -- 1024 threads x 16 coefficients, no cross-half stage, the four register
+// phases with the twiddles of root 1 (psi[2^k + i]): in the index formulas below (root 2 tm + h of a 2^15-point limb's half h) that is
+// tm = 0 with the twiddle half ht = 1.
+template <bool DEC, bool SPLIT, bool UC, int LOGN = 15>
 __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, const int wv) {
+    static_assert(LOGN == 15 || (LOGN == 14 && !SPLIT), "H16 covers N = 2^15 (and its use on the halves of N = 2^16) and N = 2^14");
     const bool big = UC ? false : big_;
-    const int tm = SPLIT ? jb.root : 1;
+    const int tm = LOGN == 14 ? 0 : (SPLIT ? jb.root : 1);
     smodptr mp = jb.mp;                                 // scalar loads: the constants live in SGPRs
     const u64 qs = mp->qs;
     MC c;
@@ -453,8 +457,9 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
     const bool red = DEC && jb.red;
     u64 x[16];
 #pragma unroll 1
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < (LOGN == 15 ? 2 : 1); ++hh) {
         const int h = __builtin_amdgcn_readfirstlane(hh);
+        const int ht = LOGN == 14 ? 1 : h;              // the half as the twiddle indices see it
         H16_STAMP(0);
         // ---- stage 0: the cross-half butterflies.  Out of place (every Decompose launch: the source is a ciphertext limb) BOTH passes
         // load x[j], x[j + N/2] and keep their own output of the butterfly -- the second pass repeats 16 products per thread (1/15 of
@@ -464,10 +469,24 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         // (tools/ubench + the MKHE_H16_X_* ablations: 245 us of a 367 us launch remain with every butterfly removed).
         // In place (src == dst) pass 0's results overwrite the source: the upper outputs are parked as before.
 #ifdef MKHE_H16_FORCE_PARK      // experiment: park the upper stage-0 outputs in the destination limb also out of place (no recompute, no source re-read)
-        const bool park = true;
+        const bool park = LOGN == 15;
 #else
-        const bool park = (const void*)src == (const void*)dst;
+        const bool park = LOGN == 15 && (const void*)src == (const void*)dst;
 #endif
+        if constexpr (LOGN == 14) {
+            // the whole limb: registers = bits 13..10, thread = bits 9..0
+            const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
+            u64 lo8[8], hi8[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { lo8[r] = ld_issue(sbk(src, r * NT), tb); hi8[r] = ld_issue(sbk(src, (8 + r) * NT), tb); }
+            ld_wait16(lo8, hi8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { x[r] = lo8[r]; x[8 + r] = hi8[r]; }
+            if ((big && (jb.sched & 1)) || red) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { x[r] = (u64)pred((i64)x[r], c); __builtin_amdgcn_sched_barrier(0); }
+            }
+        } else
         if (h == 0 || !park) {
             u64 w1[2] = {p31[2 * tm], p31[2 * tm + 1]};
             if (h != 0) {
@@ -585,18 +604,18 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
             // = 120 SGPRs do not fit the SGPR budget of 8 waves per SIMD beside the job state, and every spilled SGPR costs VALU lane moves)
             u64 tw[6], tm4[8], ta[8], tb[8];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) tw[i] = p31[2 * (2 * tm + h) + i];
+            for (int i = 0; i < 2; ++i) tw[i] = p31[2 * (2 * tm + ht) + i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tw[2 + i] = p31[2 * (4 * tm + 2 * h) + i];
+            for (int i = 0; i < 4; ++i) tw[2 + i] = p31[2 * (4 * tm + 2 * ht) + i];
             stage31<UC, 3>(x, tw, c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tm4[i] = p31[2 * (8 * tm + 4 * h) + i];
+            for (int i = 0; i < 8; ++i) tm4[i] = p31[2 * (8 * tm + 4 * ht) + i];
             stage31<UC, 2>(x, tw + 2, c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ta[i] = p31[2 * (16 * tm + 8 * h) + i];
+            for (int i = 0; i < 8; ++i) ta[i] = p31[2 * (16 * tm + 8 * ht) + i];
             stage31<UC, 1>(x, tm4, c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tb[i] = p31[2 * (16 * tm + 8 * h + 4) + i];
+            for (int i = 0; i < 8; ++i) tb[i] = p31[2 * (16 * tm + 8 * ht + 4) + i];
             stage31<UC, 0, 0, 4>(x, ta, c);
             stage31<UC, 0, 4, 4>(x, tb, c);
         }
@@ -610,7 +629,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         H16_STAMP(3);
         // ---- phase B: bits 9..6, twiddles psi[2^k + ((16h + wave) << (k-5)) + i], k = 5..8
         {
-            const int cb = 16 * h + wv;
+            const int cb = 16 * ht + wv;
             u64 tw[6], tm4[8], ta[8], tb[8];
 #pragma unroll
             for (int i = 0; i < 2; ++i) tw[i] = p31[2 * (32 * tm + cb) + i];
@@ -637,7 +656,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         // butterflies use them in that order (8, 4, 4, 2, 2, 2, 2, 1 x 8 times), a ring of four pairs (16 VGPRs) keeps the next three in flight.
         {
             const int lc = lane_id();
-            const unsigned cu = (unsigned)((16 * h + wv) * 16 + (lc >> 2));
+            const unsigned cu = (unsigned)((16 * ht + wv) * 16 + (lc >> 2));
             __builtin_assume(cu < 512);
             u64 g[RING][2];
             gcptr p31v = (gcptr)jb.psi31;
@@ -673,7 +692,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         // two butterflies each) and 4..11 (k = 14)
         if constexpr (D31) {
             const int ld = lane_id();
-            const unsigned du = (unsigned)((16 * h + wv) * 64 + ld);
+            const unsigned du = (unsigned)((16 * ht + wv) * 64 + ld);
             __builtin_assume(du < 2048);
             u64 g[RING][2];
             gcptr p31v = (gcptr)jb.psi31;
@@ -698,7 +717,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         // (phase D keeps the two-round product on the balanced path: with pairs of constants per twiddle the register allocator spills around it)
         // ---- phase D: bits 1..0, twiddles psi[2^13 + 4d + i], psi[2^14 + 8d + i], d = (16h + wave) * 64 + lane
             const int ld = lane_id();
-            const unsigned du = (unsigned)((16 * h + wv) * 64 + ld);
+            const unsigned du = (unsigned)((16 * ht + wv) * 64 + ld);
             __builtin_assume(du < 2048);
             u64 g[6][2];
             auto loadg = [&](int k) {
@@ -755,8 +774,9 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
     }
 }
 
-template <bool DEC, bool SPLIT>
+template <bool DEC, bool SPLIT, int LOGN = 15>
 __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
+    constexpr int NL = 1 << LOGN;                 // words per limb = twiddle words per modulus
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int njobs = (b.nslots * b.nouter) << (SPLIT ? 1 : 0);
     // optional start delay of the second half of the persistent grid (the co-resident workgroup of every CU, as far as the
@@ -785,8 +805,8 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         Job jb;
         jb.src = (gcptr)(sbase_ + (long)outer * kb->src_outer + (long)(kb->src_mapped ? m : p) * kb->src_inner);
         jb.dst = (gptr)(dbase_ + (long)outer * kb->dst_outer + (long)(kb->dst_mapped ? m : p) * kb->dst_inner);
-        jb.psi = kb->psi + (long)m * (SPLIT ? 2 * NN : NN);
-        jb.psi31 = kb->psi31 + 2 * (long)m * (SPLIT ? 2 * NN : NN);
+        jb.psi = kb->psi + (long)m * (SPLIT ? 2 * NL : NL);
+        jb.psi31 = kb->psi31 + 2 * (long)m * (SPLIT ? 2 * NL : NL);
         jb.psi31n = kb->psi31n + 8 * (long)m;
         jb.sched = kb->src_lazy ? 15 : kb->sched[m];        // lazy (BFV) digits reach 2^62: the schedule of round 2
         jb.root = 1;
@@ -810,8 +830,8 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
             tw[14] = blockIdx.x;
         }
 #endif
-        if ((kb->u_mods >> m) & 1) limb<DEC, SPLIT, true>(jb, false, lds, wv);
-        else limb<DEC, SPLIT, false>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv);
+        if ((kb->u_mods >> m) & 1) limb<DEC, SPLIT, true, LOGN>(jb, false, lds, wv);
+        else limb<DEC, SPLIT, false, LOGN>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv);
 #ifdef MKHE_PHASE_TRACE
         if (jb.trace && ((int)threadIdx.x & 63) == 0) jb.trace[(long)wv * 32 + 28] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -822,6 +842,12 @@ template <bool DEC>
 __global__ void __launch_bounds__(NT, 8) ntt16_fwd_kernel(NttBatch b) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     fwd_body<DEC, false>(b, lds);
+}
+// N = 2^14: one pass per limb (the reference's first benchmark set PN14QP439, mkckks/mkckks_benchmark_test.go:13, and the cnn ring)
+template <bool DEC>
+__global__ void __launch_bounds__(NT, 8) ntt14_fwd_kernel(NttBatch b) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    fwd_body<DEC, false, 14>(b, lds);
 }
 // the two 2^15-point sub-transforms of every 2^16-point limb, in place, after the cross-half stage (NttBatch::split)
 __global__ void __launch_bounds__(NT, 8) ntt16_fwd_split_kernel(NttBatch b) {
@@ -848,6 +874,8 @@ int resident16(size_t lds) {
         (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)ntt16_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)ntt16_fwd_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)ntt14_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)ntt14_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int cus = 256, per = 1;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)ntt16_fwd_kernel<true>, NT, lds) != hipSuccess || per < 1) per = 1;
@@ -873,10 +901,12 @@ void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
     hipLaunchKernelGGL(ntt16_fwd_split_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
 }
 bool ntt16_ok(int logN, const NttBatch& b) {
-    static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128);
-    return on && !b.no_h16 && b.psi31 && logN == 15 && !b.split && !b.prestaged && b.nslots <= 64 && b.nslots * b.nouter >= minl;
+    static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128), minl14 = env_int16("MKHE_NTT14_MIN", 128);
+    if (!on || b.no_h16 || !b.psi31 || b.split || b.prestaged || b.nslots > 64) return false;
+    if (logN == 14) return b.nslots * b.nouter >= minl14;      // (one pass: a workgroup has loaded its whole limb before it stores, in place included)
+    return logN == 15 && b.nslots * b.nouter >= minl;
 }
-void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
+void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st, int logN) {
     using namespace h16;
     NttBatch c = b;
     // big-modulus limbs (the longer jobs) first, as in launch_ntt_fwd_mixed
@@ -894,6 +924,11 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
     const int resident = resident16(lds);
     const int need = c.nslots * c.nouter;
     const int blocks = need < resident ? need : resident;
+    if (logN == 14) {
+        if (c.reduce_in) hipLaunchKernelGGL(ntt14_fwd_kernel<true>, dim3(blocks), dim3(NT), lds, st, c);
+        else hipLaunchKernelGGL(ntt14_fwd_kernel<false>, dim3(blocks), dim3(NT), lds, st, c);
+        return;
+    }
     if (c.reduce_in) hipLaunchKernelGGL(ntt16_fwd_kernel<true>, dim3(blocks), dim3(NT), lds, st, c);
     else hipLaunchKernelGGL(ntt16_fwd_kernel<false>, dim3(blocks), dim3(NT), lds, st, c);
 }

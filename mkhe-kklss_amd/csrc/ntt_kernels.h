@@ -107,7 +107,7 @@ void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st);
 // N = 2^15 launches that fill the chip (ntt16_kernels.hip): 16 coefficients per thread, two workgroups per CU, both modulus
 // classes in one persistent launch.  ntt16_ok: false when the launch does not qualify (MKHE_NTT16=0 switches the path off).
 bool ntt16_ok(int logN, const NttBatch& b);
-void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st);
+void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st, int logN = 15);
 // the same kernel on the 2^15-point sub-transforms of a split N = 2^16 launch (one modulus class per launch)
 bool ntt16_split_ok(const NttBatch& c);
 void launch_ntt16_fwd_split(const NttBatch& c, bool small, hipStream_t st);

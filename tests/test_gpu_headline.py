@@ -240,3 +240,85 @@ def test_pn16_mul_and_relin_eight_parties():
     pair.ksw.MulAndRelinHoisted(ct0, ct1, hh[0], hh[1], rlk, out2)
     assert (out2.download() == ref).all()
     pair.params.close()
+
+
+# ---------------------------------------------------------------- PN14QP439: the first set of the reference's benchmark (mkckks_benchmark_test.go:13)
+@pytest.fixture(scope="module")
+def pn14():
+    from oracle import oracle as O
+    from mkhe_kklss_amd import mkckks
+    p = H.PN14QP439
+    ks = O.KeySwitcher(p["logN"], p["Q"], p["P"], 2)
+    params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"], device=0)
+    return dict(pset=p, ks=ks, params=params, mk=mkckks, rng=np.random.default_rng(0x14439))
+
+
+@pytest.mark.parametrize("parties,drop", [(8, 0), (4, 0), (3, 0), (6, 2), (2, 0)])
+def test_pn14_hoisted_form_launch_classes(pn14, parties, drop):
+    """N = 2^14: Decompose launches of >= 128 limbs run the one-pass instantiation of the H16 kernel (csrc/ntt16_kernels.hip
+    ntt14_fwd_kernel<true>: 8 x 6 x 8 = 384, 192, 144 limbs, a lower level 6 x 4 x 6 = 144), smaller ones (2 x 6 x 8 = 96) the round-1
+    kernels; the 59-bit head prime and the two 60-bit special primes take the balanced path with partial reductions, the 52-bit primes the
+    U class.  Canonical digits against the oracle (mkrlwe/keyswitch.go:49-73)."""
+    p, ks, params, mk, rng = (pn14[k] for k in ("pset", "ks", "params", "mk", "rng"))
+    level = len(p["Q"]) - 1 - drop
+    names = ["p%d" % i for i in range(parties)]
+    h = _ct(p, rng, parties, level + 1)
+    ct = mk.NewCiphertext(params, names, level, p["scale"]).upload(h)
+    hoisted = mk.NewEvaluator(params).HoistedForm(ct)
+    beta = ks.beta(level)
+    act = list(range(level + 1)) + [len(p["Q"]) + j for j in range(len(p["P"]))]
+    for i, n in enumerate(names):
+        ref = ks.decompose(level, h[1 + i])
+        got = hoisted.Value[n].download()
+        assert (got[:beta][:, act] == ref[:beta][:, act]).all(), "party %d" % i
+
+
+def test_pn14_four_party_mulrelin_new(pn14):
+    """the benchmark's timed region at PN14QP439 with 4 parties (engine-internal digits: un-normalised U-class outputs)"""
+    from mkhe_kklss_amd import mkrlwe
+    p, ks, params, mk, rng = (pn14[k] for k in ("pset", "ks", "params", "mk", "rng"))
+    k = 4
+    names = ["user%d" % i for i in range(k)]
+    level = len(p["Q"]) - 1
+    h0, h1 = _ct(p, rng, k, level + 1), _ct(p, rng, k, level + 1)
+    rlk_h, rlk = {}, mkrlwe.RelinearizationKeySet(params)
+    for i, n in enumerate(names):
+        rlk_h[i] = tuple(_swk(p, rng) for _ in range(3))
+        rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, n, *rlk_h[i]))
+    u = _swk(p, rng)
+    params.AddCRS(-1, u)
+    ct0 = mk.NewCiphertext(params, names, level, p["scale"]).upload(h0)
+    ct1 = mk.NewCiphertext(params, names, level, p["scale"]).upload(h1)
+    ev = mk.NewEvaluator(params)
+    res = ev.MulRelinNew(ct0, ct1, rlk)
+    ids = list(range(k))
+    _, ref = ks.mul_and_relin(level, ids, h0, ids, h1, rlk_h, u)
+    nb, _ = ks.ckks_nb_rescales(level, p["scale"] * p["scale"], p["scale"])
+    ref = np.stack([ks.ringQ.div_round_last_many(ref[s], nb)[0] for s in range(1 + k)])
+    assert res.Level() == level - nb and (res.download() == ref).all()
+    assert (ev.MulRelinNew(ct0, ct1, rlk).download() == ref).all()
+
+
+@pytest.mark.parametrize("which", ["pn14", "pn15"])
+def test_plain_forward_ntt_of_many_limbs(which, pn14, pn15):
+    """ring.NTT of 20 polynomials at once (160 / 320 limbs): the H16 kernels without the Decompose reduction (ntt14_fwd_kernel<false>,
+    ntt16_fwd_kernel<false>), out of place and in place (N = 2^15: the parked-half path), against the oracle on every modulus."""
+    from mkhe_kklss_amd import mkrlwe
+    f = pn14 if which == "pn14" else pn15
+    p, ks, params, rng = f["pset"], f["ks"], f["params"], f["rng"]
+    mods = p["Q"] + p["P"]
+    N = 1 << p["logN"]
+    cnt = 20
+    a = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in mods]) for _ in range(cnt)])
+    src = mkrlwe.DeviceLimbs(params, cnt, len(mods)).upload(a)
+    dst = mkrlwe.DeviceLimbs(params, cnt, len(mods))
+    mkrlwe.ntt(params, src, dst)
+    got = dst.download()
+    mkrlwe.ntt(params, src, src)
+    inplace = src.download()
+    for c in (0, 7, cnt - 1):
+        for j in range(len(mods)):
+            r, i = (ks.ringQ, j) if j < len(p["Q"]) else (ks.ringP, j - len(p["Q"]))
+            ref = r.ntt(i, a[c][j])
+            assert (got[c][j] == ref).all() and (inplace[c][j] == ref).all(), (c, j)
+    assert (got == inplace).all()
