@@ -222,6 +222,7 @@ class Context {
     u64* rbuf_ = nullptr;  size_t rbuf_words_ = 0;          // BFV: operands over R, their NTTs, tensor output
     u64* c1b_ = nullptr;   size_t c1b_words_ = 0;           // batched ks.Pool[1]
     u64* tbuf_ = nullptr;  size_t tbuf_words_ = 0;          // t_i of step F
+    u64* spreadbuf_ = nullptr; size_t spreadbuf_words_ = 0;  // N = 2^16: staging of the spread digits (decompose_batch), so that the sub-transforms run out of place
     u64* tens_ = nullptr;  size_t tens_words_ = 0;          // tensor term kept in the NTT domain (times P) for the merged E / F2 batch
     // key generation scratch: uploaded samples, gadget constants (slot 0: mkrlwe gadget, 1: caller's), permuted secret
     int32_t* kg_small_ = nullptr; u64 *kg_g_ = nullptr, *kg_sk_ = nullptr;

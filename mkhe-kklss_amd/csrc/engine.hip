@@ -332,7 +332,7 @@ Context::~Context() {
 void Context::release_all() noexcept {
     (void)hipSetDevice(device);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
-                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n,
+                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)spreadbuf_,
                     (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
@@ -645,7 +645,20 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
         for (size_t base = 0; base < src.size(); base += DEC_MAX_ITEMS) {
             const int n = (int)std::min<size_t>(DEC_MAX_ITEMS, src.size() - base);
             DecompSpreadArgs da{};
-            for (int i = 0; i < n; ++i) { da.src[i] = src[base + i]; da.dst[i] = dst[base + i]; }
+            // N = 2^16 (round 3): the spread digits go to a staging buffer and the sub-transforms run OUT OF PLACE from there into the
+            // destination -- the H16 kernel then recomputes its own cross-half stage in the second pass instead of parking half of every
+            // sub-limb in the destination and reloading it (in place it has to: pass 0 overwrites the operands of pass 1).  5.4 GB of
+            // staging for the 16 operand components of an 8-party PN16QP1761 MulRelin; 288 GB of HBM are there to be used.
+            static const int oop_env = getenv("MKHE_SPREAD_OOP") ? atoi(getenv("MKHE_SPREAD_OOP")) : 1;
+            const size_t item_words = (size_t)beta_max * mtot * N;
+            bool oop = false;
+            if (oop_env && logN == 16 && !masked_ && d_psi31) {
+                NttBatch q{};                                  // the launch as ntt_fwd_launch will see it: does every class part run on H16?
+                q.mods = d_mods; slots_qp(q, level); q.nouter = n * nb; q.prestaged = 1; q.psi31 = d_psi31; q.no_h16 = 0;
+                oop = ntt_fwd_prestaged_oop_ok(logN, q, small_q_.data());
+            }
+            u64* stage = oop ? scratch(spreadbuf_, spreadbuf_words_, (size_t)n * item_words) : nullptr;
+            for (int i = 0; i < n; ++i) { da.src[i] = src[base + i]; da.dst[i] = oop ? stage + (size_t)i * item_words : dst[base + i]; }
             da.mods = d_mods; da.map = map_qp(level); da.ta = d_dec_a; da.tb = d_dec_b; da.tc = d_dec_c;
             for (int d = 0; d < nb; ++d) {
                 // decompLvl rule of DecomposeAndSplit (:437-441), digit index d
@@ -660,8 +673,8 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
             b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);
             b.src_outer = b.dst_outer = (long)mtot * N; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
             b.nitems = n; b.outers_per_item = nb;
-            for (int i = 0; i < n; ++i) { b.src_items[i] = dst[base + i]; b.dst_items[i] = dst[base + i]; }
-            b.nouter = n * nb; b.prestaged = da.first_stage; b.skip_norm = internal ? 1 : 0;
+            for (int i = 0; i < n; ++i) { b.src_items[i] = oop ? stage + (size_t)i * item_words : dst[base + i]; b.dst_items[i] = dst[base + i]; }
+            b.nouter = n * nb; b.prestaged = da.first_stage; b.prestaged_oop = oop ? 1 : 0; b.skip_norm = internal ? 1 : 0;
             ntt_fwd_launch(b, false);
         }
         MKHE_HIP(hipGetLastError());

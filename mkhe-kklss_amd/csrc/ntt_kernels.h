@@ -64,6 +64,7 @@ struct NttBatch {
     unsigned long long small_slots;   // mixed forward launch (launch_ntt_fwd_mixed): bit s set = slot s is a small-modulus (MODE 1) limb
     int prestaged;          // forward, split launches only: the cross-half stage was already applied by the producer of src
                             // (decomp_spread_kernel with first_stage): only the sub-transforms run, in place on dst
+    int prestaged_oop;      // ... and that producer wrote into src (src_items), not into dst: the sub-transforms read src and write dst
     const u64* psi31;       // forward, ntt16_kernels.hip only: [nmod][N][2] the twiddle w as the constant pair (w 2^31 mod q, w 2^63 mod q),
                             // balanced, radix-2^31 digits -- operands of the one-round product (mm31)
     const u64* psi31n;      // [nmod][4][2]: the pairs of -psi[1], -psi[2], -psi[3] (entries 1..3), for the second pass of the cross-half stage
@@ -99,6 +100,7 @@ struct NttBatch {
 // class (returns how many, small-modulus class first), launch_ntt_fwd_class launches one of them.
 int  split_ntt_fwd(const NttBatch& b, const unsigned char* small_q, NttBatch out[2]);
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st);
+bool ntt_fwd_prestaged_oop_ok(int logN, const NttBatch& b, const unsigned char* small_q);
 // both modulus classes of `b` in ONE persistent launch (N = 2^15 Decompose launches that fill the chip several times over);
 // ntt_fwd_mixed_ok: false when the launch does not qualify (the caller then issues one launch per class)
 bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q);

@@ -10,6 +10,7 @@
 //    once at the end with a Montgomery product by R mod q;
 //  * all pointers are address_space(1) so loads are global_load (vmcnt only), never flat_load.
 #include "ntt_kernels.h"
+#include <stdexcept>
 #include <cstdlib>
 #include <mutex>
 #ifndef MKHE_SB_MASK
@@ -846,6 +847,18 @@ void launch_ntt_fwd_mixed(int logN, const NttBatch& b, const unsigned char* smal
             }
     launch_fwd_t<15, 2, true>(c, st);
 }
+// would every class part of this prestaged N = 2^16 launch run on the H16 sub-transform kernel?  (only then may the producer stage its
+// output in a separate buffer: NttBatch::prestaged_oop)
+bool ntt_fwd_prestaged_oop_ok(int logN, const NttBatch& b, const unsigned char* small_q) {
+    if (logN != 16 || !b.prestaged) return false;
+    NttBatch part[2];
+    const int n = split_ntt_fwd(b, small_q, part);
+    for (int i = 0; i < n; ++i) {
+        NttBatch o = part[i]; o.reduce_in = 0; o.split = 1;
+        if (!use_split(logN, part[i]) || lds_depth(logN, part[i]) != 0 || !ntt16_split_ok(o)) return false;
+    }
+    return n > 0;
+}
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
     const bool small = b.lazy_out != 0;
@@ -859,7 +872,14 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
         }
         else if (b.reduce_in) hipLaunchKernelGGL(ntt_split_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
         else hipLaunchKernelGGL(ntt_split_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
-        const NttBatch c = in_place_of_dst(b);
+        NttBatch c = in_place_of_dst(b);
+        if (b.prestaged && b.prestaged_oop && !d && logN == 16) {
+            // the producer staged the data in src: sub-transforms src -> dst (the H16 kernel only; anything else copies nothing and would
+            // need the data in dst, so the caller only asks for this when ntt16_split_ok holds)
+            NttBatch o = b; o.reduce_in = 0; o.split = 1;
+            if (ntt16_split_ok(o)) c = o;
+            else throw std::runtime_error("mkhe: internal: out-of-place prestaged launch outside the H16 path");
+        }
         if (d) {
             for (int L = 1; L < d && d != 2; ++L) hipLaunchKernelGGL(ntt_pass_fwd_kernel, grid, dim3(SPLIT_THREADS), 0, st, c, logN, L);
             const int jobs = (b.nslots * b.nouter) << d;
