@@ -133,6 +133,15 @@ int  mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                         const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
                         const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
                         const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out);
+/* mkckks.Evaluator.mulRelinHoisted (mkckks/evaluator.go:558-581): MulAndRelin[Hoisted] followed by ONE Rescale (the usual case: the scale of
+ * the product drops below 2 * params.Scale() after one division), as one call.  `out` is the RESCALED ciphertext: one level below
+ * min(level(op0), level(op1)), ids = the union.  On one device with at most four parties per operand the DivRoundByLastModulus rides on the
+ * store of the last ModDown (the level-L product is never written); otherwise the engine runs mkhe_mul_and_relin into a pooled temporary and
+ * mkhe_rescale after it.  The same ciphertext, bit for bit, as the two calls (tests/test_gpu_parity.py). */
+int  mkhe_mul_relin_rescale(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                            const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
+                            const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
+                            const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out);
 
 /* ---- the same MulAndRelinHoisted split in phases for party-sharded multi-GPU evaluation
  *      (the reference is single-process).  Each rank passes sub-ciphertexts holding c_0

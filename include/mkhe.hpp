@@ -233,16 +233,18 @@ class KeySwitcher {
     void MulAndRelin(const Ciphertext& op0, const Ciphertext& op1, RelinearizationKeySet& rlkSet, Ciphertext& ctOut) {          // keyswitch.go:122-230
         MulAndRelinHoisted(op0, op1, nullptr, nullptr, rlkSet, ctOut);
     }
+    // rescaled = true: ctOut is one level below the product and receives Rescale(MulAndRelin(..)) in one engine call (mkhe_mul_relin_rescale)
     void MulAndRelinHoisted(const Ciphertext& op0, const Ciphertext& op1, const HoistedCiphertext* op0Hoisted, const HoistedCiphertext* op1Hoisted,
-                            RelinearizationKeySet& rlkSet, Ciphertext& ctOut) {                                                 // keyswitch_hoisted.go:44-179
-        if (op0.Level() < ctOut.Level() || op1.Level() < ctOut.Level()) throw Error("Cannot MulAndRelin: op0 and op1 have different levels");
+                            RelinearizationKeySet& rlkSet, Ciphertext& ctOut, bool rescaled = false) {                          // keyswitch_hoisted.go:44-179
+        const int lvl = ctOut.Level() + (rescaled ? 1 : 0);
+        if (op0.Level() < lvl || op1.Level() < lvl) throw Error("Cannot MulAndRelin: op0 and op1 have different levels");
         if (!params.CRS.count(-1)) throw Error("mkhe: CRS[-1] (u) has not been uploaded");
         std::vector<const mkhe_swk*> d0, v0, b1, h0, h1;
         for (auto& i : op0.ids) { auto& k = rlkSet.GetRelinearizationKey(i); d0.push_back(k.Value[1]->h); v0.push_back(k.Value[2]->h); }
         for (auto& i : op1.ids) b1.push_back(rlkSet.GetRelinearizationKey(i).Value[0]->h);
         if (op0Hoisted) for (auto& i : op0.ids) h0.push_back(op0Hoisted->Value.at(i)->h);
         if (op1Hoisted) for (auto& i : op1.ids) h1.push_back(op1Hoisted->Value.at(i)->h);
-        check(mkhe_mul_and_relin(params.ctx, op0.h, op1.h, op0Hoisted ? h0.data() : nullptr, op1Hoisted ? h1.data() : nullptr,
+        check((rescaled ? mkhe_mul_relin_rescale : mkhe_mul_and_relin)(params.ctx, op0.h, op1.h, op0Hoisted ? h0.data() : nullptr, op1Hoisted ? h1.data() : nullptr,
                                  b1.data(), d0.data(), v0.data(), params.CRS[-1]->h, ctOut.h));
     }
     void Rotate(const Ciphertext& ctIn, int rotidx, RotationKeySet& rkSet, Ciphertext& ctOut) { RotateHoisted(ctIn, rotidx, nullptr, rkSet, ctOut); }   // keyswitch.go:234-298
@@ -390,6 +392,16 @@ class Evaluator {
     }
     CiphertextPtr MulRelinHoistedNew(const Ciphertext& op0, const Ciphertext& op1, const mkrlwe::HoistedCiphertext* h0, const mkrlwe::HoistedCiphertext* h1,
                                      mkrlwe::RelinearizationKeySet& rlkSet) {                                            // evaluator.go:558-581
+        {   // the usual single Rescale rides on the engine call (the number of rescales depends on scales and moduli only)
+            const int level = std::min(op0.Level(), op1.Level());
+            double sc = op0.ScalingFactor() * op1.ScalingFactor(); int nb1 = 0;
+            while (level - nb1 >= 0 && sc / (double)params.Q()[level - nb1] >= params.Scale() / 2) { sc /= (double)params.Q()[level - nb1]; ++nb1; }
+            if (nb1 == 1 && level >= 1) {
+                auto res = std::make_unique<Ciphertext>(params, mkrlwe::Union(op0.IDSet_(), op1.IDSet_()), level - 1, sc, false);
+                ksw.MulAndRelinHoisted(op0, op1, h0, h1, rlkSet, *res, true);
+                return res;
+            }
+        }
         auto ctOut = std::make_unique<Ciphertext>(params, mkrlwe::Union(op0.IDSet_(), op1.IDSet_()), std::min(op0.Level(), op1.Level()),
                                                   op0.ScalingFactor() * op1.ScalingFactor(), false);
         ksw.MulAndRelinHoisted(op0, op1, h0, h1, rlkSet, *ctOut);

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mkhe_external_product": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int]),
     "mkhe_external_product_hoisted": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int]),
     "mkhe_mul_and_relin": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),
+    "mkhe_mul_relin_rescale": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),
     "mkhe_mr_partial": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, C.c_int, vp, vp, vp]),
     "mkhe_swk_fold": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "mkhe_mr_finish": (C.c_int, [vp, vp, vp, vp, vp, vpp, vp, vp]),

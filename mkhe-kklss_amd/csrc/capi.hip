@@ -308,6 +308,20 @@ int mkhe_mul_and_relin(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                               b1.data(), d0.data(), v0.data(), crs_u->s, out->c);
     })
 }
+int mkhe_mul_relin_rescale(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
+                           const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
+                           const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
+                           const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out) {
+    MKHE_TRY({ mark(ctx, op0, op1, crs_u, out);
+        if (!op0 || !op1 || !out || !crs_u || !rlk_b1 || !rlk_d0 || !rlk_v0) throw Error("mkhe_mul_relin_rescale: null argument");
+        auto h0 = swk_list(ctx, hoist0, op0->c.n); auto h1 = swk_list(ctx, hoist1, op1->c.n);
+        auto b1 = swk_list(ctx, rlk_b1, op1->c.n); auto d0 = swk_list(ctx, rlk_d0, op0->c.n); auto v0 = swk_list(ctx, rlk_v0, op0->c.n);
+        const bool same = (op0 == op1) && (hoist0 == hoist1);
+        need(ctx)->mul_relin_rescale(op0->c, same ? op0->c : op1->c, hoist0 ? h0.data() : nullptr,
+                                     hoist1 ? (same ? h0.data() : h1.data()) : nullptr,
+                                     b1.data(), d0.data(), v0.data(), crs_u->s, out->c);
+    })
+}
 int mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                     const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
                     const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,

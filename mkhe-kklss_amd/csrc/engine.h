@@ -89,6 +89,8 @@ class Context {
                        const Swk* const* rlk_v, const Swk& crs_u, Ct& out);
     void bfv_slots(const Ct& op0, const Ct& op1, const Ct& out, std::vector<int>& slot0, std::vector<int>& slot1) const;
     bool bfv_plan_valid_ = false;
+    void mul_relin_rescale(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, const Swk* const* rlk_b1,
+                           const Swk* const* rlk_d0, const Swk* const* rlk_v0, const Swk& crs_u, Ct& out);
     void bfv_mul_relin_unhoisted(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
                                  const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v, const Swk& crs_u, Ct& out);
     void bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
@@ -222,6 +224,7 @@ class Context {
     u64* rbuf_ = nullptr;  size_t rbuf_words_ = 0;          // BFV: operands over R, their NTTs, tensor output
     u64* c1b_ = nullptr;   size_t c1b_words_ = 0;           // batched ks.Pool[1]
     u64* tbuf_ = nullptr;  size_t tbuf_words_ = 0;          // t_i of step F
+    Ct* rs_out_ = nullptr; const u64* rs_full_ = nullptr; bool rs_done_ = false;      // mul_relin_rescale: the rescaled output, the base of the (unwritten) product, "the ModDown did it"
     u64* spreadbuf_ = nullptr; size_t spreadbuf_words_ = 0;  // N = 2^16: staging of the spread digits (decompose_batch), so that the sub-transforms run out of place
     u64* tens_ = nullptr;  size_t tens_words_ = 0;          // tensor term kept in the NTT domain (times P) for the merged E / F2 batch
     // key generation scratch: uploaded samples, gadget constants (slot 0: mkrlwe gadget, 1: caller's), permuted secret

@@ -461,6 +461,7 @@ void Context::join_side(int k) { if (!overlap) return; MKHE_HIP(hipStreamWaitEve
 void Context::recover() {
     s_ = stream;
     plan_.valid = false; plan_.x_pending = false; plan_.head_done = false; plan_.xkeys.clear(); ext_xout_ = ext_xout2_ = nullptr;
+    rs_out_ = nullptr; rs_full_ = nullptr; rs_done_ = false;
     bfv_plan_valid_ = false; bfv_xk1_.clear(); bfv_xk2_.clear();
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cs);
@@ -826,6 +827,21 @@ void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 g
             bytes += 8.0 * N * ((level + 1) * (mp->accumulate[v] ? 3.0 : 2.0) + np * mp->cnt[v]);
         }
         md.galEl = galEl; md.logN = logN;
+        if (rs_out_ && !galEl && level >= 1) {
+            // fused Rescale (mul_relin_rescale): possible when this launch is the only writer of every destination
+            bool ok = true;
+            for (int v = 0; v < mp->nvi && ok; ++v) {
+                ok = !mp->accumulate[v] && !mp->addend[v] && mp->dst[v] >= rs_full_ && mp->dst[v] < rs_full_ + (size_t)(1 + rs_out_->n) * (level + 1) * N &&
+                     (size_t)(mp->dst[v] - rs_full_) % ((size_t)(level + 1) * N) == 0 && level + 1 == rs_out_->limbs + 1;
+                for (int w = 0; w < v && ok; ++w) ok = mp->dst[w] != mp->dst[v];
+            }
+            if (ok && mp->nvi == 1 + rs_out_->n) {
+                md.rescale_row = d_rescale + (size_t)(level - 1) * nq;
+                for (int v = 0; v < mp->nvi; ++v)
+                    md.rdst[v] = rs_out_->d + (size_t)(mp->dst[v] - rs_full_) / ((size_t)(level + 1) * N) * ((size_t)level * N);
+                rs_done_ = true;
+            }
+        }
         { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_merged(md, s_); }
         return;
     }
@@ -871,6 +887,30 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
     const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= 4 && !masked_;
     mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse);
     mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
+}
+
+// mkckks.Evaluator.mulRelinHoisted (evaluator.go:558-581) = MulAndRelinHoisted + one Rescale, as ONE engine call: the DivRoundByLastModulus
+// is applied by the merged ModDown of the last batch as it stores (ModDownMergedArgs::rescale_row), so the level-L product is never written
+// and the rescale is neither a launch nor a pass of its own.  That needs every output slot to be written exactly once by that launch (up to
+// four products per destination: at most four parties per operand, single device, tensor term folded in); otherwise the product goes to a
+// pooled temporary and Context::rescale follows -- the same integers either way.
+void Context::mul_relin_rescale(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
+                                const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
+                                const Swk& crs_u, Ct& out) {
+    const int L = out.limbs + 1;                           // limbs of the product
+    if (out.limbs < 1 || L > nq) throw Error("cannot Rescale: input Ciphertext already at level 0");
+    Ct full; full.n = out.n; full.limbs = L; full.ids = out.ids;
+    const size_t words = (size_t)(1 + out.n) * L * N;
+    full.d = pool_alloc(words);
+    static const int fuse_env = getenv("MKHE_FUSE_RESCALE") ? atoi(getenv("MKHE_FUSE_RESCALE")) : 1;
+    rs_out_ = fuse_env && !masked_ ? &out : nullptr; rs_full_ = full.d; rs_done_ = false;
+    try {
+        mul_and_relin(op0, op1, hoist0, hoist1, rlk_b1, rlk_d0, rlk_v0, crs_u, full);
+        const bool done = rs_done_;
+        rs_out_ = nullptr; rs_full_ = nullptr; rs_done_ = false;
+        if (!done) rescale(full, 1, out);
+    } catch (...) { rs_out_ = nullptr; rs_full_ = nullptr; rs_done_ = false; pool_free(full.d, words); throw; }
+    pool_free(full.d, words);
 }
 
 // -- step 0: validate, map ids, hoist the operands when the caller did not (MulRelinNew, evaluator.go:416-443)

@@ -143,6 +143,12 @@ struct ModDownMergedArgs {
     int ngroups;
     u64 galEl;
     int logN;
+    // Rescale folded into the store (round 3; mkckks.Evaluator.mulRelinHoisted always rescales right after, evaluator.go:558-581): when
+    // rescale_row != NULL every destination is written exactly once by this launch (no accumulate, no permutation), and what is stored is
+    // DivRoundByLastModulus of the ModDown result -- limbs 0 .. level-1 of rdst[v] (a polynomial of the output ciphertext one level down,
+    // limb stride N) -- instead of the result itself; the thread computes limb `level` of its coefficient first (every limb slice does).
+    const u64* rescale_row;                       // [level]: RescaleParams row of the level, as div_round_last_kernel takes it
+    u64* rdst[EXT_MAX_ITEMS];
 };
 void launch_moddown_merged(const ModDownMergedArgs& a, hipStream_t st);
 

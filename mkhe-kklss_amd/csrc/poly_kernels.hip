@@ -518,8 +518,8 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
                 v[k] = (u32)(u64)vi_;
             }
         }
-        for (int j = blockIdx.y; j <= a.level; j += gridDim.y) {
-            const Mod mq = a.mods_q[j];
+        // the ModDown result of limb j for this coefficient (canonical)
+        auto down = [&](int j, const Mod& mq) -> u64 {
             u64 rlo = 0, rhi = 0, vt = 0;
 #pragma unroll
             for (int k = 0; k < MD_VI_MAX; ++k) {
@@ -538,7 +538,31 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
             const u64 hhi = mulhi64(rlo * mq.qinv, mq.q);
             const u64 lift = rhi - hhi + mq.q + vt;                      // = sum_k (the reference's per-product lift) mod q
             const u64 x = xq[(long)j * a.N + n];                         // lazy, < 2q
-            u64 z = mont_mul(lift + mq.q2 - x, a.t.downparam[j], mq.q, mq.ninv32);
+            return mont_mul(lift + mq.q2 - x, a.t.downparam[j], mq.q, mq.ninv32);
+        };
+        if (a.rescale_row) {
+            // DivRoundByLastModulus (lattigo, as div_round_last_kernel restates it) of the result, limb by limb: the dropped limb first
+            const Mod mL = a.mods_q[a.level];
+            const u64 qL = mL.q, h = (qL - 1) >> 1;
+            const u64 t = csub(down(a.level, mL) + h, qL);
+            u64* rd = ka->rdst[vi];
+            for (int j = blockIdx.y; j < a.level; j += gridDim.y) {
+                const Mod mq = a.mods_q[j];
+                u64 hr;
+                {
+                    const u64 kq = (u64)((double)h / (double)mq.q);        // BRedAdd(h, q_j) as in div_round_last_kernel
+                    hr = h - kq * mq.q;
+                    if ((i64)hr < 0) hr += mq.q;
+                    if (hr >= mq.q) hr -= mq.q;
+                }
+                const u64 z = down(j, mq);
+                rd[(long)j * a.N + n] = mont_mul(t + (mq.q - hr) + mq.q2 - z, mq.q - a.rescale_row[j], mq.q, mq.ninv32);
+            }
+            continue;
+        }
+        for (int j = blockIdx.y; j <= a.level; j += gridDim.y) {
+            const Mod mq = a.mods_q[j];
+            u64 z = down(j, mq);
             long pos = (long)j * a.N + n;
             bool flip = false;
             if (a.galEl) {

@@ -53,6 +53,7 @@ class Evaluator:
     def __init__(self, params):
         self.params = params
         self.ksw = mkrlwe.NewKeySwitcher(params)
+        self.fuse_rescale = True          # MulRelin[Hoisted]New: the single Rescale inside the engine call (False: two calls, for A/B tests)
 
     def Fork(self):
         """an evaluator on a forked context (mkrlwe.Parameters.Fork): same keys and ciphertexts, its own stream"""
@@ -159,10 +160,13 @@ class Evaluator:
 
     # ---- Rescale (evaluator.go:359-398)
     def nbRescales(self, ctIn, minScale):
+        return self._nb_rescales(ctIn.Level(), ctIn.Scale, minScale)
+
+    def _nb_rescales(self, level, scale, minScale):
         Q = self.params.Q
-        scale, nb = ctIn.Scale, 0
-        while ctIn.Level() - nb >= 0 and scale / float(Q[ctIn.Level() - nb]) >= minScale / 2:
-            scale /= float(Q[ctIn.Level() - nb])
+        nb = 0
+        while level - nb >= 0 and scale / float(Q[level - nb]) >= minScale / 2:
+            scale /= float(Q[level - nb])
             nb += 1
         return nb, scale
 
@@ -192,8 +196,15 @@ class Evaluator:
 
     # ---- MulRelinHoistedNew / mulRelinHoisted (evaluator.go:558-581)
     def MulRelinHoistedNew(self, op0, op1, op0Hoisted, op1Hoisted, rlkSet):
-        ctOut = NewCiphertext(self.params, op0.IDSet() | op1.IDSet(), min(op0.Level(), op1.Level()),
-                              op0.ScalingFactor() * op1.ScalingFactor(), zero=False)      # newCiphertextBinary, :306-313
+        level, prod_scale = min(op0.Level(), op1.Level()), op0.ScalingFactor() * op1.ScalingFactor()
+        # the number of rescales depends on scales and moduli only (evaluator.go:359-398): the usual single one is folded into the
+        # engine call (mkhe_mul_relin_rescale: the DivRoundByLastModulus rides on the last ModDown's store), bit-identical to the two calls
+        nb1, scale1 = self._nb_rescales(level, prod_scale, self.params.Scale())
+        if nb1 == 1 and level >= 1 and self.fuse_rescale:
+            res = NewCiphertext(self.params, op0.IDSet() | op1.IDSet(), level - 1, scale1, zero=False)
+            self.ksw.MulAndRelinHoisted(op0, op1, op0Hoisted, op1Hoisted, rlkSet, res, rescaled=True)
+            return res
+        ctOut = NewCiphertext(self.params, op0.IDSet() | op1.IDSet(), level, prod_scale, zero=False)      # newCiphertextBinary, :306-313
         self.ksw.MulAndRelinHoisted(op0, op1, op0Hoisted, op1Hoisted, rlkSet, ctOut)
         nb, scale = self.nbRescales(ctOut, self.params.Scale())
         if nb == 0 or ctOut.Level() == 0:

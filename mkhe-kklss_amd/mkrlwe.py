@@ -408,8 +408,10 @@ class KeySwitcher:
         self.MulAndRelinHoisted(op0, op1, None, None, rlkSet, ctOut)
 
     # -- MulAndRelinHoisted (keyswitch_hoisted.go:44-179)
-    def MulAndRelinHoisted(self, op0, op1, op0Hoisted, op1Hoisted, rlkSet, ctOut):
-        level = ctOut.Level()
+    def MulAndRelinHoisted(self, op0, op1, op0Hoisted, op1Hoisted, rlkSet, ctOut, rescaled=False):
+        """rescaled=True (no reference counterpart at this level; mkckks.Evaluator.mulRelinHoisted, evaluator.go:558-581, is the caller):
+        ctOut is one level below the product and receives Rescale(MulAndRelin(..)) in one engine call (mkhe_mul_relin_rescale)"""
+        level = ctOut.Level() + (1 if rescaled else 0)
         if op0.Level() < level:
             raise MkheError("Cannot MulAndRelin: op0 and op1 have different levels")        # :48-50
         if op1.Level() < level:
@@ -427,8 +429,9 @@ class KeySwitcher:
             h1 = [op1Hoisted.Value[i].h for i in op1.ids] if op1Hoisted is not None else None
         a_h0 = handle_array(h0)
         a_h1 = a_h0 if h1 is h0 else handle_array(h1)
-        check(lib().mkhe_mul_and_relin(self.ctx, op0.h, op1.h, a_h0, a_h1, handle_array(b1), handle_array(d0),
-                                       handle_array(v0), params.CRS[-1].h, ctOut.h))
+        fn = lib().mkhe_mul_relin_rescale if rescaled else lib().mkhe_mul_and_relin
+        check(fn(self.ctx, op0.h, op1.h, a_h0, a_h1, handle_array(b1), handle_array(d0),
+                 handle_array(v0), params.CRS[-1].h, ctOut.h))
 
     def _rotidx(self, rotidx):
         n2 = self.Parameters.N() // 2

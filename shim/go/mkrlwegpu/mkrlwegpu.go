@@ -220,6 +220,17 @@ func (ctx *Context) MulAndRelin(op0, op1 *Ciphertext, rk RelinKeys, crsU *Switch
 		(**C.mkhe_swk)(unsafe.Pointer(&v0[0])), crsU.h, out.h))
 }
 
+// MulRelinRescale is mkckks.Evaluator.mulRelinHoisted's MulAndRelin + single Rescale (mkckks/evaluator.go:558-581) as one engine call:
+// out is the rescaled ciphertext, one level below the product.
+func (ctx *Context) MulRelinRescale(op0, op1 *Ciphertext, rk RelinKeys, crsU *SwitchingKey, out *Ciphertext) {
+	b1 := handles(op1.ids, rk, 0)
+	d0 := handles(op0.ids, rk, 1)
+	v0 := handles(op0.ids, rk, 2)
+	must(C.mkhe_mul_relin_rescale(ctx.c, op0.h, op1.h, nil, nil,
+		(**C.mkhe_swk)(unsafe.Pointer(&b1[0])), (**C.mkhe_swk)(unsafe.Pointer(&d0[0])),
+		(**C.mkhe_swk)(unsafe.Pointer(&v0[0])), crsU.h, out.h))
+}
+
 // Decompose replaces KeySwitcher.Decompose (keyswitch.go:49-73) for ct.Value[id].
 func (ctx *Context) Decompose(level int, ct *Ciphertext, slot int, isNTT bool, out *SwitchingKey) {
 	ntt := C.int(0)

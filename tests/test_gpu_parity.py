@@ -159,6 +159,18 @@ def test_mul_and_relin(pair, ids0, ids1, drop, extra, hoisted):
     ido, ref = oracle_mul_and_relin(pair, level, sorted(ids0), h0, sorted(ids1), h1, rlk_h, u_h, names)
     assert ido == out.ids
     assert (out.download() == ref).all()
+    # the fused MulAndRelin + Rescale entry (mkhe_mul_relin_rescale; mkckks/evaluator.go:558-581 always rescales right after): the
+    # DivRoundByLastModulus rides on the last ModDown's store where every output slot is written once (up to four products per
+    # destination), a pooled temporary + mkhe_rescale otherwise -- either way Rescale(MulAndRelin) of the oracle, bit for bit
+    if level >= 1:
+        res = mk.NewCiphertext(pair.params, names, level - 1)
+        if hoisted:
+            pair.ksw.MulAndRelinHoisted(d0, d1, hh0, hh1, rlk_d, res, rescaled=True)
+        else:
+            pair.ksw.MulAndRelinHoisted(d0, d1, None, None, rlk_d, res, rescaled=True)
+        ref_r = np.stack([pair.ks.ringQ.div_round_last_many(ref[s], 1)[0] for s in range(1 + len(names))])
+        assert (res.download() == ref_r).all()
+        assert (out.download() == ref).all()          # (and the un-rescaled product of the first call is untouched)
 
 
 def test_mul_and_relin_square(pair):
