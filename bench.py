@@ -81,6 +81,34 @@ def run_bfv(args):
     if os.environ.get("MKHE_NO_OVERLAP"):
         check(lib().mkhe_set_overlap(params.ctx, 0))
     step = lambda: ev.MulRelinNew(ct0, ct1, rlk)
+    # same order of legs as run_single: a cold-start figure first, then a long window, then the contract's W + K steps on settled clocks
+    extras = {}
+    for _ in range(args.warmup):
+        res = step()
+    params.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    params.sync()
+    extras["mulrelin_per_sec_cold_start"] = args.steps / (time.perf_counter() - t0)
+    if not getattr(args, "no_extras", False):
+        un = lambda: ev.mulRelin(ct0, ct1, rlk)         # the non-hoisted twin (mkbfv/keyswitch.go:115-251) on its own device path
+        for _ in range(2):
+            un()
+        params.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            un()
+        params.sync()
+        extras["mulrelin_unhoisted_per_sec"] = args.steps / (time.perf_counter() - t0)
+    for _ in range(60):
+        step()
+    params.sync()
+    t0 = time.perf_counter()
+    for _ in range(120):
+        step()
+    params.sync()
+    extras["mulrelin_per_sec_steady_state"] = 120 / (time.perf_counter() - t0)
     for _ in range(args.warmup):
         res = step()
     params.sync()
@@ -107,7 +135,7 @@ def run_bfv(args):
                 vs_baseline=None, dtype="u64", data="synthetic",
                 config=dict(workload="mkbfv %d-party MulRelinNew (ModUpQtoR + Rescale + DecomposeBFV + MulAndRelinBFVHoisted), %s N=2^%d, %d Q + %d QMul + %d P limbs"
                             % (k, args.params, pset["logN"], len(pset["Q"]), len(pset["QMul"]), len(pset["P"])),
-                            parties=k, params=args.params, seed=args.seed),
+                            parties=k, params=args.params, seed=args.seed, **extras),
                 roofline=roofline, cpu_baseline=cpu)
 
 
@@ -248,8 +276,8 @@ def roofline_leg(args, params, step, logN, workload, extra=None):
     # HBM traffic: PMC counters cannot be read from inside this process; the figures come from the committed rocprofv3 --pmc
     # summary of the clean profile command (profiles/traffic.json, tools/profile_r2.sh + tools/traffic_from_pmc.py:
     # (2*FETCH_SIZE + WRITE_SIZE) KB per launch).  They are attached only when the profiled run had the launch
-    # pattern measured here: same workload, and per kernel the recorded call count equals launches_per_step * (warmup + 2 * steps)
-    # of the recorded command (warm-up + timed loop + HIP-event leg) -- otherwise `traffic` stays null.
+    # pattern measured here: same workload, same kernel sources (csrc_sha256), and per kernel the recorded call count equals
+    # launches_per_step * (steps the recorded command ran) -- otherwise `traffic` stays null.
     traffic, tnote = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -261,7 +289,8 @@ def roofline_leg(args, params, step, logN, workload, extra=None):
             rec = tk.get(key) or tk.get(key.replace("[_batch]", "_batch"))
             if stale or tj.get("workload") != workload or rec is None or tj.get("steps") is None:
                 return None
-            expect = kernels[name]["launches_per_step"] * (tj["warmup"] + 2 * tj["steps"])
+            # steps the recorded command ran: cold-start leg (W + K), steady-state leg (100 + 200), timed region (W + K), HIP-event leg (K)
+            expect = kernels[name]["launches_per_step"] * (2 * (tj["warmup"] + tj["steps"]) + 300 + tj["steps"])
             return rec["hbm_bytes_per_launch"] if abs(rec["launches"] - expect) < 0.5 else None
         traffic = pmc_bytes(dom)
         for name, k in kernels.items():

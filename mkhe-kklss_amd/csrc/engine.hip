@@ -909,8 +909,11 @@ void Context::mul_relin_rescale(const Ct& op0, const Ct& op1, const Swk* const* 
         const bool done = rs_done_;
         rs_out_ = nullptr; rs_full_ = nullptr; rs_done_ = false;
         if (!done) rescale(full, 1, out);
-    } catch (...) { rs_out_ = nullptr; rs_full_ = nullptr; rs_done_ = false; pool_free(full.d, words); throw; }
-    pool_free(full.d, words);
+    } catch (...) { rs_out_ = nullptr; rs_full_ = nullptr; rs_done_ = false; const HandleUsers none; pool_free(full.d, words, &none); throw; }
+    // the temporary never left this context (no handle, no other context can have work queued on it): an EMPTY user list, so that the pool does
+    // not order its next user behind every live context (users == nullptr means "unknown": the forks of the cnn evaluation would serialise)
+    const HandleUsers none;
+    pool_free(full.d, words, &none);
 }
 
 // -- step 0: validate, map ids, hoist the operands when the caller did not (MulRelinNew, evaluator.go:416-443)
