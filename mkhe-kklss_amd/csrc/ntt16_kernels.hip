@@ -381,6 +381,45 @@ __device__ __forceinline__ int lane_id() {
     asm volatile("" : "+v"(l));            // not hoisted, not common-subexpression'd across phases
     return l;
 }
+// Round 3: the WRITE side of the A -> B, B -> C and C -> D re-distributions is lane-linear (word address = wave-uniform base + lane +
+// constant(register)), which is what ds_write_addtid_b32 does without an address register: LDS address = M0 + 16-bit offset + 4 * lane.
+// Its data path costs 2 cycles per wave-instruction where ds_write_b32 (address + data VGPR) costs 4 (MI355X_MICROARCH.md, LDS), and the
+// exchanges are bound by exactly that path when the sixteen waves of a workgroup go through them together.
+#ifndef MKHE_H16_ADDTID
+#define MKHE_H16_ADDTID 1
+#endif
+template <int X, int R0> __device__ __forceinline__ void addtid_write8(const u32 (&w)[8], unsigned base_bytes) {
+    asm volatile("s_mov_b32 m0, %8\n\t"
+                 "s_nop 0\n\t"                              // (SALU write of M0 -> add-TID LDS instruction: one wait state; hazards inside an asm block are ours)
+                 "ds_write_addtid_b32 %0 offset:%9\n\t"
+                 "ds_write_addtid_b32 %1 offset:%10\n\t"
+                 "ds_write_addtid_b32 %2 offset:%11\n\t"
+                 "ds_write_addtid_b32 %3 offset:%12\n\t"
+                 "ds_write_addtid_b32 %4 offset:%13\n\t"
+                 "ds_write_addtid_b32 %5 offset:%14\n\t"
+                 "ds_write_addtid_b32 %6 offset:%15\n\t"
+                 "ds_write_addtid_b32 %7 offset:%16"
+                 : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "s"(base_bytes),
+                     "n"(4 * woff<X>(R0 + 0)), "n"(4 * woff<X>(R0 + 1)), "n"(4 * woff<X>(R0 + 2)), "n"(4 * woff<X>(R0 + 3)),
+                     "n"(4 * woff<X>(R0 + 4)), "n"(4 * woff<X>(R0 + 5)), "n"(4 * woff<X>(R0 + 6)), "n"(4 * woff<X>(R0 + 7))
+                 : "m0", "memory");
+}
+template <int X, bool HI> __device__ __forceinline__ void write_plane(const u64 (&x)[16], u32* lds, int wv, int l) {
+    typedef __attribute__((address_space(3))) u32* lptr;
+    if constexpr (MKHE_H16_ADDTID && X != X_DE) {
+        static_assert(4 * woff<X>(15) <= 65535, "16-bit offset field");
+        const unsigned base = (unsigned)(unsigned long)(lptr)lds + 4u * (unsigned)wbase<X>(wv, 0);      // wave-uniform
+        u32 a[8], b[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a[r] = HI ? hi32(x[r]) : lo32(x[r]); b[r] = HI ? hi32(x[8 + r]) : lo32(x[8 + r]); }
+        addtid_write8<X, 0>(a, base);
+        addtid_write8<X, 8>(b, base);
+    } else {
+        lptr wr = (lptr)lds + wbase<X>(wv, l);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wr[woff<X>(r)] = HI ? hi32(x[r]) : lo32(x[r]);
+    }
+}
 template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds, int wv) {
     constexpr bool CROSS = X == X_AB;
 #ifdef MKHE_H16_X_NOXCHG
@@ -390,20 +429,17 @@ template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds
     const int l = lane_id();
     typedef __attribute__((address_space(3))) u32* lptr;
     typedef volatile __attribute__((address_space(3))) u32* vlptr;
-    lptr wr = (lptr)lds + wbase<X>(wv, l);
     // The reads are volatile so that they stay single ds_read_b32: merged into ds_read2_b32 the two words of one instruction
     // (same plane, two different coefficients) land in a consecutive register pair and every coefficient then needs two v_mov to
     // get its own (low, high) pair back -- 32 VALU instructions per re-distribution, in a kernel that is VALU-issue bound.
     vlptr rd = (vlptr)((lptr)lds + rbase<X>(wv, l));
     if constexpr (CROSS) __syncthreads();          // every wave is done reading its region (previous pass)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) wr[woff<X>(r)] = lo32(x[r]);
+    write_plane<X, false>(x, lds, wv, l);
     xsync<CROSS>();
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = (x[r] & 0xffffffff00000000ull) | rd[roff<X>(r)];
     xsync<CROSS>();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) wr[woff<X>(r)] = hi32(x[r]);
+    write_plane<X, true>(x, lds, wv, l);
     xsync<CROSS>();
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = ((u64)rd[roff<X>(r)] << 32) | lo32(x[r]);
@@ -923,7 +959,11 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
     c.lazy_out = stagger;
     const int resident = resident16(lds);
     const int need = c.nslots * c.nouter;
-    const int blocks = need < resident ? need : resident;
+    int blocks = need < resident ? need : resident;
+    // experiment (MKHE_NTT16_EVEN=1): as many workgroups as give every one of them the same number of limbs (1792 and 896 limbs: 448 instead of
+    // 512) -- an even last round on 7/8 of the CUs instead of a ragged one on all of them
+    static const int even = env_int16("MKHE_NTT16_EVEN", 0);
+    if (even && need > resident) { const int rounds = (need + resident - 1) / resident; blocks = (need + rounds - 1) / rounds; }
     if (logN == 14) {
         if (c.reduce_in) hipLaunchKernelGGL(ntt14_fwd_kernel<true>, dim3(blocks), dim3(NT), lds, st, c);
         else hipLaunchKernelGGL(ntt14_fwd_kernel<false>, dim3(blocks), dim3(NT), lds, st, c);
