@@ -31,6 +31,11 @@
 // phase (pred() below) where ntt_kernels.hip runs Harvey butterflies.  Same DEC digit reduction, same skip_norm / canonical outputs,
 // so the two kernels are interchangeable bit for bit on canonical outputs (internal lazy representatives differ).
 //
+// Round 3: two instantiations of the limb body -- the U class (moduli with 160 q < 2^62: unsigned low data digit, one-round product of radix
+// 2^30 "mm30u", no reductions) and the balanced path above for the 59/60-bit primes, whose partial reductions follow a per-modulus schedule
+// (NttBatch::sched); lane-linear LDS writes as ds_write_addtid_b32; the same body as ntt14_fwd_kernel for N = 2^14 (one pass per limb).  The
+// kernel runs at the package power cap (tools/power_probe.sh); DESIGN.md section 3 "Round 3" has the steady-state ablation of its two sides.
+//
 // Replaces: lattigo ring.NTTLvl as called from DecomposeSingleNTT (mkrlwe/keyswitch.go:21-31,49-73).
 #include "ntt_kernels.h"
 #include <cstdlib>
@@ -441,9 +446,17 @@ template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds
     xsync<CROSS>();
     write_plane<X, true>(x, lds, wv, l);
     xsync<CROSS>();
+#ifdef MKHE_H16_FLOW
+    // experiment: the high words are requested in the order in which the first stage of the next phase consumes them (pairs r, r + 8) and
+    // nothing waits for all of them: the compiler's counted lgkmcnt waits let the first butterflies start while the later words are in flight
+    // (a wave's LDS operations execute in order, so the next write to this region -- a whole phase later -- needs no fence)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int r = (k >> 1) | ((k & 1) << 3); x[r] = ((u64)rd[roff<X>(r)] << 32) | lo32(x[r]); }
+#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = ((u64)rd[roff<X>(r)] << 32) | lo32(x[r]);
     if constexpr (!CROSS) xsync<false>();
+#endif
 }
 
 // ------------------------------------------------------------------ one limb
