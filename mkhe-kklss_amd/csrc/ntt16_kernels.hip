@@ -393,6 +393,9 @@ __device__ __forceinline__ int lane_id() {
 #ifndef MKHE_H16_ADDTID
 #define MKHE_H16_ADDTID 1
 #endif
+#ifndef MKHE_H16_PRIO
+#define MKHE_H16_PRIO 1
+#endif
 template <int X, int R0> __device__ __forceinline__ void addtid_write8(const u32 (&w)[8], unsigned base_bytes) {
     asm volatile("s_mov_b32 m0, %8\n\t"
                  "s_nop 0\n\t"                              // (SALU write of M0 -> add-TID LDS instruction: one wait state; hazards inside an asm block are ours)
@@ -510,6 +513,11 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         const int h = __builtin_amdgcn_readfirstlane(hh);
         const int ht = LOGN == 14 ? 1 : h;              // the half as the twiddle indices see it
         H16_STAMP(0);
+        // The part of a pass that ends in the four workgroup barriers of the A -> B exchange runs at raised wave priority, so that the sixteen
+        // waves of a workgroup reach those barriers together while the co-resident workgroup's waves, if they are in the barrier-free phases
+        // B .. E, yield (profiles/r2_ntt16_phase_trace.txt: a wave spends a quarter of a pass waiting at those barriers): 264.9 -> 262.4 us
+        // for the 1792-limb launch, 143.5 -> 140.6 us for the 896-limb one (MKHE_H16_PRIO=0 switches it off)
+        if (MKHE_H16_PRIO) __builtin_amdgcn_s_setprio(MKHE_H16_PRIO);
         // ---- stage 0: the cross-half butterflies.  Out of place (every Decompose launch: the source is a ciphertext limb) BOTH passes
         // load x[j], x[j + N/2] and keep their own output of the butterfly -- the second pass repeats 16 products per thread (1/15 of
         // the butterfly work) and re-reads the source, which 15 other workgroups read as well (L2 / Infinity Cache), instead of
@@ -675,6 +683,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         reduce_all(x, c, big && (jb.sched & 2));
         H16_STAMP(2);
         exchange<X_AB>(x, lds, wv);
+        if (MKHE_H16_PRIO) __builtin_amdgcn_s_setprio(0);
         H16_STAMP(3);
         // ---- phase B: bits 9..6, twiddles psi[2^k + ((16h + wave) << (k-5)) + i], k = 5..8
         {

@@ -44,7 +44,7 @@ REPS=1500 bash tools/ntt16_variants.sh "shipped:" "no_mem_no_xchg:-DMKHE_H16_X_N
     "no_mem:-DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE" "no_store:-DMKHE_H16_X_NOSTORE" "no_src:-DMKHE_H16_X_NOSRC" "no_tw:-DMKHE_H16_X_NOTWLOAD" \
     "no_xchg:-DMKHE_H16_X_NOXCHG=15" "no_bfly:-DMKHE_H16_X_NOBFLY=3" "no_scalar_bfly:-DMKHE_H16_X_NOBFLY=1" "no_perlane_bfly:-DMKHE_H16_X_NOBFLY=2" \
     "skeleton:-DMKHE_H16_X_NOBFLY=3 -DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE" "force_park:-DMKHE_H16_FORCE_PARK" "pipelined_loads:-DMKHE_H16_PIPE" \
-    "phase_d_one_round:-DMKHE_H16_UD31=1" "plain_lds_writes:-DMKHE_H16_ADDTID=0" "flowing_lds_reads:-DMKHE_H16_FLOW" "shipped_again:" > $O/ntt16_ablation.txt 2>&1
+    "phase_d_one_round:-DMKHE_H16_UD31=1" "plain_lds_writes:-DMKHE_H16_ADDTID=0" "no_priority:-DMKHE_H16_PRIO=0" "flowing_lds_reads:-DMKHE_H16_FLOW" "shipped_again:" > $O/ntt16_ablation.txt 2>&1
 (echo "== U class off (MKHE_H16_UCLASS=0)"; MKHE_H16_UCLASS=0 python3 tools/ntt16_bench.py 1500 | grep -E "limbs +(1792|896) " | cut -c1-112; echo "== round-2 reduction schedule (MKHE_H16_SCHED=0)"; MKHE_H16_SCHED=0 python3 tools/ntt16_bench.py 1500 | grep -E "limbs +(1792|896) " | cut -c1-112) >> $O/ntt16_ablation.txt 2>&1
 python3 tools/ntt16_bench.py 1500 > $O/ntt16_bench.txt 2>&1
 echo "ntt done"

@@ -129,7 +129,7 @@ each other's operands, one of the two is read twice), the x / y round trip, and 
   no LDS exchanges {abl("no_xchg"):.0f}; no memory stream at all {abl("no_mem"):.0f}; neither memory nor exchanges — the vector-ALU side alone — **{abl("no_mem_no_xchg"):.0f}** ({16 * 32768 * 1792 / abl("no_mem_no_xchg") / 8e6:.2f} of the roofline); all butterflies removed — the memory / LDS side alone — **{abl("no_bfly"):.0f}**;
   exchanges and barriers alone {abl("skeleton"):.0f}.  0.50 of the roofline would be 235 µs: above both floors, but only with 87 % of either side hidden under the other; the kernel hides about two thirds.  Experiments on hiding more, same table:
   one memory round trip per pass (`pipelined_loads`) {abl("pipelined_loads"):.0f}, parking instead of recomputing stage 0 (`force_park`) {abl("force_park"):.0f}, phase D on the one-round product (`phase_d_one_round`, 10 spilled VGPRs) {abl("phase_d_one_round"):.0f}.
-  LDS writes as plain `ds_write_b32` (`plain_lds_writes`) {abl("plain_lds_writes"):.0f}, the last LDS reads of a re-distribution flowing into the next phase (`flowing_lds_reads`) {abl("flowing_lds_reads"):.0f}.
+  LDS writes as plain `ds_write_b32` (`plain_lds_writes`) {abl("plain_lds_writes"):.0f}, no raised wave priority in front of the cross-wave barriers (`no_priority`) {abl("no_priority"):.0f}, the last LDS reads of a re-distribution flowing into the next phase (`flowing_lds_reads`) {abl("flowing_lds_reads"):.0f}.
   What round 3 changed: the U class off (`MKHE_H16_UCLASS=0`) {abl("U class off"):.0f}, the round-2 reduction schedule for the 59/60-bit primes {abl("round-2 reduction schedule"):.0f}.
 * `{tag}_ubench.txt`: the bare butterfly on `mm31` (round 2) {m31.group(3) if m31 else "?"} cycles per wave at {m31.group(1) if m31 else "?"} GHz = {m31.group(2) if m31 else "?"} ns, on `mm30u` (round 3: unsigned low data digit, no fix-up instructions) **{m30.group(3) if m30 else "?"} cycles at {m30.group(1) if m30 else "?"} GHz = {m30.group(2) if m30 else "?"} ns**
   (65 536 products checked against the host first).  `{tag}_ntt16_isa.txt`: 13.6 VALU instructions per butterfly in the U-class pass body of the shipped code object (round 2: 17.7).
