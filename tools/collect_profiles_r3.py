@@ -20,7 +20,17 @@ for f, t in (("party_sweep.jsonl", "party_sweep.jsonl"), ("ubench.txt", "ubench.
              ("ntt16_ablation.txt", "ntt16_ablation.txt")):
     src = os.path.join(G, f)
     if os.path.exists(src):
-        txt = "\n".join(l[:230] for l in open(src).read().split("\n") if not l.startswith(("RCCL", "HIP version", "ROCm version", "Hostname", "Librccl", "/opt/amdgpu")))
+        txt = "\n".join(l for l in open(src).read().split("\n") if not l.startswith(("RCCL", "HIP version", "ROCm version", "Hostname", "Librccl", "/opt/amdgpu")))
+        if f == "power_probe.txt":
+            # one sample per line: rocm-smi prints every field on a line of its own and the probe joins them
+            out_l = []
+            for l in open(src).read().split("\n"):
+                mc, mp = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", l), re.search(r"Power \(W\): ([0-9.]+)", l)
+                if mc and mp and "mclk" in l:
+                    out_l.append("sample under load: sclk clock level: 1 (%sMhz)   Package Power (W): %s" % (mc.group(1), mp.group(1)))
+                elif l.strip():
+                    out_l.append(l[:200])
+            txt = "\n".join(out_l) + "\n"
         open(os.path.join(P, "%s_%s" % (tag, t)), "w").write(txt)
 out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "traffic_from_pmc.py"),
                                os.path.join(G, "pmc_fetch"), os.path.join(G, "pmc_write"), workload, "6", "2"])

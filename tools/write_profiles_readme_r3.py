@@ -64,7 +64,7 @@ dom = pmc_rec("ntt16_fwd_kernel<true>") or {}
 cb = pl["cpu_baseline"]
 C = pl["config"]
 tot_bytes, cov = whole_step()
-power = [l for l in open(P + tag + "_power_probe.txt").read().split("\n") if "sclk" in l and "Power" in l]
+power = [l for l in open(P + tag + "_power_probe.txt").read().split("\n") if l.startswith("sample under load")]
 pw = sorted(float(re.search(r"Power \(W\): ([0-9.]+)", l).group(1)) for l in power)
 ck = sorted(float(re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", l).group(1)) for l in power)
 ub = open(P + tag + "_ubench.txt").read()
@@ -124,7 +124,7 @@ each other's operands, one of the two is read twice), the x / y round trip, and 
   {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and the register spills (24 B of scratch per lane).  Read: the source limbs in both passes
   (each is spread under 16 moduli) and the twiddle pairs — an XCD's 4 MiB L2 holds neither its 14 source limbs (3.5 MB) plus the tables of the 4–5 moduli in flight (1.5 MB), so part of the re-reads come from the Infinity Cache.
 * **It runs at the package power cap** (`{tag}_power_probe.txt`): {pw[len(pw) // 2]:.0f} W (median of the samples under load; cap 1400 W, idle 236 W) at {ck[len(ck) // 2] / 1e3:.2f} GHz.  After an idle phase the clocks need ≈ 150 ms to settle: ten back-to-back launches (round 2's tables)
-  measure 355 µs for 1792 limbs, 1500 launches **{abl("shipped"):.0f} µs** — the same 0.148 µs per limb as inside the MulRelin.
+  measure 355 µs for 1792 limbs, 1500 launches **{abl("shipped"):.0f} µs** = {abl("shipped") / 1792:.3f} µs per limb ({R["avg_launch_us"] / 1344:.3f} µs per limb inside the MulRelin, whose launches alternate with memory-bound kernels).
 * **Steady-state ablation of the shipped kernel** (`{tag}_ntt16_ablation.txt`, 1792 limbs, µs per launch): shipped {abl("shipped"):.0f}; no result stores {abl("no_store"):.0f}, no source loads {abl("no_src"):.0f}, no per-lane twiddle loads {abl("no_tw"):.0f},
   no LDS exchanges {abl("no_xchg"):.0f}; no memory stream at all {abl("no_mem"):.0f}; neither memory nor exchanges — the vector-ALU side alone — **{abl("no_mem_no_xchg"):.0f}** ({16 * 32768 * 1792 / abl("no_mem_no_xchg") / 8e6:.2f} of the roofline); all butterflies removed — the memory / LDS side alone — **{abl("no_bfly"):.0f}**;
   exchanges and barriers alone {abl("skeleton"):.0f}.  0.50 of the roofline would be 235 µs: above both floors, but only with 87 % of either side hidden under the other; the kernel hides about two thirds.  Experiments on hiding more, same table:
