@@ -837,20 +837,43 @@ __device__ __forceinline__ void spread_prepare(const DecompSpreadArgs& a, const 
     }
     c.v = (u64)vi;
 }
-__device__ __forceinline__ u64 spread_value(const SpreadCoeff& c, const u64* tb, const u64* tc, int m, int nd, const Mod& mt) {
+// The per-slot constants are wave-uniform: they are read with SCALAR loads (constant address space) into SlotConsts once per slot and shared by
+// the four coefficients of a thread -- round 2 fetched them with per-lane vector loads (every lane the same address) inside spread_value, one
+// dependent global round trip per coefficient and slot at four waves per SIMD, which is what the kernel was bound by.  vtimesqmodp[v] (v <= nd <= 4,
+// per coefficient) is selected from the nd + 1 scalar entries instead of gathered.
+typedef const __attribute__((address_space(4))) u64* sc_u64;
+typedef const __attribute__((address_space(4))) int* sc_int;
+typedef const __attribute__((address_space(4))) Mod* sc_mod;
+struct SlotConsts { u64 tb[DEC_MAXA]; u64 tc[DEC_MAXA + 1]; };
+__device__ __forceinline__ Mod load_mod(sc_mod p) {
+    Mod m;
+    m.q = p->q; m.q2 = p->q2; m.ninv32 = p->ninv32; m.finv = p->finv; m.qinv = p->qinv; m.r1 = p->r1; m.r2 = p->r2; m.qs = p->qs; m.r1s = p->r1s;
+    return m;
+}
+__device__ __forceinline__ void slot_consts(SlotConsts& k, const u64* tb, const u64* tc, int m, int nd) {
+    sc_u64 b = (sc_u64)tb + (long)m * DEC_MAXA, c = (sc_u64)tc + (long)m * (DEC_MAXA + 1);
+#pragma unroll
+    for (int i = 0; i < DEC_MAXA; ++i) k.tb[i] = i < nd ? b[i] : 0;
+#pragma unroll
+    for (int i = 0; i <= DEC_MAXA; ++i) k.tc[i] = i <= nd ? c[i] : 0;
+}
+__device__ __forceinline__ u64 spread_value(const SpreadCoeff& c, const SlotConsts& k, int nd, const Mod& mt) {
     u64 rlo = 0, rhi = 0;
 #pragma unroll
     for (int i = 0; i < DEC_MAXA; ++i) {
         if (i < nd) {
             u64 mhi, mlo;
-            mul64x64(c.y[i], tb[(long)m * DEC_MAXA + i], mhi, mlo);
+            mul64x64(c.y[i], k.tb[i], mhi, mlo);
             u64 sum = rlo + mlo;
             rhi += mhi + (sum < rlo ? 1 : 0);
             rlo = sum;
         }
     }
     const u64 hhi = mulhi64(rlo * mt.qinv, mt.q);
-    return rhi - hhi + mt.q + tc[(long)m * (DEC_MAXA + 1) + c.v];
+    u64 vt = k.tc[0];
+#pragma unroll
+    for (int i = 1; i <= DEC_MAXA; ++i) vt = (i <= nd && c.v == (u64)i) ? k.tc[i] : vt;
+    return rhi - hhi + mt.q + vt;
 }
 // first Cooley-Tukey stage on the pair (lo, hi) = coefficients (n, n + N/2), both < 4q: same arithmetic as ntt_split_fwd_kernel
 __device__ __forceinline__ void spread_first_stage(u64& lo, u64& hi, u64 w, const Mod& mt) {
@@ -905,14 +928,16 @@ __global__ void __launch_bounds__(PW_THREADS) decomp_spread_kernel(DecompSpreadA
     spread_prepare(a, src, ta, start, nd, n + 1, c01);
     if (a.first_stage) { spread_prepare(a, src, ta, start, nd, n + H, c10); spread_prepare(a, src, ta, start, nd, n + H + 1, c11); }
     for (int s = 0; s < a.nslots; ++s) {
-        const int m = a.map[s];
-        const Mod mt = a.mods[m];
-        u64 lo0 = spread_value(c00, tb, tc, m, nd, mt);
-        u64 lo1 = spread_value(c01, tb, tc, m, nd, mt);
+        const int m = ((sc_int)a.map)[s];
+        const Mod mt = load_mod((sc_mod)a.mods + m);
+        SlotConsts k;
+        slot_consts(k, tb, tc, m, nd);
+        u64 lo0 = spread_value(c00, k, nd, mt);
+        u64 lo1 = spread_value(c01, k, nd, mt);
         if (a.first_stage) {
-            u64 hi0 = spread_value(c10, tb, tc, m, nd, mt);
-            u64 hi1 = spread_value(c11, tb, tc, m, nd, mt);
-            const u64 w = a.psi[(long)m * a.N + 1];
+            u64 hi0 = spread_value(c10, k, nd, mt);
+            u64 hi1 = spread_value(c11, k, nd, mt);
+            const u64 w = ((sc_u64)a.psi)[(long)m * a.N + 1];
             spread_first_stage(lo0, hi0, w, mt);
             spread_first_stage(lo1, hi1, w, mt);
             st2(dst + (long)m * a.N + n + H, hi0, hi1);
