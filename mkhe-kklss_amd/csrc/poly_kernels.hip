@@ -16,6 +16,24 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 // Measured on MI355X: inner_product_kernel 102 -> 88 us per launch (5.1 -> 6.0 TB/s), the step 1.23 -> 1.217 ms.
 __device__ __forceinline__ u64x2 ld_stream(const u64* p) { return __builtin_nontemporal_load((const u64x2*)p); }
 __device__ __forceinline__ u64x2 ld_cached(const u64* p) { return *(const u64x2*)p; }
+// Wave-uniform table entries (per-modulus constants, base-conversion tables) are read through the constant address space, i.e. with SCALAR
+// loads: indexed by a value that came out of a vector load (a slot -> modulus map) or by a loop counter the compiler does not prove uniform,
+// they were fetched per lane -- one dependent vector round trip per entry inside the limb loops of the latency-bound kernels (round 3).
+typedef const __attribute__((address_space(4))) u64* sc_u64;
+typedef const __attribute__((address_space(4))) int* sc_int;
+typedef const __attribute__((address_space(4))) Mod* sc_mod;
+__device__ __forceinline__ Mod load_mod(sc_mod p) {
+    Mod m;
+    m.q = p->q; m.q2 = p->q2; m.ninv32 = p->ninv32; m.finv = p->finv; m.qinv = p->qinv; m.r1 = p->r1; m.r2 = p->r2; m.qs = p->qs; m.r1s = p->r1s;
+    return m;
+}
+// table[v] for a per-lane v in [0, n]: the n + 1 entries are wave-uniform (scalar loads), the lane selects
+template <int NMAX> __device__ __forceinline__ u64 select_entry(sc_u64 row, int n, u64 v) {
+    u64 r = row[0];
+#pragma unroll
+    for (int i = 1; i <= NMAX; ++i) if (i <= n) r = v == (u64)i ? row[i] : r;
+    return r;
+}
 template <int NT>
 __global__ void __launch_bounds__(PW_THREADS) inner_product_kernel(InnerProductArgs a) {
     const int s = blockIdx.y;                 // active-limb slot
@@ -418,31 +436,31 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             if (i < a.np) {
-                const Mod mp = a.mods_p[i];
-                y[i] = mont_mul(xp[(long)i * a.N + n], a.t.qoverqiinvqi[i], mp.q, mp.ninv32);
+                const Mod mp = load_mod((sc_mod)a.mods_p + i);
+                y[i] = mont_mul(xp[(long)i * a.N + n], ((sc_u64)a.t.qoverqiinvqi)[i], mp.q, mp.ninv32);
                 vi = vi + (double)y[i] / (double)mp.q;
             }
         }
         const u64 v = (u64)vi;
         const int nj = a.qlist ? a.nqlist : a.level + 1;
         for (int jj = blockIdx.y; jj < nj; jj += gridDim.y) {
-            const int j = a.qlist ? a.qlist[jj] : jj;
-            const Mod mq = a.mods_q[j];
+            const int j = a.qlist ? ((sc_int)a.qlist)[jj] : jj;
+            const Mod mq = load_mod((sc_mod)a.mods_q + j);
             u64 rlo = 0, rhi = 0;
 #pragma unroll
             for (int i = 0; i < MAXP; ++i) {
                 if (i < a.np) {
                     u64 mhi, mlo;
-                    mul64x64(y[i], a.t.qoverqimodp[(long)j * a.np + i], mhi, mlo);
+                    mul64x64(y[i], ((sc_u64)a.t.qoverqimodp)[(long)j * a.np + i], mhi, mlo);
                     u64 sum = rlo + mlo;
                     rhi += mhi + (sum < rlo ? 1 : 0);
                     rlo = sum;
                 }
             }
             const u64 hhi = mulhi64(rlo * mq.qinv, mq.q);
-            const u64 lift = rhi - hhi + mq.q + a.t.vtimesqmodp[(long)j * (a.np + 1) + v];
+            const u64 lift = rhi - hhi + mq.q + select_entry<MAXP>((sc_u64)a.t.vtimesqmodp + (long)j * (a.np + 1), a.np, v);
             const u64 x = xq[(long)j * a.N + n];
-            u64 z = mont_mul(lift + mq.q2 - x, a.t.downparam[j], mq.q, mq.ninv32);
+            u64 z = mont_mul(lift + mq.q2 - x, ((sc_u64)a.t.downparam)[j], mq.q, mq.ninv32);
             long pos = (long)j * a.N + n;
             bool flip = false;
             if (a.galEl) {
@@ -511,8 +529,8 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
                 double vi_ = 0.0;
 #pragma unroll
                 for (int i = 0; i < NPT; ++i) {
-                    const Mod mp = a.mods_p[i];
-                    y[k][i] = mont_mul(xp[(long)i * a.N + n], a.t.qoverqiinvqi[i], mp.q, mp.ninv32);
+                    const Mod mp = load_mod((sc_mod)a.mods_p + i);
+                    y[k][i] = mont_mul(xp[(long)i * a.N + n], ((sc_u64)a.t.qoverqiinvqi)[i], mp.q, mp.ninv32);
                     vi_ = vi_ + (double)y[k][i] / (double)mp.q;
                 }
                 v[k] = (u32)(u64)vi_;
@@ -527,27 +545,27 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
 #pragma unroll
                     for (int i = 0; i < NPT; ++i) {
                         u64 mhi, mlo;
-                        mul64x64(y[k][i], a.t.qoverqimodp[(long)j * NPT + i], mhi, mlo);
+                        mul64x64(y[k][i], ((sc_u64)a.t.qoverqimodp)[(long)j * NPT + i], mhi, mlo);
                         const u64 sum = rlo + mlo;
                         rhi += mhi + (sum < rlo ? 1 : 0);
                         rlo = sum;
                     }
-                    vt = csub(vt + a.t.vtimesqmodp[(long)j * (NPT + 1) + v[k]], mq.q);
+                    vt = csub(vt + select_entry<NPT>((sc_u64)a.t.vtimesqmodp + (long)j * (NPT + 1), NPT, (u64)v[k]), mq.q);
                 }
             }
             const u64 hhi = mulhi64(rlo * mq.qinv, mq.q);
             const u64 lift = rhi - hhi + mq.q + vt;                      // = sum_k (the reference's per-product lift) mod q
             const u64 x = xq[(long)j * a.N + n];                         // lazy, < 2q
-            return mont_mul(lift + mq.q2 - x, a.t.downparam[j], mq.q, mq.ninv32);
+            return mont_mul(lift + mq.q2 - x, ((sc_u64)a.t.downparam)[j], mq.q, mq.ninv32);
         };
         if (a.rescale_row) {
             // DivRoundByLastModulus (lattigo, as div_round_last_kernel restates it) of the result, limb by limb: the dropped limb first
-            const Mod mL = a.mods_q[a.level];
+            const Mod mL = load_mod((sc_mod)a.mods_q + a.level);
             const u64 qL = mL.q, h = (qL - 1) >> 1;
             const u64 t = csub(down(a.level, mL) + h, qL);
             u64* rd = ka->rdst[vi];
             for (int j = blockIdx.y; j < a.level; j += gridDim.y) {
-                const Mod mq = a.mods_q[j];
+                const Mod mq = load_mod((sc_mod)a.mods_q + j);
                 u64 hr;
                 {
                     const u64 kq = (u64)((double)h / (double)mq.q);        // BRedAdd(h, q_j) as in div_round_last_kernel
@@ -556,12 +574,12 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
                     if (hr >= mq.q) hr -= mq.q;
                 }
                 const u64 z = down(j, mq);
-                rd[(long)j * a.N + n] = mont_mul(t + (mq.q - hr) + mq.q2 - z, mq.q - a.rescale_row[j], mq.q, mq.ninv32);
+                rd[(long)j * a.N + n] = mont_mul(t + (mq.q - hr) + mq.q2 - z, mq.q - ((sc_u64)a.rescale_row)[j], mq.q, mq.ninv32);
             }
             continue;
         }
         for (int j = blockIdx.y; j <= a.level; j += gridDim.y) {
-            const Mod mq = a.mods_q[j];
+            const Mod mq = load_mod((sc_mod)a.mods_q + j);
             u64 z = down(j, mq);
             long pos = (long)j * a.N + n;
             bool flip = false;
@@ -841,15 +859,7 @@ __device__ __forceinline__ void spread_prepare(const DecompSpreadArgs& a, const 
 // the four coefficients of a thread -- round 2 fetched them with per-lane vector loads (every lane the same address) inside spread_value, one
 // dependent global round trip per coefficient and slot at four waves per SIMD, which is what the kernel was bound by.  vtimesqmodp[v] (v <= nd <= 4,
 // per coefficient) is selected from the nd + 1 scalar entries instead of gathered.
-typedef const __attribute__((address_space(4))) u64* sc_u64;
-typedef const __attribute__((address_space(4))) int* sc_int;
-typedef const __attribute__((address_space(4))) Mod* sc_mod;
 struct SlotConsts { u64 tb[DEC_MAXA]; u64 tc[DEC_MAXA + 1]; };
-__device__ __forceinline__ Mod load_mod(sc_mod p) {
-    Mod m;
-    m.q = p->q; m.q2 = p->q2; m.ninv32 = p->ninv32; m.finv = p->finv; m.qinv = p->qinv; m.r1 = p->r1; m.r2 = p->r2; m.qs = p->qs; m.r1s = p->r1s;
-    return m;
-}
 __device__ __forceinline__ void slot_consts(SlotConsts& k, const u64* tb, const u64* tc, int m, int nd) {
     sc_u64 b = (sc_u64)tb + (long)m * DEC_MAXA, c = (sc_u64)tc + (long)m * (DEC_MAXA + 1);
 #pragma unroll
