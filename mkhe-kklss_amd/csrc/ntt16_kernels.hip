@@ -832,6 +832,10 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
     }
 }
 
+__device__ __forceinline__ int kb_lpt_long() {
+    kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+    return kb->lpt_long;
+}
 template <bool DEC, bool SPLIT, int LOGN = 15>
 __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
     constexpr int NL = 1 << LOGN;                 // words per limb = twiddle words per modulus
@@ -842,7 +846,26 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
     if (b.lazy_out > 0 && blockIdx.x >= (gridDim.x >> 1)) { for (int i = 0; i < b.lazy_out; ++i) __builtin_amdgcn_s_sleep(127); }
 #pragma unroll 1
     for (int job2 = blockIdx.x; job2 < njobs; job2 += gridDim.x) {
-        const int job = SPLIT ? job2 >> 1 : job2;           // SPLIT: the two halves of a limb are consecutive jobs
+        // Which limb position job2 of the walk gets (round 3).  Workgroups b and b + C share a CU (C = gridDim / 2), so CU c owns the positions
+        // = c mod C of the job list, and when the list does not fill the last row (njobs mod C = r != 0) the CUs r .. C-1 own one position fewer.
+        // The first `lpt_long` jobs of the list are the long ones (59/60-bit moduli: +35 % instructions); they go to those lighter CUs, row by
+        // row -- 896 limbs with 168 long ones on 256 CUs: no CU carries more than 4.0 limb-units where the list order gives half of them 4.35
+        // (141.8 -> 138.3 us for that launch).  A bijection of [0, njobs): every limb is still transformed exactly once.
+        int job = job2;
+        if constexpr (!SPLIT) {
+            const int B0 = kb_lpt_long(), C = (int)gridDim.x >> 1;
+            const int r = C > 0 ? njobs % C : 0;
+            if (B0 > 0 && r != 0 && (int)gridDim.x == 2 * C && njobs > (int)gridDim.x) {
+                const int w = C - r, q = njobs / C;                   // light CUs; complete rows
+                const int B = B0 < q * w ? B0 : q * w;                // long jobs that find a light position
+                const int full = B / w, rem = B - full * w;           // rows whose light positions all take one, and the next row's share
+                const int row = __builtin_amdgcn_readfirstlane(job2 / C), col = job2 - row * C;
+                const int srow = row < full ? w : (row == full ? rem : 0);
+                const int before = row <= full ? row * w : B;         // special positions in the rows above
+                if (col >= r && col - r < srow) job = before + (col - r);
+                else job = B + job2 - before - (col > r ? (col - r < srow ? col - r : srow) : 0);
+            }
+        } else job = job2 >> 1;                              // SPLIT: the two halves of a limb are consecutive jobs
         // The launch description is re-read from the kernel-argument segment for every limb (a handful of scalar loads) instead
         // of being kept in SGPRs across the limb: kept live it overflows the SGPR file into VGPR lanes, and those VGPRs are
         // what the 64-register budget of this kernel does not have.
@@ -977,8 +1000,13 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
                 ++c.nslots;
             }
     const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
-    static const int stagger = env_int16("MKHE_NTT16_STAGGER", 0);
+    static const int stagger = env_int16("MKHE_NTT16_STAGGER", 0), lpt = env_int16("MKHE_NTT16_LPT", 1);
     c.lazy_out = stagger;
+    {   // the long jobs lead the slot-major list: every slot of a 59/60-bit modulus, nouter limbs each
+        int nbig = 0;
+        for (int s2 = 0; s2 < c.nslots; ++s2) if (!((c.small_slots >> s2) & 1)) ++nbig;
+        c.lpt_long = lpt && nbig < c.nslots ? nbig * c.nouter : 0;
+    }
     const int resident = resident16(lds);
     const int need = c.nslots * c.nouter;
     int blocks = need < resident ? need : resident;
