@@ -41,6 +41,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <utility>
+#include <stdexcept>
 
 namespace mkhe {
 namespace h16 {
@@ -395,6 +396,9 @@ __device__ __forceinline__ int lane_id() {
 #endif
 #ifndef MKHE_H16_PRIO
 #define MKHE_H16_PRIO 1
+#endif
+#ifndef MKHE_H16_URED
+#define MKHE_H16_URED 1          // 0: the round-2 rule (reduce digits above 4q at the load) for the U class too (A/B)
 #endif
 template <int X, int R0> __device__ __forceinline__ void addtid_write8(const u32 (&w)[8], unsigned base_bytes) {
     asm volatile("s_mov_b32 m0, %8\n\t"
@@ -791,6 +795,13 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
                 if (n == 4) loadg(3);
                 if (n == 8) loadg(4);
                 if (n == 10) loadg(5);
+                if (n == 8 && !(big || !jb.skip_norm)) {
+                    // the positive bias of engine-internal digits (see "output representative" below) enters through the eight U operands of the
+                    // LAST stage -- X = (U + b) + T, Y = (U + b) - T -- instead of being added to the sixteen results
+                    const i64 bias = UC ? (i64)((c.q << 6) + (c.q << 3) + (c.q << 1) + c.q) : (i64)((c.q << 4) + (c.q << 3));
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) x[r] = (u64)((i64)x[r] + bias);
+                }
                 const int gi = n & 7;
                 if (n < 8) bfly1<1>(x, gi, g[gi >> 2][(gi >> 1) & 1], c);
                 else bfly1<0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
@@ -806,9 +817,11 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
             }
         } else {
             // engine-internal digits: same residue, positive.  Balanced path: |x| < 20q -> + 24q -> (4q, 44q); U class: x in (-75q, 79q) -> + 75q -> (0, 154q) < 2^62
-            const i64 bias = UC ? (i64)((c.q << 6) + (c.q << 3) + (c.q << 1) + c.q) : (i64)((c.q << 4) + (c.q << 3));
+            if constexpr (D31) {           // (the two-round phase D above has added it already, through the U operands of its last stage)
+                const i64 bias = UC ? (i64)((c.q << 6) + (c.q << 3) + (c.q << 1) + c.q) : (i64)((c.q << 4) + (c.q << 3));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = (u64)((i64)x[r] + bias);
+                for (int r = 0; r < 16; ++r) x[r] = (u64)((i64)x[r] + bias);
+            }
         }
         H16_STAMP(9);
         exchange<X_DE>(x, lds, wv);
@@ -832,10 +845,9 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
     }
 }
 
-__device__ __forceinline__ int kb_lpt_long() {
-    kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
-    return kb->lpt_long;
-}
+// n / d for 0 <= n < 2^16, 1 <= d < 2^16 as ONE scalar multiply-high: magic = floor(2^32 / d) + 1 (host: magic_of), exact in that range
+// (the error term n * (magic * d - 2^32) / (d * 2^32) stays below 1 / d)
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return (unsigned)(((unsigned long long)n * magic) >> 32); }
 template <bool DEC, bool SPLIT, int LOGN = 15>
 __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
     constexpr int NL = 1 << LOGN;                 // words per limb = twiddle words per modulus
@@ -851,15 +863,15 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         // The first `lpt_long` jobs of the list are the long ones (59/60-bit moduli: +35 % instructions); they go to those lighter CUs, row by
         // row -- 896 limbs with 168 long ones on 256 CUs: no CU carries more than 4.0 limb-units where the list order gives half of them 4.35
         // (141.8 -> 138.3 us for that launch).  A bijection of [0, njobs): every limb is still transformed exactly once.
+        // (every quotient of the mapping is a launch constant computed by launch_ntt16_fwd -- NttBatch::lpt -- or a multiply-high by a
+        // precomputed reciprocal on the scalar unit: an integer division here runs on the VALU, in all sixteen waves, for every limb)
         int job = job2;
         if constexpr (!SPLIT) {
-            const int B0 = kb_lpt_long(), C = (int)gridDim.x >> 1;
-            const int r = C > 0 ? njobs % C : 0;
-            if (B0 > 0 && r != 0 && (int)gridDim.x == 2 * C && njobs > (int)gridDim.x) {
-                const int w = C - r, q = njobs / C;                   // light CUs; complete rows
-                const int B = B0 < q * w ? B0 : q * w;                // long jobs that find a light position
-                const int full = B / w, rem = B - full * w;           // rows whose light positions all take one, and the next row's share
-                const int row = __builtin_amdgcn_readfirstlane(job2 / C), col = job2 - row * C;
+            kargptr kl = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+            const int B = kl->lpt.B;
+            if (B > 0) {
+                const int C = kl->lpt.C, r = kl->lpt.r, w = C - r, full = kl->lpt.full, rem = kl->lpt.rem;
+                const int row = (int)udiv_magic((unsigned)job2, kl->lpt.magic_C), col = job2 - row * C;
                 const int srow = row < full ? w : (row == full ? rem : 0);
                 const int before = row <= full ? row * w : B;         // special positions in the rows above
                 if (col >= r && col - r < srow) job = before + (col - r);
@@ -873,13 +885,13 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         asm volatile("" : "+s"(kb));
         // slot-major job order (ntt_kernels.hip job_pointers): consecutive workgroups share a modulus
         const int nouter = kb->nouter;
-        const int s = __builtin_amdgcn_readfirstlane(job / nouter);      // integer division runs on the VALU: make the result an SGPR again
-        int outer = __builtin_amdgcn_readfirstlane(job - s * nouter);
+        const int s = (int)udiv_magic((unsigned)job, kb->magic_nouter);
+        int outer = job - s * nouter;
         const int m = kb->mod[s], p = kb->pos[s];
         const u64* sbase_ = kb->src; u64* dbase_ = kb->dst;
         if (kb->nitems > 0) {
             const int opi = kb->outers_per_item;
-            const int item = __builtin_amdgcn_readfirstlane(outer / opi);
+            const int item = (int)udiv_magic((unsigned)outer, kb->magic_opi);
             outer -= item * opi;
             sbase_ = kb->src_items[item]; dbase_ = kb->dst_items[item];
         }
@@ -901,7 +913,10 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
             const int rs = kb->reduce_src_mod_is_outer;
             if (rs == 1) sm = outer; else if (rs == 2) sm = kb->outer_mod[outer];
             const u64 qsb = ((smodptr)kb->mods)[sm].q << (kb->src_lazy ? 2 : 0);     // bound of the digit values (< 2^63)
-            jb.red = qsb > 4 * jb.mp->q;
+            // U class: raw canonical digits of ANY modulus (< 2^60) fit its range budget -- input + 75q of growth + the 75q bias stay below 2^62 for
+            // the 2^54 - delta primes -- so that only lazy (BFV) digits are reduced at the load; the balanced path reduces what exceeds 4q
+            if (MKHE_H16_URED && ((kb->u_mods >> m) & 1)) jb.red = qsb >= (1ull << 62) - 150 * jb.mp->q;
+            else jb.red = qsb > 4 * jb.mp->q;
         }
 #ifdef MKHE_PHASE_TRACE
         if (jb.trace && ((int)threadIdx.x & 63) == 0) {
@@ -966,6 +981,20 @@ int resident16(size_t lds) {
     return ls.resident[dev & 63];
 }
 }
+// launch constants of the job walk (fwd_body): reciprocals for the scalar multiply-high divisions and the placement of the long jobs
+static unsigned magic_of(int d) { return d > 0 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
+static void fill_job_constants(NttBatch& c, int njobs, int blocks, int lpt_long) {
+    if (njobs >= 65536 || c.nouter >= 65536) throw std::runtime_error("mkhe: internal: an H16 launch of 2^16 limbs or more");
+    c.magic_nouter = magic_of(c.nouter);
+    c.magic_opi = magic_of(c.nitems > 0 ? c.outers_per_item : 1);
+    c.lpt = NttBatch::Lpt{};
+    const int C = blocks >> 1;
+    if (lpt_long > 0 && C > 0 && blocks == 2 * C && njobs > blocks && njobs % C != 0) {
+        const int r = njobs % C, w = C - r, q = njobs / C;             // CUs 0 .. r-1 own one position more; w light CUs; q complete rows
+        const int B = lpt_long < q * w ? lpt_long : q * w;             // long jobs that find a light position
+        c.lpt.B = B; c.lpt.C = C; c.lpt.r = r; c.lpt.full = B / w; c.lpt.rem = B - (B / w) * w; c.lpt.magic_C = magic_of(C);
+    }
+}
 // sub-transforms of a split N = 2^16 launch (one modulus class per launch: `small` = 31 q < 2^62 for every slot)
 bool ntt16_split_ok(const NttBatch& c) {
     static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128);
@@ -979,6 +1008,7 @@ void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
     const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
     const int resident = resident16(lds);
     const int need = 2 * c.nslots * c.nouter;
+    fill_job_constants(c, c.nslots * c.nouter, 0, 0);
     hipLaunchKernelGGL(ntt16_fwd_split_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
 }
 bool ntt16_ok(int logN, const NttBatch& b) {
@@ -1002,11 +1032,9 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
     const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
     static const int stagger = env_int16("MKHE_NTT16_STAGGER", 0), lpt = env_int16("MKHE_NTT16_LPT", 1);
     c.lazy_out = stagger;
-    {   // the long jobs lead the slot-major list: every slot of a 59/60-bit modulus, nouter limbs each
-        int nbig = 0;
-        for (int s2 = 0; s2 < c.nslots; ++s2) if (!((c.small_slots >> s2) & 1)) ++nbig;
-        c.lpt_long = lpt && nbig < c.nslots ? nbig * c.nouter : 0;
-    }
+    int nbig = 0;                                      // the long jobs lead the slot-major list: every slot of a 59/60-bit modulus, nouter limbs each
+    for (int s2 = 0; s2 < c.nslots; ++s2) if (!((c.small_slots >> s2) & 1)) ++nbig;
+    const int lpt_long = lpt && nbig < c.nslots ? nbig * c.nouter : 0;
     const int resident = resident16(lds);
     const int need = c.nslots * c.nouter;
     int blocks = need < resident ? need : resident;
@@ -1014,6 +1042,7 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
     // 512) -- an even last round on 7/8 of the CUs instead of a ragged one on all of them
     static const int even = env_int16("MKHE_NTT16_EVEN", 0);
     if (even && need > resident) { const int rounds = (need + resident - 1) / resident; blocks = (need + rounds - 1) / rounds; }
+    fill_job_constants(c, need, blocks, lpt_long);
     if (logN == 14) {
         if (c.reduce_in) hipLaunchKernelGGL(ntt14_fwd_kernel<true>, dim3(blocks), dim3(NT), lds, st, c);
         else hipLaunchKernelGGL(ntt14_fwd_kernel<false>, dim3(blocks), dim3(NT), lds, st, c);

@@ -72,7 +72,10 @@ struct NttBatch {
                             // (u = w 2^30 mod q in [0, q) as digits u0, u1 >= 0; v = w 2^62 mod q balanced) of ntt16_kernels.hip mm30u
     unsigned char sched[NTT_MAX_SLOTS];   // ntt16_kernels.hip, indexed by MODULUS: where a limb of a 59/60-bit modulus gets its partial reductions when its
                             // inputs are below 2^60 (bit 0: at the load, bits 1..3: after phases A, B, C); Context::h16_sched_
-    int lpt_long;           // ntt16_kernels.hip: the first lpt_long jobs of the list are the long ones (big-modulus limbs); see fwd_body
+    // ntt16_kernels.hip, filled by its launchers: reciprocals for the per-limb index arithmetic (scalar multiply-high instead of VALU
+    // divisions) and the placement of the long jobs (the first B jobs of the list: big-modulus limbs) on the CUs that own fewer positions
+    unsigned magic_nouter, magic_opi;
+    struct Lpt { int B, C, r, full, rem; unsigned magic_C; } lpt;
     int no_h16;             // this context has a modulus the H16 kernel's ranges do not cover (48q >= 2^62 > 31q): keep to the other kernels
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
     int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists
