@@ -488,7 +488,7 @@ struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* p
 // phases with the twiddles of root 1 (psi[2^k + i]): in the index formulas below (root 2 tm + h of a 2^15-point limb's half h) that is
 // tm = 0 with the twiddle half ht = 1.
 template <bool DEC, bool SPLIT, bool UC, int LOGN = 15>
-__device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, const int wv) {
+__device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, const int wv, const int h_first = 0, const int h_last = 1) {
     static_assert(LOGN == 15 || (LOGN == 14 && !SPLIT), "H16 covers N = 2^15 (and its use on the halves of N = 2^16) and N = 2^14");
     const bool big = UC ? false : big_;
     const int tm = LOGN == 14 ? 0 : (SPLIT ? jb.root : 1);
@@ -513,7 +513,7 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
     const bool red = DEC && jb.red;
     u64 x[16];
 #pragma unroll 1
-    for (int hh = 0; hh < (LOGN == 15 ? 2 : 1); ++hh) {
+    for (int hh = (LOGN == 15 ? h_first : 0); hh <= (LOGN == 15 ? h_last : 0); ++hh) {
         const int h = __builtin_amdgcn_readfirstlane(hh);
         const int ht = LOGN == 14 ? 1 : h;              // the half as the twiddle indices see it
         H16_STAMP(0);
@@ -852,7 +852,11 @@ template <bool DEC, bool SPLIT, int LOGN = 15>
 __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
     constexpr int NL = 1 << LOGN;                 // words per limb = twiddle words per modulus
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int njobs = (b.nslots * b.nouter) << (SPLIT ? 1 : 0);
+    // half_jobs (out-of-place N = 2^15 launches, round 3): the two passes of a limb do not depend on each other out of place (each recomputes
+    // stage 0 from the source), so they are two jobs of the walk -- twice as many, half as long: a launch of 896 limbs deals 7 half-limbs to
+    // every CU instead of 4 limbs to one half of them and 3 to the other
+    const bool halves = !SPLIT && LOGN == 15 && b.half_jobs != 0;
+    const int njobs = (b.nslots * b.nouter) << ((SPLIT || halves) ? 1 : 0);
     // optional start delay of the second half of the persistent grid (the co-resident workgroup of every CU, as far as the
     // dispatcher deals workgroups b and b + gridDim/2 to the same CU): the two workgroups of a CU then sit in different phases
     if (b.lazy_out > 0 && blockIdx.x >= (gridDim.x >> 1)) { for (int i = 0; i < b.lazy_out; ++i) __builtin_amdgcn_s_sleep(127); }
@@ -865,7 +869,7 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         // (141.8 -> 138.3 us for that launch).  A bijection of [0, njobs): every limb is still transformed exactly once.
         // (every quotient of the mapping is a launch constant computed by launch_ntt16_fwd -- NttBatch::lpt -- or a multiply-high by a
         // precomputed reciprocal on the scalar unit: an integer division here runs on the VALU, in all sixteen waves, for every limb)
-        int job = job2;
+        int job = job2, half_pass = 0;
         if constexpr (!SPLIT) {
             kargptr kl = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
             const int B = kl->lpt.B;
@@ -876,6 +880,14 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
                 const int before = row <= full ? row * w : B;         // special positions in the rows above
                 if (col >= r && col - r < srow) job = before + (col - r);
                 else job = B + job2 - before - (col > r ? (col - r < srow ? col - r : srow) : 0);
+            }
+            if (halves) {
+                // (the mapping above ran on half-limb positions.)  XCD = workgroup index mod 8 and the job list is slot-major with the source limbs
+                // innermost, so whole-limb jobs give every XCD one eighth of the source limbs to keep in its L2; half-limb positions keep that
+                // property when blocks of 16 of them hold 8 limbs x 2 passes (limb mod 8 = position mod 8) -- plain (limb, pass) pairs put a limb's
+                // passes on two XCDs and double every L2's source set (the 1792-limb launch: 256 -> 270 us)
+                if (kl->half_jobs == 2) { half_pass = (job >> 3) & 1; job = ((job >> 4) << 3) | (job & 7); }
+                else { half_pass = job & 1; job >>= 1; }
             }
         } else job = job2 >> 1;                              // SPLIT: the two halves of a limb are consecutive jobs
         // The launch description is re-read from the kernel-argument segment for every limb (a handful of scalar loads) instead
@@ -926,8 +938,9 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
             tw[14] = blockIdx.x;
         }
 #endif
-        if ((kb->u_mods >> m) & 1) limb<DEC, SPLIT, true, LOGN>(jb, false, lds, wv);
-        else limb<DEC, SPLIT, false, LOGN>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv);
+        const int hf = halves ? half_pass : 0, hl = halves ? half_pass : 1;
+        if ((kb->u_mods >> m) & 1) limb<DEC, SPLIT, true, LOGN>(jb, false, lds, wv, hf, hl);
+        else limb<DEC, SPLIT, false, LOGN>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv, hf, hl);
 #ifdef MKHE_PHASE_TRACE
         if (jb.trace && ((int)threadIdx.x & 63) == 0) jb.trace[(long)wv * 32 + 28] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1042,7 +1055,15 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
     // 512) -- an even last round on 7/8 of the CUs instead of a ragged one on all of them
     static const int even = env_int16("MKHE_NTT16_EVEN", 0);
     if (even && need > resident) { const int rounds = (need + resident - 1) / resident; blocks = (need + rounds - 1) / rounds; }
-    fill_job_constants(c, need, blocks, lpt_long);
+    // half-limb jobs: Decompose launches only (source = ciphertext limbs, destination = hoisted digits: never in place) whose whole limbs would
+    // leave the last row of positions ragged (896 limbs on 256 CUs: 134.0 -> 128.7 us); a launch that deals whole limbs evenly keeps them -- as
+    // half-limb jobs the 1792-limb launch (7 limbs per CU either way) is 5 % SLOWER (256 -> 270 us, measured twice on one box; MKHE_NTT16_HALVES=2
+    // forces them for every launch)
+    static const int halfj = env_int16("MKHE_NTT16_HALVES", 1);
+    const int cus = resident >> 1;
+    c.half_jobs = (halfj && logN == 15 && c.reduce_in && need > resident && (halfj == 2 || (cus > 0 && need % cus != 0))) ? 1 : 0;
+    if (c.half_jobs && need % 8 == 0 && lpt_long % 8 == 0) c.half_jobs = 2;      // 8 limbs x 2 passes per block of 16 positions (see fwd_body)
+    fill_job_constants(c, c.half_jobs ? 2 * need : need, blocks, c.half_jobs ? 2 * lpt_long : lpt_long);
     if (logN == 14) {
         if (c.reduce_in) hipLaunchKernelGGL(ntt14_fwd_kernel<true>, dim3(blocks), dim3(NT), lds, st, c);
         else hipLaunchKernelGGL(ntt14_fwd_kernel<false>, dim3(blocks), dim3(NT), lds, st, c);

@@ -74,6 +74,7 @@ struct NttBatch {
                             // inputs are below 2^60 (bit 0: at the load, bits 1..3: after phases A, B, C); Context::h16_sched_
     // ntt16_kernels.hip, filled by its launchers: reciprocals for the per-limb index arithmetic (scalar multiply-high instead of VALU
     // divisions) and the placement of the long jobs (the first B jobs of the list: big-modulus limbs) on the CUs that own fewer positions
+    int half_jobs;          // the two passes of every limb are separate jobs of the walk (out-of-place N = 2^15 launches)
     unsigned magic_nouter, magic_opi;
     struct Lpt { int B, C, r, full, rem; unsigned magic_C; } lpt;
     int no_h16;             // this context has a modulus the H16 kernel's ranges do not cover (48q >= 2^62 > 31q): keep to the other kernels
