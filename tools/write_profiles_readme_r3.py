@@ -121,7 +121,7 @@ each other's operands, one of the two is read twice), the x / y round trip, and 
 * algorithmic bytes per launch {R["alg_bytes_per_launch"] / 1e6:.1f} MB (16·N B per limb-NTT × (1792 + 896)/2 limbs) ⇒ **{R["achieved"]:.0f} GB/s = {R["frac"]:.3f} of the 8 TB/s HBM peak** (round 2: 0.42, round 1: 0.296).
   By the compulsory bytes of the fused Decompose ({R.get("compulsory_bytes_per_launch", 0) / 1e6:.0f} MB per average launch) it is {R.get("frac_compulsory", 0):.3f}.
 * HBM traffic from the PMC passes: {dom.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch (FETCH_SIZE {dom.get("fetch_size_kb", 0) / 1e3:.1f} MB ×2 + WRITE_SIZE {dom.get("write_size_kb", 0) / 1e3:.1f} MB) =
-  {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and the register spills (24 B of scratch per lane).  Read: the source limbs in both passes
+  {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and nothing else (no spilled VGPR, no scratch: `{tag}_ntt16_isa.txt`; round 2 wrote 403 MB, the first build of round 3 396 MB).  Read: the source limbs in both passes
   (each is spread under 16 moduli) and the twiddle pairs — an XCD's 4 MiB L2 holds neither its 14 source limbs (3.5 MB) plus the tables of the 4–5 moduli in flight (1.5 MB), so part of the re-reads come from the Infinity Cache.
 * **It runs at the package power cap** (`{tag}_power_probe.txt`): {pw[len(pw) // 2]:.0f} W (median of the samples under load; cap 1400 W, idle 236 W) at {ck[len(ck) // 2] / 1e3:.2f} GHz.  After an idle phase the clocks need ≈ 150 ms to settle: ten back-to-back launches (round 2's tables)
   measure 355 µs for 1792 limbs, 1500 launches **{abl("shipped"):.0f} µs** = {abl("shipped") / 1792:.3f} µs per limb ({R["avg_launch_us"] / 1344:.3f} µs per limb inside the MulRelin, whose launches alternate with memory-bound kernels).
