@@ -205,6 +205,7 @@ class Context {
     u64* d_pmodq = nullptr;                      // [nq] MForm(P mod q_j)
     u64* d_rescale = nullptr;
     u64 *d_dec_a = nullptr, *d_dec_b = nullptr, *d_dec_c = nullptr;     // Decomposer tables (alpha >= 2)
+    u64 *d_tb30 = nullptr, *d_tw30 = nullptr;                           // ... and those of the radix-4 spread (alpha = 2, N = 2^16, moduli < 2^57)
     // mkbfv tables: convQQMul in both directions, ModDown constants, mFormQMul, MForm(t) per limb of R
     int* d_map_r = nullptr;
     u64 *d_bq_qoverqiinvqi = nullptr, *d_bq_qoverqimodp = nullptr, *d_bq_vtimes = nullptr;     // Q -> QMul

@@ -272,6 +272,34 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
             }
         }
         d_dec_a = dev_upload(ta); d_dec_b = dev_upload(tb); d_dec_c = dev_upload(tc);
+        // Round 3, radix-4 digit spread in front of the N = 2^16 forward NTT (poly_kernels.hip decomp_spread4_kernel): two-limb digits and moduli
+        // below 2^57 only; every constant t as the pair (t 2^30 mod p, t 2^62 mod p), radix-2^30 digits in the two halves of a word
+        bool all57 = true;
+        for (int m = 0; m < mtot; ++m) all57 = all57 && moduli[m] < (1ull << 57);
+        if (alpha == 2 && logN == 16 && all57) {
+            auto pack30 = [](u64 x) { return (x & ((1ull << 30) - 1)) | ((x >> 30) << 32); };
+            std::vector<u64> tb30((size_t)beta_max * mtot * 4, 0), tw30((size_t)mtot * 8, 0);
+            for (int m = 0; m < mtot; ++m) {
+                const u64 tj = moduli[m], c30 = powmod(2, 30, tj), c62 = powmod(2, 62, tj);
+                for (int d = 0; d < beta_max; ++d) {
+                    if (d * 2 + 2 > nq) break;
+                    const u64* S = Q + d * 2;
+                    for (int i = 0; i < 2; ++i) {
+                        const u64 t = S[1 - i] % tj;                       // Q_d / q_i mod p
+                        tb30[((size_t)d * mtot + m) * 4 + 2 * i] = pack30(mulmod(t, c30, tj));
+                        tb30[((size_t)d * mtot + m) * 4 + 2 * i + 1] = pack30(mulmod(t, c62, tj));
+                    }
+                }
+                const u64 rinv = powmod(powmod(2, 64, tj), tj - 2, tj);
+                for (int j = 0; j < 4; ++j) {
+                    u64 t = 1;
+                    if (j) { const u64 ps = psi[(size_t)m * N + j]; t = mulmod(ps - ((u64)((u32)ps >> 31) << 32), rinv, tj); }   // undo sd_split, leave Montgomery form
+                    tw30[(size_t)m * 8 + 2 * j] = pack30(mulmod(t, c30, tj));
+                    tw30[(size_t)m * 8 + 2 * j + 1] = pack30(mulmod(t, c62, tj));
+                }
+            }
+            d_tb30 = dev_upload(tb30); d_tw30 = dev_upload(tw30);
+        }
     }
 
     if (nqm) {
@@ -333,7 +361,7 @@ void Context::release_all() noexcept {
     (void)hipSetDevice(device);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
                     (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)spreadbuf_,
-                    (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_map_own, (void*)d_ownq,
+                    (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_tb30, (void*)d_tw30, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
                     (void*)d_map_r, (void*)d_bq_qoverqiinvqi, (void*)d_bq_qoverqimodp, (void*)d_bq_vtimes,
@@ -646,18 +674,29 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
         for (size_t base = 0; base < src.size(); base += DEC_MAX_ITEMS) {
             const int n = (int)std::min<size_t>(DEC_MAX_ITEMS, src.size() - base);
             DecompSpreadArgs da{};
-            // N = 2^16 (round 3): the spread digits go to a staging buffer and the sub-transforms run OUT OF PLACE from there into the
-            // destination -- the H16 kernel then recomputes its own cross-half stage in the second pass instead of parking half of every
-            // sub-limb in the destination and reloading it (in place it has to: pass 0 overwrites the operands of pass 1).  5.4 GB of
-            // staging for the 16 operand components of an 8-party PN16QP1761 MulRelin; 288 GB of HBM are there to be used.
+            // N = 2^16 (round 3).  When every class part of the NTT launch runs on the H16 kernel, the spread kernel applies the first TWO stages
+            // of the transform and the four 2^14-point sub-transforms of every limb are single passes of that kernel, in place: one read and one
+            // write of every digit limb.  MKHE_SPREAD_RADIX4=0 is the earlier form: cross-half stage only, the spread digits staged in a separate
+            // buffer (5.4 GB for the 16 operand components of an 8-party PN16QP1761 MulRelin) and the 2^15-point sub-transforms out of place from
+            // there, two passes each, the second recomputing its cross stage from a second read of the source -- 6.3 GB moved per 2.1 GB Decompose
+            // launch against 4.2 GB (MKHE_SPREAD_OOP=0: in place, the upper half parked in the destination and reloaded instead).
             static const int oop_env = getenv("MKHE_SPREAD_OOP") ? atoi(getenv("MKHE_SPREAD_OOP")) : 1;
+            static const int radix4_env = getenv("MKHE_SPREAD_RADIX4") ? atoi(getenv("MKHE_SPREAD_RADIX4")) : 1;
             const size_t item_words = (size_t)beta_max * mtot * N;
-            bool oop = false;
-            if (oop_env && logN == 16 && !masked_ && d_psi31) {
+            bool h16 = false;
+            if (logN == 16 && !masked_ && d_psi31) {
                 NttBatch q{};                                  // the launch as ntt_fwd_launch will see it: does every class part run on H16?
                 q.mods = d_mods; slots_qp(q, level); q.nouter = n * nb; q.prestaged = 1; q.psi31 = d_psi31; q.no_h16 = 0;
-                oop = ntt_fwd_prestaged_oop_ok(logN, q, small_q_.data());
+                h16 = ntt_fwd_prestaged_oop_ok(logN, q, small_q_.data());
             }
+            bool radix4 = h16 && radix4_env && d_tb30 && d_tw30;
+            // (what the H16 sub-transforms then load is below 22.2 p, not 4 p: a U-class modulus -- never reduced -- has to hold that input, 14 stages
+            // of growth by 5 p and the 75 p bias below 2^62; the other moduli are brought to |x| < p at the load, Job::red)
+            for (int s2 = 0; s2 < level + 1 + np && radix4; ++s2) {
+                const int m = s2 <= level ? s2 : nq + (s2 - level - 1);
+                if (((u_mods_ >> m) & 1) && (double)moduli[m] * (22.2 + 70 + 75) >= 4611686018427387904.0) radix4 = false;
+            }
+            const bool oop = h16 && oop_env && !radix4;
             u64* stage = oop ? scratch(spreadbuf_, spreadbuf_words_, (size_t)n * item_words) : nullptr;
             for (int i = 0; i < n; ++i) { da.src[i] = src[base + i]; da.dst[i] = oop ? stage + (size_t)i * item_words : dst[base + i]; }
             da.mods = d_mods; da.map = map_qp(level); da.ta = d_dec_a; da.tb = d_dec_b; da.tc = d_dec_c;
@@ -668,7 +707,8 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
             }
             da.alpha = alpha; da.ndigits = nb; da.nslots = level + 1 + np; da.mtot = mtot; da.N = N; da.nitems = n;
             // N = 2^16: the forward NTT always runs split; its cross-half stage is applied by the spread kernel itself
-            da.psi = d_psi; da.first_stage = (logN == 16 && !masked_) ? 1 : 0;
+            da.psi = d_psi; da.first_stage = radix4 ? 2 : (logN == 16 && !masked_) ? 1 : 0;
+            da.tb30 = d_tb30; da.tw30 = d_tw30;
             { ProfScope ps(this, PROF_OTHER, 8.0 * N * n * ((level + 1) + (double)nb * da.nslots)); launch_decomp_spread(da, s_); }
             NttBatch b{};
             b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);

@@ -489,9 +489,11 @@ struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* p
 // tm = 0 with the twiddle half ht = 1.
 template <bool DEC, bool SPLIT, bool UC, int LOGN = 15>
 __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, const int wv, const int h_first = 0, const int h_last = 1) {
-    static_assert(LOGN == 15 || (LOGN == 14 && !SPLIT), "H16 covers N = 2^15 (and its use on the halves of N = 2^16) and N = 2^14");
+    static_assert(LOGN == 15 || LOGN == 14, "H16 covers N = 2^15 and N = 2^14, whole limbs or the halves / quarters of a split N = 2^16 limb");
     const bool big = UC ? false : big_;
-    const int tm = LOGN == 14 ? 0 : (SPLIT ? jb.root : 1);
+    // LOGN = 14 + SPLIT (round 3): the 2^14 points are one QUARTER of a 2^16-point limb whose two cross stages have been applied by the producer
+    // (decomp_spread_kernel<2>): sub-transform root 4 + quarter = 2 tm + ht in the index formulas below
+    const int tm = LOGN == 14 ? (SPLIT ? (jb.root >> 1) : 0) : (SPLIT ? jb.root : 1);
     smodptr mp = jb.mp;                                 // scalar loads: the constants live in SGPRs
     const u64 qs = mp->qs;
     MC c;
@@ -510,12 +512,12 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
     scptr p31 = (scptr)jb.psi31;                            // (u, v) of twiddle i at words 2i, 2i + 1
     gcptr psi_v = (gcptr)jb.psi;
     const gcptr src = jb.src; const gptr dst = jb.dst;
-    const bool red = DEC && jb.red;
+    const bool red = (DEC || (SPLIT && LOGN == 14)) && jb.red;
     u64 x[16];
 #pragma unroll 1
     for (int hh = (LOGN == 15 ? h_first : 0); hh <= (LOGN == 15 ? h_last : 0); ++hh) {
         const int h = __builtin_amdgcn_readfirstlane(hh);
-        const int ht = LOGN == 14 ? 1 : h;              // the half as the twiddle indices see it
+        const int ht = LOGN == 14 ? (SPLIT ? (jb.root & 1) : 1) : h;              // the half as the twiddle indices see it
         H16_STAMP(0);
         // The part of a pass that ends in the four workgroup barriers of the A -> B exchange runs at raised wave priority, so that the sixteen
         // waves of a workgroup reach those barriers together while the co-resident workgroup's waves, if they are in the barrier-free phases
@@ -856,7 +858,7 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
     // stage 0 from the source), so they are two jobs of the walk -- twice as many, half as long: a launch of 896 limbs deals 7 half-limbs to
     // every CU instead of 4 limbs to one half of them and 3 to the other
     const bool halves = !SPLIT && LOGN == 15 && b.half_jobs != 0;
-    const int njobs = (b.nslots * b.nouter) << ((SPLIT || halves) ? 1 : 0);
+    const int njobs = (b.nslots * b.nouter) << (SPLIT ? (LOGN == 14 ? 2 : 1) : (halves ? 1 : 0));
     // optional start delay of the second half of the persistent grid (the co-resident workgroup of every CU, as far as the
     // dispatcher deals workgroups b and b + gridDim/2 to the same CU): the two workgroups of a CU then sit in different phases
     if (b.lazy_out > 0 && blockIdx.x >= (gridDim.x >> 1)) { for (int i = 0; i < b.lazy_out; ++i) __builtin_amdgcn_s_sleep(127); }
@@ -889,7 +891,7 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
                 if (kl->half_jobs == 2) { half_pass = (job >> 3) & 1; job = ((job >> 4) << 3) | (job & 7); }
                 else { half_pass = job & 1; job >>= 1; }
             }
-        } else job = job2 >> 1;                              // SPLIT: the two halves of a limb are consecutive jobs
+        } else job = job2 >> (LOGN == 14 ? 2 : 1);           // SPLIT: the two halves (four quarters) of a limb are consecutive jobs
         // The launch description is re-read from the kernel-argument segment for every limb (a handful of scalar loads) instead
         // of being kept in SGPRs across the limb: kept live it overflows the SGPR file into VGPR lanes, and those VGPRs are
         // what the 64-register budget of this kernel does not have.
@@ -910,16 +912,21 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         Job jb;
         jb.src = (gcptr)(sbase_ + (long)outer * kb->src_outer + (long)(kb->src_mapped ? m : p) * kb->src_inner);
         jb.dst = (gptr)(dbase_ + (long)outer * kb->dst_outer + (long)(kb->dst_mapped ? m : p) * kb->dst_inner);
-        jb.psi = kb->psi + (long)m * (SPLIT ? 2 * NL : NL);
-        jb.psi31 = kb->psi31 + 2 * (long)m * (SPLIT ? 2 * NL : NL);
+        constexpr int NLIMB = SPLIT ? (1 << 16) : NL;         // twiddle words per modulus: a split launch uses the rows of the whole 2^16-point limb
+        jb.psi = kb->psi + (long)m * NLIMB;
+        jb.psi31 = kb->psi31 + 2 * (long)m * NLIMB;
         jb.psi31n = kb->psi31n + 8 * (long)m;
         jb.sched = kb->src_lazy ? 15 : kb->sched[m];        // lazy (BFV) digits reach 2^62: the schedule of round 2
         jb.root = 1;
-        if constexpr (SPLIT) { const int half = job2 & 1; jb.src += half * NN; jb.dst += half * NN; jb.root = 2 + half; }
+        if constexpr (SPLIT && LOGN == 15) { const int half = job2 & 1; jb.src += half * NN; jb.dst += half * NN; jb.root = 2 + half; }
+        if constexpr (SPLIT && LOGN == 14) { const int quarter = job2 & 3; jb.src += quarter * NL; jb.dst += quarter * NL; jb.root = 4 + quarter; }
         jb.mp = (smodptr)kb->mods + m;
         jb.skip_norm = kb->skip_norm != 0;
         jb.trace = kb->trace ? kb->trace + (long)job2 * 16 * 32 : nullptr;
         jb.red = false;
+        // quarters: the radix-4 spread hands over values below 22.2 q (poly_kernels.hip decomp_spread4_kernel), which the U class takes as they are
+        // (Context::decompose_batch checks its range budget) and the balanced path reduces at the load
+        if constexpr (SPLIT && LOGN == 14) jb.red = ((kb->u_mods >> m) & 1) == 0;
         if constexpr (DEC) {
             int sm = m;
             const int rs = kb->reduce_src_mod_is_outer;
@@ -964,6 +971,12 @@ __global__ void __launch_bounds__(NT, 8) ntt16_fwd_split_kernel(NttBatch b) {
     fwd_body<false, true>(b, lds);
 }
 
+// the four 2^14-point sub-transforms of every 2^16-point limb, one pass each (in place or not), after the two cross stages (NttBatch::split = 2)
+__global__ void __launch_bounds__(NT, 8) ntt14_fwd_split_kernel(NttBatch b) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    fwd_body<false, true, 14>(b, lds);
+}
+
 }  // namespace h16
 
 // ------------------------------------------------------------------ launcher
@@ -985,6 +998,7 @@ int resident16(size_t lds) {
         (void)hipFuncSetAttribute((const void*)ntt16_fwd_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)ntt14_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)ntt14_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)ntt14_fwd_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int cus = 256, per = 1;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)ntt16_fwd_kernel<true>, NT, lds) != hipSuccess || per < 1) per = 1;
@@ -1011,7 +1025,7 @@ static void fill_job_constants(NttBatch& c, int njobs, int blocks, int lpt_long)
 // sub-transforms of a split N = 2^16 launch (one modulus class per launch: `small` = 31 q < 2^62 for every slot)
 bool ntt16_split_ok(const NttBatch& c) {
     static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128);
-    return on && !c.no_h16 && c.psi31 && c.split && !c.reduce_in && c.nslots <= 64 && 2 * c.nslots * c.nouter >= minl;
+    return on && !c.no_h16 && c.psi31 && (c.split == 1 || c.split == 2) && !c.reduce_in && c.nslots <= 64 && 2 * c.nslots * c.nouter >= minl;
 }
 void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
     using namespace h16;
@@ -1020,9 +1034,10 @@ void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
     c.lazy_out = 0;
     const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
     const int resident = resident16(lds);
-    const int need = 2 * c.nslots * c.nouter;
+    const int need = (c.nslots * c.nouter) << c.split;
     fill_job_constants(c, c.nslots * c.nouter, 0, 0);
-    hipLaunchKernelGGL(ntt16_fwd_split_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
+    if (c.split == 2) hipLaunchKernelGGL(ntt14_fwd_split_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
+    else hipLaunchKernelGGL(ntt16_fwd_split_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
 }
 bool ntt16_ok(int logN, const NttBatch& b) {
     static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128), minl14 = env_int16("MKHE_NTT14_MIN", 128);

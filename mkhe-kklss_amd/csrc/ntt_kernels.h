@@ -62,8 +62,10 @@ struct NttBatch {
                             // sub-transforms (twiddle rows of 2^16 words, root index 2 + half); the cross-half radix-2 stage
                             // runs as a separate streaming pass (launch_ntt_* do both)
     unsigned long long small_slots;   // mixed forward launch (launch_ntt_fwd_mixed): bit s set = slot s is a small-modulus (MODE 1) limb
-    int prestaged;          // forward, split launches only: the cross-half stage was already applied by the producer of src
-                            // (decomp_spread_kernel with first_stage): only the sub-transforms run, in place on dst
+    int prestaged;          // forward, split launches only: 1 = the cross-half stage was already applied by the producer of src
+                            // (decomp_spread_kernel with first_stage): only the sub-transforms run, in place on dst.  2 (N = 2^16, H16 only) = the
+                            // first TWO stages were (first_stage = 2): what remains are four independent 2^14-point sub-transforms per limb,
+                            // split = 2 (twiddle root 4 + quarter), one pass of the H16 kernel each
     int prestaged_oop;      // ... and that producer wrote into src (src_items), not into dst: the sub-transforms read src and write dst
     const u64* psi31;       // forward, ntt16_kernels.hip only: [nmod][N][2] the twiddle w as the constant pair (w 2^31 mod q, w 2^63 mod q),
                             // balanced, radix-2^31 digits -- operands of the one-round product (mm31)

@@ -862,6 +862,15 @@ bool ntt_fwd_prestaged_oop_ok(int logN, const NttBatch& b, const unsigned char* 
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
     const bool small = b.lazy_out != 0;
+    if (b.prestaged == 2) {
+        // N = 2^16, both cross stages applied by the producer (decomp_spread_kernel<2>): four one-pass 2^14-point sub-transforms per limb on
+        // the H16 kernel, in place on dst or from the producer's staging buffer (the caller has asked ntt_fwd_prestaged_oop_ok)
+        NttBatch o = b.prestaged_oop ? b : in_place_of_dst(b);
+        o.reduce_in = 0; o.split = 2;
+        if (logN != 16 || !ntt16_split_ok(o)) throw std::runtime_error("mkhe: internal: radix-4 prestaged launch outside the H16 path");
+        launch_ntt16_fwd_split(o, small, st);
+        return;
+    }
     if (use_split(logN, b)) {
         const dim3 grid(32, b.nslots * b.nouter);
         const int d = lds_depth(logN, b);

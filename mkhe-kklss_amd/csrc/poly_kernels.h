@@ -220,9 +220,15 @@ struct DecompSpreadArgs {
     int alpha, ndigits, nslots, mtot, N, nitems;
     // first_stage (N = 2^16, whose forward NTT always runs split): each thread produces the coefficients n and n + N/2 and
     // applies the first Cooley-Tukey stage (twiddle psi[m][1]) before storing, exactly as ntt_split_fwd_kernel would -- the
-    // NTT that follows (NttBatch::prestaged) then skips its streaming pass (one read + one write of every digit limb)
+    // NTT that follows (NttBatch::prestaged) then skips its streaming pass (one read + one write of every digit limb).
+    // first_stage = 2 (round 3): the coefficients n + k N/4, k = 0..3, and the first TWO stages (psi[m][1]; psi[m][2], psi[m][3]): what is
+    // left of the transform are four 2^14-point sub-transforms per limb, ONE pass of the H16 kernel each (NttBatch::prestaged = 2)
     const u64* psi;                    // forward twiddle tables [mtot][N], signed-split form
     int first_stage;
+    // first_stage = 2 only (alpha = 2, every modulus < 2^57): constants of the all-unsigned radix-2^30 one-round product (poly_kernels.hip
+    // decomp_spread4_kernel), each a pair (t 2^30 mod p, t 2^62 mod p) as two words of radix-2^30 digits (low digit in the low half)
+    const u64* tb30;                   // [ndig][mtot][2][2]   qoverqimodp of the two-limb digit d under modulus m
+    const u64* tw30;                   // [mtot][4][2]         entry 0: t = 1; entries 1..3: t = psi[m][1..3]
 };
 void launch_decomp_spread(const DecompSpreadArgs& a, hipStream_t st);
 

@@ -1,6 +1,7 @@
 // poly_kernels.hip -- see poly_kernels.h.
 #include "poly_kernels.h"
 #include <cstdlib>
+#include <stdexcept>
 
 namespace mkhe {
 
@@ -897,35 +898,49 @@ __device__ __forceinline__ void st2(u64* p, u64 x0, u64 x1) {
     u64x2 r; r.x = x0; r.y = x1;
     __builtin_nontemporal_store(r, (u64x2*)p);          // written once, gigabytes per launch, read by the NTT that follows: past the caches
 }
+// the first FS Cooley-Tukey stages of the N-point transform on the 2^FS values v[k] = coefficient n + k N / 2^FS (all < 4q, and < 4q again
+// afterwards): FS = 1: the pair (0, 1) with psi[1]  (FS = 2 is decomp_spread4_kernel below)
+template <int FS>
+__device__ __forceinline__ void spread_stages(u64* v, const u64* w, const Mod& mt) {
+    if constexpr (FS == 1) spread_first_stage(v[0], v[1], w[1], mt);
+}
+// FS = DecompSpreadArgs::first_stage: a thread produces the coefficients n, n + 1 at each of the 2^FS points n + k N / 2^FS and applies the first
+// FS stages of the forward NTT to them before they are stored
+template <int FS>
 __global__ void __launch_bounds__(PW_THREADS) decomp_spread_kernel(DecompSpreadArgs a) {
+    constexpr int NP = 1 << FS;
     dspread_kargs ka = (dspread_kargs)__builtin_amdgcn_kernarg_segment_ptr();
     const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
-    const int H = a.N >> 1;
-    if (n >= (a.first_stage ? H : a.N)) return;
+    const int S = a.N >> FS;
+    if (n >= S) return;
     const int d = blockIdx.y, item = blockIdx.z;
     const int start = d * a.alpha, nd = ka->nd[d];
     const u64* src = ka->src[item] + (long)start * a.N;
     u64* dst = ka->dst[item] + (long)d * a.mtot * a.N;
     if (nd == 1) {
-        const u64x2 x = *(const u64x2*)(src + n);
-        u64x2 x2; x2.x = 0; x2.y = 0;
-        if (a.first_stage) x2 = *(const u64x2*)(src + n + H);
+        u64x2 x[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) x[k] = *(const u64x2*)(src + n + k * S);
         const u64 qs = a.mods[start].q;
         for (int s = 0; s < a.nslots; ++s) {
             const int m = a.map[s];
             const Mod mt = a.mods[m];
             const bool red = qs > 4 * mt.q;
-            u64 lo0 = red ? mont_mul_lazy(x.x, mt.r1, mt.q, mt.ninv32) : x.x;
-            u64 lo1 = red ? mont_mul_lazy(x.y, mt.r1, mt.q, mt.ninv32) : x.y;
-            if (a.first_stage) {
-                u64 hi0 = red ? mont_mul_lazy(x2.x, mt.r1, mt.q, mt.ninv32) : x2.x;
-                u64 hi1 = red ? mont_mul_lazy(x2.y, mt.r1, mt.q, mt.ninv32) : x2.y;
-                const u64 w = a.psi[(long)m * a.N + 1];
-                spread_first_stage(lo0, hi0, w, mt);
-                spread_first_stage(lo1, hi1, w, mt);
-                st2(dst + (long)m * a.N + n + H, hi0, hi1);
+            u64 v0[NP], v1[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                v0[k] = red ? mont_mul_lazy(x[k].x, mt.r1, mt.q, mt.ninv32) : x[k].x;
+                v1[k] = red ? mont_mul_lazy(x[k].y, mt.r1, mt.q, mt.ninv32) : x[k].y;
             }
-            st2(dst + (long)m * a.N + n, lo0, lo1);
+            if constexpr (FS > 0) {
+                u64 w[4];
+#pragma unroll
+                for (int i = 1; i < NP; ++i) w[i] = a.psi[(long)m * a.N + i];
+                spread_stages<FS>(v0, w, mt);
+                spread_stages<FS>(v1, w, mt);
+            }
+#pragma unroll
+            for (int k = NP - 1; k >= 0; --k) st2(dst + (long)m * a.N + n + k * S, v0[k], v1[k]);
         }
         return;
     }
@@ -933,32 +948,138 @@ __global__ void __launch_bounds__(PW_THREADS) decomp_spread_kernel(DecompSpreadA
     const u64* ta = a.ta + tsel * DEC_MAXA;
     const u64* tb = a.tb + tsel * a.mtot * DEC_MAXA;
     const u64* tc = a.tc + tsel * a.mtot * (DEC_MAXA + 1);
-    SpreadCoeff c00, c01, c10, c11;
-    spread_prepare(a, src, ta, start, nd, n, c00);
-    spread_prepare(a, src, ta, start, nd, n + 1, c01);
-    if (a.first_stage) { spread_prepare(a, src, ta, start, nd, n + H, c10); spread_prepare(a, src, ta, start, nd, n + H + 1, c11); }
+    SpreadCoeff c0[NP], c1[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { spread_prepare(a, src, ta, start, nd, n + k * S, c0[k]); spread_prepare(a, src, ta, start, nd, n + k * S + 1, c1[k]); }
     for (int s = 0; s < a.nslots; ++s) {
         const int m = ((sc_int)a.map)[s];
         const Mod mt = load_mod((sc_mod)a.mods + m);
-        SlotConsts k;
-        slot_consts(k, tb, tc, m, nd);
-        u64 lo0 = spread_value(c00, k, nd, mt);
-        u64 lo1 = spread_value(c01, k, nd, mt);
-        if (a.first_stage) {
-            u64 hi0 = spread_value(c10, k, nd, mt);
-            u64 hi1 = spread_value(c11, k, nd, mt);
-            const u64 w = ((sc_u64)a.psi)[(long)m * a.N + 1];
-            spread_first_stage(lo0, hi0, w, mt);
-            spread_first_stage(lo1, hi1, w, mt);
-            st2(dst + (long)m * a.N + n + H, hi0, hi1);
+        SlotConsts kc;
+        slot_consts(kc, tb, tc, m, nd);
+        u64 v0[NP], v1[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { v0[k] = spread_value(c0[k], kc, nd, mt); v1[k] = spread_value(c1[k], kc, nd, mt); }
+        if constexpr (FS > 0) {
+            u64 w[4];
+#pragma unroll
+            for (int i = 1; i < NP; ++i) w[i] = ((sc_u64)a.psi)[(long)m * a.N + i];
+            spread_stages<FS>(v0, w, mt);
+            spread_stages<FS>(v1, w, mt);
         }
-        st2(dst + (long)m * a.N + n, lo0, lo1);
+#pragma unroll
+        for (int k = NP - 1; k >= 0; --k) st2(dst + (long)m * a.N + n + k * S, v0[k], v1[k]);
+    }
+}
+// ---- the radix-4 form (first_stage = 2, round 3): digits of one or two limbs, every modulus below 2^57
+// The digit value and the two butterfly stages run on one-round products of radix 2^30 with every operand NON-NEGATIVE (the all-unsigned
+// sibling of ntt16_kernels.hip mm30u): a data word y = hi 2^32 + lo meets a constant t as the pre-reduced pair u = t 2^30 mod p, v = t 2^62 mod p
+// (both in [0, p), radix-2^30 digits), and
+//   C = sum lo u0 + hi v0 ; m = lo30(C * -p^-1) ; T = ((C + m p0) >> 30) + sum lo u1 + hi v1 + m p1 = (sum (lo u + hi v) + m p) / 2^30 = sum y t  (mod p)
+// with ONE reduction round for the whole sum: 13 multiplier-class instructions for a two-limb digit where the 128-bit multSum + 64-bit
+// Montgomery fold of spread_value takes 21, 9 for a butterfly product.  Only the residue class of a spread digit reaches the results (the
+// NTT that follows reduces), so the representative is free: 0 <= T < (2^32 nd + 2^25 nd + 2^30) p / 2^30 < 9.1 p for nd = 2, a butterfly
+// product of V < 2^62 is < 6p and its outputs are U + T and U + (6p - T): below 22.2 p after the two stages, < 2^62 for p < 2^57.
+struct Pair30 { u32 u0, u1, v0, v1; };
+__device__ __forceinline__ Pair30 load_pair30(sc_u64 p) {
+    const u64 u = p[0], v = p[1];
+    Pair30 r{lo32(u), hi32(u), lo32(v), hi32(v)};
+    asm("" : "+s"(r.u0), "+s"(r.u1), "+s"(r.v0), "+s"(r.v1));          // opaque 32-bit scalars (else they are multiplied as halves of a 64-bit constant)
+    return r;
+}
+struct Mod30 { u32 p0, p1, ninv; u64 six; };
+__device__ __forceinline__ u64 fold30(u64 c0, u64 c1, const Mod30& k) {
+    const u32 m = (lo32(c0) * k.ninv) & 0x3fffffffu;
+    return ((c0 + (u64)m * k.p0) >> 30) + c1 + (u64)m * k.p1;
+}
+__device__ __forceinline__ u64 prod30(u64 y, const Pair30& t, const Mod30& k) {
+    const u32 lo = lo32(y), hi = hi32(y);
+    return fold30((u64)lo * t.u0 + (u64)hi * t.v0, (u64)lo * t.u1 + (u64)hi * t.v1, k);
+}
+__device__ __forceinline__ u64 sum30(u64 y0, u64 y1, const Pair30& t0, const Pair30& t1, const Mod30& k) {
+    const u32 l0 = lo32(y0), h0 = hi32(y0), l1 = lo32(y1), h1 = hi32(y1);
+    return fold30((u64)l0 * t0.u0 + (u64)h0 * t0.v0 + (u64)l1 * t1.u0 + (u64)h1 * t1.v0,
+                  (u64)l0 * t0.u1 + (u64)h0 * t0.v1 + (u64)l1 * t1.u1 + (u64)h1 * t1.v1, k);
+}
+__device__ __forceinline__ void bfly30(u64& U, u64& V, const Pair30& w, const Mod30& k) {
+    const u64 T = prod30(V, w, k);
+    V = U + (k.six - T);
+    U = U + T;
+}
+__device__ __forceinline__ void stages30(u64* v, const Pair30* w, const Mod30& k) {
+    bfly30(v[0], v[2], w[0], k);
+    bfly30(v[1], v[3], w[0], k);
+    bfly30(v[0], v[1], w[1], k);
+    bfly30(v[2], v[3], w[2], k);
+}
+__global__ void __launch_bounds__(PW_THREADS) decomp_spread4_kernel(DecompSpreadArgs a) {
+    dspread_kargs ka = (dspread_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
+    const int S = a.N >> 2;
+    if (n >= S) return;
+    const int d = blockIdx.y, item = blockIdx.z;
+    const int start = d * a.alpha, nd = ka->nd[d];
+    const u64* src = ka->src[item] + (long)start * a.N;
+    u64* dst = ka->dst[item] + (long)d * a.mtot * a.N;
+    u64 y0[4][2], y1[4][2];                  // [point][adjacent coefficient]: the y_i of the digit's two limbs (nd = 1: the coefficient itself in y0)
+    u32 cv[4][2];
+    if (nd == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const u64x2 x = *(const u64x2*)(src + n + k * S); y0[k][0] = x.x; y0[k][1] = x.y; y1[k][0] = y1[k][1] = 0; cv[k][0] = cv[k][1] = 0; }
+    } else {
+        const u64* ta = a.ta + (long)d * (a.alpha - 1) * DEC_MAXA;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                SpreadCoeff c;
+                spread_prepare(a, src, ta, start, 2, n + k * S + e, c);
+                y0[k][e] = c.y[0]; y1[k][e] = c.y[1]; cv[k][e] = (u32)c.v;
+            }
+    }
+    sc_u64 t30 = (sc_u64)a.tb30 + (long)d * a.mtot * 4;
+    sc_u64 tcs = (sc_u64)a.tc + (long)d * (a.alpha - 1) * a.mtot * (DEC_MAXA + 1);
+    const u64 qs = ((sc_mod)a.mods)[start].q;
+    for (int s = 0; s < a.nslots; ++s) {
+        const int m = ((sc_int)a.map)[s];
+        sc_mod mp = (sc_mod)a.mods + m;
+        const u64 q = mp->q;
+        Mod30 k30{lo32(q) & 0x3fffffffu, (u32)(q >> 30), mp->ninv32, 6 * q};
+        asm("" : "+s"(k30.p0), "+s"(k30.p1), "+s"(k30.ninv));
+        Pair30 w[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = load_pair30((sc_u64)a.tw30 + ((long)m * 4 + 1 + i) * 2);
+        u64 v0[4], v1[4];
+        if (nd == 1) {
+            // copy path (:443-451): the limb itself under every modulus; one product by 2^30-form 1 (= a reduction below 6p) when its bound exceeds 4p
+            const bool red = qs > 4 * q;
+            const Pair30 one = load_pair30((sc_u64)a.tw30 + (long)m * 4 * 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v0[k] = red ? prod30(y0[k][0], one, k30) : y0[k][0]; v1[k] = red ? prod30(y0[k][1], one, k30) : y0[k][1]; }
+        } else {
+            const Pair30 t0 = load_pair30(t30 + (long)m * 4), t1 = load_pair30(t30 + (long)m * 4 + 2);
+            const u64 c1 = tcs[(long)m * (DEC_MAXA + 1) + 1], c2 = tcs[(long)m * (DEC_MAXA + 1) + 2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v0[k] = sum30(y0[k][0], y1[k][0], t0, t1, k30) + (cv[k][0] == 0 ? 0 : cv[k][0] == 1 ? c1 : c2);
+                v1[k] = sum30(y0[k][1], y1[k][1], t0, t1, k30) + (cv[k][1] == 0 ? 0 : cv[k][1] == 1 ? c1 : c2);
+            }
+        }
+        stages30(v0, w, k30);
+        stages30(v1, w, k30);
+#pragma unroll
+        for (int k = 3; k >= 0; --k) st2(dst + (long)m * a.N + n + k * S, v0[k], v1[k]);
     }
 }
 void launch_decomp_spread(const DecompSpreadArgs& a, hipStream_t st) {
-    const int cnt = (a.first_stage ? a.N / 2 : a.N) / 2;          // two coefficients per thread
+    const int cnt = (a.N >> a.first_stage) / 2;          // two adjacent coefficients per thread at each of its points
     const int bx = (cnt + PW_THREADS - 1) / PW_THREADS;
-    hipLaunchKernelGGL(decomp_spread_kernel, dim3(bx, a.ndigits, a.nitems), dim3(PW_THREADS), 0, st, a);
+    const dim3 grid(bx, a.ndigits, a.nitems);
+    if (a.first_stage == 2) {
+        if (!a.tb30 || !a.tw30 || a.alpha != 2) throw std::runtime_error("mkhe: internal: radix-4 digit spread without its tables");
+        hipLaunchKernelGGL(decomp_spread4_kernel, grid, dim3(PW_THREADS), 0, st, a);
+    }
+    else if (a.first_stage == 1) hipLaunchKernelGGL(decomp_spread_kernel<1>, grid, dim3(PW_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(decomp_spread_kernel<0>, grid, dim3(PW_THREADS), 0, st, a);
 }
 
 // ------------------------------------------------------------------ automorphism

@@ -52,3 +52,26 @@ def test_pn16_rotate_hoisted(pair):
     pair.ksw.RotateHoisted(d, 5, hh, rkset, out)
     ref = pair.ks.rotate(level, pow(5, 5, 2 * pair.N), [0], h, [k], crs_h)
     assert (out.download() == ref).all()
+
+
+@pytest.mark.parametrize("drop", [1, 31])
+def test_pn16_rotate_hoisted_lower_levels(pair, drop):
+    """levels whose last gadget digit has ONE limb (33 and 3 limbs, alpha = 2: the copy path of DecomposeAndSplit, basis_extension.go:443-451);
+    at 33 limbs the digits go through the radix-4 spread + quarter sub-transforms, at 3 limbs through the small-launch path"""
+    mk = pair.mk
+    level = pair.maxlevel - drop
+    assert (level + 1) % 2 == 1
+    names = ["a"]
+    h, d = pair.ct(names, level)
+    crs_h = H.uniform_swk(pair.rng, pair.ks)
+    pair.params.AddCRS(7, crs_h)
+    k = H.uniform_swk(pair.rng, pair.ks)
+    rkset = mk.RotationKeySet()
+    rkset.AddRotationKey(mk.RotationKey(pair.params, 7, "a", k))
+    hh = mk.NewHoistedCiphertext()
+    hh.Value["a"] = mk.NewSwitchingKey(pair.params)
+    pair.ksw.Decompose(level, d, "a", hh.Value["a"])
+    out = mk.NewCiphertext(pair.params, names, level)
+    pair.ksw.RotateHoisted(d, 7, hh, rkset, out)
+    ref = pair.ks.rotate(level, pow(5, 7, 2 * pair.N), [0], h, [k], crs_h)
+    assert (out.download() == ref).all()
