@@ -586,7 +586,7 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     const bool side = (n == 2) && (s_ == stream);
     for (int i = n - 1; i >= 0; --i) {
         const bool small = part[i].lazy_out != 0;
-        const int cls = decompose ? (small ? PROF_NTT_DECOMP : PROF_NTT_DECOMP_BIGQ) : (small ? PROF_NTT_FWD : PROF_NTT_FWD_BIGQ);
+        const int cls = b.prestaged == 2 ? PROF_NTT14_SPLIT : decompose ? (small ? PROF_NTT_DECOMP : PROF_NTT_DECOMP_BIGQ) : (small ? PROF_NTT_FWD : PROF_NTT_FWD_BIGQ);
         const bool on_side = side && i == 1;
         if (on_side) { fork_side(0); s_ = overlap ? stream2 : stream; }
         {
@@ -709,7 +709,7 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
             // N = 2^16: the forward NTT always runs split; its cross-half stage is applied by the spread kernel itself
             da.psi = d_psi; da.first_stage = radix4 ? 2 : (logN == 16 && !masked_) ? 1 : 0;
             da.tb30 = d_tb30; da.tw30 = d_tw30;
-            { ProfScope ps(this, PROF_OTHER, 8.0 * N * n * ((level + 1) + (double)nb * da.nslots)); launch_decomp_spread(da, s_); }
+            { ProfScope ps(this, PROF_SPREAD, 8.0 * N * n * ((level + 1) + (double)nb * da.nslots)); launch_decomp_spread(da, s_); }
             NttBatch b{};
             b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);
             b.src_outer = b.dst_outer = (long)mtot * N; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;

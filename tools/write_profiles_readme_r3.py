@@ -102,6 +102,9 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
 * `value` is timed on settled clocks since round 3 (the secondary legs run before the timed region).  Same run: cold start (what rounds 1 and 2 reported) **{C.get("mulrelin_per_sec_cold_start", 0):.0f}/s**, 200 steps after 100 untimed ones
   {C.get("mulrelin_per_sec_steady_state", 0):.0f}/s, two MulRelin in flight through forked contexts {C.get("mulrelin_per_sec_two_in_flight", 0):.0f}/s.
 * under `rocprofv3 --kernel-trace`, overlap off: {no["value"]:.0f} MulRelin/s ({no["ms_per_step"]:.3f} ms); overlap on: {ov["value"]:.0f} MulRelin/s ({ov["ms_per_step"]:.3f} ms).
+* **Box to box** the figures move by ± 2 % with the clock a part sustains at the 1400 W cap: the same sources, default `bench.py`, on the three boxes gpurun dealt on the last day of the round gave
+  1185 MulRelin/s / `roofline.frac` 0.498 (2.09 GHz under the NTT kernel), 1197 / 0.496 (2.13 GHz, this set) and 1212 / 0.510 (the earlier set of this round, 2.16 GHz: 1192 / 0.508); on that third box the library of the commit before ran
+  1206 / 0.510 in the same call -- kernel comparisons in this repository are therefore made inside one gpurun call (`MKHE_LIB=.../libmkhe_prev.so` beside the new build), never across calls.
 
 Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per step.  "algorithmic GB/s" is the byte model of DESIGN.md §4 (`roofline.kernels_over_peak` = {R.get("kernels_over_peak")}: no model claims more than the chip moves any more);
 "PMC GB/s" is what the kernel really moved through the L2's memory side, (2·FETCH_SIZE + WRITE_SIZE) from `traffic.json` over the same launch pattern:
@@ -167,6 +170,15 @@ if pn:
 ## BASELINE.json configs[3] ring on ONE GPU: 8-party MulRelin + hoisted Rotate, PN16QP1761 (N = 2^16, 34 Q + 4 P primes, α = 2, β = 17)
 
 `python3 bench.py --params PN16QP1761 --parties 8 --steps 10 --warmup 2`: **{pn["value"]:.1f} MulRelin/s** ({pn["ms_per_step"]:.2f} ms per step; round 2: 68.5, round 1: 53.8), Rotate {c.get("rotate_per_sec", 0):.0f}/s, RotateHoisted {c.get("rotate_hoisted_per_sec", 0):.0f}/s.
+Round 3 changed its Decompose (DESIGN.md §4 "N = 2^16"): `decomp_spread4_kernel` reconstructs the two-limb digits on one-round radix-2^30 products and applies the first TWO stages of the forward NTT before it stores, and the four 2^14-point
+sub-transforms of every limb are single in-place passes of the H16 kernel (`ntt14_fwd_split_kernel`).  Per Decompose launch (8 components x 17 digits x 38 moduli + the x / y digits = 8058 limbs of 2^16 words = 4.2 GB): 0.99 + 2.62 ms
+(cross-half stage only, two-pass 2^15-point sub-transforms out of place: 4.2 GB written by the spread, 8.4 GB read and 4.2 GB written by the NTT = 4.8 TB/s, HBM-bound) became 0.83 + 2.23 ms (4.2 + 4.2 + 4.2 GB; the spread stores at 5.1 TB/s, the NTT is bound by its
+butterflies under the power cap like the N = 2^15 kernel) -- 75.5 → 81.1 MulRelin/s on one box, same call (`MKHE_SPREAD_RADIX4=0` is the A/B switch).  Per kernel class (HIP events, overlap off, per step):
+
+| kernel | launches/step | avg µs/launch | ms/step | algorithmic GB/s | PMC GB/s |
+|---|---|---|---|---|---|
+{table(pn, False)}
+
 The keys (7.9 GB) are written on the device by the CRS expander; `config.device_keys_check` = {c.get("device_keys_check")}: the keys of the first two parties and the CRS regenerated on the host from the same seed, the engine's two-party MulRelinNew on the resident keys against the oracle.
 Bit-exactness at this ring with 8 parties against the oracle with host keys: `tests/test_gpu_headline.py::test_pn16_mul_and_relin_eight_parties` (MulAndRelin and MulAndRelinHoisted, maximum level) and `::test_pn16_rotate_hoisted_eight_parties`.
 The party-sharded N > 1 run of this configuration is `python3 bench.py --gpus 8 --params PN16QP1761 --parties 8` (DESIGN.md §7 has the link model; not measurable on the single-GPU boxes of this pool).
