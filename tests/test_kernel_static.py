@@ -20,3 +20,39 @@ HIPCC = "/opt/rocm/bin/hipcc"
 def test_no_instruction_touches_a_register_of_a_load_in_flight(flags, ok):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight.py"), *flags], capture_output=True, text=True, timeout=900)
     assert (r.returncode == 0) == ok, r.stdout[-1500:] + r.stderr[-500:]
+
+
+def _kernel_resources(src):
+    """name -> dict of the code-object metadata (.vgpr_count, .vgpr_spill_count, .sgpr_spill_count, .private_segment_fixed_size) of every kernel of a csrc file"""
+    import re
+    csrc = os.path.join(ROOT, "mkhe-kklss_amd", "csrc")
+    r = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only",
+                        os.path.join(csrc, src), "-o", "-"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = {}
+    for blk in r.stdout.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        out[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")}
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_h16_kernels_fit_eight_waves_per_simd_without_scratch():
+    """every instantiation of the H16 forward kernel (N = 2^15, N = 2^14, the halves and the quarters of N = 2^16) keeps 16 coefficients per thread in at most 64
+    VGPRs -- 8 waves per SIMD, two 1024-thread workgroups per CU -- and spills no vector register (scratch of 512 resident workgroups goes through HBM)"""
+    res = _kernel_resources("ntt16_kernels.hip")
+    names = [n for n in res if "ntt16_fwd" in n or "ntt14_fwd" in n]
+    assert len(names) == 6, sorted(res)
+    for n in names:
+        assert res[n]["vgpr_count"] <= 64 and res[n]["vgpr_spill_count"] == 0 and res[n]["private_segment_fixed_size"] == 0, (n, res[n])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_digit_spread_kernels_do_not_spill():
+    res = _kernel_resources("poly_kernels.hip")
+    names = [n for n in res if "decomp_spread" in n]
+    assert len(names) == 3, sorted(res)                      # <0>, <1> and the radix-4 kernel
+    for n in names:
+        assert res[n]["vgpr_spill_count"] == 0 and res[n]["private_segment_fixed_size"] == 0, (n, res[n])
+    r4 = [n for n in names if "spread4" in n][0]
+    assert res[r4]["vgpr_count"] <= 128, res[r4]              # four waves per SIMD
