@@ -92,6 +92,7 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
 | `{tag}_ntt16_ablation.txt` | `tools/ntt16_variants.sh`: the dominant kernel re-built without its memory streams / LDS exchanges / butterflies (wrong results on purpose) and with the experiments that were not kept, 1500 launches each (steady state) |
 | `{tag}_ntt16_launch_sizes.txt` | `tools/ntt16_bench.py 1500`: the Decompose NTT at 1792 / 896 / 448 / 224 limbs |
 | `{tag}_kernel_stats_bfv.csv`, `{tag}_bench_bfv*.json` | `bench.py --scheme bfv` under the profiler (overlap off) and plain |
+| `{tag}_pn16_traffic.txt` | `tools/pn16_traffic.sh` + `tools/pn16_traffic.py`: FETCH_SIZE / WRITE_SIZE per kernel of the PN16QP1761 8-party step, radix-4 Decompose beside `MKHE_SPREAD_RADIX4=0` |
 | `{tag}_bench_pn16*.json`, `{tag}_kernel_stats_pn16.csv` | `bench.py --params PN16QP1761 --parties 8` (configs[3] ring on one GPU; the plain run carries `config.device_keys_check`) |
 | `{tag}_bench_cnn2/4.json`, `{tag}_bench_pn14.json`, `{tag}_party_sweep.jsonl` | secondary workloads |
 
@@ -173,7 +174,9 @@ if pn:
 Round 3 changed its Decompose (DESIGN.md §4 "N = 2^16"): `decomp_spread4_kernel` reconstructs the two-limb digits on one-round radix-2^30 products and applies the first TWO stages of the forward NTT before it stores, and the four 2^14-point
 sub-transforms of every limb are single in-place passes of the H16 kernel (`ntt14_fwd_split_kernel`).  Per Decompose launch (8 components x 17 digits x 38 moduli + the x / y digits = 8058 limbs of 2^16 words = 4.2 GB): 0.99 + 2.62 ms
 (cross-half stage only, two-pass 2^15-point sub-transforms out of place: 4.2 GB written by the spread, 8.4 GB read and 4.2 GB written by the NTT = 4.8 TB/s, HBM-bound) became 0.83 + 2.23 ms (4.2 + 4.2 + 4.2 GB; the spread stores at 5.1 TB/s, the NTT is bound by its
-butterflies under the power cap like the N = 2^15 kernel) -- 75.5 → 81.1 MulRelin/s on one box, same call (`MKHE_SPREAD_RADIX4=0` is the A/B switch).  Per kernel class (HIP events, overlap off, per step):
+butterflies under the power cap like the N = 2^15 kernel) -- 75.5 → 81.1 MulRelin/s on one box, same call (`MKHE_SPREAD_RADIX4=0` is the A/B switch).  `{tag}_pn16_traffic.txt` has the PMC bytes of both paths (`tools/pn16_traffic.sh`): the largest
+Decompose launch (both operands: 16 components, 5.29 GB of digits) reads 5.46 GB and writes 5.29 GB in `ntt14_fwd_split_kernel` where `ntt16_fwd_split_kernel` read 11.4 GB; the whole step moves ≈ 53 GB through HBM = 4.5 TB/s over its 11.7 ms -- this configuration is
+memory-bound as a whole (`ext_inner_kernel` 2 × 6.6 GB, `inner_product_kernel<8>` 2 × 5.6 GB, the Decompose pair 2 × 12.3 GB).  Per kernel class (HIP events, overlap off, per step):
 
 | kernel | launches/step | avg µs/launch | ms/step | algorithmic GB/s | PMC GB/s |
 |---|---|---|---|---|---|
