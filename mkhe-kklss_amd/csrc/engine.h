@@ -196,6 +196,8 @@ class Context {
     Mod* d_mods = nullptr;
     u64 *d_psi = nullptr, *d_psiinv = nullptr, *d_inv_aux = nullptr;
     u64* d_psi31n = nullptr;                     // [mall][4][2]: pairs of -psi[1..3] (NttBatch::psi31n)
+    u64 *d_psiinv31 = nullptr, *d_inv31c = nullptr;   // inverse twiddles as pairs [mall][N][2]; last-stage constants [mall][8][6] (NttBatch::inv31c)
+    unsigned long long small_mods_ = 0;          // bit m set = modulus m has 31 q < 2^62
     std::vector<unsigned char> h16_sched_;       // per modulus: NttBatch::sched
     unsigned long long u_mods_ = 0;              // bit m: modulus m is of the H16 kernel's U class (NttBatch::u_mods)
     u64* d_psi31 = nullptr;                      // logN >= 15: twiddle pairs of the H16 kernel's one-round product (NttBatch::psi31)
@@ -256,6 +258,7 @@ class Context {
     void slots_qp(NttBatch& b, int level) const;
     void slots_range(NttBatch& b, int mod_base, int limbs) const;
     void ntt_fwd_launch(const NttBatch& b, bool decompose);
+    void ntt_inv_launch(NttBatch& b);       // fills in the tables of the H16-class inverse kernel, then launch_ntt_inv
     std::vector<unsigned char> small_q_;                     // per modulus: 34q < 2^63
     void ext_core(int level, const u64* ah, const u64* bg, u64* c, bool accumulate);
 

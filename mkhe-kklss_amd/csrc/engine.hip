@@ -178,6 +178,40 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
             }
         }
         d_psi31 = dev_upload(p31); d_psi31n = dev_upload(p31n);
+        // the inverse kernel of the same family (ntt14_inv_kernel): the inverse twiddles as pairs in the format of the modulus's class, and per
+        // modulus and sub-transform root 1..7 the two constants of its last stage, N^-1 and psiinv[root] N^-1 (N = this ring's degree)
+        std::vector<u64> pi31(2 * (size_t)mall * N), fin((size_t)mall * 8 * 6, 0);
+        for (int i = 0; i < mall; ++i) {
+            const u64 q = moduli[i];
+            const bool uc = ((u_mods_ >> i) & 1) != 0;
+            const int sh = uc ? 30 : 31;
+            const u64 cinv = powmod(powmod(2, 64 - sh, q), q - 2, q), c32 = powmod(2, 32, q);
+            auto pack = [q, sh](u64 x, bool balanced) {
+                const i64 b = balanced && x > q / 2 ? (i64)x - (i64)q : (i64)x;
+                i64 d0 = (i64)((u64)b & ((1ull << sh) - 1));
+                if (balanced && d0 >= (1ll << (sh - 1))) d0 -= 1ll << sh;
+                const i64 d1 = (b - d0) >> sh;
+                return (u64)(u32)(i32)d0 | ((u64)(u32)(i32)d1 << 32);
+            };
+            auto pair_of = [&](u64 wR, u64* out) {                                   // wR = w 2^64 mod q
+                const u64 u = mulmod(wR, cinv, q), v = mulmod(u, c32, q);
+                out[0] = pack(u, !uc); out[1] = pack(v, true);
+            };
+            const u64 ninvR = to_mont(powmod((u64)N, q - 2, q), q);
+            for (size_t j = 0; j < (size_t)N; ++j) {
+                const u64 ps = psiinv[(size_t)i * N + j];
+                const u64 wR = ps - ((u64)((u32)ps >> 31) << 32);                  // undo sd_split
+                pair_of(wR, &pi31[2 * ((size_t)i * N + j)]);
+                if (j >= 1 && j < 8) {
+                    const u64 wn = mulmod(wR, powmod((u64)N, q - 2, q), q);            // psiinv[j] N^-1 R
+                    u64* f = &fin[((size_t)i * 8 + j) * 6];
+                    pair_of(ninvR, f); pair_of(wn, f + 2);
+                    f[4] = sd_split(ninvR); f[5] = sd_split(wn);                        // the same two for the two-round product
+                }
+            }
+            if (small_q_[i]) small_mods_ |= 1ull << i;
+        }
+        d_psiinv31 = dev_upload(pi31); d_inv31c = dev_upload(fin);
         // Reduction schedule of the balanced path for inputs below 2^60 (canonical digits of any modulus): the never-reduced values must stay
         // below 2^62.9 (column sums of mm31) and grow by at most 1.03q per one-round stage (q + |x| q / 2^64) and q/2 + |x|/16 per two-round
         // stage of phase D; a partial reduction leaves |x| <= 0.51q.  Greedy from the load: reduce only where the next phase would overflow.
@@ -360,7 +394,7 @@ Context::~Context() {
 void Context::release_all() noexcept {
     (void)hipSetDevice(device);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
-                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)spreadbuf_,
+                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)d_psiinv31, (void*)d_inv31c, (void*)spreadbuf_,
                     (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_tb30, (void*)d_tw30, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
@@ -598,6 +632,11 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     if (side) join_side(0);
 }
 
+void Context::ntt_inv_launch(NttBatch& b) {
+    b.psi31 = d_psiinv31; b.inv31c = d_inv31c; b.u_mods = u_mods_; b.small_mods = small_mods_; b.no_h16 = d_psiinv31 ? 0 : 1;
+    launch_ntt_inv(logN, b, s_);
+}
+
 // ------------------------------------------------------------------ ring level
 void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, bool inverse, bool lazy) {
     if (mod_base < 0 || mod_base + limbs > mall) throw Error("mkhe: ntt modulus range");
@@ -607,7 +646,7 @@ void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, 
     slots_range(b, mod_base, limbs);
     b.src_outer = b.dst_outer = (long)limbs * N; b.src_inner = b.dst_inner = N;
     b.nouter = count; b.lazy_out = lazy ? 1 : 0;
-    if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * limbs); launch_ntt_inv(logN, b, s_); }
+    if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * limbs); ntt_inv_launch(b); }
     else ntt_fwd_launch(b, false);
     MKHE_HIP(hipGetLastError());
 }
@@ -645,7 +684,7 @@ void Context::ext_core(int level, const u64* ah, const u64* bg, u64* c, bool acc
     b.src = c1_; b.dst = c1_; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_qp(b, level);
     b.nouter = 1; b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
     b.lazy_out = 1;
-    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * nslots); launch_ntt_inv(logN, b, s_); }
+    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * nslots); ntt_inv_launch(b); }
 
     ModDownArgs md{};
     md.xq = c1_; md.xp = c1_ + (size_t)nq * N; md.dst = c; md.mods_q = d_mods; md.mods_p = d_mods + nq;
@@ -844,12 +883,12 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
             for (int k = 0; k < VI_MAX; ++k) b.vi_mem[v] |= (unsigned)mp->mem[v][k] << (8 * k);
         }
         b.vi_jobs = mp->nvi * (level + 1) + n * np;
-        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * b.vi_jobs); launch_ntt_inv(logN, b, s_); }
+        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * b.vi_jobs); ntt_inv_launch(b); }
         return;
     }
     slots_qp(b, level);
     b.nouter = n;
-    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); launch_ntt_inv(logN, b, s_); }
+    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); ntt_inv_launch(b); }
 }
 // back half: ModDown of the items in c1 into (or onto) their destinations
 void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 galEl, const ExtMerge* mp) {
@@ -1046,7 +1085,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
             NttBatch ib{};
             ib.src = out.d; ib.dst = out.d; ib.mods = d_mods; ib.psi = d_psiinv; ib.aux = d_inv_aux; slots_q_owned(ib, L);
             ib.src_outer = ib.dst_outer = (long)PO; ib.src_inner = ib.dst_inner = N; ib.nouter = 1 + out.n;
-            if (ib.nslots > 0) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * ib.nouter * ib.nslots); launch_ntt_inv(logN, ib, s_); }
+            if (ib.nslots > 0) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * ib.nouter * ib.nslots); ntt_inv_launch(ib); }
         }
         side_done(1);
         s_ = stream;
@@ -1428,7 +1467,7 @@ void Context::ntt_r(const u64* src, u64* dst, int count, bool inverse) {
     for (int j = 0; j < 2 * nq; ++j) { b.mod[j] = j < nq ? j : mtot + (j - nq); b.pos[j] = j; }
     b.src_outer = b.dst_outer = 2L * nq * N; b.src_inner = b.dst_inner = N;
     b.nouter = count;
-    if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * 2 * nq); launch_ntt_inv(logN, b, s_); }
+    if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * 2 * nq); ntt_inv_launch(b); }
     else ntt_fwd_launch(b, false);
     MKHE_HIP(hipGetLastError());
 }

@@ -977,6 +977,447 @@ __global__ void __launch_bounds__(NT, 8) ntt14_fwd_split_kernel(NttBatch b) {
     fwd_body<false, true, 14>(b, lds);
 }
 
+// ------------------------------------------------------------------ inverse (round 3)
+// The mirror image of one forward pass on 2^14 points: Gentleman-Sande butterflies X = U + V, Y = (U - V) w on the same one-round products, the
+// phases in the order D, C, B, A with the four re-distributions run backwards (written where the forward pass reads, read where it writes: the same
+// conflict-free address sets), inverse twiddles at the forward indices (NttBatch::psi31 / psi = the INVERSE tables for these launches).  A job is
+//   split = 0: a whole N = 2^14 limb (root 1);   split = 1: one half of an N = 2^15 limb (root 2 + half), the cross-half stage follows as the
+//   streaming pass ntt_split_inv_kernel;   split = 2: one quarter of an N = 2^16 limb (root 4 + quarter), the two cross stages follow as
+//   ntt_pass4_inv_kernel -- one pass per job either way, in place or not.  N^-1 of the WHOLE limb is folded into the last stage (both outputs are
+// products there: NttBatch::inv31c holds the pairs of N^-1 and psiinv[root] N^-1), results are canonical.
+// Ranges: a sum doubles per stage where a forward stage adds, so the never-reduced values are brought back by the cheap partial reduction after
+// phase D and after phase B (U class: 0.51 q x 2^8 = 131 q < 2^62 / q = 160), the moduli in between also after phase C, the 59/60-bit primes at
+// the load and after every second stage (2^62 = 4 q there).  Merged launches (NttBatch::vi) add up the group's members at the load.
+// (one partial reduction at a time: interleaved, the temporaries of sixteen of them do not fit beside a ring of twiddle pairs in flight)
+__device__ __forceinline__ void reduce_seq(u64 (&x)[16], const MC& c, bool on) {
+    if (on) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { x[r] = (u64)pred((i64)x[r], c); __builtin_amdgcn_sched_barrier(0); }
+    }
+}
+template <bool SW, bool UC> __device__ __forceinline__ void gs31(u64& U, u64& V, const u64* tw, const MC& c) {
+    const i64 u = (i64)U, v = (i64)V;
+    U = (u64)(u + v);
+    V = (u64)(UC ? mm30u<SW>(u - v, tw[0], tw[1], c) : mm31<SW>(u - v, tw[0], tw[1], c));
+}
+template <bool UC, int B, int G0 = 0, int NG = 8> __device__ __forceinline__ void stage_gs31(u64 (&x)[16], const u64* tw, const MC& c) {
+#pragma unroll
+    for (int g = G0; g < G0 + NG; ++g) {
+        const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+        gs31<true, UC>(x[i0], x[i0 | (1 << B)], tw + 2 * ((g >> B) - (G0 >> B)), c);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <bool UC, int B> __device__ __forceinline__ void gs1_31(u64 (&x)[16], int g, const u64* tw, const MC& c) {
+    const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+    gs31<false, UC>(x[i0], x[i0 | (1 << B)], tw, c);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int B> __device__ __forceinline__ void gs1(u64 (&x)[16], int g, u64 w, const MC& c) {
+    const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+    const i64 u = (i64)x[i0], v = (i64)x[i0 | (1 << B)];
+    x[i0] = (u64)(u + v);
+    x[i0 | (1 << B)] = (u64)mm<false>(u - v, w, c);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int X> __device__ __forceinline__ void exchange_inv(u64 (&x)[16], u32* lds, int wv) {
+    constexpr bool CROSS = X == X_AB;
+    const int l = lane_id();
+    typedef __attribute__((address_space(3))) u32* lptr;
+    typedef volatile __attribute__((address_space(3))) u32* vlptr;
+    lptr wr = (lptr)lds + rbase<X>(wv, l);
+    vlptr rd = (vlptr)((lptr)lds + wbase<X>(wv, l));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[roff<X>(r)] = lo32(x[r]);
+    xsync<CROSS>();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = (x[r] & 0xffffffff00000000ull) | rd[woff<X>(r)];
+    xsync<CROSS>();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[roff<X>(r)] = hi32(x[r]);
+    xsync<CROSS>();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = ((u64)rd[woff<X>(r)] << 32) | lo32(x[r]);
+    xsync<CROSS>();                  // (cross-wave: the regions are free again before anybody's next write)
+}
+struct JobInv { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* fin; smodptr mp; int root; int nsum; long off[VI_MAX + 1]; };
+template <bool UC>
+__device__ __forceinline__ void limb_inv(const JobInv& jb, const bool big_, u32* lds, const int wv) {
+    // (the balanced instantiation serves the 59/60-bit primes and the few moduli between the classes alike, on the schedule of the former: no
+    // wave-uniform branches around the reductions -- with them the register allocator spilled 140 VGPRs)
+    constexpr bool big = !UC;
+    (void)big_;
+    const int tm = jb.root >> 1, ht = jb.root & 1;
+    smodptr mp = jb.mp;
+    const u64 qs = mp->qs;
+    MC c;
+    c.q = mp->q; c.ninv = mp->ninv32;
+    c.q0 = (i32)lo32(qs); c.q1 = (i32)hi32(qs);
+    c.finv = __builtin_bit_cast(float, mp->finv);
+    if constexpr (UC) {
+        c.p0 = (i32)((u32)c.q << 2) >> 2;
+        c.p1 = (i32)((c.q - (u64)(i64)c.p0) >> 30);
+    } else {
+        c.p0 = (i32)((u32)c.q << 1) >> 1;
+        c.p1 = (i32)((c.q - (u64)(i64)c.p0) >> 31);
+    }
+    asm("" : "+s"(c.q0), "+s"(c.q1), "+s"(c.ninv), "+s"(c.p0), "+s"(c.p1));
+    scptr p31 = (scptr)jb.psi31;
+    gcptr psi_v = (gcptr)jb.psi;
+    const gcptr src = jb.src; const gptr dst = jb.dst;
+    u64 x[16];
+    {
+        // the forward pass's output layout: register r = words wave * 1024 + r * 64 + lane of the 2^14 block
+        const unsigned lb = 8u * (unsigned)(wv * 1024 + lane_id());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = *at(sbk(src, r * 64), lb);
+#pragma unroll
+        for (int k = 1; k <= VI_MAX; ++k)
+            if (k < jb.nsum) {
+                const gcptr sk = src + jb.off[k];
+                // (eight summands in flight at a time: sixteen more loads beside the sixteen values do not fit the 64-VGPR budget)
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    u64 t8[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) t8[r] = *at(sbk(sk, (r0 + r) * 64), lb);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) x[r0 + r] += t8[r];                     // canonical summands: < 5q together
+                    asm volatile("" ::: "memory");
+                }
+            }
+    }
+    reduce_seq(x, c, big);
+    exchange_inv<X_DE>(x, lds, wv);
+    // ---- phase D backwards: bits 0, 1 (two-round product on the 8-byte inverse twiddles, as in the forward pass)
+    {
+        const int ld = lane_id();
+        const unsigned du = (unsigned)((16 * ht + wv) * 64 + ld);
+        __builtin_assume(du < 2048);
+        u64 g[6][2];
+        auto loadg = [&](int k) {
+            if (k < 2) ld2(g[k], (gcptr2)sbk(psi_v, 8192 * tm) + k, 2 * du);
+            else ld2(g[k], (gcptr2)sbk(psi_v, 16384 * tm) + (k - 2), 4 * du);
+        };
+        loadg(2); loadg(3); loadg(4);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            if (n == 2) loadg(5);
+            if (n == 4) loadg(0);
+            if (n == 6) loadg(1);
+            const int gi = n & 7;
+            if (n < 8) gs1<0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
+            else gs1<1>(x, gi, g[gi >> 2][(gi >> 1) & 1], c);
+        }
+    }
+    reduce_seq(x, c, true);
+    // ---- phase C backwards: bits 2..5, per-lane pairs; pair t as in the forward pass (0: k = 9; 1, 2: k = 10; 3..6: k = 11; 7..14: k = 12), used
+    // in the order 7..14, 3..6, 1, 2, 0
+    {
+        const int lc = lane_id();
+        const unsigned cu = (unsigned)((16 * ht + wv) * 16 + (lc >> 2));
+        __builtin_assume(cu < 512);
+        u64 g[RING][2];
+        gcptr p31v = (gcptr)jb.psi31;
+        auto loadt = [&](int t, int slot) {
+            if (t == 0) ld2(g[slot], (gcptr2)sbk(p31v, 2 * 512 * tm), cu);
+            else if (t < 3) ld2(g[slot], (gcptr2)sbk(p31v, 2 * 1024 * tm) + (t - 1), 2 * cu);
+            else if (t < 7) ld2(g[slot], (gcptr2)sbk(p31v, 2 * 2048 * tm) + (t - 3), 4 * cu);
+            else ld2(g[slot], (gcptr2)sbk(p31v, 2 * 4096 * tm) + (t - 7), 8 * cu);
+        };
+        constexpr int seq[15] = {7, 8, 9, 10, 11, 12, 13, 14, 3, 4, 5, 6, 1, 2, 0};
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) loadt(seq[i], i);
+        exchange_inv<X_CD>(x, lds, wv);
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            const int gi = n & 7;
+            const int i = n < 8 ? gi : n < 16 ? 8 + (gi >> 1) : n < 24 ? 12 + (gi >> 2) : 14;          // position in seq of this butterfly's pair
+            const int ip = n == 0 ? -1 : (n - 1 < 8 ? ((n - 1) & 7) : n - 1 < 16 ? 8 + (((n - 1) & 7) >> 1) : n - 1 < 24 ? 12 + (((n - 1) & 7) >> 2) : 14);
+            if (i != ip && i + RING - 1 < 15) loadt(seq[i + RING - 1], (i + RING - 1) % RING);
+            if (n < 8) gs1_31<UC, 0>(x, gi, g[i % RING], c);
+            else if (n < 16) gs1_31<UC, 1>(x, gi, g[i % RING], c);
+            else if (n < 24) gs1_31<UC, 2>(x, gi, g[i % RING], c);
+            else gs1_31<UC, 3>(x, gi, g[i % RING], c);
+            if (n == 15) reduce_seq(x, c, big);
+        }
+    }
+    reduce_seq(x, c, !UC);
+    exchange_inv<X_BC>(x, lds, wv);
+    // ---- phase B backwards: bits 6..9, scalar pairs
+    {
+        const int cb = 16 * ht + wv;
+        u64 tw[6], tm4[8], ta[8], tb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ta[i] = p31[2 * (256 * tm + 8 * cb) + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tb[i] = p31[2 * (256 * tm + 8 * cb + 4) + i];
+        stage_gs31<UC, 0, 0, 4>(x, ta, c);
+        stage_gs31<UC, 0, 4, 4>(x, tb, c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tm4[i] = p31[2 * (128 * tm + 4 * cb) + i];
+        stage_gs31<UC, 1>(x, tm4, c);
+        reduce_seq(x, c, big);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tw[2 + i] = p31[2 * (64 * tm + 2 * cb) + i];
+        stage_gs31<UC, 2>(x, tw + 2, c);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tw[i] = p31[2 * (32 * tm + cb) + i];
+        stage_gs31<UC, 3>(x, tw, c);
+    }
+    reduce_seq(x, c, true);
+    exchange_inv<X_AB>(x, lds, wv);
+    // ---- phase A backwards: bits 10..13; the last stage multiplies both outputs (N^-1 folded in)
+    {
+        u64 tw[6], tm4[8], ta[8], tb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ta[i] = p31[2 * (16 * tm + 8 * ht) + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tb[i] = p31[2 * (16 * tm + 8 * ht + 4) + i];
+        stage_gs31<UC, 0, 0, 4>(x, ta, c);
+        stage_gs31<UC, 0, 4, 4>(x, tb, c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tm4[i] = p31[2 * (8 * tm + 4 * ht) + i];
+        stage_gs31<UC, 1>(x, tm4, c);
+        reduce_seq(x, c, big);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tw[2 + i] = p31[2 * (4 * tm + 2 * ht) + i];
+        stage_gs31<UC, 2>(x, tw + 2, c);
+        scptr fin = (scptr)jb.fin;
+        const u64 f[4] = {fin[0], fin[1], fin[2], fin[3]};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const i64 u = (i64)x[g], v = (i64)x[g + 8];
+            const i64 s = UC ? mm30u<true>(u + v, f[0], f[1], c) : mm31<true>(u + v, f[0], f[1], c);
+            const i64 d = UC ? mm30u<true>(u - v, f[2], f[3], c) : mm31<true>(u - v, f[2], f[3], c);
+            x[g] = (u64)s; x[g + 8] = (u64)d;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const i64 y = pred((i64)x[r], c);
+        x[r] = (u64)(y + ((y >> 63) & (i64)c.q));                           // canonical
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+        const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *at(sbk(dst, r * NT), tb) = x[r];
+    }
+}
+// The same pass for the moduli outside the U class (the 59/60-bit primes and the few between the classes): Harvey-style Gentleman-Sande
+// butterflies on the two-round product with the 8-byte inverse twiddles, values in [0, 2q) throughout -- X = (U + V) - [2q], Y = (U + 2q - V) w --
+// so that no partial reduction is needed anywhere (on the one-round product with reductions after every second stage this instantiation spilled
+// 738 VGPRs).  15 + 6 instructions per butterfly against 9 + 3: the minority of the limbs.
+template <bool SW> __device__ __forceinline__ void gsH(u64& U, u64& V, u64 w, const MC& c, u64 q2) {
+    const u64 s = csub(U + V, q2), d = U + q2 - V;
+    U = s;
+    V = (u64)(mm<SW>((i64)d, w, c) + (i64)c.q);
+}
+template <int B, int G0 = 0, int NG = 8> __device__ __forceinline__ void stage_gsH(u64 (&x)[16], const u64* tw, const MC& c, u64 q2) {
+#pragma unroll
+    for (int g = G0; g < G0 + NG; ++g) {
+        const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+        gsH<true>(x[i0], x[i0 | (1 << B)], tw[(g >> B) - (G0 >> B)], c, q2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int B> __device__ __forceinline__ void gsH1(u64 (&x)[16], int g, u64 w, const MC& c, u64 q2) {
+    const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+    gsH<false>(x[i0], x[i0 | (1 << B)], w, c, q2);
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void limb_inv_cs(const JobInv& jb, u32* lds, const int wv) {
+    const int tm = jb.root >> 1, ht = jb.root & 1;
+    smodptr mp = jb.mp;
+    const u64 qs = mp->qs;
+    MC c;
+    c.q = mp->q; c.ninv = mp->ninv32;
+    c.q0 = (i32)lo32(qs); c.q1 = (i32)hi32(qs);
+    c.finv = 0.0f; c.p0 = 0; c.p1 = 0;
+    asm("" : "+s"(c.q0), "+s"(c.q1), "+s"(c.ninv));
+    const u64 q = c.q, q2 = 2 * c.q;
+    scptr psi_s = (scptr)jb.psi;
+    gcptr psi_v = (gcptr)jb.psi;
+    const gcptr src = jb.src; const gptr dst = jb.dst;
+    u64 x[16];
+    {
+        const unsigned lb = 8u * (unsigned)(wv * 1024 + lane_id());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = *at(sbk(src, r * 64), lb);
+#pragma unroll
+        for (int k = 1; k <= VI_MAX; ++k)
+            if (k < jb.nsum) {
+                const gcptr sk = src + jb.off[k];
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    u64 t8[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) t8[r] = *at(sbk(sk, (r0 + r) * 64), lb);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) x[r0 + r] = csub(x[r0 + r] + t8[r], q);      // canonical summands, canonical sum
+                    asm volatile("" ::: "memory");
+                }
+            }
+    }
+    exchange_inv<X_DE>(x, lds, wv);
+    {
+        const int ld = lane_id();
+        const unsigned du = (unsigned)((16 * ht + wv) * 64 + ld);
+        __builtin_assume(du < 2048);
+        u64 g[6][2];
+        auto loadg = [&](int k) {
+            if (k < 2) ld2(g[k], (gcptr2)sbk(psi_v, 8192 * tm) + k, 2 * du);
+            else ld2(g[k], (gcptr2)sbk(psi_v, 16384 * tm) + (k - 2), 4 * du);
+        };
+        loadg(2); loadg(3); loadg(4);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            if (n == 2) loadg(5);
+            if (n == 4) loadg(0);
+            if (n == 6) loadg(1);
+            const int gi = n & 7;
+            if (n < 8) gsH1<0>(x, gi, g[2 + (gi >> 1)][gi & 1], c, q2);
+            else gsH1<1>(x, gi, g[gi >> 2][(gi >> 1) & 1], c, q2);
+        }
+    }
+    // phase C: the 15 twiddles psi[512 tm + cu] | psi[1024 tm + 2 cu + {0,1}] | psi[2048 tm + 4 cu + {0..3}] | psi[4096 tm + 8 cu + {0..7}] as eight
+    // 16-byte groups, used in the order G0..G3 (bit 2: 8 twiddles), G4, G5 (bit 3: 4), G6 (bit 4: 2), G7 (bit 5: 1); three groups in flight
+    {
+        const int lc = lane_id();
+        const unsigned cu = (unsigned)((16 * ht + wv) * 16 + (lc >> 2));
+        __builtin_assume(cu < 512);
+        u64 g[3][2];
+        auto loadt = [&](int G, int slot) {
+            if (G < 4) ld2(g[slot], (gcptr2)sbk(psi_v, 4096 * tm) + G, 4 * cu);
+            else if (G < 6) ld2(g[slot], (gcptr2)sbk(psi_v, 2048 * tm) + (G - 4), 2 * cu);
+            else if (G == 6) ld2(g[slot], (gcptr2)sbk(psi_v, 1024 * tm), cu);
+            else { g[slot][0] = *at(sbk(psi_v, 512 * tm), 8u * cu); g[slot][1] = 0; }
+        };
+        loadt(0, 0); loadt(1, 1);
+        exchange_inv<X_CD>(x, lds, wv);
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            const int gi = n & 7;
+            const int G = n < 8 ? (gi >> 1) : n < 16 ? 4 + (gi >> 2) : n < 24 ? 6 : 7;
+            const int Gp = n == 0 ? -1 : (n - 1 < 8 ? (((n - 1) & 7) >> 1) : n - 1 < 16 ? 4 + (((n - 1) & 7) >> 2) : n - 1 < 24 ? 6 : 7);
+            if (G != Gp && G + 2 < 8) loadt(G + 2, (G + 2) % 3);
+            const u64 w = n < 8 ? g[G % 3][gi & 1] : n < 16 ? g[G % 3][(gi >> 1) & 1] : n < 24 ? g[G % 3][gi >> 2] : g[G % 3][0];
+            if (n < 8) gsH1<0>(x, gi, w, c, q2);
+            else if (n < 16) gsH1<1>(x, gi, w, c, q2);
+            else if (n < 24) gsH1<2>(x, gi, w, c, q2);
+            else gsH1<3>(x, gi, w, c, q2);
+        }
+    }
+    exchange_inv<X_BC>(x, lds, wv);
+    {
+        const int cb = 16 * ht + wv;
+        u64 tw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tw[i] = psi_s[256 * tm + 8 * cb + i];
+        stage_gsH<0>(x, tw, c, q2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tw[i] = psi_s[128 * tm + 4 * cb + i];
+        stage_gsH<1>(x, tw, c, q2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tw[i] = psi_s[64 * tm + 2 * cb + i];
+        stage_gsH<2>(x, tw, c, q2);
+        tw[0] = psi_s[32 * tm + cb];
+        stage_gsH<3>(x, tw, c, q2);
+    }
+    exchange_inv<X_AB>(x, lds, wv);
+    {
+        u64 tw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tw[i] = psi_s[16 * tm + 8 * ht + i];
+        stage_gsH<0>(x, tw, c, q2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tw[i] = psi_s[8 * tm + 4 * ht + i];
+        stage_gsH<1>(x, tw, c, q2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tw[i] = psi_s[4 * tm + 2 * ht + i];
+        stage_gsH<2>(x, tw, c, q2);
+        scptr fin = (scptr)jb.fin;
+        const u64 f0 = fin[4], f1 = fin[5];                   // N^-1 R, psiinv[root] N^-1 R (signed-split form)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const u64 U = x[g], V = x[g + 8];
+            const u64 sv = (u64)(mm<true>((i64)(U + V), f0, c) + (i64)q);
+            const u64 dv = (u64)(mm<true>((i64)(U + q2 - V), f1, c) + (i64)q);
+            x[g] = csub(sv, q); x[g + 8] = csub(dv, q);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    {
+        const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *at(sbk(dst, r * NT), tb) = x[r];
+    }
+}
+__global__ void __launch_bounds__(NT, 8) ntt14_inv_kernel(NttBatch b) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int njobs = (b.nslots * b.nouter) << b.split;
+#pragma unroll 1
+    for (int job2 = blockIdx.x; job2 < njobs; job2 += gridDim.x) {
+        kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kb));
+        const int split = kb->split, job = job2 >> split, part = job2 & ((1 << split) - 1);
+        const int nouter = kb->nouter;
+        const int s = (int)udiv_magic((unsigned)job, kb->magic_nouter);
+        int outer = job - s * nouter;
+        const int m = kb->mod[s];
+        JobInv jb;
+        jb.nsum = 1;
+#pragma unroll
+        for (int k = 0; k <= VI_MAX; ++k) jb.off[k] = 0;
+        if (kb->vi) {
+            // as ntt_kernels.hip job_pointers<true> / vi_member_offset
+            const int cnt = kb->vi_cnt[outer];
+            const unsigned mem = kb->vi_mem[outer];
+            const int k = s < kb->vi_q ? 0 : (int)udiv_magic((unsigned)(s - kb->vi_q), kb->magic_vi_np);
+            if (k >= cnt) continue;                          // a P slot of a member this group does not have (the whole workgroup skips it)
+            const long off = (long)((mem >> (8 * k)) & 255u) * kb->src_outer + (long)m * kb->src_inner;
+            jb.src = (gcptr)(kb->src + off); jb.dst = (gptr)(kb->dst + off);
+            if (s < kb->vi_q) {
+                const u64* extra = kb->vi_extra[outer];
+                jb.nsum = cnt + (extra != nullptr ? 1 : 0);
+#pragma unroll
+                for (int kk = 1; kk <= VI_MAX; ++kk) {
+                    if (kk < cnt) jb.off[kk] = ((long)((mem >> (8 * kk)) & 255u) - (long)(mem & 255u)) * kb->src_outer;
+                    else if (kk == cnt && extra) jb.off[kk] = (long)(((u64)extra - (u64)(kb->src + off)) >> 3) + (long)m * kb->src_inner;
+                }
+            }
+        } else {
+            const int p = kb->pos[s];
+            const u64* sbase_ = kb->src; u64* dbase_ = kb->dst;
+            if (kb->nitems > 0) {
+                const int item = (int)udiv_magic((unsigned)outer, kb->magic_opi);
+                outer -= item * kb->outers_per_item;
+                sbase_ = kb->src_items[item]; dbase_ = kb->dst_items[item];
+            }
+            jb.src = (gcptr)(sbase_ + (long)outer * kb->src_outer + (long)(kb->src_mapped ? m : p) * kb->src_inner);
+            jb.dst = (gptr)(dbase_ + (long)outer * kb->dst_outer + (long)(kb->dst_mapped ? m : p) * kb->dst_inner);
+        }
+        jb.src += part * HH; jb.dst += part * HH;
+        jb.root = (1 << split) + part;
+        const long nlimb = (long)HH << split;                     // twiddle words per modulus: the rows of the whole limb
+        jb.psi = kb->psi + (long)m * nlimb;
+        jb.psi31 = kb->psi31 + 2 * (long)m * nlimb;
+        jb.fin = kb->inv31c + ((long)m * 8 + jb.root) * 6;
+        jb.mp = (smodptr)kb->mods + m;
+#if defined(MKHE_INV_ONLY) && MKHE_INV_ONLY == 1
+        limb_inv<true>(jb, false, lds, wv);
+#elif defined(MKHE_INV_ONLY) && MKHE_INV_ONLY == 0
+        limb_inv_cs(jb, lds, wv);
+#else
+        if ((kb->u_mods >> m) & 1) limb_inv<true>(jb, false, lds, wv);
+        else limb_inv_cs(jb, lds, wv);
+#endif
+    }
+}
+
 }  // namespace h16
 
 // ------------------------------------------------------------------ launcher
@@ -1038,6 +1479,39 @@ void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
     fill_job_constants(c, c.nslots * c.nouter, 0, 0);
     if (c.split == 2) hipLaunchKernelGGL(ntt14_fwd_split_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
     else hipLaunchKernelGGL(ntt16_fwd_split_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
+}
+// inverse: launches of at least MKHE_NTT16_INV_MIN one-pass jobs (2^14 points each); the caller (launch_ntt_inv) runs the cross stages of
+// N = 2^15 / 2^16 behind it.  b.psi31 / b.psi are the INVERSE tables here, b.inv31c the pairs of the last stage.
+bool ntt16_inv_ok(int logN, const NttBatch& b) {
+    static const int on = env_int16("MKHE_NTT16_INV", 1), minj = env_int16("MKHE_NTT16_INV_MIN", 256);
+    if (!on || b.no_h16 || !b.psi31 || !b.inv31c || b.split || b.nslots > 64 || logN < 14 || logN > 16) return false;
+    const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;
+    return (limbs << (logN - 14)) >= minj && b.nslots * b.nouter < 65536;
+}
+void launch_ntt16_inv(const NttBatch& b, hipStream_t st, int logN) {
+    using namespace h16;
+    NttBatch c = b;
+    c.split = logN - 14;
+    const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
+    static LaunchState16 ls;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int resident = 0;
+    {
+        std::lock_guard<std::mutex> g(ls.mu);
+        if (!ls.resident[dev & 63]) {
+            (void)hipFuncSetAttribute((const void*)ntt14_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            int cus = 256, per = 1;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)ntt14_inv_kernel, NT, lds) != hipSuccess || per < 1) per = 1;
+            ls.resident[dev & 63] = cus * per;
+        }
+        resident = ls.resident[dev & 63];
+    }
+    const int need = (c.nslots * c.nouter) << c.split;
+    fill_job_constants(c, c.nslots * c.nouter, 0, 0);
+    c.magic_vi_np = magic_of(c.vi ? c.vi_np : 1);
+    hipLaunchKernelGGL(ntt14_inv_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
 }
 bool ntt16_ok(int logN, const NttBatch& b) {
     static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128), minl14 = env_int16("MKHE_NTT14_MIN", 128);

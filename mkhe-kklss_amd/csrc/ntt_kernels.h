@@ -77,7 +77,10 @@ struct NttBatch {
     // ntt16_kernels.hip, filled by its launchers: reciprocals for the per-limb index arithmetic (scalar multiply-high instead of VALU
     // divisions) and the placement of the long jobs (the first B jobs of the list: big-modulus limbs) on the CUs that own fewer positions
     int half_jobs;          // the two passes of every limb are separate jobs of the walk (out-of-place N = 2^15 launches)
-    unsigned magic_nouter, magic_opi;
+    unsigned magic_nouter, magic_opi, magic_vi_np;
+    // inverse launches on ntt14_inv_kernel (ntt16_kernels.hip): psi31 / psi are then the INVERSE tables, and
+    const u64* inv31c;      // [nmod][8][6]: entry `root` = the pair of N^-1, the pair of psiinv[root] N^-1 (N = the whole limb; format of the modulus's class), and both in signed-split Montgomery form
+    unsigned long long small_mods;   // bit m set = modulus m has 31 q < 2^62 (no 59/60-bit reduction schedule)
     struct Lpt { int B, C, r, full, rem; unsigned magic_C; } lpt;
     int no_h16;             // this context has a modulus the H16 kernel's ranges do not cover (48q >= 2^62 > 31q): keep to the other kernels
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
@@ -115,6 +118,8 @@ void launch_ntt_fwd_mixed(int logN, const NttBatch& b, const unsigned char* smal
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st);
 // N = 2^15 launches that fill the chip (ntt16_kernels.hip): 16 coefficients per thread, two workgroups per CU, both modulus
 // classes in one persistent launch.  ntt16_ok: false when the launch does not qualify (MKHE_NTT16=0 switches the path off).
+bool ntt16_inv_ok(int logN, const NttBatch& b);
+void launch_ntt16_inv(const NttBatch& b, hipStream_t st, int logN);
 bool ntt16_ok(int logN, const NttBatch& b);
 void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st, int logN = 15);
 // the same kernel on the 2^15-point sub-transforms of a split N = 2^16 launch (one modulus class per launch)

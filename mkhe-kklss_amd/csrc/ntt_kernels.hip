@@ -906,6 +906,19 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
 }
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
+    if (ntt16_inv_ok(logN, b)) {
+        // launches that fill the chip: one-pass 2^14-point sub-transforms on the H16-class inverse kernel (src -> dst, canonical, N^-1 folded in),
+        // then the cross stages of the larger rings as one streaming pass in place on dst
+        launch_ntt16_inv(b, st, logN);
+        if (logN > 14) {
+            NttBatch e = in_place_of_dst(b);                  // only the dst addressing is used
+            e.lazy_out = b.lazy_out; e.psi = b.psi; e.split = 0;
+            const dim3 grid(32, b.nslots * b.nouter);
+            if (logN == 15) hipLaunchKernelGGL(ntt_split_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, e, logN);
+            else hipLaunchKernelGGL(ntt_pass4_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, e, logN);
+        }
+        return;
+    }
     if (!b.split && use_split(logN, b)) {
         if (const int d = lds_depth(logN, b)) {
             const int jobs = (b.nslots * b.nouter) << d;

@@ -322,3 +322,41 @@ def test_plain_forward_ntt_of_many_limbs(which, pn14, pn15):
             ref = r.ntt(i, a[c][j])
             assert (got[c][j] == ref).all() and (inplace[c][j] == ref).all(), (c, j)
     assert (got == inplace).all()
+
+
+@pytest.mark.parametrize("which,cnt", [("pn14", 70), ("pn15", 20), ("pn16", 4)])
+def test_plain_inverse_ntt_of_many_limbs(which, cnt, pn14, pn15):
+    """ring.InvNTT / InvNTTLazy of many polynomials at once (560 limbs of 2^14, 320 of 2^15, 152 of 2^16): launches that fill the chip run the
+    one-pass 2^14-point sub-transforms of the H16-class inverse kernel (ntt14_inv_kernel: whole limbs, halves + ntt_split_inv_kernel, quarters +
+    ntt_pass4_inv_kernel), out of place and in place, against the oracle on every modulus and as the inverse of the forward transform."""
+    from mkhe_kklss_amd import mkrlwe
+    if which == "pn16":
+        from oracle import oracle as O
+        from mkhe_kklss_amd import mkckks
+        p = H.PN16QP1761
+        params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"], device=0)
+        ks = O.KeySwitcher(p["logN"], p["Q"], p["P"], 2)
+        rng = np.random.default_rng(1616)
+    else:
+        f = pn14 if which == "pn14" else pn15
+        p, ks, params, rng = f["pset"], f["ks"], f["params"], f["rng"]
+    mods = p["Q"] + p["P"]
+    N = 1 << p["logN"]
+    a = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in mods]) for _ in range(cnt)])
+    src = mkrlwe.DeviceLimbs(params, cnt, len(mods)).upload(a)
+    dst = mkrlwe.DeviceLimbs(params, cnt, len(mods))
+    mkrlwe.ntt(params, src, dst, inverse=True)
+    got = dst.download()
+    mkrlwe.ntt(params, src, dst, inverse=True, lazy=True)
+    lazy = dst.download()
+    for c in (0, cnt - 1):
+        for j in range(len(mods)):
+            r, i = (ks.ringQ, j) if j < len(p["Q"]) else (ks.ringP, j - len(p["Q"]))
+            ref = r.intt(i, a[c][j])
+            assert (got[c][j] == ref).all(), (c, j)
+    for j, q in enumerate(mods):                     # InvNTTLazy: the same residues, below 2q
+        assert (lazy[:, j] < 2 * q).all() and (lazy[:, j] % q == got[:, j]).all(), j
+    mkrlwe.ntt(params, src, src, inverse=True)       # in place
+    assert (src.download() == got).all()
+    mkrlwe.ntt(params, src, src)                     # and back
+    assert (src.download() == a).all()

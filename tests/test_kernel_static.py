@@ -45,6 +45,11 @@ def test_h16_kernels_fit_eight_waves_per_simd_without_scratch():
     assert len(names) == 6, sorted(res)
     for n in names:
         assert res[n]["vgpr_count"] <= 64 and res[n]["vgpr_spill_count"] == 0 and res[n]["private_segment_fixed_size"] == 0, (n, res[n])
+    # the inverse kernel of the family (round 3): same occupancy; a dozen spilled registers around the member sums of a merged launch are tolerated,
+    # the 738 of its first balanced-path instantiation are not
+    inv = [n for n in res if "ntt14_inv" in n]
+    assert len(inv) == 1, sorted(res)
+    assert res[inv[0]]["vgpr_count"] <= 64 and res[inv[0]]["vgpr_spill_count"] <= 16 and res[inv[0]]["private_segment_fixed_size"] <= 64, res[inv[0]]
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
