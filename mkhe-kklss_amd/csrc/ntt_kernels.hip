@@ -871,6 +871,20 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
         launch_ntt16_fwd_split(o, small, st);
         return;
     }
+    if (logN == 16 && !b.prestaged) {
+        // N = 2^16 without a fused producer (the tensor-step inputs, plain NTTs): both cross stages as ONE streaming pass, then the four one-pass
+        // 2^14-point sub-transforms per limb on the H16 kernel -- instead of a radix-2 pass and two-pass 2^15-point halves (MKHE_NTT16_RADIX4=0)
+        static const int r4 = env_int("MKHE_NTT16_RADIX4", 1);
+        NttBatch o = in_place_of_dst(b);
+        o.reduce_in = 0; o.split = 2;
+        if (r4 && ntt16_split_ok(o)) {
+            const dim3 grid(32, b.nslots * b.nouter);
+            if (b.reduce_in) hipLaunchKernelGGL(ntt_pass4_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+            else hipLaunchKernelGGL(ntt_pass4_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+            launch_ntt16_fwd_split(o, small, st);
+            return;
+        }
+    }
     if (use_split(logN, b)) {
         const dim3 grid(32, b.nslots * b.nouter);
         const int d = lds_depth(logN, b);
