@@ -847,9 +847,10 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
     }
 }
 
-// n / d for 0 <= n < 2^16, 1 <= d < 2^16 as ONE scalar multiply-high: magic = floor(2^32 / d) + 1 (host: magic_of), exact in that range
+// n / d for 0 <= n < 2^16, 2 <= d < 2^16 as ONE scalar multiply-high: magic = floor(2^32 / d) + 1 (host: magic_of), exact in that range;
+// d = 1 has no 32-bit magic (2^32 + 1): magic_of returns 0 for it and the quotient is n itself
 // (the error term n * (magic * d - 2^32) / (d * 2^32) stays below 1 / d)
-__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return (unsigned)(((unsigned long long)n * magic) >> 32); }
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return magic ? (unsigned)(((unsigned long long)n * magic) >> 32) : n; }
 template <bool DEC, bool SPLIT, int LOGN = 15>
 __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
     constexpr int NL = 1 << LOGN;                 // words per limb = twiddle words per modulus
@@ -1450,7 +1451,7 @@ int resident16(size_t lds) {
 }
 }
 // launch constants of the job walk (fwd_body): reciprocals for the scalar multiply-high divisions and the placement of the long jobs
-static unsigned magic_of(int d) { return d > 0 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
+static unsigned magic_of(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }      // (0: divisor 1, see udiv_magic)
 static void fill_job_constants(NttBatch& c, int njobs, int blocks, int lpt_long) {
     if (njobs >= 65536 || c.nouter >= 65536) throw std::runtime_error("mkhe: internal: an H16 launch of 2^16 limbs or more");
     c.magic_nouter = magic_of(c.nouter);
