@@ -1,0 +1,24 @@
+#!/bin/bash
+# The GPU parity suite under the A/B switch sets of DESIGN.md section 6 (run on the GPU box):  gpurun --timeout 1200 -- 'bash tools/switch_matrix.sh'
+# Every path a measurement decided against -- and every H16 kernel on every launch shape, thresholds at 1 -- has to give the same bits as the defaults.
+# Each set is one pytest process (the switches are read once per process); a GPU fault anywhere fails the set.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/switch_matrix
+mkdir -p $O
+cd $R
+rc=0
+run() {
+    local name=$1; shift
+    env "$@" python3 -m pytest tests -m gpu -x -q > $O/$name.txt 2>&1
+    local r=$?
+    if grep -q "Memory access fault" $O/$name.txt; then r=99; fi
+    echo "$name: rc=$r  $(tail -1 $O/$name.txt)"
+    [ $r -ne 0 ] && rc=1
+    return $r
+}
+run defaults MKHE_UNUSED=1 &&
+run thresholds_at_1 MKHE_NTT16_INV_MIN=1 MKHE_NTT16_MIN=1 MKHE_NTT14_MIN=1 &&
+run round3_off MKHE_SPREAD_RADIX4=0 MKHE_NTT16_RADIX4=0 MKHE_NTT16_INV=0 MKHE_H16_UCLASS=0 MKHE_NTT16_HALVES=0 MKHE_NTT16_LPT=0 MKHE_FUSE_RESCALE=0 MKHE_FUSE_X=0 MKHE_H16_SCHED=0 &&
+run round2_off MKHE_NTT16_HALVES=2 MKHE_SPREAD_RADIX4=0 MKHE_SPREAD_OOP=0 MKHE_EXT_MERGE=0 MKHE_TENSOR_FOLD=0 MKHE_EXT_GROUP=0 MKHE_NTT_LDS=0 MKHE_NTT_MIXED=0 &&
+run round1_kernels MKHE_NTT16=0 MKHE_NTT16_INV=0 MKHE_NTT_SPLIT=0 MKHE_NO_OVERLAP=1
+exit $rc
