@@ -126,6 +126,10 @@ CASES = [
     ([], ["a"], 0, 0, False),
     (["a"], [], 0, 0, True),
     (["p%d" % i for i in range(7)], ["p%d" % i for i in range(3, 9)], 0, 0, False),
+    # five, six and eight parties in op0: x as the by-product of step F1 in its wide form (ext_inner_xwide_kernel; seven is the case above)
+    (["p%d" % i for i in range(5)], ["p0", "p5"], 0, 0, True),
+    (["p%d" % i for i in range(6)], ["p%d" % i for i in range(6)], 1, 0, False),
+    (["p%d" % i for i in range(8)], ["p%d" % i for i in range(2, 6)], 0, 0, False),
 ]
 
 
