@@ -833,7 +833,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     if (n < 1 || nslots < 1) return;
     ExtInnerArgs ia{};
     bool two = false;
-    bool xby = ext_xout_ != nullptr && n <= (ext_xout2_ ? 4 : 8);      // (five to eight single-gadget items: ext_inner_xwide_kernel)
+    bool xby = ext_xout_ != nullptr && n <= (ext_xout2_ ? 4 : 16);     // (five to sixteen single-gadget items: ext_inner_xwide_kernel)
     const bool xby2 = ext_xout2_ != nullptr;               // mkbfv: both gadgets carry their x
     for (int i = 0; i < n; ++i) {
         ia.ah[i] = it[i].ah; ia.bg[i] = it[i].bg;
@@ -963,8 +963,8 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
                             const Swk& crs_u, Ct& out) {
     mr_prepare(op0, op1, hoist0, hoist1, true, out);
     static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
-    static const int wide_env = getenv("MKHE_FUSE_X_WIDE") ? atoi(getenv("MKHE_FUSE_X_WIDE")) : 1;      // A/B: the by-product for five to eight parties
-    const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= (wide_env ? 8 : 4) && !masked_;
+    static const int wide_env = getenv("MKHE_FUSE_X_WIDE") ? atoi(getenv("MKHE_FUSE_X_WIDE")) : 1;      // A/B: the by-product for five to sixteen parties
+    const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= (wide_env ? 16 : 4) && !masked_;
     mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse);
     mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
 }

@@ -385,39 +385,43 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_group_kernel(ExtInnerArg
     r.x = csub(a0, q); r.y = csub(a1, q);
     *(u64x2*)out = r;
 }
-// Step F1 of a MulAndRelin with FIVE TO EIGHT parties (round 3): all items share bg = y and every item's digits meet its own key d_i as well, so
+// Step F1 of a MulAndRelin with FIVE TO SIXTEEN parties (round 3): all items share bg = y and every item's digits meet its own key d_i as well, so
 // that x = sum_i d_i (.) h(c0_i) comes out of the same pass over the h(c0_i) as the external products <h(c0_i), y> -- what ext_group_singles<G> does
-// for up to four parties, here with the members of a digit taken four at a time (eight accumulator pairs, eight loads in flight).  Without it
+// for up to four parties, here with the members of a digit taken four at a time (8, 12 or 16 accumulator pairs, eight loads in flight).  Without it
 // x is a separate inner_product_kernel launch that reads the 8 x 331 MB of hoisted digits of an 8-party PN16QP1761 MulRelin a second time.
-template <int G>
+template <int G4>
 __device__ __forceinline__ void ext_x_wide(const ExtInnerArgs& a, ext_kargs ka, long off, const Mod& md) {
+    constexpr int GM = 4 * G4;                  // accumulators held; the launch has G = a.nitems <= GM members (wave-uniform guards)
+    const int G = a.nitems;
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
     const long ds = a.digit_stride;
     const u64* bg = ka->bg[0] + off;
     u64* xo = a.xout + off;
-    u64 acc[G][2];
+    u64 acc[GM][2];
 #pragma unroll
-    for (int m = 0; m < G; ++m) { acc[m][0] = 0; acc[m][1] = 0; }
+    for (int m = 0; m < GM; ++m) { acc[m][0] = 0; acc[m][1] = 0; }
 #pragma unroll 1
     for (int i = 0; i < a.nb; ++i) {
         const long io = off + i * ds;
         const u64x2 g = ld_stream(bg + i * ds);
         u64 x0 = 0, x1 = 0;
 #pragma unroll
-        for (int m0 = 0; m0 < G; m0 += 4) {
-            u64x2 h[4], k[4];
+        for (int m0 = 0; m0 < GM; m0 += 4) {
+            if (m0 < G) {
+                u64x2 h[4], k[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                if (m0 + m < G) { h[m] = ld_stream(ka->ah[m0 + m] + io); k[m] = ld_stream(ka->xkey[m0 + m] + io); }
+                for (int m = 0; m < 4; ++m)
+                    if (m0 + m < G) { h[m] = ld_stream(ka->ah[m0 + m] + io); k[m] = ld_stream(ka->xkey[m0 + m] + io); }
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                if (m0 + m < G) {
-                    acc[m0 + m][0] = csub(acc[m0 + m][0] + mont_mul_lazy(g.x, h[m].x, q, ninv), q2);
-                    acc[m0 + m][1] = csub(acc[m0 + m][1] + mont_mul_lazy(g.y, h[m].y, q, ninv), q2);
-                    x0 = csub(x0 + mont_mul_lazy(k[m].x, h[m].x, q, ninv), q2);
-                    x1 = csub(x1 + mont_mul_lazy(k[m].y, h[m].y, q, ninv), q2);
-                }
+                for (int m = 0; m < 4; ++m)
+                    if (m0 + m < G) {
+                        acc[m0 + m][0] = csub(acc[m0 + m][0] + mont_mul_lazy(g.x, h[m].x, q, ninv), q2);
+                        acc[m0 + m][1] = csub(acc[m0 + m][1] + mont_mul_lazy(g.y, h[m].y, q, ninv), q2);
+                        x0 = csub(x0 + mont_mul_lazy(k[m].x, h[m].x, q, ninv), q2);
+                        x1 = csub(x1 + mont_mul_lazy(k[m].y, h[m].y, q, ninv), q2);
+                    }
+            }
         }
         x0 = csub(x0, q); x1 = csub(x1, q);
         if (a.xmform) { x0 = mont_mul(x0, md.r2, q, ninv); x1 = mont_mul(x1, md.r2, q, ninv); }
@@ -425,30 +429,28 @@ __device__ __forceinline__ void ext_x_wide(const ExtInnerArgs& a, ext_kargs ka, 
         *(u64x2*)(xo + i * ds) = r;
     }
 #pragma unroll
-    for (int m = 0; m < G; ++m) ext_store(a.c1 + (long)m * a.c1_item + off, acc[m][0], acc[m][1], q);
+    for (int m = 0; m < GM; ++m)
+        if (m < G) ext_store(a.c1 + (long)m * a.c1_item + off, acc[m][0], acc[m][1], q);
 }
+template <int G4>
 __global__ void __launch_bounds__(PW_THREADS) ext_inner_xwide_kernel(ExtInnerArgs a) {
     ext_kargs ka = (ext_kargs)__builtin_amdgcn_kernarg_segment_ptr();
     const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
     if (n >= a.N) return;
     const int m = a.map[blockIdx.y];
     const Mod md = a.mods[m];
-    const long off = (long)m * a.N + n;
-    switch (a.nitems) {
-        case 5: ext_x_wide<5>(a, ka, off, md); break;
-        case 6: ext_x_wide<6>(a, ka, off, md); break;
-        case 7: ext_x_wide<7>(a, ka, off, md); break;
-        case 8: ext_x_wide<8>(a, ka, off, md); break;
-        default: break;
-    }
+    ext_x_wide<G4>(a, ka, (long)m * a.N + n, md);
 }
 void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
     ExtInnerArgs a = a_in;
     if (a.xout && a.nitems > 4) {
-        // (checked by the caller: single items, one shared key, one gadget, five to eight of them)
-        if (a.nitems > 8 || a.xout2) throw std::runtime_error("mkhe: internal: wide x by-product outside its range");
+        // (checked by the caller: single items, one shared key, one gadget, five to sixteen of them)
+        if (a.nitems > 16 || a.xout2) throw std::runtime_error("mkhe: internal: wide x by-product outside its range");
         const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
-        hipLaunchKernelGGL(ext_inner_xwide_kernel, dim3(bx, a.nslots, 1), dim3(PW_THREADS), 0, st, a);
+        const dim3 grid(bx, a.nslots, 1), blk(PW_THREADS);
+        if (a.nitems <= 8) hipLaunchKernelGGL(ext_inner_xwide_kernel<2>, grid, blk, 0, st, a);
+        else if (a.nitems <= 12) hipLaunchKernelGGL(ext_inner_xwide_kernel<3>, grid, blk, 0, st, a);
+        else hipLaunchKernelGGL(ext_inner_xwide_kernel<4>, grid, blk, 0, st, a);
         return;
     }
     static const int grouping = getenv("MKHE_EXT_GROUP") ? atoi(getenv("MKHE_EXT_GROUP")) : 1;

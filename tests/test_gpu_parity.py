@@ -130,6 +130,9 @@ CASES = [
     (["p%d" % i for i in range(5)], ["p0", "p5"], 0, 0, True),
     (["p%d" % i for i in range(6)], ["p%d" % i for i in range(6)], 1, 0, False),
     (["p%d" % i for i in range(8)], ["p%d" % i for i in range(2, 6)], 0, 0, False),
+    (["p%d" % i for i in range(10)], ["p1", "p9"], 0, 0, False),
+    (["p%d" % i for i in range(13)], ["p%d" % i for i in range(13)], 0, 0, True),
+    (["p%d" % i for i in range(16)], ["p3"], 1, 0, False),
 ]
 
 
