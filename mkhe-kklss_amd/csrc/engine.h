@@ -198,6 +198,8 @@ class Context {
     u64* d_psi31n = nullptr;                     // [mall][4][2]: pairs of -psi[1..3] (NttBatch::psi31n)
     u64 *d_psiinv31 = nullptr, *d_inv31c = nullptr;   // inverse twiddles as pairs [mall][N][2]; last-stage constants [mall][8][6] (NttBatch::inv31c)
     unsigned long long small_mods_ = 0;          // bit m set = modulus m has 31 q < 2^62
+    u64* d_psif = nullptr;                       // [mall][N] forward twiddles as doubles, N = 2^16 only (NttBatch::psif)
+    unsigned long long f_mods_ = 0;              // bit m set = modulus m is of the F class (80 q < 2^52)
     std::vector<unsigned char> h16_sched_;       // per modulus: NttBatch::sched
     unsigned long long u_mods_ = 0;              // bit m: modulus m is of the H16 kernel's U class (NttBatch::u_mods)
     u64* d_psi31 = nullptr;                      // logN >= 15: twiddle pairs of the H16 kernel's one-round product (NttBatch::psi31)

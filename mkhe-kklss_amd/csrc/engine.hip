@@ -212,6 +212,24 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
             if (small_q_[i]) small_mods_ |= 1ull << i;
         }
         d_psiinv31 = dev_upload(pi31); d_inv31c = dev_upload(fin);
+        // F class (N = 2^16 only: the quarter sub-transforms behind the radix-4 producers): moduli with 80 q < 2^52 run double-precision butterflies;
+        // their forward twiddles as plain residues in double format (MKHE_H16_FCLASS=0 switches the class off)
+        static const int fclass_on = [] { const char* e = getenv("MKHE_H16_FCLASS"); return (e && *e) ? atoi(e) : 1; }();
+        if (fclass_on && logN == 16) {
+            std::vector<u64> pf((size_t)mall * N, 0);
+            for (int i = 0; i < mall; ++i) {
+                const u64 q = moduli[i];
+                if (!(q < (1ull << 52) / 80)) continue;
+                f_mods_ |= 1ull << i;
+                const u64 rinv = powmod(powmod(2, 64, q), q - 2, q);
+                for (size_t j = 0; j < (size_t)N; ++j) {
+                    const u64 ps = psi[(size_t)i * N + j];
+                    const double w = (double)mulmod(ps - ((u64)((u32)ps >> 31) << 32), rinv, q);      // undo sd_split, leave Montgomery form
+                    std::memcpy(&pf[(size_t)i * N + j], &w, 8);
+                }
+            }
+            if (f_mods_) d_psif = dev_upload(pf);
+        }
         // Reduction schedule of the balanced path for inputs below 2^60 (canonical digits of any modulus): the never-reduced values must stay
         // below 2^62.9 (column sums of mm31) and grow by at most 1.03q per one-round stage (q + |x| q / 2^64) and q/2 + |x|/16 per two-round
         // stage of phase D; a partial reduction leaves |x| <= 0.51q.  Greedy from the load: reduce only where the next phase would overflow.
@@ -394,7 +412,7 @@ Context::~Context() {
 void Context::release_all() noexcept {
     (void)hipSetDevice(device);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
-                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)d_psiinv31, (void*)d_inv31c, (void*)spreadbuf_,
+                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)d_psiinv31, (void*)d_inv31c, (void*)d_psif, (void*)spreadbuf_,
                     (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_tb30, (void*)d_tw30, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
@@ -599,6 +617,7 @@ void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
 void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     NttBatch b = b_in;
     b.psi31 = d_psi31; b.psi31n = d_psi31n; b.u_mods = u_mods_; b.no_h16 = d_psi31 ? 0 : 1;
+    b.psif = d_psif; b.f_mods = f_mods_;
     for (int i = 0; i < mall && i < NTT_MAX_SLOTS; ++i) b.sched[i] = h16_sched_.empty() ? 15 : h16_sched_[i];
     if (ntt16_ok(logN, b)) {
         ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);

@@ -468,7 +468,7 @@ template <int X> __device__ __forceinline__ void exchange(u64 (&x)[16], u32* lds
 
 // ------------------------------------------------------------------ one limb
 // what one limb needs, all wave-uniform
-struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* psi31n; smodptr mp; bool red; bool skip_norm; int root; u64* trace; int sched; };
+struct Job { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* psi31n; smodptr mp; bool red; bool skip_norm; int root; u64* trace; int sched; const u64* psif; };
 // diagnostic build (make trace): shader-clock stamps per wave and pass, 32 words per (job, wave): [16 * pass + k], see tools/ntt16_trace.py
 // (every lane stores the same word: a lane-0 branch here makes the compiler lose the uniformity of the scalar twiddle loads)
 #ifdef MKHE_PHASE_TRACE
@@ -847,6 +847,173 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
     }
 }
 
+// ------------------------------------------------------------------ the F class (round 3): moduli below 2^45.67 in double precision
+// FP64 FMA issues at full rate on CDNA4, the 32 x 32 -> 64 multiply-adds of the integer products at a quarter of it, and a modular product of exact
+// integers held in doubles is an error-free transformation:
+//   h = a w (rounded), l = fma(a, w, -h) (the exact rest), k = rint(h / q) (rounded reciprocal: off by at most 2), r = fma(-k, q, h) (exact: an
+//   integer below 2.5 q), T = r + l = a w - k q exactly, |T| <= 1.02 q in practice  --  6 full-rate instructions + add and subtract.
+// tools/ubench/bflyf64_rate.hip: 38.9 cycles per wave-butterfly at 2.37 GHz = 16.4 ns against 53.8 cycles at 2.11 GHz = 25.5 ns for mm30u (the clock
+// RISES: the kernel runs at the package power cap, and the FP64 pipe draws less than the integer multiplier).  Everything must stay an exact integer
+// below 2^53: inputs below 22.2 q (decomp_spread4_kernel) + 14 stages of growth by at most 2.5 q + the 40 q bias of internal digits < 2^52 holds
+// for 80 q < 2^52 -- the 45-bit primes of PN16QP1761 (33 of its 38 moduli).  Twiddles are PLAIN residues as doubles (NttBatch::psif), values travel
+// through the LDS re-distributions as their bit patterns, u64 <-> double by the 2^52 trick (one OR / AND on the high word, one add).
+__device__ __forceinline__ double u2d(u64 v) { return __builtin_bit_cast(double, v | 0x4330000000000000ull) - 4503599627370496.0; }      // v < 2^52
+__device__ __forceinline__ u64 d2u(double y) { return __builtin_bit_cast(u64, y + 4503599627370496.0) & 0x000fffffffffffffull; }         // 0 <= y < 2^52
+struct FC { double q, qinv; };
+__device__ __forceinline__ void bflyF(u64& U, u64& V, double w, const FC& c) {
+    const double a = __builtin_bit_cast(double, V), u = __builtin_bit_cast(double, U);
+    const double h = a * w;
+    const double l = __builtin_fma(a, w, -h);
+    const double k = __builtin_rint(h * c.qinv);
+    const double r = __builtin_fma(-k, c.q, h);
+    const double T = r + l;
+    U = __builtin_bit_cast(u64, u + T);
+    V = __builtin_bit_cast(u64, u - T);
+}
+template <int B, int G0 = 0, int NG = 8> __device__ __forceinline__ void stageF(u64 (&x)[16], const u64* tw, const FC& c) {
+#pragma unroll
+    for (int g = G0; g < G0 + NG; ++g) {
+        const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+        bflyF(x[i0], x[i0 | (1 << B)], __builtin_bit_cast(double, tw[(g >> B) - (G0 >> B)]), c);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int B> __device__ __forceinline__ void bflyF1(u64 (&x)[16], int g, u64 w, const FC& c) {
+    const int i0 = ((g >> B) << (B + 1)) | (g & ((1 << B) - 1));
+    bflyF(x[i0], x[i0 | (1 << B)], __builtin_bit_cast(double, w), c);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// one quarter (2^14 points, twiddle root jb.root) of an N = 2^16 limb: the forward pass of limb<.., 14> on the products above
+__device__ __forceinline__ void limb_f(const Job& jb, u32* lds, const int wv) {
+    const int tm = jb.root >> 1, ht = jb.root & 1;
+    FC c;
+    {
+        const u64 q = jb.mp->q;
+        c.q = (double)q; c.qinv = 1.0 / (double)q;
+        // (computed on the vector unit from a wave-uniform q: back into scalar registers, so that they are SGPR operands of every product)
+        const u64 qb = __builtin_bit_cast(u64, c.q), ib = __builtin_bit_cast(u64, c.qinv);
+        const u64 qs_ = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)hi32(qb)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)lo32(qb));
+        const u64 is_ = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)hi32(ib)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)lo32(ib));
+        c.q = __builtin_bit_cast(double, qs_); c.qinv = __builtin_bit_cast(double, is_);
+    }
+    scptr pf = (scptr)jb.psif;                                // plain twiddles as doubles, bit-reversed order, rows of the whole limb
+    gcptr pfv = (gcptr)jb.psif;
+    const gcptr src = jb.src; const gptr dst = jb.dst;
+    u64 x[16];
+    {
+        const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
+        u64 lo8[8], hi8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { lo8[r] = ld_issue(sbk(src, r * NT), tb); hi8[r] = ld_issue(sbk(src, (8 + r) * NT), tb); }
+        ld_wait16(lo8, hi8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { x[r] = __builtin_bit_cast(u64, u2d(lo8[r])); x[8 + r] = __builtin_bit_cast(u64, u2d(hi8[r])); }
+    }
+    if (MKHE_H16_PRIO) __builtin_amdgcn_s_setprio(MKHE_H16_PRIO);
+    {
+        u64 tw[8];
+        tw[0] = pf[2 * tm + ht];
+        stageF<3>(x, tw, c);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tw[i] = pf[4 * tm + 2 * ht + i];
+        stageF<2>(x, tw, c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tw[i] = pf[8 * tm + 4 * ht + i];
+        stageF<1>(x, tw, c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tw[i] = pf[16 * tm + 8 * ht + i];
+        stageF<0>(x, tw, c);
+    }
+    exchange<X_AB>(x, lds, wv);
+    if (MKHE_H16_PRIO) __builtin_amdgcn_s_setprio(0);
+    {
+        const int cb = 16 * ht + wv;
+        u64 tw[8];
+        tw[0] = pf[32 * tm + cb];
+        stageF<3>(x, tw, c);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tw[i] = pf[64 * tm + 2 * cb + i];
+        stageF<2>(x, tw, c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tw[i] = pf[128 * tm + 4 * cb + i];
+        stageF<1>(x, tw, c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tw[i] = pf[256 * tm + 8 * cb + i];
+        stageF<0>(x, tw, c);
+    }
+    // phase C: the 15 per-lane twiddles as eight 16-byte groups, in the order {t0}, {1,2}, {3,4}, {5,6}, {7,8} .. {13,14}; three groups in flight
+    {
+        const int lc = lane_id();
+        const unsigned cu = (unsigned)((16 * ht + wv) * 16 + (lc >> 2));
+        __builtin_assume(cu < 512);
+        u64 g[3][2];
+        auto loadt = [&](int G, int slot) {
+            if (G == 0) { g[slot][0] = *at(sbk(pfv, 512 * tm), 8u * cu); g[slot][1] = 0; }
+            else if (G == 1) ld2(g[slot], (gcptr2)sbk(pfv, 1024 * tm), cu);
+            else if (G < 4) ld2(g[slot], (gcptr2)sbk(pfv, 2048 * tm) + (G - 2), 2 * cu);
+            else ld2(g[slot], (gcptr2)sbk(pfv, 4096 * tm) + (G - 4), 4 * cu);
+        };
+        loadt(0, 0); loadt(1, 1);
+        exchange<X_BC>(x, lds, wv);
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            const int gi = n & 7;
+            const int G = n < 8 ? 0 : n < 16 ? 1 : n < 24 ? 2 + (gi >> 2) : 4 + (gi >> 1);
+            const int Gp = n == 0 ? -1 : (n - 1 < 8 ? 0 : n - 1 < 16 ? 1 : n - 1 < 24 ? 2 + (((n - 1) & 7) >> 2) : 4 + (((n - 1) & 7) >> 1));
+            if (G != Gp && G + 2 < 8) loadt(G + 2, (G + 2) % 3);
+            const u64 w = n < 8 ? g[G % 3][0] : n < 16 ? g[G % 3][gi >> 2] : n < 24 ? g[G % 3][(gi >> 1) & 1] : g[G % 3][gi & 1];
+            if (n < 8) bflyF1<3>(x, gi, w, c);
+            else if (n < 16) bflyF1<2>(x, gi, w, c);
+            else if (n < 24) bflyF1<1>(x, gi, w, c);
+            else bflyF1<0>(x, gi, w, c);
+        }
+    }
+    // phase D: psi[2^13 root' + 4 d + i], psi[2^14 root' + 8 d + i] as in the integer pass
+    {
+        const int ld = lane_id();
+        const unsigned du = (unsigned)((16 * ht + wv) * 64 + ld);
+        __builtin_assume(du < 2048);
+        u64 g[6][2];
+        auto loadg = [&](int k) {
+            if (k < 2) ld2(g[k], (gcptr2)sbk(pfv, 8192 * tm) + k, 2 * du);
+            else ld2(g[k], (gcptr2)sbk(pfv, 16384 * tm) + (k - 2), 4 * du);
+        };
+        loadg(0); loadg(1); loadg(2);
+        exchange<X_CD>(x, lds, wv);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            if (n == 4) loadg(3);
+            if (n == 8) loadg(4);
+            if (n == 10) loadg(5);
+            const int gi = n & 7;
+            if (n < 8) bflyF1<1>(x, gi, g[gi >> 2][(gi >> 1) & 1], c);
+            else bflyF1<0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
+        }
+    }
+    // output representative: canonical, or (engine-internal digits) the same residue made positive: |x| < 37 q -> + 40 q
+    if (!jb.skip_norm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double v = __builtin_bit_cast(double, x[r]);
+            double y = __builtin_fma(-__builtin_rint(v * c.qinv), c.q, v);          // |y| <= (q + 1) / 2
+            y = y < 0.0 ? y + c.q : y;
+            x[r] = d2u(y);
+        }
+    } else {
+        const double bias = 40.0 * c.q;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = d2u(__builtin_bit_cast(double, x[r]) + bias);
+    }
+    exchange<X_DE>(x, lds, wv);
+    {
+        const int obase = wv * 1024;
+        const unsigned lb = 8u * (unsigned)lane_id();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_nontemporal_store(x[r], (u64 __attribute__((address_space(1)))*)at(sbk(dst, obase + r * 64), lb));
+    }
+}
+
 // n / d for 0 <= n < 2^16, 2 <= d < 2^16 as ONE scalar multiply-high: magic = floor(2^32 / d) + 1 (host: magic_of), exact in that range;
 // d = 1 has no 32-bit magic (2^32 + 1): magic_of returns 0 for it and the quotient is n itself
 // (the error term n * (magic * d - 2^32) / (d * 2^32) stays below 1 / d)
@@ -947,6 +1114,10 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         }
 #endif
         const int hf = halves ? half_pass : 0, hl = halves ? half_pass : 1;
+        if constexpr (SPLIT && LOGN == 14) {
+            // the quarters of an N = 2^16 limb under a modulus of the F class: double-precision butterflies (limb_f)
+            if (kb->psif && ((kb->f_mods >> m) & 1)) { jb.psif = kb->psif + (long)m * (1 << 16); limb_f(jb, lds, wv); continue; }
+        }
         if ((kb->u_mods >> m) & 1) limb<DEC, SPLIT, true, LOGN>(jb, false, lds, wv, hf, hl);
         else limb<DEC, SPLIT, false, LOGN>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv, hf, hl);
 #ifdef MKHE_PHASE_TRACE

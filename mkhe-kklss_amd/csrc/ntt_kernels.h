@@ -81,6 +81,9 @@ struct NttBatch {
     // inverse launches on ntt14_inv_kernel (ntt16_kernels.hip): psi31 / psi are then the INVERSE tables, and
     const u64* inv31c;      // [nmod][8][6]: entry `root` = the pair of N^-1, the pair of psiinv[root] N^-1 (N = the whole limb; format of the modulus's class), and both in signed-split Montgomery form
     unsigned long long small_mods;   // bit m set = modulus m has 31 q < 2^62 (no 59/60-bit reduction schedule)
+    // the F class (ntt16_kernels.hip limb_f: double-precision butterflies for the quarters of N = 2^16 limbs): bit m set = 80 q < 2^52, and
+    const u64* psif;        // [nmod][N] the forward twiddles as PLAIN residues in double format (bit patterns), bit-reversed order; NULL = class off
+    unsigned long long f_mods;
     struct Lpt { int B, C, r, full, rem; unsigned magic_C; } lpt;
     int no_h16;             // this context has a modulus the H16 kernel's ranges do not cover (48q >= 2^62 > 31q): keep to the other kernels
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
