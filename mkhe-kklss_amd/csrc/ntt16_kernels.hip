@@ -850,12 +850,14 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
 // ------------------------------------------------------------------ the F class (round 3): moduli below 2^45.67 in double precision
 // FP64 FMA issues at full rate on CDNA4, the 32 x 32 -> 64 multiply-adds of the integer products at a quarter of it, and a modular product of exact
 // integers held in doubles is an error-free transformation:
-//   h = a w (rounded), l = fma(a, w, -h) (the exact rest), k = rint(h / q) (rounded reciprocal: off by at most 2), r = fma(-k, q, h) (exact: an
-//   integer below 2.5 q), T = r + l = a w - k q exactly, |T| <= 1.02 q in practice  --  6 full-rate instructions + add and subtract.
+//   h = a w (rounded), l = fma(a, w, -h) (the exact rest), k = rint(h (1/q)) -- three roundings of relative size 2^-53 on a quotient below 2^51:
+//   within 0.75 of a w / q before the rint --, r = fma(-k, q, h) (exact), T = r + l = a w - k q exactly, |T| <= 1.25 q (1.02 q observed)
+//   --  6 full-rate instructions + add and subtract.
 // tools/ubench/bflyf64_rate.hip: 38.9 cycles per wave-butterfly at 2.37 GHz = 16.4 ns against 53.8 cycles at 2.11 GHz = 25.5 ns for mm30u (the clock
 // RISES: the kernel runs at the package power cap, and the FP64 pipe draws less than the integer multiplier).  Everything must stay an exact integer
-// below 2^53: inputs below 22.2 q (decomp_spread4_kernel) + 14 stages of growth by at most 2.5 q + the 40 q bias of internal digits < 2^52 holds
-// for 80 q < 2^52 -- the 45-bit primes of PN16QP1761 (33 of its 38 moduli).  Twiddles are PLAIN residues as doubles (NttBatch::psif), values travel
+// below 2^53 (and data words below 2^51 for the bound above): inputs in [0, 22.2 q) (decomp_spread4_kernel; < 4 q behind ntt_pass4_fwd_kernel), 14
+// stages of growth by at most 1.25 q: x in (-17.5 q, 39.7 q), and the 40 q bias of internal digits: (22.5 q, 79.7 q) -- 80 q < 2^52 is the class,
+// the 45-bit primes of PN16QP1761 (33 of its 38 moduli).  Twiddles are PLAIN residues as doubles (NttBatch::psif), values travel
 // through the LDS re-distributions as their bit patterns, u64 <-> double by the 2^52 trick (one OR / AND on the high word, one add).
 __device__ __forceinline__ double u2d(u64 v) { return __builtin_bit_cast(double, v | 0x4330000000000000ull) - 4503599627370496.0; }      // v < 2^52
 __device__ __forceinline__ u64 d2u(double y) { return __builtin_bit_cast(u64, y + 4503599627370496.0) & 0x000fffffffffffffull; }         // 0 <= y < 2^52
@@ -990,7 +992,7 @@ __device__ __forceinline__ void limb_f(const Job& jb, u32* lds, const int wv) {
             else bflyF1<0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
         }
     }
-    // output representative: canonical, or (engine-internal digits) the same residue made positive: |x| < 37 q -> + 40 q
+    // output representative: canonical, or (engine-internal digits) the same residue made positive: x in (-17.5 q, 39.7 q) -> + 40 q
     if (!jb.skip_norm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
