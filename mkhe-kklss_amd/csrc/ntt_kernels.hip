@@ -518,15 +518,20 @@ __device__ __forceinline__ int sm_pad(int p) { return p + ((p >> 4) << 1); }    
 // MODE 0 / 1: forward (Harvey / signed never-reduced), 2: inverse (stages in descending order).
 // FIN 1: forward normalisation on the way out (canonical, or +16q when skip_norm); FIN 2: inverse, times N^-1.
 // nsum > 1 (first inverse phase of a merged launch, NttBatch::vi): the input is the canonical sum of nsum limbs, gsrc + sum_off[k].
-template <int S0, int NB, bool FROM_G, bool TO_G, int MODE, int FIN>
+// LOGM: log2 of the sub-transform.  13: 1024 threads x 8 coefficients (N = 2^15: four per limb behind the radix-4 pass).  12 (round 3): 512 threads
+// x 8 coefficients, 36 KB of LDS -- N = 2^14 limbs as FOUR sub-transforms behind the radix-4 pass instead of two of 2^13 points behind a radix-2
+// pass: the launches of that ring (PN14QP439, the cnn) are a few dozen limbs, a kernel lasts as long as ONE workgroup, and a workgroup of half
+// the size with half the work finishes sooner on twice as many CUs.
+template <int LOGM> struct SmGeo { static constexpr int T = LOGM == 12 ? 512 : SM_T, E = (1 << LOGM) / T, LDSW = (1 << LOGM) + (1 << (LOGM - 3)); };
+template <int S0, int NB, bool FROM_G, bool TO_G, int MODE, int FIN, int LOGM = SM_LOGM>
 __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr psi, int root, int t, const Mod& md, u64 fin_c, int skip_norm,
                                          int nsum = 1, const long* sum_off = nullptr) {
-    constexpr int LGL = SM_LOGM - S0 - NB, GL = 1 << LGL, UPT = SM_E >> NB, NE = 1 << NB;
+    constexpr int LGL = LOGM - S0 - NB, GL = 1 << LGL, UPT = SmGeo<LOGM>::E >> NB, NE = 1 << NB;
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
 #pragma unroll
     for (int k = 0; k < UPT; ++k) {
-        const int u = k * SM_T + t;
+        const int u = k * SmGeo<LOGM>::T + t;
         const int low = u & (GL - 1), high = u >> LGL;
         const int p = (high << (LGL + NB)) | low;
         u64 x[NE];
@@ -567,25 +572,30 @@ __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr 
     }
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(SM_T) ntt_fwd_lds_kernel(NttBatch b, int d) {
+template <int MODE, int LOGM = SM_LOGM>
+__global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_fwd_lds_kernel(NttBatch b, int d) {
     extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
+    constexpr int M = 1 << LOGM;
     const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
     gcptr src; gptr dst; int m, outer;
     job_pointers(b, job >> d, src, dst, m, outer);
-    src += part * SM_M; dst += part * SM_M;
+    src += part * M; dst += part * M;
     const int root = (1 << d) + part;
     const Mod md = b.mods[m];
-    gcptr psi = (gcptr)(b.psi + ((long)m * SM_M << d));
-    sm_phase<0, 3, true, false, MODE, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    gcptr psi = (gcptr)(b.psi + ((long)m * M << d));
+    sm_phase<0, 3, true, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
     __syncthreads();
-    sm_phase<3, 3, false, false, MODE, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    sm_phase<3, 3, false, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
     __syncthreads();
-    sm_phase<6, 3, false, false, MODE, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    sm_phase<6, 3, false, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
     __syncthreads();
-    sm_phase<9, 3, false, false, MODE, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
-    __syncthreads();
-    sm_phase<12, 1, false, true, MODE, 1>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
+    if constexpr (LOGM == 13) {
+        sm_phase<9, 3, false, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+        __syncthreads();
+        sm_phase<12, 1, false, true, MODE, 1, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
+    } else {
+        sm_phase<9, 3, false, true, MODE, 1, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
+    }
 }
 
 // (8 waves per SIMD = two workgroups per CU: the merged E / F2 launch of a 4-party MulRelin has 376 sub-transforms for 256 CUs;
@@ -613,6 +623,31 @@ __global__ void __launch_bounds__(SM_T) __attribute__((amdgpu_waves_per_eu(8, 8)
     sm_phase<3, 3, false, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
     __syncthreads();
     sm_phase<0, 3, false, true, 2, 2>(src, dst, sm_lds, psi, root, t, md, ninvR, 0);
+}
+
+// the 2^12-point inverse sub-transforms (see SmGeo): four phases of three stages, 512 threads
+__global__ void __launch_bounds__(512) ntt_inv_lds12_kernel(NttBatch b, int d) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
+    constexpr int M = 1 << 12;
+    const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
+    gcptr src; gptr dst; int m, outer;
+    const int nsum = job_pointers<true>(b, job >> d, src, dst, m, outer);
+    if (nsum == 0) return;
+    long sum_off[VI_MAX + 1] = {};
+#pragma unroll
+    for (int k = 1; k <= VI_MAX; ++k) if (k < nsum) sum_off[k] = vi_member_offset(b, outer, k, m, src);
+    src += part * M; dst += part * M;
+    const int root = (1 << d) + part;
+    const Mod md = b.mods[m];
+    gcptr psi = (gcptr)(b.psi + ((long)m * M << d));
+    const u64 ninvR = b.aux[6 * m];
+    sm_phase<9, 3, true, false, 2, 0, 12>(src, dst, sm_lds, psi, root, t, md, 0, 0, nsum, sum_off);
+    __syncthreads();
+    sm_phase<6, 3, false, false, 2, 0, 12>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<3, 3, false, false, 2, 0, 12>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    __syncthreads();
+    sm_phase<0, 3, false, true, 2, 2, 12>(src, dst, sm_lds, psi, root, t, md, ninvR, 0);
 }
 
 // cross-block radix-2 passes below the first one (level L >= 1: blocks of N >> L coefficients, twiddle index 2^L + block),
@@ -824,6 +859,20 @@ static int lds_depth(int logN, const NttBatch& b) {
             ls.attr[dev] = true;
         }
     }
+    static const int lds12 = env_int("MKHE_NTT_LDS12", 1);       // N = 2^14: four 2^12-point sub-transforms per limb (0: two of 2^13 points)
+    if (lds12 && logN == 14) {
+        static LaunchState ls12;
+        const int dev = current_device();
+        std::lock_guard<std::mutex> g(ls12.mu);
+        if (!ls12.attr[dev]) {
+            const int lds = SmGeo<12>::LDSW * (int)sizeof(u64);
+            (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<0, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)ntt_inv_lds12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            ls12.attr[dev] = true;
+        }
+        return 2;
+    }
     return logN - SM_LOGM;
 }
 bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q) {
@@ -906,6 +955,12 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
         if (d) {
             for (int L = 1; L < d && d != 2; ++L) hipLaunchKernelGGL(ntt_pass_fwd_kernel, grid, dim3(SPLIT_THREADS), 0, st, c, logN, L);
             const int jobs = (b.nslots * b.nouter) << d;
+            if (logN - d == 12) {
+                const size_t lds = SmGeo<12>::LDSW * sizeof(u64);
+                if (small) hipLaunchKernelGGL((ntt_fwd_lds_kernel<1, 12>), dim3(jobs), dim3(512), lds, st, c, d);
+                else hipLaunchKernelGGL((ntt_fwd_lds_kernel<0, 12>), dim3(jobs), dim3(512), lds, st, c, d);
+                return;
+            }
             const size_t lds = SM_LDS_WORDS * sizeof(u64);
             if (small) hipLaunchKernelGGL(ntt_fwd_lds_kernel<1>, dim3(jobs), dim3(SM_T), lds, st, c, d);
             else hipLaunchKernelGGL(ntt_fwd_lds_kernel<0>, dim3(jobs), dim3(SM_T), lds, st, c, d);
@@ -936,6 +991,8 @@ void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
     if (!b.split && use_split(logN, b)) {
         if (const int d = lds_depth(logN, b)) {
             const int jobs = (b.nslots * b.nouter) << d;
+            if (logN - d == 12) hipLaunchKernelGGL(ntt_inv_lds12_kernel, dim3(jobs), dim3(512), SmGeo<12>::LDSW * sizeof(u64), st, b, d);
+            else
             hipLaunchKernelGGL(ntt_inv_lds_kernel, dim3(jobs), dim3(SM_T), SM_LDS_WORDS * sizeof(u64), st, b, d);     // src -> dst, [0,2q), N^-1 folded in
             const NttBatch ip = in_place_of_dst(b);
             const dim3 grid(32, b.nslots * b.nouter);
