@@ -742,6 +742,83 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass4_inv_kernel(NttBatch b
     }
 }
 
+// The THREE outermost stages in one streaming pass (round 3; small launches at N = 2^15: eight 2^12-point sub-transforms per limb): every thread owns
+// the coefficients j + k N/8, k = 0..7.  Forward: src -> dst (optionally with the Decompose reduction), values < 4q out; inverse: in place on dst,
+// [0,2q) in (N^-1 folded in by the sub-transforms), canonical or lazy out.  Sub-transform p occupies words [p N/8, (p + 1) N/8), twiddle root 8 + p.
+template <bool DEC>
+__global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass8_fwd_kernel(NttBatch b, int logN) {
+    const int N = 1 << logN, E = N >> 3;
+    gcptr src; gptr dst; int m, outer;
+    job_pointers(b, blockIdx.y, src, dst, m, outer);
+    const Mod md = b.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    u64 w[8];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) w[i] = b.psi[(long)m * N + i];
+    bool red = false;
+    if constexpr (DEC) {
+        int sm = m;
+        if (b.reduce_src_mod_is_outer == 1) sm = outer;
+        else if (b.reduce_src_mod_is_outer == 2) sm = ((kargptr)__builtin_amdgcn_kernarg_segment_ptr())->outer_mod[outer];
+        const u64 qs = b.mods[sm].q << (b.src_lazy ? 2 : 0);
+        red = qs > 4 * q;
+    }
+    auto bf = [&](u64& x, u64& y, u64 tw) {
+        const u64 U = csub(x, q2), T = mont_mul_sdu(y, tw, md.qs, q, ninv);
+        x = U + T; y = U + (q2 - T);
+    };
+    for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < E; j += gridDim.x * SPLIT_THREADS) {
+        u64 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = src[j + k * E];
+        if (red) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = mont_mul_sdu(a[k], md.r1s, md.qs, q, ninv);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bf(a[k], a[k + 4], w[1]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) bf(a[4 * h + k], a[4 * h + k + 2], w[2 + h]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bf(a[2 * c], a[2 * c + 1], w[4 + c]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[j + k * E] = a[k];
+    }
+}
+__global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass8_inv_kernel(NttBatch b, int logN) {
+    const int N = 1 << logN, E = N >> 3;
+    gcptr src; gptr dst; int m, outer;
+    if (!job_pointers<true>(b, blockIdx.y, src, dst, m, outer)) return;
+    const Mod md = b.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    u64 w[8];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) w[i] = b.psi[(long)m * N + i];
+    auto gs = [&](u64& x, u64& y, u64 tw) {
+        const u64 s_ = csub(x + y, q2), d_ = mont_mul_sdu(x + q2 - y, tw, md.qs, q, ninv);
+        x = s_; y = d_;
+    };
+    for (int j = blockIdx.x * SPLIT_THREADS + threadIdx.x; j < E; j += gridDim.x * SPLIT_THREADS) {
+        u64 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = dst[j + k * E];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gs(a[2 * c], a[2 * c + 1], w[4 + c]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) gs(a[4 * h + k], a[4 * h + k + 2], w[2 + h]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gs(a[k], a[k + 4], w[1]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[j + k * E] = b.lazy_out ? a[k] : csub(a[k], q);
+    }
+}
+
 static NttBatch in_place_of_dst(const NttBatch& b) {
     NttBatch c = b;
     c.src = b.dst; c.src_outer = b.dst_outer; c.src_inner = b.dst_inner; c.src_mapped = b.dst_mapped;
@@ -860,7 +937,8 @@ static int lds_depth(int logN, const NttBatch& b) {
         }
     }
     static const int lds12 = env_int("MKHE_NTT_LDS12", 1);       // N = 2^14: four 2^12-point sub-transforms per limb (0: two of 2^13 points)
-    if (lds12 && logN == 14) {
+    static const int lds12_15 = env_int("MKHE_NTT_LDS12_15", 1);       // N = 2^15: eight 2^12-point sub-transforms behind the radix-8 pass (0: four of 2^13)
+    if (lds12 && (logN == 14 || (logN == 15 && lds12_15))) {
         static LaunchState ls12;
         const int dev = current_device();
         std::lock_guard<std::mutex> g(ls12.mu);
@@ -871,7 +949,7 @@ static int lds_depth(int logN, const NttBatch& b) {
             (void)hipFuncSetAttribute((const void*)ntt_inv_lds12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             ls12.attr[dev] = true;
         }
-        return 2;
+        return logN - 12;
     }
     return logN - SM_LOGM;
 }
@@ -938,6 +1016,10 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
         const dim3 grid(32, b.nslots * b.nouter);
         const int d = lds_depth(logN, b);
         if (b.prestaged) { /* first stage done by the producer */ }
+        else if (d == 3) {
+            if (b.reduce_in) hipLaunchKernelGGL(ntt_pass8_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+            else hipLaunchKernelGGL(ntt_pass8_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+        }
         else if (d == 2) {
             if (b.reduce_in) hipLaunchKernelGGL(ntt_pass4_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
             else hipLaunchKernelGGL(ntt_pass4_fwd_kernel<false>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
@@ -953,7 +1035,7 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
             else throw std::runtime_error("mkhe: internal: out-of-place prestaged launch outside the H16 path");
         }
         if (d) {
-            for (int L = 1; L < d && d != 2; ++L) hipLaunchKernelGGL(ntt_pass_fwd_kernel, grid, dim3(SPLIT_THREADS), 0, st, c, logN, L);
+            for (int L = 1; L < d && d != 2 && d != 3; ++L) hipLaunchKernelGGL(ntt_pass_fwd_kernel, grid, dim3(SPLIT_THREADS), 0, st, c, logN, L);
             const int jobs = (b.nslots * b.nouter) << d;
             if (logN - d == 12) {
                 const size_t lds = SmGeo<12>::LDSW * sizeof(u64);
@@ -997,6 +1079,7 @@ void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
             const NttBatch ip = in_place_of_dst(b);
             const dim3 grid(32, b.nslots * b.nouter);
             NttBatch e = ip; e.lazy_out = b.lazy_out; e.psi = b.psi;
+            if (d == 3) { hipLaunchKernelGGL(ntt_pass8_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, e, logN); return; }
             if (d == 2) { hipLaunchKernelGGL(ntt_pass4_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, e, logN); return; }
             for (int L = d - 1; L >= 1; --L) hipLaunchKernelGGL(ntt_pass_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, ip, logN, L);
             hipLaunchKernelGGL(ntt_split_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, e, logN);
