@@ -522,7 +522,7 @@ __device__ __forceinline__ int sm_pad(int p) { return p + ((p >> 4) << 1); }    
 // x 8 coefficients, 36 KB of LDS -- N = 2^14 limbs as FOUR sub-transforms behind the radix-4 pass instead of two of 2^13 points behind a radix-2
 // pass: the launches of that ring (PN14QP439, the cnn) are a few dozen limbs, a kernel lasts as long as ONE workgroup, and a workgroup of half
 // the size with half the work finishes sooner on twice as many CUs.
-template <int LOGM> struct SmGeo { static constexpr int T = LOGM == 12 ? 512 : SM_T, E = (1 << LOGM) / T, LDSW = (1 << LOGM) + (1 << (LOGM - 3)); };
+template <int LOGM> struct SmGeo { static constexpr int T = LOGM == 11 ? 256 : LOGM == 12 ? 512 : SM_T, E = (1 << LOGM) / T, LDSW = (1 << LOGM) + (1 << (LOGM - 3)); };
 template <int S0, int NB, bool FROM_G, bool TO_G, int MODE, int FIN, int LOGM = SM_LOGM>
 __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr psi, int root, int t, const Mod& md, u64 fin_c, int skip_norm,
                                          int nsum = 1, const long* sum_off = nullptr) {
@@ -593,8 +593,10 @@ __global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_fwd_lds_kernel(NttBatch b,
         sm_phase<9, 3, false, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
         __syncthreads();
         sm_phase<12, 1, false, true, MODE, 1, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
-    } else {
+    } else if constexpr (LOGM == 12) {
         sm_phase<9, 3, false, true, MODE, 1, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
+    } else {
+        sm_phase<9, 2, false, true, MODE, 1, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
     }
 }
 
@@ -625,10 +627,11 @@ __global__ void __launch_bounds__(SM_T) __attribute__((amdgpu_waves_per_eu(8, 8)
     sm_phase<0, 3, false, true, 2, 2>(src, dst, sm_lds, psi, root, t, md, ninvR, 0);
 }
 
-// the 2^12-point inverse sub-transforms (see SmGeo): four phases of three stages, 512 threads
-__global__ void __launch_bounds__(512) ntt_inv_lds12_kernel(NttBatch b, int d) {
+// the 2^12- and 2^11-point inverse sub-transforms (see SmGeo): four phases, 512 / 256 threads
+template <int LOGM>
+__global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_inv_ldsS_kernel(NttBatch b, int d) {
     extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
-    constexpr int M = 1 << 12;
+    constexpr int M = 1 << LOGM;
     const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
     gcptr src; gptr dst; int m, outer;
     const int nsum = job_pointers<true>(b, job >> d, src, dst, m, outer);
@@ -641,13 +644,14 @@ __global__ void __launch_bounds__(512) ntt_inv_lds12_kernel(NttBatch b, int d) {
     const Mod md = b.mods[m];
     gcptr psi = (gcptr)(b.psi + ((long)m * M << d));
     const u64 ninvR = b.aux[6 * m];
-    sm_phase<9, 3, true, false, 2, 0, 12>(src, dst, sm_lds, psi, root, t, md, 0, 0, nsum, sum_off);
+    if constexpr (LOGM == 12) sm_phase<9, 3, true, false, 2, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0, nsum, sum_off);
+    else sm_phase<9, 2, true, false, 2, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0, nsum, sum_off);
     __syncthreads();
-    sm_phase<6, 3, false, false, 2, 0, 12>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    sm_phase<6, 3, false, false, 2, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
     __syncthreads();
-    sm_phase<3, 3, false, false, 2, 0, 12>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    sm_phase<3, 3, false, false, 2, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
     __syncthreads();
-    sm_phase<0, 3, false, true, 2, 2, 12>(src, dst, sm_lds, psi, root, t, md, ninvR, 0);
+    sm_phase<0, 3, false, true, 2, 2, LOGM>(src, dst, sm_lds, psi, root, t, md, ninvR, 0);
 }
 
 // cross-block radix-2 passes below the first one (level L >= 1: blocks of N >> L coefficients, twiddle index 2^L + block),
@@ -946,9 +950,13 @@ static int lds_depth(int logN, const NttBatch& b) {
             const int lds = SmGeo<12>::LDSW * (int)sizeof(u64);
             (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<0, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<1, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)ntt_inv_lds12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)ntt_inv_ldsS_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             ls12.attr[dev] = true;
         }
+        // N = 2^14 launches that would not even give every CU one 2^12-point workgroup: eight 2^11-point sub-transforms per limb (256 threads)
+        static const int lds11 = env_int("MKHE_NTT_LDS11", 1);
+        const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;
+        if (lds11 && logN == 14 && limbs * 4 < 256) return 3;
         return logN - 12;
     }
     return logN - SM_LOGM;
@@ -1043,6 +1051,12 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
                 else hipLaunchKernelGGL((ntt_fwd_lds_kernel<0, 12>), dim3(jobs), dim3(512), lds, st, c, d);
                 return;
             }
+            if (logN - d == 11) {
+                const size_t lds = SmGeo<11>::LDSW * sizeof(u64);            // (18 KB: below the default dynamic-LDS limit, no attribute needed)
+                if (small) hipLaunchKernelGGL((ntt_fwd_lds_kernel<1, 11>), dim3(jobs), dim3(256), lds, st, c, d);
+                else hipLaunchKernelGGL((ntt_fwd_lds_kernel<0, 11>), dim3(jobs), dim3(256), lds, st, c, d);
+                return;
+            }
             const size_t lds = SM_LDS_WORDS * sizeof(u64);
             if (small) hipLaunchKernelGGL(ntt_fwd_lds_kernel<1>, dim3(jobs), dim3(SM_T), lds, st, c, d);
             else hipLaunchKernelGGL(ntt_fwd_lds_kernel<0>, dim3(jobs), dim3(SM_T), lds, st, c, d);
@@ -1073,7 +1087,8 @@ void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
     if (!b.split && use_split(logN, b)) {
         if (const int d = lds_depth(logN, b)) {
             const int jobs = (b.nslots * b.nouter) << d;
-            if (logN - d == 12) hipLaunchKernelGGL(ntt_inv_lds12_kernel, dim3(jobs), dim3(512), SmGeo<12>::LDSW * sizeof(u64), st, b, d);
+            if (logN - d == 12) hipLaunchKernelGGL(ntt_inv_ldsS_kernel<12>, dim3(jobs), dim3(512), SmGeo<12>::LDSW * sizeof(u64), st, b, d);
+            else if (logN - d == 11) hipLaunchKernelGGL(ntt_inv_ldsS_kernel<11>, dim3(jobs), dim3(256), SmGeo<11>::LDSW * sizeof(u64), st, b, d);
             else
             hipLaunchKernelGGL(ntt_inv_lds_kernel, dim3(jobs), dim3(SM_T), SM_LDS_WORDS * sizeof(u64), st, b, d);     // src -> dst, [0,2q), N^-1 folded in
             const NttBatch ip = in_place_of_dst(b);
