@@ -523,9 +523,24 @@ __device__ __forceinline__ int sm_pad(int p) { return p + ((p >> 4) << 1); }    
 // pass: the launches of that ring (PN14QP439, the cnn) are a few dozen limbs, a kernel lasts as long as ONE workgroup, and a workgroup of half
 // the size with half the work finishes sooner on twice as many CUs.
 template <int LOGM> struct SmGeo { static constexpr int T = LOGM == 11 ? 256 : LOGM == 12 ? 512 : SM_T, E = (1 << LOGM) / T, LDSW = (1 << LOGM) + (1 << (LOGM - 3)); };
-template <int S0, int NB, bool FROM_G, bool TO_G, int MODE, int FIN, int LOGM = SM_LOGM>
+// PRE (the 2^12- and 2^11-point kernels): the twiddles of ALL phases were requested at the start of the kernel (sm_tw_load: they do not depend on
+// the data; 28 words per thread), so that a phase does not begin with a global round trip behind its barrier -- these kernels last as long as one
+// workgroup, and a workgroup's time is its phase structure, not its instruction count.
+template <int S0, int NB, int LOGM>
+__device__ __forceinline__ void sm_tw_load(gcptr psi, int root, int t, u64* tw) {
+    constexpr int LGL = LOGM - S0 - NB, UPT = SmGeo<LOGM>::E >> NB, NE = 1 << NB;
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) {
+        const int high = (k * SmGeo<LOGM>::T + t) >> LGL;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < (1 << i); ++j) tw[k * (NE - 1) + (1 << i) - 1 + j] = psi[(root << (S0 + i)) + (high << i) + j];
+    }
+}
+template <int S0, int NB, bool FROM_G, bool TO_G, int MODE, int FIN, int LOGM = SM_LOGM, bool PRE = false>
 __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr psi, int root, int t, const Mod& md, u64 fin_c, int skip_norm,
-                                         int nsum = 1, const long* sum_off = nullptr) {
+                                         int nsum = 1, const long* sum_off = nullptr, const u64* tw = nullptr) {
     constexpr int LGL = LOGM - S0 - NB, GL = 1 << LGL, UPT = SmGeo<LOGM>::E >> NB, NE = 1 << NB;
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
@@ -552,7 +567,7 @@ __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr 
 #pragma unroll
             for (int a = 0; a < NE; ++a) {
                 if (a & half) continue;
-                const u64 w = psi[(root << (S0 + i)) + (high << i) + (a >> (NB - i))];
+                const u64 w = PRE ? tw[k * (NE - 1) + (1 << i) - 1 + (a >> (NB - i))] : psi[(root << (S0 + i)) + (high << i) + (a >> (NB - i))];
                 if constexpr (MODE == 2) bfly_inv(x[a], x[a + half], w, q, q2, md.qs, ninv);
                 else if constexpr (MODE == 1) bfly_fwd_nr(x[a], x[a + half], w, md.qs, ninv);
                 else bfly_fwd_cs(x[a], x[a + half], w, q, q2, md.qs, ninv);
@@ -583,20 +598,28 @@ __global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_fwd_lds_kernel(NttBatch b,
     const int root = (1 << d) + part;
     const Mod md = b.mods[m];
     gcptr psi = (gcptr)(b.psi + ((long)m * M << d));
-    sm_phase<0, 3, true, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
-    __syncthreads();
-    sm_phase<3, 3, false, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
-    __syncthreads();
-    sm_phase<6, 3, false, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
-    __syncthreads();
-    if constexpr (LOGM == 13) {
+    if constexpr (LOGM <= 12) {
+        constexpr int NBL = LOGM == 12 ? 3 : 2, NL = (SmGeo<LOGM>::E >> NBL) * ((1 << NBL) - 1);
+        u64 t0[7], t1[7], t2[7], t3[NL];
+        sm_tw_load<0, 3, LOGM>(psi, root, t, t0); sm_tw_load<3, 3, LOGM>(psi, root, t, t1);
+        sm_tw_load<6, 3, LOGM>(psi, root, t, t2); sm_tw_load<9, NBL, LOGM>(psi, root, t, t3);
+        sm_phase<0, 3, true, false, MODE, 0, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, 0, 1, nullptr, t0);
+        __syncthreads();
+        sm_phase<3, 3, false, false, MODE, 0, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, 0, 1, nullptr, t1);
+        __syncthreads();
+        sm_phase<6, 3, false, false, MODE, 0, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, 0, 1, nullptr, t2);
+        __syncthreads();
+        sm_phase<9, NBL, false, true, MODE, 1, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm, 1, nullptr, t3);
+    } else {
+        sm_phase<0, 3, true, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+        __syncthreads();
+        sm_phase<3, 3, false, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+        __syncthreads();
+        sm_phase<6, 3, false, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+        __syncthreads();
         sm_phase<9, 3, false, false, MODE, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
         __syncthreads();
         sm_phase<12, 1, false, true, MODE, 1, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
-    } else if constexpr (LOGM == 12) {
-        sm_phase<9, 3, false, true, MODE, 1, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
-    } else {
-        sm_phase<9, 2, false, true, MODE, 1, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
     }
 }
 
@@ -644,14 +667,17 @@ __global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_inv_ldsS_kernel(NttBatch b
     const Mod md = b.mods[m];
     gcptr psi = (gcptr)(b.psi + ((long)m * M << d));
     const u64 ninvR = b.aux[6 * m];
-    if constexpr (LOGM == 12) sm_phase<9, 3, true, false, 2, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0, nsum, sum_off);
-    else sm_phase<9, 2, true, false, 2, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0, nsum, sum_off);
+    constexpr int NBL = LOGM == 12 ? 3 : 2, NL = (SmGeo<LOGM>::E >> NBL) * ((1 << NBL) - 1);
+    u64 t0[7], t1[7], t2[7], t3[NL];
+    sm_tw_load<9, NBL, LOGM>(psi, root, t, t3); sm_tw_load<6, 3, LOGM>(psi, root, t, t2);
+    sm_tw_load<3, 3, LOGM>(psi, root, t, t1); sm_tw_load<0, 3, LOGM>(psi, root, t, t0);
+    sm_phase<9, NBL, true, false, 2, 0, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, 0, nsum, sum_off, t3);
     __syncthreads();
-    sm_phase<6, 3, false, false, 2, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    sm_phase<6, 3, false, false, 2, 0, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, 0, 1, nullptr, t2);
     __syncthreads();
-    sm_phase<3, 3, false, false, 2, 0, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, 0);
+    sm_phase<3, 3, false, false, 2, 0, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, 0, 1, nullptr, t1);
     __syncthreads();
-    sm_phase<0, 3, false, true, 2, 2, LOGM>(src, dst, sm_lds, psi, root, t, md, ninvR, 0);
+    sm_phase<0, 3, false, true, 2, 2, LOGM, true>(src, dst, sm_lds, psi, root, t, md, ninvR, 0, 1, nullptr, t0);
 }
 
 // cross-block radix-2 passes below the first one (level L >= 1: blocks of N >> L coefficients, twiddle index 2^L + block),
