@@ -909,7 +909,7 @@ __device__ __forceinline__ void limb_f(const Job& jb, u32* lds, const int wv) {
         for (int r = 0; r < 8; ++r) { lo8[r] = ld_issue(sbk(src, r * NT), tb); hi8[r] = ld_issue(sbk(src, (8 + r) * NT), tb); }
         ld_wait16(lo8, hi8);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { x[r] = __builtin_bit_cast(u64, u2d(lo8[r])); x[8 + r] = __builtin_bit_cast(u64, u2d(hi8[r])); }
+        for (int r = 0; r < 8; ++r) { x[r] = __builtin_bit_cast(u64, u2d(lo8[r])); x[8 + r] = __builtin_bit_cast(u64, u2d(hi8[r])); __builtin_amdgcn_sched_barrier(0); }
     }
     if (MKHE_H16_PRIO) __builtin_amdgcn_s_setprio(MKHE_H16_PRIO);
     {
@@ -975,36 +975,34 @@ __device__ __forceinline__ void limb_f(const Job& jb, u32* lds, const int wv) {
         const int ld = lane_id();
         const unsigned du = (unsigned)((16 * ht + wv) * 64 + ld);
         __builtin_assume(du < 2048);
-        u64 g[6][2];
-        auto loadg = [&](int k) {
-            if (k < 2) ld2(g[k], (gcptr2)sbk(pfv, 8192 * tm) + k, 2 * du);
-            else ld2(g[k], (gcptr2)sbk(pfv, 16384 * tm) + (k - 2), 4 * du);
+        // (a ring of three 16-byte groups, as in phase C: with all six groups named the allocator spilled ten registers around this phase)
+        u64 g[3][2];
+        auto loadg = [&](int G, int slot) {
+            if (G < 2) ld2(g[slot], (gcptr2)sbk(pfv, 8192 * tm) + G, 2 * du);
+            else ld2(g[slot], (gcptr2)sbk(pfv, 16384 * tm) + (G - 2), 4 * du);
         };
-        loadg(0); loadg(1); loadg(2);
+        loadg(0, 0);
         exchange<X_CD>(x, lds, wv);
+        loadg(1, 1);
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
-            if (n == 4) loadg(3);
-            if (n == 8) loadg(4);
-            if (n == 10) loadg(5);
             const int gi = n & 7;
-            if (n < 8) bflyF1<1>(x, gi, g[gi >> 2][(gi >> 1) & 1], c);
-            else bflyF1<0>(x, gi, g[2 + (gi >> 1)][gi & 1], c);
+            const int G = n < 8 ? (gi >> 2) : 2 + (gi >> 1);
+            const int Gp = n == 0 ? -1 : (n - 1 < 8 ? (((n - 1) & 7) >> 2) : 2 + (((n - 1) & 7) >> 1));
+            if (G != Gp && G + 2 < 6) loadg(G + 2, (G + 2) % 3);
+            if (n < 8) bflyF1<1>(x, gi, g[G % 3][(gi >> 1) & 1], c);
+            else bflyF1<0>(x, gi, g[G % 3][gi & 1], c);
         }
     }
-    // output representative: canonical, or (engine-internal digits) the same residue made positive: x in (-17.5 q, 39.7 q) -> + 40 q
-    if (!jb.skip_norm) {
+    // output representative: always canonical (a valid positive representative for the engine-internal digits too: in double precision the
+    // reduction is four instructions more than adding a bias, and one code path instead of two keeps the pass within its 64 registers)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const double v = __builtin_bit_cast(double, x[r]);
-            double y = __builtin_fma(-__builtin_rint(v * c.qinv), c.q, v);          // |y| <= (q + 1) / 2
-            y = y < 0.0 ? y + c.q : y;
-            x[r] = d2u(y);
-        }
-    } else {
-        const double bias = 40.0 * c.q;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = d2u(__builtin_bit_cast(double, x[r]) + bias);
+    for (int r = 0; r < 16; ++r) {
+        const double v = __builtin_bit_cast(double, x[r]);
+        double y = __builtin_fma(-__builtin_rint(v * c.qinv), c.q, v);          // |y| <= (q + 1) / 2
+        y = y < 0.0 ? y + c.q : y;
+        x[r] = d2u(y);
+        __builtin_amdgcn_sched_barrier(0);                                        // (one value at a time: interleaved, their temporaries spill)
     }
     exchange<X_DE>(x, lds, wv);
     {
