@@ -104,7 +104,7 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
   {C.get("mulrelin_per_sec_steady_state", 0):.0f}/s, two MulRelin in flight through forked contexts {C.get("mulrelin_per_sec_two_in_flight", 0):.0f}/s.
 * under `rocprofv3 --kernel-trace`, overlap off: {no["value"]:.0f} MulRelin/s ({no["ms_per_step"]:.3f} ms); overlap on: {ov["value"]:.0f} MulRelin/s ({ov["ms_per_step"]:.3f} ms).
 * **Box to box** the figures move by ± 2 % with the clock a part sustains at the 1400 W cap: the same kernel, default `bench.py`, on the boxes gpurun dealt on the last day of the round gave
-  1185 MulRelin/s / `roofline.frac` 0.498 (2.09 GHz under the NTT kernel), 1197 / 0.496 (2.13 GHz), 1212 / 0.510 (2.16 GHz), 1199 / 0.512 (2.14 GHz), 1216 / 0.515, 1206 / 0.501, 1217 / 0.510, 1175 / 0.494, 1232 / 0.520 and 1209 / 0.502 (this set; the last two with the smaller LDS sub-transforms of the small launches); on the third box the library of the commit before ran
+  1185 MulRelin/s / `roofline.frac` 0.498 (2.09 GHz under the NTT kernel), 1197 / 0.496 (2.13 GHz), 1212 / 0.510 (2.16 GHz), 1199 / 0.512 (2.14 GHz), 1216 / 0.515, 1206 / 0.501, 1217 / 0.510, 1175 / 0.494, 1232 / 0.520, 1209 / 0.502, 1164 / 0.488 and 1174 / 0.491 (this set; the last four with the smaller LDS sub-transforms of the small launches -- on the two slowest boxes the HBM-bound `ext_inner_kernel` is 5 % slower as well, 0.2615 against 0.2493 ms per step: the parts differ in more than the core clock); on the third box the library of the commit before ran
   1206 / 0.510 in the same call -- kernel comparisons in this repository are therefore made inside one gpurun call (`MKHE_LIB=.../libmkhe_prev.so` beside the new build, or the A/B switches of DESIGN.md §6), never across calls.
 
 Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per step.  "algorithmic GB/s" is the byte model of DESIGN.md §4 (`roofline.kernels_over_peak` = {R.get("kernels_over_peak")}: no model claims more than the chip moves any more);
