@@ -195,6 +195,8 @@ class Context {
     // device tables (public for the C ABI accessors / tests)
     Mod* d_mods = nullptr;
     u64 *d_psi = nullptr, *d_psiinv = nullptr, *d_inv_aux = nullptr;
+    u64* d_psi31b = nullptr;                     // [mall][16][64][2]: the pairs of stages 5..9 per wave of ntt32_kernels.hip (NttBatch::psi31b)
+    u64* d_psi31c = nullptr;                     // [mall][16][31][64][2]: the pairs of stages 10..14 in the load order of ntt32_kernels.hip (NttBatch::psi31c)
     u64* d_psi31n = nullptr;                     // [mall][4][2]: pairs of -psi[1..3] (NttBatch::psi31n)
     u64 *d_psiinv31 = nullptr, *d_inv31c = nullptr;   // inverse twiddles as pairs [mall][N][2]; last-stage constants [mall][8][6] (NttBatch::inv31c)
     unsigned long long small_mods_ = 0;          // bit m set = modulus m has 31 q < 2^62

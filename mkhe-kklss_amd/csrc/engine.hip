@@ -178,6 +178,39 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
             }
         }
         d_psi31 = dev_upload(p31); d_psi31n = dev_upload(p31n);
+        if (logN == 15) {
+            // H32 (ntt32_kernels.hip): in its last register phase thread t = 64 wave + lane holds the coefficients 32 t .. 32 t + 31, and pair
+            // number k = 2^j - 1 + i of the phase (stage 10 + j, i < 2^j) is twiddle ((1024 + t) << j) + i: sixteen consecutive pairs per lane in
+            // the last stage, i.e. a stride of 256 B between the lanes of one load instruction (64 cache lines touched, 16 B of each used, and the
+            // L1 does not hold them until the other fifteen loads come).  Stored once more in load order, every instruction reads 1 KiB in a row.
+            std::vector<u64> p31c((size_t)mall * 16 * 31 * 64 * 2);
+            for (int i = 0; i < mall; ++i)
+                for (int w = 0; w < 16; ++w)
+                    for (int k = 0; k < 31; ++k) {
+                        int j = 0; while ((2 << j) - 1 <= k) ++j;
+                        const int ii = k + 1 - (1 << j);
+                        for (int l = 0; l < 64; ++l) {
+                            const size_t tw = ((size_t)(1024 + 64 * w + l) << j) + ii;
+                            const size_t o = 2 * ((((size_t)i * 16 + w) * 31 + k) * 64 + l);
+                            p31c[o] = p31[2 * ((size_t)i * N + tw)]; p31c[o + 1] = p31[2 * ((size_t)i * N + tw) + 1];
+                        }
+                    }
+            d_psi31c = dev_upload(p31c);
+            // ... and its middle phase (stages 5..9): thread = (bits 14..10, bits 4..0) with wave = bits 14..11, so that a wave uses TWO sets of 31 pairs
+            // (bit 10 = lane >> 5).  Per modulus and wave one 1 KiB row [half][31 pairs] (+ 2 unused entries): loaded by ONE coalesced instruction
+            // per limb, parked in LDS and read from there by broadcast -- instead of 31 per-lane 16-byte loads with two distinct addresses each
+            std::vector<u64> p31b((size_t)mall * 16 * 64 * 2, 0);
+            for (int i = 0; i < mall; ++i)
+                for (int w = 0; w < 16; ++w)
+                    for (int h = 0; h < 2; ++h)
+                        for (int k = 0; k < 31; ++k) {
+                            int j = 0; while ((2 << j) - 1 <= k) ++j;
+                            const size_t tw = ((size_t)(32 + 2 * w + h) << j) + (k + 1 - (1 << j));
+                            const size_t o = 2 * (((size_t)i * 16 + w) * 64 + 31 * h + k);
+                            p31b[o] = p31[2 * ((size_t)i * N + tw)]; p31b[o + 1] = p31[2 * ((size_t)i * N + tw) + 1];
+                        }
+            d_psi31b = dev_upload(p31b);
+        }
         // the inverse kernel of the same family (ntt14_inv_kernel): the inverse twiddles as pairs in the format of the modulus's class, and per
         // modulus and sub-transform root 1..7 the two constants of its last stage, N^-1 and psiinv[root] N^-1 (N = this ring's degree)
         std::vector<u64> pi31(2 * (size_t)mall * N), fin((size_t)mall * 8 * 6, 0);
@@ -412,7 +445,7 @@ Context::~Context() {
 void Context::release_all() noexcept {
     (void)hipSetDevice(device);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
-                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)d_psiinv31, (void*)d_inv31c, (void*)d_psif, (void*)spreadbuf_,
+                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)d_psi31c, (void*)d_psi31b, (void*)d_psiinv31, (void*)d_inv31c, (void*)d_psif, (void*)spreadbuf_,
                     (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_tb30, (void*)d_tw30, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
@@ -616,9 +649,15 @@ void Context::slots_range(NttBatch& b, int mod_base, int limbs) const {
 // forward NTT launch: one kernel per modulus class, each with its own timing record
 void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     NttBatch b = b_in;
-    b.psi31 = d_psi31; b.psi31n = d_psi31n; b.u_mods = u_mods_; b.no_h16 = d_psi31 ? 0 : 1;
+    b.psi31 = d_psi31; b.psi31n = d_psi31n; b.psi31c = d_psi31c; b.psi31b = d_psi31b; b.u_mods = u_mods_; b.no_h16 = d_psi31 ? 0 : 1;
     b.psif = d_psif; b.f_mods = f_mods_;
     for (int i = 0; i < mall && i < NTT_MAX_SLOTS; ++i) b.sched[i] = h16_sched_.empty() ? 15 : h16_sched_[i];
+    if (ntt32_ok(logN, b)) {
+        ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
+        NttBatch bt = b; bt.trace = ntt_trace;
+        launch_ntt32_fwd(bt, small_q_.data(), s_);
+        return;
+    }
     if (ntt16_ok(logN, b)) {
         ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;
@@ -1488,7 +1527,12 @@ void Context::ntt_r(const u64* src, u64* dst, int count, bool inverse) {
     b.src_outer = b.dst_outer = 2L * nq * N; b.src_inner = b.dst_inner = N;
     b.nouter = count;
     if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * 2 * nq); ntt_inv_launch(b); }
-    else ntt_fwd_launch(b, false);
+    else {
+        // ring-R polynomials out of ModUpQtoR / Rescale are lazy multSum representatives (< 3q, mkbfv/basis_extension.go:54-62,91-96): the
+        // 59/60-bit reduction schedule of the H16 kernel must not assume inputs below 2^60 (NttBatch::src_lazy only selects that schedule here)
+        b.src_lazy = 1;
+        ntt_fwd_launch(b, false);
+    }
     MKHE_HIP(hipGetLastError());
 }
 

@@ -69,6 +69,9 @@ struct NttBatch {
     int prestaged_oop;      // ... and that producer wrote into src (src_items), not into dst: the sub-transforms read src and write dst
     const u64* psi31;       // forward, ntt16_kernels.hip only: [nmod][N][2] the twiddle w as the constant pair (w 2^31 mod q, w 2^63 mod q),
                             // balanced, radix-2^31 digits -- operands of the one-round product (mm31)
+    const u64* psi31c;      // ntt32_kernels.hip (N = 2^15): the pairs of stages 10..14 in the order in which the waves of the single-pass kernel load them,
+                            // [nmod][16 waves][31 pairs][64 lanes][2]: every wave-instruction of its last phase reads 1 KiB of consecutive bytes
+    const u64* psi31b;      // ntt32_kernels.hip: the pairs of stages 5..9, [nmod][16 waves][2 halves x 31 pairs (+ 2 unused)][2]: one 1 KiB row per wave
     const u64* psi31n;      // [nmod][4][2]: the pairs of -psi[1], -psi[2], -psi[3] (entries 1..3), for the second pass of the cross-half stage
     unsigned long long u_mods;   // bit m set = modulus m is of the U class (160 q < 2^62): its psi31 rows hold the UNSIGNED radix-2^30 format
                             // (u = w 2^30 mod q in [0, q) as digits u0, u1 >= 0; v = w 2^62 mod q balanced) of ntt16_kernels.hip mm30u
@@ -125,6 +128,9 @@ bool ntt16_inv_ok(int logN, const NttBatch& b);
 void launch_ntt16_inv(const NttBatch& b, hipStream_t st, int logN);
 bool ntt16_ok(int logN, const NttBatch& b);
 void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st, int logN = 15);
+// N = 2^15 launches of several limbs per CU, one pass per limb (ntt32_kernels.hip: one 1024-thread workgroup per CU, 32 coefficients per thread)
+bool ntt32_ok(int logN, const NttBatch& b);
+void launch_ntt32_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st);
 // the same kernel on the 2^15-point sub-transforms of a split N = 2^16 launch (one modulus class per launch)
 bool ntt16_split_ok(const NttBatch& c);
 void launch_ntt16_fwd_split(const NttBatch& c, bool small, hipStream_t st);

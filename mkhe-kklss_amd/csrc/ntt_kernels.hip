@@ -363,6 +363,13 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_fwd_kernel(NttBatch b) {
     const int sub = G::LPB == 1 ? 0 : threadIdx.x / G::T, t = G::LPB == 1 ? threadIdx.x : threadIdx.x % G::T;
     u32* lds = lds_all + sub * lds_words<LOGN>();
     const int njobs = (b.nslots * b.nouter) << b.split;
+#ifdef MKHE_R1_PRIO      // experiment (round 4): static wave priorities inside the only resident workgroup, so that one wave group's memory / LDS phases run under the other's butterflies
+    {
+        const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        if (MKHE_R1_PRIO == 2) { if (w < 8) __builtin_amdgcn_s_setprio(3); }
+        else { const int g = w >> 2; if (g == 0) __builtin_amdgcn_s_setprio(3); else if (g == 1) __builtin_amdgcn_s_setprio(2); else if (g == 2) __builtin_amdgcn_s_setprio(1); }
+    }
+#endif
     // persistent workgroups: each one walks the job list with stride gridDim.x.  A wave that finishes its
     // part of a limb starts loading the next limb at once; the only workgroup-wide rendezvous are the
     // barriers around the cross-wave exchange.
