@@ -139,6 +139,9 @@ def run_bfv(args):
                 roofline=roofline, cpu_baseline=cpu)
 
 
+id_builtin = id
+
+
 def run_cnn(args):
     """--scheme cnn: the reference's BenchmarkCNN (cnn/cnn_bench_test.go:11-78): one encrypted inference = Convolution,
     square, FC1, square, FC2 on PN14QP433; --parties 2 = the reference's dataOwner / modelOwner, 4 = one owner per layer
@@ -165,13 +168,17 @@ def run_cnn(args):
     keygen_s = time.perf_counter() - t0
     rng = np.random.default_rng(args.seed)
     level, N = len(p["Q"]) - 1, 1 << p["logN"]
+    host_cts = {}
     def ct(id):
         host = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in p["Q"]]) for _ in range(2)])
-        return mkckks.NewCiphertext(params, [id], level, p["scale"]).upload(host)
+        c = mkckks.NewCiphertext(params, [id], level, p["scale"]).upload(host)
+        host_cts[id_of(c)] = (id, host)                 # kept for the CPU-baseline leg (the oracle runs the same inference on the same inputs)
+        return c
+    id_of = id_builtin
     ctImage, ctKernels = ct(owners["image"]), [ct(owners["kernels"]) for _ in range(4)]
     ctFC1, ctFC2, ctB1, ctB2 = [ct(owners["fc1"]) for _ in range(8)], ct(owners["fc2"]), ct(owners["fc1"]), ct(owners["fc2"])
-    ptMask = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in p["Q"][: level - 3]])
-    ptMask = mkrlwe.DeviceLimbs(params, 1, level - 3).upload(ptMask[None])            # resident plaintext (uploaded once)
+    ptMask_host = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in p["Q"][: level - 3]])
+    ptMask = mkrlwe.DeviceLimbs(params, 1, level - 3).upload(ptMask_host[None])            # resident plaintext (uploaded once)
     ev = mkckks.NewEvaluator(params)
     forks = [ev.Fork() for _ in range(max(0, args.forks))]       # extra engine contexts: the independent chains of a layer overlap
     if os.environ.get("MKHE_CNN_INTRA_OVERLAP", "0") == "0":
@@ -225,6 +232,43 @@ def run_cnn(args):
     for _ in range(args.steps):                      # per-layer figures: a second, untimed-for-`value` pass with a sync per layer
         inference(True)
     roofline = roofline_leg(args, params, lambda: inference(False), p["logN"], "cnn PN14QP433 k=%d" % len(set(owners.values())))
+    # ---- CPU baseline (cnn/cnn_bench_test.go:12-75 on the host): the SAME inference -- same circuit (mkhe_kklss_amd/cnn.py is duck-typed over its
+    # evaluator), same keys (downloaded once), same input limbs -- on the oracle through tests/oracle_evaluator.py, one host thread, then with the
+    # oracle's limb loops spread over the cores; its output ciphertext is compared with the device's bit for bit
+    cpu = None
+    if not args.no_cpu:
+        from oracle import oracle as O
+        import oracle_evaluator as OE
+        ks = O.KeySwitcher(p["logN"], p["Q"], p["P"], 2)
+        parties = sorted(set(owners.values()))
+        rots = sorted(set(HC.ROTS + [1 << i for i in range(p["logN"] - 1)]))
+        rlk_h = {id: tuple(rlkSet.GetRelinearizationKey(id).Value[j].download() for j in range(3)) for id in parties}
+        rk_h = {(id, r): rtkSet.GetRotationKey(id, r).Value.download() for id in parties for r in rots}
+        crs_h = {r: params.CRS[r].download() for r in rots + [-1] if r in params.CRS}
+        oev = OE.OracleEvaluator(ks, p["Q"], p["scale"], rlk_h, rk_h, crs_h, p["logN"])
+        H_ = lambda c: OE.OCt([host_cts[id_of(c)][0]], host_cts[id_of(c)][1], p["scale"])
+        oI, oK, oF1, oF2, oB1, oB2 = H_(ctImage), [H_(c) for c in ctKernels], [H_(c) for c in ctFC1], H_(ctFC2), H_(ctB1), H_(ctB2)
+        ohoist = (oev.HoistedForm(oI), [oev.HoistedForm(c) for c in oK], [oev.HoistedForm(c) for c in oF1])           # precomputation, outside the timer like the device's
+        def cpu_inference():
+            convOut = cnn.Convolution(oev, None, None, oI, ohoist[0], oK, ohoist[1], None)
+            sq1 = (lambda h: oev.MulRelinHoistedNew(convOut, convOut, h, h, None))(oev.HoistedForm(convOut))
+            fc1 = cnn.FC1Layer(oev, None, None, sq1, oev.HoistedForm(sq1), oF1, ohoist[2], oB1, None)
+            sq2 = (lambda h: oev.MulRelinHoistedNew(fc1, fc1, h, h, None))(oev.HoistedForm(fc1))
+            return cnn.FC2Layer(oev, None, None, sq2, oF2, oB2, ptMask_host, p["scale"])
+        O.set_threads(1)
+        t0 = time.perf_counter(); ref = cpu_inference(); cdt = time.perf_counter() - t0
+        got = out.download()
+        same = bool(got.shape == ref.host.shape and (got == ref.host).all() and out.Level() == ref.Level() and out.Scale == ref.Scale)
+        nth = min(os.cpu_count() or 1, len(p["Q"]) + len(p["P"]))
+        O.set_threads(nth)
+        cpu_inference()
+        t0 = time.perf_counter(); ref_mt = cpu_inference(); mdt = time.perf_counter() - t0
+        O.set_threads(1)
+        cpu = dict(value=1.0 / cdt, unit="inference/s", cores=1, kind="port",
+                   sample="1 full encrypted inference (Convolution + square + FC1 + square + FC2, %d parties, PN14QP433) on 1 host thread, %.1f s" % (len(parties), cdt),
+                   bit_exact_vs_gpu=same, value_limb_parallel=1.0 / mdt, cores_limb_parallel=nth,
+                   limb_parallel_identical=bool((ref_mt.host == ref.host).all()))
+        del rlk_h, rk_h, crs_h
     return dict(metric="cnn_inference_per_sec", value=args.steps / dt, unit="inference/s", n_gpus=1, steps=args.steps,
                 warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps, higher_is_better=True, scaling="strong",
                 vs_baseline=None, dtype="u64", data="synthetic",
@@ -233,7 +277,7 @@ def run_cnn(args):
                             parties=len(set(owners.values())), params="PN14QP433", seed=args.seed,
                             forks=len(forks), hip_graph=graph is not None, host_issue_ms=issue * 1e3 / args.steps, layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
                             keygen_s=keygen_s, keys_generated=len(set(owners.values())) * (3 + len(HC.ROTS) + p["logN"] - 1)),
-                roofline=roofline, cpu_baseline=None)
+                roofline=roofline, cpu_baseline=cpu)
 
 
 def csrc_digest():

@@ -108,3 +108,31 @@ def test_capture_refused_on_old_runtime_or_works():
             pass
     except MkheError as e:
         assert "cannot end a multi-stream capture" in str(e)
+
+
+def test_encrypted_cnn_matches_the_oracle_evaluator():
+    """the whole inference, device against the CPU oracle running the same circuit on the same ciphertexts and keys (tests/oracle_evaluator.py:
+    the cpu_baseline leg of bench.py --scheme cnn): every output limb bit for bit, same level, same scale"""
+    import oracle_evaluator as OE
+    from oracle import oracle as O
+    from mkhe_kklss_amd import cnn
+    p = HC.PN14QP433
+    sc = HC.CnnScenario(TWO, seed=6)
+    cts = sc.encrypt_model(HC.synthetic_model(10))
+    pt, pt_scale = sc.mask_plaintext(sc.level - 4)
+    out = cnn.Inference(sc.eval, sc.rlkSet, sc.rtkSet, cts["ctImage"], cts["ctKernels"], cts["ctFC1"], cts["ctFC2"], cts["ctB1"], cts["ctB2"], pt, pt_scale)
+    parties = sorted(set(TWO.values()))
+    rots = sorted(set(HC.ROTS + [1 << i for i in range(p["logN"] - 1)]))
+    rlk_h = {id: tuple(sc.rlkSet.GetRelinearizationKey(id).Value[j].download() for j in range(3)) for id in parties}
+    rk_h = {(id, r): sc.rtkSet.GetRotationKey(id, r).Value.download() for id in parties for r in rots}
+    crs_h = {r: sc.params.CRS[r].download() for r in rots + [-1] if r in sc.params.CRS}
+    O.set_threads(8)
+    try:
+        oev = OE.OracleEvaluator(O.KeySwitcher(p["logN"], p["Q"], p["P"], 2), p["Q"], p["scale"], rlk_h, rk_h, crs_h, p["logN"])
+        H_ = lambda c: OE.OCt(c.ids, c.download(), c.Scale)
+        ref = cnn.Inference(oev, None, None, H_(cts["ctImage"]), [H_(c) for c in cts["ctKernels"]], [H_(c) for c in cts["ctFC1"]], H_(cts["ctFC2"]),
+                            H_(cts["ctB1"]), H_(cts["ctB2"]), pt, pt_scale)
+    finally:
+        O.set_threads(1)
+    assert out.ids == ref.ids and out.Level() == ref.Level() and out.Scale == ref.Scale
+    assert (out.download() == ref.host).all()
