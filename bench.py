@@ -318,7 +318,7 @@ def roofline_leg(args, params, step, logN, workload, extra=None):
     dom = names_k[di]
     achieved = byt[di] / (ms[di] * 1e-3) / 1e9
     # HBM traffic: PMC counters cannot be read from inside this process; the figures come from the committed rocprofv3 --pmc
-    # summary of the clean profile command (profiles/traffic.json, tools/profile_r2.sh + tools/traffic_from_pmc.py:
+    # summary of the clean profile command (profiles/traffic.json, tools/profile_round.sh + tools/traffic_from_pmc.py:
     # (2*FETCH_SIZE + WRITE_SIZE) KB per launch).  They are attached only when the profiled run had the launch
     # pattern measured here: same workload, same kernel sources (csrc_sha256), and per kernel the recorded call count equals
     # launches_per_step * (steps the recorded command ran) -- otherwise `traffic` stays null.
@@ -343,7 +343,7 @@ def roofline_leg(args, params, step, logN, workload, extra=None):
                 k["hbm_bytes_per_launch_pmc"] = hb
                 k["hbm_GBs_pmc"] = hb / (k["avg_launch_us"] * 1e-6) / 1e9          # what the kernel really moves: never above the peak
         if traffic is None:
-            tnote = ("profiles/traffic.json was recorded for other kernel sources (csrc_sha256 differs): re-run tools/profile_r3.sh" if stale
+            tnote = ("profiles/traffic.json was recorded for other kernel sources (csrc_sha256 differs): re-run tools/profile_round.sh" if stale
                      else "profiles/traffic.json was recorded for another workload or launch pattern")
     out = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                frac=achieved / HBM_PEAK_GBS, traffic=traffic,

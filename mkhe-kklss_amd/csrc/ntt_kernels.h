@@ -31,6 +31,15 @@
 #pragma once
 #include "modarith.h"
 
+// Timing experiments that produce WRONG RESULTS on purpose -- the MKHE_*_X_* switches of the NTT kernels (butterflies, LDS exchanges, result
+// stores, source or twiddle loads taken out: tools/ntt16_ablation.sh, tools/build_variant.sh) -- exist only in builds that say so with
+// -DMKHE_ABLATION; a product build that picks one of them up by accident does not compile.
+#if !defined(MKHE_ABLATION) && (defined(MKHE_H16_X_NOBFLY) || defined(MKHE_H16_X_NOXCHG) || defined(MKHE_H16_X_NOSTORE) || defined(MKHE_H16_X_NOPARK) || \
+                                defined(MKHE_H16_X_NOSRC) || defined(MKHE_H16_X_NOTWLOAD) || defined(MKHE_H32_X_NOBFLY) || defined(MKHE_H32_X_NOXCHG) || \
+                                defined(MKHE_H32_X_NOSTORE) || defined(MKHE_H32_X_NOTWB) || defined(MKHE_X_NOXCHG) || defined(MKHE_X_NO_NTSTORE))
+#error "MKHE_*_X_* switches give wrong results on purpose (timing experiments): build them with -DMKHE_ABLATION"
+#endif
+
 namespace mkhe {
 
 constexpr int NTT_MAX_ITEMS = 64;

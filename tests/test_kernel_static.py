@@ -64,3 +64,55 @@ def test_digit_spread_kernels_do_not_spill():
         assert res[n]["vgpr_spill_count"] == 0 and res[n]["private_segment_fixed_size"] == 0, (n, res[n])
     r4 = [n for n in names if "spread4" in n][0]
     assert res[r4]["vgpr_count"] <= 128, res[r4]              # four waves per SIMD
+
+
+def _isa(src, *flags):
+    csrc = os.path.join(ROOT, "mkhe-kklss_amd", "csrc")
+    r = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", *flags, "-S", "--cuda-device-only",
+                        os.path.join(csrc, src), "-o", "-"], capture_output=True, text=True, timeout=900)
+    return r
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_m0_is_only_touched_by_the_addtid_groups():
+    """ds_write_addtid_b32 takes its base from M0, which the asm blocks of ntt16_kernels.hip set themselves (addtid_write8); hipcc answers the `m0`
+    clobber with "reserved registers on the clobber list may not be preserved" (157 notes): the compiler promises nothing about M0 around the block.
+    What the kernels need is weaker and checkable on the ISA: (1) every add-TID store sits in a group `s_mov_b32 m0, sN; s_nop 0; ds_write_addtid_b32 x 8`
+    with nothing else in between (the write of M0 and its wait state are ours); (2) NO other instruction of these kernels reads or writes M0 -- so there
+    is no compiler-held value in M0 that the blocks could destroy, and none that could leak into a block.  A compiler that starts using M0 in these
+    kernels (LDS-DMA, s_movrel, interpolation ...) fails here instead of computing wrong limbs."""
+    r = _isa("ntt16_kernels.hip")
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l.strip() for l in r.stdout.splitlines()]
+    code = [l for l in lines if l and not l.startswith((";", ".", "//")) and not l.endswith(":")]
+    groups = stores = 0
+    i = 0
+    while i < len(code):
+        op = code[i].split()[0]
+        if op == "s_mov_b32" and code[i].split()[1].rstrip(",") == "m0":
+            assert code[i + 1].startswith("s_nop 0"), code[i:i + 3]
+            n = 0
+            while code[i + 2 + n].startswith("ds_write_addtid_b32"):
+                n += 1
+            assert n == 8, code[i:i + 12]
+            groups += 1; stores += n; i += 2 + n
+            continue
+        assert op != "ds_write_addtid_b32", "an add-TID store outside its group: " + code[i]
+        toks = code[i].replace(",", " ").split()
+        assert "m0" not in toks[1:], "M0 used outside the add-TID groups: " + code[i]
+        i += 1
+    assert groups >= 24 and stores == 8 * groups, (groups, stores)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_h32_kernel_fits_one_workgroup_per_cu_without_scratch():
+    """ntt32_kernels.hip: 32 coefficients per thread + the pinned product temporaries v122..v127 in at most 128 VGPRs (4 waves per SIMD: the one
+    1024-thread workgroup per CU), no spilled vector register, no scratch; its ablation switches do not compile without -DMKHE_ABLATION"""
+    res = _kernel_resources("ntt32_kernels.hip")
+    names = [n for n in res if "ntt32_fwd" in n]
+    assert len(names) == 2, sorted(res)
+    for n in names:
+        assert res[n]["vgpr_count"] <= 128 and res[n]["vgpr_spill_count"] == 0 and res[n]["private_segment_fixed_size"] == 0, (n, res[n])
+    r = _isa("ntt32_kernels.hip", "-DMKHE_H32_X_NOBFLY")
+    assert r.returncode != 0 and "MKHE_ABLATION" in r.stderr
+    assert _isa("ntt32_kernels.hip", "-DMKHE_H32_X_NOBFLY", "-DMKHE_ABLATION").returncode == 0

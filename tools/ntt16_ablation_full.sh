@@ -10,7 +10,7 @@ run() {
     name=$1; shift
     mkdir -p $B/abl_$name
     for f in ntt_kernels poly_kernels keygen_kernels engine keygen capi; do cp $B/$f.o $B/abl_$name/$f.o; done
-    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$C "$@" -c $C/ntt16_kernels.hip -o $B/abl_$name/ntt16_kernels.o 2>/dev/null || { echo "$name: build failed"; return; }
+    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DMKHE_ABLATION -I$C "$@" -c $C/ntt16_kernels.hip -o $B/abl_$name/ntt16_kernels.o 2>/dev/null || { echo "$name: build failed"; return; }
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/abl_$name/lib.so $B/abl_$name/*.o
     echo "== $name   ($*)"
     MKHE_LIB=$B/abl_$name/lib.so python3 $R/tools/ntt16_bench.py 10 2>&1 | grep -E "limbs +(1792|896) " | cut -c1-112

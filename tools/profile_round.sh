@@ -1,28 +1,54 @@
 #!/bin/bash
-# Round profile set (run on the GPU box through gpurun): kernel-trace stats of bench.py with and without the
-# side-stream overlap, and the two HBM-traffic PMC passes (separate runs, kernel-trace only, as the guide prescribes).
-#   gpurun -- 'bash tools/profile_round.sh r1f'
-TAG=${1:-r1x}
+# Profile set of one round (run on the GPU box through gpurun):  gpurun --timeout 1200 -- 'bash tools/profile_round.sh r4a'
+# then, here:  python tools/collect_profiles.py r4a r4 "PN15QP880 k=4"
+# Every profiled pass runs the SAME command, `python3 bench.py --no-cpu --no-extras` with MKHE_NO_OVERLAP=1 (each kernel alone on the
+# main stream).  With --no-extras the dominant kernel (the Decompose-fused forward NTT) is launched exactly 2 * (2 * (W + K) + 300 + K)
+# times: twice per MulRelin -- in the cold-start leg (W + K), the 100 + 200 steps of the steady-state leg, the timed region (W + K)
+# and the HIP-event leg (K).
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
-MKHE_NO_OVERLAP=1 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_noovl -o p -- python3 bench.py --steps 20 --warmup 3 --no-cpu > $O/bench_noovl.json 2> $O/bench_noovl.err
-rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_ovl -o p -- python3 bench.py --steps 20 --warmup 3 --no-cpu > $O/bench_ovl.json 2> $O/bench_ovl.err
-MKHE_NO_OVERLAP=1 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu > $O/bench_pmc_fetch.json 2> $O/bench_pmc_fetch.err
-MKHE_NO_OVERLAP=1 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu > $O/bench_pmc_write.json 2> $O/bench_pmc_write.err
-MKHE_NO_OVERLAP=1 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_bfv -o p -- python3 bench.py --scheme bfv --steps 10 --warmup 2 --no-cpu > $O/bench_bfv.json 2> $O/bench_bfv.err
-python3 bench.py --steps 20 --warmup 3 > $O/bench_plain.json 2> $O/bench_plain.err
-# secondary workloads: the configs[3] ring on one GPU (N = 2^16, 8 parties, keys written on the device) and the encrypted CNN
-MKHE_NO_OVERLAP=1 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_pn16 -o p -- python3 bench.py --params PN16QP1761 --parties 8 --steps 6 --warmup 2 > $O/bench_pn16_noovl.json 2> $O/bench_pn16_noovl.err
+P="rocprofv3 --output-format csv --kernel-trace"
+python3 bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+echo "plain done" 
+MKHE_NO_OVERLAP=1 $P --stats -d $O/stats_noovl -o p -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-extras > $O/bench_noovl.json 2> $O/bench_noovl.err
+$P --stats -d $O/stats_ovl -o p -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-extras > $O/bench_ovl.json 2> $O/bench_ovl.err
+echo "stats done"
+export MKHE_NO_OVERLAP=1
+$P --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-extras > $O/bench_pmc_fetch.json 2> $O/bench_pmc_fetch.err
+$P --pmc WRITE_SIZE -d $O/pmc_write -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-extras > $O/bench_pmc_write.json 2> $O/bench_pmc_write.err
+echo "traffic done"
+$P --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES -d $O/sq_a -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu --no-extras > $O/sq_a.json 2> $O/sq_a.err
+$P --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA -d $O/sq_b -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu --no-extras > $O/sq_b.json 2> $O/sq_b.err
+$P --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $O/sq_d -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu --no-extras > $O/sq_d.json 2> $O/sq_d.err
+echo "sq done"
+$P --stats -d $O/stats_bfv -o p -- python3 bench.py --scheme bfv --steps 10 --warmup 2 --no-cpu > $O/bench_bfv.json 2> $O/bench_bfv.err
+unset MKHE_NO_OVERLAP
+python3 bench.py --scheme bfv --steps 10 --warmup 2 > $O/bench_bfv_plain.json 2> $O/bench_bfv_plain.err
+echo "bfv done"
+MKHE_NO_OVERLAP=1 $P --stats -d $O/stats_pn16 -o p -- python3 bench.py --params PN16QP1761 --parties 8 --steps 6 --warmup 2 --no-cpu --no-extras > $O/bench_pn16_noovl.json 2> $O/bench_pn16_noovl.err
 python3 bench.py --params PN16QP1761 --parties 8 --steps 10 --warmup 2 > $O/bench_pn16.json 2> $O/bench_pn16.err
-MKHE_NO_OVERLAP=1 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_cnn -o p -- python3 bench.py --scheme cnn --parties 2 --steps 10 --warmup 2 > $O/bench_cnn_noovl.json 2> $O/bench_cnn_noovl.err
+echo "pn16 done"
 python3 bench.py --scheme cnn --parties 2 --steps 20 --warmup 3 > $O/bench_cnn2.json 2> $O/bench_cnn2.err
 python3 bench.py --scheme cnn --parties 4 --steps 20 --warmup 3 > $O/bench_cnn4.json 2> $O/bench_cnn4.err
-python3 bench.py --scheme bfv --steps 10 --warmup 2 > $O/bench_bfv_plain.json 2> $O/bench_bfv_plain.err
-find $O/stats_pn16 $O/stats_cnn -name '*kernel_trace.csv' -delete
-# keep the merge small: drop the per-dispatch traces of the stats runs, keep their *_stats.csv
-find $O/stats_noovl $O/stats_ovl $O/stats_bfv -name '*kernel_trace.csv' -delete
+python3 bench.py --params PN14QP439 --steps 20 --warmup 3 --no-cpu > $O/bench_pn14.json 2> $O/bench_pn14.err
+for k in 1 2 4 8 16; do python3 bench.py --parties $k --no-cpu --device-keys --steps 20 --warmup 3 2>/dev/null; done > $O/party_sweep.jsonl
+echo "secondary done"
+# issue-rate microbenchmarks (built from source here: no binaries in the tree), power / clock under the dominant kernel, steady-state ablation table of the shipped kernel
+for u in bfly30u_rate bfly31_rate valu_rate bfly_asm_rate; do [ -f tools/ubench/$u.hip ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null; done
+(echo "== tools/ubench/bfly30u_rate.hip"; tools/ubench/bfly30u_rate; echo "== tools/ubench/bfly31_rate.hip"; tools/ubench/bfly31_rate; echo "== tools/ubench/valu_rate.hip"; tools/ubench/valu_rate; echo "== tools/ubench/bfly_asm_rate.hip"; tools/ubench/bfly_asm_rate) > $O/ubench.txt 2>&1
+bash tools/power_probe.sh > $O/power_probe.txt 2>&1
+REPS=1500 bash tools/ntt16_variants.sh "shipped:" "no_mem_no_xchg:-DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE -DMKHE_H16_X_NOXCHG=15" \
+    "no_mem:-DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE" "no_store:-DMKHE_H16_X_NOSTORE" "no_src:-DMKHE_H16_X_NOSRC" "no_tw:-DMKHE_H16_X_NOTWLOAD" \
+    "no_xchg:-DMKHE_H16_X_NOXCHG=15" "no_bfly:-DMKHE_H16_X_NOBFLY=3" "no_scalar_bfly:-DMKHE_H16_X_NOBFLY=1" "no_perlane_bfly:-DMKHE_H16_X_NOBFLY=2" \
+    "skeleton:-DMKHE_H16_X_NOBFLY=3 -DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE" "force_park:-DMKHE_H16_FORCE_PARK" "pipelined_loads:-DMKHE_H16_PIPE" \
+    "phase_d_one_round:-DMKHE_H16_UD31=1" "plain_lds_writes:-DMKHE_H16_ADDTID=0" "no_priority:-DMKHE_H16_PRIO=0" "flowing_lds_reads:-DMKHE_H16_FLOW" "shipped_again:" > $O/ntt16_ablation.txt 2>&1
+(echo "== U class off (MKHE_H16_UCLASS=0)"; MKHE_H16_UCLASS=0 python3 tools/ntt16_bench.py 1500 | grep -E "limbs +(1792|896) " | cut -c1-112; echo "== round-2 reduction schedule (MKHE_H16_SCHED=0)"; MKHE_H16_SCHED=0 python3 tools/ntt16_bench.py 1500 | grep -E "limbs +(1792|896) " | cut -c1-112) >> $O/ntt16_ablation.txt 2>&1
+python3 tools/ntt16_bench.py 1500 > $O/ntt16_bench.txt 2>&1
+echo "ntt done"
+find $O -name '*kernel_trace.csv' -path '*stats_*' -delete
+find $O -name '*agent_info.csv' -delete
 du -sh $O
-ls -R $O | head -50
