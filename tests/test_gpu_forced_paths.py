@@ -87,3 +87,143 @@ def test_small_shapes_through_the_h16_kernels():
     r = subprocess.run([sys.executable, "-c", SCRIPT % dict(tests=os.path.join(ROOT, "tests"), root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "forced paths ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     assert "Memory access fault" not in r.stderr
+
+
+# ---------------------------------------------------------------- round 4: 59/60-bit moduli behind producers whose outputs are not below 2^60
+PRIMES = r'''
+def is_prime(n):
+    if n < 2: return False
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n %% p == 0: return n == p
+    d, s = n - 1, 0
+    while d %% 2 == 0: d //= 2; s += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, n)
+        if x in (1, n - 1): continue
+        for _ in range(s - 1):
+            x = x * x %% n
+            if x == n - 1: break
+        else: return False
+    return True
+def primes_below(top, step, count, avoid=()):
+    """`count` primes = 1 mod `step`, descending from `top`"""
+    out, c = [], (top - 1) // step * step + 1
+    while len(out) < count:
+        if is_prime(c) and c not in avoid: out.append(c)
+        c -= step
+    return out
+'''
+
+SCRIPT_N16 = PRIMES + r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import harness as H
+from oracle import oracle as O
+from mkhe_kklss_amd import mkckks, mkrlwe
+N = 1 << 16
+q60 = 0xfffffffff6a0001                                   # the head prime of mkckks.PN15QP880: = 1 mod 2^17
+assert (q60 - 1) %% (2 * N) == 0
+p59 = primes_below(1 << 59, 2 * N, 2)
+rng = np.random.default_rng(160)
+for name, Q, P in (("alpha = 1", [q60, 0x3fffffffd60001, 0x3fffffffca0001, 0x3fffffff360001], p59),
+                   ("alpha = 2", [q60] + H.PN16_Q[1:5], H.PN16_P)):
+    ks = O.KeySwitcher(16, Q, P, 2)
+    params = mkckks.Parameters(16, Q, P, float(1 << 45), device=0)
+    mods = Q + P
+    # (a) plain forward transforms of a few polynomials over every modulus (split launches: the halves see values in [0, 4q))
+    a = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in mods]) for _ in range(3)])
+    a[0, :, :4] = np.array([[0, 1, q - 1, q // 2] for q in mods], dtype=np.uint64)
+    src = mkrlwe.DeviceLimbs(params, 3, len(mods)).upload(a)
+    dst = mkrlwe.DeviceLimbs(params, 3, len(mods))
+    mkrlwe.ntt(params, src, dst)
+    f = dst.download()
+    for c in range(3):
+        for j in range(len(mods)):
+            r, i = (ks.ringQ, j) if j < len(Q) else (ks.ringP, j - len(Q))
+            assert (f[c][j] == r.ntt(i, a[c][j])).all(), (name, c, j)
+    # (b) hoisted forms at the top level and one below (Decompose-fused launches; alpha = 2: the digit spread in front of the halves)
+    for level in (len(Q) - 1, len(Q) - 2):
+        names = ["p0", "p1"]
+        h = np.empty((3, level + 1, N), dtype=np.uint64)
+        for l in range(level + 1):
+            h[:, l] = rng.integers(0, Q[l], (3, N), dtype=np.uint64)
+        ct = mkckks.NewCiphertext(params, names, level, float(1 << 45)).upload(h)
+        hoisted = mkckks.NewEvaluator(params).HoistedForm(ct)
+        beta = ks.beta(level)
+        act = list(range(level + 1)) + [len(Q) + j for j in range(len(P))]
+        for i, n in enumerate(names):
+            ref = ks.decompose(level, h[1 + i])
+            got = hoisted.Value[n].download()
+            assert (got[:beta][:, act] == ref[:beta][:, act]).all(), (name, level, i)
+    params.close()
+print("n16 big-modulus paths ok")
+'''
+
+SCRIPT_BFV = PRIMES + r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import harness as H
+import harness_bfv as HB
+from mkhe_kklss_amd import mkbfv, mkrlwe
+from mkhe_kklss_amd._abi import check, lib
+logN = 15
+q60 = primes_below(1 << 60, 1 << 16, 3, avoid=(0xffffffffffc0001, 0xfffffffff840001))
+pset = dict(logN=logN, Q=[q60[0], 0x3fffffffd60001, q60[2]], QMul=[q60[1], 0x3fffffffca0001, 0x3fffffff5d0001], P=HB.BFV_PN15QP880["P"], T=65537)
+bfv = HB.make_bfv(pset)
+params = mkbfv.Parameters(pset["logN"], pset["Q"], pset["QMul"], pset["P"], pset["T"])
+ev = mkbfv.NewEvaluator(params)
+rng = np.random.default_rng(61)
+N, nq = 1 << logN, len(pset["Q"])
+# ring-R forward transforms of lazy ModUpQtoR / Rescale outputs (< 3q under the 60-bit primes), then the whole MulRelinNew
+x = np.stack([H.uniform_poly(rng, pset["Q"], N) for _ in range(6)])
+src = mkrlwe.DeviceLimbs(params, 6, nq).upload(x)
+for conv, ora in ((ev.conv.ModUpQtoR, bfv.modup_q_to_r), (ev.conv.Rescale, bfv.rescale)):
+    dst = mkbfv.PolyR(params, 6)
+    conv(src, dst)
+    got = dst.download()
+    ref = np.stack([ora(x[c]) for c in range(6)])
+    assert (got == ref).all()
+    check(lib().mkhe_bfv_ntt_r(params.ctx, dst.devptr(), dst.devptr(), 6, 0))
+    got = dst.download()
+    for c in range(6):
+        assert (got[c] == bfv.ntt_r(ref[c])).all(), c
+names = ["a", "b"]
+h0, h1 = H.uniform_ct(rng, bfv.ks, 2, nq), H.uniform_ct(rng, bfv.ks, 2, nq)
+c0, c1 = mkbfv.NewCiphertext(params, names).upload(h0), mkbfv.NewCiphertext(params, names).upload(h1)
+rlk_h, rlk_d = {}, mkbfv.NewRelinearizationKeyKeySet(params)
+for i, n in enumerate(names):
+    ks5 = [H.uniform_swk(rng, bfv.ks) for _ in range(5)]
+    rlk_h[i] = tuple(ks5)
+    rlk_d.AddRelinearizationKey(mkbfv.RelinearizationKey(params, n, *ks5))
+u_h = H.uniform_swk(rng, bfv.ks)
+params.CRS[-1] = mkrlwe.SwitchingKey(params, u_h)
+_, ref = bfv.mul_relin_new([0, 1], h0, [0, 1], h1, rlk_h, u_h)
+assert (ev.MulRelinNew(c0, c1, rlk_d).download() == ref).all()
+assert (ev.mulRelin(c0, c1, rlk_d).download() == ref).all()
+print("bfv big-modulus paths ok")
+'''
+
+
+def _run(script, env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-c", script % dict(tests=os.path.join(ROOT, "tests"), root=ROOT)], env=env, capture_output=True, text=True, timeout=1200)
+    assert "Memory access fault" not in r.stderr
+    return r
+
+
+@pytest.mark.parametrize("env_extra", [dict(MKHE_NTT16_RADIX4="0", MKHE_SPREAD_RADIX4="0"), dict()], ids=["halves", "default"])
+def test_n16_with_a_60_bit_modulus(env_extra):
+    """N = 2^16 rings with a 60-bit head prime and 59-bit special primes: the H16 sub-transforms behind the streaming cross-half stage and behind
+    the alpha = 2 digit spread start from values in [0, 4q) -- above the 2^60 that the per-modulus reduction schedule assumes (ADVICE r3, medium)"""
+    r = _run(SCRIPT_N16, dict(MKHE_NTT16_MIN="1", MKHE_NTT14_MIN="1", MKHE_NTT16_INV_MIN="1", **env_extra))
+    assert r.returncode == 0 and "n16 big-modulus paths ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("env_extra", [dict(), dict(MKHE_NTT32="1", MKHE_NTT32_MIN="1")], ids=["h16", "h32"])
+def test_bfv_with_60_bit_moduli(env_extra):
+    """mkbfv over 60-bit Q / QMul primes at N = 2^15: the ring-R forward transforms take lazy ModUpQtoR / Rescale outputs (< 3q = 2^61.6), which the
+    H16 / H32 kernels must reduce at the load (NttBatch::src_lazy, set by Context::ntt_r since round 4)"""
+    r = _run(SCRIPT_BFV, dict(MKHE_NTT16_MIN="1", MKHE_NTT16_INV_MIN="1", **env_extra))
+    assert r.returncode == 0 and "bfv big-modulus paths ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
