@@ -188,19 +188,32 @@ def run_cnn(args):
         for e in [ev] + forks:
             check(lib().mkhe_set_overlap(e.params.ctx, 0))
     hoisted = (ev.HoistedForm(ctImage), [ev.HoistedForm(c) for c in ctKernels], [ev.HoistedForm(c) for c in ctFC1])     # precomputation, as in the reference
+    B = max(1, args.batch)
+    if B > 1:
+        # B images in lock step: the model ciphertexts are broadcast, every evaluator call is one launch set for the B images (no forks: the
+        # batch is the concurrency)
+        bev = mkckks.BatchEvaluator(params, B)
+        images = [ctImage] + [ct(owners["image"]) for _ in range(B - 1)]
+        bImage = mkckks.BatchCiphertext(images)
+        bhoisted = (bev.HoistedForm(bImage), hoisted[1], hoisted[2])
     layer_ms = {}
     def timed(name, fn):
         params.sync(); t = time.perf_counter(); out = fn(); params.sync()
         layer_ms[name] = layer_ms.get(name, 0.0) + (time.perf_counter() - t) * 1e3
         return out
-    def inference(record):
+    def inference(record, E=None, img=None, hst=None, fk="default"):
+        E, img, hst, fk = E or ev, img or ctImage, hst or hoisted, forks if fk == "default" else fk
         T = timed if record else (lambda name, fn: fn())
-        convOut = T("Convolution", lambda: cnn.Convolution(ev, rlkSet, rtkSet, ctImage, hoisted[0], ctKernels, hoisted[1], forks))
-        sq1 = T("Square1", lambda: (lambda h: (ev.MulRelinHoistedNew(convOut, convOut, h, h, rlkSet)))(ev.HoistedForm(convOut)))
-        sq1h = T("Square1", lambda: ev.HoistedForm(sq1))
-        fc1 = T("FC1", lambda: cnn.FC1Layer(ev, rlkSet, rtkSet, sq1, sq1h, ctFC1, hoisted[2], ctB1, forks))
-        sq2 = T("Square2", lambda: (lambda h: ev.MulRelinHoistedNew(fc1, fc1, h, h, rlkSet))(ev.HoistedForm(fc1)))
-        return T("FC2", lambda: cnn.FC2Layer(ev, rlkSet, rtkSet, sq2, ctFC2, ctB2, ptMask, p["scale"]))
+        convOut = T("Convolution", lambda: cnn.Convolution(E, rlkSet, rtkSet, img, hst[0], ctKernels, hst[1], fk))
+        sq1 = T("Square1", lambda: (lambda h: (E.MulRelinHoistedNew(convOut, convOut, h, h, rlkSet)))(E.HoistedForm(convOut)))
+        sq1h = T("Square1", lambda: E.HoistedForm(sq1))
+        fc1 = T("FC1", lambda: cnn.FC1Layer(E, rlkSet, rtkSet, sq1, sq1h, ctFC1, hst[2], ctB1, fk))
+        sq2 = T("Square2", lambda: (lambda h: E.MulRelinHoistedNew(fc1, fc1, h, h, rlkSet))(E.HoistedForm(fc1)))
+        return T("FC2", lambda: cnn.FC2Layer(E, rlkSet, rtkSet, sq2, ctFC2, ctB2, ptMask, p["scale"]))
+    single_inference = inference
+    batch_check = None
+    if B > 1:
+        inference = lambda record: single_inference(record, bev, bImage, bhoisted, None)
     for _ in range(max(1, args.warmup)):
         out = inference(False)
     params.sync()
@@ -232,6 +245,15 @@ def run_cnn(args):
     for _ in range(args.steps):                      # per-layer figures: a second, untimed-for-`value` pass with a sync per layer
         inference(True)
     roofline = roofline_leg(args, params, lambda: inference(False), p["logN"], "cnn PN14QP433 k=%d" % len(set(owners.values())))
+    if B > 1:
+        # every image of the batch against its own single-image inference (bit for bit); `out` becomes image 0's ciphertext for the oracle leg below
+        bout = out
+        same_b = []
+        for k in range(B):
+            ref_k = single_inference(False, ev, images[k], (ev.HoistedForm(images[k]), hoisted[1], hoisted[2]), forks)
+            same_b.append(bool(ref_k.Scale == bout.cts[k].Scale and (ref_k.download() == bout.cts[k].download()).all()))
+        batch_check = dict(images=B, identical_to_single_image_inference=all(same_b))
+        out = bout.cts[0]
     # ---- CPU baseline (cnn/cnn_bench_test.go:12-75 on the host): the SAME inference -- same circuit (mkhe_kklss_amd/cnn.py is duck-typed over its
     # evaluator), same keys (downloaded once), same input limbs -- on the oracle through tests/oracle_evaluator.py, one host thread, then with the
     # oracle's limb loops spread over the cores; its output ciphertext is compared with the device's bit for bit
@@ -269,13 +291,13 @@ def run_cnn(args):
                    bit_exact_vs_gpu=same, value_limb_parallel=1.0 / mdt, cores_limb_parallel=nth,
                    limb_parallel_identical=bool((ref_mt.host == ref.host).all()))
         del rlk_h, rk_h, crs_h
-    return dict(metric="cnn_inference_per_sec", value=args.steps / dt, unit="inference/s", n_gpus=1, steps=args.steps,
+    return dict(metric="cnn_inference_per_sec", value=B * args.steps / dt, unit="inference/s", n_gpus=1, steps=args.steps,
                 warmup=args.warmup, ms_per_step=dt * 1e3 / args.steps, higher_is_better=True, scaling="strong",
                 vs_baseline=None, dtype="u64", data="synthetic",
                 config=dict(workload="cnn encrypted inference (Convolution + square + FC1 + square + FC2, cnn/cnn.go), PN14QP433 N=2^14, "
                                      "7 Q + 2 P limbs, %d parties" % len(set(owners.values())),
-                            parties=len(set(owners.values())), params="PN14QP433", seed=args.seed,
-                            forks=len(forks), hip_graph=graph is not None, host_issue_ms=issue * 1e3 / args.steps, layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
+                            parties=len(set(owners.values())), params="PN14QP433", seed=args.seed, batch=B, batch_check=batch_check,
+                            forks=len(forks) if B == 1 else 0, hip_graph=graph is not None, host_issue_ms=issue * 1e3 / args.steps, layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
                             keygen_s=keygen_s, keys_generated=len(set(owners.values())) * (3 + len(HC.ROTS) + p["logN"] - 1)),
                 roofline=roofline, cpu_baseline=cpu)
 
@@ -409,6 +431,19 @@ def run_single(args):
 
     def step():
         return ev.MulRelinNew(ct0, ct1, rlk)
+    B = max(1, args.batch)
+    if B > 1:
+        # B MulRelin in lock step (mkhe_mul_relin_batch): input 0 is the pair above, the others are further uniform ciphertexts of the same shape
+        bev = mkckks.BatchEvaluator(params, B)
+        rngb = np.random.default_rng(args.seed + 7)
+        def more():
+            h = np.stack([np.stack([rngb.integers(0, q, 1 << pset["logN"], dtype=np.uint64) for q in pset["Q"]]) for _ in range(1 + k)])
+            return mkckks.NewCiphertext(params, names, level, pset["scale"]).upload(h)
+        b0 = mkckks.BatchCiphertext([ct0] + [more() for _ in range(B - 1)])
+        b1 = mkckks.BatchCiphertext([ct1] + [more() for _ in range(B - 1)])
+        single_step = step
+        def step():
+            return bev.MulRelinNew(b0, b1, rlk)
 
     # ---- order of the legs (round 3).  After an idle phase (the host-side set-up above is one) this GPU takes about 150 ms of load to settle its
     # clocks (tools/ramp_probe.py: a 5-step window runs at 1.10 ms per step right after 0.2 s of idleness and at 0.92 ms 120 steps later), and
@@ -509,7 +544,21 @@ def run_single(args):
     params.sync()
     dt = time.perf_counter() - t0
     ms_per_step = dt * 1e3 / args.steps
-    value = args.steps / dt
+    value = B * args.steps / dt
+    if B > 1:
+        same_b = [bool((res.cts[i].download() == ev.MulRelinNew(b0.cts[i], b1.cts[i], rlk).download()).all()) for i in range(B)]
+        extras["batch"] = B
+        extras["batch_check"] = dict(inputs=B, identical_to_single_mulrelin=all(same_b))
+        extras["mulrelin_per_sec_single_input_same_run"] = None
+        for _ in range(20):
+            single_step()
+        params.sync()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            single_step()
+        params.sync()
+        extras["mulrelin_per_sec_single_input_same_run"] = 100 / (time.perf_counter() - t1)
+        res = res.cts[0]
 
     beta = params.Beta(level)
     roofline = roofline_leg(args, params, step, pset["logN"], "%s k=%d" % (args.params, k),
@@ -592,6 +641,10 @@ def main():
                          "alpha = 2) on ONE GPU, keys written on the device (implies --device-keys, single GPU only)")
     ap.add_argument("--forks", type=int, default=7,
                     help="--scheme cnn: extra engine contexts through which the independent chains of a layer are issued (0 = one stream)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="B inputs in lock step (mkhe_*_batch entry points, mkckks.BatchEvaluator): --scheme cnn evaluates B images per step, "
+                         "--scheme ckks B MulRelin per step; value counts inputs (inferences / MulRelin per second), every output is compared "
+                         "with the B = 1 evaluation of the same input")
     ap.add_argument("--graph", type=int, default=0,
                     help="--scheme cnn: 1 = replay the inference from a captured HIP graph (falls back to eager issue when the loaded HIP "
                          "runtime cannot capture), 0 = issue every call eagerly (default: 3.9 ms per inference in every run; replays "

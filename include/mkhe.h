@@ -216,6 +216,26 @@ int  mkhe_ct_mul_const(mkhe_ctx* ctx, const mkhe_ct* in, const uint64_t* c_first
  * polynomial dev_pt = uint64[limbs][N] (coefficient domain, device), via NTT / MForm / InvNTT. */
 int  mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe_ct* out);
 
+/* ---- B independent operations of ONE shape per call (round 4; no reference counterpart: the reference evaluates one ciphertext at a time).
+ *      On the small rings (PN14QP439, mkckks/mkckks_benchmark_test.go:13; cnn's PN14QP433, cnn/cnn_test.go:80-96) an operation is a chain of
+ *      launches of a few dozen limbs each; B inputs in lock step are the same launches with B times the items.  All ciphertexts of one list
+ *      have the same ids and limb count; keys and CRS are per party and shared by the inputs; an operand that is the same ciphertext for
+ *      every input (cnn's model) is passed nbatch times; outputs are distinct handles.  Hoisted forms are flat lists [b * n + a] (input b,
+ *      party component a) or NULL (the engine hoists).  Each output equals the single-operation entry point's, bit for bit.
+ *        mkhe_hoisted_form_batch : mkckks.Evaluator.HoistedForm            mkckks/evaluator.go:543-553
+ *        mkhe_rotate_batch       : KeySwitcher.RotateHoisted / Rotate      mkrlwe/keyswitch_hoisted.go:183-247, keyswitch.go:234-298
+ *        mkhe_mul_relin_batch    : KeySwitcher.MulAndRelin[Hoisted] (+ the single Rescale of mkckks.Evaluator.mulRelinHoisted when rescale != 0:
+ *                                  out is then one level below the product)     keyswitch_hoisted.go:44-179, mkckks/evaluator.go:558-581
+ *        mkhe_ct_binary_batch    : op 0 = AddNew, 1 = SubNew               mkckks/evaluator.go:316-356 */
+int  mkhe_hoisted_form_batch(mkhe_ctx* ctx, int level, int nbatch, const mkhe_ct* const* cts, mkhe_swk* const* out);
+int  mkhe_rotate_batch(mkhe_ctx* ctx, uint64_t galEl, int nbatch, const mkhe_ct* const* in, const mkhe_swk* const* hoist,
+                       const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* const* out);
+int  mkhe_mul_relin_batch(mkhe_ctx* ctx, int nbatch, const mkhe_ct* const* op0, const mkhe_ct* const* op1,
+                          const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
+                          const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0, const mkhe_swk* const* rlk_v0,
+                          const mkhe_swk* crs_u, int rescale, mkhe_ct* const* out);
+int  mkhe_ct_binary_batch(mkhe_ctx* ctx, int op, int nbatch, const mkhe_ct* const* op0, const mkhe_ct* const* op1, mkhe_ct* const* out);
+
 /* ==== mkbfv ========================================================================================
  * Context for mkbfv.NewParametersFromLiteral (mkbfv/params.go:28-76): rings Q, QMul (same length), R = Q||QMul,
  * P and the plaintext modulus T; replaces mkbfv.NewKeySwitcher (keyswitch.go:31-65) + NewFastBasisExtender

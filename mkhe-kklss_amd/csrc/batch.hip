@@ -1,0 +1,284 @@
+// batch.hip -- B independent evaluator operations of ONE shape as one launch set (round 4).
+//
+// The reference's small rings -- PN14QP439, its first benchmark set (mkckks/mkckks_benchmark_test.go:13), and cnn's PN14QP433
+// (cnn/cnn_test.go:80-96) -- give an operation a few dozen 2^14-point limbs per launch: a fraction of the 256 CUs, and an encrypted
+// inference is about 360 DEPENDENT launches whose issue, not their work, sets its 2.9 ms.  Nothing shortens that chain;
+// what a server evaluating the same circuit on many inputs can do is run B of them in lock step: every kernel of the engine already takes
+// LISTS -- gadget decompositions (NttBatch items), external products (ExtItem), ModDown destinations, ciphertext components (CtBinArgs) --
+// so the B operations of one step are the same launches with B times the items, and the launch count per input falls by almost B.
+//
+// All B operations of a call have the same shape: the same id lists, limb counts and keys (the relinearization / rotation keys and the CRS
+// belong to the parties, not to the inputs).  An operand that is the SAME ciphertext for every input (the model of cnn: kernels, weights,
+// biases) is passed B times.  Results are the integers of the single-operation entry points, bit for bit (tests/test_gpu_batch.py): the
+// batch path takes no shortcut that changes a representative -- it does not even use the fusions that are specific to one operation at a
+// time (x as a by-product of step F1, Rescale folded into the last ModDown, the hoisted digits' diagonal as tensor input).
+//
+// Replaces, B at a time: KeySwitcher.MulAndRelin[Hoisted] (mkrlwe/keyswitch_hoisted.go:44-179) + Rescale (mkckks/evaluator.go:558-581),
+// RotateHoisted / Rotate (:183-247, keyswitch.go:234-298), Evaluator.HoistedForm (mkckks/evaluator.go:543-553), AddNew / SubNew (:316-356).
+#include "engine.h"
+#include <algorithm>
+
+namespace mkhe {
+
+namespace {
+// one pooled block carved into the temporaries of a batched call (returned to the context's stream-ordered pool at the end)
+struct Arena {
+    Context* c; u64* base = nullptr; size_t words = 0, used = 0;
+    Arena(Context* c_, size_t w) : c(c_), words(w) { if (w) base = c->pool_alloc(w); }
+    ~Arena() { if (base) { const HandleUsers none; c->pool_free(base, words, &none); } }
+    u64* take(size_t w) { if (used + w > words) throw Error("mkhe: internal: batch arena overrun"); u64* p = base + used; used += w; return p; }
+};
+void same_shape(const std::vector<const Ct*>& v, const char* what) {
+    for (const Ct* c : v) {
+        if (!c) throw Error(std::string("mkhe: null ciphertext in a batch (") + what + ")");
+        if (c->n != v[0]->n || c->limbs != v[0]->limbs || c->ids != v[0]->ids) throw Error(std::string("mkhe: the ciphertexts of a batch must have one shape (") + what + ")");
+    }
+}
+}  // namespace
+
+void Context::hoisted_form_batch(int level, const std::vector<const Ct*>& cts, const std::vector<Swk*>& outs) {
+    if (cts.empty()) return;
+    same_shape(cts, "HoistedForm");
+    const int n = cts[0]->n;
+    if (cts[0]->limbs < level + 1) throw Error("mkhe: ciphertext level below requested level");
+    if (outs.size() != cts.size() * (size_t)n) throw Error("mkhe: hoisted_form_batch: one output per party component");
+    std::vector<const u64*> src; std::vector<u64*> dst;
+    const size_t PI = (size_t)cts[0]->limbs * N;
+    for (size_t b = 0; b < cts.size(); ++b)
+        for (int a = 0; a < n; ++a) { src.push_back(cts[b]->d + (1 + a) * PI); dst.push_back(outs[b * n + a]->d); }
+    if (!src.empty()) decompose_batch(level, src, dst, false);
+}
+
+void Context::rotate_batch(u64 galEl, const std::vector<const Ct*>& ins, const std::vector<const Swk*>& hoists, const Swk* const* rk,
+                           const Swk& crs, const std::vector<Ct*>& outs) {
+    const size_t B = ins.size();
+    if (!B) return;
+    if (outs.size() != B) throw Error("mkhe: rotate_batch: one output per input");
+    same_shape(ins, "Rotate");
+    { std::vector<const Ct*> o(outs.begin(), outs.end()); same_shape(o, "Rotate outputs"); }
+    const int n = ins[0]->n, L = outs[0]->limbs, level = L - 1;
+    check_level(level);
+    if (ins[0]->limbs < L) throw Error("Cannot Rotate: ctIn and ctOut have different levels");
+    if (outs[0]->n != n || outs[0]->ids != ins[0]->ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
+    if (!hoists.empty() && hoists.size() != B * (size_t)n) throw Error("mkhe: rotate_batch: one hoisted form per party component");
+    bool alias = false;
+    for (size_t b = 0; b < B; ++b) alias = alias || ins[b]->d == outs[b]->d;
+    if (n == 0 || 2 * n > EXT_MAX_ITEMS || alias || galEl == 0) {
+        // (no party, or the fused permutation does not apply: one operation at a time)
+        for (size_t b = 0; b < B; ++b) {
+            std::vector<const Swk*> h;
+            for (int a = 0; a < n && !hoists.empty(); ++a) h.push_back(hoists[b * n + a]);
+            rotate(galEl, *ins[b], hoists.empty() ? nullptr : h.data(), rk, crs, *outs[b]);
+        }
+        return;
+    }
+    for (int a = 0; a < n; ++a) if (!rk[a]) throw Error("cannot GetRotationKeys: there is no rotation key with given id");
+    const size_t PI = (size_t)ins[0]->limbs * N, PO = (size_t)L * N;
+    Arena ar(this, hoists.empty() ? B * n * swk_words() : 0);
+    std::vector<const u64*> h(B * n);
+    if (hoists.empty()) {
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (size_t b = 0; b < B; ++b)
+            for (int a = 0; a < n; ++a) { u64* d = ar.take(swk_words()); dsrc.push_back(ins[b]->d + (1 + a) * PI); ddst.push_back(d); h[b * n + a] = d; }
+        decompose_batch(level, dsrc, ddst, true);
+    } else {
+        for (size_t i = 0; i < B * n; ++i) { if (!hoists[i]) throw Error("mkhe: missing hoisted form"); h[i] = hoists[i]->d; }
+    }
+    // whole ciphertexts per ext_batch call: the products of one destination must meet in one ModDown launch (the fused permutation)
+    const size_t per = std::max<size_t>(1, EXT_MAX_ITEMS / (2 * n));
+    for (size_t b0 = 0; b0 < B; b0 += per) {
+        std::vector<ExtItem> items;
+        for (size_t b = b0; b < std::min(B, b0 + per); ++b)
+            for (int a = 0; a < n; ++a) {
+                items.push_back(ExtItem{h[b * n + a], rk[a]->d, outs[b]->d, true});
+                if (a == 0) items.back().addend = ins[b]->d;
+                items.push_back(ExtItem{h[b * n + a], crs.d, outs[b]->d + (size_t)(1 + a) * PO, false});
+            }
+        ext_batch(level, items, -1, 0, galEl);
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
+void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vector<const Ct*>& op1, const std::vector<const Swk*>& hoist0,
+                              const std::vector<const Swk*>& hoist1, const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
+                              const Swk& crs_u, bool rescale_out, const std::vector<Ct*>& outs) {
+    const size_t B = op0.size();
+    if (!B) return;
+    if (op1.size() != B || outs.size() != B) throw Error("mkhe: mul_relin_batch: one op1 and one output per op0");
+    if (masked_) throw Error("mkhe: a limb-sharded context evaluates one operation at a time");
+    same_shape(op0, "MulRelin op0"); same_shape(op1, "MulRelin op1");
+    { std::vector<const Ct*> o(outs.begin(), outs.end()); same_shape(o, "MulRelin outputs"); }
+    const Ct& o0 = *outs[0];
+    const int L = o0.limbs + (rescale_out ? 1 : 0), level = L - 1, n0 = op0[0]->n, n1 = op1[0]->n, nout = o0.n;
+    check_level(level);
+    if (rescale_out && (o0.limbs < 1 || L > nq)) throw Error("cannot Rescale: input Ciphertext already at level 0");
+    if (op0[0]->limbs < L || op1[0]->limbs < L) throw Error("Cannot MulAndRelin: op0 and op1 have different levels");
+    if (n0 > 32 || n1 > 32 || nout > 32) throw Error("mkhe: too many parties");
+    if (!hoist0.empty() && hoist0.size() != B * (size_t)n0) throw Error("mkhe: mul_relin_batch: one hoisted form per party component of op0");
+    if (!hoist1.empty() && hoist1.size() != B * (size_t)n1) throw Error("mkhe: mul_relin_batch: one hoisted form per party component of op1");
+    // out ids = the union of the operand id sets (newCiphertextBinary, mkckks/evaluator.go:306-313)
+    std::vector<int> slot0(n0), slot1(n1);
+    {
+        auto find = [&](int id) { for (int o = 0; o < nout; ++o) if (o0.ids[o] == id) return o; return -1; };
+        std::vector<char> seen(nout, 0);
+        for (int a = 0; a < n0; ++a) { const int o = find(op0[0]->ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); slot0[a] = o; seen[o] = 1; }
+        for (int a = 0; a < n1; ++a) { const int o = find(op1[0]->ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); slot1[a] = o; seen[o] = 1; }
+        for (int o = 0; o < nout; ++o) if (!seen[o]) throw Error("mkhe: ctOut has an id that neither operand has");
+    }
+    for (int a = 0; a < n0; ++a) if (!rlk_d0[a] || !rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+    for (int a = 0; a < n1; ++a) if (!rlk_b1[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+    bool same = hoist0.size() == hoist1.size();          // squares: op1 IS op0 (and its hoisted forms): hoist once
+    for (size_t b = 0; b < B && same; ++b) same = op0[b] == op1[b];
+    for (size_t i = 0; i < hoist0.size() && same; ++i) same = hoist0[i] == hoist1[i];
+    const bool own0 = hoist0.empty(), own1 = hoist1.empty() && !same;
+    const size_t P0 = (size_t)op0[0]->limbs * N, P1 = (size_t)op1[0]->limbs * N, PO = (size_t)L * N, SW = swk_words();
+    const bool fold = n0 >= 1 && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
+    const size_t per_b = (size_t)(2 + n0 + n1) * PO + (size_t)(1 + nout) * PO * ((fold ? 1 : 0) + (rescale_out ? 1 : 0)) + 2 * SW + (size_t)n0 * PO + (size_t)n0 * SW +
+                         (own0 ? (size_t)n0 * SW : 0) + (own1 ? (size_t)n1 * SW : 0);
+    Arena ar(this, B * per_b);
+    std::vector<u64*> nb_(B), tens(B, nullptr), full(B), x(B), y(B), tbuf(B);
+    std::vector<const u64*> h0(B * n0), h1(B * n1);
+    std::vector<u64*> h2(B * n0);
+    {
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (size_t b = 0; b < B; ++b) {
+            nb_[b] = ar.take((size_t)(2 + n0 + n1) * PO);
+            if (fold) tens[b] = ar.take((size_t)(1 + nout) * PO);
+            full[b] = rescale_out ? ar.take((size_t)(1 + nout) * PO) : outs[b]->d;
+            x[b] = ar.take(SW); y[b] = ar.take(SW); tbuf[b] = ar.take((size_t)n0 * PO);
+            for (int a = 0; a < n0; ++a) h2[b * n0 + a] = ar.take(SW);
+            for (int a = 0; a < n0; ++a) {
+                if (own0) { u64* d = ar.take(SW); dsrc.push_back(op0[b]->d + (1 + a) * P0); ddst.push_back(d); h0[b * n0 + a] = d; }
+                else { if (!hoist0[b * n0 + a]) throw Error("mkhe: missing hoisted form"); h0[b * n0 + a] = hoist0[b * n0 + a]->d; }
+            }
+            for (int a = 0; a < n1; ++a) {
+                if (same) h1[b * n1 + a] = h0[b * n0 + a];
+                else if (own1) { u64* d = ar.take(SW); dsrc.push_back(op1[b]->d + (1 + a) * P1); ddst.push_back(d); h1[b * n1 + a] = d; }
+                else { if (!hoist1[b * n1 + a]) throw Error("mkhe: missing hoisted form"); h1[b * n1 + a] = hoist1[b * n1 + a]->d; }
+            }
+        }
+        // hoisting of whatever the caller did not supply (MulRelinNew, mkckks/evaluator.go:416-443): engine-internal digits
+        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst, true);
+    }
+    // ---- step D: tensor product in the NTT domain (keyswitch_hoisted.go:119-144): NTT of every component of both operands, one launch per side
+    for (int side = 0; side < (same ? 1 : 2); ++side) {
+        const std::vector<const Ct*>& ops = side ? op1 : op0;
+        const int n = side ? n1 : n0;
+        for (size_t base = 0; base < B; base += NTT_MAX_ITEMS) {
+            const int cnt = (int)std::min<size_t>(NTT_MAX_ITEMS, B - base);
+            NttBatch b{};
+            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_q_owned(b, L);
+            b.src_inner = b.dst_inner = N; b.src_outer = (long)(side ? P1 : P0); b.dst_outer = (long)PO;
+            b.nitems = cnt; b.outers_per_item = 1 + n; b.nouter = cnt * (1 + n);
+            for (int i = 0; i < cnt; ++i) { b.src_items[i] = ops[base + i]->d; b.dst_items[i] = nb_[base + i] + (side ? (size_t)(1 + n0) * PO : 0); }
+            ntt_fwd_launch(b, false);
+        }
+    }
+    for (size_t b = 0; b < B; ++b) {
+        TensorArgs ta{};
+        ta.a0 = nb_[b]; ta.b0 = same ? nb_[b] : nb_[b] + (size_t)(1 + n0) * PO; ta.out = fold ? tens[b] : full[b]; ta.mods = d_mods;
+        if (fold) ta.scale = d_pmodq;
+        ta.nout = nout; ta.L = L; ta.N = N; ta.with_c0 = 1;
+        for (int a = 0; a < n0; ++a) { const int o = 1 + slot0[a]; ta.a[o] = nb_[b] + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
+        for (int a = 0; a < n1; ++a) { const int o = 1 + slot1[a]; ta.b[o] = (same ? nb_[b] : nb_[b] + (size_t)(1 + n0) * PO) + (size_t)(1 + a) * PO; ta.b_ls[o] = N; }
+        { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + nout)); launch_tensor(ta, s_); }
+        if (!fold) ntt(full[b], full[b], 1 + nout, L, 0, true, false);
+    }
+    // ---- steps B, C: x = MForm(sum_i d_i (.) h(c0_i)), y = MForm(sum_j b_j (.) h(c1_j))   (:79-117)
+    {
+        const int nbt = beta(level), nslots = nslots_qp(level);
+        if (n0 > MAX_TERMS || n1 > MAX_TERMS) throw Error("mkhe: too many parties");
+        for (size_t b = 0; b < B; ++b)
+            for (int side = 1; side >= 0; --side) {
+                const int n = side ? n1 : n0;
+                InnerProductArgs ip{};
+                for (int a = 0; a < n; ++a) { ip.a[a] = (side ? rlk_b1[a] : rlk_d0[a])->d; ip.b[a] = side ? h1[b * n1 + a] : h0[b * n0 + a]; }
+                ip.out = side ? y[b] : x[b]; ip.mods = d_mods; ip.map = map_qp(level);
+                ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nbt; ip.N = N; ip.mform_out = 1;
+                if (n == 0) { MKHE_HIP(hipMemsetAsync(ip.out, 0, SW * sizeof(u64), s_)); continue; }
+                { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nbt * (2.0 * n + 1)); launch_inner_product(ip, s_); }
+            }
+    }
+    // ---- step F1: t_i = <h(c0_i), y>_P (:165-169), every input in one batch; then h(t_i)
+    if (n0) {
+        std::vector<ExtItem> items;
+        for (size_t b = 0; b < B; ++b)
+            for (int a = 0; a < n0; ++a) items.push_back(ExtItem{h0[b * n0 + a], y[b], tbuf[b] + (size_t)a * PO, false});
+        ext_batch(level, items);
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (size_t b = 0; b < B; ++b)
+            for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf[b] + (size_t)a * PO); ddst.push_back(h2[b * n0 + a]); }
+        decompose_batch(level, dsrc, ddst, true);
+    }
+    // ---- steps E, F2: out_j += <h(c1_j), x>_P ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P   (:146-154,173-177); whole operations per call
+    if (2 * n0 + n1 > 0) {
+        const size_t m = (size_t)(2 * n0 + n1), per = std::max<size_t>(1, EXT_MAX_ITEMS / m);
+        for (size_t b0 = 0; b0 < B; b0 += per) {
+            std::vector<ExtItem> items;
+            for (size_t b = b0; b < std::min(B, b0 + per); ++b) {
+                const size_t first = items.size();
+                for (int a = 0; a < n0; ++a) {
+                    items.push_back(ExtItem{h2[b * n0 + a], rlk_v0[a]->d, full[b], true});
+                    items.push_back(ExtItem{h2[b * n0 + a], crs_u.d, full[b] + (size_t)(1 + slot0[a]) * PO, true});
+                }
+                for (int a = 0; a < n1; ++a) items.push_back(ExtItem{h1[b * n1 + a], x[b], full[b] + (size_t)(1 + slot1[a]) * PO, true});
+                if (fold) {
+                    // the tensor term of every output slot (NTT domain, times P) rides on the first product that goes there: ModDown returns it as itself
+                    std::vector<const u64*> seen;
+                    for (size_t i = first; i < items.size(); ++i) {
+                        if (std::find(seen.begin(), seen.end(), items[i].dst) != seen.end()) continue;
+                        seen.push_back(items[i].dst);
+                        items[i].accumulate = false; items[i].qadd = tens[b] + (items[i].dst - full[b]);
+                    }
+                    if ((int)seen.size() != 1 + nout) throw Error("mkhe: internal: an output slot without an external product");
+                }
+            }
+            ext_batch(level, items);
+        }
+    }
+    // ---- the single Rescale of mkckks.Evaluator.mulRelinHoisted (mkckks/evaluator.go:558-581)
+    if (rescale_out)
+        for (size_t b = 0; b < B; ++b)
+            launch_div_round_last(outs[b]->d, full[b], d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, 1 + nout, (long)PO, (long)(level * (size_t)N), s_);
+    MKHE_HIP(hipGetLastError());
+}
+
+void Context::ct_binary_batch(int op, const std::vector<const Ct*>& a, const std::vector<const Ct*>& b, const std::vector<Ct*>& outs) {
+    const size_t B = a.size();
+    if (!B) return;
+    if (b.size() != B || outs.size() != B) throw Error("mkhe: ct_binary_batch: one op1 and one output per op0");
+    same_shape(a, "Add op0"); same_shape(b, "Add op1");
+    { std::vector<const Ct*> o(outs.begin(), outs.end()); same_shape(o, "Add outputs"); }
+    const Ct& A = *a[0]; const Ct& Bc = *b[0]; const Ct& O = *outs[0];
+    const int L = O.limbs;
+    if (A.limbs < L || Bc.limbs < L) throw Error("mkhe: operand level below ctOut level");
+    if (1 + O.n > CTBIN_MAX) throw Error("mkhe: too many parties in one ciphertext");
+    const size_t PA = (size_t)A.limbs * N, PB = (size_t)Bc.limbs * N, PO = (size_t)L * N;
+    auto find = [](const Ct& c, int id) { for (int i = 0; i < c.n; ++i) if (c.ids[i] == id) return i; return -1; };
+    std::vector<int> ia(1 + O.n), ib(1 + O.n);
+    for (int o = -1; o < O.n; ++o) {
+        ia[1 + o] = o < 0 ? 0 : 1 + find(A, O.ids[o]); ib[1 + o] = o < 0 ? 0 : 1 + find(Bc, O.ids[o]);
+        if (o >= 0 && ia[1 + o] == 0 && ib[1 + o] == 0) throw Error("mkhe: ctOut has an id that neither operand has");
+    }
+    const size_t per = std::max<size_t>(1, CTBIN_MAX / (1 + O.n));
+    for (size_t b0 = 0; b0 < B; b0 += per) {
+        CtBinArgs ba{};
+        ba.mods = d_mods; ba.L = L; ba.N = N;
+        double bytes = 0;
+        int c = 0;
+        for (size_t k = b0; k < std::min(B, b0 + per); ++k)
+            for (int o = -1; o < O.n; ++o, ++c) {
+                const bool ha = o < 0 || ia[1 + o] > 0, hb = o < 0 || ib[1 + o] > 0;
+                ba.dst[c] = outs[k]->d + (size_t)(1 + o) * PO;
+                ba.a[c] = ha ? a[k]->d + ia[1 + o] * PA : nullptr;
+                ba.b[c] = hb ? b[k]->d + ib[1 + o] * PB : nullptr;
+                ba.mode[c] = (ha && hb) ? (op == 0 ? 0 : 1) : ha ? 2 : (op == 0 ? 3 : 4);
+                bytes += 8.0 * N * L * ((ha && hb) ? 3 : 2);
+            }
+        ba.ncomp = c;
+        { ProfScope ps(this, PROF_OTHER, bytes); launch_ct_binary(ba, s_); }
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
+}  // namespace mkhe

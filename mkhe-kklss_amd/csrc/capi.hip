@@ -419,6 +419,76 @@ int mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe_
     MKHE_TRY({ mark(ctx, in, out); if (!in || !out || !dev_pt) throw Error("mkhe_ct_mul_ptxt: null argument"); need(ctx)->ct_mul_ptxt(in->c, (const u64*)dev_pt, out->c); })
 }
 
+// ---- B operations of one shape per call (batch.hip)
+static std::vector<const Ct*> ct_list(const mkhe_ctx* ctx, const mkhe_ct* const* v, int n, const char* what) {
+    if (!v) throw Error(std::string(what) + ": null ciphertext list");
+    std::vector<const Ct*> r(n);
+    for (int i = 0; i < n; ++i) { if (!v[i]) throw Error(std::string(what) + ": null ciphertext in the batch"); mark(ctx, v[i]); r[i] = &v[i]->c; }
+    return r;
+}
+static std::vector<Ct*> ct_list_out(const mkhe_ctx* ctx, mkhe_ct* const* v, int n, const char* what) {
+    if (!v) throw Error(std::string(what) + ": null output list");
+    std::vector<Ct*> r(n);
+    for (int i = 0; i < n; ++i) {
+        if (!v[i]) throw Error(std::string(what) + ": null output in the batch");
+        for (int k = 0; k < i; ++k) if (v[k] == v[i]) throw Error(std::string(what) + ": the outputs of a batch must be distinct");
+        mark(ctx, v[i]); r[i] = &v[i]->c;
+    }
+    return r;
+}
+static std::vector<const Swk*> swk_flat(const mkhe_ctx* ctx, const mkhe_swk* const* v, size_t n) {
+    std::vector<const Swk*> r;
+    if (!v) return r;
+    r.resize(n);
+    for (size_t i = 0; i < n; ++i) { if (!v[i]) throw Error("mkhe: null hoisted form in a batch"); mark(ctx, v[i]); r[i] = &v[i]->s; }
+    return r;
+}
+int mkhe_hoisted_form_batch(mkhe_ctx* ctx, int level, int nbatch, const mkhe_ct* const* cts, mkhe_swk* const* out) {
+    MKHE_TRY({
+        if (nbatch < 1) throw Error("mkhe_hoisted_form_batch: empty batch");
+        auto c = ct_list(ctx, cts, nbatch, "mkhe_hoisted_form_batch");
+        const size_t n = (size_t)nbatch * c[0]->n;
+        if (n && !out) throw Error("mkhe_hoisted_form_batch: null argument");
+        std::vector<Swk*> o(n);
+        for (size_t i = 0; i < n; ++i) { if (!out[i]) throw Error("mkhe_hoisted_form_batch: null output handle"); mark(ctx, out[i]); o[i] = &out[i]->s; }
+        need(ctx)->hoisted_form_batch(level, c, o);
+    })
+}
+int mkhe_rotate_batch(mkhe_ctx* ctx, uint64_t galEl, int nbatch, const mkhe_ct* const* in, const mkhe_swk* const* hoist,
+                      const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* const* out) {
+    MKHE_TRY({ mark(ctx, crs);
+        if (nbatch < 1 || !rk || !crs) throw Error("mkhe_rotate_batch: bad argument");
+        auto i = ct_list(ctx, in, nbatch, "mkhe_rotate_batch");
+        auto o = ct_list_out(ctx, out, nbatch, "mkhe_rotate_batch");
+        auto h = swk_flat(ctx, hoist, (size_t)nbatch * i[0]->n);
+        auto k = swk_list(ctx, rk, i[0]->n);
+        need(ctx)->rotate_batch(galEl, i, h, k.data(), crs->s, o);
+    })
+}
+int mkhe_mul_relin_batch(mkhe_ctx* ctx, int nbatch, const mkhe_ct* const* op0, const mkhe_ct* const* op1,
+                         const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
+                         const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0, const mkhe_swk* const* rlk_v0,
+                         const mkhe_swk* crs_u, int rescale, mkhe_ct* const* out) {
+    MKHE_TRY({ mark(ctx, crs_u);
+        if (nbatch < 1 || !crs_u || !rlk_b1 || !rlk_d0 || !rlk_v0) throw Error("mkhe_mul_relin_batch: bad argument");
+        auto a = ct_list(ctx, op0, nbatch, "mkhe_mul_relin_batch");
+        auto b = ct_list(ctx, op1, nbatch, "mkhe_mul_relin_batch");
+        auto o = ct_list_out(ctx, out, nbatch, "mkhe_mul_relin_batch");
+        auto h0 = swk_flat(ctx, hoist0, (size_t)nbatch * a[0]->n); auto h1 = swk_flat(ctx, hoist1, (size_t)nbatch * b[0]->n);
+        auto b1 = swk_list(ctx, rlk_b1, b[0]->n); auto d0 = swk_list(ctx, rlk_d0, a[0]->n); auto v0 = swk_list(ctx, rlk_v0, a[0]->n);
+        need(ctx)->mul_relin_batch(a, b, h0, h1, b1.data(), d0.data(), v0.data(), crs_u->s, rescale != 0, o);
+    })
+}
+int mkhe_ct_binary_batch(mkhe_ctx* ctx, int op, int nbatch, const mkhe_ct* const* op0, const mkhe_ct* const* op1, mkhe_ct* const* out) {
+    MKHE_TRY({
+        if (nbatch < 1 || (op != 0 && op != 1)) throw Error("mkhe_ct_binary_batch: bad argument");
+        auto a = ct_list(ctx, op0, nbatch, "mkhe_ct_binary_batch");
+        auto b = ct_list(ctx, op1, nbatch, "mkhe_ct_binary_batch");
+        auto o = ct_list_out(ctx, out, nbatch, "mkhe_ct_binary_batch");
+        need(ctx)->ct_binary_batch(op, a, b, o);
+    })
+}
+
 // ---- key generation / CRS expansion
 int mkhe_keygen_secret(mkhe_ctx* ctx, const int32_t* s, void* dev_sk) {
     MKHE_TRY({ if (!s || !dev_sk) throw Error("mkhe_keygen_secret: null argument"); need(ctx)->keygen_secret(s, (u64*)dev_sk); })

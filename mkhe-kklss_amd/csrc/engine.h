@@ -116,6 +116,15 @@ class Context {
     void mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
                    const Swk& crs_u, Ct& out);
     void fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform);
+    // ---- B independent operations of one shape as one launch set (batch.hip; small rings: DESIGN.md section 8).  Flat lists: hoisted forms are
+    // [b * n + a] (input b, party component a) or empty (the engine hoists); keys are per party, shared by the inputs.
+    void hoisted_form_batch(int level, const std::vector<const Ct*>& cts, const std::vector<Swk*>& outs);
+    void rotate_batch(u64 galEl, const std::vector<const Ct*>& ins, const std::vector<const Swk*>& hoists, const Swk* const* rk, const Swk& crs,
+                      const std::vector<Ct*>& outs);
+    void mul_relin_batch(const std::vector<const Ct*>& op0, const std::vector<const Ct*>& op1, const std::vector<const Swk*>& hoist0,
+                         const std::vector<const Swk*>& hoist1, const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
+                         const Swk& crs_u, bool rescale_out, const std::vector<Ct*>& outs);
+    void ct_binary_batch(int op, const std::vector<const Ct*>& a, const std::vector<const Ct*>& b, const std::vector<Ct*>& outs);
     u64* pool_x() { return x_; }
     u64* pool_y() { return y_; }
     // batched building blocks (all parties in one launch)
@@ -264,6 +273,7 @@ class Context {
     void ntt_fwd_launch(const NttBatch& b, bool decompose);
     void ntt_inv_launch(NttBatch& b);       // fills in the tables of the H16-class inverse kernel, then launch_ntt_inv
     std::vector<unsigned char> small_q_;                     // per modulus: 34q < 2^63
+    std::vector<unsigned char> small16_;                     // per modulus: 48q < 2^62 -- the short class of the H16 / H32 kernels (ntt16_kernels.hip)
     void ext_core(int level, const u64* ah, const u64* bg, u64* c, bool accumulate);
 
     struct MrPlan {

@@ -105,7 +105,13 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
     for (int i = 0; i < mall; ++i) small_q_.push_back(moduli[i] < (1ull << 62) / 31 ? 1 : 0);
     // the H16 kernel (ntt16_kernels.hip) grows its never-reduced values by up to 1.03q per stage (one-round product): < 4q + 15 * 1.03q
     // < 20q, internal digits leave as x + 24q < 44q -- small-class moduli have to satisfy 48q < 2^62 there
-    for (int i = 0; i < mall; ++i) if (small_q_[i] && moduli[i] >= (1ull << 62) / 48) h16_gap_ = true;
+    // Round 4: a modulus in that gap (31q < 2^62 <= 48q: the head prime 2^57 + 0x2b0001 of cnn's PN14QP433) takes the balanced path of the H16 / H32
+    // kernels as a member of their LONG class instead (partial reductions where its schedule asks for them -- none at this size -- and canonical
+    // outputs): small16_ is the class map those launchers get.  Until then one such prime kept a whole context on the round-1 kernels: every
+    // forward and inverse NTT of the cnn ring (71 us per launch where the H16 family takes 20).  N = 2^16 keeps the old rule: its split launches are
+    // cut into class parts by small_q_ before the H16 sub-transforms see them.
+    for (int i = 0; i < mall; ++i) small16_.push_back(moduli[i] < (1ull << 62) / 48 ? 1 : 0);
+    for (int i = 0; i < mall; ++i) if (logN == 16 && small_q_[i] && !small16_[i]) h16_gap_ = true;
     MKHE_HIP(hipSetDevice(device));
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
@@ -155,7 +161,7 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
         std::vector<u64> p31(2 * (size_t)mall * N), p31n(8 * (size_t)mall, 0);
         for (int i = 0; i < mall; ++i) {
             const u64 q = moduli[i];
-            const bool uc = uclass_on && small_q_[i] && q < (1ull << 62) / 160;
+            const bool uc = uclass_on && small16_[i] && q < (1ull << 62) / 160;
             if (uc) u_mods_ |= 1ull << i;
             const int sh = uc ? 30 : 31;
             const u64 cinv = powmod(powmod(2, 64 - sh, q), q - 2, q), c32 = powmod(2, 32, q);
@@ -523,7 +529,21 @@ void Context::note_use(HandleUsers& u) {
 }
 void Context::pool_free(u64* p, size_t words, const HandleUsers* users) {
     if (!p) return;
-    if (free_list_.size() >= 64) { (void)hipDeviceSynchronize(); (void)hipFree(p); return; }
+    // bound of the cache: entries and bytes.  Batched evaluation (batch.hip) frees and re-creates B output ciphertexts per operation, a few hundred
+    // handles in flight at B = 16: the list is sized for that -- at the old bound of 64 entries every further free was a device-wide
+    // synchronisation plus hipFree, and the next create a hipMalloc (119 ms per batched cnn step instead of 6).  Over the bound the OLDEST entry
+    // goes back to the driver (its work is long done: one synchronisation, rare).
+    {
+        static const size_t cap_entries = 4096, cap_words = (size_t)(getenv("MKHE_POOL_GB") ? atof(getenv("MKHE_POOL_GB")) : 48.0) * (1ull << 27);
+        size_t held = words;
+        for (const auto& f : free_list_) held += f.words;
+        while (!free_list_.empty() && (free_list_.size() >= cap_entries || held > cap_words)) {
+            (void)hipDeviceSynchronize();
+            held -= free_list_.front().words;
+            (void)hipFree(free_list_.front().p);
+            free_list_.erase(free_list_.begin());
+        }
+    }
     FreeEntry e{words, p, {}};
     {
         auto& r = registry(device);
@@ -655,13 +675,13 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     if (ntt32_ok(logN, b)) {
         ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;
-        launch_ntt32_fwd(bt, small_q_.data(), s_);
+        launch_ntt32_fwd(bt, small16_.data(), s_);
         return;
     }
     if (ntt16_ok(logN, b)) {
         ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;
-        launch_ntt16_fwd(bt, small_q_.data(), s_, logN);
+        launch_ntt16_fwd(bt, small16_.data(), s_, logN);
         return;
     }
     if (decompose && ntt_fwd_mixed_ok(logN, b, small_q_.data())) {

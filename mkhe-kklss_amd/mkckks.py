@@ -258,3 +258,145 @@ class Evaluator:
 
 def NewEvaluator(params):
     return Evaluator(params)
+
+
+# ---------------------------------------------------------------- B inputs in lock step (round 4; include/mkhe.h "B independent operations")
+class BatchCiphertext:
+    """B ciphertexts of one shape (same ids, level, scale): what a BatchEvaluator consumes and returns.  cts[b] are ordinary Ciphertexts."""
+
+    def __init__(self, cts):
+        self.cts = list(cts)
+        c0 = self.cts[0]
+        for c in self.cts:
+            if c.ids != c0.ids or c.Level() != c0.Level() or c.Scale != c0.Scale:
+                raise MkheError("BatchCiphertext: the ciphertexts of a batch must have one shape and scale")
+        self.ids, self.Scale, self.params = c0.ids, c0.Scale, c0.params
+
+    def __len__(self): return len(self.cts)
+    def IDSet(self): return set(self.ids)
+    def Level(self): return self.cts[0].Level()
+    def ScalingFactor(self): return self.Scale
+    def download(self): return np.stack([c.download() for c in self.cts])
+
+
+class BatchHoisted:
+    """per input the hoisted forms of its party components (mkrlwe.HoistedCiphertext each)"""
+
+    def __init__(self, hoisted):
+        self.hoisted = list(hoisted)
+
+
+class BatchEvaluator:
+    """The mkckks.Evaluator surface on B inputs at a time: every method takes BatchCiphertexts (or, for an operand that is the same for every
+    input -- the model of cnn -- a plain Ciphertext / HoistedCiphertext, which is broadcast) and issues ONE launch set for the B operations
+    (mkhe_*_batch).  mkhe_kklss_amd.cnn runs on it unchanged.  Scale bookkeeping is the single-input evaluator's (one shape, one scale)."""
+
+    def __init__(self, params, B):
+        self.params, self.B = params, int(B)
+        self.ev = Evaluator(params)
+
+    # -- helpers
+    def _cts(self, op):
+        return op.cts if isinstance(op, BatchCiphertext) else [op] * self.B
+
+    def _new(self, like_ids, level, scale):
+        return BatchCiphertext([NewCiphertext(self.params, like_ids, level, scale, zero=False) for _ in range(self.B)])
+
+    @staticmethod
+    def _h(cts):
+        return handle_array([c.h for c in cts])
+
+    def _hoists(self, hoisted, ops):
+        """flat [b * n + a] handle list, or None"""
+        if hoisted is None:
+            return None
+        hs = hoisted.hoisted if isinstance(hoisted, BatchHoisted) else [hoisted] * self.B
+        return handle_array([hs[b].Value[i].h for b in range(self.B) for i in ops[b].ids])
+
+    # -- HoistedForm (evaluator.go:543-553)
+    def HoistedForm(self, ct):
+        if not isinstance(ct, BatchCiphertext):
+            return self.ev.HoistedForm(ct)
+        hs = []
+        for c in ct.cts:
+            h = mkrlwe.NewHoistedCiphertext()
+            for id in c.ids:
+                h.Value[id] = mkrlwe.SwitchingKey(self.params, zero=False)
+            hs.append(h)
+        check(lib().mkhe_hoisted_form_batch(self.params.ctx, ct.Level(), self.B, self._h(ct.cts),
+                                            handle_array([hs[b].Value[id].h for b in range(self.B) for id in ct.cts[b].ids])))
+        return BatchHoisted(hs)
+
+    # -- AddNew / SubNew (evaluator.go:316-357)
+    def _binary(self, op0, op1, opcode):
+        a, b = self._cts(op0), self._cts(op1)
+        s0, s1 = a[0].ScalingFactor(), b[0].ScalingFactor()
+        if (s1 > s0 and math.floor(s1 / s0) > 1) or (s0 > s1 and math.floor(s0 / s1) > 1):
+            # scale matching multiplies one operand by a constant first (evaluateInPlace :270-292): rare in the circuits this class serves -- per input
+            fn = self.ev.AddNew if opcode == 0 else self.ev.SubNew
+            return BatchCiphertext([fn(a[k], b[k]) for k in range(self.B)])
+        out = self._new(a[0].IDSet() | b[0].IDSet(), min(a[0].Level(), b[0].Level()), max(s0, s1))
+        check(lib().mkhe_ct_binary_batch(self.params.ctx, opcode, self.B, self._h(a), self._h(b), self._h(out.cts)))
+        return out
+
+    def AddNew(self, op0, op1): return self._binary(op0, op1, 0)
+    def SubNew(self, op0, op1): return self._binary(op0, op1, 1)
+
+    # -- MulRelin[Hoisted]New (evaluator.go:416-443,558-581)
+    def MulRelinNew(self, op0, op1, rlkSet):
+        return self.MulRelinHoistedNew(op0, op1, None, None, rlkSet)
+
+    def MulRelinHoistedNew(self, op0, op1, op0Hoisted, op1Hoisted, rlkSet):
+        a, b = self._cts(op0), self._cts(op1)
+        params = self.params
+        level, prod_scale = min(a[0].Level(), b[0].Level()), a[0].ScalingFactor() * b[0].ScalingFactor()
+        if -1 not in params.CRS:
+            raise MkheError("mkhe: CRS[-1] (u) has not been uploaded")
+        nb1, scale1 = self.ev._nb_rescales(level, prod_scale, params.Scale())
+        rescale = nb1 >= 1 and level >= 1
+        ids = a[0].IDSet() | b[0].IDSet()
+        out = self._new(ids, level - 1 if rescale else level, prod_scale / float(params.Q[level]) if rescale else prod_scale)
+        d0 = [rlkSet.GetRelinearizationKey(i).Value[1].h for i in a[0].ids]
+        v0 = [rlkSet.GetRelinearizationKey(i).Value[2].h for i in a[0].ids]
+        b1 = [rlkSet.GetRelinearizationKey(i).Value[0].h for i in b[0].ids]
+        check(lib().mkhe_mul_relin_batch(params.ctx, self.B, self._h(a), self._h(b), self._hoists(op0Hoisted, a), self._hoists(op1Hoisted, b),
+                                         handle_array(b1), handle_array(d0), handle_array(v0), params.CRS[-1].h, 1 if rescale else 0, self._h(out.cts)))
+        if rescale and nb1 > 1:                        # further divisions (not in the circuits of the reference): per input
+            return BatchCiphertext([self.ev.RescaleNew(c, params.Scale()) for c in out.cts])
+        return out
+
+    # -- RotateNew / RotateHoistedNew (evaluator.go:485-525,585-617)
+    def _rotate(self, ct, rotidx, hoisted, rkSet):
+        params = self.params
+        cts = self._cts(ct)
+        out = self._new(cts[0].IDSet(), cts[0].Level(), cts[0].Scale)
+        rk = [rkSet.GetRotationKey(i, rotidx).Value.h for i in cts[0].ids]
+        check(lib().mkhe_rotate_batch(params.ctx, params.GaloisElementForColumnRotationBy(rotidx), self.B, self._h(cts), self._hoists(hoisted, cts),
+                                      handle_array(rk), params.CRS[rotidx].h, self._h(out.cts)))
+        return out
+
+    def RotateNew(self, ct, rotidx, rkSet):
+        rotidx = self.ev._norm_rot(rotidx)
+        if rotidx == 0:
+            return BatchCiphertext([self.ev.RotateNew(c, 0, rkSet) for c in self._cts(ct)])
+        if rotidx in self.params.CRS:
+            return self._rotate(ct, rotidx, None, rkSet)
+        tmp, k = ct, 1
+        while rotidx > 0:                                   # power-of-two decomposition, :516-523
+            if rotidx % 2:
+                tmp = self._rotate(tmp, k, None, rkSet)
+            rotidx //= 2
+            k *= 2
+        return tmp
+
+    def RotateHoistedNew(self, ct, rotidx, ctHoisted, rkSet):
+        rotidx = self.ev._norm_rot(rotidx)
+        if rotidx == 0:
+            return BatchCiphertext([self.ev.RotateNew(c, 0, rkSet) for c in self._cts(ct)])
+        if rotidx not in self.params.CRS:
+            raise MkheError("Hoisted rotation only works for precomputed rotation keys")
+        return self._rotate(ct, rotidx, ctHoisted, rkSet)
+
+    # -- MulPtxtNew (evaluator.go:465-481): once per inference in cnn -- per input
+    def MulPtxtNew(self, ct, pt_value, pt_scale):
+        return BatchCiphertext([self.ev.MulPtxtNew(c, pt_value, pt_scale) for c in self._cts(ct)])

@@ -1,0 +1,172 @@
+"""B inputs in lock step (mkhe_*_batch, mkckks.BatchEvaluator; -m gpu): every output of a batched call equals the single-operation entry
+point's on the same input bit for bit -- which the other GPU tests pin to the oracle -- and one case per operation is compared with the oracle
+directly.  Shapes: hoisted and engine-hoisted operands, squares, an operand broadcast to every input (the model ciphertexts of cnn), batches
+that overflow one launch's item lists (more than 64 external products: several launches per step), and the whole cnn inference on B images."""
+import numpy as np
+import pytest
+
+import harness as H
+import harness_cnn as HC
+
+pytestmark = pytest.mark.gpu
+
+
+class Case:
+    def __init__(self, pset, names, seed):
+        from oracle import oracle as O
+        from mkhe_kklss_amd import mkckks, mkrlwe
+        self.mkckks, self.mkrlwe, self.p, self.names = mkckks, mkrlwe, pset, names
+        self.ks = O.KeySwitcher(pset["logN"], pset["Q"], pset["P"], 2)
+        self.params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"], device=0)
+        self.rng = np.random.default_rng(seed)
+        self.level = len(pset["Q"]) - 1
+        self.rlk_h, self.rlk = {}, mkrlwe.RelinearizationKeySet(self.params)
+        for n in names:
+            k = tuple(H.uniform_swk(self.rng, self.ks) for _ in range(3))
+            self.rlk_h[n] = k
+            self.rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(self.params, n, *k))
+        self.u_h = H.uniform_swk(self.rng, self.ks)
+        self.params.AddCRS(-1, self.u_h)
+        self.rots = [1, 5]
+        self.rk_h, self.rtk, self.crs_h = {}, mkrlwe.RotationKeySet(), {}
+        for r in self.rots:
+            self.crs_h[r] = H.uniform_swk(self.rng, self.ks)
+            self.params.AddCRS(r, self.crs_h[r])
+            for n in names:
+                self.rk_h[(n, r)] = H.uniform_swk(self.rng, self.ks)
+                self.rtk.AddRotationKey(mkrlwe.RotationKey(self.params, r, n, self.rk_h[(n, r)]))
+        self.ev = mkckks.NewEvaluator(self.params)
+
+    def ct(self, ids, level=None):
+        level = self.level if level is None else level
+        h = H.uniform_ct(self.rng, self.ks, len(ids), level + 1)
+        return h, self.mkckks.NewCiphertext(self.params, ids, level, self.p["scale"]).upload(h)
+
+    def batch(self, ids, B, level=None):
+        pairs = [self.ct(ids, level) for _ in range(B)]
+        return [h for h, _ in pairs], self.mkckks.BatchCiphertext([c for _, c in pairs])
+
+
+@pytest.fixture(scope="module")
+def case():
+    return Case(H.small_ckks(12, 4), ["a", "b", "c", "d"], 77)
+
+
+@pytest.mark.parametrize("ids0,ids1,B", [(["a", "b"], ["a", "b"], 3), (["a"], ["b", "c"], 2), (["a", "b", "c", "d"], ["a", "b", "c", "d"], 7), ([], ["a"], 2), (["a", "b"], [], 2)])
+@pytest.mark.parametrize("hoisted", [False, True])
+def test_mul_relin_batch(case, ids0, ids1, B, hoisted):
+    bev = case.mkckks.BatchEvaluator(case.params, B)
+    h0, b0 = case.batch(ids0, B)
+    h1, b1 = case.batch(ids1, B)
+    hh0 = bev.HoistedForm(b0) if hoisted else None
+    hh1 = bev.HoistedForm(b1) if hoisted else None
+    out = bev.MulRelinHoistedNew(b0, b1, hh0, hh1, case.rlk)
+    assert len(out) == B and out.ids == sorted(set(ids0) | set(ids1))
+    for k in range(B):
+        ref = case.ev.MulRelinNew(b0.cts[k], b1.cts[k], case.rlk)
+        assert out.cts[k].Level() == ref.Level() and out.Scale == ref.Scale
+        assert (out.cts[k].download() == ref.download()).all(), k
+    # input 0 against the oracle itself
+    names = out.ids
+    idx = {n: i for i, n in enumerate(names)}
+    _, o = case.ks.mul_and_relin(case.level, [idx[i] for i in ids0], h0[0], [idx[i] for i in ids1], h1[0], {idx[n]: case.rlk_h[n] for n in names}, case.u_h)
+    nb, _ = case.ks.ckks_nb_rescales(case.level, case.p["scale"] ** 2, case.p["scale"])
+    o = np.stack([case.ks.ringQ.div_round_last_many(o[s], nb)[0] for s in range(o.shape[0])])
+    assert (out.cts[0].download() == o).all()
+
+
+def test_square_and_broadcast_operand(case):
+    B = 4
+    bev = case.mkckks.BatchEvaluator(case.params, B)
+    _, b0 = case.batch(["a", "c"], B)
+    hb = bev.HoistedForm(b0)
+    sq = bev.MulRelinHoistedNew(b0, b0, hb, hb, case.rlk)                     # squares: op1 is op0
+    _, model = case.ct(["b"])                                                 # one ciphertext for every input (cnn's kernels / weights)
+    hm = case.ev.HoistedForm(model)
+    pr = bev.MulRelinHoistedNew(b0, model, hb, hm, case.rlk)
+    pr2 = bev.MulRelinNew(b0, model, case.rlk)
+    for k in range(B):
+        assert (sq.cts[k].download() == case.ev.MulRelinNew(b0.cts[k], b0.cts[k], case.rlk).download()).all()
+        ref = case.ev.MulRelinNew(b0.cts[k], model, case.rlk).download()
+        assert (pr.cts[k].download() == ref).all() and (pr2.cts[k].download() == ref).all()
+    s = bev.AddNew(pr, pr2)                                                   # batch + batch
+    t = bev.SubNew(sq, bev.AddNew(sq, sq))
+    for k in range(B):
+        assert (s.cts[k].download() == case.ev.AddNew(pr.cts[k], pr2.cts[k]).download()).all()
+        assert (t.cts[k].download() == case.ev.SubNew(sq.cts[k], case.ev.AddNew(sq.cts[k], sq.cts[k])).download()).all()
+    # a batch plus ONE ciphertext with other ids (cnn's bias): the union of the id sets, components copied
+    _, bias = case.ct(["d"], level=sq.Level())
+    w = bev.AddNew(sq, bias)
+    for k in range(B):
+        assert (w.cts[k].download() == case.ev.AddNew(sq.cts[k], bias).download()).all()
+
+
+@pytest.mark.parametrize("ids,B", [(["a", "b"], 3), (["a", "b", "c", "d"], 9), (["c"], 2)])
+@pytest.mark.parametrize("hoisted", [False, True])
+def test_rotate_batch(case, ids, B, hoisted):
+    bev = case.mkckks.BatchEvaluator(case.params, B)
+    hs, b = case.batch(ids, B)
+    hb = bev.HoistedForm(b) if hoisted else None
+    for r in case.rots:
+        out = bev.RotateHoistedNew(b, r, hb, case.rtk) if hoisted else bev.RotateNew(b, r, case.rtk)
+        for k in range(B):
+            assert (out.cts[k].download() == case.ev.RotateNew(b.cts[k], r, case.rtk).download()).all(), (r, k)
+        o = case.ks.rotate(case.level, pow(5, r, 2 << case.p["logN"]), list(range(len(ids))), hs[B - 1], [case.rk_h[(n, r)] for n in sorted(ids)], case.crs_h[r])
+        assert (out.cts[B - 1].download() == o).all()
+    # 6 = 5 + 1 is not a CRS index: RotateNew decomposes it (evaluator.go:516-523) -- here 6 = 2 + 4 has no keys, so use what exists: rotation by 0
+    z = bev.RotateNew(b, 0, case.rtk)
+    for k in range(B):
+        assert (z.cts[k].download() == b.cts[k].download()).all()
+
+
+def test_hoisted_form_batch_matches_decompose(case):
+    B = 5
+    bev = case.mkckks.BatchEvaluator(case.params, B)
+    hs, b = case.batch(["a", "d"], B, level=2)
+    hb = bev.HoistedForm(b)
+    beta = case.ks.beta(2)
+    act = [0, 1, 2] + [len(case.p["Q"]) + j for j in range(len(case.p["P"]))]
+    for k in range(B):
+        for i, n in enumerate(["a", "d"]):
+            ref = case.ks.decompose(2, hs[k][1 + i])
+            got = hb.hoisted[k].Value[n].download()
+            assert (got[:beta][:, act] == ref[:beta][:, act]).all(), (k, n)
+
+
+def test_batch_shape_errors(case):
+    from mkhe_kklss_amd._abi import MkheError
+    bev = case.mkckks.BatchEvaluator(case.params, 2)
+    _, c0 = case.ct(["a"])
+    _, c1 = case.ct(["b"])
+    with pytest.raises(MkheError):
+        case.mkckks.BatchCiphertext([c0, c1])
+    _, b = case.batch(["a"], 2)
+    with pytest.raises(MkheError):
+        bev.RotateNew(b, 5, case.mkrlwe.RotationKeySet())                     # no rotation key
+    out = bev.RotateNew(b, 1, case.rtk)                                       # the context is usable after the error
+    assert (out.cts[1].download() == case.ev.RotateNew(b.cts[1], 1, case.rtk).download()).all()
+
+
+TWO = dict(image="dataOwner", kernels="modelOwner", fc1="modelOwner", fc2="modelOwner")
+FOUR = dict(image="dataOwner", kernels="convOwner", fc1="fc1Owner", fc2="fc2Owner")
+
+
+@pytest.mark.parametrize("owners,B", [(TWO, 3), (FOUR, 8)], ids=["2party_B3", "4party_B8"])
+def test_cnn_inference_on_a_batch_of_images(owners, B):
+    """cnn/cnn.go on B images at once: every image's output ciphertext equals its own single-image inference bit for bit, and image 0 decrypts
+    to the plaintext network's logits"""
+    from mkhe_kklss_amd import cnn, mkckks
+    sc = HC.CnnScenario(owners, seed=11)
+    models = [HC.synthetic_model(20 + k) for k in range(B)]
+    m0 = sc.encrypt_model(models[0])                                          # the model: one for all images
+    imgs = [sc.encrypt(HC.pack_image(m), owners["image"]) for m in models]
+    pt, pt_scale = sc.mask_plaintext(sc.level - 4)
+    bev = mkckks.BatchEvaluator(sc.params, B)
+    out = cnn.Inference(bev, sc.rlkSet, sc.rtkSet, mkckks.BatchCiphertext(imgs), m0["ctKernels"], m0["ctFC1"], m0["ctFC2"], m0["ctB1"], m0["ctB2"], pt, pt_scale)
+    assert len(out) == B and out.Level() == 0
+    for k in range(B):
+        ref = cnn.Inference(sc.eval, sc.rlkSet, sc.rtkSet, imgs[k], m0["ctKernels"], m0["ctFC1"], m0["ctFC2"], m0["ctB1"], m0["ctB2"], pt, pt_scale)
+        assert out.cts[k].Scale == ref.Scale and (out.cts[k].download() == ref.download()).all(), k
+    got = sc.decrypt(out.cts[0])[:HC.NCLS]
+    exp = HC.plain_forward(models[0])
+    assert int(np.argmax(got.real)) == int(np.argmax(exp)) and np.abs(got.real - exp).max() < 1e-3 * max(1.0, np.abs(exp).max())
