@@ -227,6 +227,13 @@ int  mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe
  *        mkhe_mul_relin_batch    : KeySwitcher.MulAndRelin[Hoisted] (+ the single Rescale of mkckks.Evaluator.mulRelinHoisted when rescale != 0:
  *                                  out is then one level below the product)     keyswitch_hoisted.go:44-179, mkckks/evaluator.go:558-581
  *        mkhe_ct_binary_batch    : op 0 = AddNew, 1 = SubNew               mkckks/evaluator.go:316-356 */
+/*      Handles for a batch in one call: nbatch ciphertexts of one shape (contents undefined, like mkhe_ct_create_uninit) / count switching keys,
+ *      views into ONE pooled block that is returned when the last of them has been destroyed (one by one with mkhe_ct_destroy / mkhe_swk_destroy, or
+ *      all of them with the *_destroy_batch calls). */
+int  mkhe_ct_create_batch(mkhe_ctx* ctx, int nbatch, int n, const int* ids, int limbs, mkhe_ct** out);
+void mkhe_ct_destroy_batch(mkhe_ctx* ctx, int nbatch, mkhe_ct* const* cts);
+int  mkhe_swk_create_batch(mkhe_ctx* ctx, int count, mkhe_swk** out);
+void mkhe_swk_destroy_batch(mkhe_ctx* ctx, int count, mkhe_swk* const* swks);
 int  mkhe_hoisted_form_batch(mkhe_ctx* ctx, int level, int nbatch, const mkhe_ct* const* cts, mkhe_swk* const* out);
 int  mkhe_rotate_batch(mkhe_ctx* ctx, uint64_t galEl, int nbatch, const mkhe_ct* const* in, const mkhe_swk* const* hoist,
                        const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* const* out);

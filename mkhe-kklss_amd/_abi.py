@@ -75,6 +75,10 @@ SIGNATURES = {
     "mkhe_ct_sub": (C.c_int, [vp, vp, vp, vp]),
     "mkhe_ct_mul_const": (C.c_int, [vp, vp, u64p, u64p, vp]),
     "mkhe_ct_mul_ptxt": (C.c_int, [vp, vp, vp, vp]),
+    "mkhe_ct_create_batch": (C.c_int, [vp, C.c_int, C.c_int, i32p, C.c_int, vpp]),
+    "mkhe_ct_destroy_batch": (None, [vp, C.c_int, vpp]),
+    "mkhe_swk_create_batch": (C.c_int, [vp, C.c_int, vpp]),
+    "mkhe_swk_destroy_batch": (None, [vp, C.c_int, vpp]),
     "mkhe_hoisted_form_batch": (C.c_int, [vp, C.c_int, C.c_int, vpp, vpp]),
     "mkhe_rotate_batch": (C.c_int, [vp, C.c_uint64, C.c_int, vpp, vpp, vpp, vp, vpp]),
     "mkhe_mul_relin_batch": (C.c_int, [vp, C.c_int, vpp, vpp, vpp, vpp, vpp, vpp, vpp, vp, C.c_int, vpp]),

@@ -174,30 +174,52 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
             ntt_fwd_launch(b, false);
         }
     }
-    for (size_t b = 0; b < B; ++b) {
-        TensorArgs ta{};
-        ta.a0 = nb_[b]; ta.b0 = same ? nb_[b] : nb_[b] + (size_t)(1 + n0) * PO; ta.out = fold ? tens[b] : full[b]; ta.mods = d_mods;
-        if (fold) ta.scale = d_pmodq;
-        ta.nout = nout; ta.L = L; ta.N = N; ta.with_c0 = 1;
-        for (int a = 0; a < n0; ++a) { const int o = 1 + slot0[a]; ta.a[o] = nb_[b] + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
-        for (int a = 0; a < n1; ++a) { const int o = 1 + slot1[a]; ta.b[o] = (same ? nb_[b] : nb_[b] + (size_t)(1 + n0) * PO) + (size_t)(1 + a) * PO; ta.b_ls[o] = N; }
-        { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + nout)); launch_tensor(ta, s_); }
-        if (!fold) ntt(full[b], full[b], 1 + nout, L, 0, true, false);
+    {
+        // (the temporaries of the inputs sit at one stride in the arena: ONE tensor launch for the batch when the term stays in the NTT domain)
+        const long stride = B > 1 ? (long)(nb_[1] - nb_[0]) : 0;
+        const bool one = fold && B > 1 && (rescale_out || true);
+        for (size_t b = 0; b < (one ? 1 : B); ++b) {
+            TensorArgs ta{};
+            ta.a0 = nb_[b]; ta.b0 = same ? nb_[b] : nb_[b] + (size_t)(1 + n0) * PO; ta.out = fold ? tens[b] : full[b]; ta.mods = d_mods;
+            if (fold) ta.scale = d_pmodq;
+            ta.nout = nout; ta.L = L; ta.N = N; ta.with_c0 = 1;
+            if (one) { ta.nbatch = (int)B; ta.in_batch = stride; ta.out_batch = (long)(tens[1] - tens[0]); }
+            for (int a = 0; a < n0; ++a) { const int o = 1 + slot0[a]; ta.a[o] = nb_[b] + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
+            for (int a = 0; a < n1; ++a) { const int o = 1 + slot1[a]; ta.b[o] = (same ? nb_[b] : nb_[b] + (size_t)(1 + n0) * PO) + (size_t)(1 + a) * PO; ta.b_ls[o] = N; }
+            { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + nout) * (one ? B : 1)); launch_tensor(ta, s_); }
+            if (!fold) ntt(full[b], full[b], 1 + nout, L, 0, true, false);
+        }
     }
-    // ---- steps B, C: x = MForm(sum_i d_i (.) h(c0_i)), y = MForm(sum_j b_j (.) h(c1_j))   (:79-117)
+    // ---- steps B, C: x = MForm(sum_i d_i (.) h(c0_i)), y = MForm(sum_j b_j (.) h(c1_j))   (:79-117): one launch per side for up to sixteen inputs
     {
         const int nbt = beta(level), nslots = nslots_qp(level);
         if (n0 > MAX_TERMS || n1 > MAX_TERMS) throw Error("mkhe: too many parties");
-        for (size_t b = 0; b < B; ++b)
-            for (int side = 1; side >= 0; --side) {
-                const int n = side ? n1 : n0;
+        for (int side = 1; side >= 0; --side) {
+            const int n = side ? n1 : n0;
+            if (n == 0) { for (size_t b = 0; b < B; ++b) MKHE_HIP(hipMemsetAsync(side ? y[b] : x[b], 0, SW * sizeof(u64), s_)); continue; }
+            if (n <= IPB_MAX_TERMS) {
+                for (size_t b0 = 0; b0 < B; b0 += IPB_MAX_BATCH) {
+                    const int cnt = (int)std::min<size_t>(IPB_MAX_BATCH, B - b0);
+                    InnerProductBatchArgs ip{};
+                    for (int a = 0; a < n; ++a) ip.a[a] = (side ? rlk_b1[a] : rlk_d0[a])->d;
+                    for (int k = 0; k < cnt; ++k) {
+                        for (int a = 0; a < n; ++a) ip.b[k][a] = side ? h1[(b0 + k) * n1 + a] : h0[(b0 + k) * n0 + a];
+                        ip.out[k] = side ? y[b0 + k] : x[b0 + k];
+                    }
+                    ip.mods = d_mods; ip.map = map_qp(level); ip.term_outer = ip.out_outer = (long)mtot * N;
+                    ip.nterms = n; ip.nslots = nslots; ip.nouter = nbt; ip.N = N; ip.nbatch = cnt; ip.mform_out = 1;
+                    { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nbt * (2.0 * n + 1) * cnt); launch_inner_product_batch(ip, s_); }
+                }
+                continue;
+            }
+            for (size_t b = 0; b < B; ++b) {
                 InnerProductArgs ip{};
                 for (int a = 0; a < n; ++a) { ip.a[a] = (side ? rlk_b1[a] : rlk_d0[a])->d; ip.b[a] = side ? h1[b * n1 + a] : h0[b * n0 + a]; }
                 ip.out = side ? y[b] : x[b]; ip.mods = d_mods; ip.map = map_qp(level);
                 ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nbt; ip.N = N; ip.mform_out = 1;
-                if (n == 0) { MKHE_HIP(hipMemsetAsync(ip.out, 0, SW * sizeof(u64), s_)); continue; }
                 { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nbt * (2.0 * n + 1)); launch_inner_product(ip, s_); }
             }
+        }
     }
     // ---- step F1: t_i = <h(c0_i), y>_P (:165-169), every input in one batch; then h(t_i)
     if (n0) {
@@ -210,7 +232,12 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
             for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf[b] + (size_t)a * PO); ddst.push_back(h2[b * n0 + a]); }
         decompose_batch(level, dsrc, ddst, true);
     }
-    // ---- steps E, F2: out_j += <h(c1_j), x>_P ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P   (:146-154,173-177); whole operations per call
+    // ---- steps E, F2: out_j += <h(c1_j), x>_P ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P   (:146-154,173-177); whole operations per call.
+    // With the tensor term folded in, every polynomial of a product is written exactly once by the merged ModDown of its call: the single
+    // Rescale of mkckks.Evaluator.mulRelinHoisted rides on that store (Context::rs_maps_) and the product itself is never written.
+    rs_maps_.clear();
+    if (rescale_out && fold)
+        for (size_t b = 0; b < B; ++b) rs_maps_.push_back(RsMap{full[b], outs[b]->d, 1 + nout, o0.limbs, false});
     if (2 * n0 + n1 > 0) {
         const size_t m = (size_t)(2 * n0 + n1), per = std::max<size_t>(1, EXT_MAX_ITEMS / m);
         for (size_t b0 = 0; b0 < B; b0 += per) {
@@ -237,9 +264,12 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
         }
     }
     // ---- the single Rescale of mkckks.Evaluator.mulRelinHoisted (mkckks/evaluator.go:558-581)
+    std::vector<char> rescaled(B, 0);
+    for (size_t b = 0; b < rs_maps_.size(); ++b) rescaled[b] = rs_maps_[b].done ? 1 : 0;
+    rs_maps_.clear();
     if (rescale_out)
         for (size_t b = 0; b < B; ++b)
-            launch_div_round_last(outs[b]->d, full[b], d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, 1 + nout, (long)PO, (long)(level * (size_t)N), s_);
+            if (!rescaled[b]) launch_div_round_last(outs[b]->d, full[b], d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, 1 + nout, (long)PO, (long)(level * (size_t)N), s_);
     MKHE_HIP(hipGetLastError());
 }
 

@@ -7,8 +7,28 @@
 using namespace mkhe;
 
 struct mkhe_ctx { Context* c; };
-struct mkhe_swk { Swk s; mutable HandleUsers users; };
-struct mkhe_ct { Ct c; mutable HandleUsers users; };
+// handles created in one call (mkhe_ct_create_batch / mkhe_swk_create_batch) are views into ONE pooled block, which goes back to the pool when the last
+// of them is destroyed -- behind the uses of all of them
+struct mkhe_block { u64* base; size_t words; int refs; HandleUsers users; };
+struct mkhe_swk { Swk s; mutable HandleUsers users; mkhe_block* blk = nullptr; };
+struct mkhe_ct { Ct c; mutable HandleUsers users; mkhe_block* blk = nullptr; };
+static mkhe_block* block_new(Context* c, size_t words, int refs) {
+    mkhe_block* b = new mkhe_block();
+    b->words = words; b->refs = refs; b->base = nullptr;
+    try { b->base = c->pool_alloc(words); } catch (...) { delete b; throw; }
+    return b;
+}
+static void block_release(mkhe_ctx* ctx, mkhe_block* b, const HandleUsers& u) {
+    for (const auto& e : u.v) {
+        bool found = false;
+        for (auto& f : b->users.v) if (f.first == e.first) { if (e.second > f.second) f.second = e.second; found = true; }
+        if (!found) b->users.v.push_back(e);
+    }
+    b->users.exposed = b->users.exposed || u.exposed;
+    if (--b->refs > 0) return;
+    if (ctx) ctx->c->pool_free(b->base, b->words, &b->users); else (void)hipFree(b->base);
+    delete b;
+}
 struct mkhe_graph { hipGraphExec_t exec; };
 
 static thread_local std::string g_err;
@@ -113,8 +133,22 @@ int mkhe_swk_create(mkhe_ctx* ctx, mkhe_swk** out) { MKHE_TRY(swk_create(ctx, ou
 int mkhe_swk_create_uninit(mkhe_ctx* ctx, mkhe_swk** out) { MKHE_TRY(swk_create(ctx, out, false)) }
 void mkhe_swk_destroy(mkhe_ctx* ctx, mkhe_swk* swk) {
     if (!swk) return;
-    if (swk->s.d && swk->s.owned) { if (ctx) ctx->c->pool_free(swk->s.d, ctx->c->swk_words(), &swk->users); else (void)hipFree(swk->s.d); }
+    if (swk->blk) block_release(ctx, swk->blk, swk->users);
+    else if (swk->s.d && swk->s.owned) { if (ctx) ctx->c->pool_free(swk->s.d, ctx->c->swk_words(), &swk->users); else (void)hipFree(swk->s.d); }
     delete swk;
+}
+int mkhe_swk_create_batch(mkhe_ctx* ctx, int count, mkhe_swk** out) {
+    MKHE_TRY({
+        Context* c = need(ctx);
+        if (!out || count < 1) throw Error("mkhe_swk_create_batch: bad argument");
+        MKHE_HIP(hipSetDevice(c->device));
+        mkhe_block* b = block_new(c, (size_t)count * c->swk_words(), count);
+        for (int i = 0; i < count; ++i) { mkhe_swk* s = new mkhe_swk(); s->s.d = b->base + (size_t)i * c->swk_words(); s->s.owned = false; s->blk = b; out[i] = s; }
+    })
+}
+void mkhe_swk_destroy_batch(mkhe_ctx* ctx, int count, mkhe_swk* const* swks) {
+    if (!swks) return;
+    for (int i = 0; i < count; ++i) mkhe_swk_destroy(ctx, swks[i]);
 }
 int mkhe_swk_upload(mkhe_ctx* ctx, mkhe_swk* swk, const uint64_t* host) {
     MKHE_TRY({ mark(ctx, swk);
@@ -171,8 +205,29 @@ static void ct_create(mkhe_ctx* ctx, int n, const int* ids, int limbs, bool zero
 extern "C" {
 void mkhe_ct_destroy(mkhe_ctx* ctx, mkhe_ct* ct) {
     if (!ct) return;
-    if (ct->c.d) { if (ctx) ctx->c->pool_free(ct->c.d, (size_t)(1 + ct->c.n) * ct->c.limbs * ctx->c->N, &ct->users); else (void)hipFree(ct->c.d); }
+    if (ct->blk) block_release(ctx, ct->blk, ct->users);
+    else if (ct->c.d) { if (ctx) ctx->c->pool_free(ct->c.d, (size_t)(1 + ct->c.n) * ct->c.limbs * ctx->c->N, &ct->users); else (void)hipFree(ct->c.d); }
     delete ct;
+}
+int mkhe_ct_create_batch(mkhe_ctx* ctx, int nbatch, int n, const int* ids, int limbs, mkhe_ct** out) {
+    MKHE_TRY({
+        Context* c = need(ctx);
+        if (!out || nbatch < 1 || (n > 0 && !ids)) throw Error("mkhe_ct_create_batch: bad argument");
+        if (n < 0 || n > 32 || limbs < 1 || limbs > c->nq) throw Error("mkhe_ct_create_batch: bad shape");
+        for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) if (ids[i] == ids[j]) throw Error("mkhe_ct_create_batch: repeated id");
+        MKHE_HIP(hipSetDevice(c->device));
+        const size_t w = (size_t)(1 + n) * limbs * c->N;
+        mkhe_block* b = block_new(c, (size_t)nbatch * w, nbatch);
+        for (int k = 0; k < nbatch; ++k) {
+            mkhe_ct* t = new mkhe_ct();
+            t->c.n = n; t->c.limbs = limbs; t->c.ids.assign(ids, ids + n); t->c.d = b->base + (size_t)k * w; t->blk = b;
+            out[k] = t;
+        }
+    })
+}
+void mkhe_ct_destroy_batch(mkhe_ctx* ctx, int nbatch, mkhe_ct* const* cts) {
+    if (!cts) return;
+    for (int k = 0; k < nbatch; ++k) mkhe_ct_destroy(ctx, cts[k]);
 }
 int mkhe_ct_upload(mkhe_ctx* ctx, mkhe_ct* ct, const uint64_t* host) {
     MKHE_TRY({ mark(ctx, ct);

@@ -240,7 +240,10 @@ class Context {
     u64* rbuf_ = nullptr;  size_t rbuf_words_ = 0;          // BFV: operands over R, their NTTs, tensor output
     u64* c1b_ = nullptr;   size_t c1b_words_ = 0;           // batched ks.Pool[1]
     u64* tbuf_ = nullptr;  size_t tbuf_words_ = 0;          // t_i of step F
-    Ct* rs_out_ = nullptr; const u64* rs_full_ = nullptr; bool rs_done_ = false;      // mul_relin_rescale: the rescaled output, the base of the (unwritten) product, "the ModDown did it"
+    // mul_relin_rescale / mul_relin_batch: Rescale folded into the store of the last merged ModDown.  One entry per product that is not to be
+    // written: its (unwritten) base, the rescaled output one level down, its polynomials; `done` once a launch has covered all of them
+    struct RsMap { const u64* full; u64* out; int npolys; int out_limbs; bool done; };
+    std::vector<RsMap> rs_maps_;
     u64* spreadbuf_ = nullptr; size_t spreadbuf_words_ = 0;  // N = 2^16: staging of the spread digits (decompose_batch), so that the sub-transforms run out of place
     u64* tens_ = nullptr;  size_t tens_words_ = 0;          // tensor term kept in the NTT domain (times P) for the merged E / F2 batch
     // key generation scratch: uploaded samples, gadget constants (slot 0: mkrlwe gadget, 1: caller's), permuted secret

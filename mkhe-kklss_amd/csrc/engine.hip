@@ -594,7 +594,7 @@ void Context::join_side(int k) { if (!overlap) return; MKHE_HIP(hipStreamWaitEve
 void Context::recover() {
     s_ = stream;
     plan_.valid = false; plan_.x_pending = false; plan_.head_done = false; plan_.xkeys.clear(); ext_xout_ = ext_xout2_ = nullptr;
-    rs_out_ = nullptr; rs_full_ = nullptr; rs_done_ = false;
+    rs_maps_.clear();
     bfv_plan_valid_ = false; bfv_xk1_.clear(); bfv_xk2_.clear();
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cs);
@@ -984,19 +984,31 @@ void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 g
             bytes += 8.0 * N * ((level + 1) * (mp->accumulate[v] ? 3.0 : 2.0) + np * mp->cnt[v]);
         }
         md.galEl = galEl; md.logN = logN;
-        if (rs_out_ && !galEl && level >= 1) {
-            // fused Rescale (mul_relin_rescale): possible when this launch is the only writer of every destination
+        if (!rs_maps_.empty() && !galEl && level >= 1) {
+            // fused Rescale (mul_relin_rescale, mul_relin_batch): possible when this launch is the only writer of every polynomial of the products it
+            // touches -- every destination inside a registered product, on a polynomial boundary, written once, all polynomials of the product present
+            const size_t PF = (size_t)(level + 1) * N;
             bool ok = true;
+            std::vector<int> which(mp->nvi, -1), cover(rs_maps_.size(), 0);
             for (int v = 0; v < mp->nvi && ok; ++v) {
-                ok = !mp->accumulate[v] && !mp->addend[v] && mp->dst[v] >= rs_full_ && mp->dst[v] < rs_full_ + (size_t)(1 + rs_out_->n) * (level + 1) * N &&
-                     (size_t)(mp->dst[v] - rs_full_) % ((size_t)(level + 1) * N) == 0 && level + 1 == rs_out_->limbs + 1;
+                ok = !mp->accumulate[v] && !mp->addend[v];
+                for (size_t m = 0; m < rs_maps_.size() && ok && which[v] < 0; ++m) {
+                    const RsMap& r = rs_maps_[m];
+                    if (!r.done && r.out_limbs == level && mp->dst[v] >= r.full && mp->dst[v] < r.full + (size_t)r.npolys * PF &&
+                        (size_t)(mp->dst[v] - r.full) % PF == 0) which[v] = (int)m;
+                }
+                ok = ok && which[v] >= 0;
                 for (int w = 0; w < v && ok; ++w) ok = mp->dst[w] != mp->dst[v];
+                if (ok) ++cover[which[v]];
             }
-            if (ok && mp->nvi == 1 + rs_out_->n) {
+            for (size_t m = 0; m < rs_maps_.size() && ok; ++m) ok = cover[m] == 0 || cover[m] == rs_maps_[m].npolys;
+            if (ok) {
                 md.rescale_row = d_rescale + (size_t)(level - 1) * nq;
-                for (int v = 0; v < mp->nvi; ++v)
-                    md.rdst[v] = rs_out_->d + (size_t)(mp->dst[v] - rs_full_) / ((size_t)(level + 1) * N) * ((size_t)level * N);
-                rs_done_ = true;
+                for (int v = 0; v < mp->nvi; ++v) {
+                    RsMap& r = rs_maps_[which[v]];
+                    md.rdst[v] = r.out + (size_t)(mp->dst[v] - r.full) / PF * ((size_t)level * N);
+                    r.done = true;
+                }
             }
         }
         { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_merged(md, s_); }
@@ -1061,13 +1073,14 @@ void Context::mul_relin_rescale(const Ct& op0, const Ct& op1, const Swk* const* 
     const size_t words = (size_t)(1 + out.n) * L * N;
     full.d = pool_alloc(words);
     static const int fuse_env = getenv("MKHE_FUSE_RESCALE") ? atoi(getenv("MKHE_FUSE_RESCALE")) : 1;
-    rs_out_ = fuse_env && !masked_ ? &out : nullptr; rs_full_ = full.d; rs_done_ = false;
+    rs_maps_.clear();
+    if (fuse_env && !masked_) rs_maps_.push_back(RsMap{full.d, out.d, 1 + out.n, out.limbs, false});
     try {
         mul_and_relin(op0, op1, hoist0, hoist1, rlk_b1, rlk_d0, rlk_v0, crs_u, full);
-        const bool done = rs_done_;
-        rs_out_ = nullptr; rs_full_ = nullptr; rs_done_ = false;
+        const bool done = !rs_maps_.empty() && rs_maps_[0].done;
+        rs_maps_.clear();
         if (!done) rescale(full, 1, out);
-    } catch (...) { rs_out_ = nullptr; rs_full_ = nullptr; rs_done_ = false; const HandleUsers none; pool_free(full.d, words, &none); throw; }
+    } catch (...) { rs_maps_.clear(); const HandleUsers none; pool_free(full.d, words, &none); throw; }
     // the temporary never left this context (no handle, no other context can have work queued on it): an EMPTY user list, so that the pool does
     // not order its next user behind every live context (users == nullptr means "unknown": the forks of the cnn evaluation would serialise)
     const HandleUsers none;

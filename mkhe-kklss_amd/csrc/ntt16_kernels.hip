@@ -1443,9 +1443,13 @@ void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
 // inverse: launches of at least MKHE_NTT16_INV_MIN one-pass jobs (2^14 points each); the caller (launch_ntt_inv) runs the cross stages of
 // N = 2^15 / 2^16 behind it.  b.psi31 / b.psi are the INVERSE tables here, b.inv31c the pairs of the last stage.
 bool ntt16_inv_ok(int logN, const NttBatch& b) {
-    static const int on = env_int16("MKHE_NTT16_INV", 1), minj = env_int16("MKHE_NTT16_INV_MIN", 256);
+    static const int on = env_int16("MKHE_NTT16_INV", 1), minj = env_int16("MKHE_NTT16_INV_MIN", 256), minj14 = env_int16("MKHE_NTT14_INV_MIN", 129);
     if (!on || b.no_h16 || !b.psi31 || !b.inv31c || b.split || b.nslots > 64 || logN < 14 || logN > 16) return false;
     const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;
+    // N = 2^14 (round 4): up to 128 limbs run as LDS sub-transforms (launch_ntt_inv), everything above comes here -- between 129 and 255 limbs
+    // the launch used to fall to the round-1 register kernel, 69 us per launch whatever its size: the batched evaluation of the small rings
+    // (batch.hip) lives in exactly that range
+    if (logN == 14) return limbs >= minj14 && b.nslots * b.nouter < 65536;
     return (limbs << (logN - 14)) >= minj && b.nslots * b.nouter < 65536;
 }
 void launch_ntt16_inv(const NttBatch& b, hipStream_t st, int logN) {

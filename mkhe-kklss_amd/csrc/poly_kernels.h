@@ -29,6 +29,19 @@ struct InnerProductArgs {
                              // MulCoeffsMontgomeryAndAddLvl onto a pool vector, mkbfv/keyswitch.go:160-189
 };
 void launch_inner_product(const InnerProductArgs& a, hipStream_t st);
+// The same sums for up to IPB_MAX_BATCH independent inputs in ONE launch (batch.hip): the keys a[t] are shared, every input has its own
+// digit vectors b[input][t] and its own output; nterms <= IPB_MAX_TERMS.
+constexpr int IPB_MAX_TERMS = 8, IPB_MAX_BATCH = 16;
+struct InnerProductBatchArgs {
+    const u64* a[IPB_MAX_TERMS];
+    const u64* b[IPB_MAX_BATCH][IPB_MAX_TERMS];
+    u64* out[IPB_MAX_BATCH];
+    const Mod* mods;
+    const int* map;
+    long term_outer, out_outer;
+    int nterms, nslots, nouter, N, nbatch, mform_out;
+};
+void launch_inner_product_batch(const InnerProductBatchArgs& a, hipStream_t st);
 
 // ModDownQPtoQ (mkrlwe/basis_extension.go:192-232 = lattigo Baseconverter.ModDownQPtoQ) on
 // coefficient-domain lazy inputs, optionally accumulated into dst (ringQ.AddLvl).
@@ -172,6 +185,8 @@ struct TensorArgs {
     const int* map;            // [L] modulus index of limb l (NULL: l itself)          -- ring R of mkbfv
     const u64* scale;          // [L] Montgomery constants multiplied into every output (NULL: none)
                                //     -- ringR.MulScalar(t) of Quantize, mkbfv/basis_extension.go:71
+    int nbatch;                // > 1 (batch.hip): that many independent products in one launch, input / output pointers of product k at
+    long in_batch, out_batch;  //     + k * in_batch / + k * out_batch words
 };
 void launch_tensor(const TensorArgs& a, hipStream_t st);
 

@@ -72,6 +72,35 @@ __global__ void __launch_bounds__(PW_THREADS) inner_product_kernel(InnerProductA
     *(u64x2*)(a.out + obase + n) = r;
 }
 
+typedef const __attribute__((address_space(4))) InnerProductBatchArgs* ipb_kargs;
+__global__ void __launch_bounds__(PW_THREADS) inner_product_batch_kernel(InnerProductBatchArgs a) {
+    ipb_kargs ka = (ipb_kargs)__builtin_amdgcn_kernarg_segment_ptr();      // per-input pointer lists: scalar loads
+    const int s = blockIdx.y;
+    const int bi = blockIdx.z / a.nouter, o = blockIdx.z - bi * a.nouter;
+    const int m = a.map[s];
+    const Mod md = a.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const long base = (long)o * a.term_outer + (long)m * a.N;
+    const long obase = (long)o * a.out_outer + (long)m * a.N;
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
+    if (n >= a.N) return;
+    u64 acc0 = 0, acc1 = 0;
+    for (int t = 0; t < a.nterms; ++t) {
+        const u64x2 x = ld_cached(ka->a[t] + base + n), y = ld_stream(ka->b[bi][t] + base + n);      // (the keys are re-read by every input)
+        acc0 = csub(acc0 + mont_mul_lazy(x.x, y.x, q, ninv), q2);
+        acc1 = csub(acc1 + mont_mul_lazy(x.y, y.y, q, ninv), q2);
+    }
+    acc0 = csub(acc0, q); acc1 = csub(acc1, q);
+    if (a.mform_out) { acc0 = mont_mul(acc0, md.r2, q, ninv); acc1 = mont_mul(acc1, md.r2, q, ninv); }
+    u64x2 r; r.x = acc0; r.y = acc1;
+    *(u64x2*)(ka->out[bi] + obase + n) = r;
+}
+void launch_inner_product_batch(const InnerProductBatchArgs& a, hipStream_t st) {
+    const dim3 grid((a.N / 2 + PW_THREADS - 1) / PW_THREADS, a.nslots, a.nouter * a.nbatch), blk(PW_THREADS);
+    hipLaunchKernelGGL(inner_product_batch_kernel, grid, blk, 0, st, a);
+}
+
 void launch_inner_product(const InnerProductArgs& a, hipStream_t st) {
     const dim3 grid((a.N / 2 + PW_THREADS - 1) / PW_THREADS, a.nslots, a.nouter), blk(PW_THREADS);
     switch (a.nterms) {
@@ -703,22 +732,23 @@ __global__ void __launch_bounds__(PW_THREADS) tensor_kernel(TensorArgs a) {
     const bool scaled = a.scale != nullptr;
     const u64 sc = scaled ? a.scale[l] : 0;
     const long P = (long)a.L * a.N;          // words per output poly
+    const long ib = (long)blockIdx.z * a.in_batch, ob = (long)blockIdx.z * a.out_batch;      // product blockIdx.z of a batched launch
     for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
         const long e = (long)l * a.N + n;
-        const u64 a0m = mont_mul(a.a0[e], md.r2, q, ninv);    // MForm(NTT(c0_0))
-        const u64 b0 = a.b0[e];
+        const u64 a0m = mont_mul(a.a0[ib + e], md.r2, q, ninv);    // MForm(NTT(c0_0))
+        const u64 b0 = a.b0[ib + e];
         const u64 b0m = mont_mul(b0, md.r2, q, ninv);         // MForm(NTT(c1_0))
         u64 r0 = a.with_c0 ? mont_mul(a0m, b0, q, ninv) : 0;
         if (scaled) r0 = mont_mul(r0, sc, q, ninv);
-        a.out[e] = r0;
+        a.out[ob + e] = r0;
         for (int o = 1; o <= a.nout; ++o) {
             u64 r = 0;
             const u64* pa = ka->a[o];
             const u64* pb = ka->b[o];
-            if (pa) r = mont_mul(b0m, pa[(long)l * ka->a_ls[o] + n], q, ninv);
-            if (pb) r = csub(r + mont_mul(a0m, pb[(long)l * ka->b_ls[o] + n], q, ninv), q);
+            if (pa) r = mont_mul(b0m, pa[ib + (long)l * ka->a_ls[o] + n], q, ninv);
+            if (pb) r = csub(r + mont_mul(a0m, pb[ib + (long)l * ka->b_ls[o] + n], q, ninv), q);
             if (scaled) r = mont_mul(r, sc, q, ninv);
-            a.out[(long)o * P + e] = r;
+            a.out[ob + (long)o * P + e] = r;
         }
     }
 }
@@ -726,7 +756,7 @@ void launch_tensor(const TensorArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
     const int by = a.limbs ? a.nlimbs : a.L;
     if (by < 1) return;
-    hipLaunchKernelGGL(tensor_kernel, dim3(bx, by), dim3(PW_THREADS), 0, st, a);
+    hipLaunchKernelGGL(tensor_kernel, dim3(bx, by, a.nbatch > 1 ? a.nbatch : 1), dim3(PW_THREADS), 0, st, a);
 }
 
 // ------------------------------------------------------------------ add

@@ -300,7 +300,8 @@ class BatchEvaluator:
         return op.cts if isinstance(op, BatchCiphertext) else [op] * self.B
 
     def _new(self, like_ids, level, scale):
-        return BatchCiphertext([NewCiphertext(self.params, like_ids, level, scale, zero=False) for _ in range(self.B)])
+        # (one block and one create / destroy call for the B outputs instead of B of each)
+        return BatchCiphertext(mkrlwe.batch_ciphertexts(Ciphertext, self.params, like_ids, level, self.B, Scale=float(scale)))
 
     @staticmethod
     def _h(cts):
@@ -317,11 +318,13 @@ class BatchEvaluator:
     def HoistedForm(self, ct):
         if not isinstance(ct, BatchCiphertext):
             return self.ev.HoistedForm(ct)
-        hs = []
+        if not ct.ids:                                            # no party component: nothing to hoist
+            return BatchHoisted([mkrlwe.NewHoistedCiphertext() for _ in ct.cts])
+        hs, keys, k = [], mkrlwe.batch_switching_keys(self.params, self.B * len(ct.ids)), 0
         for c in ct.cts:
             h = mkrlwe.NewHoistedCiphertext()
             for id in c.ids:
-                h.Value[id] = mkrlwe.SwitchingKey(self.params, zero=False)
+                h.Value[id] = keys[k]; k += 1
             hs.append(h)
         check(lib().mkhe_hoisted_form_batch(self.params.ctx, ct.Level(), self.B, self._h(ct.cts),
                                             handle_array([hs[b].Value[id].h for b in range(self.B) for id in ct.cts[b].ids])))

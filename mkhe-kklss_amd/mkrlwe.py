@@ -213,7 +213,7 @@ class SwitchingKey:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
+            if getattr(self, "h", None) and getattr(self, "_block", None) is None:
                 lib().mkhe_swk_destroy(self.params.ctx, self.h)          # ctx None (context already closed): plain hipFree
                 self.h = None
         except Exception:
@@ -370,7 +370,7 @@ class Ciphertext:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
+            if getattr(self, "h", None) and getattr(self, "_block", None) is None:
                 lib().mkhe_ct_destroy(self.params.ctx, self.h)           # ctx None (context already closed): plain hipFree
                 self.h = None
         except Exception:
@@ -380,6 +380,54 @@ class Ciphertext:
 def NewCiphertext(params, idset, level):
     """elements.go:22-33"""
     return Ciphertext(params, idset, level)
+
+
+class _HandleBlock:
+    """the handles of one mkhe_ct_create_batch / mkhe_swk_create_batch call: views of one pooled block, destroyed by ONE call when the last Python
+    view is gone (every view keeps a reference to this object)"""
+
+    def __init__(self, params, arr, count, destroy):
+        self.params, self.arr, self.count, self.destroy = params, arr, count, destroy
+
+    def __del__(self):
+        try:
+            if self.arr is not None:
+                self.destroy(self.params.ctx, self.count, self.arr)
+                self.arr = None
+        except Exception:
+            pass
+
+
+def batch_ciphertexts(cls, params, idset, level, B, **attrs):
+    """B uninitialised ciphertexts of one shape as views of one block (mkhe_ct_create_batch); cls: Ciphertext or a subclass, attrs: extra attributes"""
+    ids = sorted(idset)
+    arr_ids = np.asarray([params.party_index(i) for i in ids], dtype=np.int32)
+    hs = (C.c_void_p * B)()
+    check(lib().mkhe_ct_create_batch(params.ctx, B, len(ids), arr_ids.ctypes.data_as(_abi.i32p), level + 1, hs))
+    block = _HandleBlock(params, hs, B, lib().mkhe_ct_destroy_batch)
+    _pin(block)
+    out = []
+    for k in range(B):
+        c = object.__new__(cls)
+        c.params, c.ids, c._level, c.h, c._block = params, ids, int(level), C.c_void_p(hs[k]), block
+        for a, v in attrs.items():
+            setattr(c, a, v)
+        out.append(c)
+    return out
+
+
+def batch_switching_keys(params, count):
+    """count uninitialised switching keys / hoisted-digit vectors as views of one block (mkhe_swk_create_batch)"""
+    hs = (C.c_void_p * count)()
+    check(lib().mkhe_swk_create_batch(params.ctx, count, hs))
+    block = _HandleBlock(params, hs, count, lib().mkhe_swk_destroy_batch)
+    _pin(block)
+    out = []
+    for k in range(count):
+        s = object.__new__(SwitchingKey)
+        s.params, s.h, s._block = params, C.c_void_p(hs[k]), block
+        out.append(s)
+    return out
 
 
 class KeySwitcher:
