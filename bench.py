@@ -149,6 +149,7 @@ def run_cnn(args):
     not depend on the values; encrypted == plaintext is tests/test_gpu_cnn.py).  Secondary line, same JSON contract."""
     import harness_cnn as HC
     from mkhe_kklss_amd import cnn, mkckks, mkrlwe
+    from mkhe_kklss_amd._abi import check, lib
     p = HC.PN14QP433
     owners = (dict(image="dataOwner", kernels="modelOwner", fc1="modelOwner", fc2="modelOwner") if args.parties <= 2 else
               dict(image="dataOwner", kernels="convOwner", fc1="fc1Owner", fc2="fc2Owner"))
@@ -213,7 +214,11 @@ def run_cnn(args):
     single_inference = inference
     batch_check = None
     if B > 1:
-        inference = lambda record: single_inference(record, bev, bImage, bhoisted, None)
+        bforks = [bev.Fork() for _ in range(max(0, args.batch_forks))]
+        for e in [bev] + bforks:
+            if os.environ.get("MKHE_CNN_INTRA_OVERLAP", "0") == "0":
+                check(lib().mkhe_set_overlap(e.params.ctx, 0))
+        inference = lambda record: single_inference(record, bev, bImage, bhoisted, bforks or None)
     for _ in range(max(1, args.warmup)):
         out = inference(False)
     params.sync()
@@ -645,6 +650,7 @@ def main():
                     help="B inputs in lock step (mkhe_*_batch entry points, mkckks.BatchEvaluator): --scheme cnn evaluates B images per step, "
                          "--scheme ckks B MulRelin per step; value counts inputs (inferences / MulRelin per second), every output is compared "
                          "with the B = 1 evaluation of the same input")
+    ap.add_argument("--batch-forks", type=int, default=3, help="--scheme cnn --batch B: forked batch evaluators for the independent chains of a layer")
     ap.add_argument("--graph", type=int, default=0,
                     help="--scheme cnn: 1 = replay the inference from a captured HIP graph (falls back to eager issue when the loaded HIP "
                          "runtime cannot capture), 0 = issue every call eagerly (default: 3.9 ms per inference in every run; replays "

@@ -242,6 +242,9 @@ int  mkhe_mul_relin_batch(mkhe_ctx* ctx, int nbatch, const mkhe_ct* const* op0, 
                           const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0, const mkhe_swk* const* rlk_v0,
                           const mkhe_swk* crs_u, int rescale, mkhe_ct* const* out);
 int  mkhe_ct_binary_batch(mkhe_ctx* ctx, int op, int nbatch, const mkhe_ct* const* op0, const mkhe_ct* const* op1, mkhe_ct* const* out);
+/*      mkckks.Evaluator.MulPtxtNew (mkckks/evaluator.go:465-481): mkhe_ct_mul_ptxt followed by nb_rescale >= 0 DivRoundByLastModulus steps (the
+ *      Rescale of :480; the host decides nb_rescale from the scales, :376-384); out has limbs(in) - nb_rescale limbs */
+int  mkhe_ct_mul_ptxt_batch(mkhe_ctx* ctx, int nbatch, const mkhe_ct* const* in, const void* dev_pt, int nb_rescale, mkhe_ct* const* out);
 
 /* ==== mkbfv ========================================================================================
  * Context for mkbfv.NewParametersFromLiteral (mkbfv/params.go:28-76): rings Q, QMul (same length), R = Q||QMul,

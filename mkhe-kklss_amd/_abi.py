@@ -83,6 +83,7 @@ SIGNATURES = {
     "mkhe_rotate_batch": (C.c_int, [vp, C.c_uint64, C.c_int, vpp, vpp, vpp, vp, vpp]),
     "mkhe_mul_relin_batch": (C.c_int, [vp, C.c_int, vpp, vpp, vpp, vpp, vpp, vpp, vpp, vp, C.c_int, vpp]),
     "mkhe_ct_binary_batch": (C.c_int, [vp, C.c_int, C.c_int, vpp, vpp, vpp]),
+    "mkhe_ct_mul_ptxt_batch": (C.c_int, [vp, C.c_int, vpp, vp, C.c_int, vpp]),
     "mkhe_ctx_create_bfv": (C.c_int, [vpp, C.c_int, u64p, u64p, C.c_int, u64p, C.c_int, C.c_int, C.c_uint64, C.c_int]),
     "mkhe_bfv_modup_q_to_r": (C.c_int, [vp, vp, vp, C.c_int]),
     "mkhe_bfv_rescale": (C.c_int, [vp, vp, vp, C.c_int]),

@@ -311,4 +311,59 @@ void Context::ct_binary_batch(int op, const std::vector<const Ct*>& a, const std
     MKHE_HIP(hipGetLastError());
 }
 
+// mkckks.Evaluator.MulPtxtNew (mkckks/evaluator.go:465-481) on B inputs: NTT of the plaintext once, of every component of every input in one
+// launch, one product launch, one inverse launch, and the nb divisions of the Rescale that follows (:480) with one launch each for the batch.
+void Context::ct_mul_ptxt_batch(const std::vector<const Ct*>& ins, const u64* dev_pt, int nb, const std::vector<Ct*>& outs) {
+    const size_t B = ins.size();
+    if (!B) return;
+    if (outs.size() != B) throw Error("mkhe: ct_mul_ptxt_batch: one output per input");
+    same_shape(ins, "MulPtxt");
+    { std::vector<const Ct*> o(outs.begin(), outs.end()); same_shape(o, "MulPtxt outputs"); }
+    const int L = ins[0]->limbs, np_ = 1 + ins[0]->n, level = L - 1;
+    if (nb < 0 || nb > level) throw Error("cannot Rescale: input Ciphertext already at level 0");
+    if (outs[0]->limbs != L - nb || outs[0]->n != ins[0]->n || outs[0]->ids != ins[0]->ids) throw Error("mkhe: ctOut shape does not match ct");
+    const size_t PO = (size_t)L * N;
+    Arena ar(this, (1 + 2 * B * np_) * PO);
+    u64* pt = ar.take(PO); u64* w = ar.take(B * np_ * PO); u64* w2 = ar.take(B * np_ * PO);
+    ntt(dev_pt, pt, 1, L, 0, false, false);
+    for (size_t base = 0; base < B; base += NTT_MAX_ITEMS) {
+        const int cnt = (int)std::min<size_t>(NTT_MAX_ITEMS, B - base);
+        NttBatch b{};
+        b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_range(b, 0, L);
+        b.src_inner = b.dst_inner = N; b.src_outer = b.dst_outer = (long)PO;
+        b.nitems = cnt; b.outers_per_item = np_; b.nouter = cnt * np_;
+        for (int i = 0; i < cnt; ++i) { b.src_items[i] = ins[base + i]->d; b.dst_items[i] = w + (base + i) * np_ * PO; }
+        ntt_fwd_launch(b, false);
+    }
+    { ProfScope ps(this, PROF_OTHER, 8.0 * N * L * (2.0 * B * np_ + 1)); launch_mul_by_poly(w, w, pt, d_mods, L, N, (int)(B * np_), s_); }
+    if (nb == 0) {
+        for (size_t base = 0; base < B; base += NTT_MAX_ITEMS) {
+            const int cnt = (int)std::min<size_t>(NTT_MAX_ITEMS, B - base);
+            NttBatch b{};
+            b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux; slots_range(b, 0, L);
+            b.src_inner = b.dst_inner = N; b.src_outer = b.dst_outer = (long)PO;
+            b.nitems = cnt; b.outers_per_item = np_; b.nouter = cnt * np_;
+            for (int i = 0; i < cnt; ++i) { b.src_items[i] = w + (base + i) * np_ * PO; b.dst_items[i] = outs[base + i]->d; }
+            { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * b.nouter * L); ntt_inv_launch(b); }
+        }
+        return;
+    }
+    ntt(w, w, (int)(B * np_), L, 0, true, false);
+    // DivRoundByLastModulusMany (mkckks/evaluator.go:385-391): nb steps, the last one into the output ciphertexts
+    u64* cur = w; u64* nxt = w2;
+    for (int k = 0; k < nb; ++k) {
+        const int lv = level - k;
+        if (k < nb - 1) { launch_div_round_last(nxt, cur, d_mods, d_rescale + (size_t)(lv - 1) * nq, lv, N, (int)(B * np_), (long)PO, (long)PO, s_); std::swap(cur, nxt); continue; }
+        for (size_t b0 = 0; b0 < B; b0 += DRL_MAX) {
+            DivRoundListArgs da{};
+            da.ngroups = (int)std::min<size_t>(DRL_MAX, B - b0);
+            for (int g = 0; g < da.ngroups; ++g) da.dst[g] = outs[b0 + g]->d;
+            da.src = cur + b0 * np_ * PO; da.mods = d_mods; da.rescale_row = d_rescale + (size_t)(lv - 1) * nq;
+            da.src_poly = (long)PO; da.dst_poly = (long)(L - nb) * N; da.level = lv; da.N = N; da.per_group = np_;
+            launch_div_round_last_list(da, s_);
+        }
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
 }  // namespace mkhe

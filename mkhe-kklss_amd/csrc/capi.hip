@@ -534,6 +534,14 @@ int mkhe_mul_relin_batch(mkhe_ctx* ctx, int nbatch, const mkhe_ct* const* op0, c
         need(ctx)->mul_relin_batch(a, b, h0, h1, b1.data(), d0.data(), v0.data(), crs_u->s, rescale != 0, o);
     })
 }
+int mkhe_ct_mul_ptxt_batch(mkhe_ctx* ctx, int nbatch, const mkhe_ct* const* in, const void* dev_pt, int nb_rescale, mkhe_ct* const* out) {
+    MKHE_TRY({
+        if (nbatch < 1 || !dev_pt) throw Error("mkhe_ct_mul_ptxt_batch: bad argument");
+        auto i = ct_list(ctx, in, nbatch, "mkhe_ct_mul_ptxt_batch");
+        auto o = ct_list_out(ctx, out, nbatch, "mkhe_ct_mul_ptxt_batch");
+        need(ctx)->ct_mul_ptxt_batch(i, (const u64*)dev_pt, nb_rescale, o);
+    })
+}
 int mkhe_ct_binary_batch(mkhe_ctx* ctx, int op, int nbatch, const mkhe_ct* const* op0, const mkhe_ct* const* op1, mkhe_ct* const* out) {
     MKHE_TRY({
         if (nbatch < 1 || (op != 0 && op != 1)) throw Error("mkhe_ct_binary_batch: bad argument");

@@ -125,6 +125,8 @@ class Context {
                          const std::vector<const Swk*>& hoist1, const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                          const Swk& crs_u, bool rescale_out, const std::vector<Ct*>& outs);
     void ct_binary_batch(int op, const std::vector<const Ct*>& a, const std::vector<const Ct*>& b, const std::vector<Ct*>& outs);
+    // MulPtxtNew body (ct_mul_ptxt) for the batch, followed by nb >= 0 divisions by the last modulus (outs have limbs(in) - nb limbs)
+    void ct_mul_ptxt_batch(const std::vector<const Ct*>& ins, const u64* dev_pt, int nb, const std::vector<Ct*>& outs);
     u64* pool_x() { return x_; }
     u64* pool_y() { return y_; }
     // batched building blocks (all parties in one launch)

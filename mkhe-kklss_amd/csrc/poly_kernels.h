@@ -291,6 +291,19 @@ void launch_automorphism(u64* dst, const u64* src, const Mod* mods, int L, int l
 void launch_div_round_last(u64* dst, const u64* src, const Mod* mods, const u64* rescale_row /*[level]*/,
                            int level, int N, int npolys, long src_poly, long dst_poly, hipStream_t st);
 
+// the same step on a contiguous source [ngroups * per_group polys] whose results go to ngroups separate destinations (the ciphertexts of a batch,
+// batch.hip): polynomial p of group g -> dst[g] + p * dst_poly
+constexpr int DRL_MAX = 64;
+struct DivRoundListArgs {
+    u64* dst[DRL_MAX];
+    const u64* src;
+    const Mod* mods;
+    const u64* rescale_row;
+    long src_poly, dst_poly;
+    int level, N, per_group, ngroups;
+};
+void launch_div_round_last_list(const DivRoundListArgs& a, hipStream_t st);
+
 // In-place fold of sums of canonical residues (< 2^63) back to [0,q), optionally to Montgomery form.
 struct FoldArgs {
     u64* buf;

@@ -1229,6 +1229,34 @@ void launch_div_round_last(u64* dst, const u64* src, const Mod* mods, const u64*
     hipLaunchKernelGGL(div_round_last_kernel, dim3(bx, level, npolys), dim3(PW_THREADS), 0, st, dst, src, mods, rescale_row, level, N, src_poly, dst_poly);
 }
 
+typedef const __attribute__((address_space(4))) DivRoundListArgs* drl_kargs;
+__global__ void __launch_bounds__(PW_THREADS) div_round_last_list_kernel(DivRoundListArgs a) {
+    drl_kargs ka = (drl_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int i = blockIdx.y, pidx = blockIdx.z, g = pidx / a.per_group, p = pidx - g * a.per_group;
+    const Mod mi = a.mods[i];
+    const u64 qL = a.mods[a.level].q, h = (qL - 1) >> 1;
+    u64 hr;
+    {
+        const u64 k = (u64)((double)h / (double)mi.q);             // BRedAdd(h, q_i) as in div_round_last_kernel
+        hr = h - k * mi.q;
+        if ((i64)hr < 0) hr += mi.q;
+        if (hr >= mi.q) hr -= mi.q;
+    }
+    const u64 hneg = mi.q - hr;
+    const u64 rp = mi.q - a.rescale_row[i];
+    const u64* s = a.src + (long)pidx * a.src_poly;
+    u64* d = ka->dst[g] + (long)p * a.dst_poly;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
+        const u64 t = csub(s[(long)a.level * a.N + n] + h, qL);
+        d[(long)i * a.N + n] = mont_mul(t + hneg + mi.q2 - s[(long)i * a.N + n], rp, mi.q, mi.ninv32);
+    }
+}
+void launch_div_round_last_list(const DivRoundListArgs& a, hipStream_t st) {
+    if (a.level < 1 || a.ngroups < 1) return;
+    const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    hipLaunchKernelGGL(div_round_last_list_kernel, dim3(bx, a.level, a.ngroups * a.per_group), dim3(PW_THREADS), 0, st, a);
+}
+
 // ------------------------------------------------------------------ fold (reduction epilogue)
 __global__ void __launch_bounds__(PW_THREADS) fold_kernel(FoldArgs a) {
     const int m = a.map[blockIdx.y];

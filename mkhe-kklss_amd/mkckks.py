@@ -271,6 +271,7 @@ class BatchCiphertext:
             if c.ids != c0.ids or c.Level() != c0.Level() or c.Scale != c0.Scale:
                 raise MkheError("BatchCiphertext: the ciphertexts of a batch must have one shape and scale")
         self.ids, self.Scale, self.params = c0.ids, c0.Scale, c0.params
+        self._harr = handle_array([c.h for c in self.cts])          # (built once: every batched call passes it)
 
     def __len__(self): return len(self.cts)
     def IDSet(self): return set(self.ids)
@@ -294,6 +295,11 @@ class BatchEvaluator:
     def __init__(self, params, B):
         self.params, self.B = params, int(B)
         self.ev = Evaluator(params)
+        self._bcast = {}                       # broadcast operands (the model ciphertexts of cnn): their (void*)[B], keyed by object
+
+    def Fork(self):
+        """a batch evaluator on a forked context (own stream, shared keys and ciphertexts): independent chains of a circuit overlap on the GPU"""
+        return BatchEvaluator(self.params.Fork(), self.B)
 
     # -- helpers
     def _cts(self, op):
@@ -303,16 +309,31 @@ class BatchEvaluator:
         # (one block and one create / destroy call for the B outputs instead of B of each)
         return BatchCiphertext(mkrlwe.batch_ciphertexts(Ciphertext, self.params, like_ids, level, self.B, Scale=float(scale)))
 
-    @staticmethod
-    def _h(cts):
-        return handle_array([c.h for c in cts])
+    def _h(self, op):
+        """the (void*)[B] of an operand: cached on a BatchCiphertext, built (and cached per evaluator) for a broadcast ciphertext"""
+        if isinstance(op, BatchCiphertext):
+            return op._harr
+        if isinstance(op, list):
+            return handle_array([c.h for c in op])
+        key = id(op)
+        hit = self._bcast.get(key)
+        if hit is None or hit[0] is not op:
+            if len(self._bcast) > 256:
+                self._bcast.clear()
+            hit = self._bcast[key] = (op, handle_array([op.h] * self.B))
+        return hit[1]
 
     def _hoists(self, hoisted, ops):
         """flat [b * n + a] handle list, or None"""
         if hoisted is None:
             return None
-        hs = hoisted.hoisted if isinstance(hoisted, BatchHoisted) else [hoisted] * self.B
-        return handle_array([hs[b].Value[i].h for b in range(self.B) for i in ops[b].ids])
+        ids = tuple(ops[0].ids)
+        cache = hoisted.__dict__.setdefault("_flat", {})
+        arr = cache.get((ids, self.B))
+        if arr is None:
+            hs = hoisted.hoisted if isinstance(hoisted, BatchHoisted) else [hoisted] * self.B
+            arr = cache[(ids, self.B)] = handle_array([hs[b].Value[i].h for b in range(self.B) for i in ids])
+        return arr
 
     # -- HoistedForm (evaluator.go:543-553)
     def HoistedForm(self, ct):
@@ -326,7 +347,7 @@ class BatchEvaluator:
             for id in c.ids:
                 h.Value[id] = keys[k]; k += 1
             hs.append(h)
-        check(lib().mkhe_hoisted_form_batch(self.params.ctx, ct.Level(), self.B, self._h(ct.cts),
+        check(lib().mkhe_hoisted_form_batch(self.params.ctx, ct.Level(), self.B, self._h(ct),
                                             handle_array([hs[b].Value[id].h for b in range(self.B) for id in ct.cts[b].ids])))
         return BatchHoisted(hs)
 
@@ -339,7 +360,7 @@ class BatchEvaluator:
             fn = self.ev.AddNew if opcode == 0 else self.ev.SubNew
             return BatchCiphertext([fn(a[k], b[k]) for k in range(self.B)])
         out = self._new(a[0].IDSet() | b[0].IDSet(), min(a[0].Level(), b[0].Level()), max(s0, s1))
-        check(lib().mkhe_ct_binary_batch(self.params.ctx, opcode, self.B, self._h(a), self._h(b), self._h(out.cts)))
+        check(lib().mkhe_ct_binary_batch(self.params.ctx, opcode, self.B, self._h(op0), self._h(op1), self._h(out)))
         return out
 
     def AddNew(self, op0, op1): return self._binary(op0, op1, 0)
@@ -362,8 +383,8 @@ class BatchEvaluator:
         d0 = [rlkSet.GetRelinearizationKey(i).Value[1].h for i in a[0].ids]
         v0 = [rlkSet.GetRelinearizationKey(i).Value[2].h for i in a[0].ids]
         b1 = [rlkSet.GetRelinearizationKey(i).Value[0].h for i in b[0].ids]
-        check(lib().mkhe_mul_relin_batch(params.ctx, self.B, self._h(a), self._h(b), self._hoists(op0Hoisted, a), self._hoists(op1Hoisted, b),
-                                         handle_array(b1), handle_array(d0), handle_array(v0), params.CRS[-1].h, 1 if rescale else 0, self._h(out.cts)))
+        check(lib().mkhe_mul_relin_batch(params.ctx, self.B, self._h(op0), self._h(op1), self._hoists(op0Hoisted, a), self._hoists(op1Hoisted, b),
+                                         handle_array(b1), handle_array(d0), handle_array(v0), params.CRS[-1].h, 1 if rescale else 0, self._h(out)))
         if rescale and nb1 > 1:                        # further divisions (not in the circuits of the reference): per input
             return BatchCiphertext([self.ev.RescaleNew(c, params.Scale()) for c in out.cts])
         return out
@@ -374,8 +395,8 @@ class BatchEvaluator:
         cts = self._cts(ct)
         out = self._new(cts[0].IDSet(), cts[0].Level(), cts[0].Scale)
         rk = [rkSet.GetRotationKey(i, rotidx).Value.h for i in cts[0].ids]
-        check(lib().mkhe_rotate_batch(params.ctx, params.GaloisElementForColumnRotationBy(rotidx), self.B, self._h(cts), self._hoists(hoisted, cts),
-                                      handle_array(rk), params.CRS[rotidx].h, self._h(out.cts)))
+        check(lib().mkhe_rotate_batch(params.ctx, params.GaloisElementForColumnRotationBy(rotidx), self.B, self._h(ct), self._hoists(hoisted, cts),
+                                      handle_array(rk), params.CRS[rotidx].h, self._h(out)))
         return out
 
     def RotateNew(self, ct, rotidx, rkSet):
@@ -400,6 +421,18 @@ class BatchEvaluator:
             raise MkheError("Hoisted rotation only works for precomputed rotation keys")
         return self._rotate(ct, rotidx, ctHoisted, rkSet)
 
-    # -- MulPtxtNew (evaluator.go:465-481): once per inference in cnn -- per input
+    # -- MulPtxtNew (evaluator.go:465-481)
     def MulPtxtNew(self, ct, pt_value, pt_scale):
-        return BatchCiphertext([self.ev.MulPtxtNew(c, pt_value, pt_scale) for c in self._cts(ct)])
+        params = self.params
+        cts = self._cts(ct)
+        level, scale = cts[0].Level(), cts[0].Scale * float(pt_scale)
+        if isinstance(pt_value, mkrlwe.DeviceLimbs):
+            pt = pt_value
+            if pt.limbs != level + 1:
+                raise MkheError("MulPtxtNew: the resident plaintext must have level + 1 limbs")
+        else:
+            pt = mkrlwe.DeviceLimbs(params, 1, level + 1).upload(np.ascontiguousarray(pt_value, dtype=np.uint64)[None, : level + 1])
+        nb, rscale = (0, scale) if level == 0 else self.ev._nb_rescales(level, scale, params.Scale())
+        out = self._new(cts[0].IDSet(), level - nb, rscale if nb else scale)
+        check(lib().mkhe_ct_mul_ptxt_batch(params.ctx, self.B, self._h(ct), pt.devptr(), nb, self._h(out)))
+        return out
