@@ -161,9 +161,12 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
         if (!dsrc.empty()) decompose_batch(level, dsrc, ddst, true);
     }
     // ---- step D: tensor product in the NTT domain (keyswitch_hoisted.go:119-144): NTT of every component of both operands, one launch per side
+    // (alpha = 1: digit l of an engine-hoisted component under its own modulus l IS NTT_l of its limb l -- the diagonal h[l][l], limb stride
+    // (nQ + nP + 1) N -- so that only c_0 of such an operand is transformed; caller-supplied hoisted forms are not trusted with that, as in mr_prepare)
+    const bool diag0 = own0 && alpha == 1, diag1 = (own1 || (same && own0)) && alpha == 1;
     for (int side = 0; side < (same ? 1 : 2); ++side) {
         const std::vector<const Ct*>& ops = side ? op1 : op0;
-        const int n = side ? n1 : n0;
+        const int n = (side ? diag1 : diag0) ? 0 : (side ? n1 : n0);
         for (size_t base = 0; base < B; base += NTT_MAX_ITEMS) {
             const int cnt = (int)std::min<size_t>(NTT_MAX_ITEMS, B - base);
             NttBatch b{};
@@ -184,8 +187,16 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
             if (fold) ta.scale = d_pmodq;
             ta.nout = nout; ta.L = L; ta.N = N; ta.with_c0 = 1;
             if (one) { ta.nbatch = (int)B; ta.in_batch = stride; ta.out_batch = (long)(tens[1] - tens[0]); }
-            for (int a = 0; a < n0; ++a) { const int o = 1 + slot0[a]; ta.a[o] = nb_[b] + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
-            for (int a = 0; a < n1; ++a) { const int o = 1 + slot1[a]; ta.b[o] = (same ? nb_[b] : nb_[b] + (size_t)(1 + n0) * PO) + (size_t)(1 + a) * PO; ta.b_ls[o] = N; }
+            const long dstride = (long)(mtot + 1) * N;
+            for (int a = 0; a < n0; ++a) {
+                const int o = 1 + slot0[a];
+                if (diag0) { ta.a[o] = h0[b * n0 + a]; ta.a_ls[o] = dstride; } else { ta.a[o] = nb_[b] + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
+            }
+            for (int a = 0; a < n1; ++a) {
+                const int o = 1 + slot1[a];
+                if (diag1) { ta.b[o] = h1[b * n1 + a]; ta.b_ls[o] = dstride; }
+                else { ta.b[o] = (same ? nb_[b] : nb_[b] + (size_t)(1 + n0) * PO) + (size_t)(1 + a) * PO; ta.b_ls[o] = N; }
+            }
             { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + nout) * (one ? B : 1)); launch_tensor(ta, s_); }
             if (!fold) ntt(full[b], full[b], 1 + nout, L, 0, true, false);
         }
