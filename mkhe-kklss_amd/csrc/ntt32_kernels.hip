@@ -58,8 +58,11 @@ constexpr int RING = MKHE_H32_RING;        // twiddle pairs (4 VGPRs each) live 
 #ifndef MKHE_H32_PHPRIO
 #define MKHE_H32_PHPRIO 2
 #endif
+#ifndef MKHE_NTT32_EVEN_DEFAULT
+#define MKHE_NTT32_EVEN_DEFAULT 0
+#endif
 #ifndef MKHE_NTT32_DEFAULT
-#define MKHE_NTT32_DEFAULT 0               // MKHE_NTT32=1 switches the kernel on
+#define MKHE_NTT32_DEFAULT 1               // MKHE_NTT32=0: every launch on the H16 kernel (A/B)
 #endif
 template <int... I, class F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
@@ -469,7 +472,20 @@ bool ntt32_ok(int logN, const NttBatch& b) {
     static const int on = env_int32("MKHE_NTT32", MKHE_NTT32_DEFAULT), minl = env_int32("MKHE_NTT32_MIN", 512);
     if (!on || logN != 15 || b.no_h16 || !b.psi31 || !b.psi31c || !b.psi31b || b.split || b.prestaged || b.nslots > 64) return false;
     if ((long)b.nslots * b.nouter >= 65536 || b.nouter >= 65536) return false;      // (job-walk reciprocals: exact below 2^16)
-    return b.nslots * b.nouter >= minl;
+    // one workgroup per CU, whole limbs: a launch that does not deal the limbs evenly leaves CUs idle in its last round (896 limbs on 256 CUs: four
+    // rounds for 3.5 rounds of work), where the H16 kernel deals half-limb jobs.  MKHE_NTT32_EVEN=1 keeps such launches on H16.
+    static const int even = env_int32("MKHE_NTT32_EVEN", MKHE_NTT32_EVEN_DEFAULT);
+    const int need = b.nslots * b.nouter;
+    if (even) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        static int cached_cus = 0;
+        if (!cached_cus) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); cached_cus = cus; }
+        cus = cached_cus;
+        const int rounds = (need + cus - 1) / cus;
+        if (need % cus != 0 && rounds < 8) return false;
+    }
+    return need >= minl;
 }
 void launch_ntt32_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
     using namespace h32;
