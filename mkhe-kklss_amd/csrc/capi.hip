@@ -683,6 +683,7 @@ const char* mkhe_prof_name(int cls) {
     static const char* names[] = {"ntt_fwd_kernel<N,1,true>  (Decompose, q<2^57)", "ntt_fwd_kernel<N,0,true>  (Decompose, q>=2^57)",
                                   "ntt_fwd_kernel<N,2,true>  (Decompose, both modulus classes in one persistent launch)",
                                   "ntt16_fwd_kernel<true>  (Decompose, 16 coefficients per thread, two workgroups per CU)", "ntt16_fwd_kernel<false>",
+                                  "ntt32_fwd_kernel<true>  (Decompose, ONE pass per limb: 32 coefficients per thread, one workgroup per CU)", "ntt32_fwd_kernel<false>",
                                   "ntt14_fwd_split_kernel  (N = 2^16 Decompose after decomp_spread4_kernel: four one-pass 2^14-point sub-transforms per limb)",
                                   "ntt_fwd_kernel<N,1,false>", "ntt_fwd_kernel<N,0,false>", "ntt_inv_kernel<N>",
                                   "inner_product_kernel", "ext_inner_kernel", "moddown[_batch]_kernel", "tensor_kernel", "basis_conv_kernel", "decomp_spread_kernel", "other"};

@@ -197,7 +197,7 @@ class Context {
     void wait_for(Context& other);
 
     // ---- per-kernel-class timing with HIP events on the context stream (bench.py roofline leg)
-    enum { PROF_NTT_DECOMP = 0, PROF_NTT_DECOMP_BIGQ, PROF_NTT_DECOMP_MIXED, PROF_NTT16_DECOMP, PROF_NTT16_FWD, PROF_NTT14_SPLIT, PROF_NTT_FWD, PROF_NTT_FWD_BIGQ, PROF_NTT_INV, PROF_INNER, PROF_EXT_INNER,
+    enum { PROF_NTT_DECOMP = 0, PROF_NTT_DECOMP_BIGQ, PROF_NTT_DECOMP_MIXED, PROF_NTT16_DECOMP, PROF_NTT16_FWD, PROF_NTT32_DECOMP, PROF_NTT32_FWD, PROF_NTT14_SPLIT, PROF_NTT_FWD, PROF_NTT_FWD_BIGQ, PROF_NTT_INV, PROF_INNER, PROF_EXT_INNER,
            PROF_MODDOWN, PROF_TENSOR, PROF_BASISCONV, PROF_SPREAD, PROF_OTHER, PROF_NCLASS };
     void prof_enable(bool on);
     void prof_collect(double* ms, long* launches, double* alg_bytes);

@@ -673,7 +673,7 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     b.psif = d_psif; b.f_mods = f_mods_;
     for (int i = 0; i < mall && i < NTT_MAX_SLOTS; ++i) b.sched[i] = h16_sched_.empty() ? 15 : h16_sched_[i];
     if (ntt32_ok(logN, b)) {
-        ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
+        ProfScope ps(this, decompose ? PROF_NTT32_DECOMP : PROF_NTT32_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;
         launch_ntt32_fwd(bt, small16_.data(), s_);
         return;

@@ -42,7 +42,7 @@ for d in ("sq_a", "sq_b", "sq_d"):
     if not os.path.exists(cc):
         continue
     for r in csv.DictReader(open(cc)):
-        m = re.search(r"mkhe::(?:h16::)?(\w+)(<[^>]*>)?", r["Kernel_Name"])
+        m = re.search(r"mkhe::(?:h16::|h32::)?(\w+)(<[^>]*>)?", r["Kernel_Name"])
         if m:
             agg[m.group(1) + (m.group(2) or "").replace(" ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(P, "%s_sq_counters.txt" % tag), "w") as f:

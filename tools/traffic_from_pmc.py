@@ -23,7 +23,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(cc)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"mkhe::(?:h16::)?(\w+)(<[^>]*>)?", r["Kernel_Name"])
+            m = re.search(r"mkhe::(?:h16::|h32::)?(\w+)(<[^>]*>)?", r["Kernel_Name"])
             if not m:
                 continue
             key = m.group(1) + (m.group(2) or "").replace(" ", "")
