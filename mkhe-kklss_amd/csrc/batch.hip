@@ -10,8 +10,9 @@
 // All B operations of a call have the same shape: the same id lists, limb counts and keys (the relinearization / rotation keys and the CRS
 // belong to the parties, not to the inputs).  An operand that is the SAME ciphertext for every input (the model of cnn: kernels, weights,
 // biases) is passed B times.  Results are the integers of the single-operation entry points, bit for bit (tests/test_gpu_batch.py): the
-// batch path takes no shortcut that changes a representative -- it does not even use the fusions that are specific to one operation at a
-// time (x as a by-product of step F1, Rescale folded into the last ModDown, the hoisted digits' diagonal as tensor input).
+// batch path takes no shortcut that changes a representative.  The fusions of the single-operation path carry over per input: the tensor term
+// rides on the first product of every output slot, the Rescale on the merged ModDown's store (Context::rs_maps_), the diagonal of engine-hoisted
+// digits is the tensor input, and x_b comes out of input b's step F1 (up to four parties per operand: Context::ext_xmap_).
 //
 // Replaces, B at a time: KeySwitcher.MulAndRelin[Hoisted] (mkrlwe/keyswitch_hoisted.go:44-179) + Rescale (mkckks/evaluator.go:558-581),
 // RotateHoisted / Rotate (:183-247, keyswitch.go:234-298), Evaluator.HoistedForm (mkckks/evaluator.go:543-553), AddNew / SubNew (:316-356).
@@ -133,6 +134,8 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     const bool own0 = hoist0.empty(), own1 = hoist1.empty() && !same;
     const size_t P0 = (size_t)op0[0]->limbs * N, P1 = (size_t)op1[0]->limbs * N, PO = (size_t)L * N, SW = swk_words();
     const bool fold = n0 >= 1 && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
+    static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
+    const bool fuse_x = fuse_env && n0 >= 1 && n0 <= 4;      // x_b = sum_i d_i (.) h(c0_{b,i}) as a by-product of input b's step F1
     const size_t per_b = (size_t)(2 + n0 + n1) * PO + (size_t)(1 + nout) * PO * ((fold ? 1 : 0) + (rescale_out ? 1 : 0)) + 2 * SW + (size_t)n0 * PO + (size_t)n0 * SW +
                          (own0 ? (size_t)n0 * SW : 0) + (own1 ? (size_t)n1 * SW : 0);
     Arena ar(this, B * per_b);
@@ -164,17 +167,28 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     // (alpha = 1: digit l of an engine-hoisted component under its own modulus l IS NTT_l of its limb l -- the diagonal h[l][l], limb stride
     // (nQ + nP + 1) N -- so that only c_0 of such an operand is transformed; caller-supplied hoisted forms are not trusted with that, as in mr_prepare)
     const bool diag0 = own0 && alpha == 1, diag1 = (own1 || (same && own0)) && alpha == 1;
-    for (int side = 0; side < (same ? 1 : 2); ++side) {
-        const std::vector<const Ct*>& ops = side ? op1 : op0;
-        const int n = (side ? diag1 : diag0) ? 0 : (side ? n1 : n0);
-        for (size_t base = 0; base < B; base += NTT_MAX_ITEMS) {
-            const int cnt = (int)std::min<size_t>(NTT_MAX_ITEMS, B - base);
-            NttBatch b{};
-            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_q_owned(b, L);
-            b.src_inner = b.dst_inner = N; b.src_outer = (long)(side ? P1 : P0); b.dst_outer = (long)PO;
-            b.nitems = cnt; b.outers_per_item = 1 + n; b.nouter = cnt * (1 + n);
-            for (int i = 0; i < cnt; ++i) { b.src_items[i] = ops[base + i]->d; b.dst_items[i] = nb_[base + i] + (side ? (size_t)(1 + n0) * PO : 0); }
-            ntt_fwd_launch(b, false);
+    {
+        const int nn0 = diag0 ? 0 : n0, nn1 = diag1 ? 0 : n1;
+        // (both sides as the items of ONE launch when they have one shape: twice the limbs per launch -- on the small rings that is what
+        // takes it over the threshold of the H16-class kernel, one launch for both modulus classes instead of four of the round-1 kernel)
+        const bool both = !same && P0 == P1 && nn0 == nn1;
+        struct It { const u64* s; u64* d; };
+        for (int side = 0; side < (same || both ? 1 : 2); ++side) {
+            const int n = side ? nn1 : nn0;
+            std::vector<It> its;
+            for (size_t b = 0; b < B; ++b) {
+                if (both || side == 0) its.push_back(It{op0[b]->d, nb_[b]});
+                if (both || side == 1) its.push_back(It{op1[b]->d, nb_[b] + (size_t)(1 + n0) * PO});
+            }
+            for (size_t base = 0; base < its.size(); base += NTT_MAX_ITEMS) {
+                const int cnt = (int)std::min<size_t>(NTT_MAX_ITEMS, its.size() - base);
+                NttBatch b{};
+                b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_q_owned(b, L);
+                b.src_inner = b.dst_inner = N; b.src_outer = (long)(side ? P1 : P0); b.dst_outer = (long)PO;
+                b.nitems = cnt; b.outers_per_item = 1 + n; b.nouter = cnt * (1 + n);
+                for (int i = 0; i < cnt; ++i) { b.src_items[i] = its[base + i].s; b.dst_items[i] = its[base + i].d; }
+                ntt_fwd_launch(b, false);
+            }
         }
     }
     {
@@ -205,7 +219,7 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     {
         const int nbt = beta(level), nslots = nslots_qp(level);
         if (n0 > MAX_TERMS || n1 > MAX_TERMS) throw Error("mkhe: too many parties");
-        for (int side = 1; side >= 0; --side) {
+        for (int side = 1; side >= (fuse_x ? 1 : 0); --side) {
             const int n = side ? n1 : n0;
             if (n == 0) { for (size_t b = 0; b < B; ++b) MKHE_HIP(hipMemsetAsync(side ? y[b] : x[b], 0, SW * sizeof(u64), s_)); continue; }
             if (n <= IPB_MAX_TERMS) {
@@ -232,12 +246,23 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
             }
         }
     }
-    // ---- step F1: t_i = <h(c0_i), y>_P (:165-169), every input in one batch; then h(t_i)
+    // ---- step F1: t_i = <h(c0_i), y>_P (:165-169), every input in one batch (whole inputs per launch: with fuse_x the thread that holds input
+    // b's digits h(c0_i) multiplies them by the d_i as well and stores x_b); then h(t_i)
     if (n0) {
-        std::vector<ExtItem> items;
-        for (size_t b = 0; b < B; ++b)
-            for (int a = 0; a < n0; ++a) items.push_back(ExtItem{h0[b * n0 + a], y[b], tbuf[b] + (size_t)a * PO, false});
-        ext_batch(level, items);
+        const size_t per = std::max<size_t>(1, EXT_MAX_ITEMS / (size_t)n0);
+        for (size_t b0 = 0; b0 < B; b0 += per) {
+            std::vector<ExtItem> items;
+            ext_xmap_.clear();
+            for (size_t b = b0; b < std::min(B, b0 + per); ++b) {
+                for (int a = 0; a < n0; ++a) {
+                    items.push_back(ExtItem{h0[b * n0 + a], y[b], tbuf[b] + (size_t)a * PO, false});
+                    if (fuse_x) items.back().xkey = rlk_d0[a]->d;
+                }
+                if (fuse_x) ext_xmap_.push_back({y[b], x[b]});
+            }
+            try { ext_batch(level, items); } catch (...) { ext_xmap_.clear(); throw; }
+            ext_xmap_.clear();
+        }
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (size_t b = 0; b < B; ++b)
             for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf[b] + (size_t)a * PO); ddst.push_back(h2[b * n0 + a]); }

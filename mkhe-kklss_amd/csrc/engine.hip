@@ -923,6 +923,23 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     }
     if ((ext_xout_ || ext_xout2_) && !xby) throw Error("mkhe: internal: x by-product requested for a batch that cannot carry it");
     ia.xout = xby ? ext_xout_ : nullptr; ia.xout2 = xby && xby2 ? ext_xout2_ : nullptr; ia.xmform = 1;
+    int xgroups = 0;
+    if (!ext_xmap_.empty()) {
+        // B inputs' step F1 in one launch (mul_relin_batch): the items that share y_b are input b's, at most four, and carry x_b
+        if (xby || two || mp) throw Error("mkhe: internal: per-input x by-products on a batch that cannot carry them");
+        for (int i = 0; i < n; ++i) {
+            u64* xo = nullptr; int cnt = 0;
+            for (const auto& e : ext_xmap_) if (e.first == it[i].bg) xo = e.second;
+            for (int k = 0; k < n; ++k) cnt += it[k].bg == it[i].bg;
+            if (!xo || !it[i].xkey || cnt > 4) throw Error("mkhe: internal: per-input x by-products on a batch that cannot carry them");
+            ia.xkey2[i] = xo;
+            bool first = true;
+            for (int k = 0; k < i; ++k) first = first && it[k].bg != it[i].bg;
+            xgroups += first;
+        }
+        ia.xout = ext_xmap_[0].second; ia.xmulti = 1;
+        xby = true;
+    }
     // keys that a single item reads (v_i, rotation keys) are streamed; x, y, u are shared by several items and stay cached
     for (int i = 0; i < n; ++i) {
         int uses = 0;
@@ -944,7 +961,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         for (int i = 0; i < n; ++i) { add(ia.ah[i]); add(ia.bg[i]); add(ia.ah2[i]); add(ia.bg2[i]); }
         distinct = ns;
     }
-    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + 1.0) * (xby2 ? 2 : 1) : 0.0))); launch_ext_inner(ia, s_); }
+    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0))); launch_ext_inner(ia, s_); }
     NttBatch b{};
     b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux;
     b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;

@@ -88,6 +88,7 @@ struct ExtInnerArgs {
     const u64* xkey[EXT_MAX_ITEMS];
     u64* xout;
     int xmform;
+    int xmulti;              // several groups, each with its own x (batch.hip: one group per input): xkey2[i] holds the xout of item i's group, no second gadget
     const u64* xkey2[EXT_MAX_ITEMS];     // the same for the second gadget (mkbfv: x2 = sum_i d2_i (.) h2(c0_i), keyswitch_hoisted.go:76-101)
     u64* xout2;
     u64* c1;                 // [nitems][mtot][N]

@@ -190,7 +190,7 @@ __device__ __forceinline__ void ext_group_singles(const ExtInnerArgs& a, ext_kar
         const u64* xk[G];
 #pragma unroll
         for (int m = 0; m < G; ++m) xk[m] = ka->xkey[idx[m]] + off;
-        u64* xo = a.xout + off;
+        u64* xo = (a.xmulti ? (u64*)ka->xkey2[leader] : a.xout) + off;
 #pragma unroll 1
         for (int i = 0; i < a.nb; ++i) {
             const u64x2 g = once ? ld_stream(bg + i * ds) : ld_cached(bg + i * ds);
@@ -224,7 +224,7 @@ __device__ __forceinline__ void ext_group_singles(const ExtInnerArgs& a, ext_kar
         }
     }
     }
-    if (ka->ah2[leader]) {                       // second gadget (mkbfv: the QMul digits), same shape
+    if (!a.xmulti && ka->ah2[leader]) {          // second gadget (mkbfv: the QMul digits), same shape
         const u64* ah2[G];
 #pragma unroll
         for (int m = 0; m < G; ++m) ah2[m] = ka->ah2[idx[m]] + off;
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xwide_kernel(ExtInnerArg
 }
 void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
     ExtInnerArgs a = a_in;
-    if (a.xout && a.nitems > 4) {
+    if (a.xout && !a.xmulti && a.nitems > 4) {
         // (checked by the caller: single items, one shared key, one gadget, five to sixteen of them)
         if (a.nitems > 16 || a.xout2) throw std::runtime_error("mkhe: internal: wide x by-product outside its range");
         const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
@@ -484,11 +484,13 @@ void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
     }
     static const int grouping = getenv("MKHE_EXT_GROUP") ? atoi(getenv("MKHE_EXT_GROUP")) : 1;
     for (int i = 0; i < a.nitems; ++i) { a.grp[i] = 0; a.gnext[i] = 255; }
-    if (a.xout) {
+    if (a.xout && !a.xmulti) {
         // the x by-product needs every item in ONE group (checked by the caller: single items, one shared key, at most four)
         for (int i = 0; i < a.nitems; ++i) { a.grp[i] = i ? 2 : 1; a.gnext[i] = i + 1 < a.nitems ? (unsigned char)(i + 1) : 255; }
         a.bg_once[0] = 1;
-    } else if (grouping) {
+    } else if (grouping || a.xmulti) {
+        // (xmulti: the items that share a key are one input's step F1 -- at most four, checked by the caller -- and form a group even alone:
+        // the group form is the one that carries the x by-product)
         for (int i = 0; i < a.nitems; ++i) {
             if (a.grp[i] || a.pair[i] == 2) continue;
             const bool pr = a.pair[i] == 1;            // (pairs never carry a second gadget: see Context::ext_front)
@@ -498,7 +500,7 @@ void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
                 if (pr ? (a.bg[k + 1] != a.bg[i + 1]) : (a.bg[k] != a.bg[i] || a.bg2[k] != a.bg2[i])) continue;
                 a.gnext[last] = (unsigned char)k; a.grp[k] = 2; last = k; ++cnt;
             }
-            if (cnt > 1) {
+            if (cnt > 1 || a.xmulti) {
                 a.grp[i] = 1;
                 // the shared operand is read once per coefficient by this group: stream it past the caches when no other group uses it
                 const u64* sh = pr ? a.bg[i + 1] : a.bg[i];

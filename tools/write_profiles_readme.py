@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Regenerates profiles/README.md from the distilled files of one round:  python tools/write_profiles_readme.py r3"""
+"""Regenerates profiles/README.md from the distilled files of one round:  python tools/write_profiles_readme.py r4"""
 import csv, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles") + "/"
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 J = lambda n: json.load(open(P + tag + "_" + n + ".json")) if os.path.exists(P + tag + "_" + n + ".json") else None
 pl, no, ov, bf, bfp, pn, pn_no, c2, c4, p14 = (J(n) for n in ("bench_plain", "bench_noovl", "bench_ovl", "bench_bfv", "bench_bfv_plain", "bench_pn16",
                                                           "bench_pn16_noovl", "bench_cnn2", "bench_cnn4", "bench_pn14"))
@@ -50,17 +50,20 @@ def whole_step():
     return tot, cov_ms / all_ms
 
 
-def abl(name, limbs=1792):
-    """us per launch of a variant in the ablation table"""
+def abl(name, limbs=1792, kernel="ntt32"):
+    """us per launch of a variant in the ablation table (the file has one part per kernel: '## ntt32_fwd_kernel ...', '## ntt16_fwd_kernel ...')"""
     txt = open(P + tag + "_ntt16_ablation.txt").read()
+    parts = re.split(r"^## ", txt, flags=re.M)
+    txt = next((x for x in parts if x.startswith(kernel)), txt)
     m = re.search(r"== %s .*?\n(?:.*\n)*?limbs +%d .*? ([0-9.]+) us/launch" % (re.escape(name), limbs), txt)
     return float(m.group(1)) if m else float("nan")
 
 
 R, Rn = pl["roofline"], no["roofline"]
-avg, calls, mn, mx = st("ntt16_fwd_kernel<true>")
+DOM = "ntt32_fwd_kernel<true>"
+avg, calls, mn, mx = st(DOM)
 expect = 2 * steps_of(no)
-dom = pmc_rec("ntt16_fwd_kernel<true>") or {}
+dom = pmc_rec(DOM) or {}
 cb = pl["cpu_baseline"]
 C = pl["config"]
 tot_bytes, cov = whole_step()
@@ -68,15 +71,24 @@ power = [l for l in open(P + tag + "_power_probe.txt").read().split("\n") if l.s
 pw = sorted(float(re.search(r"Power \(W\): ([0-9.]+)", l).group(1)) for l in power)
 ck = sorted(float(re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", l).group(1)) for l in power)
 ub = open(P + tag + "_ubench.txt").read()
+cb8, cb16, c2b8 = J("bench_cnn4_batch8"), J("bench_cnn4_batch16"), J("bench_cnn2_batch8")
+pn14b = [json.loads(l) for l in open(P + tag + "_pn14_batch.jsonl") if l.strip().startswith("{")] if os.path.exists(P + tag + "_pn14_batch.jsonl") else []
+sizes = open(P + tag + "_ntt16_launch_sizes.txt").read()
+def size_us(kernel_part, limbs):
+    parts = re.split(r"^== ", sizes, flags=re.M)
+    part = next((x for x in parts if kernel_part in x.split("\n")[0]), "")
+    m = re.search(r"limbs +%d .*? ([0-9.]+) us/launch" % limbs, part)
+    return float(m.group(1)) if m else float("nan")
+bf2 = re.search(r"two-butterfly asm block.*", ub)
 m31 = re.search(r"mm31 .*?8 waves/SIMD\s+[0-9.]+ ms\s+clock ([0-9.]+) GHz\s+([0-9.]+) ns .*?\(\s*([0-9.]+) cyc\)", ub)
 m30 = re.search(r"mm30u .*?8 waves/SIMD\s+[0-9.]+ ms\s+clock ([0-9.]+) GHz\s+([0-9.]+) ns .*?\(\s*([0-9.]+) cyc\)", ub)
-txt = f'''# profiles/ — measured on MI355X (gfx950), round 3
+txt = f'''# profiles/ — measured on MI355X (gfx950), round 4
 
 Distilled by `tools/collect_profiles.py` from ONE `gpurun` call of `tools/profile_round.sh` (the commands are in that script; build = the commit that carries these files); this file is written by
 `tools/write_profiles_readme.py`.  Files of earlier rounds (`r1*`, `r2*`, `r3*`) are kept for comparison.
 
-Every profiled pass runs the same command, `MKHE_NO_OVERLAP=1 python3 bench.py --steps K --warmup W --no-cpu --no-extras` (every kernel alone on the main stream).  Since round 3 `bench.py` runs its legs in this order: cold-start figure (W + K steps),
-300 steps of the steady-state leg, the timed region (W + K), the HIP-event leg (K) — so the dominant kernel, the Decompose-fused forward NTT `ntt16_fwd_kernel<true>` (twice per MulRelin: 1792 limbs for the hoisting of the 8 operand components, 896 limbs for the 4 intermediate t_i),
+Every profiled pass runs the same command, `MKHE_NO_OVERLAP=1 python3 bench.py --steps K --warmup W --no-cpu --no-extras` (every kernel alone on the main stream).  `bench.py` runs its legs in this order: cold-start figure (W + K steps),
+300 steps of the steady-state leg, the timed region (W + K), the HIP-event leg (K) — so the dominant kernel, the Decompose-fused forward NTT `{DOM}` (twice per MulRelin: 1792 limbs for the hoisting of the 8 operand components, 896 limbs for the 4 intermediate t_i),
 is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
 
 | file | command |
@@ -86,57 +98,57 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
 | `{tag}_kernel_stats_ovl.csv`, `{tag}_bench_ovl.json` | the same with the side-stream overlap on |
 | `traffic.json` | two passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of the same command with `--steps 6 --warmup 2` (dominant kernel: 2 × {2 * (2 + 6) + 300 + 6} = {2 * (2 * 8 + 306)} calls; recorded: {dom.get("launches", "?")}); tied to the kernel sources by `csrc_sha256` |
 | `{tag}_sq_counters.txt` | three `--pmc` passes (SQ wave / wait / instruction counters, LDS, L2 hit rate) with `--steps 4 --warmup 2` |
-| `{tag}_ntt16_isa.txt` | `tools/ntt16_isa.py`: instruction counts of the dominant kernel's U-class pass body from the gfx950 ISA, one butterfly verbatim, code-object record |
-| `{tag}_ubench.txt` | `tools/ubench/bfly30u_rate` (the round-3 butterfly against round 2's, bare, with a correctness check against the host), `bfly31_rate`, `valu_rate` |
+| `{tag}_ntt32_isa.txt` | `tools/ntt32_isa.py`: instruction counts of the dominant kernel from the gfx950 ISA, one two-butterfly asm block verbatim, code-object record (`{tag}_ntt16_isa.txt`: the same for the H16 kernel's pass body) |
+| `{tag}_ubench.txt` | `tools/ubench/bfly30u_rate`, `bfly31_rate`, `valu_rate`, and `bfly_asm_rate` (round 4: the butterfly as the compiler emits it beside the hand-scheduled two-butterfly block, 1 / 4 / 8 waves per SIMD) |
 | `{tag}_power_probe.txt` | `tools/power_probe.sh`: rocm-smi package power and shader clock beside 30 000 back-to-back launches of the dominant kernel |
-| `{tag}_ntt16_ablation.txt` | `tools/ntt16_variants.sh`: the dominant kernel re-built without its memory streams / LDS exchanges / butterflies (wrong results on purpose) and with the experiments that were not kept, 1500 launches each (steady state) |
-| `{tag}_ntt16_launch_sizes.txt` | `tools/ntt16_bench.py 1500`: the Decompose NTT at 1792 / 896 / 448 / 224 limbs |
+| `{tag}_ntt16_ablation.txt` | `tools/ntt16_variants.sh`: the single-pass kernel (and, second part, the H16 kernel) re-built without its memory streams / LDS exchanges / butterflies (wrong results on purpose) and with the experiments that were not kept, 1500 launches each (steady state) |
+| `{tag}_ntt16_launch_sizes.txt` | `tools/ntt16_bench.py 1500`: the Decompose NTT at 1792 / 896 / 448 / 224 limbs, default build and `MKHE_NTT32=0`, same call |
 | `{tag}_kernel_stats_bfv.csv`, `{tag}_bench_bfv*.json` | `bench.py --scheme bfv` under the profiler (overlap off) and plain |
-| `{tag}_pn16_traffic.txt` | `tools/pn16_traffic.sh` + `tools/pn16_traffic.py`: FETCH_SIZE / WRITE_SIZE per kernel of the PN16QP1761 8-party step, radix-4 Decompose beside `MKHE_SPREAD_RADIX4=0` |
 | `{tag}_bench_pn16*.json`, `{tag}_kernel_stats_pn16.csv` | `bench.py --params PN16QP1761 --parties 8` (configs[3] ring on one GPU; the plain run carries `config.device_keys_check`) |
-| `{tag}_bench_cnn2/4.json`, `{tag}_bench_pn14.json`, `{tag}_party_sweep.jsonl` | secondary workloads |
+| `{tag}_bench_cnn2/4.json`, `{tag}_bench_cnn4_batch8/16.json`, `{tag}_bench_cnn2_batch8.json` | `bench.py --scheme cnn --parties 2/4 [--batch B]` (the unbatched lines carry `cpu_baseline`) |
+| `{tag}_bench_pn14.json`, `{tag}_pn14_batch.jsonl`, `{tag}_party_sweep.jsonl` | secondary workloads; `bench.py --params PN14QP439 --batch 4/8/16` |
+| `{tag}_dist_5ranks.json` | `bench.py --gpus 5` with all ranks on the one device of the box (DESIGN.md §7) |
+| `{tag}_gputests*.txt`, `{tag}_switch_matrix.txt` | `pytest -m gpu` with the defaults and with the single-pass kernel forced onto every N = 2^15 launch (`MKHE_NTT32_MIN=1`) |
 
 ## Headline (BASELINE.json configs[1]): mkckks 4-party MulRelin, PN15QP880, N = 2^15, 14 Q + 2 P limbs
 
-* **{pl["value"]:.0f} MulRelin/s** ({pl["ms_per_step"]:.3f} ms per step: hoist both operands + MulAndRelinHoisted + Rescale; round 2: 1038, round 1: 763), bit-exact against the oracle on the same inputs in this very run
+* **{pl["value"]:.0f} MulRelin/s** ({pl["ms_per_step"]:.3f} ms per step: hoist both operands + MulAndRelinHoisted + Rescale; round 3: 1157–1207, round 2: 1038, round 1: 763), bit-exact against the oracle on the same inputs in this very run
   (`cpu_baseline.bit_exact_vs_gpu = {cb["bit_exact_vs_gpu"]}`); CPU oracle on the GPU box's host: {cb["value"]:.2f} MulRelin/s on 1 thread, {cb.get("value_limb_parallel", 0):.2f} with its limb loops on {cb.get("cores_limb_parallel", "?")} threads.
-* `value` is timed on settled clocks since round 3 (the secondary legs run before the timed region, DESIGN.md §6).  Same run: cold start (what rounds 1 and 2 reported) **{C.get("mulrelin_per_sec_cold_start", 0):.0f}/s**, 200 steps after 100 untimed ones
-  {C.get("mulrelin_per_sec_steady_state", 0):.0f}/s, two MulRelin in flight through forked contexts {C.get("mulrelin_per_sec_two_in_flight", 0):.0f}/s.
+* Same run: cold start **{C.get("mulrelin_per_sec_cold_start", 0):.0f}/s**, 200 steps after 100 untimed ones {C.get("mulrelin_per_sec_steady_state", 0):.0f}/s, two MulRelin in flight through forked contexts {C.get("mulrelin_per_sec_two_in_flight", 0):.0f}/s.
 * under `rocprofv3 --kernel-trace`, overlap off: {no["value"]:.0f} MulRelin/s ({no["ms_per_step"]:.3f} ms); overlap on: {ov["value"]:.0f} MulRelin/s ({ov["ms_per_step"]:.3f} ms).
-* **Box to box** the figures move by ± 2 % with the clock a part sustains at the 1400 W cap: the same kernel, default `bench.py`, on the boxes gpurun dealt on the last day of the round gave
-  1185 MulRelin/s / `roofline.frac` 0.498 (2.09 GHz under the NTT kernel), 1197 / 0.496 (2.13 GHz), 1212 / 0.510 (2.16 GHz), 1199 / 0.512 (2.14 GHz), 1216 / 0.515, 1206 / 0.501, 1217 / 0.510, 1175 / 0.494, 1232 / 0.520, 1209 / 0.502, 1164 / 0.488 and 1174 / 0.491 (this set; the last four with the smaller LDS sub-transforms of the small launches -- on the two slowest boxes the HBM-bound `ext_inner_kernel` is 5 % slower as well, 0.2615 against 0.2493 ms per step: the parts differ in more than the core clock); on the third box the library of the commit before ran
-  1206 / 0.510 in the same call -- kernel comparisons in this repository are therefore made inside one gpurun call (`MKHE_LIB=.../libmkhe_prev.so` beside the new build, or the A/B switches of DESIGN.md §6), never across calls.
+* **Box to box** the figures move by ± 2 % (round 3's list: 1164–1232 MulRelin/s, `roofline.frac` 0.488–0.520 for one build).  Round 4's A/B runs, each pair inside ONE gpurun call (`MKHE_NTT32=0` is the switch): single-pass kernel 1213 / 0.525, 1218 / 0.531, 1215 / 0.527
+  against 1185 / 0.508, 1207 / 0.515, 1188 / 0.510 for the H16 kernel; this set: {pl["value"]:.0f} / {R["frac"]:.3f}.
 
-Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per step.  "algorithmic GB/s" is the byte model of DESIGN.md §4 (`roofline.kernels_over_peak` = {R.get("kernels_over_peak")}: no model claims more than the chip moves any more);
+Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per step.  "algorithmic GB/s" is the byte model of DESIGN.md §4 (`roofline.kernels_over_peak` = {R.get("kernels_over_peak")});
 "PMC GB/s" is what the kernel really moved through the L2's memory side, (2·FETCH_SIZE + WRITE_SIZE) from `traffic.json` over the same launch pattern:
 
 | kernel | launches/step | avg µs/launch | ms/step | algorithmic GB/s | PMC GB/s |
 |---|---|---|---|---|---|
 {table(pl, True)}
 
-Whole step: the kernels with a PMC column ({100 * cov:.0f} % of the kernel time) move **{tot_bytes / 1e9:.2f} GB per MulRelin** through HBM (round 2: 3.40 GB) = {tot_bytes / 1e9 / pl["ms_per_step"]:.2f} TB/s averaged over the {pl["ms_per_step"]:.3f} ms step.  The three streaming launches
-are at their compulsory bytes (y: 528 MB, F1 + x: 587 MB, E / F2: 822 MB); what remains above the 1.75 GB of SURVEY.md §8(d)'s compulsory model is the second read of one operand's hoisted digits (y needs h(c1), step E needs it again once x exists — x and y depend on
-each other's operands, one of the two is read twice), the x / y round trip, and the Decompose NTT's re-reads (below).
+Whole step: the kernels with a PMC column ({100 * cov:.0f} % of the kernel time) move **{tot_bytes / 1e9:.2f} GB per MulRelin** through HBM (round 3: 2.76, round 2: 3.40 GB) = {tot_bytes / 1e9 / pl["ms_per_step"]:.2f} TB/s averaged over the {pl["ms_per_step"]:.3f} ms step.  The three streaming launches
+are at their compulsory bytes (y: 528 MB, F1 + x: 587 MB, E / F2: 822 MB).
 
-### Dominant kernel `ntt16_fwd_kernel<true>` (DESIGN.md §3 "Round 3", §4)
+### Dominant kernel `{DOM}` (DESIGN.md §4 "The single-pass kernel")
 
 * HIP-event average inside `bench.py`: **{R["avg_launch_us"]:.1f} µs per launch** (plain run), {Rn["avg_launch_us"]:.1f} µs in the profiled run; rocprofv3 kernel-trace average of that profiled run: **{avg:.1f} µs** over {calls} calls
-  (min {mn:.0f} = the 896-limb launches, max {mx:.0f} µs).  Round 2: 207 µs, round 1 (`ntt_fwd_kernel<15,2,true>`): 297.5 µs.
-* algorithmic bytes per launch {R["alg_bytes_per_launch"] / 1e6:.1f} MB (16·N B per limb-NTT × (1792 + 896)/2 limbs) ⇒ **{R["achieved"]:.0f} GB/s = {R["frac"]:.3f} of the 8 TB/s HBM peak** (round 2: 0.42, round 1: 0.296).
+  (min {mn:.0f} = the 896-limb launches, max {mx:.0f} µs).  Round 3 (`ntt16_fwd_kernel<true>`): 172–176 µs, round 2: 207 µs, round 1 (`ntt_fwd_kernel<15,2,true>`): 297.5 µs.
+* algorithmic bytes per launch {R["alg_bytes_per_launch"] / 1e6:.1f} MB (16·N B per limb-NTT × (1792 + 896)/2 limbs) ⇒ **{R["achieved"]:.0f} GB/s = {R["frac"]:.3f} of the 8 TB/s HBM peak** (round 3: 0.50–0.51, round 2: 0.42, round 1: 0.296).
   By the compulsory bytes of the fused Decompose ({R.get("compulsory_bytes_per_launch", 0) / 1e6:.0f} MB per average launch) it is {R.get("frac_compulsory", 0):.3f}.
 * HBM traffic from the PMC passes: {dom.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch (FETCH_SIZE {dom.get("fetch_size_kb", 0) / 1e3:.1f} MB ×2 + WRITE_SIZE {dom.get("write_size_kb", 0) / 1e3:.1f} MB) =
-  {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and nothing else (no spilled VGPR, no scratch: `{tag}_ntt16_isa.txt`; round 2 wrote 403 MB, the first build of round 3 396 MB).  Read: the source limbs in both passes
-  (each is spread under 16 moduli) and the twiddle pairs — an XCD's 4 MiB L2 holds neither its 14 source limbs (3.5 MB) plus the tables of the 4–5 moduli in flight (1.5 MB), so part of the re-reads come from the Infinity Cache.
-* **It runs at the package power cap** (`{tag}_power_probe.txt`): {pw[len(pw) // 2]:.0f} W (median of the samples under load; cap 1400 W, idle 236 W) at {ck[len(ck) // 2] / 1e3:.2f} GHz.  After an idle phase the clocks need ≈ 150 ms to settle: ten back-to-back launches (round 2's tables)
-  measure 355 µs for 1792 limbs, 1500 launches **{abl("shipped"):.0f} µs** = {abl("shipped") / 1792:.3f} µs per limb ({R["avg_launch_us"] / 1344:.3f} µs per limb inside the MulRelin, whose launches alternate with memory-bound kernels).
-* **Steady-state ablation of the shipped kernel** (`{tag}_ntt16_ablation.txt`, 1792 limbs, µs per launch): shipped {abl("shipped"):.0f}; no result stores {abl("no_store"):.0f}, no source loads {abl("no_src"):.0f}, no per-lane twiddle loads {abl("no_tw"):.0f},
-  no LDS exchanges {abl("no_xchg"):.0f}; no memory stream at all {abl("no_mem"):.0f}; neither memory nor exchanges — the vector-ALU side alone — **{abl("no_mem_no_xchg"):.0f}** ({16 * 32768 * 1792 / abl("no_mem_no_xchg") / 8e6:.2f} of the roofline); all butterflies removed — the memory / LDS side alone — **{abl("no_bfly"):.0f}**;
-  exchanges and barriers alone {abl("skeleton"):.0f}.  0.50 of the roofline would be 235 µs: above both floors, but only with 87 % of either side hidden under the other; the kernel hides about two thirds.  Experiments on hiding more, same table:
-  one memory round trip per pass (`pipelined_loads`) {abl("pipelined_loads"):.0f}, parking instead of recomputing stage 0 (`force_park`) {abl("force_park"):.0f}, phase D on the one-round product (`phase_d_one_round`, 10 spilled VGPRs) {abl("phase_d_one_round"):.0f}.
-  LDS writes as plain `ds_write_b32` (`plain_lds_writes`) {abl("plain_lds_writes"):.0f}, no raised wave priority in front of the cross-wave barriers (`no_priority`) {abl("no_priority"):.0f}, the last LDS reads of a re-distribution flowing into the next phase (`flowing_lds_reads`) {abl("flowing_lds_reads"):.0f}.
-  What round 3 changed: the U class off (`MKHE_H16_UCLASS=0`) {abl("U class off"):.0f}, the round-2 reduction schedule for the 59/60-bit primes {abl("round-2 reduction schedule"):.0f}.
-* `{tag}_ubench.txt`: the bare butterfly on `mm31` (round 2) {m31.group(3) if m31 else "?"} cycles per wave at {m31.group(1) if m31 else "?"} GHz = {m31.group(2) if m31 else "?"} ns, on `mm30u` (round 3: unsigned low data digit, no fix-up instructions) **{m30.group(3) if m30 else "?"} cycles at {m30.group(1) if m30 else "?"} GHz = {m30.group(2) if m30 else "?"} ns**
-  (65 536 products checked against the host first).  `{tag}_ntt16_isa.txt`: 13.6 VALU instructions per butterfly in the U-class pass body of the shipped code object (round 2: 17.7).
+  {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes (H16, round 3: 0.93×: the second pass's re-read of the source is gone).  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and nothing else (no scratch: `{tag}_ntt32_isa.txt`).  Read: every source limb once per modulus it is spread under (mostly L2 hits) and 512 KB of twiddle pairs per limb-NTT —
+  as many bytes as the limb itself moves; they come from the L2 / Infinity Cache (16 moduli × 1 MB of tables).
+* Back to back (`{tag}_ntt16_launch_sizes.txt`, 1500 launches, same call): 1792 limbs **{size_us("default", 1792):.1f} µs** against {size_us("MKHE_NTT32=0", 1792):.1f} for the H16 kernel; 896 limbs {size_us("default", 896):.1f} against {size_us("MKHE_NTT32=0", 896):.1f} (one workgroup per CU deals whole limbs: four rounds for 3.5 rounds of work);
+  448 and 224 limbs stay on the H16 kernel ({size_us("default", 448):.1f} / {size_us("default", 224):.1f} µs).  VERDICT r3's 235 / 117 µs are not reached.
+* Power (`{tag}_power_probe.txt`): {pw[len(pw) // 2]:.0f} W (median of the samples under load; cap 1400 W) at {ck[len(ck) // 2] / 1e3:.2f} GHz — the H16 kernel sat at the cap at 2.09 GHz.
+* **Steady-state ablation** (`{tag}_ntt16_ablation.txt`, 1792 limbs, µs per launch): shipped {abl("shipped"):.0f}; no result stores {abl("no_stores"):.0f}, no source loads {abl("no_source_loads"):.0f}, no twiddle loads {abl("no_twiddle_loads"):.0f}, no LDS exchanges {abl("no_exchanges"):.0f};
+  the vector-ALU side alone (no loads, stores, exchanges) **{abl("butterflies_only"):.0f}**; all butterflies removed **{abl("no_butterflies"):.0f}**; butterflies and twiddle loads removed {abl("no_butterflies_no_twiddles"):.0f} (the data stream alone: {16 * 32768 * 1792 / abl("no_butterflies_no_twiddles") / 8e6:.2f} of the roofline).
+  Both sides are as long as the whole: the kernel no longer waits for one of them, it is as long as its butterflies AND as long as its memory instructions with their waits — the twiddle pairs are half of the second (per limb: 31 per-lane 16-byte loads + 31 `ds_read_b128` per thread, against 32 + 32 eight-byte data accesses).
+  Not kept, same table: no phase priorities {abl("no_phase_priorities"):.0f}, one priority set {abl("one_priority_set"):.0f}, eight twiddle pairs in flight {abl("ring_8"):.0f}, one butterfly per asm block {abl("one_butterfly_per_asm_block"):.0f}.
+  Second part of the file, the H16 kernel in the same call: shipped {abl("shipped", kernel="ntt16"):.0f}, vector-ALU side alone {abl("no_mem_no_xchg", kernel="ntt16"):.0f}, no butterflies {abl("no_bfly", kernel="ntt16"):.0f}.
+* `{tag}_ubench.txt`: the U-class butterfly as one lone wave issues it — compiler's form {re.search(r"compiler's form \(nops\)\s+waves/SIMD\s+1\.0.*?([0-9.]+) cycles", ub).group(1) if re.search(r"compiler's form \(nops\)\s+waves/SIMD\s+1\.0.*?([0-9.]+) cycles", ub) else "?"} cycles,
+  the hand-scheduled two-butterfly block {re.search(r"subtract before add\s+waves/SIMD\s+1\.0.*?([0-9.]+) cycles", ub).group(1) if re.search(r"subtract before add\s+waves/SIMD\s+1\.0.*?([0-9.]+) cycles", ub) else "?"}; with four waves per SIMD (the kernel's occupancy)
+  {re.search(r"compiler's form \(nops\)\s+waves/SIMD\s+4\.0.*?([0-9.]+) cycles", ub).group(1) if re.search(r"compiler's form \(nops\)\s+waves/SIMD\s+4\.0.*?([0-9.]+) cycles", ub) else "?"} against {re.search(r"subtract before add\s+waves/SIMD\s+4\.0.*?([0-9.]+) cycles", ub).group(1) if re.search(r"subtract before add\s+waves/SIMD\s+4\.0.*?([0-9.]+) cycles", ub) else "?"}: 12 VALU instructions per butterfly are ≈ 49 cycles of a SIMD, 240 butterflies per thread and limb ≈ 47 000 of the ≈ 80 000 cycles a limb takes.
 
 ### Streaming kernels
 
