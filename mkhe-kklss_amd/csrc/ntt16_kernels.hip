@@ -866,7 +866,9 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         jb.psi31n = kb->psi31n + 8 * (long)m;
         // the per-modulus schedule assumes inputs below 2^60; lazy inputs (BFV digits and ring-R polynomials: src_lazy) and the halves of a split
         // N = 2^16 limb (values in [0, 4q) behind the streaming cross-half stage) keep the round-2 schedule: reduce at the load and after every phase
-        jb.sched = (kb->src_lazy || (SPLIT && LOGN == 15)) ? 15 : kb->sched[m];
+        // (the byte through a scalar dword load: a byte load of a kernel argument is a VECTOR memory instruction, and the s_waitcnt vmcnt(0) the
+        // compiler puts behind it waits for every store of the previous job before this one has requested a word -- round 3 shipped that)
+        jb.sched = (kb->src_lazy || (SPLIT && LOGN == 15)) ? 15 : (int)((((const __attribute__((address_space(4))) unsigned*)kb->sched)[m >> 2] >> (8 * (m & 3))) & 0xffu);
         jb.root = 1;
         if constexpr (SPLIT && LOGN == 15) { const int half = job2 & 1; jb.src += half * NN; jb.dst += half * NN; jb.root = 2 + half; }
         if constexpr (SPLIT && LOGN == 14) { const int quarter = job2 & 3; jb.src += quarter * NL; jb.dst += quarter * NL; jb.root = 4 + quarter; }

@@ -58,6 +58,9 @@ constexpr int RING = MKHE_H32_RING;        // twiddle pairs (4 VGPRs each) live 
 #ifndef MKHE_H32_PHPRIO
 #define MKHE_H32_PHPRIO 2
 #endif
+#ifndef MKHE_H32_PREFETCH
+#define MKHE_H32_PREFETCH 0                // (experiment, slower by 3 %: DESIGN.md) the next limb's source loads are issued between the stores of this one (register by register)
+#endif
 #ifndef MKHE_NTT32_EVEN_DEFAULT
 #define MKHE_NTT32_EVEN_DEFAULT 0
 #endif
@@ -235,8 +238,22 @@ __device__ __forceinline__ void phase_lane(u64 (&x)[32], gcptr base, const unsig
 #define H32_STAMP(k) do { } while (0)
 #endif
 // one limb; big: a 59/60-bit modulus (balanced path only)
+// asm forms of the source load and the result store: issued in program order (volatile, memory clobber), invisible to the compiler's own
+// s_waitcnt bookkeeping -- the counted waits of stage 0 are written out (wait_pair)
+__device__ __forceinline__ void ld_into(u64& v, gcptr base, unsigned byte_off) {
+#ifdef MKHE_H16_X_NOSRC         // MKHE_ABLATION: timing experiment only (wrong results)
+    v = (u64)byte_off * 0x9E3779B97F4A7C15ull; return;
+#endif
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void st_nt(gptr base, unsigned byte_off, u64 v) {
+#ifdef MKHE_H32_X_NOSTORE       // MKHE_ABLATION: timing experiment only
+    if (v != 0x123456789abcdefull) return;
+#endif
+    asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
+}
 template <bool DEC, bool UC>
-__device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, const int wv) {
+__device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, const int wv, u64 (&x)[32]) {
     const bool big = UC ? false : big_;
     smodptr mp = jb.mp;
     const u64 qs = mp->qs;
@@ -256,7 +273,6 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
     gcptr p31v = (gcptr)jb.psi31;
     const gcptr src = jb.src; const gptr dst = jb.dst;
     const bool red = DEC && jb.red;
-    u64 x[32];
     H32_STAMP(0);
     // ---- loads (pairs x[g], x[g + 16] in the order stage 0 consumes them) + stage 0 behind counted waits
     if (MKHE_H32_PRIO) __builtin_amdgcn_s_setprio(MKHE_H32_PRIO);
@@ -264,14 +280,21 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         const unsigned tb = 8u * (unsigned)(wv * 64 + lane_id());
         // this wave's phase-B twiddle row (issued first: it has landed when the last counted wait below returns)
         u64 trow[2];
+#if MKHE_H32_PREFETCH
+        // the loads are in flight (issued between the previous limb's stores: step g = store r_g, store r_g + 16, load x[g], load x[g + 16]; the
+        // first limb's have landed): behind the pair of step g there are 4 (15 - g) memory operations and this load
+        (void)tb; (void)src;
+        ld2(trow, (gcptr2)sbase((gcptr)jb.psi31n) + 64 * wv, (unsigned)lane_id());
+#else
         ld2(trow, (gcptr2)sbase((gcptr)jb.psi31n) + 64 * wv, (unsigned)lane_id());
 #pragma unroll
         for (int g = 0; g < 16; ++g) { x[g] = ld_issue(sbk(src, g * NT), tb); x[g + 16] = ld_issue(sbk(src, (g + 16) * NT), tb); }
+#endif
         const u64 t0[2] = {p31[2], p31[3]};                 // psi[1]
         static_for(std::make_integer_sequence<int, 8>{}, [&](auto gc) {
             constexpr int g = 2 * decltype(gc)::value;
-            wait_pair<30 - 2 * g>(x[g], x[g + 16]);
-            wait_pair<28 - 2 * g>(x[g + 1], x[g + 17]);
+            wait_pair<MKHE_H32_PREFETCH ? 61 - 4 * g : 30 - 2 * g>(x[g], x[g + 16]);
+            wait_pair<MKHE_H32_PREFETCH ? 57 - 4 * g : 28 - 2 * g>(x[g + 1], x[g + 17]);
             // digits of a foreign modulus (Decompose) may be far above q: bring them to (-q, q) first where the class has no headroom for them
             if ((big && (jb.sched & 1)) || red) {
                 x[g] = (u64)pred((i64)x[g], c); x[g + 16] = (u64)pred((i64)x[g + 16], c);
@@ -364,24 +387,40 @@ __device__ __forceinline__ void limb(const Job& jb, const bool big_, u32* lds, c
         }
     }
     H32_STAMP(7);
-    // ---- C -> E and the stores: register r = words wave * 2048 + 64 r + lane
-    {
-        const int l = lane_id();
-        lptr wr = (lptr)lds + wv * WREG + l;
-        vlptr rd = (vlptr)((lptr)lds + wv * WREG + 65 * (l & 31) + (l >> 5));
-        exchange<65, 2, false>(x, wr, rd);
-        H32_STAMP(8);
-        const unsigned lb = 8u * (unsigned)l;
+}
+// ---- C -> E and the stores: register r = words wave * 2048 + 64 r + lane.  Common to both modulus classes, and with MKHE_H32_PREFETCH the ONE place
+// where source loads are issued: register by register the next limb's words follow this limb's stores into the memory pipeline (nsrc: the
+// next job's source, or this one's again behind the last job -- loads nobody waits for), so that stage 0 of the next limb starts behind two
+// stores and two loads instead of behind thirty-two stores and its own request.
+__device__ __forceinline__ void tail(u64 (&x)[32], const Job& jb, gcptr nsrc, u32* lds, const int wv) {
+    const gptr dst = jb.dst;
+    const int l = lane_id();
+    lptr wr = (lptr)lds + wv * WREG + l;
+    vlptr rd = (vlptr)((lptr)lds + wv * WREG + 65 * (l & 31) + (l >> 5));
+    exchange<65, 2, false>(x, wr, rd);
+    H32_STAMP(8);
+    const unsigned lb = 8u * (unsigned)l;
+#if MKHE_H32_PREFETCH
+    const unsigned tb = 8u * (unsigned)(wv * 64 + l);
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-#ifdef MKHE_H32_X_NOSTORE       // MKHE_ABLATION: timing experiment only
-            if (x[r] != 0x123456789abcdefull) continue;
-#endif
-            __builtin_nontemporal_store(x[r], (u64 __attribute__((address_space(1)))*)at(sbk(dst, wv * 2048 + r * 64), lb));
-        }
-        H32_STAMP(9);
-        if (MKHE_H32_PHPRIO == 1) __builtin_amdgcn_s_setprio(0);
+    for (int g = 0; g < 16; ++g) {
+        st_nt(sbk(dst, wv * 2048 + g * 64), lb, x[g]);
+        st_nt(sbk(dst, wv * 2048 + (g + 16) * 64), lb, x[g + 16]);
+        ld_into(x[g], sbk(nsrc, g * NT), tb);
+        ld_into(x[g + 16], sbk(nsrc, (g + 16) * NT), tb);
     }
+#else
+    (void)nsrc;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+#ifdef MKHE_H32_X_NOSTORE       // MKHE_ABLATION: timing experiment only
+        if (x[r] != 0x123456789abcdefull) continue;
+#endif
+        __builtin_nontemporal_store(x[r], (u64 __attribute__((address_space(1)))*)at(sbk(dst, wv * 2048 + r * 64), lb));
+    }
+#endif
+    H32_STAMP(9);
+    if (MKHE_H32_PHPRIO == 1) __builtin_amdgcn_s_setprio(0);
 }
 
 template <bool DEC>
@@ -396,10 +435,10 @@ __global__ void __launch_bounds__(NT, 4) __attribute__((amdgpu_num_vgpr(128))) n
 #elif MKHE_H32_STAGGER == 4
     { const int g = wv >> 2; if (g == 0) __builtin_amdgcn_s_setprio(3); else if (g == 1) __builtin_amdgcn_s_setprio(2); else if (g == 2) __builtin_amdgcn_s_setprio(1); }
 #endif
-#pragma unroll 1
-    for (int job2 = blockIdx.x; job2 < njobs; job2 += gridDim.x) {
-        // placement of the long jobs (59/60-bit moduli, the head of the slot-major list) on the CUs that own one position fewer when the list
-        // leaves the last row ragged: the bijection of ntt16_kernels.hip fwd_body with C = the number of workgroups (one per CU here)
+    // job2 (position in this workgroup's walk) -> job (index in the slot-major list): the long jobs (59/60-bit moduli, the head of the list) are
+    // placed on the CUs that own one position fewer when the list leaves the last row ragged -- the bijection of ntt16_kernels.hip fwd_body with
+    // C = the number of workgroups (one per CU here)
+    auto job_of = [&](int job2) {
         int job = job2;
         kargptr kl = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
         const int B = kl->lpt.B;
@@ -411,6 +450,46 @@ __global__ void __launch_bounds__(NT, 4) __attribute__((amdgpu_num_vgpr(128))) n
             if (col >= r && col - r < srow) job = before + (col - r);
             else job = B + job2 - before - (col > r ? (col - r < srow ? col - r : srow) : 0);
         }
+        return job;
+    };
+    // source limb of a job
+    auto src_of = [&](int job) {
+        kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kb));
+        const int nouter = kb->nouter;
+        const int s = (int)udiv_magic((unsigned)job, kb->magic_nouter);
+        int outer = job - s * nouter;
+        const int m = kb->mod[s], p = kb->pos[s];
+        const u64* sbase_ = kb->src;
+        if (kb->nitems > 0) {
+            const int item = (int)udiv_magic((unsigned)outer, kb->magic_opi);
+            outer -= item * kb->outers_per_item;
+            sbase_ = kb->src_items[item];
+        }
+        return (gcptr)(sbase_ + (long)outer * kb->src_outer + (long)(kb->src_mapped ? m : p) * kb->src_inner);
+    };
+    u64 x[32];
+    // all registers of x behind every memory operation in flight (s_waitcnt vmcnt(0)): where the compiler may move them (between the two loops below)
+    auto landed = [&] {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]),
+                     "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) : : "memory");
+        asm volatile("" : "+v"(x[16]), "+v"(x[17]), "+v"(x[18]), "+v"(x[19]), "+v"(x[20]), "+v"(x[21]), "+v"(x[22]), "+v"(x[23]), "+v"(x[24]), "+v"(x[25]),
+                     "+v"(x[26]), "+v"(x[27]), "+v"(x[28]), "+v"(x[29]), "+v"(x[30]), "+v"(x[31]) : : "memory");
+    };
+#if MKHE_H32_PREFETCH
+    if ((int)blockIdx.x < njobs) {
+        // the first limb's words (every later limb's are requested by the limb before it); landed before the loop: one exposed round trip per launch
+        const gcptr src0 = src_of(job_of(blockIdx.x));
+        const unsigned tb = 8u * (unsigned)((int)threadIdx.x);
+#pragma unroll
+        for (int g = 0; g < 32; ++g) ld_into(x[g], sbk(src0, g * NT), tb);
+        landed();
+    }
+#endif
+    // one limb: the job's constants, the transform (limb<DEC, UC>), the stores with the next job's loads between them (tail)
+    auto body = [&](const int job2, auto ucc) {
+        constexpr bool UC = decltype(ucc)::value;
+        const int job = job_of(job2);
         kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kb));
         const int nouter = kb->nouter;
@@ -435,7 +514,9 @@ __global__ void __launch_bounds__(NT, 4) __attribute__((amdgpu_num_vgpr(128))) n
         jb.psif = kb->psi31c + (long)m * (16 * 31 * 64 * 2);      // (this kernel's use of the slot: the load-order pairs of the last phase)
         // bit 0 of the H16 schedule (reduce at the load) carries over: inputs below 2^60 leave a 59/60-bit modulus below 2^62.9 through the five
         // stages of phase A (2^60 + 5 * 1.03 q); lazy inputs (BFV digits, ring-R polynomials) are reduced at the load
-        jb.sched = kb->src_lazy ? 15 : kb->sched[m];
+        // (the byte through a scalar dword load: a byte load is a VECTOR memory instruction, and the s_waitcnt vmcnt(0) the compiler puts behind it
+        // would wait for every store and prefetched word of the previous limb right here)
+        jb.sched = kb->src_lazy ? 15 : (int)((((const __attribute__((address_space(4))) unsigned*)kb->sched)[m >> 2] >> (8 * (m & 3))) & 0xffu);
         jb.mp = (smodptr)kb->mods + m;
         jb.skip_norm = kb->skip_norm != 0;
         jb.red = false;
@@ -446,18 +527,40 @@ __global__ void __launch_bounds__(NT, 4) __attribute__((amdgpu_num_vgpr(128))) n
             const u64 qsb = ((smodptr)kb->mods)[sm].q << (kb->src_lazy ? 2 : 0);     // bound of the digit values (< 2^63)
             // U class: raw canonical digits of any modulus (< 2^60) fit its range budget (input + 75 q of growth + the 75 q bias < 2^62); the balanced
             // path reduces what exceeds 4q -- the rules of ntt16_kernels.hip
-            if ((kb->u_mods >> m) & 1) jb.red = qsb >= (1ull << 62) - 150 * jb.mp->q;
+            if constexpr (UC) jb.red = qsb >= (1ull << 62) - 150 * jb.mp->q;
             else jb.red = qsb > 4 * jb.mp->q;
         }
 #ifdef MKHE_PHASE_TRACE
         if (jb.trace && ((int)threadIdx.x & 63) == 0) { u64* tw = jb.trace + (long)wv * 32; tw[12] = __builtin_amdgcn_s_memrealtime(); tw[14] = blockIdx.x; tw[15] = m; }
 #endif
-        if ((kb->u_mods >> m) & 1) limb<DEC, true>(jb, false, lds, wv);
-        else limb<DEC, false>(jb, ((kb->small_slots >> s) & 1) == 0, lds, wv);
+        limb<DEC, UC>(jb, UC ? false : ((kb->small_slots >> s) & 1) == 0, lds, wv, x);
+        // (the next job's source, this one's again behind the last: see tail)
+        gcptr nsrc = jb.src;
+        if (MKHE_H32_PREFETCH && job2 + (int)gridDim.x < njobs) nsrc = src_of(job_of(job2 + (int)gridDim.x));
+        tail(x, jb, nsrc, lds, wv);
 #ifdef MKHE_PHASE_TRACE
         if (jb.trace && ((int)threadIdx.x & 63) == 0) jb.trace[(long)wv * 32 + 13] = __builtin_amdgcn_s_memrealtime();
 #endif
-    }
+    };
+    // the launcher lists the slots of the balanced path first (59/60-bit moduli, then the ones between the classes) and the U class last, and the
+    // placement above keeps that order inside every workgroup's walk: two loops with ONE instantiation of the limb each -- in one loop with both,
+    // the 32 registers in flight across the back edge meet a two-way merge, and the allocator moves (spills) them there
+    auto is_u = [&](const int job2) {
+        kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+        const int s = (int)udiv_magic((unsigned)job_of(job2), kb->magic_nouter);
+        return ((kb->u_mods >> kb->mod[s]) & 1) != 0;
+    };
+    int job2 = blockIdx.x;
+#pragma unroll 1
+    for (; job2 < njobs && !is_u(job2); job2 += gridDim.x) body(job2, std::false_type{});
+#if MKHE_H32_PREFETCH
+    landed();
+#endif
+#pragma unroll 1
+    for (; job2 < njobs; job2 += gridDim.x) body(job2, std::true_type{});
+#if MKHE_H32_PREFETCH
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the loads behind the last job's stores)
+#endif
 }
 
 }  // namespace h32
@@ -491,14 +594,18 @@ void launch_ntt32_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
     using namespace h32;
     NttBatch c = b;
     // big-modulus limbs (the longer jobs) first, as in launch_ntt16_fwd
+    // ... then the moduli between the classes, the U class last (the kernel runs the two instantiations of its limb in two loops, in this order)
     c.small_slots = 0; c.nslots = 0;
-    for (int cls = 0; cls < 2; ++cls)
-        for (int s = 0; s < b.nslots; ++s)
-            if ((small_q[b.mod[s]] != 0) == (cls == 1)) {
+    for (int cls = 0; cls < 3; ++cls)
+        for (int s = 0; s < b.nslots; ++s) {
+            const bool small = small_q[b.mod[s]] != 0, u = small && ((b.u_mods >> b.mod[s]) & 1);
+            if ((cls == 0 && !small) || (cls == 1 && small && !u) || (cls == 2 && u)) {
                 c.mod[c.nslots] = b.mod[s]; c.pos[c.nslots] = b.pos[s];
                 if (cls) c.small_slots |= 1ull << c.nslots;
                 ++c.nslots;
             }
+        }
+    if (c.nslots != b.nslots) throw std::runtime_error("mkhe: internal: a U-class modulus outside the small class");
     const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
     static LaunchState32 ls;
     int dev = 0;

@@ -84,7 +84,7 @@ struct NttBatch {
     const u64* psi31n;      // [nmod][4][2]: the pairs of -psi[1], -psi[2], -psi[3] (entries 1..3), for the second pass of the cross-half stage
     unsigned long long u_mods;   // bit m set = modulus m is of the U class (160 q < 2^62): its psi31 rows hold the UNSIGNED radix-2^30 format
                             // (u = w 2^30 mod q in [0, q) as digits u0, u1 >= 0; v = w 2^62 mod q balanced) of ntt16_kernels.hip mm30u
-    unsigned char sched[NTT_MAX_SLOTS];   // ntt16_kernels.hip, indexed by MODULUS: where a limb of a 59/60-bit modulus gets its partial reductions when its
+    alignas(4) unsigned char sched[NTT_MAX_SLOTS];   // ntt16_kernels.hip, indexed by MODULUS: where a limb of a 59/60-bit modulus gets its partial reductions when its
                             // inputs are below 2^60 (bit 0: at the load, bits 1..3: after phases A, B, C); Context::h16_sched_
     // ntt16_kernels.hip, filled by its launchers: reciprocals for the per-limb index arithmetic (scalar multiply-high instead of VALU
     // divisions) and the placement of the long jobs (the first B jobs of the list: big-modulus limbs) on the CUs that own fewer positions

@@ -116,3 +116,28 @@ def test_h32_kernel_fits_one_workgroup_per_cu_without_scratch():
     r = _isa("ntt32_kernels.hip", "-DMKHE_H32_X_NOBFLY")
     assert r.returncode != 0 and "MKHE_ABLATION" in r.stderr
     assert _isa("ntt32_kernels.hip", "-DMKHE_H32_X_NOBFLY", "-DMKHE_ABLATION").returncode == 0
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("src", ["ntt16_kernels.hip", "ntt32_kernels.hip"])
+def test_forward_kernels_read_their_job_constants_with_scalar_loads(src):
+    """Round 3 shipped `kb->sched[m]` (a byte of the kernel arguments, dynamic index) in the job walk of every H16-class forward kernel: a byte load
+    is a VECTOR memory instruction (global_load_ubyte + v_readfirstlane), and the `s_waitcnt vmcnt(0)` the compiler has to put between the two waited
+    for every result store of the previous job before the next one had requested a single word -- 6-7 % of the kernels' time back to back
+    (round 4: 246 -> 229 us for 1792 limbs on H32, 258 -> 242 on H16).  The constants of a job are wave-uniform and come through s_load: no
+    sub-dword vector load may appear in these files, and the only dword vector loads are the data / twiddle loads (x2 and x4)."""
+    r = _isa(src)
+    assert r.returncode == 0, r.stderr[-1500:]
+    bad = [l.strip() for l in r.stdout.splitlines() if l.strip().startswith(("global_load_ubyte", "global_load_sbyte", "global_load_ushort", "global_load_sshort",
+                                                                             "global_load_dword ", "flat_load", "buffer_load"))]
+    assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_h32_prefetch_experiment_keeps_its_registers_in_flight_untouched():
+    """-DMKHE_H32_PREFETCH=1 (not the default: slower by 3 %) requests the next limb's words between the stores of the current one; the 64
+    destination registers are in flight across the loop's back edge, invisible to the compiler.  tools/ntt32_inflight_check.py walks the ISA from
+    the requests to the counted waits of stage 0: no instruction may touch a register before the wait that covers it, and no full vector-memory
+    wait may precede the first counted one."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ntt32_inflight_check.py"), "-DMKHE_H32_PREFETCH=1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
