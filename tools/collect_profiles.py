@@ -12,12 +12,13 @@ for d, name in (("stats_noovl", "kernel_stats_noovl"), ("stats_ovl", "kernel_sta
     f = os.path.join(G, d, "p_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.csv" % (tag, name)))
-for f in ("bench_plain", "bench_noovl", "bench_ovl", "bench_bfv", "bench_bfv_plain", "bench_pn16", "bench_pn16_noovl", "bench_cnn2", "bench_cnn4", "bench_pn14"):
+for f in ("bench_plain", "bench_noovl", "bench_ovl", "bench_bfv", "bench_bfv_plain", "bench_pn16", "bench_pn16_noovl", "bench_cnn2", "bench_cnn4", "bench_pn14",
+          "bench_cnn4_batch8", "bench_cnn4_batch16", "bench_cnn2_batch8"):
     src = os.path.join(G, f + ".json")
     if os.path.exists(src) and os.path.getsize(src) > 10:
         shutil.copy(src, os.path.join(P, "%s_%s.json" % (tag, f)))
 for f, t in (("party_sweep.jsonl", "party_sweep.jsonl"), ("ubench.txt", "ubench.txt"), ("ntt16_bench.txt", "ntt16_launch_sizes.txt"), ("power_probe.txt", "power_probe.txt"),
-             ("ntt16_ablation.txt", "ntt16_ablation.txt")):
+             ("ntt16_ablation.txt", "ntt16_ablation.txt"), ("ntt_in_context.txt", "ntt_in_context.txt"), ("pn14_batch.jsonl", "pn14_batch.jsonl")):
     src = os.path.join(G, f)
     if os.path.exists(src):
         txt = "\n".join(l for l in open(src).read().split("\n") if not l.startswith(("RCCL", "HIP version", "ROCm version", "Hostname", "Librccl", "/opt/amdgpu")))
@@ -60,5 +61,6 @@ with open(os.path.join(P, "%s_sq_counters.txt" % tag), "w") as f:
         if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
             f.write("   L2 hit rate %.3f\n" % (c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ntt16_isa.py"), tag], stdout=subprocess.DEVNULL)
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ntt32_isa.py"), tag], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_profiles_readme.py"), tag])
 print("profiles/ updated:", sorted(x for x in os.listdir(P) if x.startswith(tag) or x in ("traffic.json", "README.md")))

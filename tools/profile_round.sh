@@ -42,17 +42,20 @@ for B in 4 8 16; do python3 bench.py --params PN14QP439 --steps 30 --warmup 3 --
 for k in 1 2 4 8 16; do python3 bench.py --parties $k --no-cpu --device-keys --steps 20 --warmup 3 2>/dev/null; done > $O/party_sweep.jsonl
 echo "secondary done"
 # issue-rate microbenchmarks (built from source here: no binaries in the tree), power / clock under the dominant kernel, steady-state ablation table of the shipped kernel
-for u in bfly30u_rate bfly31_rate valu_rate bfly_asm_rate; do [ -f tools/ubench/$u.hip ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null; done
-(echo "== tools/ubench/bfly30u_rate.hip"; tools/ubench/bfly30u_rate; echo "== tools/ubench/bfly31_rate.hip"; tools/ubench/bfly31_rate; echo "== tools/ubench/valu_rate.hip"; tools/ubench/valu_rate; echo "== tools/ubench/bfly_asm_rate.hip"; tools/ubench/bfly_asm_rate) > $O/ubench.txt 2>&1
+for u in bfly30u_rate bfly31_rate valu_rate bfly_asm_rate read_bw; do [ -f tools/ubench/$u.hip ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null; done
+(echo "== tools/ubench/bfly30u_rate.hip"; tools/ubench/bfly30u_rate; echo "== tools/ubench/bfly31_rate.hip"; tools/ubench/bfly31_rate; echo "== tools/ubench/valu_rate.hip"; tools/ubench/valu_rate; echo "== tools/ubench/bfly_asm_rate.hip"; tools/ubench/bfly_asm_rate; echo "== tools/ubench/read_bw.hip"; tools/ubench/read_bw) > $O/ubench.txt 2>&1
 bash tools/power_probe.sh > $O/power_probe.txt 2>&1
 # steady-state table of the single-pass kernel (H32: the default for launches of 512 limbs and more) and of the two-pass kernel it replaced there
 (echo "## ntt32_fwd_kernel (default)"; SRC=ntt32_kernels REPS=1500 bash tools/ntt16_variants.sh "shipped:" "no_butterflies:-DMKHE_H32_X_NOBFLY" "no_exchanges:-DMKHE_H32_X_NOXCHG" "no_stores:-DMKHE_H32_X_NOSTORE" \
     "no_source_loads:-DMKHE_H16_X_NOSRC" "no_twiddle_loads:-DMKHE_H16_X_NOTWLOAD -DMKHE_H32_X_NOTWB" "butterflies_only:-DMKHE_H32_X_NOXCHG -DMKHE_H32_X_NOSTORE -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOTWLOAD -DMKHE_H32_X_NOTWB" \
     "no_butterflies_no_twiddles:-DMKHE_H32_X_NOBFLY -DMKHE_H16_X_NOTWLOAD -DMKHE_H32_X_NOTWB" "one_butterfly_per_asm_block:-DMKHE_H32_BF2=0" "no_phase_priorities:-DMKHE_H32_PHPRIO=0" "one_priority_set:-DMKHE_H32_PHPRIO=1" \
-    "ring_8:-DMKHE_H32_RING=8" "shipped_again:"
+    "ring_8:-DMKHE_H32_RING=8" "prefetch_next_limb:-DMKHE_H32_PREFETCH=1" "shipped_again:"
  echo "## ntt16_fwd_kernel<true> (MKHE_NTT32=0)"; export MKHE_NTT32=0; REPS=1500 bash tools/ntt16_variants.sh "shipped:" "no_mem_no_xchg:-DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE -DMKHE_H16_X_NOXCHG=15" \
     "no_bfly:-DMKHE_H16_X_NOBFLY=3" "shipped_again:"; unset MKHE_NTT32) > $O/ntt16_ablation.txt 2>&1
 (echo "== default (ntt32_fwd_kernel)"; python3 tools/ntt16_bench.py 1500; echo "== MKHE_NTT32=0 (ntt16_fwd_kernel<true>)"; MKHE_NTT32=0 python3 tools/ntt16_bench.py 1500) > $O/ntt16_bench.txt 2>&1
+# the Decompose launches INSIDE the MulRelin (kernel trace of the bench command, second half of the run): the two launch sizes apart, both kernels
+bash tools/trace_ntt_in_context.sh h32 h16:MKHE_NTT32=0 > $O/ntt_in_context.txt 2>&1
+rm -rf $R/gpurun_out/ctx
 echo "ntt done"
 find $O -name '*kernel_trace.csv' -path '*stats_*' -delete
 find $O -name '*agent_info.csv' -delete
