@@ -108,6 +108,7 @@ SIGNATURES = {
     "mkhe_prof_enable": (C.c_int, [vp, C.c_int]),
     "mkhe_ntt_trace": (C.c_int, [vp, vp]),
     "mkhe_set_overlap": (C.c_int, [vp, C.c_int]),
+    "mkhe_ntt_choice": (C.c_int, [vp, C.c_long, C.c_int]),
     "mkhe_prof_nclass": (C.c_int, []),
     "mkhe_prof_name": (C.c_char_p, [C.c_int]),
     "mkhe_prof_collect": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),

@@ -678,6 +678,14 @@ int mkhe_bfv_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, co
 int mkhe_set_overlap(mkhe_ctx* ctx, int on) { MKHE_TRY({ need(ctx)->sync(); need(ctx)->overlap = on != 0; }) }
 int mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf) { need(ctx)->ntt_trace = (u64*)dev_buf; return 0; }
 int mkhe_prof_enable(mkhe_ctx* ctx, int on) { MKHE_TRY(need(ctx)->prof_enable(on != 0)) }
+int mkhe_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose) {
+    Context* c = need(ctx);
+    for (int lazy = 0; lazy < 2; ++lazy) {
+        auto it = c->ntt_tune_.find((limbs << 2) | (decompose ? 2 : 0) | lazy);
+        if (it != c->ntt_tune_.end() && it->second.decided >= 0) return it->second.decided;
+    }
+    return -1;
+}
 int mkhe_prof_nclass(void) { return Context::PROF_NCLASS; }
 const char* mkhe_prof_name(int cls) {
     static const char* names[] = {"ntt_fwd_kernel<N,1,true>  (Decompose, q<2^57)", "ntt_fwd_kernel<N,0,true>  (Decompose, q>=2^57)",

@@ -463,6 +463,8 @@ void Context::release_all() noexcept {
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
     for (auto& f : free_list_) (void)hipFree(f.p);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto& kv : ntt_tune_) if (kv.second.e0) { (void)hipEventDestroy(kv.second.e0); (void)hipEventDestroy(kv.second.e1); }
+    ntt_tune_.clear();
     if (fence_ev_) (void)hipEventDestroy(fence_ev_);
     if (xev_) (void)hipEventDestroy(xev_);
     if (stream2) (void)hipStreamDestroy(stream2);
@@ -672,18 +674,22 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     b.psi31 = d_psi31; b.psi31n = d_psi31n; b.psi31c = d_psi31c; b.psi31b = d_psi31b; b.u_mods = u_mods_; b.no_h16 = d_psi31 ? 0 : 1;
     b.psif = d_psif; b.f_mods = f_mods_;
     for (int i = 0; i < mall && i < NTT_MAX_SLOTS; ++i) b.sched[i] = h16_sched_.empty() ? 15 : h16_sched_[i];
-    if (ntt32_ok(logN, b)) {
+    const bool ok32 = ntt32_ok(logN, b), ok16 = ntt16_ok(logN, b);
+    NttTune* sampling = nullptr;
+    int use32 = ok32 ? 1 : 0;
+    if (ok32 && ok16 && ntt32_mode() == 2) use32 = ntt_pick((((long)b.nslots * b.nouter) << 2) | (decompose ? 2 : 0) | (b.src_lazy ? 1 : 0), sampling);
+    if (sampling) (void)hipEventRecord(sampling->e0, s_);
+    if (use32) {
         ProfScope ps(this, decompose ? PROF_NTT32_DECOMP : PROF_NTT32_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;
         launch_ntt32_fwd(bt, small16_.data(), s_);
-        return;
-    }
-    if (ntt16_ok(logN, b)) {
+    } else if (ok16) {
         ProfScope ps(this, decompose ? PROF_NTT16_DECOMP : PROF_NTT16_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;
         launch_ntt16_fwd(bt, small16_.data(), s_, logN);
-        return;
     }
+    if (sampling) (void)hipEventRecord(sampling->e1, s_);
+    if (use32 || ok16) return;
     if (decompose && ntt_fwd_mixed_ok(logN, b, small_q_.data())) {
         // large Decompose launches: both modulus classes in one persistent grid (no ragged tail of the big-modulus class)
         ProfScope ps(this, PROF_NTT_DECOMP_MIXED, 16.0 * N * b.nouter * b.nslots);
@@ -708,6 +714,46 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
         if (on_side) { side_done(0); s_ = stream; }
     }
     if (side) join_side(0);
+}
+
+int Context::ntt_pick(long key, NttTune*& sampling) {
+    constexpr int SKIP = 2, K = 5;                     // per shape: the first two launches untimed (cold tables), then five samples per kernel
+    sampling = nullptr;
+    NttTune& t = ntt_tune_[key];
+    if (t.decided >= 0) return t.decided;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s_, &cs);
+    if (cs != hipStreamCaptureStatusNone) return 1;    // (no timing inside a graph capture: the recorded sequence keeps the default)
+    if (t.pending >= 0) {
+        float ms = 0.f;
+        const hipError_t e = hipEventElapsedTime(&ms, t.e0, t.e1);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }          // the timed launch is still running: this one goes untimed
+        if (e == hipSuccess && t.n[t.pending] < K) t.t[t.pending][t.n[t.pending]++] = ms;
+        (void)hipGetLastError();
+        t.pending = -1;
+    }
+    if (t.n[0] >= K && t.n[1] >= K) {
+        auto med = [](float* v, int n) { std::sort(v, v + n); return v[n / 2]; };
+        const float m32 = med(t.t[1], K), m16 = med(t.t[0], K);
+        t.decided = m32 <= m16 ? 1 : 0;
+        // a smaller shape follows the choice of the largest one decided so far unless the other kernel is ahead by more than 3 % (one kernel per
+        // operation where the medians are a coin flip: 896 limbs inside a MulRelin are 113.4 against 112.9 us)
+        long lead = -1;
+        for (const auto& kv : ntt_tune_) if (kv.second.decided >= 0 && &kv.second != &t && (kv.first >> 2) > (key >> 2) && (kv.first >> 2) > (lead >> 2)) lead = kv.first;
+        if (lead >= 0) {
+            const int l = ntt_tune_[lead].decided;
+            const float ml = l ? m32 : m16, mo = l ? m16 : m32;
+            if (mo > 0.97f * ml) t.decided = l;
+        }
+        if (t.e0) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); t.e0 = t.e1 = nullptr; }
+        return t.decided;
+    }
+    if (t.seen++ < SKIP) return 1;
+    if (!t.e0) { MKHE_HIP(hipEventCreate(&t.e0)); MKHE_HIP(hipEventCreate(&t.e1)); }
+    const int k = t.n[1] <= t.n[0] ? 1 : 0;            // alternate, H32 first
+    t.pending = k;
+    sampling = &t;
+    return k;
 }
 
 void Context::ntt_inv_launch(NttBatch& b) {

@@ -65,7 +65,12 @@ constexpr int RING = MKHE_H32_RING;        // twiddle pairs (4 VGPRs each) live 
 #define MKHE_NTT32_EVEN_DEFAULT 0
 #endif
 #ifndef MKHE_NTT32_DEFAULT
-#define MKHE_NTT32_DEFAULT 1               // MKHE_NTT32=0: every launch on the H16 kernel (A/B)
+// MKHE_NTT32: 0 (default) = every launch on the two-pass H16 kernel, 1 = this kernel wherever it applies, 2 = measured per launch shape at the start of the
+// workload (Context::ntt_pick).  Why 0: back to back this kernel is ahead everywhere (229 against 242 us for 1792 limbs), inside the MulRelin it is ahead
+// by 2 % on parts that sustain 1400 W (0.53-0.54 against 0.52 of the roofline) and BEHIND by 6 % on parts that cap at 1255 W (0.46-0.47 against
+// 0.49-0.515: its one workgroup per CU is throttled where the two independent workgroups of H16 keep their clock), and MulRelin/s is equal (1230 /
+// 1232) or lower (1161 / 1180) -- profiles/README.md.  2 settles in the first milliseconds, on ramping clocks, and picked wrongly on a capped part.
+#define MKHE_NTT32_DEFAULT 0
 #endif
 template <int... I, class F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
@@ -571,6 +576,7 @@ int env_int32(const char* name, int dflt) { const char* e = getenv(name); return
 struct LaunchState32 { std::mutex mu; int resident[64] = {}; };
 unsigned magic_of32(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
 }
+int ntt32_mode() { static const int on = env_int32("MKHE_NTT32", MKHE_NTT32_DEFAULT); return on; }
 bool ntt32_ok(int logN, const NttBatch& b) {
     static const int on = env_int32("MKHE_NTT32", MKHE_NTT32_DEFAULT), minl = env_int32("MKHE_NTT32_MIN", 512);
     if (!on || logN != 15 || b.no_h16 || !b.psi31 || !b.psi31c || !b.psi31b || b.split || b.prestaged || b.nslots > 64) return false;

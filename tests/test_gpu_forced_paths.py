@@ -227,3 +227,65 @@ def test_bfv_with_60_bit_moduli(env_extra):
     H16 / H32 kernels must reduce at the load (NttBatch::src_lazy, set by Context::ntt_r since round 4)"""
     r = _run(SCRIPT_BFV, dict(MKHE_NTT16_MIN="1", MKHE_NTT16_INV_MIN="1", **env_extra))
     assert r.returncode == 0 and "bfv big-modulus paths ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+# ---------------------------------------------------------------- round 4: the single-pass forward kernel (not the default) on every N = 2^15 launch shape
+SCRIPT_H32 = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import harness as H
+from oracle import oracle as O
+from mkhe_kklss_amd import mkckks, mkrlwe
+from mkhe_kklss_amd._abi import lib
+p = H.PN15QP880
+ks = O.KeySwitcher(p["logN"], p["Q"], p["P"], 2)
+params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"], device=0)
+rng = np.random.default_rng(321)
+N, mods = 1 << p["logN"], p["Q"] + p["P"]
+# (a) plain forward transforms, one polynomial and three, out of place and in place, edge values in front
+for cnt in (1, 3):
+    a = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in mods]) for _ in range(cnt)])
+    a[0, :, :4] = np.array([[0, 1, q - 1, q // 2] for q in mods], dtype=np.uint64)
+    src = mkrlwe.DeviceLimbs(params, cnt, len(mods)).upload(a)
+    dst = mkrlwe.DeviceLimbs(params, cnt, len(mods))
+    mkrlwe.ntt(params, src, dst)
+    f = dst.download()
+    for c in range(cnt):
+        for j in range(len(mods)):
+            r, i = (ks.ringQ, j) if j < len(p["Q"]) else (ks.ringP, j - len(p["Q"]))
+            assert (f[c][j] == r.ntt(i, a[c][j])).all(), (cnt, c, j)
+    mkrlwe.ntt(params, src, src)
+    assert (src.download() == f).all()
+# (b) hoisted forms (the Decompose-fused launches): top level, a middle level, level 0
+ev = mkckks.NewEvaluator(params)
+for level in (len(p["Q"]) - 1, 5, 0):
+    names = ["p0", "p1"]
+    h = np.empty((3, level + 1, N), dtype=np.uint64)
+    for l in range(level + 1):
+        h[:, l] = rng.integers(0, p["Q"][l], (3, N), dtype=np.uint64)
+    ct = mkckks.NewCiphertext(params, names, level, p["scale"]).upload(h)
+    beta = ks.beta(level)
+    act = list(range(level + 1)) + [len(p["Q"]) + j for j in range(len(p["P"]))]
+    refs = [ks.decompose(level, h[1 + i]) for i in range(len(names))]
+    for rep in range(%(reps)d):                       # (MKHE_NTT32=2 samples both kernels over the first launches of a shape: every one of them checked)
+        hoisted = ev.HoistedForm(ct)
+        for i, n in enumerate(names):
+            got = hoisted.Value[n].download()
+            assert (got[:beta][:, act] == refs[i][:beta][:, act]).all(), (level, rep, i)
+top = len(p["Q"]) - 1
+per = ks.beta(top) * len(mods)
+print("choice", lib().mkhe_ntt_choice(params.ctx, 2 * per, 1))
+print("h32 paths ok")
+'''
+
+
+@pytest.mark.parametrize("mode,reps", [("1", 1), ("2", 14)], ids=["forced", "measured"])
+def test_single_pass_forward_kernel_on_every_launch_shape(mode, reps):
+    """ntt32_fwd_kernel (MKHE_NTT32=1; the default is the two-pass kernel since the end of round 4) with its size threshold at 1: plain transforms of one
+    and three polynomials and Decompose launches at three levels against the oracle; MKHE_NTT32=2: the engine alternates between the two kernels
+    over the first launches of a shape and settles -- every launch of the sampling phase and after it gives the oracle's digits"""
+    r = _run(SCRIPT_H32 % dict(tests="%(tests)s", root="%(root)s", reps=reps), dict(MKHE_NTT32=mode, MKHE_NTT32_MIN="1", MKHE_NTT16_MIN="1"))
+    assert r.returncode == 0 and "h32 paths ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    choice = int(r.stdout.split("choice")[1].split()[0])
+    assert choice == (-1 if mode == "1" else choice) and (mode == "1" or choice in (0, 1)), r.stdout[-300:]

@@ -12,7 +12,7 @@ for d, name in (("stats_noovl", "kernel_stats_noovl"), ("stats_ovl", "kernel_sta
     f = os.path.join(G, d, "p_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.csv" % (tag, name)))
-for f in ("bench_plain", "bench_noovl", "bench_ovl", "bench_bfv", "bench_bfv_plain", "bench_pn16", "bench_pn16_noovl", "bench_cnn2", "bench_cnn4", "bench_pn14",
+for f in ("bench_plain", "bench_plain_h32", "bench_noovl", "bench_ovl", "bench_bfv", "bench_bfv_plain", "bench_pn16", "bench_pn16_noovl", "bench_cnn2", "bench_cnn4", "bench_pn14",
           "bench_cnn4_batch8", "bench_cnn4_batch16", "bench_cnn2_batch8"):
     src = os.path.join(G, f + ".json")
     if os.path.exists(src) and os.path.getsize(src) > 10:
@@ -34,7 +34,8 @@ for f, t in (("party_sweep.jsonl", "party_sweep.jsonl"), ("ubench.txt", "ubench.
             txt = "\n".join(out_l) + "\n"
         open(os.path.join(P, "%s_%s" % (tag, t)), "w").write(txt)
 out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "traffic_from_pmc.py"),
-                               os.path.join(G, "pmc_fetch"), os.path.join(G, "pmc_write"), workload, "6", "2"])
+                               os.path.join(G, "pmc_fetch"), os.path.join(G, "pmc_write"), workload, "6", "2"] +
+                              ([os.path.join(G, "pmc_fetch_h32"), os.path.join(G, "pmc_write_h32")] if os.path.isdir(os.path.join(G, "pmc_fetch_h32")) else []))
 open(os.path.join(P, "traffic.json"), "wb").write(out)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)

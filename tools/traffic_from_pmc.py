@@ -36,11 +36,18 @@ def per_kernel(d, counter):
 
 
 def main():
-    """argv: <fetch_dir> <write_dir> "<workload>" [steps warmup]  -- steps / warmup of the profiled bench.py command are recorded so
-    that bench.py can refuse the figures when the launch pattern it measures is not the profiled one"""
+    """argv: <fetch_dir> <write_dir> "<workload>" [steps warmup [fetch_dir2 write_dir2]]  -- steps / warmup of the profiled bench.py command are
+    recorded so that bench.py can refuse the figures when the launch pattern it measures is not the profiled one.  The second pair of
+    directories (the same command with the single-pass forward NTT kernel, MKHE_NTT32=1) only contributes kernels the first pair does not have."""
     fetch, write, workload = sys.argv[1], sys.argv[2], sys.argv[3]
     steps, warmup = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (None, None)
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    if len(sys.argv) > 7:
+        f2, w2 = per_kernel(sys.argv[6], "FETCH_SIZE"), per_kernel(sys.argv[7], "WRITE_SIZE")
+        for k in set(f2) | set(w2):
+            if k not in f and k not in w:
+                if k in f2: f[k] = f2[k]
+                if k in w2: w[k] = w2[k]
     kernels = {}
     for k in sorted(set(f) | set(w)):
         fm = sum(f[k]) / len(f[k]) if f.get(k) else 0.0
