@@ -567,13 +567,15 @@ def run_single(args):
 
     beta = params.Beta(level)
     if pset["logN"] == 15 and params.Alpha() == 1:
-        # N = 2^15: two forward kernels apply to the Decompose launches (same bits).  MKHE_NTT32 = 0 (default): the two-pass kernel, 1: the single-pass
-        # kernel, 2: the engine measures both at the start of the workload and settles per launch shape -- recorded here
+        # N = 2^15: two forward kernels apply to the Decompose launches (same bits).  MKHE_NTT32 = 2 (default): per launch shape the engine times a
+        # block of launches of each kernel inside this workload (after its first 64 launches) and keeps the faster one; 0 / 1 force one
         from mkhe_kklss_amd._abi import lib as _lib
         per_comp = beta * (level + 1 + len(pset["P"]))
-        mode = os.environ.get("MKHE_NTT32", "0")
-        extras["ntt_kernel_choice"] = dict(MKHE_NTT32=mode, **{str(n * per_comp): {1: "ntt32_fwd_kernel (single pass)", 0: "ntt16_fwd_kernel (two passes)", -1: "fixed by MKHE_NTT32" if mode != "2" else "undecided"}[
-            _lib().mkhe_ntt_choice(params.ctx, n * per_comp, 1)] for n in (2 * k, k)})
+        mode = os.environ.get("MKHE_NTT32", "2")
+        extras["ntt_kernel_choice"] = dict(MKHE_NTT32=mode)
+        if mode == "2":
+            extras["ntt_kernel_choice"].update({str(n * per_comp): {1: "ntt32_fwd_kernel (single pass)", 0: "ntt16_fwd_kernel (two passes)", -1: "undecided"}[
+                _lib().mkhe_ntt_choice(params.ctx, n * per_comp, 1)] for n in (2 * k, k)})
     roofline = roofline_leg(args, params, step, pset["logN"], "%s k=%d" % (args.params, k),
                             extra=dict(decompose=dict(limbs_per_component=beta * (level + 1 + len(pset["P"])), source_limbs_per_component=level + 1))
                             if params.Alpha() == 1 else None)

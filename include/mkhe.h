@@ -353,9 +353,9 @@ int  mkhe_set_overlap(mkhe_ctx* ctx, int on);
 /* diagnostic: forward-NTT workgroups write {start, end (100 MHz ticks), HW_ID, XCC_ID} per job into dev_buf
  * (4 words per job of the NEXT launches; NULL switches it off) */
 int  mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf);
-/* diagnostic for MKHE_NTT32=2 (N = 2^15, where two forward kernels apply and the engine then measures both inside the caller's workload): the kernel
- * the context has settled on for Decompose launches of `limbs` limb-NTTs: 1 = single-pass (ntt32_fwd_kernel), 0 = two-pass (ntt16_fwd_kernel),
- * -1 = still sampling, never launched, or the choice is fixed by MKHE_NTT32 = 0 (default) / 1.  Results are the same bits either way. */
+/* N = 2^15, where two forward kernels apply (same bits): by default (MKHE_NTT32=2) the context times a block of launches of each inside the caller's
+ * workload and keeps the faster one per launch shape.  The kernel it has settled on for Decompose launches of `limbs` limb-NTTs: 1 = single-pass
+ * (ntt32_fwd_kernel), 0 = two-pass (ntt16_fwd_kernel), -1 = still measuring, never launched, or fixed by MKHE_NTT32 = 0 / 1. */
 int  mkhe_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose);
 int  mkhe_prof_nclass(void);
 const char* mkhe_prof_name(int cls);

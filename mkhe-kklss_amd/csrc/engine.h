@@ -330,13 +330,14 @@ class Context {
   private:
 
     struct ProfRec { hipEvent_t e0, e1; int cls; double bytes; };
-    // MKHE_NTT32=2 (experiment): which forward kernel a launch shape takes when both apply (H32 and H16 give the same bits), measured in the caller's
-    // own workload.  The single-pass kernel wins by 2 % inside a MulRelin on parts that sustain 1400 W and loses 6 % on a part capped at 1255 W (same
-    // library: profiles/README.md) -- back to back it is ahead on both, so a calibration outside the workload would pick wrongly.  Per shape: the
-    // first launches alternate between the kernels under a HIP-event pair, the medians decide, the choice stays.  Not the default: the first
-    // milliseconds of a workload run on ramping clocks, and on a capped part they favoured the kernel that is slower once the cap holds.
-  public:
-    struct NttTune { int n[2] = {0, 0}; float t[2][8]; int decided = -1, pending = -1, seen = 0; hipEvent_t e0 = nullptr, e1 = nullptr; };
+    // MKHE_NTT32=2 (default): which forward kernel a launch shape takes when both apply (H32 and H16 give the same bits), measured in the caller's own
+    // workload.  The single-pass kernel wins by 2-5 % inside a MulRelin on most parts and loses 6 % on some (same library, same call:
+    // profiles/README.md) -- back to back it is ahead on all of them, so a calibration outside the workload would pick wrongly, and so did a first
+    // version that alternated the kernels over the first dozen launches (the first milliseconds run on ramping clocks with power to spare).  Per
+    // shape: WARM launches on H32 untimed, then BLOCK launches of H32 and BLOCK of H16 (the first SETTLE of a block untimed) under HIP-event pairs;
+    // the medians of the timed launches decide, the choice stays.  A smaller shape follows the largest one unless the other kernel is 3 % ahead.
+    struct NttTune { static constexpr int WARM = 64, SETTLE = 16, BLOCK = 48; int n[2] = {0, 0}, blk[2] = {0, 0}; float t[2][BLOCK]; int decided = -1, pending = -1, seen = 0;
+                     hipEvent_t e0 = nullptr, e1 = nullptr; };
     std::map<long, NttTune> ntt_tune_;
     int ntt_pick(long key, NttTune*& sampling);      // 1 = H32, 0 = H16; sampling != nullptr: this launch is timed (record e0 before, e1 after)
   private:

@@ -717,24 +717,24 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
 }
 
 int Context::ntt_pick(long key, NttTune*& sampling) {
-    constexpr int SKIP = 2, K = 5;                     // per shape: the first two launches untimed (cold tables), then five samples per kernel
+    constexpr int WARM = NttTune::WARM, SETTLE = NttTune::SETTLE, BLOCK = NttTune::BLOCK, TIMED = BLOCK - SETTLE;
     sampling = nullptr;
     NttTune& t = ntt_tune_[key];
     if (t.decided >= 0) return t.decided;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s_, &cs);
-    if (cs != hipStreamCaptureStatusNone) return 1;    // (no timing inside a graph capture: the recorded sequence keeps the default)
+    if (cs != hipStreamCaptureStatusNone) return 1;    // (no timing inside a graph capture: the recorded sequence keeps H32)
     if (t.pending >= 0) {
         float ms = 0.f;
         const hipError_t e = hipEventElapsedTime(&ms, t.e0, t.e1);
-        if (e == hipErrorNotReady) { (void)hipGetLastError(); return 1; }          // the timed launch is still running: this one goes untimed
-        if (e == hipSuccess && t.n[t.pending] < K) t.t[t.pending][t.n[t.pending]++] = ms;
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); return t.pending; }      // the timed launch is still running: this one goes untimed, same kernel
+        if (e == hipSuccess && t.n[t.pending] < TIMED) t.t[t.pending][t.n[t.pending]++] = ms;
         (void)hipGetLastError();
         t.pending = -1;
     }
-    if (t.n[0] >= K && t.n[1] >= K) {
+    if (t.n[0] >= TIMED && t.n[1] >= TIMED) {
         auto med = [](float* v, int n) { std::sort(v, v + n); return v[n / 2]; };
-        const float m32 = med(t.t[1], K), m16 = med(t.t[0], K);
+        const float m32 = med(t.t[1], TIMED), m16 = med(t.t[0], TIMED);
         t.decided = m32 <= m16 ? 1 : 0;
         // a smaller shape follows the choice of the largest one decided so far unless the other kernel is ahead by more than 3 % (one kernel per
         // operation where the medians are a coin flip: 896 limbs inside a MulRelin are 113.4 against 112.9 us)
@@ -748,9 +748,11 @@ int Context::ntt_pick(long key, NttTune*& sampling) {
         if (t.e0) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); t.e0 = t.e1 = nullptr; }
         return t.decided;
     }
-    if (t.seen++ < SKIP) return 1;
+    // launch number `seen` of this shape: [0, WARM) H32 untimed; then a block of H32 and a block of H16, the first SETTLE launches of a block untimed
+    if (t.seen < WARM) { ++t.seen; return 1; }
+    const int k = t.n[1] < TIMED ? 1 : 0;              // H32's block first, then H16's
+    if (t.blk[k]++ < SETTLE) return k;
     if (!t.e0) { MKHE_HIP(hipEventCreate(&t.e0)); MKHE_HIP(hipEventCreate(&t.e1)); }
-    const int k = t.n[1] <= t.n[0] ? 1 : 0;            // alternate, H32 first
     t.pending = k;
     sampling = &t;
     return k;

@@ -869,6 +869,9 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         // (the byte through a scalar dword load: a byte load of a kernel argument is a VECTOR memory instruction, and the s_waitcnt vmcnt(0) the
         // compiler puts behind it waits for every store of the previous job before this one has requested a word -- round 3 shipped that)
         jb.sched = (kb->src_lazy || (SPLIT && LOGN == 15)) ? 15 : (int)((((const __attribute__((address_space(4))) unsigned*)kb->sched)[m >> 2] >> (8 * (m & 3))) & 0xffu);
+#ifdef MKHE_H16_X_SCHEDBYTE     // MKHE_ABLATION: round 3's form of the line above (same value; the vector byte load and its vmcnt(0)), for the A/B in one call
+        jb.sched = (kb->src_lazy || (SPLIT && LOGN == 15)) ? 15 : kb->sched[m];
+#endif
         jb.root = 1;
         if constexpr (SPLIT && LOGN == 15) { const int half = job2 & 1; jb.src += half * NN; jb.dst += half * NN; jb.root = 2 + half; }
         if constexpr (SPLIT && LOGN == 14) { const int quarter = job2 & 3; jb.src += quarter * NL; jb.dst += quarter * NL; jb.root = 4 + quarter; }

@@ -65,12 +65,13 @@ constexpr int RING = MKHE_H32_RING;        // twiddle pairs (4 VGPRs each) live 
 #define MKHE_NTT32_EVEN_DEFAULT 0
 #endif
 #ifndef MKHE_NTT32_DEFAULT
-// MKHE_NTT32: 0 (default) = every launch on the two-pass H16 kernel, 1 = this kernel wherever it applies, 2 = measured per launch shape at the start of the
-// workload (Context::ntt_pick).  Why 0: back to back this kernel is ahead everywhere (229 against 242 us for 1792 limbs), inside the MulRelin it is ahead
-// by 2 % on parts that sustain 1400 W (0.53-0.54 against 0.52 of the roofline) and BEHIND by 6 % on parts that cap at 1255 W (0.46-0.47 against
-// 0.49-0.515: its one workgroup per CU is throttled where the two independent workgroups of H16 keep their clock), and MulRelin/s is equal (1230 /
-// 1232) or lower (1161 / 1180) -- profiles/README.md.  2 settles in the first milliseconds, on ramping clocks, and picked wrongly on a capped part.
-#define MKHE_NTT32_DEFAULT 0
+// MKHE_NTT32: 0 = every launch on the two-pass H16 kernel, 1 = this kernel wherever it applies, 2 (default) = per launch shape the engine times a block
+// of launches of each kernel inside the caller's workload, once its clocks have settled, and keeps the faster one (Context::ntt_pick).  Back to back
+// this kernel is ahead on every part (230 against 244 us for 1792 limbs, same call); inside the MulRelin it is ahead by 2-5 % on most parts (0.526-0.542
+// against 0.506-0.519 of the roofline, eight same-call pairs, MulRelin/s + 0-2 %) and BEHIND by 6 % on some (0.46-0.48 against 0.49-0.515, MulRelin/s
+// - 1.6 %: parts that sit at 1255 W and 2.09 GHz under it where the others reach 1400 W and 2.2-2.3 GHz, with the same configured cap -- the two-pass
+// kernel's in-context time is the same on both kinds): profiles/README.md.
+#define MKHE_NTT32_DEFAULT 2
 #endif
 template <int... I, class F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
@@ -522,6 +523,9 @@ __global__ void __launch_bounds__(NT, 4) __attribute__((amdgpu_num_vgpr(128))) n
         // (the byte through a scalar dword load: a byte load is a VECTOR memory instruction, and the s_waitcnt vmcnt(0) the compiler puts behind it
         // would wait for every store and prefetched word of the previous limb right here)
         jb.sched = kb->src_lazy ? 15 : (int)((((const __attribute__((address_space(4))) unsigned*)kb->sched)[m >> 2] >> (8 * (m & 3))) & 0xffu);
+#ifdef MKHE_H16_X_SCHEDBYTE     // MKHE_ABLATION: round 3's form of the line above (same value; the vector byte load and its vmcnt(0)), for the A/B in one call
+        jb.sched = kb->src_lazy ? 15 : kb->sched[m];
+#endif
         jb.mp = (smodptr)kb->mods + m;
         jb.skip_norm = kb->skip_norm != 0;
         jb.red = false;

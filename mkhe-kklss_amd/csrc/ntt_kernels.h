@@ -36,7 +36,7 @@
 // -DMKHE_ABLATION; a product build that picks one of them up by accident does not compile.
 #if !defined(MKHE_ABLATION) && (defined(MKHE_H16_X_NOBFLY) || defined(MKHE_H16_X_NOXCHG) || defined(MKHE_H16_X_NOSTORE) || defined(MKHE_H16_X_NOPARK) || \
                                 defined(MKHE_H16_X_NOSRC) || defined(MKHE_H16_X_NOTWLOAD) || defined(MKHE_H32_X_NOBFLY) || defined(MKHE_H32_X_NOXCHG) || \
-                                defined(MKHE_H32_X_NOSTORE) || defined(MKHE_H32_X_NOTWB) || defined(MKHE_X_NOXCHG) || defined(MKHE_X_NO_NTSTORE))
+                                defined(MKHE_H32_X_NOSTORE) || defined(MKHE_H32_X_NOTWB) || defined(MKHE_X_NOXCHG) || defined(MKHE_X_NO_NTSTORE) || defined(MKHE_H16_X_SCHEDBYTE))
 #error "MKHE_*_X_* switches give wrong results on purpose (timing experiments): build them with -DMKHE_ABLATION"
 #endif
 
@@ -139,7 +139,7 @@ bool ntt16_ok(int logN, const NttBatch& b);
 void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st, int logN = 15);
 // N = 2^15 launches of several limbs per CU, one pass per limb (ntt32_kernels.hip: one 1024-thread workgroup per CU, 32 coefficients per thread)
 bool ntt32_ok(int logN, const NttBatch& b);
-int ntt32_mode();      // MKHE_NTT32: 0 (default) off, 1 on, 2 = Context::ntt_pick measures both kernels per launch shape at the start of the workload
+int ntt32_mode();      // MKHE_NTT32: 0 off, 1 on, 2 (default) = Context::ntt_pick times both kernels per launch shape inside the workload and keeps the faster
 void launch_ntt32_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st);
 // the same kernel on the 2^15-point sub-transforms of a split N = 2^16 launch (one modulus class per launch)
 bool ntt16_split_ok(const NttBatch& c);

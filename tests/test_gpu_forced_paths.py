@@ -221,7 +221,7 @@ def test_n16_with_a_60_bit_modulus(env_extra):
     assert r.returncode == 0 and "n16 big-modulus paths ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("env_extra", [dict(), dict(MKHE_NTT32="1", MKHE_NTT32_MIN="1")], ids=["h16", "h32"])
+@pytest.mark.parametrize("env_extra", [dict(MKHE_NTT32="0"), dict(MKHE_NTT32="1", MKHE_NTT32_MIN="1")], ids=["h16", "h32"])
 def test_bfv_with_60_bit_moduli(env_extra):
     """mkbfv over 60-bit Q / QMul primes at N = 2^15: the ring-R forward transforms take lazy ModUpQtoR / Rescale outputs (< 3q = 2^61.6), which the
     H16 / H32 kernels must reduce at the load (NttBatch::src_lazy, set by Context::ntt_r since round 4)"""
@@ -268,8 +268,10 @@ for level in (len(p["Q"]) - 1, 5, 0):
     beta = ks.beta(level)
     act = list(range(level + 1)) + [len(p["Q"]) + j for j in range(len(p["P"]))]
     refs = [ks.decompose(level, h[1 + i]) for i in range(len(names))]
-    for rep in range(%(reps)d):                       # (MKHE_NTT32=2 samples both kernels over the first launches of a shape: every one of them checked)
+    for rep in range(%(reps)d):                       # (MKHE_NTT32=2: 64 launches on H32, a block of 48 on H32, a block of 48 on H16, then the choice -- a sample of every phase is checked)
         hoisted = ev.HoistedForm(ct)
+        if rep not in (0, 1, 63, 64, 80, 111, 112, 128, 159, 160, 169):
+            continue
         for i, n in enumerate(names):
             got = hoisted.Value[n].download()
             assert (got[:beta][:, act] == refs[i][:beta][:, act]).all(), (level, rep, i)
@@ -280,12 +282,12 @@ print("h32 paths ok")
 '''
 
 
-@pytest.mark.parametrize("mode,reps", [("1", 1), ("2", 14)], ids=["forced", "measured"])
+@pytest.mark.parametrize("mode,reps", [("1", 1), ("2", 170), ("0", 1)], ids=["forced", "measured", "two_pass"])
 def test_single_pass_forward_kernel_on_every_launch_shape(mode, reps):
-    """ntt32_fwd_kernel (MKHE_NTT32=1; the default is the two-pass kernel since the end of round 4) with its size threshold at 1: plain transforms of one
-    and three polynomials and Decompose launches at three levels against the oracle; MKHE_NTT32=2: the engine alternates between the two kernels
-    over the first launches of a shape and settles -- every launch of the sampling phase and after it gives the oracle's digits"""
+    """ntt32_fwd_kernel (MKHE_NTT32=1) with its size threshold at 1: plain transforms of one
+    and three polynomials and Decompose launches at three levels against the oracle; MKHE_NTT32=2 (the default): per shape the
+    engine times a block of launches of each kernel and settles -- a sample of the launches of every phase gives the oracle's digits"""
     r = _run(SCRIPT_H32 % dict(tests="%(tests)s", root="%(root)s", reps=reps), dict(MKHE_NTT32=mode, MKHE_NTT32_MIN="1", MKHE_NTT16_MIN="1"))
     assert r.returncode == 0 and "h32 paths ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     choice = int(r.stdout.split("choice")[1].split()[0])
-    assert choice == (-1 if mode == "1" else choice) and (mode == "1" or choice in (0, 1)), r.stdout[-300:]
+    assert (choice in (0, 1)) if mode == "2" else choice == -1, r.stdout[-300:]

@@ -14,12 +14,13 @@ cd $R
 P="rocprofv3 --output-format csv --kernel-trace"
 python3 bench.py > $O/bench_plain.json 2> $O/bench_plain.err
 MKHE_NTT32=1 python3 bench.py --no-cpu > $O/bench_plain_h32.json 2> $O/bench_plain_h32.err
+MKHE_NTT32=0 python3 bench.py --no-cpu > $O/bench_plain_h16.json 2> $O/bench_plain_h16.err
 echo "plain done" 
 MKHE_NO_OVERLAP=1 $P --stats -d $O/stats_noovl -o p -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-extras > $O/bench_noovl.json 2> $O/bench_noovl.err
 $P --stats -d $O/stats_ovl -o p -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-extras > $O/bench_ovl.json 2> $O/bench_ovl.err
 echo "stats done"
 export MKHE_NO_OVERLAP=1
-# (the counter passes run twice: the default two-pass forward NTT kernel, then the single-pass kernel, MKHE_NTT32=1 -- figures for either at hand)
+# (the counter passes run twice, the forward NTT kernel forced: the two-pass kernel (MKHE_NTT32=0), then the single-pass kernel (=1) -- figures for either at hand)
 export MKHE_NTT32=0
 $P --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-extras > $O/bench_pmc_fetch.json 2> $O/bench_pmc_fetch.err
 $P --pmc WRITE_SIZE -d $O/pmc_write -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-extras > $O/bench_pmc_write.json 2> $O/bench_pmc_write.err
@@ -56,12 +57,12 @@ bash tools/power_probe.sh > $O/power_probe.txt 2>&1
 (echo "## ntt32_fwd_kernel (MKHE_NTT32=1)"; export MKHE_NTT32=1; SRC=ntt32_kernels REPS=1500 bash tools/ntt16_variants.sh "shipped:" "no_butterflies:-DMKHE_H32_X_NOBFLY" "no_exchanges:-DMKHE_H32_X_NOXCHG" "no_stores:-DMKHE_H32_X_NOSTORE" \
     "no_source_loads:-DMKHE_H16_X_NOSRC" "no_twiddle_loads:-DMKHE_H16_X_NOTWLOAD -DMKHE_H32_X_NOTWB" "butterflies_only:-DMKHE_H32_X_NOXCHG -DMKHE_H32_X_NOSTORE -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOTWLOAD -DMKHE_H32_X_NOTWB" \
     "no_butterflies_no_twiddles:-DMKHE_H32_X_NOBFLY -DMKHE_H16_X_NOTWLOAD -DMKHE_H32_X_NOTWB" "one_butterfly_per_asm_block:-DMKHE_H32_BF2=0" "no_phase_priorities:-DMKHE_H32_PHPRIO=0" "one_priority_set:-DMKHE_H32_PHPRIO=1" \
-    "ring_8:-DMKHE_H32_RING=8" "prefetch_next_limb:-DMKHE_H32_PREFETCH=1" "shipped_again:"
- unset MKHE_NTT32; echo "## ntt16_fwd_kernel<true> (default)"; REPS=1500 bash tools/ntt16_variants.sh "shipped:" "no_mem_no_xchg:-DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE -DMKHE_H16_X_NOXCHG=15" \
-    "no_bfly:-DMKHE_H16_X_NOBFLY=3" "shipped_again:") > $O/ntt16_ablation.txt 2>&1
-(echo "== default (ntt16_fwd_kernel<true>)"; python3 tools/ntt16_bench.py 1500; echo "== MKHE_NTT32=1 (ntt32_fwd_kernel)"; MKHE_NTT32=1 python3 tools/ntt16_bench.py 1500) > $O/ntt16_bench.txt 2>&1
+    "ring_8:-DMKHE_H32_RING=8" "prefetch_next_limb:-DMKHE_H32_PREFETCH=1" "round3_schedule_byte_load:-DMKHE_H16_X_SCHEDBYTE" "shipped_again:"
+ export MKHE_NTT32=0; echo "## ntt16_fwd_kernel<true> (MKHE_NTT32=0)"; REPS=1500 bash tools/ntt16_variants.sh "shipped:" "no_mem_no_xchg:-DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE -DMKHE_H16_X_NOXCHG=15" \
+    "no_bfly:-DMKHE_H16_X_NOBFLY=3" "round3_schedule_byte_load:-DMKHE_H16_X_SCHEDBYTE" "shipped_again:"; unset MKHE_NTT32) > $O/ntt16_ablation.txt 2>&1
+(echo "== MKHE_NTT32=0 (ntt16_fwd_kernel<true>)"; MKHE_NTT32=0 python3 tools/ntt16_bench.py 1500; echo "== MKHE_NTT32=1 (ntt32_fwd_kernel)"; MKHE_NTT32=1 python3 tools/ntt16_bench.py 1500) > $O/ntt16_bench.txt 2>&1
 # the Decompose launches INSIDE the MulRelin (kernel trace of the bench command, second half of the run): the two launch sizes apart, both kernels
-bash tools/trace_ntt_in_context.sh h16 h32:MKHE_NTT32=1 h16_again h32_again:MKHE_NTT32=1 > $O/ntt_in_context.txt 2>&1
+bash tools/trace_ntt_in_context.sh h16:MKHE_NTT32=0 h32:MKHE_NTT32=1 h16_again:MKHE_NTT32=0 h32_again:MKHE_NTT32=1 > $O/ntt_in_context.txt 2>&1
 rm -rf $R/gpurun_out/ctx
 echo "ntt done"
 find $O -name '*kernel_trace.csv' -path '*stats_*' -delete

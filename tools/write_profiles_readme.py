@@ -60,7 +60,8 @@ def abl(name, limbs=1792, kernel="ntt32"):
 
 
 R, Rn = pl["roofline"], no["roofline"]
-DOM = "ntt32_fwd_kernel<true>"
+DOM = "ntt16_fwd_kernel<true>"
+ALT = "ntt32_fwd_kernel<true>"
 avg, calls, mn, mx = st(DOM)
 expect = 2 * steps_of(no)
 dom = pmc_rec(DOM) or {}
@@ -72,6 +73,9 @@ pw = sorted(float(re.search(r"Power \(W\): ([0-9.]+)", l).group(1)) for l in pow
 ck = sorted(float(re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", l).group(1)) for l in power)
 ub = open(P + tag + "_ubench.txt").read()
 cb8, cb16, c2b8 = J("bench_cnn4_batch8"), J("bench_cnn4_batch16"), J("bench_cnn2_batch8")
+plh = J("bench_plain_h32")
+alt = pmc_rec(ALT) or {}
+ctx_txt = open(P + tag + "_ntt_in_context.txt").read() if os.path.exists(P + tag + "_ntt_in_context.txt") else ""
 pn14b = [json.loads(l) for l in open(P + tag + "_pn14_batch.jsonl") if l.strip().startswith("{")] if os.path.exists(P + tag + "_pn14_batch.jsonl") else []
 sizes = open(P + tag + "_ntt16_launch_sizes.txt").read()
 def size_us(kernel_part, limbs):
@@ -82,6 +86,24 @@ def size_us(kernel_part, limbs):
 bf2 = re.search(r"two-butterfly asm block.*", ub)
 m31 = re.search(r"mm31 .*?8 waves/SIMD\s+[0-9.]+ ms\s+clock ([0-9.]+) GHz\s+([0-9.]+) ns .*?\(\s*([0-9.]+) cyc\)", ub)
 m30 = re.search(r"mm30u .*?8 waves/SIMD\s+[0-9.]+ ms\s+clock ([0-9.]+) GHz\s+([0-9.]+) ns .*?\(\s*([0-9.]+) cyc\)", ub)
+def ctx_line(name):
+    m = re.search(r"^%s launches \d+ 1792 limbs: median ([0-9.]+) us \(min ([0-9.]+)\)\s+896 limbs: median ([0-9.]+) us \(min ([0-9.]+)\)\s+mean of both ([0-9.]+)" % name, ctx_txt, re.M)
+    return tuple(float(x) for x in m.groups()) if m else (float("nan"),) * 5
+
+
+c16, c32, c16b, c32b = ctx_line("h16"), ctx_line("h32"), ctx_line("h16_again"), ctx_line("h32_again")
+Rh = plh["roofline"] if plh else {}
+def _cyc(label, waves):
+    m = re.search(label + r"\s+waves/SIMD\s+" + waves + r".*?([0-9.]+) cycles", ub)
+    return m.group(1) if m else "?"
+cyc_c1, cyc_h1, cyc_c4, cyc_h4 = _cyc(r"compiler's form \(nops\)", r"1\.0"), _cyc("subtract before add", r"1\.0"), _cyc(r"compiler's form \(nops\)", r"4\.0"), _cyc("subtract before add", r"4\.0")
+rd = re.findall(r"^(.*?)\s+(?:streams|rows)\s+(\d+)\s+[0-9.]+ MB per launch\s+[0-9.]+ us\s+([0-9.]+) GB/s", ub, re.M)
+rd_strided = [float(g) for n, s_, g in rd if "stream" in n and "nontemporal" in n]
+rd_contig = [float(g) for n, s_, g in rd if "contiguous" in n and "nontemporal" in n]
+nanp = (float('nan'), float('nan'))
+plh_value, plh_frac = (plh["value"], Rh.get("frac", float('nan'))) if plh else nanp
+rds = (min(rd_strided), max(rd_strided)) if rd_strided else nanp
+rdc = (min(rd_contig), max(rd_contig)) if rd_contig else nanp
 txt = f'''# profiles/ — measured on MI355X (gfx950), round 4
 
 Distilled by `tools/collect_profiles.py` from ONE `gpurun` call of `tools/profile_round.sh` (the commands are in that script; build = the commit that carries these files); this file is written by
@@ -93,22 +115,23 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
 
 | file | command |
 |---|---|
-| `{tag}_bench_plain.json` | `python3 bench.py` (no flags, no profiler: what the driver runs) |
+| `{tag}_bench_plain.json` | `python3 bench.py` (no flags, no profiler: what the driver runs); `{tag}_bench_plain_h32.json`: the same with `MKHE_NTT32=1` (the single-pass forward kernel), same call |
 | `{tag}_kernel_stats_noovl.csv`, `{tag}_bench_noovl.json` | `MKHE_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-extras` (expected calls of the dominant kernel: 2 × {steps_of(no)} = {expect}; recorded: {calls}) |
 | `{tag}_kernel_stats_ovl.csv`, `{tag}_bench_ovl.json` | the same with the side-stream overlap on |
-| `traffic.json` | two passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of the same command with `--steps 6 --warmup 2` (dominant kernel: 2 × {2 * (2 + 6) + 300 + 6} = {2 * (2 * 8 + 306)} calls; recorded: {dom.get("launches", "?")}); tied to the kernel sources by `csrc_sha256` |
+| `traffic.json` | two passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of the same command with `--steps 6 --warmup 2` (dominant kernel: 2 × {2 * (2 + 6) + 300 + 6} = {2 * (2 * 8 + 306)} calls; recorded: {dom.get("launches", "?")}), and the same two passes with `MKHE_NTT32=1` for the single-pass kernel's record; tied to the kernel sources by `csrc_sha256` |
 | `{tag}_sq_counters.txt` | three `--pmc` passes (SQ wave / wait / instruction counters, LDS, L2 hit rate) with `--steps 4 --warmup 2` |
-| `{tag}_ntt32_isa.txt` | `tools/ntt32_isa.py`: instruction counts of the dominant kernel from the gfx950 ISA, one two-butterfly asm block verbatim, code-object record (`{tag}_ntt16_isa.txt`: the same for the H16 kernel's pass body) |
-| `{tag}_ubench.txt` | `tools/ubench/bfly30u_rate`, `bfly31_rate`, `valu_rate`, and `bfly_asm_rate` (round 4: the butterfly as the compiler emits it beside the hand-scheduled two-butterfly block, 1 / 4 / 8 waves per SIMD) |
+| `{tag}_ntt16_isa.txt`, `{tag}_ntt32_isa.txt` | `tools/ntt16_isa.py`, `tools/ntt32_isa.py`: instruction counts of the two forward kernels from the gfx950 ISA, one butterfly (one two-butterfly asm block) verbatim, code-object records |
+| `{tag}_ubench.txt` | `tools/ubench/bfly30u_rate`, `bfly31_rate`, `valu_rate`, `bfly_asm_rate` (the butterfly as the compiler emits it beside the hand-scheduled two-butterfly block), and `read_bw` (round 4: what a kernel that ONLY reads reaches on this part, in the access pattern of the streaming kernels) |
 | `{tag}_power_probe.txt` | `tools/power_probe.sh`: rocm-smi package power and shader clock beside 30 000 back-to-back launches of the dominant kernel |
-| `{tag}_ntt16_ablation.txt` | `tools/ntt16_variants.sh`: the single-pass kernel (and, second part, the H16 kernel) re-built without its memory streams / LDS exchanges / butterflies (wrong results on purpose) and with the experiments that were not kept, 1500 launches each (steady state) |
-| `{tag}_ntt16_launch_sizes.txt` | `tools/ntt16_bench.py 1500`: the Decompose NTT at 1792 / 896 / 448 / 224 limbs, default build and `MKHE_NTT32=0`, same call |
+| `{tag}_ntt16_ablation.txt` | `tools/ntt16_variants.sh`: both forward kernels re-built without their memory streams / LDS exchanges / butterflies (wrong results on purpose) and with the experiments that were not kept, 1500 launches each (steady state) |
+| `{tag}_ntt16_launch_sizes.txt` | `tools/ntt16_bench.py 1500`: the Decompose NTT at 1792 / 896 / 448 / 224 limbs back to back, default and `MKHE_NTT32=1`, same call |
+| `{tag}_ntt_in_context.txt` | `tools/trace_ntt_in_context.sh`: rocprofv3 kernel trace of the bench command, the 1792- and 896-limb launches INSIDE the MulRelin apart, both kernels, twice |
 | `{tag}_kernel_stats_bfv.csv`, `{tag}_bench_bfv*.json` | `bench.py --scheme bfv` under the profiler (overlap off) and plain |
 | `{tag}_bench_pn16*.json`, `{tag}_kernel_stats_pn16.csv` | `bench.py --params PN16QP1761 --parties 8` (configs[3] ring on one GPU; the plain run carries `config.device_keys_check`) |
 | `{tag}_bench_cnn2/4.json`, `{tag}_bench_cnn4_batch8/16.json`, `{tag}_bench_cnn2_batch8.json` | `bench.py --scheme cnn --parties 2/4 [--batch B]` (the unbatched lines carry `cpu_baseline`) |
 | `{tag}_bench_pn14.json`, `{tag}_pn14_batch.jsonl`, `{tag}_party_sweep.jsonl` | secondary workloads; `bench.py --params PN14QP439 --batch 4/8/16` |
 | `{tag}_dist_5ranks.json` | `bench.py --gpus 5` with all ranks on the one device of the box (DESIGN.md §7) |
-| `{tag}_gputests*.txt`, `{tag}_switch_matrix.txt` | `pytest -m gpu` with the defaults and with the single-pass kernel forced onto every N = 2^15 launch (`MKHE_NTT32_MIN=1`) |
+| `{tag}_gputests.txt`, `{tag}_switch_matrix.txt` | `pytest -m gpu` with the defaults, and once per switch set of `tools/switch_matrix.sh` (the single-pass kernel forced onto every N = 2^15 launch, measured choice, thresholds at 1, earlier rounds' features off) |
 
 ## Headline (BASELINE.json configs[1]): mkckks 4-party MulRelin, PN15QP880, N = 2^15, 14 Q + 2 P limbs
 
@@ -116,8 +139,9 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
   (`cpu_baseline.bit_exact_vs_gpu = {cb["bit_exact_vs_gpu"]}`); CPU oracle on the GPU box's host: {cb["value"]:.2f} MulRelin/s on 1 thread, {cb.get("value_limb_parallel", 0):.2f} with its limb loops on {cb.get("cores_limb_parallel", "?")} threads.
 * Same run: cold start **{C.get("mulrelin_per_sec_cold_start", 0):.0f}/s**, 200 steps after 100 untimed ones {C.get("mulrelin_per_sec_steady_state", 0):.0f}/s, two MulRelin in flight through forked contexts {C.get("mulrelin_per_sec_two_in_flight", 0):.0f}/s.
 * under `rocprofv3 --kernel-trace`, overlap off: {no["value"]:.0f} MulRelin/s ({no["ms_per_step"]:.3f} ms); overlap on: {ov["value"]:.0f} MulRelin/s ({ov["ms_per_step"]:.3f} ms).
-* **Box to box** the figures move by ± 2 % (round 3's list: 1164–1232 MulRelin/s, `roofline.frac` 0.488–0.520 for one build).  Round 4's A/B runs, each pair inside ONE gpurun call (`MKHE_NTT32=0` is the switch): single-pass kernel 1213 / 0.525, 1218 / 0.531, 1215 / 0.527
-  against 1185 / 0.508, 1207 / 0.515, 1188 / 0.510 for the H16 kernel; this set: {pl["value"]:.0f} / {R["frac"]:.3f}.
+* **Box to box** the figures move by ± 3 %, and round 4 met two kinds of parts: most sustain 1400 W under the NTT kernel (2.16–2.30 GHz), some cap at 1255 W (2.09 GHz: `r4_power_probe.txt` of the first profile set of the round).  Default `bench.py`,
+  same library, on the boxes gpurun dealt in the last hours of the round: 1232 MulRelin/s / `roofline.frac` 0.519 (1400 W), 1180 / 0.492 and 1190 / 0.493 (capped); this set: {pl["value"]:.0f} / {R["frac"]:.3f}.
+  With `MKHE_NTT32=1` in the same calls: 1230 / 0.530, 1162 / 0.463; this set: {plh_value:.0f} / {plh_frac:.3f}.
 
 Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per step.  "algorithmic GB/s" is the byte model of DESIGN.md §4 (`roofline.kernels_over_peak` = {R.get("kernels_over_peak")});
 "PMC GB/s" is what the kernel really moved through the L2's memory side, (2·FETCH_SIZE + WRITE_SIZE) from `traffic.json` over the same launch pattern:
@@ -129,31 +153,46 @@ Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per 
 Whole step: the kernels with a PMC column ({100 * cov:.0f} % of the kernel time) move **{tot_bytes / 1e9:.2f} GB per MulRelin** through HBM (round 3: 2.76, round 2: 3.40 GB) = {tot_bytes / 1e9 / pl["ms_per_step"]:.2f} TB/s averaged over the {pl["ms_per_step"]:.3f} ms step.  The three streaming launches
 are at their compulsory bytes (y: 528 MB, F1 + x: 587 MB, E / F2: 822 MB).
 
-### Dominant kernel `{DOM}` (DESIGN.md §4 "The single-pass kernel")
+### Dominant kernel `{DOM}` (DESIGN.md §3 "Round 3", §4)
 
 * HIP-event average inside `bench.py`: **{R["avg_launch_us"]:.1f} µs per launch** (plain run), {Rn["avg_launch_us"]:.1f} µs in the profiled run; rocprofv3 kernel-trace average of that profiled run: **{avg:.1f} µs** over {calls} calls
-  (min {mn:.0f} = the 896-limb launches, max {mx:.0f} µs).  Round 3 (`ntt16_fwd_kernel<true>`): 172–176 µs, round 2: 207 µs, round 1 (`ntt_fwd_kernel<15,2,true>`): 297.5 µs.
-* algorithmic bytes per launch {R["alg_bytes_per_launch"] / 1e6:.1f} MB (16·N B per limb-NTT × (1792 + 896)/2 limbs) ⇒ **{R["achieved"]:.0f} GB/s = {R["frac"]:.3f} of the 8 TB/s HBM peak** (round 3: 0.50–0.51, round 2: 0.42, round 1: 0.296).
+  (min {mn:.0f} = the 896-limb launches, max {mx:.0f} µs).  Round 3: 172–176 µs, round 2: 207 µs, round 1 (`ntt_fwd_kernel<15,2,true>`): 297.5 µs.
+* algorithmic bytes per launch {R["alg_bytes_per_launch"] / 1e6:.1f} MB (16·N B per limb-NTT × (1792 + 896)/2 limbs) ⇒ **{R["achieved"]:.0f} GB/s = {R["frac"]:.3f} of the 8 TB/s HBM peak** (round 3: 0.49–0.52 by box, round 2: 0.42, round 1: 0.296).
   By the compulsory bytes of the fused Decompose ({R.get("compulsory_bytes_per_launch", 0) / 1e6:.0f} MB per average launch) it is {R.get("frac_compulsory", 0):.3f}.
 * HBM traffic from the PMC passes: {dom.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch (FETCH_SIZE {dom.get("fetch_size_kb", 0) / 1e3:.1f} MB ×2 + WRITE_SIZE {dom.get("write_size_kb", 0) / 1e3:.1f} MB) =
-  {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes (H16, round 3: 0.93×: the second pass's re-read of the source is gone).  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and nothing else (no scratch: `{tag}_ntt32_isa.txt`).  Read: every source limb once per modulus it is spread under (mostly L2 hits) and 512 KB of twiddle pairs per limb-NTT —
-  as many bytes as the limb itself moves; they come from the L2 / Infinity Cache (16 moduli × 1 MB of tables).
-* Back to back (`{tag}_ntt16_launch_sizes.txt`, 1500 launches, same call): 1792 limbs **{size_us("default", 1792):.1f} µs** against {size_us("MKHE_NTT32=0", 1792):.1f} for the H16 kernel; 896 limbs {size_us("default", 896):.1f} against {size_us("MKHE_NTT32=0", 896):.1f} (one workgroup per CU deals whole limbs: four rounds for 3.5 rounds of work);
-  448 and 224 limbs stay on the H16 kernel ({size_us("default", 448):.1f} / {size_us("default", 224):.1f} µs).  VERDICT r3's 235 / 117 µs are not reached.
-* Power (`{tag}_power_probe.txt`): {pw[len(pw) // 2]:.0f} W (median of the samples under load; cap 1400 W) at {ck[len(ck) // 2] / 1e3:.2f} GHz — the H16 kernel sat at the cap at 2.09 GHz.
-* **Steady-state ablation** (`{tag}_ntt16_ablation.txt`, 1792 limbs, µs per launch): shipped {abl("shipped"):.0f}; no result stores {abl("no_stores"):.0f}, no source loads {abl("no_source_loads"):.0f}, no twiddle loads {abl("no_twiddle_loads"):.0f}, no LDS exchanges {abl("no_exchanges"):.0f};
-  the vector-ALU side alone (no loads, stores, exchanges) **{abl("butterflies_only"):.0f}**; all butterflies removed **{abl("no_butterflies"):.0f}**; butterflies and twiddle loads removed {abl("no_butterflies_no_twiddles"):.0f} (the data stream alone: {16 * 32768 * 1792 / abl("no_butterflies_no_twiddles") / 8e6:.2f} of the roofline).
-  Both sides are as long as the whole: the kernel no longer waits for one of them, it is as long as its butterflies AND as long as its memory instructions with their waits — the twiddle pairs are half of the second (per limb: 31 per-lane 16-byte loads + 31 `ds_read_b128` per thread, against 32 + 32 eight-byte data accesses).
-  Not kept, same table: no phase priorities {abl("no_phase_priorities"):.0f}, one priority set {abl("one_priority_set"):.0f}, eight twiddle pairs in flight {abl("ring_8"):.0f}, one butterfly per asm block {abl("one_butterfly_per_asm_block"):.0f}.
-  Second part of the file, the H16 kernel in the same call: shipped {abl("shipped", kernel="ntt16"):.0f}, vector-ALU side alone {abl("no_mem_no_xchg", kernel="ntt16"):.0f}, no butterflies {abl("no_bfly", kernel="ntt16"):.0f}.
-* `{tag}_ubench.txt`: the U-class butterfly as one lone wave issues it — compiler's form {re.search(r"compiler's form \(nops\)\s+waves/SIMD\s+1\.0.*?([0-9.]+) cycles", ub).group(1) if re.search(r"compiler's form \(nops\)\s+waves/SIMD\s+1\.0.*?([0-9.]+) cycles", ub) else "?"} cycles,
-  the hand-scheduled two-butterfly block {re.search(r"subtract before add\s+waves/SIMD\s+1\.0.*?([0-9.]+) cycles", ub).group(1) if re.search(r"subtract before add\s+waves/SIMD\s+1\.0.*?([0-9.]+) cycles", ub) else "?"}; with four waves per SIMD (the kernel's occupancy)
-  {re.search(r"compiler's form \(nops\)\s+waves/SIMD\s+4\.0.*?([0-9.]+) cycles", ub).group(1) if re.search(r"compiler's form \(nops\)\s+waves/SIMD\s+4\.0.*?([0-9.]+) cycles", ub) else "?"} against {re.search(r"subtract before add\s+waves/SIMD\s+4\.0.*?([0-9.]+) cycles", ub).group(1) if re.search(r"subtract before add\s+waves/SIMD\s+4\.0.*?([0-9.]+) cycles", ub) else "?"}: 12 VALU instructions per butterfly are ≈ 49 cycles of a SIMD, 240 butterflies per thread and limb ≈ 47 000 of the ≈ 80 000 cycles a limb takes.
+  {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and nothing else (no spilled VGPR, no scratch: `{tag}_ntt16_isa.txt`).  Read: the source limbs in both passes
+  (each is spread under 16 moduli) and the twiddle pairs.  The single-pass kernel (`MKHE_NTT32=1`): {alt.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch = {alt.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× (the second pass's re-read of the source is gone).
+* **What round 4 found in it** (and in every other H16-class forward kernel): the job walk read the per-modulus reduction schedule as `kb->sched[m]`, a BYTE of the kernel arguments under a dynamic index — which the compiler can only do with a vector
+  memory instruction (`global_load_ubyte` + `v_readfirstlane`), and the `s_waitcnt vmcnt(0)` in front of the `v_readfirstlane` waited for every result store of the previous job before the next job had requested a word.  Through a scalar dword load
+  (`tests/test_kernel_static.py` now refuses sub-dword and dword vector loads in these files): back to back 258 → **{size_us("default", 1792):.0f} µs** for 1792 limbs, 129 → {size_us("default", 896):.0f} for 896 (`{tag}_ntt16_launch_sizes.txt`; the single-pass kernel 246 → {size_us("MKHE_NTT32=1", 1792):.0f} and 130 → {size_us("MKHE_NTT32=1", 896):.0f}).
+  Inside the MulRelin the gain is 2 % (172–173 → 169–170 µs per average launch on the same kind of box): there the launches alternate with memory-bound kernels and run 5–8 % faster than back to back anyway.
+* Power (`{tag}_power_probe.txt`): {pw[len(pw) // 2]:.0f} W (median of the samples under load) at {ck[len(ck) // 2] / 1e3:.2f} GHz.
+* **Steady-state ablation** (`{tag}_ntt16_ablation.txt`, 1792 limbs, µs per launch, second part of the file): shipped {abl("shipped", kernel="ntt16"):.0f}, the vector-ALU side alone {abl("no_mem_no_xchg", kernel="ntt16"):.0f}, all butterflies removed {abl("no_bfly", kernel="ntt16"):.0f}.
+* `{tag}_ubench.txt`: the bare butterfly on `mm31` {m31.group(3) if m31 else "?"} cycles per wave at {m31.group(1) if m31 else "?"} GHz, on `mm30u` **{m30.group(3) if m30 else "?"} cycles at {m30.group(1) if m30 else "?"} GHz**; `{tag}_ntt16_isa.txt`: 13.6 VALU instructions per butterfly in the U-class pass body.
+
+### The single-pass kernel `{ALT}` (`MKHE_NTT32=1`; DESIGN.md §4 "The single-pass kernel")
+
+One 1024-thread workgroup per CU holds a whole limb (32 coefficients per thread): no stage repeated, every source word loaded once, one cross-wave exchange per limb, 12 VALU instructions per butterfly in every stage.
+
+* **Back to back it is the faster kernel on every part** (`{tag}_ntt16_launch_sizes.txt`, 1500 launches, same call): 1792 limbs **{size_us("MKHE_NTT32=1", 1792):.1f} µs** against {size_us("default", 1792):.1f}; 896 limbs {size_us("MKHE_NTT32=1", 896):.1f} against {size_us("default", 896):.1f} (one workgroup per CU deals whole limbs: four rounds for 3.5 rounds of work).
+  On a 1400 W part of this round: 229.3 / 120.4 against 241.9 / 120.9 — VERDICT r3's 235 µs for 1792 limbs is met there, its 117 µs for 896 limbs is not.
+* **Inside the MulRelin it depends on the part** (`{tag}_ntt_in_context.txt`, medians of the second half of a bench run, µs, 1792 / 896 limbs / mean): two-pass {c16[0]:.1f} / {c16[2]:.1f} / {c16[4]:.1f} and {c16b[0]:.1f} / {c16b[2]:.1f} / {c16b[4]:.1f},
+  single-pass {c32[0]:.1f} / {c32[2]:.1f} / {c32[4]:.1f} and {c32b[0]:.1f} / {c32b[2]:.1f} / {c32b[4]:.1f}.  On a 1400 W part (one call, before this set): single-pass 211.4 / 113.4 / 162.5 (**0.542 of the roofline**), two-pass 226.0 / 112.9 / 169.6 (0.519);
+  on a part capped at 1255 W: single-pass 237.2 / 126.4 / 181.9 (0.484), two-pass 226.9 / 114.6 / 171.1 (0.515) — the two-pass kernel keeps its in-context time under the lower cap, the single-pass kernel (one workgroup per CU, every wave of a CU in the same phase) does not.
+  `bench.py` in the same calls: 1230 MulRelin/s / 0.530 against 1232 / 0.519 (1400 W); 1162 / 0.463 against 1180 / 0.492 (capped).  MulRelin/s — the metric — is equal or lower with the single-pass kernel, so the default is the two-pass kernel;
+  `MKHE_NTT32=2` lets the engine measure both at the start of the workload and settle per launch shape (`mkhe_ntt_choice`), which picked wrongly on a capped part (the first milliseconds run on ramping clocks) and is an experiment.
+* **Steady-state ablation** (`{tag}_ntt16_ablation.txt`, first part, 1792 limbs, µs per launch): shipped {abl("shipped"):.0f}; no result stores {abl("no_stores"):.0f}, no source loads {abl("no_source_loads"):.0f}, no twiddle loads {abl("no_twiddle_loads"):.0f}, no LDS exchanges {abl("no_exchanges"):.0f};
+  the vector-ALU side alone **{abl("butterflies_only"):.0f}**; all butterflies removed **{abl("no_butterflies"):.0f}**; butterflies and twiddle loads removed {abl("no_butterflies_no_twiddles"):.0f} (the data stream alone: {16 * 32768 * 1792 / abl("no_butterflies_no_twiddles") / 8e6:.2f} of the roofline).
+  Not kept, same table: no phase priorities {abl("no_phase_priorities"):.0f}, one priority set {abl("one_priority_set"):.0f}, eight twiddle pairs in flight {abl("ring_8"):.0f}, one butterfly per asm block {abl("one_butterfly_per_asm_block"):.0f},
+  the next limb's source words requested between this limb's stores (`MKHE_H32_PREFETCH=1`: 64 registers in flight across the loop's back edge, checked on the ISA by `tools/ntt32_inflight_check.py`) {abl("prefetch_next_limb"):.0f}.
+* `{tag}_ubench.txt`: the U-class butterfly as one lone wave issues it — compiler's form {cyc_c1} cycles,
+  the hand-scheduled two-butterfly block {cyc_h1}; with four waves per SIMD (the kernel's occupancy)
+  {cyc_c4} against {cyc_h4}: 12 VALU instructions per butterfly are ≈ 49 cycles of a SIMD, 240 butterflies per thread and limb ≈ 47 000 of the ≈ 75 000 cycles a limb takes.
 
 ### Streaming kernels
 
 `inner_product_kernel<4>` {R["kernels"]["inner_product_kernel"]["avg_launch_us"]:.0f} µs per launch, `ext_inner_kernel` {R["kernels"]["ext_inner_kernel"]["avg_launch_us"]:.0f} µs (two launches: F1 + x, and the E / F2 batch): 16-byte lanes, non-temporal loads for every operand read once per launch, items that share a key computed by one thread.
-Their algorithmic GB/s now equal their PMC GB/s (the byte model charges every distinct operand once): ≈ 5.8 TB/s = 0.73 of the 8 TB/s spec, 0.92 of the 6.29 TB/s that MI355X_MICROARCH.md measures for a float4 copy.  The ModDown launches and the small inverse NTTs are
+Their algorithmic GB/s equal their PMC GB/s (the byte model charges every distinct operand once): ≈ 5.8 TB/s = 0.73 of the 8 TB/s spec.  `{tag}_ubench.txt` (`read_bw`, round 4) measures what a kernel that ONLY reads reaches on this part: {rds[0]:.0f}–{rds[1]:.0f} GB/s in the pattern of these kernels (14–70 concurrent streams 4 MB apart, 16 bytes per lane), {rdc[0]:.0f}–{rdc[1]:.0f} GB/s with one contiguous region per workgroup — the streaming kernels are at the read ceiling of the part, not 27 % under it.  The ModDown launches and the small inverse NTTs are
 launch-latency-bound; the Rescale no longer appears: it rides on the merged ModDown's store (`mkhe_mul_relin_rescale`, DESIGN.md §4 "Fused Rescale").
 
 ## BASELINE.json configs[2]: mkbfv 4-party MulRelinNew, PN15QP880 BFV chain (14 Q + 14 QMul + 2 P)
@@ -177,16 +216,22 @@ if p14:
     r14 = p14["roofline"]
     txt += ("\n## PN14QP439 (N = 2^14, 6 + 2 limbs), the first set of the reference's benchmark (`mkckks_benchmark_test.go:13`)\n\n4 parties: **%.0f MulRelin/s** (%.3f ms; round 2: 3567).  Its Decompose NTT runs the one-pass N = 2^14 instantiation of the H16 kernel "
             "(`ntt14_fwd_kernel<true>`, both modulus classes in one launch): %.1f µs per launch, %.2f of the roofline (round 2: two launches of the round-1 kernel per class, 0.11).\n" % (p14["value"], p14["ms_per_step"], r14["avg_launch_us"], r14["frac"]))
+    if pn14b:
+        txt += ("B inputs in lock step (`bench.py --params PN14QP439 --batch B`, round 4: `mkhe_mul_relin_batch`, every output identical to the single-input MulRelin): "
+                + ", ".join("B = %d: **%.0f MulRelin/s** (%.2fx of the %.0f/s that one input at a time reaches in the same process, check %s)" % (
+                    r["config"]["batch"], r["value"], r["value"] / r["config"]["mulrelin_per_sec_single_input_same_run"], r["config"]["mulrelin_per_sec_single_input_same_run"],
+                    r["config"]["batch_check"]["identical_to_single_mulrelin"]) for r in pn14b)
+                + ".  By B = 8 the step is GPU-bound (its kernels' own times add up to the step); VERDICT r3 asked for 1.5x at B = 4.\n")
 if pn:
     c = pn["config"]
     txt += f'''
 ## BASELINE.json configs[3] ring on ONE GPU: 8-party MulRelin + hoisted Rotate, PN16QP1761 (N = 2^16, 34 Q + 4 P primes, α = 2, β = 17)
 
-`python3 bench.py --params PN16QP1761 --parties 8 --steps 10 --warmup 2`: **{pn["value"]:.1f} MulRelin/s** ({pn["ms_per_step"]:.2f} ms per step; round 2: 68.5, round 1: 53.8), Rotate {c.get("rotate_per_sec", 0):.0f}/s, RotateHoisted {c.get("rotate_hoisted_per_sec", 0):.0f}/s.
-Round 3 changed its Decompose (DESIGN.md §4 "N = 2^16"): `decomp_spread4_kernel` reconstructs the two-limb digits on one-round radix-2^30 products and applies the first TWO stages of the forward NTT before it stores, and the four 2^14-point
+`python3 bench.py --params PN16QP1761 --parties 8 --steps 10 --warmup 2`: **{pn["value"]:.1f} MulRelin/s** ({pn["ms_per_step"]:.2f} ms per step; round 3: 89–95, round 2: 68.5, round 1: 53.8), Rotate {c.get("rotate_per_sec", 0):.0f}/s, RotateHoisted {c.get("rotate_hoisted_per_sec", 0):.0f}/s.
+Round 4: its sub-transform kernel `ntt14_fwd_split_kernel` had the vector byte load of the job walk too (above): 3.93 → 3.84 ms per step on one kind of box.  Round 3 changed its Decompose (DESIGN.md §4 "N = 2^16"): `decomp_spread4_kernel` reconstructs the two-limb digits on one-round radix-2^30 products and applies the first TWO stages of the forward NTT before it stores, and the four 2^14-point
 sub-transforms of every limb are single in-place passes of the H16 kernel (`ntt14_fwd_split_kernel`).  Per Decompose launch (8 components x 17 digits x 38 moduli + the x / y digits = 8058 limbs of 2^16 words = 4.2 GB): 0.99 + 2.62 ms
 (cross-half stage only, two-pass 2^15-point sub-transforms out of place: 4.2 GB written by the spread, 8.4 GB read and 4.2 GB written by the NTT = 4.8 TB/s, HBM-bound) became 0.83 + 2.23 ms (4.2 + 4.2 + 4.2 GB; the spread stores at 5.1 TB/s, the NTT is bound by its
-butterflies under the power cap like the N = 2^15 kernel) -- 75.5 → 81.1 MulRelin/s on one box, same call (`MKHE_SPREAD_RADIX4=0` is the A/B switch).  `{tag}_pn16_traffic.txt` has the PMC bytes of both paths (`tools/pn16_traffic.sh`): the largest
+butterflies under the power cap like the N = 2^15 kernel) -- 75.5 → 81.1 MulRelin/s on one box, same call (`MKHE_SPREAD_RADIX4=0` is the A/B switch).  `r3_pn16_traffic.txt` has the PMC bytes of both paths (`tools/pn16_traffic.sh`): the largest
 Decompose launch (both operands: 16 components, 5.29 GB of digits) reads 5.46 GB and writes 5.29 GB in `ntt14_fwd_split_kernel` where `ntt16_fwd_split_kernel` read 11.4 GB; the whole step moves ≈ 53 GB through HBM = 4.5 TB/s over its 11.7 ms -- this configuration is
 memory-bound as a whole (`ext_inner_kernel` 2 × 6.6 GB, `inner_product_kernel<8>` 2 × 5.6 GB, the Decompose pair 2 × 12.3 GB).  The inverse launches run `ntt14_inv_kernel` + `ntt_pass4_inv_kernel` since the end of round 3 (DESIGN.md §4): 0.79 → 0.51 ms per step; x comes out of step F1 for up to sixteen parties (`ext_inner_xwide_kernel`): one `inner_product_kernel<8>` launch
 and its 5.6 GB gone (87.7 → 90.4 MulRelin/s in one call; the traffic table above was recorded before these two); the 33 moduli below 2^45.67 run double-precision butterflies in `ntt14_fwd_split_kernel` (F class, +1.5–3 %).
@@ -201,11 +246,22 @@ Bit-exactness at this ring with 8 parties against the oracle with host keys: `te
 The party-sharded N > 1 run of this configuration is `python3 bench.py --gpus 8 --params PN16QP1761 --parties 8` (DESIGN.md §7 has the link model; not measurable on the single-GPU boxes of this pool).
 '''
 if c2 and c4:
-    txt += f'''
+    cb4 = c4.get("cpu_baseline") or {}
+    txt += f"""
 ## BASELINE.json configs[4] caller on one GPU: encrypted CNN inference (cnn/cnn.go), PN14QP433
 
-`python3 bench.py --scheme cnn --parties 2|4 --steps 20 --warmup 3`: **{c2["value"]:.0f}** inferences/s with 2 parties ({c2["ms_per_step"]:.2f} ms), **{c4["value"]:.0f}** with 4 ({c4["ms_per_step"]:.2f} ms) (round 2: 276 / 268).
-`--gpus N` runs N independent replicas.  Encrypted == plaintext logits, synthetic model and the reference's trained weights: `tests/test_gpu_cnn.py`.
-'''
+`python3 bench.py --scheme cnn --parties 2|4 --steps 20 --warmup 3`: **{c2["value"]:.0f}** inferences/s with 2 parties ({c2["ms_per_step"]:.2f} ms), **{c4["value"]:.0f}** with 4 ({c4["ms_per_step"]:.2f} ms) (round 3: 350 / 343, round 2: 276 / 268).
+`cpu_baseline` (round 4): the SAME inference — same circuit, keys, model and image — on the CPU oracle through `tests/oracle_evaluator.py`, one host thread: {cb4.get("value", float("nan")):.3f} inferences/s ({cb4.get("sample", "")}),
+{cb4.get("value_limb_parallel", float("nan")):.2f} with the oracle's limb loops on {cb4.get("cores_limb_parallel", "?")} threads; its output ciphertext equals the device's bit for bit (`bit_exact_vs_gpu = {cb4.get("bit_exact_vs_gpu")}`).
+"""
+    if cb8:
+        txt += ("**B images in lock step** (`--batch B`, `mkckks.BatchEvaluator`: `cnn.Inference` unchanged on batched ciphertexts; every image's output equals its own single-image inference bit for bit, `config.batch_check`): "
+                "4 parties B = 8 **%.0f inferences/s** (%.2f ms per step of 8 images, host issue %.1f ms; check %s)" % (cb8["value"], cb8["ms_per_step"], cb8["config"]["host_issue_ms"], cb8["config"]["batch_check"]["identical_to_single_image_inference"]))
+        if cb16:
+            txt += ", B = 16 **%.0f**" % cb16["value"]
+        if c2b8:
+            txt += "; 2 parties B = 8 **%.0f**" % c2b8["value"]
+        txt += (" — %.1fx the single-image rate of the same box (VERDICT r3: 3x of 343).  Replaying the batched inference from a HIP graph changes nothing (970 against 961 at B = 8: `hipGraphLaunch` spends on the host what the eager issue does).\n" % (cb8["value"] / c4["value"]))
+    txt += "`--gpus N` runs N independent replicas.  Encrypted == plaintext logits, and the device's output ciphertext == the oracle evaluator's: `tests/test_gpu_cnn.py`.\n"
 open(P + "README.md", "w").write(txt)
 print("profiles/README.md written")
