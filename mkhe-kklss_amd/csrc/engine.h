@@ -330,16 +330,21 @@ class Context {
   private:
 
     struct ProfRec { hipEvent_t e0, e1; int cls; double bytes; };
+  public:
     // MKHE_NTT32=2 (default): which forward kernel a launch shape takes when both apply (H32 and H16 give the same bits), measured in the caller's own
     // workload.  The single-pass kernel wins by 2-5 % inside a MulRelin on most parts and loses 6 % on some (same library, same call:
-    // profiles/README.md) -- back to back it is ahead on all of them, so a calibration outside the workload would pick wrongly, and so did a first
-    // version that alternated the kernels over the first dozen launches (the first milliseconds run on ramping clocks with power to spare).  Per
-    // shape: WARM launches on H32 untimed, then BLOCK launches of H32 and BLOCK of H16 (the first SETTLE of a block untimed) under HIP-event pairs;
-    // the medians of the timed launches decide, the choice stays.  A smaller shape follows the largest one unless the other kernel is 3 % ahead.
-    struct NttTune { static constexpr int WARM = 64, SETTLE = 16, BLOCK = 48; int n[2] = {0, 0}, blk[2] = {0, 0}; float t[2][BLOCK]; int decided = -1, pending = -1, seen = 0;
-                     hipEvent_t e0 = nullptr, e1 = nullptr; };
+    // profiles/README.md) -- back to back it is ahead on all of them, so a calibration outside the workload would pick wrongly; so did a first version
+    // that alternated the kernels over the first dozen launches (the first milliseconds run on ramping clocks with power to spare), and a second that
+    // timed the kernel alone (with the side stream on, a kernel's duration says little about the operation's).  What is measured is the PERIOD of the
+    // shape -- the time from one of its launches to the next on the GPU's clock, i.e. the whole operation around it in a running service.  Per shape:
+    // WARM launches on H32, then a block on H32 and a block on H16 (SETTLE launches, then TIMED periods); the medians decide, the choice stays.
+    // A smaller shape follows the largest one unless the other kernel is 3 % ahead.
+    struct NttTune { static constexpr int WARM = 64, SETTLE = 16, TIMED = 32, RING = 2 * (TIMED + 1); int n[2] = {0, 0}, req[2] = {0, 0}, blk[2] = {0, 0}; float t[2][TIMED];
+                     int decided = -1, seen = 0;
+                     // start events of the timed launches that have not been turned into periods yet (the host runs ahead of the GPU): ring[head .. head + inflight)
+                     hipEvent_t e0[RING] = {}; int which[RING] = {}; int head = 0, inflight = 0; int slot = -1; };
     std::map<long, NttTune> ntt_tune_;
-    int ntt_pick(long key, NttTune*& sampling);      // 1 = H32, 0 = H16; sampling != nullptr: this launch is timed (record e0 before, e1 after)
+    int ntt_pick(long key, NttTune*& sampling);      // 1 = H32, 0 = H16; sampling != nullptr: this launch is timed (record e0[slot] in front of it)
   private:
     bool prof_on_ = false;
     std::vector<ProfRec> prof_recs_;

@@ -463,7 +463,7 @@ void Context::release_all() noexcept {
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
     for (auto& f : free_list_) (void)hipFree(f.p);
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
-    for (auto& kv : ntt_tune_) if (kv.second.e0) { (void)hipEventDestroy(kv.second.e0); (void)hipEventDestroy(kv.second.e1); }
+    for (auto& kv : ntt_tune_) for (int i = 0; i < NttTune::RING; ++i) if (kv.second.e0[i]) (void)hipEventDestroy(kv.second.e0[i]);
     ntt_tune_.clear();
     if (fence_ev_) (void)hipEventDestroy(fence_ev_);
     if (xev_) (void)hipEventDestroy(xev_);
@@ -678,7 +678,7 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     NttTune* sampling = nullptr;
     int use32 = ok32 ? 1 : 0;
     if (ok32 && ok16 && ntt32_mode() == 2) use32 = ntt_pick((((long)b.nslots * b.nouter) << 2) | (decompose ? 2 : 0) | (b.src_lazy ? 1 : 0), sampling);
-    if (sampling) (void)hipEventRecord(sampling->e0, s_);
+    if (sampling) (void)hipEventRecord(sampling->e0[sampling->slot], s_);
     if (use32) {
         ProfScope ps(this, decompose ? PROF_NTT32_DECOMP : PROF_NTT32_FWD, 16.0 * N * b.nouter * b.nslots);
         NttBatch bt = b; bt.trace = ntt_trace;
@@ -688,7 +688,6 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
         NttBatch bt = b; bt.trace = ntt_trace;
         launch_ntt16_fwd(bt, small16_.data(), s_, logN);
     }
-    if (sampling) (void)hipEventRecord(sampling->e1, s_);
     if (use32 || ok16) return;
     if (decompose && ntt_fwd_mixed_ok(logN, b, small_q_.data())) {
         // large Decompose launches: both modulus classes in one persistent grid (no ragged tail of the big-modulus class)
@@ -717,27 +716,31 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
 }
 
 int Context::ntt_pick(long key, NttTune*& sampling) {
-    constexpr int WARM = NttTune::WARM, SETTLE = NttTune::SETTLE, BLOCK = NttTune::BLOCK, TIMED = BLOCK - SETTLE;
+    constexpr int WARM = NttTune::WARM, SETTLE = NttTune::SETTLE, TIMED = NttTune::TIMED, RING = NttTune::RING;
     sampling = nullptr;
     NttTune& t = ntt_tune_[key];
     if (t.decided >= 0) return t.decided;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s_, &cs);
     if (cs != hipStreamCaptureStatusNone) return 1;    // (no timing inside a graph capture: the recorded sequence keeps H32)
-    if (t.pending >= 0) {
-        float ms = 0.f;
-        const hipError_t e = hipEventElapsedTime(&ms, t.e0, t.e1);
-        if (e == hipErrorNotReady) { (void)hipGetLastError(); return t.pending; }      // the timed launch is still running: this one goes untimed, same kernel
-        if (e == hipSuccess && t.n[t.pending] < TIMED) t.t[t.pending][t.n[t.pending]++] = ms;
-        (void)hipGetLastError();
-        t.pending = -1;
+    // periods between consecutive timed launches of one block, oldest first, as far as the GPU has come
+    while (t.inflight >= 2) {
+        const int h = t.head, nx = (h + 1) % RING;
+        if (t.which[nx] == t.which[h]) {
+            float ms = 0.f;
+            const hipError_t e = hipEventElapsedTime(&ms, t.e0[h], t.e0[nx]);
+            if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }
+            if (e == hipSuccess && t.n[t.which[h]] < TIMED) t.t[t.which[h]][t.n[t.which[h]]++] = ms;
+            else if (e != hipSuccess) --t.req[t.which[h]];             // (lost sample: one more launch of this kernel is asked for)
+            (void)hipGetLastError();
+        }
+        t.head = nx; --t.inflight;
     }
     if (t.n[0] >= TIMED && t.n[1] >= TIMED) {
         auto med = [](float* v, int n) { std::sort(v, v + n); return v[n / 2]; };
         const float m32 = med(t.t[1], TIMED), m16 = med(t.t[0], TIMED);
         t.decided = m32 <= m16 ? 1 : 0;
-        // a smaller shape follows the choice of the largest one decided so far unless the other kernel is ahead by more than 3 % (one kernel per
-        // operation where the medians are a coin flip: 896 limbs inside a MulRelin are 113.4 against 112.9 us)
+        // a smaller shape follows the choice of the largest one decided so far unless the other kernel is ahead by more than 3 %
         long lead = -1;
         for (const auto& kv : ntt_tune_) if (kv.second.decided >= 0 && &kv.second != &t && (kv.first >> 2) > (key >> 2) && (kv.first >> 2) > (lead >> 2)) lead = kv.first;
         if (lead >= 0) {
@@ -745,15 +748,18 @@ int Context::ntt_pick(long key, NttTune*& sampling) {
             const float ml = l ? m32 : m16, mo = l ? m16 : m32;
             if (mo > 0.97f * ml) t.decided = l;
         }
-        if (t.e0) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); t.e0 = t.e1 = nullptr; }
-        return t.decided;
+        return t.decided;                              // (the events stay until the context goes: release_all)
     }
-    // launch number `seen` of this shape: [0, WARM) H32 untimed; then a block of H32 and a block of H16, the first SETTLE launches of a block untimed
+    // launch number `seen` of this shape: [0, WARM) H32; then a block of H32 and a block of H16 -- SETTLE launches, then TIMED + 1 launches with a start
+    // event (TIMED periods) -- and H32 again until the last period has come back.  The host runs ahead of the GPU by up to hundreds of launches: the
+    // blocks are counted in REQUESTED events (the GPU executes the launches in this order whenever it gets to them), the decision waits for the harvest.
     if (t.seen < WARM) { ++t.seen; return 1; }
-    const int k = t.n[1] < TIMED ? 1 : 0;              // H32's block first, then H16's
+    const int k = t.req[1] < TIMED + 1 ? 1 : (t.req[0] < TIMED + 1 ? 0 : -1);
+    if (k < 0 || t.inflight >= RING) return 1;
     if (t.blk[k]++ < SETTLE) return k;
-    if (!t.e0) { MKHE_HIP(hipEventCreate(&t.e0)); MKHE_HIP(hipEventCreate(&t.e1)); }
-    t.pending = k;
+    const int sl = (t.head + t.inflight) % RING;
+    if (!t.e0[sl]) MKHE_HIP(hipEventCreate(&t.e0[sl]));
+    t.which[sl] = k; t.slot = sl; ++t.inflight; ++t.req[k];
     sampling = &t;
     return k;
 }
