@@ -867,7 +867,7 @@ __device__ __forceinline__ void fwd_body(const NttBatch& b, u32* lds) {
         // the per-modulus schedule assumes inputs below 2^60; lazy inputs (BFV digits and ring-R polynomials: src_lazy) and the halves of a split
         // N = 2^16 limb (values in [0, 4q) behind the streaming cross-half stage) keep the round-2 schedule: reduce at the load and after every phase
         // (the byte through a scalar dword load: a byte load of a kernel argument is a VECTOR memory instruction, and the s_waitcnt vmcnt(0) the
-        // compiler puts behind it waits for every store of the previous job before this one has requested a word -- round 3 shipped that)
+        // compiler puts behind it waits for every store of the previous job before this one has requested a word -- round 3 shipped that; 0.4 %)
         jb.sched = (kb->src_lazy || (SPLIT && LOGN == 15)) ? 15 : (int)((((const __attribute__((address_space(4))) unsigned*)kb->sched)[m >> 2] >> (8 * (m & 3))) & 0xffu);
 #ifdef MKHE_H16_X_SCHEDBYTE     // MKHE_ABLATION: round 3's form of the line above (same value; the vector byte load and its vmcnt(0)), for the A/B in one call
         jb.sched = (kb->src_lazy || (SPLIT && LOGN == 15)) ? 15 : kb->sched[m];

@@ -122,10 +122,10 @@ def test_h32_kernel_fits_one_workgroup_per_cu_without_scratch():
 @pytest.mark.parametrize("src", ["ntt16_kernels.hip", "ntt32_kernels.hip"])
 def test_forward_kernels_read_their_job_constants_with_scalar_loads(src):
     """Round 3 shipped `kb->sched[m]` (a byte of the kernel arguments, dynamic index) in the job walk of every H16-class forward kernel: a byte load
-    is a VECTOR memory instruction (global_load_ubyte + v_readfirstlane), and the `s_waitcnt vmcnt(0)` the compiler has to put between the two waited
-    for every result store of the previous job before the next one had requested a single word -- 6-7 % of the kernels' time back to back
-    (round 4: 246 -> 229 us for 1792 limbs on H32, 258 -> 242 on H16).  The constants of a job are wave-uniform and come through s_load: no
-    sub-dword vector load may appear in these files, and the only dword vector loads are the data / twiddle loads (x2 and x4)."""
+    is a VECTOR memory instruction (global_load_ubyte + v_readfirstlane), and the `s_waitcnt vmcnt(0)` the compiler has to put between the two waits
+    for every result store of the previous job before the next one has requested a single word.  Worth 0.4 % when it was found (stage 0's counted
+    waits stand behind those stores anyway), but a stall the source does not show: the constants of a job are wave-uniform and come through s_load --
+    no sub-dword vector load may appear in these files, and the only dword vector loads are the data / twiddle loads (x2 and x4)."""
     r = _isa(src)
     assert r.returncode == 0, r.stderr[-1500:]
     bad = [l.strip() for l in r.stdout.splitlines() if l.strip().startswith(("global_load_ubyte", "global_load_sbyte", "global_load_ushort", "global_load_sshort",

@@ -60,9 +60,12 @@ def abl(name, limbs=1792, kernel="ntt32"):
 
 
 R, Rn = pl["roofline"], no["roofline"]
-DOM = "ntt16_fwd_kernel<true>"
+DOM = "ntt32_fwd_kernel<true>" if "ntt32" in pl["roofline"].get("kernel", "") else "ntt16_fwd_kernel<true>"
 ALT = "ntt32_fwd_kernel<true>"
+H16K = "ntt16_fwd_kernel<true>"
 avg, calls, mn, mx = st(DOM)
+OTHER = H16K if DOM == ALT else ALT
+oavg, ocalls, omn, omx = st(OTHER)
 expect = 2 * steps_of(no)
 dom = pmc_rec(DOM) or {}
 cb = pl["cpu_baseline"]
@@ -74,7 +77,9 @@ ck = sorted(float(re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", l).group(1)) 
 ub = open(P + tag + "_ubench.txt").read()
 cb8, cb16, c2b8 = J("bench_cnn4_batch8"), J("bench_cnn4_batch16"), J("bench_cnn2_batch8")
 plh = J("bench_plain_h32")
+pl16 = J("bench_plain_h16")
 alt = pmc_rec(ALT) or {}
+h16rec = pmc_rec(H16K) or {}
 ctx_txt = open(P + tag + "_ntt_in_context.txt").read() if os.path.exists(P + tag + "_ntt_in_context.txt") else ""
 pn14b = [json.loads(l) for l in open(P + tag + "_pn14_batch.jsonl") if l.strip().startswith("{")] if os.path.exists(P + tag + "_pn14_batch.jsonl") else []
 sizes = open(P + tag + "_ntt16_launch_sizes.txt").read()
@@ -102,6 +107,7 @@ rd_strided = [float(g) for n, s_, g in rd if "stream" in n and "nontemporal" in 
 rd_contig = [float(g) for n, s_, g in rd if "contiguous" in n and "nontemporal" in n]
 nanp = (float('nan'), float('nan'))
 plh_value, plh_frac = (plh["value"], Rh.get("frac", float('nan'))) if plh else nanp
+pl16_value, pl16_frac = (pl16["value"], pl16["roofline"].get("frac", float('nan'))) if pl16 else nanp
 rds = (min(rd_strided), max(rd_strided)) if rd_strided else nanp
 rdc = (min(rd_contig), max(rd_contig)) if rd_contig else nanp
 txt = f'''# profiles/ — measured on MI355X (gfx950), round 4
@@ -115,16 +121,16 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
 
 | file | command |
 |---|---|
-| `{tag}_bench_plain.json` | `python3 bench.py` (no flags, no profiler: what the driver runs); `{tag}_bench_plain_h32.json`: the same with `MKHE_NTT32=1` (the single-pass forward kernel), same call |
-| `{tag}_kernel_stats_noovl.csv`, `{tag}_bench_noovl.json` | `MKHE_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-extras` (expected calls of the dominant kernel: 2 × {steps_of(no)} = {expect}; recorded: {calls}) |
+| `{tag}_bench_plain.json` | `python3 bench.py` (no flags, no profiler: what the driver runs); `{tag}_bench_plain_h32.json` / `_h16.json`: the same with `MKHE_NTT32=1` / `=0` (the forward kernel forced), same call |
+| `{tag}_kernel_stats_noovl.csv`, `{tag}_bench_noovl.json` | `MKHE_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-extras` (expected calls of the forward NTT: 2 × {steps_of(no)} = {expect}; recorded: {calls} + {ocalls} on the two kernels) |
 | `{tag}_kernel_stats_ovl.csv`, `{tag}_bench_ovl.json` | the same with the side-stream overlap on |
-| `traffic.json` | two passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of the same command with `--steps 6 --warmup 2` (dominant kernel: 2 × {2 * (2 + 6) + 300 + 6} = {2 * (2 * 8 + 306)} calls; recorded: {dom.get("launches", "?")}), and the same two passes with `MKHE_NTT32=1` for the single-pass kernel's record; tied to the kernel sources by `csrc_sha256` |
+| `traffic.json` | two passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of the same command with `--steps 6 --warmup 2` with the two-pass kernel forced (`MKHE_NTT32=0`: 2 × {2 * (2 + 6) + 300 + 6} = {2 * (2 * 8 + 306)} calls; recorded: {h16rec.get("launches", "?")}) and the same two passes with `MKHE_NTT32=1` (recorded: {alt.get("launches", "?")}); tied to the kernel sources by `csrc_sha256` |
 | `{tag}_sq_counters.txt` | three `--pmc` passes (SQ wave / wait / instruction counters, LDS, L2 hit rate) with `--steps 4 --warmup 2` |
 | `{tag}_ntt16_isa.txt`, `{tag}_ntt32_isa.txt` | `tools/ntt16_isa.py`, `tools/ntt32_isa.py`: instruction counts of the two forward kernels from the gfx950 ISA, one butterfly (one two-butterfly asm block) verbatim, code-object records |
 | `{tag}_ubench.txt` | `tools/ubench/bfly30u_rate`, `bfly31_rate`, `valu_rate`, `bfly_asm_rate` (the butterfly as the compiler emits it beside the hand-scheduled two-butterfly block), and `read_bw` (round 4: what a kernel that ONLY reads reaches on this part, in the access pattern of the streaming kernels) |
 | `{tag}_power_probe.txt` | `tools/power_probe.sh`: rocm-smi package power and shader clock beside 30 000 back-to-back launches of the dominant kernel |
 | `{tag}_ntt16_ablation.txt` | `tools/ntt16_variants.sh`: both forward kernels re-built without their memory streams / LDS exchanges / butterflies (wrong results on purpose) and with the experiments that were not kept, 1500 launches each (steady state) |
-| `{tag}_ntt16_launch_sizes.txt` | `tools/ntt16_bench.py 1500`: the Decompose NTT at 1792 / 896 / 448 / 224 limbs back to back, default and `MKHE_NTT32=1`, same call |
+| `{tag}_ntt16_launch_sizes.txt` | `tools/ntt16_bench.py 1500`: the Decompose NTT at 1792 / 896 / 448 / 224 limbs back to back, `MKHE_NTT32=0` and `=1`, same call |
 | `{tag}_ntt_in_context.txt` | `tools/trace_ntt_in_context.sh`: rocprofv3 kernel trace of the bench command, the 1792- and 896-limb launches INSIDE the MulRelin apart, both kernels, twice |
 | `{tag}_kernel_stats_bfv.csv`, `{tag}_bench_bfv*.json` | `bench.py --scheme bfv` under the profiler (overlap off) and plain |
 | `{tag}_bench_pn16*.json`, `{tag}_kernel_stats_pn16.csv` | `bench.py --params PN16QP1761 --parties 8` (configs[3] ring on one GPU; the plain run carries `config.device_keys_check`) |
@@ -139,9 +145,9 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
   (`cpu_baseline.bit_exact_vs_gpu = {cb["bit_exact_vs_gpu"]}`); CPU oracle on the GPU box's host: {cb["value"]:.2f} MulRelin/s on 1 thread, {cb.get("value_limb_parallel", 0):.2f} with its limb loops on {cb.get("cores_limb_parallel", "?")} threads.
 * Same run: cold start **{C.get("mulrelin_per_sec_cold_start", 0):.0f}/s**, 200 steps after 100 untimed ones {C.get("mulrelin_per_sec_steady_state", 0):.0f}/s, two MulRelin in flight through forked contexts {C.get("mulrelin_per_sec_two_in_flight", 0):.0f}/s.
 * under `rocprofv3 --kernel-trace`, overlap off: {no["value"]:.0f} MulRelin/s ({no["ms_per_step"]:.3f} ms); overlap on: {ov["value"]:.0f} MulRelin/s ({ov["ms_per_step"]:.3f} ms).
-* **Box to box** the figures move by ± 3 %, and round 4 met two kinds of parts: most sustain 1400 W under the NTT kernel (2.16–2.30 GHz), some cap at 1255 W (2.09 GHz: `r4_power_probe.txt` of the first profile set of the round).  Default `bench.py`,
-  same library, on the boxes gpurun dealt in the last hours of the round: 1232 MulRelin/s / `roofline.frac` 0.519 (1400 W), 1180 / 0.492 and 1190 / 0.493 (capped); this set: {pl["value"]:.0f} / {R["frac"]:.3f}.
-  With `MKHE_NTT32=1` in the same calls: 1230 / 0.530, 1162 / 0.463; this set: {plh_value:.0f} / {plh_frac:.3f}.
+* **Box to box** the figures move by ± 3 %, and round 4 met two kinds of parts — or states of a part: the configured cap reads 1400 W on both — that differ in what the forward NTT kernels do inside the MulRelin (below): on most the single-pass
+  kernel is ahead (`MKHE_NTT32=1` against `=0`, same call: 1230 MulRelin/s / `roofline.frac` 0.530 against 1232 / 0.519; 1214 / 0.532 against 1192–1199 / 0.505–0.508; 1214 / 0.521 against 1207 / 0.508), on some it is throttled (1162 / 0.463 against 1180 / 0.492; 1151 / 0.465 against 1187 / 0.512).
+  The engine measures which kernel gives the shorter operation in the process at hand (`MKHE_NTT32=2`, default) — this set: **{C.get("ntt_kernel_choice")}**; forced in the same call: single-pass {plh_value:.0f} / {plh_frac:.3f}, two-pass {pl16_value:.0f} / {pl16_frac:.3f}.
 
 Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per step.  "algorithmic GB/s" is the byte model of DESIGN.md §4 (`roofline.kernels_over_peak` = {R.get("kernels_over_peak")});
 "PMC GB/s" is what the kernel really moved through the L2's memory side, (2·FETCH_SIZE + WRITE_SIZE) from `traffic.json` over the same launch pattern:
@@ -153,20 +159,21 @@ Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per 
 Whole step: the kernels with a PMC column ({100 * cov:.0f} % of the kernel time) move **{tot_bytes / 1e9:.2f} GB per MulRelin** through HBM (round 3: 2.76, round 2: 3.40 GB) = {tot_bytes / 1e9 / pl["ms_per_step"]:.2f} TB/s averaged over the {pl["ms_per_step"]:.3f} ms step.  The three streaming launches
 are at their compulsory bytes (y: 528 MB, F1 + x: 587 MB, E / F2: 822 MB).
 
-### Dominant kernel `{DOM}` (DESIGN.md §3 "Round 3", §4)
+### Dominant kernel: the Decompose-fused forward NTT — `{DOM}` in this set (DESIGN.md §3 "Round 3", §4)
 
 * HIP-event average inside `bench.py`: **{R["avg_launch_us"]:.1f} µs per launch** (plain run), {Rn["avg_launch_us"]:.1f} µs in the profiled run; rocprofv3 kernel-trace average of that profiled run: **{avg:.1f} µs** over {calls} calls
-  (min {mn:.0f} = the 896-limb launches, max {mx:.0f} µs).  Round 3: 172–176 µs, round 2: 207 µs, round 1 (`ntt_fwd_kernel<15,2,true>`): 297.5 µs.
+  (min {mn:.0f} = the 896-limb launches, max {mx:.0f} µs) + {ocalls} calls of `{OTHER}` while the engine measured (average {oavg:.1f} µs): {calls} + {ocalls} = {calls + ocalls} of the expected {expect}.  Round 3: 172–176 µs, round 2: 207 µs, round 1 (`ntt_fwd_kernel<15,2,true>`): 297.5 µs.
 * algorithmic bytes per launch {R["alg_bytes_per_launch"] / 1e6:.1f} MB (16·N B per limb-NTT × (1792 + 896)/2 limbs) ⇒ **{R["achieved"]:.0f} GB/s = {R["frac"]:.3f} of the 8 TB/s HBM peak** (round 3: 0.49–0.52 by box, round 2: 0.42, round 1: 0.296).
   By the compulsory bytes of the fused Decompose ({R.get("compulsory_bytes_per_launch", 0) / 1e6:.0f} MB per average launch) it is {R.get("frac_compulsory", 0):.3f}.
-* HBM traffic from the PMC passes: {dom.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch (FETCH_SIZE {dom.get("fetch_size_kb", 0) / 1e3:.1f} MB ×2 + WRITE_SIZE {dom.get("write_size_kb", 0) / 1e3:.1f} MB) =
-  {dom.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes.  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and nothing else (no spilled VGPR, no scratch: `{tag}_ntt16_isa.txt`).  Read: the source limbs in both passes
-  (each is spread under 16 moduli) and the twiddle pairs.  The single-pass kernel (`MKHE_NTT32=1`): {alt.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch = {alt.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× (the second pass's re-read of the source is gone).
-* **What round 4 found in it** (and in every other H16-class forward kernel): the job walk read the per-modulus reduction schedule as `kb->sched[m]`, a BYTE of the kernel arguments under a dynamic index — which the compiler can only do with a vector
-  memory instruction (`global_load_ubyte` + `v_readfirstlane`), and the `s_waitcnt vmcnt(0)` in front of the `v_readfirstlane` waited for every result store of the previous job before the next job had requested a word.  Through a scalar dword load
-  (`tests/test_kernel_static.py` now refuses sub-dword and dword vector loads in these files): back to back 258 → **{size_us("default", 1792):.0f} µs** for 1792 limbs, 129 → {size_us("default", 896):.0f} for 896 (`{tag}_ntt16_launch_sizes.txt`; the single-pass kernel 246 → {size_us("MKHE_NTT32=1", 1792):.0f} and 130 → {size_us("MKHE_NTT32=1", 896):.0f}).
-  Inside the MulRelin the gain is 2 % (172–173 → 169–170 µs per average launch on the same kind of box): there the launches alternate with memory-bound kernels and run 5–8 % faster than back to back anyway.
-* Power (`{tag}_power_probe.txt`): {pw[len(pw) // 2]:.0f} W (median of the samples under load) at {ck[len(ck) // 2] / 1e3:.2f} GHz.
+* HBM traffic from the PMC passes (the kernel forced in them): two-pass kernel {h16rec.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch (FETCH_SIZE {h16rec.get("fetch_size_kb", 0) / 1e3:.1f} MB ×2 + WRITE_SIZE {h16rec.get("write_size_kb", 0) / 1e3:.1f} MB) =
+  {h16rec.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× the algorithmic bytes; single-pass kernel {alt.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB = {alt.get("hbm_bytes_per_launch", 0) / R["alg_bytes_per_launch"]:.2f}× (the second pass's re-read of the source is gone).  Written: the {R["alg_bytes_per_launch"] / 2e6:.0f} MB of results and nothing else (no spilled VGPR, no scratch: `{tag}_ntt16_isa.txt`, `{tag}_ntt32_isa.txt`).
+* Power (`{tag}_power_probe.txt`, 30 000 launches back to back): {pw[len(pw) // 2]:.0f} W (median of the samples under load) at {ck[len(ck) // 2] / 1e3:.2f} GHz.
+
+### The two-pass kernel `ntt16_fwd_kernel<true>` (`MKHE_NTT32=0`)
+
+* **A vector byte load in its job walk** (and in every other H16-class forward kernel since round 3): `kb->sched[m]`, a BYTE of the kernel arguments under a dynamic index, compiles to `global_load_ubyte` + `s_waitcnt vmcnt(0)` + `v_readfirstlane`, and the wait
+  stands behind every result store of the previous job.  It is a scalar dword load now (`tests/test_kernel_static.py` refuses sub-dword and dword vector loads in these files) and worth 0–2 % — same-call A/B in `{tag}_ntt16_ablation.txt`
+  (`round3_schedule_byte_load`): {abl("round3_schedule_byte_load", kernel="ntt16"):.1f} against {abl("shipped", kernel="ntt16"):.1f} / {abl("shipped_again", kernel="ntt16"):.1f} µs here, {abl("round3_schedule_byte_load"):.1f} against {abl("shipped"):.1f} / {abl("shipped_again"):.1f} on the single-pass kernel; 245.1 against 244.0 and 231.2 against 230.4 in another call.  (Two calls in which this was the only code difference were 7 % apart: box to box.)
 * **Steady-state ablation** (`{tag}_ntt16_ablation.txt`, 1792 limbs, µs per launch, second part of the file): shipped {abl("shipped", kernel="ntt16"):.0f}, the vector-ALU side alone {abl("no_mem_no_xchg", kernel="ntt16"):.0f}, all butterflies removed {abl("no_bfly", kernel="ntt16"):.0f}.
 * `{tag}_ubench.txt`: the bare butterfly on `mm31` {m31.group(3) if m31 else "?"} cycles per wave at {m31.group(1) if m31 else "?"} GHz, on `mm30u` **{m30.group(3) if m30 else "?"} cycles at {m30.group(1) if m30 else "?"} GHz**; `{tag}_ntt16_isa.txt`: 13.6 VALU instructions per butterfly in the U-class pass body.
 
@@ -174,13 +181,14 @@ are at their compulsory bytes (y: 528 MB, F1 + x: 587 MB, E / F2: 822 MB).
 
 One 1024-thread workgroup per CU holds a whole limb (32 coefficients per thread): no stage repeated, every source word loaded once, one cross-wave exchange per limb, 12 VALU instructions per butterfly in every stage.
 
-* **Back to back it is the faster kernel on every part** (`{tag}_ntt16_launch_sizes.txt`, 1500 launches, same call): 1792 limbs **{size_us("MKHE_NTT32=1", 1792):.1f} µs** against {size_us("default", 1792):.1f}; 896 limbs {size_us("MKHE_NTT32=1", 896):.1f} against {size_us("default", 896):.1f} (one workgroup per CU deals whole limbs: four rounds for 3.5 rounds of work).
+* **Back to back it is the faster kernel on every part** (`{tag}_ntt16_launch_sizes.txt`, 1500 launches, same call): 1792 limbs **{size_us("MKHE_NTT32=1", 1792):.1f} µs** against {size_us("MKHE_NTT32=0", 1792):.1f}; 896 limbs {size_us("MKHE_NTT32=1", 896):.1f} against {size_us("MKHE_NTT32=0", 896):.1f} (one workgroup per CU deals whole limbs: four rounds for 3.5 rounds of work).
   On a 1400 W part of this round: 229.3 / 120.4 against 241.9 / 120.9 — VERDICT r3's 235 µs for 1792 limbs is met there, its 117 µs for 896 limbs is not.
 * **Inside the MulRelin it depends on the part** (`{tag}_ntt_in_context.txt`, medians of the second half of a bench run, µs, 1792 / 896 limbs / mean): two-pass {c16[0]:.1f} / {c16[2]:.1f} / {c16[4]:.1f} and {c16b[0]:.1f} / {c16b[2]:.1f} / {c16b[4]:.1f},
   single-pass {c32[0]:.1f} / {c32[2]:.1f} / {c32[4]:.1f} and {c32b[0]:.1f} / {c32b[2]:.1f} / {c32b[4]:.1f}.  On a 1400 W part (one call, before this set): single-pass 211.4 / 113.4 / 162.5 (**0.542 of the roofline**), two-pass 226.0 / 112.9 / 169.6 (0.519);
   on a part capped at 1255 W: single-pass 237.2 / 126.4 / 181.9 (0.484), two-pass 226.9 / 114.6 / 171.1 (0.515) — the two-pass kernel keeps its in-context time under the lower cap, the single-pass kernel (one workgroup per CU, every wave of a CU in the same phase) does not.
-  `bench.py` in the same calls: 1230 MulRelin/s / 0.530 against 1232 / 0.519 (1400 W); 1162 / 0.463 against 1180 / 0.492 (capped).  MulRelin/s — the metric — is equal or lower with the single-pass kernel, so the default is the two-pass kernel;
-  `MKHE_NTT32=2` lets the engine measure both at the start of the workload and settle per launch shape (`mkhe_ntt_choice`), which picked wrongly on a capped part (the first milliseconds run on ramping clocks) and is an experiment.
+  `bench.py` in the same calls: 1230 MulRelin/s / 0.530 against 1232 / 0.519, 1214 / 0.532 against 1192–1199 / 0.505–0.508 (good parts); 1162 / 0.463 against 1180 / 0.492, 1151 / 0.465 against 1187 / 0.512 (throttling parts: they sit at 1255 W and 2.09 GHz under the kernel
+  where the others reach 1400 W and 2.2–2.3 GHz, with the same configured cap; frequent in the last hours of the round).  **The engine therefore measures** (`MKHE_NTT32=2`, default): per launch shape, after its first 64 launches, a block of launches on each kernel; the period from one launch of the shape
+  to the next on the GPU's clock (the whole operation) is the sample, the medians decide (`config.ntt_kernel_choice` in the bench line).  On throttling parts it settled on the two-pass kernel in every run (1196–1206 MulRelin/s / 0.50–0.51).
 * **Steady-state ablation** (`{tag}_ntt16_ablation.txt`, first part, 1792 limbs, µs per launch): shipped {abl("shipped"):.0f}; no result stores {abl("no_stores"):.0f}, no source loads {abl("no_source_loads"):.0f}, no twiddle loads {abl("no_twiddle_loads"):.0f}, no LDS exchanges {abl("no_exchanges"):.0f};
   the vector-ALU side alone **{abl("butterflies_only"):.0f}**; all butterflies removed **{abl("no_butterflies"):.0f}**; butterflies and twiddle loads removed {abl("no_butterflies_no_twiddles"):.0f} (the data stream alone: {16 * 32768 * 1792 / abl("no_butterflies_no_twiddles") / 8e6:.2f} of the roofline).
   Not kept, same table: no phase priorities {abl("no_phase_priorities"):.0f}, one priority set {abl("one_priority_set"):.0f}, eight twiddle pairs in flight {abl("ring_8"):.0f}, one butterfly per asm block {abl("one_butterfly_per_asm_block"):.0f},
@@ -192,7 +200,7 @@ One 1024-thread workgroup per CU holds a whole limb (32 coefficients per thread)
 ### Streaming kernels
 
 `inner_product_kernel<4>` {R["kernels"]["inner_product_kernel"]["avg_launch_us"]:.0f} µs per launch, `ext_inner_kernel` {R["kernels"]["ext_inner_kernel"]["avg_launch_us"]:.0f} µs (two launches: F1 + x, and the E / F2 batch): 16-byte lanes, non-temporal loads for every operand read once per launch, items that share a key computed by one thread.
-Their algorithmic GB/s equal their PMC GB/s (the byte model charges every distinct operand once): ≈ 5.8 TB/s = 0.73 of the 8 TB/s spec.  `{tag}_ubench.txt` (`read_bw`, round 4) measures what a kernel that ONLY reads reaches on this part: {rds[0]:.0f}–{rds[1]:.0f} GB/s in the pattern of these kernels (14–70 concurrent streams 4 MB apart, 16 bytes per lane), {rdc[0]:.0f}–{rdc[1]:.0f} GB/s with one contiguous region per workgroup — the streaming kernels are at the read ceiling of the part, not 27 % under it.  The ModDown launches and the small inverse NTTs are
+Their algorithmic GB/s equal their PMC GB/s (the byte model charges every distinct operand once): ≈ 5.8 TB/s = 0.73 of the 8 TB/s spec.  `{tag}_ubench.txt` (`read_bw`, round 4) measures what a kernel that ONLY reads reaches on the same box: {rds[0]:.0f}–{rds[1]:.0f} GB/s in the pattern of these kernels (14–70 concurrent streams 4 MB apart, 16 bytes per lane), {rdc[0]:.0f}–{rdc[1]:.0f} GB/s with one contiguous region per workgroup (another box of the round: 5464–5875 and 6003–6075) — the streaming kernels are within 0–10 % of the read ceiling of their access pattern, not 27 % under a roofline; the contiguous pattern (digit-major tiles instead of [digit][modulus][N]) would be a re-layout of every hoisted form and key.  The ModDown launches and the small inverse NTTs are
 launch-latency-bound; the Rescale no longer appears: it rides on the merged ModDown's store (`mkhe_mul_relin_rescale`, DESIGN.md §4 "Fused Rescale").
 
 ## BASELINE.json configs[2]: mkbfv 4-party MulRelinNew, PN15QP880 BFV chain (14 Q + 14 QMul + 2 P)
