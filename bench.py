@@ -91,6 +91,8 @@ def run_bfv(args):
         res = step()
     params.sync()
     extras["mulrelin_per_sec_cold_start"] = args.steps / (time.perf_counter() - t0)
+    extras["timing_protocol"] = ("legs in this order: cold start (W warm-up + K timed steps right after the host-side set-up: mulrelin_per_sec_cold_start, the figure "
+                                 "rounds 1-2 reported as value) -> secondary legs -> 60 untimed + 120 timed steps (steady state) -> W + K = the timed region of `value` -> K steps under HIP events (roofline)")
     if not getattr(args, "no_extras", False):
         un = lambda: ev.mulRelin(ct0, ct1, rlk)         # the non-hoisted twin (mkbfv/keyswitch.go:115-251) on its own device path
         for _ in range(2):
@@ -464,6 +466,9 @@ def run_single(args):
         res = step()
     params.sync()
     extras["mulrelin_per_sec_cold_start"] = args.steps / (time.perf_counter() - t0)
+    extras["timing_protocol"] = ("legs in this order: cold start (W warm-up + K timed steps right after the host-side set-up: mulrelin_per_sec_cold_start, the figure "
+                                 "rounds 1-2 reported as value) -> secondary legs (Rotate / Conjugate / two in flight / key generation) -> 100 untimed + 200 timed steps "
+                                 "(steady state) -> W + K = the timed region of `value` -> K steps under HIP events (roofline)")
 
     # ---- secondary figure: hoisted rotation of the same k-party ciphertext, hoisting included / excluded
     if not args.no_extras:

@@ -111,7 +111,8 @@ class Context {
     // defer_x: x is accumulated on the side stream and joined by mr_finish just before its first use (step E), so that it
     // overlaps the latency-bound part of step F; false (split-phase ABI): x and y are both complete on the main stream
     // fuse_x: x is not computed here but by the F1 kernel of mr_finish_head (one pass over h(c0_i) less); needs 1 <= n0 <= 4
-    void mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x = false, bool fuse_x = false);
+    // fuse_y (with fuse_x, n1 == n0 <= 4): y is not computed here either but inside the same F1 kernel, from the b_j and h(c1_j), and never stored
+    void mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x = false, bool fuse_x = false, bool fuse_y = false);
     void mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out);          // F1 + Decompose(t_i): needs y only
     void mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const Swk* const* rlk_v0, const Swk& crs_u, Ct& out);
     void mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
@@ -139,6 +140,7 @@ class Context {
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
     u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
     u64* ext_xout2_ = nullptr;            // ... and the second gadget's x (mkbfv)
+    std::vector<const u64*> ext_ykeys_, ext_yh_;          // set around the F1 call whose kernel computes y itself (ExtInnerArgs::ykey / yh)
     std::vector<std::pair<const u64*, u64*>> ext_xmap_;   // batch.hip: (shared key y_b, x_b) per input around the F1 call of a batch: one x per group
     std::vector<const u64*> bfv_xk1_, bfv_xk2_;   // mkbfv single-device MulRelinNew: d1_i, d2_i for the fused x1, x2
     // External products that ModDown adds into ONE destination are merged (ModDown is linear in the Q part, see NttBatch::vi and
@@ -294,6 +296,7 @@ class Context {
         bool head_done = false;              // mr_finish_head ran, mr_finish_tail still to come
         std::vector<const u64*> xkeys;       // non-empty: x is produced by the F1 kernel of mr_finish_head (into xfused) instead of by mr_xy
         u64* xfused = nullptr;
+        std::vector<const u64*> ykeys;       // non-empty: y is computed inside the F1 kernel from these keys (b_j) and h1 (never stored)
     } plan_;
 
     // Stream-ordered buffer pool.  A buffer freed through this context may still be in use by kernels that ANOTHER context of the

@@ -977,6 +977,8 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     }
     if ((ext_xout_ || ext_xout2_) && !xby) throw Error("mkhe: internal: x by-product requested for a batch that cannot carry it");
     ia.xout = xby ? ext_xout_ : nullptr; ia.xout2 = xby && xby2 ? ext_xout2_ : nullptr; ia.xmform = 1;
+    const bool xy = !ext_ykeys_.empty();
+    if (xy && (!xby || xby2 || mp || n > 4 || (int)ext_ykeys_.size() != n || (int)ext_yh_.size() != n)) throw Error("mkhe: internal: y inside a launch that cannot compute it");
     int xgroups = 0;
     if (!ext_xmap_.empty()) {
         // B inputs' step F1 in one launch (mul_relin_batch): the items that share y_b are input b's, at most four, and carry x_b
@@ -1015,7 +1017,14 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         for (int i = 0; i < n; ++i) { add(ia.ah[i]); add(ia.bg[i]); add(ia.ah2[i]); add(ia.bg2[i]); }
         distinct = ns;
     }
-    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0))); launch_ext_inner(ia, s_); }
+    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * n - 1.0) : 0.0)));
+      if (xy) {
+          ExtXyArgs xa{};
+          for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
+          xa.xout = ext_xout_; xa.c1 = c1; xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;
+          xa.g = n; xa.nb = nb; xa.nslots = nslots; xa.N = N;
+          launch_ext_inner_xy(xa, s_);
+      } else launch_ext_inner(ia, s_); }
     NttBatch b{};
     b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux;
     b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
@@ -1126,7 +1135,11 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
     static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
     static const int wide_env = getenv("MKHE_FUSE_X_WIDE") ? atoi(getenv("MKHE_FUSE_X_WIDE")) : 1;      // A/B: the by-product for five to sixteen parties
     const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= (wide_env ? 16 : 4) && !masked_;
-    mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse);
+    // y inside the F1 kernel as well (round 4): the thread that forms <h(c0_i), y> at a coefficient needs y there and nowhere else, so that y is
+    // neither a launch nor 2 x 59 MB of traffic -- when op1 has as many parties as op0 (at most four: the group form of the kernel)
+    static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
+    const bool fuse_y = fuse && fuse_y_env && plan_.n0 <= 4 && plan_.n1 == plan_.n0;
+    mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse, fuse_y);
     mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
 }
 
@@ -1258,7 +1271,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
 
 // -- steps B, C: x = [MForm] sum_i d_i (.) h(c0_i),  y = [MForm] sum_j b_j (.) h(c1_j)   (keyswitch_hoisted.go:79-117)
 // mform = false leaves the canonical partial sums for a cross-device reduction (party sharding).
-void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x, bool fuse_x) {
+void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x, bool fuse_x, bool fuse_y) {
     MrPlan& p = plan_;
     if (!p.valid) throw Error("mkhe: mr_xy without mr_prepare");
     const int nb = beta(p.level), nslots = nslots_qp(p.level);
@@ -1271,8 +1284,16 @@ void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, 
         }
         p.xfused = x;
     }
+    p.ykeys.clear();
+    if (fuse_y) {
+        if (!fuse_x || p.n1 != p.n0 || p.n0 > 4) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and as many parties in op1 as in op0");
+        for (int a = 0; a < p.n1; ++a) {
+            if (!rlk_b1[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+            p.ykeys.push_back(rlk_b1[a]->d);
+        }
+    }
     // y first: it feeds step F, the long chain (F1 -> Decompose -> F2); x only feeds step E
-    for (int side = 1; side >= (fuse_x ? 1 : 0); --side) {
+    for (int side = fuse_y ? 0 : 1; side >= (fuse_x ? 1 : 0); --side) {
         const int n = side ? p.n1 : p.n0;
         if (n > MAX_TERMS) throw Error("mkhe: too many parties");
         InnerProductArgs ip{};
@@ -1310,8 +1331,9 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
         items.push_back(it);
     }
     if (!p.xkeys.empty()) ext_xout_ = p.xfused;          // x = sum_i d_i (.) h(c0_i) comes out of the same pass over h(c0_i)
-    try { ext_batch(level, items); } catch (...) { ext_xout_ = nullptr; throw; }
-    ext_xout_ = nullptr;
+    if (!p.ykeys.empty()) { ext_ykeys_ = p.ykeys; ext_yh_ = p.h1; }          // ... and y is computed in it
+    try { ext_batch(level, items); } catch (...) { ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); throw; }
+    ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear();
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;

@@ -100,6 +100,19 @@ struct ExtInnerArgs {
 };
 void launch_ext_inner(const ExtInnerArgs& a, hipStream_t st);
 
+// Step F1 with x AND y computed in the thread (ext_inner_xy_kernel<G>, poly_kernels.hip): item g's digits ah[g] = h(c0_g) meet y = MForm(sum_j
+// ykey[j] (.) yh[j]) for the product (c1 item g) and xkey[g] = d_g for x (xout, MForm'd).  ykey = the b_j, yh = the h(c1_j), g of each.
+struct ExtXyArgs {
+    const u64* ah[4]; const u64* xkey[4]; const u64* ykey[4]; const u64* yh[4];
+    u64* xout;
+    u64* c1;                 // [g][mtot][N]
+    const Mod* mods;
+    const int* map;
+    long digit_stride, c1_item;
+    int g, nb, nslots, N;
+};
+void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st);
+
 // Batched ModDown tail: item b reads c1[b] and writes / accumulates into dst[b].  Items that share a
 // destination are applied one after the other by the same thread (out_0 += sum_i ..., step F).
 struct ModDownBatchArgs {

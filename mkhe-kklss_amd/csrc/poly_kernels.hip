@@ -470,6 +470,64 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xwide_kernel(ExtInnerArg
     const Mod md = a.mods[m];
     ext_x_wide<G4>(a, ka, (long)m * a.N + n, md);
 }
+// Step F1 of a single-device MulAndRelin with as many parties in op1 as in op0 (G <= 4): t_i = <h(c0_i), y>, x = MForm(sum_i d_i (.) h(c0_i)) AND
+// y = MForm(sum_j b_j (.) h(c1_j)) in ONE pass -- the thread that forms the products at a coefficient needs y there and nowhere else, so y is neither
+// a launch of its own nor written and read back (2 x 59 MB at PN15QP880).  Per digit and thread: 4 G sixteen-byte loads, y[d] in registers, x[d]
+// stored.  Same operations as inner_product_kernel (mform_out) + ext_group_singles<G> with the x by-product: the same integers.
+template <int G>
+__global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_kernel(ExtXyArgs a) {
+    const int s = blockIdx.y;
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
+    if (n >= a.N) return;
+    const int m = a.map[s];
+    const Mod md = a.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const long off = (long)m * a.N + n, ds = a.digit_stride;
+    u64 acc[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; }
+#pragma unroll 1
+    for (int i = 0; i < a.nb; ++i) {
+        u64x2 h[G], k[G], b[G], c[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            b[g] = ld_stream(a.ykey[g] + off + i * ds); c[g] = ld_stream(a.yh[g] + off + i * ds);
+            h[g] = ld_stream(a.ah[g] + off + i * ds); k[g] = ld_stream(a.xkey[g] + off + i * ds);
+        }
+        u64 y0 = 0, y1 = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            y0 = csub(y0 + mont_mul_lazy(b[g].x, c[g].x, q, ninv), q2);
+            y1 = csub(y1 + mont_mul_lazy(b[g].y, c[g].y, q, ninv), q2);
+        }
+        y0 = mont_mul(csub(y0, q), md.r2, q, ninv); y1 = mont_mul(csub(y1, q), md.r2, q, ninv);
+        u64 x0 = 0, x1 = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            acc[g][0] = csub(acc[g][0] + mont_mul_lazy(y0, h[g].x, q, ninv), q2);
+            acc[g][1] = csub(acc[g][1] + mont_mul_lazy(y1, h[g].y, q, ninv), q2);
+            x0 = csub(x0 + mont_mul_lazy(k[g].x, h[g].x, q, ninv), q2);
+            x1 = csub(x1 + mont_mul_lazy(k[g].y, h[g].y, q, ninv), q2);
+        }
+        x0 = mont_mul(csub(x0, q), md.r2, q, ninv); x1 = mont_mul(csub(x1, q), md.r2, q, ninv);
+        u64x2 r; r.x = x0; r.y = x1;
+        *(u64x2*)(a.xout + off + i * ds) = r;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) ext_store(a.c1 + (long)g * a.c1_item + off, acc[g][0], acc[g][1], q);
+}
+void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st) {
+    if (a.g < 1 || a.g > 4) throw std::runtime_error("mkhe: internal: ext_inner_xy_kernel takes one to four parties");
+    const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
+    const dim3 grid(bx, a.nslots, 1), blk(PW_THREADS);
+    switch (a.g) {
+        case 1: hipLaunchKernelGGL(ext_inner_xy_kernel<1>, grid, blk, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(ext_inner_xy_kernel<2>, grid, blk, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(ext_inner_xy_kernel<3>, grid, blk, 0, st, a); break;
+        default: hipLaunchKernelGGL(ext_inner_xy_kernel<4>, grid, blk, 0, st, a); break;
+    }
+}
 void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
     ExtInnerArgs a = a_in;
     if (a.xout && !a.xmulti && a.nitems > 4) {

@@ -27,7 +27,7 @@ def per_kernel(d, counter):
             if not m:
                 continue
             key = m.group(1) + (m.group(2) or "").replace(" ", "")
-            if key == "ext_inner_group_kernel":         # same timing class as the per-item form (mkhe_prof_name: "ext_inner_kernel")
+            if key == "ext_inner_group_kernel" or key.startswith("ext_inner_xy_kernel"):         # same timing class as the per-item form (mkhe_prof_name: "ext_inner_kernel")
                 key = "ext_inner_kernel"
             if key.startswith("moddown_merged_kernel"):  # same timing class as the per-product ModDown ("moddown[_batch]_kernel")
                 key = "moddown_batch_kernel"
