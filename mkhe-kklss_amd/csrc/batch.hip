@@ -136,6 +136,8 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     const bool fold = n0 >= 1 && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
     static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
     const bool fuse_x = fuse_env && n0 >= 1 && n0 <= 4;      // x_b = sum_i d_i (.) h(c0_{b,i}) as a by-product of input b's step F1
+    static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
+    const bool fuse_y = fuse_x && fuse_y_env && n1 == n0;    // ... and y_b computed in the same threads (ext_inner_xy_batch_kernel), never stored
     const size_t per_b = (size_t)(2 + n0 + n1) * PO + (size_t)(1 + nout) * PO * ((fold ? 1 : 0) + (rescale_out ? 1 : 0)) + 2 * SW + (size_t)n0 * PO + (size_t)n0 * SW +
                          (own0 ? (size_t)n0 * SW : 0) + (own1 ? (size_t)n1 * SW : 0);
     Arena ar(this, B * per_b);
@@ -219,7 +221,7 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     {
         const int nbt = beta(level), nslots = nslots_qp(level);
         if (n0 > MAX_TERMS || n1 > MAX_TERMS) throw Error("mkhe: too many parties");
-        for (int side = 1; side >= (fuse_x ? 1 : 0); --side) {
+        for (int side = fuse_y ? 0 : 1; side >= (fuse_x ? 1 : 0); --side) {
             const int n = side ? n1 : n0;
             if (n == 0) { for (size_t b = 0; b < B; ++b) MKHE_HIP(hipMemsetAsync(side ? y[b] : x[b], 0, SW * sizeof(u64), s_)); continue; }
             if (n <= IPB_MAX_TERMS) {
@@ -252,16 +254,18 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
         const size_t per = std::max<size_t>(1, EXT_MAX_ITEMS / (size_t)n0);
         for (size_t b0 = 0; b0 < B; b0 += per) {
             std::vector<ExtItem> items;
-            ext_xmap_.clear();
+            ext_xmap_.clear(); ext_ykeys_.clear(); ext_yh_.clear();
             for (size_t b = b0; b < std::min(B, b0 + per); ++b) {
                 for (int a = 0; a < n0; ++a) {
                     items.push_back(ExtItem{h0[b * n0 + a], y[b], tbuf[b] + (size_t)a * PO, false});
                     if (fuse_x) items.back().xkey = rlk_d0[a]->d;
+                    if (fuse_y) ext_yh_.push_back(h1[b * n1 + a]);
                 }
                 if (fuse_x) ext_xmap_.push_back({y[b], x[b]});
             }
-            try { ext_batch(level, items); } catch (...) { ext_xmap_.clear(); throw; }
-            ext_xmap_.clear();
+            if (fuse_y) for (int a = 0; a < n1; ++a) ext_ykeys_.push_back(rlk_b1[a]->d);
+            try { ext_batch(level, items); } catch (...) { ext_xmap_.clear(); ext_ykeys_.clear(); ext_yh_.clear(); throw; }
+            ext_xmap_.clear(); ext_ykeys_.clear(); ext_yh_.clear();
         }
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (size_t b = 0; b < B; ++b)

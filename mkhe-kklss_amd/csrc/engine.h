@@ -140,7 +140,8 @@ class Context {
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
     u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
     u64* ext_xout2_ = nullptr;            // ... and the second gadget's x (mkbfv)
-    std::vector<const u64*> ext_ykeys_, ext_yh_;          // set around the F1 call whose kernel computes y itself (ExtInnerArgs::ykey / yh)
+    std::vector<const u64*> ext_ykeys_, ext_yh_;          // set around the F1 call whose kernel computes y itself (ExtXyArgs::ykey / yh); with ext_xmap_ (a
+                                                         // batch): ext_yh_ holds every input's digits in turn, ext_ykeys_.size() per input
     std::vector<std::pair<const u64*, u64*>> ext_xmap_;   // batch.hip: (shared key y_b, x_b) per input around the F1 call of a batch: one x per group
     std::vector<const u64*> bfv_xk1_, bfv_xk2_;   // mkbfv single-device MulRelinNew: d1_i, d2_i for the fused x1, x2
     // External products that ModDown adds into ONE destination are merged (ModDown is linear in the Q part, see NttBatch::vi and

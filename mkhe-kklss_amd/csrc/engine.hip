@@ -977,7 +977,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     }
     if ((ext_xout_ || ext_xout2_) && !xby) throw Error("mkhe: internal: x by-product requested for a batch that cannot carry it");
     ia.xout = xby ? ext_xout_ : nullptr; ia.xout2 = xby && xby2 ? ext_xout2_ : nullptr; ia.xmform = 1;
-    const bool xy = !ext_ykeys_.empty();
+    const bool xy = !ext_ykeys_.empty() && ext_xmap_.empty(), xyb = !ext_ykeys_.empty() && !ext_xmap_.empty();
     if (xy && (!xby || xby2 || mp || n > 4 || (int)ext_ykeys_.size() != n || (int)ext_yh_.size() != n)) throw Error("mkhe: internal: y inside a launch that cannot compute it");
     int xgroups = 0;
     if (!ext_xmap_.empty()) {
@@ -1017,13 +1017,34 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         for (int i = 0; i < n; ++i) { add(ia.ah[i]); add(ia.bg[i]); add(ia.ah2[i]); add(ia.bg2[i]); }
         distinct = ns;
     }
-    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * n - 1.0) : 0.0)));
+    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * n - 1.0) : 0.0) + (xyb ? nb * (1.0 * n + ext_ykeys_.size() - xgroups) : 0.0)));
       if (xy) {
           ExtXyArgs xa{};
           for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
           xa.xout = ext_xout_; xa.c1 = c1; xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;
           xa.g = n; xa.nb = nb; xa.nslots = nslots; xa.N = N;
           launch_ext_inner_xy(xa, s_);
+      } else if (xyb) {
+          // B inputs' step F1 with x_b and y_b in the thread: the items come input by input (g per input, mul_relin_batch), up to XYB_MAX inputs per launch
+          const int g = (int)ext_ykeys_.size(), nin = n / g;
+          if (two || mp || g < 1 || g > 4 || nin * g != n || (int)ext_yh_.size() != n || (int)ext_xmap_.size() != nin) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
+          for (int b0 = 0; b0 < nin; b0 += XYB_MAX) {
+              ExtXyBatchArgs xa{};
+              const int cnt = std::min(XYB_MAX, nin - b0);
+              for (int b = 0; b < cnt; ++b) {
+                  for (int j = 0; j < g; ++j) {
+                      const ExtItem& e = it[(b0 + b) * g + j];
+                      if (e.bg != ext_xmap_[b0 + b].first || !e.xkey) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
+                      xa.ah[b][j] = e.ah; xa.yh[b][j] = ext_yh_[(b0 + b) * g + j];
+                      if (b == 0) { xa.xkey[j] = e.xkey; xa.ykey[j] = ext_ykeys_[j]; }
+                      else if (e.xkey != xa.xkey[j]) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
+                  }
+                  xa.xout[b] = ext_xmap_[b0 + b].second;
+              }
+              xa.c1 = c1 + (size_t)b0 * g * item_words; xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;
+              xa.g = g; xa.nbatch = cnt; xa.nb = nb; xa.nslots = nslots; xa.N = N;
+              launch_ext_inner_xy_batch(xa, s_);
+          }
       } else launch_ext_inner(ia, s_); }
     NttBatch b{};
     b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux;

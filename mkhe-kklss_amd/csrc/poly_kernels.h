@@ -112,6 +112,19 @@ struct ExtXyArgs {
     int g, nb, nslots, N;
 };
 void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st);
+// ... and for B inputs in lock step (mul_relin_batch): input b's digits ah[b][g] / yh[b][g] meet the shared keys; its x goes to xout[b], its products
+// to the c1 items b * g .. b * g + g - 1 of the launch
+constexpr int XYB_MAX = 16;
+struct ExtXyBatchArgs {
+    const u64* ah[XYB_MAX][4]; const u64* yh[XYB_MAX][4]; u64* xout[XYB_MAX];
+    const u64* xkey[4]; const u64* ykey[4];
+    u64* c1;                 // [nbatch * g][mtot][N]
+    const Mod* mods;
+    const int* map;
+    long digit_stride, c1_item;
+    int g, nbatch, nb, nslots, N;
+};
+void launch_ext_inner_xy_batch(const ExtXyBatchArgs& a, hipStream_t st);
 
 // Batched ModDown tail: item b reads c1[b] and writes / accumulates into dst[b].  Items that share a
 // destination are applied one after the other by the same thread (out_0 += sum_i ..., step F).

@@ -528,6 +528,66 @@ void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st) {
         default: hipLaunchKernelGGL(ext_inner_xy_kernel<4>, grid, blk, 0, st, a); break;
     }
 }
+typedef const __attribute__((address_space(4))) ExtXyBatchArgs* xyb_kargs;
+template <int G>
+__global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_batch_kernel(ExtXyBatchArgs a) {
+    xyb_kargs ka = (xyb_kargs)__builtin_amdgcn_kernarg_segment_ptr();      // per-input pointer lists: scalar loads
+    const int s = blockIdx.y, bi = blockIdx.z;
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
+    if (n >= a.N) return;
+    const int m = a.map[s];
+    const Mod md = a.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const long off = (long)m * a.N + n, ds = a.digit_stride;
+    const u64* ah[G]; const u64* yh[G]; const u64* xk[G]; const u64* yk[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { ah[g] = ka->ah[bi][g] + off; yh[g] = ka->yh[bi][g] + off; xk[g] = ka->xkey[g] + off; yk[g] = ka->ykey[g] + off; }
+    u64* xo = ka->xout[bi] + off;
+    u64 acc[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; }
+#pragma unroll 1
+    for (int i = 0; i < a.nb; ++i) {
+        u64x2 h[G], k[G], b[G], c[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            b[g] = ld_cached(yk[g] + i * ds); c[g] = ld_stream(yh[g] + i * ds);          // (the keys are re-read by every input)
+            h[g] = ld_stream(ah[g] + i * ds); k[g] = ld_cached(xk[g] + i * ds);
+        }
+        u64 y0 = 0, y1 = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            y0 = csub(y0 + mont_mul_lazy(b[g].x, c[g].x, q, ninv), q2);
+            y1 = csub(y1 + mont_mul_lazy(b[g].y, c[g].y, q, ninv), q2);
+        }
+        y0 = mont_mul(csub(y0, q), md.r2, q, ninv); y1 = mont_mul(csub(y1, q), md.r2, q, ninv);
+        u64 x0 = 0, x1 = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            acc[g][0] = csub(acc[g][0] + mont_mul_lazy(y0, h[g].x, q, ninv), q2);
+            acc[g][1] = csub(acc[g][1] + mont_mul_lazy(y1, h[g].y, q, ninv), q2);
+            x0 = csub(x0 + mont_mul_lazy(k[g].x, h[g].x, q, ninv), q2);
+            x1 = csub(x1 + mont_mul_lazy(k[g].y, h[g].y, q, ninv), q2);
+        }
+        x0 = mont_mul(csub(x0, q), md.r2, q, ninv); x1 = mont_mul(csub(x1, q), md.r2, q, ninv);
+        u64x2 r; r.x = x0; r.y = x1;
+        *(u64x2*)(xo + i * ds) = r;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) ext_store(a.c1 + (long)(bi * G + g) * a.c1_item + off, acc[g][0], acc[g][1], q);
+}
+void launch_ext_inner_xy_batch(const ExtXyBatchArgs& a, hipStream_t st) {
+    if (a.g < 1 || a.g > 4 || a.nbatch < 1 || a.nbatch > XYB_MAX) throw std::runtime_error("mkhe: internal: ext_inner_xy_batch_kernel out of its range");
+    const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
+    const dim3 grid(bx, a.nslots, a.nbatch), blk(PW_THREADS);
+    switch (a.g) {
+        case 1: hipLaunchKernelGGL(ext_inner_xy_batch_kernel<1>, grid, blk, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(ext_inner_xy_batch_kernel<2>, grid, blk, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(ext_inner_xy_batch_kernel<3>, grid, blk, 0, st, a); break;
+        default: hipLaunchKernelGGL(ext_inner_xy_batch_kernel<4>, grid, blk, 0, st, a); break;
+    }
+}
 void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
     ExtInnerArgs a = a_in;
     if (a.xout && !a.xmulti && a.nitems > 4) {

@@ -133,6 +133,12 @@ CASES = [
     (["p%d" % i for i in range(10)], ["p1", "p9"], 0, 0, False),
     (["p%d" % i for i in range(13)], ["p%d" % i for i in range(13)], 0, 0, True),
     (["p%d" % i for i in range(16)], ["p3"], 1, 0, False),
+    # as many parties in op1 as in op0, up to four: y computed inside the F1 kernel (ext_inner_xy_kernel<1..4>, round 4) -- equal, overlapping and
+    # disjoint id sets (one and two parties are the cases at the top)
+    (["p0", "p1", "p2"], ["p0", "p1", "p2"], 0, 0, False),
+    (["p0", "p1", "p2", "p3"], ["p0", "p1", "p2", "p3"], 0, 0, True),
+    (["p0", "p1", "p2"], ["p1", "p2", "p3"], 1, 0, True),
+    (["p0", "p1", "p2", "p3"], ["p4", "p5", "p6", "p7"], 0, 0, False),
 ]
 
 
