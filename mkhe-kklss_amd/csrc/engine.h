@@ -30,6 +30,7 @@ struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
 // one external product of a batch: dst (+)= ModDown_P( sum_i bg[i] (.) ah[i] )
 struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const u64* ah2 = nullptr; const u64* bg2 = nullptr;
                  const u64* xkey = nullptr;   /* F1 only: this party's d_i, for the x by-product (ExtInnerArgs::xkey) */
+                 bool pre = false;            /* the inner products of this item are already in its c1 slot (step E computed by the F1 kernel): no inner launch work */
                  const u64* xkey2 = nullptr;  /* mkbfv F1: this party's d2_i (second gadget) */
                  const u64* addend = nullptr; /* accumulate onto this polynomial instead of onto dst (Rotate: c_0 of the input) */
                  const u64* qadd = nullptr;   /* first product of a destination, not accumulating: an NTT-domain polynomial [L][N] (canonical, already
@@ -140,6 +141,7 @@ class Context {
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
     u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
     u64* ext_xout2_ = nullptr;            // ... and the second gadget's x (mkbfv)
+    int ext_e_slot_ = -1;                                  // >= 0 around the F1 call that computes step E too: first c1 slot of the E products
     std::vector<const u64*> ext_ykeys_, ext_yh_;          // set around the F1 call whose kernel computes y itself (ExtXyArgs::ykey / yh); with ext_xmap_ (a
                                                          // batch): ext_yh_ holds every input's digits in turn, ext_ykeys_.size() per input
     std::vector<std::pair<const u64*, u64*>> ext_xmap_;   // batch.hip: (shared key y_b, x_b) per input around the F1 call of a batch: one x per group
@@ -298,6 +300,7 @@ class Context {
         std::vector<const u64*> xkeys;       // non-empty: x is produced by the F1 kernel of mr_finish_head (into xfused) instead of by mr_xy
         u64* xfused = nullptr;
         std::vector<const u64*> ykeys;       // non-empty: y is computed inside the F1 kernel from these keys (b_j) and h1 (never stored)
+        bool e_done = false;                 // ... and so was step E: its products sit in the c1 slots 2 n0 .. 2 n0 + n1 - 1 of the scratch, for the tail batch
     } plan_;
 
     // Stream-ordered buffer pool.  A buffer freed through this context may still be in use by kernels that ANOTHER context of the

@@ -1005,6 +1005,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     // neighbours that share their digits (step F: <h(t_i), v_i> and <h(t_i), u>) are computed together
     for (int i = 0; i + 1 < n && !xby; ++i)
         if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }
+    for (int i = 0; i < n; ++i) if (it[i].pre) { if (ia.pair[i]) throw Error("mkhe: internal: a precomputed item inside a pair"); ia.pair[i] = 2; }      // (role 2 = computed elsewhere: the kernels skip it)
     ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
     ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
     // algorithmic bytes: every DISTINCT digit / key array once (items that share x, y or the CRS u are computed by one thread that loads the
@@ -1014,14 +1015,14 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     {
         const u64* seen[4 * EXT_MAX_ITEMS]; int ns = 0;
         auto add = [&](const u64* p) { if (!p) return; for (int k = 0; k < ns; ++k) if (seen[k] == p) return; seen[ns++] = p; };
-        for (int i = 0; i < n; ++i) { add(ia.ah[i]); add(ia.bg[i]); add(ia.ah2[i]); add(ia.bg2[i]); }
+        for (int i = 0; i < n; ++i) if (!it[i].pre) { add(ia.ah[i]); add(ia.bg[i]); add(ia.ah2[i]); add(ia.bg2[i]); }
         distinct = ns;
     }
     { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * n - 1.0) : 0.0) + (xyb ? nb * (1.0 * n + ext_ykeys_.size() - xgroups) : 0.0)));
       if (xy) {
           ExtXyArgs xa{};
           for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
-          xa.xout = ext_xout_; xa.c1 = c1; xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;
+          xa.xout = ext_e_slot_ >= 0 ? nullptr : ext_xout_; xa.e_out = ext_e_slot_ >= 0 ? c1 + (size_t)ext_e_slot_ * item_words : nullptr; xa.c1 = c1; xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;
           xa.g = n; xa.nb = nb; xa.nslots = nslots; xa.N = N;
           launch_ext_inner_xy(xa, s_);
       } else if (xyb) {
@@ -1352,9 +1353,20 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
         items.push_back(it);
     }
     if (!p.xkeys.empty()) ext_xout_ = p.xfused;          // x = sum_i d_i (.) h(c0_i) comes out of the same pass over h(c0_i)
-    if (!p.ykeys.empty()) { ext_ykeys_ = p.ykeys; ext_yh_ = p.h1; }          // ... and y is computed in it
-    try { ext_batch(level, items); } catch (...) { ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); throw; }
-    ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear();
+    if (!p.ykeys.empty()) {
+        ext_ykeys_ = p.ykeys; ext_yh_ = p.h1;            // ... and y is computed in it
+        // ... and step E: the thread holds x[d] and h(c1_j)[d], so <h(c1_j), x> costs it G more accumulators, and x is never stored nor the h(c1_j) read
+        // again by the tail batch -- whose c1 slots 2 n0 .. 2 n0 + n1 - 1 (the E items) are filled here: the scratch is sized for the tail now, so
+        // that it is the same allocation then (nothing else of a MulAndRelin touches it in between)
+        static const int fuse_e_env = getenv("MKHE_FUSE_E") ? atoi(getenv("MKHE_FUSE_E")) : 1;
+        if (fuse_e_env && 2 * n0 + p.n1 <= EXT_MAX_ITEMS) {
+            scratch(c1b_, c1b_words_, (size_t)(2 * n0 + p.n1) * mtot * N);
+            ext_e_slot_ = 2 * n0;
+        }
+    }
+    try { ext_batch(level, items); } catch (...) { ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1; throw; }
+    p.e_done = ext_e_slot_ >= 0;
+    ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1;
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
@@ -1379,7 +1391,7 @@ void Context::mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const S
         items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
         items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
     }
-    for (int a = 0; a < n1; ++a) items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
+    for (int a = 0; a < n1; ++a) { items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true}); items.back().pre = p.e_done; }
     if (p.x_pending) { join_side(2); p.x_pending = false; }
     if (p.tens) {
         // the tensor term of every output slot rides on the first product that goes there (see mr_prepare)

@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xwide_kernel(ExtInnerArg
 // y = MForm(sum_j b_j (.) h(c1_j)) in ONE pass -- the thread that forms the products at a coefficient needs y there and nowhere else, so y is neither
 // a launch of its own nor written and read back (2 x 59 MB at PN15QP880).  Per digit and thread: 4 G sixteen-byte loads, y[d] in registers, x[d]
 // stored.  Same operations as inner_product_kernel (mform_out) + ext_group_singles<G> with the x by-product: the same integers.
-template <int G>
+template <int G, bool E>
 __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_kernel(ExtXyArgs a) {
     const int s = blockIdx.y;
     const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
@@ -484,9 +484,9 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_kernel(ExtXyArgs a) {
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
     const long off = (long)m * a.N + n, ds = a.digit_stride;
-    u64 acc[G][2];
+    u64 acc[G][2], ace[E ? G : 1][2];
 #pragma unroll
-    for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; }
+    for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; if (E) { ace[g][0] = 0; ace[g][1] = 0; } }
 #pragma unroll 1
     for (int i = 0; i < a.nb; ++i) {
         u64x2 h[G], k[G], b[G], c[G];
@@ -511,21 +511,36 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_kernel(ExtXyArgs a) {
             x1 = csub(x1 + mont_mul_lazy(k[g].y, h[g].y, q, ninv), q2);
         }
         x0 = mont_mul(csub(x0, q), md.r2, q, ninv); x1 = mont_mul(csub(x1, q), md.r2, q, ninv);
-        u64x2 r; r.x = x0; r.y = x1;
-        *(u64x2*)(a.xout + off + i * ds) = r;
+        if constexpr (E) {
+            // step E from what the thread holds: <h(c1_j), x> (ext_inner_kernel: acc += mont_mul_lazy(x[d], h(c1_j)[d]))
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                ace[g][0] = csub(ace[g][0] + mont_mul_lazy(x0, c[g].x, q, ninv), q2);
+                ace[g][1] = csub(ace[g][1] + mont_mul_lazy(x1, c[g].y, q, ninv), q2);
+            }
+        }
+        if (a.xout) { u64x2 r; r.x = x0; r.y = x1; *(u64x2*)(a.xout + off + i * ds) = r; }
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) ext_store(a.c1 + (long)g * a.c1_item + off, acc[g][0], acc[g][1], q);
+    for (int g = 0; g < G; ++g) {
+        ext_store(a.c1 + (long)g * a.c1_item + off, acc[g][0], acc[g][1], q);
+        if constexpr (E) ext_store(a.e_out + (long)g * a.c1_item + off, ace[g][0], ace[g][1], q);
+    }
 }
 void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st) {
     if (a.g < 1 || a.g > 4) throw std::runtime_error("mkhe: internal: ext_inner_xy_kernel takes one to four parties");
     const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
     const dim3 grid(bx, a.nslots, 1), blk(PW_THREADS);
-    switch (a.g) {
-        case 1: hipLaunchKernelGGL(ext_inner_xy_kernel<1>, grid, blk, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(ext_inner_xy_kernel<2>, grid, blk, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(ext_inner_xy_kernel<3>, grid, blk, 0, st, a); break;
-        default: hipLaunchKernelGGL(ext_inner_xy_kernel<4>, grid, blk, 0, st, a); break;
+    if (a.e_out) switch (a.g) {
+        case 1: hipLaunchKernelGGL((ext_inner_xy_kernel<1, true>), grid, blk, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((ext_inner_xy_kernel<2, true>), grid, blk, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((ext_inner_xy_kernel<3, true>), grid, blk, 0, st, a); break;
+        default: hipLaunchKernelGGL((ext_inner_xy_kernel<4, true>), grid, blk, 0, st, a); break;
+    } else switch (a.g) {
+        case 1: hipLaunchKernelGGL((ext_inner_xy_kernel<1, false>), grid, blk, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((ext_inner_xy_kernel<2, false>), grid, blk, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((ext_inner_xy_kernel<3, false>), grid, blk, 0, st, a); break;
+        default: hipLaunchKernelGGL((ext_inner_xy_kernel<4, false>), grid, blk, 0, st, a); break;
     }
 }
 typedef const __attribute__((address_space(4))) ExtXyBatchArgs* xyb_kargs;
