@@ -156,8 +156,8 @@ Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per 
 |---|---|---|---|---|---|
 {table(pl, True)}
 
-Whole step: the kernels with a PMC column ({100 * cov:.0f} % of the kernel time) move **{tot_bytes / 1e9:.2f} GB per MulRelin** through HBM (round 3: 2.76, round 2: 3.40 GB) = {tot_bytes / 1e9 / pl["ms_per_step"]:.2f} TB/s averaged over the {pl["ms_per_step"]:.3f} ms step.  The three streaming launches
-are at their compulsory bytes (y: 528 MB, F1 + x: 587 MB, E / F2: 822 MB).
+Whole step: the kernels with a PMC column ({100 * cov:.0f} % of the kernel time) move **{tot_bytes / 1e9:.2f} GB per MulRelin** through HBM (round 3: 2.76, round 2: 3.40 GB) = {tot_bytes / 1e9 / pl["ms_per_step"]:.2f} TB/s averaged over the {pl["ms_per_step"]:.3f} ms step.  Round 4 removed a launch and three passes from it (below): the two streaming launches left
+read every key once (b, d: 470 MB; v, u: 294 MB) and every hoisted digit once (h(c0), h(c1): 470 MB; h(t): 235 MB) — the compulsory bytes of the algorithm.
 
 ### Dominant kernel: the Decompose-fused forward NTT — `{DOM}` in this set (DESIGN.md §3 "Round 3", §4)
 
@@ -199,7 +199,12 @@ One 1024-thread workgroup per CU holds a whole limb (32 coefficients per thread)
 
 ### Streaming kernels
 
-`inner_product_kernel<4>` {R["kernels"]["inner_product_kernel"]["avg_launch_us"]:.0f} µs per launch, `ext_inner_kernel` {R["kernels"]["ext_inner_kernel"]["avg_launch_us"]:.0f} µs (two launches: F1 + x, and the E / F2 batch): 16-byte lanes, non-temporal loads for every operand read once per launch, items that share a key computed by one thread.
+**Round 4: y and step E inside the F1 kernel.**  Rounds 1–3 ran the 4-party MulAndRelin's linear algebra as three streaming launches: y = Σ_j b_j ⊙ h(c1_j) (`inner_product_kernel`: 528 MB), F1 + x (the t_i = ⟨h(c0_i), y⟩ and, as a by-product,
+x = Σ_i d_i ⊙ h(c0_i): 587 MB), and the E / F2 batch (⟨h(c1_j), x⟩, ⟨h(t_i), v_i⟩, ⟨h(t_i), u⟩: 822 MB).  All of it is pointwise in the coefficient: the thread that forms the F1 products at a coefficient needs y there and nowhere else, and once it holds x[d] and
+h(c1_j)[d] (which it loaded for y) step E costs it G more accumulators.  `ext_inner_xy_kernel<G, E>` (op1 with as many parties as op0, at most four; single device) reads the four operand families once — h(c0), d, h(c1), b: 16 sixteen-byte loads per digit and thread — and
+writes the t_i and the E products; y and x are never stored, the h(c1_j) are not read a second time, and the tail batch finds its E items precomputed in its c1 slots (`ExtItem::pre`).  Same operations on the same values: the same integers (the whole GPU suite,
+`MKHE_FUSE_Y=0` / `MKHE_FUSE_E=0` are the switches).  Same call: 1203–1213 → 1231–1238 MulRelin/s with y inside, → **1308–1318** with step E inside as well; `ext_inner_kernel` here: two launches of {R["kernels"]["ext_inner_kernel"]["avg_launch_us"]:.0f} µs on average.
+The batched entry (`ext_inner_xy_batch_kernel`, B inputs) computes x_b and y_b in the thread; step E there is still a tail item.
 Their algorithmic GB/s equal their PMC GB/s (the byte model charges every distinct operand once): ≈ 5.8 TB/s = 0.73 of the 8 TB/s spec.  `{tag}_ubench.txt` (`read_bw`, round 4) measures what a kernel that ONLY reads reaches on the same box: {rds[0]:.0f}–{rds[1]:.0f} GB/s in the pattern of these kernels (14–70 concurrent streams 4 MB apart, 16 bytes per lane), {rdc[0]:.0f}–{rdc[1]:.0f} GB/s with one contiguous region per workgroup (another box of the round: 5464–5875 and 6003–6075) — the streaming kernels are within 0–10 % of the read ceiling of their access pattern, not 27 % under a roofline; the contiguous pattern (digit-major tiles instead of [digit][modulus][N]) would be a re-layout of every hoisted form and key.  The ModDown launches and the small inverse NTTs are
 launch-latency-bound; the Rescale no longer appears: it rides on the merged ModDown's store (`mkhe_mul_relin_rescale`, DESIGN.md §4 "Fused Rescale").
 
