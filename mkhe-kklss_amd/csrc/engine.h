@@ -86,7 +86,7 @@ class Context {
     void bfv_external_product(const u64* polyr, const u64* bg1, const u64* bg2, u64* c);
     void bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
                         const Swk* const* rlk_d1, const Swk* const* rlk_d2, bool with_c0, bool mform, Ct& out,
-                        u64* x1, u64* x2, u64* y1, u64* y2, bool fuse_x = false);
+                        u64* x1, u64* x2, u64* y1, u64* y2, bool fuse_x = false, bool fuse_y = false);
     void bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u64* x2, const u64* y1, const u64* y2,
                        const Swk* const* rlk_v, const Swk& crs_u, Ct& out);
     void bfv_slots(const Ct& op0, const Ct& op1, const Ct& out, std::vector<int>& slot0, std::vector<int>& slot1) const;
@@ -146,6 +146,8 @@ class Context {
                                                          // batch): ext_yh_ holds every input's digits in turn, ext_ykeys_.size() per input
     std::vector<std::pair<const u64*, u64*>> ext_xmap_;   // batch.hip: (shared key y_b, x_b) per input around the F1 call of a batch: one x per group
     std::vector<const u64*> bfv_xk1_, bfv_xk2_;   // mkbfv single-device MulRelinNew: d1_i, d2_i for the fused x1, x2
+    std::vector<const u64*> bfv_yk1_, bfv_yk2_;   // ... and b1_j, b2_j when y1, y2 (and step E) are computed inside the F1 kernel too
+    std::vector<const u64*> ext_ykeys2_, ext_yh2_;  // second gadget of ext_ykeys_ / ext_yh_
     // External products that ModDown adds into ONE destination are merged (ModDown is linear in the Q part, see NttBatch::vi and
     // ModDownMergedArgs): virtual item v = up to VI_MAX items of the batch with the same destination; their Q limbs are summed in the
     // NTT domain at the load of ONE inverse NTT, their P limbs are transformed and lifted one by one.  MKHE_EXT_MERGE=0 switches it off.

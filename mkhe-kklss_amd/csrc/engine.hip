@@ -978,7 +978,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     if ((ext_xout_ || ext_xout2_) && !xby) throw Error("mkhe: internal: x by-product requested for a batch that cannot carry it");
     ia.xout = xby ? ext_xout_ : nullptr; ia.xout2 = xby && xby2 ? ext_xout2_ : nullptr; ia.xmform = 1;
     const bool xy = !ext_ykeys_.empty() && ext_xmap_.empty(), xyb = !ext_ykeys_.empty() && !ext_xmap_.empty();
-    if (xy && (!xby || xby2 || mp || n > 4 || (int)ext_ykeys_.size() != n || (int)ext_yh_.size() != n)) throw Error("mkhe: internal: y inside a launch that cannot compute it");
+    if (xy && (!xby || mp || n > 4 || (int)ext_ykeys_.size() != n || (int)ext_yh_.size() != n || (xby2 && ((int)ext_ykeys2_.size() != n || (int)ext_yh2_.size() != n)))) throw Error("mkhe: internal: y inside a launch that cannot compute it");
     int xgroups = 0;
     if (!ext_xmap_.empty()) {
         // B inputs' step F1 in one launch (mul_relin_batch): the items that share y_b are input b's, at most four, and carry x_b
@@ -1022,6 +1022,8 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
       if (xy) {
           ExtXyArgs xa{};
           for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
+          if (xby2) for (int j = 0; j < n; ++j) { xa.ah2[j] = it[j].ah2; xa.xkey2[j] = it[j].xkey2; xa.ykey2[j] = ext_ykeys2_[j]; xa.yh2[j] = ext_yh2_[j]; }
+          xa.xout2 = (xby2 && ext_e_slot_ < 0) ? ext_xout2_ : nullptr;
           xa.xout = ext_e_slot_ >= 0 ? nullptr : ext_xout_; xa.e_out = ext_e_slot_ >= 0 ? c1 + (size_t)ext_e_slot_ * item_words : nullptr; xa.c1 = c1; xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;
           xa.g = n; xa.nb = nb; xa.nslots = nslots; xa.N = N;
           launch_ext_inner_xy(xa, s_);
@@ -1821,10 +1823,10 @@ void Context::bfv_slots(const Ct& op0, const Ct& op1, const Ct& out, std::vector
 
 void Context::bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
                              const Swk* const* rlk_d1, const Swk* const* rlk_d2, bool with_c0, bool mform, Ct& out,
-                             u64* x1, u64* x2, u64* y1, u64* y2, bool fuse_x) {
+                             u64* x1, u64* x2, u64* y1, u64* y2, bool fuse_x, bool fuse_y) {
     if (!is_bfv()) throw Error("mkhe: not a BFV context");
     const int level = nq - 1, L = nq, n0 = op0.n, n1 = op1.n;
-    bfv_xk1_.clear(); bfv_xk2_.clear();
+    bfv_xk1_.clear(); bfv_xk2_.clear(); bfv_yk1_.clear(); bfv_yk2_.clear();
     std::vector<int> slot0, slot1;
     bfv_slots(op0, op1, out, slot0, slot1);
     for (int a = 0; a < n0; ++a) if (!rlk_d1[a] || !rlk_d2[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
@@ -1880,7 +1882,12 @@ void Context::bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk
         if (!mform) throw Error("mkhe: internal: the fused x is produced in Montgomery form");
         for (int a = 0; a < n0; ++a) { bfv_xk1_.push_back(rlk_d1[a]->d); bfv_xk2_.push_back(rlk_d2[a]->d); }
     }
-    for (int which = 3; which >= (fuse_x ? 2 : 0); --which) {
+    // ... and y1, y2 (and step E) inside it as well, when op1 has as many parties (Context::mul_and_relin, round 4)
+    if (fuse_y) {
+        if (!fuse_x || n1 != n0 || n0 > 4) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and as many parties in op1 as in op0");
+        for (int a = 0; a < n1; ++a) { bfv_yk1_.push_back(rlk_b1[a]->d); bfv_yk2_.push_back(rlk_b2[a]->d); }
+    }
+    for (int which = fuse_y ? 1 : 3; which >= (fuse_x ? 2 : 0); --which) {
         const int side = which >> 1, half = which & 1;
         const int n = side ? n1 : n0;
         InnerProductArgs ip{};
@@ -1924,9 +1931,21 @@ void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u
         items.push_back(it);
     }
     if (fused) { ext_xout_ = const_cast<u64*>(x1); ext_xout2_ = const_cast<u64*>(x2); }
-    try { ext_batch(level, items); } catch (...) { ext_xout_ = ext_xout2_ = nullptr; throw; }
-    ext_xout_ = ext_xout2_ = nullptr;
-    bfv_xk1_.clear(); bfv_xk2_.clear();
+    bool e_done = false;
+    if (fused && !bfv_yk1_.empty()) {
+        ext_ykeys_ = bfv_yk1_; ext_ykeys2_ = bfv_yk2_;
+        for (int a = 0; a < n1; ++a) { ext_yh_.push_back(hoist_slot(1, a).d); ext_yh2_.push_back(hoist_slot(4, a).d); }
+        static const int fuse_e_env = getenv("MKHE_FUSE_E") ? atoi(getenv("MKHE_FUSE_E")) : 1;
+        if (fuse_e_env && 2 * n0 + n1 <= EXT_MAX_ITEMS) {
+            scratch(c1b_, c1b_words_, (size_t)(2 * n0 + n1) * mtot * N);
+            ext_e_slot_ = 2 * n0;
+        }
+    }
+    auto clear_xy = [&] { ext_xout_ = ext_xout2_ = nullptr; ext_ykeys_.clear(); ext_ykeys2_.clear(); ext_yh_.clear(); ext_yh2_.clear(); ext_e_slot_ = -1; };
+    try { ext_batch(level, items); } catch (...) { clear_xy(); throw; }
+    e_done = ext_e_slot_ >= 0;
+    clear_xy();
+    bfv_xk1_.clear(); bfv_xk2_.clear(); bfv_yk1_.clear(); bfv_yk2_.clear();
     // F2: ks.Decompose(t_i) ; out_0 += <h(t_i), v_i> ; out_i += <h(t_i), u>
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
@@ -1941,7 +1960,7 @@ void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u
         items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true});
     }
     for (int a = 0; a < n1; ++a) {
-        ExtItem it{hoist_slot(1, a).d, x1, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = hoist_slot(4, a).d; it.bg2 = x2; items.push_back(it);
+        ExtItem it{hoist_slot(1, a).d, x1, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = hoist_slot(4, a).d; it.bg2 = x2; it.pre = e_done; items.push_back(it);
     }
     join_side(2);
     ext_batch(level, items, 1);        // joins the tensor / Quantize chain before the ModDown accumulates into out
@@ -1955,7 +1974,9 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
     for (int a = 0; a < op0.n; ++a) if (!rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
     static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
     const bool fuse = fuse_env && op0.n >= 1 && op0.n <= 4 && !masked_;
-    bfv_mr_partial(op0, op1, rlk_b1, rlk_b2, rlk_d1, rlk_d2, true, true, out, x_, x2_, y_, y2_, fuse);
+    static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
+    const bool fuse_y = fuse && fuse_y_env && op1.n == op0.n;
+    bfv_mr_partial(op0, op1, rlk_b1, rlk_b2, rlk_d1, rlk_d2, true, true, out, x_, x2_, y_, y2_, fuse, fuse_y);
     bfv_mr_finish(op0, op1, x_, x2_, y_, y2_, rlk_v, crs_u, out);
 }
 

@@ -104,7 +104,9 @@ void launch_ext_inner(const ExtInnerArgs& a, hipStream_t st);
 // ykey[j] (.) yh[j]) for the product (c1 item g) and xkey[g] = d_g for x (xout, MForm'd).  ykey = the b_j, yh = the h(c1_j), g of each.
 struct ExtXyArgs {
     const u64* ah[4]; const u64* xkey[4]; const u64* ykey[4]; const u64* yh[4];
+    const u64* ah2[4]; const u64* xkey2[4]; const u64* ykey2[4]; const u64* yh2[4];      // second gadget (mkbfv: the QMul digits and keys) or ah2[0] = NULL
     u64* xout;               // x[d] stored (NULL: not needed, see e_out)
+    u64* xout2;              // ... of the second gadget
     u64* e_out;              // non-NULL: step E as well -- <h(c1_j), x> for the g parties of op1, from the x[d] and h(c1_j)[d] the thread holds: g more
                              // products [mtot][N] at e_out + j * c1_item (the c1 slots of the E items of the tail batch), and neither x nor a second
                              // pass over the h(c1_j) exists

@@ -474,26 +474,19 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xwide_kernel(ExtInnerArg
 // y = MForm(sum_j b_j (.) h(c1_j)) in ONE pass -- the thread that forms the products at a coefficient needs y there and nowhere else, so y is neither
 // a launch of its own nor written and read back (2 x 59 MB at PN15QP880).  Per digit and thread: 4 G sixteen-byte loads, y[d] in registers, x[d]
 // stored.  Same operations as inner_product_kernel (mform_out) + ext_group_singles<G> with the x by-product: the same integers.
+// one gadget's pass of ext_inner_xy_kernel: per digit y[d], x[d], the F1 products and (E) the step-E products
 template <int G, bool E>
-__global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_kernel(ExtXyArgs a) {
-    const int s = blockIdx.y;
-    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
-    if (n >= a.N) return;
-    const int m = a.map[s];
-    const Mod md = a.mods[m];
+__device__ __forceinline__ void xy_gadget(const u64* const (&ah)[4], const u64* const (&xkey)[4], const u64* const (&ykey)[4], const u64* const (&yh)[4], u64* xout,
+                                          u64 (&acc)[G][2], u64 (&ace)[E ? G : 1][2], const long off, const long ds, const int nb, const Mod& md) {
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
-    const long off = (long)m * a.N + n, ds = a.digit_stride;
-    u64 acc[G][2], ace[E ? G : 1][2];
-#pragma unroll
-    for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; if (E) { ace[g][0] = 0; ace[g][1] = 0; } }
 #pragma unroll 1
-    for (int i = 0; i < a.nb; ++i) {
+    for (int i = 0; i < nb; ++i) {
         u64x2 h[G], k[G], b[G], c[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            b[g] = ld_stream(a.ykey[g] + off + i * ds); c[g] = ld_stream(a.yh[g] + off + i * ds);
-            h[g] = ld_stream(a.ah[g] + off + i * ds); k[g] = ld_stream(a.xkey[g] + off + i * ds);
+            b[g] = ld_stream(ykey[g] + off + i * ds); c[g] = ld_stream(yh[g] + off + i * ds);
+            h[g] = ld_stream(ah[g] + off + i * ds); k[g] = ld_stream(xkey[g] + off + i * ds);
         }
         u64 y0 = 0, y1 = 0;
 #pragma unroll
@@ -519,12 +512,27 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_kernel(ExtXyArgs a) {
                 ace[g][1] = csub(ace[g][1] + mont_mul_lazy(x1, c[g].y, q, ninv), q2);
             }
         }
-        if (a.xout) { u64x2 r; r.x = x0; r.y = x1; *(u64x2*)(a.xout + off + i * ds) = r; }
+        if (xout) { u64x2 r; r.x = x0; r.y = x1; *(u64x2*)(xout + off + i * ds) = r; }
     }
+}
+template <int G, bool E>
+__global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_kernel(ExtXyArgs a) {
+    const int s = blockIdx.y;
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
+    if (n >= a.N) return;
+    const int m = a.map[s];
+    const Mod md = a.mods[m];
+    const long off = (long)m * a.N + n;
+    u64 acc[G][2], ace[E ? G : 1][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; if (E) { ace[g][0] = 0; ace[g][1] = 0; } }
+    xy_gadget<G, E>(a.ah, a.xkey, a.ykey, a.yh, a.xout, acc, ace, off, a.digit_stride, a.nb, md);
+    // mkbfv: the second gadget (QMul digits h2, keys d2 / b2, sums x2 / y2) adds its products to the same sums (keyswitch_hoisted.go:20-28)
+    if (a.ah2[0]) xy_gadget<G, E>(a.ah2, a.xkey2, a.ykey2, a.yh2, a.xout2, acc, ace, off, a.digit_stride, a.nb, md);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        ext_store(a.c1 + (long)g * a.c1_item + off, acc[g][0], acc[g][1], q);
-        if constexpr (E) ext_store(a.e_out + (long)g * a.c1_item + off, ace[g][0], ace[g][1], q);
+        ext_store(a.c1 + (long)g * a.c1_item + off, acc[g][0], acc[g][1], md.q);
+        if constexpr (E) ext_store(a.e_out + (long)g * a.c1_item + off, ace[g][0], ace[g][1], md.q);
     }
 }
 void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st) {
