@@ -978,7 +978,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     if ((ext_xout_ || ext_xout2_) && !xby) throw Error("mkhe: internal: x by-product requested for a batch that cannot carry it");
     ia.xout = xby ? ext_xout_ : nullptr; ia.xout2 = xby && xby2 ? ext_xout2_ : nullptr; ia.xmform = 1;
     const bool xy = !ext_ykeys_.empty() && ext_xmap_.empty(), xyb = !ext_ykeys_.empty() && !ext_xmap_.empty();
-    if (xy && (!xby || mp || n > 4 || (int)ext_ykeys_.size() != n || (int)ext_yh_.size() != n || (xby2 && ((int)ext_ykeys2_.size() != n || (int)ext_yh2_.size() != n)))) throw Error("mkhe: internal: y inside a launch that cannot compute it");
+    if (xy && (!xby || mp || n > (xby2 ? 4 : 8) || (int)ext_ykeys_.size() != n || (int)ext_yh_.size() != n || (xby2 && ((int)ext_ykeys2_.size() != n || (int)ext_yh2_.size() != n)))) throw Error("mkhe: internal: y inside a launch that cannot compute it");
     int xgroups = 0;
     if (!ext_xmap_.empty()) {
         // B inputs' step F1 in one launch (mul_relin_batch): the items that share y_b are input b's, at most four, and carry x_b
@@ -1019,7 +1019,14 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         distinct = ns;
     }
     { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * n - 1.0) : 0.0) + (xyb ? nb * (1.0 * n + ext_ykeys_.size() - xgroups) : 0.0)));
-      if (xy) {
+      if (xy && n > 4) {
+          ExtXyWideArgs xa{};
+          for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
+          xa.xout = ext_e_slot_ >= 0 ? nullptr : ext_xout_; xa.e_out = ext_e_slot_ >= 0 ? c1 + (size_t)ext_e_slot_ * item_words : nullptr; xa.c1 = c1;
+          xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;
+          xa.g = n; xa.nb = nb; xa.nslots = nslots; xa.N = N;
+          launch_ext_inner_xy_wide(xa, s_);
+      } else if (xy) {
           ExtXyArgs xa{};
           for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
           if (xby2) for (int j = 0; j < n; ++j) { xa.ah2[j] = it[j].ah2; xa.xkey2[j] = it[j].xkey2; xa.ykey2[j] = ext_ykeys2_[j]; xa.yh2[j] = ext_yh2_[j]; }
@@ -1162,7 +1169,7 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
     // y inside the F1 kernel as well (round 4): the thread that forms <h(c0_i), y> at a coefficient needs y there and nowhere else, so that y is
     // neither a launch nor 2 x 59 MB of traffic -- when op1 has as many parties as op0 (at most four: the group form of the kernel)
     static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
-    const bool fuse_y = fuse && fuse_y_env && plan_.n0 <= 4 && plan_.n1 == plan_.n0;
+    const bool fuse_y = fuse && fuse_y_env && plan_.n0 <= 8 && plan_.n1 == plan_.n0;      // (five to eight: ext_inner_xy_wide_kernel)
     mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse, fuse_y);
     mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
 }
@@ -1310,7 +1317,7 @@ void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, 
     }
     p.ykeys.clear();
     if (fuse_y) {
-        if (!fuse_x || p.n1 != p.n0 || p.n0 > 4) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and as many parties in op1 as in op0");
+        if (!fuse_x || p.n1 != p.n0 || p.n0 > 8) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and as many parties in op1 as in op0");
         for (int a = 0; a < p.n1; ++a) {
             if (!rlk_b1[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
             p.ykeys.push_back(rlk_b1[a]->d);

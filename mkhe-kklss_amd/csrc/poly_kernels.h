@@ -117,6 +117,18 @@ struct ExtXyArgs {
     int g, nb, nslots, N;
 };
 void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st);
+// ... for five to eight parties per operand (ext_inner_xy_wide_kernel<G, E>: the loads of a digit in chunks of four)
+struct ExtXyWideArgs {
+    const u64* ah[8]; const u64* xkey[8]; const u64* ykey[8]; const u64* yh[8];
+    u64* xout;               // NULL with e_out
+    u64* e_out;
+    u64* c1;
+    const Mod* mods;
+    const int* map;
+    long digit_stride, c1_item;
+    int g, nb, nslots, N;
+};
+void launch_ext_inner_xy_wide(const ExtXyWideArgs& a, hipStream_t st);
 // ... and for B inputs in lock step (mul_relin_batch): input b's digits ah[b][g] / yh[b][g] meet the shared keys; its x goes to xout[b], its products
 // to the c1 items b * g .. b * g + g - 1 of the launch
 constexpr int XYB_MAX = 16;

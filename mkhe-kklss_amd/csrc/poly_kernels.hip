@@ -551,6 +551,80 @@ void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st) {
         default: hipLaunchKernelGGL((ext_inner_xy_kernel<4, false>), grid, blk, 0, st, a); break;
     }
 }
+// Five to eight parties per operand (PN16QP1761 with 8 parties: y was a 0.95 ms inner_product_kernel<8> launch, step E a second read of 8 x 331 MB of
+// digits): the same pass with the 4 G loads of a digit taken four at a time -- the h(c1_j)[d] stay in registers for step E (8 x 4 VGPRs), the keys
+// and the h(c0_i)[d] pass through.
+typedef const __attribute__((address_space(4))) ExtXyWideArgs* xyw_kargs;
+template <int G, bool E>
+__global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_wide_kernel(ExtXyWideArgs a) {
+    xyw_kargs ka = (xyw_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int s = blockIdx.y;
+    const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
+    if (n >= a.N) return;
+    const int m = a.map[s];
+    const Mod md = a.mods[m];
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const long off = (long)m * a.N + n, ds = a.digit_stride;
+    u64 acc[G][2], ace[E ? G : 1][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; if (E) { ace[g][0] = 0; ace[g][1] = 0; } }
+#pragma unroll 1
+    for (int i = 0; i < a.nb; ++i) {
+        const long o = off + i * ds;
+        u64x2 c[G];
+        u64 y0 = 0, y1 = 0;
+#pragma unroll
+        for (int g0 = 0; g0 < G; g0 += 4) {
+            u64x2 b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (g0 + j < G) { b[j] = ld_stream(ka->ykey[g0 + j] + o); c[g0 + j] = ld_stream(ka->yh[g0 + j] + o); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (g0 + j < G) {
+                y0 = csub(y0 + mont_mul_lazy(b[j].x, c[g0 + j].x, q, ninv), q2);
+                y1 = csub(y1 + mont_mul_lazy(b[j].y, c[g0 + j].y, q, ninv), q2);
+            }
+        }
+        y0 = mont_mul(csub(y0, q), md.r2, q, ninv); y1 = mont_mul(csub(y1, q), md.r2, q, ninv);
+        u64 x0 = 0, x1 = 0;
+#pragma unroll
+        for (int g0 = 0; g0 < G; g0 += 4) {
+            u64x2 h[4], k[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (g0 + j < G) { h[j] = ld_stream(ka->ah[g0 + j] + o); k[j] = ld_stream(ka->xkey[g0 + j] + o); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (g0 + j < G) {
+                acc[g0 + j][0] = csub(acc[g0 + j][0] + mont_mul_lazy(y0, h[j].x, q, ninv), q2);
+                acc[g0 + j][1] = csub(acc[g0 + j][1] + mont_mul_lazy(y1, h[j].y, q, ninv), q2);
+                x0 = csub(x0 + mont_mul_lazy(k[j].x, h[j].x, q, ninv), q2);
+                x1 = csub(x1 + mont_mul_lazy(k[j].y, h[j].y, q, ninv), q2);
+            }
+        }
+        x0 = mont_mul(csub(x0, q), md.r2, q, ninv); x1 = mont_mul(csub(x1, q), md.r2, q, ninv);
+        if constexpr (E) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                ace[g][0] = csub(ace[g][0] + mont_mul_lazy(x0, c[g].x, q, ninv), q2);
+                ace[g][1] = csub(ace[g][1] + mont_mul_lazy(x1, c[g].y, q, ninv), q2);
+            }
+        }
+        if (a.xout) { u64x2 r; r.x = x0; r.y = x1; *(u64x2*)(a.xout + o) = r; }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        ext_store(a.c1 + (long)g * a.c1_item + off, acc[g][0], acc[g][1], q);
+        if constexpr (E) ext_store(a.e_out + (long)g * a.c1_item + off, ace[g][0], ace[g][1], q);
+    }
+}
+void launch_ext_inner_xy_wide(const ExtXyWideArgs& a, hipStream_t st) {
+    if (a.g < 5 || a.g > 8) throw std::runtime_error("mkhe: internal: ext_inner_xy_wide_kernel takes five to eight parties");
+    const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
+    const dim3 grid(bx, a.nslots, 1), blk(PW_THREADS);
+#define MKHE_XYW(GV) do { if (a.e_out) hipLaunchKernelGGL((ext_inner_xy_wide_kernel<GV, true>), grid, blk, 0, st, a); \
+                          else hipLaunchKernelGGL((ext_inner_xy_wide_kernel<GV, false>), grid, blk, 0, st, a); } while (0)
+    switch (a.g) { case 5: MKHE_XYW(5); break; case 6: MKHE_XYW(6); break; case 7: MKHE_XYW(7); break; default: MKHE_XYW(8); break; }
+#undef MKHE_XYW
+}
 typedef const __attribute__((address_space(4))) ExtXyBatchArgs* xyb_kargs;
 template <int G>
 __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_batch_kernel(ExtXyBatchArgs a) {

@@ -139,6 +139,10 @@ CASES = [
     (["p0", "p1", "p2", "p3"], ["p0", "p1", "p2", "p3"], 0, 0, True),
     (["p0", "p1", "p2"], ["p1", "p2", "p3"], 1, 0, True),
     (["p0", "p1", "p2", "p3"], ["p4", "p5", "p6", "p7"], 0, 0, False),
+    # ... and five to eight parties per operand (ext_inner_xy_wide_kernel<5..8>; six equal parties is a case above)
+    (["p%d" % i for i in range(5)], ["p%d" % i for i in range(3, 8)], 0, 0, False),
+    (["p%d" % i for i in range(7)], ["p%d" % i for i in range(7)], 1, 0, True),
+    (["p%d" % i for i in range(8)], ["p%d" % i for i in range(8)], 0, 0, False),
 ]
 
 
