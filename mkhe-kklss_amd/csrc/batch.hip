@@ -137,7 +137,7 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
     const bool fuse_x = fuse_env && n0 >= 1 && n0 <= 4;      // x_b = sum_i d_i (.) h(c0_{b,i}) as a by-product of input b's step F1
     static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
-    const bool fuse_y = fuse_x && fuse_y_env && n1 == n0;    // ... and y_b computed in the same threads (ext_inner_xy_batch_kernel), never stored
+    const bool fuse_y = fuse_x && fuse_y_env && n1 >= 1 && n1 <= 4;    // ... and y_b computed in the same threads (ext_inner_xy_batch_kernel<G0, G1>), never stored
     const size_t per_b = (size_t)(2 + n0 + n1) * PO + (size_t)(1 + nout) * PO * ((fold ? 1 : 0) + (rescale_out ? 1 : 0)) + 2 * SW + (size_t)n0 * PO + (size_t)n0 * SW +
                          (own0 ? (size_t)n0 * SW : 0) + (own1 ? (size_t)n1 * SW : 0);
     Arena ar(this, B * per_b);
@@ -259,8 +259,8 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
                 for (int a = 0; a < n0; ++a) {
                     items.push_back(ExtItem{h0[b * n0 + a], y[b], tbuf[b] + (size_t)a * PO, false});
                     if (fuse_x) items.back().xkey = rlk_d0[a]->d;
-                    if (fuse_y) ext_yh_.push_back(h1[b * n1 + a]);
                 }
+                if (fuse_y) for (int a = 0; a < n1; ++a) ext_yh_.push_back(h1[b * n1 + a]);
                 if (fuse_x) ext_xmap_.push_back({y[b], x[b]});
             }
             if (fuse_y) for (int a = 0; a < n1; ++a) ext_ykeys_.push_back(rlk_b1[a]->d);

@@ -978,7 +978,9 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     if ((ext_xout_ || ext_xout2_) && !xby) throw Error("mkhe: internal: x by-product requested for a batch that cannot carry it");
     ia.xout = xby ? ext_xout_ : nullptr; ia.xout2 = xby && xby2 ? ext_xout2_ : nullptr; ia.xmform = 1;
     const bool xy = !ext_ykeys_.empty() && ext_xmap_.empty(), xyb = !ext_ykeys_.empty() && !ext_xmap_.empty();
-    if (xy && (!xby || mp || n > (xby2 ? 4 : 8) || (int)ext_ykeys_.size() != n || (int)ext_yh_.size() != n || (xby2 && ((int)ext_ykeys2_.size() != n || (int)ext_yh2_.size() != n)))) throw Error("mkhe: internal: y inside a launch that cannot compute it");
+    const int ny = (int)ext_ykeys_.size();
+    if (xy && (!xby || mp || n > (xby2 ? 4 : 8) || (n > 4 && ny != n) || ny < 1 || ny > 8 || (n <= 4 && ny > 4) || (int)ext_yh_.size() != ny ||
+               (xby2 && ((int)ext_ykeys2_.size() != ny || (int)ext_yh2_.size() != ny)))) throw Error("mkhe: internal: y inside a launch that cannot compute it");
     int xgroups = 0;
     if (!ext_xmap_.empty()) {
         // B inputs' step F1 in one launch (mul_relin_batch): the items that share y_b are input b's, at most four, and carry x_b
@@ -1018,7 +1020,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         for (int i = 0; i < n; ++i) if (!it[i].pre) { add(ia.ah[i]); add(ia.bg[i]); add(ia.ah2[i]); add(ia.bg2[i]); }
         distinct = ns;
     }
-    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * n - 1.0) : 0.0) + (xyb ? nb * (1.0 * n + ext_ykeys_.size() - xgroups) : 0.0)));
+    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * ny - 1.0) : 0.0) + (xyb ? nb * (1.0 * n + ext_ykeys_.size() - xgroups) : 0.0)));
       if (xy && n > 4) {
           ExtXyWideArgs xa{};
           for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
@@ -1028,16 +1030,17 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
           launch_ext_inner_xy_wide(xa, s_);
       } else if (xy) {
           ExtXyArgs xa{};
-          for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
-          if (xby2) for (int j = 0; j < n; ++j) { xa.ah2[j] = it[j].ah2; xa.xkey2[j] = it[j].xkey2; xa.ykey2[j] = ext_ykeys2_[j]; xa.yh2[j] = ext_yh2_[j]; }
+          for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; }
+          for (int j = 0; j < ny; ++j) { xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
+          if (xby2) { for (int j = 0; j < n; ++j) { xa.ah2[j] = it[j].ah2; xa.xkey2[j] = it[j].xkey2; } for (int j = 0; j < ny; ++j) { xa.ykey2[j] = ext_ykeys2_[j]; xa.yh2[j] = ext_yh2_[j]; } }
           xa.xout2 = (xby2 && ext_e_slot_ < 0) ? ext_xout2_ : nullptr;
           xa.xout = ext_e_slot_ >= 0 ? nullptr : ext_xout_; xa.e_out = ext_e_slot_ >= 0 ? c1 + (size_t)ext_e_slot_ * item_words : nullptr; xa.c1 = c1; xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;
-          xa.g = n; xa.nb = nb; xa.nslots = nslots; xa.N = N;
+          xa.g = n; xa.g1 = ny; xa.nb = nb; xa.nslots = nslots; xa.N = N;
           launch_ext_inner_xy(xa, s_);
       } else if (xyb) {
           // B inputs' step F1 with x_b and y_b in the thread: the items come input by input (g per input, mul_relin_batch), up to XYB_MAX inputs per launch
-          const int g = (int)ext_ykeys_.size(), nin = n / g;
-          if (two || mp || g < 1 || g > 4 || nin * g != n || (int)ext_yh_.size() != n || (int)ext_xmap_.size() != nin) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
+          const int nin = (int)ext_xmap_.size(), g = nin ? n / nin : 0, g1 = (int)ext_ykeys_.size();
+          if (two || mp || g < 1 || g > 4 || g1 < 1 || g1 > 4 || nin * g != n || (int)ext_yh_.size() != nin * g1) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
           for (int b0 = 0; b0 < nin; b0 += XYB_MAX) {
               ExtXyBatchArgs xa{};
               const int cnt = std::min(XYB_MAX, nin - b0);
@@ -1045,14 +1048,15 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
                   for (int j = 0; j < g; ++j) {
                       const ExtItem& e = it[(b0 + b) * g + j];
                       if (e.bg != ext_xmap_[b0 + b].first || !e.xkey) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
-                      xa.ah[b][j] = e.ah; xa.yh[b][j] = ext_yh_[(b0 + b) * g + j];
-                      if (b == 0) { xa.xkey[j] = e.xkey; xa.ykey[j] = ext_ykeys_[j]; }
-                      else if (e.xkey != xa.xkey[j]) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
+                      xa.ah[b][j] = e.ah;
+                      if (b == 0) xa.xkey[j] = e.xkey; else if (e.xkey != xa.xkey[j]) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
                   }
+                  for (int j = 0; j < g1; ++j) xa.yh[b][j] = ext_yh_[(b0 + b) * g1 + j];
                   xa.xout[b] = ext_xmap_[b0 + b].second;
               }
+              for (int j = 0; j < g1; ++j) xa.ykey[j] = ext_ykeys_[j];
               xa.c1 = c1 + (size_t)b0 * g * item_words; xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;
-              xa.g = g; xa.nbatch = cnt; xa.nb = nb; xa.nslots = nslots; xa.N = N;
+              xa.g = g; xa.g1 = g1; xa.nbatch = cnt; xa.nb = nb; xa.nslots = nslots; xa.N = N;
               launch_ext_inner_xy_batch(xa, s_);
           }
       } else launch_ext_inner(ia, s_); }
@@ -1169,7 +1173,7 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
     // y inside the F1 kernel as well (round 4): the thread that forms <h(c0_i), y> at a coefficient needs y there and nowhere else, so that y is
     // neither a launch nor 2 x 59 MB of traffic -- when op1 has as many parties as op0 (at most four: the group form of the kernel)
     static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
-    const bool fuse_y = fuse && fuse_y_env && plan_.n0 <= 8 && plan_.n1 == plan_.n0;      // (five to eight: ext_inner_xy_wide_kernel)
+    const bool fuse_y = fuse && fuse_y_env && plan_.n1 >= 1 && (plan_.n0 <= 4 ? plan_.n1 <= 4 : (plan_.n0 <= 8 && plan_.n1 == plan_.n0));      // (one to four parties per operand: ext_inner_xy_kernel<G0, G1>; five to eight in both: ext_inner_xy_wide_kernel)
     mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse, fuse_y);
     mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
 }
@@ -1317,7 +1321,7 @@ void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, 
     }
     p.ykeys.clear();
     if (fuse_y) {
-        if (!fuse_x || p.n1 != p.n0 || p.n0 > 8) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and as many parties in op1 as in op0");
+        if (!fuse_x || p.n1 < 1 || p.n0 > 8 || (p.n0 > 4 ? p.n1 != p.n0 : p.n1 > 4)) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and one to four parties per operand (or five to eight in both)");
         for (int a = 0; a < p.n1; ++a) {
             if (!rlk_b1[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
             p.ykeys.push_back(rlk_b1[a]->d);
@@ -1891,7 +1895,7 @@ void Context::bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk
     }
     // ... and y1, y2 (and step E) inside it as well, when op1 has as many parties (Context::mul_and_relin, round 4)
     if (fuse_y) {
-        if (!fuse_x || n1 != n0 || n0 > 4) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and as many parties in op1 as in op0");
+        if (!fuse_x || n1 < 1 || n1 > 4 || n0 > 4) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and one to four parties per operand");
         for (int a = 0; a < n1; ++a) { bfv_yk1_.push_back(rlk_b1[a]->d); bfv_yk2_.push_back(rlk_b2[a]->d); }
     }
     for (int which = fuse_y ? 1 : 3; which >= (fuse_x ? 2 : 0); --which) {
@@ -1982,7 +1986,7 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
     static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
     const bool fuse = fuse_env && op0.n >= 1 && op0.n <= 4 && !masked_;
     static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
-    const bool fuse_y = fuse && fuse_y_env && op1.n == op0.n;
+    const bool fuse_y = fuse && fuse_y_env && op1.n >= 1 && op1.n <= 4;
     bfv_mr_partial(op0, op1, rlk_b1, rlk_b2, rlk_d1, rlk_d2, true, true, out, x_, x2_, y_, y2_, fuse, fuse_y);
     bfv_mr_finish(op0, op1, x_, x2_, y_, y2_, rlk_v, crs_u, out);
 }

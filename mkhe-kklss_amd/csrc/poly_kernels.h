@@ -114,7 +114,7 @@ struct ExtXyArgs {
     const Mod* mods;
     const int* map;
     long digit_stride, c1_item;
-    int g, nb, nslots, N;
+    int g, g1, nb, nslots, N;        // g items (parties of op0), g1 terms of y / step-E products (parties of op1), one to four each
 };
 void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st);
 // ... for five to eight parties per operand (ext_inner_xy_wide_kernel<G, E>: the loads of a digit in chunks of four)
@@ -139,7 +139,7 @@ struct ExtXyBatchArgs {
     const Mod* mods;
     const int* map;
     long digit_stride, c1_item;
-    int g, nbatch, nb, nslots, N;
+    int g, g1, nbatch, nb, nslots, N;      // g items per input (parties of op0), g1 terms of y (parties of op1)
 };
 void launch_ext_inner_xy_batch(const ExtXyBatchArgs& a, hipStream_t st);
 

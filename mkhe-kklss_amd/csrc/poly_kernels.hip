@@ -474,30 +474,29 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xwide_kernel(ExtInnerArg
 // y = MForm(sum_j b_j (.) h(c1_j)) in ONE pass -- the thread that forms the products at a coefficient needs y there and nowhere else, so y is neither
 // a launch of its own nor written and read back (2 x 59 MB at PN15QP880).  Per digit and thread: 4 G sixteen-byte loads, y[d] in registers, x[d]
 // stored.  Same operations as inner_product_kernel (mform_out) + ext_group_singles<G> with the x by-product: the same integers.
-// one gadget's pass of ext_inner_xy_kernel: per digit y[d], x[d], the F1 products and (E) the step-E products
-template <int G, bool E>
+// one gadget's pass of ext_inner_xy_kernel: per digit y[d] (G1 terms), x[d] and the F1 products (G0 items) and (E) the G1 step-E products
+template <int G0, int G1, bool E>
 __device__ __forceinline__ void xy_gadget(const u64* const (&ah)[4], const u64* const (&xkey)[4], const u64* const (&ykey)[4], const u64* const (&yh)[4], u64* xout,
-                                          u64 (&acc)[G][2], u64 (&ace)[E ? G : 1][2], const long off, const long ds, const int nb, const Mod& md) {
+                                          u64 (&acc)[G0][2], u64 (&ace)[E ? G1 : 1][2], const long off, const long ds, const int nb, const Mod& md) {
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
 #pragma unroll 1
     for (int i = 0; i < nb; ++i) {
-        u64x2 h[G], k[G], b[G], c[G];
+        u64x2 h[G0], k[G0], b[G1], c[G1];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            b[g] = ld_stream(ykey[g] + off + i * ds); c[g] = ld_stream(yh[g] + off + i * ds);
-            h[g] = ld_stream(ah[g] + off + i * ds); k[g] = ld_stream(xkey[g] + off + i * ds);
-        }
+        for (int g = 0; g < G1; ++g) { b[g] = ld_stream(ykey[g] + off + i * ds); c[g] = ld_stream(yh[g] + off + i * ds); }
+#pragma unroll
+        for (int g = 0; g < G0; ++g) { h[g] = ld_stream(ah[g] + off + i * ds); k[g] = ld_stream(xkey[g] + off + i * ds); }
         u64 y0 = 0, y1 = 0;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < G1; ++g) {
             y0 = csub(y0 + mont_mul_lazy(b[g].x, c[g].x, q, ninv), q2);
             y1 = csub(y1 + mont_mul_lazy(b[g].y, c[g].y, q, ninv), q2);
         }
         y0 = mont_mul(csub(y0, q), md.r2, q, ninv); y1 = mont_mul(csub(y1, q), md.r2, q, ninv);
         u64 x0 = 0, x1 = 0;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < G0; ++g) {
             acc[g][0] = csub(acc[g][0] + mont_mul_lazy(y0, h[g].x, q, ninv), q2);
             acc[g][1] = csub(acc[g][1] + mont_mul_lazy(y1, h[g].y, q, ninv), q2);
             x0 = csub(x0 + mont_mul_lazy(k[g].x, h[g].x, q, ninv), q2);
@@ -507,7 +506,7 @@ __device__ __forceinline__ void xy_gadget(const u64* const (&ah)[4], const u64* 
         if constexpr (E) {
             // step E from what the thread holds: <h(c1_j), x> (ext_inner_kernel: acc += mont_mul_lazy(x[d], h(c1_j)[d]))
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
+            for (int g = 0; g < G1; ++g) {
                 ace[g][0] = csub(ace[g][0] + mont_mul_lazy(x0, c[g].x, q, ninv), q2);
                 ace[g][1] = csub(ace[g][1] + mont_mul_lazy(x1, c[g].y, q, ninv), q2);
             }
@@ -515,7 +514,7 @@ __device__ __forceinline__ void xy_gadget(const u64* const (&ah)[4], const u64* 
         if (xout) { u64x2 r; r.x = x0; r.y = x1; *(u64x2*)(xout + off + i * ds) = r; }
     }
 }
-template <int G, bool E>
+template <int G0, int G1, bool E>
 __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_kernel(ExtXyArgs a) {
     const int s = blockIdx.y;
     const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
@@ -523,33 +522,37 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_kernel(ExtXyArgs a) {
     const int m = a.map[s];
     const Mod md = a.mods[m];
     const long off = (long)m * a.N + n;
-    u64 acc[G][2], ace[E ? G : 1][2];
+    u64 acc[G0][2], ace[E ? G1 : 1][2];
 #pragma unroll
-    for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; if (E) { ace[g][0] = 0; ace[g][1] = 0; } }
-    xy_gadget<G, E>(a.ah, a.xkey, a.ykey, a.yh, a.xout, acc, ace, off, a.digit_stride, a.nb, md);
+    for (int g = 0; g < G0; ++g) { acc[g][0] = 0; acc[g][1] = 0; }
+    if constexpr (E) {
+#pragma unroll
+        for (int g = 0; g < G1; ++g) { ace[g][0] = 0; ace[g][1] = 0; }
+    }
+    xy_gadget<G0, G1, E>(a.ah, a.xkey, a.ykey, a.yh, a.xout, acc, ace, off, a.digit_stride, a.nb, md);
     // mkbfv: the second gadget (QMul digits h2, keys d2 / b2, sums x2 / y2) adds its products to the same sums (keyswitch_hoisted.go:20-28)
-    if (a.ah2[0]) xy_gadget<G, E>(a.ah2, a.xkey2, a.ykey2, a.yh2, a.xout2, acc, ace, off, a.digit_stride, a.nb, md);
+    if (a.ah2[0]) xy_gadget<G0, G1, E>(a.ah2, a.xkey2, a.ykey2, a.yh2, a.xout2, acc, ace, off, a.digit_stride, a.nb, md);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        ext_store(a.c1 + (long)g * a.c1_item + off, acc[g][0], acc[g][1], md.q);
-        if constexpr (E) ext_store(a.e_out + (long)g * a.c1_item + off, ace[g][0], ace[g][1], md.q);
+    for (int g = 0; g < G0; ++g) ext_store(a.c1 + (long)g * a.c1_item + off, acc[g][0], acc[g][1], md.q);
+    if constexpr (E) {
+#pragma unroll
+        for (int g = 0; g < G1; ++g) ext_store(a.e_out + (long)g * a.c1_item + off, ace[g][0], ace[g][1], md.q);
     }
 }
+template <int G0, int G1> void launch_xy_e(const ExtXyArgs& a, dim3 grid, dim3 blk, hipStream_t st) {
+    if (a.e_out) hipLaunchKernelGGL((ext_inner_xy_kernel<G0, G1, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((ext_inner_xy_kernel<G0, G1, false>), grid, blk, 0, st, a);
+}
+template <int G0> void launch_xy_g1(const ExtXyArgs& a, dim3 grid, dim3 blk, hipStream_t st) {
+    switch (a.g1) { case 1: launch_xy_e<G0, 1>(a, grid, blk, st); break; case 2: launch_xy_e<G0, 2>(a, grid, blk, st); break;
+                    case 3: launch_xy_e<G0, 3>(a, grid, blk, st); break; default: launch_xy_e<G0, 4>(a, grid, blk, st); break; }
+}
 void launch_ext_inner_xy(const ExtXyArgs& a, hipStream_t st) {
-    if (a.g < 1 || a.g > 4) throw std::runtime_error("mkhe: internal: ext_inner_xy_kernel takes one to four parties");
+    if (a.g < 1 || a.g > 4 || a.g1 < 1 || a.g1 > 4) throw std::runtime_error("mkhe: internal: ext_inner_xy_kernel takes one to four parties per operand");
     const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
     const dim3 grid(bx, a.nslots, 1), blk(PW_THREADS);
-    if (a.e_out) switch (a.g) {
-        case 1: hipLaunchKernelGGL((ext_inner_xy_kernel<1, true>), grid, blk, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((ext_inner_xy_kernel<2, true>), grid, blk, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((ext_inner_xy_kernel<3, true>), grid, blk, 0, st, a); break;
-        default: hipLaunchKernelGGL((ext_inner_xy_kernel<4, true>), grid, blk, 0, st, a); break;
-    } else switch (a.g) {
-        case 1: hipLaunchKernelGGL((ext_inner_xy_kernel<1, false>), grid, blk, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((ext_inner_xy_kernel<2, false>), grid, blk, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((ext_inner_xy_kernel<3, false>), grid, blk, 0, st, a); break;
-        default: hipLaunchKernelGGL((ext_inner_xy_kernel<4, false>), grid, blk, 0, st, a); break;
-    }
+    switch (a.g) { case 1: launch_xy_g1<1>(a, grid, blk, st); break; case 2: launch_xy_g1<2>(a, grid, blk, st); break;
+                   case 3: launch_xy_g1<3>(a, grid, blk, st); break; default: launch_xy_g1<4>(a, grid, blk, st); break; }
 }
 // Five to eight parties per operand (PN16QP1761 with 8 parties: y was a 0.95 ms inner_product_kernel<8> launch, step E a second read of 8 x 331 MB of
 // digits): the same pass with the 4 G loads of a digit taken four at a time -- the h(c1_j)[d] stay in registers for step E (8 x 4 VGPRs), the keys
@@ -626,7 +629,7 @@ void launch_ext_inner_xy_wide(const ExtXyWideArgs& a, hipStream_t st) {
 #undef MKHE_XYW
 }
 typedef const __attribute__((address_space(4))) ExtXyBatchArgs* xyb_kargs;
-template <int G>
+template <int G0, int G1>
 __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_batch_kernel(ExtXyBatchArgs a) {
     xyb_kargs ka = (xyb_kargs)__builtin_amdgcn_kernarg_segment_ptr();      // per-input pointer lists: scalar loads
     const int s = blockIdx.y, bi = blockIdx.z;
@@ -637,31 +640,32 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_batch_kernel(ExtXyBat
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
     const long off = (long)m * a.N + n, ds = a.digit_stride;
-    const u64* ah[G]; const u64* yh[G]; const u64* xk[G]; const u64* yk[G];
+    const u64* ah[G0]; const u64* xk[G0]; const u64* yh[G1]; const u64* yk[G1];
 #pragma unroll
-    for (int g = 0; g < G; ++g) { ah[g] = ka->ah[bi][g] + off; yh[g] = ka->yh[bi][g] + off; xk[g] = ka->xkey[g] + off; yk[g] = ka->ykey[g] + off; }
+    for (int g = 0; g < G0; ++g) { ah[g] = ka->ah[bi][g] + off; xk[g] = ka->xkey[g] + off; }
+#pragma unroll
+    for (int g = 0; g < G1; ++g) { yh[g] = ka->yh[bi][g] + off; yk[g] = ka->ykey[g] + off; }
     u64* xo = ka->xout[bi] + off;
-    u64 acc[G][2];
+    u64 acc[G0][2];
 #pragma unroll
-    for (int g = 0; g < G; ++g) { acc[g][0] = 0; acc[g][1] = 0; }
+    for (int g = 0; g < G0; ++g) { acc[g][0] = 0; acc[g][1] = 0; }
 #pragma unroll 1
     for (int i = 0; i < a.nb; ++i) {
-        u64x2 h[G], k[G], b[G], c[G];
+        u64x2 h[G0], k[G0], b[G1], c[G1];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            b[g] = ld_cached(yk[g] + i * ds); c[g] = ld_stream(yh[g] + i * ds);          // (the keys are re-read by every input)
-            h[g] = ld_stream(ah[g] + i * ds); k[g] = ld_cached(xk[g] + i * ds);
-        }
+        for (int g = 0; g < G1; ++g) { b[g] = ld_cached(yk[g] + i * ds); c[g] = ld_stream(yh[g] + i * ds); }          // (the keys are re-read by every input)
+#pragma unroll
+        for (int g = 0; g < G0; ++g) { h[g] = ld_stream(ah[g] + i * ds); k[g] = ld_cached(xk[g] + i * ds); }
         u64 y0 = 0, y1 = 0;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < G1; ++g) {
             y0 = csub(y0 + mont_mul_lazy(b[g].x, c[g].x, q, ninv), q2);
             y1 = csub(y1 + mont_mul_lazy(b[g].y, c[g].y, q, ninv), q2);
         }
         y0 = mont_mul(csub(y0, q), md.r2, q, ninv); y1 = mont_mul(csub(y1, q), md.r2, q, ninv);
         u64 x0 = 0, x1 = 0;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < G0; ++g) {
             acc[g][0] = csub(acc[g][0] + mont_mul_lazy(y0, h[g].x, q, ninv), q2);
             acc[g][1] = csub(acc[g][1] + mont_mul_lazy(y1, h[g].y, q, ninv), q2);
             x0 = csub(x0 + mont_mul_lazy(k[g].x, h[g].x, q, ninv), q2);
@@ -672,18 +676,18 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_batch_kernel(ExtXyBat
         *(u64x2*)(xo + i * ds) = r;
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) ext_store(a.c1 + (long)(bi * G + g) * a.c1_item + off, acc[g][0], acc[g][1], q);
+    for (int g = 0; g < G0; ++g) ext_store(a.c1 + (long)(bi * G0 + g) * a.c1_item + off, acc[g][0], acc[g][1], q);
+}
+template <int G0> void launch_xyb_g1(const ExtXyBatchArgs& a, dim3 grid, dim3 blk, hipStream_t st) {
+    switch (a.g1) { case 1: hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, 1>), grid, blk, 0, st, a); break; case 2: hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, 2>), grid, blk, 0, st, a); break;
+                    case 3: hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, 3>), grid, blk, 0, st, a); break; default: hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, 4>), grid, blk, 0, st, a); break; }
 }
 void launch_ext_inner_xy_batch(const ExtXyBatchArgs& a, hipStream_t st) {
-    if (a.g < 1 || a.g > 4 || a.nbatch < 1 || a.nbatch > XYB_MAX) throw std::runtime_error("mkhe: internal: ext_inner_xy_batch_kernel out of its range");
+    if (a.g < 1 || a.g > 4 || a.g1 < 1 || a.g1 > 4 || a.nbatch < 1 || a.nbatch > XYB_MAX) throw std::runtime_error("mkhe: internal: ext_inner_xy_batch_kernel out of its range");
     const int bx = (a.N / 2 + PW_THREADS - 1) / PW_THREADS;
     const dim3 grid(bx, a.nslots, a.nbatch), blk(PW_THREADS);
-    switch (a.g) {
-        case 1: hipLaunchKernelGGL(ext_inner_xy_batch_kernel<1>, grid, blk, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(ext_inner_xy_batch_kernel<2>, grid, blk, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(ext_inner_xy_batch_kernel<3>, grid, blk, 0, st, a); break;
-        default: hipLaunchKernelGGL(ext_inner_xy_batch_kernel<4>, grid, blk, 0, st, a); break;
-    }
+    switch (a.g) { case 1: launch_xyb_g1<1>(a, grid, blk, st); break; case 2: launch_xyb_g1<2>(a, grid, blk, st); break;
+                   case 3: launch_xyb_g1<3>(a, grid, blk, st); break; default: launch_xyb_g1<4>(a, grid, blk, st); break; }
 }
 void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
     ExtInnerArgs a = a_in;
