@@ -201,16 +201,16 @@ One 1024-thread workgroup per CU holds a whole limb (32 coefficients per thread)
 
 **Round 4: y and step E inside the F1 kernel.**  Rounds 1–3 ran the 4-party MulAndRelin's linear algebra as three streaming launches: y = Σ_j b_j ⊙ h(c1_j) (`inner_product_kernel`: 528 MB), F1 + x (the t_i = ⟨h(c0_i), y⟩ and, as a by-product,
 x = Σ_i d_i ⊙ h(c0_i): 587 MB), and the E / F2 batch (⟨h(c1_j), x⟩, ⟨h(t_i), v_i⟩, ⟨h(t_i), u⟩: 822 MB).  All of it is pointwise in the coefficient: the thread that forms the F1 products at a coefficient needs y there and nowhere else, and once it holds x[d] and
-h(c1_j)[d] (which it loaded for y) step E costs it G more accumulators.  `ext_inner_xy_kernel<G, E>` (op1 with as many parties as op0, at most four; single device) reads the four operand families once — h(c0), d, h(c1), b: 16 sixteen-byte loads per digit and thread — and
+h(c1_j)[d] (which it loaded for y) step E costs it G more accumulators.  `ext_inner_xy_kernel<G0, G1, E>` (one to four parties per operand, single device; five to eight in both: `ext_inner_xy_wide_kernel`) reads the four operand families once — h(c0), d, h(c1), b: 16 sixteen-byte loads per digit and thread — and
 writes the t_i and the E products; y and x are never stored, the h(c1_j) are not read a second time, and the tail batch finds its E items precomputed in its c1 slots (`ExtItem::pre`).  Same operations on the same values: the same integers (the whole GPU suite,
 `MKHE_FUSE_Y=0` / `MKHE_FUSE_E=0` are the switches).  Same call: 1203–1213 → 1231–1238 MulRelin/s with y inside, → **1308–1318** with step E inside as well; `ext_inner_kernel` here: two launches of {R["kernels"]["ext_inner_kernel"]["avg_launch_us"]:.0f} µs on average.
-The batched entry (`ext_inner_xy_batch_kernel`, B inputs) computes x_b and y_b in the thread; step E there is still a tail item.
+The batched entry (`ext_inner_xy_batch_kernel<G0, G1>`, B inputs) computes x_b and y_b in the thread; step E there is still a tail item (cnn, whose MulRelins have 1 to 3 parties per operand: 330 → 338 inferences/s one image at a time, 978 → 1022 at B = 8, same call).  mkbfv runs the same kernel over its two gadgets (623–629 → 747–751 MulRelin/s, same call); five to eight parties per operand take `ext_inner_xy_wide_kernel` (PN16QP1761 with 8 parties 91–92 → 99.4 MulRelin/s, PN15QP880 with 8 parties 628 → 681).
 Their algorithmic GB/s equal their PMC GB/s (the byte model charges every distinct operand once): ≈ 5.8 TB/s = 0.73 of the 8 TB/s spec.  `{tag}_ubench.txt` (`read_bw`, round 4) measures what a kernel that ONLY reads reaches on the same box: {rds[0]:.0f}–{rds[1]:.0f} GB/s in the pattern of these kernels (14–70 concurrent streams 4 MB apart, 16 bytes per lane), {rdc[0]:.0f}–{rdc[1]:.0f} GB/s with one contiguous region per workgroup (another box of the round: 5464–5875 and 6003–6075) — the streaming kernels are within 0–10 % of the read ceiling of their access pattern, not 27 % under a roofline; the contiguous pattern (digit-major tiles instead of [digit][modulus][N]) would be a re-layout of every hoisted form and key.  The ModDown launches and the small inverse NTTs are
 launch-latency-bound; the Rescale no longer appears: it rides on the merged ModDown's store (`mkhe_mul_relin_rescale`, DESIGN.md §4 "Fused Rescale").
 
 ## BASELINE.json configs[2]: mkbfv 4-party MulRelinNew, PN15QP880 BFV chain (14 Q + 14 QMul + 2 P)
 
-* **{bfp["value"]:.0f} MulRelin/s** ({bfp["ms_per_step"]:.3f} ms per step; round 2: 571, round 1: 435), bit-exact against the oracle at full size (`tests/test_gpu_headline.py`, and `bench.py --scheme bfv` in every run: `bit_exact_vs_gpu = {bfp["cpu_baseline"]["bit_exact_vs_gpu"] if bfp.get("cpu_baseline") else "n/a"}`);
+* **{bfp["value"]:.0f} MulRelin/s** ({bfp["ms_per_step"]:.3f} ms per step; round 3: ≈ 620, round 2: 571, round 1: 435; round 4: y1, y2 and step E inside the F1 kernel), bit-exact against the oracle at full size (`tests/test_gpu_headline.py`, and `bench.py --scheme bfv` in every run: `bit_exact_vs_gpu = {bfp["cpu_baseline"]["bit_exact_vs_gpu"] if bfp.get("cpu_baseline") else "n/a"}`);
   cold start {bfp["config"].get("mulrelin_per_sec_cold_start", 0):.0f}/s; the reference's non-hoisted twin on its own device path (`mkhe_bfv_mul_relin_unhoisted`: every component decomposed twice, no batching) {bfp["config"].get("mulrelin_unhoisted_per_sec", 0):.0f}/s; under the profiler with overlap off {bf["value"]:.0f}/s.
 
 | kernel | launches/step | avg µs/launch | ms/step | algorithmic GB/s | PMC GB/s |
@@ -241,7 +241,7 @@ if pn:
 ## BASELINE.json configs[3] ring on ONE GPU: 8-party MulRelin + hoisted Rotate, PN16QP1761 (N = 2^16, 34 Q + 4 P primes, α = 2, β = 17)
 
 `python3 bench.py --params PN16QP1761 --parties 8 --steps 10 --warmup 2`: **{pn["value"]:.1f} MulRelin/s** ({pn["ms_per_step"]:.2f} ms per step; round 3: 89–95, round 2: 68.5, round 1: 53.8), Rotate {c.get("rotate_per_sec", 0):.0f}/s, RotateHoisted {c.get("rotate_hoisted_per_sec", 0):.0f}/s.
-Round 4: its sub-transform kernel `ntt14_fwd_split_kernel` had the vector byte load of the job walk too (above): 3.93 → 3.84 ms per step on one kind of box.  Round 3 changed its Decompose (DESIGN.md §4 "N = 2^16"): `decomp_spread4_kernel` reconstructs the two-limb digits on one-round radix-2^30 products and applies the first TWO stages of the forward NTT before it stores, and the four 2^14-point
+Round 4: y and step E inside the F1 kernel (`ext_inner_xy_wide_kernel<8>`: 91–92 → 99.4 MulRelin/s in one call; y was a 1.0 ms `inner_product_kernel<8>` launch).  Round 3 changed its Decompose (DESIGN.md §4 "N = 2^16"): `decomp_spread4_kernel` reconstructs the two-limb digits on one-round radix-2^30 products and applies the first TWO stages of the forward NTT before it stores, and the four 2^14-point
 sub-transforms of every limb are single in-place passes of the H16 kernel (`ntt14_fwd_split_kernel`).  Per Decompose launch (8 components x 17 digits x 38 moduli + the x / y digits = 8058 limbs of 2^16 words = 4.2 GB): 0.99 + 2.62 ms
 (cross-half stage only, two-pass 2^15-point sub-transforms out of place: 4.2 GB written by the spread, 8.4 GB read and 4.2 GB written by the NTT = 4.8 TB/s, HBM-bound) became 0.83 + 2.23 ms (4.2 + 4.2 + 4.2 GB; the spread stores at 5.1 TB/s, the NTT is bound by its
 butterflies under the power cap like the N = 2^15 kernel) -- 75.5 → 81.1 MulRelin/s on one box, same call (`MKHE_SPREAD_RADIX4=0` is the A/B switch).  `r3_pn16_traffic.txt` has the PMC bytes of both paths (`tools/pn16_traffic.sh`): the largest
