@@ -138,10 +138,12 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     const bool fuse_x = fuse_env && n0 >= 1 && n0 <= 4;      // x_b = sum_i d_i (.) h(c0_{b,i}) as a by-product of input b's step F1
     static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
     const bool fuse_y = fuse_x && fuse_y_env && n1 >= 1 && n1 <= 4;    // ... and y_b computed in the same threads (ext_inner_xy_batch_kernel<G0, G1>), never stored
+    static const int fuse_e_env = getenv("MKHE_FUSE_E") ? atoi(getenv("MKHE_FUSE_E")) : 1;
+    const bool fuse_e = fuse_y && fuse_e_env;                          // ... and step E: input b's <h(c1_j), x_b> as precomputed items of the tail batch
     const size_t per_b = (size_t)(2 + n0 + n1) * PO + (size_t)(1 + nout) * PO * ((fold ? 1 : 0) + (rescale_out ? 1 : 0)) + 2 * SW + (size_t)n0 * PO + (size_t)n0 * SW +
-                         (own0 ? (size_t)n0 * SW : 0) + (own1 ? (size_t)n1 * SW : 0);
+                         (own0 ? (size_t)n0 * SW : 0) + (own1 ? (size_t)n1 * SW : 0) + (fuse_e ? (size_t)n1 * mtot * N : 0);
     Arena ar(this, B * per_b);
-    std::vector<u64*> nb_(B), tens(B, nullptr), full(B), x(B), y(B), tbuf(B);
+    std::vector<u64*> nb_(B), tens(B, nullptr), full(B), x(B), y(B), tbuf(B), epre(B, nullptr);
     std::vector<const u64*> h0(B * n0), h1(B * n1);
     std::vector<u64*> h2(B * n0);
     {
@@ -151,6 +153,7 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
             if (fold) tens[b] = ar.take((size_t)(1 + nout) * PO);
             full[b] = rescale_out ? ar.take((size_t)(1 + nout) * PO) : outs[b]->d;
             x[b] = ar.take(SW); y[b] = ar.take(SW); tbuf[b] = ar.take((size_t)n0 * PO);
+            if (fuse_e) epre[b] = ar.take((size_t)n1 * mtot * N);
             for (int a = 0; a < n0; ++a) h2[b * n0 + a] = ar.take(SW);
             for (int a = 0; a < n0; ++a) {
                 if (own0) { u64* d = ar.take(SW); dsrc.push_back(op0[b]->d + (1 + a) * P0); ddst.push_back(d); h0[b * n0 + a] = d; }
@@ -254,8 +257,9 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
         const size_t per = std::max<size_t>(1, EXT_MAX_ITEMS / (size_t)n0);
         for (size_t b0 = 0; b0 < B; b0 += per) {
             std::vector<ExtItem> items;
-            ext_xmap_.clear(); ext_ykeys_.clear(); ext_yh_.clear();
+            ext_xmap_.clear(); ext_ykeys_.clear(); ext_yh_.clear(); ext_eouts_.clear();
             for (size_t b = b0; b < std::min(B, b0 + per); ++b) {
+                if (fuse_e) ext_eouts_.push_back(epre[b]);
                 for (int a = 0; a < n0; ++a) {
                     items.push_back(ExtItem{h0[b * n0 + a], y[b], tbuf[b] + (size_t)a * PO, false});
                     if (fuse_x) items.back().xkey = rlk_d0[a]->d;
@@ -264,8 +268,8 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
                 if (fuse_x) ext_xmap_.push_back({y[b], x[b]});
             }
             if (fuse_y) for (int a = 0; a < n1; ++a) ext_ykeys_.push_back(rlk_b1[a]->d);
-            try { ext_batch(level, items); } catch (...) { ext_xmap_.clear(); ext_ykeys_.clear(); ext_yh_.clear(); throw; }
-            ext_xmap_.clear(); ext_ykeys_.clear(); ext_yh_.clear();
+            try { ext_batch(level, items); } catch (...) { ext_xmap_.clear(); ext_ykeys_.clear(); ext_yh_.clear(); ext_eouts_.clear(); throw; }
+            ext_xmap_.clear(); ext_ykeys_.clear(); ext_yh_.clear(); ext_eouts_.clear();
         }
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (size_t b = 0; b < B; ++b)
@@ -288,7 +292,10 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
                     items.push_back(ExtItem{h2[b * n0 + a], rlk_v0[a]->d, full[b], true});
                     items.push_back(ExtItem{h2[b * n0 + a], crs_u.d, full[b] + (size_t)(1 + slot0[a]) * PO, true});
                 }
-                for (int a = 0; a < n1; ++a) items.push_back(ExtItem{h1[b * n1 + a], x[b], full[b] + (size_t)(1 + slot1[a]) * PO, true});
+                for (int a = 0; a < n1; ++a) {
+                    items.push_back(ExtItem{h1[b * n1 + a], x[b], full[b] + (size_t)(1 + slot1[a]) * PO, true});
+                    if (fuse_e) { items.back().pre = true; items.back().pre_src = epre[b] + (size_t)a * mtot * N; }
+                }
                 if (fold) {
                     // the tensor term of every output slot (NTT domain, times P) rides on the first product that goes there: ModDown returns it as itself
                     std::vector<const u64*> seen;

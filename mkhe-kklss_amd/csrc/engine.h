@@ -30,7 +30,8 @@ struct Ct { int n = 0; int limbs = 0; std::vector<int> ids; u64* d = nullptr; };
 // one external product of a batch: dst (+)= ModDown_P( sum_i bg[i] (.) ah[i] )
 struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const u64* ah2 = nullptr; const u64* bg2 = nullptr;
                  const u64* xkey = nullptr;   /* F1 only: this party's d_i, for the x by-product (ExtInnerArgs::xkey) */
-                 bool pre = false;            /* the inner products of this item are already in its c1 slot (step E computed by the F1 kernel): no inner launch work */
+                 bool pre = false;            /* the inner products of this item exist already (step E computed by the F1 kernel): in its c1 slot, or ... */
+                 const u64* pre_src = nullptr; /* ... at pre_src [mtot][N] (a batch: the inner kernel copies them into the slot instead of computing) */
                  const u64* xkey2 = nullptr;  /* mkbfv F1: this party's d2_i (second gadget) */
                  const u64* addend = nullptr; /* accumulate onto this polynomial instead of onto dst (Rotate: c_0 of the input) */
                  const u64* qadd = nullptr;   /* first product of a destination, not accumulating: an NTT-domain polynomial [L][N] (canonical, already
@@ -141,6 +142,7 @@ class Context {
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
     u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
     u64* ext_xout2_ = nullptr;            // ... and the second gadget's x (mkbfv)
+    std::vector<u64*> ext_eouts_;                           // a batch's F1 call that computes step E too: where input b's E products go ([n1][mtot][N])
     int ext_e_slot_ = -1;                                  // >= 0 around the F1 call that computes step E too: first c1 slot of the E products
     std::vector<const u64*> ext_ykeys_, ext_yh_;          // set around the F1 call whose kernel computes y itself (ExtXyArgs::ykey / yh); with ext_xmap_ (a
                                                          // batch): ext_yh_ holds every input's digits in turn, ext_ykeys_.size() per input
@@ -346,7 +348,7 @@ class Context {
     // that alternated the kernels over the first dozen launches (the first milliseconds run on ramping clocks with power to spare), and a second that
     // timed the kernel alone (with the side stream on, a kernel's duration says little about the operation's).  What is measured is the PERIOD of the
     // shape -- the time from one of its launches to the next on the GPU's clock, i.e. the whole operation around it in a running service.  Per shape:
-    // WARM launches on H32, then a block on H32 and a block on H16 (SETTLE launches, then TIMED periods); the medians decide, the choice stays.
+    // WARM launches on H16, then a block on H32 and a block on H16 (SETTLE launches, then TIMED periods); the medians decide, the choice stays.
     // A smaller shape follows the largest one unless the other kernel is 3 % ahead.
     struct NttTune { static constexpr int WARM = 64, SETTLE = 16, TIMED = 32, RING = 2 * (TIMED + 1); int n[2] = {0, 0}, req[2] = {0, 0}, blk[2] = {0, 0}; float t[2][TIMED];
                      int decided = -1, seen = 0;

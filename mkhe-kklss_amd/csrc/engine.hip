@@ -722,7 +722,7 @@ int Context::ntt_pick(long key, NttTune*& sampling) {
     if (t.decided >= 0) return t.decided;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s_, &cs);
-    if (cs != hipStreamCaptureStatusNone) return 1;    // (no timing inside a graph capture: the recorded sequence keeps H32)
+    if (cs != hipStreamCaptureStatusNone) return 0;    // (no timing inside a graph capture: the recorded sequence keeps the two-pass kernel)
     // periods between consecutive timed launches of one block, oldest first, as far as the GPU has come
     while (t.inflight >= 2) {
         const int h = t.head, nx = (h + 1) % RING;
@@ -750,12 +750,14 @@ int Context::ntt_pick(long key, NttTune*& sampling) {
         }
         return t.decided;                              // (the events stay until the context goes: release_all)
     }
-    // launch number `seen` of this shape: [0, WARM) H32; then a block of H32 and a block of H16 -- SETTLE launches, then TIMED + 1 launches with a start
-    // event (TIMED periods) -- and H32 again until the last period has come back.  The host runs ahead of the GPU by up to hundreds of launches: the
-    // blocks are counted in REQUESTED events (the GPU executes the launches in this order whenever it gets to them), the decision waits for the harvest.
-    if (t.seen < WARM) { ++t.seen; return 1; }
+    // launch number `seen` of this shape: [0, WARM) on the two-pass kernel (whose time inside an operation is the same on every part met: the safe
+    // choice for a shape that never gets as far as a decision); then a block of H32 and a block of H16 -- SETTLE launches, then TIMED + 1 launches with
+    // a start event (TIMED periods) -- and H16 again until the last period has come back.  The host runs ahead of the GPU by up to hundreds of
+    // launches: the blocks are counted in REQUESTED events (the GPU executes the launches in this order whenever it gets to them), the decision waits
+    // for the harvest.
+    if (t.seen < WARM) { ++t.seen; return 0; }
     const int k = t.req[1] < TIMED + 1 ? 1 : (t.req[0] < TIMED + 1 ? 0 : -1);
-    if (k < 0 || t.inflight >= RING) return 1;
+    if (k < 0 || t.inflight >= RING) return 0;
     if (t.blk[k]++ < SETTLE) return k;
     const int sl = (t.head + t.inflight) % RING;
     if (!t.e0[sl]) MKHE_HIP(hipEventCreate(&t.e0[sl]));
@@ -1007,7 +1009,10 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     // neighbours that share their digits (step F: <h(t_i), v_i> and <h(t_i), u>) are computed together
     for (int i = 0; i + 1 < n && !xby; ++i)
         if (!ia.pair[i] && ia.ah[i] == ia.ah[i + 1] && !ia.ah2[i] && !ia.ah2[i + 1]) { ia.pair[i] = 1; ia.pair[i + 1] = 2; ++i; }
-    for (int i = 0; i < n; ++i) if (it[i].pre) { if (ia.pair[i]) throw Error("mkhe: internal: a precomputed item inside a pair"); ia.pair[i] = 2; }      // (role 2 = computed elsewhere: the kernels skip it)
+    for (int i = 0; i < n; ++i) if (it[i].pre) {      // (role 2 = computed elsewhere, in the slot: the kernels skip it; role 3 = computed elsewhere, at pre_src: they copy it)
+        if (ia.pair[i]) throw Error("mkhe: internal: a precomputed item inside a pair");
+        if (it[i].pre_src) { ia.pair[i] = 3; ia.bg[i] = it[i].pre_src; ia.bg_once[i] = 1; } else ia.pair[i] = 2;
+    }
     ia.c1 = c1; ia.mods = d_mods; ia.map = map_qp(level); ia.digit_stride = (long)item_words; ia.c1_item = (long)item_words;
     ia.nitems = n; ia.nb = nb; ia.nslots = nslots; ia.N = N;
     // algorithmic bytes: every DISTINCT digit / key array once (items that share x, y or the CRS u are computed by one thread that loads the
@@ -1040,7 +1045,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
       } else if (xyb) {
           // B inputs' step F1 with x_b and y_b in the thread: the items come input by input (g per input, mul_relin_batch), up to XYB_MAX inputs per launch
           const int nin = (int)ext_xmap_.size(), g = nin ? n / nin : 0, g1 = (int)ext_ykeys_.size();
-          if (two || mp || g < 1 || g > 4 || g1 < 1 || g1 > 4 || nin * g != n || (int)ext_yh_.size() != nin * g1) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
+          if (two || mp || g < 1 || g > 4 || g1 < 1 || g1 > 4 || nin * g != n || (int)ext_yh_.size() != nin * g1 || (!ext_eouts_.empty() && (int)ext_eouts_.size() != nin)) throw Error("mkhe: internal: per-input y on a batch that cannot carry it");
           for (int b0 = 0; b0 < nin; b0 += XYB_MAX) {
               ExtXyBatchArgs xa{};
               const int cnt = std::min(XYB_MAX, nin - b0);
@@ -1053,6 +1058,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
                   }
                   for (int j = 0; j < g1; ++j) xa.yh[b][j] = ext_yh_[(b0 + b) * g1 + j];
                   xa.xout[b] = ext_xmap_[b0 + b].second;
+                  if (!ext_eouts_.empty()) xa.eout[b] = ext_eouts_[b0 + b];
               }
               for (int j = 0; j < g1; ++j) xa.ykey[j] = ext_ykeys_[j];
               xa.c1 = c1 + (size_t)b0 * g * item_words; xa.mods = d_mods; xa.map = map_qp(level); xa.digit_stride = (long)item_words; xa.c1_item = (long)item_words;

@@ -74,7 +74,8 @@ struct ExtInnerArgs {
     const u64* ah2[EXT_MAX_ITEMS];   // second gadget (BFV: QMul digits, keyswitch_hoisted.go:20-28) or all NULL
     const u64* bg2[EXT_MAX_ITEMS];
     unsigned char bg_once[EXT_MAX_ITEMS];  // this item's key is read by no other item of the launch: stream it past the caches
-    unsigned char pair[EXT_MAX_ITEMS];   // 1: this item and the next one share `ah` (step F: <h(t_i), v_i> and <h(t_i), u>):
+    unsigned char pair[EXT_MAX_ITEMS];   // (3: the item's products exist already at bg[item] [mtot][N]: copied into its c1 slot; 2 also: nothing to do)
+                                         // 1: this item and the next one share `ah` (step F: <h(t_i), v_i> and <h(t_i), u>):
                                          // computed together, the digits are read once; 2: the follower (skipped); 0: single
     // groups (set by launch_ext_inner): single items that share `bg` (step E: every <h(c1_j), x>; F1: every <h(c0_i), y>) and pairs that
     // share their second key (step F2: the CRS u) are computed by ONE thread, up to four at a time, so that the shared operand is
@@ -134,6 +135,7 @@ void launch_ext_inner_xy_wide(const ExtXyWideArgs& a, hipStream_t st);
 constexpr int XYB_MAX = 16;
 struct ExtXyBatchArgs {
     const u64* ah[XYB_MAX][4]; const u64* yh[XYB_MAX][4]; u64* xout[XYB_MAX];
+    u64* eout[XYB_MAX];      // eout[0] non-NULL: step E too (input b's g1 products [mtot][N] at eout[b] + j * c1_item; xout is then not written)
     const u64* xkey[4]; const u64* ykey[4];
     u64* c1;                 // [nbatch * g][mtot][N]
     const Mod* mods;

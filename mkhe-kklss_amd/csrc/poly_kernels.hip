@@ -313,6 +313,10 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_kernel(ExtInnerArgs a) {
     const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
     if (n >= a.N) return;
     const int m = a.map[s];
+    if (role == 3) {                          // computed before (step E inside a batch's F1 kernel): into the slot
+        *(u64x2*)(a.c1 + (long)item * a.c1_item + (long)m * a.N + n) = ld_stream(a.bg[item] + (long)m * a.N + n);
+        return;
+    }
     const Mod md = a.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
@@ -364,6 +368,10 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_group_kernel(ExtInnerArg
     const int n = 2 * (blockIdx.x * PW_THREADS + threadIdx.x);
     if (n >= a.N) return;
     const int m = a.map[s];
+    if (role == 3) {                                      // computed before (step E inside a batch's F1 kernel): into the slot
+        *(u64x2*)(a.c1 + (long)item * a.c1_item + (long)m * a.N + n) = ld_stream(ka->bg[item] + (long)m * a.N + n);
+        return;
+    }
     const Mod md = a.mods[m];
     if (grp == 1) {
         const long off = (long)m * a.N + n;
@@ -629,7 +637,7 @@ void launch_ext_inner_xy_wide(const ExtXyWideArgs& a, hipStream_t st) {
 #undef MKHE_XYW
 }
 typedef const __attribute__((address_space(4))) ExtXyBatchArgs* xyb_kargs;
-template <int G0, int G1>
+template <int G0, int G1, bool E>
 __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_batch_kernel(ExtXyBatchArgs a) {
     xyb_kargs ka = (xyb_kargs)__builtin_amdgcn_kernarg_segment_ptr();      // per-input pointer lists: scalar loads
     const int s = blockIdx.y, bi = blockIdx.z;
@@ -645,10 +653,14 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_batch_kernel(ExtXyBat
     for (int g = 0; g < G0; ++g) { ah[g] = ka->ah[bi][g] + off; xk[g] = ka->xkey[g] + off; }
 #pragma unroll
     for (int g = 0; g < G1; ++g) { yh[g] = ka->yh[bi][g] + off; yk[g] = ka->ykey[g] + off; }
-    u64* xo = ka->xout[bi] + off;
-    u64 acc[G0][2];
+    u64* xo = E ? nullptr : ka->xout[bi] + off;
+    u64 acc[G0][2], ace[E ? G1 : 1][2];
 #pragma unroll
     for (int g = 0; g < G0; ++g) { acc[g][0] = 0; acc[g][1] = 0; }
+    if constexpr (E) {
+#pragma unroll
+        for (int g = 0; g < G1; ++g) { ace[g][0] = 0; ace[g][1] = 0; }
+    }
 #pragma unroll 1
     for (int i = 0; i < a.nb; ++i) {
         u64x2 h[G0], k[G0], b[G1], c[G1];
@@ -672,15 +684,32 @@ __global__ void __launch_bounds__(PW_THREADS) ext_inner_xy_batch_kernel(ExtXyBat
             x1 = csub(x1 + mont_mul_lazy(k[g].y, h[g].y, q, ninv), q2);
         }
         x0 = mont_mul(csub(x0, q), md.r2, q, ninv); x1 = mont_mul(csub(x1, q), md.r2, q, ninv);
-        u64x2 r; r.x = x0; r.y = x1;
-        *(u64x2*)(xo + i * ds) = r;
+        if constexpr (E) {
+#pragma unroll
+            for (int g = 0; g < G1; ++g) {
+                ace[g][0] = csub(ace[g][0] + mont_mul_lazy(x0, c[g].x, q, ninv), q2);
+                ace[g][1] = csub(ace[g][1] + mont_mul_lazy(x1, c[g].y, q, ninv), q2);
+            }
+        } else {
+            u64x2 r; r.x = x0; r.y = x1;
+            *(u64x2*)(xo + i * ds) = r;
+        }
     }
 #pragma unroll
     for (int g = 0; g < G0; ++g) ext_store(a.c1 + (long)(bi * G0 + g) * a.c1_item + off, acc[g][0], acc[g][1], q);
+    if constexpr (E) {
+        u64* eo = ka->eout[bi] + off;
+#pragma unroll
+        for (int g = 0; g < G1; ++g) ext_store(eo + (long)g * a.c1_item, ace[g][0], ace[g][1], q);
+    }
+}
+template <int G0, int G1> void launch_xyb_e(const ExtXyBatchArgs& a, dim3 grid, dim3 blk, hipStream_t st) {
+    if (a.eout[0]) hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, G1, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, G1, false>), grid, blk, 0, st, a);
 }
 template <int G0> void launch_xyb_g1(const ExtXyBatchArgs& a, dim3 grid, dim3 blk, hipStream_t st) {
-    switch (a.g1) { case 1: hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, 1>), grid, blk, 0, st, a); break; case 2: hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, 2>), grid, blk, 0, st, a); break;
-                    case 3: hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, 3>), grid, blk, 0, st, a); break; default: hipLaunchKernelGGL((ext_inner_xy_batch_kernel<G0, 4>), grid, blk, 0, st, a); break; }
+    switch (a.g1) { case 1: launch_xyb_e<G0, 1>(a, grid, blk, st); break; case 2: launch_xyb_e<G0, 2>(a, grid, blk, st); break;
+                    case 3: launch_xyb_e<G0, 3>(a, grid, blk, st); break; default: launch_xyb_e<G0, 4>(a, grid, blk, st); break; }
 }
 void launch_ext_inner_xy_batch(const ExtXyBatchArgs& a, hipStream_t st) {
     if (a.g < 1 || a.g > 4 || a.g1 < 1 || a.g1 > 4 || a.nbatch < 1 || a.nbatch > XYB_MAX) throw std::runtime_error("mkhe: internal: ext_inner_xy_batch_kernel out of its range");
@@ -711,7 +740,7 @@ void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
         // (xmulti: the items that share a key are one input's step F1 -- at most four, checked by the caller -- and form a group even alone:
         // the group form is the one that carries the x by-product)
         for (int i = 0; i < a.nitems; ++i) {
-            if (a.grp[i] || a.pair[i] == 2) continue;
+            if (a.grp[i] || a.pair[i] >= 2) continue;
             const bool pr = a.pair[i] == 1;            // (pairs never carry a second gadget: see Context::ext_front)
             int last = i, cnt = 1;
             for (int k = i + 1; k < a.nitems && cnt < 4; ++k) {

@@ -161,8 +161,8 @@ read every key once (b, d: 470 MB; v, u: 294 MB) and every hoisted digit once (h
 
 ### Dominant kernel: the Decompose-fused forward NTT — `{DOM}` in this set (DESIGN.md §3 "Round 3", §4)
 
-* HIP-event average inside `bench.py`: **{R["avg_launch_us"]:.1f} µs per launch** (plain run), {Rn["avg_launch_us"]:.1f} µs in the profiled run; rocprofv3 kernel-trace average of that profiled run: **{avg:.1f} µs** over {calls} calls
-  (min {mn:.0f} = the 896-limb launches, max {mx:.0f} µs) + {ocalls} calls of `{OTHER}` while the engine measured (average {oavg:.1f} µs): {calls} + {ocalls} = {calls + ocalls} of the expected {expect}.  Round 3: 172–176 µs, round 2: 207 µs, round 1 (`ntt_fwd_kernel<15,2,true>`): 297.5 µs.
+* HIP-event average inside `bench.py`: **{R["avg_launch_us"]:.1f} µs per launch** (plain run), {Rn["avg_launch_us"]:.1f} µs in the profiled run; rocprofv3 kernel-trace of that profiled run: `{DOM}` **{avg:.1f} µs** over {calls} calls
+  (min {mn:.0f}, max {mx:.0f} µs), `{OTHER}` {oavg:.1f} µs over {ocalls} calls (the engine times a block of launches of each form per launch shape before it settles, and may settle on different forms for the 1792- and the 896-limb shape): {calls} + {ocalls} = {calls + ocalls} of the expected {expect}, **{(avg * calls + oavg * ocalls) / max(1, calls + ocalls):.1f} µs** over all of them.  Round 3: 172–176 µs, round 2: 207 µs, round 1 (`ntt_fwd_kernel<15,2,true>`): 297.5 µs.
 * algorithmic bytes per launch {R["alg_bytes_per_launch"] / 1e6:.1f} MB (16·N B per limb-NTT × (1792 + 896)/2 limbs) ⇒ **{R["achieved"]:.0f} GB/s = {R["frac"]:.3f} of the 8 TB/s HBM peak** (round 3: 0.49–0.52 by box, round 2: 0.42, round 1: 0.296).
   By the compulsory bytes of the fused Decompose ({R.get("compulsory_bytes_per_launch", 0) / 1e6:.0f} MB per average launch) it is {R.get("frac_compulsory", 0):.3f}.
 * HBM traffic from the PMC passes (the kernel forced in them): two-pass kernel {h16rec.get("hbm_bytes_per_launch", 0) / 1e6:.1f} MB per launch (FETCH_SIZE {h16rec.get("fetch_size_kb", 0) / 1e3:.1f} MB ×2 + WRITE_SIZE {h16rec.get("write_size_kb", 0) / 1e3:.1f} MB) =
