@@ -377,7 +377,16 @@ def roofline_leg(args, params, step, logN, workload, extra=None):
             # steps the recorded command ran: cold-start leg (W + K), steady-state leg (100 + 200), timed region (W + K), HIP-event leg (K)
             expect = kernels[name]["launches_per_step"] * (2 * (tj["warmup"] + tj["steps"]) + 300 + tj["steps"])
             return rec["hbm_bytes_per_launch"] if abs(rec["launches"] - expect) < 0.5 else None
-        traffic = pmc_bytes(dom) if dom in kernels else None        # (a Decompose NTT split over its two forms has no recorded launch pattern)
+        if dom in kernels:
+            traffic = pmc_bytes(dom)
+        elif len(dec) == 2 and not stale and tj.get("workload") == workload and tj.get("steps") is not None:
+            # the Decompose NTT split over its two forms (one launch shape each): the recorded per-shape figures of the two kernels, when each of
+            # them ran its shape once per step in the recorded command too
+            big, small = sorted(dec, key=lambda i: -(byt[i] / cnt[i]))
+            rb, rs = (tk.get(names_k[big].split()[0]) or {}).get("large"), (tk.get(names_k[small].split()[0]) or {}).get("small")
+            nsteps = 2 * (tj["warmup"] + tj["steps"]) + 300 + tj["steps"]
+            if rb and rs and cnt[big] == cnt[small] == args.steps and rb["launches"] == nsteps and rs["launches"] == nsteps:
+                traffic = 0.5 * (rb["hbm_bytes_per_launch"] + rs["hbm_bytes_per_launch"])
         for name, k in kernels.items():
             hb = pmc_bytes(name)
             if hb is not None:

@@ -54,6 +54,14 @@ def main():
         wm = sum(w[k]) / len(w[k]) if w.get(k) else 0.0
         kernels[k] = dict(fetch_size_kb=fm, write_size_kb=wm, launches=len(f.get(k, [])),
                           hbm_bytes_per_launch=(2 * fm + wm) * 1024)
+        # the Decompose NTT runs two launch shapes per MulRelin (1792 and 896 limbs) and the engine may settle on a different kernel form for each:
+        # the two shapes apart (told by what a dispatch writes; the dispatches of the two passes are in the same order)
+        if k in ("ntt16_fwd_kernel<true>", "ntt32_fwd_kernel<true>") and f.get(k) and w.get(k) and len(f[k]) == len(w[k]) and max(w[k]) > 1.5 * min(w[k]):
+            thr = 0.5 * (max(w[k]) + min(w[k]))
+            for name, sel in (("large", [i for i, v in enumerate(w[k]) if v > thr]), ("small", [i for i, v in enumerate(w[k]) if v <= thr])):
+                if sel:
+                    fs, ws = sum(f[k][i] for i in sel) / len(sel), sum(w[k][i] for i in sel) / len(sel)
+                    kernels[k][name] = dict(fetch_size_kb=fs, write_size_kb=ws, launches=len(sel), hbm_bytes_per_launch=(2 * fs + ws) * 1024)
     # a kernel with a single template instance in the run is also listed under its bare name (bench.py's timing classes
     # do not spell the template arguments of inner_product_kernel<NT>)
     bare = collections.defaultdict(list)
