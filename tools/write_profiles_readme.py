@@ -147,6 +147,7 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
 * under `rocprofv3 --kernel-trace`, overlap off: {no["value"]:.0f} MulRelin/s ({no["ms_per_step"]:.3f} ms); overlap on: {ov["value"]:.0f} MulRelin/s ({ov["ms_per_step"]:.3f} ms).
 * **Box to box** the figures move by ± 3 %, and round 4 met two kinds of parts — or states of a part: the configured cap reads 1400 W on both — that differ in what the forward NTT kernels do inside the MulRelin (below): on most the single-pass
   kernel is ahead (`MKHE_NTT32=1` against `=0`, same call: 1230 MulRelin/s / `roofline.frac` 0.530 against 1232 / 0.519; 1214 / 0.532 against 1192–1199 / 0.505–0.508; 1214 / 0.521 against 1207 / 0.508), on some it is throttled (1162 / 0.463 against 1180 / 0.492; 1151 / 0.465 against 1187 / 0.512).
+  (Those pairs predate the F1 fusion below, which added ≈ 100 MulRelin/s to both columns.)  Default `bench.py` with the final library on five other boxes: 1337 MulRelin/s / 0.528 and 1353 / 0.515 (1792-limb shape on the single-pass kernel, 896-limb shape on the two-pass one), 1335 / 0.498 (the same choice), 1313 / 0.491 and 1298 / 0.493 (two-pass for both).
   The engine measures which kernel gives the shorter operation in the process at hand (`MKHE_NTT32=2`, default) — this set: **{C.get("ntt_kernel_choice")}**; forced in the same call: single-pass {plh_value:.0f} / {plh_frac:.3f}, two-pass {pl16_value:.0f} / {pl16_frac:.3f}.
 
 Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per step.  "algorithmic GB/s" is the byte model of DESIGN.md §4 (`roofline.kernels_over_peak` = {R.get("kernels_over_peak")});
