@@ -1,0 +1,147 @@
+// Package mkrlwegpu, batchgpu.go: B inputs of ONE shape per call (mkhe_*_batch; no reference counterpart -- the Go evaluator issues one operation at
+// a time).  A service that evaluates one circuit on many inputs calls these instead of B single operations: every output equals the single-operation
+// wrapper's on the same input bit for bit (tests/test_gpu_batch.py), and on the small rings the throughput is 3x (DESIGN.md section 4 "B inputs in
+// lock step").  All inputs of a call have the same ids and level; keys and CRS belong to the parties and are shared; an operand that is the same for
+// every input (a model) is passed B times.  Un-built here like the rest of the shim (no Go toolchain in the build image); its C calls are checked
+// against include/mkhe.h by tests/test_go_shim_static.py.
+package mkrlwegpu
+
+/*
+#include <stdlib.h>
+#include "mkhe.h"
+*/
+import "C"
+
+import (
+	"unsafe"
+)
+
+// ctArray copies ciphertext handles into C memory (see swkArray).  The caller frees it.
+func ctArray(cts []*Ciphertext) **C.mkhe_ct {
+	arr := (**C.mkhe_ct)(C.malloc(C.size_t(len(cts)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	s := unsafe.Slice(arr, len(cts)+1)
+	for i, c := range cts {
+		s[i] = c.h
+	}
+	s[len(cts)] = nil
+	return arr
+}
+
+// NewCiphertextBatch creates B ciphertexts of one shape as views of one pooled block (mkhe_ct_create_batch); Close them one by one.
+func (ctx *Context) NewCiphertextBatch(ids []string, level int, B int) []*Ciphertext {
+	cids := make([]C.int, len(ids)+1)
+	for i, id := range ids {
+		cids[i] = ctx.id(id)
+	}
+	arr := (**C.mkhe_ct)(C.malloc(C.size_t(B+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(arr))
+	must(C.mkhe_ct_create_batch(ctx.c, C.int(B), C.int(len(ids)), &cids[0], C.int(level+1), arr))
+	s := unsafe.Slice(arr, B)
+	out := make([]*Ciphertext, B)
+	for i := range out {
+		out[i] = &Ciphertext{h: s[i], ids: append([]string(nil), ids...), ctx: ctx}
+	}
+	return out
+}
+
+// NewSwitchingKeyBatch creates count switching keys (hoisted forms) as views of one pooled block (mkhe_swk_create_batch).
+func (ctx *Context) NewSwitchingKeyBatch(count int) []*SwitchingKey {
+	arr := (**C.mkhe_swk)(C.malloc(C.size_t(count+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(arr))
+	must(C.mkhe_swk_create_batch(ctx.c, C.int(count), arr))
+	s := unsafe.Slice(arr, count)
+	out := make([]*SwitchingKey, count)
+	for i := range out {
+		out[i] = &SwitchingKey{h: s[i], ctx: ctx}
+	}
+	return out
+}
+
+// HoistedFormBatch: mkckks.Evaluator.HoistedForm (mkckks/evaluator.go:543-553) of B ciphertexts; the result holds len(ids) keys per input, input
+// after input, aligned with the ids.
+func (ctx *Context) HoistedFormBatch(cts []*Ciphertext, level int) []*SwitchingKey {
+	if len(cts) == 0 {
+		return nil
+	}
+	out := ctx.NewSwitchingKeyBatch(len(cts) * len(cts[0].ids))
+	in := ctArray(cts)
+	defer C.free(unsafe.Pointer(in))
+	arr := swkArray(out)
+	defer C.free(unsafe.Pointer(arr))
+	must(C.mkhe_hoisted_form_batch(ctx.c, C.int(level), C.int(len(cts)), in, arr))
+	return out
+}
+
+// MulRelinBatch: KeySwitcher.MulAndRelin[Hoisted] (mkrlwe/keyswitch_hoisted.go:44-179) for B pairs, followed by the single Rescale of
+// mkckks.Evaluator.mulRelinHoisted (mkckks/evaluator.go:558-581) when rescale is set (out is then one level below the product).  hoisted0 /
+// hoisted1: HoistedFormBatch results or nil (the engine hoists).
+func (ctx *Context) MulRelinBatch(op0, op1 []*Ciphertext, hoisted0, hoisted1 []*SwitchingKey, rk RelinKeys, crsU *SwitchingKey, rescale bool, out []*Ciphertext) {
+	if len(op0) == 0 {
+		return
+	}
+	b1 := handles(op1[0].ids, rk, 0)
+	d0 := handles(op0[0].ids, rk, 1)
+	v0 := handles(op0[0].ids, rk, 2)
+	a0, a1, ao := ctArray(op0), ctArray(op1), ctArray(out)
+	defer C.free(unsafe.Pointer(a0))
+	defer C.free(unsafe.Pointer(a1))
+	defer C.free(unsafe.Pointer(ao))
+	var h0, h1 **C.mkhe_swk
+	if hoisted0 != nil {
+		h0 = swkArray(hoisted0)
+		defer C.free(unsafe.Pointer(h0))
+	}
+	if hoisted1 != nil {
+		h1 = swkArray(hoisted1)
+		defer C.free(unsafe.Pointer(h1))
+	}
+	must(C.mkhe_mul_relin_batch(ctx.c, C.int(len(op0)), a0, a1, h0, h1,
+		(**C.mkhe_swk)(unsafe.Pointer(&b1[0])), (**C.mkhe_swk)(unsafe.Pointer(&d0[0])),
+		(**C.mkhe_swk)(unsafe.Pointer(&v0[0])), crsU.h, b2i(rescale), ao))
+}
+
+// RotateBatch: KeySwitcher.RotateHoisted / Rotate (mkrlwe/keyswitch_hoisted.go:183-247, keyswitch.go:234-298) of B ciphertexts by one rotation
+// index; hoisted: HoistedFormBatch result or nil; rk aligned with the ids, crs = params.CRS[rotidx].
+func (ctx *Context) RotateBatch(in []*Ciphertext, rotidx int, hoisted []*SwitchingKey, rk []*SwitchingKey, crs *SwitchingKey, out []*Ciphertext) {
+	if len(in) == 0 {
+		return
+	}
+	ai, ao := ctArray(in), ctArray(out)
+	defer C.free(unsafe.Pointer(ai))
+	defer C.free(unsafe.Pointer(ao))
+	var h **C.mkhe_swk
+	if hoisted != nil {
+		h = swkArray(hoisted)
+		defer C.free(unsafe.Pointer(h))
+	}
+	r := swkArray(rk)
+	defer C.free(unsafe.Pointer(r))
+	must(C.mkhe_rotate_batch(ctx.c, C.uint64_t(ctx.params.GaloisElementForColumnRotationBy(rotidx)), C.int(len(in)), ai, h, r, crs.h, ao))
+}
+
+// AddBatch / SubBatch: mkckks.Evaluator.AddNew / SubNew (mkckks/evaluator.go:316-356) for B pairs (scales already matched by the caller).
+func (ctx *Context) AddBatch(op0, op1, out []*Ciphertext) { ctx.binaryBatch(0, op0, op1, out) }
+func (ctx *Context) SubBatch(op0, op1, out []*Ciphertext) { ctx.binaryBatch(1, op0, op1, out) }
+
+func (ctx *Context) binaryBatch(op int, op0, op1, out []*Ciphertext) {
+	if len(op0) == 0 {
+		return
+	}
+	a0, a1, ao := ctArray(op0), ctArray(op1), ctArray(out)
+	defer C.free(unsafe.Pointer(a0))
+	defer C.free(unsafe.Pointer(a1))
+	defer C.free(unsafe.Pointer(ao))
+	must(C.mkhe_ct_binary_batch(ctx.c, C.int(op), C.int(len(op0)), a0, a1, ao))
+}
+
+// MulPtxtBatch: mkckks.Evaluator.MulPtxtNew (mkckks/evaluator.go:465-481) for B ciphertexts and one resident plaintext, followed by nbRescale
+// DivRoundByLastModulus steps (the host decides nbRescale from the scales, :376-384).
+func (ctx *Context) MulPtxtBatch(in []*Ciphertext, pt *Plaintext, nbRescale int, out []*Ciphertext) {
+	if len(in) == 0 {
+		return
+	}
+	ai, ao := ctArray(in), ctArray(out)
+	defer C.free(unsafe.Pointer(ai))
+	defer C.free(unsafe.Pointer(ao))
+	must(C.mkhe_ct_mul_ptxt_batch(ctx.c, C.int(len(in)), ai, pt.dev, C.int(nbRescale), ao))
+}

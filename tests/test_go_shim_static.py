@@ -90,11 +90,17 @@ def classify(expr, fn_src):
         # declared in the enclosing function (parameter list or body) with a recognisable type or initialiser
         if re.search(r"\b%s\b(?:\s*,\s*[A-Za-z_][A-Za-z0-9_]*)*\s+(?:unsafe\.Pointer|\*+C\.[A-Za-z0-9_]+)" % name, fn_src):
             return "pointer", None
-        if re.search(r"(?:\b%s\b|\b[A-Za-z_0-9]+\s*,\s*%s\b|\b%s\s*,\s*[A-Za-z_0-9]+(?:\s*,\s*[A-Za-z_0-9]+)*)\s*:?=\s*(?:swkList|swkArray)\(" % (name, name, name), fn_src):
-            return "pointer", (2, "mkhe_swk")
-        if re.search(r"\b%s\b[^\n]*:?=\s*[^\n]*(?:swkList|swkArray)\(" % name, fn_src):
-            return "pointer", (2, "mkhe_swk")
-        if re.search(r"\b%s\s*=\s*\(\*+C\." % name, fn_src) or re.search(r"var\s+[^\n]*\b%s\b[^\n]*\*+C\." % name, fn_src):
+        # handle arrays built by the shim's helpers: swkList / swkArray -> **C.mkhe_swk, ctArray -> **C.mkhe_ct (batchgpu.go); in a multiple
+        # assignment every name on the left takes the helper of the statement (the shim only ever mixes one helper per statement)
+        for helpers, ctype in ((r"(?:swkList|swkArray)", "mkhe_swk"), (r"ctArray", "mkhe_ct")):
+            if re.search(r"(?:\b%s\b|\b[A-Za-z_0-9]+\s*,\s*%s\b|\b%s\s*,\s*[A-Za-z_0-9]+(?:\s*,\s*[A-Za-z_0-9]+)*|\b[A-Za-z_0-9]+\s*,\s*[A-Za-z_0-9]+\s*,\s*%s\b|\b[A-Za-z_0-9]+\s*,\s*%s\s*,\s*[A-Za-z_0-9]+)\s*:?=\s*%s\(" % (name, name, name, name, name, helpers), fn_src):
+                return "pointer", (2, ctype)
+            if re.search(r"\b%s\b[^\n]*:?=\s*[^\n]*%s\(" % (name, helpers), fn_src):
+                return "pointer", (2, ctype)
+        m2 = re.search(r"\b%s\s*:?=\s*\((\*+)C\.([A-Za-z0-9_]+)\)\(" % name, fn_src)
+        if m2:
+            return "pointer", (len(m2.group(1)), m2.group(2))
+        if re.search(r"var\s+[^\n]*\b%s\b[^\n]*\*+C\." % name, fn_src):
             return "pointer", None
         if re.search(r"\b%s\s*:?=\s*C\.(int|uint64_t|size_t|int32_t)\(" % name, fn_src):
             return "scalar", None
