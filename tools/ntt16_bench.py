@@ -1,6 +1,8 @@
 """Decompose-fused forward NTT at N = 2^15: time per launch for the launch sizes of a 4-party MulRelin (1792 and 896 limbs),
 HIP events on the context stream (mkhe_prof_*), one line per launch size.  Usage: [MKHE_LIB=...] python tools/ntt16_bench.py [reps]
-Also checks the hoisted digits of one party against a second evaluation with MKHE_NTT16 toggled in a child process (--ref file)."""
+Also checks the hoisted digits of one party against a second evaluation with MKHE_NTT16 toggled in a child process (--ref file).
+N = 2^15 has two forward kernels: MKHE_NTT32=0 / 1 time one of them; with the default (2) the engine measures both inside this loop and settles, so
+both appear, each with its own launch count (tools/profile_round.sh runs this tool once per kernel)."""
 import ctypes as C, os, sys, time, hashlib
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
