@@ -19,6 +19,13 @@
  *  - One context per Evaluator, calls on a context serialized by the caller (the reference is
  *    not reentrant either: shared pools keyswitch.go:12-15).  All work is enqueued on the
  *    context's HIP stream; *_download and mkhe_ctx_sync synchronize.
+ *
+ * Environment (the COMPLETE list of variables libmkhe_hip.so reads; each once per process)
+ *  - MKHE_NTT32   = 0 | 1 | 2   forward NTT at N = 2^15 where two kernels apply (same bits): two-pass, single-pass, or (default 2)
+ *                               whichever a measurement inside the caller's workload finds faster; mkhe_ctx_set_ntt_choice pins it per context
+ *  - MKHE_POOL_GB = <GiB>       device-wide bound of the buffer pools that recycle freed handles (default 32; fractions allowed; 0 = keep nothing)
+ * Every other MKHE_* variable named in DESIGN.md section 6 is A/B instrumentation and exists only in the diagnostic build
+ * libmkhe_hip_switches.so (csrc/switches.h, `make switches`); the product library ignores them.
  */
 #ifndef MKHE_H
 #define MKHE_H
@@ -220,7 +227,9 @@ int  mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe
  *      On the small rings (PN14QP439, mkckks/mkckks_benchmark_test.go:13; cnn's PN14QP433, cnn/cnn_test.go:80-96) an operation is a chain of
  *      launches of a few dozen limbs each; B inputs in lock step are the same launches with B times the items.  All ciphertexts of one list
  *      have the same ids and limb count; keys and CRS are per party and shared by the inputs; an operand that is the same ciphertext for
- *      every input (cnn's model) is passed nbatch times; outputs are distinct handles.  Hoisted forms are flat lists [b * n + a] (input b,
+ *      every input (cnn's model) is passed nbatch times; outputs are distinct handles, and output k must not be an INPUT of another item j != k
+ *      (an error: the items of a batch run as one launch set, in no order; output k may be input k where the single operation may run in place).
+ *      Hoisted forms are flat lists [b * n + a] (input b,
  *      party component a) or NULL (the engine hoists).  Each output equals the single-operation entry point's, bit for bit.
  *        mkhe_hoisted_form_batch : mkckks.Evaluator.HoistedForm            mkckks/evaluator.go:543-553
  *        mkhe_rotate_batch       : KeySwitcher.RotateHoisted / Rotate      mkrlwe/keyswitch_hoisted.go:183-247, keyswitch.go:234-298
@@ -356,7 +365,16 @@ int  mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf);
 /* N = 2^15, where two forward kernels apply (same bits): by default (MKHE_NTT32=2) the context times a block of launches of each inside the caller's
  * workload and keeps the faster one per launch shape.  The kernel it has settled on for Decompose launches of `limbs` limb-NTTs: 1 = single-pass
  * (ntt32_fwd_kernel), 0 = two-pass (ntt16_fwd_kernel), -1 = still measuring, never launched, or fixed by MKHE_NTT32 = 0 / 1. */
-int  mkhe_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose);
+int  mkhe_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose);      /* -2: error (mkhe_last_error) */
+/* Pins that choice instead of measuring it, so that a run can be repeated with the kernels of an earlier one (a bench line records
+ * config.ntt_kernel_choice): choice 1 = single-pass, 0 = two-pass, -1 = forget and measure again.  limbs > 0: launches of that many limb-NTTs
+ * (decompose = 1: Decompose launches, 0: plain forward transforms); limbs <= 0: every shape of the context, met so far or not.  Same bits either way. */
+int  mkhe_ctx_set_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose, int choice);
+/* The stream-ordered buffer pools (freed ciphertext / key handles are kept for reuse, bounded per DEVICE by MKHE_POOL_GB): bytes this context's
+ * pool holds, and "hand everything the pools of this context's device hold back to the driver" (one device-wide synchronisation; the engine does
+ * this by itself when an allocation fails for lack of memory and retries once). */
+long long mkhe_pool_held_bytes(mkhe_ctx* ctx);                          /* -1: error */
+int  mkhe_pool_trim(mkhe_ctx* ctx);
 int  mkhe_prof_nclass(void);
 const char* mkhe_prof_name(int cls);
 int  mkhe_prof_collect(mkhe_ctx* ctx, double* ms, long* launches, double* alg_bytes);

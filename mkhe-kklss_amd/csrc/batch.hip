@@ -35,6 +35,14 @@ void same_shape(const std::vector<const Ct*>& v, const char* what) {
         if (c->n != v[0]->n || c->limbs != v[0]->limbs || c->ids != v[0]->ids) throw Error(std::string("mkhe: the ciphertexts of a batch must have one shape (") + what + ")");
     }
 }
+// Aliasing rule of the batch entry points (include/mkhe.h): output k may be input k of the same call where the single-operation entry point
+// allows in-place evaluation; it must never be an input of ANOTHER item -- the items of a batch run in one launch set, in no order.
+void no_cross_alias(const std::vector<const Ct*>& ins, const std::vector<Ct*>& outs, const char* what) {
+    for (size_t k = 0; k < outs.size(); ++k)
+        for (size_t j = 0; j < ins.size(); ++j)
+            if (j != k && ins[j] && outs[k] && ins[j]->d == outs[k]->d)
+                throw Error(std::string("mkhe: output ") + std::to_string(k) + " of the batch is input " + std::to_string(j) + " of another item (" + what + ")");
+}
 }  // namespace
 
 void Context::hoisted_form_batch(int level, const std::vector<const Ct*>& cts, const std::vector<Swk*>& outs) {
@@ -62,6 +70,7 @@ void Context::rotate_batch(u64 galEl, const std::vector<const Ct*>& ins, const s
     if (ins[0]->limbs < L) throw Error("Cannot Rotate: ctIn and ctOut have different levels");
     if (outs[0]->n != n || outs[0]->ids != ins[0]->ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
     if (!hoists.empty() && hoists.size() != B * (size_t)n) throw Error("mkhe: rotate_batch: one hoisted form per party component");
+    no_cross_alias(ins, outs, "Rotate");
     bool alias = false;
     for (size_t b = 0; b < B; ++b) alias = alias || ins[b]->d == outs[b]->d;
     if (n == 0 || 2 * n > EXT_MAX_ITEMS || alias || galEl == 0) {
@@ -108,6 +117,7 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     if (op1.size() != B || outs.size() != B) throw Error("mkhe: mul_relin_batch: one op1 and one output per op0");
     if (masked_) throw Error("mkhe: a limb-sharded context evaluates one operation at a time");
     same_shape(op0, "MulRelin op0"); same_shape(op1, "MulRelin op1");
+    no_cross_alias(op0, outs, "MulRelin op0"); no_cross_alias(op1, outs, "MulRelin op1");
     { std::vector<const Ct*> o(outs.begin(), outs.end()); same_shape(o, "MulRelin outputs"); }
     const Ct& o0 = *outs[0];
     const int L = o0.limbs + (rescale_out ? 1 : 0), level = L - 1, n0 = op0[0]->n, n1 = op1[0]->n, nout = o0.n;
@@ -134,11 +144,11 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     const bool own0 = hoist0.empty(), own1 = hoist1.empty() && !same;
     const size_t P0 = (size_t)op0[0]->limbs * N, P1 = (size_t)op1[0]->limbs * N, PO = (size_t)L * N, SW = swk_words();
     const bool fold = n0 >= 1 && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
-    static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
+    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
     const bool fuse_x = fuse_env && n0 >= 1 && n0 <= 4;      // x_b = sum_i d_i (.) h(c0_{b,i}) as a by-product of input b's step F1
-    static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
+    static const int fuse_y_env = MKHE_AB_INT("MKHE_FUSE_Y", 1);
     const bool fuse_y = fuse_x && fuse_y_env && n1 >= 1 && n1 <= 4;    // ... and y_b computed in the same threads (ext_inner_xy_batch_kernel<G0, G1>), never stored
-    static const int fuse_e_env = getenv("MKHE_FUSE_E") ? atoi(getenv("MKHE_FUSE_E")) : 1;
+    static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
     const bool fuse_e = fuse_y && fuse_e_env;                          // ... and step E: input b's <h(c1_j), x_b> as precomputed items of the tail batch
     const size_t per_b = (size_t)(2 + n0 + n1) * PO + (size_t)(1 + nout) * PO * ((fold ? 1 : 0) + (rescale_out ? 1 : 0)) + 2 * SW + (size_t)n0 * PO + (size_t)n0 * SW +
                          (own0 ? (size_t)n0 * SW : 0) + (own1 ? (size_t)n1 * SW : 0) + (fuse_e ? (size_t)n1 * mtot * N : 0);
@@ -325,6 +335,7 @@ void Context::ct_binary_batch(int op, const std::vector<const Ct*>& a, const std
     if (!B) return;
     if (b.size() != B || outs.size() != B) throw Error("mkhe: ct_binary_batch: one op1 and one output per op0");
     same_shape(a, "Add op0"); same_shape(b, "Add op1");
+    no_cross_alias(a, outs, "Add op0"); no_cross_alias(b, outs, "Add op1");
     { std::vector<const Ct*> o(outs.begin(), outs.end()); same_shape(o, "Add outputs"); }
     const Ct& A = *a[0]; const Ct& Bc = *b[0]; const Ct& O = *outs[0];
     const int L = O.limbs;
@@ -365,6 +376,7 @@ void Context::ct_mul_ptxt_batch(const std::vector<const Ct*>& ins, const u64* de
     if (!B) return;
     if (outs.size() != B) throw Error("mkhe: ct_mul_ptxt_batch: one output per input");
     same_shape(ins, "MulPtxt");
+    no_cross_alias(ins, outs, "MulPtxt");
     { std::vector<const Ct*> o(outs.begin(), outs.end()); same_shape(o, "MulPtxt outputs"); }
     const int L = ins[0]->limbs, np_ = 1 + ins[0]->n, level = L - 1;
     if (nb < 0 || nb > level) throw Error("cannot Rescale: input Ciphertext already at level 0");

@@ -679,13 +679,33 @@ int mkhe_set_overlap(mkhe_ctx* ctx, int on) { MKHE_TRY({ need(ctx)->sync(); need
 int mkhe_ntt_trace(mkhe_ctx* ctx, void* dev_buf) { need(ctx)->ntt_trace = (u64*)dev_buf; return 0; }
 int mkhe_prof_enable(mkhe_ctx* ctx, int on) { MKHE_TRY(need(ctx)->prof_enable(on != 0)) }
 int mkhe_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose) {
-    Context* c = need(ctx);
-    for (int lazy = 0; lazy < 2; ++lazy) {
-        auto it = c->ntt_tune_.find((limbs << 2) | (decompose ? 2 : 0) | lazy);
-        if (it != c->ntt_tune_.end() && it->second.decided >= 0) return it->second.decided;
+    g_last_ctx = nullptr;
+    try {
+        Context* c = need(ctx);
+        for (int lazy = 0; lazy < 2; ++lazy) {
+            auto it = c->ntt_tune_.find((limbs << 2) | (decompose ? 2 : 0) | lazy);
+            if (it != c->ntt_tune_.end() && it->second.decided >= 0) return it->second.decided;
+        }
+        return c->ntt_forced_ >= 0 ? c->ntt_forced_ : -1;
     }
-    return -1;
+    catch (const std::exception& e) { g_err = e.what(); return -2; }
+    catch (...) { g_err = "mkhe: unknown error"; return -2; }
 }
+int mkhe_ctx_set_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose, int choice) {
+    MKHE_TRY({
+        Context* c = need(ctx);
+        if (choice < -1 || choice > 1) throw Error("mkhe: ntt choice must be -1 (measure), 0 (two-pass) or 1 (single-pass)");
+        if (limbs <= 0) { c->ntt_forced_ = choice; for (auto& kv : c->ntt_tune_) c->ntt_reset(kv.second, choice); }
+        else for (int lazy = 0; lazy < 2; ++lazy) c->ntt_reset(c->ntt_tune_[(limbs << 2) | (decompose ? 2 : 0) | lazy], choice);
+    })
+}
+long long mkhe_pool_held_bytes(mkhe_ctx* ctx) {
+    g_last_ctx = nullptr;
+    try { return (long long)(need(ctx)->pool_held_words() * sizeof(u64)); }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+    catch (...) { g_err = "mkhe: unknown error"; return -1; }
+}
+int mkhe_pool_trim(mkhe_ctx* ctx) { MKHE_TRY(need(ctx)->pool_trim_device()) }
 int mkhe_prof_nclass(void) { return Context::PROF_NCLASS; }
 const char* mkhe_prof_name(int cls) {
     static const char* names[] = {"ntt_fwd_kernel<N,1,true>  (Decompose, q<2^57)", "ntt_fwd_kernel<N,0,true>  (Decompose, q>=2^57)",

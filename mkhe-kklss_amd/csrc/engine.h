@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <string>
 #include <atomic>
+#include <mutex>
 #include <map>
 #include <vector>
 #include <stdexcept>
@@ -199,6 +200,9 @@ class Context {
     // synchronise or hipFree, the words go back to a size-keyed free list and are reused by the next
     // create (all work of a context is ordered on its main stream, so reuse is safe).
     u64* pool_alloc(size_t words);
+    size_t pool_take_all(std::vector<u64*>& out);      // empties the free list into `out` (the caller synchronises the device, then frees); words taken
+    size_t pool_held_words();                          // what this context's free list holds
+    size_t pool_trim_device();                         // every context's free list of this device back to the driver; words released
     void pool_free(u64* p, size_t words, const HandleUsers* users = nullptr);   // users == nullptr / exposed: every live context counts
     void sync() { const unsigned long long s0 = seq_.load(); MKHE_HIP(hipStreamSynchronize(stream)); if (completed_.load() < s0) completed_.store(s0); }
     // cross-context ordering on one device: everything enqueued on this context from now on starts after everything
@@ -318,6 +322,7 @@ class Context {
     // that names the handle), so a temporary that never left its context costs nothing and never orders independent forks.
     struct FreeEntry { size_t words; u64* p; std::vector<std::pair<seq_t, seq_t>> behind; };      // (uid of a context, its seq_ at the free)
     std::vector<FreeEntry> free_list_;
+    std::mutex pool_mu_;                                      // guards free_list_ (a trim may come from another context's thread); taken AFTER the registry mutex, never before
     hipEvent_t fence_ev_ = nullptr;
     void registry_add();
     void init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP, const u64* QMul, int nqm_, u64 T);     // the constructor's body
@@ -355,6 +360,8 @@ class Context {
                      // start events of the timed launches that have not been turned into periods yet (the host runs ahead of the GPU): ring[head .. head + inflight)
                      hipEvent_t e0[RING] = {}; int which[RING] = {}; int head = 0, inflight = 0; int slot = -1; };
     std::map<long, NttTune> ntt_tune_;
+    int ntt_forced_ = -1;                            // mkhe_ctx_set_ntt_choice(limbs <= 0): the answer for every shape that has no entry of its own
+    void ntt_reset(NttTune& t, int choice);          // pins a shape (0 / 1) or makes it measure again (-1); samples in flight are dropped
     int ntt_pick(long key, NttTune*& sampling);      // 1 = H32, 0 = H16; sampling != nullptr: this launch is timed (record e0[slot] in front of it)
   private:
     bool prof_on_ = false;

@@ -60,7 +60,21 @@ template <typename T> static T* dev_upload(const std::vector<T>& v) {
     if (!v.empty()) MKHE_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return d;
 }
-static u64* dev_alloc_words(size_t w) { u64* d = nullptr; MKHE_HIP(hipMalloc(&d, std::max<size_t>(w, 1) * sizeof(u64))); return d; }
+// Device allocation of the engine's buffers.  The stream-ordered pools (Context::pool_free) keep freed handles' memory for reuse; when the
+// driver runs out, what the pools of this device hold is handed back (one device-wide synchronisation) and the allocation is tried once more,
+// so that a process never fails with most of HBM sitting in free lists.
+static size_t trim_device_pools();
+static u64* dev_alloc_words(size_t w) {
+    u64* d = nullptr;
+    const size_t bytes = std::max<size_t>(w, 1) * sizeof(u64);
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        if (trim_device_pools() > 0) e = hipMalloc(&d, bytes);
+    }
+    if (e != hipSuccess) throw Error(std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    return d;
+}
 
 // ------------------------------------------------------------------ construction
 Context::Context(int logN_, const u64* Q, int nq_, const u64* P, int np_, int gamma_,
@@ -157,7 +171,7 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
         // the product as hi 2^32 + lo with lo UNSIGNED, the pair is u = w 2^30 mod q in [0, q) with non-negative radix-2^30 digits and
         // v = w 2^62 mod q balanced, one round of radix 2^30 (ntt16_kernels.hip mm30u).  psi31n: the pairs of -psi[1..3] (the second pass of
         // the cross-half stage multiplies by -w; the unsigned digits cannot be negated in place), in the format of the modulus's class.
-        static const int uclass_on = [] { const char* e = getenv("MKHE_H16_UCLASS"); return (e && *e) ? atoi(e) : 1; }();
+        static const int uclass_on = MKHE_AB_INT("MKHE_H16_UCLASS", 1);
         std::vector<u64> p31(2 * (size_t)mall * N), p31n(8 * (size_t)mall, 0);
         for (int i = 0; i < mall; ++i) {
             const u64 q = moduli[i];
@@ -253,7 +267,7 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
         d_psiinv31 = dev_upload(pi31); d_inv31c = dev_upload(fin);
         // F class (N = 2^16 only: the quarter sub-transforms behind the radix-4 producers): moduli with 80 q < 2^52 run double-precision butterflies;
         // their forward twiddles as plain residues in double format (MKHE_H16_FCLASS=0 switches the class off)
-        static const int fclass_on = [] { const char* e = getenv("MKHE_H16_FCLASS"); return (e && *e) ? atoi(e) : 1; }();
+        static const int fclass_on = MKHE_AB_INT("MKHE_H16_FCLASS", 1);
         if (fclass_on && logN == 16) {
             std::vector<u64> pf((size_t)mall * N, 0);
             for (int i = 0; i < mall; ++i) {
@@ -272,7 +286,7 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
         // Reduction schedule of the balanced path for inputs below 2^60 (canonical digits of any modulus): the never-reduced values must stay
         // below 2^62.9 (column sums of mm31) and grow by at most 1.03q per one-round stage (q + |x| q / 2^64) and q/2 + |x|/16 per two-round
         // stage of phase D; a partial reduction leaves |x| <= 0.51q.  Greedy from the load: reduce only where the next phase would overflow.
-        static const int lightsched = [] { const char* e = getenv("MKHE_H16_SCHED"); return (e && *e) ? atoi(e) : 1; }();
+        static const int lightsched = MKHE_AB_INT("MKHE_H16_SCHED", 1);
         h16_sched_.assign(mall, 15);
         for (int i = 0; i < mall && lightsched; ++i) {
             const double q = (double)moduli[i], H = 0.98 * 8.6e18 / q;          // 2^62.9 = 8.606e18, 2 % of slack on the bound
@@ -461,7 +475,7 @@ void Context::release_all() noexcept {
                     (void*)kg_small_, (void*)kg_g_, (void*)kg_sk_})
         if (p) (void)hipFree(p);
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
-    for (auto& f : free_list_) (void)hipFree(f.p);
+    { std::vector<u64*> mine; (void)pool_take_all(mine); for (u64* p : mine) (void)hipFree(p); }
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto& kv : ntt_tune_) for (int i = 0; i < NttTune::RING; ++i) if (kv.second.e0[i]) (void)hipEventDestroy(kv.second.e0[i]);
     ntt_tune_.clear();
@@ -474,19 +488,57 @@ void Context::release_all() noexcept {
 
 // live contexts per device: who may still be using a buffer that some context returns to its pool
 namespace {
-struct DeviceRegistry { std::mutex mu; std::vector<Context*> live; unsigned long long next_uid = 1; };
+// pooled_words: what the free lists of ALL contexts of the device hold together -- the cache bound is one budget per device (a forked
+// BatchEvaluator has four contexts; a bound per context let a process run out of memory with most of HBM in free lists)
+struct DeviceRegistry { std::mutex mu; std::vector<Context*> live; unsigned long long next_uid = 1; std::atomic<size_t> pooled_words{0}; };
 DeviceRegistry& registry(int device) { static DeviceRegistry r[64]; return r[device & 63]; }
+// MKHE_POOL_GB (configuration, include/mkhe.h): device-wide bound of the pools in GiB, fractions allowed (0 = keep nothing)
+size_t pool_cap_words() {
+    static const size_t cap = [] { const char* e = getenv("MKHE_POOL_GB"); const double gb = (e && *e) ? atof(e) : 32.0; return (size_t)((gb < 0 ? 0 : gb) * (double)(1ull << 27)); }();
+    return cap;
 }
+}
+// every free-list entry of every live context of the current device goes back to the driver; returns the words released
+static size_t trim_device_pools() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::vector<u64*> victims;
+    size_t words = 0;
+    { auto& r = registry(dev); std::lock_guard<std::mutex> g(r.mu); for (Context* c : r.live) words += c->pool_take_all(victims); }
+    if (victims.empty()) return 0;
+    (void)hipDeviceSynchronize();                      // (entries may still be read by queued work of any context)
+    for (u64* p : victims) (void)hipFree(p);
+    return words;
+}
+size_t Context::pool_trim_device() { MKHE_HIP(hipSetDevice(device)); return trim_device_pools(); }
+size_t Context::pool_take_all(std::vector<u64*>& out) {
+    std::lock_guard<std::mutex> g(pool_mu_);
+    size_t words = 0;
+    for (auto& f : free_list_) { out.push_back(f.p); words += f.words; }
+    free_list_.clear();
+    registry(device).pooled_words.fetch_sub(words);
+    return words;
+}
+size_t Context::pool_held_words() { std::lock_guard<std::mutex> g(pool_mu_); size_t w = 0; for (auto& f : free_list_) w += f.words; return w; }
 void Context::registry_add() { auto& r = registry(device); std::lock_guard<std::mutex> g(r.mu); uid_ = r.next_uid++; r.live.push_back(this); }
 void Context::registry_remove() {
     auto& r = registry(device); std::lock_guard<std::mutex> g(r.mu);
     for (size_t i = 0; i < r.live.size(); ++i) if (r.live[i] == this) { r.live.erase(r.live.begin() + i); break; }
 }
 u64* Context::pool_alloc(size_t words) {
-    for (size_t i = 0; i < free_list_.size(); ++i)
-        if (free_list_[i].words == words) {
-            const FreeEntry e = std::move(free_list_[i]);
-            free_list_.erase(free_list_.begin() + i);          // the oldest matching entry: most likely already ordered
+    FreeEntry e{0, nullptr, {}};
+    {
+        std::lock_guard<std::mutex> g(pool_mu_);
+        for (size_t i = 0; i < free_list_.size(); ++i)
+            if (free_list_[i].words == words) {
+                e = std::move(free_list_[i]);
+                free_list_.erase(free_list_.begin() + i);          // the oldest matching entry: most likely already ordered
+                registry(device).pooled_words.fetch_sub(words);
+                break;
+            }
+    }
+    if (e.p) {
+        {
             if (!e.behind.empty()) {
                 hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
                 (void)hipStreamIsCapturing(stream, &cs);
@@ -509,6 +561,7 @@ u64* Context::pool_alloc(size_t words) {
             }
             return e.p;
         }
+    }
     MKHE_HIP(hipSetDevice(device));
     return dev_alloc_words(words);
 }
@@ -535,15 +588,25 @@ void Context::pool_free(u64* p, size_t words, const HandleUsers* users) {
     // handles in flight at B = 16: the list is sized for that -- at the old bound of 64 entries every further free was a device-wide
     // synchronisation plus hipFree, and the next create a hipMalloc (119 ms per batched cnn step instead of 6).  Over the bound the OLDEST entry
     // goes back to the driver (its work is long done: one synchronisation, rare).
+    // The byte bound is ONE budget per device (DeviceRegistry::pooled_words, a running counter), MKHE_POOL_GB GiB, default 32.
+    auto& reg = registry(device);
     {
-        static const size_t cap_entries = 4096, cap_words = (size_t)(getenv("MKHE_POOL_GB") ? atof(getenv("MKHE_POOL_GB")) : 48.0) * (1ull << 27);
-        size_t held = words;
-        for (const auto& f : free_list_) held += f.words;
-        while (!free_list_.empty() && (free_list_.size() >= cap_entries || held > cap_words)) {
+        const size_t cap_entries = 4096, cap_words = pool_cap_words();
+        std::vector<u64*> evict;
+        {
+            std::lock_guard<std::mutex> g(pool_mu_);
+            while (!free_list_.empty() && (free_list_.size() >= cap_entries || reg.pooled_words.load() + words > cap_words)) {
+                reg.pooled_words.fetch_sub(free_list_.front().words);
+                evict.push_back(free_list_.front().p);
+                free_list_.erase(free_list_.begin());
+            }
+        }
+        const bool keep = reg.pooled_words.load() + words <= cap_words;     // (other contexts hold the budget: this buffer goes back to the driver itself)
+        if (!evict.empty() || !keep) {
+            (void)hipSetDevice(device);
             (void)hipDeviceSynchronize();
-            held -= free_list_.front().words;
-            (void)hipFree(free_list_.front().p);
-            free_list_.erase(free_list_.begin());
+            for (u64* q : evict) (void)hipFree(q);
+            if (!keep) { (void)hipFree(p); return; }
         }
     }
     FreeEntry e{words, p, {}};
@@ -559,6 +622,8 @@ void Context::pool_free(u64* p, size_t words, const HandleUsers* users) {
                 if (std::max(synced_with(m->uid_), m->completed_.load()) < s) e.behind.push_back({m->uid_, s});
             }
     }
+    std::lock_guard<std::mutex> g(pool_mu_);
+    reg.pooled_words.fetch_add(words);
     free_list_.push_back(std::move(e));
 }
 u64* Context::scratch(u64*& p, size_t& have, size_t want) {
@@ -715,9 +780,15 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     if (side) join_side(0);
 }
 
+void Context::ntt_reset(NttTune& t, int choice) {
+    for (int k = 0; k < 2; ++k) t.n[k] = t.req[k] = t.blk[k] = 0;
+    t.head = t.inflight = 0; t.slot = -1; t.seen = 0;       // (the events are kept and re-recorded)
+    t.decided = choice;
+}
 int Context::ntt_pick(long key, NttTune*& sampling) {
     constexpr int WARM = NttTune::WARM, SETTLE = NttTune::SETTLE, TIMED = NttTune::TIMED, RING = NttTune::RING;
     sampling = nullptr;
+    { auto it = ntt_tune_.find(key); if (it == ntt_tune_.end() && ntt_forced_ >= 0) return ntt_forced_; }
     NttTune& t = ntt_tune_[key];
     if (t.decided >= 0) return t.decided;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -853,8 +924,8 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
             // buffer (5.4 GB for the 16 operand components of an 8-party PN16QP1761 MulRelin) and the 2^15-point sub-transforms out of place from
             // there, two passes each, the second recomputing its cross stage from a second read of the source -- 6.3 GB moved per 2.1 GB Decompose
             // launch against 4.2 GB (MKHE_SPREAD_OOP=0: in place, the upper half parked in the destination and reloaded instead).
-            static const int oop_env = getenv("MKHE_SPREAD_OOP") ? atoi(getenv("MKHE_SPREAD_OOP")) : 1;
-            static const int radix4_env = getenv("MKHE_SPREAD_RADIX4") ? atoi(getenv("MKHE_SPREAD_RADIX4")) : 1;
+            static const int oop_env = MKHE_AB_INT("MKHE_SPREAD_OOP", 1);
+            static const int radix4_env = MKHE_AB_INT("MKHE_SPREAD_RADIX4", 1);
             const size_t item_words = (size_t)beta_max * mtot * N;
             bool h16 = false;
             if (logN == 16 && !masked_ && d_psi31) {
@@ -912,7 +983,7 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
 // items: independent external products  dst (+)= ModDown( sum_i bg[i] (.) ah[i] )
 // front half: inner products over the gadget digits + lazy inverse NTT of up to EXT_MAX_ITEMS items into c1 ([item][mtot][N])
 int Context::ext_merge_members(int level) const {
-    static const int on = getenv("MKHE_EXT_MERGE") ? atoi(getenv("MKHE_EXT_MERGE")) : 1;
+    static const int on = MKHE_AB_INT("MKHE_EXT_MERGE", 1);
     if (!on || masked_ || np > 4) return 0;
     static_assert(VI_MAX == 4 && MD_VI_MAX == 4 && EXT_MAX_ITEMS == 64 && NTT_MAX_ITEMS == 64, "ExtMerge is sized for these");
     // members per virtual item: the padded slot list of the inverse launch has to fit, and the merged multSum adds
@@ -1173,12 +1244,12 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
                             const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                             const Swk& crs_u, Ct& out) {
     mr_prepare(op0, op1, hoist0, hoist1, true, out);
-    static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
-    static const int wide_env = getenv("MKHE_FUSE_X_WIDE") ? atoi(getenv("MKHE_FUSE_X_WIDE")) : 1;      // A/B: the by-product for five to sixteen parties
+    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
+    static const int wide_env = MKHE_AB_INT("MKHE_FUSE_X_WIDE", 1);      // A/B: the by-product for five to sixteen parties
     const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= (wide_env ? 16 : 4) && !masked_;
     // y inside the F1 kernel as well (round 4): the thread that forms <h(c0_i), y> at a coefficient needs y there and nowhere else, so that y is
     // neither a launch nor 2 x 59 MB of traffic -- when op1 has as many parties as op0 (at most four: the group form of the kernel)
-    static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
+    static const int fuse_y_env = MKHE_AB_INT("MKHE_FUSE_Y", 1);
     const bool fuse_y = fuse && fuse_y_env && plan_.n1 >= 1 && (plan_.n0 <= 4 ? plan_.n1 <= 4 : (plan_.n0 <= 8 && plan_.n1 == plan_.n0));      // (one to four parties per operand: ext_inner_xy_kernel<G0, G1>; five to eight in both: ext_inner_xy_wide_kernel)
     mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse, fuse_y);
     mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
@@ -1197,7 +1268,7 @@ void Context::mul_relin_rescale(const Ct& op0, const Ct& op1, const Swk* const* 
     Ct full; full.n = out.n; full.limbs = L; full.ids = out.ids;
     const size_t words = (size_t)(1 + out.n) * L * N;
     full.d = pool_alloc(words);
-    static const int fuse_env = getenv("MKHE_FUSE_RESCALE") ? atoi(getenv("MKHE_FUSE_RESCALE")) : 1;
+    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_RESCALE", 1);
     rs_maps_.clear();
     if (fuse_env && !masked_) rs_maps_.push_back(RsMap{full.d, out.d, 1 + out.n, out.limbs, false});
     try {
@@ -1277,7 +1348,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
         // With at least one party in op0 every output slot receives an external product in steps E / F2.  The tensor term then
         // stays in the NTT domain, times P, and joins the summed Q parts of that (merged) batch: ModDown's (x - lift) * P^-1
         // returns it as itself, canonical like everything else -- no inverse NTT for step D.  MKHE_TENSOR_FOLD=0: A/B switch.
-        static const int fold_env = getenv("MKHE_TENSOR_FOLD") ? atoi(getenv("MKHE_TENSOR_FOLD")) : 1;
+        static const int fold_env = MKHE_AB_INT("MKHE_TENSOR_FOLD", 1);
         const bool fold = fold_env && n0 >= 1 && !masked_ && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
         u64* tout = out.d;
         if (fold) { tout = scratch(tens_, tens_words_, (size_t)(1 + out.n) * PO); p.tens = tout; }
@@ -1377,7 +1448,7 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
         // ... and step E: the thread holds x[d] and h(c1_j)[d], so <h(c1_j), x> costs it G more accumulators, and x is never stored nor the h(c1_j) read
         // again by the tail batch -- whose c1 slots 2 n0 .. 2 n0 + n1 - 1 (the E items) are filled here: the scratch is sized for the tail now, so
         // that it is the same allocation then (nothing else of a MulAndRelin touches it in between)
-        static const int fuse_e_env = getenv("MKHE_FUSE_E") ? atoi(getenv("MKHE_FUSE_E")) : 1;
+        static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
         if (fuse_e_env && 2 * n0 + p.n1 <= EXT_MAX_ITEMS) {
             scratch(c1b_, c1b_words_, (size_t)(2 * n0 + p.n1) * mtot * N);
             ext_e_slot_ = 2 * n0;
@@ -1952,7 +2023,7 @@ void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u
     if (fused && !bfv_yk1_.empty()) {
         ext_ykeys_ = bfv_yk1_; ext_ykeys2_ = bfv_yk2_;
         for (int a = 0; a < n1; ++a) { ext_yh_.push_back(hoist_slot(1, a).d); ext_yh2_.push_back(hoist_slot(4, a).d); }
-        static const int fuse_e_env = getenv("MKHE_FUSE_E") ? atoi(getenv("MKHE_FUSE_E")) : 1;
+        static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
         if (fuse_e_env && 2 * n0 + n1 <= EXT_MAX_ITEMS) {
             scratch(c1b_, c1b_words_, (size_t)(2 * n0 + n1) * mtot * N);
             ext_e_slot_ = 2 * n0;
@@ -1989,9 +2060,9 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
                             const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
                             const Swk& crs_u, Ct& out) {
     for (int a = 0; a < op0.n; ++a) if (!rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-    static const int fuse_env = getenv("MKHE_FUSE_X") ? atoi(getenv("MKHE_FUSE_X")) : 1;
+    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
     const bool fuse = fuse_env && op0.n >= 1 && op0.n <= 4 && !masked_;
-    static const int fuse_y_env = getenv("MKHE_FUSE_Y") ? atoi(getenv("MKHE_FUSE_Y")) : 1;
+    static const int fuse_y_env = MKHE_AB_INT("MKHE_FUSE_Y", 1);
     const bool fuse_y = fuse && fuse_y_env && op1.n >= 1 && op1.n <= 4;
     bfv_mr_partial(op0, op1, rlk_b1, rlk_b2, rlk_d1, rlk_d2, true, true, out, x_, x2_, y_, y2_, fuse, fuse_y);
     bfv_mr_finish(op0, op1, x_, x2_, y_, y2_, rlk_v, crs_u, out);

@@ -12,6 +12,7 @@
 // kernel for another modulus or for the caller is canonical or an explicitly restated
 // lazy formula (mult_sum).
 #pragma once
+#include "switches.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

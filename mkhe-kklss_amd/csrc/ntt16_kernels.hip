@@ -1381,13 +1381,12 @@ __global__ void __launch_bounds__(NT, 8) ntt14_inv_kernel(NttBatch b) {
 
 // ------------------------------------------------------------------ launcher
 namespace {
-int env_int16(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 struct LaunchState16 { std::mutex mu; int resident[64] = {}; };      // per device, see ntt_kernels.hip
 }
 namespace {
 int resident16(size_t lds) {
     using namespace h16;
-    static const int per_cu = env_int16("MKHE_NTT16_PER_CU", 0);
+    static const int per_cu = MKHE_AB_INT("MKHE_NTT16_PER_CU", 0);
     static LaunchState16 ls;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1428,7 +1427,7 @@ static void fill_job_constants(NttBatch& c, int njobs, int blocks, int lpt_long)
 }
 // sub-transforms of a split N = 2^16 launch (one modulus class per launch: `small` = 31 q < 2^62 for every slot)
 bool ntt16_split_ok(const NttBatch& c) {
-    static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128);
+    static const int on = MKHE_AB_INT("MKHE_NTT16", 1), minl = MKHE_AB_INT("MKHE_NTT16_MIN", 128);
     // (the job walk divides by multiply-high reciprocals that are exact below 2^16: larger launches keep the round-1 kernels)
     return on && !c.no_h16 && c.psi31 && (c.split == 1 || c.split == 2) && !c.reduce_in && c.nslots <= 64 && 2 * c.nslots * c.nouter >= minl &&
            (long)c.nslots * c.nouter < 65536 && c.nouter < 65536;
@@ -1448,7 +1447,7 @@ void launch_ntt16_fwd_split(const NttBatch& b, bool small, hipStream_t st) {
 // inverse: launches of at least MKHE_NTT16_INV_MIN one-pass jobs (2^14 points each); the caller (launch_ntt_inv) runs the cross stages of
 // N = 2^15 / 2^16 behind it.  b.psi31 / b.psi are the INVERSE tables here, b.inv31c the pairs of the last stage.
 bool ntt16_inv_ok(int logN, const NttBatch& b) {
-    static const int on = env_int16("MKHE_NTT16_INV", 1), minj = env_int16("MKHE_NTT16_INV_MIN", 256), minj14 = env_int16("MKHE_NTT14_INV_MIN", 129);
+    static const int on = MKHE_AB_INT("MKHE_NTT16_INV", 1), minj = MKHE_AB_INT("MKHE_NTT16_INV_MIN", 256), minj14 = MKHE_AB_INT("MKHE_NTT14_INV_MIN", 129);
     if (!on || b.no_h16 || !b.psi31 || !b.inv31c || b.split || b.nslots > 64 || logN < 14 || logN > 16) return false;
     const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;
     // N = 2^14 (round 4): up to 128 limbs run as LDS sub-transforms (launch_ntt_inv), everything above comes here -- between 129 and 255 limbs
@@ -1483,7 +1482,7 @@ void launch_ntt16_inv(const NttBatch& b, hipStream_t st, int logN) {
     hipLaunchKernelGGL(ntt14_inv_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
 }
 bool ntt16_ok(int logN, const NttBatch& b) {
-    static const int on = env_int16("MKHE_NTT16", 1), minl = env_int16("MKHE_NTT16_MIN", 128), minl14 = env_int16("MKHE_NTT14_MIN", 128);
+    static const int on = MKHE_AB_INT("MKHE_NTT16", 1), minl = MKHE_AB_INT("MKHE_NTT16_MIN", 128), minl14 = MKHE_AB_INT("MKHE_NTT14_MIN", 128);
     if (!on || b.no_h16 || !b.psi31 || b.split || b.prestaged || b.nslots > 64) return false;
     if ((long)b.nslots * b.nouter >= 65536 || b.nouter >= 65536) return false;      // (fill_job_constants: reciprocals exact below 2^16)
     if (logN == 14) return b.nslots * b.nouter >= minl14;      // (one pass: a workgroup has loaded its whole limb before it stores, in place included)
@@ -1502,7 +1501,7 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
                 ++c.nslots;
             }
     const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
-    static const int stagger = env_int16("MKHE_NTT16_STAGGER", 0), lpt = env_int16("MKHE_NTT16_LPT", 1);
+    static const int stagger = MKHE_AB_INT("MKHE_NTT16_STAGGER", 0), lpt = MKHE_AB_INT("MKHE_NTT16_LPT", 1);
     c.lazy_out = stagger;
     int nbig = 0;                                      // the long jobs lead the slot-major list: every slot of a 59/60-bit modulus, nouter limbs each
     for (int s2 = 0; s2 < c.nslots; ++s2) if (!((c.small_slots >> s2) & 1)) ++nbig;
@@ -1512,13 +1511,13 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
     int blocks = need < resident ? need : resident;
     // experiment (MKHE_NTT16_EVEN=1): as many workgroups as give every one of them the same number of limbs (1792 and 896 limbs: 448 instead of
     // 512) -- an even last round on 7/8 of the CUs instead of a ragged one on all of them
-    static const int even = env_int16("MKHE_NTT16_EVEN", 0);
+    static const int even = MKHE_AB_INT("MKHE_NTT16_EVEN", 0);
     if (even && need > resident) { const int rounds = (need + resident - 1) / resident; blocks = (need + rounds - 1) / rounds; }
     // half-limb jobs: Decompose launches only (source = ciphertext limbs, destination = hoisted digits: never in place) whose whole limbs would
     // leave the last row of positions ragged (896 limbs on 256 CUs: 134.0 -> 128.7 us); a launch that deals whole limbs evenly keeps them -- as
     // half-limb jobs the 1792-limb launch (7 limbs per CU either way) is 5 % SLOWER (256 -> 270 us, measured twice on one box; MKHE_NTT16_HALVES=2
     // forces them for every launch)
-    static const int halfj = env_int16("MKHE_NTT16_HALVES", 1);
+    static const int halfj = MKHE_AB_INT("MKHE_NTT16_HALVES", 1);
     const int cus = resident >> 1;
     c.half_jobs = (halfj && logN == 15 && c.reduce_in && need > resident && 2 * need < 65536 && (halfj == 2 || (cus > 0 && need % cus != 0))) ? 1 : 0;
     if (c.half_jobs && need % 8 == 0 && lpt_long % 8 == 0) c.half_jobs = 2;      // 8 limbs x 2 passes per block of 16 positions (see fwd_body)

@@ -576,25 +576,30 @@ __global__ void __launch_bounds__(NT, 4) __attribute__((amdgpu_num_vgpr(128))) n
 
 // ------------------------------------------------------------------ launcher
 namespace {
-int env_int32(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 struct LaunchState32 { std::mutex mu; int resident[64] = {}; };
 unsigned magic_of32(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
+// CU count of the CURRENT device, cached per device behind a mutex (a process may hold contexts on several GPUs, driven by several threads)
+int device_cus32() {
+    static std::mutex mu; static int cus_of[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    int& c = cus_of[dev & 63];
+    if (!c) { int v = 256; (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); c = v > 0 ? v : 256; }
+    return c;
 }
-int ntt32_mode() { static const int on = env_int32("MKHE_NTT32", MKHE_NTT32_DEFAULT); return on; }
+}
+int ntt32_mode() { static const int on = MKHE_CFG_INT("MKHE_NTT32", MKHE_NTT32_DEFAULT); return on; }
 bool ntt32_ok(int logN, const NttBatch& b) {
-    static const int on = env_int32("MKHE_NTT32", MKHE_NTT32_DEFAULT), minl = env_int32("MKHE_NTT32_MIN", 512);
+    static const int on = MKHE_CFG_INT("MKHE_NTT32", MKHE_NTT32_DEFAULT), minl = MKHE_AB_INT("MKHE_NTT32_MIN", 512);
     if (!on || logN != 15 || b.no_h16 || !b.psi31 || !b.psi31c || !b.psi31b || b.split || b.prestaged || b.nslots > 64) return false;
     if ((long)b.nslots * b.nouter >= 65536 || b.nouter >= 65536) return false;      // (job-walk reciprocals: exact below 2^16)
     // one workgroup per CU, whole limbs: a launch that does not deal the limbs evenly leaves CUs idle in its last round (896 limbs on 256 CUs: four
     // rounds for 3.5 rounds of work), where the H16 kernel deals half-limb jobs.  MKHE_NTT32_EVEN=1 keeps such launches on H16.
-    static const int even = env_int32("MKHE_NTT32_EVEN", MKHE_NTT32_EVEN_DEFAULT);
+    static const int even = MKHE_AB_INT("MKHE_NTT32_EVEN", MKHE_NTT32_EVEN_DEFAULT);
     const int need = b.nslots * b.nouter;
     if (even) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        static int cached_cus = 0;
-        if (!cached_cus) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); cached_cus = cus; }
-        cus = cached_cus;
+        const int cus = device_cus32();
         const int rounds = (need + cus - 1) / cus;
         if (need % cus != 0 && rounds < 8) return false;
     }
@@ -636,7 +641,7 @@ void launch_ntt32_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
     const int blocks = need < resident ? need : resident;
     int nbig = 0;
     for (int s2 = 0; s2 < c.nslots; ++s2) if (!((c.small_slots >> s2) & 1)) ++nbig;
-    static const int lpt = env_int32("MKHE_NTT32_LPT", 1);
+    static const int lpt = MKHE_AB_INT("MKHE_NTT32_LPT", 1);
     const int lpt_long = lpt && nbig < c.nslots ? nbig * c.nouter : 0;
     c.magic_nouter = magic_of32(c.nouter);
     c.magic_opi = magic_of32(c.nitems > 0 ? c.outers_per_item : 1);

@@ -870,11 +870,12 @@ static NttBatch in_place_of_dst(const NttBatch& b) {
 namespace {
 struct LaunchState { std::mutex mu; int resident[64] = {}; bool attr[64] = {}; };
 int current_device() { int dev = 0; (void)hipGetDevice(&dev); return dev & 63; }
-int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
 }
 // workgroups that are co-resident on the whole chip for this kernel (persistent grid size)
 static int resident_blocks(const void* fn, int threads, size_t lds) {
+#ifdef MKHE_SWITCHES
     if (const char* e = getenv("MKHE_NTT_GRID")) { if (e[0] == 'f') return 1 << 30; }     // "full": one workgroup per limb (A/B testing)
+#endif
     int dev = 0, cus = 256, per = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -948,9 +949,9 @@ int split_ntt_fwd(const NttBatch& b, const unsigned char* small_q, NttBatch out[
 static bool use_split(int logN, const NttBatch& b) {
     if (logN == 16) return true;
     if (logN < 13) return false;
-    static const int forced = env_int("MKHE_NTT_SPLIT", -1);                 // (function-local statics: initialised once, thread-safe)
+    static const int forced = MKHE_AB_INT("MKHE_NTT_SPLIT", -1);                 // (function-local statics: initialised once, thread-safe)
     if (forced >= 0) return forced != 0;
-    static const int lim = env_int("MKHE_NTT_SPLIT_MAX", 128);               // A/B: limb count up to which a launch runs split
+    static const int lim = MKHE_AB_INT("MKHE_NTT_SPLIT_MAX", 128);               // A/B: limb count up to which a launch runs split
     const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;                // merged launches: the jobs that exist
     if ((logN == 14 || logN == 15) && limbs <= lim) return true;
     return limbs <= 128;        // at most one sub-transform workgroup per CU (256 CUs)
@@ -958,7 +959,7 @@ static bool use_split(int logN, const NttBatch& b) {
 // depth of the low-latency path for this launch: 0 = register-resident sub-transforms, d >= 1 = 2^d LDS sub-transforms of
 // 2^13 coefficients per limb after d streaming passes.  MKHE_NTT_LDS=0 switches it off (A/B tests).
 static int lds_depth(int logN, const NttBatch& b) {
-    static const int on = env_int("MKHE_NTT_LDS", 1);
+    static const int on = MKHE_AB_INT("MKHE_NTT_LDS", 1);
     if (!on || b.prestaged) return 0;
     if (logN != 14 && logN != 15) return 0;
     static LaunchState ls;
@@ -973,8 +974,8 @@ static int lds_depth(int logN, const NttBatch& b) {
             ls.attr[dev] = true;
         }
     }
-    static const int lds12 = env_int("MKHE_NTT_LDS12", 1);       // N = 2^14: four 2^12-point sub-transforms per limb (0: two of 2^13 points)
-    static const int lds12_15 = env_int("MKHE_NTT_LDS12_15", 1);       // N = 2^15: eight 2^12-point sub-transforms behind the radix-8 pass (0: four of 2^13)
+    static const int lds12 = MKHE_AB_INT("MKHE_NTT_LDS12", 1);       // N = 2^14: four 2^12-point sub-transforms per limb (0: two of 2^13 points)
+    static const int lds12_15 = MKHE_AB_INT("MKHE_NTT_LDS12_15", 1);       // N = 2^15: eight 2^12-point sub-transforms behind the radix-8 pass (0: four of 2^13)
     if (lds12 && (logN == 14 || (logN == 15 && lds12_15))) {
         static LaunchState ls12;
         const int dev = current_device();
@@ -987,7 +988,7 @@ static int lds_depth(int logN, const NttBatch& b) {
             ls12.attr[dev] = true;
         }
         // N = 2^14 launches that would not even give every CU one 2^12-point workgroup: eight 2^11-point sub-transforms per limb (256 threads)
-        static const int lds11 = env_int("MKHE_NTT_LDS11", 1);
+        static const int lds11 = MKHE_AB_INT("MKHE_NTT_LDS11", 1);
         const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;
         if (lds11 && logN == 14 && limbs * 4 < 256) return 3;
         return logN - 12;
@@ -995,7 +996,7 @@ static int lds_depth(int logN, const NttBatch& b) {
     return logN - SM_LOGM;
 }
 bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q) {
-    static const int on = env_int("MKHE_NTT_MIXED", 1);
+    static const int on = MKHE_AB_INT("MKHE_NTT_MIXED", 1);
     if (!on || logN != 15 || !b.reduce_in || b.split || b.nslots > 64 || b.nslots * b.nouter <= 512) return false;
     int nsmall = 0;
     for (int s = 0; s < b.nslots; ++s) if (small_q[b.mod[s]]) ++nsmall;
@@ -1042,7 +1043,7 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (logN == 16 && !b.prestaged) {
         // N = 2^16 without a fused producer (the tensor-step inputs, plain NTTs): both cross stages as ONE streaming pass, then the four one-pass
         // 2^14-point sub-transforms per limb on the H16 kernel -- instead of a radix-2 pass and two-pass 2^15-point halves (MKHE_NTT16_RADIX4=0)
-        static const int r4 = env_int("MKHE_NTT16_RADIX4", 1);
+        static const int r4 = MKHE_AB_INT("MKHE_NTT16_RADIX4", 1);
         NttBatch o = in_place_of_dst(b);
         o.reduce_in = 0; o.split = 2;
         if (r4 && ntt16_split_ok(o)) {

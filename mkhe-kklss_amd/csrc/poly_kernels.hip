@@ -730,7 +730,7 @@ void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
         else hipLaunchKernelGGL(ext_inner_xwide_kernel<4>, grid, blk, 0, st, a);
         return;
     }
-    static const int grouping = getenv("MKHE_EXT_GROUP") ? atoi(getenv("MKHE_EXT_GROUP")) : 1;
+    static const int grouping = MKHE_AB_INT("MKHE_EXT_GROUP", 1);
     for (int i = 0; i < a.nitems; ++i) { a.grp[i] = 0; a.gnext[i] = 255; }
     if (a.xout && !a.xmulti) {
         // the x by-product needs every item in ONE group (checked by the caller: single items, one shared key, at most four)
@@ -841,7 +841,7 @@ void launch_moddown_batch(const ModDownBatchArgs& a_in, hipStream_t st) {
     // thread produces: few limb slices per coefficient, the parallelism comes from the destination groups
     const int nj = a.qlist ? a.nqlist : a.level + 1;
     static int cap = 0;
-    if (!cap) { const char* e = getenv("MKHE_MD_BY"); cap = (e && *e) ? atoi(e) : 4; }
+    if (!cap) cap = MKHE_AB_INT("MKHE_MD_BY", 4);
     int by = nj < cap ? nj : cap;
     if (a.ngroups * by < 8) by = nj < 8 ? nj : 8;          // a single external product: spread over the limbs instead
     if (by < 1) return;
@@ -958,7 +958,7 @@ void launch_moddown_merged(const ModDownMergedArgs& a_in, hipStream_t st) {
     const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
     const int nj = a.level + 1;
     static int cap = 0;
-    if (!cap) { const char* e = getenv("MKHE_MDM_BY"); cap = (e && *e) ? atoi(e) : 4; }
+    if (!cap) cap = MKHE_AB_INT("MKHE_MDM_BY", 4);
     int by = nj < cap ? nj : cap;
     if (a.ngroups * by < 8) by = nj < 8 ? nj : 8;
     const dim3 grid(bx, by, a.ngroups), blk(PW_THREADS);
@@ -1177,7 +1177,7 @@ __global__ void __launch_bounds__(PW_THREADS) basis_conv_kernel(BasisConvArgs a)
 void launch_basis_conv(const BasisConvArgs& a, hipStream_t st) {
     const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
     static int per = 0;                      // target limbs per thread: the y[] set-up (ns products + ns float64 divisions) is amortised over them
-    if (!per) { const char* e = getenv("MKHE_BC_PER"); per = (e && *e) ? atoi(e) : 7; }     // measured at PN15 (nt = 14): 7 -> 44.6 us per launch, 4 -> 54.8, 14 -> 54.2, 2 -> 68.7
+    if (!per) per = MKHE_AB_INT("MKHE_BC_PER", 7);     // measured at PN15 (nt = 14): 7 -> 44.6 us per launch, 4 -> 54.8, 14 -> 54.2, 2 -> 68.7
     int by = (a.nt + per - 1) / per;
     if (by < 1) by = 1;
     hipLaunchKernelGGL(basis_conv_kernel, dim3(bx, by, a.npolys), dim3(PW_THREADS), 0, st, a);

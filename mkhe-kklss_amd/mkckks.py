@@ -377,7 +377,9 @@ class BatchEvaluator:
         if -1 not in params.CRS:
             raise MkheError("mkhe: CRS[-1] (u) has not been uploaded")
         nb1, scale1 = self.ev._nb_rescales(level, prod_scale, params.Scale())
-        rescale = nb1 >= 1 and level >= 1
+        # the single evaluator's branch (Evaluator.MulRelinHoistedNew): the Rescale is folded into the engine call only when it is the usual single
+        # one and fuse_rescale is set; otherwise the product is formed at its level and ONE mkhe_rescale(nb) per input follows, as there
+        rescale = nb1 == 1 and level >= 1 and self.ev.fuse_rescale
         ids = a[0].IDSet() | b[0].IDSet()
         out = self._new(ids, level - 1 if rescale else level, prod_scale / float(params.Q[level]) if rescale else prod_scale)
         d0 = [rlkSet.GetRelinearizationKey(i).Value[1].h for i in a[0].ids]
@@ -385,9 +387,15 @@ class BatchEvaluator:
         b1 = [rlkSet.GetRelinearizationKey(i).Value[0].h for i in b[0].ids]
         check(lib().mkhe_mul_relin_batch(params.ctx, self.B, self._h(op0), self._h(op1), self._hoists(op0Hoisted, a), self._hoists(op1Hoisted, b),
                                          handle_array(b1), handle_array(d0), handle_array(v0), params.CRS[-1].h, 1 if rescale else 0, self._h(out)))
-        if rescale and nb1 > 1:                        # further divisions (not in the circuits of the reference): per input
-            return BatchCiphertext([self.ev.RescaleNew(c, params.Scale()) for c in out.cts])
-        return out
+        if rescale:
+            return out
+        nb, scale = self.ev.nbRescales(out.cts[0], params.Scale())
+        if nb == 0 or out.cts[0].Level() == 0:
+            return out
+        res = self._new(ids, out.cts[0].Level() - nb, scale)
+        for c, r in zip(out.cts, res.cts):              # (nb != 1 or fuse_rescale off: not in the circuits of the reference -- per input)
+            check(lib().mkhe_rescale(params.ctx, c.h, nb, r.h))
+        return res
 
     # -- RotateNew / RotateHoistedNew (evaluator.go:485-525,585-617)
     def _rotate(self, ct, rotidx, hoisted, rkSet):

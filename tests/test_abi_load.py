@@ -70,3 +70,22 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     subprocess.check_call(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                            "-L", libdir, "-lmkhe_hip", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"])
     assert os.path.exists(exe)
+
+
+def test_product_library_reads_only_the_documented_environment():
+    """A/B switches are compiled into libmkhe_hip_switches.so only.  Every MKHE_* string of the product library is a
+    configuration variable that include/mkhe.h documents under "Environment", and there are at most ten of them."""
+    import re
+    import subprocess
+    from mkhe_kklss_amd import _abi
+    out = subprocess.run(["strings", _abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted({l.strip() for l in out.splitlines() if re.fullmatch(r"MKHE_[A-Z0-9_]+", l.strip())})
+    hdr = open(os.path.join(ROOT, "include", "mkhe.h")).read()
+    env_doc = hdr[hdr.index("Environment (the COMPLETE list"):hdr.index("#ifndef MKHE_H")]
+    assert 0 < len(names) <= 10, names
+    for n in names:
+        assert n in env_doc, "%s is read by the product library but not documented in include/mkhe.h" % n
+    sw = os.path.join(os.path.dirname(_abi.LIB_PATH), "libmkhe_hip_switches.so")
+    assert os.path.exists(sw), "build() makes the -DMKHE_SWITCHES library too"
+    out = subprocess.run(["strings", sw], capture_output=True, text=True, check=True).stdout
+    assert sum(1 for l in out.splitlines() if re.fullmatch(r"MKHE_[A-Z0-9_]+", l.strip())) > 30

@@ -170,3 +170,63 @@ def test_cnn_inference_on_a_batch_of_images(owners, B):
     got = sc.decrypt(out.cts[0])[:HC.NCLS]
     exp = HC.plain_forward(models[0])
     assert int(np.argmax(got.real)) == int(np.argmax(exp)) and np.abs(got.real - exp).max() < 1e-3 * max(1.0, np.abs(exp).max())
+
+
+# ---------------------------------------------------------------- round 5
+def test_batch_rejects_an_output_that_is_another_items_input(case):
+    """The items of a batch run as one launch set, in no order: output k aliasing input j != k is an error (include/mkhe.h), not a race."""
+    from mkhe_kklss_amd._abi import MkheError
+    B = 3
+    bev = case.mkckks.BatchEvaluator(case.params, B)
+    _, b0 = case.batch(["a", "b"], B)
+    _, b1 = case.batch(["a", "b"], B)
+    crossed = case.mkckks.BatchCiphertext([b0.cts[1], b0.cts[2], b0.cts[0]])          # out[k] = op0[k + 1]
+    with pytest.raises(MkheError, match="input . of another item"):
+        from mkhe_kklss_amd._abi import check, lib
+        check(lib().mkhe_ct_binary_batch(case.params.ctx, 0, B, bev._h(b0), bev._h(b1), bev._h(crossed)))
+    rk = [case.rtk.GetRotationKey(i, 1).Value.h for i in b0.ids]
+    from mkhe_kklss_amd._abi import handle_array
+    with pytest.raises(MkheError, match="input . of another item"):
+        check(lib().mkhe_rotate_batch(case.params.ctx, case.params.GaloisElementForColumnRotationBy(1), B, bev._h(b0), None, handle_array(rk), case.params.CRS[1].h, bev._h(crossed)))
+    # in place per item stays legal for the elementwise entry: a[k] += b[k]
+    ref = [(case.ev.AddNew(b0.cts[k], b1.cts[k])).download() for k in range(B)]
+    check(lib().mkhe_ct_binary_batch(case.params.ctx, 0, B, bev._h(b0), bev._h(b1), bev._h(b0)))
+    for k in range(B):
+        assert (b0.cts[k].download() == ref[k]).all()
+
+
+def test_batch_mul_relin_without_the_fused_rescale_matches_the_single_evaluator(case):
+    """BatchEvaluator mirrors Evaluator.MulRelinHoistedNew's branch: with fuse_rescale off the product is formed at its level and one
+    mkhe_rescale(nb) per input follows (it used to fold the first Rescale regardless)."""
+    B = 2
+    bev = case.mkckks.BatchEvaluator(case.params, B)
+    _, b0 = case.batch(["a", "b"], B)
+    _, b1 = case.batch(["b", "c"], B)
+    fused = bev.MulRelinNew(b0, b1, case.rlk)
+    old = bev.ev.fuse_rescale
+    bev.ev.fuse_rescale = False
+    try:
+        plain = bev.MulRelinNew(b0, b1, case.rlk)
+        single = [bev.ev.MulRelinNew(b0.cts[k], b1.cts[k], case.rlk) for k in range(B)]
+    finally:
+        bev.ev.fuse_rescale = old
+    for k in range(B):
+        assert plain.cts[k].Level() == fused.cts[k].Level() == single[k].Level()
+        assert (plain.cts[k].download() == fused.cts[k].download()).all() and (plain.cts[k].download() == single[k].download()).all()
+
+
+def test_pool_statistics_and_trim(case):
+    """The stream-ordered pools are bounded per device and can be handed back (mkhe_pool_trim; the engine does it itself when hipMalloc fails)."""
+    from mkhe_kklss_amd._abi import check, lib
+    ctx = case.params.ctx
+    cts = [case.ct(["a", "b"])[1] for _ in range(4)]
+    want = [c.download() for c in cts]
+    del cts[2:]                                            # two handles go back to the pool
+    import gc; gc.collect()
+    assert lib().mkhe_pool_held_bytes(ctx) > 0
+    check(lib().mkhe_pool_trim(ctx))
+    assert lib().mkhe_pool_held_bytes(ctx) == 0
+    assert (cts[0].download() == want[0]).all() and (cts[1].download() == want[1]).all()
+    _, again = case.ct(["a", "b"])                         # allocation after a trim
+    assert again.download().shape == want[0].shape
+    assert lib().mkhe_pool_held_bytes(None) == -1 and lib().mkhe_ntt_choice(None, 1792, 1) == -2

@@ -12,6 +12,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# The thresholds and kernel selectors below are A/B instrumentation: they exist only in the -DMKHE_SWITCHES build of the same sources
+# (csrc/switches.h, `make switches`); the product library does not read them.
+SWITCHES_LIB = os.path.join(ROOT, "mkhe-kklss_amd", "lib", "libmkhe_hip_switches.so")
+
 SCRIPT = r'''
 import sys
 import numpy as np
@@ -83,7 +87,7 @@ print("forced paths ok")
 
 
 def test_small_shapes_through_the_h16_kernels():
-    env = dict(os.environ, MKHE_NTT16_MIN="1", MKHE_NTT14_MIN="1", MKHE_NTT16_INV_MIN="1")
+    env = dict(os.environ, MKHE_LIB=SWITCHES_LIB, MKHE_NTT16_MIN="1", MKHE_NTT14_MIN="1", MKHE_NTT16_INV_MIN="1")
     r = subprocess.run([sys.executable, "-c", SCRIPT % dict(tests=os.path.join(ROOT, "tests"), root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "forced paths ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     assert "Memory access fault" not in r.stderr
@@ -207,7 +211,7 @@ print("bfv big-modulus paths ok")
 
 
 def _run(script, env_extra):
-    env = dict(os.environ, **env_extra)
+    env = dict(os.environ, MKHE_LIB=SWITCHES_LIB, **env_extra)
     r = subprocess.run([sys.executable, "-c", script % dict(tests=os.path.join(ROOT, "tests"), root=ROOT)], env=env, capture_output=True, text=True, timeout=1200)
     assert "Memory access fault" not in r.stderr
     return r

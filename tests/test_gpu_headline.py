@@ -98,6 +98,29 @@ def test_pn15_hoisted_form_launch_classes(pn15, parties, drop):
         assert (got[:beta][:, act] == ref[:beta][:, act]).all(), "party %d" % i
 
 
+def test_pn15_pinned_forward_kernel_choice(pn15):
+    """mkhe_ctx_set_ntt_choice pins the forward kernel of N = 2^15 launches where two apply (a bench line can be repeated with
+    the kernels it records): 0 = two-pass, 1 = single-pass, for every shape of the context; same bits, and mkhe_ntt_choice reports the pin."""
+    from mkhe_kklss_amd._abi import check, lib
+    p, ks, params, mk, rng = (pn15[k] for k in ("pset", "ks", "params", "mk", "rng"))
+    level, parties = len(p["Q"]) - 1, 3                       # 3 * 14 * 16 = 672 limbs: both kernels apply
+    names = ["p%d" % i for i in range(parties)]
+    h = _ct(p, rng, parties, level + 1)
+    ct = mk.NewCiphertext(params, names, level, p["scale"]).upload(h)
+    ref = ks.decompose(level, h[1])
+    try:
+        for choice in (0, 1, 0):
+            check(lib().mkhe_ctx_set_ntt_choice(params.ctx, 0, 1, choice))
+            got = mk.NewEvaluator(params).HoistedForm(ct).Value["p0"].download()
+            assert (got == ref).all(), choice
+            assert lib().mkhe_ntt_choice(params.ctx, 672, 1) == choice
+        check(lib().mkhe_ctx_set_ntt_choice(params.ctx, 672, 1, 1))      # one shape
+        assert lib().mkhe_ntt_choice(params.ctx, 672, 1) == 1
+        assert lib().mkhe_ctx_set_ntt_choice(params.ctx, 0, 1, 7) != 0    # bad value: an error, not a crash
+    finally:
+        check(lib().mkhe_ctx_set_ntt_choice(params.ctx, 0, 1, -1))        # back to measuring for the tests that follow
+
+
 def test_n15_modulus_outside_the_h16_ranges():
     """A small-class modulus (31q < 2^62) that the one-round product of csrc/ntt16_kernels.hip does not cover (48q >= 2^62: its
     never-reduced values grow by q per stage): such a context keeps the round-1 forward kernels for its large Decompose

@@ -6,10 +6,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/switch_matrix
 mkdir -p $O
 cd $R
+# the switches exist only in the -DMKHE_SWITCHES build of the same sources (csrc/switches.h; `make -C mkhe-kklss_amd/csrc switches`)
+LIB=$R/mkhe-kklss_amd/lib/libmkhe_hip_switches.so
+[ -f $LIB ] || { echo "missing $LIB"; exit 2; }
 rc=0
 run() {
     local name=$1; shift
-    env "$@" python3 -m pytest tests -m gpu -x -q > $O/$name.txt 2>&1
+    env MKHE_LIB=$LIB "$@" python3 -m pytest tests -m gpu -x -q > $O/$name.txt 2>&1
     local r=$?
     if grep -q "Memory access fault" $O/$name.txt; then r=99; fi
     echo "$name: rc=$r  $(tail -1 $O/$name.txt)"
