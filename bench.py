@@ -304,7 +304,9 @@ def run_cnn(args):
                 config=dict(workload="cnn encrypted inference (Convolution + square + FC1 + square + FC2, cnn/cnn.go), PN14QP433 N=2^14, "
                                      "7 Q + 2 P limbs, %d parties" % len(set(owners.values())),
                             parties=len(set(owners.values())), params="PN14QP433", seed=args.seed, batch=B, batch_check=batch_check,
-                            forks=len(forks) if B == 1 else 0, hip_graph=graph is not None, host_issue_ms=issue * 1e3 / args.steps, layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
+                            forks=len(forks) if B == 1 else 0, chains=("forks" if forks else "lanes") if B == 1 else "forks of the batch evaluator",
+                            launch_groups_per_inference=(sum(k["launches_per_step"] for k in roofline["kernels"].values()) / B) if roofline and roofline.get("kernels") else None,
+                            hip_graph=graph is not None, host_issue_ms=issue * 1e3 / args.steps, layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
                             keygen_s=keygen_s, keys_generated=len(set(owners.values())) * (3 + len(HC.ROTS) + p["logN"] - 1)),
                 roofline=roofline, cpu_baseline=cpu)
 
@@ -680,8 +682,9 @@ def main():
     ap.add_argument("--params", default="PN15QP880", choices=["PN15QP880", "PN14QP439", "PN16QP1761"],
                     help="PN15QP880 = BASELINE.json configs[1] (default); PN16QP1761 = the configs[3] ring (N = 2^16, 34 + 4 primes, "
                          "alpha = 2) on ONE GPU, keys written on the device (implies --device-keys, single GPU only)")
-    ap.add_argument("--forks", type=int, default=7,
-                    help="--scheme cnn: extra engine contexts through which the independent chains of a layer are issued (0 = one stream)")
+    ap.add_argument("--forks", type=int, default=0,
+                    help="--scheme cnn: extra engine contexts through which the independent chains of a layer are issued (rounds 1-4: 7); "
+                         "0 (default since round 5) = the chains are LANES of one launch set on one context (mkhe_kklss_amd/cnn.py, Evaluator.Lanes)")
     ap.add_argument("--batch", type=int, default=1,
                     help="B inputs in lock step (mkhe_*_batch entry points, mkckks.BatchEvaluator): --scheme cnn evaluates B images per step, "
                          "--scheme ckks B MulRelin per step; value counts inputs (inferences / MulRelin per second), every output is compared "

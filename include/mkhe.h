@@ -246,6 +246,14 @@ void mkhe_swk_destroy_batch(mkhe_ctx* ctx, int count, mkhe_swk* const* swks);
 int  mkhe_hoisted_form_batch(mkhe_ctx* ctx, int level, int nbatch, const mkhe_ct* const* cts, mkhe_swk* const* out);
 int  mkhe_rotate_batch(mkhe_ctx* ctx, uint64_t galEl, int nbatch, const mkhe_ct* const* in, const mkhe_swk* const* hoist,
                        const mkhe_swk* const* rk, const mkhe_swk* crs, mkhe_ct* const* out);
+/*      nbatch rotations of nbatch ciphertexts of one shape, EACH by its own Galois element galEl[b] with its own keys -- rk flat [b * n + a]
+ *      (rkSet.GetRotationKey(ids[a], rotidx_b)), crs[b] = params.CRS[rotidx_b], hoist flat [b * n + a] or NULL -- and, when post_add != NULL,
+ *      out[b] = post_add[b] + Rotate(in[b]) with the addition of mkckks.Evaluator.AddNew (equal scales: ring.Add) on the store of the rotation:
+ *      the independent rotate -> hoist -> MulRelin chains of cnn.Convolution / FC1Layer (cnn/cnn.go:16-30,51-62) as lanes of one launch set, and
+ *      the "temp = RotateNew(x, r); x = AddNew(x, temp)" steps of its log-sums (:33-37,64-67,83-86,90-93) as one pass (nbatch = 1).  Bit for bit
+ *      what mkhe_rotate followed by mkhe_ct_add(post_add[b], .) gives.  post_add[b] has the ids of in[b], at out's level or above, and is not an output. */
+int  mkhe_rotate_multi(mkhe_ctx* ctx, int nbatch, const uint64_t* galEl, const mkhe_ct* const* in, const mkhe_swk* const* hoist,
+                       const mkhe_swk* const* rk, const mkhe_swk* const* crs, const mkhe_ct* const* post_add, mkhe_ct* const* out);
 int  mkhe_mul_relin_batch(mkhe_ctx* ctx, int nbatch, const mkhe_ct* const* op0, const mkhe_ct* const* op1,
                           const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
                           const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0, const mkhe_swk* const* rlk_v0,

@@ -4,7 +4,14 @@ the calls; the only host work is the float64 scale bookkeeping inside the mkckks
 
 `forks` (optional, a list of mkckks.Evaluator.Fork() evaluators): the independent rotate -> hoist -> MulRelin chains of
 Convolution (3) and FC1Layer (8) are issued through different engine contexts and overlap on the GPU -- every launch of
-this workload covers a few dozen 2^14-point limbs, a fraction of the 256 CUs.  Results are the same bit for bit."""
+this workload covers a few dozen 2^14-point limbs, a fraction of the 256 CUs.  Results are the same bit for bit.
+
+Round 5: an evaluator that offers `Lanes(n)` (the device mkckks.Evaluator) runs those independent chains as the LANES of one launch set instead
+(BatchEvaluator over the same context: one rotation launch for the 3 resp. 7 rotated copies, each with its own Galois element and keys, one hoisting
+launch, one MulRelin launch set for the 4 resp. 8 products) -- a kernel trace showed that the small kernels of forked chains do not overlap on this
+chip, so 8 chains cost 8 times the launches -- and one that offers `RotateAndAddNew` folds the AddNew of every "rotate, then add" step of the log-sums
+into the rotation's store.  Evaluators without them (the CPU evaluator of tests/, a BatchEvaluator over B images) take the reference's sequence
+of calls unchanged; the device result equals it bit for bit (tests/test_gpu_cnn.py)."""
 
 
 def _fan_out(eval, used):
@@ -17,8 +24,42 @@ def _fan_in(eval, used):
         eval.params.wait_for(f.params)
 
 
+def _rot_add(eval, ct, rot, rtkSet):
+    """temp = eval.RotateNew(ct, rot, rtkSet); ct = eval.AddNew(ct, temp)   (cnn.go:33-37,64-67,83-86,90-93)"""
+    fused = getattr(eval, "RotateAndAddNew", None)
+    return fused(ct, rot, rtkSet) if fused else eval.AddNew(ct, eval.RotateNew(ct, rot, rtkSet))
+
+
+def _lane_products(eval, rlkSet, rtkSet, ct, ctHoisted, rots, ctOther, ctOtherHoisted):
+    """[MulRelinHoistedNew(Rot_r(ct), ctOther[i], HoistedForm(Rot_r(ct)), ctOtherHoisted[i]) for i, r in enumerate(rots)] as lanes of one launch set;
+    r = 0: the rotation is a copy and its hoisted form IS ctHoisted (cnn.go:16, :53 with i = 0)"""
+    from .mkckks import BatchCiphertext, BatchHoisted
+    moving = [r for r in rots if r != 0]
+    temps, tempsH = [], []
+    if moving:
+        lanes = eval.Lanes(len(moving))
+        t = lanes.RotateHoistedNew(ct, moving, ctHoisted, rtkSet)
+        temps, tempsH = t.cts, lanes.HoistedForm(t).hoisted
+    ops, hs, k = [], [], 0
+    for r in rots:
+        if r == 0:
+            ops.append(ct); hs.append(ctHoisted)
+        else:
+            ops.append(temps[k]); hs.append(tempsH[k]); k += 1
+    prods = eval.Lanes(len(rots)).MulRelinHoistedNew(BatchCiphertext(ops), BatchCiphertext(list(ctOther)), BatchHoisted(hs), BatchHoisted(list(ctOtherHoisted)), rlkSet)
+    return prods.cts
+
+
 def Convolution(eval, rlkSet, rtkSet, ctImage, ctImageHoisted, ctKernels, ctKernelsHoisted, forks=None):
     """cnn.go:10-39: kernels pre-rotated by 0, 1, 14, 15; the image is hoisted once and reused by the three rotations"""
+    if not forks and hasattr(eval, "Lanes"):
+        prods = _lane_products(eval, rlkSet, rtkSet, ctImage, ctImageHoisted, (0, 1, 14, 15), ctKernels, ctKernelsHoisted)
+        convOut = prods[0]
+        for temp in prods[1:]:
+            convOut = eval.AddNew(convOut, temp)
+        for rot in (2048, 1024):
+            convOut = _rot_add(eval, convOut, rot, rtkSet)
+        return convOut
     def chain(ev, i, rot):
         temp = ev.RotateHoistedNew(ctImage, rot, ctImageHoisted, rtkSet)
         tempHoisted = ev.HoistedForm(temp)
@@ -32,7 +73,7 @@ def Convolution(eval, rlkSet, rtkSet, ctImage, ctImageHoisted, ctKernels, ctKern
     for temp in temps:
         convOut = eval.AddNew(convOut, temp)
     for rot in (2048, 1024):
-        convOut = eval.AddNew(convOut, eval.RotateNew(convOut, rot, rtkSet))
+        convOut = _rot_add(eval, convOut, rot, rtkSet)
     return convOut
 
 
@@ -42,16 +83,19 @@ def FC1Layer(eval, rlkSet, rtkSet, ctVec, ctVecHoisted, ctMat, ctMatHoisted, ctB
         temp = ev.RotateHoistedNew(ctVec, i * 128, ctVecHoisted, rtkSet)
         tempHoisted = ev.HoistedForm(temp)
         return ev.MulRelinHoistedNew(temp, ctMat[i], tempHoisted, ctMatHoisted[i], rlkSet)
-    evs = [eval] + list(forks or [])
-    used = set(evs[i % len(evs)] for i in range(len(ctMat))) - {eval}
-    _fan_out(eval, used)
-    temps = [chain(evs[i % len(evs)], i) for i in range(len(ctMat))]
-    _fan_in(eval, used)
+    if not forks and hasattr(eval, "Lanes"):
+        temps = _lane_products(eval, rlkSet, rtkSet, ctVec, ctVecHoisted, [i * 128 for i in range(len(ctMat))], ctMat, ctMatHoisted)
+    else:
+        evs = [eval] + list(forks or [])
+        used = set(evs[i % len(evs)] for i in range(len(ctMat))) - {eval}
+        _fan_out(eval, used)
+        temps = [chain(evs[i % len(evs)], i) for i in range(len(ctMat))]
+        _fan_in(eval, used)
     fc1Out = temps[0]
     for temp in temps[1:]:
         fc1Out = eval.AddNew(fc1Out, temp)
     for i in range(7):                                        # log2(128)
-        fc1Out = eval.AddNew(fc1Out, eval.RotateNew(fc1Out, 1 << i, rtkSet))
+        fc1Out = _rot_add(eval, fc1Out, 1 << i, rtkSet)
     return eval.AddNew(fc1Out, ctBias)
 
 
@@ -59,10 +103,10 @@ def FC2Layer(eval, rlkSet, rtkSet, ctVec, ctMat, ctBias, ptMask, ptMaskScale):
     """cnn.go:73-96; ptMask: the plaintext polynomial of the 0/1 mask (host, coefficient domain) and its scale"""
     fc2Out = eval.MulPtxtNew(ctVec, ptMask, ptMaskScale)
     for i in range(4):                                        # log2(16)
-        fc2Out = eval.AddNew(fc2Out, eval.RotateNew(fc2Out, -(1 << i), rtkSet))
+        fc2Out = _rot_add(eval, fc2Out, -(1 << i), rtkSet)
     fc2Out = eval.MulRelinNew(fc2Out, ctMat, rlkSet)
     for i in range(6):                                        # log2(64)
-        fc2Out = eval.AddNew(fc2Out, eval.RotateNew(fc2Out, 128 * (1 << i), rtkSet))
+        fc2Out = _rot_add(eval, fc2Out, 128 * (1 << i), rtkSet)
     return eval.AddNew(fc2Out, ctBias)
 
 

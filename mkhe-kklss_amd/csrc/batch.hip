@@ -109,6 +109,80 @@ void Context::rotate_batch(u64 galEl, const std::vector<const Ct*>& ins, const s
     MKHE_HIP(hipGetLastError());
 }
 
+// B rotations of B ciphertexts of ONE shape in one launch set, each by its own Galois element with its own rotation keys and CRS -- the independent
+// rotate -> hoist -> MulRelin chains of cnn's Convolution and FC1Layer (cnn/cnn.go:16-30,51-62) are lanes of one batch instead of chains on forked
+// contexts (round 5: a small kernel does not overlap another one on this chip; 8 chains were 8 times the launches) -- and optionally
+// out[b] = post_add[b] + Rotate(in[b]): the AddNew that follows every RotateNew of the log-sums (cnn.go:33-37,64-67,83-86,90-93) rides on the store.
+void Context::rotate_multi(const std::vector<u64>& galEl, const std::vector<const Ct*>& ins, const std::vector<const Swk*>& hoists, const std::vector<const Swk*>& rk,
+                           const std::vector<const Swk*>& crs, const std::vector<const Ct*>& post_add, const std::vector<Ct*>& outs) {
+    const size_t B = ins.size();
+    if (!B) return;
+    if (outs.size() != B || galEl.size() != B || crs.size() != B) throw Error("mkhe: rotate_multi: one Galois element, one CRS and one output per input");
+    if (!post_add.empty() && post_add.size() != B) throw Error("mkhe: rotate_multi: one addend per input (or none)");
+    same_shape(ins, "Rotate");
+    { std::vector<const Ct*> o(outs.begin(), outs.end()); same_shape(o, "Rotate outputs"); }
+    const int n = ins[0]->n, L = outs[0]->limbs, level = L - 1;
+    check_level(level);
+    if (ins[0]->limbs < L) throw Error("Cannot Rotate: ctIn and ctOut have different levels");
+    if (outs[0]->n != n || outs[0]->ids != ins[0]->ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
+    if (rk.size() != B * (size_t)n) throw Error("mkhe: rotate_multi: one rotation key per input and party");
+    if (!hoists.empty() && hoists.size() != B * (size_t)n) throw Error("mkhe: rotate_multi: one hoisted form per party component");
+    no_cross_alias(ins, outs, "Rotate");
+    for (size_t b = 0; b < B; ++b) {
+        if (galEl[b] == 0 || galEl[b] >= (2ull << logN) || !(galEl[b] & 1)) throw Error("mkhe: rotate_multi: bad Galois element");
+        if (!crs[b]) throw Error("mkhe: rotate_multi: missing CRS");
+        if (!post_add.empty()) {
+            const Ct* p = post_add[b];
+            if (!p || p->n != n || p->ids != ins[0]->ids || p->limbs < L) throw Error("mkhe: rotate_multi: the addend must carry the ids of ctIn at ctOut's level or above");
+            for (size_t k = 0; k < B; ++k) if (p->d == outs[k]->d) throw Error("mkhe: rotate_multi: an output aliases an addend");
+        }
+        for (int a = 0; a < n; ++a) if (!rk[b * n + a]) throw Error("cannot GetRotationKeys: there is no rotation key with given id");
+    }
+    bool alias = false;
+    for (size_t b = 0; b < B; ++b) alias = alias || ins[b]->d == outs[b]->d;
+    if (n == 0 || 2 * n > EXT_MAX_ITEMS || alias) {
+        // (no party component, or in place: one operation at a time, then the addition)
+        for (size_t b = 0; b < B; ++b) {
+            std::vector<const Swk*> h, r(rk.begin() + b * n, rk.begin() + (b + 1) * n);
+            for (int a = 0; a < n && !hoists.empty(); ++a) h.push_back(hoists[b * n + a]);
+            if (n == 0) automorphism(galEl[b], *ins[b], *outs[b]);
+            else rotate(galEl[b], *ins[b], hoists.empty() ? nullptr : h.data(), r.data(), *crs[b], *outs[b]);
+            if (!post_add.empty()) ct_binary(0, *post_add[b], *outs[b], *outs[b]);
+        }
+        return;
+    }
+    const size_t PI = (size_t)ins[0]->limbs * N, PO = (size_t)L * N;
+    Arena ar(this, hoists.empty() ? B * n * swk_words() : 0);
+    std::vector<const u64*> h(B * n);
+    if (hoists.empty()) {
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (size_t b = 0; b < B; ++b)
+            for (int a = 0; a < n; ++a) { u64* d = ar.take(swk_words()); dsrc.push_back(ins[b]->d + (1 + a) * PI); ddst.push_back(d); h[b * n + a] = d; }
+        decompose_batch(level, dsrc, ddst, true);
+    } else {
+        for (size_t i = 0; i < B * n; ++i) { if (!hoists[i]) throw Error("mkhe: missing hoisted form"); h[i] = hoists[i]->d; }
+    }
+    // whole ciphertexts per ext_batch call: the products of one destination meet in one ModDown launch (the fused permutation)
+    const size_t per = std::max<size_t>(1, EXT_MAX_ITEMS / (2 * n));
+    for (size_t b0 = 0; b0 < B; b0 += per) {
+        std::vector<ExtItem> items;
+        for (size_t b = b0; b < std::min(B, b0 + per); ++b) {
+            const size_t PP = post_add.empty() ? 0 : (size_t)post_add[b]->limbs * N;
+            for (int a = 0; a < n; ++a) {
+                items.push_back(ExtItem{h[b * n + a], rk[b * n + a]->d, outs[b]->d, true});
+                if (a == 0) items.back().addend = ins[b]->d;
+                items.back().gal = (unsigned)galEl[b];
+                if (PP) items.back().post = post_add[b]->d;
+                items.push_back(ExtItem{h[b * n + a], crs[b]->d, outs[b]->d + (size_t)(1 + a) * PO, false});
+                items.back().gal = (unsigned)galEl[b];
+                if (PP) items.back().post = post_add[b]->d + (size_t)(1 + a) * PP;
+            }
+        }
+        ext_batch(level, items, -1, 0, 0);
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
 void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vector<const Ct*>& op1, const std::vector<const Swk*>& hoist0,
                               const std::vector<const Swk*>& hoist1, const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                               const Swk& crs_u, bool rescale_out, const std::vector<Ct*>& outs) {

@@ -520,6 +520,20 @@ int mkhe_rotate_batch(mkhe_ctx* ctx, uint64_t galEl, int nbatch, const mkhe_ct* 
         need(ctx)->rotate_batch(galEl, i, h, k.data(), crs->s, o);
     })
 }
+int mkhe_rotate_multi(mkhe_ctx* ctx, int nbatch, const uint64_t* galEl, const mkhe_ct* const* in, const mkhe_swk* const* hoist,
+                      const mkhe_swk* const* rk, const mkhe_swk* const* crs, const mkhe_ct* const* post_add, mkhe_ct* const* out) {
+    MKHE_TRY({
+        if (nbatch < 1 || !galEl || !rk || !crs) throw Error("mkhe_rotate_multi: bad argument");
+        auto i = ct_list(ctx, in, nbatch, "mkhe_rotate_multi");
+        auto o = ct_list_out(ctx, out, nbatch, "mkhe_rotate_multi");
+        auto h = swk_flat(ctx, hoist, (size_t)nbatch * i[0]->n);
+        auto k = swk_flat(ctx, rk, (size_t)nbatch * i[0]->n);
+        auto c = swk_flat(ctx, crs, (size_t)nbatch);
+        std::vector<const Ct*> p;
+        if (post_add) p = ct_list(ctx, post_add, nbatch, "mkhe_rotate_multi");
+        need(ctx)->rotate_multi(std::vector<u64>(galEl, galEl + nbatch), i, h, k, c, p, o);
+    })
+}
 int mkhe_mul_relin_batch(mkhe_ctx* ctx, int nbatch, const mkhe_ct* const* op0, const mkhe_ct* const* op1,
                          const mkhe_swk* const* hoist0, const mkhe_swk* const* hoist1,
                          const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0, const mkhe_swk* const* rlk_v0,

@@ -36,7 +36,10 @@ struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const 
                  const u64* xkey2 = nullptr;  /* mkbfv F1: this party's d2_i (second gadget) */
                  const u64* addend = nullptr; /* accumulate onto this polynomial instead of onto dst (Rotate: c_0 of the input) */
                  const u64* qadd = nullptr;   /* first product of a destination, not accumulating: an NTT-domain polynomial [L][N] (canonical, already
-                                                 times P) that joins the summed Q parts of the merged batch -- dst = that term + the products */ };
+                                                 times P) that joins the summed Q parts of the merged batch -- dst = that term + the products */
+                 unsigned gal = 0;            /* rotate_multi: this destination's own Galois element (0: the ext_batch call's); same for every product of a destination */
+                 const u64* post = nullptr;   /* rotate_multi: polynomial [L][N] added to the finished destination at the STORED (permuted) position --
+                                                 ring.Add(post, Rotate(..)) of AddNew(ct, RotateNew(ct, r)), cnn/cnn.go:33-37 -- by the last product of the destination */ };
 
 typedef unsigned long long seq_t;
 // per handle: (uid of a context, that context's call counter at its latest use of the buffer); `exposed` once the raw device
@@ -129,6 +132,10 @@ class Context {
     void mul_relin_batch(const std::vector<const Ct*>& op0, const std::vector<const Ct*>& op1, const std::vector<const Swk*>& hoist0,
                          const std::vector<const Swk*>& hoist1, const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                          const Swk& crs_u, bool rescale_out, const std::vector<Ct*>& outs);
+    // B rotations in one launch set, each with its own Galois element and keys (rk flat [b * n + a], crs per input), optionally
+    // out[b] = post_add[b] + Rotate(in[b]) (batch.hip; nbatch = 1: the fused rotate-and-add of one ciphertext)
+    void rotate_multi(const std::vector<u64>& galEl, const std::vector<const Ct*>& ins, const std::vector<const Swk*>& hoists, const std::vector<const Swk*>& rk,
+                      const std::vector<const Swk*>& crs, const std::vector<const Ct*>& post_add, const std::vector<Ct*>& outs);
     void ct_binary_batch(int op, const std::vector<const Ct*>& a, const std::vector<const Ct*>& b, const std::vector<Ct*>& outs);
     // MulPtxtNew body (ct_mul_ptxt) for the batch, followed by nb >= 0 divisions by the last modulus (outs have limbs(in) - nb limbs)
     void ct_mul_ptxt_batch(const std::vector<const Ct*>& ins, const u64* dev_pt, int nb, const std::vector<Ct*>& outs);
@@ -160,6 +167,8 @@ class Context {
         u64* dst[64] = {};
         const u64* addend[64] = {};
         const u64* qadd[64] = {};
+        unsigned gal[64] = {};
+        const u64* post[64] = {};
     };
     int ext_merge_members(int level) const;      // members a virtual item may have at this level (< 2: no merging)
     bool ext_plan_merge(int level, const ExtItem* items, int n, ExtMerge& mp) const;

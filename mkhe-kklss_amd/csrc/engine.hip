@@ -1021,6 +1021,7 @@ bool Context::ext_plan_merge(int level, const ExtItem* it, int n, ExtMerge& mp) 
                 mp.accumulate[v] = first ? (it[i].accumulate ? 1 : 0) : 1;
                 mp.addend[v] = first ? it[i].addend : nullptr;
                 mp.qadd[v] = first ? it[i].qadd : nullptr;
+                mp.gal[v] = it[i].gal; mp.post[v] = it[i].post;      // (the destination's: every virtual item of the group carries them, the kernel applies post once)
                 first = 0;
             }
             const int v = mp.nvi - 1;
@@ -1172,11 +1173,14 @@ void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 g
         double bytes = 0;
         for (int v = 0; v < mp->nvi; ++v) {
             md.dst[v] = mp->dst[v]; md.accumulate[v] = mp->accumulate[v]; md.addend[v] = mp->addend[v]; md.cnt[v] = mp->cnt[v];
+            md.gal_v[v] = mp->gal[v]; md.post[v] = mp->post[v];
             for (int k = 0; k < MD_VI_MAX; ++k) md.mem[v] |= (unsigned)mp->mem[v][k] << (8 * k);
             bytes += 8.0 * N * ((level + 1) * (mp->accumulate[v] ? 3.0 : 2.0) + np * mp->cnt[v]);
         }
         md.galEl = galEl; md.logN = logN;
-        if (!rs_maps_.empty() && !galEl && level >= 1) {
+        bool any_gal = galEl != 0;
+        for (int v = 0; v < mp->nvi; ++v) any_gal = any_gal || mp->gal[v] || mp->post[v];
+        if (!rs_maps_.empty() && !any_gal && level >= 1) {
             // fused Rescale (mul_relin_rescale, mul_relin_batch): possible when this launch is the only writer of every polynomial of the products it
             // touches -- every destination inside a registered product, on a polynomial boundary, written once, all polynomials of the product present
             const size_t PF = (size_t)(level + 1) * N;
@@ -1214,6 +1218,7 @@ void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 g
     double bytes = 0;
     for (int i = 0; i < n; ++i) {
         md.dst[i] = it[i].dst; md.accumulate[i] = it[i].accumulate ? 1 : 0; md.addend[i] = it[i].addend;
+        md.gal_v[i] = it[i].gal; md.post[i] = it[i].post;
         bytes += 8.0 * N * ((level + 1) * (it[i].accumulate ? 3.0 : 2.0) + np);
     }
     md.galEl = galEl; md.logN = logN;

@@ -171,6 +171,10 @@ struct ModDownBatchArgs {
     const u64* addend[EXT_MAX_ITEMS];
     u64 galEl;
     int logN;
+    // Context::rotate_multi: gal_v[b] != 0: item b's own Galois element (instead of galEl); post[b] != NULL: that polynomial (limb stride N) is added
+    // to the finished destination at the stored position by the LAST item of the destination's group (AddNew(ct, RotateNew(ct, r)) in one pass)
+    unsigned int gal_v[EXT_MAX_ITEMS];
+    const u64* post[EXT_MAX_ITEMS];
 };
 void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st);
 
@@ -208,6 +212,8 @@ struct ModDownMergedArgs {
     // limb stride N) -- instead of the result itself; the thread computes limb `level` of its coefficient first (every limb slice does).
     const u64* rescale_row;                       // [level]: RescaleParams row of the level, as div_round_last_kernel takes it
     u64* rdst[EXT_MAX_ITEMS];
+    unsigned int gal_v[EXT_MAX_ITEMS];            // as ModDownBatchArgs::gal_v / post, per virtual item
+    const u64* post[EXT_MAX_ITEMS];
 };
 void launch_moddown_merged(const ModDownMergedArgs& a, hipStream_t st);
 

@@ -777,6 +777,8 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
         const u64* xp = xq + a.p_offset;
         u64* dst = ka->dst[item];
         const int acc = ka->accumulate[item];
+        const u64 gal = ka->gal_v[item] ? (u64)ka->gal_v[item] : a.galEl;
+        const u64* post = (k == ka->gstart[g + 1] - 1) ? ka->post[item] : nullptr;
         u64 y[MAXP];
         double vi = 0.0;
 #pragma unroll
@@ -809,8 +811,8 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
             u64 z = mont_mul(lift + mq.q2 - x, ((sc_u64)a.t.downparam)[j], mq.q, mq.ninv32);
             long pos = (long)j * a.N + n;
             bool flip = false;
-            if (a.galEl) {
-                const u64 raw = (u64)n * a.galEl;
+            if (gal) {
+                const u64 raw = (u64)n * gal;
                 pos = (long)j * a.N + (long)(raw & (u64)(a.N - 1));
                 flip = ((raw >> a.logN) & 1) != 0;
             }
@@ -820,7 +822,9 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
                 else if (flip) z = csub((mq.q - dst[pos]) + z, mq.q);       // the stored value is q - (sum so far), in (0, q]
                 else z = csub(dst[pos] + z, mq.q);
             }
-            dst[pos] = flip ? mq.q - z : z;
+            u64 outv = flip ? mq.q - z : z;
+            if (post) outv = csub(post[pos] + outv, mq.q);                  // ring.Add(post, rotated): outv in [0, q] (q for a flipped zero), the sum canonical
+            dst[pos] = outv;
         }
     }
 }
@@ -863,6 +867,8 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
         const u64* xq = a.c1 + (long)(members & 255u) * a.c1_item;
         u64* dst = ka->dst[vi];
         const int acc = (int)ka->accumulate[vi];
+        const u64 gal = ka->gal_v[vi] ? (u64)ka->gal_v[vi] : a.galEl;
+        const u64* post = (kk == ka->gstart[g + 1] - 1) ? ka->post[vi] : nullptr;
         u64 y[MD_VI_MAX][NPT];
         u32 v[MD_VI_MAX];
 #pragma unroll
@@ -929,8 +935,8 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
             u64 z = down(j, mq);
             long pos = (long)j * a.N + n;
             bool flip = false;
-            if (a.galEl) {
-                const u64 raw = (u64)n * a.galEl;
+            if (gal) {
+                const u64 raw = (u64)n * gal;
                 pos = (long)j * a.N + (long)(raw & (u64)(a.N - 1));
                 flip = ((raw >> a.logN) & 1) != 0;
             }
@@ -940,7 +946,9 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
                 else if (flip) z = csub((mq.q - dst[pos]) + z, mq.q);       // the stored value is q - (sum so far), in (0, q]
                 else z = csub(dst[pos] + z, mq.q);
             }
-            dst[pos] = flip ? mq.q - z : z;
+            u64 outv = flip ? mq.q - z : z;
+            if (post) outv = csub(post[pos] + outv, mq.q);                  // ring.Add(post, rotated): outv in [0, q] (q for a flipped zero), the sum canonical
+            dst[pos] = outv;
         }
     }
 }

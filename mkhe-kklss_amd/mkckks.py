@@ -255,6 +255,44 @@ class Evaluator:
         self.ksw.Conjugate(ct0, ckSet, ctOut)
         return ctOut
 
+    # ---- AddNew(ct0, RotateNew(ct0, rotidx, rkSet)): the step every log-sum of cnn/cnn.go repeats (:33-37,64-67,83-86,90-93) as ONE engine call --
+    # the ring.Add rides on the store of the rotation's ModDown (mkhe_rotate_multi with post_add).  Same integers as the two calls.
+    def RotateAndAddNew(self, ct0, rotidx, rkSet):
+        rotidx = self._norm_rot(rotidx)
+        if rotidx == 0:
+            return self.AddNew(ct0, self.RotateNew(ct0, 0, rkSet))
+        ctTmp, k, steps = ct0, 1, []
+        if rotidx in self.params.CRS:
+            steps = [rotidx]
+        else:
+            r = rotidx
+            while r > 0:                                    # power-of-two decomposition, :516-523: the addition joins the LAST rotation
+                if r % 2:
+                    steps.append(k)
+                r //= 2
+                k *= 2
+        for s in steps[:-1]:
+            nxt = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale, zero=False)
+            self.ksw.Rotate(ctTmp, s, rkSet, nxt)
+            ctTmp = nxt
+        last = steps[-1]
+        if last not in self.params.CRS:
+            raise MkheError("mkhe: no CRS for rotation index %d" % last)
+        ctOut = NewCiphertext(self.params, ct0.IDSet(), ct0.Level(), ct0.Scale, zero=False)
+        rk = [rkSet.GetRotationKey(i, last).Value.h for i in ct0.ids]
+        gal = (C.c_uint64 * 1)(self.params.GaloisElementForColumnRotationBy(last))
+        check(lib().mkhe_rotate_multi(self.params.ctx, 1, gal, handle_array([ctTmp.h]), None, handle_array(rk), handle_array([self.params.CRS[last].h]),
+                                      handle_array([ct0.h]), handle_array([ctOut.h])))
+        return ctOut
+
+    def Lanes(self, n):
+        """n independent operations of one shape on THIS context as one launch set (a BatchEvaluator over the same stream): how the device runs the
+        independent chains of cnn.Convolution / FC1Layer -- small kernels do not overlap each other on this chip, lanes make them one kernel"""
+        hit = self.__dict__.setdefault("_lanes", {}).get(n)
+        if hit is None:
+            hit = self._lanes[n] = BatchEvaluator(self.params, n, ev=self)
+        return hit
+
 
 def NewEvaluator(params):
     return Evaluator(params)
@@ -292,9 +330,9 @@ class BatchEvaluator:
     input -- the model of cnn -- a plain Ciphertext / HoistedCiphertext, which is broadcast) and issues ONE launch set for the B operations
     (mkhe_*_batch).  mkhe_kklss_amd.cnn runs on it unchanged.  Scale bookkeeping is the single-input evaluator's (one shape, one scale)."""
 
-    def __init__(self, params, B):
+    def __init__(self, params, B, ev=None):
         self.params, self.B = params, int(B)
-        self.ev = Evaluator(params)
+        self.ev = ev if ev is not None else Evaluator(params)
         self._bcast = {}                       # broadcast operands (the model ciphertexts of cnn): their (void*)[B], keyed by object
 
     def Fork(self):
@@ -422,12 +460,38 @@ class BatchEvaluator:
         return tmp
 
     def RotateHoistedNew(self, ct, rotidx, ctHoisted, rkSet):
+        if isinstance(rotidx, (list, tuple)):
+            return self._rotate_multi(ct, [self.ev._norm_rot(r) for r in rotidx], ctHoisted, rkSet, None)
         rotidx = self.ev._norm_rot(rotidx)
         if rotidx == 0:
             return BatchCiphertext([self.ev.RotateNew(c, 0, rkSet) for c in self._cts(ct)])
         if rotidx not in self.params.CRS:
             raise MkheError("Hoisted rotation only works for precomputed rotation keys")
         return self._rotate(ct, rotidx, ctHoisted, rkSet)
+
+    def _rotate_multi(self, ct, rots, hoisted, rkSet, post):
+        """input b rotated by rots[b] (every index non-zero and with a CRS), each with its own keys: one launch set (mkhe_rotate_multi);
+        post: BatchCiphertext / Ciphertext added to the rotated ciphertexts on the store, or None"""
+        params = self.params
+        cts = self._cts(ct)
+        if len(rots) != self.B:
+            raise MkheError("BatchEvaluator: one rotation index per input")
+        for r in rots:
+            if r == 0 or r not in params.CRS:
+                raise MkheError("Hoisted rotation only works for precomputed rotation keys")
+        out = self._new(cts[0].IDSet(), cts[0].Level(), cts[0].Scale)
+        rk = [rkSet.GetRotationKey(i, r).Value.h for r in rots for i in cts[0].ids]
+        gal = (C.c_uint64 * self.B)(*[params.GaloisElementForColumnRotationBy(r) for r in rots])
+        check(lib().mkhe_rotate_multi(params.ctx, self.B, gal, self._h(ct), self._hoists(hoisted, cts), handle_array(rk),
+                                      handle_array([params.CRS[r].h for r in rots]), self._h(post) if post is not None else None, self._h(out)))
+        return out
+
+    def RotateAndAddNew(self, ct, rotidx, rkSet):
+        """AddNew(ct, RotateNew(ct, rotidx, rkSet)) for every input, the addition on the store of the rotation (Evaluator.RotateAndAddNew)"""
+        rotidx = self.ev._norm_rot(rotidx)
+        if rotidx == 0 or rotidx not in self.params.CRS:
+            return self.AddNew(ct, self.RotateNew(ct, rotidx, rkSet))
+        return self._rotate_multi(ct, [rotidx] * self.B, None, rkSet, ct)
 
     # -- MulPtxtNew (evaluator.go:465-481)
     def MulPtxtNew(self, ct, pt_value, pt_scale):

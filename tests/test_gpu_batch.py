@@ -230,3 +230,67 @@ def test_pool_statistics_and_trim(case):
     _, again = case.ct(["a", "b"])                         # allocation after a trim
     assert again.download().shape == want[0].shape
     assert lib().mkhe_pool_held_bytes(None) == -1 and lib().mkhe_ntt_choice(None, 1792, 1) == -2
+
+
+# ---------------------------------------------------------------- round 5: lanes with their own rotation, rotate-and-add in one pass
+@pytest.mark.parametrize("ids,level", [(["a", "b"], None), (["a", "b", "c", "d"], 2), (["c"], 1), (["a", "b", "c"], 0)])
+@pytest.mark.parametrize("hoisted", [False, True])
+def test_rotate_multi_each_lane_its_own_rotation(case, ids, level, hoisted):
+    """mkhe_rotate_multi: lane b rotates by rots[b] with the keys of THAT rotation; every lane against the oracle's Rotate (keyswitch_hoisted.go:183-247)"""
+    rots = [1, 5, 5, 1, 1]
+    B = len(rots)
+    level = case.level if level is None else level
+    bev = case.mkckks.BatchEvaluator(case.params, B)
+    hs, b = case.batch(ids, B, level)
+    hb = bev.HoistedForm(b) if hoisted else None
+    out = bev._rotate_multi(b, rots, hb, case.rtk, None)
+    for k, r in enumerate(rots):
+        o = case.ks.rotate(level, pow(5, r, 2 << case.p["logN"]), list(range(len(ids))), hs[k], [case.rk_h[(n, r)] for n in sorted(ids)], case.crs_h[r])
+        assert (out.cts[k].download() == o).all(), (k, r)
+    # one input broadcast to every lane (cnn: the image / the FC1 input), hoisted once
+    h1, c1 = case.ct(ids, level)
+    hh = case.ev.HoistedForm(c1) if hoisted else None
+    out = bev.RotateHoistedNew(c1, rots, hh, case.rtk) if hoisted else bev._rotate_multi(c1, rots, None, case.rtk, None)
+    for k, r in enumerate(rots):
+        o = case.ks.rotate(level, pow(5, r, 2 << case.p["logN"]), list(range(len(ids))), h1, [case.rk_h[(n, r)] for n in sorted(ids)], case.crs_h[r])
+        assert (out.cts[k].download() == o).all(), (k, r)
+
+
+@pytest.mark.parametrize("ids,level", [(["a", "b"], None), (["a", "b", "c", "d"], 1), (["d"], 0)])
+def test_rotate_and_add_is_the_two_calls(case, ids, level):
+    """AddNew(ct, RotateNew(ct, r)) in one engine call (the add on the rotation's store; cnn/cnn.go:33-37): against the oracle's Rotate followed by
+    ring.Add, for one ciphertext, for a batch, and with an addend that is NOT the rotated ciphertext; a rotated zero coefficient with a sign flip is
+    stored as q by the permutation (keyswitch.go:290) and must still add up canonically"""
+    from mkhe_kklss_amd._abi import check, lib, handle_array, MkheError
+    import ctypes as C
+    level = case.level if level is None else level
+    N, Q = 1 << case.p["logN"], case.p["Q"]
+    h, c = case.ct(ids, level)
+    def ref(hin, hadd, r):
+        o = case.ks.rotate(level, pow(5, r, 2 * N), list(range(len(ids))), hin, [case.rk_h[(n, r)] for n in sorted(ids)], case.crs_h[r])
+        return np.stack([np.stack([case.ks.ringQ.add(j, hadd[s, j], o[s, j]) for j in range(level + 1)]) for s in range(o.shape[0])])
+    for r in case.rots:
+        got = case.ev.RotateAndAddNew(c, r, case.rtk)
+        assert (got.download() == ref(h, h, r)).all(), r
+        two = case.ev.AddNew(c, case.ev.RotateNew(c, r, case.rtk))
+        assert (got.download() == two.download()).all() and got.Scale == two.Scale and got.Level() == two.Level()
+    assert (case.ev.RotateAndAddNew(c, 0, case.rtk).download() == case.ev.AddNew(c, c).download()).all()
+    # batch, and a different addend per lane
+    B = 3
+    bev = case.mkckks.BatchEvaluator(case.params, B)
+    hs, b = case.batch(ids, B, level)
+    ha, a = case.batch(ids, B, level)
+    got = bev.RotateAndAddNew(b, 5, case.rtk)
+    oth = bev._rotate_multi(b, [5, 1, 5], None, case.rtk, a)
+    for k in range(B):
+        assert (got.cts[k].download() == ref(hs[k], hs[k], 5)).all(), k
+        assert (oth.cts[k].download() == ref(hs[k], ha[k], [5, 1, 5][k])).all(), k
+    # errors: an output that is an addend; an addend with other ids
+    rk = [case.rtk.GetRotationKey(i, 1).Value.h for i in c.ids]
+    gal = (C.c_uint64 * 1)(case.params.GaloisElementForColumnRotationBy(1))
+    out = case.mkckks.NewCiphertext(case.params, ids, level, case.p["scale"])
+    with pytest.raises(MkheError, match="aliases an addend"):
+        check(lib().mkhe_rotate_multi(case.params.ctx, 1, gal, handle_array([c.h]), None, handle_array(rk), handle_array([case.params.CRS[1].h]), handle_array([out.h]), handle_array([out.h])))
+    _, other = case.ct(["a", "c"] if ids != ["a", "c"] else ["b"], level)
+    with pytest.raises(MkheError, match="addend must carry the ids"):
+        check(lib().mkhe_rotate_multi(case.params.ctx, 1, gal, handle_array([c.h]), None, handle_array(rk), handle_array([case.params.CRS[1].h]), handle_array([other.h]), handle_array([out.h])))
