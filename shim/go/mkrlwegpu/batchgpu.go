@@ -4,6 +4,9 @@
 // lock step").  All inputs of a call have the same ids and level; keys and CRS belong to the parties and are shared; an operand that is the same for
 // every input (a model) is passed B times.  Un-built here like the rest of the shim (no Go toolchain in the build image); its C calls are checked
 // against include/mkhe.h by tests/test_go_shim_static.py.
+//
+//go:build mkhe_gpu
+
 package mkrlwegpu
 
 /*
@@ -15,6 +18,15 @@ import "C"
 import (
 	"unsafe"
 )
+
+// sameLen panics unless every list of a batched call has the batch's length: C reads nbatch entries of each array (ADVICE r4).
+func sameLen(what string, n int, lens ...int) {
+	for _, l := range lens {
+		if l != n {
+			panic("mkrlwegpu: " + what + ": the lists of a batch must have one length")
+		}
+	}
+}
 
 // ctArray copies ciphertext handles into C memory (see swkArray).  The caller frees it.
 func ctArray(cts []*Ciphertext) **C.mkhe_ct {
@@ -60,7 +72,7 @@ func (ctx *Context) NewSwitchingKeyBatch(count int) []*SwitchingKey {
 // HoistedFormBatch: mkckks.Evaluator.HoistedForm (mkckks/evaluator.go:543-553) of B ciphertexts; the result holds len(ids) keys per input, input
 // after input, aligned with the ids.
 func (ctx *Context) HoistedFormBatch(cts []*Ciphertext, level int) []*SwitchingKey {
-	if len(cts) == 0 {
+	if len(cts) == 0 || len(cts[0].ids) == 0 {
 		return nil
 	}
 	out := ctx.NewSwitchingKeyBatch(len(cts) * len(cts[0].ids))
@@ -78,6 +90,13 @@ func (ctx *Context) HoistedFormBatch(cts []*Ciphertext, level int) []*SwitchingK
 func (ctx *Context) MulRelinBatch(op0, op1 []*Ciphertext, hoisted0, hoisted1 []*SwitchingKey, rk RelinKeys, crsU *SwitchingKey, rescale bool, out []*Ciphertext) {
 	if len(op0) == 0 {
 		return
+	}
+	sameLen("MulRelinBatch", len(op0), len(op1), len(out))
+	if hoisted0 != nil {
+		sameLen("MulRelinBatch (hoisted0)", len(op0)*len(op0[0].ids), len(hoisted0))
+	}
+	if hoisted1 != nil {
+		sameLen("MulRelinBatch (hoisted1)", len(op1)*len(op1[0].ids), len(hoisted1))
 	}
 	b1 := handles(op1[0].ids, rk, 0)
 	d0 := handles(op0[0].ids, rk, 1)
@@ -106,6 +125,11 @@ func (ctx *Context) RotateBatch(in []*Ciphertext, rotidx int, hoisted []*Switchi
 	if len(in) == 0 {
 		return
 	}
+	sameLen("RotateBatch", len(in), len(out))
+	sameLen("RotateBatch (rk)", len(in[0].ids), len(rk))
+	if hoisted != nil {
+		sameLen("RotateBatch (hoisted)", len(in)*len(in[0].ids), len(hoisted))
+	}
 	ai, ao := ctArray(in), ctArray(out)
 	defer C.free(unsafe.Pointer(ai))
 	defer C.free(unsafe.Pointer(ao))
@@ -127,6 +151,7 @@ func (ctx *Context) binaryBatch(op int, op0, op1, out []*Ciphertext) {
 	if len(op0) == 0 {
 		return
 	}
+	sameLen("AddBatch / SubBatch", len(op0), len(op1), len(out))
 	a0, a1, ao := ctArray(op0), ctArray(op1), ctArray(out)
 	defer C.free(unsafe.Pointer(a0))
 	defer C.free(unsafe.Pointer(a1))
@@ -140,8 +165,43 @@ func (ctx *Context) MulPtxtBatch(in []*Ciphertext, pt *Plaintext, nbRescale int,
 	if len(in) == 0 {
 		return
 	}
+	sameLen("MulPtxtBatch", len(in), len(out))
 	ai, ao := ctArray(in), ctArray(out)
 	defer C.free(unsafe.Pointer(ai))
 	defer C.free(unsafe.Pointer(ao))
 	must(C.mkhe_ct_mul_ptxt_batch(ctx.c, C.int(len(in)), ai, pt.dev, C.int(nbRescale), ao))
+}
+
+// RotateMulti: B rotations of B ciphertexts of one shape, each by its own rotation index with its own keys (mkhe_rotate_multi; rk flat
+// [b * n + a], crs[b] = params.CRS[rotidx[b]]), optionally out[b] = postAdd[b] + Rotate(in[b]) with the AddNew on the rotation's store
+// (cnn/cnn.go:16-37,51-67: the independent chains of a layer as lanes of one launch set, the log-sum steps as one pass).
+func (ctx *Context) RotateMulti(in []*Ciphertext, rotidx []int, hoisted []*SwitchingKey, rk []*SwitchingKey, crs []*SwitchingKey, postAdd []*Ciphertext, out []*Ciphertext) {
+	if len(in) == 0 {
+		return
+	}
+	sameLen("RotateMulti", len(in), len(out), len(rotidx), len(crs))
+	sameLen("RotateMulti (rk)", len(in)*len(in[0].ids), len(rk))
+	gal := make([]C.uint64_t, len(rotidx))
+	for i, r := range rotidx {
+		gal[i] = C.uint64_t(ctx.params.GaloisElementForColumnRotationBy(r))
+	}
+	ai, ao := ctArray(in), ctArray(out)
+	defer C.free(unsafe.Pointer(ai))
+	defer C.free(unsafe.Pointer(ao))
+	var h **C.mkhe_swk
+	if hoisted != nil {
+		sameLen("RotateMulti (hoisted)", len(in)*len(in[0].ids), len(hoisted))
+		h = swkArray(hoisted)
+		defer C.free(unsafe.Pointer(h))
+	}
+	r, c := swkArray(rk), swkArray(crs)
+	defer C.free(unsafe.Pointer(r))
+	defer C.free(unsafe.Pointer(c))
+	var p **C.mkhe_ct
+	if postAdd != nil {
+		sameLen("RotateMulti (postAdd)", len(in), len(postAdd))
+		p = ctArray(postAdd)
+		defer C.free(unsafe.Pointer(p))
+	}
+	must(C.mkhe_rotate_multi(ctx.c, C.int(len(in)), &gal[0], ai, h, r, c, p, ao))
 }

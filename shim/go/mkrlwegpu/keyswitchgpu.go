@@ -19,8 +19,6 @@ import (
 	"unsafe"
 
 	"github.com/ldsec/lattigo/v2/ring"
-
-	"mk-lattigo/mkrlwe"
 )
 
 // NewSwitchingKey allocates an uninitialised device switching key / hoisted-digit vector (mkrlwe.NewSwitchingKey, keys.go:245-255:
@@ -180,4 +178,3 @@ func (ctx *Context) MulPtxt(in *Ciphertext, pt *Plaintext, out *Ciphertext) {
 // Sync waits for everything enqueued on the context (the reference is synchronous; Download synchronises by itself).
 func (ctx *Context) Sync() { must(C.mkhe_ctx_sync(ctx.c)) }
 
-var _ = mkrlwe.NewIDSet

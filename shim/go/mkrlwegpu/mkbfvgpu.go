@@ -17,15 +17,22 @@ import (
 	"runtime"
 	"unsafe"
 
-	"mk-lattigo/mkbfv"
-	"mk-lattigo/mkrlwe"
+	"github.com/ldsec/lattigo/v2/ring"
+	"github.com/ldsec/lattigo/v2/rlwe"
 )
+
+// BFVParams is what the binding reads of mkbfv.Parameters (mkbfv/params.go:27-34,83-103) beyond Params.
+type BFVParams interface {
+	Params
+	RingQMul() *ring.Ring
+	T() uint64
+}
 
 // NewBFVContext replaces mkbfv.NewKeySwitcher + NewFastBasisExtender (mkbfv/keyswitch.go:31-65,
 // basis_extension.go:20-47).  The engine generates lattigo's default roots itself (ring.NewRing rule).
-func NewBFVContext(params mkbfv.Parameters, device int) *Context {
+func NewBFVContext(params BFVParams, device int) *Context {
 	q, qm, p := params.RingQ().Modulus, params.RingQMul().Modulus, params.RingP().Modulus
-	ctx := &Context{params: params.Parameters, ids: map[string]C.int{}}
+	ctx := &Context{params: params, ids: map[string]C.int{}}
 	must(C.mkhe_ctx_create_bfv(&ctx.c, C.int(params.LogN()),
 		(*C.uint64_t)(unsafe.Pointer(&q[0])), (*C.uint64_t)(unsafe.Pointer(&qm[0])), C.int(len(q)),
 		(*C.uint64_t)(unsafe.Pointer(&p[0])), C.int(len(p)), C.int(params.Gamma()), C.uint64_t(params.T()), C.int(device)))
@@ -38,20 +45,31 @@ type BFVRelinKeys struct {
 	B1, B2, D1, D2, V map[string]*SwitchingKey
 }
 
-func (ctx *Context) UploadBFVRelinKey(rk *BFVRelinKeys, rlk *mkbfv.RelinearizationKey) {
-	id := rlk.ID
-	rk.B1[id] = ctx.UploadSwitchingKey(rlk.Value[0].Value[0])
-	rk.B2[id] = ctx.UploadSwitchingKey(rlk.Value[1].Value[0])
-	rk.D1[id] = ctx.UploadSwitchingKey(rlk.Value[0].Value[1])
-	rk.D2[id] = ctx.UploadSwitchingKey(rlk.Value[1].Value[1])
-	rk.V[id] = ctx.UploadSwitchingKey(rlk.Value[0].Value[2])
+// NewBFVRelinKeys returns an empty key table.
+func NewBFVRelinKeys() *BFVRelinKeys {
+	return &BFVRelinKeys{B1: map[string]*SwitchingKey{}, B2: map[string]*SwitchingKey{}, D1: map[string]*SwitchingKey{}, D2: map[string]*SwitchingKey{}, V: map[string]*SwitchingKey{}}
+}
+
+// UploadBFVRelinKey: party id's key, rlk.Value[g].Value[k].Value for gadget g = 0, 1 and k = 0 (b), 1 (d), 2 (v) (mkbfv/keys.go:6-9:
+// two mkrlwe.RelinearizationKeys; v of the second gadget is not used, mkbfv/keygen.go:24-88).
+func (ctx *Context) UploadBFVRelinKey(rk *BFVRelinKeys, id string, b1, b2, d1, d2, v []rlwe.PolyQP) {
+	rk.B1[id] = ctx.UploadSwitchingKey(b1)
+	rk.B2[id] = ctx.UploadSwitchingKey(b2)
+	rk.D1[id] = ctx.UploadSwitchingKey(d1)
+	rk.D2[id] = ctx.UploadSwitchingKey(d2)
+	rk.V[id] = ctx.UploadSwitchingKey(v)
 }
 
 func swkList(ids []string, m map[string]*SwitchingKey) **C.mkhe_swk {
-	arr := (**C.mkhe_swk)(C.malloc(C.size_t(len(ids)) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-	s := unsafe.Slice(arr, len(ids))
+	arr := (**C.mkhe_swk)(C.malloc(C.size_t(len(ids)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	s := unsafe.Slice(arr, len(ids)+1)
+	s[len(ids)] = nil
 	for i, id := range ids {
-		s[i] = m[id].h
+		k, ok := m[id]
+		if !ok {
+			panic("cannot GetRelinearizationKey: there is no relinearization key with given id") // mkbfv/keys.go:75-83
+		}
+		s[i] = k.h
 	}
 	return arr
 }
@@ -98,4 +116,3 @@ func (ctx *Context) ExternalProductBFVHoisted(ah1, ah2, bg1, bg2 *SwitchingKey, 
 func (ctx *Context) AddBFV(op0, op1, out *Ciphertext) { must(C.mkhe_ct_add(ctx.c, op0.h, op1.h, out.h)) }
 func (ctx *Context) SubBFV(op0, op1, out *Ciphertext) { must(C.mkhe_ct_sub(ctx.c, op0.h, op1.h, out.h)) }
 
-var _ = mkrlwe.NewIDSet

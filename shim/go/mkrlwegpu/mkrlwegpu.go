@@ -6,6 +6,13 @@
 //
 //	go build -tags mkhe_gpu ./...      with CGO_CFLAGS=-I<repo>/include  CGO_LDFLAGS="-L<repo>/mkhe-kklss_amd/lib -lmkhe_hip"
 //
+// Round 5: this package is a LEAF -- it imports lattigo and nothing of mk-lattigo.  The reference's tests live inside its packages
+// (`package mkrlwe`, `package mkckks`: they use unexported helpers), and a test of package P cannot import a package that imports P; so the
+// signature-compatible drop-in types are files of the reference's own packages behind the same build tag (shim/go/dropin/mkrlwe, mkckks,
+// mkbfv: they import this package), and what this package needs of mkrlwe.Parameters is the interface Params below, which that type
+// satisfies as it stands.  Ciphertexts and keys cross as the lattigo values the reference's structs hold (map[string]*ring.Poly,
+// []rlwe.PolyQP).
+//
 //go:build mkhe_gpu
 
 package mkrlwegpu
@@ -19,12 +26,11 @@ import "C"
 import (
 	"fmt"
 	"runtime"
+	"sort"
 	"unsafe"
 
 	"github.com/ldsec/lattigo/v2/ring"
 	"github.com/ldsec/lattigo/v2/rlwe"
-
-	"mk-lattigo/mkrlwe"
 )
 
 func must(rc C.int) {
@@ -33,10 +39,25 @@ func must(rc C.int) {
 	}
 }
 
+// Params is what the binding reads of mkrlwe.Parameters (mkrlwe/params.go:8-12,63-75; the rest through the embedded rlwe.Parameters).
+type Params interface {
+	LogN() int
+	N() int
+	QCount() int
+	PCount() int
+	MaxLevel() int
+	RingQ() *ring.Ring
+	RingP() *ring.Ring
+	Gamma() int
+	Beta(levelQ int) int
+	GaloisElementForColumnRotationBy(k int) uint64
+	GaloisElementForRowRotation() uint64
+}
+
 // Context replaces mkrlwe.NewKeySwitcher (mkrlwe/keyswitch.go:33-47).
 type Context struct {
 	c      *C.mkhe_ctx
-	params mkrlwe.Parameters
+	params Params
 	ids    map[string]C.int // Go string ids -> dense ints of the C ABI
 }
 
@@ -45,7 +66,7 @@ func psiOf(r *ring.Ring, i int) uint64 {
 	return ring.InvMForm(r.NttPsi[i][r.N>>1], r.Modulus[i], r.MredParams[i])
 }
 
-func NewContext(params mkrlwe.Parameters, device int) *Context {
+func NewContext(params Params, device int) *Context {
 	rq, rp := params.RingQ(), params.RingP()
 	psiQ := make([]uint64, len(rq.Modulus))
 	psiP := make([]uint64, len(rp.Modulus))
@@ -64,6 +85,9 @@ func NewContext(params mkrlwe.Parameters, device int) *Context {
 	runtime.SetFinalizer(ctx, func(c *Context) { C.mkhe_ctx_destroy(c.c) })
 	return ctx
 }
+
+// Params returns the parameters the context was created from.
+func (ctx *Context) Params() Params { return ctx.params }
 
 func (ctx *Context) id(s string) C.int {
 	if v, ok := ctx.ids[s]; ok {
@@ -89,23 +113,37 @@ func (k *SwitchingKey) Close() {
 	runtime.SetFinalizer(k, nil)
 }
 
-// UploadSwitchingKey copies []rlwe.PolyQP into ONE contiguous Go buffer [digit][Q limbs..., P limbs...][N] and hands that to
-// mkhe_swk_upload.  (Storing the Go limb pointers in a C array -- mkhe_swk_upload_limbs -- is not allowed by the cgo pointer
-// rules unless every slice is pinned with runtime.Pinner; one staging copy of 56 MiB at key-upload time is the simpler contract.)
-func (ctx *Context) UploadSwitchingKey(swk *mkrlwe.SwitchingKey) *SwitchingKey {
+// stageSwitchingKey copies []rlwe.PolyQP (mkrlwe.SwitchingKey.Value) into ONE contiguous Go buffer [digit][Q limbs..., P limbs...][N], the layout
+// of mkhe_swk_upload / mkhe_swk_download.  (Storing the Go limb pointers in a C array -- mkhe_swk_upload_limbs -- is not allowed by the cgo
+// pointer rules unless every slice is pinned with runtime.Pinner; one staging copy of 56 MiB at key-upload time is the simpler contract.)
+func (ctx *Context) swkWords(digits int) int {
+	return digits * (ctx.params.QCount() + ctx.params.PCount()) * ctx.params.N()
+}
+
+// UploadSwitchingKey copies a switching key / CRS / hoisted digit vector (value = mkrlwe.SwitchingKey.Value, NTT domain as the Go side
+// stores it) to the device.  Digits beyond len(value) -- a key allocated at a lower level -- stay zero.
+func (ctx *Context) UploadSwitchingKey(value []rlwe.PolyQP) *SwitchingKey {
 	out := &SwitchingKey{ctx: ctx}
 	must(C.mkhe_swk_create(ctx.c, &out.h))
 	runtime.SetFinalizer(out, func(k *SwitchingKey) { k.Close() })
 	nq, np, n := ctx.params.QCount(), ctx.params.PCount(), ctx.params.N()
-	buf := make([]uint64, len(swk.Value)*(nq+np)*n)
+	beta := ctx.params.Beta(ctx.params.MaxLevel())
+	if len(value) > beta {
+		panic("mkrlwegpu: switching key with more digits than Beta(MaxLevel)")
+	}
+	buf := make([]uint64, ctx.swkWords(beta))
 	k := 0
-	for _, p := range swk.Value {
+	for _, p := range value {
 		for j := 0; j < nq; j++ {
-			copy(buf[k:k+n], p.Q.Coeffs[j])
+			if j < len(p.Q.Coeffs) {
+				copy(buf[k:k+n], p.Q.Coeffs[j])
+			}
 			k += n
 		}
 		for j := 0; j < np; j++ {
-			copy(buf[k:k+n], p.P.Coeffs[j])
+			if j < len(p.P.Coeffs) {
+				copy(buf[k:k+n], p.P.Coeffs[j])
+			}
 			k += n
 		}
 	}
@@ -114,12 +152,37 @@ func (ctx *Context) UploadSwitchingKey(swk *mkrlwe.SwitchingKey) *SwitchingKey {
 	return out
 }
 
+// DownloadSwitchingKey writes the device key back into value (the digits and limbs value has).
+func (ctx *Context) DownloadSwitchingKey(d *SwitchingKey, value []rlwe.PolyQP) {
+	nq, np, n := ctx.params.QCount(), ctx.params.PCount(), ctx.params.N()
+	beta := ctx.params.Beta(ctx.params.MaxLevel())
+	buf := make([]uint64, ctx.swkWords(beta))
+	must(C.mkhe_swk_download(ctx.c, d.h, (*C.uint64_t)(unsafe.Pointer(&buf[0]))))
+	k := 0
+	for i := 0; i < beta; i++ {
+		for j := 0; j < nq+np; j++ {
+			if i < len(value) {
+				if j < nq && j < len(value[i].Q.Coeffs) {
+					copy(value[i].Q.Coeffs[j], buf[k:k+n])
+				} else if j >= nq && j-nq < len(value[i].P.Coeffs) {
+					copy(value[i].P.Coeffs[j-nq], buf[k:k+n])
+				}
+			}
+			k += n
+		}
+	}
+	runtime.KeepAlive(d)
+}
+
 // Ciphertext mirrors mkrlwe.Ciphertext (elements.go:17-19) on the device.
 type Ciphertext struct {
 	h   *C.mkhe_ct
 	ids []string
 	ctx *Context
 }
+
+// IDs are the party ids of the device ciphertext, in slot order (slot 0 = "0", slot 1 + i = IDs()[i]).
+func (c *Ciphertext) IDs() []string { return c.ids }
 
 func (c *Ciphertext) Close() {
 	if c.h != nil {
@@ -140,31 +203,29 @@ func (ctx *Context) newCt(ids []string, level int) *Ciphertext {
 	return out
 }
 
-func sortedIDs(ct *mkrlwe.Ciphertext) []string {
-	ids := []string{}
-	for id := range ct.IDSet().Value {
-		ids = append(ids, id)
-	}
-	// any fixed order: every accumulation of the algorithm is canonical (SURVEY.md 8b)
-	for i := range ids {
-		for j := i + 1; j < len(ids); j++ {
-			if ids[j] < ids[i] {
-				ids[i], ids[j] = ids[j], ids[i]
-			}
+// SortedIDs: the party ids of a ciphertext value (every key but "0") in the fixed order the device slots use.  Any fixed order gives the
+// reference's result: every accumulation of the algorithm is canonical (SURVEY.md 8b; Go iterates its maps in random order).
+func SortedIDs(value map[string]*ring.Poly) []string {
+	ids := make([]string, 0, len(value))
+	for id := range value {
+		if id != "0" {
+			ids = append(ids, id)
 		}
 	}
+	sort.Strings(ids)
 	return ids
 }
 
-// Upload copies ct.Value[...] (coefficient domain) to the device through one contiguous staging buffer [slot][limb][N].
-func (ctx *Context) Upload(ct *mkrlwe.Ciphertext) *Ciphertext {
-	ids := sortedIDs(ct)
-	out := ctx.newCt(ids, ct.Level())
-	limbs, n := ct.Level()+1, ctx.params.N()
+// Upload copies value (mkrlwe.Ciphertext.Value: "0" and one polynomial per party id, coefficient domain) at the given level to the device
+// through one contiguous staging buffer [slot][limb][N].
+func (ctx *Context) Upload(value map[string]*ring.Poly, level int) *Ciphertext {
+	ids := SortedIDs(value)
+	out := ctx.newCt(ids, level)
+	limbs, n := level+1, ctx.params.N()
 	buf := make([]uint64, (len(ids)+1)*limbs*n)
 	for slot, id := range append([]string{"0"}, ids...) {
 		for j := 0; j < limbs; j++ {
-			copy(buf[(slot*limbs+j)*n:(slot*limbs+j+1)*n], ct.Value[id].Coeffs[j])
+			copy(buf[(slot*limbs+j)*n:(slot*limbs+j+1)*n], value[id].Coeffs[j])
 		}
 	}
 	must(C.mkhe_ct_upload(ctx.c, out.h, (*C.uint64_t)(unsafe.Pointer(&buf[0]))))
@@ -172,30 +233,30 @@ func (ctx *Context) Upload(ct *mkrlwe.Ciphertext) *Ciphertext {
 	return out
 }
 
-// Download writes the device ciphertext back into ct (which must have the same ids and level).
-func (ctx *Context) Download(d *Ciphertext, ct *mkrlwe.Ciphertext) {
-	limbs, n := ct.Level()+1, ctx.params.N()
+// UploadPoly: one polynomial as a ciphertext without party components (slot 0), the operand form of Decompose / ExternalProduct.
+func (ctx *Context) UploadPoly(p *ring.Poly, level int) *Ciphertext {
+	return ctx.Upload(map[string]*ring.Poly{"0": p}, level)
+}
+
+// Download writes the device ciphertext back into value (which must hold the same ids; level + 1 limbs of every polynomial are written).
+func (ctx *Context) Download(d *Ciphertext, value map[string]*ring.Poly, level int) {
+	limbs, n := level+1, ctx.params.N()
 	buf := make([]uint64, (len(d.ids)+1)*limbs*n)
 	must(C.mkhe_ct_download(ctx.c, d.h, (*C.uint64_t)(unsafe.Pointer(&buf[0]))))
 	for slot, id := range append([]string{"0"}, d.ids...) {
+		p, ok := value[id]
+		if !ok {
+			panic("mkrlwegpu: Download into a ciphertext that lacks id " + id)
+		}
 		for j := 0; j < limbs; j++ {
-			copy(ct.Value[id].Coeffs[j], buf[(slot*limbs+j)*n:(slot*limbs+j+1)*n])
+			copy(p.Coeffs[j], buf[(slot*limbs+j)*n:(slot*limbs+j+1)*n])
 		}
 	}
 	runtime.KeepAlive(d)
-	runtime.KeepAlive(ct)
 }
 
 // RelinKeys holds the device copies of rlkSet.Value[id].Value[0..2] = (b, d, v) (keys.go:34-37).
 type RelinKeys map[string][3]*SwitchingKey
-
-func (ctx *Context) UploadRelinKeys(rlkSet *mkrlwe.RelinearizationKeySet) RelinKeys {
-	out := RelinKeys{}
-	for id, rlk := range rlkSet.Value {
-		out[id] = [3]*SwitchingKey{ctx.UploadSwitchingKey(rlk.Value[0]), ctx.UploadSwitchingKey(rlk.Value[1]), ctx.UploadSwitchingKey(rlk.Value[2])}
-	}
-	return out
-}
 
 func handles(ids []string, rk RelinKeys, which int) []*C.mkhe_swk {
 	out := make([]*C.mkhe_swk, len(ids)+1)
@@ -221,12 +282,21 @@ func (ctx *Context) MulAndRelin(op0, op1 *Ciphertext, rk RelinKeys, crsU *Switch
 }
 
 // MulRelinRescale is mkckks.Evaluator.mulRelinHoisted's MulAndRelin + single Rescale (mkckks/evaluator.go:558-581) as one engine call:
-// out is the rescaled ciphertext, one level below the product.
-func (ctx *Context) MulRelinRescale(op0, op1 *Ciphertext, rk RelinKeys, crsU *SwitchingKey, out *Ciphertext) {
+// out is the rescaled ciphertext, one level below the product.  hoisted0 / hoisted1 as for MulAndRelinHoisted (nil: the engine hoists).
+func (ctx *Context) MulRelinRescale(op0, op1 *Ciphertext, hoisted0, hoisted1 []*SwitchingKey, rk RelinKeys, crsU *SwitchingKey, out *Ciphertext) {
 	b1 := handles(op1.ids, rk, 0)
 	d0 := handles(op0.ids, rk, 1)
 	v0 := handles(op0.ids, rk, 2)
-	must(C.mkhe_mul_relin_rescale(ctx.c, op0.h, op1.h, nil, nil,
+	var h0, h1 **C.mkhe_swk
+	if hoisted0 != nil {
+		h0 = swkArray(hoisted0)
+		defer C.free(unsafe.Pointer(h0))
+	}
+	if hoisted1 != nil {
+		h1 = swkArray(hoisted1)
+		defer C.free(unsafe.Pointer(h1))
+	}
+	must(C.mkhe_mul_relin_rescale(ctx.c, op0.h, op1.h, h0, h1,
 		(**C.mkhe_swk)(unsafe.Pointer(&b1[0])), (**C.mkhe_swk)(unsafe.Pointer(&d0[0])),
 		(**C.mkhe_swk)(unsafe.Pointer(&v0[0])), crsU.h, out.h))
 }
@@ -265,4 +335,3 @@ func (ctx *Context) RotateHoisted(in *Ciphertext, rotidx int, hoisted []*Switchi
 }
 
 var _ = fmt.Sprintf
-var _ rlwe.PolyQP
