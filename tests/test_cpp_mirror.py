@@ -15,7 +15,8 @@ def build(tmp_path):
     from oracle import oracle as O
     O.build()
     exe = str(tmp_path / "mirror_check")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"),
+    # UBSan on the host mirror and its checker: a misaligned access, a shift or a signed overflow in include/mkhe.hpp aborts the run
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"),
                            os.path.join(ROOT, "tests", "cpp", "mirror_check.cpp"), "-o", exe,
                            "-L", LIB, "-lmkhe_hip", "-L", ORA, "-lmkhe_oracle",
                            "-Wl,-rpath," + LIB, "-Wl,-rpath," + ORA, "-Wl,--allow-shlib-undefined"])
