@@ -626,18 +626,39 @@ def run_single(args):
         got = ev.MulRelinNew(c0, c1, rlk).download()
         rl = {i: tuple(kg.crs_expand(args.seed, 1000 + 3 * i + j) for j in range(3)) for i in range(kc)}
         u_h = kg.crs_expand(args.seed, -1)
-        O.set_threads(min(os.cpu_count() or 1, 16))
         ids = list(range(kc))
-        _, ref = ks.mul_and_relin(level, ids, h0, ids, h1, rl, u_h)
         nb, _ = ks.ckks_nb_rescales(level, pset["scale"] * pset["scale"], pset["scale"])
-        ref = np.stack([ks.ringQ.div_round_last_many(ref[s_], nb)[0] for s_ in range(1 + kc)])
+        # the same oracle run is the CPU baseline of this line: ONE thread like the single-goroutine reference, on the
+        # sub-problem whose keys exist on the host -- kc parties, stated in `sample`, no extrapolation to the k parties of the timed GPU workload
         O.set_threads(1)
-        extras["device_keys_check"] = dict(parties=kc, bit_exact_vs_oracle=bool(got.shape == ref.shape and (got == ref).all()),
+        tc1 = time.perf_counter()
+        _, ref = ks.mul_and_relin(level, ids, h0, ids, h1, rl, u_h)
+        ref = np.stack([ks.ringQ.div_round_last_many(ref[s_], nb)[0] for s_ in range(1 + kc)])
+        cdt = time.perf_counter() - tc1
+        nth = min(os.cpu_count() or 1, 16)
+        O.set_threads(nth)
+        tc2 = time.perf_counter()
+        _, ref_mt = ks.mul_and_relin(level, ids, h0, ids, h1, rl, u_h)
+        ref_mt = np.stack([ks.ringQ.div_round_last_many(ref_mt[s_], nb)[0] for s_ in range(1 + kc)])
+        mdt = time.perf_counter() - tc2
+        O.set_threads(1)
+        same = bool(got.shape == ref.shape and (got == ref).all())
+        extras["device_keys_check"] = dict(parties=kc, bit_exact_vs_oracle=same,
                                            keys_regenerated_on_host=3 * kc + 1, seconds=time.perf_counter() - tc0)
+        # the GPU on the SAME kc-party sub-problem (same context and resident keys), so that the two figures of this object are comparable
+        params.sync(); tg = time.perf_counter()
+        for _ in range(10):
+            ev.MulRelinNew(c0, c1, rlk)
+        params.sync(); gdt = (time.perf_counter() - tg) / 10
+        device_cpu = dict(value=1.0 / cdt, unit="MulRelin/s", cores=1, kind="port", parties=kc,
+                          sample="1 full %d-party MulRelin (%s; the timed GPU workload has %d parties -- the keys of the first %d exist on the host too, "
+                                 "regenerated from the public seed; no extrapolation) on 1 host thread, %.1f s" % (kc, args.params, k, kc, cdt),
+                          bit_exact_vs_gpu=same, value_limb_parallel=1.0 / mdt, cores_limb_parallel=nth,
+                          limb_parallel_identical=bool((ref_mt == ref).all()), gpu_same_subproblem_per_sec=1.0 / gdt)
         del rl, u_h, c0, c1
 
     # ---- CPU baseline: the oracle (single-thread C restatement of the Go path) on the same inputs
-    cpu = None
+    cpu = device_cpu if device_check else None
     if not args.no_cpu:
         from oracle import oracle as O
         ks = O.KeySwitcher(pset["logN"], pset["Q"], pset["P"], 2)

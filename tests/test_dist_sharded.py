@@ -65,15 +65,34 @@ def _worker(rank, world, port, names, seed, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("names", [["u0", "u1"], ["u0", "u1", "u2"]])
-def test_sharded_mulrelin_gloo_world2(tmp_path, names):
-    import torch.multiprocessing as mp
+def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    return port
+
+
+@pytest.mark.parametrize("names", [["u0", "u1"], ["u0", "u1", "u2"]])
+def test_sharded_mulrelin_gloo_world2(tmp_path, names):
+    import torch.multiprocessing as mp
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_worker, args=(2, port, names, 42, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), names, 42, out), nprocs=2, join=True)
+    assert np.load(out)[0]
+
+
+# Round 5: the rendezvous and every collective of the N > 1 paths at FIVE and EIGHT real processes, on the CPU (gloo, the oracle
+# doing each rank's arithmetic) -- the GPU boxes of this pool admit six processes on their one card, so `--gpus 8` cannot be rehearsed there.
+#   5 ranks, 3 parties: six half-party units on five ranks (the uneven split);  5 ranks, 5 parties: whole parties;
+#   8 ranks, 4 parties: one half-party unit per rank -- the driver's `bench.py --gpus 8` at its default four parties.
+@pytest.mark.parametrize("world,names", [(5, ["u0", "u1", "u2"]), (5, ["u0", "u1", "u2", "u3", "u4"]), (8, ["u0", "u1", "u2", "u3"])])
+def test_sharded_mulrelin_gloo_world5_and_8(tmp_path, world, names):
+    import torch.multiprocessing as mp
+    from mkhe_kklss_amd.dist import assign_units
+    units = assign_units(names, world)
+    assert len(units) == world and sorted(sum((u[0] for u in units), [])) == names and sorted(sum((u[1] for u in units), [])) == names
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(world, _free_port(), names, 42 + world, out), nprocs=world, join=True)
     assert np.load(out)[0]
 
 
@@ -156,14 +175,11 @@ def _rot_worker(rank, world, port, names, out_path):
     dist.destroy_process_group()
 
 
-def test_sharded_rotate_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 5, 8])          # 5 and 8 ranks, 3 parties: ranks that own no party take part in the all-reduce with zeros
+def test_sharded_rotate_gloo(tmp_path, world):
     import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_rot_worker, args=(2, port, ["u0", "u1", "u2"], out), nprocs=2, join=True)
+    mp.spawn(_rot_worker, args=(world, _free_port(), ["u0", "u1", "u2"], out), nprocs=world, join=True)
     assert np.load(out)[0]
 
 
@@ -249,14 +265,11 @@ def _limb_worker(rank, world, port, names, out_path):
     dist.destroy_process_group()
 
 
-def test_limb_sharded_exchange_pattern_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 5, 8])          # small_ckks(10, 3) has 3 + 2 moduli: with 8 ranks three of them own none
+def test_limb_sharded_exchange_pattern_gloo(tmp_path, world):
     import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_limb_worker, args=(2, port, ["u0", "u1"], out), nprocs=2, join=True)
+    mp.spawn(_limb_worker, args=(world, _free_port(), ["u0", "u1"], out), nprocs=world, join=True)
     assert np.load(out)[0]
 
 
