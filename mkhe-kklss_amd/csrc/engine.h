@@ -172,8 +172,6 @@ class Context {
     };
     int ext_merge_members(int level) const;      // members a virtual item may have at this level (< 2: no merging)
     bool ext_plan_merge(int level, const ExtItem* items, int n, ExtMerge& mp) const;
-    bool ext_fuse_pass_ = false;                 // around ext_front: the ModDown of the same call follows, it may take the last inverse pass
-    void ext_inv_launch(NttBatch& b, double bytes);
     void ext_front(int level, const ExtItem* items, int n, u64* c1, const ExtMerge* mp = nullptr);   // inner products + lazy inverse NTT into c1 [n][mtot][N]
     void ext_back(int level, const ExtItem* items, int n, const u64* c1, u64 galEl = 0, const ExtMerge* mp = nullptr);   // ModDown of c1 into / onto the destinations [signed-permuted]
 
@@ -246,8 +244,6 @@ class Context {
     int *d_map_qp = nullptr, *d_map_id = nullptr;
     u64 *d_md_qoverqiinvqi = nullptr, *d_md_qoverqimodp = nullptr, *d_md_vtimes = nullptr, *d_md_down = nullptr;
     u64* d_pmodq = nullptr;                      // [nq] MForm(P mod q_j)
-    u64* d_xpass_ = nullptr;                     // [mall][2][2][8][8]: the 2 / 3 outermost stages of the forward / inverse transform as 4 x 4 / 8 x 8 matrices (NttBatch::xpass)
-    int ext_pass_d_ = 0;                         // set by ext_front for ext_back: the inverse launch left its last pass_d stages to the ModDown kernel
     u64* d_rescale = nullptr;
     u64 *d_dec_a = nullptr, *d_dec_b = nullptr, *d_dec_c = nullptr;     // Decomposer tables (alpha >= 2)
     u64 *d_tb30 = nullptr, *d_tw30 = nullptr;                           // ... and those of the radix-4 spread (alpha = 2, N = 2^16, moduli < 2^57)

@@ -164,39 +164,6 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
     for (auto& v : psiinv) v = sd_split(v);
     for (auto& v : aux) v = sd_split(v);
     d_mods = dev_upload(mods); d_psi = dev_upload(psi); d_psiinv = dev_upload(psiinv); d_inv_aux = dev_upload(aux);
-    {
-        // The d = 2 / 3 outermost stages of a transform act on the 2^d blocks of a limb with constant twiddles: block r of the result is
-        // sum_k X[r][k] * block k (NttBatch::xpass).  X by running the stages on the unit vectors: forward (Cooley-Tukey, stage s pairs blocks 2^(d-1-s)
-        // apart, twiddle psi[2^s + blk]) and inverse (Gentleman-Sande, the same stages backwards with psiinv) -- exactly ntt_pass4/8_fwd/inv_kernel.
-        std::vector<u64> xp((size_t)mall * 256, 0);
-        for (int i = 0; i < mall; ++i) {
-            const u64 q = moduli[i], ps = psi_plain[i], psinv = powmod(ps, q - 2, q);
-            u64 wf[8], wi[8];
-            for (int t = 1; t < 8; ++t) { wf[t] = powmod(ps, bitrev((u64)t, logN), q); wi[t] = powmod(psinv, bitrev((u64)t, logN), q); }
-            for (int inv = 0; inv < 2; ++inv)
-                for (int d = 2; d <= 3; ++d) {
-                    const int n = 1 << d;
-                    for (int k = 0; k < n; ++k) {
-                        u64 a[8] = {};
-                        a[k] = 1;
-                        for (int ss = 0; ss < d; ++ss) {
-                            const int s = inv ? d - 1 - ss : ss, half = 1 << (d - 1 - s);
-                            for (int blk = 0; blk < (1 << s); ++blk) {
-                                const u64 w = inv ? wi[(1 << s) + blk] : wf[(1 << s) + blk];
-                                for (int j = 0; j < half; ++j) {
-                                    const int lo = blk * 2 * half + j, hi = lo + half;
-                                    const u64 U = a[lo], V = a[hi];
-                                    if (!inv) { const u64 T = mulmod(V, w, q); a[lo] = (U + T) % q; a[hi] = (U + q - T) % q; }
-                                    else { a[lo] = (U + V) % q; a[hi] = mulmod((U + q - V) % q, w, q); }
-                                }
-                            }
-                        }
-                        for (int r = 0; r < n; ++r) xp[(((size_t)i * 2 + inv) * 2 + (d - 2)) * 64 + r * 8 + k] = to_mont(a[r], q);
-                    }
-                }
-        }
-        d_xpass_ = dev_upload(xp);
-    }
     if (logN >= 14 && !h16_gap_) {
         // one-round product of the H16 kernel: a * w = a0 * u + a1 * u' with u = w 2^31, u' = w 2^63 (mod q, balanced), then ONE Montgomery
         // round of radix 2^31.  psi holds w * 2^64 in signed-split form at this point: w * 2^31 = psi * 2^-33.
@@ -498,7 +465,7 @@ Context::~Context() {
 void Context::release_all() noexcept {
     (void)hipSetDevice(device);
     for (void* p : {(void*)d_mods, (void*)d_psi, (void*)d_psiinv, (void*)d_inv_aux, (void*)d_map_qp, (void*)d_map_id,
-                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)d_xpass_, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)d_psi31c, (void*)d_psi31b, (void*)d_psiinv31, (void*)d_inv31c, (void*)d_psif, (void*)spreadbuf_,
+                    (void*)d_md_qoverqiinvqi, (void*)d_md_qoverqimodp, (void*)d_md_vtimes, (void*)d_md_down, (void*)d_rescale, (void*)d_pmodq, (void*)tens_, (void*)d_psi31, (void*)d_psi31n, (void*)d_psi31c, (void*)d_psi31b, (void*)d_psiinv31, (void*)d_inv31c, (void*)d_psif, (void*)spreadbuf_,
                     (void*)d_dec_a, (void*)d_dec_b, (void*)d_dec_c, (void*)d_tb30, (void*)d_tw30, (void*)d_map_own, (void*)d_ownq,
                     (void*)x_, (void*)y_, (void*)swk3_, (void*)c1_, (void*)polyq_[0], (void*)polyq_[1], (void*)polyq_[2],
                     (void*)invntt_, (void*)nttbuf_, (void*)ctbuf_, (void*)c1b_, (void*)tbuf_, (void*)rbuf_, (void*)x2_, (void*)y2_,
@@ -771,7 +738,6 @@ void Context::ntt_fwd_launch(const NttBatch& b_in, bool decompose) {
     NttBatch b = b_in;
     b.psi31 = d_psi31; b.psi31n = d_psi31n; b.psi31c = d_psi31c; b.psi31b = d_psi31b; b.u_mods = u_mods_; b.no_h16 = d_psi31 ? 0 : 1;
     b.psif = d_psif; b.f_mods = f_mods_;
-    b.xpass = masked_ ? nullptr : d_xpass_;
     for (int i = 0; i < mall && i < NTT_MAX_SLOTS; ++i) b.sched[i] = h16_sched_.empty() ? 15 : h16_sched_[i];
     const bool ok32 = ntt32_ok(logN, b), ok16 = ntt16_ok(logN, b);
     NttTune* sampling = nullptr;
@@ -1188,26 +1154,12 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
             for (int k = 0; k < VI_MAX; ++k) b.vi_mem[v] |= (unsigned)mp->mem[v][k] << (8 * k);
         }
         b.vi_jobs = mp->nvi * (level + 1) + n * np;
-        ext_inv_launch(b, 16.0 * N * b.vi_jobs);
+        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * b.vi_jobs); ntt_inv_launch(b); }
         return;
     }
     slots_qp(b, level);
     b.nouter = n;
-    ext_inv_launch(b, 16.0 * N * n * nslots);
-}
-// the lazy inverse NTT of an external-product batch.  Small launches of the N = 2^14 ring run as LDS sub-transforms + one streaming pass of 2 / 3
-// cross stages; when the ModDown kernel follows in the same call (ext_fuse_pass_) that pass is left to its load (ModDownBatchArgs::pass_d): one
-// launch less on a chain of launches that each last as long as one workgroup.
-void Context::ext_inv_launch(NttBatch& b, double bytes) {
-    ext_pass_d_ = 0;
-    if (ext_fuse_pass_ && logN == 14 && !masked_) {
-        NttBatch probe = b;
-        probe.xpass = d_xpass_; probe.psi31 = d_psiinv31; probe.no_h16 = d_psiinv31 ? 0 : 1;
-        ext_pass_d_ = ntt_inv_fusable_pass(logN, probe);
-    }
-    b.xpass = d_xpass_; b.skip_last_pass = ext_pass_d_ ? 1 : 0;
-    ProfScope ps(this, PROF_NTT_INV, bytes);
-    ntt_inv_launch(b);
+    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); ntt_inv_launch(b); }
 }
 // back half: ModDown of the items in c1 into (or onto) their destinations
 void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 galEl, const ExtMerge* mp) {
@@ -1226,7 +1178,6 @@ void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 g
             bytes += 8.0 * N * ((level + 1) * (mp->accumulate[v] ? 3.0 : 2.0) + np * mp->cnt[v]);
         }
         md.galEl = galEl; md.logN = logN;
-        md.xpass = d_xpass_; md.pass_d = ext_pass_d_; md.nq = nq;
         bool any_gal = galEl != 0;
         for (int v = 0; v < mp->nvi; ++v) any_gal = any_gal || mp->gal[v] || mp->post[v];
         if (!rs_maps_.empty() && !any_gal && level >= 1) {
@@ -1271,7 +1222,6 @@ void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 g
         bytes += 8.0 * N * ((level + 1) * (it[i].accumulate ? 3.0 : 2.0) + np);
     }
     md.galEl = galEl; md.logN = logN;
-    md.xpass = d_xpass_; md.pass_d = ext_pass_d_; md.nq = nq;
     { ProfScope ps(this, PROF_MODDOWN, bytes); launch_moddown_batch(md, s_); }
 }
 void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown, int stage, u64 galEl) {
@@ -1284,13 +1234,10 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
         u64* c1 = scratch(c1b_, c1b_words_, (size_t)n * item_words);
         ExtMerge mp;
         const bool merged = stage == 0 && ext_plan_merge(level, items.data() + base, n, mp);
-        ext_fuse_pass_ = stage == 0; ext_pass_d_ = 0;
         if (stage != 2) ext_front(level, items.data() + base, n, c1, merged ? &mp : nullptr);
-        ext_fuse_pass_ = false;
         if (stage == 1) continue;
         if (join_before_moddown >= 0) { join_side(join_before_moddown); join_before_moddown = -1; }
         ext_back(level, items.data() + base, n, c1, galEl, merged ? &mp : nullptr);
-        ext_pass_d_ = 0;
     }
     if (join_before_moddown >= 0) join_side(join_before_moddown);
     MKHE_HIP(hipGetLastError());

@@ -97,13 +97,6 @@ struct NttBatch {
     const u64* psif;        // [nmod][N] the forward twiddles as PLAIN residues in double format (bit patterns), bit-reversed order; NULL = class off
     unsigned long long f_mods;
     struct Lpt { int B, C, r, full, rem; unsigned magic_C; } lpt;
-    // Cross stages as a dot product at the load (round 5, small launches of the N = 2^14 / 2^15 rings; Context::d_xpass_): the d outermost stages of a
-    // transform are a linear map between the 2^d sub-blocks of a limb with CONSTANT coefficients per modulus -- block r of the result is
-    // sum_k X[r][k] * block k -- so the forward sub-transform kernel forms its input from the 2^d source blocks itself (one 128-bit accumulation and
-    // one Montgomery reduction per coefficient: no streaming pass in front of it, no launch), and the consumer of an inverse launch (the ModDown
-    // kernels) does the same with the 2^d sub-transform outputs (skip_last_pass: launch_ntt_inv leaves the pass out).
-    const u64* xpass;       // [nmod][2 (forward, inverse)][2 (d = 2, 3)][8][8] Montgomery form, or NULL (fusion off)
-    int skip_last_pass;     // inverse only
     int no_h16;             // this context has a modulus the H16 kernel's ranges do not cover (48q >= 2^62 > 31q): keep to the other kernels
     u64* trace;             // diagnostic: per job {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}; normally NULL
     int nitems, outers_per_item;   // nitems > 0: outer = item * outers_per_item + digit, bases from the lists
@@ -138,9 +131,6 @@ bool ntt_fwd_prestaged_oop_ok(int logN, const NttBatch& b, const unsigned char* 
 bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q);
 void launch_ntt_fwd_mixed(int logN, const NttBatch& b, const unsigned char* small_q, hipStream_t st);
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st);
-// d (2 or 3) when launch_ntt_inv would run this launch as 2^(logN - d)-point LDS sub-transforms followed by ONE streaming pass of d stages that a
-// consumer can apply at its load instead (NttBatch::skip_last_pass); 0 otherwise
-int  ntt_inv_fusable_pass(int logN, const NttBatch& b);
 // N = 2^15 launches that fill the chip (ntt16_kernels.hip): 16 coefficients per thread, two workgroups per CU, both modulus
 // classes in one persistent launch.  ntt16_ok: false when the launch does not qualify (MKHE_NTT16=0 switches the path off).
 bool ntt16_inv_ok(int logN, const NttBatch& b);

@@ -545,27 +545,9 @@ __device__ __forceinline__ void sm_tw_load(gcptr psi, int root, int t, u64* tw) 
             for (int j = 0; j < (1 << i); ++j) tw[k * (NE - 1) + (1 << i) - 1 + j] = psi[(root << (S0 + i)) + (high << i) + j];
     }
 }
-// sum_k c[k] * p[k * stride] mod q for the 2^D blocks of a limb: the D outermost stages of a transform as ONE dot product (NttBatch::xpass).  The
-// products are accumulated in 128 bits and folded by one Montgomery reduction: with operands below 4q (red: reduced first, below 2q) and
-// constants below q the sum stays below 2^D * 4 q^2 <= q 2^64 * (2^(D+2) q / 2^64), so the result is below 3q (D = 3, q < 2^60).
-template <int D>
-__device__ __forceinline__ u64 xdot(gcptr p, long stride, const u64* c, const Mod& md, bool red) {
-    u64 lo = 0, hi = 0;
-#pragma unroll
-    for (int k = 0; k < (1 << D); ++k) {
-        u64 v = p[(long)k * stride];
-        if (red) v = mont_mul_sdu(v, md.r1s, md.qs, md.q, md.ninv32);
-        u64 h, l;
-        mul64x64(v, c[k], h, l);
-        const u64 s = lo + l;
-        hi += h + (s < lo ? 1 : 0);
-        lo = s;
-    }
-    return hi - mulhi64(lo * md.qinv, md.q) + md.q;
-}
-template <int S0, int NB, bool FROM_G, bool TO_G, int MODE, int FIN, int LOGM = SM_LOGM, bool PRE = false, int XD = 0>
+template <int S0, int NB, bool FROM_G, bool TO_G, int MODE, int FIN, int LOGM = SM_LOGM, bool PRE = false>
 __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr psi, int root, int t, const Mod& md, u64 fin_c, int skip_norm,
-                                         int nsum = 1, const long* sum_off = nullptr, const u64* tw = nullptr, const u64* xc = nullptr, bool xred = false) {
+                                         int nsum = 1, const long* sum_off = nullptr, const u64* tw = nullptr) {
     constexpr int LGL = LOGM - S0 - NB, GL = 1 << LGL, UPT = SmGeo<LOGM>::E >> NB, NE = 1 << NB;
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
@@ -576,10 +558,7 @@ __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr 
         const int p = (high << (LGL + NB)) | low;
         u64 x[NE];
 #pragma unroll
-        for (int a = 0; a < NE; ++a) {
-            if constexpr (FROM_G && XD > 0) x[a] = xdot<XD>(gsrc + (p + a * GL), 1l << LOGM, xc, md, xred);
-            else x[a] = FROM_G ? gsrc[p + a * GL] : lds[sm_pad(p + a * GL)];
-        }
+        for (int a = 0; a < NE; ++a) x[a] = FROM_G ? gsrc[p + a * GL] : lds[sm_pad(p + a * GL)];
         if constexpr (FROM_G && MODE == 2) {
 #pragma unroll
             for (int k = 1; k <= VI_MAX; ++k)
@@ -649,48 +628,6 @@ __global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_fwd_lds_kernel(NttBatch b,
         __syncthreads();
         sm_phase<12, 1, false, true, MODE, 1, LOGM>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm);
     }
-}
-
-// The same 2^12- / 2^11-point forward sub-transforms with the XD cross stages in front of them applied at the load (xdot): job = (limb, block r of
-// 2^XD); reads the 2^XD blocks of the SOURCE limb (the digit of a Decompose, a plain polynomial), writes block r of the destination limb.  Replaces
-// ntt_pass4/8_fwd_kernel + ntt_fwd_lds_kernel for the small launches of the N = 2^14 / 2^15 rings: one launch instead of two on a chain of
-// launches that each last as long as one workgroup.
-template <int MODE, int LOGM, int XD, bool DEC>
-__global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_fwd_ldsx_kernel(NttBatch b) {
-    extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
-    constexpr int M = 1 << LOGM;
-    const int job = blockIdx.x, part = job & ((1 << XD) - 1), t = threadIdx.x;
-    gcptr src; gptr dst; int m, outer;
-    job_pointers(b, job >> XD, src, dst, m, outer);
-    dst += part * M;
-    const int root = (1 << XD) + part;
-    const Mod md = b.mods[m];
-    gcptr psi = (gcptr)(b.psi + ((long)m * M << XD));
-    bool red = false;
-    if constexpr (DEC) {
-        int sm = m;
-        if (b.reduce_src_mod_is_outer == 1) sm = outer;
-        else if (b.reduce_src_mod_is_outer == 2) sm = ((kargptr)__builtin_amdgcn_kernarg_segment_ptr())->outer_mod[outer];
-        const u64 qs = b.mods[sm].q << (b.src_lazy ? 2 : 0);
-        red = qs > 4 * md.q;
-    }
-    u64 xc[1 << XD];
-    {
-        const u64* row = b.xpass + (((long)m * 2 + 0) * 2 + (XD - 2)) * 64 + part * 8;
-#pragma unroll
-        for (int k = 0; k < (1 << XD); ++k) xc[k] = row[k];
-    }
-    constexpr int NBL = LOGM == 12 ? 3 : 2, NL = (SmGeo<LOGM>::E >> NBL) * ((1 << NBL) - 1);
-    u64 t0[7], t1[7], t2[7], t3[NL];
-    sm_tw_load<0, 3, LOGM>(psi, root, t, t0); sm_tw_load<3, 3, LOGM>(psi, root, t, t1);
-    sm_tw_load<6, 3, LOGM>(psi, root, t, t2); sm_tw_load<9, NBL, LOGM>(psi, root, t, t3);
-    sm_phase<0, 3, true, false, MODE, 0, LOGM, true, XD>(src, dst, sm_lds, psi, root, t, md, 0, 0, 1, nullptr, t0, xc, red);
-    __syncthreads();
-    sm_phase<3, 3, false, false, MODE, 0, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, 0, 1, nullptr, t1);
-    __syncthreads();
-    sm_phase<6, 3, false, false, MODE, 0, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, 0, 1, nullptr, t2);
-    __syncthreads();
-    sm_phase<9, NBL, false, true, MODE, 1, LOGM, true>(src, dst, sm_lds, psi, root, t, md, 0, b.skip_norm, 1, nullptr, t3);
 }
 
 // (8 waves per SIMD = two workgroups per CU: the merged E / F2 launch of a 4-party MulRelin has 376 sub-transforms for 256 CUs;
@@ -1091,24 +1028,6 @@ bool ntt_fwd_prestaged_oop_ok(int logN, const NttBatch& b, const unsigned char* 
     }
     return n > 0;
 }
-template <int MODE, int LOGM, int XD, bool DEC> static void launch_fwd_ldsx_t(int jobs, const NttBatch& b, hipStream_t st) {
-    static LaunchState ls;
-    const size_t lds = SmGeo<LOGM>::LDSW * sizeof(u64);
-    {
-        const int dev = current_device();
-        std::lock_guard<std::mutex> g(ls.mu);
-        if (!ls.attr[dev]) { (void)hipFuncSetAttribute((const void*)ntt_fwd_ldsx_kernel<MODE, LOGM, XD, DEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); ls.attr[dev] = true; }
-    }
-    hipLaunchKernelGGL((ntt_fwd_ldsx_kernel<MODE, LOGM, XD, DEC>), dim3(jobs), dim3(SmGeo<LOGM>::T), lds, st, b);
-}
-static void launch_fwd_ldsx(int logm, int d, bool small, bool dec, int jobs, const NttBatch& b, hipStream_t st) {
-#define MKHE_LDSX(MODE, LOGM, XD) do { if (dec) launch_fwd_ldsx_t<MODE, LOGM, XD, true>(jobs, b, st); else launch_fwd_ldsx_t<MODE, LOGM, XD, false>(jobs, b, st); } while (0)
-    if (logm == 12 && d == 2) { if (small) MKHE_LDSX(1, 12, 2); else MKHE_LDSX(0, 12, 2); }
-    else if (logm == 12 && d == 3) { if (small) MKHE_LDSX(1, 12, 3); else MKHE_LDSX(0, 12, 3); }
-    else if (logm == 11 && d == 3) { if (small) MKHE_LDSX(1, 11, 3); else MKHE_LDSX(0, 11, 3); }
-    else throw std::runtime_error("mkhe: internal: no fused forward sub-transform of this shape");
-#undef MKHE_LDSX
-}
 void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
     const bool small = b.lazy_out != 0;
@@ -1138,13 +1057,6 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (use_split(logN, b)) {
         const dim3 grid(32, b.nslots * b.nouter);
         const int d = lds_depth(logN, b);
-        static const int fuse_pass = MKHE_AB_INT("MKHE_NTT_FUSE_PASS", 1);
-        if (fuse_pass && b.xpass && !b.prestaged && (d == 2 || d == 3) && (logN - d == 12 || logN - d == 11)) {
-            // the d cross stages at the load of the sub-transforms (ntt_fwd_ldsx_kernel): one launch
-            const int jobs = (b.nslots * b.nouter) << d;
-            launch_fwd_ldsx(logN - d, d, small, b.reduce_in != 0, jobs, b, st);
-            return;
-        }
         if (b.prestaged) { /* first stage done by the producer */ }
         else if (d == 3) {
             if (b.reduce_in) hipLaunchKernelGGL(ntt_pass8_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
@@ -1191,12 +1103,6 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
     if (b.reduce_in) { if (small) launch_fwd_mode<1, true>(logN, b, st); else launch_fwd_mode<0, true>(logN, b, st); }
     else             { if (small) launch_fwd_mode<1, false>(logN, b, st); else launch_fwd_mode<0, false>(logN, b, st); }
 }
-int ntt_inv_fusable_pass(int logN, const NttBatch& b) {
-    static const int fuse_pass = MKHE_AB_INT("MKHE_NTT_FUSE_PASS", 1);
-    if (!fuse_pass || !b.xpass || b.nslots <= 0 || b.nouter <= 0 || !b.lazy_out || b.split || ntt16_inv_ok(logN, b) || !use_split(logN, b)) return 0;
-    const int d = lds_depth(logN, b);
-    return (d == 2 || d == 3) && (logN - d == 12 || logN - d == 11) ? d : 0;
-}
 void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
     if (b.nslots <= 0 || b.nouter <= 0) return;
     if (ntt16_inv_ok(logN, b)) {
@@ -1219,7 +1125,6 @@ void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
             else if (logN - d == 11) hipLaunchKernelGGL(ntt_inv_ldsS_kernel<11>, dim3(jobs), dim3(256), SmGeo<11>::LDSW * sizeof(u64), st, b, d);
             else
             hipLaunchKernelGGL(ntt_inv_lds_kernel, dim3(jobs), dim3(SM_T), SM_LDS_WORDS * sizeof(u64), st, b, d);     // src -> dst, [0,2q), N^-1 folded in
-            if (b.skip_last_pass && (d == 2 || d == 3)) return;         // the consumer applies the d cross stages at its load (ntt_inv_fusable_pass)
             const NttBatch ip = in_place_of_dst(b);
             const dim3 grid(32, b.nslots * b.nouter);
             NttBatch e = ip; e.lazy_out = b.lazy_out; e.psi = b.psi;

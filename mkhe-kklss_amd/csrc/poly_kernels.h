@@ -175,11 +175,6 @@ struct ModDownBatchArgs {
     // to the finished destination at the stored position by the LAST item of the destination's group (AddNew(ct, RotateNew(ct, r)) in one pass)
     unsigned int gal_v[EXT_MAX_ITEMS];
     const u64* post[EXT_MAX_ITEMS];
-    // pass_d = 2 / 3: c1 holds the outputs of the 2^(logN - pass_d)-point inverse sub-transforms; the pass_d cross stages that would complete the
-    // inverse NTT are applied here, at the load, as a dot product over the 2^pass_d blocks of a limb (NttBatch::xpass, its inverse rows; nq = the
-    // modulus index of the first special prime in that table)
-    const u64* xpass;
-    int pass_d, nq;
 };
 void launch_moddown_batch(const ModDownBatchArgs& a, hipStream_t st);
 
@@ -219,8 +214,6 @@ struct ModDownMergedArgs {
     u64* rdst[EXT_MAX_ITEMS];
     unsigned int gal_v[EXT_MAX_ITEMS];            // as ModDownBatchArgs::gal_v / post, per virtual item
     const u64* post[EXT_MAX_ITEMS];
-    const u64* xpass;                             // as ModDownBatchArgs::xpass / pass_d / nq
-    int pass_d, nq;
 };
 void launch_moddown_merged(const ModDownMergedArgs& a, hipStream_t st);
 

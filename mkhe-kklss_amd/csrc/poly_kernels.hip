@@ -765,31 +765,6 @@ void launch_ext_inner(const ExtInnerArgs& a_in, hipStream_t st) {
     else hipLaunchKernelGGL(ext_inner_kernel, dim3(bx, a.nslots, a.nitems), dim3(PW_THREADS), 0, st, a);
 }
 
-// coefficient n of a limb of c1: the word itself, or -- when the last pass_d stages of the inverse NTT were left to this kernel (ModDownBatchArgs::
-// pass_d) -- the dot product of the 2^pass_d sub-transform outputs at n mod (N >> pass_d) with the constant row of block n / (N >> pass_d) of
-// modulus `mi`.  Operands below 2q, constants below q: the 128-bit sum is below 2^pass_d * 2 q^2 <= q 2^64, the folded result in (0, 2q) --
-// what the pass itself (ntt_pass4/8_inv_kernel, lazy) leaves.  The block index is uniform over the workgroup (256 consecutive coefficients).
-template <typename A>
-__device__ __forceinline__ u64 md_load(const A& a, const u64* limb, int n, int mi, const Mod& mm) {
-    if (!a.pass_d) return limb[n];
-    const int lg = a.logN - a.pass_d, E = 1 << lg;
-    const int row = (int)(blockIdx.x * PW_THREADS) >> lg;
-    const u64* c = a.xpass + (((long)mi * 2 + 1) * 2 + (a.pass_d - 2)) * 64 + row * 8;
-    const u64* p = limb + (n & (E - 1));
-    u64 lo = 0, hi = 0;
-    const int cnt = 1 << a.pass_d;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (k < cnt) {
-            u64 h, l;
-            mul64x64(p[(long)k << lg], ((sc_u64)c)[k], h, l);
-            const u64 s = lo + l;
-            hi += h + (s < lo ? 1 : 0);
-            lo = s;
-        }
-    }
-    return hi - mulhi64(lo * mm.qinv, mm.q) + mm.q;
-}
 typedef const __attribute__((address_space(4))) ModDownBatchArgs* mdb_kargs;
 __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchArgs a) {
     mdb_kargs ka = (mdb_kargs)__builtin_amdgcn_kernarg_segment_ptr();
@@ -810,7 +785,7 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
         for (int i = 0; i < MAXP; ++i) {
             if (i < a.np) {
                 const Mod mp = load_mod((sc_mod)a.mods_p + i);
-                y[i] = mont_mul(md_load(a, xp + (long)i * a.N, n, a.nq + i, mp), ((sc_u64)a.t.qoverqiinvqi)[i], mp.q, mp.ninv32);
+                y[i] = mont_mul(xp[(long)i * a.N + n], ((sc_u64)a.t.qoverqiinvqi)[i], mp.q, mp.ninv32);
                 vi = vi + (double)y[i] / (double)mp.q;
             }
         }
@@ -832,7 +807,7 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_batch_kernel(ModDownBatchA
             }
             const u64 hhi = mulhi64(rlo * mq.qinv, mq.q);
             const u64 lift = rhi - hhi + mq.q + select_entry<MAXP>((sc_u64)a.t.vtimesqmodp + (long)j * (a.np + 1), a.np, v);
-            const u64 x = md_load(a, xq + (long)j * a.N, n, j, mq);
+            const u64 x = xq[(long)j * a.N + n];
             u64 z = mont_mul(lift + mq.q2 - x, ((sc_u64)a.t.downparam)[j], mq.q, mq.ninv32);
             long pos = (long)j * a.N + n;
             bool flip = false;
@@ -873,7 +848,6 @@ void launch_moddown_batch(const ModDownBatchArgs& a_in, hipStream_t st) {
     if (!cap) cap = MKHE_AB_INT("MKHE_MD_BY", 4);
     int by = nj < cap ? nj : cap;
     if (a.ngroups * by < 8) by = nj < 8 ? nj : 8;          // a single external product: spread over the limbs instead
-    if (a.pass_d && by > 2 && a.ngroups >= 2) by = 2;      // the P part costs 2^pass_d products per word now and is repeated by every limb slice
     if (by < 1) return;
     hipLaunchKernelGGL(moddown_batch_kernel, dim3(bx, by, a.ngroups), dim3(PW_THREADS), 0, st, a);
 }
@@ -908,7 +882,7 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
 #pragma unroll
                 for (int i = 0; i < NPT; ++i) {
                     const Mod mp = load_mod((sc_mod)a.mods_p + i);
-                    y[k][i] = mont_mul(md_load(a, xp + (long)i * a.N, n, a.nq + i, mp), ((sc_u64)a.t.qoverqiinvqi)[i], mp.q, mp.ninv32);
+                    y[k][i] = mont_mul(xp[(long)i * a.N + n], ((sc_u64)a.t.qoverqiinvqi)[i], mp.q, mp.ninv32);
                     vi_ = vi_ + (double)y[k][i] / (double)mp.q;
                 }
                 v[k] = (u32)(u64)vi_;
@@ -933,7 +907,7 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
             }
             const u64 hhi = mulhi64(rlo * mq.qinv, mq.q);
             const u64 lift = rhi - hhi + mq.q + vt;                      // = sum_k (the reference's per-product lift) mod q
-            const u64 x = md_load(a, xq + (long)j * a.N, n, j, mq);      // lazy, < 2q
+            const u64 x = xq[(long)j * a.N + n];                         // lazy, < 2q
             return mont_mul(lift + mq.q2 - x, ((sc_u64)a.t.downparam)[j], mq.q, mq.ninv32);
         };
         if (a.rescale_row) {
@@ -995,7 +969,6 @@ void launch_moddown_merged(const ModDownMergedArgs& a_in, hipStream_t st) {
     if (!cap) cap = MKHE_AB_INT("MKHE_MDM_BY", 4);
     int by = nj < cap ? nj : cap;
     if (a.ngroups * by < 8) by = nj < 8 ? nj : 8;
-    if (a.pass_d && by > 2 && a.ngroups >= 2) by = 2;      // (see launch_moddown_batch)
     const dim3 grid(bx, by, a.ngroups), blk(PW_THREADS);
     switch (a.np) {
         case 1: hipLaunchKernelGGL(moddown_merged_kernel<1>, grid, blk, 0, st, a); break;
