@@ -219,6 +219,10 @@ int  mkhe_ct_sub(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct*
  * [0, N/2) are multiplied by c_first[l], [N/2, N) by c_second[l] (host arrays, Montgomery form = the reference's
  * ring.MForm(scaledConst); the float64 getConstAndScale / scaleUpExact logic :40-94 stays on the host). */
 int  mkhe_ct_mul_const(mkhe_ctx* ctx, const mkhe_ct* in, const uint64_t* c_first, const uint64_t* c_second, mkhe_ct* out);
+/* out = in[0] + in[1] + ... + in[n-1] for n ciphertexts of one shape (same ids; out at its own level <= theirs, may be one of them when at
+ * their level): the chain `out = eval.AddNew(out, temp)` over the products of a layer (cnn/cnn.go:19-30,58-62; equal scales: ring.Add per
+ * component, mkckks/evaluator.go:316-327) as one launch.  Every partial sum is canonical, so the result is the chain's bit for bit. */
+int  mkhe_ct_sum(mkhe_ctx* ctx, int n, const mkhe_ct* const* in, mkhe_ct* out);
 /* mkckks.Evaluator.MulPtxtNew body (evaluator.go:465-478) without its Rescale: every component times the plaintext
  * polynomial dev_pt = uint64[limbs][N] (coefficient domain, device), via NTT / MForm / InvNTT. */
 int  mkhe_ct_mul_ptxt(mkhe_ctx* ctx, const mkhe_ct* in, const void* dev_pt, mkhe_ct* out);

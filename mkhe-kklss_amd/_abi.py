@@ -81,6 +81,7 @@ SIGNATURES = {
     "mkhe_swk_destroy_batch": (None, [vp, C.c_int, vpp]),
     "mkhe_hoisted_form_batch": (C.c_int, [vp, C.c_int, C.c_int, vpp, vpp]),
     "mkhe_rotate_batch": (C.c_int, [vp, C.c_uint64, C.c_int, vpp, vpp, vpp, vp, vpp]),
+    "mkhe_ct_sum": (C.c_int, [vp, C.c_int, vpp, vp]),
     "mkhe_rotate_multi": (C.c_int, [vp, C.c_int, u64p, vpp, vpp, vpp, vpp, vpp, vpp]),
     "mkhe_mul_relin_batch": (C.c_int, [vp, C.c_int, vpp, vpp, vpp, vpp, vpp, vpp, vpp, vp, C.c_int, vpp]),
     "mkhe_ct_binary_batch": (C.c_int, [vp, C.c_int, C.c_int, vpp, vpp, vpp]),

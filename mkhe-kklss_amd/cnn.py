@@ -30,6 +30,17 @@ def _rot_add(eval, ct, rot, rtkSet):
     return fused(ct, rot, rtkSet) if fused else eval.AddNew(ct, eval.RotateNew(ct, rot, rtkSet))
 
 
+def _sum(eval, cts):
+    """out = cts[0]; for c in cts[1:]: out = eval.AddNew(out, c)   (cnn.go:19-30,58-62)"""
+    fused = getattr(eval, "SumNew", None)
+    if fused:
+        return fused(cts)
+    out = cts[0]
+    for c in cts[1:]:
+        out = eval.AddNew(out, c)
+    return out
+
+
 def _lane_products(eval, rlkSet, rtkSet, ct, ctHoisted, rots, ctOther, ctOtherHoisted):
     """[MulRelinHoistedNew(Rot_r(ct), ctOther[i], HoistedForm(Rot_r(ct)), ctOtherHoisted[i]) for i, r in enumerate(rots)] as lanes of one launch set;
     r = 0: the rotation is a copy and its hoisted form IS ctHoisted (cnn.go:16, :53 with i = 0)"""
@@ -54,9 +65,7 @@ def Convolution(eval, rlkSet, rtkSet, ctImage, ctImageHoisted, ctKernels, ctKern
     """cnn.go:10-39: kernels pre-rotated by 0, 1, 14, 15; the image is hoisted once and reused by the three rotations"""
     if not forks and hasattr(eval, "Lanes"):
         prods = _lane_products(eval, rlkSet, rtkSet, ctImage, ctImageHoisted, (0, 1, 14, 15), ctKernels, ctKernelsHoisted)
-        convOut = prods[0]
-        for temp in prods[1:]:
-            convOut = eval.AddNew(convOut, temp)
+        convOut = _sum(eval, prods)
         for rot in (2048, 1024):
             convOut = _rot_add(eval, convOut, rot, rtkSet)
         return convOut
@@ -91,9 +100,7 @@ def FC1Layer(eval, rlkSet, rtkSet, ctVec, ctVecHoisted, ctMat, ctMatHoisted, ctB
         _fan_out(eval, used)
         temps = [chain(evs[i % len(evs)], i) for i in range(len(ctMat))]
         _fan_in(eval, used)
-    fc1Out = temps[0]
-    for temp in temps[1:]:
-        fc1Out = eval.AddNew(fc1Out, temp)
+    fc1Out = _sum(eval, temps)
     for i in range(7):                                        # log2(128)
         fc1Out = _rot_add(eval, fc1Out, 1 << i, rtkSet)
     return eval.AddNew(fc1Out, ctBias)

@@ -404,6 +404,36 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     MKHE_HIP(hipGetLastError());
 }
 
+void Context::ct_sum(const std::vector<const Ct*>& ins, Ct& out) {
+    if (ins.empty()) throw Error("mkhe: ct_sum: nothing to add");
+    same_shape(ins, "Sum");
+    if (out.n != ins[0]->n || out.ids != ins[0]->ids) throw Error("mkhe: ctOut must carry the ids of the summands");
+    if (out.limbs < 1 || out.limbs > ins[0]->limbs) throw Error("mkhe: operand level below ctOut level");
+    const bool same_limbs = out.limbs == ins[0]->limbs;
+    for (const Ct* c : ins) if (c->d == out.d && !same_limbs) throw Error("mkhe: ct_sum in place needs ctOut at the summands' level");
+    const int L = out.limbs, npolys = 1 + out.n;
+    const size_t PI = (size_t)ins[0]->limbs * N, PO = (size_t)L * N;
+    // more than CTSUM_MAX summands: partial sums into out, which then joins the next group as its first summand
+    size_t k0 = 0;
+    bool have = false;
+    while (k0 < ins.size()) {
+        // (summands at a higher level than out: polynomial stride differs -> one launch per polynomial)
+        const size_t take = std::min<size_t>(ins.size() - k0, (size_t)CTSUM_MAX - (have ? 1 : 0));
+        for (int p = 0; p < (same_limbs ? 1 : npolys); ++p) {
+            CtSumArgs a{};
+            a.mods = d_mods; a.L = L; a.N = N; a.npolys = same_limbs ? npolys : 1;
+            int c = 0;
+            if (have) a.in[c++] = out.d + (size_t)p * PO;
+            for (size_t k = k0; k < k0 + take; ++k) a.in[c++] = ins[k]->d + (size_t)p * PI;
+            a.n = c; a.dst = out.d + (size_t)p * PO;
+            ProfScope ps(this, PROF_OTHER, 8.0 * N * L * a.npolys * (c + 1));
+            launch_ct_sum(a, s_);
+        }
+        have = true; k0 += take;
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
 void Context::ct_binary_batch(int op, const std::vector<const Ct*>& a, const std::vector<const Ct*>& b, const std::vector<Ct*>& outs) {
     const size_t B = a.size();
     if (!B) return;

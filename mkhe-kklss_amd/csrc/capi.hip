@@ -467,6 +467,14 @@ int mkhe_ct_add(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* 
 int mkhe_ct_sub(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, mkhe_ct* out) {
     MKHE_TRY({ mark(ctx, op0, op1, out); if (!op0 || !op1 || !out) throw Error("mkhe_ct_sub: null argument"); need(ctx)->ct_binary(1, op0->c, op1->c, out->c); })
 }
+int mkhe_ct_sum(mkhe_ctx* ctx, int n, const mkhe_ct* const* in, mkhe_ct* out) {
+    MKHE_TRY({ mark(ctx, out);
+        if (n < 1 || !in || !out) throw Error("mkhe_ct_sum: bad argument");
+        std::vector<const Ct*> v(n);
+        for (int i = 0; i < n; ++i) { if (!in[i]) throw Error("mkhe_ct_sum: null ciphertext"); mark(ctx, in[i]); v[i] = &in[i]->c; }
+        need(ctx)->ct_sum(v, out->c);
+    })
+}
 int mkhe_ct_mul_const(mkhe_ctx* ctx, const mkhe_ct* in, const uint64_t* c_first, const uint64_t* c_second, mkhe_ct* out) {
     MKHE_TRY({ mark(ctx, in, out); if (!in || !out || !c_first || !c_second) throw Error("mkhe_ct_mul_const: null argument"); need(ctx)->ct_mul_const(in->c, c_first, c_second, out->c); })
 }

@@ -136,6 +136,8 @@ class Context {
     // out[b] = post_add[b] + Rotate(in[b]) (batch.hip; nbatch = 1: the fused rotate-and-add of one ciphertext)
     void rotate_multi(const std::vector<u64>& galEl, const std::vector<const Ct*>& ins, const std::vector<const Swk*>& hoists, const std::vector<const Swk*>& rk,
                       const std::vector<const Swk*>& crs, const std::vector<const Ct*>& post_add, const std::vector<Ct*>& outs);
+    // out = ins[0] + ... + ins[n-1] (one shape; out at its own level <= theirs): the AddNew chain over the lanes' products as one launch
+    void ct_sum(const std::vector<const Ct*>& ins, Ct& out);
     void ct_binary_batch(int op, const std::vector<const Ct*>& a, const std::vector<const Ct*>& b, const std::vector<Ct*>& outs);
     // MulPtxtNew body (ct_mul_ptxt) for the batch, followed by nb >= 0 divisions by the last modulus (outs have limbs(in) - nb limbs)
     void ct_mul_ptxt_batch(const std::vector<const Ct*>& ins, const u64* dev_pt, int nb, const std::vector<Ct*>& outs);

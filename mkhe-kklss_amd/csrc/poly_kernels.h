@@ -332,6 +332,18 @@ struct CtBinArgs {
 };
 void launch_ct_binary(const CtBinArgs& a, hipStream_t st);
 
+// dst = in[0] + in[1] + ... + in[n-1] over whole ciphertexts of ONE shape ([npolys][L][N] each, dst may be one of them): the chain
+// "out = AddNew(out, temp)" of cnn.Convolution / FC1Layer (cnn/cnn.go:19-30,58-62) in one launch; every partial sum canonical (csub), so the
+// order is immaterial
+constexpr int CTSUM_MAX = 16;
+struct CtSumArgs {
+    const u64* in[CTSUM_MAX];
+    u64* dst;
+    const Mod* mods;
+    int n, L, N, npolys;
+};
+void launch_ct_sum(const CtSumArgs& a, hipStream_t st);
+
 // dst = CRed(a + b) per limb
 void launch_add(u64* dst, const u64* a, const u64* b, const Mod* mods, int L, int N, hipStream_t st);
 

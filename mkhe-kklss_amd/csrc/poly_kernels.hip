@@ -1065,6 +1065,23 @@ void launch_ct_binary(const CtBinArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
     hipLaunchKernelGGL(ct_binary_kernel, dim3(bx, a.L, a.ncomp), dim3(PW_THREADS), 0, st, a);
 }
+typedef const __attribute__((address_space(4))) CtSumArgs* ctsum_kargs;
+__global__ void __launch_bounds__(PW_THREADS) ct_sum_kernel(CtSumArgs a) {
+    ctsum_kargs ka = (ctsum_kargs)__builtin_amdgcn_kernarg_segment_ptr();
+    const int l = blockIdx.y;
+    const u64 q = a.mods[l].q;
+    const long base = ((long)blockIdx.z * a.L + l) * a.N;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
+        u64 v = ka->in[0][base + n];
+        for (int k = 1; k < a.n; ++k) v = csub(v + ka->in[k][base + n], q);
+        a.dst[base + n] = v;
+    }
+}
+void launch_ct_sum(const CtSumArgs& a, hipStream_t st) {
+    if (a.n < 1 || a.npolys < 1 || a.L < 1) return;
+    const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    hipLaunchKernelGGL(ct_sum_kernel, dim3(bx, a.L, a.npolys), dim3(PW_THREADS), 0, st, a);
+}
 // ring.Neg writes q - a, i.e. q for a = 0 (lattigo ring_operations.go Neg), kept literally
 __global__ void __launch_bounds__(PW_THREADS) neg_kernel(u64* dst, const u64* x, const Mod* mods, int N) {
     const int l = blockIdx.y;

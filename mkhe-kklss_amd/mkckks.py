@@ -285,6 +285,20 @@ class Evaluator:
                                       handle_array([ct0.h]), handle_array([ctOut.h])))
         return ctOut
 
+    # ---- out = cts[0]; for c in cts[1:]: out = AddNew(out, c) -- the sum over the products of a layer (cnn/cnn.go:19-30,58-62) -- as ONE launch
+    # when the summands have one shape and one scale (then every AddNew is a plain ring.Add per component); the chain itself otherwise.
+    def SumNew(self, cts):
+        cts = list(cts)
+        c0 = cts[0]
+        if len(cts) == 1 or any(c.ids != c0.ids or c.Level() != c0.Level() or c.Scale != c0.Scale for c in cts):
+            out = c0
+            for c in cts[1:]:
+                out = self.AddNew(out, c)
+            return out
+        out = NewCiphertext(self.params, c0.IDSet(), c0.Level(), c0.Scale, zero=False)
+        check(lib().mkhe_ct_sum(self.params.ctx, len(cts), handle_array([c.h for c in cts]), out.h))
+        return out
+
     def Lanes(self, n):
         """n independent operations of one shape on THIS context as one launch set (a BatchEvaluator over the same stream): how the device runs the
         independent chains of cnn.Convolution / FC1Layer -- small kernels do not overlap each other on this chip, lanes make them one kernel"""

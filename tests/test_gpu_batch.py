@@ -294,3 +294,23 @@ def test_rotate_and_add_is_the_two_calls(case, ids, level):
     _, other = case.ct(["a", "c"] if ids != ["a", "c"] else ["b"], level)
     with pytest.raises(MkheError, match="addend must carry the ids"):
         check(lib().mkhe_rotate_multi(case.params.ctx, 1, gal, handle_array([c.h]), None, handle_array(rk), handle_array([case.params.CRS[1].h]), handle_array([other.h]), handle_array([out.h])))
+
+
+@pytest.mark.parametrize("n,ids,level", [(2, ["a", "b"], None), (8, ["a", "b", "c"], 2), (19, ["d"], 1), (1, ["a"], 0)])
+def test_sum_of_ciphertexts_is_the_add_chain(case, n, ids, level):
+    """mkhe_ct_sum: out = cts[0] + ... + cts[n-1] in one launch (19 > 16: partial sums), against the oracle's ring.Add chain and the AddNew chain"""
+    level = case.level if level is None else level
+    pairs = [case.ct(ids, level) for _ in range(n)]
+    got = case.ev.SumNew([c for _, c in pairs])
+    ref = pairs[0][0].copy()
+    for h, _ in pairs[1:]:
+        ref = np.stack([np.stack([case.ks.ringQ.add(j, ref[s, j], h[s, j]) for j in range(level + 1)]) for s in range(ref.shape[0])])
+    assert (got.download() == ref).all()
+    chain = pairs[0][1]
+    for _, c in pairs[1:]:
+        chain = case.ev.AddNew(chain, c)
+    assert (got.download() == chain.download()).all() and got.Scale == chain.Scale
+    # summands of different shapes fall back to the chain (id union, scale matching): same as AddNew
+    _, other = case.ct(["a", "d"] if ids != ["a", "d"] else ["b"], level)
+    mixed = case.ev.SumNew([pairs[0][1], other])
+    assert (mixed.download() == case.ev.AddNew(pairs[0][1], other).download()).all()
