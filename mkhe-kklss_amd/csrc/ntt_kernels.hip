@@ -990,7 +990,8 @@ static int lds_depth(int logN, const NttBatch& b) {
         // N = 2^14 launches that would not even give every CU one 2^12-point workgroup: eight 2^11-point sub-transforms per limb (256 threads)
         static const int lds11 = MKHE_AB_INT("MKHE_NTT_LDS11", 1);
         const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;
-        if (lds11 && logN == 14 && limbs * 4 < 256) return 3;
+        static const int lds11_max = MKHE_AB_INT("MKHE_NTT_LDS11_MAX", 64);      // (limbs below which the 2^11-point form is used)
+        if (lds11 && logN == 14 && limbs < lds11_max) return 3;
         return logN - 12;
     }
     return logN - SM_LOGM;
