@@ -422,6 +422,38 @@ def roofline_leg(args, params, step, logN, workload, extra=None):
     return out
 
 
+def valu_bound_leg(reps=300):
+    """roofline.valu_bound ("secondary ceiling to report"): the Decompose NTT of N = 2^15 with its loads, stores and
+    LDS exchanges compiled out -- butterflies, reductions, address arithmetic, barriers only (lib/libmkhe_hip_bflyonly.so: WRONG results on purpose,
+    timing only) -- beside the shipped kernel, both back to back on the launch shapes of the 4-party MulRelin (tools/ntt16_bench.py in child processes,
+    HIP events on the context stream), both forward kernels.  What the vector ALU alone needs is the floor no byte-level change can move."""
+    import re
+    import subprocess
+    libdir = os.path.join(ROOT, "mkhe-kklss_amd", "lib")
+    bf = os.path.join(libdir, "libmkhe_hip_bflyonly.so")
+    if not os.path.exists(bf) or os.environ.get("MKHE_LIB"):
+        return None
+    out = {}
+    try:
+        for kern, mode in (("ntt32_fwd_kernel<true>", "1"), ("ntt16_fwd_kernel<true>", "0")):
+            rec = {}
+            for tag, env in (("shipped_us", {}), ("butterflies_only_us", {"MKHE_LIB": bf})):
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ntt16_bench.py"), str(reps)], capture_output=True, text=True, timeout=300,
+                                   env=dict(os.environ, MKHE_NTT32=mode, **env))
+                us = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"limbs\s+(\d+)\s+\S+\s+launches\s+\d+\s+([0-9.]+) us/launch", r.stdout)}
+                if 1792 not in us or 896 not in us:
+                    return dict(error="tools/ntt16_bench.py gave no timing (%s)" % (r.stderr.strip().splitlines() or ["no output"])[-1][:200])
+                rec[tag] = {"1792_limbs": us[1792], "896_limbs": us[896]}
+            rec["butterflies_share"] = {k: rec["butterflies_only_us"][k] / rec["shipped_us"][k] for k in rec["shipped_us"]}
+            # the roofline fraction (16 N bytes per limb over 8 TB/s) the kernel would reach if its memory side cost nothing
+            rec["frac_if_alu_only"] = {k: 16.0 * 32768 * int(k.split("_")[0]) / (rec["butterflies_only_us"][k] * 1e-6) / 1e9 / HBM_PEAK_GBS for k in rec["shipped_us"]}
+            out[kern] = rec
+    except Exception as e:                                  # a diagnostic leg: never fails the bench line
+        return dict(error=str(e)[:200])
+    out["how"] = "%d launches back to back per shape (clock settled under load); butterflies_only = loads, stores, LDS exchanges compiled out" % reps
+    return out
+
+
 def run_single(args):
     import harness as H
     from mkhe_kklss_amd import mkrlwe, mkckks
@@ -607,6 +639,11 @@ def run_single(args):
     roofline = roofline_leg(args, params, step, pset["logN"], "%s k=%d" % (args.params, k),
                             extra=dict(decompose=dict(limbs_per_component=beta * (level + 1 + len(pset["P"])), source_limbs_per_component=level + 1))
                             if params.Alpha() == 1 else None)
+    if args.params == "PN15QP880" and not args.no_extras and roofline is not None:
+        params.sync()
+        vb = valu_bound_leg()
+        if vb is not None:
+            roofline["valu_bound"] = vb
 
     # ---- device-expanded keys (PN16QP1761: 7.9 GB of key material that never exists on the host) still get an oracle check: the keys of the
     # first two parties and the CRS u are regenerated on the host from the same public seed (oracle/ora_keygen.c restates the Philox
