@@ -559,6 +559,25 @@ def run_single(args):
             params.sync()
             extras[key] = args.steps / (time.perf_counter() - t0)
 
+        if B == 1 and not device_keys and args.params in ("PN15QP880", "PN14QP439"):
+            # ---- B MulRelin in lock step on THIS ring (mkhe_mul_relin_batch): the latency-bound tails of a step -- inverse NTT and
+            # ModDown launches of a few dozen limbs -- serve B inputs at once, the Decompose launches deal whole rounds.  Throughput of a service
+            # that has B independent products at hand; `value` stays the single-input rate.  Every output is checked against the single-input result.
+            ref_single = step().download()
+            for Bb in (2, 4):
+                bevb = mkckks.BatchEvaluator(params, Bb)
+                bb0, bb1 = mkckks.BatchCiphertext([ct0] * Bb), mkckks.BatchCiphertext([ct1] * Bb)
+                for _ in range(3):
+                    outb = bevb.MulRelinNew(bb0, bb1, rlk)
+                params.sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    outb = bevb.MulRelinNew(bb0, bb1, rlk)
+                params.sync()
+                extras["mulrelin_per_sec_batch%d" % Bb] = Bb * args.steps / (time.perf_counter() - t0)
+                extras["batch%d_identical_to_single" % Bb] = bool(all((c.download() == ref_single).all() for c in outb.cts))
+                del outb, bb0, bb1, bevb
+
         # ---- throughput with two independent MulRelin in flight (forked engine contexts, one stream each): the latency-bound
         # stretches of one step (small inverse NTTs, ModDown, the t_i chain) are filled by the other
         ev2 = ev.Fork()
