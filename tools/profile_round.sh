@@ -5,13 +5,16 @@
 # main stream).  With --no-extras the dominant kernel (the Decompose-fused forward NTT) is launched exactly 2 * (2 * (W + K) + 300 + K)
 # times: twice per MulRelin -- in the cold-start leg (W + K), the 100 + 200 steps of the steady-state leg, the timed region (W + K)
 # and the HIP-event leg (K).
-TAG=${1:-r4}
+# Round 5: two calls (the default bench line carries more legs now): `bash tools/profile_round.sh r5a part1`, then `... r5a part2`; no second argument = everything.
+TAG=${1:-r5}
+PART=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
 P="rocprofv3 --output-format csv --kernel-trace"
+if [ "$PART" != part2 ]; then
 python3 bench.py > $O/bench_plain.json 2> $O/bench_plain.err
 MKHE_NTT32=1 python3 bench.py --no-cpu > $O/bench_plain_h32.json 2> $O/bench_plain_h32.err
 MKHE_NTT32=0 python3 bench.py --no-cpu > $O/bench_plain_h16.json 2> $O/bench_plain_h16.err
@@ -33,6 +36,9 @@ $P --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_IN
 $P --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA -d $O/sq_b -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu --no-extras > $O/sq_b.json 2> $O/sq_b.err
 $P --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $O/sq_d -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu --no-extras > $O/sq_d.json 2> $O/sq_d.err
 echo "sq done"
+fi
+if [ "$PART" != part1 ]; then
+export MKHE_NO_OVERLAP=1
 $P --stats -d $O/stats_bfv -o p -- python3 bench.py --scheme bfv --steps 10 --warmup 2 --no-cpu > $O/bench_bfv.json 2> $O/bench_bfv.err
 unset MKHE_NO_OVERLAP
 python3 bench.py --scheme bfv --steps 10 --warmup 2 > $O/bench_bfv_plain.json 2> $O/bench_bfv_plain.err
@@ -65,6 +71,7 @@ bash tools/power_probe.sh > $O/power_probe.txt 2>&1
 bash tools/trace_ntt_in_context.sh h16:MKHE_NTT32=0 h32:MKHE_NTT32=1 h16_again:MKHE_NTT32=0 h32_again:MKHE_NTT32=1 > $O/ntt_in_context.txt 2>&1
 rm -rf $R/gpurun_out/ctx
 echo "ntt done"
+fi
 find $O -name '*kernel_trace.csv' -path '*stats_*' -delete
 find $O -name '*agent_info.csv' -delete
 du -sh $O
