@@ -4,7 +4,7 @@ import csv, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles") + "/"
-tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
 J = lambda n: json.load(open(P + tag + "_" + n + ".json")) if os.path.exists(P + tag + "_" + n + ".json") else None
 pl, no, ov, bf, bfp, pn, pn_no, c2, c4, p14 = (J(n) for n in ("bench_plain", "bench_noovl", "bench_ovl", "bench_bfv", "bench_bfv_plain", "bench_pn16",
                                                           "bench_pn16_noovl", "bench_cnn2", "bench_cnn4", "bench_pn14"))
@@ -110,10 +110,46 @@ plh_value, plh_frac = (plh["value"], Rh.get("frac", float('nan'))) if plh else n
 pl16_value, pl16_frac = (pl16["value"], pl16["roofline"].get("frac", float('nan'))) if pl16 else nanp
 rds = (min(rd_strided), max(rd_strided)) if rd_strided else nanp
 rdc = (min(rd_contig), max(rd_contig)) if rd_contig else nanp
-txt = f'''# profiles/ — measured on MI355X (gfx950), round 4
+def round5_block():
+    """what round 5 added to the record (the sections below keep their structure from round 4)"""
+    out = ["## Round 5 at a glance", ""]
+    vb = (pl["roofline"].get("valu_bound") or {})
+    if vb and "error" not in vb:
+        for kern in ("ntt32_fwd_kernel<true>", "ntt16_fwd_kernel<true>"):
+            r = vb.get(kern)
+            if r:
+                out.append("* `roofline.valu_bound` in the bench line (`lib/libmkhe_hip_bflyonly.so`: the kernel with loads, stores and LDS exchanges compiled out, 300 launches back to back, "
+                           "same process tree as the bench): `%s` shipped %.0f / %.0f µs (1792 / 896 limbs), **butterflies only %.0f / %.0f µs** = %.2f / %.2f of the shipped time; "
+                           "with a free memory side the kernel would stand at %.2f / %.2f of the 16·N roofline." % (
+                               kern, r["shipped_us"]["1792_limbs"], r["shipped_us"]["896_limbs"], r["butterflies_only_us"]["1792_limbs"], r["butterflies_only_us"]["896_limbs"],
+                               r["butterflies_share"]["1792_limbs"], r["butterflies_share"]["896_limbs"], r["frac_if_alu_only"]["1792_limbs"], r["frac_if_alu_only"]["896_limbs"]))
+        out.append("  The vector ALU alone is three quarters of the kernel: 0.50–0.54 of the HBM roofline is where a 64-bit modular butterfly of 12 VALU instructions puts this part, "
+                   "whatever the bytes do (DESIGN.md §3; no rewrite of the phase structure was attempted this round).")
+    if C.get("mulrelin_per_sec_batch2"):
+        out.append("* B MulRelin in lock step on the headline ring (`config.mulrelin_per_sec_batch2/4`, every output identical to the single-input result: %s / %s): **%.0f / %.0f MulRelin/s** "
+                   "against %.0f for one input at a time in the same run — the step is the Decompose NTT and two streaming launches at their ceilings, batching has no idle time to fill "
+                   "(on PN14QP439 it has: see below)." % (C.get("batch2_identical_to_single"), C.get("batch4_identical_to_single"), C["mulrelin_per_sec_batch2"], C["mulrelin_per_sec_batch4"], pl["value"]))
+    if c4:
+        cc = c4["config"]
+        out.append("* cnn (4 parties): **%.0f inferences/s, %.2f ms per image** (round 4: 337 / 2.97 ms) — the independent rotate → hoist → MulRelin chains of Convolution / FC1 run as LANES of one launch "
+                   "set on one context (`mkhe_rotate_multi`: each lane its own Galois element and keys; `Evaluator.Lanes`), every `AddNew(x, RotateNew(x, r))` is one engine call (the add on the ModDown's "
+                   "store) and the sums over a layer's products one launch (`mkhe_ct_sum`).  Kernel trace, same box (`r5_cnn4_lanes_trace_summary.txt` / `_forks_`): **213 kernels per inference instead of 447**; "
+                   "the trace also shows why forks never helped: with 7 forked contexts every kernel ran ALONE (\"alone µs\" = total µs for every kernel) — small kernels of different streams do not overlap on this chip.  "
+                   "Per layer (ms, a sync per layer): %s; host issue %.2f ms." % (c4["value"], c4["ms_per_step"], ", ".join("%s %.2f" % (k, v) for k, v in cc.get("layer_ms", {}).items()), cc.get("host_issue_ms", 0)))
+    out.append("* Measured and NOT kept (`r5_fuse_pass_ab.txt`, one call, switches library): the 2 / 3 cross stages of the small N = 2^14 NTTs as a dot product at the load (fused forward sub-transform kernel; "
+               "inverse pass inside the ModDown kernels) — 627 GPU tests green with it, every line slower (cnn 449 → 392, PN14QP439 6072 → 5418, headline 1364 → 1336): 8 products and 8 loads per word cost more than the launch they save.  "
+               "Thresholds of the small-launch forms (`MKHE_NTT_LDS11_MAX`, `MKHE_NTT14_MIN`): the defaults stand (± 1 %).")
+    out.append("* PN16QP1761 line: `cpu_baseline` = the oracle on the 2-party sub-problem whose keys exist on the host (no extrapolation), `gpu_same_subproblem_per_sec` beside it (`r5_bench_pn16.json`).")
+    out.append("* The product library reads two environment variables (`MKHE_NTT32`, `MKHE_POOL_GB`); every A/B switch lives in `libmkhe_hip_switches.so` (`r5_switch_matrix.txt`: the GPU suite per switch set on that build).")
+    return "\n".join(out) + "\n"
+
+
+txt = f'''# profiles/ — measured on MI355X (gfx950), round 5
+
+{round5_block()}
 
 Distilled by `tools/collect_profiles.py` from ONE `gpurun` call of `tools/profile_round.sh` (the commands are in that script; build = the commit that carries these files); this file is written by
-`tools/write_profiles_readme.py`.  Files of earlier rounds (`r1*`, `r2*`, `r3*`) are kept for comparison.
+`tools/write_profiles_readme.py`.  Files of earlier rounds (`r1*` … `r4*`) are kept for comparison.
 
 Every profiled pass runs the same command, `MKHE_NO_OVERLAP=1 python3 bench.py --steps K --warmup W --no-cpu --no-extras` (every kernel alone on the main stream).  `bench.py` runs its legs in this order: cold-start figure (W + K steps),
 300 steps of the steady-state leg, the timed region (W + K), the HIP-event leg (K) — so the dominant kernel, the Decompose-fused forward NTT `{DOM}` (twice per MulRelin: 1792 limbs for the hoisting of the 8 operand components, 896 limbs for the 4 intermediate t_i),
@@ -141,7 +177,7 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
 
 ## Headline (BASELINE.json configs[1]): mkckks 4-party MulRelin, PN15QP880, N = 2^15, 14 Q + 2 P limbs
 
-* **{pl["value"]:.0f} MulRelin/s** ({pl["ms_per_step"]:.3f} ms per step: hoist both operands + MulAndRelinHoisted + Rescale; round 3: 1157–1207, round 2: 1038, round 1: 763), bit-exact against the oracle on the same inputs in this very run
+* **{pl["value"]:.0f} MulRelin/s** ({pl["ms_per_step"]:.3f} ms per step: hoist both operands + MulAndRelinHoisted + Rescale; round 4: 1310–1370 by box — the step itself did not change in round 5 —, round 3: 1157–1207, round 2: 1038, round 1: 763), bit-exact against the oracle on the same inputs in this very run
   (`cpu_baseline.bit_exact_vs_gpu = {cb["bit_exact_vs_gpu"]}`); CPU oracle on the GPU box's host: {cb["value"]:.2f} MulRelin/s on 1 thread, {cb.get("value_limb_parallel", 0):.2f} with its limb loops on {cb.get("cores_limb_parallel", "?")} threads.
 * Same run: cold start **{C.get("mulrelin_per_sec_cold_start", 0):.0f}/s**, 200 steps after 100 untimed ones {C.get("mulrelin_per_sec_steady_state", 0):.0f}/s, two MulRelin in flight through forked contexts {C.get("mulrelin_per_sec_two_in_flight", 0):.0f}/s.
 * under `rocprofv3 --kernel-trace`, overlap off: {no["value"]:.0f} MulRelin/s ({no["ms_per_step"]:.3f} ms); overlap on: {ov["value"]:.0f} MulRelin/s ({ov["ms_per_step"]:.3f} ms).
@@ -264,7 +300,7 @@ if c2 and c4:
     txt += f"""
 ## BASELINE.json configs[4] caller on one GPU: encrypted CNN inference (cnn/cnn.go), PN14QP433
 
-`python3 bench.py --scheme cnn --parties 2|4 --steps 20 --warmup 3`: **{c2["value"]:.0f}** inferences/s with 2 parties ({c2["ms_per_step"]:.2f} ms), **{c4["value"]:.0f}** with 4 ({c4["ms_per_step"]:.2f} ms) (round 3: 350 / 343, round 2: 276 / 268).
+`python3 bench.py --scheme cnn --parties 2|4 --steps 20 --warmup 3`: **{c2["value"]:.0f}** inferences/s with 2 parties ({c2["ms_per_step"]:.2f} ms), **{c4["value"]:.0f}** with 4 ({c4["ms_per_step"]:.2f} ms) (round 4: 360 / 337 through forked contexts — round 5 runs the independent chains as lanes of one launch set, see the top of this file —, round 3: 350 / 343, round 2: 276 / 268).
 `cpu_baseline` (round 4): the SAME inference — same circuit, keys, model and image — on the CPU oracle through `tests/oracle_evaluator.py`, one host thread: {cb4.get("value", float("nan")):.3f} inferences/s ({cb4.get("sample", "")}),
 {cb4.get("value_limb_parallel", float("nan")):.2f} with the oracle's limb loops on {cb4.get("cores_limb_parallel", "?")} threads; its output ciphertext equals the device's bit for bit (`bit_exact_vs_gpu = {cb4.get("bit_exact_vs_gpu")}`).
 """
