@@ -304,7 +304,7 @@ def run_cnn(args):
                 config=dict(workload="cnn encrypted inference (Convolution + square + FC1 + square + FC2, cnn/cnn.go), PN14QP433 N=2^14, "
                                      "7 Q + 2 P limbs, %d parties" % len(set(owners.values())),
                             parties=len(set(owners.values())), params="PN14QP433", seed=args.seed, batch=B, batch_check=batch_check,
-                            forks=len(forks) if B == 1 else 0, chains=("forks" if forks else "lanes") if B == 1 else "forks of the batch evaluator",
+                            forks=len(forks) if B == 1 else 0, chains=("forks" if forks else "lanes") if B == 1 else ("forks of the batch evaluator" if args.batch_forks > 0 else "lanes of the batch's launch sets"),
                             launch_groups_per_inference=(sum(k["launches_per_step"] for k in roofline["kernels"].values()) / B) if roofline and roofline.get("kernels") else None,
                             hip_graph=graph is not None, host_issue_ms=issue * 1e3 / args.steps, layer_ms={k: v / args.steps for k, v in layer_ms.items()}, out_level=out.Level(),
                             keygen_s=keygen_s, keys_generated=len(set(owners.values())) * (3 + len(HC.ROTS) + p["logN"] - 1)),
@@ -766,7 +766,8 @@ def main():
                     help="B inputs in lock step (mkhe_*_batch entry points, mkckks.BatchEvaluator): --scheme cnn evaluates B images per step, "
                          "--scheme ckks B MulRelin per step; value counts inputs (inferences / MulRelin per second), every output is compared "
                          "with the B = 1 evaluation of the same input")
-    ap.add_argument("--batch-forks", type=int, default=3, help="--scheme cnn --batch B: forked batch evaluators for the independent chains of a layer")
+    ap.add_argument("--batch-forks", type=int, default=0, help="--scheme cnn --batch B: forked batch evaluators for the independent chains of a layer (round 4: 3); "
+                                                                "0 (default since round 5): the chains are lanes of the batch's launch sets (B x n items)")
     ap.add_argument("--graph", type=int, default=0,
                     help="--scheme cnn: 1 = replay the inference from a captured HIP graph (falls back to eager issue when the loaded HIP "
                          "runtime cannot capture), 0 = issue every call eagerly (default: 3.9 ms per inference in every run; replays "

@@ -46,6 +46,24 @@ def _lane_products(eval, rlkSet, rtkSet, ct, ctHoisted, rots, ctOther, ctOtherHo
     r = 0: the rotation is a copy and its hoisted form IS ctHoisted (cnn.go:16, :53 with i = 0)"""
     from .mkckks import BatchCiphertext, BatchHoisted
     moving = [r for r in rots if r != 0]
+    if isinstance(ct, BatchCiphertext):
+        # B images in lock step: lane-major item lists of B * n (item j * B + b = lane j of image b); the model operands are the same for every image
+        B = len(ct.cts)
+        temps, tempsH = [], []
+        if moving:
+            lanes = eval.Lanes(len(moving))
+            t = lanes.RotateHoistedNew(BatchCiphertext([c for _ in moving for c in ct.cts]), [r for r in moving for _ in range(B)],
+                                       BatchHoisted([h for _ in moving for h in ctHoisted.hoisted]), rtkSet)
+            temps, tempsH = t.cts, lanes.HoistedForm(t).hoisted
+        ops, hs, k = [], [], 0
+        for r in rots:
+            if r == 0:
+                ops += ct.cts; hs += ctHoisted.hoisted
+            else:
+                ops += temps[k * B:(k + 1) * B]; hs += tempsH[k * B:(k + 1) * B]; k += 1
+        prods = eval.Lanes(len(rots)).MulRelinHoistedNew(BatchCiphertext(ops), BatchCiphertext([c for c in ctOther for _ in range(B)]), BatchHoisted(hs),
+                                                         BatchHoisted([h for h in ctOtherHoisted for _ in range(B)]), rlkSet)
+        return [BatchCiphertext(prods.cts[i * B:(i + 1) * B]) for i in range(len(rots))]
     temps, tempsH = [], []
     if moving:
         lanes = eval.Lanes(len(moving))

@@ -353,6 +353,21 @@ class BatchEvaluator:
         """a batch evaluator on a forked context (own stream, shared keys and ciphertexts): independent chains of a circuit overlap on the GPU"""
         return BatchEvaluator(self.params.Fork(), self.B)
 
+    def Lanes(self, n):
+        """n independent operations PER INPUT as one launch set: a BatchEvaluator of B * n items on the same context, lane-major (item j * B + b = lane j
+        of input b).  The independent chains of cnn.Convolution / FC1Layer on B images: one rotation / hoisting / MulRelin launch set for all of them."""
+        hit = self.__dict__.setdefault("_lanes", {}).get(n)
+        if hit is None:
+            hit = self._lanes[n] = BatchEvaluator(self.params, self.B * n, ev=self.ev)
+        return hit
+
+    def SumNew(self, cts):
+        """out = cts[0]; for c in cts[1:]: out = AddNew(out, c), on batches (one batched Add per summand)"""
+        out = cts[0]
+        for c in cts[1:]:
+            out = self.AddNew(out, c)
+        return out
+
     # -- helpers
     def _cts(self, op):
         return op.cts if isinstance(op, BatchCiphertext) else [op] * self.B
