@@ -178,3 +178,26 @@ def test_checker_reports_a_dropped_parameter_a_changed_type_and_a_missing_method
     del bad2["GPUEvaluator"]["MulRelinNew"]
     text = "\n".join(check_evaluator("mkckks", gold, f2, bad2, s2))
     assert "RescaleNew" in text and "MulRelinNew: missing" in text
+
+
+def test_dropin_declares_no_name_the_package_already_has():
+    """Go refuses a second declaration of a top-level name in a package: nothing the drop-in files declare (functions, Type.Method, types, variables) may
+    exist in the files of the reference package that stay compiled under the tag (`declared` in the golden table; the two replaced mkrlwe files are out)"""
+    decl = json.load(open(GOLDEN))["declared"]
+    for pkg in ("mkrlwe", "mkckks", "mkbfv"):
+        for tagged in (True, False):
+            _, _, srcs = dropin(pkg, tagged)
+            mine = set()
+            for s in srcs.values():
+                mine |= gen.declared_names(s)
+            clash = sorted(mine & set(decl[pkg]))
+            assert not clash, "package %s already declares %s" % (pkg, clash)
+    # and the two builds of a package do not declare a name twice between the drop-in files themselves
+    for pkg in ("mkckks", "mkbfv"):
+        for tagged in (True, False):
+            _, _, srcs = dropin(pkg, tagged)
+            seen = {}
+            for f, s in srcs.items():
+                for n in gen.declared_names(s):
+                    assert n not in seen, "%s declared in %s and %s" % (n, seen[n], f)
+                    seen[n] = f

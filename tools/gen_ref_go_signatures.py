@@ -116,6 +116,24 @@ def exported(d):
     return {k: v for k, v in d.items() if k[:1].isupper()}
 
 
+# files the build tag excludes when the drop-in is active (shim/go/patches/mkrlwe_build_tags.diff): their names are free again
+EXCLUDED = {"mkrlwe": ["mkrlwe/keyswitch.go", "mkrlwe/keyswitch_hoisted.go"]}
+
+
+def declared_names(src):
+    """top-level identifiers a Go file declares: funcs, Type.Method, types, package-level vars / consts (single and grouped)"""
+    src = _strip_comments(src)
+    p = parse_go_signatures(src)
+    names = set(p["funcs"])
+    for t, ms in p["methods"].items():
+        names |= {"%s.%s" % (t, m) for m in ms}
+    names |= set(re.findall(r"^type\s+([A-Za-z_][A-Za-z0-9_]*)", src, flags=re.M))
+    names |= set(re.findall(r"^(?:var|const)\s+([A-Za-z_][A-Za-z0-9_]*)", src, flags=re.M))
+    for m in re.finditer(r"^(?:var|const)\s*\((.*?)^\)", src, flags=re.M | re.S):
+        names |= set(re.findall(r"^\s*([A-Za-z_][A-Za-z0-9_]*)", m.group(1), flags=re.M))
+    return names
+
+
 def build(ref_root):
     table = {}
     for pkg, files in FILES.items():
@@ -128,7 +146,16 @@ def build(ref_root):
                 for k, v in exported(ms).items():
                     methods.setdefault(t, {})[k] = dict(v, file=f)
         table[pkg] = {"funcs": funcs, "methods": methods}
-    return {"reference": "SNUCP/MKHE-KKLSS", "files": FILES, "packages": table}
+    declared = {}
+    for pkg in FILES:
+        names = set()
+        for fn in sorted(os.listdir(os.path.join(ref_root, pkg))):
+            rel = "%s/%s" % (pkg, fn)
+            if fn.endswith(".go") and not fn.endswith("_test.go") and rel not in EXCLUDED.get(pkg, []):
+                names |= declared_names(open(os.path.join(ref_root, rel)).read())
+        declared[pkg] = sorted(names)
+    # `declared`: every top-level name of the package's non-test files that stay compiled under the tag -- a drop-in file may not declare one again
+    return {"reference": "SNUCP/MKHE-KKLSS", "files": FILES, "excluded_under_tag": EXCLUDED, "packages": table, "declared": declared}
 
 
 if __name__ == "__main__":
