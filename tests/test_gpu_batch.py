@@ -285,6 +285,16 @@ def test_rotate_and_add_is_the_two_calls(case, ids, level):
     for k in range(B):
         assert (got.cts[k].download() == ref(hs[k], hs[k], 5)).all(), k
         assert (oth.cts[k].download() == ref(hs[k], ha[k], [5, 1, 5][k])).all(), k
+    if level < case.level:
+        # an addend (and an input) one level ABOVE the output: only the first level + 1 limbs take part (mkrlwe/keyswitch_hoisted.go:183-190: the level is ctOut's)
+        hu, up = case.batch(ids, B, level + 1)
+        hv, add_up = case.batch(ids, B, level + 1)
+        out = bev._new(set(ids), level, case.p["scale"])
+        rk = [case.rtk.GetRotationKey(i, r).Value.h for r in [1, 5, 1] for i in up.ids]
+        galv = (C.c_uint64 * B)(*[case.params.GaloisElementForColumnRotationBy(r) for r in [1, 5, 1]])
+        check(lib().mkhe_rotate_multi(case.params.ctx, B, galv, bev._h(up), None, handle_array(rk), handle_array([case.params.CRS[r].h for r in [1, 5, 1]]), bev._h(add_up), bev._h(out)))
+        for k in range(B):
+            assert (out.cts[k].download() == ref(np.ascontiguousarray(hu[k][:, :level + 1]), np.ascontiguousarray(hv[k][:, :level + 1]), [1, 5, 1][k])).all(), k
     # errors: an output that is an addend; an addend with other ids
     rk = [case.rtk.GetRotationKey(i, 1).Value.h for i in c.ids]
     gal = (C.c_uint64 * 1)(case.params.GaloisElementForColumnRotationBy(1))
