@@ -21,7 +21,8 @@
 //     struct, as the reference does -- 56 MiB over PCIe per Decompose at PN15QP880; callers that only pass hoisted forms on (mkckks.Evaluator
 //     does: evaluator.go:423-437,549,579) set it to false, and Materialize fetches a vector if it is ever wanted on the host.
 //   - ciphertext polynomials: uploaded and downloaded per call.
-//   - device copies are released when the host struct they are bound to is collected (a finalizer on the *SwitchingKey) or by Forget / Close.
+//   - device copies are released when the host struct they are bound to is collected (a finalizer on the *SwitchingKey queues them; the next
+//     engine call of the owner closes them) or by Forget.
 //
 //go:build mkhe_gpu
 
@@ -55,6 +56,8 @@ type KeySwitcher struct {
 	gpu      *mkrlwegpu.Context
 	mu       sync.Mutex
 	resident map[uintptr]*mkrlwegpu.SwitchingKey // host *SwitchingKey (as an address: no strong reference) -> device copy
+	garbage  []*mkrlwegpu.SwitchingKey          // device copies whose host struct was collected: closed by the next engine call (finalizers run on
+	// their own goroutine, and the calls on one engine context are serialized by its owner)
 }
 
 func NewKeySwitcher(params Parameters) *KeySwitcher {
@@ -75,7 +78,25 @@ func (ks *KeySwitcher) GPU() *mkrlwegpu.Context {
 	if ks.gpu == nil {
 		ks.gpu = mkrlwegpu.NewContext(ks.Parameters, ks.Device)
 	}
+	ks.mu.Lock()
+	dead := ks.garbage
+	ks.garbage = nil
+	ks.mu.Unlock()
+	for _, d := range dead {
+		d.Close()
+	}
 	return ks.gpu
+}
+
+// collected is the finalizer of a host SwitchingKey that has a device copy: the copy is handed to the next engine call for closing.
+func (ks *KeySwitcher) collected(swk *SwitchingKey) {
+	key := uintptr(unsafe.Pointer(swk))
+	ks.mu.Lock()
+	if d, ok := ks.resident[key]; ok {
+		delete(ks.resident, key)
+		ks.garbage = append(ks.garbage, d)
+	}
+	ks.mu.Unlock()
 }
 
 // ---- residency
@@ -94,7 +115,7 @@ func (ks *KeySwitcher) bind(swk *SwitchingKey, d *mkrlwegpu.SwitchingKey) {
 		// own, or it has one already -- keeps its device copy until Forget)
 		func() {
 			defer func() { _ = recover() }()
-			runtime.SetFinalizer(swk, func(s *SwitchingKey) { ks.Forget(s) })
+			runtime.SetFinalizer(swk, ks.collected)
 		}()
 	}
 }
