@@ -10,7 +10,6 @@
 #include <string>
 #include <atomic>
 #include <mutex>
-#include <functional>
 #include <map>
 #include <vector>
 #include <stdexcept>
@@ -151,8 +150,6 @@ class Context {
     // stage 0: whole external products; 1: front half only (inner products + inverse NTT into the c1 pool);
     // 2: back half only (ModDown of the c1 pool filled by the preceding stage-1 call with the same items)
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
-    bool tensor_late_ = false, tensor_pending_ = false;      // MKHE_TENSOR_LATE: mr_prepare hands the tensor chain to mr_finish_head (tensor_fn_), which
-    std::function<void()> tensor_fn_, after_inner_;           // starts it right after the F1 kernel (after_inner_: ext_front's hook behind its inner-product launch)
     u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
     u64* ext_xout2_ = nullptr;            // ... and the second gadget's x (mkbfv)
     std::vector<u64*> ext_eouts_;                           // a batch's F1 call that computes step E too: where input b's E products go ([n1][mtot][N])

@@ -661,7 +661,6 @@ void Context::join_side(int k) { if (!overlap) return; MKHE_HIP(hipStreamWaitEve
 void Context::recover() {
     s_ = stream;
     plan_.valid = false; plan_.x_pending = false; plan_.head_done = false; plan_.xkeys.clear(); ext_xout_ = ext_xout2_ = nullptr;
-    tensor_late_ = false; tensor_pending_ = false; tensor_fn_ = nullptr; after_inner_ = nullptr;
     rs_maps_.clear();
     bfv_plan_valid_ = false; bfv_xk1_.clear(); bfv_xk2_.clear();
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1139,7 +1138,6 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
               launch_ext_inner_xy_batch(xa, s_);
           }
       } else launch_ext_inner(ia, s_); }
-    if (after_inner_) { auto f = std::move(after_inner_); after_inner_ = nullptr; f(); }      // (MKHE_TENSOR_LATE: the tensor chain forks off here)
     NttBatch b{};
     b.src = c1; b.dst = c1; b.mods = d_mods; b.psi = d_psiinv; b.aux = d_inv_aux;
     b.src_inner = b.dst_inner = N; b.src_mapped = b.dst_mapped = 1;
@@ -1250,10 +1248,7 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
 void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
                             const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                             const Swk& crs_u, Ct& out) {
-    static const int late_env = MKHE_AB_INT("MKHE_TENSOR_LATE", 0);
-    tensor_late_ = late_env != 0 && !masked_;
-    try { mr_prepare(op0, op1, hoist0, hoist1, true, out); } catch (...) { tensor_late_ = false; throw; }
-    tensor_late_ = false;
+    mr_prepare(op0, op1, hoist0, hoist1, true, out);
     static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
     static const int wide_env = MKHE_AB_INT("MKHE_FUSE_X_WIDE", 1);      // A/B: the by-product for five to sixteen parties
     const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= (wide_env ? 16 : 4) && !masked_;
@@ -1330,11 +1325,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
     // D: tensor product in the NTT domain, back to coefficients -- started here on the side stream: it only
     // needs the operands and the engine's own hoisted digits, runs beside the x / y accumulation and meets
     // the main chain again at the first ModDown of mr_finish.
-    // MKHE_TENSOR_LATE (round 5 experiment): the chain is enqueued -- and its fork event recorded -- right after the F1 kernel of mr_finish_head instead of
-    // here, so that its small launches run beside the latency-bound tail of F1 (inverse NTT, ModDown of a few dozen limbs: most of the chip idle) instead
-    // of beside the HBM-bound F1 kernel itself.  Single-device MulAndRelin only (tensor_late_: the operands outlive the call).
-    auto tensor_chain = [this, &op0, &op1, &out, with_c0, P0, P1]() {
-        MrPlan& p = plan_;
+    {
         const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
         const size_t PO = (size_t)L * N;
         u64* nb_ = scratch(nttbuf_, nttbuf_words_, (size_t)(2 + n0 + n1) * PO);
@@ -1391,9 +1382,7 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
         }
         side_done(1);
         s_ = stream;
-    };
-    if (tensor_late_ && overlap && p.n0 >= 1) { tensor_fn_ = tensor_chain; p.tens = nullptr; tensor_pending_ = true; }
-    else tensor_chain();
+    }
     p.valid = true; p.head_done = false;
 }
 
@@ -1470,9 +1459,7 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
             ext_e_slot_ = 2 * n0;
         }
     }
-    if (tensor_pending_) { after_inner_ = std::move(tensor_fn_); tensor_fn_ = nullptr; tensor_pending_ = false; }
-    try { ext_batch(level, items); } catch (...) { ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1; after_inner_ = nullptr; throw; }
-    if (after_inner_) throw Error("mkhe: internal: the deferred tensor chain was not started");
+    try { ext_batch(level, items); } catch (...) { ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1; throw; }
     p.e_done = ext_e_slot_ >= 0;
     ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1;
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
