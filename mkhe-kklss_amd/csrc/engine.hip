@@ -338,9 +338,14 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
     d_md_qoverqiinvqi = dev_upload(t1); d_md_qoverqimodp = dev_upload(t2); d_md_vtimes = dev_upload(t3); d_md_down = dev_upload(t4);
 
     // RescaleParams[L-1][i] = MForm(q_L^-1 mod q_i)  (lattigo ring.go genNTTParams)
-    std::vector<u64> rs((size_t)nq * nq, 0);
+    // second half of the table (round 5): BRedAdd((q_L - 1) / 2, q_i) = h mod q_i, the other per-(level, limb) constant of DivRoundByLastModulus -- the
+    // merged ModDown computed it per coefficient and limb with a float64 division, 9 % of its instructions
+    std::vector<u64> rs(2 * (size_t)nq * nq, 0);
     for (int L = 1; L < nq; ++L)
-        for (int i = 0; i < L; ++i) rs[(size_t)(L - 1) * nq + i] = to_mont(powmod(Q[L] % Q[i], Q[i] - 2, Q[i]), Q[i]);
+        for (int i = 0; i < L; ++i) {
+            rs[(size_t)(L - 1) * nq + i] = to_mont(powmod(Q[L] % Q[i], Q[i] - 2, Q[i]), Q[i]);
+            rs[(size_t)nq * nq + (size_t)(L - 1) * nq + i] = ((Q[L] - 1) >> 1) % Q[i];
+        }
     d_rescale = dev_upload(rs);
 
     if (alpha > 1) {
@@ -1200,6 +1205,7 @@ void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 g
             for (size_t m = 0; m < rs_maps_.size() && ok; ++m) ok = cover[m] == 0 || cover[m] == rs_maps_[m].npolys;
             if (ok) {
                 md.rescale_row = d_rescale + (size_t)(level - 1) * nq;
+                md.rescale_h = md.rescale_row + (size_t)nq * nq;
                 for (int v = 0; v < mp->nvi; ++v) {
                     RsMap& r = rs_maps_[which[v]];
                     md.rdst[v] = r.out + (size_t)(mp->dst[v] - r.full) / PF * ((size_t)level * N);

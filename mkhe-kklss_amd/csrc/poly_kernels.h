@@ -211,6 +211,7 @@ struct ModDownMergedArgs {
     // DivRoundByLastModulus of the ModDown result -- limbs 0 .. level-1 of rdst[v] (a polynomial of the output ciphertext one level down,
     // limb stride N) -- instead of the result itself; the thread computes limb `level` of its coefficient first (every limb slice does).
     const u64* rescale_row;                       // [level]: RescaleParams row of the level, as div_round_last_kernel takes it
+    const u64* rescale_h;                         // [level]: (q_level - 1) / 2 mod q_j -- BRedAdd(h, q_j) of the same formula, from the host
     u64* rdst[EXT_MAX_ITEMS];
     unsigned int gal_v[EXT_MAX_ITEMS];            // as ModDownBatchArgs::gal_v / post, per virtual item
     const u64* post[EXT_MAX_ITEMS];

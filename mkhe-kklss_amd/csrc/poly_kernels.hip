@@ -888,23 +888,30 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
                 v[k] = (u32)(u64)vi_;
             }
         }
+        // The members' y under one special prime meet the same constant in the 128-bit multSum: sum_k y_k[i] * c[j][i] = (sum_k y_k[i]) * c[j][i] as
+        // INTEGERS (at most four summands below 2^60: below 2^62; the product below 2^122), so the accumulator -- and with it every bit of the result --
+        // is the same with NPT products per limb instead of members x NPT (round 5: the kernel is bound by its instruction count, 1169 per wave)
+        u64 ys[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            ys[i] = y[0][i];
+#pragma unroll
+            for (int k = 1; k < MD_VI_MAX; ++k) ys[i] += y[k][i];          // (y[k][i] = 0 for k >= cnt)
+        }
         // the ModDown result of limb j for this coefficient (canonical)
         auto down = [&](int j, const Mod& mq) -> u64 {
             u64 rlo = 0, rhi = 0, vt = 0;
 #pragma unroll
-            for (int k = 0; k < MD_VI_MAX; ++k) {
-                if (k < cnt) {
-#pragma unroll
-                    for (int i = 0; i < NPT; ++i) {
-                        u64 mhi, mlo;
-                        mul64x64(y[k][i], ((sc_u64)a.t.qoverqimodp)[(long)j * NPT + i], mhi, mlo);
-                        const u64 sum = rlo + mlo;
-                        rhi += mhi + (sum < rlo ? 1 : 0);
-                        rlo = sum;
-                    }
-                    vt = csub(vt + select_entry<NPT>((sc_u64)a.t.vtimesqmodp + (long)j * (NPT + 1), NPT, (u64)v[k]), mq.q);
-                }
+            for (int i = 0; i < NPT; ++i) {
+                u64 mhi, mlo;
+                mul64x64(ys[i], ((sc_u64)a.t.qoverqimodp)[(long)j * NPT + i], mhi, mlo);
+                const u64 sum = rlo + mlo;
+                rhi += mhi + (sum < rlo ? 1 : 0);
+                rlo = sum;
             }
+#pragma unroll
+            for (int k = 0; k < MD_VI_MAX; ++k)
+                if (k < cnt) vt = csub(vt + select_entry<NPT>((sc_u64)a.t.vtimesqmodp + (long)j * (NPT + 1), NPT, (u64)v[k]), mq.q);
             const u64 hhi = mulhi64(rlo * mq.qinv, mq.q);
             const u64 lift = rhi - hhi + mq.q + vt;                      // = sum_k (the reference's per-product lift) mod q
             const u64 x = xq[(long)j * a.N + n];                         // lazy, < 2q
@@ -918,13 +925,7 @@ __global__ void __launch_bounds__(PW_THREADS) moddown_merged_kernel(ModDownMerge
             u64* rd = ka->rdst[vi];
             for (int j = blockIdx.y; j < a.level; j += gridDim.y) {
                 const Mod mq = load_mod((sc_mod)a.mods_q + j);
-                u64 hr;
-                {
-                    const u64 kq = (u64)((double)h / (double)mq.q);        // BRedAdd(h, q_j) as in div_round_last_kernel
-                    hr = h - kq * mq.q;
-                    if ((i64)hr < 0) hr += mq.q;
-                    if (hr >= mq.q) hr -= mq.q;
-                }
+                const u64 hr = ((sc_u64)a.rescale_h)[j];                   // BRedAdd(h, q_j) = h mod q_j (div_round_last_kernel computes it in place)
                 const u64 z = down(j, mq);
                 rd[(long)j * a.N + n] = mont_mul(t + (mq.q - hr) + mq.q2 - z, mq.q - ((sc_u64)a.rescale_row)[j], mq.q, mq.ninv32);
             }
