@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libmkhe_oracle.so")
+# MKHE_ORACLE_LIB: another build of the same sources (tests/test_sanitizers.py: the ASan + UBSan build, oracle/Makefile SAN=1)
+_LIB_PATH = os.environ.get("MKHE_ORACLE_LIB") or os.path.join(_HERE, "_build", "libmkhe_oracle.so")
 
 u64p = C.POINTER(C.c_uint64)
 i32p = C.POINTER(C.c_int)
