@@ -1,6 +1,6 @@
 // ntt16_kernels.hip -- forward negacyclic NTT, N = 2^15, for the large Decompose launches of a MulRelin ("H16" form).
 //
-// Why a second forward kernel: the register-resident kernel of ntt_kernels.hip
+// Why a second forward kernel (docs/DESIGN_HISTORY.md section 4, round 2): the register-resident kernel of ntt_kernels.hip
 // holds a whole limb in ONE workgroup per CU (1024 threads x 32 coefficients x 128 VGPRs).  Its three resources --
 // VALU (butterflies), LDS (re-distribution) and the memory pipe (loads / stores) -- are then used one after the
 // other, because the 16 waves of the only resident workgroup move through the same phases together: 36 us + 9 us +
@@ -34,7 +34,7 @@
 // Round 3: two instantiations of the limb body -- the U class (moduli with 160 q < 2^62: unsigned low data digit, one-round product of radix
 // 2^30 "mm30u", no reductions) and the balanced path above for the 59/60-bit primes, whose partial reductions follow a per-modulus schedule
 // (NttBatch::sched); lane-linear LDS writes as ds_write_addtid_b32; the same body as ntt14_fwd_kernel for N = 2^14 (one pass per limb).  The
-// kernel runs at the package power cap (tools/power_probe.sh); DESIGN.md section 3 "Round 3" has the steady-state ablation of its two sides.
+// kernel runs at the package power cap (tools/power_probe.sh); docs/DESIGN_HISTORY.md section 3 "Round 3" has the steady-state ablation of its two sides.
 //
 // Replaces: lattigo ring.NTTLvl as called from DecomposeSingleNTT (mkrlwe/keyswitch.go:21-31,49-73).
 #include "ntt_kernels.h"

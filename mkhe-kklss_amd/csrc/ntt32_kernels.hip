@@ -3,7 +3,7 @@
 // The H16 kernel (ntt16_kernels.hip) transforms a limb in two passes of 2^14 points so that two 64-VGPR workgroups share a CU; the price is
 // stage 0 computed twice (1/15 of the butterflies), the source limb read twice, two cross-wave exchanges (eight workgroup barriers) per limb,
 // eight LDS re-distributions of sixteen registers per limb, and a last phase on the two-round product because a ring of twiddle PAIRS does not
-// fit its 64 registers.  It runs at the package power cap (DESIGN.md section 3 "Round 3"), where what a limb costs is the energy of its
+// fit its 64 registers.  It runs at the package power cap (docs/DESIGN_HISTORY.md section 3 "Round 3"), where what a limb costs is the energy of its
 // instructions and bytes rather than how well its phases overlap.  H32 is the other trade: ONE workgroup of 1024 threads per CU holds the
 // whole limb (32 coefficients per thread, 128 VGPRs, 4 waves per SIMD) and runs the 15 stages as three register phases of five:
 //   A: index bits 14..10 in registers, thread = bits 9..0                     31 twiddle pairs, uniform per workgroup (scalar loads)
@@ -59,7 +59,7 @@ constexpr int RING = MKHE_H32_RING;        // twiddle pairs (4 VGPRs each) live 
 #define MKHE_H32_PHPRIO 2
 #endif
 #ifndef MKHE_H32_PREFETCH
-#define MKHE_H32_PREFETCH 0                // (experiment, slower by 3 %: DESIGN.md) the next limb's source loads are issued between the stores of this one (register by register)
+#define MKHE_H32_PREFETCH 0                // (experiment, slower by 3 %: DESIGN.md section 10) the next limb's source loads are issued between the stores of this one (register by register)
 #endif
 #ifndef MKHE_NTT32_EVEN_DEFAULT
 #define MKHE_NTT32_EVEN_DEFAULT 0

@@ -1,6 +1,6 @@
 // Package mkrlwegpu, batchgpu.go: B inputs of ONE shape per call (mkhe_*_batch; no reference counterpart -- the Go evaluator issues one operation at
 // a time).  A service that evaluates one circuit on many inputs calls these instead of B single operations: every output equals the single-operation
-// wrapper's on the same input bit for bit (tests/test_gpu_batch.py), and on the small rings the throughput is 3x (DESIGN.md section 4 "B inputs in
+// wrapper's on the same input bit for bit (tests/test_gpu_batch.py), and on the small rings the throughput is 3x (DESIGN.md section 8 "B inputs in
 // lock step").  All inputs of a call have the same ids and level; keys and CRS belong to the parties and are shared; an operand that is the same for
 // every input (a model) is passed B times.  Un-built here like the rest of the shim (no Go toolchain in the build image); its C calls are checked
 // against include/mkhe.h by tests/test_go_shim_static.py.

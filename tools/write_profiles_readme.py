@@ -124,7 +124,7 @@ def round5_block():
                                kern, r["shipped_us"]["1792_limbs"], r["shipped_us"]["896_limbs"], r["butterflies_only_us"]["1792_limbs"], r["butterflies_only_us"]["896_limbs"],
                                r["butterflies_share"]["1792_limbs"], r["butterflies_share"]["896_limbs"], r["frac_if_alu_only"]["1792_limbs"], r["frac_if_alu_only"]["896_limbs"]))
         out.append("  The vector ALU alone is three quarters of the kernel: 0.50–0.54 of the HBM roofline is where a 64-bit modular butterfly of 12 VALU instructions puts this part, "
-                   "whatever the bytes do (DESIGN.md §3; no rewrite of the phase structure was attempted this round).")
+                   "whatever the bytes do (DESIGN.md §4.1; no rewrite of the phase structure was attempted this round).")
     if C.get("mulrelin_per_sec_batch2"):
         out.append("* B MulRelin in lock step on the headline ring (`config.mulrelin_per_sec_batch2/4`, every output identical to the single-input result: %s / %s): **%.0f / %.0f MulRelin/s** "
                    "against %.0f for one input at a time in the same run — the step is the Decompose NTT and two streaming launches at their ceilings, batching has no idle time to fill "
@@ -196,7 +196,7 @@ Per kernel class, HIP events inside `bench.py` (roofline leg, overlap off), per 
 Whole step: the kernels with a PMC column ({100 * cov:.0f} % of the kernel time) move **{tot_bytes / 1e9:.2f} GB per MulRelin** through HBM (round 3: 2.76, round 2: 3.40 GB) = {tot_bytes / 1e9 / pl["ms_per_step"]:.2f} TB/s averaged over the {pl["ms_per_step"]:.3f} ms step.  Round 4 removed a launch and three passes from it (below): the two streaming launches left
 read every key once (b, d: 470 MB; v, u: 294 MB) and every hoisted digit once (h(c0), h(c1): 470 MB; h(t): 235 MB) — the compulsory bytes of the algorithm.
 
-### Dominant kernel: the Decompose-fused forward NTT — `{DOM}` in this set (DESIGN.md §3 "Round 3", §4)
+### Dominant kernel: the Decompose-fused forward NTT — `{DOM}` in this set
 
 * HIP-event average inside `bench.py`: **{R["avg_launch_us"]:.1f} µs per launch** (plain run), {Rn["avg_launch_us"]:.1f} µs in the profiled run; rocprofv3 kernel-trace of that profiled run: `{DOM}` **{avg:.1f} µs** over {calls} calls
   (min {mn:.0f}, max {mx:.0f} µs), `{OTHER}` {oavg:.1f} µs over {ocalls} calls (the engine times a block of launches of each form per launch shape before it settles, and may settle on different forms for the 1792- and the 896-limb shape): {calls} + {ocalls} = {calls + ocalls} of the expected {expect}, **{(avg * calls + oavg * ocalls) / max(1, calls + ocalls):.1f} µs** over all of them.  Round 3: 172–176 µs, round 2: 207 µs, round 1 (`ntt_fwd_kernel<15,2,true>`): 297.5 µs.
@@ -214,7 +214,7 @@ read every key once (b, d: 470 MB; v, u: 294 MB) and every hoisted digit once (h
 * **Steady-state ablation** (`{tag}_ntt16_ablation.txt`, 1792 limbs, µs per launch, second part of the file): shipped {abl("shipped", kernel="ntt16"):.0f}, the vector-ALU side alone {abl("no_mem_no_xchg", kernel="ntt16"):.0f}, all butterflies removed {abl("no_bfly", kernel="ntt16"):.0f}.
 * `{tag}_ubench.txt`: the bare butterfly on `mm31` {m31.group(3) if m31 else "?"} cycles per wave at {m31.group(1) if m31 else "?"} GHz, on `mm30u` **{m30.group(3) if m30 else "?"} cycles at {m30.group(1) if m30 else "?"} GHz**; `{tag}_ntt16_isa.txt`: 13.6 VALU instructions per butterfly in the U-class pass body.
 
-### The single-pass kernel `{ALT}` (`MKHE_NTT32=1`; DESIGN.md §4 "The single-pass kernel")
+### The single-pass kernel `{ALT}` (`MKHE_NTT32=1`)
 
 One 1024-thread workgroup per CU holds a whole limb (32 coefficients per thread): no stage repeated, every source word loaded once, one cross-wave exchange per limb, 12 VALU instructions per butterfly in every stage.
 
@@ -243,7 +243,7 @@ writes the t_i and the E products; y and x are never stored, the h(c1_j) are not
 `MKHE_FUSE_Y=0` / `MKHE_FUSE_E=0` are the switches).  Same call: 1203–1213 → 1231–1238 MulRelin/s with y inside, → **1308–1318** with step E inside as well; `ext_inner_kernel` here: two launches of {R["kernels"]["ext_inner_kernel"]["avg_launch_us"]:.0f} µs on average.
 The batched entry (`ext_inner_xy_batch_kernel<G0, G1>`, B inputs) computes x_b and y_b in the thread; step E there is still a tail item (cnn, whose MulRelins have 1 to 3 parties per operand: 330 → 338 inferences/s one image at a time, 978 → 1022 at B = 8, same call).  mkbfv runs the same kernel over its two gadgets (623–629 → 747–751 MulRelin/s, same call); five to eight parties per operand take `ext_inner_xy_wide_kernel` (PN16QP1761 with 8 parties 91–92 → 99.4 MulRelin/s, PN15QP880 with 8 parties 628 → 681).
 Their algorithmic GB/s equal their PMC GB/s (the byte model charges every distinct operand once): ≈ 5.8 TB/s = 0.73 of the 8 TB/s spec.  `{tag}_ubench.txt` (`read_bw`, round 4) measures what a kernel that ONLY reads reaches on the same box: {rds[0]:.0f}–{rds[1]:.0f} GB/s in the pattern of these kernels (14–70 concurrent streams 4 MB apart, 16 bytes per lane), {rdc[0]:.0f}–{rdc[1]:.0f} GB/s with one contiguous region per workgroup (another box of the round: 5464–5875 and 6003–6075) — the streaming kernels are within 0–10 % of the read ceiling of their access pattern, not 27 % under a roofline; the contiguous pattern (digit-major tiles instead of [digit][modulus][N]) would be a re-layout of every hoisted form and key.  The ModDown launches and the small inverse NTTs are
-launch-latency-bound; the Rescale no longer appears: it rides on the merged ModDown's store (`mkhe_mul_relin_rescale`, DESIGN.md §4 "Fused Rescale").
+launch-latency-bound; the Rescale no longer appears: it rides on the merged ModDown's store (`mkhe_mul_relin_rescale`).
 
 ## BASELINE.json configs[2]: mkbfv 4-party MulRelinNew, PN15QP880 BFV chain (14 Q + 14 QMul + 2 P)
 
