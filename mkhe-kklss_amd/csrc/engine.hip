@@ -1,4 +1,5 @@
-// engine.hip -- Context: host-side table generation + orchestration of the HIP kernels.
+// engine.hip -- Context: host-side table generation, buffer pools, stream plumbing, the NTT launch choice, Decompose and the external-product batch
+// (engine_mulrelin.hip, engine_ops.hip, engine_bfv.hip, batch.hip hold the operations built on them).
 #include "engine.h"
 #include <mutex>
 #include <algorithm>
@@ -1246,912 +1247,6 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
         ext_back(level, items.data() + base, n, c1, galEl, merged ? &mp : nullptr);
     }
     if (join_before_moddown >= 0) join_side(join_before_moddown);
-    MKHE_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------ MulAndRelin[Hoisted]
-// keyswitch_hoisted.go:44-179 (hoist == nullptr: keyswitch.go:122-230, same values).
-void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
-                            const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
-                            const Swk& crs_u, Ct& out) {
-    mr_prepare(op0, op1, hoist0, hoist1, true, out);
-    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
-    static const int wide_env = MKHE_AB_INT("MKHE_FUSE_X_WIDE", 1);      // A/B: the by-product for five to sixteen parties
-    const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= (wide_env ? 16 : 4) && !masked_;
-    // y inside the F1 kernel as well (round 4): the thread that forms <h(c0_i), y> at a coefficient needs y there and nowhere else, so that y is
-    // neither a launch nor 2 x 59 MB of traffic -- when op1 has as many parties as op0 (at most four: the group form of the kernel)
-    static const int fuse_y_env = MKHE_AB_INT("MKHE_FUSE_Y", 1);
-    const bool fuse_y = fuse && fuse_y_env && plan_.n1 >= 1 && (plan_.n0 <= 4 ? plan_.n1 <= 4 : (plan_.n0 <= 8 && plan_.n1 == plan_.n0));      // (one to four parties per operand: ext_inner_xy_kernel<G0, G1>; five to eight in both: ext_inner_xy_wide_kernel)
-    mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse, fuse_y);
-    mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
-}
-
-// mkckks.Evaluator.mulRelinHoisted (evaluator.go:558-581) = MulAndRelinHoisted + one Rescale, as ONE engine call: the DivRoundByLastModulus
-// is applied by the merged ModDown of the last batch as it stores (ModDownMergedArgs::rescale_row), so the level-L product is never written
-// and the rescale is neither a launch nor a pass of its own.  That needs every output slot to be written exactly once by that launch (up to
-// four products per destination: at most four parties per operand, single device, tensor term folded in); otherwise the product goes to a
-// pooled temporary and Context::rescale follows -- the same integers either way.
-void Context::mul_relin_rescale(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
-                                const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
-                                const Swk& crs_u, Ct& out) {
-    const int L = out.limbs + 1;                           // limbs of the product
-    if (out.limbs < 1 || L > nq) throw Error("cannot Rescale: input Ciphertext already at level 0");
-    Ct full; full.n = out.n; full.limbs = L; full.ids = out.ids;
-    const size_t words = (size_t)(1 + out.n) * L * N;
-    full.d = pool_alloc(words);
-    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_RESCALE", 1);
-    rs_maps_.clear();
-    if (fuse_env && !masked_) rs_maps_.push_back(RsMap{full.d, out.d, 1 + out.n, out.limbs, false});
-    try {
-        mul_and_relin(op0, op1, hoist0, hoist1, rlk_b1, rlk_d0, rlk_v0, crs_u, full);
-        const bool done = !rs_maps_.empty() && rs_maps_[0].done;
-        rs_maps_.clear();
-        if (!done) rescale(full, 1, out);
-    } catch (...) { rs_maps_.clear(); const HandleUsers none; pool_free(full.d, words, &none); throw; }
-    // the temporary never left this context (no handle, no other context can have work queued on it): an EMPTY user list, so that the pool does
-    // not order its next user behind every live context (users == nullptr means "unknown": the forks of the cnn evaluation would serialise)
-    const HandleUsers none;
-    pool_free(full.d, words, &none);
-}
-
-// -- step 0: validate, map ids, hoist the operands when the caller did not (MulRelinNew, evaluator.go:416-443)
-// and start step D (tensor).  with_c0 = false leaves c0_0*c1_0 out of out_0 (another rank of a party-sharded
-// evaluation adds it).
-void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, bool with_c0, Ct& out) {
-    MrPlan& p = plan_;
-    p = MrPlan{};
-    p.level = out.limbs - 1; p.L = p.level + 1;
-    check_level(p.level);
-    if (op0.limbs < p.L || op1.limbs < p.L) throw Error("Cannot MulAndRelin: op0 and op1 have different levels");
-    p.n0 = op0.n; p.n1 = op1.n; p.nout = out.n;
-    if (p.n0 > 32 || p.n1 > 32 || out.n > 32) throw Error("mkhe: too many parties");
-    // out ids must be the union of the operand id sets (newCiphertextBinary, mkckks/evaluator.go:306-313)
-    p.slot0.assign(p.n0, 0); p.slot1.assign(p.n1, 0);
-    auto find = [&](int id) { for (int o = 0; o < out.n; ++o) if (out.ids[o] == id) return o; return -1; };
-    std::vector<char> seen(out.n, 0);
-    for (int a = 0; a < p.n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); p.slot0[a] = o; seen[o] = 1; }
-    for (int a = 0; a < p.n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); p.slot1[a] = o; seen[o] = 1; }
-    for (int o = 0; o < out.n; ++o) if (!seen[o]) throw Error("mkhe: ctOut has an id that neither operand has");
-    const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N;
-    p.h0.assign(p.n0, nullptr); p.h1.assign(p.n1, nullptr);
-    const bool same = (&op0 == &op1) && hoist0 == hoist1;
-    p.own0 = (hoist0 == nullptr) && alpha == 1; p.own1 = (hoist1 == nullptr) && alpha == 1;
-    if (masked_ && !(p.own0 && p.own1)) throw Error("mkhe: a limb-sharded evaluation hoists its operands itself");
-    std::vector<const u64*> dsrc; std::vector<u64*> ddst;
-    for (int a = 0; a < p.n0; ++a) {
-        if (hoist0) { if (!hoist0[a]) throw Error("mkhe: missing hoisted form"); p.h0[a] = hoist0[a]->d; }
-        else { Swk& s = hoist_slot(0, a); dsrc.push_back(op0.d + (1 + a) * P0); ddst.push_back(s.d); p.h0[a] = s.d; }
-    }
-    for (int a = 0; a < p.n1; ++a) {
-        if (hoist1) { if (!hoist1[a]) throw Error("mkhe: missing hoisted form"); p.h1[a] = hoist1[a]->d; }
-        else if (same) p.h1[a] = p.h0[a];
-        else { Swk& s = hoist_slot(1, a); dsrc.push_back(op1.d + (1 + a) * P1); ddst.push_back(s.d); p.h1[a] = s.d; }
-    }
-    if (!dsrc.empty()) decompose_batch(p.level, dsrc, ddst, true);
-    // D: tensor product in the NTT domain, back to coefficients -- started here on the side stream: it only
-    // needs the operands and the engine's own hoisted digits, runs beside the x / y accumulation and meets
-    // the main chain again at the first ModDown of mr_finish.
-    {
-        const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
-        const size_t PO = (size_t)L * N;
-        u64* nb_ = scratch(nttbuf_, nttbuf_words_, (size_t)(2 + n0 + n1) * PO);
-        (void)level;
-        fork_side(1);
-        s_ = overlap ? stream2 : stream;
-        {
-            // NTT(c0_0), NTT(c1_0) always; party components only when the caller supplied the hoisted forms
-            // (the engine's own hoisted digits already contain NTT(c_i) on their diagonal, alpha = 1)
-            NttBatch b{};
-            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_q_owned(b, L);
-            b.src_inner = b.dst_inner = N; b.dst_outer = (long)PO;
-            if (p.own0 && p.own1) {
-                b.nitems = 2; b.outers_per_item = 1; b.nouter = 2;
-                b.src_items[0] = op0.d; b.src_items[1] = op1.d;
-                b.dst_items[0] = nb_; b.dst_items[1] = nb_ + (size_t)(1 + n0) * PO;
-                ntt_fwd_launch(b, false);
-            } else {
-                b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.nouter = p.own0 ? 1 : 1 + n0;
-                ntt_fwd_launch(b, false);
-                b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.nouter = p.own1 ? 1 : 1 + n1;
-                ntt_fwd_launch(b, false);
-            }
-        }
-        // With at least one party in op0 every output slot receives an external product in steps E / F2.  The tensor term then
-        // stays in the NTT domain, times P, and joins the summed Q parts of that (merged) batch: ModDown's (x - lift) * P^-1
-        // returns it as itself, canonical like everything else -- no inverse NTT for step D.  MKHE_TENSOR_FOLD=0: A/B switch.
-        static const int fold_env = MKHE_AB_INT("MKHE_TENSOR_FOLD", 1);
-        const bool fold = fold_env && n0 >= 1 && !masked_ && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
-        u64* tout = out.d;
-        if (fold) { tout = scratch(tens_, tens_words_, (size_t)(1 + out.n) * PO); p.tens = tout; }
-        TensorArgs ta{};
-        ta.a0 = nb_; ta.b0 = nb_ + (size_t)(1 + n0) * PO; ta.out = tout; ta.mods = d_mods;
-        if (fold) ta.scale = d_pmodq;
-        ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
-        if (masked_) { ta.limbs = d_ownq; ta.nlimbs = nq_owned(level); }
-        const long diag = (long)(mtot + 1) * N;
-        for (int a = 0; a < n0; ++a) {
-            const int o = 1 + p.slot0[a];
-            if (p.own0) { ta.a[o] = p.h0[a]; ta.a_ls[o] = diag; } else { ta.a[o] = nb_ + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
-        }
-        for (int a = 0; a < n1; ++a) {
-            const int o = 1 + p.slot1[a];
-            if (p.own1) { ta.b[o] = p.h1[a]; ta.b_ls[o] = diag; } else { ta.b[o] = nb_ + (size_t)(2 + n0 + a) * PO; ta.b_ls[o] = N; }
-        }
-        { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, s_); }
-        if (fold) { /* no inverse NTT: see above */ }
-        else if (!masked_) ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
-        else {
-            NttBatch ib{};
-            ib.src = out.d; ib.dst = out.d; ib.mods = d_mods; ib.psi = d_psiinv; ib.aux = d_inv_aux; slots_q_owned(ib, L);
-            ib.src_outer = ib.dst_outer = (long)PO; ib.src_inner = ib.dst_inner = N; ib.nouter = 1 + out.n;
-            if (ib.nslots > 0) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * ib.nouter * ib.nslots); ntt_inv_launch(ib); }
-        }
-        side_done(1);
-        s_ = stream;
-    }
-    p.valid = true; p.head_done = false;
-}
-
-// -- steps B, C: x = [MForm] sum_i d_i (.) h(c0_i),  y = [MForm] sum_j b_j (.) h(c1_j)   (keyswitch_hoisted.go:79-117)
-// mform = false leaves the canonical partial sums for a cross-device reduction (party sharding).
-void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x, bool fuse_x, bool fuse_y) {
-    MrPlan& p = plan_;
-    if (!p.valid) throw Error("mkhe: mr_xy without mr_prepare");
-    const int nb = beta(p.level), nslots = nslots_qp(p.level);
-    p.xkeys.clear(); p.xfused = nullptr;
-    if (fuse_x) {
-        if (!mform) throw Error("mkhe: internal: the fused x is produced in Montgomery form");
-        for (int a = 0; a < p.n0; ++a) {
-            if (!rlk_d0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-            p.xkeys.push_back(rlk_d0[a]->d);
-        }
-        p.xfused = x;
-    }
-    p.ykeys.clear();
-    if (fuse_y) {
-        if (!fuse_x || p.n1 < 1 || p.n0 > 8 || (p.n0 > 4 ? p.n1 != p.n0 : p.n1 > 4)) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and one to four parties per operand (or five to eight in both)");
-        for (int a = 0; a < p.n1; ++a) {
-            if (!rlk_b1[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-            p.ykeys.push_back(rlk_b1[a]->d);
-        }
-    }
-    // y first: it feeds step F, the long chain (F1 -> Decompose -> F2); x only feeds step E
-    for (int side = fuse_y ? 0 : 1; side >= (fuse_x ? 1 : 0); --side) {
-        const int n = side ? p.n1 : p.n0;
-        if (n > MAX_TERMS) throw Error("mkhe: too many parties");
-        InnerProductArgs ip{};
-        for (int a = 0; a < n; ++a) {
-            const Swk* key = side ? rlk_b1[a] : rlk_d0[a];
-            if (!key) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-            ip.a[a] = key->d; ip.b[a] = side ? p.h1[a] : p.h0[a];
-        }
-        ip.out = side ? y : x; ip.mods = d_mods; ip.map = map_qp(p.level);
-        ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nb; ip.N = N; ip.mform_out = mform ? 1 : 0;
-        const bool on_side = side == 0 && defer_x && overlap;
-        if (on_side) { fork_side(2); s_ = stream2; }
-        { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nb * (2.0 * n + 1)); launch_inner_product(ip, s_); }
-        if (on_side) { side_done(2); s_ = stream; p.x_pending = true; }
-    }
-    MKHE_HIP(hipGetLastError());
-}
-
-// -- steps D, E, F (keyswitch_hoisted.go:119-178) with x, y in Montgomery form.
-// mr_finish = head (F1 and the Decompose of its results: needs y only) + tail (E and F2: needs x).  A party-sharded caller
-// runs the head while the all-reduce of x is still in flight (mkhe-kklss_amd/dist.py).
-void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out) {
-    MrPlan& p = plan_;
-    if (!p.valid) throw Error("mkhe: mr_finish without mr_prepare");
-    if (out.limbs != p.L || out.n != p.nout || op0.n != p.n0 || op1.n != p.n1) throw Error("mkhe: mr_finish arguments do not match mr_prepare");
-    const int level = p.level, L = p.L, n0 = p.n0;
-    const size_t PO = (size_t)L * N;
-    u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
-    std::vector<ExtItem> items;
-    // F1: t_i = <h(c0_i), y>_P -- the head of the long chain; E (needs x, which may still be accumulating on the side
-    // stream) joins the last batch below
-    for (int a = 0; a < n0; ++a) {
-        ExtItem it{p.h0[a], y, tbuf + (size_t)a * PO, false};
-        if (!p.xkeys.empty()) it.xkey = p.xkeys[a];
-        items.push_back(it);
-    }
-    if (!p.xkeys.empty()) ext_xout_ = p.xfused;          // x = sum_i d_i (.) h(c0_i) comes out of the same pass over h(c0_i)
-    if (!p.ykeys.empty()) {
-        ext_ykeys_ = p.ykeys; ext_yh_ = p.h1;            // ... and y is computed in it
-        // ... and step E: the thread holds x[d] and h(c1_j)[d], so <h(c1_j), x> costs it G more accumulators, and x is never stored nor the h(c1_j) read
-        // again by the tail batch -- whose c1 slots 2 n0 .. 2 n0 + n1 - 1 (the E items) are filled here: the scratch is sized for the tail now, so
-        // that it is the same allocation then (nothing else of a MulAndRelin touches it in between)
-        static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
-        if (fuse_e_env && 2 * n0 + p.n1 <= EXT_MAX_ITEMS) {
-            scratch(c1b_, c1b_words_, (size_t)(2 * n0 + p.n1) * mtot * N);
-            ext_e_slot_ = 2 * n0;
-        }
-    }
-    try { ext_batch(level, items); } catch (...) { ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1; throw; }
-    p.e_done = ext_e_slot_ >= 0;
-    ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1;
-    // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
-    {
-        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
-        for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
-        if (n0) decompose_batch(level, dsrc, ddst, true);
-    }
-    p.head_done = true;
-    MKHE_HIP(hipGetLastError());
-}
-void Context::mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const Swk* const* rlk_v0, const Swk& crs_u, Ct& out) {
-    MrPlan& p = plan_;
-    if (!p.valid || !p.head_done) throw Error("mkhe: mr_finish_tail without mr_finish_head");
-    if (out.limbs != p.L || out.n != p.nout || op0.n != p.n0 || op1.n != p.n1) throw Error("mkhe: mr_finish arguments do not match mr_prepare");
-    const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
-    const size_t PO = (size_t)L * N;
-    // E: out_j += <h(c1_j), x>_P ; F2: out_0 += <h(t_i), v_i>_P, out_i += <h(t_i), u>_P   (one batch; items that share a
-    // destination are accumulated one after the other by the same thread of the ModDown kernel)
-    std::vector<ExtItem> items;
-    // (the F2 pairs first: grouped four at a time they are the longest blocks of the launch, and the sums are order independent)
-    for (int a = 0; a < n0; ++a) {
-        if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-        items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
-        items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
-    }
-    for (int a = 0; a < n1; ++a) { items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true}); items.back().pre = p.e_done; }
-    if (p.x_pending) { join_side(2); p.x_pending = false; }
-    if (p.tens) {
-        // the tensor term of every output slot rides on the first product that goes there (see mr_prepare)
-        std::vector<const u64*> seen;
-        for (auto& it : items) {
-            if (std::find(seen.begin(), seen.end(), it.dst) != seen.end()) continue;
-            seen.push_back(it.dst);
-            it.accumulate = false; it.qadd = p.tens + (it.dst - out.d);
-        }
-        if ((int)seen.size() != 1 + out.n) throw Error("mkhe: internal: an output slot without an external product");
-        join_side(1);                  // the tensor chain, before the inverse NTT that sums it in
-        ext_batch(level, items);
-    } else
-    ext_batch(level, items, 1);        // joins the tensor chain before the ModDown accumulates into out
-    p.valid = false; p.head_done = false;
-    MKHE_HIP(hipGetLastError());
-}
-void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
-                        const Swk& crs_u, Ct& out) {
-    mr_finish_head(op0, op1, y, out);
-    mr_finish_tail(op0, op1, x, rlk_v0, crs_u, out);
-}
-
-// ------------------------------------------------------------------ limb-sharded MulAndRelin (see engine.h)
-void Context::zero_unowned(u64* base, int npolys, long poly_stride, int first_mod, int nlimbs) {
-    for (int l = 0; l < nlimbs; ++l)
-        if (!own_[first_mod + l])
-            MKHE_HIP(hipMemset2DAsync(base + (size_t)l * N, (size_t)poly_stride * sizeof(u64), 0, (size_t)N * sizeof(u64), npolys, s_));
-}
-
-size_t Context::lsh_phase(int phase, const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_d0,
-                          const Swk* const* rlk_v0, const Swk* crs_u, Ct& out, u64* stage) {
-    if (!masked_) throw Error("mkhe: lsh_phase needs mkhe_ctx_set_owned first");
-    if (!stage) throw Error("mkhe: lsh_phase needs a staging buffer");
-    MrPlan& p = plan_;
-    const size_t item_words = (size_t)mtot * N, prow = (size_t)np * N * sizeof(u64);
-    // P limbs of the c1 pool <-> contiguous staging [item][np][N]; limbs this rank does not own travel as zeros
-    auto pack = [&](int n) -> size_t {
-        zero_unowned(c1b_ + (size_t)nq * N, n, (long)item_words, nq, np);
-        if (n) MKHE_HIP(hipMemcpy2DAsync(stage, prow, c1b_ + (size_t)nq * N, item_words * sizeof(u64), prow, n, hipMemcpyDeviceToDevice, s_));
-        return (size_t)n * np * N;
-    };
-    auto unpack = [&](int n) {
-        if (n) MKHE_HIP(hipMemcpy2DAsync(c1b_ + (size_t)nq * N, item_words * sizeof(u64), stage, prow, prow, n, hipMemcpyDeviceToDevice, s_));
-    };
-    if (phase == 1) {
-        // every rank computes its limbs of the tensor product (c0_0*c1_0 included: the limbs are disjoint), hoists all
-        // parties under its moduli and accumulates x, y there: complete sums, no exchange
-        mr_prepare(op0, op1, nullptr, nullptr, true, out);
-        mr_xy(rlk_b1, rlk_d0, x_, y_, true, false);
-        const size_t PO = (size_t)p.L * N;
-        u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)std::max(p.n0, 1) * PO);
-        lsh_items_.clear();
-        for (int a = 0; a < p.n0; ++a) lsh_items_.push_back(ExtItem{p.h0[a], y_, tbuf + (size_t)a * PO, false});
-        scratch(c1b_, c1b_words_, (size_t)std::max<size_t>(lsh_items_.size(), 1) * item_words);
-        ext_batch(p.level, lsh_items_, -1, 1);
-        return pack((int)lsh_items_.size());
-    }
-    if (!p.valid) throw Error("mkhe: lsh_phase out of order");
-    const int level = p.level, L = p.L;
-    const size_t PO = (size_t)L * N;
-    if (phase == 2) {
-        unpack((int)lsh_items_.size());
-        ext_batch(level, lsh_items_, -1, 2);                       // t_i, owned limbs
-        zero_unowned(tbuf_, p.n0, (long)PO, 0, L);
-        if (p.n0) MKHE_HIP(hipMemcpyAsync(stage, tbuf_, (size_t)p.n0 * PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
-        return (size_t)p.n0 * PO;
-    }
-    if (phase == 3) {
-        if (!crs_u || !rlk_v0) throw Error("mkhe: lsh_phase 3 needs the v keys and the CRS");
-        if (p.n0) MKHE_HIP(hipMemcpyAsync(tbuf_, stage, (size_t)p.n0 * PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
-        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
-        for (int a = 0; a < p.n0; ++a) { dsrc.push_back(tbuf_ + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
-        if (p.n0) decompose_batch(level, dsrc, ddst, true);
-        lsh_items_.clear();
-        for (int a = 0; a < p.n1; ++a) lsh_items_.push_back(ExtItem{p.h1[a], x_, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
-        for (int a = 0; a < p.n0; ++a) {
-            if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-            lsh_items_.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
-            lsh_items_.push_back(ExtItem{hoist_slot(2, a).d, crs_u->d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
-        }
-        scratch(c1b_, c1b_words_, (size_t)std::max<size_t>(lsh_items_.size(), 1) * item_words);
-        ext_batch(level, lsh_items_, -1, 1);
-        return pack((int)lsh_items_.size());
-    }
-    if (phase == 4) {
-        unpack((int)lsh_items_.size());
-        ext_batch(level, lsh_items_, 1, 2);                        // joins the tensor chain, then accumulates into out
-        zero_unowned(out.d, 1 + out.n, (long)PO, 0, L);
-        p.valid = false;
-        MKHE_HIP(hipGetLastError());
-        return (size_t)(1 + out.n) * PO;
-    }
-    throw Error("mkhe: lsh_phase 1..4");
-}
-
-// reduction epilogue of the party-sharded path: words hold sums of canonical residues of several ranks
-// (each < q, total < 2^63); bring them back to [0,q) and optionally to Montgomery form (MFormLvl).
-void Context::fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform) {
-    check_level(level);
-    FoldArgs fa{};
-    fa.buf = buf; fa.mods = d_mods; fa.map = qp_shaped ? map_qp(level) : d_map_id;
-    fa.nslots = qp_shaped ? nslots_qp(level) : level + 1; fa.npolys = npolys; fa.poly_stride = poly_stride; fa.N = N; fa.mform = mform ? 1 : 0;
-    { ProfScope ps(this, PROF_OTHER, 16.0 * N * fa.nslots * npolys); launch_fold(fa, s_); }
-    MKHE_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------ Rotate[Hoisted] / Conjugate
-// keyswitch.go:234-298, keyswitch_hoisted.go:183-247
-void Context::rotate(u64 galEl, const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, Ct& out) {
-    const int L = out.limbs, n = in.n;
-    if (n > 0 && 2 * n <= EXT_MAX_ITEMS && in.d != out.d) {
-        // the signed permutation and the + c_0 ride on the ModDown of the external products: no staging copy of the
-        // ciphertext, no separate permutation kernel
-        rotate_core(in, hoist, rk, crs, true, out, galEl);
-        return;
-    }
-    Ct tmp; tmp.n = n; tmp.limbs = L; tmp.ids = in.ids;
-    tmp.d = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * L * N);
-    rotate_partial(in, hoist, rk, crs, true, tmp);
-    automorphism(galEl, tmp, out);
-}
-
-// Rotate without the final permutation: out_0 = [c_0 +] sum_i <h(c_i), rk_i>_P, out_i = <h(c_i), crs>_P
-// (keyswitch.go:251-265).  with_c0 = false leaves c_0 out (party-sharded evaluation: one rank adds it).
-void Context::rotate_partial(const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, bool with_c0, Ct& out) {
-    rotate_core(in, hoist, rk, crs, with_c0, out, 0);
-}
-void Context::rotate_core(const Ct& in, const Swk* const* hoist, const Swk* const* rk, const Swk& crs, bool with_c0, Ct& out, u64 galEl) {
-    const int level = out.limbs - 1, L = level + 1, n = in.n;
-    check_level(level);
-    if (in.limbs < L) throw Error("Cannot Rotate: ctIn and ctOut have different levels");
-    if (out.n != n || out.ids != in.ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
-    const size_t PI = (size_t)in.limbs * N, PO = (size_t)L * N;
-    u64* tmp = out.d;
-    const bool fused = galEl != 0;          // c_0 enters as the addend of the first accumulating item, stores are permuted
-    if (fused && !with_c0) throw Error("mkhe: a fused rotation includes c_0");
-    if (!fused) {
-        if (with_c0) MKHE_HIP(hipMemcpyAsync(tmp, in.d, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
-        else MKHE_HIP(hipMemsetAsync(tmp, 0, PO * sizeof(u64), s_));
-    }
-    std::vector<const u64*> h(n);
-    {
-        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
-        for (int a = 0; a < n; ++a) {
-            if (!rk[a]) throw Error("cannot GetRotationKeys: there is no rotation key with given id");
-            if (hoist) { if (!hoist[a]) throw Error("mkhe: missing hoisted form"); h[a] = hoist[a]->d; }
-            else { Swk& s = hoist_slot(0, a); dsrc.push_back(in.d + (1 + a) * PI); ddst.push_back(s.d); h[a] = s.d; }
-        }
-        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst, true);
-    }
-    std::vector<ExtItem> items;
-    for (int a = 0; a < n; ++a) {
-        items.push_back(ExtItem{h[a], rk[a]->d, tmp, true});
-        if (fused && a == 0) items.back().addend = in.d;
-        items.push_back(ExtItem{h[a], crs.d, tmp + (size_t)(1 + a) * PO, false});
-    }
-    ext_batch(level, items, -1, 0, galEl);
-    MKHE_HIP(hipGetLastError());
-}
-
-// signed coefficient permutation X -> X^galEl of every component (keyswitch.go:267-296)
-void Context::automorphism(u64 galEl, const Ct& in, Ct& out) {
-    const int L = out.limbs;
-    if (in.limbs != L || in.n != out.n) throw Error("mkhe: automorphism operands differ in shape");
-    if (in.d == out.d) throw Error("mkhe: automorphism cannot run in place");
-    launch_automorphism(out.d, in.d, d_mods, L, logN, galEl, 1 + in.n, s_);
-    MKHE_HIP(hipGetLastError());
-}
-
-// keyswitch.go:302-332
-void Context::conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk& crs, Ct& out) {
-    const int level = out.limbs - 1, L = level + 1, n = in.n;
-    check_level(level);
-    if (in.limbs < L) throw Error("Cannot Conjugate: ctIn and ctOut have different levels");
-    if (out.n != n || out.ids != in.ids) throw Error("mkhe: ctOut must carry the ids of ctIn");
-    const size_t PI = (size_t)in.limbs * N, PO = (size_t)L * N;
-    u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + n) * PO);
-    if (in.limbs == L) launch_automorphism(tmp, in.d, d_mods, L, logN, galEl, 1 + n, s_);
-    else for (int a = 0; a <= n; ++a) launch_automorphism(tmp + a * PO, in.d + a * PI, d_mods, L, logN, galEl, 1, s_);
-    if (n == 0) { MKHE_HIP(hipMemcpyAsync(out.d, tmp, PO * sizeof(u64), hipMemcpyDeviceToDevice, s_)); return; }
-    // all parties in one Decompose launch and one batch of external products, like Rotate; sigma(c_0) enters as the addend
-    // of the first accumulating item (the permuted polynomials keep q for a sign-flipped 0, exactly what the reference
-    // decomposes)
-    std::vector<const u64*> dsrc; std::vector<u64*> ddst;
-    for (int a = 0; a < n; ++a) {
-        if (!ck[a]) throw Error("cannot GetConjugationKey: there is no conjugation key with given id");
-        dsrc.push_back(tmp + (size_t)(1 + a) * PO); ddst.push_back(hoist_slot(0, a).d);
-    }
-    decompose_batch(level, dsrc, ddst, true);
-    std::vector<ExtItem> items;
-    for (int a = 0; a < n; ++a) {
-        items.push_back(ExtItem{ddst[a], ck[a]->d, out.d, true});
-        if (a == 0) items.back().addend = tmp;
-        items.push_back(ExtItem{ddst[a], crs.d, out.d + (size_t)(1 + a) * PO, false});
-    }
-    ext_batch(level, items);
-    MKHE_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------ Rescale body
-// mkckks/evaluator.go:385-391 -> lattigo DivRoundByLastModulusManyLvl.  The reference's in-place
-// "+ (q_L-1)/2" on the dropped limb of ctIn is NOT reproduced (ctIn stays untouched).
-void Context::rescale(const Ct& in, int nb, Ct& out) {
-    const int level = in.limbs - 1;
-    check_level(level);
-    if (nb < 0 || nb > level) throw Error("cannot Rescale: input Ciphertext already at level 0");
-    if (out.limbs != in.limbs - nb || out.n != in.n) throw Error("mkhe: ctOut shape does not match the rescaled ciphertext");
-    const int np_ = 1 + in.n;
-    const size_t PI = (size_t)in.limbs * N, PO = (size_t)out.limbs * N;
-    if (nb == 0) { if (out.d != in.d) MKHE_HIP(hipMemcpyAsync(out.d, in.d, np_ * PI * sizeof(u64), hipMemcpyDeviceToDevice, s_)); return; }
-    // source and destination polynomials have different strides (in.limbs vs out.limbs): in place the threads of one polynomial
-    // would overwrite limbs of the next one that other threads still read
-    if (out.d == in.d) throw Error("cannot Rescale in place: ctOut must not alias ctIn when levels are dropped");
-    if (nb == 1) {
-        launch_div_round_last(out.d, in.d, d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, np_, (long)PI, (long)PO, s_);
-    } else {
-        u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)np_ * PI);
-        launch_div_round_last(tmp, in.d, d_mods, d_rescale + (size_t)(level - 1) * nq, level, N, np_, (long)PI, (long)PI, s_);
-        for (int k = 1; k < nb; ++k) {
-            const int lv = level - k;
-            const bool last = (k == nb - 1);
-            launch_div_round_last(last ? out.d : tmp, tmp, d_mods, d_rescale + (size_t)(lv - 1) * nq, lv, N, np_,
-                                  (long)PI, last ? (long)PO : (long)PI, s_);
-        }
-    }
-    MKHE_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------ elementwise evaluator ops
-// evaluateInPlace of mkckks/evaluator.go:41-70 and mkbfv/evaluator.go:27-62: c_0 and the components both
-// operands have are combined, the others are copied (Sub: negated when only op1 has them, :59-66).
-void Context::ct_binary(int op, const Ct& a, const Ct& b, Ct& out) {
-    const int L = out.limbs;
-    if (a.limbs < L || b.limbs < L) throw Error("mkhe: operand level below ctOut level");
-    const size_t PA = (size_t)a.limbs * N, PB = (size_t)b.limbs * N, PO = (size_t)L * N;
-    auto find = [](const Ct& c, int id) { for (int i = 0; i < c.n; ++i) if (c.ids[i] == id) return i; return -1; };
-    if (1 + out.n > CTBIN_MAX) throw Error("mkhe: too many parties in one ciphertext");
-    CtBinArgs ba{};
-    ba.mods = d_mods; ba.L = L; ba.N = N; ba.ncomp = 1 + out.n;
-    double bytes = 0;
-    for (int o = -1; o < out.n; ++o) {
-        const int ia = o < 0 ? 0 : 1 + find(a, out.ids[o]), ib = o < 0 ? 0 : 1 + find(b, out.ids[o]);
-        const bool ha = o < 0 || ia > 0, hb = o < 0 || ib > 0;
-        if (!ha && !hb) throw Error("mkhe: ctOut has an id that neither operand has");
-        const int c = 1 + o;
-        ba.dst[c] = out.d + (size_t)c * PO;
-        ba.a[c] = ha ? a.d + ia * PA : nullptr;
-        ba.b[c] = hb ? b.d + ib * PB : nullptr;
-        ba.mode[c] = (ha && hb) ? (op == 0 ? 0 : 1) : ha ? 2 : (op == 0 ? 3 : 4);
-        bytes += 8.0 * N * L * ((ha && hb) ? 3 : 2);
-    }
-    { ProfScope ps(this, PROF_OTHER, bytes); launch_ct_binary(ba, s_); }
-    MKHE_HIP(hipGetLastError());
-}
-
-void Context::ct_mul_const(const Ct& in, const u64* c_first, const u64* c_second, Ct& out) {
-    const int L = std::min(in.limbs, out.limbs);                   // level := min(ct0.Level(), ctOut.Level()), :119
-    if (in.n != out.n || in.ids != out.ids) throw Error("mkhe: ctOut must carry the ids of ct0");
-    if (L > 48) throw Error("mkhe: too many limbs");
-    MulConstArgs a{};
-    a.src = in.d; a.dst = out.d; a.mods = d_mods; a.src_poly = (long)in.limbs * N; a.dst_poly = (long)out.limbs * N;
-    a.L = L; a.N = N; a.npolys = 1 + in.n;
-    for (int l = 0; l < L; ++l) {
-        if (c_first[l] >= moduli[l] || c_second[l] >= moduli[l]) throw Error("mkhe: MultByConst constants must be reduced");
-        a.c[0][l] = c_first[l]; a.c[1][l] = c_second[l];
-    }
-    { ProfScope ps(this, PROF_OTHER, 16.0 * N * L * (1 + in.n)); launch_mul_const_halves(a, s_); }
-    MKHE_HIP(hipGetLastError());
-}
-
-void Context::ct_mul_ptxt(const Ct& in, const u64* dev_pt, Ct& out) {
-    const int L = in.limbs, np_ = 1 + in.n;
-    if (out.limbs != L || out.n != in.n || out.ids != in.ids) throw Error("mkhe: ctOut shape does not match ct");
-    const size_t PO = (size_t)L * N;
-    u64* tmp = scratch(ctbuf_, ctbuf_words_, (size_t)(1 + np_) * PO);
-    ntt(dev_pt, tmp, 1, L, 0, false, false);
-    ntt(in.d, tmp + PO, np_, L, 0, false, false);
-    { ProfScope ps(this, PROF_OTHER, 8.0 * N * L * (2.0 * np_ + 1)); launch_mul_by_poly(tmp + PO, tmp + PO, tmp, d_mods, L, N, np_, s_); }
-    ntt(tmp + PO, out.d, np_, L, 0, true, false);
-    MKHE_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------ mkbfv
-// ring R = Q || QMul (mkbfv/params.go:36-38): limb j of a PolyR uses modulus j (j < nq) or nq+np+(j-nq)
-void Context::ntt_r(const u64* src, u64* dst, int count, bool inverse) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    NttBatch b{};
-    b.src = src; b.dst = dst; b.mods = d_mods; b.psi = inverse ? d_psiinv : d_psi; b.aux = d_inv_aux;
-    b.nslots = 2 * nq;
-    for (int j = 0; j < 2 * nq; ++j) { b.mod[j] = j < nq ? j : mtot + (j - nq); b.pos[j] = j; }
-    b.src_outer = b.dst_outer = 2L * nq * N; b.src_inner = b.dst_inner = N;
-    b.nouter = count;
-    if (inverse) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * count * 2 * nq); ntt_inv_launch(b); }
-    else {
-        // ring-R polynomials out of ModUpQtoR / Rescale are lazy multSum representatives (< 3q, mkbfv/basis_extension.go:54-62,91-96): the
-        // 59/60-bit reduction schedule of the H16 kernel must not assume inputs below 2^60 (NttBatch::src_lazy only selects that schedule here)
-        b.src_lazy = 1;
-        ntt_fwd_launch(b, false);
-    }
-    MKHE_HIP(hipGetLastError());
-}
-
-// conv.ModUpQtoR (mkbfv/basis_extension.go:49-64): Q part copied, QMul part = lazy ModUpQtoP
-void Context::bfv_modup_q_to_r(const u64* polyq, u64* polyr, int npolys) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    BasisConvArgs a{};
-    a.src = polyq; a.src_poly = (long)nq * N;
-    a.dst = polyr + (size_t)nq * N; a.dst_poly = 2L * nq * N;
-    a.copy_dst = polyr; a.copy_poly = 2L * nq * N;
-    a.mods_s = d_mods; a.mods_t = d_mods + mtot;
-    a.t = BasisConvTables{d_bq_qoverqiinvqi, d_bq_qoverqimodp, d_bq_vtimes};
-    a.ns = nq; a.nt = nq; a.N = N; a.npolys = npolys;
-    { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npolys * 3.0 * nq); launch_basis_conv(a, s_); }
-    MKHE_HIP(hipGetLastError());
-}
-
-// conv.Rescale (basis_extension.go:82-96): QMul part = ModDownQPtoP(x * QMul mod Q, 0), Q part = lazy ModUpPtoQ of it
-void Context::bfv_rescale(const u64* polyq, u64* polyr, int npolys) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    BasisConvArgs a{};
-    a.src = polyq; a.src_poly = (long)nq * N;
-    a.dst = polyr + (size_t)nq * N; a.dst_poly = 2L * nq * N;
-    a.mods_s = d_mods; a.mods_t = d_mods + mtot;
-    a.prescale = d_mform_qmul; a.downparam = d_down_q_in_m;
-    a.t = BasisConvTables{d_bq_qoverqiinvqi, d_bq_qoverqimodp, d_bq_vtimes};
-    a.ns = nq; a.nt = nq; a.N = N; a.npolys = npolys;
-    { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npolys * 2.0 * nq); launch_basis_conv(a, s_); }
-    BasisConvArgs c{};
-    c.src = polyr + (size_t)nq * N; c.src_poly = 2L * nq * N;
-    c.dst = polyr; c.dst_poly = 2L * nq * N;
-    c.mods_s = d_mods + mtot; c.mods_t = d_mods;
-    c.t = BasisConvTables{d_bm_qoverqiinvqi, d_bm_qoverqimodp, d_bm_vtimes};
-    c.ns = nq; c.nt = nq; c.N = N; c.npolys = npolys;
-    { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npolys * 2.0 * nq); launch_basis_conv(c, s_); }
-    MKHE_HIP(hipGetLastError());
-}
-
-// conv.Quantize (basis_extension.go:66-80) AFTER the MulScalar(t): InvNTT over R (in place), ModDownQPtoQ with QMul as "P".
-// The MulScalar itself is folded into the producer (tensor kernel) or done by the caller (bfv_quantize_full).
-static void quantize_tail_args(BasisConvArgs& a, const Context& c, u64* polyr, u64* polyq, int npolys) {
-    a.src = polyr + (size_t)c.nq * c.N; a.src_poly = 2L * c.nq * c.N;
-    a.xsub = polyr; a.xsub_poly = 2L * c.nq * c.N;
-    a.dst = polyq; a.dst_poly = (long)c.nq * c.N;
-    a.mods_s = c.d_mods + c.mtot; a.mods_t = c.d_mods;
-    a.downparam = c.d_down_m_in_q;
-    a.t = BasisConvTables{c.d_bm_qoverqiinvqi, c.d_bm_qoverqimodp, c.d_bm_vtimes};
-    a.ns = c.nq; a.nt = c.nq; a.N = c.N; a.npolys = npolys;
-}
-void Context::bfv_quantize(const u64* polyr_ntt, u64* polyq, int npolys) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    const size_t PR = 2 * (size_t)nq * N;
-    u64* tmp = scratch(rbuf_, rbuf_words_, (size_t)npolys * PR);
-    // scalar multiplication limb by limb: z = x * t  (MRed(x, MForm(t)))
-    { ProfScope ps(this, PROF_OTHER, 16.0 * N * npolys * 2 * nq); launch_mul_const(tmp, polyr_ntt, d_mods, d_map_r, d_t_mont, 2 * nq, N, npolys, (long)PR, s_); }
-    ntt_r(tmp, tmp, npolys, true);
-    BasisConvArgs a{};
-    quantize_tail_args(a, *this, tmp, polyq, npolys);
-    { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npolys * 3.0 * nq); launch_basis_conv(a, s_); }
-    MKHE_HIP(hipGetLastError());
-}
-
-// DecomposeBFV (mkbfv/keyswitch.go:67-90), alpha = 1: digit d = limb d of aR spread under Q and P and NTT'd
-// (DecomposeSingleNTT); Q digits -> ad1, QMul digits -> ad2.  The QMul limbs of ModUpQtoR outputs and the Q limbs
-// of Rescale outputs are lazy (< 3x their modulus): src_lazy.
-void Context::bfv_decompose_batch(const std::vector<const u64*>& srcr, const std::vector<u64*>& ad1, const std::vector<u64*>& ad2, bool internal) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    const int level = nq - 1;
-    for (int half = 0; half < 2; ++half) {
-        for (size_t base = 0; base < srcr.size(); base += NTT_MAX_ITEMS) {
-            const int n = (int)std::min<size_t>(NTT_MAX_ITEMS, srcr.size() - base);
-            NttBatch b{};
-            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_qp(b, level);
-            b.src_outer = N; b.src_inner = 0; b.src_mapped = 0;
-            b.dst_outer = (long)mtot * N; b.dst_inner = N; b.dst_mapped = 1;
-            b.reduce_in = 1; b.reduce_src_mod_is_outer = 2; b.src_lazy = 1; b.skip_norm = internal ? 1 : 0;
-            for (int d = 0; d < nq; ++d) b.outer_mod[d] = half ? mtot + d : d;
-            b.nitems = n; b.outers_per_item = nq;
-            for (int i = 0; i < n; ++i) {
-                b.src_items[i] = srcr[base + i] + (half ? (size_t)nq * N : 0);
-                b.dst_items[i] = half ? ad2[base + i] : ad1[base + i];
-            }
-            b.nouter = n * nq;
-            ntt_fwd_launch(b, true);
-        }
-    }
-    MKHE_HIP(hipGetLastError());
-}
-
-// ExternalProductBFV (mkbfv/keyswitch.go:83-113): DecomposeBFV into the engine's own pool (ks.swkPool1 / swkPool2 there), then the
-// same sum over digits, InvNTTLazy and ModDownQPtoQ as the hoisted form
-void Context::bfv_external_product(const u64* polyr, const u64* bg1, const u64* bg2, u64* c) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    u64* a1 = hoist_slot(3, 0).d; u64* a2 = hoist_slot(3, 1).d;
-    bfv_decompose_batch({polyr}, {a1}, {a2}, true);
-    bfv_external_product_hoisted(a1, a2, bg1, bg2, c);
-}
-
-// ExternalProductBFVHoisted (keyswitch_hoisted.go:6-34)
-void Context::bfv_external_product_hoisted(const u64* ah1, const u64* ah2, const u64* bg1, const u64* bg2, u64* c) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    std::vector<ExtItem> items;
-    ExtItem it{ah1, bg1, c, false}; it.ah2 = ah2; it.bg2 = bg2;
-    items.push_back(it);
-    ext_batch(nq - 1, items);
-}
-
-// Evaluator.MulRelinNew = mulRelinHoisted (mkbfv/evaluator.go:78-82,118-140) followed by
-// KeySwitcher.MulAndRelinBFVHoisted (keyswitch_hoisted.go:36-206), in two phases so that the parties can be sharded over GPUs
-// (mkhe_kklss_amd/dist.py ShardedBfvMulRelin):
-//   bfv_mr_partial: ModUpQtoR / Rescale, tensor over R + Quantize (out_0 only where with_c0), DecomposeBFV of the party
-//                   components, the partial sums x1, x2, y1, y2 (MForm'ed when mform, canonical partial sums otherwise);
-//   bfv_mr_finish:  steps E and F with the complete x, y.
-// Quantize rounds, so both tensor terms of an output slot (op0_0 * op1_j + op0_j * op1_0) have to be added before it: a rank
-// must own whole parties (both components of every id it holds).
-void Context::bfv_slots(const Ct& op0, const Ct& op1, const Ct& out, std::vector<int>& slot0, std::vector<int>& slot1) const {
-    const int n0 = op0.n, n1 = op1.n;
-    if (op0.limbs != nq || op1.limbs != nq || out.limbs != nq) throw Error("mkhe: BFV ciphertexts live at the maximum level");
-    if (n0 > 32 || n1 > 32 || out.n > 32) throw Error("mkhe: too many parties");
-    slot0.assign(n0, 0); slot1.assign(n1, 0);
-    auto find = [&](int id) { for (int o = 0; o < out.n; ++o) if (out.ids[o] == id) return o; return -1; };
-    std::vector<char> seen(out.n, 0);
-    for (int a = 0; a < n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); slot0[a] = o; seen[o] = 1; }
-    for (int a = 0; a < n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); slot1[a] = o; seen[o] = 1; }
-    for (int o = 0; o < out.n; ++o) if (!seen[o]) throw Error("mkhe: ctOut has an id that neither operand has");
-}
-
-void Context::bfv_mr_partial(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
-                             const Swk* const* rlk_d1, const Swk* const* rlk_d2, bool with_c0, bool mform, Ct& out,
-                             u64* x1, u64* x2, u64* y1, u64* y2, bool fuse_x, bool fuse_y) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    const int level = nq - 1, L = nq, n0 = op0.n, n1 = op1.n;
-    bfv_xk1_.clear(); bfv_xk2_.clear(); bfv_yk1_.clear(); bfv_yk2_.clear();
-    std::vector<int> slot0, slot1;
-    bfv_slots(op0, op1, out, slot0, slot1);
-    for (int a = 0; a < n0; ++a) if (!rlk_d1[a] || !rlk_d2[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-    for (int a = 0; a < n1; ++a) if (!rlk_b1[a] || !rlk_b2[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-
-    const size_t PR = 2 * (size_t)nq * N;
-    const int np0 = 1 + n0, np1 = 1 + n1, npo = 1 + out.n;
-    // rbuf: [ct0R | ct1R | NTT(ct0R) | NTT(ct1R) | tensor out]
-    u64* rb = scratch(rbuf_, rbuf_words_, (size_t)(2 * (np0 + np1) + npo) * PR);
-    u64 *r0 = rb, *r1 = rb + (size_t)np0 * PR, *f0 = r1 + (size_t)np1 * PR, *f1 = f0 + (size_t)np0 * PR, *tz = f1 + (size_t)np1 * PR;
-    bfv_modup_q_to_r(op0.d, r0, np0);
-    bfv_rescale(op1.d, r1, np1);
-
-    // tensor over R + Quantize on the side stream (needs only ct0R / ct1R)
-    fork_side(1);
-    s_ = overlap ? stream2 : stream;
-    {
-        ntt_r(r0, f0, np0 + np1, false);        // f0, f1 are contiguous like r0, r1
-        TensorArgs ta{};
-        ta.a0 = f0; ta.b0 = f1; ta.out = tz; ta.mods = d_mods; ta.map = d_map_r; ta.scale = d_t_mont;
-        ta.nout = out.n; ta.L = 2 * nq; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
-        for (int a = 0; a < n0; ++a) { ta.a[1 + slot0[a]] = f0 + (size_t)(1 + a) * PR; ta.a_ls[1 + slot0[a]] = N; }
-        for (int a = 0; a < n1; ++a) { ta.b[1 + slot1[a]] = f1 + (size_t)(1 + a) * PR; ta.b_ls[1 + slot1[a]] = N; }
-        { ProfScope ps(this, PROF_TENSOR, 8.0 * N * 2 * nq * (2.0 + n0 + n1 + npo)); launch_tensor(ta, s_); }
-        ntt_r(tz, tz, npo, true);
-        BasisConvArgs qa{};
-        quantize_tail_args(qa, *this, tz, out.d, npo);
-        { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npo * 3.0 * nq); launch_basis_conv(qa, s_); }
-    }
-    side_done(1);
-    s_ = stream;
-
-    // hoisted forms of the party components (DecomposeBFV of every id of both operands, evaluator.go:126-133)
-    std::vector<const u64*> h0a(n0), h0b(n0), h1a(n1), h1b(n1);
-    {
-        std::vector<const u64*> src; std::vector<u64*> d1, d2;
-        for (int a = 0; a < n0; ++a) {
-            Swk& s1 = hoist_slot(0, a); Swk& s2 = hoist_slot(3, a);
-            src.push_back(r0 + (size_t)(1 + a) * PR); d1.push_back(s1.d); d2.push_back(s2.d); h0a[a] = s1.d; h0b[a] = s2.d;
-        }
-        for (int a = 0; a < n1; ++a) {
-            Swk& s1 = hoist_slot(1, a); Swk& s2 = hoist_slot(4, a);
-            src.push_back(r1 + (size_t)(1 + a) * PR); d1.push_back(s1.d); d2.push_back(s2.d); h1a[a] = s1.d; h1b[a] = s2.d;
-        }
-        if (!src.empty()) bfv_decompose_batch(src, d1, d2, true);
-    }
-    // y1, y2 on the main stream (they feed step F, the long chain), x1, x2 on the side stream (step E joins the last
-    // batch)   (keyswitch_hoisted.go:76-126)
-    const int nslots = L + np;
-    // single-device evaluation with 1..4 parties in op0: x1, x2 come out of step F1 as by-products of the digits it holds anyway
-    // (Context::mul_and_relin does the same for mkckks) -- two inner-product launches and one pass over h1(c0_i), h2(c0_i) less
-    if (fuse_x) {
-        if (!mform) throw Error("mkhe: internal: the fused x is produced in Montgomery form");
-        for (int a = 0; a < n0; ++a) { bfv_xk1_.push_back(rlk_d1[a]->d); bfv_xk2_.push_back(rlk_d2[a]->d); }
-    }
-    // ... and y1, y2 (and step E) inside it as well, when op1 has as many parties (Context::mul_and_relin, round 4)
-    if (fuse_y) {
-        if (!fuse_x || n1 < 1 || n1 > 4 || n0 > 4) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and one to four parties per operand");
-        for (int a = 0; a < n1; ++a) { bfv_yk1_.push_back(rlk_b1[a]->d); bfv_yk2_.push_back(rlk_b2[a]->d); }
-    }
-    for (int which = fuse_y ? 1 : 3; which >= (fuse_x ? 2 : 0); --which) {
-        const int side = which >> 1, half = which & 1;
-        const int n = side ? n1 : n0;
-        InnerProductArgs ip{};
-        for (int a = 0; a < n; ++a) {
-            const Swk* key = side ? (half ? rlk_b2[a] : rlk_b1[a]) : (half ? rlk_d2[a] : rlk_d1[a]);
-            ip.a[a] = key->d;
-            ip.b[a] = side ? (half ? h1b[a] : h1a[a]) : (half ? h0b[a] : h0a[a]);
-        }
-        ip.out = side ? (half ? y2 : y1) : (half ? x2 : x1);
-        ip.mods = d_mods; ip.map = map_qp(level);
-        ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = beta_max; ip.N = N; ip.mform_out = mform ? 1 : 0;
-        const bool on_side = side == 0 && overlap;
-        if (which == 1 && on_side) fork_side(2);
-        if (on_side) s_ = stream2;
-        { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * beta_max * (2.0 * n + 1)); launch_inner_product(ip, s_); }
-        if (on_side) s_ = stream;
-        if (which == 0 && on_side) side_done(2);
-    }
-    // split-phase callers read x1, x2 between the phases (cross-device reduction): the side chain joins the main stream here
-    if (!mform) join_side(2);
-    bfv_plan_valid_ = true;
-    MKHE_HIP(hipGetLastError());
-}
-
-void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u64* x2, const u64* y1, const u64* y2,
-                            const Swk* const* rlk_v, const Swk& crs_u, Ct& out) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    if (!bfv_plan_valid_) throw Error("mkhe: bfv_mr_finish without bfv_mr_partial");
-    const int level = nq - 1, n0 = op0.n, n1 = op1.n;
-    std::vector<int> slot0, slot1;
-    bfv_slots(op0, op1, out, slot0, slot1);
-    for (int a = 0; a < n0; ++a) if (!rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-    const size_t PQ = (size_t)nq * N;
-    // F1: t_i = <h(c0_i), (y1,y2)>
-    u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PQ);
-    std::vector<ExtItem> items;
-    const bool fused = !bfv_xk1_.empty();
-    for (int a = 0; a < n0; ++a) {
-        ExtItem it{hoist_slot(0, a).d, y1, tbuf + (size_t)a * PQ, false}; it.ah2 = hoist_slot(3, a).d; it.bg2 = y2;
-        if (fused) { it.xkey = bfv_xk1_[a]; it.xkey2 = bfv_xk2_[a]; }
-        items.push_back(it);
-    }
-    if (fused) { ext_xout_ = const_cast<u64*>(x1); ext_xout2_ = const_cast<u64*>(x2); }
-    bool e_done = false;
-    if (fused && !bfv_yk1_.empty()) {
-        ext_ykeys_ = bfv_yk1_; ext_ykeys2_ = bfv_yk2_;
-        for (int a = 0; a < n1; ++a) { ext_yh_.push_back(hoist_slot(1, a).d); ext_yh2_.push_back(hoist_slot(4, a).d); }
-        static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
-        if (fuse_e_env && 2 * n0 + n1 <= EXT_MAX_ITEMS) {
-            scratch(c1b_, c1b_words_, (size_t)(2 * n0 + n1) * mtot * N);
-            ext_e_slot_ = 2 * n0;
-        }
-    }
-    auto clear_xy = [&] { ext_xout_ = ext_xout2_ = nullptr; ext_ykeys_.clear(); ext_ykeys2_.clear(); ext_yh_.clear(); ext_yh2_.clear(); ext_e_slot_ = -1; };
-    try { ext_batch(level, items); } catch (...) { clear_xy(); throw; }
-    e_done = ext_e_slot_ >= 0;
-    clear_xy();
-    bfv_xk1_.clear(); bfv_xk2_.clear(); bfv_yk1_.clear(); bfv_yk2_.clear();
-    // F2: ks.Decompose(t_i) ; out_0 += <h(t_i), v_i> ; out_i += <h(t_i), u>
-    {
-        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
-        for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PQ); ddst.push_back(hoist_slot(2, a).d); }
-        if (n0) decompose_batch(level, dsrc, ddst, true);
-    }
-    // E: out_j += <h(c1_j), (x1,x2)> together with F2
-    items.clear();
-    // (the F2 pairs first, as in Context::mr_finish_tail: out_0 is the longest ModDown group)
-    for (int a = 0; a < n0; ++a) {
-        items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v[a]->d, out.d, true});
-        items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true});
-    }
-    for (int a = 0; a < n1; ++a) {
-        ExtItem it{hoist_slot(1, a).d, x1, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = hoist_slot(4, a).d; it.bg2 = x2; it.pre = e_done; items.push_back(it);
-    }
-    join_side(2);
-    ext_batch(level, items, 1);        // joins the tensor / Quantize chain before the ModDown accumulates into out
-    bfv_plan_valid_ = false;
-    MKHE_HIP(hipGetLastError());
-}
-
-void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
-                            const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
-                            const Swk& crs_u, Ct& out) {
-    for (int a = 0; a < op0.n; ++a) if (!rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
-    const bool fuse = fuse_env && op0.n >= 1 && op0.n <= 4 && !masked_;
-    static const int fuse_y_env = MKHE_AB_INT("MKHE_FUSE_Y", 1);
-    const bool fuse_y = fuse && fuse_y_env && op1.n >= 1 && op1.n <= 4;
-    bfv_mr_partial(op0, op1, rlk_b1, rlk_b2, rlk_d1, rlk_d2, true, true, out, x_, x2_, y_, y2_, fuse, fuse_y);
-    bfv_mr_finish(op0, op1, x_, x2_, y_, y2_, rlk_v, crs_u, out);
-}
-
-// Evaluator.mulRelin (mkbfv/evaluator.go:95-113) -> KeySwitcher.MulAndRelinBFV (mkbfv/keyswitch.go:115-251): the NON-hoisted twin, restated
-// in the reference's own order with its pool discipline -- ONE pair of digit vectors (ks.swkPool1 / swkPool2) that every DecomposeBFV
-// overwrites, so every party component is decomposed twice (once for its term of x or y, once inside ExternalProductBFV) and the digit
-// scratch is 2 vectors instead of 4k; x1, x2, y1, y2 grow party by party through MulCoeffsMontgomeryAndAdd (InnerProductArgs::addend) and
-// are MForm'ed by the call of the last party; every ExternalProductBFV / ExternalProduct is its own Decompose + inner product + InvNTTLazy +
-// ModDown + AddLvl (no batching over parties, no merged ModDown, no x by-product).  Same integers as bfv_mul_relin (the products are exact
-// residues and every sum is canonical), checked bit for bit on the device in tests/test_gpu_bfv.py.
-void Context::bfv_mul_relin_unhoisted(const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_b2,
-                                      const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
-                                      const Swk& crs_u, Ct& out) {
-    if (!is_bfv()) throw Error("mkhe: not a BFV context");
-    const int level = nq - 1, L = nq, n0 = op0.n, n1 = op1.n;
-    std::vector<int> slot0, slot1;
-    bfv_slots(op0, op1, out, slot0, slot1);
-    for (int a = 0; a < n0; ++a) if (!rlk_d1[a] || !rlk_d2[a] || !rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-    for (int a = 0; a < n1; ++a) if (!rlk_b1[a] || !rlk_b2[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-    const size_t PR = 2 * (size_t)nq * N, PQ = (size_t)nq * N;
-    const int np0 = 1 + n0, np1 = 1 + n1, npo = 1 + out.n;
-    u64* rb = scratch(rbuf_, rbuf_words_, (size_t)(2 * (np0 + np1) + npo) * PR);
-    u64 *r0 = rb, *r1 = rb + (size_t)np0 * PR, *f0 = r1 + (size_t)np1 * PR, *f1 = f0 + (size_t)np0 * PR, *tz = f1 + (size_t)np1 * PR;
-    bfv_modup_q_to_r(op0.d, r0, np0);                  // evaluator.go:102-105
-    bfv_rescale(op1.d, r1, np1);                       // evaluator.go:107-110
-    u64* p1 = hoist_slot(3, 0).d; u64* p2 = hoist_slot(3, 1).d;        // ks.swkPool1, ks.swkPool2
-    const int nslots = L + np;
-    // x1, x2 (keyswitch.go:157-171), then y1, y2 (:173-187)
-    for (int side = 0; side < 2; ++side) {
-        const int n = side ? n1 : n0;
-        u64* s1 = side ? y_ : x_; u64* s2 = side ? y2_ : x2_;
-        if (n == 0) { MKHE_HIP(hipMemsetAsync(s1, 0, swk_words() * sizeof(u64), s_)); MKHE_HIP(hipMemsetAsync(s2, 0, swk_words() * sizeof(u64), s_)); }
-        for (int a = 0; a < n; ++a) {
-            bfv_decompose_batch({(side ? r1 : r0) + (size_t)(1 + a) * PR}, {p1}, {p2}, true);
-            for (int half = 0; half < 2; ++half) {
-                InnerProductArgs ip{};
-                ip.a[0] = (side ? (half ? rlk_b2[a] : rlk_b1[a]) : (half ? rlk_d2[a] : rlk_d1[a]))->d;
-                ip.b[0] = half ? p2 : p1;
-                ip.out = half ? s2 : s1;
-                ip.addend = a ? ip.out : nullptr;          // the pool vector was zeroed at :146-155
-                ip.mods = d_mods; ip.map = map_qp(level);
-                ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = 1; ip.nslots = nslots; ip.nouter = beta_max; ip.N = N;
-                ip.mform_out = a == n - 1 ? 1 : 0;         // MFormLvl after the last party (:168-171, :184-187)
-                { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * beta_max * (a ? 4.0 : 3.0)); launch_inner_product(ip, s_); }
-            }
-        }
-    }
-    // tensor over R + Quantize (:189-233), in the batched form of bfv_mr_partial (same kernels, same integers)
-    {
-        ntt_r(r0, f0, np0 + np1, false);
-        TensorArgs ta{};
-        ta.a0 = f0; ta.b0 = f1; ta.out = tz; ta.mods = d_mods; ta.map = d_map_r; ta.scale = d_t_mont;
-        ta.nout = out.n; ta.L = 2 * nq; ta.N = N; ta.with_c0 = 1;
-        for (int a = 0; a < n0; ++a) { ta.a[1 + slot0[a]] = f0 + (size_t)(1 + a) * PR; ta.a_ls[1 + slot0[a]] = N; }
-        for (int a = 0; a < n1; ++a) { ta.b[1 + slot1[a]] = f1 + (size_t)(1 + a) * PR; ta.b_ls[1 + slot1[a]] = N; }
-        { ProfScope ps(this, PROF_TENSOR, 8.0 * N * 2 * nq * (2.0 + n0 + n1 + npo)); launch_tensor(ta, s_); }
-        ntt_r(tz, tz, npo, true);
-        BasisConvArgs qa{};
-        quantize_tail_args(qa, *this, tz, out.d, npo);
-        { ProfScope ps(this, PROF_BASISCONV, 8.0 * N * npo * 3.0 * nq); launch_basis_conv(qa, s_); }
-    }
-    // ctOut_j += ExternalProductBFV(op1_j, x1, x2)   (:235-239)
-    for (int a = 0; a < n1; ++a) {
-        bfv_decompose_batch({r1 + (size_t)(1 + a) * PR}, {p1}, {p2}, true);
-        ExtItem it{p1, x_, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = p2; it.bg2 = x2_;
-        ext_batch(level, {it});
-    }
-    // t = ExternalProductBFV(op0_i, y1, y2); ctOut_0 += ExternalProduct(t, v_i); ctOut_i += ExternalProduct(t, u)   (:241-250)
-    u64* t = scratch(tbuf_, tbuf_words_, PQ);
-    for (int a = 0; a < n0; ++a) {
-        bfv_decompose_batch({r0 + (size_t)(1 + a) * PR}, {p1}, {p2}, true);
-        ExtItem it{p1, y_, t, false}; it.ah2 = p2; it.bg2 = y2_;
-        ext_batch(level, {it});
-        external_product(level, false, t, rlk_v[a]->d, out.d, true);
-        external_product(level, false, t, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true);
-    }
     MKHE_HIP(hipGetLastError());
 }
 

@@ -1,0 +1,360 @@
+// engine_mulrelin.hip -- Context: MulAndRelin[Hoisted] (steps A-F), its split-phase and limb-sharded forms (engine.hip has the tables, pools and the external-product batch)
+#include "engine.h"
+#include <algorithm>
+#include <cstring>
+#include <cstdlib>
+
+namespace mkhe {
+
+// ------------------------------------------------------------------ MulAndRelin[Hoisted]
+// keyswitch_hoisted.go:44-179 (hoist == nullptr: keyswitch.go:122-230, same values).
+void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
+                            const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
+                            const Swk& crs_u, Ct& out) {
+    mr_prepare(op0, op1, hoist0, hoist1, true, out);
+    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
+    static const int wide_env = MKHE_AB_INT("MKHE_FUSE_X_WIDE", 1);      // A/B: the by-product for five to sixteen parties
+    const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= (wide_env ? 16 : 4) && !masked_;
+    // y inside the F1 kernel as well (round 4): the thread that forms <h(c0_i), y> at a coefficient needs y there and nowhere else, so that y is
+    // neither a launch nor 2 x 59 MB of traffic -- when op1 has as many parties as op0 (at most four: the group form of the kernel)
+    static const int fuse_y_env = MKHE_AB_INT("MKHE_FUSE_Y", 1);
+    const bool fuse_y = fuse && fuse_y_env && plan_.n1 >= 1 && (plan_.n0 <= 4 ? plan_.n1 <= 4 : (plan_.n0 <= 8 && plan_.n1 == plan_.n0));      // (one to four parties per operand: ext_inner_xy_kernel<G0, G1>; five to eight in both: ext_inner_xy_wide_kernel)
+    mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse, fuse_y);
+    mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
+}
+
+// mkckks.Evaluator.mulRelinHoisted (evaluator.go:558-581) = MulAndRelinHoisted + one Rescale, as ONE engine call: the DivRoundByLastModulus
+// is applied by the merged ModDown of the last batch as it stores (ModDownMergedArgs::rescale_row), so the level-L product is never written
+// and the rescale is neither a launch nor a pass of its own.  That needs every output slot to be written exactly once by that launch (up to
+// four products per destination: at most four parties per operand, single device, tensor term folded in); otherwise the product goes to a
+// pooled temporary and Context::rescale follows -- the same integers either way.
+void Context::mul_relin_rescale(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1,
+                                const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
+                                const Swk& crs_u, Ct& out) {
+    const int L = out.limbs + 1;                           // limbs of the product
+    if (out.limbs < 1 || L > nq) throw Error("cannot Rescale: input Ciphertext already at level 0");
+    Ct full; full.n = out.n; full.limbs = L; full.ids = out.ids;
+    const size_t words = (size_t)(1 + out.n) * L * N;
+    full.d = pool_alloc(words);
+    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_RESCALE", 1);
+    rs_maps_.clear();
+    if (fuse_env && !masked_) rs_maps_.push_back(RsMap{full.d, out.d, 1 + out.n, out.limbs, false});
+    try {
+        mul_and_relin(op0, op1, hoist0, hoist1, rlk_b1, rlk_d0, rlk_v0, crs_u, full);
+        const bool done = !rs_maps_.empty() && rs_maps_[0].done;
+        rs_maps_.clear();
+        if (!done) rescale(full, 1, out);
+    } catch (...) { rs_maps_.clear(); const HandleUsers none; pool_free(full.d, words, &none); throw; }
+    // the temporary never left this context (no handle, no other context can have work queued on it): an EMPTY user list, so that the pool does
+    // not order its next user behind every live context (users == nullptr means "unknown": the forks of the cnn evaluation would serialise)
+    const HandleUsers none;
+    pool_free(full.d, words, &none);
+}
+
+// -- step 0: validate, map ids, hoist the operands when the caller did not (MulRelinNew, evaluator.go:416-443)
+// and start step D (tensor).  with_c0 = false leaves c0_0*c1_0 out of out_0 (another rank of a party-sharded
+// evaluation adds it).
+void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0, const Swk* const* hoist1, bool with_c0, Ct& out) {
+    MrPlan& p = plan_;
+    p = MrPlan{};
+    p.level = out.limbs - 1; p.L = p.level + 1;
+    check_level(p.level);
+    if (op0.limbs < p.L || op1.limbs < p.L) throw Error("Cannot MulAndRelin: op0 and op1 have different levels");
+    p.n0 = op0.n; p.n1 = op1.n; p.nout = out.n;
+    if (p.n0 > 32 || p.n1 > 32 || out.n > 32) throw Error("mkhe: too many parties");
+    // out ids must be the union of the operand id sets (newCiphertextBinary, mkckks/evaluator.go:306-313)
+    p.slot0.assign(p.n0, 0); p.slot1.assign(p.n1, 0);
+    auto find = [&](int id) { for (int o = 0; o < out.n; ++o) if (out.ids[o] == id) return o; return -1; };
+    std::vector<char> seen(out.n, 0);
+    for (int a = 0; a < p.n0; ++a) { int o = find(op0.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op0"); p.slot0[a] = o; seen[o] = 1; }
+    for (int a = 0; a < p.n1; ++a) { int o = find(op1.ids[a]); if (o < 0) throw Error("mkhe: ctOut lacks an id of op1"); p.slot1[a] = o; seen[o] = 1; }
+    for (int o = 0; o < out.n; ++o) if (!seen[o]) throw Error("mkhe: ctOut has an id that neither operand has");
+    const size_t P0 = (size_t)op0.limbs * N, P1 = (size_t)op1.limbs * N;
+    p.h0.assign(p.n0, nullptr); p.h1.assign(p.n1, nullptr);
+    const bool same = (&op0 == &op1) && hoist0 == hoist1;
+    p.own0 = (hoist0 == nullptr) && alpha == 1; p.own1 = (hoist1 == nullptr) && alpha == 1;
+    if (masked_ && !(p.own0 && p.own1)) throw Error("mkhe: a limb-sharded evaluation hoists its operands itself");
+    std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+    for (int a = 0; a < p.n0; ++a) {
+        if (hoist0) { if (!hoist0[a]) throw Error("mkhe: missing hoisted form"); p.h0[a] = hoist0[a]->d; }
+        else { Swk& s = hoist_slot(0, a); dsrc.push_back(op0.d + (1 + a) * P0); ddst.push_back(s.d); p.h0[a] = s.d; }
+    }
+    for (int a = 0; a < p.n1; ++a) {
+        if (hoist1) { if (!hoist1[a]) throw Error("mkhe: missing hoisted form"); p.h1[a] = hoist1[a]->d; }
+        else if (same) p.h1[a] = p.h0[a];
+        else { Swk& s = hoist_slot(1, a); dsrc.push_back(op1.d + (1 + a) * P1); ddst.push_back(s.d); p.h1[a] = s.d; }
+    }
+    if (!dsrc.empty()) decompose_batch(p.level, dsrc, ddst, true);
+    // D: tensor product in the NTT domain, back to coefficients -- started here on the side stream: it only
+    // needs the operands and the engine's own hoisted digits, runs beside the x / y accumulation and meets
+    // the main chain again at the first ModDown of mr_finish.
+    {
+        const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
+        const size_t PO = (size_t)L * N;
+        u64* nb_ = scratch(nttbuf_, nttbuf_words_, (size_t)(2 + n0 + n1) * PO);
+        (void)level;
+        fork_side(1);
+        s_ = overlap ? stream2 : stream;
+        {
+            // NTT(c0_0), NTT(c1_0) always; party components only when the caller supplied the hoisted forms
+            // (the engine's own hoisted digits already contain NTT(c_i) on their diagonal, alpha = 1)
+            NttBatch b{};
+            b.mods = d_mods; b.psi = d_psi; b.aux = d_inv_aux; slots_q_owned(b, L);
+            b.src_inner = b.dst_inner = N; b.dst_outer = (long)PO;
+            if (p.own0 && p.own1) {
+                b.nitems = 2; b.outers_per_item = 1; b.nouter = 2;
+                b.src_items[0] = op0.d; b.src_items[1] = op1.d;
+                b.dst_items[0] = nb_; b.dst_items[1] = nb_ + (size_t)(1 + n0) * PO;
+                ntt_fwd_launch(b, false);
+            } else {
+                b.src = op0.d; b.src_outer = (long)P0; b.dst = nb_; b.nouter = p.own0 ? 1 : 1 + n0;
+                ntt_fwd_launch(b, false);
+                b.src = op1.d; b.src_outer = (long)P1; b.dst = nb_ + (size_t)(1 + n0) * PO; b.nouter = p.own1 ? 1 : 1 + n1;
+                ntt_fwd_launch(b, false);
+            }
+        }
+        // With at least one party in op0 every output slot receives an external product in steps E / F2.  The tensor term then
+        // stays in the NTT domain, times P, and joins the summed Q parts of that (merged) batch: ModDown's (x - lift) * P^-1
+        // returns it as itself, canonical like everything else -- no inverse NTT for step D.  MKHE_TENSOR_FOLD=0: A/B switch.
+        static const int fold_env = MKHE_AB_INT("MKHE_TENSOR_FOLD", 1);
+        const bool fold = fold_env && n0 >= 1 && !masked_ && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
+        u64* tout = out.d;
+        if (fold) { tout = scratch(tens_, tens_words_, (size_t)(1 + out.n) * PO); p.tens = tout; }
+        TensorArgs ta{};
+        ta.a0 = nb_; ta.b0 = nb_ + (size_t)(1 + n0) * PO; ta.out = tout; ta.mods = d_mods;
+        if (fold) ta.scale = d_pmodq;
+        ta.nout = out.n; ta.L = L; ta.N = N; ta.with_c0 = with_c0 ? 1 : 0;
+        if (masked_) { ta.limbs = d_ownq; ta.nlimbs = nq_owned(level); }
+        const long diag = (long)(mtot + 1) * N;
+        for (int a = 0; a < n0; ++a) {
+            const int o = 1 + p.slot0[a];
+            if (p.own0) { ta.a[o] = p.h0[a]; ta.a_ls[o] = diag; } else { ta.a[o] = nb_ + (size_t)(1 + a) * PO; ta.a_ls[o] = N; }
+        }
+        for (int a = 0; a < n1; ++a) {
+            const int o = 1 + p.slot1[a];
+            if (p.own1) { ta.b[o] = p.h1[a]; ta.b_ls[o] = diag; } else { ta.b[o] = nb_ + (size_t)(2 + n0 + a) * PO; ta.b_ls[o] = N; }
+        }
+        { ProfScope ps(this, PROF_TENSOR, 8.0 * N * L * (2.0 + n0 + n1 + 1 + out.n)); launch_tensor(ta, s_); }
+        if (fold) { /* no inverse NTT: see above */ }
+        else if (!masked_) ntt(out.d, out.d, 1 + out.n, L, 0, true, false);
+        else {
+            NttBatch ib{};
+            ib.src = out.d; ib.dst = out.d; ib.mods = d_mods; ib.psi = d_psiinv; ib.aux = d_inv_aux; slots_q_owned(ib, L);
+            ib.src_outer = ib.dst_outer = (long)PO; ib.src_inner = ib.dst_inner = N; ib.nouter = 1 + out.n;
+            if (ib.nslots > 0) { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * ib.nouter * ib.nslots); ntt_inv_launch(ib); }
+        }
+        side_done(1);
+        s_ = stream;
+    }
+    p.valid = true; p.head_done = false;
+}
+
+// -- steps B, C: x = [MForm] sum_i d_i (.) h(c0_i),  y = [MForm] sum_j b_j (.) h(c1_j)   (keyswitch_hoisted.go:79-117)
+// mform = false leaves the canonical partial sums for a cross-device reduction (party sharding).
+void Context::mr_xy(const Swk* const* rlk_b1, const Swk* const* rlk_d0, u64* x, u64* y, bool mform, bool defer_x, bool fuse_x, bool fuse_y) {
+    MrPlan& p = plan_;
+    if (!p.valid) throw Error("mkhe: mr_xy without mr_prepare");
+    const int nb = beta(p.level), nslots = nslots_qp(p.level);
+    p.xkeys.clear(); p.xfused = nullptr;
+    if (fuse_x) {
+        if (!mform) throw Error("mkhe: internal: the fused x is produced in Montgomery form");
+        for (int a = 0; a < p.n0; ++a) {
+            if (!rlk_d0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+            p.xkeys.push_back(rlk_d0[a]->d);
+        }
+        p.xfused = x;
+    }
+    p.ykeys.clear();
+    if (fuse_y) {
+        if (!fuse_x || p.n1 < 1 || p.n0 > 8 || (p.n0 > 4 ? p.n1 != p.n0 : p.n1 > 4)) throw Error("mkhe: internal: y inside the F1 kernel needs the x by-product and one to four parties per operand (or five to eight in both)");
+        for (int a = 0; a < p.n1; ++a) {
+            if (!rlk_b1[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+            p.ykeys.push_back(rlk_b1[a]->d);
+        }
+    }
+    // y first: it feeds step F, the long chain (F1 -> Decompose -> F2); x only feeds step E
+    for (int side = fuse_y ? 0 : 1; side >= (fuse_x ? 1 : 0); --side) {
+        const int n = side ? p.n1 : p.n0;
+        if (n > MAX_TERMS) throw Error("mkhe: too many parties");
+        InnerProductArgs ip{};
+        for (int a = 0; a < n; ++a) {
+            const Swk* key = side ? rlk_b1[a] : rlk_d0[a];
+            if (!key) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+            ip.a[a] = key->d; ip.b[a] = side ? p.h1[a] : p.h0[a];
+        }
+        ip.out = side ? y : x; ip.mods = d_mods; ip.map = map_qp(p.level);
+        ip.term_outer = ip.out_outer = (long)mtot * N; ip.nterms = n; ip.nslots = nslots; ip.nouter = nb; ip.N = N; ip.mform_out = mform ? 1 : 0;
+        const bool on_side = side == 0 && defer_x && overlap;
+        if (on_side) { fork_side(2); s_ = stream2; }
+        { ProfScope ps(this, PROF_INNER, 8.0 * N * nslots * nb * (2.0 * n + 1)); launch_inner_product(ip, s_); }
+        if (on_side) { side_done(2); s_ = stream; p.x_pending = true; }
+    }
+    MKHE_HIP(hipGetLastError());
+}
+
+// -- steps D, E, F (keyswitch_hoisted.go:119-178) with x, y in Montgomery form.
+// mr_finish = head (F1 and the Decompose of its results: needs y only) + tail (E and F2: needs x).  A party-sharded caller
+// runs the head while the all-reduce of x is still in flight (mkhe-kklss_amd/dist.py).
+void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out) {
+    MrPlan& p = plan_;
+    if (!p.valid) throw Error("mkhe: mr_finish without mr_prepare");
+    if (out.limbs != p.L || out.n != p.nout || op0.n != p.n0 || op1.n != p.n1) throw Error("mkhe: mr_finish arguments do not match mr_prepare");
+    const int level = p.level, L = p.L, n0 = p.n0;
+    const size_t PO = (size_t)L * N;
+    u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)n0 * PO);
+    std::vector<ExtItem> items;
+    // F1: t_i = <h(c0_i), y>_P -- the head of the long chain; E (needs x, which may still be accumulating on the side
+    // stream) joins the last batch below
+    for (int a = 0; a < n0; ++a) {
+        ExtItem it{p.h0[a], y, tbuf + (size_t)a * PO, false};
+        if (!p.xkeys.empty()) it.xkey = p.xkeys[a];
+        items.push_back(it);
+    }
+    if (!p.xkeys.empty()) ext_xout_ = p.xfused;          // x = sum_i d_i (.) h(c0_i) comes out of the same pass over h(c0_i)
+    if (!p.ykeys.empty()) {
+        ext_ykeys_ = p.ykeys; ext_yh_ = p.h1;            // ... and y is computed in it
+        // ... and step E: the thread holds x[d] and h(c1_j)[d], so <h(c1_j), x> costs it G more accumulators, and x is never stored nor the h(c1_j) read
+        // again by the tail batch -- whose c1 slots 2 n0 .. 2 n0 + n1 - 1 (the E items) are filled here: the scratch is sized for the tail now, so
+        // that it is the same allocation then (nothing else of a MulAndRelin touches it in between)
+        static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
+        if (fuse_e_env && 2 * n0 + p.n1 <= EXT_MAX_ITEMS) {
+            scratch(c1b_, c1b_words_, (size_t)(2 * n0 + p.n1) * mtot * N);
+            ext_e_slot_ = 2 * n0;
+        }
+    }
+    try { ext_batch(level, items); } catch (...) { ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1; throw; }
+    p.e_done = ext_e_slot_ >= 0;
+    ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1;
+    // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
+    {
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
+        if (n0) decompose_batch(level, dsrc, ddst, true);
+    }
+    p.head_done = true;
+    MKHE_HIP(hipGetLastError());
+}
+void Context::mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const Swk* const* rlk_v0, const Swk& crs_u, Ct& out) {
+    MrPlan& p = plan_;
+    if (!p.valid || !p.head_done) throw Error("mkhe: mr_finish_tail without mr_finish_head");
+    if (out.limbs != p.L || out.n != p.nout || op0.n != p.n0 || op1.n != p.n1) throw Error("mkhe: mr_finish arguments do not match mr_prepare");
+    const int level = p.level, L = p.L, n0 = p.n0, n1 = p.n1;
+    const size_t PO = (size_t)L * N;
+    // E: out_j += <h(c1_j), x>_P ; F2: out_0 += <h(t_i), v_i>_P, out_i += <h(t_i), u>_P   (one batch; items that share a
+    // destination are accumulated one after the other by the same thread of the ModDown kernel)
+    std::vector<ExtItem> items;
+    // (the F2 pairs first: grouped four at a time they are the longest blocks of the launch, and the sums are order independent)
+    for (int a = 0; a < n0; ++a) {
+        if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+        items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
+        items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
+    }
+    for (int a = 0; a < n1; ++a) { items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true}); items.back().pre = p.e_done; }
+    if (p.x_pending) { join_side(2); p.x_pending = false; }
+    if (p.tens) {
+        // the tensor term of every output slot rides on the first product that goes there (see mr_prepare)
+        std::vector<const u64*> seen;
+        for (auto& it : items) {
+            if (std::find(seen.begin(), seen.end(), it.dst) != seen.end()) continue;
+            seen.push_back(it.dst);
+            it.accumulate = false; it.qadd = p.tens + (it.dst - out.d);
+        }
+        if ((int)seen.size() != 1 + out.n) throw Error("mkhe: internal: an output slot without an external product");
+        join_side(1);                  // the tensor chain, before the inverse NTT that sums it in
+        ext_batch(level, items);
+    } else
+    ext_batch(level, items, 1);        // joins the tensor chain before the ModDown accumulates into out
+    p.valid = false; p.head_done = false;
+    MKHE_HIP(hipGetLastError());
+}
+void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
+                        const Swk& crs_u, Ct& out) {
+    mr_finish_head(op0, op1, y, out);
+    mr_finish_tail(op0, op1, x, rlk_v0, crs_u, out);
+}
+
+// ------------------------------------------------------------------ limb-sharded MulAndRelin (see engine.h)
+void Context::zero_unowned(u64* base, int npolys, long poly_stride, int first_mod, int nlimbs) {
+    for (int l = 0; l < nlimbs; ++l)
+        if (!own_[first_mod + l])
+            MKHE_HIP(hipMemset2DAsync(base + (size_t)l * N, (size_t)poly_stride * sizeof(u64), 0, (size_t)N * sizeof(u64), npolys, s_));
+}
+
+size_t Context::lsh_phase(int phase, const Ct& op0, const Ct& op1, const Swk* const* rlk_b1, const Swk* const* rlk_d0,
+                          const Swk* const* rlk_v0, const Swk* crs_u, Ct& out, u64* stage) {
+    if (!masked_) throw Error("mkhe: lsh_phase needs mkhe_ctx_set_owned first");
+    if (!stage) throw Error("mkhe: lsh_phase needs a staging buffer");
+    MrPlan& p = plan_;
+    const size_t item_words = (size_t)mtot * N, prow = (size_t)np * N * sizeof(u64);
+    // P limbs of the c1 pool <-> contiguous staging [item][np][N]; limbs this rank does not own travel as zeros
+    auto pack = [&](int n) -> size_t {
+        zero_unowned(c1b_ + (size_t)nq * N, n, (long)item_words, nq, np);
+        if (n) MKHE_HIP(hipMemcpy2DAsync(stage, prow, c1b_ + (size_t)nq * N, item_words * sizeof(u64), prow, n, hipMemcpyDeviceToDevice, s_));
+        return (size_t)n * np * N;
+    };
+    auto unpack = [&](int n) {
+        if (n) MKHE_HIP(hipMemcpy2DAsync(c1b_ + (size_t)nq * N, item_words * sizeof(u64), stage, prow, prow, n, hipMemcpyDeviceToDevice, s_));
+    };
+    if (phase == 1) {
+        // every rank computes its limbs of the tensor product (c0_0*c1_0 included: the limbs are disjoint), hoists all
+        // parties under its moduli and accumulates x, y there: complete sums, no exchange
+        mr_prepare(op0, op1, nullptr, nullptr, true, out);
+        mr_xy(rlk_b1, rlk_d0, x_, y_, true, false);
+        const size_t PO = (size_t)p.L * N;
+        u64* tbuf = scratch(tbuf_, tbuf_words_, (size_t)std::max(p.n0, 1) * PO);
+        lsh_items_.clear();
+        for (int a = 0; a < p.n0; ++a) lsh_items_.push_back(ExtItem{p.h0[a], y_, tbuf + (size_t)a * PO, false});
+        scratch(c1b_, c1b_words_, (size_t)std::max<size_t>(lsh_items_.size(), 1) * item_words);
+        ext_batch(p.level, lsh_items_, -1, 1);
+        return pack((int)lsh_items_.size());
+    }
+    if (!p.valid) throw Error("mkhe: lsh_phase out of order");
+    const int level = p.level, L = p.L;
+    const size_t PO = (size_t)L * N;
+    if (phase == 2) {
+        unpack((int)lsh_items_.size());
+        ext_batch(level, lsh_items_, -1, 2);                       // t_i, owned limbs
+        zero_unowned(tbuf_, p.n0, (long)PO, 0, L);
+        if (p.n0) MKHE_HIP(hipMemcpyAsync(stage, tbuf_, (size_t)p.n0 * PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+        return (size_t)p.n0 * PO;
+    }
+    if (phase == 3) {
+        if (!crs_u || !rlk_v0) throw Error("mkhe: lsh_phase 3 needs the v keys and the CRS");
+        if (p.n0) MKHE_HIP(hipMemcpyAsync(tbuf_, stage, (size_t)p.n0 * PO * sizeof(u64), hipMemcpyDeviceToDevice, s_));
+        std::vector<const u64*> dsrc; std::vector<u64*> ddst;
+        for (int a = 0; a < p.n0; ++a) { dsrc.push_back(tbuf_ + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
+        if (p.n0) decompose_batch(level, dsrc, ddst, true);
+        lsh_items_.clear();
+        for (int a = 0; a < p.n1; ++a) lsh_items_.push_back(ExtItem{p.h1[a], x_, out.d + (size_t)(1 + p.slot1[a]) * PO, true});
+        for (int a = 0; a < p.n0; ++a) {
+            if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+            lsh_items_.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
+            lsh_items_.push_back(ExtItem{hoist_slot(2, a).d, crs_u->d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
+        }
+        scratch(c1b_, c1b_words_, (size_t)std::max<size_t>(lsh_items_.size(), 1) * item_words);
+        ext_batch(level, lsh_items_, -1, 1);
+        return pack((int)lsh_items_.size());
+    }
+    if (phase == 4) {
+        unpack((int)lsh_items_.size());
+        ext_batch(level, lsh_items_, 1, 2);                        // joins the tensor chain, then accumulates into out
+        zero_unowned(out.d, 1 + out.n, (long)PO, 0, L);
+        p.valid = false;
+        MKHE_HIP(hipGetLastError());
+        return (size_t)(1 + out.n) * PO;
+    }
+    throw Error("mkhe: lsh_phase 1..4");
+}
+
+// reduction epilogue of the party-sharded path: words hold sums of canonical residues of several ranks
+// (each < q, total < 2^63); bring them back to [0,q) and optionally to Montgomery form (MFormLvl).
+void Context::fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform) {
+    check_level(level);
+    FoldArgs fa{};
+    fa.buf = buf; fa.mods = d_mods; fa.map = qp_shaped ? map_qp(level) : d_map_id;
+    fa.nslots = qp_shaped ? nslots_qp(level) : level + 1; fa.npolys = npolys; fa.poly_stride = poly_stride; fa.N = N; fa.mform = mform ? 1 : 0;
+    { ProfScope ps(this, PROF_OTHER, 16.0 * N * fa.nslots * npolys); launch_fold(fa, s_); }
+    MKHE_HIP(hipGetLastError());
+}
+
+}  // namespace mkhe

@@ -1,0 +1,87 @@
+"""The Go side of the shim (shim/go/**, never compiled: no Go toolchain in this image) against a few of the Go compiler's hard errors that need no
+toolchain to find -- unused imports, locals that are declared and never mentioned again, unbalanced brackets, and calls of the cgo binding from the
+drop-in with an argument count no wrapper of that name takes (tools/go_lint.py).  The second half shows on doctored copies of the shipped files that
+each class of mistake IS reported: a lint that cannot fail proves nothing."""
+import importlib.util
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "shim", "go")
+
+_spec = importlib.util.spec_from_file_location("go_lint", os.path.join(ROOT, "tools", "go_lint.py"))
+lint = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(lint)
+
+KS = os.path.join(SHIM, "dropin", "mkrlwe", "keyswitch_gpu.go")
+BIND = os.path.join(SHIM, "mkrlwegpu", "mkrlwegpu.go")
+
+
+def arities():
+    import glob
+    return lint.wrapper_arities([lint.strip(open(f).read()) for f in sorted(glob.glob(os.path.join(SHIM, "mkrlwegpu", "*.go")))])
+
+
+def test_shim_tree_is_clean():
+    res = lint.lint_tree(SHIM)
+    assert not res, "\n".join("%s: %s" % (os.path.relpath(f, ROOT), p) for f, ps in res.items() for p in ps)
+
+
+def test_the_lint_sees_every_function_and_every_binding_call():
+    """the checks only mean something if the parser finds the code: every `func` of the drop-in has a body here, and the drop-in's engine calls are seen"""
+    src = open(KS).read()
+    text = lint.strip(src)
+    bodies = lint.func_bodies(text)
+    assert len(bodies) == len(re.findall(r"^func\b", text, flags=re.M)) and len(bodies) >= 20
+    names = {n for n, _, _, _ in bodies}
+    assert {"NewKeySwitcher", "GPU", "Decompose", "MulAndRelinHoisted", "RotateHoisted", "Conjugate", "ExternalProduct"} <= names
+    calls = re.findall(r"%s\.(%s)\s*\(" % (lint.BINDING_RECEIVER, lint.IDENT), text)
+    assert {"MulAndRelinHoisted", "RotateHoisted", "Conjugate", "UploadSwitchingKey", "NewCiphertext"} <= set(calls)
+    ar = arities()
+    assert len(ar) >= 45 and ar["MulAndRelinHoisted"] == {(7, 7)} and ar["SortedIDs"] == {(1, 1)}
+
+
+def test_unused_import_is_reported():
+    src = open(KS).read().replace('import (\n', 'import (\n\t"strings"\n', 1)
+    assert any('"strings" imported and not used' in p for p in lint.lint_file(KS, src))
+    # ... and cgo's pseudo-package counts as an import that must be used
+    bsrc = re.sub(r"\bC\.", "X.", open(BIND).read())
+    assert any('"C" imported and not used' in p for p in lint.lint_file(BIND, bsrc))
+
+
+def test_unused_local_is_reported():
+    src = open(KS).read()
+    doctored = src.replace("\tg := ks.GPU()\n", "\tg := ks.GPU()\n\tleftover := 3\n", 1)
+    assert doctored != src
+    probs = lint.lint_file(KS, doctored)
+    assert any("`leftover` declared and not used" in p for p in probs), probs
+    doctored = src.replace("\tg := ks.GPU()\n", "\tg := ks.GPU()\n\tvar spare []uint64\n", 1)
+    assert any("`spare` declared and not used" in p for p in lint.lint_file(KS, doctored))
+
+
+def test_wrong_argument_count_and_unknown_wrapper_are_reported():
+    src = open(KS).read()
+    text = lint.strip(src)
+    m = re.search(r"\bg\.MulAndRelinHoisted\(", text)
+    assert m
+    end = lint.match_close(text, m.end() - 1, "(", ")")
+    args = lint.split_args(src[m.end():end - 1])
+    assert len(args) == 7
+    doctored = src[:m.end()] + ",".join(args[:-1]) + src[end - 1:]
+    probs = lint.lint_file(KS, doctored, arities=arities())
+    assert any("call of MulAndRelinHoisted with 6 argument(s)" in p for p in probs), probs
+    doctored = src.replace("g.MulAndRelinHoisted(", "g.MulAndRelinFused(", 1)
+    probs = lint.lint_file(KS, doctored, arities=arities())
+    assert any("MulAndRelinFused is not an exported func / method of the binding" in p for p in probs), probs
+
+
+def test_unbalanced_brackets_and_missing_package_clause_are_reported():
+    src = open(KS).read()
+    i = src.rindex("}")
+    assert any("unclosed" in p or "unbalanced" in p for p in lint.lint_file(KS, src[:i] + src[i + 1:]))
+    assert any("no package clause" in p for p in lint.lint_file(KS, re.sub(r"^package mkrlwe$", "", src, count=1, flags=re.M)))
+
+
+def test_literals_and_comments_do_not_confuse_the_lexer():
+    src = 'package x\n\nimport "fmt"\n\n// a } in a comment, an unused := in a comment: y := 1\nfunc f() {\n\ts := "} not a brace \\" { "\n\tr := \'}\'\n\traw := `{{{`\n\tfmt.Println(s, r, raw)\n}\n'
+    assert lint.lint_file("x.go", src) == []

@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""A few of the Go compiler's hard errors, checked without a Go toolchain (there is none in this image): the Go side of the shim has never been
+compiled, and `imported and not used` / `declared and not used` / a wrong argument count are the mistakes an un-compiled Go file is most likely to hold.
+
+    python3 tools/go_lint.py shim/go            # prints the problems, exit 1 if any
+
+Checks, per file (comments, strings and runes are removed by a small lexer first):
+  * the file has a package clause; (), [], {} balance;
+  * every import is used (`name.` occurs; `_` and `C` -- cgo -- are exempt: `C` must be used too when imported);
+  * every local name introduced by `:=`, `var` or a `for ... := range` clause inside a function body occurs again in that body (an approximation of
+    "declared and not used": a name that is only ever assigned passes here and fails in Go);
+  * calls of the cgo binding's exported wrappers (package mkrlwegpu) from OTHER packages have an argument count some wrapper of that name accepts
+    (calls are recognised by their receiver: `g.` after `g := ks.GPU()`, `ks.GPU().`, `eval.gpu().`, `eval.bfv.`, `mkrlwegpu.`); a call of a name the binding
+    does not export through such a receiver is reported too.
+tests/test_go_lint_static.py runs it over shim/go and shows on doctored sources that each class of mistake is reported."""
+import glob
+import os
+import re
+import sys
+
+IDENT = r"[A-Za-z_][A-Za-z0-9_]*"
+
+
+def strip(src):
+    """Go source -> same length text with comments, string / rune literals blanked (newlines kept)"""
+    out = []
+    i, n = 0, len(src)
+    while i < n:
+        c = src[i]
+        two = src[i:i + 2]
+        if two == "//":
+            j = src.find("\n", i)
+            j = n if j < 0 else j
+            out.append(" " * (j - i)); i = j
+        elif two == "/*":
+            j = src.find("*/", i + 2)
+            j = n if j < 0 else j + 2
+            out.append(re.sub(r"[^\n]", " ", src[i:j])); i = j
+        elif c == "`":
+            j = src.find("`", i + 1)
+            j = n if j < 0 else j + 1
+            out.append('""' + re.sub(r"[^\n]", " ", src[i + 2:j])); i = j
+        elif c == '"' or c == "'":
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            j += 1
+            out.append('""' + " " * (j - i - 2) if c == '"' else "0" + " " * (j - i - 1)); i = j
+        else:
+            out.append(c); i += 1
+    return "".join(out)
+
+
+def balance(text):
+    stack = []
+    pairs = {")": "(", "]": "[", "}": "{"}
+    line = 1
+    for ch in text:
+        if ch == "\n":
+            line += 1
+        elif ch in "([{":
+            stack.append((ch, line))
+        elif ch in ")]}":
+            if not stack or stack[-1][0] != pairs[ch]:
+                return "unbalanced %r at line %d" % (ch, line)
+            stack.pop()
+    if stack:
+        return "unclosed %r opened at line %d" % stack[-1]
+    return None
+
+
+def imports(src_raw, text):
+    """-> [(name, path)] ; needs the raw source for the paths (strings are blanked in text)"""
+    out = []
+    for m in re.finditer(r"^import\s*\(", text, flags=re.M):
+        j = text.index(")", m.end())
+        for ln in src_raw[m.end():j].split("\n"):
+            mm = re.match(r'\s*(?:(%s|_|\.)\s+)?"([^"]+)"' % IDENT, ln)
+            if mm:
+                out.append((mm.group(1) or mm.group(2).split("/")[-1], mm.group(2)))
+    for m in re.finditer(r'^import\s+(?:(%s|_|\.)\s+)?"' % IDENT, text, flags=re.M):
+        mm = re.match(r'import\s+(?:(%s|_|\.)\s+)?"([^"]+)"' % IDENT, src_raw[m.start():])
+        if mm:
+            out.append((mm.group(1) or mm.group(2).split("/")[-1], mm.group(2)))
+    return out
+
+
+def match_close(text, i, open_ch="{", close_ch="}"):
+    depth = 0
+    while i < len(text):
+        if text[i] == open_ch:
+            depth += 1
+        elif text[i] == close_ch:
+            depth -= 1
+            if depth == 0:
+                return i + 1
+        i += 1
+    return len(text)
+
+
+def func_bodies(text):
+    """-> [(name, header_text, body_text, line_of_func)] for every top-level func with a body"""
+    out = []
+    for m in re.finditer(r"^func\b", text, flags=re.M):
+        i = m.end()
+        # skip receiver, name, parameter list(s) up to the body's "{" at paren depth 0
+        depth = 0
+        j = i
+        while j < len(text):
+            ch = text[j]
+            if ch in "([":
+                depth += 1
+            elif ch in ")]":
+                depth -= 1
+            elif ch == "{" and depth == 0:
+                # `interface{}` / `struct{}` in a signature: an empty brace pair directly after the keyword
+                before = text[i:j].rstrip()
+                if before.endswith("interface") or before.endswith("struct"):
+                    j = match_close(text, j)
+                    continue
+                break
+            elif ch == "\n" and depth == 0 and text[j + 1:j + 2] not in (" ", "\t", ")"):
+                j = -1
+                break
+            j += 1
+        if j < 0 or j >= len(text):
+            continue
+        k = match_close(text, j)
+        hdr = text[i:j]
+        names = re.findall(r"(%s)\s*\(" % IDENT, re.sub(r"^\s*\([^()]*\)", "", hdr))        # receiver dropped: the first `name(` is the function's
+        name = names[0] if names else "?"
+        out.append((name, hdr, text[j:k], text.count("\n", 0, m.start()) + 1))
+    return out
+
+
+def declared_locals(body):
+    """names introduced in a function body: `a, b := ...`, `var a, b T`, `for i, v := range` -- with the offset just past the declaration token"""
+    out = []
+    for m in re.finditer(r"((?:%s\s*,\s*)*%s)\s*:=" % (IDENT, IDENT), body):
+        for nm in re.split(r"\s*,\s*", m.group(1).strip()):
+            out.append((nm, m.start(1), m.end()))
+    for m in re.finditer(r"\bvar\s+((?:%s\s*,\s*)*%s)\b" % (IDENT, IDENT), body):
+        for nm in re.split(r"\s*,\s*", m.group(1).strip()):
+            out.append((nm, m.start(1), m.end()))
+    return out
+
+
+def unused_locals(body):
+    problems = []
+    seen = set()
+    for nm, s, e in declared_locals(body):
+        if nm == "_" or (nm, s) in seen:
+            continue
+        seen.add((nm, s))
+        # any other occurrence of the identifier in the body (not as a selector `.nm`, not as a struct-literal key `nm:`)
+        uses = 0
+        for u in re.finditer(r"(?<![A-Za-z0-9_.])%s\b" % re.escape(nm), body):
+            if s <= u.start() < e and body[u.start():u.end()] == nm and u.start() < e and u.start() >= s:
+                # inside the declaration's own name list
+                continue
+            uses += 1
+        if uses == 0:
+            problems.append("`%s` declared and not used (line +%d of the function)" % (nm, body.count("\n", 0, s)))
+    return problems
+
+
+def split_args(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def wrapper_arities(binding_texts):
+    """exported funcs / methods of the binding -> {name: set of (min_args, max_args or None)}"""
+    ar = {}
+    for text in binding_texts:
+        for m in re.finditer(r"^func\s*(\([^)]*\)\s*)?(%s)\s*\(" % IDENT, text, flags=re.M):
+            name = m.group(2)
+            if not name[:1].isupper():
+                continue
+            i = m.end() - 1
+            j = match_close(text, i, "(", ")")
+            params = [p.strip() for p in split_args(text[i + 1:j - 1]) if p.strip()]
+            variadic = bool(params) and "..." in params[-1]
+            n = len(params)
+            ar.setdefault(name, set()).add((n - 1 if variadic else n, None if variadic else n))
+    return ar
+
+
+# how the drop-in reaches the binding: `g := ks.GPU()` / `eval.gpu()` / `eval.bfv` (a *mkrlwegpu.Context) or the package itself
+BINDING_RECEIVER = r"(?:\bg|GPU\(\)|gpu\(\)|\.bfv|\bmkrlwegpu)"
+
+
+def check_calls(text, arities, ambiguous=()):
+    problems = []
+    for m in re.finditer(r"%s\.(%s)\s*\(" % (BINDING_RECEIVER, IDENT), text):
+        name = m.group(1)
+        if name in ambiguous:
+            continue
+        if name not in arities:
+            if name[:1].isupper() and not re.match(r"[A-Z][A-Za-z0-9]*\s*\{", text[m.start(1):]):
+                problems.append("line %d: %s is not an exported func / method of the binding" % (text.count("\n", 0, m.start()) + 1, name))
+            continue
+        i = m.end() - 1
+        j = match_close(text, i, "(", ")")
+        args = [a for a in split_args(text[i + 1:j - 1]) if a.strip()]
+        n = len(args)
+        spread = bool(args) and args[-1].rstrip().endswith("...")
+        ok = any((lo <= n and (hi is None or n <= hi)) or (spread and hi is None and n == lo + 1) for lo, hi in arities[name])
+        if not ok:
+            problems.append("line %d: call of %s with %d argument(s); the binding takes %s" %
+                            (text.count("\n", 0, m.start()) + 1, name, n, sorted("%d%s" % (lo, "+" if hi is None else "") for lo, hi in arities[name])))
+    return problems
+
+
+def lint_file(path, src=None, arities=None, ambiguous=()):
+    src = open(path).read() if src is None else src
+    text = strip(src)
+    problems = []
+    if not re.search(r"^package\s+%s\s*$" % IDENT, text, flags=re.M):
+        problems.append("no package clause")
+    b = balance(text)
+    if b:
+        problems.append(b)
+        return problems
+    body_text = re.sub(r"^import\s*\((?:[^)]*)\)", "", text, flags=re.M)
+    body_text = re.sub(r'^import\s+[^\n]*', "", body_text, flags=re.M)
+    for name, ipath in imports(src, text):
+        if name in ("_", "."):
+            continue
+        if not re.search(r"(?<![A-Za-z0-9_.])%s\s*\." % re.escape(name), body_text):
+            problems.append('"%s" imported and not used' % ipath)
+    for name, hdr, body, line in func_bodies(text):
+        for p in unused_locals(body):
+            problems.append("func %s (line %d): %s" % (name, line, p))
+    if arities:
+        problems += check_calls(text, arities, ambiguous)
+    return problems
+
+
+def lint_tree(root):
+    files = sorted(glob.glob(os.path.join(root, "**", "*.go"), recursive=True))
+    binding = [f for f in files if os.sep + "mkrlwegpu" + os.sep in f]
+    arities = wrapper_arities([strip(open(f).read()) for f in binding])
+    out = {}
+    for f in files:
+        inside = f in binding
+        # names the reference's packages (and Go's own) use too: a call `.Name(` in a drop-in file may not be the binding's
+        p = lint_file(f, arities=None if inside else arities)
+        if p:
+            out[f] = p
+    return out
+
+
+if __name__ == "__main__":
+    res = lint_tree(sys.argv[1] if len(sys.argv) > 1 else "shim/go")
+    for f, ps in res.items():
+        for p in ps:
+            print("%s: %s" % (f, p))
+    sys.exit(1 if res else 0)
