@@ -10,6 +10,7 @@
 // (rings Q, QMul, P and the plaintext modulus).  In the reference's tests: shim/go/patches/mkbfv_tests_gpu_evaluator.diff (two lines).
 //
 //go:build mkhe_gpu
+// +build mkhe_gpu
 
 package mkbfv
 

@@ -2,6 +2,7 @@
 // shim/go/dropin/mkckks/evaluator_gpu_off.go).
 //
 //go:build !mkhe_gpu
+// +build !mkhe_gpu
 
 package mkbfv
 

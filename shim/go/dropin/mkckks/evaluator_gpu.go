@@ -12,6 +12,7 @@
 // (the evaluator field of testParams and its constructor: two lines).
 //
 //go:build mkhe_gpu
+// +build mkhe_gpu
 
 package mkckks
 
@@ -42,7 +43,7 @@ func (eval *GPUEvaluator) gpu() *mkrlwegpu.Context { return eval.ksw.GPU() }
 func (eval *GPUEvaluator) rescaleCount(level int, scale, minScale float64) (nb int, out float64) {
 	q := eval.params.RingQ().Modulus
 	out = scale
-	for out/float64(q[level-nb]) >= minScale/2 && level-nb >= 0 {
+	for level-nb >= 0 && out/float64(q[level-nb]) >= minScale/2 { // (the bound first: the reference indexes before it checks)
 		out /= float64(q[level-nb])
 		nb++
 	}

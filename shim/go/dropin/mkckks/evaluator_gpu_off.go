@@ -2,6 +2,7 @@
 // patched to construct a GPUEvaluator (shim/go/patches/mkckks_tests_gpu_evaluator.diff) still build and run as the pure-Go reference.
 //
 //go:build !mkhe_gpu
+// +build !mkhe_gpu
 
 package mkckks
 

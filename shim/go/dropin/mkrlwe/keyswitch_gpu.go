@@ -25,6 +25,7 @@
 //     engine call of the owner closes them) or by Forget.
 //
 //go:build mkhe_gpu
+// +build mkhe_gpu
 
 package mkrlwe
 

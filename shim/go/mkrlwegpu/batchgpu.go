@@ -6,6 +6,7 @@
 // against include/mkhe.h by tests/test_go_shim_static.py.
 //
 //go:build mkhe_gpu
+// +build mkhe_gpu
 
 package mkrlwegpu
 
@@ -31,7 +32,7 @@ func sameLen(what string, n int, lens ...int) {
 // ctArray copies ciphertext handles into C memory (see swkArray).  The caller frees it.
 func ctArray(cts []*Ciphertext) **C.mkhe_ct {
 	arr := (**C.mkhe_ct)(C.malloc(C.size_t(len(cts)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-	s := unsafe.Slice(arr, len(cts)+1)
+	s := ctSlice(arr, len(cts)+1)
 	for i, c := range cts {
 		s[i] = c.h
 	}
@@ -48,7 +49,7 @@ func (ctx *Context) NewCiphertextBatch(ids []string, level int, B int) []*Cipher
 	arr := (**C.mkhe_ct)(C.malloc(C.size_t(B+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
 	defer C.free(unsafe.Pointer(arr))
 	must(C.mkhe_ct_create_batch(ctx.c, C.int(B), C.int(len(ids)), &cids[0], C.int(level+1), arr))
-	s := unsafe.Slice(arr, B)
+	s := ctSlice(arr, B)
 	out := make([]*Ciphertext, B)
 	for i := range out {
 		out[i] = &Ciphertext{h: s[i], ids: append([]string(nil), ids...), ctx: ctx}
@@ -61,7 +62,7 @@ func (ctx *Context) NewSwitchingKeyBatch(count int) []*SwitchingKey {
 	arr := (**C.mkhe_swk)(C.malloc(C.size_t(count+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
 	defer C.free(unsafe.Pointer(arr))
 	must(C.mkhe_swk_create_batch(ctx.c, C.int(count), arr))
-	s := unsafe.Slice(arr, count)
+	s := swkSlice(arr, count)
 	out := make([]*SwitchingKey, count)
 	for i := range out {
 		out[i] = &SwitchingKey{h: s[i], ctx: ctx}

@@ -6,6 +6,7 @@
 // signed integers and hands those to the engine, which does the NTTs and the products with the CRS on the GPU.
 //
 //go:build mkhe_gpu
+// +build mkhe_gpu
 
 package mkrlwegpu
 

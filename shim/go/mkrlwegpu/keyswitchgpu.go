@@ -5,6 +5,7 @@
 // this package against include/mkhe.h (name, number of arguments, pointer / scalar kind of each one).
 //
 //go:build mkhe_gpu
+// +build mkhe_gpu
 
 package mkrlwegpu
 
@@ -40,12 +41,22 @@ func b2i(b bool) C.int {
 	return 0
 }
 
+// swkSlice / ctSlice view n C pointers at arr as a Go slice.  (The array-pointer idiom, not unsafe.Slice: the reference's go.mod says `go 1.13`,
+// and unsafe.Slice needs language version 1.17.)
+func swkSlice(arr **C.mkhe_swk, n int) []*C.mkhe_swk {
+	return (*[1 << 28]*C.mkhe_swk)(unsafe.Pointer(arr))[:n:n]
+}
+
+func ctSlice(arr **C.mkhe_ct, n int) []*C.mkhe_ct {
+	return (*[1 << 28]*C.mkhe_ct)(unsafe.Pointer(arr))[:n:n]
+}
+
 // swkArray copies the handles into C memory (NULL-terminated by one spare slot): a Go slice of C pointers may not be handed to C as **T
 // while it holds Go-allocated backing under the cgo pointer rules only if it contains Go pointers -- these are C pointers, but the
 // array itself is then pinned for the call by being C memory.  The caller frees it.
 func swkArray(keys []*SwitchingKey) **C.mkhe_swk {
 	arr := (**C.mkhe_swk)(C.malloc(C.size_t(len(keys)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-	s := unsafe.Slice(arr, len(keys)+1)
+	s := swkSlice(arr, len(keys)+1)
 	for i, k := range keys {
 		s[i] = k.h
 	}

@@ -4,6 +4,7 @@
 // adds so that mkbfv.Evaluator.MulRelinNew (mkbfv/evaluator.go:78-82) runs on an MI355X.
 //
 //go:build mkhe_gpu
+// +build mkhe_gpu
 
 package mkrlwegpu
 
@@ -62,7 +63,7 @@ func (ctx *Context) UploadBFVRelinKey(rk *BFVRelinKeys, id string, b1, b2, d1, d
 
 func swkList(ids []string, m map[string]*SwitchingKey) **C.mkhe_swk {
 	arr := (**C.mkhe_swk)(C.malloc(C.size_t(len(ids)+1) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-	s := unsafe.Slice(arr, len(ids)+1)
+	s := swkSlice(arr, len(ids)+1)
 	s[len(ids)] = nil
 	for i, id := range ids {
 		k, ok := m[id]

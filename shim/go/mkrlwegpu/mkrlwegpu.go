@@ -14,6 +14,7 @@
 // []rlwe.PolyQP).
 //
 //go:build mkhe_gpu
+// +build mkhe_gpu
 
 package mkrlwegpu
 

@@ -3,6 +3,7 @@ toolchain to find -- unused imports, locals that are declared and never mentione
 drop-in with an argument count no wrapper of that name takes (tools/go_lint.py).  The second half shows on doctored copies of the shipped files that
 each class of mistake IS reported: a lint that cannot fail proves nothing."""
 import importlib.util
+import json
 import os
 import re
 
@@ -22,8 +23,14 @@ def arities():
     return lint.wrapper_arities([lint.strip(open(f).read()) for f in sorted(glob.glob(os.path.join(SHIM, "mkrlwegpu", "*.go")))])
 
 
+def go_directive():
+    """the `go` line of the reference's go.mod (tests/golden/ref_go_signatures.json, written by tools/gen_ref_go_signatures.py)"""
+    return tuple(json.load(open(os.path.join(ROOT, "tests", "golden", "ref_go_signatures.json")))["go_directive"])
+
+
 def test_shim_tree_is_clean():
-    res = lint.lint_tree(SHIM)
+    assert go_directive() == (1, 13)
+    res = lint.lint_tree(SHIM, go=go_directive())
     assert not res, "\n".join("%s: %s" % (os.path.relpath(f, ROOT), p) for f, ps in res.items() for p in ps)
 
 
@@ -85,3 +92,17 @@ def test_unbalanced_brackets_and_missing_package_clause_are_reported():
 def test_literals_and_comments_do_not_confuse_the_lexer():
     src = 'package x\n\nimport "fmt"\n\n// a } in a comment, an unused := in a comment: y := 1\nfunc f() {\n\ts := "} not a brace \\" { "\n\tr := \'}\'\n\traw := `{{{`\n\tfmt.Println(s, r, raw)\n}\n'
     assert lint.lint_file("x.go", src) == []
+
+
+def test_features_newer_than_the_modules_go_directive_are_reported():
+    """the reference's go.mod says `go 1.13`: unsafe.Slice (1.17), `any` (1.18) and a //go:build line without its // +build twin do not compile / are not
+    honoured there -- the first two were in the shim until round 5"""
+    src = open(os.path.join(SHIM, "mkrlwegpu", "keyswitchgpu.go")).read()
+    go = go_directive()
+    doctored = src.replace("return (*[1 << 28]*C.mkhe_swk)(unsafe.Pointer(arr))[:n:n]", "return unsafe.Slice(arr, n)", 1)
+    assert doctored != src and any("unsafe.Slice" in p and "needs go 1.17" in p for p in lint.lint_file("k.go", doctored, go=go))
+    assert not any("needs go" in p for p in lint.lint_file("k.go", doctored, go=(1, 21)))
+    doctored = src.replace("// +build mkhe_gpu\n", "", 1)
+    assert doctored != src and any("without the `// +build mkhe_gpu` line" in p for p in lint.lint_file("k.go", doctored, go=go))
+    doctored = src.replace("func b2i(b bool) C.int {", "func b2i(b bool, _ any) C.int {", 1)
+    assert doctored != src and any("`any`" in p for p in lint.lint_file("k.go", doctored, go=go))

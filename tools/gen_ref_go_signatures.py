@@ -155,7 +155,9 @@ def build(ref_root):
                 names |= declared_names(open(os.path.join(ref_root, rel)).read())
         declared[pkg] = sorted(names)
     # `declared`: every top-level name of the package's non-test files that stay compiled under the tag -- a drop-in file may not declare one again
-    return {"reference": "SNUCP/MKHE-KKLSS", "files": FILES, "excluded_under_tag": EXCLUDED, "packages": table, "declared": declared}
+    m = re.search(r"^go\s+(\d+)\.(\d+)", open(os.path.join(ref_root, "go.mod")).read(), flags=re.M)
+    # `go_directive`: the language version the module compiles at (go.mod) -- the shim may not use anything newer (tools/go_lint.py)
+    return {"reference": "SNUCP/MKHE-KKLSS", "go_directive": [int(m.group(1)), int(m.group(2))], "files": FILES, "excluded_under_tag": EXCLUDED, "packages": table, "declared": declared}
 
 
 if __name__ == "__main__":

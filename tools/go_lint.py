@@ -2,10 +2,12 @@
 """A few of the Go compiler's hard errors, checked without a Go toolchain (there is none in this image): the Go side of the shim has never been
 compiled, and `imported and not used` / `declared and not used` / a wrong argument count are the mistakes an un-compiled Go file is most likely to hold.
 
-    python3 tools/go_lint.py shim/go            # prints the problems, exit 1 if any
+    python3 tools/go_lint.py shim/go [1.13]     # prints the problems, exit 1 if any; the second argument is the module's `go` directive
 
 Checks, per file (comments, strings and runes are removed by a small lexer first):
   * the file has a package clause; (), [], {} balance;
+  * nothing newer than the module's `go` directive is used (the reference's go.mod says 1.13: no unsafe.Slice, no `any`, no generics, and every
+    `//go:build` line has its `// +build` twin);
   * every import is used (`name.` occurs; `_` and `C` -- cgo -- are exempt: `C` must be used too when imported);
   * every local name introduced by `:=`, `var` or a `for ... := range` clause inside a function body occurs again in that body (an approximation of
     "declared and not used": a name that is only ever assigned passes here and fails in Go);
@@ -223,10 +225,36 @@ def check_calls(text, arities, ambiguous=()):
     return problems
 
 
-def lint_file(path, src=None, arities=None, ambiguous=()):
+# language / library features newer than a go.mod `go` directive allows: (first version, pattern on the stripped text, what)
+NEWER = [((1, 17), r"\bunsafe\.(Slice|Add)\s*\(", "unsafe.Slice / unsafe.Add"),
+         ((1, 20), r"\bunsafe\.(String|StringData|SliceData)\s*\(", "unsafe.String / SliceData"),
+         ((1, 18), r"^func\s*(\([^)]*\)\s*)?%s\s*\[" % IDENT, "type parameters"),
+         ((1, 18), r"(?<![A-Za-z0-9_.])any\b(?!\s*(:?=|\())", "the predeclared `any`"),
+         ((1, 21), r"\bruntime\.Pinner\b", "runtime.Pinner"),
+         ((1, 21), r"(?<![A-Za-z0-9_.])(min|max|clear)\s*\(", "the builtins min / max / clear"),
+         ((1, 19), r"\batomic\.(Int32|Int64|Uint32|Uint64|Bool|Pointer)\b", "the typed atomics")]
+
+
+def version_problems(src, text, go):
+    problems = []
+    for since, pat, what in NEWER:
+        if go < since:
+            for m in re.finditer(pat, text, flags=re.M):
+                problems.append("line %d: %s needs go %d.%d, the module is at go %d.%d" % (text.count("\n", 0, m.start()) + 1, what, since[0], since[1], go[0], go[1]))
+    if go < (1, 17):
+        # toolchains before 1.17 only read the old form: every //go:build line needs its `// +build` twin (same simple expression) right after it
+        lines = src.split("\n")
+        for i, l in enumerate(lines):
+            m = re.match(r"^//go:build (.+)$", l)
+            if m and not (i + 1 < len(lines) and lines[i + 1] == "// +build " + m.group(1)):
+                problems.append("line %d: `//go:build %s` without the `// +build %s` line a go %d.%d module's toolchains may need" % (i + 1, m.group(1), m.group(1), go[0], go[1]))
+    return problems
+
+
+def lint_file(path, src=None, arities=None, ambiguous=(), go=None):
     src = open(path).read() if src is None else src
     text = strip(src)
-    problems = []
+    problems = version_problems(src, text, go) if go else []
     if not re.search(r"^package\s+%s\s*$" % IDENT, text, flags=re.M):
         problems.append("no package clause")
     b = balance(text)
@@ -248,7 +276,7 @@ def lint_file(path, src=None, arities=None, ambiguous=()):
     return problems
 
 
-def lint_tree(root):
+def lint_tree(root, go=None):
     files = sorted(glob.glob(os.path.join(root, "**", "*.go"), recursive=True))
     binding = [f for f in files if os.sep + "mkrlwegpu" + os.sep in f]
     arities = wrapper_arities([strip(open(f).read()) for f in binding])
@@ -256,14 +284,14 @@ def lint_tree(root):
     for f in files:
         inside = f in binding
         # names the reference's packages (and Go's own) use too: a call `.Name(` in a drop-in file may not be the binding's
-        p = lint_file(f, arities=None if inside else arities)
+        p = lint_file(f, arities=None if inside else arities, go=go)
         if p:
             out[f] = p
     return out
 
 
 if __name__ == "__main__":
-    res = lint_tree(sys.argv[1] if len(sys.argv) > 1 else "shim/go")
+    res = lint_tree(sys.argv[1] if len(sys.argv) > 1 else "shim/go", go=tuple(int(x) for x in sys.argv[2].split(".")) if len(sys.argv) > 2 else None)
     for f, ps in res.items():
         for p in ps:
             print("%s: %s" % (f, p))
