@@ -86,11 +86,14 @@ void Context::rotate_batch(u64 galEl, const std::vector<const Ct*>& ins, const s
     const size_t PI = (size_t)ins[0]->limbs * N, PO = (size_t)L * N;
     Arena ar(this, hoists.empty() ? B * n * swk_words() : 0);
     std::vector<const u64*> h(B * n);
+    bool stage = false;
     if (hoists.empty()) {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (size_t b = 0; b < B; ++b)
             for (int a = 0; a < n; ++a) { u64* d = ar.take(swk_words()); dsrc.push_back(ins[b]->d + (1 + a) * PI); ddst.push_back(d); h[b * n + a] = d; }
-        decompose_batch(level, dsrc, ddst, true);
+        // (digits the engine made for itself, read once by the two products of their party: a small launch finishes the transform inside the product kernel)
+        stage = ext_fused_ok(level, (int)(B * n));
+        decompose_batch(level, dsrc, ddst, true, stage);
     } else {
         for (size_t i = 0; i < B * n; ++i) { if (!hoists[i]) throw Error("mkhe: missing hoisted form"); h[i] = hoists[i]->d; }
     }
@@ -154,11 +157,14 @@ void Context::rotate_multi(const std::vector<u64>& galEl, const std::vector<cons
     const size_t PI = (size_t)ins[0]->limbs * N, PO = (size_t)L * N;
     Arena ar(this, hoists.empty() ? B * n * swk_words() : 0);
     std::vector<const u64*> h(B * n);
+    bool stage = false;
     if (hoists.empty()) {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (size_t b = 0; b < B; ++b)
             for (int a = 0; a < n; ++a) { u64* d = ar.take(swk_words()); dsrc.push_back(ins[b]->d + (1 + a) * PI); ddst.push_back(d); h[b * n + a] = d; }
-        decompose_batch(level, dsrc, ddst, true);
+        // (digits the engine made for itself, read once by the two products of their party: a small launch finishes the transform inside the product kernel)
+        stage = ext_fused_ok(level, (int)(B * n));
+        decompose_batch(level, dsrc, ddst, true, stage);
     } else {
         for (size_t i = 0; i < B * n; ++i) { if (!hoists[i]) throw Error("mkhe: missing hoisted form"); h[i] = hoists[i]->d; }
     }
@@ -178,7 +184,9 @@ void Context::rotate_multi(const std::vector<u64>& galEl, const std::vector<cons
                 if (PP) items.back().post = post_add[b]->d + (size_t)(1 + a) * PP;
             }
         }
-        ext_batch(level, items, -1, 0, 0);
+        if (stage) ext_staged_.assign(h.begin() + b0 * n, h.begin() + std::min(B, b0 + per) * n);
+        try { ext_batch(level, items, -1, 0, 0); } catch (...) { ext_staged_.clear(); throw; }
+        ext_staged_.clear();
     }
     MKHE_HIP(hipGetLastError());
 }

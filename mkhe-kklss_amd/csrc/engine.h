@@ -146,11 +146,15 @@ class Context {
     // batched building blocks (all parties in one launch)
     // internal = true: the digits stay inside the engine (hoist pools): their forward NTT skips the final
     // normalisation (values < 34q with the same residues; every consumer is a Montgomery product)
-    void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst, bool internal = false);
+    // stage_only (alpha = 1, N = 2^14, engine-internal): digit spread + the three cross stages only -- the digits are then consumed by ext_batch through
+    // ext_fused_lds_kernel (ext_staged_ names them), which finishes the transform in LDS and multiplies in the same kernel (ntt_kernels.h, ExtFusedArgs)
+    void decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst, bool internal = false, bool stage_only = false);
+    bool ext_fused_ok(int level, int nvec) const;
     // stage 0: whole external products; 1: front half only (inner products + inverse NTT into the c1 pool);
     // 2: back half only (ModDown of the c1 pool filled by the preceding stage-1 call with the same items)
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
     u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
+    std::vector<const u64*> ext_staged_;  // set around the one ext_batch call whose items read digit vectors that decompose_batch left staged (stage_only)
     u64* ext_xout2_ = nullptr;            // ... and the second gadget's x (mkbfv)
     std::vector<u64*> ext_eouts_;                           // a batch's F1 call that computes step E too: where input b's E products go ([n1][mtot][N])
     int ext_e_slot_ = -1;                                  // >= 0 around the F1 call that computes step E too: first c1 slot of the E products
@@ -319,6 +323,7 @@ class Context {
         std::vector<const u64*> xkeys;       // non-empty: x is produced by the F1 kernel of mr_finish_head (into xfused) instead of by mr_xy
         u64* xfused = nullptr;
         std::vector<const u64*> ykeys;       // non-empty: y is computed inside the F1 kernel from these keys (b_j) and h1 (never stored)
+        bool f2_staged = false;              // the digits of the t_i were left after the cross stages (decompose_batch stage_only): the tail batch finishes them
         bool e_done = false;                 // ... and so was step E: its products sit in the c1 slots 2 n0 .. 2 n0 + n1 - 1 of the scratch, for the tail batch
     } plan_;
 

@@ -915,9 +915,17 @@ void Context::external_product(int level, bool is_ntt, const u64* a, const u64* 
 }
 
 // ------------------------------------------------------------------ batched forms (one launch for all parties)
-void Context::decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst, bool internal) {
+// Small launches of the small ring: forward sub-transforms + inner products in one kernel (ExtFusedArgs).  The limit is in limbs of the Decompose
+// launch (vectors x digits x limb slots): beyond it the launch fills the chip and the one-pass H16-class kernel + the streaming inner product win.
+bool Context::ext_fused_ok(int level, int nvec) const {
+    static const int lim = MKHE_AB_INT("MKHE_EXT_FUSED_MAX", 150);
+    if (alpha != 1 || logN != 14 || masked_ || is_bfv() || nvec < 1 || nvec > EXTF_MAX_V || mall > 64) return false;
+    return nvec * beta(level) * nslots_qp(level) <= lim;
+}
+void Context::decompose_batch(int level, const std::vector<const u64*>& src, const std::vector<u64*>& dst, bool internal, bool stage_only) {
     check_level(level);
     const int nb = beta(level);
+    if (stage_only && (alpha != 1 || !internal || logN != 14 || src.size() > (size_t)NTT_MAX_ITEMS)) throw Error("mkhe: internal: staged Decompose outside its shape");
     if (alpha != 1) {
         // alpha >= 2: CRT-reconstructed digits are spread in the coefficient domain first (DecomposeAndSplit,
         // basis_extension.go:428-535), then NTT'd in place (DecomposeSingleNTT, keyswitch.go:29-30)
@@ -981,7 +989,8 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
         b.nitems = n; b.outers_per_item = nb;
         for (int i = 0; i < n; ++i) { b.src_items[i] = src[base + i]; b.dst_items[i] = dst[base + i]; }
         b.nouter = n * nb;
-        ntt_fwd_launch(b, true);
+        if (stage_only) { ProfScope ps(this, PROF_NTT_DECOMP, 16.0 * N * b.nouter * b.nslots); launch_ntt_cross8_dec(b, logN, s_); }
+        else ntt_fwd_launch(b, true);
     }
     MKHE_HIP(hipGetLastError());
 }
@@ -1044,7 +1053,7 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     const size_t item_words = (size_t)mtot * N;
     if (n < 1 || nslots < 1) return;
     ExtInnerArgs ia{};
-    bool two = false;
+    bool two = false, fused_inv = false;
     bool xby = ext_xout_ != nullptr && n <= (ext_xout2_ ? 4 : 16);     // (five to sixteen single-gadget items: ext_inner_xwide_kernel)
     const bool xby2 = ext_xout2_ != nullptr;               // mkbfv: both gadgets carry their x
     for (int i = 0; i < n; ++i) {
@@ -1104,7 +1113,30 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         distinct = ns;
     }
     { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * ny - 1.0) : 0.0) + (xyb ? nb * (1.0 * n + ext_ykeys_.size() - xgroups) : 0.0)));
-      if (xy && n > 4) {
+      if (!ext_staged_.empty()) {
+          // the items' digit vectors were left after the cross stages (decompose_batch, stage_only): sub-transforms and products in one kernel
+          if (xby || xy || xyb || two || (int)ext_staged_.size() > EXTF_MAX_V) throw Error("mkhe: internal: staged digits in a launch that cannot take them");
+          ExtFusedArgs fa{};
+          fa.nv = (int)ext_staged_.size();
+          for (int v = 0; v < fa.nv; ++v) fa.stage[v] = ext_staged_[v];
+          for (int i = 0; i < n; ++i) {
+              if (it[i].pre && !it[i].pre_src) continue;                 // (computed before, in its slot)
+              int v = -1;
+              for (int k = 0; k < fa.nv; ++k) if (ext_staged_[k] == it[i].ah) v = k;
+              if (v < 0 || it[i].pre || fa.nk[v] >= 2) throw Error("mkhe: internal: staged digits in a launch that cannot take them");
+              fa.bg[v][fa.nk[v]] = it[i].bg; fa.out[v][fa.nk[v]] = c1 + (size_t)i * item_words; ++fa.nk[v];
+          }
+          for (int v = 0; v < fa.nv; ++v) if (!fa.nk[v]) throw Error("mkhe: internal: a staged digit vector without a product");
+          fa.mods = d_mods; fa.map = map_qp(level); fa.psi = d_psi; fa.digit_stride = (long)item_words;
+          for (int m2 = 0; m2 < mall && m2 < 64; ++m2) if (small_q_[m2]) fa.small_mask |= 1ull << m2;
+          fa.nb = nb; fa.nslots = nslots; fa.N = N; fa.logN = logN;
+          // every product of the launch made here, two digit groups, no NTT-domain summand (rotations, conjugations): the inverse sub-transforms as well
+          static const int inv_env = MKHE_AB_INT("MKHE_EXT_FUSED_INV", 1);
+          fused_inv = inv_env && nb >= 2;
+          for (int i = 0; i < n; ++i) fused_inv = fused_inv && !it[i].pre && !it[i].qadd;
+          if (fused_inv) { fa.inv = 1; fa.psiinv = d_psiinv; fa.aux = d_inv_aux; }
+          launch_ext_fused_lds(fa, s_);
+      } else if (xy && n > 4) {
           ExtXyWideArgs xa{};
           for (int j = 0; j < n; ++j) { xa.ah[j] = it[j].ah; xa.xkey[j] = it[j].xkey; xa.ykey[j] = ext_ykeys_[j]; xa.yh[j] = ext_yh_[j]; }
           xa.xout = ext_e_slot_ >= 0 ? nullptr : ext_xout_; xa.e_out = ext_e_slot_ >= 0 ? c1 + (size_t)ext_e_slot_ * item_words : nullptr; xa.c1 = c1;
@@ -1160,12 +1192,12 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
             for (int k = 0; k < VI_MAX; ++k) b.vi_mem[v] |= (unsigned)mp->mem[v][k] << (8 * k);
         }
         b.vi_jobs = mp->nvi * (level + 1) + n * np;
-        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * b.vi_jobs); ntt_inv_launch(b); }
+        { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * b.vi_jobs); if (fused_inv) launch_ntt_inv_cross8_sum(b, logN, s_); else ntt_inv_launch(b); }
         return;
     }
     slots_qp(b, level);
     b.nouter = n;
-    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); ntt_inv_launch(b); }
+    { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * n * nslots); if (fused_inv) launch_ntt_inv_cross8_sum(b, logN, s_); else ntt_inv_launch(b); }
 }
 // back half: ModDown of the items in c1 into (or onto) their destinations
 void Context::ext_back(int level, const ExtItem* it, int n, const u64* c1, u64 galEl, const ExtMerge* mp) {

@@ -229,7 +229,10 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
-        if (n0) decompose_batch(level, dsrc, ddst, true);
+        // (the digits of the t_i are read once, by the two F2 products of their party: a small launch of the small ring leaves them after the cross
+        // stages and the tail's product kernel finishes the transform -- when step E is not an item that reads other digits in the same launch)
+        p.f2_staged = n0 > 0 && (p.e_done || p.n1 == 0) && ext_fused_ok(level, n0);
+        if (n0) decompose_batch(level, dsrc, ddst, true, p.f2_staged);
     }
     p.head_done = true;
     MKHE_HIP(hipGetLastError());
@@ -251,6 +254,8 @@ void Context::mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const S
     }
     for (int a = 0; a < n1; ++a) { items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true}); items.back().pre = p.e_done; }
     if (p.x_pending) { join_side(2); p.x_pending = false; }
+    if (p.f2_staged) { ext_staged_.clear(); for (int a = 0; a < n0; ++a) ext_staged_.push_back(hoist_slot(2, a).d); }
+    struct Unstage { Context* c; ~Unstage() { c->ext_staged_.clear(); } } unstage{this};
     if (p.tens) {
         // the tensor term of every output slot rides on the first product that goes there (see mr_prepare)
         std::vector<const u64*> seen;

@@ -48,7 +48,11 @@ void Context::rotate_core(const Ct& in, const Swk* const* hoist, const Swk* cons
             if (hoist) { if (!hoist[a]) throw Error("mkhe: missing hoisted form"); h[a] = hoist[a]->d; }
             else { Swk& s = hoist_slot(0, a); dsrc.push_back(in.d + (1 + a) * PI); ddst.push_back(s.d); h[a] = s.d; }
         }
-        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst, true);
+        // (a rotation of a ciphertext without a hoisted form: its digits are read once, by the two products below -- small launches finish their
+        // transform inside the product kernel)
+        const bool stage = !hoist && ext_fused_ok(level, (int)dsrc.size());
+        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst, true, stage);
+        if (stage) ext_staged_.assign(ddst.begin(), ddst.end());
     }
     std::vector<ExtItem> items;
     for (int a = 0; a < n; ++a) {
@@ -56,7 +60,8 @@ void Context::rotate_core(const Ct& in, const Swk* const* hoist, const Swk* cons
         if (fused && a == 0) items.back().addend = in.d;
         items.push_back(ExtItem{h[a], crs.d, tmp + (size_t)(1 + a) * PO, false});
     }
-    ext_batch(level, items, -1, 0, galEl);
+    try { ext_batch(level, items, -1, 0, galEl); } catch (...) { ext_staged_.clear(); throw; }
+    ext_staged_.clear();
     MKHE_HIP(hipGetLastError());
 }
 
@@ -88,14 +93,17 @@ void Context::conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk
         if (!ck[a]) throw Error("cannot GetConjugationKey: there is no conjugation key with given id");
         dsrc.push_back(tmp + (size_t)(1 + a) * PO); ddst.push_back(hoist_slot(0, a).d);
     }
-    decompose_batch(level, dsrc, ddst, true);
+    const bool stage = ext_fused_ok(level, n);
+    decompose_batch(level, dsrc, ddst, true, stage);
+    if (stage) ext_staged_.assign(ddst.begin(), ddst.end());
     std::vector<ExtItem> items;
     for (int a = 0; a < n; ++a) {
         items.push_back(ExtItem{ddst[a], ck[a]->d, out.d, true});
         if (a == 0) items.back().addend = tmp;
         items.push_back(ExtItem{ddst[a], crs.d, out.d + (size_t)(1 + a) * PO, false});
     }
-    ext_batch(level, items);
+    try { ext_batch(level, items); } catch (...) { ext_staged_.clear(); throw; }
+    ext_staged_.clear();
     MKHE_HIP(hipGetLastError());
 }
 

@@ -113,6 +113,8 @@ struct NttBatch {
     // that limb over the members (formed at the load), written over the first member's limb; slots >= vi_q: P limb mod[s] of
     // member (s - vi_q) / vi_np, in place -- no job when the group has fewer members.  vi_jobs = jobs that exist.
     int vi, vi_q, vi_np, vi_jobs;
+    int sum_in_cross;       // merged inverse launch whose sub-transforms ran per MEMBER (ext_fused_lds_kernel<2, true>): the cross pass (ntt_pass8_inv_kernel) sums
+                            // the members of a group's Q limbs at its load; no vi_extra summand in such a launch
     // vi_extra[g] != NULL: one more Q-only summand of group g, a plain polynomial [.. limbs ..][N] in the NTT domain, canonical
     // (MulAndRelin's tensor term times P: it leaves ModDown as the tensor term itself, so that it needs no inverse NTT of its own)
     const u64* vi_extra[NTT_MAX_ITEMS];
@@ -144,5 +146,35 @@ void launch_ntt32_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
 // the same kernel on the 2^15-point sub-transforms of a split N = 2^16 launch (one modulus class per launch)
 bool ntt16_split_ok(const NttBatch& c);
 void launch_ntt16_fwd_split(const NttBatch& c, bool small, hipStream_t st);
+
+
+// Small rings (N = 2^14), small launches: the forward sub-transforms of an engine-internal Decompose and the inner products that consume them in ONE
+// kernel (round 5).  A key switch of one ciphertext there is a chain of launches of a few dozen limbs that last as long as one workgroup each; the
+// digits of a polynomial the engine decomposes for its own use (Rotate / Conjugate without a hoisted form, step F2 of MulAndRelin) are read exactly
+// once, by the inner products with its one or two keys.  launch_ntt_cross8_dec leaves them after the three cross stages (ntt_pass8_fwd_kernel<true>:
+// digit spread + radix-8 pass, eight independent 2^11-point blocks per limb); ext_fused_lds_kernel<NG> then gives a workgroup one (vector, limb, block):
+// NG groups of 256 threads transform the block of NG digits at a time in LDS (the phases of ntt_fwd_lds_kernel<MODE, 11>, the last one back into
+// LDS), every thread then multiplies 8 / NG coefficients of all NG digits with the key(s) and keeps the sums -- the same integers as
+// ntt_fwd_lds_kernel + ext_inner[_group]_kernel (canonical sums of the same products), without the store and the reload of the digits and one launch less.
+constexpr int EXTF_MAX_V = 32;
+struct ExtFusedArgs {
+    const u64* stage[EXTF_MAX_V];          // per vector: the cross-passed digits [digit][mtot][N] (a hoisted-form buffer)
+    const u64* bg[EXTF_MAX_V][2];          // its one or two keys (gadget ciphertext halves), [digit][mtot][N], Montgomery form
+    u64* out[EXTF_MAX_V][2];               // their products' limbs base ([mtot][N]: a c1 slot), canonical
+    unsigned char nk[EXTF_MAX_V];
+    const Mod* mods;
+    const int* map;                        // limb slot -> modulus index
+    const u64* psi;                        // forward twiddles [nmod][N]
+    unsigned long long small_mask;         // bit m: modulus m runs the signed never-reduced butterflies (MODE 1), else Harvey (MODE 0)
+    const u64* psiinv;                     // inv != 0: the inverse twiddles [nmod][N] and
+    const u64* aux;                        // the inverse constants (NttBatch::aux)
+    int inv;                               // the products leave the kernel after their inverse 2^11-point sub-transforms ([0, 2q), N^-1 folded in): the
+                                           // caller follows with launch_ntt_inv_cross8_sum instead of launch_ntt_inv (two digit groups, nb >= 2)
+    long digit_stride;
+    int nb, nslots, N, logN, nv;
+};
+void launch_ntt_cross8_dec(const NttBatch& b, int logN, hipStream_t st);
+void launch_ext_fused_lds(const ExtFusedArgs& a, hipStream_t st);
+void launch_ntt_inv_cross8_sum(const NttBatch& b, int logN, hipStream_t st);
 
 }  // namespace mkhe

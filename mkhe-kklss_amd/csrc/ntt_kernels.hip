@@ -828,13 +828,19 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass8_fwd_kernel(NttBatch b
 __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass8_inv_kernel(NttBatch b, int logN) {
     const int N = 1 << logN, E = N >> 3;
     gcptr src; gptr dst; int m, outer;
-    if (!job_pointers<true>(b, blockIdx.y, src, dst, m, outer)) return;
+    const int nsum = job_pointers<true>(b, blockIdx.y, src, dst, m, outer);
+    if (!nsum) return;
     const Mod md = b.mods[m];
     const u64 q = md.q, q2 = md.q2;
     const u32 ninv = md.ninv32;
     u64 w[8];
 #pragma unroll
     for (int i = 1; i < 8; ++i) w[i] = b.psi[(long)m * N + i];
+    // (sum_in_cross: the sub-transforms ran per member, inside ext_fused_lds_kernel -- the members of the destination, all in [0, 2q), meet here)
+    long moff[VI_MAX] = {};
+    const int ns = b.sum_in_cross ? nsum : 1;
+#pragma unroll
+    for (int k = 1; k < VI_MAX; ++k) if (k < ns) moff[k] = vi_member_offset(b, outer, k, m, src);
     auto gs = [&](u64& x, u64& y, u64 tw) {
         const u64 s_ = csub(x + y, q2), d_ = mont_mul_sdu(x + q2 - y, tw, md.qs, q, ninv);
         x = s_; y = d_;
@@ -843,6 +849,12 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass8_inv_kernel(NttBatch b
         u64 a[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) a[k] = dst[j + k * E];
+#pragma unroll
+        for (int mm = 1; mm < VI_MAX; ++mm)
+            if (mm < ns) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = csub(a[k] + dst[moff[mm] + j + k * E], q2);
+            }
 #pragma unroll
         for (int c = 0; c < 4; ++c) gs(a[2 * c], a[2 * c + 1], w[4 + c]);
 #pragma unroll
@@ -854,6 +866,137 @@ __global__ void __launch_bounds__(SPLIT_THREADS) ntt_pass8_inv_kernel(NttBatch b
 #pragma unroll
         for (int k = 0; k < 8; ++k) dst[j + k * E] = b.lazy_out ? a[k] : csub(a[k], q);
     }
+}
+
+// ---- forward sub-transforms + inner products in one kernel (see ntt_kernels.h, ExtFusedArgs)
+template <int NG, int MODE, bool INV>
+__device__ __forceinline__ void extf_body(const ExtFusedArgs& a, u64* lds, const Mod& md, int m, int part, int v) {
+    constexpr int LOGM = 11, M = 1 << LOGM, TALL = NG * 256, CPT = M / TALL;
+    const int g = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const int d = a.logN - LOGM, root = (1 << d) + part;
+    gcptr psi = (gcptr)(a.psi + (long)m * a.N);
+    u64* region = lds + g * SmGeo<LOGM>::LDSW;
+    constexpr int NL = (SmGeo<LOGM>::E >> 2) * 3;
+    u64 t0[7], t1[7], t2[7], t3[NL];
+    sm_tw_load<0, 3, LOGM>(psi, root, t, t0); sm_tw_load<3, 3, LOGM>(psi, root, t, t1);
+    sm_tw_load<6, 3, LOGM>(psi, root, t, t2); sm_tw_load<9, 2, LOGM>(psi, root, t, t3);
+    const u64 q = md.q, q2 = md.q2;
+    const u32 ninv = md.ninv32;
+    const long limb = (long)m * a.N + (long)part * M;
+    const int nk = a.nk[v];
+    gcptr st = (gcptr)a.stage[v];
+    gcptr k0 = (gcptr)a.bg[v][0], k1 = (gcptr)a.bg[v][1];
+    u64 acc0[CPT], acc1[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) { acc0[j] = 0; acc1[j] = 0; }
+    // (PF) the source of the NEXT round is requested while this one is transformed (first phase: thread t owns the words t + 256 a of its block)
+    constexpr bool PF = true, PFS = true;   // the keys of a round and the source of the next one are requested ahead (measured: 2.14 -> 1.99 ms per cnn inference with, 2.10 without)
+    static_assert(NG == 1 || NG == 2, "three and four groups (768 / 1024 threads) spill and were measured slower");
+    static_assert(!INV || NG == 2, "the inverse sub-transforms are the work of two groups");
+    u64 xn[8];
+    if constexpr (PFS) {
+        if (g < a.nb) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xn[e] = st[(long)g * a.digit_stride + limb + t + 256 * e];
+        }
+    }
+    for (int r = 0; r * NG < a.nb; ++r) {
+        const int dg = r * NG + g;
+        const bool active = dg < a.nb;
+        gcptr src = st + (long)dg * a.digit_stride + limb;
+        // (PF) the keys of the round are requested before the transform: the products do not wait for a second global round trip behind the last barrier
+        u64 kv0[PF ? NG : 1][CPT], kv1[PF ? NG : 1][CPT];
+        if constexpr (PF) {
+#pragma unroll
+            for (int dd = 0; dd < NG; ++dd) {
+                const int dig = r * NG + dd;
+                const long ko = (long)(dig < a.nb ? dig : 0) * a.digit_stride + limb;
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    const int pos = (int)threadIdx.x + j * TALL;
+                    kv0[dd][j] = k0[ko + pos];
+                    kv1[dd][j] = nk > 1 ? k1[ko + pos] : 0;
+                }
+            }
+        }
+        if constexpr (PFS) {
+            if (active) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) region[sm_pad(t + 256 * e)] = xn[e];          // (read back by the same thread: no barrier)
+                sm_phase<0, 3, false, false, MODE, 0, LOGM, true>(src, nullptr, region, psi, root, t, md, 0, 0, 1, nullptr, t0);
+            }
+            if (dg + NG < a.nb) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xn[e] = st[(long)(dg + NG) * a.digit_stride + limb + t + 256 * e];
+            }
+        } else if (active) sm_phase<0, 3, true, false, MODE, 0, LOGM, true>(src, nullptr, region, psi, root, t, md, 0, 0, 1, nullptr, t0);
+        __syncthreads();
+        if (active) sm_phase<3, 3, false, false, MODE, 0, LOGM, true>(src, nullptr, region, psi, root, t, md, 0, 0, 1, nullptr, t1);
+        __syncthreads();
+        if (active) sm_phase<6, 3, false, false, MODE, 0, LOGM, true>(src, nullptr, region, psi, root, t, md, 0, 0, 1, nullptr, t2);
+        __syncthreads();
+        if (active) sm_phase<9, 2, false, false, MODE, 1, LOGM, true>(src, nullptr, region, psi, root, t, md, 0, 1, 1, nullptr, t3);   // (skip_norm: an engine-internal form)
+        __syncthreads();
+        // products: this thread's CPT coefficients of every digit of the round
+#pragma unroll
+        for (int dd = 0; dd < NG; ++dd) {
+            const int dig = r * NG + dd;
+            if (dig < a.nb) {
+                const long ko = (long)dig * a.digit_stride + limb;
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    const int pos = (int)threadIdx.x + j * TALL;
+                    const u64 h = lds[dd * SmGeo<LOGM>::LDSW + sm_pad(pos)];
+                    const u64 g0 = PF ? kv0[PF ? dd : 0][j] : k0[ko + pos];
+                    acc0[j] = csub(acc0[j] + mont_mul_lazy(g0, h, q, ninv), q2);
+                    if (nk > 1) { const u64 g1 = PF ? kv1[PF ? dd : 0][j] : k1[ko + pos]; acc1[j] = csub(acc1[j] + mont_mul_lazy(g1, h, q, ninv), q2); }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (INV) {
+        // ... and the inverse sub-transform of each product by one group: what ntt_inv_ldsS_kernel<11> does with the stored product (members of a
+        // merged destination are then summed by the cross pass, ntt_pass8_inv_kernel with NttBatch::sum_in_cross -- the transform is linear)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int pos = (int)threadIdx.x + j * TALL;
+            lds[sm_pad(pos)] = csub(acc0[j], q);
+            if (nk > 1) lds[SmGeo<LOGM>::LDSW + sm_pad(pos)] = csub(acc1[j], q);
+        }
+        __syncthreads();
+        const bool work = g < nk;
+        gcptr psii = (gcptr)(a.psiinv + (long)m * a.N);
+        const u64 ninvR = a.aux[6 * m];
+        u64 i0[7], i1[7], i2[7], i3[NL];
+        if (work) {
+            sm_tw_load<9, 2, LOGM>(psii, root, t, i3); sm_tw_load<6, 3, LOGM>(psii, root, t, i2);
+            sm_tw_load<3, 3, LOGM>(psii, root, t, i1); sm_tw_load<0, 3, LOGM>(psii, root, t, i0);
+            sm_phase<9, 2, false, false, 2, 0, LOGM, true>(nullptr, nullptr, region, psii, root, t, md, 0, 0, 1, nullptr, i3);
+        }
+        __syncthreads();
+        if (work) sm_phase<6, 3, false, false, 2, 0, LOGM, true>(nullptr, nullptr, region, psii, root, t, md, 0, 0, 1, nullptr, i2);
+        __syncthreads();
+        if (work) sm_phase<3, 3, false, false, 2, 0, LOGM, true>(nullptr, nullptr, region, psii, root, t, md, 0, 0, 1, nullptr, i1);
+        __syncthreads();
+        if (work) sm_phase<0, 3, false, true, 2, 2, LOGM, true>(nullptr, (gptr)(a.out[v][g] + limb), region, psii, root, t, md, ninvR, 0, 1, nullptr, i0);
+    } else {
+    u64* o0 = a.out[v][0] + limb; u64* o1 = a.out[v][1];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int pos = (int)threadIdx.x + j * TALL;
+        o0[pos] = csub(acc0[j], q);
+        if (nk > 1) o1[limb + pos] = csub(acc1[j], q);
+    }
+    }
+}
+template <int NG, bool INV>
+__global__ void __launch_bounds__(NG * 256) ext_fused_lds_kernel(ExtFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
+    const int part = blockIdx.x, m = a.map[blockIdx.y], v = blockIdx.z;
+    const Mod md = a.mods[m];
+    if ((a.small_mask >> m) & 1) extf_body<NG, 1, INV>(a, sm_lds, md, m, part, v);
+    else extf_body<NG, 0, INV>(a, sm_lds, md, m, part, v);
 }
 
 static NttBatch in_place_of_dst(const NttBatch& b) {
@@ -1152,6 +1295,32 @@ void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
         case 15: launch_inv_t<15>(b, st); break;
         default: break;
     }
+}
+
+void launch_ntt_cross8_dec(const NttBatch& b, int logN, hipStream_t st) {
+    if (b.nslots <= 0 || b.nouter <= 0) return;
+    const dim3 grid(((1 << logN) / 8 + SPLIT_THREADS - 1) / SPLIT_THREADS, b.nslots * b.nouter);
+    hipLaunchKernelGGL(ntt_pass8_fwd_kernel<true>, grid, dim3(SPLIT_THREADS), 0, st, b, logN);
+}
+void launch_ext_fused_lds(const ExtFusedArgs& a, hipStream_t st) {
+    if (a.logN != 14 || a.nv < 1 || a.nv > EXTF_MAX_V || a.nb < 1 || a.N != (1 << a.logN)) throw std::runtime_error("mkhe: internal: ext_fused_lds_kernel outside its shape");
+    for (int v = 0; v < a.nv; ++v) if (a.nk[v] < 1 || a.nk[v] > 2) throw std::runtime_error("mkhe: internal: ext_fused_lds_kernel takes one or two keys per vector");
+    const int ng = a.nb >= 2 ? 2 : 1;
+    if (a.inv && (ng != 2 || !a.psiinv || !a.aux)) throw std::runtime_error("mkhe: internal: ext_fused_lds_kernel with inverse sub-transforms outside its shape");
+    const size_t lds = (size_t)ng * SmGeo<11>::LDSW * sizeof(u64);
+    const dim3 grid(1 << (a.logN - 11), a.nslots, a.nv);
+    if (a.inv) hipLaunchKernelGGL((ext_fused_lds_kernel<2, true>), grid, dim3(512), lds, st, a);
+    else if (ng == 2) hipLaunchKernelGGL((ext_fused_lds_kernel<2, false>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((ext_fused_lds_kernel<1, false>), grid, dim3(256), lds, st, a);
+}
+// the cross stages of an inverse launch whose sub-transforms were done by ext_fused_lds_kernel<2, true>: in place on dst, the members of a merged
+// destination summed at the load
+void launch_ntt_inv_cross8_sum(const NttBatch& b, int logN, hipStream_t st) {
+    if (b.nslots <= 0 || b.nouter <= 0) return;
+    NttBatch e = in_place_of_dst(b);
+    e.lazy_out = b.lazy_out; e.psi = b.psi; e.sum_in_cross = 1;
+    const dim3 grid(((1 << logN) / 8 + SPLIT_THREADS - 1) / SPLIT_THREADS, b.nslots * b.nouter);
+    hipLaunchKernelGGL(ntt_pass8_inv_kernel, grid, dim3(SPLIT_THREADS), 0, st, e, logN);
 }
 
 }  // namespace mkhe
