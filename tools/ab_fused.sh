@@ -10,12 +10,12 @@ run() { n=$1; shift
   env "$@" python3 bench.py --scheme cnn --parties 4 --no-cpu > $O/cnn4_$n.json 2> $O/cnn4_$n.err
   env "$@" python3 bench.py --scheme cnn --parties 2 --no-cpu > $O/cnn2_$n.json 2> $O/cnn2_$n.err
   env "$@" python3 bench.py --params PN14QP439 --no-cpu > $O/pn14_$n.json 2> $O/pn14_$n.err; }
-run a_off MKHE_EXT_FUSED_MAX=0
-run b_fwd MKHE_EXT_FUSED_INV=0
-run c_inv MKHE_UNUSED=1
-run d_off MKHE_EXT_FUSED_MAX=0
-run e_fwd MKHE_EXT_FUSED_INV=0
-run f_inv MKHE_UNUSED=1
+run a_150 MKHE_UNUSED=1
+run b_200 MKHE_EXT_FUSED_MAX=200
+run c_300 MKHE_EXT_FUSED_MAX=300
+run d_100 MKHE_EXT_FUSED_MAX=100
+run e_150 MKHE_UNUSED=1
+run f_200 MKHE_EXT_FUSED_MAX=200
 python3 - $O <<'PY'
 import json, sys, glob, os
 for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
