@@ -251,6 +251,65 @@ def test_rotate(pair, hoisted):
     assert (out.download() == ref).all()
 
 
+@pytest.fixture(scope="module")
+def pn14():
+    return Pair(H.PN14QP439, seed=1414)
+
+
+@pytest.mark.parametrize("parties,level", [(1, 0), (1, 5), (2, 1), (3, 2), (4, 0), (4, 3), (4, 4), (4, 5)])
+def test_small_ring_rotate_and_conjugate_every_digit_count(pn14, parties, level):
+    """Rotate / Conjugate of a ciphertext without a hoisted form on the N = 2^14 ring, where the engine leaves its own digits after the cross stages and
+    ext_fused_lds_kernel finishes the transform, multiplies and (two digit groups: level >= 1) runs the inverse sub-transforms in the same kernel
+    (csrc/ntt_kernels.h, ExtFusedArgs): one to six gadget digits (one, two and three rounds of the kernel, the single-group form at level 0), one to four
+    parties (merged destinations of one to four members; 4 parties at level 5 is 192 limbs -- above the limit, the unfused path), input above the
+    output's level.  Bit for bit against the oracle."""
+    pair, mk = pn14, pn14.mk
+    names = ["p%d" % i for i in range(parties)]
+    rot = 5
+    in_level = min(level + 1, pair.maxlevel)
+    h, d = pair.ct(names, in_level)
+    crs_h = H.uniform_swk(pair.rng, pair.ks)
+    pair.params.AddCRS(rot, crs_h)
+    rkset, rk_h = mk.RotationKeySet(), []
+    for i in names:
+        k = H.uniform_swk(pair.rng, pair.ks)
+        rk_h.append(k)
+        rkset.AddRotationKey(mk.RotationKey(pair.params, rot, i, k))
+    out = mk.NewCiphertext(pair.params, names, level)
+    pair.ksw.Rotate(d, rot, rkset, out)
+    ref = pair.ks.rotate(level, pow(5, rot, 2 * pair.N), list(range(parties)), h, rk_h, crs_h)
+    assert (out.download() == ref).all()
+    if parties in (1, 3, 4) and level in (0, 2, 4):
+        ccrs = H.uniform_swk(pair.rng, pair.ks)
+        pair.params.AddCRS(-2, ccrs)
+        ckset, ck_h = mk.ConjugationKeySet(), []
+        for i in names:
+            k = H.uniform_swk(pair.rng, pair.ks)
+            ck_h.append(k)
+            ckset.AddConjugationKey(mk.ConjugationKey(pair.params, i, k))
+        out = mk.NewCiphertext(pair.params, names, level)
+        pair.ksw.Conjugate(d, ckset, out)
+        ref = pair.ks.conjugate(level, 2 * pair.N - 1, list(range(parties)), h, ck_h, ccrs)
+        assert (out.download() == ref).all()
+
+
+@pytest.mark.parametrize("parties,level", [(4, 1), (4, 2), (4, 4), (2, 0), (3, 3)])
+def test_small_ring_mul_and_relin_staged_f2(pn14, parties, level):
+    """MulAndRelin on the N = 2^14 ring below the top level: the digits of the t_i (step F2) are left after the cross stages and the tail batch finishes
+    them inside its product kernel, beside the precomputed step-E products and the NTT-domain tensor term (Context::mr_finish_head / _tail)."""
+    pair, mk = pn14, pn14.mk
+    names = ["p%d" % i for i in range(parties)]
+    h0, d0 = pair.ct(names, level)
+    h1, d1 = pair.ct(names, level)
+    rlk_h, rlk_d = pair.rlk_set(names)
+    u_h = H.uniform_swk(pair.rng, pair.ks)
+    pair.params.AddCRS(-1, u_h)
+    out = mk.NewCiphertext(pair.params, names, level)
+    pair.ksw.MulAndRelin(d0, d1, rlk_d, out)
+    ido, ref = oracle_mul_and_relin(pair, level, names, h0, names, h1, rlk_h, u_h, names)
+    assert ido == out.ids and (out.download() == ref).all()
+
+
 @pytest.mark.parametrize("nP,gamma", [(1, 1), (3, 3), (3, 1)])
 def test_merged_products_other_special_prime_counts(nP, gamma):
     """The merged external products (one inverse NTT of the summed Q limbs, one ModDown tail per destination: csrc/poly_kernels.hip
