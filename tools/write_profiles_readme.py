@@ -131,11 +131,15 @@ def round5_block():
                    "(on PN14QP439 it has: see below)." % (C.get("batch2_identical_to_single"), C.get("batch4_identical_to_single"), C["mulrelin_per_sec_batch2"], C["mulrelin_per_sec_batch4"], pl["value"]))
     if c4:
         cc = c4["config"]
-        out.append("* cnn (4 parties): **%.0f inferences/s, %.2f ms per image** (round 4: 337 / 2.97 ms) — the independent rotate → hoist → MulRelin chains of Convolution / FC1 run as LANES of one launch "
+        out.append("* cnn (4 parties): **%.0f inferences/s, %.2f ms per image** (round 4: 337 / 2.97 ms; 2.15 ms before the fused kernel below) — the independent rotate → hoist → MulRelin chains of Convolution / FC1 run as LANES of one launch "
                    "set on one context (`mkhe_rotate_multi`: each lane its own Galois element and keys; `Evaluator.Lanes`), every `AddNew(x, RotateNew(x, r))` is one engine call (the add on the ModDown's "
                    "store) and the sums over a layer's products one launch (`mkhe_ct_sum`).  Kernel trace, same box (`r5_cnn4_lanes_trace_summary.txt` / `_forks_`): **213 kernels per inference instead of 447**; "
                    "the trace also shows why forks never helped: with 7 forked contexts every kernel ran ALONE (\"alone µs\" = total µs for every kernel) — small kernels of different streams do not overlap on this chip.  "
                    "Per layer (ms, a sync per layer): %s; host issue %.2f ms." % (c4["value"], c4["ms_per_step"], ", ".join("%s %.2f" % (k, v) for k, v in cc.get("layer_ms", {}).items()), cc.get("host_issue_ms", 0)))
+        out.append("* ... and, second half of round 5, **one kernel from the forward sub-transforms through the products to the inverse sub-transforms** for the digits the engine decomposes for its own use "
+                   "(`ext_fused_lds_kernel`, DESIGN.md §8: rotations, conjugations, step F2; launches of up to 150 limbs): 2.14 → 1.94 ms per image with 4 parties, 1.94 → 1.84 with 2, 213 → 191 kernels per inference "
+                   "(`r5_fused_ab.txt`: off / forward half / both halves alternating in one call, the limit in limbs, the digit-group counts that spill; `r5_cnn4_fused_trace_summary.txt`).  "
+                   "631 GPU tests green with the path forced onto every launch it can take, with and without its inverse half (`r5_switch_matrix.txt`, sets `round5_fused_*`).")
     out.append("* Measured and NOT kept (`r5_fuse_pass_ab.txt`, one call, switches library): the 2 / 3 cross stages of the small N = 2^14 NTTs as a dot product at the load (fused forward sub-transform kernel; "
                "inverse pass inside the ModDown kernels) — 627 GPU tests green with it, every line slower (cnn 449 → 392, PN14QP439 6072 → 5418, headline 1364 → 1336): 8 products and 8 loads per word cost more than the launch they save.  "
                "Thresholds of the small-launch forms (`MKHE_NTT_LDS11_MAX`, `MKHE_NTT14_MIN`): the defaults stand (± 1 %).")
