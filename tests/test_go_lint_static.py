@@ -28,9 +28,13 @@ def go_directive():
     return tuple(json.load(open(os.path.join(ROOT, "tests", "golden", "ref_go_signatures.json")))["go_directive"])
 
 
+def ref_arities():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "ref_go_signatures.json")))["arities"]
+
+
 def test_shim_tree_is_clean():
     assert go_directive() == (1, 13)
-    res = lint.lint_tree(SHIM, go=go_directive())
+    res = lint.lint_tree(SHIM, go=go_directive(), ref=ref_arities())
     assert not res, "\n".join("%s: %s" % (os.path.relpath(f, ROOT), p) for f, ps in res.items() for p in ps)
 
 
@@ -106,3 +110,25 @@ def test_features_newer_than_the_modules_go_directive_are_reported():
     assert doctored != src and any("without the `// +build mkhe_gpu` line" in p for p in lint.lint_file("k.go", doctored, go=go))
     doctored = src.replace("func b2i(b bool) C.int {", "func b2i(b bool, _ any) C.int {", 1)
     assert doctored != src and any("`any`" in p for p in lint.lint_file("k.go", doctored, go=go))
+
+
+def test_calls_into_the_reference_with_a_wrong_argument_count_are_reported():
+    """the drop-in calls the reference's own constructors and accessors (NewCiphertext has four parameters in mkckks and two in mkbfv; GetRotationKey two);
+    the golden table carries every function's and method's parameter count, the lint holds the calls against it"""
+    ref = ref_arities()
+    assert ref["mkckks"]["funcs"]["NewCiphertext"] == [[4, 4]] and ref["mkbfv"]["funcs"]["NewCiphertext"] == [[2, 2]]
+    assert ref["mkrlwe"]["methods"]["GetRotationKey"] == [[2, 2]] and ref["mkrlwe"]["funcs"]["NewSwitchingKey"] == [[1, 1]]
+    ev = os.path.join(SHIM, "dropin", "mkckks", "evaluator_gpu.go")
+    text = lint.strip(open(ev).read())
+    bind = set(arities())
+    assert lint.check_ref_calls(text, "mkckks", ref, binding=bind) == []
+    # the checks see the calls they are about
+    assert len(re.findall(r"(?<![A-Za-z0-9_.])NewCiphertext\s*\(", text)) >= 5 and "GetRotationKey(" in text and "mkrlwe.NewHoistedCiphertext(" in text
+    for old, new, what in (("NewCiphertext(eval.params, ct0.IDSet(), ct0.Level(), ct0.Scale)", "NewCiphertext(eval.params, ct0.IDSet(), ct0.Level())", "NewCiphertext called with 3"),
+                           ("rkSet.GetRotationKey(id, uint(rotidx))", "rkSet.GetRotationKey(id)", "method GetRotationKey called with 1"),
+                           ("mkrlwe.NewHoistedCiphertext()", "mkrlwe.NewHoistedCiphertext(eval.params)", "mkrlwe.NewHoistedCiphertext called with 1"),
+                           ("op0.IDSet().Union(op1.IDSet())", "op0.IDSet().Union()", "method Union called with 0")):
+        src = open(ev).read()
+        assert old in src, old
+        probs = lint.check_ref_calls(lint.strip(src.replace(old, new, 1)), "mkckks", ref, binding=bind)
+        assert any(what in p for p in probs), (what, probs)

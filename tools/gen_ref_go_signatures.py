@@ -155,9 +155,27 @@ def build(ref_root):
                 names |= declared_names(open(os.path.join(ref_root, rel)).read())
         declared[pkg] = sorted(names)
     # `declared`: every top-level name of the package's non-test files that stay compiled under the tag -- a drop-in file may not declare one again
+    # `arities`: per package, the parameter counts of EVERY function and method of its non-test files (functions by name, methods by bare name over all
+    # receivers; [min, max], max null for a variadic one) -- what tools/go_lint.py holds the drop-in's calls INTO the reference's packages against
+    arities = {}
+    for pkg in FILES:
+        fn, me = {}, {}
+        for name in sorted(os.listdir(os.path.join(ref_root, pkg))):
+            if not name.endswith(".go") or name.endswith("_test.go"):
+                continue
+            p = parse_go_signatures(open(os.path.join(ref_root, pkg, name)).read())
+            def rng(sig):
+                n = len(sig["params"]); var = n > 0 and sig["params"][-1][1].startswith("...")
+                return [n - 1 if var else n, None if var else n]
+            for k, v in p["funcs"].items():
+                if rng(v) not in fn.setdefault(k, []): fn[k].append(rng(v))
+            for t, ms in p["methods"].items():
+                for k, v in ms.items():
+                    if rng(v) not in me.setdefault(k, []): me[k].append(rng(v))
+        arities[pkg] = {"funcs": fn, "methods": me}
     m = re.search(r"^go\s+(\d+)\.(\d+)", open(os.path.join(ref_root, "go.mod")).read(), flags=re.M)
     # `go_directive`: the language version the module compiles at (go.mod) -- the shim may not use anything newer (tools/go_lint.py)
-    return {"reference": "SNUCP/MKHE-KKLSS", "go_directive": [int(m.group(1)), int(m.group(2))], "files": FILES, "excluded_under_tag": EXCLUDED, "packages": table, "declared": declared}
+    return {"reference": "SNUCP/MKHE-KKLSS", "go_directive": [int(m.group(1)), int(m.group(2))], "arities": arities, "files": FILES, "excluded_under_tag": EXCLUDED, "packages": table, "declared": declared}
 
 
 if __name__ == "__main__":

@@ -13,7 +13,9 @@ Checks, per file (comments, strings and runes are removed by a small lexer first
     "declared and not used": a name that is only ever assigned passes here and fails in Go);
   * calls of the cgo binding's exported wrappers (package mkrlwegpu) from OTHER packages have an argument count some wrapper of that name accepts
     (calls are recognised by their receiver: `g.` after `g := ks.GPU()`, `ks.GPU().`, `eval.gpu().`, `eval.bfv.`, `mkrlwegpu.`); a call of a name the binding
-    does not export through such a receiver is reported too.
+    does not export through such a receiver is reported too;
+  * calls from the drop-in INTO the reference's packages -- `NewCiphertext(...)`, `mkrlwe.NewSwitchingKey(...)`, `.GetRotationKey(...)` -- have an argument
+    count the reference declares for that name (tests/golden/ref_go_signatures.json, `arities`: every function and method of mkrlwe / mkckks / mkbfv).
 tests/test_go_lint_static.py runs it over shim/go and shows on doctored sources that each class of mistake is reported."""
 import glob
 import os
@@ -251,6 +253,41 @@ def version_problems(src, text, go):
     return problems
 
 
+def check_ref_calls(text, pkg, ref, own=(), binding=()):
+    """calls INTO the reference's packages from a drop-in file of package `pkg`: `Name(` (a function of the same package), `mkrlwe.Name(` (a function of
+    that package) and `.Name(` (a method: the bare name over all receivers of mkrlwe / mkckks / mkbfv) against the parameter counts of the golden table
+    (`arities`).  Names the drop-in declares itself (`own`) or the binding exports (`binding`: a call may be the binding's) are left alone."""
+    problems = []
+    def ok(n, spread, ranges):
+        return any((lo <= n and (hi is None or n <= hi)) or (spread and hi is None and n == lo + 1) for lo, hi in ranges)
+    def count(i):
+        j = match_close(text, i, "(", ")")
+        args = [x for x in split_args(text[i + 1:j - 1]) if x.strip()]
+        return len(args), bool(args) and args[-1].rstrip().endswith("...")
+    line = lambda pos: text.count("\n", 0, pos) + 1
+    for m in re.finditer(r"(?<![A-Za-z0-9_.])(?:(mkrlwe|mkckks|mkbfv)\.)?(%s)\s*\(" % IDENT, text):
+        q, name = m.group(1), m.group(2)
+        if text[max(0, m.start() - 5):m.start()].strip().endswith("func"):
+            continue                                             # a declaration, not a call
+        table = ref.get(q or pkg, {}).get("funcs", {})
+        if name in table and (q or name not in own):
+            n, sp = count(m.end() - 1)
+            if not ok(n, sp, table[name]):
+                problems.append("line %d: %s%s called with %d argument(s); the reference declares %s" % (line(m.start()), (q + ".") if q else "", name, n, table[name]))
+    methods = {}
+    for p_ in ("mkrlwe", "mkckks", "mkbfv"):
+        for k, v in ref.get(p_, {}).get("methods", {}).items():
+            methods.setdefault(k, []).extend(v)
+    for m in re.finditer(r"\.(%s)\s*\(" % IDENT, text):
+        name = m.group(1)
+        if name not in methods or name in own or name in binding or re.search(r"\b(mkrlwe|mkckks|mkbfv|mkrlwegpu)$", text[:m.start()]):
+            continue
+        n, sp = count(m.end() - 1)
+        if not ok(n, sp, methods[name]):
+            problems.append("line %d: method %s called with %d argument(s); the reference's methods of that name take %s" % (line(m.start()), name, n, methods[name]))
+    return problems
+
+
 def lint_file(path, src=None, arities=None, ambiguous=(), go=None):
     src = open(path).read() if src is None else src
     text = strip(src)
@@ -276,22 +313,33 @@ def lint_file(path, src=None, arities=None, ambiguous=(), go=None):
     return problems
 
 
-def lint_tree(root, go=None):
+def lint_tree(root, go=None, ref=None):
     files = sorted(glob.glob(os.path.join(root, "**", "*.go"), recursive=True))
     binding = [f for f in files if os.sep + "mkrlwegpu" + os.sep in f]
     arities = wrapper_arities([strip(open(f).read()) for f in binding])
     out = {}
     for f in files:
         inside = f in binding
+        if ref and os.sep + "dropin" + os.sep in f:
+            pkg = os.path.basename(os.path.dirname(f))
+            own = set()
+            for g in glob.glob(os.path.join(os.path.dirname(f), "*.go")):
+                own |= set(re.findall(r"^func\s*(?:\([^)]*\)\s*)?(%s)\s*\(" % IDENT, strip(open(g).read()), flags=re.M))
+            pr = check_ref_calls(strip(open(f).read()), pkg, ref, own=own, binding=set(arities))
+            if pr:
+                out.setdefault(f, []).extend(pr)
         # names the reference's packages (and Go's own) use too: a call `.Name(` in a drop-in file may not be the binding's
         p = lint_file(f, arities=None if inside else arities, go=go)
         if p:
-            out[f] = p
+            out.setdefault(f, []).extend(p)
     return out
 
 
 if __name__ == "__main__":
-    res = lint_tree(sys.argv[1] if len(sys.argv) > 1 else "shim/go", go=tuple(int(x) for x in sys.argv[2].split(".")) if len(sys.argv) > 2 else None)
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_go_signatures.json")
+    import json
+    res = lint_tree(sys.argv[1] if len(sys.argv) > 1 else "shim/go", go=tuple(int(x) for x in sys.argv[2].split(".")) if len(sys.argv) > 2 else None,
+                    ref=json.load(open(gold)).get("arities") if os.path.exists(gold) else None)
     for f, ps in res.items():
         for p in ps:
             print("%s: %s" % (f, p))
