@@ -34,7 +34,8 @@ def ref_arities():
 
 def test_shim_tree_is_clean():
     assert go_directive() == (1, 13)
-    res = lint.lint_tree(SHIM, go=go_directive(), ref=ref_arities())
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_go_signatures.json")))
+    res = lint.lint_tree(SHIM, go=go_directive(), ref=gold["arities"], fields=gold["fields"], declared=gold["declared"])
     assert not res, "\n".join("%s: %s" % (os.path.relpath(f, ROOT), p) for f, ps in res.items() for p in ps)
 
 
@@ -132,3 +133,22 @@ def test_calls_into_the_reference_with_a_wrong_argument_count_are_reported():
         assert old in src, old
         probs = lint.check_ref_calls(lint.strip(src.replace(old, new, 1)), "mkckks", ref, binding=bind)
         assert any(what in p for p in probs), (what, probs)
+
+
+def test_a_misspelt_field_is_reported():
+    """`eval.ksw`, `eval.params`, `rlk.Value`, `ct0.Scale` ... are fields of the reference's structs (golden `fields`: names only); a selector that names nothing
+    the reference, the shim or the short lattigo list declares is a compile error waiting for the first machine with Go"""
+    import glob
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_go_signatures.json")))
+    assert {"ksw", "params", "Scale"} <= set(gold["fields"]["mkckks"]) and {"CRS", "Value", "Decomposer"} <= set(gold["fields"]["mkrlwe"])
+    known = set(lint.LATTIGO_FIELDS) | lint.shim_declared(sorted(glob.glob(os.path.join(SHIM, "**", "*.go"), recursive=True)))
+    for table in (gold["fields"], gold["declared"]):
+        for v in table.values():
+            known |= {x.split(".")[-1] for x in v}
+    ev = os.path.join(SHIM, "dropin", "mkckks", "evaluator_gpu.go")
+    src = open(ev).read()
+    assert lint.check_selectors(lint.strip(src), known) == []
+    for old, new in (("eval.ksw.HostMirror = false", "eval.kws.HostMirror = false"), ("eval.params.CRS[-1]", "eval.params.Crs[-1]"), ("ct0.Scale)", "ct0.Scal)")):
+        assert old in src
+        probs = lint.check_selectors(lint.strip(src.replace(old, new, 1)), known)
+        assert len(probs) == 1 and "selector ." in probs[0], probs

@@ -173,9 +173,30 @@ def build(ref_root):
                 for k, v in ms.items():
                     if rng(v) not in me.setdefault(k, []): me[k].append(rng(v))
         arities[pkg] = {"funcs": fn, "methods": me}
+    # `fields`: per package, the field names of its struct types (embedded types by their type name) -- names only; go_lint holds the drop-in's selectors against them
+    fields = {}
+    for pkg in FILES:
+        names = set()
+        for name in sorted(os.listdir(os.path.join(ref_root, pkg))):
+            if not name.endswith(".go") or name.endswith("_test.go"):
+                continue
+            src = _strip_comments(open(os.path.join(ref_root, pkg, name)).read())
+            for sm in re.finditer(r"^type\s+[A-Za-z_][A-Za-z0-9_]*\s+struct\s*\{(.*?)^\}", src, flags=re.M | re.S):
+                for ln in sm.group(1).split("\n"):
+                    ln = ln.strip()
+                    if not ln:
+                        continue
+                    fm = re.match(r"^((?:[A-Za-z_][A-Za-z0-9_]*\s*,\s*)*[A-Za-z_][A-Za-z0-9_]*)\s+\S", ln)
+                    if fm:
+                        names |= {x.strip() for x in fm.group(1).split(",")}
+                    else:
+                        em = re.match(r"^\*?(?:[A-Za-z_][A-Za-z0-9_]*\.)?([A-Za-z_][A-Za-z0-9_]*)$", ln)
+                        if em:
+                            names.add(em.group(1))
+        fields[pkg] = sorted(names)
     m = re.search(r"^go\s+(\d+)\.(\d+)", open(os.path.join(ref_root, "go.mod")).read(), flags=re.M)
     # `go_directive`: the language version the module compiles at (go.mod) -- the shim may not use anything newer (tools/go_lint.py)
-    return {"reference": "SNUCP/MKHE-KKLSS", "go_directive": [int(m.group(1)), int(m.group(2))], "arities": arities, "files": FILES, "excluded_under_tag": EXCLUDED, "packages": table, "declared": declared}
+    return {"reference": "SNUCP/MKHE-KKLSS", "go_directive": [int(m.group(1)), int(m.group(2))], "arities": arities, "fields": fields, "files": FILES, "excluded_under_tag": EXCLUDED, "packages": table, "declared": declared}
 
 
 if __name__ == "__main__":

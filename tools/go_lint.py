@@ -15,7 +15,9 @@ Checks, per file (comments, strings and runes are removed by a small lexer first
     (calls are recognised by their receiver: `g.` after `g := ks.GPU()`, `ks.GPU().`, `eval.gpu().`, `eval.bfv.`, `mkrlwegpu.`); a call of a name the binding
     does not export through such a receiver is reported too;
   * calls from the drop-in INTO the reference's packages -- `NewCiphertext(...)`, `mkrlwe.NewSwitchingKey(...)`, `.GetRotationKey(...)` -- have an argument
-    count the reference declares for that name (tests/golden/ref_go_signatures.json, `arities`: every function and method of mkrlwe / mkckks / mkbfv).
+    count the reference declares for that name (tests/golden/ref_go_signatures.json, `arities`: every function and method of mkrlwe / mkckks / mkbfv);
+  * every selector of the drop-in that is not a call (`eval.ksw`, `rlk.Value`, `ct0.Scale`, `mkrlwegpu.RelinKeys`) names a field / type / method value that the
+    reference (golden `fields`, `declared`), the shim itself or a short list of lattigo / standard-library names declares.
 tests/test_go_lint_static.py runs it over shim/go and shows on doctored sources that each class of mistake is reported."""
 import glob
 import os
@@ -288,6 +290,24 @@ def check_ref_calls(text, pkg, ref, own=(), binding=()):
     return problems
 
 
+# fields / types of lattigo v2.3.0 and the standard library the shim selects (the module is not vendored: this list is the whole of what is trusted unseen)
+LATTIGO_FIELDS = {"Coeffs", "IsNTT", "Modulus", "MredParams", "BredParams", "NttPsi", "NttPsiInv", "N", "Q", "P", "Poly", "PolyQP", "Ring", "Mutex", "Pool", "Baseconverter",
+                  "GaussianSampler", "Sampler", "Parameters", "KeySwitcher", "TestPN13QP218"}
+
+
+def check_selectors(text, known):
+    """every `.name` that is not a call must be a field / type / method value something declares: the reference's structs and top-level names (golden
+    `fields`, `declared`), the shim's own declarations, or the short lattigo / standard-library list above -- a typo in a field name is a compile error"""
+    problems = []
+    for m in re.finditer(r"\.(%s)\b(?!\s*\()" % IDENT, text):
+        name = m.group(1)
+        if text[m.start() - 1:m.start()].isdigit():
+            continue                                             # a float literal
+        if name not in known:
+            problems.append("line %d: selector .%s names no field, type or method the reference, the shim or the lattigo list declares" % (text.count("\n", 0, m.start()) + 1, name))
+    return problems
+
+
 def lint_file(path, src=None, arities=None, ambiguous=(), go=None):
     src = open(path).read() if src is None else src
     text = strip(src)
@@ -313,10 +333,33 @@ def lint_file(path, src=None, arities=None, ambiguous=(), go=None):
     return problems
 
 
-def lint_tree(root, go=None, ref=None):
+def shim_declared(files):
+    """names the shim's own files declare: struct fields, types, funcs / methods, package-level vars"""
+    names = set()
+    for f in files:
+        t = strip(open(f).read())
+        names |= set(re.findall(r"^func\s*(?:\([^)]*\)\s*)?(%s)\s*\(" % IDENT, t, flags=re.M))
+        names |= set(re.findall(r"^type\s+(%s)" % IDENT, t, flags=re.M))
+        for sm in re.finditer(r"^type\s+%s\s+struct\s*\{(.*?)^\}" % IDENT, t, flags=re.M | re.S):
+            for ln in sm.group(1).split("\n"):
+                fm = re.match(r"^\s*((?:%s\s*,\s*)*%s)\s+\S" % (IDENT, IDENT), ln)
+                if fm:
+                    names |= {x.strip() for x in fm.group(1).split(",")}
+                else:
+                    em = re.match(r"^\s*\*?(?:%s\.)?(%s)\s*$" % (IDENT, IDENT), ln)
+                    if em:
+                        names.add(em.group(1))
+    return names
+
+
+def lint_tree(root, go=None, ref=None, fields=None, declared=None):
     files = sorted(glob.glob(os.path.join(root, "**", "*.go"), recursive=True))
     binding = [f for f in files if os.sep + "mkrlwegpu" + os.sep in f]
     arities = wrapper_arities([strip(open(f).read()) for f in binding])
+    known = set(LATTIGO_FIELDS) | shim_declared(files)
+    for table in (fields or {}), (declared or {}):
+        for v in table.values():
+            known |= {x.split(".")[-1] for x in v}
     out = {}
     for f in files:
         inside = f in binding
@@ -326,6 +369,8 @@ def lint_tree(root, go=None, ref=None):
             for g in glob.glob(os.path.join(os.path.dirname(f), "*.go")):
                 own |= set(re.findall(r"^func\s*(?:\([^)]*\)\s*)?(%s)\s*\(" % IDENT, strip(open(g).read()), flags=re.M))
             pr = check_ref_calls(strip(open(f).read()), pkg, ref, own=own, binding=set(arities))
+            if fields is not None:
+                pr += check_selectors(strip(open(f).read()), known)
             if pr:
                 out.setdefault(f, []).extend(pr)
         # names the reference's packages (and Go's own) use too: a call `.Name(` in a drop-in file may not be the binding's
@@ -339,7 +384,7 @@ if __name__ == "__main__":
     gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_go_signatures.json")
     import json
     res = lint_tree(sys.argv[1] if len(sys.argv) > 1 else "shim/go", go=tuple(int(x) for x in sys.argv[2].split(".")) if len(sys.argv) > 2 else None,
-                    ref=json.load(open(gold)).get("arities") if os.path.exists(gold) else None)
+                    **({k2: json.load(open(gold)).get(k1) for k1, k2 in (("arities", "ref"), ("fields", "fields"), ("declared", "declared"))} if os.path.exists(gold) else {}))
     for f, ps in res.items():
         for p in ps:
             print("%s: %s" % (f, p))
