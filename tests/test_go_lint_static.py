@@ -148,7 +148,7 @@ def test_a_misspelt_field_is_reported():
     ev = os.path.join(SHIM, "dropin", "mkckks", "evaluator_gpu.go")
     src = open(ev).read()
     assert lint.check_selectors(lint.strip(src), known) == []
-    for old, new in (("eval.ksw.HostMirror = false", "eval.kws.HostMirror = false"), ("eval.params.CRS[-1]", "eval.params.Crs[-1]"), ("ct0.Scale)", "ct0.Scal)")):
+    for old, new in (("eval.ksw.HostMirror = false", "eval.kws.HostMirror = false"), ("eval.params.CRS[-1]", "eval.params.Crs[-1]"), ("ct0.Scale == 0", "ct0.Scal == 0")):
         assert old in src
         probs = lint.check_selectors(lint.strip(src.replace(old, new, 1)), known)
         assert len(probs) == 1 and "selector ." in probs[0], probs
