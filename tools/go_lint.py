@@ -301,7 +301,7 @@ def check_selectors(text, known):
     problems = []
     for m in re.finditer(r"\.(%s)\b(?!\s*\()" % IDENT, text):
         name = m.group(1)
-        if text[m.start() - 1:m.start()].isdigit():
+        if re.search(r"(?<![A-Za-z0-9_])[0-9]+$", text[max(0, m.start() - 24):m.start()]):
             continue                                             # a float literal
         if name not in known:
             problems.append("line %d: selector .%s names no field, type or method the reference, the shim or the lattigo list declares" % (text.count("\n", 0, m.start()) + 1, name))
