@@ -310,13 +310,14 @@ def test_small_ring_mul_and_relin_staged_f2(pn14, parties, level):
     assert ido == out.ids and (out.download() == ref).all()
 
 
-@pytest.mark.parametrize("nP,gamma", [(1, 1), (3, 3), (3, 1)])
-def test_merged_products_other_special_prime_counts(nP, gamma):
+@pytest.mark.parametrize("nP,gamma,logN", [(1, 1, 11), (3, 3, 11), (3, 1, 11), (1, 1, 14), (3, 3, 14)])
+def test_merged_products_other_special_prime_counts(nP, gamma, logN):
     """The merged external products (one inverse NTT of the summed Q limbs, one ModDown tail per destination: csrc/poly_kernels.hip
     moddown_merged_kernel<nP>) with one and three special primes -- alpha = 1 and alpha = 3 -- on a 3-party MulAndRelin with equal id sets
     (destinations with three and two products) and a Rotate (keyswitch_hoisted.go:44-179, keyswitch.go:234-298)."""
     from gpu_common import Pair, oracle_mul_and_relin
-    pset = dict(logN=11, Q=H.PN16_Q[:4], P=H.PN16_P[:nP], scale=float(1 << 45))
+    # (logN = 14, alpha = 1: the fused sub-transform + product kernel of the small ring with one and three special primes -- ext_fused_lds_kernel)
+    pset = dict(logN=logN, Q=H.PN16_Q[:4], P=H.PN16_P[:nP], scale=float(1 << 45))
     pr = Pair(pset, seed=100 * nP + gamma, gamma=gamma)
     mk, level = pr.mk, pr.maxlevel
     names = ["a", "b", "c"]
