@@ -143,6 +143,10 @@ def round5_block():
     out.append("* Measured and NOT kept (`r5_fuse_pass_ab.txt`, one call, switches library): the 2 / 3 cross stages of the small N = 2^14 NTTs as a dot product at the load (fused forward sub-transform kernel; "
                "inverse pass inside the ModDown kernels) — 627 GPU tests green with it, every line slower (cnn 449 → 392, PN14QP439 6072 → 5418, headline 1364 → 1336): 8 products and 8 loads per word cost more than the launch they save.  "
                "Thresholds of the small-launch forms (`MKHE_NTT_LDS11_MAX`, `MKHE_NTT14_MIN`): the defaults stand (± 1 %).")
+    out.append("* Also measured and not kept, each in one call on the switches library: the tensor chain forked off behind the F1 kernel (`r5_tensor_late_ab.txt`: 1316–1335 → 1243–1258 MulRelin/s); "
+               "small N = 2^15 launches as sixteen 2^11-point sub-transforms behind a radix-16 pass (`r5_pass16_ab.txt`: inverse launch 42 → 51 µs — those launches sum up to five members at their load, ≈ 100 MB); "
+               "the streaming launches reading the limb slots last-written-first for the Infinity Cache (no effect); for the fused small-ring kernel: three / four digit groups, two digits per group and round, "
+               "2^10-point blocks behind a radix-16 pass (`r5_fused_ab.txt`).")
     out.append("* PN16QP1761 line: `cpu_baseline` = the oracle on the 2-party sub-problem whose keys exist on the host (no extrapolation), `gpu_same_subproblem_per_sec` beside it (`r5_bench_pn16.json`).")
     out.append("* The product library reads two environment variables (`MKHE_NTT32`, `MKHE_POOL_GB`); every A/B switch lives in `libmkhe_hip_switches.so` (`r5_switch_matrix.txt`: the GPU suite per switch set on that build).")
     return "\n".join(out) + "\n"
