@@ -1130,9 +1130,9 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
           fa.mods = d_mods; fa.map = map_qp(level); fa.psi = d_psi; fa.digit_stride = (long)item_words;
           for (int m2 = 0; m2 < mall && m2 < 64; ++m2) if (small_q_[m2]) fa.small_mask |= 1ull << m2;
           fa.nb = nb; fa.nslots = nslots; fa.N = N; fa.logN = logN;
-          // every product of the launch made here, two digit groups, no NTT-domain summand (rotations, conjugations): the inverse sub-transforms as well
+          // every product of the launch made here, no NTT-domain summand (rotations, conjugations): the inverse sub-transforms as well
           static const int inv_env = MKHE_AB_INT("MKHE_EXT_FUSED_INV", 1);
-          fused_inv = inv_env && nb >= 2;
+          fused_inv = inv_env != 0;
           for (int i = 0; i < n; ++i) fused_inv = fused_inv && !it[i].pre && !it[i].qadd;
           if (fused_inv) { fa.inv = 1; fa.psiinv = d_psiinv; fa.aux = d_inv_aux; }
           launch_ext_fused_lds(fa, s_);

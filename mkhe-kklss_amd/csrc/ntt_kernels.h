@@ -169,7 +169,7 @@ struct ExtFusedArgs {
     const u64* psiinv;                     // inv != 0: the inverse twiddles [nmod][N] and
     const u64* aux;                        // the inverse constants (NttBatch::aux)
     int inv;                               // the products leave the kernel after their inverse 2^11-point sub-transforms ([0, 2q), N^-1 folded in): the
-                                           // caller follows with launch_ntt_inv_cross8_sum instead of launch_ntt_inv (two digit groups, nb >= 2)
+                                           // caller follows with launch_ntt_inv_cross8_sum instead of launch_ntt_inv (always two groups of threads)
     long digit_stride;
     int nb, nslots, N, logN, nv;
 };

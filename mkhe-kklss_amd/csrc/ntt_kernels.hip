@@ -1305,8 +1305,8 @@ void launch_ntt_cross8_dec(const NttBatch& b, int logN, hipStream_t st) {
 void launch_ext_fused_lds(const ExtFusedArgs& a, hipStream_t st) {
     if (a.logN != 14 || a.nv < 1 || a.nv > EXTF_MAX_V || a.nb < 1 || a.N != (1 << a.logN)) throw std::runtime_error("mkhe: internal: ext_fused_lds_kernel outside its shape");
     for (int v = 0; v < a.nv; ++v) if (a.nk[v] < 1 || a.nk[v] > 2) throw std::runtime_error("mkhe: internal: ext_fused_lds_kernel takes one or two keys per vector");
-    const int ng = a.nb >= 2 ? 2 : 1;
-    if (a.inv && (ng != 2 || !a.psiinv || !a.aux)) throw std::runtime_error("mkhe: internal: ext_fused_lds_kernel with inverse sub-transforms outside its shape");
+    const int ng = (a.nb >= 2 || a.inv) ? 2 : 1;       // (one digit with the inverse half: the second group idles through the forward round and takes the second product's inverse)
+    if (a.inv && (!a.psiinv || !a.aux)) throw std::runtime_error("mkhe: internal: ext_fused_lds_kernel with inverse sub-transforms outside its shape");
     const size_t lds = (size_t)ng * SmGeo<11>::LDSW * sizeof(u64);
     const dim3 grid(1 << (a.logN - 11), a.nslots, a.nv);
     if (a.inv) hipLaunchKernelGGL((ext_fused_lds_kernel<2, true>), grid, dim3(512), lds, st, a);
