@@ -201,3 +201,21 @@ def test_dropin_declares_no_name_the_package_already_has():
                 for n in gen.declared_names(s):
                     assert n not in seen, "%s declared in %s and %s" % (n, seen[n], f)
                     seen[n] = f
+
+
+def test_patches_apply_to_the_reference(tmp_path):
+    """where the reference is mounted (the build container): `patch --dry-run` of every shipped patch against the files it names -- what install.sh does on a
+    maintainer's checkout.  Skipped on the GPU box (no /root/reference there)."""
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(ref) or shutil.which("patch") is None:
+        pytest.skip("no reference tree / no patch(1) here")
+    for name in sorted(os.listdir(os.path.join(ROOT, "shim", "go", "patches"))):
+        d = open(os.path.join(ROOT, "shim", "go", "patches", name)).read()
+        work = tmp_path / name
+        for rel in re.findall(r"^\+\+\+ b/(\S+)", d, flags=re.M):
+            (work / os.path.dirname(rel)).mkdir(parents=True, exist_ok=True)
+            shutil.copy(os.path.join(ref, rel), work / rel)
+        r = subprocess.run(["patch", "-d", str(work), "-p1", "--forward", "--dry-run"], input=d, capture_output=True, text=True)
+        assert r.returncode == 0, "%s does not apply:\n%s%s" % (name, r.stdout, r.stderr)
