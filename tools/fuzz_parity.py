@@ -5,7 +5,8 @@
 
 For the given number of seconds: draw a ring (N = 2^14 with the PN14QP439 chain -- the ring of the fused small-ring kernel -- or N = 2^12 / 2^13 with a
 reduced chain), a level, one to four parties, an input level at or above the output's, an operation (Rotate, Conjugate, MulAndRelin with random -- equal,
-overlapping, disjoint -- id sets, with or without caller-supplied hoisted forms, plain or with the fused Rescale), run it through the C ABI and through
+overlapping, disjoint -- id sets, with or without caller-supplied hoisted forms, plain or with the fused Rescale; one case in six: mkbfv MulRelinNew or its
+non-hoisted twin on N = 2^12 / 2^13), run it through the C ABI and through
 the CPU oracle on the same seeded inputs, and compare every output word.  Prints one line per case and a summary; exit code 1 on the first mismatch."""
 import os
 import sys
@@ -25,8 +26,31 @@ rng = np.random.default_rng(seed)
 O.set_threads(min(16, os.cpu_count() or 1))
 SETS = {"N14": H.PN14QP439, "N13": H.small_ckks(13, 5), "N12": H.small_ckks(12, 4)}
 pairs = {k: Pair(v, seed=int(rng.integers(1 << 30))) for k, v in SETS.items()}
+import harness_bfv as HB                                 # noqa: E402
+from test_gpu_bfv import BfvPair                          # noqa: E402
+bfv_pairs = {"B12": BfvPair(HB.small_bfv(12, 3), seed=int(rng.integers(1 << 30))), "B13": BfvPair(HB.small_bfv(13, 4), seed=int(rng.integers(1 << 30)))}
 t0, n, counts = time.time(), 0, {}
 while time.time() - t0 < budget:
+    if rng.integers(6) == 0:
+        # mkbfv MulRelinNew / its non-hoisted twin on random id sets (mkbfv/evaluator.go:84-150)
+        ring = ["B12", "B13"][int(rng.integers(2))]
+        bp = bfv_pairs[ring]
+        pool = ["a", "b", "c", "d", "e"]
+        ids0 = sorted(rng.choice(pool, size=int(rng.integers(0, 4)), replace=False).tolist())
+        ids1 = ids0 if rng.integers(3) == 0 else sorted(rng.choice(pool, size=int(rng.integers(0, 4)), replace=False).tolist())
+        alln = sorted(set(ids0) | set(ids1)); idx = {x: i for i, x in enumerate(alln)}
+        h0, c0 = bp.ct(ids0); h1, c1 = (h0, c0) if ids1 is ids0 and rng.integers(2) else bp.ct(ids1)
+        rlk_h, rlk_d = bp.rlk_set(alln)
+        u_h, u_d = bp.swk(); bp.params.CRS[-1] = u_d
+        twin = bool(rng.integers(2))
+        out = bp.ev.mulRelin(c0, c1, rlk_d) if twin else bp.ev.MulRelinNew(c0, c1, rlk_d)
+        ido, ref = bp.bfv.mul_relin_new([idx[i] for i in ids0], h0, [idx[i] for i in ids1], h1, {idx[x]: rlk_h[x] for x in alln}, u_h)
+        ok = out.ids == [alln[i] for i in ido] and bool((out.download() == ref).all())
+        n += 1; counts[(ring, "bfv")] = counts.get((ring, "bfv"), 0) + 1
+        print("%4d %s  %s bfv %s ids %s x %s" % (n, "ok  " if ok else "MISMATCH", ring, "mulRelin" if twin else "MulRelinNew", "".join(ids0) or "-", "".join(ids1) or "-"), flush=True)
+        if not ok:
+            print("seed %d" % seed); sys.exit(1)
+        continue
     ring = ["N14", "N14", "N14", "N13", "N12"][int(rng.integers(5))]
     pr = pairs[ring]; mk = pr.mk
     level = int(rng.integers(0, pr.maxlevel + 1))
