@@ -206,3 +206,25 @@ func (ctx *Context) RotateMulti(in []*Ciphertext, rotidx []int, hoisted []*Switc
 	}
 	must(C.mkhe_rotate_multi(ctx.c, C.int(len(in)), &gal[0], ai, h, r, c, p, ao))
 }
+
+// Sum: out = in[0] + in[1] + ... (mkhe_ct_sum: the AddNew chain over a layer's products, cnn/cnn.go:19-30,58-62, as one launch); out may be in[0].
+func (ctx *Context) Sum(in []*Ciphertext, out *Ciphertext) {
+	if len(in) == 0 {
+		return
+	}
+	a := ctArray(in)
+	defer C.free(unsafe.Pointer(a))
+	must(C.mkhe_ct_sum(ctx.c, C.int(len(in)), a, out.h))
+}
+
+// SetNTTChoice pins the forward kernel of N = 2^15 for one launch shape (limbs per launch; decompose: the Decompose-fused form): choice 0 = two passes,
+// 1 = single pass, -1 = measure again (mkhe_ctx_set_ntt_choice).  limbs = 0 pins every shape not measured yet.  A bench line names its choices in
+// config.ntt_kernel_choice; with them pinned it can be repeated on the same kernels.
+func (ctx *Context) SetNTTChoice(limbs int, decompose bool, choice int) {
+	must(C.mkhe_ctx_set_ntt_choice(ctx.c, C.long(limbs), b2i(decompose), C.int(choice)))
+}
+
+// PoolHeldBytes / PoolTrim: device memory the context's buffer pool holds for reuse, and its release (MKHE_POOL_GB bounds it per device).
+func (ctx *Context) PoolHeldBytes() int64 { return int64(C.mkhe_pool_held_bytes(ctx.c)) }
+func (ctx *Context) PoolTrim()            { must(C.mkhe_pool_trim(ctx.c)) }
+
