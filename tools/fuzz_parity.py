@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random-shape parity run on the GPU box (not part of the test suite: minutes of oracle time):
 
-    gpurun --timeout 900 -- 'python3 tools/fuzz_parity.py 420 > gpurun_out/fuzz.txt'
+    gpurun --timeout 900 -- 'python3 tools/fuzz_parity.py 420 [seed] [wide] > gpurun_out/fuzz.txt'      (wide: alpha = 2 chains and N = 2^15 among the rings)
 
 For the given number of seconds: draw a ring (N = 2^14 with the PN14QP439 chain -- the ring of the fused small-ring kernel -- or N = 2^12 / 2^13 with a
 reduced chain), a level, one to four parties, an input level at or above the output's, an operation (Rotate, Conjugate, MulAndRelin with random -- equal,
@@ -24,11 +24,14 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20261004
 rng = np.random.default_rng(seed)
 O.set_threads(min(16, os.cpu_count() or 1))
-SETS = {"N14": H.PN14QP439, "N13": H.small_ckks(13, 5), "N12": H.small_ckks(12, 4)}
+SETS = {"N14": H.PN14QP439, "N13": H.small_ckks(13, 5), "N12": H.small_ckks(12, 4),
+        # alpha = 2 (CRT-reconstructed digits), and the headline ring with a short chain
+        "A12": H.small_alpha2(12, 5), "A11": H.small_alpha2(11, 4), "N15": H.small_ckks(15, 3)}
 pairs = {k: Pair(v, seed=int(rng.integers(1 << 30))) for k, v in SETS.items()}
 import harness_bfv as HB                                 # noqa: E402
 from test_gpu_bfv import BfvPair                          # noqa: E402
 bfv_pairs = {"B12": BfvPair(HB.small_bfv(12, 3), seed=int(rng.integers(1 << 30))), "B13": BfvPair(HB.small_bfv(13, 4), seed=int(rng.integers(1 << 30)))}
+RINGS = ["N14", "N14", "N14", "N13", "N12"] if len(sys.argv) <= 3 or sys.argv[3] != "wide" else ["N14", "N13", "N12", "A12", "A12", "A11", "N15"]
 t0, n, counts = time.time(), 0, {}
 while time.time() - t0 < budget:
     if rng.integers(6) == 0:
@@ -51,7 +54,7 @@ while time.time() - t0 < budget:
         if not ok:
             print("seed %d" % seed); sys.exit(1)
         continue
-    ring = ["N14", "N14", "N14", "N13", "N12"][int(rng.integers(5))]
+    ring = RINGS[int(rng.integers(len(RINGS)))]
     pr = pairs[ring]; mk = pr.mk
     level = int(rng.integers(0, pr.maxlevel + 1))
     in_level = min(pr.maxlevel, level + int(rng.integers(0, 2)))
