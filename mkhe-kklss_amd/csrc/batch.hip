@@ -107,7 +107,9 @@ void Context::rotate_batch(u64 galEl, const std::vector<const Ct*>& ins, const s
                 if (a == 0) items.back().addend = ins[b]->d;
                 items.push_back(ExtItem{h[b * n + a], crs.d, outs[b]->d + (size_t)(1 + a) * PO, false});
             }
-        ext_batch(level, items, -1, 0, galEl);
+        if (stage) ext_staged_.assign(h.begin() + b0 * n, h.begin() + std::min(B, b0 + per) * n);
+        try { ext_batch(level, items, -1, 0, galEl); } catch (...) { ext_staged_.clear(); staged_open_.clear(); throw; }
+        ext_staged_.clear();
     }
     MKHE_HIP(hipGetLastError());
 }
@@ -185,7 +187,7 @@ void Context::rotate_multi(const std::vector<u64>& galEl, const std::vector<cons
             }
         }
         if (stage) ext_staged_.assign(h.begin() + b0 * n, h.begin() + std::min(B, b0 + per) * n);
-        try { ext_batch(level, items, -1, 0, 0); } catch (...) { ext_staged_.clear(); throw; }
+        try { ext_batch(level, items, -1, 0, 0); } catch (...) { ext_staged_.clear(); staged_open_.clear(); throw; }
         ext_staged_.clear();
     }
     MKHE_HIP(hipGetLastError());

@@ -154,6 +154,8 @@ class Context {
     // 2: back half only (ModDown of the c1 pool filled by the preceding stage-1 call with the same items)
     void ext_batch(int level, const std::vector<ExtItem>& items, int join_before_moddown = -1, int stage = 0, u64 galEl = 0);
     u64* ext_xout_ = nullptr;             // set around the one ext_batch call that carries the x by-product
+    std::vector<const u64*> staged_open_; // digit vectors left after the cross stages that no product kernel has finished yet: an ext_batch that reads one of them as a
+                                          // full transform is an engine bug and throws (round 5: mkhe_rotate_batch did, for one afternoon, on launches only a fuzz run reached)
     std::vector<const u64*> ext_staged_;  // set around the one ext_batch call whose items read digit vectors that decompose_batch left staged (stage_only)
     u64* ext_xout2_ = nullptr;            // ... and the second gadget's x (mkbfv)
     std::vector<u64*> ext_eouts_;                           // a batch's F1 call that computes step E too: where input b's E products go ([n1][mtot][N])

@@ -865,6 +865,7 @@ void Context::ntt(const u64* src, u64* dst, int count, int limbs, int mod_base, 
 // ------------------------------------------------------------------ Decompose (keyswitch.go:49-73)
 void Context::decompose(int level, bool is_ntt, const u64* a, u64* out_swk) {
     check_level(level);
+    staged_open_.erase(std::remove(staged_open_.begin(), staged_open_.end(), (const u64*)out_swk), staged_open_.end());
     const u64* ainv = a;
     if (is_ntt) { ntt(a, invntt_, 1, level + 1, 0, true, false); ainv = invntt_; }
     if (alpha != 1) { decompose_batch(level, {ainv}, {out_swk}); return; }
@@ -991,6 +992,11 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
         b.nouter = n * nb;
         if (stage_only) { ProfScope ps(this, PROF_NTT_DECOMP, 16.0 * N * b.nouter * b.nslots); launch_ntt_cross8_dec(b, logN, s_); }
         else ntt_fwd_launch(b, true);
+        for (int i = 0; i < n; ++i) {
+            const u64* dp = dst[base + i];
+            staged_open_.erase(std::remove(staged_open_.begin(), staged_open_.end(), dp), staged_open_.end());
+            if (stage_only) staged_open_.push_back(dp);
+        }
     }
     MKHE_HIP(hipGetLastError());
 }
@@ -1113,12 +1119,18 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         distinct = ns;
     }
     { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * ny - 1.0) : 0.0) + (xyb ? nb * (1.0 * n + ext_ykeys_.size() - xgroups) : 0.0)));
+      if (ext_staged_.empty()) {
+          for (int i = 0; i < n; ++i)
+              if (!it[i].pre && std::find(staged_open_.begin(), staged_open_.end(), it[i].ah) != staged_open_.end())
+                  throw Error("mkhe: internal: digits left after the cross stages read as a full transform");
+      }
       if (!ext_staged_.empty()) {
           // the items' digit vectors were left after the cross stages (decompose_batch, stage_only): sub-transforms and products in one kernel
           if (xby || xy || xyb || two || (int)ext_staged_.size() > EXTF_MAX_V) throw Error("mkhe: internal: staged digits in a launch that cannot take them");
           ExtFusedArgs fa{};
           fa.nv = (int)ext_staged_.size();
           for (int v = 0; v < fa.nv; ++v) fa.stage[v] = ext_staged_[v];
+          for (int v = 0; v < fa.nv; ++v) staged_open_.erase(std::remove(staged_open_.begin(), staged_open_.end(), ext_staged_[v]), staged_open_.end());
           for (int i = 0; i < n; ++i) {
               if (it[i].pre && !it[i].pre_src) continue;                 // (computed before, in its slot)
               int v = -1;

@@ -1,5 +1,6 @@
 // engine_mulrelin.hip -- Context: MulAndRelin[Hoisted] (steps A-F), its split-phase and limb-sharded forms (engine.hip has the tables, pools and the external-product batch)
 #include "engine.h"
+#include <exception>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -255,7 +256,7 @@ void Context::mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const S
     for (int a = 0; a < n1; ++a) { items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true}); items.back().pre = p.e_done; }
     if (p.x_pending) { join_side(2); p.x_pending = false; }
     if (p.f2_staged) { ext_staged_.clear(); for (int a = 0; a < n0; ++a) ext_staged_.push_back(hoist_slot(2, a).d); }
-    struct Unstage { Context* c; ~Unstage() { c->ext_staged_.clear(); } } unstage{this};
+    struct Unstage { Context* c; ~Unstage() { c->ext_staged_.clear(); if (std::uncaught_exceptions()) c->staged_open_.clear(); } } unstage{this};
     if (p.tens) {
         // the tensor term of every output slot rides on the first product that goes there (see mr_prepare)
         std::vector<const u64*> seen;

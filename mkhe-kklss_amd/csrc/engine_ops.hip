@@ -60,7 +60,7 @@ void Context::rotate_core(const Ct& in, const Swk* const* hoist, const Swk* cons
         if (fused && a == 0) items.back().addend = in.d;
         items.push_back(ExtItem{h[a], crs.d, tmp + (size_t)(1 + a) * PO, false});
     }
-    try { ext_batch(level, items, -1, 0, galEl); } catch (...) { ext_staged_.clear(); throw; }
+    try { ext_batch(level, items, -1, 0, galEl); } catch (...) { ext_staged_.clear(); staged_open_.clear(); throw; }
     ext_staged_.clear();
     MKHE_HIP(hipGetLastError());
 }
@@ -102,7 +102,7 @@ void Context::conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk
         if (a == 0) items.back().addend = tmp;
         items.push_back(ExtItem{ddst[a], crs.d, out.d + (size_t)(1 + a) * PO, false});
     }
-    try { ext_batch(level, items); } catch (...) { ext_staged_.clear(); throw; }
+    try { ext_batch(level, items); } catch (...) { ext_staged_.clear(); staged_open_.clear(); throw; }
     ext_staged_.clear();
     MKHE_HIP(hipGetLastError());
 }

@@ -47,9 +47,11 @@ class Case:
         return [h for h, _ in pairs], self.mkckks.BatchCiphertext([c for _, c in pairs])
 
 
-@pytest.fixture(scope="module")
-def case():
-    return Case(H.small_ckks(12, 4), ["a", "b", "c", "d"], 77)
+@pytest.fixture(scope="module", params=["N12_q4", "N14_pn14"])
+def case(request):
+    # (N14: the ring on which engine-internal Decompose launches go through ext_fused_lds_kernel -- round 5: mkhe_rotate_batch staged its digits there and
+    # then read them as full transforms; every test of this file passed on N = 2^12, tools/fuzz_batch.py found it)
+    return Case({"N12_q4": H.small_ckks(12, 4), "N14_pn14": H.PN14QP439}[request.param], ["a", "b", "c", "d"], 77)
 
 
 @pytest.mark.parametrize("ids0,ids1,B", [(["a", "b"], ["a", "b"], 3), (["a"], ["b", "c"], 2), (["a", "b", "c", "d"], ["a", "b", "c", "d"], 7), ([], ["a"], 2), (["a", "b"], [], 2)])
