@@ -139,7 +139,7 @@ def round5_block():
         out.append("* ... and, second half of round 5, **one kernel from the forward sub-transforms through the products to the inverse sub-transforms** for the digits the engine decomposes for its own use "
                    "(`ext_fused_lds_kernel`, DESIGN.md §8: rotations, conjugations, step F2; launches of up to 150 limbs): 2.14 → 1.94 ms per image with 4 parties, 1.94 → 1.84 with 2, 213 → 191 kernels per inference "
                    "(`r5_fused_ab.txt`: off / forward half / both halves alternating in one call, the limit in limbs, the digit-group counts that spill; `r5_cnn4_fused_trace_summary.txt`).  "
-                   "647 GPU tests green with the path forced onto every launch it can take, with and without its inverse half (`r5_switch_matrix.txt`, sets `round5_fused_*`).")
+                   "684 GPU tests green with the path forced onto every launch it can take, with and without its inverse half (`r5_switch_matrix.txt`, sets `round5_fused_*`).")
     out.append("* Measured and NOT kept (`r5_fuse_pass_ab.txt`, one call, switches library): the 2 / 3 cross stages of the small N = 2^14 NTTs as a dot product at the load (fused forward sub-transform kernel; "
                "inverse pass inside the ModDown kernels) — 627 GPU tests green with it, every line slower (cnn 449 → 392, PN14QP439 6072 → 5418, headline 1364 → 1336): 8 products and 8 loads per word cost more than the launch they save.  "
                "Thresholds of the small-launch forms (`MKHE_NTT_LDS11_MAX`, `MKHE_NTT14_MIN`): the defaults stand (± 1 %).")
