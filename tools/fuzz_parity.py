@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random-shape parity run on the GPU box (not part of the test suite: minutes of oracle time):
 
-    gpurun --timeout 900 -- 'python3 tools/fuzz_parity.py 420 [seed] [wide] > gpurun_out/fuzz.txt'      (wide: alpha = 2 chains and N = 2^15 among the rings)
+    gpurun --timeout 900 -- 'python3 tools/fuzz_parity.py 420 [seed] [wide] > gpurun_out/fuzz.txt'      (wide: alpha = 2 chains and N = 2^15 among the rings; pn15: PN15QP880 only, full chain)
 
 For the given number of seconds: draw a ring (N = 2^14 with the PN14QP439 chain -- the ring of the fused small-ring kernel -- or N = 2^12 / 2^13 with a
 reduced chain), a level, one to four parties, an input level at or above the output's, an operation (Rotate, Conjugate, MulAndRelin with random -- equal,
@@ -31,7 +31,9 @@ pairs = {k: Pair(v, seed=int(rng.integers(1 << 30))) for k, v in SETS.items()}
 import harness_bfv as HB                                 # noqa: E402
 from test_gpu_bfv import BfvPair                          # noqa: E402
 bfv_pairs = {"B12": BfvPair(HB.small_bfv(12, 3), seed=int(rng.integers(1 << 30))), "B13": BfvPair(HB.small_bfv(13, 4), seed=int(rng.integers(1 << 30)))}
-RINGS = ["N14", "N14", "N14", "N13", "N12"] if len(sys.argv) <= 3 or sys.argv[3] != "wide" else ["N14", "N13", "N12", "A12", "A12", "A11", "N15"]
+RINGS = ["N14", "N14", "N14", "N13", "N12"] if len(sys.argv) <= 3 or sys.argv[3] not in ("wide", "pn15") else ["N14", "N13", "N12", "A12", "A12", "A11", "N15"]
+if len(sys.argv) > 3 and sys.argv[3] == "pn15":          # the headline ring with its full chain (seconds of oracle time per case)
+    pairs["PN15"] = Pair(H.PN15QP880, seed=int(rng.integers(1 << 30))); RINGS = ["PN15"]
 t0, n, counts = time.time(), 0, {}
 while time.time() - t0 < budget:
     if rng.integers(6) == 0:
