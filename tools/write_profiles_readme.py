@@ -180,7 +180,7 @@ is launched exactly **2 × (2·(W + K) + 300 + K)** times per command.
 | `{tag}_bench_pn16*.json`, `{tag}_kernel_stats_pn16.csv` | `bench.py --params PN16QP1761 --parties 8` (configs[3] ring on one GPU; the plain run carries `config.device_keys_check`) |
 | `{tag}_bench_cnn2/4.json`, `{tag}_bench_cnn4_batch8/16.json`, `{tag}_bench_cnn2_batch8.json` | `bench.py --scheme cnn --parties 2/4 [--batch B]` (the unbatched lines carry `cpu_baseline`) |
 | `{tag}_bench_pn14.json`, `{tag}_pn14_batch.jsonl`, `{tag}_party_sweep.jsonl` | secondary workloads; `bench.py --params PN14QP439 --batch 4/8/16` |
-| `{tag}_dist_5ranks.json` | `bench.py --gpus 5` with all ranks on the one device of the box (DESIGN.md §7) |
+| `{tag}_dist_5ranks.json` | `MKHE_DIST_BACKEND=gloo MKHE_DIST_ONE_DEVICE=1 python bench.py --gpus 5 --steps 2 --warmup 1`: the N > 1 path with all five ranks on the one device of the box (functional: `matches_single_gpu`; timings meaningless; DESIGN.md §7) |
 | `{tag}_gputests.txt`, `{tag}_switch_matrix.txt` | `pytest -m gpu` with the defaults, and once per switch set of `tools/switch_matrix.sh` (the single-pass kernel forced onto every N = 2^15 launch, measured choice, thresholds at 1, earlier rounds' features off) |
 
 ## Headline (BASELINE.json configs[1]): mkckks 4-party MulRelin, PN15QP880, N = 2^15, 14 Q + 2 P limbs
