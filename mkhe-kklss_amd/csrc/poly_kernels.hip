@@ -968,11 +968,11 @@ void launch_moddown_merged(const ModDownMergedArgs& a_in, hipStream_t st) {
     const int nj = a.level + 1;
     // limb slices per coefficient: every slice repeats the P part (y, v of every member: two Montgomery products and two float64 divisions per member and
     // special prime).  Round 5, after the members' y are summed before the multSum products (the per-limb work halved): at N = 2^15 two slices beat four
-    // (36.5 against 40.2 us per step for the two ModDown launches of the headline MulRelin, same call; 1: 47.9, 3: 37.4, 7: 45.5); the small rings keep four
-    // (their launches need the workgroups).
+    // (36.5 against 40.2 us per step for the two ModDown launches of the headline MulRelin, same call; 1: 47.9, 3: 37.4, 7: 45.5); the small rings too, by less
+    // (cnn 1.910 against 1.918 ms with four, PN14QP439 equal: four alternating pairs in two calls).
     static int cap_env = -1;
     if (cap_env < 0) cap_env = MKHE_AB_INT("MKHE_MDM_BY", 0);
-    const int cap = cap_env > 0 ? cap_env : (a.N >= 32768 ? 2 : 4);
+    const int cap = cap_env > 0 ? cap_env : 2;
     int by = nj < cap ? nj : cap;
     if (a.ngroups * by < 8) by = nj < 8 ? nj : 8;
     const dim3 grid(bx, by, a.ngroups), blk(PW_THREADS);
