@@ -736,7 +736,8 @@ const char* mkhe_prof_name(int cls) {
                                   "ntt32_fwd_kernel<true>  (Decompose, ONE pass per limb: 32 coefficients per thread, one workgroup per CU)", "ntt32_fwd_kernel<false>",
                                   "ntt14_fwd_split_kernel  (N = 2^16 Decompose after decomp_spread4_kernel: four one-pass 2^14-point sub-transforms per limb)",
                                   "ntt_fwd_kernel<N,1,false>", "ntt_fwd_kernel<N,0,false>", "ntt_inv_kernel<N>",
-                                  "inner_product_kernel", "ext_inner_kernel", "moddown[_batch]_kernel", "tensor_kernel", "basis_conv_kernel", "decomp_spread_kernel", "other"};
+                                  "inner_product_kernel", "ext_inner_kernel", "moddown[_batch]_kernel", "tensor_kernel", "basis_conv_kernel", "decomp_spread_kernel",
+                                  "ntt16_f2_kernel  (Decompose of the t_i with the step-F2 products in registers)", "other"};
     static_assert(sizeof(names) / sizeof(names[0]) == Context::PROF_NCLASS, "one name per timing class");
     return (cls >= 0 && cls < Context::PROF_NCLASS) ? names[cls] : "";
 }

@@ -39,7 +39,9 @@ struct ExtItem { const u64* ah; const u64* bg; u64* dst; bool accumulate; const 
                                                  times P) that joins the summed Q parts of the merged batch -- dst = that term + the products */
                  unsigned gal = 0;            /* rotate_multi: this destination's own Galois element (0: the ext_batch call's); same for every product of a destination */
                  const u64* post = nullptr;   /* rotate_multi: polynomial [L][N] added to the finished destination at the STORED (permuted) position --
-                                                 ring.Add(post, Rotate(..)) of AddNew(ct, RotateNew(ct, r)), cnn/cnn.go:33-37 -- by the last product of the destination */ };
+                                                 ring.Add(post, Rotate(..)) of AddNew(ct, RotateNew(ct, r)), cnn/cnn.go:33-37 -- by the last product of the destination */
+                 int f2_party = -1;           /* >= 0: step F2 computed by ntt16_f2_kernel (ntt_kernels.h F2FusedArgs) from the party's t (Context::ext_f2_src_): `ah` is not read */
+                 int f2_key = 0;              /* ... 0: the product with v_i, 1: with the CRS u */ };
 
 typedef unsigned long long seq_t;
 // per handle: (uid of a context, that context's call counter at its latest use of the buffer); `exposed` once the raw device
@@ -157,6 +159,13 @@ class Context {
     std::vector<const u64*> staged_open_; // digit vectors left after the cross stages that no product kernel has finished yet: an ext_batch that reads one of them as a
                                           // full transform is an engine bug and throws (round 5: mkhe_rotate_batch did, for one afternoon, on launches only a fuzz run reached)
     std::vector<const u64*> ext_staged_;  // set around the one ext_batch call whose items read digit vectors that decompose_batch left staged (stage_only)
+    // N = 2^15 (round 6): the tail batch of a MulAndRelin whose F2 products come out of the Decompose NTT of the t_i itself (ntt16_f2_kernel): the t_i by
+    // party, set around that ext_batch call; the items carry ExtItem::f2_party
+    std::vector<const u64*> ext_f2_src_;
+    struct F2Sched { F2Seg* d_segs = nullptr; int nwg = 0, parts = 1; };
+    std::map<long, F2Sched> f2_sched_;                   // by (parties, level): the runs of every workgroup, in device memory
+    const F2Sched& f2_schedule(int nparties, int level);
+    bool f2_fused_ok(int level, int n0, int n1) const;
     u64* ext_xout2_ = nullptr;            // ... and the second gadget's x (mkbfv)
     std::vector<u64*> ext_eouts_;                           // a batch's F1 call that computes step E too: where input b's E products go ([n1][mtot][N])
     int ext_e_slot_ = -1;                                  // >= 0 around the F1 call that computes step E too: first c1 slot of the E products
@@ -230,7 +239,7 @@ class Context {
 
     // ---- per-kernel-class timing with HIP events on the context stream (bench.py roofline leg)
     enum { PROF_NTT_DECOMP = 0, PROF_NTT_DECOMP_BIGQ, PROF_NTT_DECOMP_MIXED, PROF_NTT16_DECOMP, PROF_NTT16_FWD, PROF_NTT32_DECOMP, PROF_NTT32_FWD, PROF_NTT14_SPLIT, PROF_NTT_FWD, PROF_NTT_FWD_BIGQ, PROF_NTT_INV, PROF_INNER, PROF_EXT_INNER,
-           PROF_MODDOWN, PROF_TENSOR, PROF_BASISCONV, PROF_SPREAD, PROF_OTHER, PROF_NCLASS };
+           PROF_MODDOWN, PROF_TENSOR, PROF_BASISCONV, PROF_SPREAD, PROF_NTT_F2, PROF_OTHER, PROF_NCLASS };
     void prof_enable(bool on);
     void prof_collect(double* ms, long* launches, double* alg_bytes);
     void recover();             // after an exception: active stream back to the main stream, plans dropped, both streams drained   // arrays of PROF_NCLASS; syncs and resets
@@ -326,6 +335,8 @@ class Context {
         u64* xfused = nullptr;
         std::vector<const u64*> ykeys;       // non-empty: y is computed inside the F1 kernel from these keys (b_j) and h1 (never stored)
         bool f2_staged = false;              // the digits of the t_i were left after the cross stages (decompose_batch stage_only): the tail batch finishes them
+        bool f2_fused = false;               // N = 2^15: no Decompose launch for the t_i at all -- the tail batch's product kernel is ntt16_f2_kernel
+        const u64* f2_tbuf = nullptr;
         bool e_done = false;                 // ... and so was step E: its products sit in the c1 slots 2 n0 .. 2 n0 + n1 - 1 of the scratch, for the tail batch
     } plan_;
 

@@ -481,6 +481,8 @@ void Context::release_all() noexcept {
                     (void*)kg_small_, (void*)kg_g_, (void*)kg_sk_})
         if (p) (void)hipFree(p);
     for (auto& v : hoist_pool_) for (auto& s : v) if (s.d) (void)hipFree(s.d);
+    for (auto& kv : f2_sched_) if (kv.second.d_segs) (void)hipFree(kv.second.d_segs);
+    f2_sched_.clear();
     { std::vector<u64*> mine; (void)pool_take_all(mine); for (u64* p : mine) (void)hipFree(p); }
     for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto& kv : ntt_tune_) for (int i = 0; i < NttTune::RING; ++i) if (kv.second.e0[i]) (void)hipEventDestroy(kv.second.e0[i]);
@@ -1059,7 +1061,8 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
     const size_t item_words = (size_t)mtot * N;
     if (n < 1 || nslots < 1) return;
     ExtInnerArgs ia{};
-    bool two = false, fused_inv = false;
+    bool two = false, fused_inv = false, any_parts = false;
+    unsigned short f2_parts[EXT_MAX_ITEMS] = {};
     bool xby = ext_xout_ != nullptr && n <= (ext_xout2_ ? 4 : 16);     // (five to sixteen single-gadget items: ext_inner_xwide_kernel)
     const bool xby2 = ext_xout2_ != nullptr;               // mkbfv: both gadgets carry their x
     for (int i = 0; i < n; ++i) {
@@ -1118,13 +1121,42 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         for (int i = 0; i < n; ++i) if (!it[i].pre) { add(ia.ah[i]); add(ia.bg[i]); add(ia.ah2[i]); add(ia.bg2[i]); }
         distinct = ns;
     }
-    { ProfScope ps(this, PROF_EXT_INNER, 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * ny - 1.0) : 0.0) + (xyb ? nb * (1.0 * n + ext_ykeys_.size() - xgroups) : 0.0)));
+    // (the fused F2 launch: every t_i limb once, every key once, the parts of the products out)
+    const bool f2 = !ext_f2_src_.empty();
+    const double f2_bytes = f2 ? 8.0 * N * ((double)ext_f2_src_.size() * nb + (double)nb * nslots * (ext_f2_src_.size() + 1.0) + 2.0 * ext_f2_src_.size() * nslots * f2_schedule((int)ext_f2_src_.size(), level).parts) : 0.0;
+    { ProfScope ps(this, f2 ? PROF_NTT_F2 : PROF_EXT_INNER, f2 ? f2_bytes : 8.0 * N * nslots * ((double)nb * distinct + n + (xby ? nb * (n + (xgroups ? xgroups : 1.0)) * (xby2 ? 2 : 1) : 0.0) + (xy ? nb * (2.0 * ny - 1.0) : 0.0) + (xyb ? nb * (1.0 * n + ext_ykeys_.size() - xgroups) : 0.0)));
       if (ext_staged_.empty()) {
           for (int i = 0; i < n; ++i)
               if (!it[i].pre && std::find(staged_open_.begin(), staged_open_.end(), it[i].ah) != staged_open_.end())
                   throw Error("mkhe: internal: digits left after the cross stages read as a full transform");
       }
-      if (!ext_staged_.empty()) {
+      if (!ext_f2_src_.empty()) {
+          // N = 2^15: the F2 products come out of the Decompose NTT of the t_i itself (ntt16_f2_kernel); every other item of the launch exists already
+          if (xby || xy || xyb || two || !mp || !ext_staged_.empty()) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
+          const int np0 = (int)ext_f2_src_.size();
+          const F2Sched& sc = f2_schedule(np0, level);
+          F2FusedArgs fa{};
+          fa.segs = sc.d_segs; fa.nwg = sc.nwg; fa.c1 = c1; fa.item_words = (long)item_words; fa.digit_stride = (long)item_words;
+          for (int a = 0; a < np0; ++a) { fa.src[a] = ext_f2_src_[a]; fa.item_v[a] = fa.item_u[a] = -1; }
+          int nf2 = 0;
+          for (int i = 0; i < n; ++i) {
+              if (it[i].pre && !it[i].pre_src) continue;
+              const int a = it[i].f2_party;
+              if (a < 0 || a >= np0 || it[i].pre) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
+              if (it[i].f2_key == 0) { fa.kv[a] = it[i].bg; fa.item_v[a] = i; fa.extra_v[a] = n + nf2 * (sc.parts - 1); }
+              else { if (fa.ku && fa.ku != it[i].bg) throw Error("mkhe: internal: fused F2 products with more than one CRS"); fa.ku = it[i].bg; fa.item_u[a] = i; fa.extra_u[a] = n + nf2 * (sc.parts - 1); }
+              f2_parts[i] = (unsigned short)(((n + nf2 * (sc.parts - 1)) << 8) | (sc.parts - 1));
+              ++nf2;
+          }
+          for (int a = 0; a < np0; ++a) if (fa.item_v[a] < 0 || fa.item_u[a] < 0 || !fa.kv[a]) throw Error("mkhe: internal: a party without its two F2 products");
+          if (n + nf2 * (sc.parts - 1) > 255) throw Error("mkhe: internal: too many product parts");
+          fa.mods = d_mods; fa.psi = d_psi; fa.psi31 = d_psi31; fa.psi31n = d_psi31n; fa.u_mods = u_mods_;
+          for (int m2 = 0; m2 < mall && m2 < NTT_MAX_SLOTS; ++m2) { if (small16_[m2]) fa.small_mask |= 1ull << m2; fa.sched[m2] = h16_sched_.empty() ? 15 : h16_sched_[m2]; }
+          { NttBatch q{}; slots_qp(q, level); for (int s2 = 0; s2 < q.nslots; ++s2) fa.mod[s2] = q.mod[s2]; }
+          any_parts = sc.parts > 1;
+          fa.trace = ntt_trace;
+          launch_ntt16_f2(fa, s_);
+      } else if (!ext_staged_.empty()) {
           // the items' digit vectors were left after the cross stages (decompose_batch, stage_only): sub-transforms and products in one kernel
           if (xby || xy || xyb || two || (int)ext_staged_.size() > EXTF_MAX_V) throw Error("mkhe: internal: staged digits in a launch that cannot take them");
           ExtFusedArgs fa{};
@@ -1202,7 +1234,11 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
         for (int v = 0; v < mp->nvi; ++v) {
             b.vi_cnt[v] = mp->cnt[v]; b.vi_extra[v] = mp->qadd[v];
             for (int k = 0; k < VI_MAX; ++k) b.vi_mem[v] |= (unsigned)mp->mem[v][k] << (8 * k);
+            int nsum = mp->qadd[v] ? 1 : 0;
+            for (int k = 0; k < mp->cnt[v]; ++k) nsum += 1 + (f2_parts[mp->mem[v][k]] & 255);
+            if (nsum > VI_SUMS) throw Error("mkhe: internal: more summands than an inverse job adds up at its load");
         }
+        if (any_parts) for (int i = 0; i < n; ++i) b.vi_parts[i] = f2_parts[i];
         b.vi_jobs = mp->nvi * (level + 1) + n * np;
         { ProfScope ps(this, PROF_NTT_INV, 16.0 * N * b.vi_jobs); if (fused_inv) launch_ntt_inv_cross8_sum(b, logN, s_); else ntt_inv_launch(b); }
         return;
@@ -1282,7 +1318,13 @@ void Context::ext_batch(int level, const std::vector<ExtItem>& items, int join_b
     const size_t item_words = (size_t)mtot * N;
     for (size_t base = 0; base < items.size(); base += EXT_MAX_ITEMS) {
         const int n = (int)std::min<size_t>(EXT_MAX_ITEMS, items.size() - base);
-        u64* c1 = scratch(c1b_, c1b_words_, (size_t)n * item_words);
+        int extra = 0;
+        if (!ext_f2_src_.empty()) {
+            int nf2 = 0;
+            for (int i = 0; i < n; ++i) nf2 += items[base + i].f2_party >= 0;
+            extra = nf2 * (f2_schedule((int)ext_f2_src_.size(), level).parts - 1);
+        }
+        u64* c1 = scratch(c1b_, c1b_words_, (size_t)(n + extra) * item_words);
         ExtMerge mp;
         const bool merged = stage == 0 && ext_plan_merge(level, items.data() + base, n, mp);
         if (stage != 2) ext_front(level, items.data() + base, n, c1, merged ? &mp : nullptr);

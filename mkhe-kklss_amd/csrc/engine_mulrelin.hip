@@ -212,14 +212,20 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
         items.push_back(it);
     }
     if (!p.xkeys.empty()) ext_xout_ = p.xfused;          // x = sum_i d_i (.) h(c0_i) comes out of the same pass over h(c0_i)
+    // N = 2^15 (round 6): the digits of the t_i never reach HBM -- no Decompose launch below, the tail batch's product kernel transforms them itself
+    // (ntt16_f2_kernel) -- when every other product of that batch exists by then (step E inside the F1 kernel) and the batch is a merged one
+    static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
+    const bool will_e = !p.ykeys.empty() && fuse_e_env && 2 * n0 + p.n1 <= EXT_MAX_ITEMS;
+    p.f2_fused = n0 > 0 && (will_e || p.n1 == 0) && p.tens != nullptr && f2_fused_ok(level, n0, p.n1);
+    const int f2_extra = p.f2_fused ? 2 * n0 * (f2_schedule(n0, level).parts - 1) : 0;
+    if (p.f2_fused && p.ykeys.empty()) scratch(c1b_, c1b_words_, (size_t)(2 * n0 + p.n1 + f2_extra) * mtot * N);
     if (!p.ykeys.empty()) {
         ext_ykeys_ = p.ykeys; ext_yh_ = p.h1;            // ... and y is computed in it
         // ... and step E: the thread holds x[d] and h(c1_j)[d], so <h(c1_j), x> costs it G more accumulators, and x is never stored nor the h(c1_j) read
         // again by the tail batch -- whose c1 slots 2 n0 .. 2 n0 + n1 - 1 (the E items) are filled here: the scratch is sized for the tail now, so
         // that it is the same allocation then (nothing else of a MulAndRelin touches it in between)
-        static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
-        if (fuse_e_env && 2 * n0 + p.n1 <= EXT_MAX_ITEMS) {
-            scratch(c1b_, c1b_words_, (size_t)(2 * n0 + p.n1) * mtot * N);
+        if (will_e) {
+            scratch(c1b_, c1b_words_, (size_t)(2 * n0 + p.n1 + f2_extra) * mtot * N);
             ext_e_slot_ = 2 * n0;
         }
     }
@@ -227,7 +233,9 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
     p.e_done = ext_e_slot_ >= 0;
     ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1;
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
-    {
+    p.f2_tbuf = tbuf;
+    if (p.f2_fused && !(p.e_done || p.n1 == 0)) throw Error("mkhe: internal: fused F2 products without step E");
+    if (!p.f2_fused) {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
         // (the digits of the t_i are read once, by the two F2 products of their party: a small launch of the small ring leaves them after the cross
@@ -250,13 +258,17 @@ void Context::mr_finish_tail(const Ct& op0, const Ct& op1, const u64* x, const S
     // (the F2 pairs first: grouped four at a time they are the longest blocks of the launch, and the sums are order independent)
     for (int a = 0; a < n0; ++a) {
         if (!rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-        items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v0[a]->d, out.d, true});
-        items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
+        const u64* ht = p.f2_fused ? p.f2_tbuf + (size_t)a * PO : hoist_slot(2, a).d;      // (fused: the digits exist in registers only; `ah` just tells the items apart)
+        items.push_back(ExtItem{ht, rlk_v0[a]->d, out.d, true});
+        if (p.f2_fused) { items.back().f2_party = a; items.back().f2_key = 0; }
+        items.push_back(ExtItem{ht, crs_u.d, out.d + (size_t)(1 + p.slot0[a]) * PO, true});
+        if (p.f2_fused) { items.back().f2_party = a; items.back().f2_key = 1; }
     }
     for (int a = 0; a < n1; ++a) { items.push_back(ExtItem{p.h1[a], x, out.d + (size_t)(1 + p.slot1[a]) * PO, true}); items.back().pre = p.e_done; }
+    if (p.f2_fused) { ext_f2_src_.clear(); for (int a = 0; a < n0; ++a) ext_f2_src_.push_back(p.f2_tbuf + (size_t)a * PO); }
     if (p.x_pending) { join_side(2); p.x_pending = false; }
     if (p.f2_staged) { ext_staged_.clear(); for (int a = 0; a < n0; ++a) ext_staged_.push_back(hoist_slot(2, a).d); }
-    struct Unstage { Context* c; ~Unstage() { c->ext_staged_.clear(); if (std::uncaught_exceptions()) c->staged_open_.clear(); } } unstage{this};
+    struct Unstage { Context* c; ~Unstage() { c->ext_staged_.clear(); c->ext_f2_src_.clear(); if (std::uncaught_exceptions()) c->staged_open_.clear(); } } unstage{this};
     if (p.tens) {
         // the tensor term of every output slot rides on the first product that goes there (see mr_prepare)
         std::vector<const u64*> seen;
@@ -277,6 +289,76 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
                         const Swk& crs_u, Ct& out) {
     mr_finish_head(op0, op1, y, out);
     mr_finish_tail(op0, op1, x, rlk_v0, crs_u, out);
+}
+
+// ------------------------------------------------------------------ the schedule of ntt16_f2_kernel (ntt_kernels.h F2FusedArgs)
+// One workgroup per CU, one round: the kernel lasts as long as its longest workgroup, so the passes -- (party, limb slot, half limb, digit), parties
+// outermost, digits innermost -- are dealt by WEIGHT: a pass under a 59/60-bit modulus carries its partial reductions (MKHE_F2_WRED percent per
+// reduction point of the modulus's schedule; MKHE_F2_BALANCE=0: every pass the same, the cuts then fall on whole and half groups).  A workgroup's
+// passes of one (party, slot, half) are a run = one part of that group's two products; parts = the most any group is cut into (the inverse NTT adds
+// them at its load: VI_SUMS), a group cut into fewer has its last run zero the others.  parts = 0: no schedule within the kernel's limits.
+bool Context::f2_fused_ok(int level, int n0, int n1) const {
+    (void)n1;
+    if (logN != 15 || alpha != 1 || masked_ || is_bfv() || !d_psi31 || !d_psi31n || mall > NTT_MAX_SLOTS || h16_gap_) return false;
+    if (!ntt16_f2_ok(logN, n0, beta(level), nslots_qp(level))) return false;
+    if (ext_merge_members(level) < 2) return false;
+    return const_cast<Context*>(this)->f2_schedule(n0, level).parts >= 1;
+}
+const Context::F2Sched& Context::f2_schedule(int np0, int level) {
+    const long key = ((long)np0 << 8) | level;
+    auto found = f2_sched_.find(key);
+    if (found != f2_sched_.end()) return found->second;
+    F2Sched sc;
+    const int nb = beta(level), G = ntt16_f2_grid();
+    NttBatch q{};
+    slots_qp(q, level);
+    const int nslots = q.nslots, ngroups = np0 * nslots * 2;
+    static const int balance = MKHE_AB_INT("MKHE_F2_BALANCE", 0), wred = MKHE_AB_INT("MKHE_F2_WRED", 5);
+    std::vector<long> w(nslots, 100);
+    for (int s2 = 0; s2 < nslots && balance; ++s2) {
+        const int m = q.mod[s2];
+        if (!small16_[m]) w[s2] = 100 + (long)wred * __builtin_popcount((h16_sched_.empty() ? 15u : (unsigned)h16_sched_[m]) & 15u);
+    }
+    long W = 0;
+    for (int g = 0; g < ngroups; ++g) W += w[(g / 2) % nslots] * nb;
+    // pass -> workgroup by the midpoint of its weight interval; runs = maximal stretches of one group inside one workgroup
+    struct Run { int wg, g, d0, nd; };
+    std::vector<Run> runs;
+    long cum = 0;
+    for (int g = 0; g < ngroups; ++g)
+        for (int d = 0; d < nb; ++d) {
+            const long wi = w[(g / 2) % nslots];
+            int wg = (int)(((2 * cum + wi) * (long)G) / (2 * W));
+            if (wg >= G) wg = G - 1;
+            cum += wi;
+            if (!runs.empty() && runs.back().wg == wg && runs.back().g == g) ++runs.back().nd;
+            else runs.push_back(Run{wg, g, d, 1});
+        }
+    std::vector<int> per_wg(G, 0), per_g(ngroups, 0);
+    bool ok = W > 0 && nb <= 255 && np0 <= F2_MAX_P && nslots <= NTT_MAX_SLOTS;
+    for (const Run& r : runs) { if (++per_wg[r.wg] > F2_SEGS) ok = false; ++per_g[r.g]; }
+    int parts = 0;
+    for (int g = 0; g < ngroups; ++g) parts = std::max(parts, per_g[g]);
+    // four members of a merged destination (out_0) x their parts + the tensor term at the load of one inverse job
+    if (parts < 1 || VI_MAX * parts + 1 > VI_SUMS) ok = false;
+    if (ok) {
+        std::vector<F2Seg> segs((size_t)G * F2_SEGS, F2Seg{});
+        std::vector<int> nseg(G, 0), seen(ngroups, 0);
+        int nwg = 0;
+        for (const Run& r : runs) {
+            F2Seg& sg = segs[(size_t)r.wg * F2_SEGS + nseg[r.wg]++];
+            sg.party = (unsigned char)(r.g / (2 * nslots)); sg.slot = (unsigned char)((r.g / 2) % nslots); sg.half = (unsigned char)(r.g & 1);
+            sg.d0 = (unsigned char)r.d0; sg.nd = (unsigned char)r.nd; sg.part = (unsigned char)seen[r.g]++;
+            sg.pad0 = (unsigned char)(seen[r.g] == per_g[r.g] ? parts - per_g[r.g] : 0);      // the group's last run zeroes the parts the group does not have
+            nwg = std::max(nwg, r.wg + 1);
+        }
+        MKHE_HIP(hipSetDevice(device));
+        MKHE_HIP(hipMalloc(&sc.d_segs, segs.size() * sizeof(F2Seg)));
+        const hipError_t e = hipMemcpy(sc.d_segs, segs.data(), segs.size() * sizeof(F2Seg), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(sc.d_segs); sc.d_segs = nullptr; MKHE_HIP(e); }
+        sc.nwg = nwg; sc.parts = parts;
+    } else { sc.parts = 0; sc.nwg = 0; }
+    return f2_sched_.emplace(key, sc).first->second;
 }
 
 // ------------------------------------------------------------------ limb-sharded MulAndRelin (see engine.h)

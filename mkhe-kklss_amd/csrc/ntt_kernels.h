@@ -120,7 +120,12 @@ struct NttBatch {
     const u64* vi_extra[NTT_MAX_ITEMS];
     int vi_cnt[NTT_MAX_ITEMS];
     unsigned int vi_mem[NTT_MAX_ITEMS];          // item index of member k in bits 8k .. 8k+7 (32-bit lists: see ModDownMergedArgs)
+    // Products that reach the launch in PARTS (ntt16_f2_kernel: one partial sum per run of digits): item i of the buffer holds part 0, the items
+    // (vi_parts[i] >> 8) + k, k < (vi_parts[i] & 255), the others -- canonical residues of the same limbs, all of them summands of the item's jobs
+    // (Q slots: of its group's sum; P slots: of the member's own limb, so that the lift sees the whole product).  0 = the item is complete.
+    unsigned short vi_parts[NTT_MAX_ITEMS];
 };
+constexpr int VI_SUMS = 3 * VI_MAX + 1;   // summands an inverse job may have at its load: members x parts + the Q-only extra (Context::ext_front keeps to it)
 
 // small_q[m] != 0 marks moduli with 34q < 2^63 (forward NTT without in-loop reductions).  The forward
 // kernels are specialised per modulus class: split_ntt_fwd cuts the slots of `b` into one batch per
@@ -173,6 +178,41 @@ struct ExtFusedArgs {
     long digit_stride;
     int nb, nslots, N, logN, nv;
 };
+// N = 2^15, alpha = 1 (round 6): step F2 of MulAndRelin inside the Decompose NTT of the t_i (ntt16_f2_kernels.hip).  The digits of t_i are read exactly
+// once, by the products with v_i and u (mkrlwe/keyswitch_hoisted.go:170-177): a workgroup of ntt16_f2_kernel owns a RUN of digits of one (party, modulus,
+// half limb) -- a segment -- transforms digit after digit as a pass of the H16 kernel does (same modulus for the whole run: the twiddles stay put), and
+// multiplies the sixteen coefficients a thread holds with the two keys into two register accumulators.  The digits never reach HBM (470 MB written and
+// read per 4-party MulRelin on PN15QP880) and the streaming launch that read them is gone; what leaves the kernel are the canonical partial sums of the
+// runs, one c1 item per (product, part): part 0 in the product's own item, parts 1.. in the items extra[product] + part - 1, and the inverse NTT that
+// follows adds the parts of a product at its load (NttBatch::vi_parts) -- sums of canonical residues of the same limb: the same integers as
+// ext_inner_kernel on the stored digits.  The schedule (which workgroup walks which runs) is a host table balanced by the cost of the modulus classes.
+constexpr int F2_MAX_P = 16;    // parties of op0
+constexpr int F2_SEGS = 2;      // runs per workgroup (a run of fewer digits than a vector has crosses at most one group boundary)
+struct F2Seg { unsigned char party, slot, half, d0, nd, part, pad0, pad1; };      // nd = 0: no run
+struct F2FusedArgs {
+    const F2Seg* segs;              // device, [nwg][F2_SEGS]
+    const u64* src[F2_MAX_P];       // t_p in the coefficient domain, [>= nb][N]: digit d = limb d
+    const u64* kv[F2_MAX_P];        // v_p [digit][mtot][N], Montgomery form
+    const u64* ku;                  // the CRS u
+    u64* c1;                        // products [item][mtot][N]
+    int item_v[F2_MAX_P], item_u[F2_MAX_P];       // c1 item of part 0 of <h(t_p), v_p> / <h(t_p), u>
+    int extra_v[F2_MAX_P], extra_u[F2_MAX_P];     // c1 item of part 1 (parts 2.. follow)
+    long item_words, digit_stride;
+    const Mod* mods;
+    const u64* psi;                 // [nmod][N] forward twiddles (phase D: two-round product)
+    const u64* psi31;               // [nmod][N][2] pairs of the one-round products
+    const u64* psi31n;              // [nmod][4][2] pairs of -psi[1..3]
+    unsigned long long u_mods;      // bit m: modulus m is of the U class
+    unsigned long long small_mask;  // bit m: 48 q < 2^62 (no partial reductions)
+    alignas(4) unsigned char sched[NTT_MAX_SLOTS];   // NttBatch::sched
+    int mod[NTT_MAX_SLOTS];         // limb slot -> modulus index
+    int nwg;
+    u64* trace;                     // diagnostic (make trace): [workgroup][wave][pass][16] shader-clock stamps; normally NULL
+};
+bool ntt16_f2_ok(int logN, int nparties, int nb, int nslots);
+// digits a workgroup walks per unit of time for a modulus of the class (U, in between, 59/60-bit): the weights of the schedule
+void launch_ntt16_f2(const F2FusedArgs& a, hipStream_t st);
+int ntt16_f2_grid();                // workgroups the schedule should be cut for (one per CU)
 void launch_ntt_cross8_dec(const NttBatch& b, int logN, hipStream_t st);
 void launch_ext_fused_lds(const ExtFusedArgs& a, hipStream_t st);
 void launch_ntt_inv_cross8_sum(const NttBatch& b, int logN, hipStream_t st);

@@ -219,7 +219,7 @@ typedef const __attribute__((address_space(4))) NttBatch* kargptr;
 // Returns the number of source limbs to add up (1 everywhere but in the Q slots of a merged inverse launch, NttBatch::vi: the
 // group's members and its Q-only extra summand; 0 = this job does not exist: a P slot of a member the group does not have).
 template <bool VI = false>
-__device__ __forceinline__ int job_pointers(const NttBatch& b, int job, gcptr& src, gptr& dst, int& m, int& outer) {
+__device__ __forceinline__ int job_pointers(const NttBatch& b, int job, gcptr& src, gptr& dst, int& m, int& outer, int* pm = nullptr) {
     kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
     // slot-major job order: consecutive workgroups share a modulus, so at any time the chip works
     // on 2-3 twiddle tables that stay resident in every XCD's L2
@@ -230,11 +230,19 @@ __device__ __forceinline__ int job_pointers(const NttBatch& b, int job, gcptr& s
         const int cnt = kb->vi_cnt[outer];
         const int k = s < b.vi_q ? 0 : (s - b.vi_q) / b.vi_np;
         const bool exists = k < cnt;
-        const long off = (long)((kb->vi_mem[outer] >> (exists ? 8 * k : 0)) & 255u) * b.src_outer + (long)m * b.src_inner;
+        const unsigned mem = kb->vi_mem[outer];
+        const int item = (int)((mem >> (exists ? 8 * k : 0)) & 255u);
+        const long off = (long)item * b.src_outer + (long)m * b.src_inner;
         src = (gcptr)(b.src + off);
         dst = (gptr)(b.dst + off);
-        return !exists ? 0 : (s < b.vi_q ? cnt + (kb->vi_extra[outer] != nullptr ? 1 : 0) : 1);
+        if (pm) *pm = s < b.vi_q ? -1 : k;
+        if (!exists) return 0;
+        if (s >= b.vi_q) return 1 + (int)(kb->vi_parts[item] & 255u);               // P slot: the member's own parts
+        int n = kb->vi_extra[outer] != nullptr ? 1 : 0;
+        for (int j = 0; j < cnt; ++j) n += 1 + (int)(kb->vi_parts[(mem >> (8 * j)) & 255u] & 255u);
+        return n;
     }
+    if (pm) *pm = -1;
     const int p = kb->pos[s];
     const u64* sbase = b.src; u64* dbase = b.dst;
     if (b.nitems > 0) {
@@ -253,6 +261,26 @@ __device__ __forceinline__ long vi_member_offset(const NttBatch& b, int g, int k
     if (k >= kb->vi_cnt[g]) return (long)(((u64)kb->vi_extra[g] - (u64)first) >> 3) + (long)m * b.src_inner;
     const unsigned mem = kb->vi_mem[g];
     return ((long)((mem >> (8 * k)) & 255u) - (long)(mem & 255u)) * b.src_outer;
+}
+// the same with products that arrive in parts (NttBatch::vi_parts): summand k >= 1 of the job whose first summand is `first` (limb m of the group's
+// first member, or of member pm for a P slot).  Q slots (pm < 0): the members in turn, each followed by its further parts, then the Q-only extra.
+__device__ __forceinline__ long vi_summand_offset(const NttBatch& b, int g, int pm, int k, int m, gcptr first) {
+    kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned mem = kb->vi_mem[g];
+    if (pm >= 0) {
+        const int item = (int)((mem >> (8 * pm)) & 255u);
+        return ((long)(kb->vi_parts[item] >> 8) + (k - 1) - (long)item) * b.src_outer;
+    }
+    const int cnt = kb->vi_cnt[g], item0 = (int)(mem & 255u);
+    int kk = k;
+    for (int j = 0; j < cnt; ++j) {
+        const int item = (int)((mem >> (8 * j)) & 255u);
+        const unsigned parts = kb->vi_parts[item];
+        const int np_ = 1 + (int)(parts & 255u);
+        if (kk < np_) return ((long)(kk == 0 ? item : (int)(parts >> 8) + kk - 1) - (long)item0) * b.src_outer;
+        kk -= np_;
+    }
+    return (long)(((u64)kb->vi_extra[g] - (u64)first) >> 3) + (long)m * b.src_inner;
 }
 
 // ------------------------------------------------------------------ forward kernel
@@ -404,7 +432,8 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
     if constexpr (G::LPB == 1) job = __builtin_amdgcn_readfirstlane(job);    // provably wave-uniform: modulus constants and pointers stay in SGPRs
     gcptr src; gptr dst; int m, outer;
     const int half = b.split ? (job & 1) : 0;
-    const int nsum_ = job_pointers<VI>(b, b.split ? (job >> 1) : job, src, dst, m, outer);
+    int pm = -1;
+    const int nsum_ = job_pointers<VI>(b, b.split ? (job >> 1) : job, src, dst, m, outer, &pm);
     const int nsum = VI ? nsum_ : 1;
     if (nsum == 0) {                             // merged launch: a P slot of a member this group does not have
         if constexpr (G::LPB == 1) continue;     // (the whole workgroup shares the job)
@@ -424,7 +453,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::BT) ntt_inv_kernel(NttBatch b) {
         // merged launch, Q slot: the canonical sum of this limb over the group's members
 #pragma unroll 1
         for (int k = 1; k < nsum; ++k) {
-            gcptr sk = src + vi_member_offset(b, outer, k, m, src - half * G::N);
+            gcptr sk = src + vi_summand_offset(b, outer, pm, k, m, src - half * G::N);
 #pragma unroll
             for (int r = 0; r < 32; ++r) x[r] = csub(x[r] + sk[posB(t, r)], q);
         }
@@ -561,7 +590,7 @@ __device__ __forceinline__ void sm_phase(gcptr gsrc, gptr gdst, u64* lds, gcptr 
         for (int a = 0; a < NE; ++a) x[a] = FROM_G ? gsrc[p + a * GL] : lds[sm_pad(p + a * GL)];
         if constexpr (FROM_G && MODE == 2) {
 #pragma unroll
-            for (int k = 1; k <= VI_MAX; ++k)
+            for (int k = 1; k < VI_SUMS; ++k)
                 if (k < nsum) {
 #pragma unroll
                     for (int a = 0; a < NE; ++a) x[a] = csub(x[a] + gsrc[sum_off[k] + p + a * GL], q);
@@ -636,11 +665,12 @@ __global__ void __launch_bounds__(SM_T) __attribute__((amdgpu_waves_per_eu(8, 8)
     extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
     const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
     gcptr src; gptr dst; int m, outer;
-    const int nsum = job_pointers<true>(b, job >> d, src, dst, m, outer);
+    int pm = -1;
+    const int nsum = job_pointers<true>(b, job >> d, src, dst, m, outer, &pm);
     if (nsum == 0) return;                                     // merged launch: no such member (the whole workgroup returns)
-    long sum_off[VI_MAX + 1] = {};
+    long sum_off[VI_SUMS] = {};
 #pragma unroll
-    for (int k = 1; k <= VI_MAX; ++k) if (k < nsum) sum_off[k] = vi_member_offset(b, outer, k, m, src);
+    for (int k = 1; k < VI_SUMS; ++k) if (k < nsum) sum_off[k] = vi_summand_offset(b, outer, pm, k, m, src);
     src += part * SM_M; dst += part * SM_M;
     const int root = (1 << d) + part;
     const Mod md = b.mods[m];
@@ -664,11 +694,12 @@ __global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_inv_ldsS_kernel(NttBatch b
     constexpr int M = 1 << LOGM;
     const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
     gcptr src; gptr dst; int m, outer;
-    const int nsum = job_pointers<true>(b, job >> d, src, dst, m, outer);
+    int pm = -1;
+    const int nsum = job_pointers<true>(b, job >> d, src, dst, m, outer, &pm);
     if (nsum == 0) return;
-    long sum_off[VI_MAX + 1] = {};
+    long sum_off[VI_SUMS] = {};
 #pragma unroll
-    for (int k = 1; k <= VI_MAX; ++k) if (k < nsum) sum_off[k] = vi_member_offset(b, outer, k, m, src);
+    for (int k = 1; k < VI_SUMS; ++k) if (k < nsum) sum_off[k] = vi_summand_offset(b, outer, pm, k, m, src);
     src += part * M; dst += part * M;
     const int root = (1 << d) + part;
     const Mod md = b.mods[m];

@@ -6,7 +6,7 @@ does not know that the asm statement is a load).  Straight-line model: branches 
   python tools/check_inflight.py [extra hipcc flags]     -> exit code 1 if anything is flagged"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "mkhe-kklss_amd", "csrc", "ntt16_kernels.hip")
+src = os.path.join(ROOT, "mkhe-kklss_amd", "csrc", os.environ.get("CHECK_SRC", "ntt16_kernels.hip"))
 asm = "/tmp/check_inflight.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S",
                        "--cuda-device-only", src, "-o", asm] + sys.argv[1:], stderr=subprocess.DEVNULL)
