@@ -663,6 +663,17 @@ def run_single(args):
         vb = valu_bound_leg()
         if vb is not None:
             roofline["valu_bound"] = vb
+            # the dominant kernel OUTSIDE the step: the same launch shape back to back (clock settled under its own load), both forms -- beside `frac`,
+            # which is measured inside the MulRelin where the streaming kernels leave clock headroom under the power cap
+            try:
+                n_limbs = int(round(roofline["alg_bytes_per_launch"] / (16.0 * (1 << pset["logN"]))))
+                key = "%d_limbs" % n_limbs
+                b2b = {kern: 16.0 * (1 << pset["logN"]) * n_limbs / (rec["shipped_us"][key] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                       for kern, rec in vb.items() if isinstance(rec, dict) and "shipped_us" in rec and key in rec["shipped_us"]}
+                if b2b:
+                    roofline["frac_back_to_back"] = b2b
+            except Exception:
+                pass
 
     # ---- device-expanded keys (PN16QP1761: 7.9 GB of key material that never exists on the host) still get an oracle check: the keys of the
     # first two parties and the CRS u are regenerated on the host from the same public seed (oracle/ora_keygen.c restates the Philox

@@ -114,6 +114,7 @@ SIGNATURES = {
     "mkhe_ctx_set_ntt_choice": (C.c_int, [vp, C.c_long, C.c_int, C.c_int]),
     "mkhe_pool_held_bytes": (C.c_longlong, [vp]),
     "mkhe_pool_trim": (C.c_int, [vp]),
+    "mkhe_f2_schedule_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long), C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]),
     "mkhe_prof_nclass": (C.c_int, []),
     "mkhe_prof_name": (C.c_char_p, [C.c_int]),
     "mkhe_prof_collect": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),

@@ -304,6 +304,47 @@ bool Context::f2_fused_ok(int level, int n0, int n1) const {
     if (ext_merge_members(level) < 2) return false;
     return const_cast<Context*>(this)->f2_schedule(n0, level).parts >= 1;
 }
+// the cut itself, a pure function of the shape (also behind mkhe_f2_schedule_probe: tests/test_f2_schedule.py checks on the CPU that every pass of
+// every shape is dealt exactly once).  weights: per limb slot; segs: G * F2_SEGS entries.  Returns the number of workgroups, parts in *parts_out;
+// 0 = the shape has no schedule within the kernel's limits.
+int f2_build_schedule(int np0, int nb, int nslots, const long* weights, int G, F2Seg* segs, int* parts_out) {
+    *parts_out = 0;
+    if (np0 < 1 || np0 > F2_MAX_P || nb < 1 || nb > 255 || nslots < 1 || nslots > NTT_MAX_SLOTS || G < 1) return 0;
+    const int ngroups = np0 * nslots * 2;
+    long W = 0;
+    for (int g = 0; g < ngroups; ++g) { const long wi = weights[(g / 2) % nslots]; if (wi < 1) return 0; W += wi * nb; }
+    // pass -> workgroup by the midpoint of its weight interval; runs = maximal stretches of one group inside one workgroup
+    struct Run { int wg, g, d0, nd; };
+    std::vector<Run> runs;
+    long cum = 0;
+    for (int g = 0; g < ngroups; ++g)
+        for (int d = 0; d < nb; ++d) {
+            const long wi = weights[(g / 2) % nslots];
+            int wg = (int)(((2 * cum + wi) * (long)G) / (2 * W));
+            if (wg >= G) wg = G - 1;
+            cum += wi;
+            if (!runs.empty() && runs.back().wg == wg && runs.back().g == g) ++runs.back().nd;
+            else runs.push_back(Run{wg, g, d, 1});
+        }
+    std::vector<int> per_wg(G, 0), per_g(ngroups, 0);
+    for (const Run& r : runs) { if (++per_wg[r.wg] > F2_SEGS) return 0; ++per_g[r.g]; }
+    int parts = 0;
+    for (int g = 0; g < ngroups; ++g) parts = std::max(parts, per_g[g]);
+    // four members of a merged destination (out_0) x their parts + the tensor term at the load of one inverse job
+    if (parts < 1 || VI_MAX * parts + 1 > VI_SUMS) return 0;
+    for (size_t i = 0; i < (size_t)G * F2_SEGS; ++i) segs[i] = F2Seg{};
+    std::vector<int> nseg(G, 0), seen(ngroups, 0);
+    int nwg = 0;
+    for (const Run& r : runs) {
+        F2Seg& sg = segs[(size_t)r.wg * F2_SEGS + nseg[r.wg]++];
+        sg.party = (unsigned char)(r.g / (2 * nslots)); sg.slot = (unsigned char)((r.g / 2) % nslots); sg.half = (unsigned char)(r.g & 1);
+        sg.d0 = (unsigned char)r.d0; sg.nd = (unsigned char)r.nd; sg.part = (unsigned char)seen[r.g]++;
+        sg.pad0 = (unsigned char)(seen[r.g] == per_g[r.g] ? parts - per_g[r.g] : 0);      // the group's last run zeroes the parts the group does not have
+        nwg = std::max(nwg, r.wg + 1);
+    }
+    *parts_out = parts;
+    return nwg;
+}
 const Context::F2Sched& Context::f2_schedule(int np0, int level) {
     const long key = ((long)np0 << 8) | level;
     auto found = f2_sched_.find(key);
@@ -312,46 +353,17 @@ const Context::F2Sched& Context::f2_schedule(int np0, int level) {
     const int nb = beta(level), G = ntt16_f2_grid();
     NttBatch q{};
     slots_qp(q, level);
-    const int nslots = q.nslots, ngroups = np0 * nslots * 2;
+    const int nslots = q.nslots;
     static const int balance = MKHE_AB_INT("MKHE_F2_BALANCE", 0), wred = MKHE_AB_INT("MKHE_F2_WRED", 5);
     std::vector<long> w(nslots, 100);
     for (int s2 = 0; s2 < nslots && balance; ++s2) {
         const int m = q.mod[s2];
         if (!small16_[m]) w[s2] = 100 + (long)wred * __builtin_popcount((h16_sched_.empty() ? 15u : (unsigned)h16_sched_[m]) & 15u);
     }
-    long W = 0;
-    for (int g = 0; g < ngroups; ++g) W += w[(g / 2) % nslots] * nb;
-    // pass -> workgroup by the midpoint of its weight interval; runs = maximal stretches of one group inside one workgroup
-    struct Run { int wg, g, d0, nd; };
-    std::vector<Run> runs;
-    long cum = 0;
-    for (int g = 0; g < ngroups; ++g)
-        for (int d = 0; d < nb; ++d) {
-            const long wi = w[(g / 2) % nslots];
-            int wg = (int)(((2 * cum + wi) * (long)G) / (2 * W));
-            if (wg >= G) wg = G - 1;
-            cum += wi;
-            if (!runs.empty() && runs.back().wg == wg && runs.back().g == g) ++runs.back().nd;
-            else runs.push_back(Run{wg, g, d, 1});
-        }
-    std::vector<int> per_wg(G, 0), per_g(ngroups, 0);
-    bool ok = W > 0 && nb <= 255 && np0 <= F2_MAX_P && nslots <= NTT_MAX_SLOTS;
-    for (const Run& r : runs) { if (++per_wg[r.wg] > F2_SEGS) ok = false; ++per_g[r.g]; }
+    std::vector<F2Seg> segs((size_t)G * F2_SEGS);
     int parts = 0;
-    for (int g = 0; g < ngroups; ++g) parts = std::max(parts, per_g[g]);
-    // four members of a merged destination (out_0) x their parts + the tensor term at the load of one inverse job
-    if (parts < 1 || VI_MAX * parts + 1 > VI_SUMS) ok = false;
-    if (ok) {
-        std::vector<F2Seg> segs((size_t)G * F2_SEGS, F2Seg{});
-        std::vector<int> nseg(G, 0), seen(ngroups, 0);
-        int nwg = 0;
-        for (const Run& r : runs) {
-            F2Seg& sg = segs[(size_t)r.wg * F2_SEGS + nseg[r.wg]++];
-            sg.party = (unsigned char)(r.g / (2 * nslots)); sg.slot = (unsigned char)((r.g / 2) % nslots); sg.half = (unsigned char)(r.g & 1);
-            sg.d0 = (unsigned char)r.d0; sg.nd = (unsigned char)r.nd; sg.part = (unsigned char)seen[r.g]++;
-            sg.pad0 = (unsigned char)(seen[r.g] == per_g[r.g] ? parts - per_g[r.g] : 0);      // the group's last run zeroes the parts the group does not have
-            nwg = std::max(nwg, r.wg + 1);
-        }
+    const int nwg = f2_build_schedule(np0, nb, nslots, w.data(), G, segs.data(), &parts);
+    if (nwg > 0) {
         MKHE_HIP(hipSetDevice(device));
         MKHE_HIP(hipMalloc(&sc.d_segs, segs.size() * sizeof(F2Seg)));
         const hipError_t e = hipMemcpy(sc.d_segs, segs.data(), segs.size() * sizeof(F2Seg), hipMemcpyHostToDevice);

@@ -795,25 +795,30 @@ template <int X> __device__ __forceinline__ void exchange_inv(u64 (&x)[16], u32*
     for (int r = 0; r < 16; ++r) x[r] = ((u64)rd[woff<X>(r)] << 32) | lo32(x[r]);
     xsync<CROSS>();                  // (cross-wave: the regions are free again before anybody's next write)
 }
-struct JobInv { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* fin; smodptr mp; int root; int nsum; int g, pm, m; gcptr first; };
+struct JobInv { gcptr src; gptr dst; const u64* psi; const u64* psi31; const u64* fin; smodptr mp; int root; int nsum; int g, pm; };
+// NttBatch::vi_parts[item] through a scalar dword load (see ntt_kernels.hip)
+__device__ __forceinline__ unsigned vi_parts_of(kargptr kb, int item) {
+    return (((const __attribute__((address_space(4))) unsigned*)kb->vi_parts)[item >> 1] >> (16 * (item & 1))) & 0xffffu;
+}
 // word offset of summand k >= 1 of a merged job relative to jb.src (ntt_kernels.hip vi_summand_offset: members, their further parts, the Q-only extra)
 __device__ __forceinline__ long inv_summand_offset(const JobInv& jb, int k) {
     kargptr kb = (kargptr)__builtin_amdgcn_kernarg_segment_ptr();
     const unsigned mem = kb->vi_mem[jb.g];
     if (jb.pm >= 0) {
         const int item = (int)((mem >> (8 * jb.pm)) & 255u);
-        return ((long)(kb->vi_parts[item] >> 8) + (k - 1) - (long)item) * kb->src_outer;
+        return ((long)(vi_parts_of(kb, item) >> 8) + (k - 1) - (long)item) * kb->src_outer;
     }
     const int cnt = kb->vi_cnt[jb.g], item0 = (int)(mem & 255u);
     int kk = k;
     for (int j = 0; j < cnt; ++j) {
         const int item = (int)((mem >> (8 * j)) & 255u);
-        const unsigned parts = kb->vi_parts[item];
+        const unsigned parts = vi_parts_of(kb, item);
         const int np_ = 1 + (int)(parts & 255u);
         if (kk < np_) return ((long)(kk == 0 ? item : (int)(parts >> 8) + kk - 1) - (long)item0) * kb->src_outer;
         kk -= np_;
     }
-    return (long)(((u64)kb->vi_extra[jb.g] - (u64)jb.first) >> 3) + (long)jb.m * kb->src_inner;
+    // (the Q-only extra is a plain polynomial: its limb m sits where the first member's does inside its item)
+    return (long)(((u64)kb->vi_extra[jb.g] - (u64)kb->src) >> 3) - (long)item0 * kb->src_outer;
 }
 template <bool UC>
 __device__ __forceinline__ void limb_inv(const JobInv& jb, const bool big_, u32* lds, const int wv) {
@@ -1145,7 +1150,7 @@ __global__ void __launch_bounds__(NT, 8) ntt14_inv_kernel(NttBatch b) {
         int outer = job - s * nouter;
         const int m = kb->mod[s];
         JobInv jb;
-        jb.nsum = 1; jb.g = outer; jb.pm = -1; jb.m = m;
+        jb.nsum = 1; jb.g = outer; jb.pm = -1;
         if (kb->vi) {
             // as ntt_kernels.hip job_pointers<true> / vi_summand_offset
             const int cnt = kb->vi_cnt[outer];
@@ -1157,9 +1162,9 @@ __global__ void __launch_bounds__(NT, 8) ntt14_inv_kernel(NttBatch b) {
             jb.src = (gcptr)(kb->src + off); jb.dst = (gptr)(kb->dst + off);
             if (s < kb->vi_q) {
                 int n = kb->vi_extra[outer] != nullptr ? 1 : 0;
-                for (int j = 0; j < cnt; ++j) n += 1 + (int)(kb->vi_parts[(mem >> (8 * j)) & 255u] & 255u);
+                for (int j = 0; j < cnt; ++j) n += 1 + (int)(vi_parts_of(kb, (mem >> (8 * j)) & 255u) & 255u);
                 jb.nsum = n;
-            } else { jb.pm = k; jb.nsum = 1 + (int)(kb->vi_parts[item] & 255u); }
+            } else { jb.pm = k; jb.nsum = 1 + (int)(vi_parts_of(kb, item) & 255u); }
         } else {
             const int p = kb->pos[s];
             const u64* sbase_ = kb->src; u64* dbase_ = kb->dst;
@@ -1171,7 +1176,6 @@ __global__ void __launch_bounds__(NT, 8) ntt14_inv_kernel(NttBatch b) {
             jb.src = (gcptr)(sbase_ + (long)outer * kb->src_outer + (long)(kb->src_mapped ? m : p) * kb->src_inner);
             jb.dst = (gptr)(dbase_ + (long)outer * kb->dst_outer + (long)(kb->dst_mapped ? m : p) * kb->dst_inner);
         }
-        jb.first = jb.src;
         jb.src += part * HH; jb.dst += part * HH;
         jb.root = (1 << split) + part;
         const long nlimb = (long)HH << split;                     // twiddle words per modulus: the rows of the whole limb

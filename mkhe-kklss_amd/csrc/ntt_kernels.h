@@ -123,7 +123,7 @@ struct NttBatch {
     // Products that reach the launch in PARTS (ntt16_f2_kernel: one partial sum per run of digits): item i of the buffer holds part 0, the items
     // (vi_parts[i] >> 8) + k, k < (vi_parts[i] & 255), the others -- canonical residues of the same limbs, all of them summands of the item's jobs
     // (Q slots: of its group's sum; P slots: of the member's own limb, so that the lift sees the whole product).  0 = the item is complete.
-    unsigned short vi_parts[NTT_MAX_ITEMS];
+    alignas(4) unsigned short vi_parts[NTT_MAX_ITEMS];
 };
 constexpr int VI_SUMS = 3 * VI_MAX + 1;   // summands an inverse job may have at its load: members x parts + the Q-only extra (Context::ext_front keeps to it)
 
@@ -187,7 +187,7 @@ struct ExtFusedArgs {
 // follows adds the parts of a product at its load (NttBatch::vi_parts) -- sums of canonical residues of the same limb: the same integers as
 // ext_inner_kernel on the stored digits.  The schedule (which workgroup walks which runs) is a host table balanced by the cost of the modulus classes.
 constexpr int F2_MAX_P = 16;    // parties of op0
-constexpr int F2_SEGS = 2;      // runs per workgroup (a run of fewer digits than a vector has crosses at most one group boundary)
+constexpr int F2_SEGS = 3;      // runs per workgroup (a run of fewer than twice the digits of a vector touches at most three groups)
 struct F2Seg { unsigned char party, slot, half, d0, nd, part, pad0, pad1; };      // nd = 0: no run
 struct F2FusedArgs {
     const F2Seg* segs;              // device, [nwg][F2_SEGS]
@@ -210,7 +210,7 @@ struct F2FusedArgs {
     u64* trace;                     // diagnostic (make trace): [workgroup][wave][pass][16] shader-clock stamps; normally NULL
 };
 bool ntt16_f2_ok(int logN, int nparties, int nb, int nslots);
-// digits a workgroup walks per unit of time for a modulus of the class (U, in between, 59/60-bit): the weights of the schedule
+int f2_build_schedule(int np0, int nb, int nslots, const long* weights, int G, F2Seg* segs, int* parts_out);      // engine_mulrelin.hip
 void launch_ntt16_f2(const F2FusedArgs& a, hipStream_t st);
 int ntt16_f2_grid();                // workgroups the schedule should be cut for (one per CU)
 void launch_ntt_cross8_dec(const NttBatch& b, int logN, hipStream_t st);

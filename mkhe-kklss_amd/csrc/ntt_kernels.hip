@@ -216,6 +216,10 @@ __device__ __forceinline__ void phase(u64 (&x)[32], gcptr psi, int base, int pre
 // The small per-launch lists are read straight from the kernarg segment (scalar loads): indexing the
 // by-value struct dynamically would make the compiler copy all of it to scratch.
 typedef const __attribute__((address_space(4))) NttBatch* kargptr;
+// NttBatch::vi_parts[item] through a scalar dword load (a 16-bit load of a kernel argument is a VECTOR memory instruction, with a full vmcnt wait behind it)
+__device__ __forceinline__ unsigned vi_parts_of(kargptr kb, int item) {
+    return (((const __attribute__((address_space(4))) unsigned*)kb->vi_parts)[item >> 1] >> (16 * (item & 1))) & 0xffffu;
+}
 // Returns the number of source limbs to add up (1 everywhere but in the Q slots of a merged inverse launch, NttBatch::vi: the
 // group's members and its Q-only extra summand; 0 = this job does not exist: a P slot of a member the group does not have).
 template <bool VI = false>
@@ -237,9 +241,9 @@ __device__ __forceinline__ int job_pointers(const NttBatch& b, int job, gcptr& s
         dst = (gptr)(b.dst + off);
         if (pm) *pm = s < b.vi_q ? -1 : k;
         if (!exists) return 0;
-        if (s >= b.vi_q) return 1 + (int)(kb->vi_parts[item] & 255u);               // P slot: the member's own parts
+        if (s >= b.vi_q) return 1 + (int)(vi_parts_of(kb, item) & 255u);               // P slot: the member's own parts
         int n = kb->vi_extra[outer] != nullptr ? 1 : 0;
-        for (int j = 0; j < cnt; ++j) n += 1 + (int)(kb->vi_parts[(mem >> (8 * j)) & 255u] & 255u);
+        for (int j = 0; j < cnt; ++j) n += 1 + (int)(vi_parts_of(kb, (mem >> (8 * j)) & 255u) & 255u);
         return n;
     }
     if (pm) *pm = -1;
@@ -269,13 +273,13 @@ __device__ __forceinline__ long vi_summand_offset(const NttBatch& b, int g, int 
     const unsigned mem = kb->vi_mem[g];
     if (pm >= 0) {
         const int item = (int)((mem >> (8 * pm)) & 255u);
-        return ((long)(kb->vi_parts[item] >> 8) + (k - 1) - (long)item) * b.src_outer;
+        return ((long)(vi_parts_of(kb, item) >> 8) + (k - 1) - (long)item) * b.src_outer;
     }
     const int cnt = kb->vi_cnt[g], item0 = (int)(mem & 255u);
     int kk = k;
     for (int j = 0; j < cnt; ++j) {
         const int item = (int)((mem >> (8 * j)) & 255u);
-        const unsigned parts = kb->vi_parts[item];
+        const unsigned parts = vi_parts_of(kb, item);
         const int np_ = 1 + (int)(parts & 255u);
         if (kk < np_) return ((long)(kk == 0 ? item : (int)(parts >> 8) + kk - 1) - (long)item0) * b.src_outer;
         kk -= np_;

@@ -295,3 +295,58 @@ def test_single_pass_forward_kernel_on_every_launch_shape(mode, reps):
     assert r.returncode == 0 and "h32 paths ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     choice = int(r.stdout.split("choice")[1].split()[0])
     assert (choice in (0, 1)) if mode == "2" else choice == -1, r.stdout[-300:]
+
+
+# Round 6: step F2 inside the Decompose NTT of the t_i (csrc/ntt16_f2_kernels.hip).  The shipped schedule cuts every group of digits evenly (two parts at
+# four parties); the weighted schedule (MKHE_F2_BALANCE=1) cuts by the cost of the modulus classes -- runs of unequal length, three parts, groups whose
+# last run zeroes the part they do not have -- and MKHE_F2_FUSED=0 is the unfused launch set of round 5: the same bits from all of them.
+SCRIPT_F2 = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import harness as H
+from oracle import oracle as O
+from mkhe_kklss_amd import mkckks, mkrlwe
+p = H.PN15QP880
+ks = O.KeySwitcher(p["logN"], p["Q"], p["P"], 2)
+params = mkckks.Parameters(p["logN"], p["Q"], p["P"], p["scale"], device=0)
+rng = np.random.default_rng(1506)
+N, mods = 1 << p["logN"], p["Q"] + p["P"]
+def swk():
+    out = np.empty((len(p["Q"]), len(mods), N), dtype=np.uint64)
+    for j, q in enumerate(mods):
+        out[:, j] = rng.integers(0, q, (len(p["Q"]), N), dtype=np.uint64)
+    return out
+K = 5
+keys = {i: (swk(), swk(), swk()) for i in range(K)}
+u_h = swk()
+params.AddCRS(-1, u_h)
+rlk = mkrlwe.RelinearizationKeySet(params)
+for i in range(K):
+    rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, "u%%d" %% i, *keys[i]))
+ev = mkckks.NewEvaluator(params)
+for k, level in ((4, 13), (5, 13), (4, 6)):
+    names = ["u%%d" %% i for i in range(k)]
+    def ct():
+        h = np.empty((1 + k, level + 1, N), dtype=np.uint64)
+        for l in range(level + 1):
+            h[:, l] = rng.integers(0, p["Q"][l], (1 + k, N), dtype=np.uint64)
+        return h
+    h0, h1 = ct(), ct()
+    ct0 = mkckks.NewCiphertext(params, names, level, p["scale"]).upload(h0)
+    ct1 = mkckks.NewCiphertext(params, names, level, p["scale"]).upload(h1)
+    got = ev.MulRelinNew(ct0, ct1, rlk).download()
+    ids = list(range(k))
+    _, ref = ks.mul_and_relin(level, ids, h0, ids, h1, {i: keys[i] for i in ids}, u_h)
+    ref = np.stack([ks.ringQ.div_round_last_many(ref[s], 1)[0] for s in range(1 + k)])
+    assert got.shape == ref.shape and (got == ref).all(), (k, level)
+    assert (ev.MulRelinNew(ct0, ct1, rlk).download() == ref).all(), (k, level)
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("env_extra", [dict(MKHE_F2_BALANCE="1", MKHE_F2_WRED="5"), dict(MKHE_F2_BALANCE="1", MKHE_F2_WRED="2"), dict(MKHE_F2_FUSED="0")],
+                         ids=["weighted_cuts", "weighted_cuts_light", "unfused"])
+def test_fused_f2_schedules(env_extra):
+    r = _run(SCRIPT_F2, env_extra)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

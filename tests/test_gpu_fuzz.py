@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_batch.py", 8, 1201, [], 300),
     ("fuzz_parity.py", 12, 1202, ["wide"], 100),
     ("fuzz_circuit.py", 10, 1203, [], 100),
+    ("fuzz_parity.py", 20, 1204, ["pn15"], 4),          # the headline ring with its full chain (seconds of oracle time per case): levels 0-13, 1-4 parties
 ])
 def test_seeded_fuzz_run(script, seconds, seed, extra, least):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), str(seconds), str(seed)] + extra, capture_output=True, text=True, timeout=600)

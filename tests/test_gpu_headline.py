@@ -79,6 +79,49 @@ def test_pn15_four_party_mulrelin_new(pn15):
     assert (ev.MulRelinNew(ct0, ct1, rlk).download() == ref).all()
 
 
+def _mulrelin_case(fix, k0, k1=None, level=None, hoisted=False, ids1=None):
+    """One MulRelinNew (hoist + MulAndRelinHoisted + Rescale) of a k0-party by k1-party ciphertext pair at `level` against the oracle, bit for bit."""
+    from mkhe_kklss_amd import mkrlwe
+    p, ks, params, mk, rng = (fix[k] for k in ("pset", "ks", "params", "mk", "rng"))
+    k1 = k0 if k1 is None else k1
+    level = len(p["Q"]) - 1 if level is None else level
+    ids0 = list(range(k0))
+    ids1 = list(range(k1)) if ids1 is None else ids1
+    allids = sorted(set(ids0) | set(ids1))
+    names = {i: "user%d" % i for i in allids}
+    h0, h1 = _ct(p, rng, k0, level + 1), _ct(p, rng, len(ids1), level + 1)
+    rlk_h, rlk = {}, mkrlwe.RelinearizationKeySet(params)
+    for i in allids:
+        rlk_h[i] = tuple(_swk(p, rng) for _ in range(3))
+        rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, names[i], *rlk_h[i]))
+    u = _swk(p, rng)
+    params.AddCRS(-1, u)
+    ct0 = mk.NewCiphertext(params, [names[i] for i in ids0], level, p["scale"]).upload(h0)
+    ct1 = mk.NewCiphertext(params, [names[i] for i in ids1], level, p["scale"]).upload(h1)
+    ev = mk.NewEvaluator(params)
+    res = ev.MulRelinHoistedNew(ct0, ct1, ev.HoistedForm(ct0), ev.HoistedForm(ct1), rlk) if hoisted else ev.MulRelinNew(ct0, ct1, rlk)
+    oids, ref = ks.mul_and_relin(level, ids0, h0, ids1, h1, rlk_h, u)
+    nb, _ = ks.ckks_nb_rescales(level, p["scale"] * p["scale"], p["scale"])
+    assert res.Level() == level - nb
+    ref = np.stack([ks.ringQ.div_round_last_many(ref[s], nb)[0] for s in range(ref.shape[0])])
+    got = res.download()
+    assert got.shape == ref.shape and (got == ref).all()
+    assert (ev.MulRelinNew(ct0, ct1, rlk).download() == ref).all()      # warm pools, same bits
+
+
+def test_pn15_two_party_mulrelin_new(pn15):
+    """BASELINE.json configs[0] at its own size: the reference benchmark's 2-party MulRelin (mkckks/mkckks_benchmark_test.go:40-44,57-84) on PN15QP880."""
+    _mulrelin_case(pn15, 2)
+
+
+# Step F2 inside the Decompose NTT of the t_i (round 6, csrc/ntt16_f2_kernels.hip): the launches whose schedule differs -- four parties (two runs per
+# group), five (a workgroup's run crosses groups: parts of unequal length), eight (one group per workgroup: no parts), lower levels (fewer digits and
+# limb slots, other cuts), op1 with fewer parties than op0 (step E inside the F1 kernel still), hoisted forms supplied by the caller
+@pytest.mark.parametrize("k0,k1,level,hoisted", [(4, 4, 9, False), (4, 4, 1, False), (4, 2, 13, False), (5, 5, 13, False), (8, 8, 13, False), (6, 6, 5, False), (4, 4, 13, True), (7, 7, 2, False)])
+def test_pn15_fused_f2_shapes(pn15, k0, k1, level, hoisted):
+    _mulrelin_case(pn15, k0, k1, level, hoisted)
+
+
 @pytest.mark.parametrize("parties,drop", [(8, 0), (4, 0), (3, 0), (2, 0), (1, 0), (3, 2), (5, 1)])
 def test_pn15_hoisted_form_launch_classes(pn15, parties, drop):
     """HoistedForm of n components = ONE Decompose launch of n * beta * (level + 1 + nP) limbs:
@@ -320,6 +363,11 @@ def test_pn14_four_party_mulrelin_new(pn14):
     ref = np.stack([ks.ringQ.div_round_last_many(ref[s], nb)[0] for s in range(1 + k)])
     assert res.Level() == level - nb and (res.download() == ref).all()
     assert (ev.MulRelinNew(ct0, ct1, rlk).download() == ref).all()
+
+
+def test_pn14_two_party_mulrelin_new(pn14):
+    """BASELINE.json configs[0]: the reference benchmark's first case -- PN14QP439, 2 parties (mkckks/mkckks_benchmark_test.go:13,40-44)."""
+    _mulrelin_case(pn14, 2)
 
 
 @pytest.mark.parametrize("which", ["pn14", "pn15"])

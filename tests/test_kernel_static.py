@@ -22,6 +22,19 @@ def test_no_instruction_touches_a_register_of_a_load_in_flight(flags, ok):
     assert (r.returncode == 0) == ok, r.stdout[-1500:] + r.stderr[-500:]
 
 
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_fused_f2_kernel_keeps_its_loads_in_flight_untouched():
+    """ntt16_f2_kernel (round 6) holds key words and -- on the U-class path -- ten source pairs of the NEXT digit in flight across its product phase and
+    the loop's back edge, all hand-issued: the same check on its ISA.  (With twelve pairs and four key pairs the allocator spills inside the digit
+    loop, and on the balanced path it spills registers of loads in flight: that path keeps the two-group loads, and this test says if that changes.)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight.py")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, CHECK_SRC="ntt16_f2_kernels.hip"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    res = _kernel_resources("ntt16_f2_kernels.hip")
+    k = [n for n in res if "ntt16_f2_kernel" in n]
+    assert len(k) == 1 and res[k[0]]["vgpr_count"] <= 128, res          # one 1024-thread workgroup per CU: four waves per SIMD
+
+
 def _kernel_resources(src):
     """name -> dict of the code-object metadata (.vgpr_count, .vgpr_spill_count, .sgpr_spill_count, .private_segment_fixed_size) of every kernel of a csrc file"""
     import re
@@ -119,7 +132,7 @@ def test_h32_kernel_fits_one_workgroup_per_cu_without_scratch():
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
-@pytest.mark.parametrize("src", ["ntt16_kernels.hip", "ntt32_kernels.hip"])
+@pytest.mark.parametrize("src", ["ntt16_kernels.hip", "ntt32_kernels.hip", "ntt16_f2_kernels.hip"])
 def test_forward_kernels_read_their_job_constants_with_scalar_loads(src):
     """Round 3 shipped `kb->sched[m]` (a byte of the kernel arguments, dynamic index) in the job walk of every H16-class forward kernel: a byte load
     is a VECTOR memory instruction (global_load_ubyte + v_readfirstlane), and the `s_waitcnt vmcnt(0)` the compiler has to put between the two waits

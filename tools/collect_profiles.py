@@ -61,6 +61,10 @@ with open(os.path.join(P, "%s_sq_counters.txt" % tag), "w") as f:
                 c.get(x, 0) / c["SQ_WAVES"] for x in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SALU")))
         if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
             f.write("   L2 hit rate %.3f\n" % (c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
+# the ablation table must hold numbers (round 5: its variant libraries did not link and nobody noticed)
+_abl = os.path.join(P, "%s_ntt16_ablation.txt" % tag)
+if os.path.exists(_abl) and len(re.findall(r"us/launch", open(_abl).read())) < 8:
+    sys.exit("tools/collect_profiles.py: %s has no timings (variant builds failed on the GPU box?)" % _abl)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ntt16_isa.py"), tag], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ntt32_isa.py"), tag], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_profiles_readme.py"), tag])

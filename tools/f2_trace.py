@@ -59,3 +59,10 @@ span_cyc = (np.where(ok, t[..., 10], 0).max(axis=(1, 2)) - first.min(axis=(1, 2)
 print("workgroup span (shader cycles): mean %.0f  min %.0f  max %.0f" % (span_cyc.mean(), span_cyc.min(), span_cyc.max()))
 print("real-time end spread over workgroups: %.1f us" % ((rt_ok.max(axis=(1, 2)).max() - rt_ok.max(axis=(1, 2)).min()) / 100.0))
 # gap between consecutive passes of one wave (flush / loop overhead / waiting at the next pass's loads is inside stamp 0->1)
+# shader clock during the kernel: cycles between the product-phase ends of consecutive passes of a wave over the real time between them (100 MHz)
+c10, r11 = t[..., 10], t[..., 11]
+okp = ok[..., 1:] & ok[..., :-1]
+dc = (c10[..., 1:] - c10[..., :-1])[okp]; dr = (r11[..., 1:] - r11[..., :-1])[okp]
+good = dr > 0
+print("shader clock inside the kernel: %.3f GHz (median %.3f)" % ((dc[good].sum() / (dr[good].sum() * 10.0)), np.median(dc[good] / (dr[good] * 10.0))))
+print("real time per pass: mean %.2f us" % (dr[good].mean() / 100.0))

@@ -6,13 +6,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 C=$R/mkhe-kklss_amd/csrc
 B=$R/mkhe-kklss_amd/build
 SRC=${SRC:-ntt16_kernels}        # the source the variants re-compile (SRC=ntt32_kernels: the single-pass kernel)
-make -s -C $C -j8 > /dev/null 2>&1
+make -s -C $C -j8 product > /dev/null 2>&1
 run() {
     name=$1; shift
     mkdir -p $B/var_$name
-    for f in ntt_kernels ntt16_kernels ntt32_kernels poly_kernels keygen_kernels engine batch keygen capi; do cp $B/$f.o $B/var_$name/$f.o; done
+    cp $B/*.o $B/var_$name/      # every object of the product build (round 5 copied a stale list: the variant libraries did not link and the table came out empty)
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DMKHE_ABLATION -I$C $* -c $C/$SRC.hip -o $B/var_$name/$SRC.o 2>/dev/null || { echo "$name: build failed"; return; }
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/var_$name/lib.so $B/var_$name/*.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/var_$name/lib.so $B/var_$name/*.o || { echo "$name: link failed"; return; }
     echo "== $name   ($*)"
     MKHE_LIB=$B/var_$name/lib.so python3 $R/tools/ntt16_bench.py ${REPS:-10} 2>&1 | grep -E "limbs +(1792|896) " | cut -c1-150
     rm -rf $B/var_$name

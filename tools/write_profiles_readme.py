@@ -321,5 +321,10 @@ if c2 and c4:
             txt += "; 2 parties B = 8 **%.0f**" % c2b8["value"]
         txt += (" — %.1fx the single-image rate of the same box (VERDICT r3: 3x of 343).  Replaying the batched inference from a HIP graph changes nothing (970 against 961 at B = 8: `hipGraphLaunch` spends on the host what the eager issue does).\n" % (cb8["value"] / c4["value"]))
     txt += "`--gpus N` runs N independent replicas.  Encrypted == plaintext logits, and the device's output ciphertext == the oracle evaluator's: `tests/test_gpu_cnn.py`.\n"
+# a figure that is missing from the tracked files must fail here, not print as "nan" (round 5 shipped three paragraphs of "nan" from an empty table)
+import re as _re
+bad = [l[:140] for l in txt.split("\n") if _re.search(r"(?<![A-Za-z])nan(?![A-Za-z])", l)]
+if bad:
+    sys.exit("tools/write_profiles_readme.py: %d line(s) of profiles/README.md would carry a missing figure (nan):\n  " % len(bad) + "\n  ".join(bad[:8]))
 open(P + "README.md", "w").write(txt)
 print("profiles/README.md written")
