@@ -1132,7 +1132,9 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
       }
       if (!ext_f2_src_.empty()) {
           // N = 2^15: the F2 products come out of the Decompose NTT of the t_i itself (ntt16_f2_kernel); every other item of the launch exists already
-          if (xby || xy || xyb || two || !mp || !ext_staged_.empty()) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
+          bool two_live = false;                     // (mkbfv: the precomputed step-E items of the batch carry their second gadget; nothing here reads them)
+          for (int i = 0; i < n; ++i) two_live = two_live || (!it[i].pre && it[i].ah2);
+          if (xby || xy || xyb || two_live || !mp || !ext_staged_.empty()) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
           const int np0 = (int)ext_f2_src_.size();
           const F2Sched& sc = f2_schedule(np0, level);
           F2FusedArgs fa{};

@@ -260,13 +260,17 @@ void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u
         items.push_back(it);
     }
     if (fused) { ext_xout_ = const_cast<u64*>(x1); ext_xout2_ = const_cast<u64*>(x2); }
-    bool e_done = false;
+    bool e_done = false, f2 = false;
     if (fused && !bfv_yk1_.empty()) {
         ext_ykeys_ = bfv_yk1_; ext_ykeys2_ = bfv_yk2_;
         for (int a = 0; a < n1; ++a) { ext_yh_.push_back(hoist_slot(1, a).d); ext_yh2_.push_back(hoist_slot(4, a).d); }
         static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
         if (fuse_e_env && 2 * n0 + n1 <= EXT_MAX_ITEMS) {
-            scratch(c1b_, c1b_words_, (size_t)(2 * n0 + n1) * mtot * N);
+            // (step F2 is the plain Q gadget here too, keyswitch_hoisted.go:199-204: with step E done by the F1 kernel the digits of the t_i stay in the
+            // registers of ntt16_f2_kernel, as in Context::mr_finish_head; its parts live behind the tail batch's items in this same allocation)
+            f2 = n0 >= 2 && f2_fused_ok(level, n0, n1);
+            const int f2_extra = f2 ? 2 * n0 * (f2_schedule(n0, level).parts - 1) : 0;
+            scratch(c1b_, c1b_words_, (size_t)(2 * n0 + n1 + f2_extra) * mtot * N);
             ext_e_slot_ = 2 * n0;
         }
     }
@@ -278,21 +282,27 @@ void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u
     // F2: ks.Decompose(t_i) ; out_0 += <h(t_i), v_i> ; out_i += <h(t_i), u>
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
-        for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PQ); ddst.push_back(hoist_slot(2, a).d); }
-        if (n0) decompose_batch(level, dsrc, ddst, true);
+        f2 = f2 && e_done;
+        for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PQ); if (!f2) ddst.push_back(hoist_slot(2, a).d); }
+        if (f2) ext_f2_src_.assign(dsrc.begin(), dsrc.end());
+        else if (n0) decompose_batch(level, dsrc, ddst, true);
     }
     // E: out_j += <h(c1_j), (x1,x2)> together with F2
     items.clear();
     // (the F2 pairs first, as in Context::mr_finish_tail: out_0 is the longest ModDown group)
     for (int a = 0; a < n0; ++a) {
-        items.push_back(ExtItem{hoist_slot(2, a).d, rlk_v[a]->d, out.d, true});
-        items.push_back(ExtItem{hoist_slot(2, a).d, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true});
+        const u64* ht = f2 ? tbuf + (size_t)a * PQ : hoist_slot(2, a).d;
+        items.push_back(ExtItem{ht, rlk_v[a]->d, out.d, true});
+        if (f2) { items.back().f2_party = a; items.back().f2_key = 0; }
+        items.push_back(ExtItem{ht, crs_u.d, out.d + (size_t)(1 + slot0[a]) * PQ, true});
+        if (f2) { items.back().f2_party = a; items.back().f2_key = 1; }
     }
     for (int a = 0; a < n1; ++a) {
         ExtItem it{hoist_slot(1, a).d, x1, out.d + (size_t)(1 + slot1[a]) * PQ, true}; it.ah2 = hoist_slot(4, a).d; it.bg2 = x2; it.pre = e_done; items.push_back(it);
     }
     join_side(2);
-    ext_batch(level, items, 1);        // joins the tensor / Quantize chain before the ModDown accumulates into out
+    try { ext_batch(level, items, 1); } catch (...) { ext_f2_src_.clear(); throw; }        // joins the tensor / Quantize chain before the ModDown accumulates into out
+    ext_f2_src_.clear();
     bfv_plan_valid_ = false;
     MKHE_HIP(hipGetLastError());
 }

@@ -299,7 +299,7 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
 // them at its load: VI_SUMS), a group cut into fewer has its last run zero the others.  parts = 0: no schedule within the kernel's limits.
 bool Context::f2_fused_ok(int level, int n0, int n1) const {
     (void)n1;
-    if (logN != 15 || alpha != 1 || masked_ || is_bfv() || !d_psi31 || !d_psi31n || mall > NTT_MAX_SLOTS || h16_gap_) return false;
+    if (logN != 15 || alpha != 1 || masked_ || !d_psi31 || !d_psi31n || mall > NTT_MAX_SLOTS || h16_gap_) return false;
     if (!ntt16_f2_ok(logN, n0, beta(level), nslots_qp(level))) return false;
     if (ext_merge_members(level) < 2) return false;
     return const_cast<Context*>(this)->f2_schedule(n0, level).parts >= 1;

@@ -41,6 +41,7 @@ void Context::rotate_core(const Ct& in, const Swk* const* hoist, const Swk* cons
         else MKHE_HIP(hipMemsetAsync(tmp, 0, PO * sizeof(u64), s_));
     }
     std::vector<const u64*> h(n);
+    bool f2 = false;
     {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (int a = 0; a < n; ++a) {
@@ -49,19 +50,23 @@ void Context::rotate_core(const Ct& in, const Swk* const* hoist, const Swk* cons
             else { Swk& s = hoist_slot(0, a); dsrc.push_back(in.d + (1 + a) * PI); ddst.push_back(s.d); h[a] = s.d; }
         }
         // (a rotation of a ciphertext without a hoisted form: its digits are read once, by the two products below -- small launches finish their
-        // transform inside the product kernel)
-        const bool stage = !hoist && ext_fused_ok(level, (int)dsrc.size());
-        if (!dsrc.empty()) decompose_batch(level, dsrc, ddst, true, stage);
+        // transform inside the product kernel; N = 2^15 launches that fill the chip never store them at all: ntt16_f2_kernel, as step F2 of MulAndRelin)
+        f2 = !hoist && n >= 2 && f2_fused_ok(level, n, 0);
+        const bool stage = !f2 && !hoist && ext_fused_ok(level, (int)dsrc.size());
+        if (f2) { ext_f2_src_.assign(dsrc.begin(), dsrc.end()); for (int a = 0; a < n; ++a) h[a] = dsrc[a]; }
+        else if (!dsrc.empty()) decompose_batch(level, dsrc, ddst, true, stage);
         if (stage) ext_staged_.assign(ddst.begin(), ddst.end());
     }
     std::vector<ExtItem> items;
     for (int a = 0; a < n; ++a) {
         items.push_back(ExtItem{h[a], rk[a]->d, tmp, true});
         if (fused && a == 0) items.back().addend = in.d;
+        if (f2) { items.back().f2_party = a; items.back().f2_key = 0; }
         items.push_back(ExtItem{h[a], crs.d, tmp + (size_t)(1 + a) * PO, false});
+        if (f2) { items.back().f2_party = a; items.back().f2_key = 1; }
     }
-    try { ext_batch(level, items, -1, 0, galEl); } catch (...) { ext_staged_.clear(); staged_open_.clear(); throw; }
-    ext_staged_.clear();
+    try { ext_batch(level, items, -1, 0, galEl); } catch (...) { ext_staged_.clear(); ext_f2_src_.clear(); staged_open_.clear(); throw; }
+    ext_staged_.clear(); ext_f2_src_.clear();
     MKHE_HIP(hipGetLastError());
 }
 
@@ -93,17 +98,21 @@ void Context::conjugate(u64 galEl, const Ct& in, const Swk* const* ck, const Swk
         if (!ck[a]) throw Error("cannot GetConjugationKey: there is no conjugation key with given id");
         dsrc.push_back(tmp + (size_t)(1 + a) * PO); ddst.push_back(hoist_slot(0, a).d);
     }
-    const bool stage = ext_fused_ok(level, n);
-    decompose_batch(level, dsrc, ddst, true, stage);
+    const bool f2 = n >= 2 && f2_fused_ok(level, n, 0);           // (as Rotate: the digits of the permuted polynomials stay in registers)
+    const bool stage = !f2 && ext_fused_ok(level, n);
+    if (f2) ext_f2_src_.assign(dsrc.begin(), dsrc.end());
+    else decompose_batch(level, dsrc, ddst, true, stage);
     if (stage) ext_staged_.assign(ddst.begin(), ddst.end());
     std::vector<ExtItem> items;
     for (int a = 0; a < n; ++a) {
-        items.push_back(ExtItem{ddst[a], ck[a]->d, out.d, true});
+        items.push_back(ExtItem{f2 ? dsrc[a] : ddst[a], ck[a]->d, out.d, true});
         if (a == 0) items.back().addend = tmp;
-        items.push_back(ExtItem{ddst[a], crs.d, out.d + (size_t)(1 + a) * PO, false});
+        if (f2) { items.back().f2_party = a; items.back().f2_key = 0; }
+        items.push_back(ExtItem{f2 ? dsrc[a] : ddst[a], crs.d, out.d + (size_t)(1 + a) * PO, false});
+        if (f2) { items.back().f2_party = a; items.back().f2_key = 1; }
     }
-    try { ext_batch(level, items); } catch (...) { ext_staged_.clear(); staged_open_.clear(); throw; }
-    ext_staged_.clear();
+    try { ext_batch(level, items); } catch (...) { ext_staged_.clear(); ext_f2_src_.clear(); staged_open_.clear(); throw; }
+    ext_staged_.clear(); ext_f2_src_.clear();
     MKHE_HIP(hipGetLastError());
 }
 
