@@ -15,7 +15,9 @@
 //
 // Residency (the engine keeps operands in HBM; the reference passes host structs):
 //   - keys and CRS (*SwitchingKey reached through rlkSet / rkSet / ckSet / Parameters.CRS): uploaded at their first use, found by pointer
-//     afterwards.  A key that is MODIFIED in place after its first use must be dropped with Forget.
+//     afterwards.  A key that is MODIFIED in place after its first use is noticed: every lookup compares a fingerprint of the host struct
+//     (64 words sampled across its digits and limbs, taken at the upload) and uploads again on a mismatch; MKHE_GO_TRUST_RESIDENT=1 skips the
+//     comparison (a caller that never rewrites a key saves 64 loads per key and call), Forget drops a copy explicitly.
 //   - hoisted digit vectors written by Decompose: the device copy is bound to the host *SwitchingKey it was written "into" and is what
 //     ExternalProductHoisted / MulAndRelinHoisted / RotateHoisted read.  HostMirror (default true) also writes the digits into the host
 //     struct, as the reference does -- 56 MiB over PCIe per Decompose at PN15QP880; callers that only pass hoisted forms on (mkckks.Evaluator
@@ -57,6 +59,8 @@ type KeySwitcher struct {
 	gpu      *mkrlwegpu.Context
 	mu       sync.Mutex
 	resident map[uintptr]*mkrlwegpu.SwitchingKey // host *SwitchingKey (as an address: no strong reference) -> device copy
+	prints   map[uintptr]uint64                  // ... -> fingerprint of the host words the copy was uploaded from (absent: a device-born vector, Adopt)
+	trust    bool                                // MKHE_GO_TRUST_RESIDENT=1: no fingerprint comparison at a lookup
 	garbage  []*mkrlwegpu.SwitchingKey          // device copies whose host struct was collected: closed by the next engine call (finalizers run on
 	// their own goroutine, and the calls on one engine context are serialized by its owner)
 }
@@ -71,6 +75,8 @@ func NewKeySwitcher(params Parameters) *KeySwitcher {
 		ks.Device = v
 	}
 	ks.resident = make(map[uintptr]*mkrlwegpu.SwitchingKey)
+	ks.prints = make(map[uintptr]uint64)
+	ks.trust = os.Getenv("MKHE_GO_TRUST_RESIDENT") == "1"
 	return ks
 }
 
@@ -95,6 +101,7 @@ func (ks *KeySwitcher) collected(swk *SwitchingKey) {
 	ks.mu.Lock()
 	if d, ok := ks.resident[key]; ok {
 		delete(ks.resident, key)
+		delete(ks.prints, key)
 		ks.garbage = append(ks.garbage, d)
 	}
 	ks.mu.Unlock()
@@ -128,21 +135,77 @@ func (ks *KeySwitcher) lookup(swk *SwitchingKey) *mkrlwegpu.SwitchingKey {
 	return d
 }
 
-// Resident returns the device copy of a key / CRS / hoisted digit vector, uploading swk.Value at its first use.
+// fingerprint mixes up to 64 words of a host SwitchingKey, spread over its digits, its Q and P limbs and the coefficients of a limb, into 64
+// bits (splitmix64 steps): cheap enough for every lookup, and a key generator that rewrites a key in place (mkrlwe/keygen.go:137-187 fills
+// every coefficient of every limb with fresh uniform / error terms) changes all of the sampled words.
+func fingerprint(v []rlwe.PolyQP) uint64 {
+	h := uint64(0x4D4B4845) ^ uint64(len(v))<<32
+	mix := func(w uint64) {
+		h += w + 0x9E3779B97F4A7C15
+		h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9
+		h = (h ^ (h >> 27)) * 0x94D049BB133111EB
+		h ^= h >> 31
+	}
+	if len(v) == 0 {
+		return h
+	}
+	for s := 0; s < 64; s++ {
+		d := (s * 7) % len(v)
+		var limbs [][]uint64
+		if s%4 == 3 && v[d].P != nil && len(v[d].P.Coeffs) > 0 {
+			limbs = v[d].P.Coeffs
+		} else if v[d].Q != nil {
+			limbs = v[d].Q.Coeffs
+		}
+		if len(limbs) == 0 {
+			mix(uint64(s))
+			continue
+		}
+		l := limbs[(s*5)%len(limbs)]
+		if len(l) == 0 {
+			mix(uint64(s))
+			continue
+		}
+		mix(l[(s*2654435761)%len(l)])
+	}
+	return h
+}
+
+// Resident returns the device copy of a key / CRS / hoisted digit vector, uploading swk.Value at its first use -- and again when the host words
+// it was uploaded from have changed since (see the file comment; MKHE_GO_TRUST_RESIDENT=1 skips that comparison).
 func (ks *KeySwitcher) Resident(swk *SwitchingKey) *mkrlwegpu.SwitchingKey {
 	if swk == nil {
 		panic("mkrlwe (gpu): nil SwitchingKey")
 	}
+	key := uintptr(unsafe.Pointer(swk))
 	if d := ks.lookup(swk); d != nil {
-		return d
+		if ks.trust {
+			return d
+		}
+		ks.mu.Lock()
+		fp, uploaded := ks.prints[key]
+		ks.mu.Unlock()
+		// (a device-born vector -- Adopt: a hoisted form whose host Value may be empty or a stale mirror -- has no host original to compare with)
+		if !uploaded || fp == fingerprint(swk.Value) {
+			return d
+		}
+		// the host struct was rewritten in place after its upload: the copy is stale
 	}
 	d := ks.GPU().UploadSwitchingKey(swk.Value)
 	ks.bind(swk, d)
+	ks.mu.Lock()
+	ks.prints[key] = fingerprint(swk.Value)
+	ks.mu.Unlock()
 	return d
 }
 
 // Adopt binds a device digit vector (mkrlwegpu.Context.HoistedForm) to a host SwitchingKey whose Value may be empty.
-func (ks *KeySwitcher) Adopt(swk *SwitchingKey, d *mkrlwegpu.SwitchingKey) { ks.bind(swk, d) }
+func (ks *KeySwitcher) Adopt(swk *SwitchingKey, d *mkrlwegpu.SwitchingKey) {
+	ks.bind(swk, d)
+	ks.mu.Lock()
+	delete(ks.prints, uintptr(unsafe.Pointer(swk)))
+	ks.mu.Unlock()
+}
 
 // Forget drops the device copy bound to swk (a key that was regenerated in place; a hoisted form that is no longer needed).
 func (ks *KeySwitcher) Forget(swk *SwitchingKey) {
@@ -150,6 +213,7 @@ func (ks *KeySwitcher) Forget(swk *SwitchingKey) {
 	ks.mu.Lock()
 	d, ok := ks.resident[key]
 	delete(ks.resident, key)
+	delete(ks.prints, key)
 	ks.mu.Unlock()
 	if ok {
 		d.Close()
@@ -219,6 +283,10 @@ func (ks *KeySwitcher) Decompose(levelQ int, a *ring.Poly, ad *SwitchingKey) {
 		ks.bind(ad, d)
 	}
 	g.Decompose(levelQ, ct, 0, a.IsNTT, d)
+	// (the device copy is the original now, whatever ad.Value held when it was uploaded: no fingerprint to hold it against)
+	ks.mu.Lock()
+	delete(ks.prints, uintptr(unsafe.Pointer(ad)))
+	ks.mu.Unlock()
 	if ks.HostMirror {
 		g.DownloadSwitchingKey(d, ad.Value)
 	}
