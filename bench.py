@@ -400,7 +400,7 @@ def roofline_leg(args, params, step, logN, workload, extra=None):
     out = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                alg_bytes_per_launch=byt_d / cnt_d, avg_launch_us=1e3 * ms_d / cnt_d,
-               kernels=kernels)
+               kernels=kernels, launches_per_step=sum(v["launches_per_step"] for v in kernels.values()))      # (engine kernels of this rank: collectives and torch copies not counted)
     if tnote:
         out["traffic_note"] = tnote
     # no byte model may claim more than the chip moves: an algorithmic figure above the HBM peak means the model counts re-reads that

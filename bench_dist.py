@@ -165,6 +165,7 @@ def run_distributed(args):
         check(lib().mkhe_rescale(params.ctx, backend.full.h, 1, res.h))
     dt = _timed(dist, torch, params, step_party, args.steps, args.warmup)
     legs["party"] = dict(mulrelin_per_sec=args.steps / dt, ms_per_step=dt * 1e3 / args.steps, collective_ordering=psync,
+                         x_y_exchange="reduce-scatter (all-to-all of limb slices + the rank's own fold) + all-gather" if smr.used_mesh else "all-reduce",
                          exchanged_bytes_per_step=8 * (2 * nwx + (1 + (k // world if k % world == 0 else k)) * L * Nn))
     # per-kernel HIP-event leg on every rank (the steps contain collectives), rank 0's figures are reported: the dominant kernel of a
     # rank's share of the work (its launch sizes shrink with N: a "sharded k=.. N=.." workload tag keeps the single-GPU PMC traffic out)

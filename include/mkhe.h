@@ -165,6 +165,12 @@ int  mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
                      const mkhe_swk* const* rlk_b1, const mkhe_swk* const* rlk_d0,
                      int with_c0, mkhe_ct* out, mkhe_swk* x_part, mkhe_swk* y_part);
 int  mkhe_swk_fold(mkhe_ctx* ctx, mkhe_swk* swk, int level, int mform);
+/* The reduction of x / y on a point-to-point mesh (xGMI: 7 links per GPU; SURVEY.md 8e(2) "prefer reduce-scatter + all-gather"): rank r receives slice
+ * r of every rank's partial sum (one all-to-all), sums, folds and MForm's ITS slice -- this call: limbs [first_limb, first_limb + nlimbs) of a
+ * switching-key buffer ([digit][modulus][N]: limb l = digit l / (nQ + nP), modulus l % (nQ + nP)), summand p of limb i at the device address
+ * pieces + (p * piece_stride_words + i * N) words, result at dst + i * N words; limbs of inactive digits / moduli are skipped -- and the folded slices
+ * are all-gathered.  Same integers as the all-reduce + mkhe_swk_fold (a sum of canonical residues, then MFormLvl: keyswitch_hoisted.go:94-96,115-117). */
+int  mkhe_swk_fold_pieces(mkhe_ctx* ctx, const void* pieces, int npieces, long piece_stride_words, long first_limb, long nlimbs, int level, int mform, void* dst);
 int  mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x, const mkhe_swk* y,
                     const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out);
 /* mkhe_mr_finish in two halves, so that the all-reduce of x can still be in flight while the part that needs y alone runs:

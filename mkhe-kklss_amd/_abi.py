@@ -60,6 +60,7 @@ SIGNATURES = {
     "mkhe_mul_relin_rescale": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, vpp, vp, vp]),
     "mkhe_mr_partial": (C.c_int, [vp, vp, vp, vpp, vpp, vpp, vpp, C.c_int, vp, vp, vp]),
     "mkhe_swk_fold": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "mkhe_swk_fold_pieces": (C.c_int, [vp, vp, C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int, vp]),
     "mkhe_mr_finish": (C.c_int, [vp, vp, vp, vp, vp, vpp, vp, vp]),
     "mkhe_mr_finish_head": (C.c_int, [vp, vp, vp, vp, vp]),
     "mkhe_mr_finish_tail": (C.c_int, [vp, vp, vp, vp, vpp, vp, vp]),

@@ -228,11 +228,11 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     const bool own0 = hoist0.empty(), own1 = hoist1.empty() && !same;
     const size_t P0 = (size_t)op0[0]->limbs * N, P1 = (size_t)op1[0]->limbs * N, PO = (size_t)L * N, SW = swk_words();
     const bool fold = n0 >= 1 && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
-    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
+    const int fuse_env = ab_fuse_x();
     const bool fuse_x = fuse_env && n0 >= 1 && n0 <= 4;      // x_b = sum_i d_i (.) h(c0_{b,i}) as a by-product of input b's step F1
-    static const int fuse_y_env = MKHE_AB_INT("MKHE_FUSE_Y", 1);
+    const int fuse_y_env = ab_fuse_y();
     const bool fuse_y = fuse_x && fuse_y_env && n1 >= 1 && n1 <= 4;    // ... and y_b computed in the same threads (ext_inner_xy_batch_kernel<G0, G1>), never stored
-    static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
+    const int fuse_e_env = ab_fuse_e();
     const bool fuse_e = fuse_y && fuse_e_env;                          // ... and step E: input b's <h(c1_j), x_b> as precomputed items of the tail batch
     const size_t per_b = (size_t)(2 + n0 + n1) * PO + (size_t)(1 + nout) * PO * ((fold ? 1 : 0) + (rescale_out ? 1 : 0)) + 2 * SW + (size_t)n0 * PO + (size_t)n0 * SW +
                          (own0 ? (size_t)n0 * SW : 0) + (own1 ? (size_t)n1 * SW : 0) + (fuse_e ? (size_t)n1 * mtot * N : 0);

@@ -392,6 +392,9 @@ int mkhe_mr_partial(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1,
 int mkhe_swk_fold(mkhe_ctx* ctx, mkhe_swk* swk, int level, int mform) {
     MKHE_TRY({ mark(ctx, swk); if (!swk) throw Error("mkhe_swk_fold: null argument"); need(ctx)->fold(swk->s.d, true, level, need(ctx)->beta(level), (long)need(ctx)->mtot * need(ctx)->N, mform != 0); })
 }
+int mkhe_swk_fold_pieces(mkhe_ctx* ctx, const void* pieces, int npieces, long piece_stride_words, long first_limb, long nlimbs, int level, int mform, void* dst) {
+    MKHE_TRY({ mark(ctx); need(ctx)->fold_pieces((const u64*)pieces, npieces, piece_stride_words, first_limb, nlimbs, level, mform != 0, (u64*)dst); })
+}
 int mkhe_mr_finish(mkhe_ctx* ctx, const mkhe_ct* op0, const mkhe_ct* op1, const mkhe_swk* x, const mkhe_swk* y,
                    const mkhe_swk* const* rlk_v0, const mkhe_swk* crs_u, mkhe_ct* out) {
     MKHE_TRY({ mark(ctx, op0, op1, x, y, crs_u, out);

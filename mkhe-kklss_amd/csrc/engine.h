@@ -20,6 +20,11 @@
 
 namespace mkhe {
 
+// A/B switches that several translation units ask for (csrc/switches.h: constants in the product library): x, y and step E inside the F1 kernel
+int ab_fuse_x();
+int ab_fuse_y();
+int ab_fuse_e();
+
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 
 #define MKHE_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw ::mkhe::Error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -126,6 +131,9 @@ class Context {
     void mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y, const Swk* const* rlk_v0,
                    const Swk& crs_u, Ct& out);
     void fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_stride, bool mform);
+    // the reduce-scatter half of a mesh exchange of x / y (dist.py): limbs [first_limb, first_limb + nlimbs) of a switching-key buffer, summed over
+    // npieces pieces, folded and MForm'ed into dst (limb i of the range at dst + i * N)
+    void fold_pieces(const u64* pieces, int npieces, long piece_stride, long first_limb, long nlimbs, int level, bool mform, u64* dst);
     // ---- B independent operations of one shape as one launch set (batch.hip; small rings: DESIGN.md section 8).  Flat lists: hoisted forms are
     // [b * n + a] (input b, party component a) or empty (the engine hoists); keys are per party, shared by the inputs.
     void hoisted_form_batch(int level, const std::vector<const Ct*>& cts, const std::vector<Swk*>& outs);

@@ -8,6 +8,10 @@
 
 namespace mkhe {
 
+int ab_fuse_x() { static const int v = MKHE_AB_INT("MKHE_FUSE_X", 1); return v; }
+int ab_fuse_y() { static const int v = MKHE_AB_INT("MKHE_FUSE_Y", 1); return v; }
+int ab_fuse_e() { static const int v = MKHE_AB_INT("MKHE_FUSE_E", 1); return v; }
+
 typedef unsigned __int128 u128;
 
 // ------------------------------------------------------------------ host number theory
@@ -940,8 +944,7 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
             // write of every digit limb.  MKHE_SPREAD_RADIX4=0 is the earlier form: cross-half stage only, the spread digits staged in a separate
             // buffer (5.4 GB for the 16 operand components of an 8-party PN16QP1761 MulRelin) and the 2^15-point sub-transforms out of place from
             // there, two passes each, the second recomputing its cross stage from a second read of the source -- 6.3 GB moved per 2.1 GB Decompose
-            // launch against 4.2 GB (MKHE_SPREAD_OOP=0: in place, the upper half parked in the destination and reloaded instead).
-            static const int oop_env = MKHE_AB_INT("MKHE_SPREAD_OOP", 1);
+            // launch against 4.2 GB.
             static const int radix4_env = MKHE_AB_INT("MKHE_SPREAD_RADIX4", 1);
             const size_t item_words = (size_t)beta_max * mtot * N;
             bool h16 = false;
@@ -957,7 +960,7 @@ void Context::decompose_batch(int level, const std::vector<const u64*>& src, con
                 const int m = s2 <= level ? s2 : nq + (s2 - level - 1);
                 if (((u_mods_ >> m) & 1) && (double)moduli[m] * (22.2 + 70 + 75) >= 4611686018427387904.0) radix4 = false;
             }
-            const bool oop = h16 && oop_env && !radix4;
+            const bool oop = h16 && !radix4;
             u64* stage = oop ? scratch(spreadbuf_, spreadbuf_words_, (size_t)n * item_words) : nullptr;
             for (int i = 0; i < n; ++i) { da.src[i] = src[base + i]; da.dst[i] = oop ? stage + (size_t)i * item_words : dst[base + i]; }
             da.mods = d_mods; da.map = map_qp(level); da.ta = d_dec_a; da.tb = d_dec_b; da.tc = d_dec_c;
@@ -1131,10 +1134,16 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
                   throw Error("mkhe: internal: digits left after the cross stages read as a full transform");
       }
       if (!ext_f2_src_.empty()) {
-          // N = 2^15: the F2 products come out of the Decompose NTT of the t_i itself (ntt16_f2_kernel); every other item of the launch exists already
-          bool two_live = false;                     // (mkbfv: the precomputed step-E items of the batch carry their second gadget; nothing here reads them)
-          for (int i = 0; i < n; ++i) two_live = two_live || (!it[i].pre && it[i].ah2);
-          if (xby || xy || xyb || two_live || !mp || !ext_staged_.empty()) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
+          // N = 2^15: the F2 products come out of the Decompose NTT of the t_i itself (ntt16_f2_kernel).  The other items of the batch exist already
+          // (step E computed by the F1 kernel: `pre`) or are plain products of stored digits -- the sharded finish, more parties than the F1 kernel's
+          // forms take: the inner-product kernel computes those first and skips the F2 items (role 2: "computed elsewhere")
+          if (xby || xy || xyb || !mp || !ext_staged_.empty()) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
+          bool others = false;
+          for (int i = 0; i < n; ++i) {
+              if (it[i].f2_party >= 0) { if (it[i].pre || it[i].ah2) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them"); ia.pair[i] = 2; }      // (also undoes the pairing of a party's two products above: neither is computed here)
+              else others = others || !(it[i].pre && !it[i].pre_src);
+          }
+          if (others) launch_ext_inner(ia, s_);
           const int np0 = (int)ext_f2_src_.size();
           const F2Sched& sc = f2_schedule(np0, level);
           F2FusedArgs fa{};
@@ -1142,9 +1151,9 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
           for (int a = 0; a < np0; ++a) { fa.src[a] = ext_f2_src_[a]; fa.item_v[a] = fa.item_u[a] = -1; }
           int nf2 = 0;
           for (int i = 0; i < n; ++i) {
-              if (it[i].pre && !it[i].pre_src) continue;
               const int a = it[i].f2_party;
-              if (a < 0 || a >= np0 || it[i].pre) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
+              if (a < 0) continue;
+              if (a >= np0) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
               if (it[i].f2_key == 0) { fa.kv[a] = it[i].bg; fa.item_v[a] = i; fa.extra_v[a] = n + nf2 * (sc.parts - 1); }
               else { if (fa.ku && fa.ku != it[i].bg) throw Error("mkhe: internal: fused F2 products with more than one CRS"); fa.ku = it[i].bg; fa.item_u[a] = i; fa.extra_u[a] = n + nf2 * (sc.parts - 1); }
               f2_parts[i] = (unsigned short)(((n + nf2 * (sc.parts - 1)) << 8) | (sc.parts - 1));

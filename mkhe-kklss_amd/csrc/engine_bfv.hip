@@ -264,7 +264,7 @@ void Context::bfv_mr_finish(const Ct& op0, const Ct& op1, const u64* x1, const u
     if (fused && !bfv_yk1_.empty()) {
         ext_ykeys_ = bfv_yk1_; ext_ykeys2_ = bfv_yk2_;
         for (int a = 0; a < n1; ++a) { ext_yh_.push_back(hoist_slot(1, a).d); ext_yh2_.push_back(hoist_slot(4, a).d); }
-        static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
+        const int fuse_e_env = ab_fuse_e();
         if (fuse_e_env && 2 * n0 + n1 <= EXT_MAX_ITEMS) {
             // (step F2 is the plain Q gadget here too, keyswitch_hoisted.go:199-204: with step E done by the F1 kernel the digits of the t_i stay in the
             // registers of ntt16_f2_kernel, as in Context::mr_finish_head; its parts live behind the tail batch's items in this same allocation)
@@ -311,9 +311,9 @@ void Context::bfv_mul_relin(const Ct& op0, const Ct& op1, const Swk* const* rlk_
                             const Swk* const* rlk_d1, const Swk* const* rlk_d2, const Swk* const* rlk_v,
                             const Swk& crs_u, Ct& out) {
     for (int a = 0; a < op0.n; ++a) if (!rlk_v[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
-    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
+    const int fuse_env = ab_fuse_x();
     const bool fuse = fuse_env && op0.n >= 1 && op0.n <= 4 && !masked_;
-    static const int fuse_y_env = MKHE_AB_INT("MKHE_FUSE_Y", 1);
+    const int fuse_y_env = ab_fuse_y();
     const bool fuse_y = fuse && fuse_y_env && op1.n >= 1 && op1.n <= 4;
     bfv_mr_partial(op0, op1, rlk_b1, rlk_b2, rlk_d1, rlk_d2, true, true, out, x_, x2_, y_, y2_, fuse, fuse_y);
     bfv_mr_finish(op0, op1, x_, x2_, y_, y2_, rlk_v, crs_u, out);

@@ -13,12 +13,11 @@ void Context::mul_and_relin(const Ct& op0, const Ct& op1, const Swk* const* hois
                             const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                             const Swk& crs_u, Ct& out) {
     mr_prepare(op0, op1, hoist0, hoist1, true, out);
-    static const int fuse_env = MKHE_AB_INT("MKHE_FUSE_X", 1);
-    static const int wide_env = MKHE_AB_INT("MKHE_FUSE_X_WIDE", 1);      // A/B: the by-product for five to sixteen parties
-    const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= (wide_env ? 16 : 4) && !masked_;
+    const int fuse_env = ab_fuse_x();
+    const bool fuse = fuse_env && plan_.n0 >= 1 && plan_.n0 <= 16 && !masked_;      // (five to sixteen parties: the wide forms of the kernel)
     // y inside the F1 kernel as well (round 4): the thread that forms <h(c0_i), y> at a coefficient needs y there and nowhere else, so that y is
     // neither a launch nor 2 x 59 MB of traffic -- when op1 has as many parties as op0 (at most four: the group form of the kernel)
-    static const int fuse_y_env = MKHE_AB_INT("MKHE_FUSE_Y", 1);
+    const int fuse_y_env = ab_fuse_y();
     const bool fuse_y = fuse && fuse_y_env && plan_.n1 >= 1 && (plan_.n0 <= 4 ? plan_.n1 <= 4 : (plan_.n0 <= 8 && plan_.n1 == plan_.n0));      // (one to four parties per operand: ext_inner_xy_kernel<G0, G1>; five to eight in both: ext_inner_xy_wide_kernel)
     mr_xy(rlk_b1, rlk_d0, x_, y_, true, true, fuse, fuse_y);
     mr_finish(op0, op1, x_, y_, rlk_v0, crs_u, out);
@@ -116,9 +115,8 @@ void Context::mr_prepare(const Ct& op0, const Ct& op1, const Swk* const* hoist0,
         }
         // With at least one party in op0 every output slot receives an external product in steps E / F2.  The tensor term then
         // stays in the NTT domain, times P, and joins the summed Q parts of that (merged) batch: ModDown's (x - lift) * P^-1
-        // returns it as itself, canonical like everything else -- no inverse NTT for step D.  MKHE_TENSOR_FOLD=0: A/B switch.
-        static const int fold_env = MKHE_AB_INT("MKHE_TENSOR_FOLD", 1);
-        const bool fold = fold_env && n0 >= 1 && !masked_ && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
+        // returns it as itself, canonical like everything else -- no inverse NTT for step D.
+        const bool fold = n0 >= 1 && !masked_ && 2 * n0 + n1 <= EXT_MAX_ITEMS && ext_merge_members(level) >= 2;
         u64* tout = out.d;
         if (fold) { tout = scratch(tens_, tens_words_, (size_t)(1 + out.n) * PO); p.tens = tout; }
         TensorArgs ta{};
@@ -213,10 +211,11 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
     }
     if (!p.xkeys.empty()) ext_xout_ = p.xfused;          // x = sum_i d_i (.) h(c0_i) comes out of the same pass over h(c0_i)
     // N = 2^15 (round 6): the digits of the t_i never reach HBM -- no Decompose launch below, the tail batch's product kernel transforms them itself
-    // (ntt16_f2_kernel) -- when every other product of that batch exists by then (step E inside the F1 kernel) and the batch is a merged one
-    static const int fuse_e_env = MKHE_AB_INT("MKHE_FUSE_E", 1);
+    // (ntt16_f2_kernel) -- when that batch is a merged one (the parts of its products meet at the load of the inverse NTT); step E is either done by
+    // then (inside the F1 kernel) or computed by the inner-product kernel in front of it (the sharded finish: x arrives from the other ranks)
+    const int fuse_e_env = ab_fuse_e();
     const bool will_e = !p.ykeys.empty() && fuse_e_env && 2 * n0 + p.n1 <= EXT_MAX_ITEMS;
-    p.f2_fused = n0 > 0 && (will_e || p.n1 == 0) && p.tens != nullptr && f2_fused_ok(level, n0, p.n1);
+    p.f2_fused = n0 > 0 && p.tens != nullptr && f2_fused_ok(level, n0, p.n1);
     const int f2_extra = p.f2_fused ? 2 * n0 * (f2_schedule(n0, level).parts - 1) : 0;
     if (p.f2_fused && p.ykeys.empty()) scratch(c1b_, c1b_words_, (size_t)(2 * n0 + p.n1 + f2_extra) * mtot * N);
     if (!p.ykeys.empty()) {
@@ -234,7 +233,6 @@ void Context::mr_finish_head(const Ct& op0, const Ct& op1, const u64* y, Ct& out
     ext_xout_ = nullptr; ext_ykeys_.clear(); ext_yh_.clear(); ext_e_slot_ = -1;
     // F2: h(t_i) ; out_0 += <h(t_i), v_i>_P ; out_i += <h(t_i), u>_P
     p.f2_tbuf = tbuf;
-    if (p.f2_fused && !(p.e_done || p.n1 == 0)) throw Error("mkhe: internal: fused F2 products without step E");
     if (!p.f2_fused) {
         std::vector<const u64*> dsrc; std::vector<u64*> ddst;
         for (int a = 0; a < n0; ++a) { dsrc.push_back(tbuf + (size_t)a * PO); ddst.push_back(hoist_slot(2, a).d); }
@@ -454,6 +452,19 @@ void Context::fold(u64* buf, bool qp_shaped, int level, int npolys, long poly_st
     fa.buf = buf; fa.mods = d_mods; fa.map = qp_shaped ? map_qp(level) : d_map_id;
     fa.nslots = qp_shaped ? nslots_qp(level) : level + 1; fa.npolys = npolys; fa.poly_stride = poly_stride; fa.N = N; fa.mform = mform ? 1 : 0;
     { ProfScope ps(this, PROF_OTHER, 16.0 * N * fa.nslots * npolys); launch_fold(fa, s_); }
+    MKHE_HIP(hipGetLastError());
+}
+
+void Context::fold_pieces(const u64* pieces, int npieces, long piece_stride, long first_limb, long nlimbs, int level, bool mform, u64* dst) {
+    check_level(level);
+    if (!pieces || !dst || npieces < 1 || npieces > 64 || first_limb < 0 || nlimbs < 0 || first_limb + nlimbs > (long)beta_max * mtot || mtot > 64)
+        throw Error("mkhe: fold_pieces outside a switching key");
+    FoldPiecesArgs fa{};
+    fa.pieces = pieces; fa.dst = dst; fa.mods = d_mods; fa.piece_stride = piece_stride; fa.first_limb = first_limb;
+    for (int j = 0; j <= level; ++j) fa.active |= 1ull << j;
+    for (int j = 0; j < np; ++j) fa.active |= 1ull << (nq + j);
+    fa.npieces = npieces; fa.nlimbs = (int)nlimbs; fa.mtot = mtot; fa.ndigits = beta(level); fa.N = N; fa.mform = mform ? 1 : 0;
+    { ProfScope ps(this, PROF_OTHER, 8.0 * N * nlimbs * (npieces + 1.0)); launch_fold_pieces(fa, s_); }
     MKHE_HIP(hipGetLastError());
 }
 

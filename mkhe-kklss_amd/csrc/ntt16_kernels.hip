@@ -1203,7 +1203,6 @@ struct LaunchState16 { std::mutex mu; int resident[64] = {}; };      // per devi
 namespace {
 int resident16(size_t lds) {
     using namespace h16;
-    static const int per_cu = MKHE_AB_INT("MKHE_NTT16_PER_CU", 0);
     static LaunchState16 ls;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1222,13 +1221,14 @@ int resident16(size_t lds) {
         const void* others[] = {(const void*)ntt16_fwd_kernel<false>, (const void*)ntt16_fwd_split_kernel, (const void*)ntt14_fwd_kernel<true>,
                                 (const void*)ntt14_fwd_kernel<false>, (const void*)ntt14_fwd_split_kernel};
         for (const void* f : others) { int p2 = per; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2, f, NT, lds) == hipSuccess && p2 >= 1 && p2 < per) per = p2; }
-        if (per_cu > 0) per = per_cu;
         ls.resident[dev & 63] = cus * per;
     }
     return ls.resident[dev & 63];
 }
 }
 // launch constants of the job walk (fwd_body): reciprocals for the scalar multiply-high divisions and the placement of the long jobs
+static int ab_ntt16() { static const int v = MKHE_AB_INT("MKHE_NTT16", 1); return v; }
+static int ab_ntt16_min() { static const int v = MKHE_AB_INT("MKHE_NTT16_MIN", 128); return v; }
 static unsigned magic_of(int d) { return d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }      // (0: divisor 1, see udiv_magic)
 static void fill_job_constants(NttBatch& c, int njobs, int blocks, int lpt_long) {
     if (njobs >= 65536 || c.nouter >= 65536) throw std::runtime_error("mkhe: internal: an H16 launch of 2^16 limbs or more");
@@ -1244,7 +1244,7 @@ static void fill_job_constants(NttBatch& c, int njobs, int blocks, int lpt_long)
 }
 // sub-transforms of a split N = 2^16 launch (one modulus class per launch: `small` = 31 q < 2^62 for every slot)
 bool ntt16_split_ok(const NttBatch& c) {
-    static const int on = MKHE_AB_INT("MKHE_NTT16", 1), minl = MKHE_AB_INT("MKHE_NTT16_MIN", 128);
+    const int on = ab_ntt16(), minl = ab_ntt16_min();
     // (the job walk divides by multiply-high reciprocals that are exact below 2^16: larger launches keep the round-1 kernels)
     return on && !c.no_h16 && c.psi31 && (c.split == 1 || c.split == 2) && !c.reduce_in && c.nslots <= 64 && 2 * c.nslots * c.nouter >= minl &&
            (long)c.nslots * c.nouter < 65536 && c.nouter < 65536;
@@ -1299,7 +1299,8 @@ void launch_ntt16_inv(const NttBatch& b, hipStream_t st, int logN) {
     hipLaunchKernelGGL(ntt14_inv_kernel, dim3(need < resident ? need : resident), dim3(NT), lds, st, c);
 }
 bool ntt16_ok(int logN, const NttBatch& b) {
-    static const int on = MKHE_AB_INT("MKHE_NTT16", 1), minl = MKHE_AB_INT("MKHE_NTT16_MIN", 128), minl14 = MKHE_AB_INT("MKHE_NTT14_MIN", 128);
+    static const int minl14 = MKHE_AB_INT("MKHE_NTT14_MIN", 128);
+    const int on = ab_ntt16(), minl = ab_ntt16_min();
     if (!on || b.no_h16 || !b.psi31 || b.split || b.prestaged || b.nslots > 64) return false;
     if ((long)b.nslots * b.nouter >= 65536 || b.nouter >= 65536) return false;      // (fill_job_constants: reciprocals exact below 2^16)
     if (logN == 14) return b.nslots * b.nouter >= minl14;      // (one pass: a workgroup has loaded its whole limb before it stores, in place included)
@@ -1318,18 +1319,13 @@ void launch_ntt16_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
                 ++c.nslots;
             }
     const size_t lds = (size_t)LDS_WORDS * sizeof(u32);
-    static const int stagger = MKHE_AB_INT("MKHE_NTT16_STAGGER", 0), lpt = MKHE_AB_INT("MKHE_NTT16_LPT", 1);
-    c.lazy_out = stagger;
+    c.lazy_out = 0;                                    // (no start delay of the co-resident workgroups: measured, not kept -- docs/DESIGN_HISTORY.md)
     int nbig = 0;                                      // the long jobs lead the slot-major list: every slot of a 59/60-bit modulus, nouter limbs each
     for (int s2 = 0; s2 < c.nslots; ++s2) if (!((c.small_slots >> s2) & 1)) ++nbig;
-    const int lpt_long = lpt && nbig < c.nslots ? nbig * c.nouter : 0;
+    const int lpt_long = nbig < c.nslots ? nbig * c.nouter : 0;
     const int resident = resident16(lds);
     const int need = c.nslots * c.nouter;
-    int blocks = need < resident ? need : resident;
-    // experiment (MKHE_NTT16_EVEN=1): as many workgroups as give every one of them the same number of limbs (1792 and 896 limbs: 448 instead of
-    // 512) -- an even last round on 7/8 of the CUs instead of a ragged one on all of them
-    static const int even = MKHE_AB_INT("MKHE_NTT16_EVEN", 0);
-    if (even && need > resident) { const int rounds = (need + resident - 1) / resident; blocks = (need + rounds - 1) / rounds; }
+    const int blocks = need < resident ? need : resident;
     // half-limb jobs: Decompose launches only (source = ciphertext limbs, destination = hoisted digits: never in place) whose whole limbs would
     // leave the last row of positions ragged (896 limbs on 256 CUs: 134.0 -> 128.7 us); a launch that deals whole limbs evenly keeps them -- as
     // half-limb jobs the 1792-limb launch (7 limbs per CU either way) is 5 % SLOWER (256 -> 270 us, measured twice on one box; MKHE_NTT16_HALVES=2

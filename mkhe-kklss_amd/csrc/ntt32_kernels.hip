@@ -61,9 +61,6 @@ constexpr int RING = MKHE_H32_RING;        // twiddle pairs (4 VGPRs each) live 
 #ifndef MKHE_H32_PREFETCH
 #define MKHE_H32_PREFETCH 0                // (experiment, slower by 3 %: DESIGN.md section 10) the next limb's source loads are issued between the stores of this one (register by register)
 #endif
-#ifndef MKHE_NTT32_EVEN_DEFAULT
-#define MKHE_NTT32_EVEN_DEFAULT 0
-#endif
 #ifndef MKHE_NTT32_DEFAULT
 // MKHE_NTT32: 0 = every launch on the two-pass H16 kernel, 1 = this kernel wherever it applies, 2 (default) = per launch shape the engine times a block
 // of launches of each kernel inside the caller's workload, once its clocks have settled, and keeps the faster one (Context::ntt_pick).  Back to back
@@ -594,16 +591,9 @@ bool ntt32_ok(int logN, const NttBatch& b) {
     static const int on = MKHE_CFG_INT("MKHE_NTT32", MKHE_NTT32_DEFAULT), minl = MKHE_AB_INT("MKHE_NTT32_MIN", 512);
     if (!on || logN != 15 || b.no_h16 || !b.psi31 || !b.psi31c || !b.psi31b || b.split || b.prestaged || b.nslots > 64) return false;
     if ((long)b.nslots * b.nouter >= 65536 || b.nouter >= 65536) return false;      // (job-walk reciprocals: exact below 2^16)
-    // one workgroup per CU, whole limbs: a launch that does not deal the limbs evenly leaves CUs idle in its last round (896 limbs on 256 CUs: four
-    // rounds for 3.5 rounds of work), where the H16 kernel deals half-limb jobs.  MKHE_NTT32_EVEN=1 keeps such launches on H16.
-    static const int even = MKHE_AB_INT("MKHE_NTT32_EVEN", MKHE_NTT32_EVEN_DEFAULT);
-    const int need = b.nslots * b.nouter;
-    if (even) {
-        const int cus = device_cus32();
-        const int rounds = (need + cus - 1) / cus;
-        if (need % cus != 0 && rounds < 8) return false;
-    }
-    return need >= minl;
+    // (one workgroup per CU, whole limbs: a launch that does not deal the limbs evenly leaves CUs idle in its last round, where the H16 kernel deals
+    // half-limb jobs -- which kernel a shape takes is measured, Context::ntt_pick)
+    return b.nslots * b.nouter >= minl;
 }
 void launch_ntt32_fwd(const NttBatch& b, const unsigned char* small_q, hipStream_t st) {
     using namespace h32;
@@ -641,8 +631,7 @@ void launch_ntt32_fwd(const NttBatch& b, const unsigned char* small_q, hipStream
     const int blocks = need < resident ? need : resident;
     int nbig = 0;
     for (int s2 = 0; s2 < c.nslots; ++s2) if (!((c.small_slots >> s2) & 1)) ++nbig;
-    static const int lpt = MKHE_AB_INT("MKHE_NTT32_LPT", 1);
-    const int lpt_long = lpt && nbig < c.nslots ? nbig * c.nouter : 0;
+    const int lpt_long = nbig < c.nslots ? nbig * c.nouter : 0;
     c.magic_nouter = magic_of32(c.nouter);
     c.magic_opi = magic_of32(c.nitems > 0 ? c.outers_per_item : 1);
     c.lpt = NttBatch::Lpt{};

@@ -663,34 +663,6 @@ __global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_fwd_lds_kernel(NttBatch b,
     }
 }
 
-// (8 waves per SIMD = two workgroups per CU: the merged E / F2 launch of a 4-party MulRelin has 376 sub-transforms for 256 CUs;
-// 64 instead of 67 VGPRs, no spills; 48.7 -> 45.0 us per average inverse launch)
-__global__ void __launch_bounds__(SM_T) __attribute__((amdgpu_waves_per_eu(8, 8))) ntt_inv_lds_kernel(NttBatch b, int d) {
-    extern __shared__ __attribute__((aligned(16))) u64 sm_lds[];
-    const int job = blockIdx.x, part = job & ((1 << d) - 1), t = threadIdx.x;
-    gcptr src; gptr dst; int m, outer;
-    int pm = -1;
-    const int nsum = job_pointers<true>(b, job >> d, src, dst, m, outer, &pm);
-    if (nsum == 0) return;                                     // merged launch: no such member (the whole workgroup returns)
-    long sum_off[VI_SUMS] = {};
-#pragma unroll
-    for (int k = 1; k < VI_SUMS; ++k) if (k < nsum) sum_off[k] = vi_summand_offset(b, outer, pm, k, m, src);
-    src += part * SM_M; dst += part * SM_M;
-    const int root = (1 << d) + part;
-    const Mod md = b.mods[m];
-    gcptr psi = (gcptr)(b.psi + ((long)m * SM_M << d));
-    const u64 ninvR = b.aux[6 * m];                            // N^-1 * R of the WHOLE limb size, signed-split form
-    sm_phase<12, 1, true, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0, nsum, sum_off);
-    __syncthreads();
-    sm_phase<9, 3, false, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
-    __syncthreads();
-    sm_phase<6, 3, false, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
-    __syncthreads();
-    sm_phase<3, 3, false, false, 2, 0>(src, dst, sm_lds, psi, root, t, md, 0, 0);
-    __syncthreads();
-    sm_phase<0, 3, false, true, 2, 2>(src, dst, sm_lds, psi, root, t, md, ninvR, 0);
-}
-
 // the 2^12- and 2^11-point inverse sub-transforms (see SmGeo): four phases, 512 / 256 threads
 template <int LOGM>
 __global__ void __launch_bounds__(SmGeo<LOGM>::T) ntt_inv_ldsS_kernel(NttBatch b, int d) {
@@ -1123,15 +1095,11 @@ int split_ntt_fwd(const NttBatch& b, const unsigned char* small_q, NttBatch out[
 // A limb is one workgroup's work for 60-70 us whatever the batch size, so a launch with fewer limbs than CUs is latency
 // bound at half the chip idle.  Such launches (and every N = 2^16 launch) run split: cross-half radix-2 pass + two
 // half-size sub-transforms per limb (2 workgroups per CU fit), which nearly halves the latency of the small launches
-// on the critical path (tensor / ExternalProduct inverse NTTs).  MKHE_NTT_SPLIT=0 / 1 forces the choice (A/B tests).
+// on the critical path (tensor / ExternalProduct inverse NTTs).
 static bool use_split(int logN, const NttBatch& b) {
     if (logN == 16) return true;
     if (logN < 13) return false;
-    static const int forced = MKHE_AB_INT("MKHE_NTT_SPLIT", -1);                 // (function-local statics: initialised once, thread-safe)
-    if (forced >= 0) return forced != 0;
-    static const int lim = MKHE_AB_INT("MKHE_NTT_SPLIT_MAX", 128);               // A/B: limb count up to which a launch runs split
     const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;                // merged launches: the jobs that exist
-    if ((logN == 14 || logN == 15) && limbs <= lim) return true;
     return limbs <= 128;        // at most one sub-transform workgroup per CU (256 CUs)
 }
 // depth of the low-latency path for this launch: 0 = register-resident sub-transforms, d >= 1 = 2^d LDS sub-transforms of
@@ -1140,21 +1108,8 @@ static int lds_depth(int logN, const NttBatch& b) {
     static const int on = MKHE_AB_INT("MKHE_NTT_LDS", 1);
     if (!on || b.prestaged) return 0;
     if (logN != 14 && logN != 15) return 0;
-    static LaunchState ls;
+    // N = 2^14: four 2^12-point sub-transforms per limb; N = 2^15: eight of them behind the radix-8 pass (the 2^13-point forms lost in rounds 3 and 4)
     {
-        const int dev = current_device();
-        std::lock_guard<std::mutex> g(ls.mu);
-        if (!ls.attr[dev]) {
-            const int lds = SM_LDS_WORDS * (int)sizeof(u64);
-            (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)ntt_fwd_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)ntt_inv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            ls.attr[dev] = true;
-        }
-    }
-    static const int lds12 = MKHE_AB_INT("MKHE_NTT_LDS12", 1);       // N = 2^14: four 2^12-point sub-transforms per limb (0: two of 2^13 points)
-    static const int lds12_15 = MKHE_AB_INT("MKHE_NTT_LDS12_15", 1);       // N = 2^15: eight 2^12-point sub-transforms behind the radix-8 pass (0: four of 2^13)
-    if (lds12 && (logN == 14 || (logN == 15 && lds12_15))) {
         static LaunchState ls12;
         const int dev = current_device();
         std::lock_guard<std::mutex> g(ls12.mu);
@@ -1166,17 +1121,13 @@ static int lds_depth(int logN, const NttBatch& b) {
             ls12.attr[dev] = true;
         }
         // N = 2^14 launches that would not even give every CU one 2^12-point workgroup: eight 2^11-point sub-transforms per limb (256 threads)
-        static const int lds11 = MKHE_AB_INT("MKHE_NTT_LDS11", 1);
         const int limbs = b.vi ? b.vi_jobs : b.nslots * b.nouter;
-        static const int lds11_max = MKHE_AB_INT("MKHE_NTT_LDS11_MAX", 64);      // (limbs below which the 2^11-point form is used)
-        if (lds11 && logN == 14 && limbs < lds11_max) return 3;
+        if (logN == 14 && limbs < 64) return 3;
         return logN - 12;
     }
-    return logN - SM_LOGM;
 }
 bool ntt_fwd_mixed_ok(int logN, const NttBatch& b, const unsigned char* small_q) {
-    static const int on = MKHE_AB_INT("MKHE_NTT_MIXED", 1);
-    if (!on || logN != 15 || !b.reduce_in || b.split || b.nslots > 64 || b.nslots * b.nouter <= 512) return false;
+    if (logN != 15 || !b.reduce_in || b.split || b.nslots > 64 || b.nslots * b.nouter <= 512) return false;
     int nsmall = 0;
     for (int s = 0; s < b.nslots; ++s) if (small_q[b.mod[s]]) ++nsmall;
     return nsmall != 0 && nsmall != b.nslots;               // a single class: the specialised kernel
@@ -1270,10 +1221,7 @@ void launch_ntt_fwd_class(int logN, const NttBatch& b, hipStream_t st) {
                 else hipLaunchKernelGGL((ntt_fwd_lds_kernel<0, 11>), dim3(jobs), dim3(256), lds, st, c, d);
                 return;
             }
-            const size_t lds = SM_LDS_WORDS * sizeof(u64);
-            if (small) hipLaunchKernelGGL(ntt_fwd_lds_kernel<1>, dim3(jobs), dim3(SM_T), lds, st, c, d);
-            else hipLaunchKernelGGL(ntt_fwd_lds_kernel<0>, dim3(jobs), dim3(SM_T), lds, st, c, d);
-            return;
+            throw std::runtime_error("mkhe: internal: LDS sub-transforms of a size no kernel has");
         }
         if (logN == 16 && ntt16_split_ok(c)) launch_ntt16_fwd_split(c, small, st);
         else if (small) launch_fwd_mode<1, false>(logN - 1, c, st); else launch_fwd_mode<0, false>(logN - 1, c, st);
@@ -1302,8 +1250,7 @@ void launch_ntt_inv(int logN, const NttBatch& b, hipStream_t st) {
             const int jobs = (b.nslots * b.nouter) << d;
             if (logN - d == 12) hipLaunchKernelGGL(ntt_inv_ldsS_kernel<12>, dim3(jobs), dim3(512), SmGeo<12>::LDSW * sizeof(u64), st, b, d);
             else if (logN - d == 11) hipLaunchKernelGGL(ntt_inv_ldsS_kernel<11>, dim3(jobs), dim3(256), SmGeo<11>::LDSW * sizeof(u64), st, b, d);
-            else
-            hipLaunchKernelGGL(ntt_inv_lds_kernel, dim3(jobs), dim3(SM_T), SM_LDS_WORDS * sizeof(u64), st, b, d);     // src -> dst, [0,2q), N^-1 folded in
+            else throw std::runtime_error("mkhe: internal: LDS sub-transforms of a size no kernel has");     // (src -> dst, [0,2q), N^-1 folded in)
             const NttBatch ip = in_place_of_dst(b);
             const dim3 grid(32, b.nslots * b.nouter);
             NttBatch e = ip; e.lazy_out = b.lazy_out; e.psi = b.psi;

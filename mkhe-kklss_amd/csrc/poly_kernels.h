@@ -378,6 +378,17 @@ struct FoldArgs {
     int nslots, npolys, N, mform;
 };
 void launch_fold(const FoldArgs& a, hipStream_t st);
+// fold of a limb range of a switching-key-shaped buffer whose summands are `npieces` separate pieces (piece p, limb i of the range at
+// pieces + p * piece_stride + i * N) into dst + i * N; active: bit m = modulus m is active at the level
+struct FoldPiecesArgs {
+    const u64* pieces;
+    u64* dst;
+    const Mod* mods;
+    long piece_stride, first_limb;
+    unsigned long long active;
+    int npieces, nlimbs, mtot, ndigits, N, mform;
+};
+void launch_fold_pieces(const FoldPiecesArgs& a, hipStream_t st);
 
 // z = MForm(a) / z = mont_mul(a, b) helpers on limb-major buffers
 void launch_mform(u64* dst, const u64* src, const Mod* mods, const int* map, int nslots, int N, hipStream_t st);

@@ -844,8 +844,7 @@ void launch_moddown_batch(const ModDownBatchArgs& a_in, hipStream_t st) {
     // the P-limb part (two Montgomery products and two float64 divisions per coefficient) is shared by all Q limbs a
     // thread produces: few limb slices per coefficient, the parallelism comes from the destination groups
     const int nj = a.qlist ? a.nqlist : a.level + 1;
-    static int cap = 0;
-    if (!cap) cap = MKHE_AB_INT("MKHE_MD_BY", 4);
+    const int cap = 4;
     int by = nj < cap ? nj : cap;
     if (a.ngroups * by < 8) by = nj < 8 ? nj : 8;          // a single external product: spread over the limbs instead
     if (by < 1) return;
@@ -970,9 +969,7 @@ void launch_moddown_merged(const ModDownMergedArgs& a_in, hipStream_t st) {
     // special prime).  Round 5, after the members' y are summed before the multSum products (the per-limb work halved): at N = 2^15 two slices beat four
     // (36.5 against 40.2 us per step for the two ModDown launches of the headline MulRelin, same call; 1: 47.9, 3: 37.4, 7: 45.5); the small rings too, by less
     // (cnn 1.910 against 1.918 ms with four, PN14QP439 equal: four alternating pairs in two calls).
-    static int cap_env = -1;
-    if (cap_env < 0) cap_env = MKHE_AB_INT("MKHE_MDM_BY", 0);
-    const int cap = cap_env > 0 ? cap_env : 2;
+    const int cap = 2;
     int by = nj < cap ? nj : cap;
     if (a.ngroups * by < 8) by = nj < 8 ? nj : 8;
     const dim3 grid(bx, by, a.ngroups), blk(PW_THREADS);
@@ -1207,8 +1204,8 @@ __global__ void __launch_bounds__(PW_THREADS) basis_conv_kernel(BasisConvArgs a)
 }
 void launch_basis_conv(const BasisConvArgs& a, hipStream_t st) {
     const int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
-    static int per = 0;                      // target limbs per thread: the y[] set-up (ns products + ns float64 divisions) is amortised over them
-    if (!per) per = MKHE_AB_INT("MKHE_BC_PER", 7);     // measured at PN15 (nt = 14): 7 -> 44.6 us per launch, 4 -> 54.8, 14 -> 54.2, 2 -> 68.7
+    const int per = 7;                       // target limbs per thread: the y[] set-up (ns products + ns float64 divisions) is amortised over them
+                                             // (measured at PN15, nt = 14: 7 -> 44.6 us per launch, 4 -> 54.8, 14 -> 54.2, 2 -> 68.7)
     int by = (a.nt + per - 1) / per;
     if (by < 1) by = 1;
     hipLaunchKernelGGL(basis_conv_kernel, dim3(bx, by, a.npolys), dim3(PW_THREADS), 0, st, a);
@@ -1550,6 +1547,29 @@ __global__ void __launch_bounds__(PW_THREADS) fold_kernel(FoldArgs a) {
 void launch_fold(const FoldArgs& a, hipStream_t st) {
     int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
     hipLaunchKernelGGL(fold_kernel, dim3(bx, a.nslots, a.npolys), dim3(PW_THREADS), 0, st, a);
+}
+
+// The same epilogue for a limb RANGE whose summands arrive as separate pieces (the reduce-scatter half of a mesh exchange, mkhe_kklss_amd/dist.py): limb l of
+// the range = sum over the pieces, folded [and MForm'ed], written to dst.  Limb l of a switching-key buffer belongs to digit l / mtot and modulus l % mtot;
+// limbs outside the active digits / moduli of the level are left alone.
+__global__ void __launch_bounds__(PW_THREADS) fold_pieces_kernel(FoldPiecesArgs a) {
+    const long l = a.first_limb + blockIdx.y;
+    const int digit = (int)(l / a.mtot), m = (int)(l % a.mtot);
+    if (digit >= a.ndigits || !((a.active >> m) & 1)) return;
+    const Mod md = a.mods[m];
+    const u64 w = a.mform ? md.r2 : md.r1;
+    const u64* src = a.pieces + (long)blockIdx.y * a.N;
+    u64* dst = a.dst + (long)blockIdx.y * a.N;
+    for (int n = blockIdx.x * PW_THREADS + threadIdx.x; n < a.N; n += gridDim.x * PW_THREADS) {
+        u64 v = 0;
+        for (int p = 0; p < a.npieces; ++p) v += src[(long)p * a.piece_stride + n];
+        dst[n] = mont_mul(v, w, md.q, md.ninv32);
+    }
+}
+void launch_fold_pieces(const FoldPiecesArgs& a, hipStream_t st) {
+    if (a.nlimbs < 1) return;
+    int bx = (a.N + PW_THREADS - 1) / PW_THREADS;
+    hipLaunchKernelGGL(fold_pieces_kernel, dim3(bx, a.nlimbs), dim3(PW_THREADS), 0, st, a);
 }
 
 // ------------------------------------------------------------------ mform

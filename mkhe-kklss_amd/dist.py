@@ -7,7 +7,9 @@ The reference is single-process; the sharding follows the algori
 (party i, side 1) = hoist c1_i, b_i-term of y, step E of party i      (needs x)
 and every rank evaluates the reference algorithm on the sub-ciphertexts made of c_0 and the
 components of its units.  Exchange steps (the only collectives):
-  1. all-reduce(x_part), all-reduce(y_part)   uint64 sums of canonical residues, then fold + MForm
+  1. x_part, y_part: uint64 sums of canonical residues, then fold + MForm -- as reduce-scatter + all-gather over disjoint limb slices where the
+     buffer divides (round 6, `mesh`: one all-to-all of slices, every rank sums, folds and MForm's ITS slice -- 1 / world of the fold work, per-link
+     payload buffer / world on the point-to-point xGMI mesh, SURVEY.md 8e(2) -- then an all-gather of the folded slices), else an all-reduce
   2. all-reduce(out_0) + all-gather(out_i)    out_0 is a sum over ranks; out_i comes from party i's owner (ranks that own whole
                                               parties in equal numbers; otherwise one all-reduce of the whole ciphertext)
 All sums are exact (ranks * q < 2^63) and order independent, so the result is bit-identical to the
@@ -80,11 +82,37 @@ class ShardedMulRelin:
     (HipShardBackend below on the GPU); `dist` is torch.distributed (or None for world size 1).
     force_collectives: issue the collectives even at world size 1 (exercises the stream plumbing on one GPU)."""
 
-    def __init__(self, backend, dist=None, group=None, force_collectives=False):
-        self.b, self.dist, self.group, self.force = backend, dist, group, force_collectives
+    def __init__(self, backend, dist=None, group=None, force_collectives=False, mesh=True):
+        self.b, self.dist, self.group, self.force, self.mesh = backend, dist, group, force_collectives, mesh
+        self._recv = {}
+        self.used_mesh = False                # the last run exchanged x and y as reduce-scatter + all-gather
 
     def _active(self):
         return self.dist is not None and (self.force or self.dist.get_world_size(self.group) > 1)
+
+    # ---- x / y on the mesh: reduce-scatter (all-to-all of slices + the rank's own fold) and all-gather
+    def _mesh_ok(self, t):
+        """the buffer divides into one slice of whole limbs per rank, and the backend can fold a slice from pieces"""
+        if not (self.mesh and self._active() and hasattr(self.b, "fold_pieces")):
+            return False
+        world = self.dist.get_world_size(self.group)
+        return t.numel() % (world * self.b.limb_words()) == 0
+
+    def _mesh_scatter(self, t, name, async_op=False):
+        """all-to-all: piece p of the receive buffer = rank p's slice `rank` of its partial sum"""
+        recv = self._recv.get(name)
+        if recv is None or recv.numel() != t.numel() or recv.device != t.device:
+            recv = self._recv[name] = t.new_empty(t.numel())
+        return recv, self.dist.all_to_all_single(recv, t.view(-1), group=self.group, async_op=async_op)
+
+    def _mesh_finish(self, t, recv, which):
+        """this rank's slice: sum of the pieces, fold, MForm (into its place in t); then every rank's folded slice to everybody"""
+        world, rank = self.dist.get_world_size(self.group), self.dist.get_rank(self.group)
+        per = t.numel() // world
+        self.b.fold_pieces(which, recv, world, per, rank * per, per)
+        flat = t.view(-1)
+        with _section(self.b):
+            self.dist.all_gather_into_tensor(flat, flat[rank * per:(rank + 1) * per].clone(), group=self.group)
 
     def _all_reduce(self, t):
         if self._active():
@@ -94,7 +122,24 @@ class ShardedMulRelin:
     def run(self):
         b = self.b
         x, y = b.partial_xy()                 # torch int64 views of the rank's partial sums
-        if self._active() and getattr(b, "sync", "host") == "stream" and hasattr(b, "finish_head"):
+        self.used_mesh = False
+        if self._mesh_ok(x) and hasattr(b, "finish_head"):
+            self.used_mesh = True
+            # y first (F1 -> Decompose(t_i), the long chain); x's slices travel while the head runs
+            stream = getattr(b, "sync", "host") == "stream"
+            with _section(b):
+                ry, wy = self._mesh_scatter(y, "y", async_op=stream)
+                rx, wx = self._mesh_scatter(x, "x", async_op=stream)
+                if stream:
+                    wy.wait()                 # blocks the engine stream, not the host
+            self._mesh_finish(y, ry, "y")
+            b.finish_head()
+            if stream:
+                with b.torch_section():
+                    wx.wait()
+            self._mesh_finish(x, rx, "x")
+            full = b.finish_tail()
+        elif self._active() and getattr(b, "sync", "host") == "stream" and hasattr(b, "finish_head"):
             # y is needed first (F1 -> Decompose(t_i), the long chain), x only by step E: both reductions are started now, the
             # engine stream waits for y, and x is reduced under F1 / Decompose
             dist = self.dist
@@ -224,6 +269,16 @@ class HipShardBackend(_TorchOnEngineStream):
     def fold_xy(self):
         self.fold_x()
         self.fold_y()
+
+    def limb_words(self):
+        return self.params.N()
+
+    def fold_pieces(self, which, recv, npieces, piece_words, first_word, nwords):
+        """x or y: the slice [first_word, first_word + nwords) <- MForm(sum over the pieces of `recv` mod q) (mkhe_swk_fold_pieces)"""
+        N = self.params.N()
+        dst = (self.x if which == "x" else self.y).devptr() + 8 * first_word
+        self.check(self.lib().mkhe_swk_fold_pieces(self.params.ctx, self.C.c_void_p(recv.data_ptr()), npieces, piece_words, first_word // N, nwords // N,
+                                                   self.level, 1, self.C.c_void_p(dst)))
 
     def _spread_out(self):
         """the rank's slots of `out` into the full-width ciphertext (zeros elsewhere)"""

@@ -37,6 +37,30 @@ class OracleShardBackend:
                     r, k = self._ring(j)
                     buf[i][j] = r.mform(k, r.reduce(k, buf[i][j]))
 
+    # ---- the mesh form of the x / y exchange (ShardedMulRelin._mesh_*): this rank folds its slice from the pieces it received
+    def limb_words(self):
+        return self.ks.N
+
+    def fold_pieces(self, which, recv, npieces, piece_words, first_word, nwords):
+        buf = self.x if which == "x" else self.y
+        N, mtot = self.ks.N, buf.shape[1]
+        pieces = recv.numpy().view(np.uint64).reshape(npieces, piece_words)
+        flat = buf.reshape(-1)
+        for i in range(nwords // N):
+            l = first_word // N + i
+            d, j = divmod(l, mtot)
+            if d >= self.ks.beta(self.level) or j not in self.act:
+                continue
+            r, k = self._ring(j)
+            tot = pieces[:, i * N:(i + 1) * N].sum(axis=0, dtype=np.uint64)
+            flat[l * N:(l + 1) * N] = r.mform(k, r.reduce(k, tot))
+
+    def finish_head(self):
+        pass                                                  # (the oracle has no split finish: everything happens in finish_tail)
+
+    def finish_tail(self):
+        return self.finish()
+
     def finish(self):
         ido, out = self.ks.mr_finish(self.level, self.ids0, self.op0, self.ids1, self.op1, self.x, self.y,
                                      self.rlk, self.u, self.with_c0)

@@ -88,4 +88,4 @@ def test_product_library_reads_only_the_documented_environment():
     sw = os.path.join(os.path.dirname(_abi.LIB_PATH), "libmkhe_hip_switches.so")
     assert os.path.exists(sw), "build() makes the -DMKHE_SWITCHES library too"
     out = subprocess.run(["strings", sw], capture_output=True, text=True, check=True).stdout
-    assert sum(1 for l in out.splitlines() if re.fullmatch(r"MKHE_[A-Z0-9_]+", l.strip())) > 30
+    assert sum(1 for l in out.splitlines() if re.fullmatch(r"MKHE_[A-Z0-9_]+", l.strip())) >= 25          # (round 6: 27 switch names left after the pruning)

@@ -65,6 +65,28 @@ def _worker(rank, world, port, names, seed, out_path):
     dist.destroy_process_group()
 
 
+def _mesh_worker(rank, world, port, names, seed, out_path, limbs, mesh):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_oracle_backend import OracleShardBackend
+    from mkhe_kklss_amd.dist import ShardedMulRelin
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ks, level, op0, op1, rlk, u, ref = make_case(H.small_ckks(10, limbs), names, seed)
+    b = OracleShardBackend(ks, names, rank, world, op0, op1, rlk, u, level, torch)
+    sm = ShardedMulRelin(b, dist, mesh=mesh)
+    sm.run()
+    ok = bool((b.full == ref).all()) and sm.used_mesh == mesh
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, np.array([ok]))
+    else:
+        assert ok
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -85,6 +107,16 @@ def test_sharded_mulrelin_gloo_world2(tmp_path, names):
 # doing each rank's arithmetic) -- the GPU boxes of this pool admit six processes on their one card, so `--gpus 8` cannot be rehearsed there.
 #   5 ranks, 3 parties: six half-party units on five ranks (the uneven split);  5 ranks, 5 parties: whole parties;
 #   8 ranks, 4 parties: one half-party unit per rank -- the driver's `bench.py --gpus 8` at its default four parties.
+@pytest.mark.parametrize("world,names,mesh", [(2, ["u0", "u1"], True), (4, ["u0", "u1", "u2"], True), (8, ["u0", "u1", "u2", "u3"], True), (4, ["u0", "u1"], False)])
+def test_sharded_mulrelin_gloo_mesh_exchange(tmp_path, world, names, mesh):
+    """x and y as reduce-scatter + all-gather over disjoint limb slices (round 6): 4 Q + 2 P limbs, 4 digits = 24 limbs of a switching
+    key, which 2, 4 and 8 ranks divide -- every rank folds its own slice from the pieces of one all-to-all; and the all-reduce form on request."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_mesh_worker, args=(world, _free_port(), names, 23, out, 4, mesh), nprocs=world, join=True)
+    assert np.load(out)[0]
+
+
 @pytest.mark.parametrize("world,names", [(5, ["u0", "u1", "u2"]), (5, ["u0", "u1", "u2", "u3", "u4"]), (8, ["u0", "u1", "u2", "u3"])])
 def test_sharded_mulrelin_gloo_world5_and_8(tmp_path, world, names):
     import torch.multiprocessing as mp
@@ -133,6 +165,47 @@ def test_sharded_mulrelin_device_emulated_ranks(world, names):
         torch.cuda.synchronize()
         b.fold_xy()
         outs.append(b.finish().clone())
+    tot = sum(outs[1:], outs[0])
+    b = bs[0]
+    b.tfull.copy_(tot)
+    torch.cuda.synchronize()
+    b.fold_out()
+    assert (b.full.download() == ref).all()
+
+
+@pytest.mark.gpu
+def test_sharded_mulrelin_device_emulated_ranks_headline_ring():
+    """PN15QP880 at full size, eight parties on two emulated ranks (four parties each): every rank's finish runs step F2 inside the Decompose NTT of its
+    t_i (csrc/ntt16_f2_kernels.hip; round 6) behind a plain inner-product launch for its step-E items -- x comes from the other rank --, and the split
+    finish (head with y, tail with x) gives the same bits as the oracle's single-device evaluation."""
+    import torch
+    from mkhe_kklss_amd import mkckks
+    from mkhe_kklss_amd.dist import HipShardBackend
+    pset = H.PN15QP880
+    names = ["u%d" % i for i in range(8)]
+    ks, level, op0, op1, rlk, u, ref = make_case(pset, names, 15)
+    world = 2
+    bs = []
+    for r in range(world):
+        params = mkckks.Parameters(pset["logN"], pset["Q"], pset["P"], pset["scale"])
+        params.AddCRS(-1, u)
+        bs.append(HipShardBackend(params, names, r, world, op0, op1, rlk, level, torch, 0))
+    xs, ys = [], []
+    for b in bs:
+        x, y = b.partial_xy()
+        b.before_collective()
+        xs.append(x.clone()); ys.append(y.clone())
+    sx, sy = sum(xs[1:], xs[0]), sum(ys[1:], ys[0])
+    outs = []
+    for b in bs:
+        b.ty.copy_(sy)
+        torch.cuda.synchronize()
+        b.fold_y()
+        b.finish_head()
+        b.tx.copy_(sx)
+        torch.cuda.synchronize()
+        b.fold_x()
+        outs.append(b.finish_tail().clone())
     tot = sum(outs[1:], outs[0])
     b = bs[0]
     b.tfull.copy_(tot)

@@ -345,8 +345,9 @@ print("ok")
 '''
 
 
-@pytest.mark.parametrize("env_extra", [dict(MKHE_F2_BALANCE="1", MKHE_F2_WRED="5"), dict(MKHE_F2_BALANCE="1", MKHE_F2_WRED="2"), dict(MKHE_F2_FUSED="0")],
-                         ids=["weighted_cuts", "weighted_cuts_light", "unfused"])
+@pytest.mark.parametrize("env_extra", [dict(MKHE_F2_BALANCE="1", MKHE_F2_WRED="5"), dict(MKHE_F2_BALANCE="1", MKHE_F2_WRED="2"), dict(MKHE_F2_FUSED="0"),
+                                       dict(MKHE_FUSE_E="0"), dict(MKHE_FUSE_Y="0", MKHE_FUSE_RESCALE="0")],
+                         ids=["weighted_cuts", "weighted_cuts_light", "unfused", "step_E_as_plain_items", "x_y_E_as_plain_launches"])
 def test_fused_f2_schedules(env_extra):
     r = _run(SCRIPT_F2, env_extra)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -2,10 +2,10 @@
 # Profile set of one round (run on the GPU box through gpurun):  gpurun --timeout 1200 -- 'bash tools/profile_round.sh r4a'
 # then, here:  python tools/collect_profiles.py r4a r4 "PN15QP880 k=4"
 # Every profiled pass runs the SAME command, `python3 bench.py --no-cpu --no-extras` with MKHE_NO_OVERLAP=1 (each kernel alone on the
-# main stream).  With --no-extras the dominant kernel (the Decompose-fused forward NTT) is launched exactly 2 * (2 * (W + K) + 300 + K)
-# times: twice per MulRelin -- in the cold-start leg (W + K), the 100 + 200 steps of the steady-state leg, the timed region (W + K)
-# and the HIP-event leg (K).
-# Round 5: two calls (the default bench line carries more legs now): `bash tools/profile_round.sh r5a part1`, then `... r5a part2`; no second argument = everything.
+# main stream).  With --no-extras the dominant kernel (the Decompose-fused forward NTT) is launched exactly 2 * (W + K) + 300 + K
+# times: once per MulRelin since round 6 (the 1792-limb hoisting launch; the t_i are transformed inside ntt16_f2_kernel) -- in the cold-start
+# leg (W + K), the 100 + 200 steps of the steady-state leg, the timed region (W + K) and the HIP-event leg (K).
+# Round 6: three calls: `bash tools/profile_round.sh r6a part1`, then `... r6a part2`, then `... r6a part3`; no second argument = everything.
 TAG=${1:-r5}
 PART=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -14,7 +14,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
 P="rocprofv3 --output-format csv --kernel-trace"
-if [ "$PART" != part2 ]; then
+if [ "$PART" = part1 ] || [ "$PART" = all ]; then
 python3 bench.py > $O/bench_plain.json 2> $O/bench_plain.err
 MKHE_NTT32=1 python3 bench.py --no-cpu > $O/bench_plain_h32.json 2> $O/bench_plain_h32.err
 MKHE_NTT32=0 python3 bench.py --no-cpu > $O/bench_plain_h16.json 2> $O/bench_plain_h16.err
@@ -37,7 +37,7 @@ $P --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE 
 $P --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $O/sq_d -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu --no-extras > $O/sq_d.json 2> $O/sq_d.err
 echo "sq done"
 fi
-if [ "$PART" != part1 ]; then
+if [ "$PART" = part2 ] || [ "$PART" = all ]; then
 export MKHE_NO_OVERLAP=1
 $P --stats -d $O/stats_bfv -o p -- python3 bench.py --scheme bfv --steps 10 --warmup 2 --no-cpu > $O/bench_bfv.json 2> $O/bench_bfv.err
 unset MKHE_NO_OVERLAP
@@ -55,6 +55,8 @@ python3 bench.py --scheme cnn --parties 2 --steps 20 --warmup 3 --no-cpu --batch
 for B in 4 8 16; do python3 bench.py --params PN14QP439 --steps 30 --warmup 3 --no-cpu --no-extras --batch $B 2>/dev/null; done > $O/pn14_batch.jsonl
 for k in 1 2 4 8 16; do python3 bench.py --parties $k --no-cpu --device-keys --steps 20 --warmup 3 2>/dev/null; done > $O/party_sweep.jsonl
 echo "secondary done"
+fi
+if [ "$PART" = part3 ] || [ "$PART" = all ]; then
 # issue-rate microbenchmarks (built from source here: no binaries in the tree), power / clock under the dominant kernel, steady-state ablation table of the shipped kernel
 for u in bfly30u_rate bfly31_rate valu_rate bfly_asm_rate read_bw; do [ -f tools/ubench/$u.hip ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip 2>/dev/null; done
 (echo "== tools/ubench/bfly30u_rate.hip"; tools/ubench/bfly30u_rate; echo "== tools/ubench/bfly31_rate.hip"; tools/ubench/bfly31_rate; echo "== tools/ubench/valu_rate.hip"; tools/ubench/valu_rate; echo "== tools/ubench/bfly_asm_rate.hip"; tools/ubench/bfly_asm_rate; echo "== tools/ubench/read_bw.hip"; tools/ubench/read_bw) > $O/ubench.txt 2>&1
@@ -66,6 +68,12 @@ bash tools/power_probe.sh > $O/power_probe.txt 2>&1
     "ring_8:-DMKHE_H32_RING=8" "prefetch_next_limb:-DMKHE_H32_PREFETCH=1" "round3_schedule_byte_load:-DMKHE_H16_X_SCHEDBYTE" "shipped_again:"
  export MKHE_NTT32=0; echo "## ntt16_fwd_kernel<true> (MKHE_NTT32=0)"; REPS=1500 bash tools/ntt16_variants.sh "shipped:" "no_mem_no_xchg:-DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOSTORE -DMKHE_H16_X_NOXCHG=15" \
     "no_bfly:-DMKHE_H16_X_NOBFLY=3" "round3_schedule_byte_load:-DMKHE_H16_X_SCHEDBYTE" "shipped_again:"; unset MKHE_NTT32) > $O/ntt16_ablation.txt 2>&1
+# the fused Decompose + step-F2 kernel (round 6) inside the MulRelin: shipped, its experiments, and its timing-only ablations
+bash tools/f2_variants.sh "shipped:" "unpipelined_source_loads:-DMKHE_F2_SPIPE=0" "phase_C_twiddles_from_L2:-DMKHE_F2_TWLDS=0" "no_wave_priorities:-DMKHE_F2_PHPRIO=0" "key_ring_4_pairs_12:-DMKHE_F2_KRING=4 -DMKHE_F2_SP=12" \
+    "no_products_no_keys:-DMKHE_F2_X_NOMAC -DMKHE_F2_X_NOKEYS" "no_key_loads:-DMKHE_F2_X_NOKEYS" "no_source_loads:-DMKHE_H16_X_NOSRC" "no_exchanges:-DMKHE_H16_X_NOXCHG=15" "no_twiddle_loads:-DMKHE_H16_X_NOTWLOAD" \
+    "vector_alu_only:-DMKHE_H16_X_NOTWLOAD -DMKHE_H16_X_NOSRC -DMKHE_H16_X_NOXCHG=15 -DMKHE_F2_X_NOKEYS" "shipped_again:" > $O/f2_variants.txt 2>&1
+(echo "== fused (product library)"; python3 bench.py --no-cpu --no-extras 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), 'MulRelin/s', {k.split()[0]: round(v['ms_per_step']*1e3,1) for k,v in d['roofline']['kernels'].items()})"
+ for i in 1 2 3; do for m in 0 1; do echo "== MKHE_F2_FUSED=$m (switches library)"; MKHE_LIB=$R/mkhe-kklss_amd/lib/libmkhe_hip_switches.so MKHE_F2_FUSED=$m python3 bench.py --no-cpu --no-extras 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), 'MulRelin/s', round(d['config']['mulrelin_per_sec_cold_start'],1), 'cold', {k.split()[0]: round(v['ms_per_step']*1e3,1) for k,v in d['roofline']['kernels'].items()})"; done; done) > $O/f2_fused_ab.txt 2>&1
 (echo "== MKHE_NTT32=0 (ntt16_fwd_kernel<true>)"; MKHE_NTT32=0 python3 tools/ntt16_bench.py 1500; echo "== MKHE_NTT32=1 (ntt32_fwd_kernel)"; MKHE_NTT32=1 python3 tools/ntt16_bench.py 1500) > $O/ntt16_bench.txt 2>&1
 # the Decompose launches INSIDE the MulRelin (kernel trace of the bench command, second half of the run): the two launch sizes apart, both kernels
 bash tools/trace_ntt_in_context.sh h16:MKHE_NTT32=0 h32:MKHE_NTT32=1 h16_again:MKHE_NTT32=0 h32_again:MKHE_NTT32=1 > $O/ntt_in_context.txt 2>&1
