@@ -19,7 +19,8 @@ for f in ("bench_plain", "bench_plain_h32", "bench_plain_h16", "bench_noovl", "b
         shutil.copy(src, os.path.join(P, "%s_%s.json" % (tag, f)))
 for f, t in (("party_sweep.jsonl", "party_sweep.jsonl"), ("ubench.txt", "ubench.txt"), ("ntt16_bench.txt", "ntt16_launch_sizes.txt"), ("power_probe.txt", "power_probe.txt"),
              ("ntt16_ablation.txt", "ntt16_ablation.txt"), ("ntt_in_context.txt", "ntt_in_context.txt"), ("pn14_batch.jsonl", "pn14_batch.jsonl"),
-             ("f2_variants.txt", "f2_variants.txt"), ("f2_fused_ab.txt", "f2_fused_ab.txt")):
+             ("f2_variants.txt", "f2_variants.txt"), ("f2_fused_ab.txt", "f2_fused_ab.txt"), ("pmc_unfused.txt", "pmc_unfused.txt"), ("f2_trace.txt", "f2_trace.txt"),
+             ("dist_5ranks.json", "dist_5ranks.json")):
     src = os.path.join(G, f)
     if os.path.exists(src):
         txt = "\n".join(l for l in open(src).read().split("\n") if not l.startswith(("RCCL", "HIP version", "ROCm version", "Hostname", "Librccl", "/opt/amdgpu")))

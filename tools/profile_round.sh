@@ -5,7 +5,8 @@
 # main stream).  With --no-extras the dominant kernel (the Decompose-fused forward NTT) is launched exactly 2 * (W + K) + 300 + K
 # times: once per MulRelin since round 6 (the 1792-limb hoisting launch; the t_i are transformed inside ntt16_f2_kernel) -- in the cold-start
 # leg (W + K), the 100 + 200 steps of the steady-state leg, the timed region (W + K) and the HIP-event leg (K).
-# Round 6: three calls: `bash tools/profile_round.sh r6a part1`, then `... r6a part2`, then `... r6a part3`; no second argument = everything.
+# Round 6: `bash tools/profile_round.sh r6a part1`, `... part2`, `... part3` (no second argument = these three); then, here, tools/collect_profiles.py (-> traffic.json),
+# then `... r6a part4` (the bench lines again WITH the traffic figures, the PMC passes of the round-5 launch set, the phase trace, N > 1) and collect once more.
 TAG=${1:-r5}
 PART=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -48,7 +49,7 @@ python3 bench.py --params PN16QP1761 --parties 8 --steps 10 --warmup 2 > $O/benc
 echo "pn16 done"
 python3 bench.py --scheme cnn --parties 2 --steps 20 --warmup 3 > $O/bench_cnn2.json 2> $O/bench_cnn2.err
 python3 bench.py --scheme cnn --parties 4 --steps 20 --warmup 3 > $O/bench_cnn4.json 2> $O/bench_cnn4.err
-python3 bench.py --params PN14QP439 --steps 20 --warmup 3 --no-cpu > $O/bench_pn14.json 2> $O/bench_pn14.err
+python3 bench.py --params PN14QP439 --steps 20 --warmup 3 > $O/bench_pn14.json 2> $O/bench_pn14.err
 python3 bench.py --scheme cnn --parties 4 --steps 20 --warmup 3 --batch 8 > $O/bench_cnn4_batch8.json 2> $O/bench_cnn4_batch8.err
 python3 bench.py --scheme cnn --parties 4 --steps 20 --warmup 3 --no-cpu --batch 16 > $O/bench_cnn4_batch16.json 2> $O/bench_cnn4_batch16.err
 python3 bench.py --scheme cnn --parties 2 --steps 20 --warmup 3 --no-cpu --batch 8 > $O/bench_cnn2_batch8.json 2> $O/bench_cnn2_batch8.err
@@ -79,6 +80,34 @@ bash tools/f2_variants.sh "shipped:" "unpipelined_source_loads:-DMKHE_F2_SPIPE=0
 bash tools/trace_ntt_in_context.sh h16:MKHE_NTT32=0 h32:MKHE_NTT32=1 h16_again:MKHE_NTT32=0 h32_again:MKHE_NTT32=1 > $O/ntt_in_context.txt 2>&1
 rm -rf $R/gpurun_out/ctx
 echo "ntt done"
+fi
+if [ "$PART" = part4 ]; then
+# AFTER tools/collect_profiles.py has written profiles/traffic.json for these sources: the bench lines again, so that the committed lines carry
+# roofline.traffic too (round 5's were recorded before and say null); the PMC passes of the round-5 launch set on the same box; the phase trace; N > 1
+python3 bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+MKHE_NTT32=1 python3 bench.py --no-cpu > $O/bench_plain_h32.json 2> $O/bench_plain_h32.err
+MKHE_NTT32=0 python3 bench.py --no-cpu > $O/bench_plain_h16.json 2> $O/bench_plain_h16.err
+echo "lines done"
+export MKHE_NO_OVERLAP=1 MKHE_NTT32=0 MKHE_LIB=$R/mkhe-kklss_amd/lib/libmkhe_hip_switches.so MKHE_F2_FUSED=0
+$P --pmc FETCH_SIZE -d $O/pmc_fetch_unfused -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-extras > /dev/null 2> $O/pmc_fetch_unfused.err
+$P --pmc WRITE_SIZE -d $O/pmc_write_unfused -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-extras > /dev/null 2> $O/pmc_write_unfused.err
+unset MKHE_NO_OVERLAP MKHE_NTT32 MKHE_LIB MKHE_F2_FUSED
+(echo "# HBM bytes per launch, (2 FETCH_SIZE + WRITE_SIZE) 1024, of the ROUND-5 launch set (MKHE_F2_FUSED=0, diagnostic library, MKHE_NTT32=0) on the box of this round's traffic.json"
+ python3 tools/traffic_from_pmc.py $O/pmc_fetch_unfused $O/pmc_write_unfused "PN15QP880 k=4 (MKHE_F2_FUSED=0)" 6 2 | python3 -c "
+import json, sys
+d = json.load(sys.stdin); tot = 0.0
+per_step = {}
+for k, v in d['kernels'].items():
+    if '<' not in k and any(x.startswith(k + '<') for x in d['kernels']): continue          # (the un-templated alias of a templated name)
+    n = v['launches'] / 322.0
+    per_step[k] = (n, v['hbm_bytes_per_launch'])
+    tot += n * v['hbm_bytes_per_launch']
+for k, (n, b) in sorted(per_step.items(), key=lambda kv: -kv[1][0] * kv[1][1]): print('%-34s %4.1f launches / step  %8.1f MB / launch' % (k, n, b / 1e6))
+print('per step: %.2f GB' % (tot / 1e9))") > $O/pmc_unfused.txt 2>&1
+echo "unfused pmc done"
+[ -f $R/mkhe-kklss_amd/lib/libmkhe_hip_trace.so ] && MKHE_LIB=$R/mkhe-kklss_amd/lib/libmkhe_hip_trace.so timeout -k 10 300 python3 tools/f2_trace.py > $O/f2_trace.txt 2>&1
+MKHE_DIST_BACKEND=gloo MKHE_DIST_ONE_DEVICE=1 timeout -k 10 600 python3 bench.py --gpus 5 --steps 2 --warmup 1 > $O/dist_5ranks.json 2> $O/dist_5ranks.err
+echo "part4 done"
 fi
 find $O -name '*kernel_trace.csv' -path '*stats_*' -delete
 find $O -name '*agent_info.csv' -delete
