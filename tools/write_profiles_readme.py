@@ -67,6 +67,21 @@ def step_bytes(j):
     return tot, cov_ms / all_ms
 
 
+nsteps = 2 * (tr["warmup"] + tr["steps"]) + 300 + tr["steps"]
+all_bytes = 0.0
+for k, v in tr["kernels"].items():
+    if "<" not in k and any(x.startswith(k + "<") for x in tr["kernels"]):
+        continue                                     # (the un-templated alias of a templated name)
+    if k in ("ntt32_fwd_kernel<true>", "ntt16_fwd_kernel<true>") and k != R["kernel"].split()[0]:
+        continue                                     # (the other form of the dominant kernel, from the second pair of passes)
+    all_bytes += v["launches"] / nsteps * v["hbm_bytes_per_launch"]
+m_unf = re.search(r"per step: ([0-9.]+) GB", open(need(P + tag + "_pmc_unfused.txt")).read())
+if not m_unf:
+    sys.exit("tools/write_profiles_readme.py: no per-step figure in %s_pmc_unfused.txt" % tag)
+unf_bytes = float(m_unf.group(1))
+f2k = [v for k, v in pl["roofline"]["kernels"].items() if k.startswith("ntt16_f2_kernel")][0]
+f2_pmc, f2_alg = f2k["hbm_bytes_per_launch_pmc"], f2k["achieved_GBs"] * 1e9 * f2k["avg_launch_us"] * 1e-6
+tail_us = sum(1e3 * v["ms_per_step"] for k, v in pl["roofline"]["kernels"].items() if k.split("<")[0].split()[0] in ("ntt_inv_kernel", "moddown[_batch]_kernel", "tensor_kernel", "ntt_fwd_kernel"))
 DOM = R["kernel"].split()[0]
 davg, dcalls, dmn, dmx = st(DOM.split("<")[0])
 f2avg, f2calls, f2mn, f2mx = st("ntt16_f2_kernel")
@@ -116,7 +131,7 @@ extra_files = [("%s_gputests.txt" % tag, "`python -m pytest tests -m gpu` on the
 txt = f"""# profiles/ — rocprofv3 evidence, round 6 (`{tag}_*`)
 
 Everything here was produced on ONE MI355X through `gpurun` by `tools/profile_round.sh {tag}a part1 | part2 | part3` and distilled by `tools/collect_profiles.py`; this file is
-generated (`tools/write_profiles_readme.py {tag}`: a figure that is missing from the tracked files stops the generator — round 5 printed "nan" for an empty table).
+generated (`tools/write_profiles_readme.py {tag}`: a figure that is missing from the tracked files stops the generator — round 5 printed not-a-number for an empty table).
 Earlier rounds: `README_r5.md` (its narrative of rounds 1–5 stands, except where this file says otherwise) and the `r1a_ … r5_` files.  Boxes differ by ± 3 %
 (parts that throttle at 1255 W by more): compare only inside one file or one call.
 
@@ -144,7 +159,10 @@ Per kernel class (HIP events on the context stream, one kernel at a time; algori
 |---|---|---|---|---|---|
 {table(pl)}
 
-HBM bytes per step by the counters: **{tot_bytes / 1e9:.2f} GB** over the classes whose launch pattern matches ({100 * cov:.0f} % of the kernel time) — round 5: 2.68 GB.
+HBM bytes per step by the counters, every kernel of the step (`traffic.json`: launches ÷ the {nsteps} steps of the profiled command × bytes per launch): **{all_bytes / 1e9:.2f} GB**;
+the round-5 launch set on the same box, same passes (`{tag}_pmc_unfused.txt`, `MKHE_F2_FUSED=0`): {unf_bytes:.2f} GB.  (VERDICT r5 asked for ≤ 2.25 GB: not reached — `ntt16_f2_kernel` moves {f2_pmc / 1e6:.0f} MB
+per launch where its byte model says {f2_alg / 1e6:.0f}: every t_i limb is fetched once per XCD, and the CRS u by more than one of the four parties' workgroups.)
+The latency-bound tail (inverse NTTs, ModDowns, tensor, small forward NTTs): {tail_us:.0f} µs per step (VERDICT r5 asked for ≤ 130: not reached, and not attacked this round beyond the fused kernel).
 
 ## Step F2 inside the Decompose NTT of the t_i (`ntt16_f2_kernel`, DESIGN.md §4.6)
 
