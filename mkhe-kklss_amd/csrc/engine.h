@@ -198,6 +198,7 @@ class Context {
     int ext_merge_members(int level) const;      // members a virtual item may have at this level (< 2: no merging)
     bool ext_plan_merge(int level, const ExtItem* items, int n, ExtMerge& mp) const;
     void ext_front(int level, const ExtItem* items, int n, u64* c1, const ExtMerge* mp = nullptr);   // inner products + lazy inverse NTT into c1 [n][mtot][N]
+    bool ext_front_f2(int level, const ExtItem* items, int n, u64* c1, ExtInnerArgs& ia, unsigned short* f2_parts);
     void ext_back(int level, const ExtItem* items, int n, const u64* c1, u64 galEl = 0, const ExtMerge* mp = nullptr);   // ModDown of c1 into / onto the destinations [signed-permuted]
 
     // ---- limb-sharded multi-GPU evaluation (mkhe_kklss_amd/dist.py LimbShardedMulRelin): this context owns a subset of

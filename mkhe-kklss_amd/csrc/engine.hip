@@ -1059,6 +1059,44 @@ bool Context::ext_plan_merge(int level, const ExtItem* it, int n, ExtMerge& mp) 
     return any;
 }
 
+// The product kernel of a batch whose F2 items come out of the Decompose NTT of the t_i itself (N = 2^15, ntt16_f2_kernel; ExtItem::f2_party).  Returns whether
+// the products arrive in parts (f2_parts[i]: NttBatch::vi_parts of item i -- the inverse NTT adds them at its load).
+bool Context::ext_front_f2(int level, const ExtItem* it, int n, u64* c1, ExtInnerArgs& ia, unsigned short* f2_parts) {
+    const size_t item_words = (size_t)mtot * N;
+    // N = 2^15: the F2 products come out of the Decompose NTT of the t_i itself (ntt16_f2_kernel).  The other items of the batch exist already
+    // (step E computed by the F1 kernel: `pre`) or are plain products of stored digits -- the sharded finish, more parties than the F1 kernel's
+    // forms take: the inner-product kernel computes those first and skips the F2 items (role 2: "computed elsewhere")
+    bool others = false;
+    for (int i = 0; i < n; ++i) {
+        if (it[i].f2_party >= 0) { if (it[i].pre || it[i].ah2) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them"); ia.pair[i] = 2; }      // (also undoes the pairing of a party's two products above: neither is computed here)
+        else others = others || !(it[i].pre && !it[i].pre_src);
+    }
+    if (others) launch_ext_inner(ia, s_);
+    const int np0 = (int)ext_f2_src_.size();
+    const F2Sched& sc = f2_schedule(np0, level);
+    F2FusedArgs fa{};
+    fa.segs = sc.d_segs; fa.nwg = sc.nwg; fa.c1 = c1; fa.item_words = (long)item_words; fa.digit_stride = (long)item_words;
+    for (int a = 0; a < np0; ++a) { fa.src[a] = ext_f2_src_[a]; fa.item_v[a] = fa.item_u[a] = -1; }
+    int nf2 = 0;
+    for (int i = 0; i < n; ++i) {
+        const int a = it[i].f2_party;
+        if (a < 0) continue;
+        if (a >= np0) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
+        if (it[i].f2_key == 0) { fa.kv[a] = it[i].bg; fa.item_v[a] = i; fa.extra_v[a] = n + nf2 * (sc.parts - 1); }
+        else { if (fa.ku && fa.ku != it[i].bg) throw Error("mkhe: internal: fused F2 products with more than one CRS"); fa.ku = it[i].bg; fa.item_u[a] = i; fa.extra_u[a] = n + nf2 * (sc.parts - 1); }
+        f2_parts[i] = (unsigned short)(((n + nf2 * (sc.parts - 1)) << 8) | (sc.parts - 1));
+        ++nf2;
+    }
+    for (int a = 0; a < np0; ++a) if (fa.item_v[a] < 0 || fa.item_u[a] < 0 || !fa.kv[a]) throw Error("mkhe: internal: a party without its two F2 products");
+    if (n + nf2 * (sc.parts - 1) > 255) throw Error("mkhe: internal: too many product parts");
+    fa.mods = d_mods; fa.psi = d_psi; fa.psi31 = d_psi31; fa.psi31n = d_psi31n; fa.u_mods = u_mods_;
+    for (int m2 = 0; m2 < mall && m2 < NTT_MAX_SLOTS; ++m2) { if (small16_[m2]) fa.small_mask |= 1ull << m2; fa.sched[m2] = h16_sched_.empty() ? 15 : h16_sched_[m2]; }
+    { NttBatch q{}; slots_qp(q, level); for (int s2 = 0; s2 < q.nslots; ++s2) fa.mod[s2] = q.mod[s2]; }
+    fa.trace = ntt_trace;
+    launch_ntt16_f2(fa, s_);
+    return sc.parts > 1;
+}
+
 void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtMerge* mp) {
     const int nb = beta(level), nslots = nslots_qp(level);
     const size_t item_words = (size_t)mtot * N;
@@ -1134,39 +1172,8 @@ void Context::ext_front(int level, const ExtItem* it, int n, u64* c1, const ExtM
                   throw Error("mkhe: internal: digits left after the cross stages read as a full transform");
       }
       if (!ext_f2_src_.empty()) {
-          // N = 2^15: the F2 products come out of the Decompose NTT of the t_i itself (ntt16_f2_kernel).  The other items of the batch exist already
-          // (step E computed by the F1 kernel: `pre`) or are plain products of stored digits -- the sharded finish, more parties than the F1 kernel's
-          // forms take: the inner-product kernel computes those first and skips the F2 items (role 2: "computed elsewhere")
           if (xby || xy || xyb || !mp || !ext_staged_.empty()) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
-          bool others = false;
-          for (int i = 0; i < n; ++i) {
-              if (it[i].f2_party >= 0) { if (it[i].pre || it[i].ah2) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them"); ia.pair[i] = 2; }      // (also undoes the pairing of a party's two products above: neither is computed here)
-              else others = others || !(it[i].pre && !it[i].pre_src);
-          }
-          if (others) launch_ext_inner(ia, s_);
-          const int np0 = (int)ext_f2_src_.size();
-          const F2Sched& sc = f2_schedule(np0, level);
-          F2FusedArgs fa{};
-          fa.segs = sc.d_segs; fa.nwg = sc.nwg; fa.c1 = c1; fa.item_words = (long)item_words; fa.digit_stride = (long)item_words;
-          for (int a = 0; a < np0; ++a) { fa.src[a] = ext_f2_src_[a]; fa.item_v[a] = fa.item_u[a] = -1; }
-          int nf2 = 0;
-          for (int i = 0; i < n; ++i) {
-              const int a = it[i].f2_party;
-              if (a < 0) continue;
-              if (a >= np0) throw Error("mkhe: internal: fused F2 products in a launch that cannot take them");
-              if (it[i].f2_key == 0) { fa.kv[a] = it[i].bg; fa.item_v[a] = i; fa.extra_v[a] = n + nf2 * (sc.parts - 1); }
-              else { if (fa.ku && fa.ku != it[i].bg) throw Error("mkhe: internal: fused F2 products with more than one CRS"); fa.ku = it[i].bg; fa.item_u[a] = i; fa.extra_u[a] = n + nf2 * (sc.parts - 1); }
-              f2_parts[i] = (unsigned short)(((n + nf2 * (sc.parts - 1)) << 8) | (sc.parts - 1));
-              ++nf2;
-          }
-          for (int a = 0; a < np0; ++a) if (fa.item_v[a] < 0 || fa.item_u[a] < 0 || !fa.kv[a]) throw Error("mkhe: internal: a party without its two F2 products");
-          if (n + nf2 * (sc.parts - 1) > 255) throw Error("mkhe: internal: too many product parts");
-          fa.mods = d_mods; fa.psi = d_psi; fa.psi31 = d_psi31; fa.psi31n = d_psi31n; fa.u_mods = u_mods_;
-          for (int m2 = 0; m2 < mall && m2 < NTT_MAX_SLOTS; ++m2) { if (small16_[m2]) fa.small_mask |= 1ull << m2; fa.sched[m2] = h16_sched_.empty() ? 15 : h16_sched_[m2]; }
-          { NttBatch q{}; slots_qp(q, level); for (int s2 = 0; s2 < q.nslots; ++s2) fa.mod[s2] = q.mod[s2]; }
-          any_parts = sc.parts > 1;
-          fa.trace = ntt_trace;
-          launch_ntt16_f2(fa, s_);
+          any_parts = ext_front_f2(level, it, n, c1, ia, f2_parts);
       } else if (!ext_staged_.empty()) {
           // the items' digit vectors were left after the cross stages (decompose_batch, stage_only): sub-transforms and products in one kernel
           if (xby || xy || xyb || two || (int)ext_staged_.size() > EXTF_MAX_V) throw Error("mkhe: internal: staged digits in a launch that cannot take them");

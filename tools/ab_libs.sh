@@ -1,6 +1,6 @@
 #!/bin/bash
 # one gpurun call: the headline bench (no CPU leg, no extras) once per library / environment, alternating as listed, with the per-class kernel times:
-#   bash tools/ab_libs.sh <tag> "<name>[:ENV=VAL,...]" ...     name = shipped | switches | a variant of tools/build_variant2.sh (build/var_<name>/lib.so)
+#   bash tools/ab_libs.sh <tag> "<name>[:ENV=VAL,...]" ...     name = shipped | switches | a variant of tools/build_variant.sh (build/var_<name>/lib.so)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1; shift
 mkdir -p $O
