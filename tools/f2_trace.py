@@ -1,5 +1,7 @@
-"""Diagnostic: per-wave phase timeline of ntt16_f2_kernel inside a 4-party PN15QP880 MulRelin (trace build: make -C mkhe-kklss_amd/csrc trace;
-MKHE_LIB=.../libmkhe_hip_trace.so python tools/f2_trace.py [parties]).  Where do a pass's cycles go when one workgroup owns the CU?"""
+"""Diagnostic: per-wave phase timeline of ntt16_f2_kernel inside a 4-party PN15QP880 MulRelin (trace build: make -C mkhe-kklss_amd/csrc trace XFLAGS=-DMKHE_F2_SPIPE=0;
+MKHE_LIB=.../libmkhe_hip_trace.so python tools/f2_trace.py [parties]).  Where do a pass's cycles go when one workgroup owns the CU?
+(The stamps cost registers: with the pipelined source loads the trace build spills inside the digit loop and its U-class passes come out slower than the product
+library's -- build the trace library with the two-group loads, -DMKHE_F2_SPIPE=0, whose timeline the stamps do not disturb.)"""
 import sys, os
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,6 +42,7 @@ t = tr.download().reshape(-1)[:NWG * NW * NP * 16].reshape(NWG, NW, NP, 16).asty
 names_ = ["loads + stage 0", "phase A", "xchg A->B (barriers)", "phase B (+ C twiddle requests)", "xchg B->C", "phase C (+ D requests)", "xchg C->D",
           "phase D (+ first key requests)", "xchg D->E", "products (16 x 2, key ring)"]
 ok = (t[..., 10] > t[..., 0]) & (t[..., 0] > 0) & (t[..., 12] < 64) & ((t[..., 10] - t[..., 0]) < 10_000_000)
+print("# tools/f2_trace.py: lib/libmkhe_hip_trace.so (make trace XFLAGS=-DMKHE_F2_SPIPE=0: two-group source loads, see the script's header), %d-party MulRelin on PN15QP880" % k)
 print("passes traced:", int(ok.sum()), "of", NWG * NW * 7 * (k // 4 if k >= 4 else 1))
 sel = t[ok]
 d = np.diff(sel[:, :11], axis=1)
