@@ -395,8 +395,9 @@ long long mkhe_pool_held_bytes(mkhe_ctx* ctx);                          /* -1: e
 int  mkhe_pool_trim(mkhe_ctx* ctx);
 /* diagnostic, no device call: the schedule of ntt16_f2_kernel (N = 2^15: step F2 of MulAndRelin, mkrlwe/keyswitch_hoisted.go:161-178, computed inside
  * the Decompose NTT of the t_i) for `parties` parties of op0, `nb` gadget digits, `nslots` limb slots with the relative cost weights[slot] of a pass,
- * on `grid` workgroups.  segs: grid * 3 records of 8 bytes {party, slot, half, first digit, digits, part, parts this run zeroes after its own, 0}
- * (digits = 0: no run).  Returns the workgroups used (0: no schedule within the kernel's limits) and the parts per product in *parts. */
+ * on `grid` workgroups (grid < 0: on the cheapest grid of at most -grid workgroups, as the engine plans it for a device of -grid CUs).  segs: |grid| * 3
+ * records of 8 bytes {party, slot, half, first digit, digits, part, parts this run zeroes after its own, 0} (digits = 0: no run).  Returns the workgroups
+ * used (0: no schedule within the kernel's limits) and the parts per product in *parts. */
 int  mkhe_f2_schedule_probe(int parties, int nb, int nslots, const long* weights, int grid, unsigned char* segs, int* parts);
 int  mkhe_prof_nclass(void);
 const char* mkhe_prof_name(int cls);

@@ -734,9 +734,10 @@ int mkhe_pool_trim(mkhe_ctx* ctx) { MKHE_TRY(need(ctx)->pool_trim_device()) }
 int mkhe_f2_schedule_probe(int parties, int nb, int nslots, const long* weights, int grid, unsigned char* segs, int* parts) {
     static_assert(sizeof(F2Seg) == 8 && F2_SEGS == 3, "include/mkhe.h documents the record");
     int p = 0;
-    if (!weights || !segs || grid < 1 || grid > 65536) { if (parts) *parts = 0; return 0; }
+    if (!weights || !segs || grid == 0 || grid < -65536 || grid > 65536) { if (parts) *parts = 0; return 0; }
     try {
-        const int n = f2_build_schedule(parties, nb, nslots, weights, grid, reinterpret_cast<F2Seg*>(segs), &p);
+        const int n = grid > 0 ? f2_build_schedule(parties, nb, nslots, weights, grid, reinterpret_cast<F2Seg*>(segs), &p)
+                               : f2_plan_schedule(parties, nb, nslots, weights, -grid, reinterpret_cast<F2Seg*>(segs), &p);
         if (parts) *parts = p;
         return n;
     } catch (...) { if (parts) *parts = 0; return 0; }

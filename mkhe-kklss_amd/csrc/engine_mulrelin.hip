@@ -291,8 +291,8 @@ void Context::mr_finish(const Ct& op0, const Ct& op1, const u64* x, const u64* y
 
 // ------------------------------------------------------------------ the schedule of ntt16_f2_kernel (ntt_kernels.h F2FusedArgs)
 // One workgroup per CU, one round: the kernel lasts as long as its longest workgroup, so the passes -- (party, limb slot, half limb, digit), parties
-// outermost, digits innermost -- are dealt by WEIGHT: a pass under a 59/60-bit modulus carries its partial reductions (MKHE_F2_WRED percent per
-// reduction point of the modulus's schedule; MKHE_F2_BALANCE=0: every pass the same, the cuts then fall on whole and half groups).  A workgroup's
+// outermost, digits innermost -- are dealt by WEIGHT: a pass under a 59/60-bit modulus carries its partial reductions (MKHE_F2_BALANCE percent per
+// reduction point of the modulus's schedule; 0, the default: every pass the same, the cuts then fall on whole and half groups).  A workgroup's
 // passes of one (party, slot, half) are a run = one part of that group's two products; parts = the most any group is cut into (the inverse NTT adds
 // them at its load: VI_SUMS), a group cut into fewer has its last run zero the others.  parts = 0: no schedule within the kernel's limits.
 bool Context::f2_fused_ok(int level, int n0, int n1) const {
@@ -305,8 +305,9 @@ bool Context::f2_fused_ok(int level, int n0, int n1) const {
 // the cut itself, a pure function of the shape (also behind mkhe_f2_schedule_probe: tests/test_f2_schedule.py checks on the CPU that every pass of
 // every shape is dealt exactly once).  weights: per limb slot; segs: G * F2_SEGS entries.  Returns the number of workgroups, parts in *parts_out;
 // 0 = the shape has no schedule within the kernel's limits.
-int f2_build_schedule(int np0, int nb, int nslots, const long* weights, int G, F2Seg* segs, int* parts_out) {
+int f2_build_schedule(int np0, int nb, int nslots, const long* weights, int G, F2Seg* segs, int* parts_out, int max_parts, long* cost_out, long* worst_out) {
     *parts_out = 0;
+    if (max_parts <= 0) max_parts = f2_max_parts(np0);
     if (np0 < 1 || np0 > F2_MAX_P || nb < 1 || nb > 255 || nslots < 1 || nslots > NTT_MAX_SLOTS || G < 1) return 0;
     const int ngroups = np0 * nslots * 2;
     long W = 0;
@@ -328,8 +329,18 @@ int f2_build_schedule(int np0, int nb, int nslots, const long* weights, int G, F
     for (const Run& r : runs) { if (++per_wg[r.wg] > F2_SEGS) return 0; ++per_g[r.g]; }
     int parts = 0;
     for (int g = 0; g < ngroups; ++g) parts = std::max(parts, per_g[g]);
-    // four members of a merged destination (out_0) x their parts + the tensor term at the load of one inverse job
-    if (parts < 1 || VI_MAX * parts + 1 > VI_SUMS) return 0;
+    // the members of a merged destination (out_0: one per party, four at most) x their parts + the tensor term at the load of one inverse job
+    if (parts < 1 || parts > max_parts) return 0;
+    if (cost_out || worst_out) {
+        // what the launch lasts = its longest workgroup: a pass = its weight, a run = a quarter of a pass on top (twiddles of its modulus into LDS,
+        // accumulators out); the parts are read again by the inverse NTT
+        std::vector<long> wcost(G, 0), wpass(G, 0);
+        for (const Run& r : runs) { const long w = (long)r.nd * weights[(r.g / 2) % nslots]; wpass[r.wg] += w; wcost[r.wg] += w + F2_RUN_COST; }
+        long worst = 0, worst_p = 0;
+        for (int w = 0; w < G; ++w) { worst = std::max(worst, wcost[w]); worst_p = std::max(worst_p, wpass[w]); }
+        if (cost_out) *cost_out = worst + (long)F2_PART_COST * parts;
+        if (worst_out) *worst_out = worst_p;
+    }
     for (size_t i = 0; i < (size_t)G * F2_SEGS; ++i) segs[i] = F2Seg{};
     std::vector<int> nseg(G, 0), seen(ngroups, 0);
     int nwg = 0;
@@ -343,6 +354,31 @@ int f2_build_schedule(int np0, int nb, int nslots, const long* weights, int G, F
     *parts_out = parts;
     return nwg;
 }
+// the grid: the cheapest feasible cut on at most Gmax workgroups (one per CU; ties: the smaller grid).  Shapes with fewer passes than two per CU --
+// one or two parties, low levels -- are cut into more parts on fewer workgroups than CUs rather than not at all.
+int f2_plan_schedule(int np0, int nb, int nslots, const long* weights, int Gmax, F2Seg* segs, int* parts_out, int max_parts) {
+    *parts_out = 0;
+    if (Gmax < 1 || nb < 2) return 0;          // (level 0: one digit, three limb slots -- the launches it would replace are a few microseconds each)
+    std::vector<F2Seg> trial((size_t)Gmax * F2_SEGS);
+    long best = -1; int best_g = 0;
+    for (int G = 1; G <= Gmax; ++G) {
+        int parts = 0; long cost = 0;
+        if (f2_build_schedule(np0, nb, nslots, weights, G, trial.data(), &parts, max_parts, &cost) < 1) continue;
+        if (best < 0 || cost < best) { best = cost; best_g = G; }
+    }
+    if (!best_g) return 0;
+    // Worth it?  The kernel lasts as long as its longest workgroup -- whole passes, a run's set-up, the parts read again -- where the launches it replaces
+    // (Decompose NTT two workgroups per CU, streaming products) cost by the total.  Measured over parties x levels (profiles/r6_f2_plan_sweep.txt): the
+    // fused launch wins while that cost stays within ~1.4 passes of an even deal over the chip, and loses beyond (three parties at level 13: six passes in
+    // two runs where 5.25 would be even, - 3 %).
+    {
+        long W = 0;
+        for (int g = 0; g < np0 * nslots * 2; ++g) W += weights[(g / 2) % nslots] * nb;
+        if (best - W / Gmax > F2_SLACK) return 0;
+    }
+    for (size_t i = 0; i < (size_t)Gmax * F2_SEGS; ++i) segs[i] = F2Seg{};
+    return f2_build_schedule(np0, nb, nslots, weights, best_g, segs, parts_out, max_parts, nullptr);
+}
 const Context::F2Sched& Context::f2_schedule(int np0, int level) {
     const long key = ((long)np0 << 8) | level;
     auto found = f2_sched_.find(key);
@@ -352,7 +388,8 @@ const Context::F2Sched& Context::f2_schedule(int np0, int level) {
     NttBatch q{};
     slots_qp(q, level);
     const int nslots = q.nslots;
-    static const int balance = MKHE_AB_INT("MKHE_F2_BALANCE", 0), wred = MKHE_AB_INT("MKHE_F2_WRED", 5);
+    static const int balance = MKHE_AB_INT("MKHE_F2_BALANCE", 0);      // percent of a pass per reduction point of a 59/60-bit modulus (0: every pass the same)
+    const int wred = balance;
     std::vector<long> w(nslots, 100);
     for (int s2 = 0; s2 < nslots && balance; ++s2) {
         const int m = q.mod[s2];
@@ -360,7 +397,9 @@ const Context::F2Sched& Context::f2_schedule(int np0, int level) {
     }
     std::vector<F2Seg> segs((size_t)G * F2_SEGS);
     int parts = 0;
-    const int nwg = f2_build_schedule(np0, nb, nslots, w.data(), G, segs.data(), &parts);
+    const bool plan = ntt16_f2_mode() != 2;            // (MKHE_F2_FUSED=2: the whole chip or nothing, as the first version of the kernel was scheduled)
+    const int nwg = plan ? f2_plan_schedule(np0, nb, nslots, w.data(), G, segs.data(), &parts, 0)
+                         : f2_build_schedule(np0, nb, nslots, w.data(), G, segs.data(), &parts, std::min(3, f2_max_parts(np0)));
     if (nwg > 0) {
         MKHE_HIP(hipSetDevice(device));
         MKHE_HIP(hipMalloc(&sc.d_segs, segs.size() * sizeof(F2Seg)));

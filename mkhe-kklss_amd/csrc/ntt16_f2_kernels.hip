@@ -486,9 +486,9 @@ int f2_device_cus() {
 }
 }
 int ntt16_f2_grid() { return f2_device_cus(); }
+int ntt16_f2_mode() { static const int v = MKHE_AB_INT("MKHE_F2_FUSED", 1); return v; }      // 0: off; 1: the grid is planned (f2_plan_schedule); 2: one workgroup per CU or nothing (the first version)
 bool ntt16_f2_ok(int logN, int nparties, int nb, int nslots) {
-    static const int on = MKHE_AB_INT("MKHE_F2_FUSED", 1);
-    if (!on || logN != 15 || nparties < 1 || nparties > F2_MAX_P || nb < 1 || nb > 255 || nslots < 1 || nslots > NTT_MAX_SLOTS) return false;
+    if (!ntt16_f2_mode() || logN != 15 || nparties < 1 || nparties > F2_MAX_P || nb < 1 || nb > 255 || nslots < 1 || nslots > NTT_MAX_SLOTS) return false;
     return true;
 }
 void launch_ntt16_f2(const F2FusedArgs& a, hipStream_t st) {

@@ -210,7 +210,19 @@ struct F2FusedArgs {
     u64* trace;                     // diagnostic (make trace): [workgroup][wave][pass][16] shader-clock stamps; normally NULL
 };
 bool ntt16_f2_ok(int logN, int nparties, int nb, int nslots);
-int f2_build_schedule(int np0, int nb, int nslots, const long* weights, int G, F2Seg* segs, int* parts_out);      // engine_mulrelin.hip
+int ntt16_f2_mode();              // MKHE_F2_FUSED (diagnostic library): 0 off, 1 planned grid (default), 2 one workgroup per CU or nothing
+// parts a product may arrive in: the inverse job of a merged destination adds (members x parts + the tensor term [+ a step-E member]) <= VI_SUMS summands at
+// its load; out_0 has one member per party of op0 (VI_MAX at most per job)
+constexpr int F2_PARTS_MAX = 11;
+constexpr int f2_max_parts(int np0) {
+    const int members = np0 < 1 ? 1 : (np0 < VI_MAX ? np0 : VI_MAX);
+    const int a = (VI_SUMS - 1) / members, b = VI_SUMS - 2;      // (a party's own slot: its u product's parts + the step-E member + the tensor term)
+    const int r = a < b ? a : b;
+    return r > F2_PARTS_MAX ? F2_PARTS_MAX : r;
+}
+constexpr long F2_RUN_COST = 80, F2_PART_COST = 8, F2_SLACK = 190;       // in units of a pass = 100 (f2_plan_schedule)
+int f2_build_schedule(int np0, int nb, int nslots, const long* weights, int G, F2Seg* segs, int* parts_out, int max_parts = 0, long* cost_out = nullptr, long* worst_out = nullptr);      // engine_mulrelin.hip
+int f2_plan_schedule(int np0, int nb, int nslots, const long* weights, int Gmax, F2Seg* segs, int* parts_out, int max_parts = 0);
 void launch_ntt16_f2(const F2FusedArgs& a, hipStream_t st);
 int ntt16_f2_grid();                // workgroups the schedule should be cut for (one per CU)
 void launch_ntt_cross8_dec(const NttBatch& b, int logN, hipStream_t st);

@@ -13,19 +13,29 @@ from mkhe_kklss_amd._abi import lib
 F2_SEGS = 3
 
 
+VI_SUMS, VI_MAX, F2_PARTS_MAX = 13, 4, 11
+
+
+def _max_parts(parties):
+    """csrc/ntt_kernels.h f2_max_parts: members of out_0 x parts + the tensor term, and a party's own slot: parts + step E + tensor, within VI_SUMS summands"""
+    return min((VI_SUMS - 1) // min(parties, VI_MAX), VI_SUMS - 2, F2_PARTS_MAX)
+
+
 def _probe(parties, nb, nslots, weights, grid):
+    """grid > 0: the cut on exactly that grid; grid < 0: the engine's plan for a device of -grid CUs"""
     w = (C.c_long * nslots)(*weights)
-    segs = (C.c_ubyte * (grid * F2_SEGS * 8))()
+    segs = (C.c_ubyte * (abs(grid) * F2_SEGS * 8))()
     parts = C.c_int(0)
     nwg = lib().mkhe_f2_schedule_probe(parties, nb, nslots, w, grid, segs, C.byref(parts))
-    return nwg, parts.value, np.frombuffer(segs, dtype=np.uint8).reshape(grid, F2_SEGS, 8)
+    return nwg, parts.value, np.frombuffer(segs, dtype=np.uint8).reshape(abs(grid), F2_SEGS, 8)
 
 
 def _check(parties, nb, nslots, weights, grid):
     nwg, parts, segs = _probe(parties, nb, nslots, weights, grid)
     if nwg == 0:
         return 0
-    assert 1 <= nwg <= grid and 1 <= parts and 4 * parts + 1 <= 13
+    planned, grid = grid < 0, abs(grid)
+    assert 1 <= nwg <= grid and 1 <= parts <= _max_parts(parties)
     seen = np.zeros((parties, nslots, 2, nb), dtype=np.int32)
     runs = {}
     for wg in range(grid):
@@ -49,7 +59,7 @@ def _check(parties, nb, nslots, weights, grid):
             party, slot, half, d0, nd = (int(x) for x in segs[wg, si][:5])
             load[wg] += nd * weights[slot]
     total = sum(weights[s] for s in range(nslots)) * 2 * parties * nb
-    assert load.max() <= total / grid + max(weights) + 1e-9
+    assert load.max() <= total / (nwg if planned else grid) + max(weights) + 1e-9
     return parts
 
 
@@ -73,6 +83,47 @@ def test_every_pass_exactly_once(parties, level):
         _check(parties, nb, nslots, w, grid)
 
 
+F2_RUN_COST, F2_PART_COST, F2_SLACK = 80, 8, 190       # csrc/ntt_kernels.h, in units of a pass = 100
+
+
+def _cost(segs, parts, weights):
+    """f2_build_schedule's cost of a cut: the longest workgroup (passes by weight + a quarter pass per run) + the parts the inverse NTT reads again"""
+    nd = segs[:, :, 4].astype(np.int64)
+    w = np.asarray(weights, dtype=np.int64)[segs[:, :, 1].astype(np.int64)]
+    per_wg = (nd * w + (nd > 0) * F2_RUN_COST).sum(axis=1)
+    return int(per_wg.max()) + F2_PART_COST * parts
+
+
+@pytest.mark.parametrize("parties", [1, 2, 3, 4, 5, 8, 16])
+def test_planned_grid_is_the_cheapest_cut_or_none(parties):
+    # the engine's plan (round 6: the grid is chosen, not the CU count): the cheapest cut over all grids of at most 256 workgroups, taken when it stays
+    # within F2_SLACK of an even deal over the chip (the fused launch loses to the pair of launches it replaces beyond) -- checked against a scan
+    taken = 0
+    for level in range(14):
+        nb, nslots = level + 1, level + 1 + 2
+        weights = [100] * nslots
+        even = parties * nslots * 2 * nb * 100 // 256
+        best = None
+        for grid in range(1, 257):
+            nwg, parts, segs = _probe(parties, nb, nslots, weights, grid)
+            if nwg:
+                c = _cost(segs, parts, weights)
+                best = c if best is None or c < best else best
+        nwg, parts, segs = _probe(parties, nb, nslots, weights, -256)
+        if nwg == 0:
+            assert best is None or best - even > F2_SLACK or nb < 2, (parties, level, best, even)      # (level 0, one digit: never fused)
+            continue
+        taken += 1
+        assert _check(parties, nb, nslots, weights, -256) == parts
+        assert _cost(segs, parts, weights) == best and best - even <= F2_SLACK, (parties, level, nwg, parts, best, even)
+    assert taken >= 5
+
+
+def test_planned_headline_is_the_whole_chip():
+    nwg, parts, segs = _probe(4, 14, 16, [100] * 16, -256)
+    assert nwg == 256 and parts == 2 and (segs[:, 0, 4] == 7).all()
+
+
 def test_random_shapes():
     rng = np.random.default_rng(62)
     found = 0
@@ -89,5 +140,12 @@ def test_refusals():
     assert _probe(0, 14, 16, [100] * 16, 256)[0] == 0
     assert _probe(17, 14, 16, [100] * 16, 256)[0] == 0
     assert _probe(4, 14, 16, [0] * 16, 256)[0] == 0
-    # one party on 256 workgroups: 448 passes, a group of 14 digits would be cut into eight or more parts -- more than an inverse job adds at its load
-    assert _probe(1, 14, 16, [100] * 16, 256)[0] == 0
+    # four parties at level 6 on 256 workgroups: 504 passes, a group of 7 digits would be cut into four parts -- more than an inverse job with four
+    # members adds at its load; the planned grid takes fewer workgroups
+    assert _probe(4, 7, 9, [100] * 9, 256)[0] == 0
+    # -- the plan does: fewer workgroups; not at level 6, where the cheapest cut leaves the longest workgroup too far above an even deal
+    nwg, parts, _ = _probe(4, 8, 10, [100] * 10, -256)
+    assert 0 < nwg < 256 and parts <= 3
+    assert _probe(4, 7, 9, [100] * 9, -256)[0] == 0
+    # three parties at the top level: 1344 passes, six for the longest workgroup where 5.25 would be even -- measured 3 % behind the unfused launches
+    assert _probe(3, 14, 16, [100] * 16, -256)[0] == 0

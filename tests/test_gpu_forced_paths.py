@@ -298,8 +298,9 @@ def test_single_pass_forward_kernel_on_every_launch_shape(mode, reps):
 
 
 # Round 6: step F2 inside the Decompose NTT of the t_i (csrc/ntt16_f2_kernels.hip).  The shipped schedule cuts every group of digits evenly (two parts at
-# four parties); the weighted schedule (MKHE_F2_BALANCE=1) cuts by the cost of the modulus classes -- runs of unequal length, three parts, groups whose
-# last run zeroes the part they do not have -- and MKHE_F2_FUSED=0 is the unfused launch set of round 5: the same bits from all of them.
+# four parties); the weighted schedule (MKHE_F2_BALANCE=5: percent of a pass per reduction point) cuts by the cost of the modulus classes -- runs of unequal length, three parts, groups whose
+# last run zeroes the part they do not have -- MKHE_F2_FUSED=0 is the unfused launch set of round 5, 2 the first
+# version's rule (one workgroup per CU or no fused launch; 1, the default, plans the grid: f2_plan_schedule): the same bits from all of them.
 SCRIPT_F2 = r'''
 import sys
 import numpy as np
@@ -325,7 +326,7 @@ rlk = mkrlwe.RelinearizationKeySet(params)
 for i in range(K):
     rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, "u%%d" %% i, *keys[i]))
 ev = mkckks.NewEvaluator(params)
-for k, level in ((4, 13), (5, 13), (4, 6)):
+for k, level in ((4, 13), (5, 13), (4, 6), (2, 11), (1, 8)):
     names = ["u%%d" %% i for i in range(k)]
     def ct():
         h = np.empty((1 + k, level + 1, N), dtype=np.uint64)
@@ -345,9 +346,9 @@ print("ok")
 '''
 
 
-@pytest.mark.parametrize("env_extra", [dict(MKHE_F2_BALANCE="1", MKHE_F2_WRED="5"), dict(MKHE_F2_BALANCE="1", MKHE_F2_WRED="2"), dict(MKHE_F2_FUSED="0"),
+@pytest.mark.parametrize("env_extra", [dict(MKHE_F2_BALANCE="5"), dict(MKHE_F2_BALANCE="2"), dict(MKHE_F2_FUSED="0"), dict(MKHE_F2_FUSED="2"),
                                        dict(MKHE_FUSE_E="0"), dict(MKHE_FUSE_Y="0", MKHE_FUSE_RESCALE="0")],
-                         ids=["weighted_cuts", "weighted_cuts_light", "unfused", "step_E_as_plain_items", "x_y_E_as_plain_launches"])
+                         ids=["weighted_cuts", "weighted_cuts_light", "unfused", "whole_chip_or_nothing", "step_E_as_plain_items", "x_y_E_as_plain_launches"])
 def test_fused_f2_schedules(env_extra):
     r = _run(SCRIPT_F2, env_extra)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

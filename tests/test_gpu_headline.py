@@ -117,7 +117,11 @@ def test_pn15_two_party_mulrelin_new(pn15):
 # Step F2 inside the Decompose NTT of the t_i (round 6, csrc/ntt16_f2_kernels.hip): the launches whose schedule differs -- four parties (two runs per
 # group), five (a workgroup's run crosses groups: parts of unequal length), eight (one group per workgroup: no parts), lower levels (fewer digits and
 # limb slots, other cuts), op1 with fewer parties than op0 (step E inside the F1 kernel still), hoisted forms supplied by the caller
-@pytest.mark.parametrize("k0,k1,level,hoisted", [(4, 4, 9, False), (4, 4, 1, False), (4, 2, 13, False), (5, 5, 13, False), (8, 8, 13, False), (6, 6, 5, False), (4, 4, 13, True), (7, 7, 2, False)])
+# -- and the shapes whose passes do not fill the chip twice (one to three parties, low levels): the grid is planned (f2_plan_schedule: fewer workgroups
+# than CUs, up to eight parts per product, groups cut unevenly)
+@pytest.mark.parametrize("k0,k1,level,hoisted", [(4, 4, 9, False), (4, 4, 1, False), (4, 2, 13, False), (5, 5, 13, False), (8, 8, 13, False), (6, 6, 5, False), (4, 4, 13, True), (7, 7, 2, False),
+                                                 (1, 1, 13, False), (2, 2, 13, False), (3, 3, 13, False), (1, 1, 0, False), (2, 2, 6, False), (3, 1, 4, False), (4, 4, 6, False),
+                                                 (3, 3, 9, True), (1, 3, 11, False), (2, 1, 3, False)])
 def test_pn15_fused_f2_shapes(pn15, k0, k1, level, hoisted):
     _mulrelin_case(pn15, k0, k1, level, hoisted)
 

@@ -24,7 +24,7 @@ run() {
 if [ "${1:-all}" != b ]; then
 run defaults MKHE_UNUSED=1 &&
 run thresholds_at_1 MKHE_NTT16_INV_MIN=1 MKHE_NTT16_MIN=1 MKHE_NTT14_MIN=1 MKHE_NTT14_INV_MIN=1 MKHE_NTT32=0 &&
-run h32_everywhere MKHE_NTT32=1 MKHE_NTT32_MIN=1 MKHE_F2_BALANCE=1 &&
+run h32_everywhere MKHE_NTT32=1 MKHE_NTT32_MIN=1 MKHE_F2_BALANCE=5 &&
 run fusions_off MKHE_F2_FUSED=0 MKHE_FUSE_E=0 MKHE_FUSE_RESCALE=0 MKHE_EXT_FUSED_MAX=0 MKHE_POOL_GB=1 || rc=1
 fi
 if [ "${1:-all}" != a ] && [ $rc -eq 0 ]; then
