@@ -1,6 +1,7 @@
 // engine.hip -- Context: host-side table generation, buffer pools, stream plumbing, the NTT launch choice, Decompose and the external-product batch
 // (engine_mulrelin.hip, engine_ops.hip, engine_bfv.hip, batch.hip hold the operations built on them).
 #include "engine.h"
+#include <atomic>
 #include <mutex>
 #include <algorithm>
 #include <cstring>
@@ -132,8 +133,35 @@ void Context::init(const u64* Q, const u64* P, const u64* psiQ, const u64* psiP,
     for (int i = 0; i < mall; ++i) small16_.push_back(moduli[i] < (1ull << 62) / 48 ? 1 : 0);
     for (int i = 0; i < mall; ++i) if (logN == 16 && small_q_[i] && !small16_[i]) h16_gap_ = true;
     MKHE_HIP(hipSetDevice(device));
+#ifdef MKHE_CU_PARTITION_EXPERIMENT
+    // experiment (tools/build_variant.sh cupart engine -DMKHE_CU_PARTITION_EXPERIMENT): the streams of the contexts of a process take
+    // turns on MKHE_CU_PARTS disjoint sets of CUs -- two MulRelin in flight, each on its own half of the chip, the ALU-bound phases of one beside the
+    // bandwidth- and latency-bound phases of the other
+    {
+        static std::atomic<int> nctx{0};
+        const char* e = std::getenv("MKHE_CU_PARTS");
+        const int parts = e ? std::atoi(e) : 0;
+        if (parts >= 2 && parts <= 8) {
+            int ncu = 256;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+            const char* m = std::getenv("MKHE_CU_PART_MODE");          // 0: contiguous bit ranges, 1: bits interleaved by `parts`
+            const int mode = m ? std::atoi(m) : 0, idx = nctx++ % parts;
+            uint32_t mask[16] = {};
+            for (int cu = 0; cu < ncu && cu < 512; ++cu) {
+                const int owner = mode ? cu % parts : (int)((long)cu * parts / ncu);
+                if (owner == idx) mask[cu / 32] |= 1u << (cu % 32);
+            }
+            MKHE_HIP(hipExtStreamCreateWithCUMask(&stream, (uint32_t)((ncu + 31) / 32), mask));
+            MKHE_HIP(hipExtStreamCreateWithCUMask(&stream2, (uint32_t)((ncu + 31) / 32), mask));
+        } else {
+            MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        }
+    }
+#else
     MKHE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     MKHE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+#endif
     for (auto& e : ev_) MKHE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     s_ = stream;
 

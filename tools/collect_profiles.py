@@ -67,6 +67,10 @@ with open(os.path.join(P, "%s_sq_counters.txt" % tag), "w") as f:
 _abl = os.path.join(P, "%s_ntt16_ablation.txt" % tag)
 if os.path.exists(_abl) and len(re.findall(r"us/launch", open(_abl).read())) < 8:
     sys.exit("tools/collect_profiles.py: %s has no timings (variant builds failed on the GPU box?)" % _abl)
+# ... and no tracked text file of the round may be a crashed script's output (round 6 carried an _ntt_in_context.txt of tracebacks for a while)
+_bad = [x for x in sorted(os.listdir(P)) if x.startswith(tag + "_") and x.endswith((".txt", ".json", ".jsonl")) and "Traceback (most recent call last)" in open(os.path.join(P, x), errors="replace").read()]
+if _bad:
+    sys.exit("tools/collect_profiles.py: a script crashed into %s" % ", ".join(_bad))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ntt16_isa.py"), tag], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ntt32_isa.py"), tag], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "write_profiles_readme.py"), tag])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of the default bench (overlap off): durations of the Decompose NTT launches inside the MulRelin, 1792- and 896-limb launches apart
+# kernel trace of the default bench (overlap off): durations of the Decompose NTT launches inside the MulRelin, 1792- and 896-limb launches apart, and the fused step-F2 launch
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/ctx
 mkdir -p $O
@@ -11,11 +11,16 @@ for v in "$@"; do
     MKHE_NO_OVERLAP=1 rocprofv3 --output-format csv --kernel-trace -d $O/$name -o p -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-extras > $O/$name.json 2> $O/$name.err )
   python3 - $O/$name/p_kernel_trace.csv $name <<'PY'
 import csv, sys, statistics as st
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "ntt32_fwd_kernel" in r["Kernel_Name"] or "ntt16_fwd_kernel" in r["Kernel_Name"]]
-d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
-d = d[len(d) // 2:]                       # the second half of the run: settled clocks
+allrows = list(csv.DictReader(open(sys.argv[1])))
+def durs(pred):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in allrows if pred(r["Kernel_Name"])]
+    return d[len(d) // 2:]                # the second half of the run: settled clocks
+d = durs(lambda n: "ntt32_fwd_kernel" in n or "ntt16_fwd_kernel" in n)
+f2 = durs(lambda n: "ntt16_f2_kernel" in n)
 big = [x for x in d if x > 160]; small = [x for x in d if x <= 160]
-print(sys.argv[2], "launches", len(d), "1792 limbs: median %.1f us (min %.1f)" % (st.median(big), min(big)), " 896 limbs: median %.1f us (min %.1f)" % (st.median(small), min(small)),
-      " mean of both %.1f" % ((st.mean(big) + st.mean(small)) / 2))
+def fmt(label, xs):
+    return "%s: median %.1f us (min %.1f, %d launches)" % (label, st.median(xs), min(xs), len(xs)) if xs else "%s: no launch" % label
+# (round 6: the 896-limb launch of the t_i is gone at four parties -- its transforms run inside ntt16_f2_kernel)
+print(sys.argv[2], " ", fmt("1792 limbs", big), " ", fmt("896 limbs", small), " ", fmt("ntt16_f2_kernel", f2))
 PY
 done
