@@ -523,8 +523,8 @@ def run_single(args):
     extras["mulrelin_per_sec_cold_start"] = args.steps / (time.perf_counter() - t0)
     extras["timing_protocol"] = ("legs in this order: cold start (W warm-up + K timed steps right after the host-side set-up: mulrelin_per_sec_cold_start, the figure "
                                  "rounds 1-2 reported as value) -> secondary legs (Rotate / Conjugate / key generation) -> 100 untimed + 200 timed steps "
-                                 "(steady state) -> W + K = the timed region of `value` -> two / three evaluations in flight on forked contexts (30 untimed + 100 timed "
-                                 "rounds each) -> K steps under HIP events (roofline)")
+                                 "(steady state) -> W + K = the timed region of `value` -> K steps under HIP events (roofline) -> two / three evaluations in flight on forked "
+                                 "contexts (30 untimed + 100 timed rounds each)")
 
     # ---- secondary figure: hoisted rotation of the same k-party ciphertext, hoisting included / excluded
     if not args.no_extras:
@@ -633,29 +633,6 @@ def run_single(args):
         extras["mulrelin_per_sec_single_input_same_run"] = 100 / (time.perf_counter() - t1)
         res = res.cts[0]
 
-    # ---- throughput with two / three independent MulRelin in flight (forked engine contexts: same keys and ciphertexts, a stream pair each): the
-    # latency-bound stretches of one evaluation (small inverse NTTs, ModDowns) run beside the other's kernels.  Measured here, in the steady state
-    # right after the timed region of `value` (rounds 4-5 measured it among the first legs, clocks not yet settled, and read it as a loss)
-    if B == 1 and not args.no_extras:
-        evs = [ev, ev.Fork(), ev.Fork()]
-        for nfl in (2, 3):
-            use = evs[:nfl]
-            for _ in range(30):
-                for e in use:
-                    e.MulRelinNew(ct0, ct1, rlk)
-            for e in use:
-                e.params.sync()
-            t1 = time.perf_counter()
-            for _ in range(100):
-                outs = [e.MulRelinNew(ct0, ct1, rlk) for e in use]
-            for e in use:
-                e.params.sync()
-            extras["mulrelin_per_sec_%s_in_flight" % {2: "two", 3: "three"}[nfl]] = 100 * nfl / (time.perf_counter() - t1)
-            extras["in_flight_identical_to_single"] = bool(all((o.download() == res.download()).all() for o in outs))
-            del outs
-        del evs
-        params.sync()
-
     beta = params.Beta(level)
     if pset["logN"] == 15 and params.Alpha() == 1:
         # N = 2^15: two forward kernels apply to the Decompose launches (same bits).  MKHE_NTT32 = 2 (default): per launch shape the engine times a
@@ -686,6 +663,30 @@ def run_single(args):
                     roofline["frac_back_to_back"] = b2b
             except Exception:
                 pass
+
+    # ---- throughput with two / three independent MulRelin in flight (forked engine contexts: same keys and ciphertexts, a stream pair each): the
+    # latency-bound stretches of one evaluation (small inverse NTTs, ModDowns) run beside the other's kernels.  Measured here, in the steady state, as
+    # the LAST leg on the device (rounds 4-5 measured it among the first legs, clocks not yet settled, and read it as a loss; in front of the HIP-event
+    # leg it leaves the package hotter than the timed region does: the Decompose NTT then reads 250-260 us where the rocprofv3 trace says 227)
+    if B == 1 and not args.no_extras:
+        evs = [ev, ev.Fork(), ev.Fork()]
+        for nfl in (2, 3):
+            use = evs[:nfl]
+            for _ in range(30):
+                for e in use:
+                    e.MulRelinNew(ct0, ct1, rlk)
+            for e in use:
+                e.params.sync()
+            t1 = time.perf_counter()
+            for _ in range(100):
+                outs = [e.MulRelinNew(ct0, ct1, rlk) for e in use]
+            for e in use:
+                e.params.sync()
+            extras["mulrelin_per_sec_%s_in_flight" % {2: "two", 3: "three"}[nfl]] = 100 * nfl / (time.perf_counter() - t1)
+            extras["in_flight_identical_to_single"] = bool(all((o.download() == res.download()).all() for o in outs))
+            del outs
+        del evs
+        params.sync()
 
     # ---- device-expanded keys (PN16QP1761: 7.9 GB of key material that never exists on the host) still get an oracle check: the keys of the
     # first two parties and the CRS u are regenerated on the host from the same public seed (oracle/ora_keygen.c restates the Philox
