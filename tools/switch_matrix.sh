@@ -19,16 +19,19 @@ run() {
     [ $r -ne 0 ] && rc=1
     return $r
 }
-# Round 6: seven sets (the switches whose alternative lost in two rounds or more are gone from the sources: DESIGN.md section 6).  About 3.5 minutes each:
-# two gpurun calls -- `bash tools/switch_matrix.sh a`, then `... b`; no argument runs everything.
-if [ "${1:-all}" != b ]; then
+# Round 6: seven sets (the switches whose alternative lost in two rounds or more are gone from the sources: DESIGN.md section 6).  About five minutes each:
+# three gpurun calls -- `bash tools/switch_matrix.sh a`, then `... b`, then `... c`; no argument runs everything.
+P=${1:-all}
+if [ $P = a ] || [ $P = all ]; then
 run defaults MKHE_UNUSED=1 &&
 run thresholds_at_1 MKHE_NTT16_INV_MIN=1 MKHE_NTT16_MIN=1 MKHE_NTT14_MIN=1 MKHE_NTT14_INV_MIN=1 MKHE_NTT32=0 &&
-run h32_everywhere MKHE_NTT32=1 MKHE_NTT32_MIN=1 MKHE_F2_BALANCE=5 &&
-run fusions_off MKHE_F2_FUSED=0 MKHE_FUSE_E=0 MKHE_FUSE_RESCALE=0 MKHE_EXT_FUSED_MAX=0 MKHE_POOL_GB=1 || rc=1
+run h32_everywhere MKHE_NTT32=1 MKHE_NTT32_MIN=1 MKHE_F2_BALANCE=5 || rc=1
 fi
-if [ "${1:-all}" != a ] && [ $rc -eq 0 ]; then
-run classes_off MKHE_FUSE_Y=0 MKHE_SPREAD_RADIX4=0 MKHE_NTT16_RADIX4=0 MKHE_NTT16_INV=0 MKHE_H16_UCLASS=0 MKHE_H16_FCLASS=0 MKHE_NTT16_HALVES=0 MKHE_H16_SCHED=0 &&
+if { [ $P = b ] || [ $P = all ]; } && [ $rc -eq 0 ]; then
+run fusions_off MKHE_F2_FUSED=0 MKHE_FUSE_E=0 MKHE_FUSE_RESCALE=0 MKHE_EXT_FUSED_MAX=0 MKHE_POOL_GB=1 &&
+run classes_off MKHE_FUSE_Y=0 MKHE_SPREAD_RADIX4=0 MKHE_NTT16_RADIX4=0 MKHE_NTT16_INV=0 MKHE_H16_UCLASS=0 MKHE_H16_FCLASS=0 MKHE_NTT16_HALVES=0 MKHE_H16_SCHED=0 MKHE_F2_FUSED=2 || rc=1
+fi
+if { [ $P = c ] || [ $P = all ]; } && [ $rc -eq 0 ]; then
 run round1_kernels MKHE_NTT32=0 MKHE_NTT16=0 MKHE_NTT16_INV=0 MKHE_NTT_LDS=0 MKHE_EXT_MERGE=0 MKHE_EXT_GROUP=0 MKHE_FUSE_X=0 MKHE_NO_OVERLAP=1 &&
 run small_ring_fused_everywhere MKHE_EXT_FUSED_MAX=1000000 MKHE_EXT_FUSED_INV=0 MKHE_NTT16_HALVES=2 || rc=1
 fi
