@@ -12,7 +12,7 @@ for d, name in (("stats_noovl", "kernel_stats_noovl"), ("stats_ovl", "kernel_sta
     f = os.path.join(G, d, "p_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(P, "%s_%s.csv" % (tag, name)))
-for f in ("bench_plain", "bench_plain_h32", "bench_plain_h16", "bench_noovl", "bench_ovl", "bench_bfv", "bench_bfv_plain", "bench_pn16", "bench_pn16_noovl", "bench_cnn2", "bench_cnn4", "bench_pn14",
+for f in ("bench_plain", "bench_plain_h32", "bench_plain_h16", "bench_noovl", "bench_ovl", "bench_bfv", "bench_bfv_plain", "bench_pn16", "bench_pn16_noovl", "bench_cnn2", "bench_cnn4", "bench_pn14", "bench_2party",
           "bench_cnn4_batch8", "bench_cnn4_batch16", "bench_cnn2_batch8"):
     src = os.path.join(G, f + ".json")
     if os.path.exists(src) and os.path.getsize(src) > 10:

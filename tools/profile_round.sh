@@ -50,6 +50,7 @@ echo "pn16 done"
 python3 bench.py --scheme cnn --parties 2 --steps 20 --warmup 3 > $O/bench_cnn2.json 2> $O/bench_cnn2.err
 python3 bench.py --scheme cnn --parties 4 --steps 20 --warmup 3 > $O/bench_cnn4.json 2> $O/bench_cnn4.err
 python3 bench.py --params PN14QP439 --steps 20 --warmup 3 > $O/bench_pn14.json 2> $O/bench_pn14.err
+python3 bench.py --parties 2 > $O/bench_2party.json 2> $O/bench_2party.err
 python3 bench.py --scheme cnn --parties 4 --steps 20 --warmup 3 --batch 8 > $O/bench_cnn4_batch8.json 2> $O/bench_cnn4_batch8.err
 python3 bench.py --scheme cnn --parties 4 --steps 20 --warmup 3 --no-cpu --batch 16 > $O/bench_cnn4_batch16.json 2> $O/bench_cnn4_batch16.err
 python3 bench.py --scheme cnn --parties 2 --steps 20 --warmup 3 --no-cpu --batch 8 > $O/bench_cnn2_batch8.json 2> $O/bench_cnn2_batch8.err

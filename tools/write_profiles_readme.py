@@ -120,6 +120,7 @@ if not pw:
     sys.exit("tools/write_profiles_readme.py: no samples in %s_power_probe.txt" % tag)
 
 bf, bfp, pn, c2, c4, p14 = J("bench_bfv"), J("bench_bfv_plain"), J("bench_pn16"), J("bench_cnn2"), J("bench_cnn4"), J("bench_pn14")
+p2 = J("bench_2party")
 cb8, cb16 = J("bench_cnn4_batch8", False), J("bench_cnn4_batch16", False)
 pn14b = [json.loads(l) for l in open(P + tag + "_pn14_batch.jsonl") if l.strip().startswith("{")] if os.path.exists(P + tag + "_pn14_batch.jsonl") else []
 sweep = [json.loads(l) for l in open(P + tag + "_party_sweep.jsonl") if l.strip().startswith("{")] if os.path.exists(P + tag + "_party_sweep.jsonl") else []
@@ -198,6 +199,7 @@ Two-pass kernel (`MKHE_NTT32=0`): shipped {abl("shipped", kernel="ntt16"):.0f}, 
 |---|---|
 | `{tag}_bench_bfv_plain.json` | mkbfv 4-party MulRelinNew, PN15QP880 (14 + 14 + 2 limbs): **{bfp["value"]:.1f} MulRelin/s** ({bfp["ms_per_step"]:.3f} ms), dominant `{bfp["roofline"]["kernel"].split("  ")[0]}` at {bfp["roofline"]["frac"]:.3f}; CPU oracle {bfp["cpu_baseline"]["value"]:.3f}/s, bit-exact {bfp["cpu_baseline"]["bit_exact_vs_gpu"]} |
 | `{tag}_bench_pn16.json` | mkckks 8-party MulRelin, PN16QP1761 (N = 2^16, 34 + 4 limbs, α = 2): **{pn["value"]:.1f} MulRelin/s** ({pn["ms_per_step"]:.2f} ms); CPU oracle on the 2-party sub-problem {pn["cpu_baseline"]["value"]:.3f}/s (`{pn["cpu_baseline"]["sample"][:60]}…`), bit-exact {pn["cpu_baseline"]["bit_exact_vs_gpu"]} |
+| `{tag}_bench_2party.json` | mkckks 2-party MulRelin, PN15QP880 (BASELINE configs[0], the reference benchmark's own case, at the headline ring): **{p2["value"]:.0f} MulRelin/s** ({1e3 * p2["ms_per_step"]:.1f} µs; three in flight {p2["config"]["mulrelin_per_sec_three_in_flight"]:.0f}), dominant `{p2["roofline"]["kernel"].split("  ")[0]}` at {p2["roofline"]["frac"]:.2f}; CPU oracle {p2["cpu_baseline"]["value"]:.2f}/s on one thread, {p2["cpu_baseline"]["value_limb_parallel"]:.2f} on {p2["cpu_baseline"]["cores_limb_parallel"]}, bit-exact {p2["cpu_baseline"]["bit_exact_vs_gpu"]} |
 | `{tag}_bench_pn14.json` | mkckks 4-party MulRelin, PN14QP439 (the reference benchmark's first set): **{p14["value"]:.0f} MulRelin/s** ({1e3 * p14["ms_per_step"]:.1f} µs), dominant `{p14["roofline"]["kernel"].split("  ")[0]}` at {p14["roofline"]["frac"]:.2f}; CPU oracle {p14["cpu_baseline"]["value"]:.2f}/s on one thread, {p14["cpu_baseline"]["value_limb_parallel"]:.2f} on {p14["cpu_baseline"]["cores_limb_parallel"]}, bit-exact {p14["cpu_baseline"]["bit_exact_vs_gpu"]} |
 | `{tag}_bench_cnn4.json` / `_cnn2.json` | encrypted CNN inference, 4 / 2 parties: **{c4["value"]:.0f} / {c2["value"]:.0f} inferences/s** ({c4["ms_per_step"]:.2f} / {c2["ms_per_step"]:.2f} ms per image); CPU oracle {c4["cpu_baseline"]["value"]:.2f}/s, bit-exact {c4["cpu_baseline"]["bit_exact_vs_gpu"]} |
 """ + ("| `%s_bench_cnn4_batch8.json` / `_batch16.json` | B images in lock step, 4 parties: **%.0f / %s inferences/s** |\n" % (tag, cb8["value"], ("%.0f" % cb16["value"]) if cb16 else "–") if cb8 else "") + (
