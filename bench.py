@@ -523,8 +523,8 @@ def run_single(args):
     extras["mulrelin_per_sec_cold_start"] = args.steps / (time.perf_counter() - t0)
     extras["timing_protocol"] = ("legs in this order: cold start (W warm-up + K timed steps right after the host-side set-up: mulrelin_per_sec_cold_start, the figure "
                                  "rounds 1-2 reported as value) -> secondary legs (Rotate / Conjugate / key generation) -> 100 untimed + 200 timed steps "
-                                 "(steady state) -> W + K = the timed region of `value` -> K steps under HIP events (roofline) -> two / three evaluations in flight on forked "
-                                 "contexts (30 untimed + 100 timed rounds each)")
+                                 "(steady state) -> W + K = the timed region of `value` -> K steps under HIP events (roofline) -> mkhe_mul_relin_batch with B = 2, 4 -> two / three evaluations in "
+                                 "flight on forked contexts (30 untimed + 100 timed rounds each)")
 
     # ---- secondary figure: hoisted rotation of the same k-party ciphertext, hoisting included / excluded
     if not args.no_extras:
@@ -560,24 +560,6 @@ def run_single(args):
             params.sync()
             extras[key] = args.steps / (time.perf_counter() - t0)
 
-        if B == 1 and not device_keys and args.params in ("PN15QP880", "PN14QP439"):
-            # ---- B MulRelin in lock step on THIS ring (mkhe_mul_relin_batch): the latency-bound tails of a step -- inverse NTT and
-            # ModDown launches of a few dozen limbs -- serve B inputs at once, the Decompose launches deal whole rounds.  Throughput of a service
-            # that has B independent products at hand; `value` stays the single-input rate.  Every output is checked against the single-input result.
-            ref_single = step().download()
-            for Bb in (2, 4):
-                bevb = mkckks.BatchEvaluator(params, Bb)
-                bb0, bb1 = mkckks.BatchCiphertext([ct0] * Bb), mkckks.BatchCiphertext([ct1] * Bb)
-                for _ in range(3):
-                    outb = bevb.MulRelinNew(bb0, bb1, rlk)
-                params.sync()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    outb = bevb.MulRelinNew(bb0, bb1, rlk)
-                params.sync()
-                extras["mulrelin_per_sec_batch%d" % Bb] = Bb * args.steps / (time.perf_counter() - t0)
-                extras["batch%d_identical_to_single" % Bb] = bool(all((c.download() == ref_single).all() for c in outb.cts))
-                del outb, bb0, bb1, bevb
 
 
         # ---- one party's relinearization key generated on the device (samples drawn on the host beforehand,
@@ -663,6 +645,26 @@ def run_single(args):
                     roofline["frac_back_to_back"] = b2b
             except Exception:
                 pass
+
+    # ---- B MulRelin through mkhe_mul_relin_batch on THIS ring: on PN14QP439 in lock step (the latency-bound launches of a step serve B
+    # inputs at once); on PN15QP880 with four parties IN FLIGHT since round 6 (csrc/batch.hip: the single-operation path on the context and two internal
+    # ones, round robin, joined at the end of the call).  Throughput of a service that has B independent products at hand; `value` stays the single-input
+    # rate.  Every output is checked against the single-input result.  (Among the last legs, like the in-flight figures below: steady clocks.)
+    if B == 1 and not args.no_extras and not device_keys and args.params in ("PN15QP880", "PN14QP439"):
+        ref_single = step().download()
+        for Bb in (2, 4):
+            bevb = mkckks.BatchEvaluator(params, Bb)
+            bb0, bb1 = mkckks.BatchCiphertext([ct0] * Bb), mkckks.BatchCiphertext([ct1] * Bb)
+            for _ in range(3):
+                outb = bevb.MulRelinNew(bb0, bb1, rlk)
+            params.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                outb = bevb.MulRelinNew(bb0, bb1, rlk)
+            params.sync()
+            extras["mulrelin_per_sec_batch%d" % Bb] = Bb * args.steps / (time.perf_counter() - t0)
+            extras["batch%d_identical_to_single" % Bb] = bool(all((c.download() == ref_single).all() for c in outb.cts))
+            del outb, bb0, bb1, bevb
 
     # ---- throughput with two / three independent MulRelin in flight (forked engine contexts: same keys and ciphertexts, a stream pair each): the
     # latency-bound stretches of one evaluation (small inverse NTTs, ModDowns) run beside the other's kernels.  Measured here, in the steady state, as

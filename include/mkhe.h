@@ -388,6 +388,12 @@ int  mkhe_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose);      /* -2: erro
  * config.ntt_kernel_choice): choice 1 = single-pass, 0 = two-pass, -1 = forget and measure again.  limbs > 0: launches of that many limb-NTTs
  * (decompose = 1: Decompose launches, 0: plain forward transforms); limbs <= 0: every shape of the context, met so far or not.  Same bits either way. */
 int  mkhe_ctx_set_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose, int choice);
+/* mkhe_mul_relin_batch at N = 2^15: inputs whose hoisting is at least `min_limbs` limb-NTTs ((n0 + n1) * beta * (level + 1 + nP); default 1536: four
+ * parties at the top level of PN15QP880) are evaluated IN FLIGHT -- the single-operation path on this context and two internal ones, round robin, joined
+ * before the call returns to the stream -- instead of in lock step: one such evaluation fills the chip with every big kernel, what a second one can use
+ * is the first one's latency-bound stretches.  0: every batch of this ring in flight; < 0: always lock step.  Same results either way
+ * (mkrlwe/keyswitch_hoisted.go:44-179 per input). */
+int  mkhe_ctx_set_batch_lanes(mkhe_ctx* ctx, long min_limbs);
 /* The stream-ordered buffer pools (freed ciphertext / key handles are kept for reuse, bounded per DEVICE by MKHE_POOL_GB): bytes this context's
  * pool holds, and "hand everything the pools of this context's device hold back to the driver" (one device-wide synchronisation; the engine does
  * this by itself when an allocation fails for lack of memory and retries once). */

@@ -113,6 +113,7 @@ SIGNATURES = {
     "mkhe_set_overlap": (C.c_int, [vp, C.c_int]),
     "mkhe_ntt_choice": (C.c_int, [vp, C.c_long, C.c_int]),
     "mkhe_ctx_set_ntt_choice": (C.c_int, [vp, C.c_long, C.c_int, C.c_int]),
+    "mkhe_ctx_set_batch_lanes": (C.c_int, [vp, C.c_long]),
     "mkhe_pool_held_bytes": (C.c_longlong, [vp]),
     "mkhe_pool_trim": (C.c_int, [vp]),
     "mkhe_f2_schedule_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long), C.c_int, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]),

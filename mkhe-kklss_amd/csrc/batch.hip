@@ -193,6 +193,27 @@ void Context::rotate_multi(const std::vector<u64>& galEl, const std::vector<cons
     MKHE_HIP(hipGetLastError());
 }
 
+#ifndef MKHE_BATCH_LANES
+#define MKHE_BATCH_LANES 2                 // internal contexts beside the caller's (0: lock step on every ring, as rounds 4-5)
+#endif
+Context* Context::lane(int i) {
+    while ((int)lanes_.size() <= i) {
+        const u64* Q = moduli.data(); const u64* P = Q + nq;
+        std::unique_ptr<Context> c(new Context(logN, Q, nq, P, np, gamma, psi_plain.data(), psi_plain.data() + nq, device,
+                                               nqm ? Q + nq + np : nullptr, nqm, bfv_t));
+        lanes_.push_back(std::move(c));
+    }
+    return lanes_[i].get();
+}
+// -- for evaluations whose big kernels fill the chip by themselves.  Measured on PN15QP880 (profiles/r6_batch_lanes.txt): four parties (1792 hoisted
+// limb-NTTs per input) in flight 1350-1381 MulRelin/s against 1285-1350 in lock step and 1340 one at a time; two parties (896) and one (448) are
+// launch sets that lock step still merges to advantage (2478-2764 against 2418-2514; 4282-5096 against 3973-4371): the threshold sits between.
+bool Context::batch_lanes_ok(size_t B, long limbs) const {
+    if (MKHE_BATCH_LANES < 1 || logN != 15 || alpha != 1 || B < 2 || masked_ || batch_lanes_min_ < 0 || limbs < batch_lanes_min_) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cs);
+    return cs == hipStreamCaptureStatusNone;          // (a capture records the lock-step form: one stream pair)
+}
 void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vector<const Ct*>& op1, const std::vector<const Swk*>& hoist0,
                               const std::vector<const Swk*>& hoist1, const Swk* const* rlk_b1, const Swk* const* rlk_d0, const Swk* const* rlk_v0,
                               const Swk& crs_u, bool rescale_out, const std::vector<Ct*>& outs) {
@@ -222,6 +243,26 @@ void Context::mul_relin_batch(const std::vector<const Ct*>& op0, const std::vect
     }
     for (int a = 0; a < n0; ++a) if (!rlk_d0[a] || !rlk_v0[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
     for (int a = 0; a < n1; ++a) if (!rlk_b1[a]) throw Error("cannot GetRelinearizationKey: there is no relinearization key with given id");
+    // N >= 2^15: one evaluation fills the chip with every big kernel, and B of them in lock step only lengthen those kernels (PN15QP880, four parties:
+    // 1266 / 1311 MulRelin/s at B = 2 / 4 against 1340 one at a time, round 5) -- what a second evaluation can use is the latency-bound stretches of the
+    // first (small inverse NTTs, ModDowns).  So the B evaluations run through the single-operation path, round robin on this context and two internal
+    // ones: in flight side by side, + 4-9 % over one at a time (profiles/r6_cu_partition.txt, r6_batch_lanes.txt).  Same integers: it IS the single path.
+    if (batch_lanes_ok(B, (long)(n0 + n1) * beta(level) * nslots_qp(level))) {
+        const int NL = (int)std::min<size_t>(B, 1 + MKHE_BATCH_LANES);
+        for (int l = 1; l < NL; ++l) { Context* c = lane(l - 1); c->overlap = overlap; c->ntt_forced_ = ntt_forced_; c->wait_for(*this); }      // the inputs (and earlier readers of the outputs) are ordered on this stream
+        try {
+            for (size_t b = 0; b < B; ++b) {
+                Context* c = (b % NL) ? lane((int)(b % NL) - 1) : this;
+                const Swk* const* hb0 = hoist0.empty() ? nullptr : hoist0.data() + b * n0;
+                const Swk* const* hb1 = hoist1.empty() ? nullptr : ((!hoist0.empty() && op0[b] == op1[b] && std::equal(hoist0.begin() + b * n0, hoist0.begin() + (b + 1) * n0, hoist1.begin() + b * n1)) ? hb0 : hoist1.data() + b * n1);
+                if (rescale_out) c->mul_relin_rescale(*op0[b], *op1[b], hb0, hb1, rlk_b1, rlk_d0, rlk_v0, crs_u, *outs[b]);
+                else c->mul_and_relin(*op0[b], *op1[b], hb0, hb1, rlk_b1, rlk_d0, rlk_v0, crs_u, *outs[b]);
+            }
+        } catch (...) { for (auto& l : lanes_) l->recover(); throw; }
+        for (int l = 1; l < NL; ++l) wait_for(*lane(l - 1));
+        MKHE_HIP(hipGetLastError());
+        return;
+    }
     bool same = hoist0.size() == hoist1.size();          // squares: op1 IS op0 (and its hoisted forms): hoist once
     for (size_t b = 0; b < B && same; ++b) same = op0[b] == op1[b];
     for (size_t i = 0; i < hoist0.size() && same; ++i) same = hoist0[i] == hoist1[i];

@@ -724,6 +724,7 @@ int mkhe_ctx_set_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose, int choice
         else for (int lazy = 0; lazy < 2; ++lazy) c->ntt_reset(c->ntt_tune_[(limbs << 2) | (decompose ? 2 : 0) | lazy], choice);
     })
 }
+int mkhe_ctx_set_batch_lanes(mkhe_ctx* ctx, long min_limbs) { MKHE_TRY({ need(ctx)->batch_lanes_min_ = min_limbs; }) }
 long long mkhe_pool_held_bytes(mkhe_ctx* ctx) {
     g_last_ctx = nullptr;
     try { return (long long)(need(ctx)->pool_held_words() * sizeof(u64)); }

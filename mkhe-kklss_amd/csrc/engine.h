@@ -11,6 +11,7 @@
 #include <atomic>
 #include <mutex>
 #include <map>
+#include <memory>
 #include <vector>
 #include <stdexcept>
 #include "modarith.h"
@@ -399,6 +400,7 @@ class Context {
                      hipEvent_t e0[RING] = {}; int which[RING] = {}; int head = 0, inflight = 0; int slot = -1; };
     std::map<long, NttTune> ntt_tune_;
     int ntt_forced_ = -1;                            // mkhe_ctx_set_ntt_choice(limbs <= 0): the answer for every shape that has no entry of its own
+    long batch_lanes_min_ = 1536;      // mkhe_ctx_set_batch_lanes: hoisted limb-NTTs per input from which mul_relin_batch runs its inputs in flight (< 0: never)
     void ntt_reset(NttTune& t, int choice);          // pins a shape (0 / 1) or makes it measure again (-1); samples in flight are dropped
     int ntt_pick(long key, NttTune*& sampling);      // 1 = H32, 0 = H16; sampling != nullptr: this launch is timed (record e0[slot] in front of it)
   private:
@@ -409,6 +411,11 @@ class Context {
     hipStream_t s_ = nullptr;                                // active stream of the launch helpers
     hipEvent_t ev_[8] = {};                                  // fork/join events of the side stream
     hipEvent_t xev_ = nullptr;                               // wait_for
+    // mul_relin_batch at N >= 2^15: the B evaluations go through the single-operation path on this context and two internal ones, round robin -- in
+    // flight side by side (the latency-bound stretches of one beside the other's kernels) instead of in lock step (batch.hip)
+    std::vector<std::unique_ptr<Context>> lanes_;
+    Context* lane(int i);
+    bool batch_lanes_ok(size_t B, long limbs) const;
     void fork_side(int k);      // side stream waits for everything enqueued so far on the active stream
     void side_done(int k);      // marks the end of side chain k
     void join_side(int k);      // active stream waits for side chain k

@@ -224,6 +224,12 @@ func (ctx *Context) SetNTTChoice(limbs int, decompose bool, choice int) {
 	must(C.mkhe_ctx_set_ntt_choice(ctx.c, C.long(limbs), b2i(decompose), C.int(choice)))
 }
 
+// SetBatchLanes: from how many hoisted limb-NTTs per input MulRelinBatch evaluates its inputs in flight (this context and two internal ones, round
+// robin) instead of in lock step, N = 2^15 (mkhe_ctx_set_batch_lanes; default 1536, 0 = always, negative = never).  Same results either way.
+func (ctx *Context) SetBatchLanes(minLimbs int) {
+	must(C.mkhe_ctx_set_batch_lanes(ctx.c, C.long(minLimbs)))
+}
+
 // PoolHeldBytes / PoolTrim: device memory the context's buffer pool holds for reuse, and its release (MKHE_POOL_GB bounds it per device).
 func (ctx *Context) PoolHeldBytes() int64 { return int64(C.mkhe_pool_held_bytes(ctx.c)) }
 func (ctx *Context) PoolTrim()            { must(C.mkhe_pool_trim(ctx.c)) }

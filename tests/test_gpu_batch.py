@@ -47,11 +47,17 @@ class Case:
         return [h for h, _ in pairs], self.mkckks.BatchCiphertext([c for _, c in pairs])
 
 
-@pytest.fixture(scope="module", params=["N12_q4", "N14_pn14"])
+@pytest.fixture(scope="module", params=["N12_q4", "N14_pn14", "N15_q4"])
 def case(request):
+    # (N15: mkhe_mul_relin_batch runs its B evaluations IN FLIGHT there -- the single-operation path on the context and two internal ones, round robin
+    # (csrc/batch.hip, round 6) -- instead of in lock step; everything else of this file is lock step on every ring)
     # (N14: the ring on which engine-internal Decompose launches go through ext_fused_lds_kernel -- round 5: mkhe_rotate_batch staged its digits there and
     # then read them as full transforms; every test of this file passed on N = 2^12, tools/fuzz_batch.py found it)
-    return Case({"N12_q4": H.small_ckks(12, 4), "N14_pn14": H.PN14QP439}[request.param], ["a", "b", "c", "d"], 77)
+    c = Case({"N12_q4": H.small_ckks(12, 4), "N14_pn14": H.PN14QP439, "N15_q4": H.small_ckks(15, 4)}[request.param], ["a", "b", "c", "d"], 77)
+    if request.param == "N15_q4":
+        from mkhe_kklss_amd._abi import lib, check
+        check(lib().mkhe_ctx_set_batch_lanes(c.params.ctx, 0))       # (by default only launch sets of 1536 hoisted limbs and more: four parties on the full chain)
+    return c
 
 
 @pytest.mark.parametrize("ids0,ids1,B", [(["a", "b"], ["a", "b"], 3), (["a"], ["b", "c"], 2), (["a", "b", "c", "d"], ["a", "b", "c", "d"], 7), ([], ["a"], 2), (["a", "b"], [], 2)])

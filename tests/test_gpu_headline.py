@@ -126,6 +126,32 @@ def test_pn15_fused_f2_shapes(pn15, k0, k1, level, hoisted):
     _mulrelin_case(pn15, k0, k1, level, hoisted)
 
 
+def test_pn15_batch_runs_in_flight(pn15):
+    """mkhe_mul_relin_batch at N = 2^15 (round 6): B evaluations through the single-operation path on the context and two internal ones, round robin -- five
+    inputs (lanes 0 1 2 0 1), four parties, top level, twice (the internal contexts are reused), then a dependent batch on the outputs; every output equal to
+    the single evaluation's (which the tests above hold against the oracle)."""
+    from mkhe_kklss_amd import mkrlwe
+    p, params, mk, rng = (pn15[k] for k in ("pset", "params", "mk", "rng"))
+    k, B, level = 4, 5, len(p["Q"]) - 1
+    names = ["user%d" % i for i in range(k)]
+    rlk = mkrlwe.RelinearizationKeySet(params)
+    for n in names:
+        rlk.AddRelinearizationKey(mkrlwe.RelinearizationKey(params, n, *(_swk(p, rng) for _ in range(3))))
+    params.AddCRS(-1, _swk(p, rng))
+    new = lambda: mk.NewCiphertext(params, names, level, p["scale"]).upload(_ct(p, rng, k, level + 1))
+    b0, b1 = mk.BatchCiphertext([new() for _ in range(B)]), mk.BatchCiphertext([new() for _ in range(B)])
+    ev, bev = mk.NewEvaluator(params), mk.BatchEvaluator(params, B)
+    ref = [ev.MulRelinNew(b0.cts[i], b1.cts[i], rlk).download() for i in range(B)]
+    for _ in range(2):
+        out = bev.MulRelinNew(b0, b1, rlk)
+        for i in range(B):
+            assert (out.cts[i].download() == ref[i]).all(), i
+    hh = bev.HoistedForm(out)
+    sq = bev.MulRelinHoistedNew(out, out, hh, hh, rlk)              # consumes what the lanes wrote: ordered behind them on the caller's stream
+    for i in range(B):
+        assert (sq.cts[i].download() == ev.MulRelinNew(out.cts[i], out.cts[i], rlk).download()).all(), i
+
+
 @pytest.mark.parametrize("parties,drop", [(8, 0), (4, 0), (3, 0), (2, 0), (1, 0), (3, 2), (5, 1)])
 def test_pn15_hoisted_form_launch_classes(pn15, parties, drop):
     """HoistedForm of n components = ONE Decompose launch of n * beta * (level + 1 + nP) limbs:

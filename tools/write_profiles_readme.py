@@ -141,7 +141,8 @@ Earlier rounds: `README_r5.md` (its narrative of rounds 1–5 stands, except whe
 **{pl["value"]:.1f} MulRelin/s** ({pl["ms_per_step"]:.4f} ms per step; right after the host-side set-up: {C["mulrelin_per_sec_cold_start"]:.1f}), workload `{C["workload"]}`, bit-exact against the oracle in the same run
 (`cpu_baseline.bit_exact_vs_gpu = {cb["bit_exact_vs_gpu"]}`; CPU oracle {cb["value"]:.3f} MulRelin/s on one thread, {cb["value_limb_parallel"]:.2f} on {cb["cores_limb_parallel"]}).
 {R["launches_per_step"]:.0f} engine kernels per step (round 5: 11; the second Decompose launch and the streaming F2 launch became one).
-Independent evaluations in flight on forked contexts, same run, steady state: two {C["mulrelin_per_sec_two_in_flight"]:.1f}, three {C["mulrelin_per_sec_three_in_flight"]:.1f} MulRelin/s
+Independent evaluations in flight on forked contexts, same run, steady state: two {C["mulrelin_per_sec_two_in_flight"]:.1f}, three {C["mulrelin_per_sec_three_in_flight"]:.1f} MulRelin/s;
+through `mkhe_mul_relin_batch` (in flight on internal contexts at this launch size since round 6, joined at the end of each call; `{tag}_batch_lanes.txt`): B = 2 {C["mulrelin_per_sec_batch2"]:.1f}, B = 4 {C["mulrelin_per_sec_batch4"]:.1f}
 (rounds 4-5 measured this among the first legs, clocks not settled, and read it as a loss; `{tag}_cu_partition.txt`: one to four in flight, and the same on disjoint CU sets -- a loss).
 
 `roofline`: dominant kernel `{R["kernel"].split("  ")[0]}` — {R["alg_bytes_per_launch"] / 1e6:.1f} MB algorithmic (16·N bytes × {R["alg_bytes_per_launch"] / (16 * 32768):.0f} limbs) in {R["avg_launch_us"]:.1f} µs = {R["achieved"]:.0f} GB/s,
