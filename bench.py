@@ -523,8 +523,8 @@ def run_single(args):
     extras["mulrelin_per_sec_cold_start"] = args.steps / (time.perf_counter() - t0)
     extras["timing_protocol"] = ("legs in this order: cold start (W warm-up + K timed steps right after the host-side set-up: mulrelin_per_sec_cold_start, the figure "
                                  "rounds 1-2 reported as value) -> secondary legs (Rotate / Conjugate / key generation) -> 100 untimed + 200 timed steps "
-                                 "(steady state) -> W + K = the timed region of `value` -> K steps under HIP events (roofline) -> mkhe_mul_relin_batch with B = 2, 4 -> two / three evaluations in "
-                                 "flight on forked contexts (30 untimed + 100 timed rounds each)")
+                                 "(steady state) -> W + K = the timed region of `value` -> K steps under HIP events (roofline) -> mkhe_mul_relin_batch with B = 2, 4 (40 untimed + 100 timed calls each) -> two / three "
+                                 "evaluations in flight on forked contexts (100 untimed + 100 timed rounds each)")
 
     # ---- secondary figure: hoisted rotation of the same k-party ciphertext, hoisting included / excluded
     if not args.no_extras:
@@ -655,14 +655,14 @@ def run_single(args):
         for Bb in (2, 4):
             bevb = mkckks.BatchEvaluator(params, Bb)
             bb0, bb1 = mkckks.BatchCiphertext([ct0] * Bb), mkckks.BatchCiphertext([ct1] * Bb)
-            for _ in range(3):
+            for _ in range(40):                  # (the internal contexts of the in-flight form settle their own kernel choice in their first launches)
                 outb = bevb.MulRelinNew(bb0, bb1, rlk)
             params.sync()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(100):
                 outb = bevb.MulRelinNew(bb0, bb1, rlk)
             params.sync()
-            extras["mulrelin_per_sec_batch%d" % Bb] = Bb * args.steps / (time.perf_counter() - t0)
+            extras["mulrelin_per_sec_batch%d" % Bb] = Bb * 100 / (time.perf_counter() - t0)
             extras["batch%d_identical_to_single" % Bb] = bool(all((c.download() == ref_single).all() for c in outb.cts))
             del outb, bb0, bb1, bevb
 
@@ -674,7 +674,7 @@ def run_single(args):
         evs = [ev, ev.Fork(), ev.Fork()]
         for nfl in (2, 3):
             use = evs[:nfl]
-            for _ in range(30):
+            for _ in range(100):                 # (a forked context settles its own kernel choice in its first hundred launches)
                 for e in use:
                     e.MulRelinNew(ct0, ct1, rlk)
             for e in use:
