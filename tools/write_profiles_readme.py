@@ -131,7 +131,7 @@ extra_files = [("%s_gputests.txt" % tag, "`python -m pytest tests -m gpu` on the
 
 txt = f"""# profiles/ — rocprofv3 evidence, round 6 (`{tag}_*`)
 
-Everything here was produced on ONE MI355X through `gpurun` by `tools/profile_round.sh {tag}a part1 | part2 | part3` and distilled by `tools/collect_profiles.py`; this file is
+Everything here was produced on one MI355X per `gpurun` call by `tools/profile_round.sh <run> part1 | part2 | part3 | part4` (or the script a file names) and distilled by `tools/collect_profiles.py`; this file is
 generated (`tools/write_profiles_readme.py {tag}`: a figure that is missing from the tracked files stops the generator — round 5 printed not-a-number for an empty table).
 Earlier rounds: `README_r5.md` (its narrative of rounds 1–5 stands, except where this file says otherwise) and the `r1a_ … r5_` files.  Boxes differ by ± 3 %
 (parts that throttle at 1255 W by more): compare only inside one file or one call.
