@@ -392,7 +392,8 @@ int  mkhe_ctx_set_ntt_choice(mkhe_ctx* ctx, long limbs, int decompose, int choic
  * parties at the top level of PN15QP880) are evaluated IN FLIGHT -- the single-operation path on this context and two internal ones, round robin, joined
  * before the call returns to the stream -- instead of in lock step: one such evaluation fills the chip with every big kernel, what a second one can use
  * is the first one's latency-bound stretches.  0: every batch of this ring in flight; < 0: always lock step.  Same results either way
- * (mkrlwe/keyswitch_hoisted.go:44-179 per input). */
+ * (mkrlwe/keyswitch_hoisted.go:44-179 per input).  The internal contexts follow the caller's overlap setting and its pin for every shape
+ * (mkhe_ctx_set_ntt_choice with limbs <= 0); pins of single launch shapes are the caller context's own. */
 int  mkhe_ctx_set_batch_lanes(mkhe_ctx* ctx, long min_limbs);
 /* The stream-ordered buffer pools (freed ciphertext / key handles are kept for reuse, bounded per DEVICE by MKHE_POOL_GB): bytes this context's
  * pool holds, and "hand everything the pools of this context's device hold back to the driver" (one device-wide synchronisation; the engine does
