@@ -127,7 +127,16 @@ sweep = [json.loads(l) for l in open(P + tag + "_party_sweep.jsonl") if l.strip(
 extra_files = [("%s_gputests.txt" % tag, "`python -m pytest tests -m gpu` on the final sources"), ("%s_switch_matrix.txt" % tag, "`tools/switch_matrix.sh`: the GPU suite under seven switch sets of the diagnostic library"),
                ("%s_fuzz_parity.txt" % tag, "`tools/fuzz_parity.py` long runs (random rings / levels / id sets against the oracle)"), ("%s_f2_trace.txt" % tag, "`tools/f2_trace.py` (trace build): per-wave phase timeline of `ntt16_f2_kernel` and the shader clock inside it"),
                ("%s_sq_counters.txt" % tag, "SQ / TCC counters per kernel (three `--pmc` passes of the same bench command)"), ("%s_dist_5ranks.json" % tag, "`MKHE_DIST_BACKEND=gloo MKHE_DIST_ONE_DEVICE=1 python bench.py --gpus 5 --steps 2 --warmup 1`: the N > 1 path with five ranks on the one device of the box (functional only)"),
-               ("%s_pmc_unfused.txt" % tag, "the same two PMC passes with `MKHE_F2_FUSED=0` (diagnostic library): HBM bytes per step of the round-5 launch set on the same box")]
+               ("%s_pmc_unfused.txt" % tag, "the same two PMC passes with `MKHE_F2_FUSED=0` (diagnostic library): HBM bytes per step of the round-5 launch set on the same box"),
+               ("%s_f2_plan_sweep.txt" % tag, "`tools/f2_level_sweep.py` + `f2_sweep_table.py`: MulRelinNew per second over 1-6 parties x levels 0-13, planned grid of `ntt16_f2_kernel` against the unfused launches, alternating -- the data behind `F2_RUN_COST` / `F2_SLACK` (DESIGN.md section 4.6)"),
+               ("%s_f2_plan_ab.txt" % tag, "`tools/f2_plan_ab.sh`: `bench.py --parties 1..4`, mkbfv and cnn with the planned grid against the first version's rule (one workgroup per CU or nothing)"),
+               ("%s_fuzz_pn15_planned.txt" % tag, "`tools/fuzz_parity.py 240 6101 pn15` on the planned-grid sources: every (parties, level) shape of MulRelin drawn at least four times"),
+               ("%s_fuzz_circuit.txt" % tag, "`tools/fuzz_circuit.py` on the final sources"), ("%s_fuzz_batch.txt" % tag, "`tools/fuzz_batch.py` on the final sources"),
+               ("%s_batch_lanes.txt" % tag, "`tools/batch_lanes_ab.sh`: `mkhe_mul_relin_batch` on the headline ring, B evaluations in flight against B in lock step against one at a time"),
+               ("%s_cu_partition.txt" % tag, "`tools/cu_partition_ab.py`: one to four evaluations in flight on forked contexts, whole chip and disjoint CU sets (experiment)"),
+               ("%s_auto_lanes_ab.txt" % tag, "experiment: the single MulRelin entry handing its evaluations to internal contexts by itself (built, green, removed)"),
+               ("%s_party_latency.txt" % tag, "per-launch time of the latency-bound [inverse NTT, ModDown] pair by party count: what per-party pipelining would launch (DESIGN.md section 10)"),
+               ("%s_f1_tiles_ab.txt" % tag, "experiment: digit-major tiles for the operands of the F1 kernel (built, green, removed)")]
 
 txt = f"""# profiles/ — rocprofv3 evidence, round 6 (`{tag}_*`)
 
