@@ -159,7 +159,7 @@ def run_distributed(args):
     rlk = {n: party_keys(n) for n in sorted(set(ids0) | set(ids1))}
     psync = _party_sync(args, dist)
     backend = HipShardBackend(params, names, rank, world, op0, op1, rlk, level, torch, local_rank, sync=psync)
-    smr = ShardedMulRelin(backend, dist)
+    smr = ShardedMulRelin(backend, dist, mesh=os.environ.get("MKHE_DIST_MESH", "1") != "0")      # (0: x / y as all-reduces, the exchange of rounds 3-5)
     def step_party():
         smr.run()
         check(lib().mkhe_rescale(params.ctx, backend.full.h, 1, res.h))
